@@ -1,0 +1,253 @@
+"""ctypes binding of libbwamem_hip.so (include/bwamem_hip.h, include/seed_gen.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_u8p, _u32p, _u64p, _i32p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_uint64, C.c_int32))
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(_PKG, "libbwamem_hip.so")
+
+
+# every symbol include/bwamem_hip.h and include/seed_gen.h declare
+EXPORTED_SYMBOLS = [
+    "bmh_last_error", "bmh_device_count", "bmh_set_device", "bmh_index_upload", "bmh_index_from_device",
+    "bmh_index_free", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
+    "bmh_extend_batch",
+    "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
+    "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
+]
+
+
+class SeedsT(C.Structure):
+    _fields_ = [("n_seeds", C.c_uint64), ("n_smems", C.c_uint64), ("n_cands", C.c_uint64),
+                ("d_rbeg", C.c_void_p), ("d_qbeg", C.c_void_p), ("d_score", C.c_void_p),
+                ("d_n_ref_pos", C.c_void_p), ("d_prefix", C.c_void_p)]
+
+
+class ExtParams(C.Structure):
+    """bmh_ext_params_t; defaults = the GPU pipeline's (src/bwamem.c:101-146)."""
+    _fields_ = [(n, C.c_int) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "zdrop", "end_bonus")]
+
+    @classmethod
+    def default(cls, zdrop: int = 0) -> "ExtParams":
+        return cls(1, 4, 6, 1, 6, 1, zdrop, 5)
+
+
+# mirrors of include/seed_gen.h
+class BwtTGpu(C.Structure):
+    _fields_ = [("primary", C.c_uint64), ("L2", _u64p), ("seq_len", C.c_uint64), ("bwt_size", C.c_uint64),
+                ("bwt", _u32p), ("sa_intv", C.c_int), ("n_sa", C.c_uint64), ("sa", _u32p),
+                ("sa_upper_bits", _u32p), ("pack_size", C.c_uint8)]
+
+
+class MemSeedVGpu(C.Structure):
+    _fields_ = [("rbeg", _u64p), ("qbeg", _i32p), ("score", _u32p), ("n_ref_pos_fow_rev_results", _u32p),
+                ("n_ref_pos_fow_rev_prefix_sums", _u32p), ("file_bytes_skip", C.c_uint64)]
+
+
+class GpuseedStorageVector(C.Structure):
+    _fields_ = [("read_file", C.c_char_p), ("query_file", C.c_char_p), ("bwt", C.POINTER(BwtTGpu)),
+                ("bwt_gpu", BwtTGpu), ("pre_calc_seed_intervals", C.c_void_p),
+                ("pre_calc_seed_intervals_flag", C.c_int), ("pre_calc_seed_len", C.c_int),
+                ("min_seed_size", C.c_int), ("is_smem", C.c_int), ("file_bytes_skip", C.c_uint64)]
+
+
+_LIB = None
+
+
+def load_library() -> C.CDLL:
+    """Load libbwamem_hip.so; raises HipLibraryMissing (never falls back) if it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise HipLibraryMissing(f"{p} not found: build it with `make -C bwa-mem_gpu_amd/csrc` "
+                                "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(p)
+    L.bmh_last_error.restype = C.c_char_p
+    L.bmh_device_count.restype = C.c_int
+    L.bmh_set_device.argtypes = [C.c_int]
+    L.bmh_index_upload.restype = C.c_void_p
+    L.bmh_index_upload.argtypes = [C.c_uint64, _u64p, C.c_uint64, _u32p, C.c_uint64, C.c_int, _u32p, C.c_uint64,
+                                   _u32p, _u8p, C.c_uint64]
+    L.bmh_index_from_device.restype = C.c_void_p
+    L.bmh_index_from_device.argtypes = [C.c_uint64, _u64p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
+                                        C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.bmh_index_free.argtypes = [C.c_void_p]
+    L.bmh_seed_ws_create.restype = C.c_void_p
+    L.bmh_seed_ws_create.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.bmh_seed_ws_free.argtypes = [C.c_void_p]
+    L.bmh_seed_batch.restype = C.c_int
+    L.bmh_seed_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
+                                 C.c_void_p, C.POINTER(SeedsT)]
+    L.bmh_seed_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.bmh_extend_batch.restype = C.c_int
+    L.bmh_extend_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32, C.POINTER(ExtParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bwt_restore_bwt_gpu.restype = C.POINTER(BwtTGpu)
+    L.bwt_restore_bwt_gpu.argtypes = [C.c_char_p]
+    L.bwt_restore_sa_gpu.argtypes = [C.c_char_p, C.POINTER(BwtTGpu)]
+    L.gpu_cpy_wrapper.restype = BwtTGpu
+    L.gpu_cpy_wrapper.argtypes = [C.POINTER(BwtTGpu)]
+    L.seed_gpu.restype = C.POINTER(MemSeedVGpu)
+    L.seed_gpu.argtypes = [C.POINTER(GpuseedStorageVector)]
+    L.free_gpuseed_data.argtypes = [C.POINTER(GpuseedStorageVector)]
+    L.seed_gpu_last_n_reads.restype = C.c_uint64
+    _LIB = L
+    return L
+
+
+def _err(L) -> str:
+    return (L.bmh_last_error() or b"").decode()
+
+
+def _np_ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Index:
+    """FMD index resident in HBM (bmh_index_t)."""
+
+    def __init__(self, handle, keep=None):
+        self.handle = handle
+        self._keep = keep
+
+    @classmethod
+    def upload(cls, idx, pac: np.ndarray | None = None, l_pac: int = 0) -> "Index":
+        """idx: fmindex.FMDIndex on the host -> HBM (replaces gpu_cpy_wrapper)."""
+        L = load_library()
+        L2 = np.ascontiguousarray(idx.L2, dtype=np.uint64)
+        bw = np.ascontiguousarray(idx.bwt_words, dtype=np.uint32)
+        sa = np.ascontiguousarray(idx.sa, dtype=np.uint32)
+        bits = np.ascontiguousarray(idx.sa_bits, dtype=np.uint32)
+        h = L.bmh_index_upload(idx.primary, _np_ptr(L2, _u64p), idx.seq_len, _np_ptr(bw, _u32p), bw.shape[0],
+                               idx.sa_intv, _np_ptr(sa, _u32p), idx.n_sa, _np_ptr(bits, _u32p),
+                               _np_ptr(pac, _u8p) if pac is not None else None, l_pac)
+        if not h:
+            raise RuntimeError("bmh_index_upload: " + _err(L))
+        return cls(h)
+
+    @classmethod
+    def from_device(cls, primary, L2, seq_len, bwt_t, sa_intv, sa_t, sa_bits_t, pac_t=None, l_pac=0) -> "Index":
+        """Wrap torch tensors already in HBM (e.g. after the RCCL broadcast); tensors are kept alive."""
+        L = load_library()
+        L2a = np.ascontiguousarray(L2, dtype=np.uint64)
+        h = L.bmh_index_from_device(primary, _np_ptr(L2a, _u64p), seq_len, bwt_t.data_ptr(), bwt_t.numel(), sa_intv,
+                                    sa_t.data_ptr(), sa_t.numel(), sa_bits_t.data_ptr(),
+                                    pac_t.data_ptr() if pac_t is not None else None, l_pac)
+        if not h:
+            raise RuntimeError("bmh_index_from_device: " + _err(L))
+        return cls(h, keep=(bwt_t, sa_t, sa_bits_t, pac_t))
+
+    def free(self):
+        if self.handle:
+            load_library().bmh_index_free(self.handle)
+            self.handle = None
+
+
+class SeedWorkspace:
+    def __init__(self, max_reads: int, max_bases: int, max_cands: int = 0, max_occ: int = 0):
+        L = load_library()
+        self.handle = L.bmh_seed_ws_create(max_reads, max_bases, max_cands, max_occ)
+        if not self.handle:
+            raise RuntimeError("bmh_seed_ws_create: " + _err(L))
+
+    def seed_batch(self, index: Index, reads_t, offs_t, lens_t, min_seed_len: int = 19, stream: int = 0) -> SeedsT:
+        """reads_t/offs_t/lens_t: torch CUDA tensors (uint8 ASCII, int32/uint32 offsets and lengths)."""
+        L = load_library()
+        out = SeedsT()
+        rc = L.bmh_seed_batch(self.handle, index.handle, reads_t.data_ptr(), offs_t.data_ptr(), lens_t.data_ptr(),
+                              lens_t.numel(), min_seed_len, stream, C.byref(out))
+        if rc != 0:
+            raise RuntimeError(f"bmh_seed_batch rc={rc}: " + _err(L))
+        return out
+
+    def timing(self):
+        ms = (C.c_float * 7)()
+        load_library().bmh_seed_last_timing(self.handle, ms)
+        return dict(zip(("pack", "forward", "backward", "filter_scan", "expand", "locate", "total"), list(ms)))
+
+    def free(self):
+        if self.handle:
+            load_library().bmh_seed_ws_free(self.handle)
+            self.handle = None
+
+
+def seeds_to_host(s: SeedsT, n_reads: int) -> dict:
+    """Copy a bmh_seeds_t to numpy arrays (test/bench helper; uses torch only to read HBM)."""
+    import torch
+
+    def rd(ptr, n, dt, tdt):
+        if n == 0:
+            return np.zeros(0, dt)
+        buf = torch.empty(n, dtype=tdt, device="cuda")
+        _memcpy_d2d(buf.data_ptr(), ptr, n * buf.element_size())
+        return buf.cpu().numpy().view(dt)
+    ns = int(s.n_seeds)
+    return dict(rbeg=rd(s.d_rbeg, ns, np.uint64, torch.int64), qbeg=rd(s.d_qbeg, 2 * ns, np.int32, torch.int32).reshape(-1, 2),
+                score=rd(s.d_score, ns, np.uint32, torch.int32), n_ref_pos=rd(s.d_n_ref_pos, n_reads, np.uint32, torch.int32),
+                prefix=rd(s.d_prefix, n_reads, np.uint32, torch.int32))
+
+
+def _memcpy_d2d(dst: int, src: int, nbytes: int) -> None:
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = hip.hipMemcpy(dst, src, nbytes, 3)  # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy d2d failed rc={rc}")
+
+
+def extend_batch(q_t, qoff_t, qlen_t, t_t, toff_t, tlen_t, h0_t, out_t, params: ExtParams | None = None, raw_t=None,
+                 stream: int = 0) -> None:
+    """All arguments torch CUDA tensors; out_t int32 [n,3]; raw_t int32 [n,6] or None.  Asynchronous."""
+    L = load_library()
+    p = params or ExtParams.default()
+    rc = L.bmh_extend_batch(q_t.data_ptr(), qoff_t.data_ptr(), qlen_t.data_ptr(), t_t.data_ptr(), toff_t.data_ptr(),
+                            tlen_t.data_ptr(), h0_t.data_ptr(), qlen_t.numel(), C.byref(p), out_t.data_ptr(),
+                            raw_t.data_ptr() if raw_t is not None else None, stream)
+    if rc != 0:
+        raise RuntimeError(f"bmh_extend_batch rc={rc}: " + _err(L))
+
+
+def seed_file(index_prefix: str, read_file: str, min_seed_len: int = 19) -> dict:
+    """The reference's call sequence (src/fastmap.c:436-465) through the drop-in C ABI:
+    bwt_restore_bwt_gpu -> bwt_restore_sa_gpu -> gpu_cpy_wrapper -> seed_gpu -> free_gpuseed_data."""
+    L = load_library()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    d = GpuseedStorageVector()
+    d.query_file = index_prefix.encode()
+    d.read_file = read_file.encode()
+    d.file_bytes_skip = 0
+    d.min_seed_size = min_seed_len
+    d.is_smem = 1
+    d.bwt = L.bwt_restore_bwt_gpu((index_prefix + ".bwt").encode())
+    L.bwt_restore_sa_gpu((index_prefix + ".sa").encode(), d.bwt)
+    d.bwt_gpu = L.gpu_cpy_wrapper(d.bwt)
+    d.pre_calc_seed_len = 13
+    d.pre_calc_seed_intervals_flag = 0
+    res = L.seed_gpu(C.byref(d))
+    n_reads = int(L.seed_gpu_last_n_reads())
+    L.free_gpuseed_data(C.byref(d))
+    r = res.contents
+    n_ref = np.ctypeslib.as_array(r.n_ref_pos_fow_rev_results, shape=(max(n_reads, 1),))[:n_reads].copy()
+    prefix = np.ctypeslib.as_array(r.n_ref_pos_fow_rev_prefix_sums, shape=(max(n_reads, 1),))[:n_reads].copy()
+    ns = int(n_ref.sum())
+    out = dict(rbeg=np.ctypeslib.as_array(r.rbeg, shape=(max(ns, 1),))[:ns].copy(),
+               qbeg=np.ctypeslib.as_array(r.qbeg, shape=(max(2 * ns, 1),))[:2 * ns].copy().reshape(-1, 2),
+               score=np.ctypeslib.as_array(r.score, shape=(max(ns, 1),))[:ns].copy(),
+               n_ref_pos=n_ref, prefix=prefix, file_bytes=int(r.file_bytes_skip))
+    for p in (r.rbeg, r.qbeg, r.score, r.n_ref_pos_fow_rev_results, r.n_ref_pos_fow_rev_prefix_sums):
+        libc.free(C.cast(p, C.c_void_p))
+    libc.free(C.cast(res, C.c_void_p))
+    return out

@@ -1,0 +1,119 @@
+// C-ABI glue of libbwamem_hip.so: error state, device selection, index upload.
+// Reference interfaces replaced: gpu_cpy_wrapper / bwt_destroy_gpu
+// (/root/reference/src/GPUSeed/seed_gen.cu:1524-1556, 1338-1346).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "bmh_internal.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void bmh_set_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+extern "C" const char *bmh_last_error(void) { return g_err; }
+
+extern "C" int bmh_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) { bmh_set_error("hipGetDeviceCount failed: no HIP device"); return 0; }
+	return n;
+}
+
+extern "C" int bmh_set_device(int dev)
+{
+	hipError_t e = hipSetDevice(dev);
+	if (e != hipSuccess) { bmh_set_error("hipSetDevice(%d): %s", dev, hipGetErrorString(e)); return BMH_ENODEV; }
+	return BMH_OK;
+}
+
+static int check_geometry(uint64_t seq_len, const uint64_t L2[5], uint64_t n_words, int sa_intv, uint64_t n_sa)
+{
+	if (seq_len == 0 || (seq_len >> 33)) { bmh_set_error("index: seq_len %llu outside (0, 2^33)", (unsigned long long)seq_len); return BMH_EINVAL; }
+	if (L2[0] != 0 || L2[4] != seq_len) { bmh_set_error("index: L2 inconsistent with seq_len"); return BMH_EINVAL; }
+	for (int c = 0; c < 4; ++c)
+		if (L2[c + 1] < L2[c] || ((L2[c + 1] - L2[c]) >> 32)) { bmh_set_error("index: count of base %d does not fit 32 bits", c); return BMH_EINVAL; }
+	uint64_t nblk = (seq_len + 63) / 64;
+	uint64_t need = (nblk - 1) * 8 + 4 + ((seq_len + 15) / 16 - (nblk - 1) * 4) + 4;
+	if (n_words < need) { bmh_set_error("index: %llu bwt words, need %llu", (unsigned long long)n_words, (unsigned long long)need); return BMH_EINVAL; }
+	if (sa_intv < 1 || (sa_intv & (sa_intv - 1))) { bmh_set_error("index: sa_intv %d is not a power of two", sa_intv); return BMH_EINVAL; }
+	if (n_sa != (seq_len + sa_intv) / sa_intv) { bmh_set_error("index: n_sa mismatch"); return BMH_EINVAL; }
+	return BMH_OK;
+}
+
+static void fill_dev(bmh_index *ix, uint64_t primary, const uint64_t L2[5], uint64_t seq_len, int sa_intv, uint64_t n_sa, uint64_t l_pac)
+{
+	ix->dev.primary = primary;
+	memcpy(ix->dev.L2, L2, sizeof(uint64_t) * 5);
+	ix->dev.seq_len = seq_len;
+	ix->dev.n_sa = n_sa;
+	int sh = 0;
+	while ((1 << sh) < sa_intv) ++sh;
+	ix->dev.sa_shift = sh;
+	ix->dev.l_pac = l_pac;
+}
+
+extern "C" bmh_index_t *bmh_index_upload(uint64_t primary, const uint64_t L2[5], uint64_t seq_len, const uint32_t *bwt_words,
+                                         uint64_t n_words, int sa_intv, const uint32_t *sa, uint64_t n_sa, const uint32_t *sa_bits,
+                                         const uint8_t *pac, uint64_t l_pac)
+{
+	if (!L2 || !bwt_words || !sa || !sa_bits) { bmh_set_error("bmh_index_upload: null argument"); return nullptr; }
+	if (check_geometry(seq_len, L2, n_words, sa_intv, n_sa) != BMH_OK) return nullptr;
+	bmh_index *ix = (bmh_index *)calloc(1, sizeof(bmh_index));
+	ix->owns = true; ix->n_words = n_words;
+	fill_dev(ix, primary, L2, seq_len, sa_intv, n_sa, pac ? l_pac : 0);
+	// blocks are read as 32-byte units: pad the allocation so the last (partial) block is readable
+	size_t bwt_bytes = ((size_t)((seq_len + 63) / 64) + 1) * 32;
+	size_t bits_words = (size_t)(n_sa / 32 + 1);
+	uint32_t *d_bwt = nullptr, *d_sa = nullptr, *d_bits = nullptr;
+	uint8_t *d_pac = nullptr;
+	bool ok = hipMalloc((void **)&d_bwt, bwt_bytes) == hipSuccess && hipMalloc((void **)&d_sa, n_sa * 4) == hipSuccess &&
+	          hipMalloc((void **)&d_bits, bits_words * 4) == hipSuccess;
+	if (ok && pac) ok = hipMalloc((void **)&d_pac, (size_t)(l_pac / 4 + 1)) == hipSuccess;
+	if (ok) ok = hipMemset(d_bwt, 0, bwt_bytes) == hipSuccess;
+	if (ok) ok = hipMemcpy(d_bwt, bwt_words, (size_t)n_words * 4 < bwt_bytes ? (size_t)n_words * 4 : bwt_bytes, hipMemcpyHostToDevice) == hipSuccess;
+	if (ok) ok = hipMemcpy(d_sa, sa, n_sa * 4, hipMemcpyHostToDevice) == hipSuccess;
+	if (ok) ok = hipMemcpy(d_bits, sa_bits, bits_words * 4, hipMemcpyHostToDevice) == hipSuccess;
+	if (ok && pac) ok = hipMemcpy(d_pac, pac, (size_t)(l_pac / 4 + 1), hipMemcpyHostToDevice) == hipSuccess;
+	if (!ok) {
+		bmh_set_error("bmh_index_upload: %s", hipGetErrorString(hipGetLastError()));
+		if (d_bwt) (void)hipFree(d_bwt); if (d_sa) (void)hipFree(d_sa); if (d_bits) (void)hipFree(d_bits); if (d_pac) (void)hipFree(d_pac);
+		free(ix);
+		return nullptr;
+	}
+	ix->dev.blocks = (const uint4 *)d_bwt; ix->dev.sa = d_sa; ix->dev.sa_bits = d_bits; ix->dev.pac = d_pac;
+	return ix;
+}
+
+extern "C" bmh_index_t *bmh_index_from_device(uint64_t primary, const uint64_t L2[5], uint64_t seq_len, const uint32_t *d_bwt_words,
+                                              uint64_t n_words, int sa_intv, const uint32_t *d_sa, uint64_t n_sa,
+                                              const uint32_t *d_sa_bits, const uint8_t *d_pac, uint64_t l_pac)
+{
+	if (!L2 || !d_bwt_words || !d_sa || !d_sa_bits) { bmh_set_error("bmh_index_from_device: null argument"); return nullptr; }
+	if (check_geometry(seq_len, L2, n_words, sa_intv, n_sa) != BMH_OK) return nullptr;
+	if (((uintptr_t)d_bwt_words & 31) != 0) { bmh_set_error("bmh_index_from_device: bwt words must be 32-byte aligned"); return nullptr; }
+	// whole 32-byte blocks must be readable: the caller's buffer has to cover ceil(seq_len/64)+1 blocks
+	if (n_words < (((seq_len + 63) / 64) + 1) * 8) { bmh_set_error("bmh_index_from_device: buffer must be padded to %llu words", (unsigned long long)((((seq_len + 63) / 64) + 1) * 8)); return nullptr; }
+	bmh_index *ix = (bmh_index *)calloc(1, sizeof(bmh_index));
+	ix->owns = false; ix->n_words = n_words;
+	fill_dev(ix, primary, L2, seq_len, sa_intv, n_sa, d_pac ? l_pac : 0);
+	ix->dev.blocks = (const uint4 *)d_bwt_words; ix->dev.sa = d_sa; ix->dev.sa_bits = d_sa_bits; ix->dev.pac = d_pac;
+	return ix;
+}
+
+extern "C" void bmh_index_free(bmh_index_t *ix)
+{
+	if (!ix) return;
+	if (ix->owns) {
+		(void)hipFree((void *)ix->dev.blocks); (void)hipFree((void *)ix->dev.sa); (void)hipFree((void *)ix->dev.sa_bits);
+		if (ix->dev.pac) (void)hipFree((void *)ix->dev.pac);
+	}
+	free(ix);
+}

@@ -1,0 +1,261 @@
+// Zero-trimmed affine-gap seed extension (ksw_extend2) on gfx950 -- hand-written HIP, wave64.
+//
+// Contract = ksw_extend2 of the reference, opt_ext == 0 path
+// (/root/reference/src/ksw.c:864-986) followed by the local-vs-to-end rule of
+// decoy_cpu_align (src/bwamem.c:1893-1901); results are bit-identical, including
+// the row-sequential parts of the algorithm: the [beg,end) trimming driven by the
+// previous row's zeros (:963-970), the m==0 break (:946), z-drop (:951-959), the
+// "last column on ties" row maximum (:928) and the "last row on ties" gscore (:943).
+//
+// Mapping: ONE WAVE PER ALIGNMENT, one target row per step, the 64 lanes own the
+// query columns (C consecutive columns per lane, C = ceil(qlen/64), a template
+// parameter).  Because ksw_extend2 opens gaps from the diagonal value M and not
+// from H (:929-938), M of a whole row depends only on the previous row, and
+// F(i,j+1) = max(F(i,j)-e, max(M(i,j)-oe,0)) is a max-plus prefix scan along the
+// row: F(i,j) = max_{j'<j}(t(j') + e*j') - e*(j-1).  The scan and the row maximum
+// run on DPP row shifts/broadcasts (no LDS); beg/end/mj come from __ballot.
+// A lane-per-column ANTI-DIAGONAL sweep cannot reproduce `end` exactly: whether
+// cell (i,j) is inside the trimmed range depends on cells (i-1, j'>j) that such a
+// sweep has not computed yet ("why rows, not anti-diagonals").
+//
+// All row state lives in VGPRs; per alignment the wave reads qlen+tlen bytes and
+// writes 12 (or 36) bytes, so the kernel is integer-VALU bound, not HBM bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bmh_internal.h"
+
+#define NEG_INF (-(1 << 29))
+
+// inclusive max-scan over the 64 lanes (Kogge-Stone inside 16-lane rows on DPP
+// row_shr, then row_bcast:15 / row_bcast:31 across rows); lane 63 ends with the total
+__device__ __forceinline__ int wave_scan_max(int v)
+{
+	int t;
+	t = __builtin_amdgcn_update_dpp(NEG_INF, v, 0x111, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(NEG_INF, v, 0x112, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(NEG_INF, v, 0x114, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(NEG_INF, v, 0x118, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(NEG_INF, v, 0x142, 0xa, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(NEG_INF, v, 0x143, 0xc, 0xf, false); v = max(v, t);
+	return v;
+}
+
+// value of lane-1 (wave_shr:1); lane 0 receives `fill`
+__device__ __forceinline__ int wave_shr1(int v, int fill)
+{
+	return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+
+struct ext_args_t {
+	const uint8_t *q, *t;
+	const uint32_t *qoff, *qlen, *toff, *tlen, *h0;
+	const uint32_t *ids;          // alignment ids of this class
+	const uint32_t *count;        // how many
+	int32_t *out, *raw;
+	int a, b, o_del, e_del, o_ins, e_ins, zdrop, end_bonus;
+};
+
+template <int C>
+__global__ void __launch_bounds__(256) extend_kernel(ext_args_t A)
+{
+	const int lane = threadIdx.x & 63;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+	const uint32_t n = *A.count;
+	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;
+	for (uint32_t w = wave; w < n; w += n_waves) {
+		const uint32_t id = A.ids[w];
+		const int qlen = (int)A.qlen[id], tlen = (int)A.tlen[id], h0 = (int)A.h0[id];
+		const uint8_t *qp = A.q + A.qoff[id], *tp = A.t + A.toff[id];
+		int H[C], E[C], qb[C];
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			int j = lane * C + c;
+			qb[c] = j < qlen ? (int)qp[j] : 4;
+			int v = h0 - oe_ins - j * A.e_ins;            // H(-1,j), ksw.c:880-883
+			H[c] = (j < qlen && v > 0) ? v : 0;
+			E[c] = 0;
+		}
+		int beg = 0, end = qlen, mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+		int tchunk = 0;
+		for (int i = 0; i < tlen; ++i) {
+			if ((i & 63) == 0) tchunk = (i + lane < tlen) ? (int)tp[i + lane] : 4;
+			const int ti = __builtin_amdgcn_readlane(tchunk, i & 63);
+			// H(i-1,-1): the first-column value of the previous row (ksw.c:909-914, :880)
+			const int hm1 = i == 0 ? h0 : max(0, h0 - (A.o_del + A.e_del * i));
+			const int left = wave_shr1(H[C - 1], beg == 0 ? hm1 : 0);
+			int M[C], g[C];
+			int agg = NEG_INF;
+#pragma unroll
+			for (int c = 0; c < C; ++c) {
+				const int j = lane * C + c;
+				const bool act = j >= beg && j < end;
+				const int hd = c == 0 ? left : H[c - 1];
+				const int sc = (ti > 3 || qb[c] > 3) ? -1 : (ti == qb[c] ? A.a : -A.b);
+				const int m = (act && hd) ? hd + sc : 0;
+				M[c] = m;
+				const int tins = max(m - oe_ins, 0);
+				g[c] = act ? tins + A.e_ins * j : NEG_INF;
+				agg = max(agg, g[c]);
+			}
+			const int incl = wave_scan_max(agg);
+			int run = wave_shr1(incl, NEG_INF);           // max of g over all columns left of this lane
+			int lm = 0, lmj = -1;                           // lane-local row maximum and its last column (m = 0, mj = -1 start, ksw.c:900)
+			bool nzH = false, nzE = false;
+			int firstH = 1 << 20, lastH = -1, firstE = 1 << 20, lastE = -1;
+#pragma unroll
+			for (int c = 0; c < C; ++c) {
+				const int j = lane * C + c;
+				const bool act = j >= beg && j < end;
+				const int f = max(0, run - A.e_ins * (j - 1));
+				run = max(run, g[c]);
+				int h = max(max(M[c], E[c]), f);
+				int e = max(E[c] - A.e_del, max(M[c] - oe_del, 0));
+				h = act ? h : 0;
+				e = act ? e : 0;
+				H[c] = h; E[c] = e;
+				if (act && h >= lm) { lm = h; lmj = j; }
+				if (h) { nzH = true; firstH = min(firstH, j); lastH = j; }
+				if (e) { nzE = true; firstE = min(firstE, j); lastE = j; }
+			}
+			// row maximum m and mj = last column holding it (ksw.c:928-929)
+			const int m = __builtin_amdgcn_readlane(wave_scan_max(lm), 63);
+			if (end == qlen) {                              // ksw.c:942-945
+				const int jl = qlen - 1;
+				int h1 = 0;
+				if (qlen > 0) {
+					int src = 0;
+#pragma unroll
+					for (int c = 0; c < C; ++c) if (jl % C == c) src = H[c];
+					h1 = __builtin_amdgcn_readlane(src, jl / C);
+					if (!(jl >= beg)) h1 = 0;
+				} else {
+					h1 = beg == 0 ? max(0, h0 - (A.o_del + A.e_del * (i + 1))) : 0;
+				}
+				if (!(gscore > h1)) max_ie = i;
+				gscore = max(gscore, h1);
+			}
+			if (m == 0) break;
+			const unsigned long long em = __ballot(lm == m);
+			const int mj = __builtin_amdgcn_readlane(lmj, 63 - __builtin_clzll(em));
+			if (m > mx) {
+				mx = m; max_i = i; max_j = mj;
+				max_off = max(max_off, abs(mj - i));
+			} else if (A.zdrop > 0) {
+				if (i - max_i > mj - max_j) {
+					if (mx - m - ((i - max_i) - (mj - max_j)) * A.e_del > A.zdrop) break;
+				} else {
+					if (mx - m - ((mj - max_j) - (i - max_i)) * A.e_ins > A.zdrop) break;
+				}
+			}
+			// next row's [beg,end): first / last non-zero of eh[beg..end] (ksw.c:963-970), where
+			// eh[j] = {H(i,j-1), E(i+1,j)}, eh[beg].h = the first-column value, eh[end].e = 0
+			const int h1i = beg == 0 ? max(0, h0 - (A.o_del + A.e_del * (i + 1))) : 0;
+			const unsigned long long bh = __ballot(nzH), be = __ballot(nzE);
+			int fidx = 1 << 20, lidx = -1;
+			if (h1i) { fidx = beg; lidx = beg; }
+			if (bh) {
+				const int fl = __builtin_ctzll(bh), ll = 63 - __builtin_clzll(bh);
+				fidx = min(fidx, __builtin_amdgcn_readlane(firstH, fl) + 1);
+				lidx = max(lidx, __builtin_amdgcn_readlane(lastH, ll) + 1);
+			}
+			if (be) {
+				const int fl = __builtin_ctzll(be), ll = 63 - __builtin_clzll(be);
+				fidx = min(fidx, __builtin_amdgcn_readlane(firstE, fl));
+				lidx = max(lidx, __builtin_amdgcn_readlane(lastE, ll));
+			}
+			const int nbeg = min(fidx, end);
+			const int nend = min(qlen, max(lidx, nbeg - 1) + 2);
+			beg = nbeg; end = nend;
+		}
+		if (lane == 0) {
+			const int qle = max_j + 1, tle = max_i + 1, gtle = max_ie + 1;
+			int32_t *o = A.out + 3 * (size_t)id;
+			if (gscore <= 0 || gscore <= mx - A.end_bonus) { o[0] = mx; o[1] = qle; o[2] = tle; }
+			else { o[0] = gscore; o[1] = qlen; o[2] = gtle; }
+			if (A.raw) {
+				int32_t *r = A.raw + 6 * (size_t)id;
+				r[0] = mx; r[1] = qle; r[2] = tle; r[3] = gtle; r[4] = gscore; r[5] = max_off;
+			}
+		}
+	}
+}
+
+// class of an alignment = columns per lane; 0 marks an unsupported length
+#define EXT_MAX_C 8
+__global__ void __launch_bounds__(256) ext_bin_kernel(const uint32_t *__restrict__ qlen, uint32_t n, uint32_t *__restrict__ ids,
+                                                      uint32_t *__restrict__ counts, int32_t *__restrict__ out)
+{
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	int cls = -1;
+	if (t < n) {
+		uint32_t ql = qlen[t];
+		cls = ql <= 64 ? 1 : (int)((ql + 63) / 64);
+		if (cls > EXT_MAX_C) { cls = 0; out[3 * (size_t)t] = out[3 * (size_t)t + 1] = out[3 * (size_t)t + 2] = INT32_MIN; }
+	}
+	int lane = threadIdx.x & 63;
+	for (int c = 0; c <= EXT_MAX_C; ++c) {
+		unsigned long long mk = __ballot(cls == c);
+		if (!mk) continue;
+		int leader = __builtin_ctzll(mk);
+		uint32_t base = 0;
+		if (lane == leader) base = atomicAdd(&counts[c], (uint32_t)__popcll(mk));
+		base = __shfl(base, leader);
+		if (cls == c) ids[(size_t)c * n + base + __popcll(mk & ((1ull << lane) - 1))] = t;
+	}
+}
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
+
+// per-stream scratch for the class lists (grown on demand, reused across calls)
+struct ext_scratch_t { uint32_t *ids; uint32_t *counts; size_t cap; int dev; };
+static thread_local ext_scratch_t g_scr = {nullptr, nullptr, 0, -1};
+
+template <int C>
+static void launch_class(const ext_args_t &base, uint32_t n, hipStream_t st, unsigned grid)
+{
+	ext_args_t a = base;
+	a.ids = base.ids + (size_t)C * n;
+	a.count = base.count + C;
+	extend_kernel<C><<<grid, 256, 0, st>>>(a);
+}
+
+extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, const uint32_t *d_qlen, const uint8_t *d_t,
+                                const uint32_t *d_toff, const uint32_t *d_tlen, const uint32_t *d_h0, uint32_t n,
+                                const bmh_ext_params_t *p, int32_t *d_out, int32_t *d_raw, void *stream_)
+{
+	if (!p || (n && (!d_q || !d_t || !d_qoff || !d_qlen || !d_toff || !d_tlen || !d_h0 || !d_out))) {
+		bmh_set_error("bmh_extend_batch: null argument"); return BMH_EINVAL;
+	}
+	if (p->e_del < 0 || p->e_ins < 0 || p->o_del < 0 || p->o_ins < 0) { bmh_set_error("bmh_extend_batch: negative gap penalty"); return BMH_EINVAL; }
+	if (n == 0) return BMH_OK;
+	hipStream_t st = (hipStream_t)stream_;
+	int dev = 0;
+	HIPCK(hipGetDevice(&dev));
+	if (g_scr.cap < n || g_scr.dev != dev) {
+		if (g_scr.ids) { (void)hipFree(g_scr.ids); (void)hipFree(g_scr.counts); g_scr.ids = nullptr; g_scr.counts = nullptr; g_scr.cap = 0; }
+		HIPCK(hipMalloc((void **)&g_scr.ids, sizeof(uint32_t) * (size_t)n * (EXT_MAX_C + 1)));
+		HIPCK(hipMalloc((void **)&g_scr.counts, sizeof(uint32_t) * 16));
+		g_scr.cap = n; g_scr.dev = dev;
+	}
+	HIPCK(hipMemsetAsync(g_scr.counts, 0, sizeof(uint32_t) * 16, st));
+	ext_bin_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_qlen, n, g_scr.ids, g_scr.counts, d_out);
+	ext_args_t a;
+	a.q = d_q; a.t = d_t; a.qoff = d_qoff; a.qlen = d_qlen; a.toff = d_toff; a.tlen = d_tlen; a.h0 = d_h0;
+	a.ids = g_scr.ids; a.count = g_scr.counts; a.out = d_out; a.raw = d_raw;
+	a.a = p->a; a.b = p->b; a.o_del = p->o_del; a.e_del = p->e_del; a.o_ins = p->o_ins; a.e_ins = p->e_ins;
+	a.zdrop = p->zdrop; a.end_bonus = p->end_bonus;
+	// one wave per alignment, 4 per block; waves stride over their class list
+	unsigned grid = (unsigned)((n + 3) / 4);
+	const unsigned max_grid = 256 * 8;
+	if (grid > max_grid) grid = max_grid;
+	// class lists are sized by n each; the per-class counts stay on the device (no host sync)
+	{
+		// rebase: ids of class c live at ids + c*n (launch_class adds C*n)
+		launch_class<1>(a, n, st, grid); launch_class<2>(a, n, st, grid); launch_class<3>(a, n, st, grid);
+		launch_class<4>(a, n, st, grid); launch_class<5>(a, n, st, grid); launch_class<6>(a, n, st, grid);
+		launch_class<7>(a, n, st, grid); launch_class<8>(a, n, st, grid);
+	}
+	HIPCK(hipGetLastError());
+	return BMH_OK;
+}

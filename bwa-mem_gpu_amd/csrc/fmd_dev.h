@@ -1,0 +1,183 @@
+// Device-side FMD-index arithmetic for gfx950 (wave64).
+//
+// Index layout in HBM is the reference's GPU layout, kept bit-for-bit so the
+// reference's index files upload without conversion
+// (/root/reference/src/GPUSeed/seed_gen.cu:28-48): one 32-byte block per 64
+// BWT symbols = u32 occ[4] (counts of A,C,G,T before the block) + u32 bwt[4]
+// (16 symbols per word, 2 bits, MSB first).  A block is fetched with two
+// 16-byte loads from one 32-byte-aligned address, i.e. one 64-byte HBM sector.
+//
+// Rank semantics follow the CPU statement of the reference
+// (src/bwt.c:235-261 bwt_occ, :363-405 bwt_2occ4, :64-70 bwt_invPsi), not the
+// off-by-one GPU form of seed_gen.cu:403-405.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct fmd_dev_t {
+	uint64_t primary;
+	uint64_t L2[5];
+	uint64_t seq_len;
+	const uint4 *blocks;      // 2 x uint4 per block: [2b] = occ, [2b+1] = bwt words
+	const uint32_t *sa;       // sa[0] = 0xFFFFFFFF
+	const uint32_t *sa_bits;  // 33rd bit of each sample
+	uint64_t n_sa;
+	int sa_shift;             // log2(sa_intv)
+	// optional 2-bit forward-strand text (pac, 4 bases per byte, MSB first) for the
+	// unique-interval shortcut; 0 when absent
+	const uint8_t *pac;
+	uint64_t l_pac;
+};
+
+struct blk_t { uint4 occ, w; };
+
+// L2[c] for a per-lane c without indexing the kernel-argument struct dynamically
+__device__ __forceinline__ uint64_t fmd_L2(const fmd_dev_t &f, int c)
+{
+	return c == 0 ? f.L2[0] : c == 1 ? f.L2[1] : c == 2 ? f.L2[2] : c == 3 ? f.L2[3] : f.L2[4];
+}
+
+__device__ __forceinline__ blk_t fmd_load_block(const fmd_dev_t &f, uint64_t b)
+{
+	blk_t r;
+	r.occ = f.blocks[2 * b];
+	r.w = f.blocks[2 * b + 1];
+	return r;
+}
+
+// per-symbol match bits (in the 0x55555555 lanes) of the first nsym symbols
+__device__ __forceinline__ uint32_t prefix_mask(int nsym)   // nsym in 0..16
+{
+	// low bit of symbol t sits at bit 30-2t
+	return nsym <= 0 ? 0u : (0x55555555u & (0xFFFFFFFFu << (32 - 2 * (nsym > 16 ? 16 : nsym))));
+}
+
+// counts of A,C,G,T among symbols [0..off] (inclusive) of the block, plus the block's occ
+__device__ __forceinline__ void blk_occ4(const blk_t &b, int off, uint32_t cnt[4])
+{
+	const uint32_t wv[4] = {b.w.x, b.w.y, b.w.z, b.w.w};
+	uint32_t c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		uint32_t m = prefix_mask(off + 1 - 16 * i);
+		uint32_t lo = wv[i] & m, hi = (wv[i] >> 1) & m;
+		c1 += __popc(lo & ~hi);
+		c2 += __popc(hi & ~lo);
+		c3 += __popc(hi & lo);
+	}
+	cnt[0] = b.occ.x + (uint32_t)(off + 1) - c1 - c2 - c3;
+	cnt[1] = b.occ.y + c1;
+	cnt[2] = b.occ.z + c2;
+	cnt[3] = b.occ.w + c3;
+}
+
+// count of symbol c among symbols [0..off] of the block, plus the block's occ[c]
+__device__ __forceinline__ uint32_t blk_occ1(const blk_t &b, int off, int c)
+{
+	const uint32_t wv[4] = {b.w.x, b.w.y, b.w.z, b.w.w};
+	const uint32_t pat = 0x55555555u * (uint32_t)c;
+	uint32_t n = 0;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		uint32_t x = ~(wv[i] ^ pat);
+		x = x & (x >> 1) & prefix_mask(off + 1 - 16 * i);
+		n += __popc(x);
+	}
+	return (c == 0 ? b.occ.x : c == 1 ? b.occ.y : c == 2 ? b.occ.z : b.occ.w) + n;
+}
+
+__device__ __forceinline__ int blk_sym(const blk_t &b, int off)
+{
+	int wi = off >> 4;
+	uint32_t w = wi == 0 ? b.w.x : wi == 1 ? b.w.y : wi == 2 ? b.w.z : b.w.w;
+	return (w >> (30 - 2 * (off & 15))) & 3;
+}
+
+// Occ for all four symbols at full-matrix row k (src/bwt.c:235-261 semantics)
+__device__ __forceinline__ void fmd_occ4(const fmd_dev_t &f, uint64_t k, uint64_t cnt[4])
+{
+	if (k == f.seq_len) {
+#pragma unroll
+		for (int c = 0; c < 4; ++c) cnt[c] = f.L2[c + 1] - f.L2[c];
+		return;
+	}
+	if (k == (uint64_t)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
+	k -= (k >= f.primary);
+	blk_t b = fmd_load_block(f, k >> 6);
+	uint32_t c4[4];
+	blk_occ4(b, (int)(k & 63), c4);
+#pragma unroll
+	for (int c = 0; c < 4; ++c) cnt[c] = c4[c];
+}
+
+// Occ(k,c) and Occ(l,c), k <= l, sharing the block when both fall in one
+__device__ __forceinline__ void fmd_occ4_pair(const fmd_dev_t &f, uint64_t k, uint64_t l, uint64_t ck[4], uint64_t cl[4])
+{
+	bool sk = (k == f.seq_len) | (k == (uint64_t)-1), sl = (l == f.seq_len) | (l == (uint64_t)-1);
+	uint64_t k2 = k - (k >= f.primary), l2 = l - (l >= f.primary);
+	if (!sk && !sl && (k2 >> 6) == (l2 >> 6)) {
+		blk_t b = fmd_load_block(f, k2 >> 6);
+		uint32_t a4[4], b4[4];
+		blk_occ4(b, (int)(k2 & 63), a4);
+		blk_occ4(b, (int)(l2 & 63), b4);
+#pragma unroll
+		for (int c = 0; c < 4; ++c) { ck[c] = a4[c]; cl[c] = b4[c]; }
+	} else {
+		fmd_occ4(f, k, ck);
+		fmd_occ4(f, l, cl);
+	}
+}
+
+__device__ __forceinline__ uint64_t fmd_occ1(const fmd_dev_t &f, uint64_t k, int c)
+{
+	if (k == f.seq_len) return fmd_L2(f, c + 1) - fmd_L2(f, c);
+	if (k == (uint64_t)-1) return 0;
+	k -= (k >= f.primary);
+	blk_t b = fmd_load_block(f, k >> 6);
+	return blk_occ1(b, (int)(k & 63), c);
+}
+
+__device__ __forceinline__ void fmd_occ1_pair(const fmd_dev_t &f, uint64_t k, uint64_t l, int c, uint64_t &ok, uint64_t &ol)
+{
+	bool sk = (k == f.seq_len) | (k == (uint64_t)-1), sl = (l == f.seq_len) | (l == (uint64_t)-1);
+	uint64_t k2 = k - (k >= f.primary), l2 = l - (l >= f.primary);
+	if (!sk && !sl && (k2 >> 6) == (l2 >> 6)) {
+		blk_t b = fmd_load_block(f, k2 >> 6);
+		ok = blk_occ1(b, (int)(k2 & 63), c);
+		ol = blk_occ1(b, (int)(l2 & 63), c);
+	} else {
+		ok = fmd_occ1(f, k, c);
+		ol = fmd_occ1(f, l, c);
+	}
+}
+
+// LF step, CPU form (src/bwt.c:64-70)
+__device__ __forceinline__ uint64_t fmd_inv_psi(const fmd_dev_t &f, uint64_t k)
+{
+	if (k == f.primary) return 0;
+	uint64_t x = k - (k > f.primary);
+	blk_t b = fmd_load_block(f, x >> 6);
+	int off = (int)(x & 63);
+	int c = blk_sym(b, off);
+	return fmd_L2(f, c) + blk_occ1(b, off, c);
+}
+
+// SA value of row k (src/bwt.c:105-115; sample = 32 bits + packed 33rd bit, seed_gen.cu:653-657)
+__device__ __forceinline__ uint64_t fmd_sa(const fmd_dev_t &f, uint64_t k)
+{
+	uint64_t steps = 0, mask = (1ull << f.sa_shift) - 1;
+	while (k & mask) { ++steps; k = fmd_inv_psi(f, k); }
+	uint64_t idx = k >> f.sa_shift;
+	if (idx == 0) return steps - 1;            // sa[0] == (bwtint_t)-1 on the CPU path
+	uint64_t hi = (f.sa_bits[idx >> 5] >> (idx & 31)) & 1u;
+	return ((uint64_t)f.sa[idx] | (hi << 32)) + steps;
+}
+
+// symbol i of the indexed text T = fwd . revcomp(fwd) from the 2-bit pac
+__device__ __forceinline__ int fmd_text(const fmd_dev_t &f, uint64_t i)
+{
+	bool rev = i >= f.l_pac;
+	uint64_t p = rev ? 2 * f.l_pac - 1 - i : i;
+	int c = (f.pac[p >> 2] >> ((~p & 3) << 1)) & 3;
+	return rev ? 3 - c : c;
+}

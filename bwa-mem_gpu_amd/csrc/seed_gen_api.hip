@@ -1,0 +1,222 @@
+// Reference-compatible seeding entry points (include/seed_gen.h) on top of the
+// device-level API.  Replaces the host side of
+// /root/reference/src/GPUSeed/seed_gen.cu: loaders :1386-1468, gpu_cpy_wrapper
+// :1524-1556, seed_gpu :1625-2188, free_gpuseed_data :1567-1573.
+//
+// seed_gpu keeps the reference's contract -- it parses the read file itself
+// (single-line FASTA, every non-'>' line is one read, seed_gen.cu:1698-1728),
+// seeds it batch by batch and returns malloc()'d flat arrays the caller frees
+// with free() (src/fastmap.c:537-542) -- but batches are sized for 288 GB of
+// HBM (SEED_BATCH_READS reads per launch set instead of ~1 Mbase), reads are
+// staged through pinned host memory, and the per-batch H2D/D2H copies are
+// asynchronous on one stream.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "bmh_internal.h"
+#include "../../include/seed_gen.h"
+
+#define FATAL(...) do { fprintf(stderr, "[bwamem_hip] " __VA_ARGS__); fprintf(stderr, "\n"); exit(EXIT_FAILURE); } while (0)
+#define HIPX(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) FATAL("%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+static uint64_t g_last_n_reads = 0;
+extern "C" uint64_t seed_gpu_last_n_reads(void) { return g_last_n_reads; }
+
+extern "C" bwt_t_gpu *bwt_restore_bwt_gpu(const char *fn)
+{
+	FILE *fp = fopen(fn, "rb");
+	if (!fp) FATAL("Unable to open .bwt file %s", fn);
+	bwt_t_gpu *bwt = (bwt_t_gpu *)calloc(1, sizeof(bwt_t_gpu));
+	fseek(fp, 0, SEEK_END);
+	long sz = ftell(fp);
+	if (sz < 40) FATAL("%s: truncated", fn);
+	bwt->bwt_size = (uint64_t)(sz - 40) >> 2;
+	// pinned host staging, like the reference (cudaMallocHost, seed_gen.cu:1454-1455); padded to whole blocks
+	size_t words = (size_t)bwt->bwt_size + 16;
+	HIPX(hipHostMalloc((void **)&bwt->bwt, words * 4, hipHostMallocDefault));
+	memset(bwt->bwt, 0, words * 4);
+	bwt->L2 = (bwtint_t_gpu *)calloc(5, sizeof(bwtint_t_gpu));
+	fseek(fp, 0, SEEK_SET);
+	if (fread(&bwt->primary, 8, 1, fp) != 1 || fread(bwt->L2 + 1, 8, 4, fp) != 4 ||
+	    fread(bwt->bwt, 4, bwt->bwt_size, fp) != bwt->bwt_size) FATAL("%s: short read", fn);
+	bwt->seq_len = bwt->L2[4];
+	fclose(fp);
+	return bwt;
+}
+
+extern "C" void bwt_restore_sa_gpu(const char *fn, bwt_t_gpu *bwt)
+{
+	FILE *fp = fopen(fn, "rb");
+	if (!fp) FATAL("Unable to open .sa file %s", fn);
+	uint64_t primary, skipped[4], intv, seq_len;
+	if (fread(&primary, 8, 1, fp) != 1 || fread(skipped, 8, 4, fp) != 4 || fread(&intv, 8, 1, fp) != 1 ||
+	    fread(&seq_len, 8, 1, fp) != 1) FATAL("%s: short header", fn);
+	if (primary != bwt->primary) FATAL("SA-BWT inconsistency: primary is not the same.");
+	if (seq_len != bwt->seq_len) FATAL("SA-BWT inconsistency: seq_len is not the same.");
+	bwt->sa_intv = (int)intv;
+	bwt->n_sa = (bwt->seq_len + bwt->sa_intv) / bwt->sa_intv;
+	HIPX(hipHostMalloc((void **)&bwt->sa, bwt->n_sa * 4, hipHostMallocDefault));
+	bwt->sa[0] = (uint32_t)-1;
+	if (fread(bwt->sa + 1, 4, bwt->n_sa - 1, fp) != bwt->n_sa - 1) FATAL("%s: short SA", fn);
+	if (fread(&bwt->pack_size, 1, 1, fp) != 1) FATAL("%s: no pack_size", fn);
+	if (bwt->pack_size != 1) FATAL("%s: pack_size %d unsupported (seq_len >= 2^33)", fn, bwt->pack_size);
+	size_t nb = (size_t)bwt->pack_size * bwt->n_sa / 32 + 1;
+	HIPX(hipHostMalloc((void **)&bwt->sa_upper_bits, nb * 4, hipHostMallocDefault));
+	if (fread(bwt->sa_upper_bits, 4, nb, fp) != nb) FATAL("%s: short bit array", fn);
+	bwt->sa_upper_bits[0] |= 0x1;
+	fclose(fp);
+}
+
+extern "C" void bwt_destroy_gpu(bwt_t_gpu *bwt)
+{
+	if (!bwt) return;
+	if (bwt->sa) (void)hipHostFree(bwt->sa);
+	if (bwt->sa_upper_bits) (void)hipHostFree(bwt->sa_upper_bits);
+	if (bwt->bwt) (void)hipHostFree(bwt->bwt);
+	free(bwt->L2);
+	free(bwt);
+}
+
+extern "C" bwt_t_gpu gpu_cpy_wrapper(bwt_t_gpu *bwt)
+{
+	bwt_t_gpu g;
+	memset(&g, 0, sizeof(g));
+	size_t bwt_bytes = ((size_t)((bwt->seq_len + 63) / 64) + 1) * 32;
+	size_t nb = (size_t)bwt->pack_size * bwt->n_sa / 32 + 1;
+	HIPX(hipMalloc((void **)&g.bwt, bwt_bytes));
+	HIPX(hipMalloc((void **)&g.sa, bwt->n_sa * 4));
+	HIPX(hipMalloc((void **)&g.sa_upper_bits, nb * 4));
+	HIPX(hipMemset(g.bwt, 0, bwt_bytes));
+	size_t cp = (size_t)bwt->bwt_size * 4 < bwt_bytes ? (size_t)bwt->bwt_size * 4 : bwt_bytes;
+	HIPX(hipMemcpy(g.bwt, bwt->bwt, cp, hipMemcpyHostToDevice));
+	HIPX(hipMemcpy(g.sa, bwt->sa, bwt->n_sa * 4, hipMemcpyHostToDevice));
+	HIPX(hipMemcpy(g.sa_upper_bits, bwt->sa_upper_bits, nb * 4, hipMemcpyHostToDevice));
+	g.pack_size = bwt->pack_size; g.primary = bwt->primary; g.seq_len = bwt->seq_len;
+	g.sa_intv = bwt->sa_intv; g.n_sa = bwt->n_sa;
+	g.bwt_size = bwt_bytes / 4;
+	g.L2 = (bwtint_t_gpu *)malloc(5 * sizeof(bwtint_t_gpu));   // host copy (see include/seed_gen.h)
+	memcpy(g.L2, bwt->L2, 5 * sizeof(bwtint_t_gpu));
+	bwt_destroy_gpu(bwt);      // the reference frees the host copy here too (seed_gen.cu:1553)
+	return g;
+}
+
+extern "C" void pre_calc_seed_intervals_wrapper(uint2 *, int, bwt_t_gpu)
+{
+	// exported by the reference but never called (src/fastmap.c:455 sets the flag to 0)
+	FATAL("pre_calc_seed_intervals_wrapper: not used by the pipeline (reference fastmap.c:455)");
+}
+
+extern "C" void free_gpuseed_data(gpuseed_storage_vector *d)
+{
+	if (!d) return;
+	if (d->bwt_gpu.bwt) (void)hipFree(d->bwt_gpu.bwt);
+	if (d->bwt_gpu.sa) (void)hipFree(d->bwt_gpu.sa);
+	if (d->bwt_gpu.sa_upper_bits) (void)hipFree(d->bwt_gpu.sa_upper_bits);
+	free(d->bwt_gpu.L2);
+	memset(&d->bwt_gpu, 0, sizeof(d->bwt_gpu));
+}
+
+#ifndef SEED_BATCH_READS
+#define SEED_BATCH_READS (1u << 20)
+#endif
+#define SEED_BATCH_BASES ((uint64_t)SEED_BATCH_READS * 320)
+
+extern "C" mem_seed_v_gpu *seed_gpu(gpuseed_storage_vector *d)
+{
+	if (!d->is_smem) FATAL("seed_gpu: MEM mode (-g) is not implemented; only SMEM seeding (the default, fastmap.c:442)");
+	const bwt_t_gpu &g = d->bwt_gpu;
+	if (!g.bwt || !g.L2) FATAL("seed_gpu: index not on the device (call gpu_cpy_wrapper first)");
+	bmh_index_t *idx = bmh_index_from_device(g.primary, g.L2, g.seq_len, g.bwt, g.bwt_size, g.sa_intv, g.sa, g.n_sa,
+	                                         g.sa_upper_bits, nullptr, 0);
+	if (!idx) FATAL("seed_gpu: %s", bmh_last_error());
+	FILE *fp = fopen(d->read_file, "r");
+	if (!fp) FATAL("seed_gpu: cannot open %s", d->read_file);
+
+	// size the batch by the file: at most one read per two bytes, one base per byte
+	fseek(fp, 0, SEEK_END);
+	uint64_t fsz = (uint64_t)ftell(fp);
+	fseek(fp, (long)d->file_bytes_skip, SEEK_SET);
+	uint64_t left = fsz > d->file_bytes_skip ? fsz - d->file_bytes_skip : 0;
+	const uint32_t BATCH_READS = (uint32_t)(left / 2 + 1 < SEED_BATCH_READS ? left / 2 + 1 : SEED_BATCH_READS);
+	const uint64_t BATCH_BASES = left + 1 < SEED_BATCH_BASES ? left + 1 : SEED_BATCH_BASES;
+
+	hipStream_t st;
+	HIPX(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	bmh_seed_ws_t *ws = bmh_seed_ws_create(BATCH_READS, BATCH_BASES, 0, 0);
+	if (!ws) FATAL("seed_gpu: %s", bmh_last_error());
+	uint8_t *h_bases; uint32_t *h_offs, *h_lens;
+	HIPX(hipHostMalloc((void **)&h_bases, BATCH_BASES, hipHostMallocDefault));
+	HIPX(hipHostMalloc((void **)&h_offs, (size_t)BATCH_READS * 4, hipHostMallocDefault));
+	HIPX(hipHostMalloc((void **)&h_lens, (size_t)BATCH_READS * 4, hipHostMallocDefault));
+	uint8_t *d_bases; uint32_t *d_offs, *d_lens;
+	HIPX(hipMalloc((void **)&d_bases, BATCH_BASES));
+	HIPX(hipMalloc((void **)&d_offs, (size_t)BATCH_READS * 4));
+	HIPX(hipMalloc((void **)&d_lens, (size_t)BATCH_READS * 4));
+
+	std::vector<uint64_t> rbeg; std::vector<int2> qbeg; std::vector<uint32_t> score, n_ref;
+	uint64_t file_bytes = 0;
+	char *line = nullptr; size_t cap = 0;
+	bool eof = false;
+	while (!eof) {
+		uint32_t nr = 0; uint64_t nb = 0;
+		while (nr < BATCH_READS) {
+			ssize_t n = getline(&line, &cap, fp);
+			if (n < 0) { eof = true; break; }
+			file_bytes += (uint64_t)n;
+			if (line[0] == '>') continue;
+			while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) --n;
+			if (n == 0) continue;                     // blank line (kseq skips it too)
+			if (nb + (uint64_t)n > BATCH_BASES) {  // batch full: push the line back
+				fseek(fp, -(long)(strlen(line)), SEEK_CUR); file_bytes -= strlen(line);
+				break;
+			}
+			memcpy(h_bases + nb, line, (size_t)n);
+			h_offs[nr] = (uint32_t)nb; h_lens[nr] = (uint32_t)n;
+			nb += (uint64_t)n; ++nr;
+		}
+		if (nr == 0) break;
+		HIPX(hipMemcpyAsync(d_bases, h_bases, nb, hipMemcpyHostToDevice, st));
+		HIPX(hipMemcpyAsync(d_offs, h_offs, (size_t)nr * 4, hipMemcpyHostToDevice, st));
+		HIPX(hipMemcpyAsync(d_lens, h_lens, (size_t)nr * 4, hipMemcpyHostToDevice, st));
+		bmh_seeds_t s;
+		if (bmh_seed_batch(ws, idx, d_bases, d_offs, d_lens, nr, d->min_seed_size, st, &s) != BMH_OK)
+			FATAL("seed_gpu: %s", bmh_last_error());
+		size_t o = rbeg.size(), r0 = n_ref.size();
+		rbeg.resize(o + s.n_seeds); qbeg.resize(o + s.n_seeds); score.resize(o + s.n_seeds); n_ref.resize(r0 + nr);
+		if (s.n_seeds) {
+			HIPX(hipMemcpyAsync(rbeg.data() + o, s.d_rbeg, s.n_seeds * 8, hipMemcpyDeviceToHost, st));
+			HIPX(hipMemcpyAsync(qbeg.data() + o, s.d_qbeg, s.n_seeds * 8, hipMemcpyDeviceToHost, st));
+			HIPX(hipMemcpyAsync(score.data() + o, s.d_score, s.n_seeds * 4, hipMemcpyDeviceToHost, st));
+		}
+		HIPX(hipMemcpyAsync(n_ref.data() + r0, s.d_n_ref_pos, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+		HIPX(hipStreamSynchronize(st));
+	}
+	free(line);
+	fclose(fp);
+
+	mem_seed_v_gpu *out = (mem_seed_v_gpu *)malloc(sizeof(mem_seed_v_gpu));
+	size_t ns = rbeg.size(), nr = n_ref.size();
+	if ((uint64_t)ns >> 32) FATAL("seed_gpu: more than 2^32 seeds in one run (32-bit prefix sums, seed_gen.h:73)");
+	out->rbeg = (bwtint_t_gpu *)malloc((ns + 1) * 8);
+	out->qbeg = (int2 *)malloc((ns + 1) * sizeof(int2));
+	out->score = (uint32_t *)malloc((ns + 1) * 4);
+	out->n_ref_pos_fow_rev_results = (uint32_t *)malloc((nr + 1) * 4);
+	out->n_ref_pos_fow_rev_prefix_sums = (uint32_t *)malloc((nr + 1) * 4);
+	memcpy(out->rbeg, rbeg.data(), ns * 8);
+	memcpy(out->qbeg, qbeg.data(), ns * sizeof(int2));
+	memcpy(out->score, score.data(), ns * 4);
+	memcpy(out->n_ref_pos_fow_rev_results, n_ref.data(), nr * 4);
+	uint32_t acc = 0;
+	for (size_t i = 0; i < nr; ++i) { out->n_ref_pos_fow_rev_prefix_sums[i] = acc; acc += n_ref[i]; }
+	out->file_bytes_skip = file_bytes;
+	g_last_n_reads = nr;
+
+	(void)hipFree(d_bases); (void)hipFree(d_offs); (void)hipFree(d_lens);
+	(void)hipHostFree(h_bases); (void)hipHostFree(h_offs); (void)hipHostFree(h_lens);
+	bmh_seed_ws_free(ws);
+	bmh_index_free(idx);
+	(void)hipStreamDestroy(st);
+	return out;
+}

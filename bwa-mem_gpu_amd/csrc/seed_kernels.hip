@@ -1,0 +1,449 @@
+// SMEM seeding over the FMD index on gfx950 -- hand-written HIP, wave64.
+//
+// What it computes (bit-identical to the reference's CPU statement):
+//   per read, every SMEM of the first seeding pass of BWA-MEM
+//   (bwt_smem1, /root/reference/src/bwt.c:483-566, driven as
+//   bwa_index/bwamem.c:114-131) with length >= min_seed_len
+//   (src/bwamem.c:260-263), and the text position of every occurrence
+//   (bwt_sa, src/bwt.c:105-115), laid out as the reference's mem_seed_v_gpu
+//   (src/GPUSeed/seed_gen.h:68-75).
+//
+// How (our own decomposition; the reference's kernels are seed_gen.cu:868-1085,
+// 520-662, 704-780 -- we keep their candidate/backward-search idea but none of
+// their structure):
+//   pack      ASCII -> 2-bit words + N mask, transposed [word][read] so that a
+//             wave reading word w of 64 consecutive reads is one coalesced load
+//   forward   one lane per read: bidirectional forward extension; at every
+//             interval-size change with end >= min_seed_len append a candidate
+//             {read, ordinal, start, end, k, s} to a global list (one
+//             wave-aggregated atomic per append round)
+//   backward  one lane per candidate: unidirectional backward search from
+//             start-1 to the maximal begin; result written at
+//             cand_base[read]+ordinal, i.e. already sorted by (read, end)
+//   filter    one lane per result: drop length < min_seed_len and results whose
+//             longer same-pass neighbour has the same begin (contained match;
+//             src/bwt.c:535-541), emit per-result occurrence counts
+//   scan      rocPRIM exclusive scans (candidate bases, occurrence offsets)
+//   expand    SA rows of every kept SMEM, qbeg/score columns of the output
+//   locate    one lane per occurrence: LF walk to a sampled row + SA sample
+// Every rank query is one 32-byte block = two 16-byte loads from one 64-byte
+// sector; all state is in registers, there is no LDS use in these kernels
+// (the index is far larger than LDS and each block is used once).
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include <stdint.h>
+#include <stdio.h>
+#include "bmh_internal.h"
+#include "fmd_dev.h"
+
+// ---------------------------------------------------------------- read access
+
+struct read_view_t {
+	const uint32_t *pk;   // [word][read] 2-bit, base i at bits 2*(i&15)
+	const uint32_t *nm;   // [word32][read] N mask, base i at bit i&31
+	uint32_t n_reads;
+};
+
+__device__ __forceinline__ int read_base(const read_view_t &v, uint32_t r, int i)
+{
+	uint32_t w = v.pk[(size_t)(i >> 4) * v.n_reads + r];
+	uint32_t m = v.nm[(size_t)(i >> 5) * v.n_reads + r];
+	return ((m >> (i & 31)) & 1) ? 4 : (int)((w >> ((i & 15) << 1)) & 3);
+}
+
+__device__ __forceinline__ int ascii_code(uint8_t ch)
+{
+	ch &= 0xDF;
+	return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+}
+
+// one lane per (read, 32-base group): writes two 2-bit words and one mask word
+__global__ void __launch_bounds__(256) pack_reads_kernel(const uint8_t *__restrict__ ascii, const uint32_t *__restrict__ offs,
+                                                         const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t n_grp,
+                                                         uint32_t *__restrict__ pk, uint32_t *__restrict__ nm)
+{
+	size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (tid >= (size_t)n_reads * n_grp) return;
+	uint32_t r = (uint32_t)(tid % n_reads), g = (uint32_t)(tid / n_reads);
+	uint32_t len = lens[r];
+	const uint8_t *p = ascii + offs[r];
+	uint32_t w0 = 0, w1 = 0, m = 0;
+	for (int t = 0; t < 32; ++t) {
+		uint32_t i = g * 32 + t;
+		int c = i < len ? ascii_code(p[i]) : 4;
+		if (c > 3) m |= 1u << t;
+		else if (t < 16) w0 |= (uint32_t)c << (2 * t);
+		else w1 |= (uint32_t)c << (2 * (t - 16));
+	}
+	pk[(size_t)(2 * g) * n_reads + r] = w0;
+	pk[(size_t)(2 * g + 1) * n_reads + r] = w1;
+	nm[(size_t)g * n_reads + r] = m;
+}
+
+// ---------------------------------------------------------------- forward
+
+struct cand_t { uint32_t read, xe, j, s; };   // xe = start<<16 | end
+
+// append one candidate per active lane with a single atomic per wave
+__device__ __forceinline__ void cand_append(bool want, const cand_t &c, uint64_t k, cand_t *out_a, uint64_t *out_k,
+                                            unsigned long long *counter, uint64_t cap)
+{
+	unsigned long long mask = __ballot(want);
+	if (!mask) return;
+	int lane = __lane_id();
+	int leader = __ffsll((long long)mask) - 1;
+	unsigned long long base = 0;
+	if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(mask));
+	base = __shfl(base, leader);
+	if (want) {
+		uint64_t pos = base + __popcll(mask & ((1ull << lane) - 1));
+		if (pos < cap) { out_a[pos] = c; out_k[pos] = k; }
+	}
+}
+
+__global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_view_t rv, const uint32_t *__restrict__ lens,
+                                                           int min_seed_len, cand_t *__restrict__ out_a, uint64_t *__restrict__ out_k,
+                                                           unsigned long long *counter, uint64_t cap, uint32_t *__restrict__ n_cand)
+{
+	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	bool live = r < rv.n_reads;
+	int len = live ? (int)lens[r] : 0;
+	int i = 0, x = 0;
+	uint32_t j = 0;
+	uint64_t k = 0, l = 0, s = 0;
+	// state machine: one rank-pair (or one candidate append) per iteration, so the
+	// lanes of a wave stay convergent on the loads
+	enum { ST_START, ST_EXT, ST_DONE, ST_TAIL };
+	int st = live && len > 0 ? ST_START : ST_DONE;
+	while (__any(st != ST_DONE)) {
+		bool want = false;
+		cand_t c = {r, 0, 0, 0};
+		uint64_t ck = 0;
+		if (st == ST_START) {
+			// skip ambiguous bases, open a pass at the first A/C/G/T
+			int b = read_base(rv, r, i);
+			++i;
+			if (b < 4) {
+				x = i - 1;
+				k = fmd_L2(f, b) + 1; s = fmd_L2(f, b + 1) - fmd_L2(f, b); l = fmd_L2(f, 3 - b) + 1;
+				if (i == len) {           // pass that starts on the last base
+					want = i >= min_seed_len;
+					c.xe = ((uint32_t)x << 16) | (uint32_t)i; c.j = j; c.s = (uint32_t)s; ck = k;
+					st = ST_DONE;
+				} else st = ST_EXT;
+			} else if (i == len) st = ST_DONE;
+		} else if (st == ST_EXT) {
+			int b = read_base(rv, r, i);
+			if (b < 4) {
+				int cb = 3 - b;
+				uint64_t tk[4], tl[4];
+				fmd_occ4_pair(f, l - 1, l - 1 + s, tk, tl);
+				uint64_t os[4];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) os[q] = tl[q] - tk[q];
+				uint64_t nk3 = k + ((l <= f.primary) & (l + s - 1 >= f.primary));
+				uint64_t nk2 = nk3 + os[3], nk1 = nk2 + os[2], nk0 = nk1 + os[1];
+				uint64_t ns = cb == 0 ? os[0] : cb == 1 ? os[1] : cb == 2 ? os[2] : os[3];
+				uint64_t nk = cb == 0 ? nk0 : cb == 1 ? nk1 : cb == 2 ? nk2 : nk3;
+				uint64_t nl = fmd_L2(f, cb) + 1 + (cb == 0 ? tk[0] : cb == 1 ? tk[1] : cb == 2 ? tk[2] : tk[3]);
+				if (ns != s) {
+					want = i >= min_seed_len;
+					c.xe = ((uint32_t)x << 16) | (uint32_t)i; c.j = j; c.s = (uint32_t)s; ck = k;
+				}
+				if (ns == 0) st = ST_START;            // next pass starts at i (src/bwt.c:519 ret)
+				else {
+					k = nk; l = nl; s = ns; ++i;
+					if (i == len) {                       // reached the end: push the last interval
+						// the interval just computed is itself a candidate; it is appended on the
+						// next iteration through ST_TAIL below
+						st = ST_TAIL;
+					}
+				}
+			} else {                                      // ambiguous base ends the pass
+				want = i >= min_seed_len;
+				c.xe = ((uint32_t)x << 16) | (uint32_t)i; c.j = j; c.s = (uint32_t)s; ck = k;
+				st = ST_START;
+			}
+		} else if (st == ST_TAIL) {
+			want = i >= min_seed_len;
+			c.xe = ((uint32_t)x << 16) | (uint32_t)i; c.j = j; c.s = (uint32_t)s; ck = k;
+			st = ST_DONE;
+		}
+		if (want) ++j;
+		cand_append(want, c, ck, out_a, out_k, counter, cap);
+	}
+	if (live) n_cand[r] = j;
+}
+
+// ---------------------------------------------------------------- backward
+
+struct res_t { uint32_t read, be, s, pad; };   // be = begin<<16 | end; s == 0: dropped
+
+__global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_view_t rv, const cand_t *__restrict__ in_a,
+                                                            const uint64_t *__restrict__ in_k, uint64_t n_cands,
+                                                            const uint32_t *__restrict__ cand_base, int min_seed_len,
+                                                            res_t *__restrict__ res_a, uint64_t *__restrict__ res_k)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	bool live = t < n_cands;
+	cand_t c = {0, 0, 0, 0};
+	uint64_t lo = 0, hi = 0;
+	if (live) { c = in_a[t]; lo = in_k[t]; hi = lo + c.s - 1; }
+	int x = (int)(c.xe >> 16), end = (int)(c.xe & 0xFFFF);
+	int i = x - 1, beg = x;
+	bool act = live && i >= 0;
+	while (__any(act)) {
+		if (act) {
+			int b = read_base(rv, c.read, i);
+			if (b > 3) act = false;
+			else {
+				uint64_t ol, ou;
+				fmd_occ1_pair(f, lo - 1, hi, b, ol, ou);
+				uint64_t nl = fmd_L2(f, b) + ol + 1, nu = fmd_L2(f, b) + ou;
+				if (nl > nu) act = false;
+				else { lo = nl; hi = nu; beg = i; --i; act = i >= 0; }
+			}
+		}
+	}
+	if (live) {
+		res_t o;
+		o.read = c.read; o.be = ((uint32_t)beg << 16) | (uint32_t)end;
+		o.s = (end - beg >= min_seed_len) ? (uint32_t)(hi - lo + 1) : 0u;
+		o.pad = 0;
+		size_t d = (size_t)cand_base[c.read] + c.j;
+		res_a[d] = o;
+		res_k[d] = lo;
+	}
+}
+
+// ---------------------------------------------------------------- filter
+
+// keep result t unless the next result of the same read is valid and has the same begin
+__global__ void __launch_bounds__(256) smem_filter_kernel(const res_t *__restrict__ res_a, uint64_t n, uint32_t *__restrict__ occ,
+                                                          uint32_t *__restrict__ keep)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t > n) return;
+	if (t == n) { occ[t] = 0; keep[t] = 0; return; }
+	res_t e = res_a[t];
+	bool k = e.s > 0;
+	if (k && t + 1 < n) {
+		res_t nx = res_a[t + 1];
+		if (nx.read == e.read && nx.s > 0 && (nx.be >> 16) == (e.be >> 16)) k = false;
+	}
+	occ[t] = k ? e.s : 0u;
+	keep[t] = k ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) per_read_counts_kernel(const uint32_t *__restrict__ cand_base, const uint64_t *__restrict__ occ_off,
+                                                              uint32_t n_reads, uint32_t *__restrict__ n_ref_pos, uint32_t *__restrict__ prefix)
+{
+	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	uint64_t a = occ_off[cand_base[r]], b = occ_off[cand_base[r + 1]];
+	prefix[r] = (uint32_t)a;
+	n_ref_pos[r] = (uint32_t)(b - a);
+}
+
+// ---------------------------------------------------------------- expand
+
+// rows k..k+s-1 of each kept SMEM, plus the qbeg/score columns.  Small groups are written
+// by their own lane; large groups by the whole wave, one group at a time.
+__global__ void __launch_bounds__(256) expand_kernel(const res_t *__restrict__ res_a, const uint64_t *__restrict__ res_k,
+                                                     const uint32_t *__restrict__ occ, const uint64_t *__restrict__ occ_off, uint64_t n,
+                                                     uint64_t *__restrict__ rows, int2 *__restrict__ qbeg, uint32_t *__restrict__ score)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t s = 0;
+	uint64_t k = 0, off = 0;
+	int2 qb = make_int2(0, 0);
+	if (t < n) {
+		s = occ[t];
+		if (s) { res_t e = res_a[t]; k = res_k[t]; off = occ_off[t]; qb = make_int2((int)(e.be >> 16), (int)(e.be & 0xFFFF)); }
+	}
+	const uint32_t SMALL = 4;
+	if (s && s <= SMALL) {
+		for (uint32_t u = 0; u < s; ++u) { rows[off + u] = k + u; qbeg[off + u] = qb; score[off + u] = u ? 0u : s; }
+	}
+	unsigned long long big = __ballot(s > SMALL);
+	int lane = __lane_id();
+	while (big) {
+		int src = __ffsll((long long)big) - 1;
+		big &= big - 1;
+		uint32_t ss = __shfl(s, src);
+		uint64_t kk = __shfl(k, src), oo = __shfl(off, src);
+		int2 q2 = make_int2(__shfl(qb.x, src), __shfl(qb.y, src));
+		for (uint32_t u = lane; u < ss; u += 64) { rows[oo + u] = kk + u; qbeg[oo + u] = q2; score[oo + u] = u ? 0u : ss; }
+	}
+}
+
+// ---------------------------------------------------------------- locate
+
+__global__ void __launch_bounds__(256) locate_kernel(fmd_dev_t f, uint64_t *__restrict__ rows, uint64_t n)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	bool live = t < n;
+	uint64_t k = live ? rows[t] : 0, steps = 0, mask = (1ull << f.sa_shift) - 1;
+	bool act = live && (k & mask);
+	while (__any(act)) {
+		if (act) { k = fmd_inv_psi(f, k); ++steps; act = (k & mask) != 0; }
+	}
+	if (live) {
+		uint64_t idx = k >> f.sa_shift, pos;
+		if (idx == 0) pos = steps - 1;
+		else {
+			uint64_t hb = (f.sa_bits[idx >> 5] >> (idx & 31)) & 1u;
+			pos = ((uint64_t)f.sa[idx] | (hb << 32)) + steps;
+		}
+		rows[t] = pos;
+	}
+}
+
+// ---------------------------------------------------------------- host side
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
+
+struct bmh_seed_ws {
+	uint32_t max_reads; uint64_t max_bases, max_cands, max_occ;
+	uint32_t *pk, *nm;
+	uint32_t n_grp_cap;
+	cand_t *cand_a; uint64_t *cand_k;
+	res_t *res_a; uint64_t *res_k;
+	uint32_t *n_cand, *cand_base;       // [max_reads+1]
+	uint32_t *occ, *keep;               // [max_cands+1]
+	uint64_t *occ_off, *keep_off;       // [max_cands+1]
+	uint64_t *rows; int2 *qbeg; uint32_t *score;   // [max_occ]
+	uint32_t *n_ref_pos, *prefix;       // [max_reads]
+	unsigned long long *counter;
+	void *scan_tmp; size_t scan_tmp_bytes;
+	hipEvent_t ev[8];
+	float ms[7];
+};
+
+extern "C" bmh_seed_ws_t *bmh_seed_ws_create(uint32_t max_reads, uint64_t max_bases, uint64_t max_cands, uint64_t max_occ)
+{
+	if (max_reads == 0 || max_bases == 0) { bmh_set_error("bmh_seed_ws_create: empty capacity"); return nullptr; }
+	bmh_seed_ws *w = (bmh_seed_ws *)calloc(1, sizeof(bmh_seed_ws));
+	w->max_reads = max_reads; w->max_bases = max_bases;
+	w->max_cands = max_cands ? max_cands : (uint64_t)max_reads * 16 + max_bases * 2 / 5;
+	w->max_occ = max_occ ? max_occ : (uint64_t)max_reads * 64;
+	// packed-read buffers are sized by the longest read of a batch: allocated on first use
+	w->n_grp_cap = 0;
+	bool ok = true;
+#define A(p, n) ok = ok && hipMalloc((void **)&(p), (size_t)(n)) == hipSuccess
+	A(w->cand_a, sizeof(cand_t) * w->max_cands); A(w->cand_k, 8 * w->max_cands);
+	A(w->res_a, sizeof(res_t) * (w->max_cands + 1)); A(w->res_k, 8 * (w->max_cands + 1));
+	A(w->n_cand, 4 * ((size_t)max_reads + 1)); A(w->cand_base, 4 * ((size_t)max_reads + 1));
+	A(w->occ, 4 * (w->max_cands + 1)); A(w->keep, 4 * (w->max_cands + 1));
+	A(w->occ_off, 8 * (w->max_cands + 1)); A(w->keep_off, 8 * (w->max_cands + 1));
+	A(w->rows, 8 * w->max_occ); A(w->qbeg, 8 * w->max_occ); A(w->score, 4 * w->max_occ);
+	A(w->n_ref_pos, 4 * (size_t)max_reads); A(w->prefix, 4 * (size_t)max_reads);
+	A(w->counter, 16);
+	size_t t1 = 0, t2 = 0;
+	rocprim::exclusive_scan(nullptr, t1, w->n_cand, w->cand_base, 0u, (size_t)max_reads + 1, rocprim::plus<uint32_t>(), 0);
+	rocprim::exclusive_scan(nullptr, t2, w->occ, w->occ_off, (uint64_t)0, w->max_cands + 1, rocprim::plus<uint64_t>(), 0);
+	w->scan_tmp_bytes = t1 > t2 ? t1 : t2;
+	A(w->scan_tmp, w->scan_tmp_bytes + 256);
+#undef A
+	for (int i = 0; i < 8; ++i) ok = ok && hipEventCreate(&w->ev[i]) == hipSuccess;
+	if (!ok) { bmh_set_error("bmh_seed_ws_create: hipMalloc failed (%s)", hipGetErrorString(hipGetLastError())); bmh_seed_ws_free(w); return nullptr; }
+	return w;
+}
+
+extern "C" void bmh_seed_ws_free(bmh_seed_ws_t *w)
+{
+	if (!w) return;
+	void *ps[] = {w->pk, w->nm, w->cand_a, w->cand_k, w->res_a, w->res_k, w->n_cand, w->cand_base, w->occ, w->keep,
+	              w->occ_off, w->keep_off, w->rows, w->qbeg, w->score, w->n_ref_pos, w->prefix, w->counter, w->scan_tmp};
+	for (void *p : ps) if (p) (void)hipFree(p);
+	for (int i = 0; i < 8; ++i) if (w->ev[i]) (void)hipEventDestroy(w->ev[i]);
+	free(w);
+}
+
+extern "C" void bmh_seed_last_timing(const bmh_seed_ws_t *w, float ms[7]) { memcpy(ms, w->ms, sizeof(float) * 7); }
+
+static inline unsigned nblk(uint64_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
+
+extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs,
+                              const uint32_t *d_lens, uint32_t n_reads, int min_seed_len, void *stream_, bmh_seeds_t *out)
+{
+	if (!w || !idx || !out) { bmh_set_error("bmh_seed_batch: null argument"); return BMH_EINVAL; }
+	memset(out, 0, sizeof(*out));
+	if (n_reads > w->max_reads) { bmh_set_error("bmh_seed_batch: %u reads > workspace capacity %u", n_reads, w->max_reads); return BMH_ECAPACITY; }
+	if (min_seed_len < 1) { bmh_set_error("bmh_seed_batch: min_seed_len < 1"); return BMH_EINVAL; }
+	hipStream_t st = (hipStream_t)stream_;
+	out->d_rbeg = w->rows; out->d_qbeg = (const int32_t *)w->qbeg; out->d_score = w->score;
+	out->d_n_ref_pos = w->n_ref_pos; out->d_prefix = w->prefix;
+	memset(w->ms, 0, sizeof(w->ms));
+	if (n_reads == 0) return BMH_OK;
+	const fmd_dev_t &f = idx->dev;
+	// longest read -> packed geometry (host needs it; one small D2H reduce)
+	uint32_t max_len = 0;
+	{
+		uint32_t *d_max = (uint32_t *)w->counter + 2;
+		size_t tb = w->scan_tmp_bytes;
+		HIPCK(rocprim::reduce(w->scan_tmp, tb, d_lens, d_max, 0u, (size_t)n_reads, rocprim::maximum<uint32_t>(), st));
+		HIPCK(hipMemcpyAsync(&max_len, d_max, 4, hipMemcpyDeviceToHost, st));
+		HIPCK(hipStreamSynchronize(st));
+	}
+	if (max_len > 65535) { bmh_set_error("bmh_seed_batch: read longer than 65535 bases"); return BMH_EINVAL; }
+	uint32_t n_grp = (max_len + 31) / 32;
+	if (n_grp == 0) n_grp = 1;
+	if (n_grp > w->n_grp_cap) {     // grow the packed-read buffers (first batch, or a longer read length)
+		if (w->pk) (void)hipFree(w->pk);
+		if (w->nm) (void)hipFree(w->nm);
+		w->pk = w->nm = nullptr; w->n_grp_cap = 0;
+		HIPCK(hipMalloc((void **)&w->pk, (size_t)8 * n_grp * w->max_reads));
+		HIPCK(hipMalloc((void **)&w->nm, (size_t)4 * n_grp * w->max_reads));
+		w->n_grp_cap = n_grp;
+	}
+	read_view_t rv = {w->pk, w->nm, n_reads};
+
+	HIPCK(hipEventRecord(w->ev[0], st));
+	pack_reads_kernel<<<nblk((uint64_t)n_reads * n_grp, 256), 256, 0, st>>>(d_reads, d_offs, d_lens, n_reads, n_grp, w->pk, w->nm);
+	HIPCK(hipEventRecord(w->ev[1], st));
+	HIPCK(hipMemsetAsync(w->counter, 0, 8, st));
+	HIPCK(hipMemsetAsync(w->n_cand + n_reads, 0, 4, st));
+	smem_forward_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(f, rv, d_lens, min_seed_len, w->cand_a, w->cand_k, w->counter, w->max_cands, w->n_cand);
+	HIPCK(hipEventRecord(w->ev[2], st));
+	{
+		size_t tb = w->scan_tmp_bytes;
+		HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->n_cand, w->cand_base, 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
+	}
+	unsigned long long n_cands = 0;
+	HIPCK(hipMemcpyAsync(&n_cands, w->counter, 8, hipMemcpyDeviceToHost, st));
+	HIPCK(hipStreamSynchronize(st));
+	out->n_cands = n_cands;
+	if (n_cands > w->max_cands) { bmh_set_error("bmh_seed_batch: %llu candidates > capacity %llu", n_cands, (unsigned long long)w->max_cands); return BMH_ECAPACITY; }
+	if (n_cands)
+		smem_backward_kernel<<<nblk(n_cands, 256), 256, 0, st>>>(f, rv, w->cand_a, w->cand_k, n_cands, w->cand_base, min_seed_len, w->res_a, w->res_k);
+	HIPCK(hipEventRecord(w->ev[3], st));
+	smem_filter_kernel<<<nblk(n_cands + 1, 256), 256, 0, st>>>(w->res_a, n_cands, w->occ, w->keep);
+	{
+		size_t tb = w->scan_tmp_bytes;
+		HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->occ, w->occ_off, (uint64_t)0, (size_t)n_cands + 1, rocprim::plus<uint64_t>(), st));
+		tb = w->scan_tmp_bytes;
+		HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->keep, w->keep_off, (uint64_t)0, (size_t)n_cands + 1, rocprim::plus<uint64_t>(), st));
+	}
+	uint64_t tot[2] = {0, 0};
+	HIPCK(hipMemcpyAsync(&tot[0], w->occ_off + n_cands, 8, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(&tot[1], w->keep_off + n_cands, 8, hipMemcpyDeviceToHost, st));
+	HIPCK(hipStreamSynchronize(st));
+	out->n_seeds = tot[0]; out->n_smems = tot[1];
+	if (tot[0] > w->max_occ) { bmh_set_error("bmh_seed_batch: %llu occurrences > capacity %llu", (unsigned long long)tot[0], (unsigned long long)w->max_occ); return BMH_ECAPACITY; }
+	if (tot[0] >> 32) { bmh_set_error("bmh_seed_batch: more than 2^32 occurrences in one batch"); return BMH_ECAPACITY; }
+	per_read_counts_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(w->cand_base, w->occ_off, n_reads, w->n_ref_pos, w->prefix);
+	HIPCK(hipEventRecord(w->ev[4], st));
+	if (n_cands)
+		expand_kernel<<<nblk(n_cands, 256), 256, 0, st>>>(w->res_a, w->res_k, w->occ, w->occ_off, n_cands, w->rows, w->qbeg, w->score);
+	HIPCK(hipEventRecord(w->ev[5], st));
+	if (tot[0])
+		locate_kernel<<<nblk(tot[0], 256), 256, 0, st>>>(f, w->rows, tot[0]);
+	HIPCK(hipEventRecord(w->ev[6], st));
+	HIPCK(hipStreamSynchronize(st));
+	HIPCK(hipGetLastError());
+	for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&w->ms[i], w->ev[i], w->ev[i + 1]);
+	(void)hipEventElapsedTime(&w->ms[6], w->ev[0], w->ev[6]);
+	return BMH_OK;
+}

@@ -1,0 +1,119 @@
+/*
+ * include/bwamem_hip.h -- device-level C ABI of the MI355X seed-and-extend library
+ * (libbwamem_hip.so).  Plain pointers and sizes only; every pointer named d_* is a
+ * device (HBM) pointer, everything else is host memory.
+ *
+ * This is the layer the reference-compatible entry points are built on:
+ *   include/seed_gen.h   (replaces /root/reference/src/GPUSeed/seed_gen.h:92-106)
+ *   include/gasal_ext.h  (replaces the GASAL2 calls of /root/reference/src/bwamem.c:1102-1167,
+ *                         2106-2211 and src/fastmap.c:417-534)
+ * and the layer bench.py / the multi-GPU launcher use so that inputs are already
+ * resident in HBM when timing starts.
+ *
+ * Error behaviour: functions returning int return 0 on success and a negative
+ * BMH_E* code on failure; bmh_last_error() gives the message.  Nothing here
+ * falls back to a CPU implementation: without a HIP device every call fails.
+ */
+#ifndef BWAMEM_HIP_H
+#define BWAMEM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMH_OK          0
+#define BMH_ENODEV     -1   /* no HIP device / HIP runtime error */
+#define BMH_EINVAL     -2   /* bad argument */
+#define BMH_ECAPACITY  -3   /* a workspace capacity was exceeded (reference: exit(), seed_gen.cu:2037-2042) */
+#define BMH_ENOMEM     -4
+
+const char *bmh_last_error(void);
+int bmh_device_count(void);
+int bmh_set_device(int dev);
+
+/* ------------------------------------------------------------------ index */
+
+/* FMD index resident in HBM.  Layout = the reference's GPU layout
+ * (seed_gen.cu:28-48; seed_gen.h:21-33 bwt_t_gpu). */
+typedef struct bmh_index bmh_index_t;
+
+/* host arrays -> HBM (replaces gpu_cpy_wrapper, seed_gen.cu:1524-1556).
+ * bwt_words: interleaved occ/bwt blocks, n_words u32; sa: n_sa u32 samples with
+ * sa[0] ignored; sa_bits: n_sa/32+1 words; pac (optional, may be NULL): 2-bit
+ * forward strand, l_pac bases. */
+bmh_index_t *bmh_index_upload(uint64_t primary, const uint64_t L2[5], uint64_t seq_len,
+                              const uint32_t *bwt_words, uint64_t n_words, int sa_intv,
+                              const uint32_t *sa, uint64_t n_sa, const uint32_t *sa_bits,
+                              const uint8_t *pac, uint64_t l_pac);
+/* wrap arrays that already live in HBM (e.g. received by an RCCL broadcast);
+ * the index does not own them. */
+bmh_index_t *bmh_index_from_device(uint64_t primary, const uint64_t L2[5], uint64_t seq_len,
+                                   const uint32_t *d_bwt_words, uint64_t n_words, int sa_intv,
+                                   const uint32_t *d_sa, uint64_t n_sa, const uint32_t *d_sa_bits,
+                                   const uint8_t *d_pac, uint64_t l_pac);
+void bmh_index_free(bmh_index_t *idx);
+
+/* ---------------------------------------------------------------- seeding */
+
+/* Workspace for batches of up to max_reads reads / max_bases bases.
+ * max_cands bounds SMEM candidates per batch, max_occ bounds located
+ * occurrences per batch (0 = defaults: 16 per read + 0.4 per base, 64 per read;
+ * the hard upper bound on candidates is one per base). */
+typedef struct bmh_seed_ws bmh_seed_ws_t;
+bmh_seed_ws_t *bmh_seed_ws_create(uint32_t max_reads, uint64_t max_bases, uint64_t max_cands, uint64_t max_occ);
+void bmh_seed_ws_free(bmh_seed_ws_t *ws);
+
+/* Seeds of one batch, in HBM, in the reference's mem_seed_v_gpu layout
+ * (seed_gen.h:68-75): per read SMEMs by end ascending, occurrences by SA row
+ * ascending; score = #occurrences at the first slot of each SMEM group, 0 in
+ * the others.  Pointers stay valid until the next call on the same workspace. */
+typedef struct {
+	uint64_t n_seeds;            /* located occurrences in the batch */
+	uint64_t n_smems;            /* SMEM groups */
+	uint64_t n_cands;            /* forward candidates examined */
+	const uint64_t *d_rbeg;      /* [n_seeds] position in the fwd+revcomp text */
+	const int32_t *d_qbeg;       /* [n_seeds][2] = {begin, end} in the read */
+	const uint32_t *d_score;     /* [n_seeds] */
+	const uint32_t *d_n_ref_pos; /* [n_reads] occurrences per read */
+	const uint32_t *d_prefix;    /* [n_reads] exclusive scan of d_n_ref_pos */
+} bmh_seeds_t;
+
+/* d_reads: ASCII bases of all reads back to back (no separators), d_offs/d_lens
+ * per read (what the reference copies to the GPU, seed_gen.cu:1841-1843).
+ * stream: a hipStream_t (NULL = default stream).  Synchronises the stream. */
+int bmh_seed_batch(bmh_seed_ws_t *ws, const bmh_index_t *idx, const uint8_t *d_reads,
+                   const uint32_t *d_offs, const uint32_t *d_lens, uint32_t n_reads,
+                   int min_seed_len, void *stream, bmh_seeds_t *out);
+
+/* per-kernel time of the last bmh_seed_batch, in ms (HIP events on the launch stream):
+ * [0]=pack [1]=forward [2]=backward [3]=filter+scans [4]=expand [5]=locate [6]=total */
+void bmh_seed_last_timing(const bmh_seed_ws_t *ws, float ms[7]);
+
+/* -------------------------------------------------------------- extension */
+
+/* Scoring of ksw_extend2 (src/ksw.c:864) as used by the GPU pipeline
+ * (src/bwamem.c:1887-1890): mat[i][j] = a / -b / -1 against code 4
+ * (src/bwa.c:99-108), affine gaps, end_bonus = pen_clip5, zdrop (0 = off). */
+typedef struct {
+	int a, b;
+	int o_del, e_del, o_ins, e_ins;
+	int zdrop, end_bonus;
+} bmh_ext_params_t;
+
+/* n extensions: query/target bases are codes 0..4, one byte per base, at
+ * d_q + d_qoff[i] (d_qlen[i] bases) and d_t + d_toff[i] (d_tlen[i]);
+ * d_h0[i] = seed score.  Results (src/bwamem.c:1893-1901 rule applied):
+ * d_out[3*i+0..2] = {aln_score, query_end, target_end}; if d_raw != NULL also
+ * d_raw[6*i..] = {score, qle, tle, gtle, gscore, max_off} of ksw_extend2.
+ * Asynchronous on stream. */
+int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, const uint32_t *d_qlen,
+                     const uint8_t *d_t, const uint32_t *d_toff, const uint32_t *d_tlen,
+                     const uint32_t *d_h0, uint32_t n, const bmh_ext_params_t *p,
+                     int32_t *d_out, int32_t *d_raw, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

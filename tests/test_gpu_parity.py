@@ -1,0 +1,124 @@
+"""GPU parity tests proper: HIP kernels (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    import bwamem_hip as B
+    B.load_library()           # raises if the HIP extension is missing: no fallback
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return B
+
+
+def _to_dev(torch, a, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dt is not None:
+        t = t.view(dt) if t.dtype.itemsize == torch.empty(0, dtype=dt).element_size() else t.to(dt)
+    return t.cuda()
+
+
+def gpu_seed(B, idx, flat, offs, lens, min_seed_len=19):
+    import torch
+    from bwamem_hip.lib import seeds_to_host
+    from bwamem_hip import synth
+    ascii_ = synth.codes_to_ascii(flat) if flat.size else np.zeros(1, np.uint8)
+    dindex = B.Index.upload(idx)
+    ws = B.SeedWorkspace(max(len(lens), 1), max(int(flat.size), 1), max_cands=max(int(flat.size), 64), max_occ=1 << 22)
+    r = _to_dev(torch, ascii_)
+    o = torch.from_numpy(offs.astype(np.int64)).to(torch.int32).cuda()
+    l = torch.from_numpy(lens.astype(np.int64)).to(torch.int32).cuda()
+    s = ws.seed_batch(dindex, r, o, l, min_seed_len)
+    out = seeds_to_host(s, len(lens))
+    out["n_smems"] = int(s.n_smems)
+    ws.free(); dindex.free()
+    return out
+
+
+def test_seeding_matches_oracle_150bp(hip, oracle):
+    g, idx = common.genome_and_index(300_000)
+    reads, _ = hip.synth.make_reads(g, 4000, 150, seed=11)
+    flat, offs, lens = common.flat_reads(reads)
+    want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
+    got = gpu_seed(hip, idx, flat, offs, lens)
+    assert got["n_smems"] == len(want["smem_k"])
+    common.assert_seeds_equal(got, want)
+
+
+def test_seeding_edge_cases(hip, oracle):
+    g, idx = common.genome_and_index(300_000)
+    rows = common.edge_reads(g, np.random.default_rng(3))
+    flat, offs, lens = common.ragged_reads(rows)
+    want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
+    got = gpu_seed(hip, idx, flat, offs, lens)
+    common.assert_seeds_equal(got, want)
+
+
+def test_seeding_300bp_and_other_k(hip, oracle):
+    g, idx = common.genome_and_index(300_000)
+    reads, _ = hip.synth.make_reads(g, 1500, 300, seed=12)
+    flat, offs, lens = common.flat_reads(reads)
+    for k in (19, 25, 12):
+        want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens, min_seed_len=k)
+        got = gpu_seed(hip, idx, flat, offs, lens, min_seed_len=k)
+        common.assert_seeds_equal(got, want, what=f"k={k} ")
+
+
+def test_seeding_odd_genome_length(hip, oracle):
+    g, idx = common.genome_and_index(100_003, seed=5)
+    reads, _ = hip.synth.make_reads(g, 1000, 101, seed=13)
+    flat, offs, lens = common.flat_reads(reads)
+    want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
+    got = gpu_seed(hip, idx, flat, offs, lens)
+    common.assert_seeds_equal(got, want)
+
+
+def gpu_extend(B, jobs, zdrop=0, want_raw=True):
+    import torch
+    q, qoff, qlen, t, toff, tlen, h0 = jobs
+    n = len(qlen)
+    d = [torch.from_numpy(np.ascontiguousarray(x).astype(np.int64) if x.dtype == np.uint32 else np.ascontiguousarray(x)) for x in (q, qoff, qlen, t, toff, tlen, h0)]
+    d = [x.to(torch.int32).cuda() if x.dtype == torch.int64 else x.cuda() for x in d]
+    out = torch.zeros(n, 3, dtype=torch.int32, device="cuda")
+    raw = torch.zeros(n, 6, dtype=torch.int32, device="cuda") if want_raw else None
+    B.extend_batch(*d, out, params=B.ExtParams.default(zdrop=zdrop), raw_t=raw)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), raw.cpu().numpy() if want_raw else None
+
+
+@pytest.mark.parametrize("zdrop", [0, 100])
+def test_extension_matches_oracle(hip, oracle, zdrop):
+    import oracle_py
+    jobs = common.make_ext_jobs(6000, np.random.default_rng(21))
+    want3, want6, _ = oracle.extend_batch(*jobs, params=oracle_py.default_params(zdrop=zdrop), want_raw=True)
+    got3, got6 = gpu_extend(hip, jobs, zdrop=zdrop)
+    bad = np.nonzero((got6 != want6).any(1))[0]
+    assert bad.size == 0, f"{bad.size} raw mismatches, first {bad[:5]}: got {got6[bad[:5]]} want {want6[bad[:5]]} qlen {jobs[2][bad[:5]]} tlen {jobs[5][bad[:5]]}"
+    assert np.array_equal(got3, want3)
+
+
+def test_extension_long_queries(hip, oracle):
+    jobs = common.make_ext_jobs(600, np.random.default_rng(22), maxq=512)
+    want3, want6, _ = oracle.extend_batch(*jobs, want_raw=True)
+    got3, got6 = gpu_extend(hip, jobs)
+    assert np.array_equal(got6, want6) and np.array_equal(got3, want3)
+
+
+def test_seed_gpu_file_api(hip, oracle, tmp_path):
+    """The reference's own call sequence (fastmap.c:436-465) through include/seed_gen.h."""
+    from bwamem_hip import fmindex, synth
+    g, idx = common.genome_and_index(300_000)
+    prefix = str(tmp_path / "ref.fa")
+    fmindex.write_index(prefix, idx)
+    reads, _ = synth.make_reads(g, 2500, 150, seed=14)
+    fq = str(tmp_path / "reads.fa")
+    synth.write_fasta_reads(fq, reads)
+    got = hip.seed_file(prefix, fq, 19)
+    flat, offs, lens = common.flat_reads(reads)
+    want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
+    common.assert_seeds_equal(got, want)

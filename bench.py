@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- seed-and-extend hot path on MI355X: Mreads/s, roofline and CPU baseline.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 launched by
+torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+  1 M synthetic 150 bp single-end reads per GPU against a seeded synthetic genome standing in
+  for hg38 (no network, no hg38 on the box; see DESIGN.md "workload").  A step = one pass of the
+  hot path over the batch: SMEM seeding (pack, forward, backward, filter, expand, locate kernels)
+  + seed extension (ksw_extend2 kernel) of the batch's extension jobs.  Reads, index and
+  extension jobs are resident in HBM when the timed region starts.
+Multi-GPU: reads shard across ranks (weak scaling: READS_PER_GPU per rank); rank 0 builds the
+index and broadcasts it over RCCL once, outside the timed region; no data-path collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import bwamem_hip as B  # noqa: E402
+from bwamem_hip import pipeline as P  # noqa: E402
+from bwamem_hip.parallel import broadcast_index, shard_range  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(g, idx, reads, sample: int, n_threads: int):
+    """Oracle (our C restatement of the reference CPU path, parity-pinned to the compiled
+    reference) timed on the host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_py
+    orc = oracle_py.Oracle()
+    f = orc.fmd(idx)
+    sub = reads[:sample]
+    L = sub.shape[1]
+    flat = sub.reshape(-1)
+    offs = np.arange(sub.shape[0], dtype=np.uint64) * L
+    lens = np.full(sub.shape[0], L, np.uint32)
+    t0 = time.time()
+    s = orc.seed_reads(f, flat, offs, lens, 19, n_threads=n_threads)
+    t_seed = time.time() - t0
+    # the same first-seed extension jobs as the GPU leg, built on the CPU from the oracle's seeds
+    dev = torch.device("cpu")
+    seeds = {k: torch.from_numpy(s[k].astype(np.int64) if s[k].dtype in (np.uint64, np.uint32) else s[k]) for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")}
+    seeds["qbeg"] = seeds["qbeg"].to(torch.int32); seeds["score"] = seeds["score"].to(torch.int32)
+    dr = P.DeviceReads(None, None, torch.from_numpy(lens.astype(np.int32)), torch.from_numpy(np.ascontiguousarray(sub)))
+    jobs = P.first_seed_jobs(seeds, dr, torch.from_numpy(g))
+    arr = [x.numpy().astype(np.uint32) if x.dtype == torch.int32 else x.numpy() for x in (jobs.q, jobs.qoff, jobs.qlen, jobs.t, jobs.toff, jobs.tlen, jobs.h0)]
+    t0 = time.time()
+    _, _, cells = orc.extend_batch(*arr, n_threads=n_threads)
+    t_ext = time.time() - t0
+    return dict(t_seed=t_seed, t_ext=t_ext, n=sub.shape[0], work=s["work"], cells=cells, n_jobs=jobs.n,
+                n_seeds=int(len(s["rbeg"])))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("BENCH_GENOME_MBP", "1000")))
+    ap.add_argument("--reads-per-gpu", type=int, default=int(os.environ.get("BENCH_READS_PER_GPU", "1000000")))
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BENCH_CPU_SAMPLE", "200000")))
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE {world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B.load_library().bmh_set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    # ---------------- setup (untimed): genome, index (rank 0) -> RCCL broadcast, reads shard, jobs
+    n_genome = int(a.genome_mbp * 1e6)
+    g = B.synth.make_genome(n_genome, seed=42)            # every rank regenerates the same genome
+    idx = None
+    t0 = time.time()
+    if rank == 0:
+        idx = B.fmindex.build_fmd_index(g, device=str(dev))
+    t_index = time.time() - t0
+    torch.cuda.empty_cache()
+    hdr, bwt_t, sa_t, bits_t = broadcast_index(idx, dev, src=0, world=world)
+    dindex = B.Index.from_device(hdr["primary"], hdr["L2"], hdr["seq_len"], bwt_t, hdr["sa_intv"], sa_t, bits_t)
+    lo, hi = shard_range(a.reads_per_gpu * world, rank, world)
+    reads, _ = B.synth.make_reads(g, hi - lo, a.read_len, seed=7 + rank)
+    dr = P.reads_to_device(reads, dev)
+    n_reads = dr.n
+    ws = B.SeedWorkspace(n_reads, n_reads * a.read_len)
+    s = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19)
+    seeds = P.seeds_to_torch(s, n_reads, dev)
+    gdev = torch.from_numpy(g).to(dev)
+    jobs = P.first_seed_jobs(seeds, dr, gdev)
+    del gdev, seeds
+    out = torch.zeros(max(jobs.n, 1), 3, dtype=torch.int32, device=dev)
+    params = B.ExtParams.default()
+    L = B.load_library()
+
+    def step():
+        ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19)
+        B.extend_batch(jobs.q, jobs.qoff, jobs.qlen, jobs.t, jobs.toff, jobs.tlen, jobs.h0, out, params=params)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stage_ms = {}
+    for _ in range(a.steps):
+        step()
+        tm = ws.timing()                       # HIP events on the launch stream, per stage
+        tm["extend"] = L.bmh_extend_last_ms()  # idem for the DP kernels (waits for them)
+        for k, v in tm.items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        tot = torch.tensor([n_reads], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        total_reads = int(tot.item())
+    else:
+        total_reads = n_reads
+    stage_ms = {k: v / a.steps for k, v in stage_ms.items()}
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = total_reads * a.steps / dt / 1e6
+        res = {
+            "metric": "Mreads/s (150 bp single-end seed-and-extend hot path)", "value": round(value, 3), "unit": "Mreads/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"{a.reads_per_gpu} synthetic {a.read_len} bp single-end reads per GPU vs seeded synthetic "
+                                   f"{a.genome_mbp:g} Mbp genome (hg38 stand-in: uniform + 10% diverged repeat families); "
+                                   "seeding = all SMEMs >= 19 bp + locate; extension = left/right jobs of each read's longest seed",
+                       "reads_per_gpu": n_reads, "read_len": a.read_len, "genome_mbp": a.genome_mbp,
+                       "index_bytes": int(bwt_t.numel() * 4 + sa_t.numel() * 4 + bits_t.numel() * 4),
+                       "ext_jobs_per_gpu": jobs.n, "seeds_per_gpu": int(s.n_seeds), "min_seed_len": 19,
+                       "scoring": "a1 b4 o6 e1 clip5 zdrop0", "index_build_s": round(t_index, 2)},
+            "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+        }
+        # ---------------- CPU baseline + roofline of the dominant kernel (N = 1 only)
+        if world == 1:
+            ncores = os.cpu_count() or 1
+            cb = cpu_baseline(g, idx, reads, min(a.cpu_sample, n_reads), ncores)
+            cpu_mreads = cb["n"] / (cb["t_seed"] + cb["t_ext"]) / 1e6
+            res["cpu_baseline"] = {"value": round(cpu_mreads, 5), "unit": "Mreads/s", "cores": ncores, "kind": "port",
+                                   "sample": f"first {cb['n']} reads of the same batch: oracle seeding {cb['t_seed']:.2f}s + "
+                                             f"oracle extension {cb['t_ext']:.2f}s on {ncores} threads"}
+            res["speedup_vs_cpu_baseline"] = round(value / cpu_mreads, 1)
+            # algorithmic bytes per read, counted by the oracle on the sample
+            wk, n = cb["work"], cb["n"]
+            per_read = {
+                "forward": 32.0 * wk["n_blk_fwd"] / n + a.read_len / 4 + 8,
+                "backward": 32.0 * wk["n_blk_back"] / n,
+                "locate": (32.0 * wk["n_blk_lf"] + 4.0 * wk["n_sa"] + 20.0 * cb["n_seeds"]) / n,
+            }
+            q, t = jobs.qlen.long(), jobs.tlen.long()
+            ext_bytes = float(((q + 3) // 4 + (t + 3) // 4 + (q + t + 7) // 8 + 28).sum().item())
+            kernel_bytes = {k: v * n_reads for k, v in per_read.items()}
+            kernel_bytes["extend"] = ext_bytes
+            dom = max(kernel_bytes.keys(), key=lambda k: stage_ms.get(k, 0.0))
+            ach = kernel_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9
+            res["roofline"] = {"bound": "hbm", "kernel": {"forward": "smem_forward_kernel", "backward": "smem_backward_kernel",
+                                                           "locate": "locate_kernel", "extend": "extend_kernel<1>"}[dom],
+                               "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                               "traffic": None, "avg_ms": round(stage_ms[dom], 3),
+                               "algorithmic_bytes_per_launch": int(kernel_bytes[dom])}
+            res["roofline_all"] = {k: {"ms": round(stage_ms[k], 3), "algorithmic_GBps": round(kernel_bytes[k] / (stage_ms[k] * 1e-3) / 1e9, 2)}
+                                   for k in kernel_bytes}
+            res["extension_gcups"] = round(cb["cells"] / cb["n_jobs"] * jobs.n / (stage_ms["extend"] * 1e-3) / 1e9, 1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -208,8 +208,18 @@ __global__ void __launch_bounds__(256) ext_bin_kernel(const uint32_t *__restrict
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
 
 // per-stream scratch for the class lists (grown on demand, reused across calls)
-struct ext_scratch_t { uint32_t *ids; uint32_t *counts; size_t cap; int dev; };
-static thread_local ext_scratch_t g_scr = {nullptr, nullptr, 0, -1};
+struct ext_scratch_t { uint32_t *ids; uint32_t *counts; size_t cap; int dev; hipEvent_t ev0, ev1; bool have_ev; };
+static thread_local ext_scratch_t g_scr = {nullptr, nullptr, 0, -1, nullptr, nullptr, false};
+
+// device time of the DP kernels of the last bmh_extend_batch on this thread (HIP events on its stream)
+extern "C" float bmh_extend_last_ms(void)
+{
+	if (!g_scr.have_ev) return -1.f;
+	float ms = -1.f;
+	if (hipEventSynchronize(g_scr.ev1) != hipSuccess) return -1.f;
+	if (hipEventElapsedTime(&ms, g_scr.ev0, g_scr.ev1) != hipSuccess) return -1.f;
+	return ms;
+}
 
 template <int C>
 static void launch_class(const ext_args_t &base, uint32_t n, hipStream_t st, unsigned grid)
@@ -238,6 +248,7 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 		HIPCK(hipMalloc((void **)&g_scr.counts, sizeof(uint32_t) * 16));
 		g_scr.cap = n; g_scr.dev = dev;
 	}
+	if (!g_scr.have_ev) { HIPCK(hipEventCreate(&g_scr.ev0)); HIPCK(hipEventCreate(&g_scr.ev1)); g_scr.have_ev = true; }
 	HIPCK(hipMemsetAsync(g_scr.counts, 0, sizeof(uint32_t) * 16, st));
 	ext_bin_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_qlen, n, g_scr.ids, g_scr.counts, d_out);
 	ext_args_t a;
@@ -246,6 +257,7 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 	a.a = p->a; a.b = p->b; a.o_del = p->o_del; a.e_del = p->e_del; a.o_ins = p->o_ins; a.e_ins = p->e_ins;
 	a.zdrop = p->zdrop; a.end_bonus = p->end_bonus;
 	// one wave per alignment, 4 per block; waves stride over their class list
+	HIPCK(hipEventRecord(g_scr.ev0, st));
 	unsigned grid = (unsigned)((n + 3) / 4);
 	const unsigned max_grid = 256 * 8;
 	if (grid > max_grid) grid = max_grid;
@@ -256,6 +268,7 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 		launch_class<4>(a, n, st, grid); launch_class<5>(a, n, st, grid); launch_class<6>(a, n, st, grid);
 		launch_class<7>(a, n, st, grid); launch_class<8>(a, n, st, grid);
 	}
+	HIPCK(hipEventRecord(g_scr.ev1, st));
 	HIPCK(hipGetLastError());
 	return BMH_OK;
 }

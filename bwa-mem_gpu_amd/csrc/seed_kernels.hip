@@ -85,21 +85,42 @@ __global__ void __launch_bounds__(256) pack_reads_kernel(const uint8_t *__restri
 
 struct cand_t { uint32_t read, xe, j, s; };   // xe = start<<16 | end
 
-// append one candidate per active lane with a single atomic per wave
+// Candidate list appends.  A single global counter bumped once per wave per append round
+// saturates (one word takes ~90 atomics/us on this chip), so each wave reserves CHUNK
+// slots at a time with one atomic and hands them out with a wave-uniform cursor and a
+// ballot prefix; the unused tail of a chunk is filled with invalid entries
+// (read == CAND_INVALID) that the backward kernel skips.
+#define CAND_CHUNK 1024u
+#define CAND_INVALID 0xFFFFFFFFu
+
+struct cand_cursor_t { unsigned long long cur, end; };   // wave-uniform
+
+__device__ __forceinline__ void cand_fill_invalid(const cand_cursor_t &cc, cand_t *out_a, uint64_t cap)
+{
+	const int lane = __lane_id();
+	for (unsigned long long p = cc.cur + lane; p < cc.end; p += 64)
+		if (p < cap) { cand_t inv = {CAND_INVALID, 0, 0, 0}; out_a[p] = inv; }
+}
+
 __device__ __forceinline__ void cand_append(bool want, const cand_t &c, uint64_t k, cand_t *out_a, uint64_t *out_k,
-                                            unsigned long long *counter, uint64_t cap)
+                                            unsigned long long *counter, uint64_t cap, cand_cursor_t &cc)
 {
 	unsigned long long mask = __ballot(want);
 	if (!mask) return;
-	int lane = __lane_id();
-	int leader = __ffsll((long long)mask) - 1;
-	unsigned long long base = 0;
-	if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(mask));
-	base = __shfl(base, leader);
+	const int lane = __lane_id();
+	const unsigned n = (unsigned)__popcll(mask);
+	if (cc.cur + n > cc.end) {                 // wave-uniform branch: take a fresh chunk
+		cand_fill_invalid(cc, out_a, cap);
+		unsigned long long base = 0;
+		if (lane == 0) base = atomicAdd(counter, (unsigned long long)CAND_CHUNK);
+		cc.cur = __shfl(base, 0);
+		cc.end = cc.cur + CAND_CHUNK;
+	}
 	if (want) {
-		uint64_t pos = base + __popcll(mask & ((1ull << lane) - 1));
+		uint64_t pos = cc.cur + __popcll(mask & ((1ull << lane) - 1));
 		if (pos < cap) { out_a[pos] = c; out_k[pos] = k; }
 	}
+	cc.cur += n;
 }
 
 __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_view_t rv, const uint32_t *__restrict__ lens,
@@ -116,6 +137,7 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 	// lanes of a wave stay convergent on the loads
 	enum { ST_START, ST_EXT, ST_DONE, ST_TAIL };
 	int st = live && len > 0 ? ST_START : ST_DONE;
+	cand_cursor_t cc = {0, 0};
 	while (__any(st != ST_DONE)) {
 		bool want = false;
 		cand_t c = {r, 0, 0, 0};
@@ -171,8 +193,9 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 			st = ST_DONE;
 		}
 		if (want) ++j;
-		cand_append(want, c, ck, out_a, out_k, counter, cap);
+		cand_append(want, c, ck, out_a, out_k, counter, cap, cc);
 	}
+	cand_fill_invalid(cc, out_a, cap);
 	if (live) n_cand[r] = j;
 }
 
@@ -189,7 +212,8 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 	bool live = t < n_cands;
 	cand_t c = {0, 0, 0, 0};
 	uint64_t lo = 0, hi = 0;
-	if (live) { c = in_a[t]; lo = in_k[t]; hi = lo + c.s - 1; }
+	if (live) { c = in_a[t]; live = c.read != CAND_INVALID; }
+	if (live) { lo = in_k[t]; hi = lo + c.s - 1; }
 	int x = (int)(c.xe >> 16), end = (int)(c.xe & 0xFFFF);
 	int i = x - 1, beg = x;
 	bool act = live && i >= 0;
@@ -327,6 +351,7 @@ extern "C" bmh_seed_ws_t *bmh_seed_ws_create(uint32_t max_reads, uint64_t max_ba
 	bmh_seed_ws *w = (bmh_seed_ws *)calloc(1, sizeof(bmh_seed_ws));
 	w->max_reads = max_reads; w->max_bases = max_bases;
 	w->max_cands = max_cands ? max_cands : (uint64_t)max_reads * 16 + max_bases * 2 / 5;
+	w->max_cands += ((uint64_t)max_reads / 64 + 1) * (CAND_CHUNK + 64);   // chunked appends: one open chunk per wave
 	w->max_occ = max_occ ? max_occ : (uint64_t)max_reads * 64;
 	// packed-read buffers are sized by the longest read of a batch: allocated on first use
 	w->n_grp_cap = 0;
@@ -411,13 +436,16 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 		size_t tb = w->scan_tmp_bytes;
 		HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->n_cand, w->cand_base, 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
 	}
-	unsigned long long n_cands = 0;
-	HIPCK(hipMemcpyAsync(&n_cands, w->counter, 8, hipMemcpyDeviceToHost, st));
+	unsigned long long n_list = 0;     // slots handed out in the candidate list (chunks, incl. invalid fillers)
+	uint32_t n_cands32 = 0;            // true number of candidates = size of the (read, ordinal)-sorted result array
+	HIPCK(hipMemcpyAsync(&n_list, w->counter, 8, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(&n_cands32, w->cand_base + n_reads, 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));
+	const unsigned long long n_cands = n_cands32;
 	out->n_cands = n_cands;
-	if (n_cands > w->max_cands) { bmh_set_error("bmh_seed_batch: %llu candidates > capacity %llu", n_cands, (unsigned long long)w->max_cands); return BMH_ECAPACITY; }
-	if (n_cands)
-		smem_backward_kernel<<<nblk(n_cands, 256), 256, 0, st>>>(f, rv, w->cand_a, w->cand_k, n_cands, w->cand_base, min_seed_len, w->res_a, w->res_k);
+	if (n_list > w->max_cands) { bmh_set_error("bmh_seed_batch: %llu candidate slots > capacity %llu", n_list, (unsigned long long)w->max_cands); return BMH_ECAPACITY; }
+	if (n_list)
+		smem_backward_kernel<<<nblk(n_list, 256), 256, 0, st>>>(f, rv, w->cand_a, w->cand_k, n_list, w->cand_base, min_seed_len, w->res_a, w->res_k);
 	HIPCK(hipEventRecord(w->ev[3], st));
 	smem_filter_kernel<<<nblk(n_cands + 1, 256), 256, 0, st>>>(w->res_a, n_cands, w->occ, w->keep);
 	{

@@ -113,6 +113,10 @@ int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, const uint32_t 
                      const uint32_t *d_h0, uint32_t n, const bmh_ext_params_t *p,
                      int32_t *d_out, int32_t *d_raw, void *stream);
 
+/* device time in ms of the DP kernels launched by the calling thread's last
+ * bmh_extend_batch (HIP events on that call's stream; waits for them). */
+float bmh_extend_last_ms(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,7 +77,7 @@ static void bi_extend(const fmd_t *f, const bi_t *ik, bi_t ok[4], int is_back, f
 	uint64_t lo = ik->x[a] - 1, hi = ik->x[a] - 1 + ik->x[2];
 	fmd_occ4(f, lo, tk);
 	fmd_occ4(f, hi, tl);
-	if (w) w->n_blk += pair_blocks(f, lo, hi);
+	if (w) { int nb = pair_blocks(f, lo, hi); w->n_blk += nb; if (is_back) w->n_blk_back += nb; else w->n_blk_fwd += nb; }
 	for (c = 0; c < 4; ++c) {
 		ok[c].x[a] = f->L2[c] + 1 + tk[c];
 		ok[c].x[2] = tl[c] - tk[c];
@@ -173,7 +173,7 @@ uint64_t fmd_sa(const fmd_t *f, uint64_t k, fmd_work_t *w)
 	uint64_t steps = 0, mask = (uint64_t)f->sa_intv - 1;
 	while (k & mask) {
 		++steps;
-		if (w && k != f->primary) w->n_blk++;
+		if (w && k != f->primary) { w->n_blk++; w->n_blk_lf++; }
 		k = fmd_inv_psi(f, k);
 	}
 	if (w) { w->n_lf_steps += steps; w->n_sa++; }
@@ -283,6 +283,7 @@ oracle_seeds_t *oracle_seed_reads(const fmd_t *f, const uint8_t *reads, const ui
 		o->work.n_blk += j->work.n_blk; o->work.n_sa += j->work.n_sa;
 		o->work.n_fwd_steps += j->work.n_fwd_steps; o->work.n_back_steps += j->work.n_back_steps;
 		o->work.n_lf_steps += j->work.n_lf_steps;
+		o->work.n_blk_fwd += j->work.n_blk_fwd; o->work.n_blk_back += j->work.n_blk_back; o->work.n_blk_lf += j->work.n_blk_lf;
 		free(j->sm.k); free(j->sm.s); free(j->sm.qb); free(j->sm.qe); free(j->sm.rd); free(j->rbeg);
 	}
 	uint32_t acc = 0;

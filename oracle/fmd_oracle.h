@@ -38,6 +38,7 @@ typedef struct {
 	uint64_t n_blk;      /* 32-byte index blocks the algorithm must touch */
 	uint64_t n_sa;       /* located occurrences (one SA sample each) */
 	uint64_t n_fwd_steps, n_back_steps, n_lf_steps;
+	uint64_t n_blk_fwd, n_blk_back, n_blk_lf;   /* n_blk split by phase */
 } fmd_work_t;
 
 /* Occ(k,c) on the full (seq_len+1)-row matrix; reference src/bwt.c:235-261

@@ -30,7 +30,7 @@ class FmdT(C.Structure):
 
 
 class WorkT(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("n_blk", "n_sa", "n_fwd_steps", "n_back_steps", "n_lf_steps")]
+    _fields_ = [(n, C.c_uint64) for n in ("n_blk", "n_sa", "n_fwd_steps", "n_back_steps", "n_lf_steps", "n_blk_fwd", "n_blk_back", "n_blk_lf")]
 
 
 class SeedsT(C.Structure):

@@ -1,0 +1,114 @@
+"""CPU tests of the oracle (our C restatement): against the committed golden vectors (produced by the
+reference's own compiled C, tests/golden/make_golden.py) and, where oracle/_ref/libref.so exists,
+against the reference itself on fresh seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+import oracle_py
+from bwamem_hip import fmindex, synth
+
+G = common.GOLDEN
+
+
+def _golden_genome():
+    z = np.load(os.path.join(G, "seed_kat.npz"))
+    n = int(z["n_genome"])
+    bits = np.unpackbits(z["genome"])[: 2 * n].reshape(n, 2)
+    return (bits[:, 0] * 2 + bits[:, 1]).astype(np.uint8), z
+
+
+def test_ext_golden(oracle):
+    z = np.load(os.path.join(G, "ext_kat.npz"))
+    jobs = tuple(z[k] for k in ("q", "qoff", "qlen", "t", "toff", "tlen", "h0"))
+    for zd in (0, 100):
+        o3, r6, cells = oracle.extend_batch(*jobs, params=oracle_py.default_params(zdrop=zd), want_raw=True)
+        assert np.array_equal(r6, z[f"raw6_z{zd}"])
+        assert np.array_equal(o3, z[f"out3_z{zd}"])
+        assert cells > 0
+
+
+def test_seed_golden(oracle):
+    g, z = _golden_genome()
+    assert np.array_equal(g, synth.make_genome(200_000, seed=42)), "generator drifted from the golden genome"
+    idx = fmindex.build_fmd_index(g)
+    got = oracle.seed_reads(oracle.fmd(idx), z["reads"], z["offs"], z["lens"], 19)
+    for k in ("smem_k", "smem_s", "smem_qb", "smem_qe", "smem_read") + common.SEED_KEYS:
+        assert np.array_equal(got[k], z[k]), k
+    # threads do not change the result
+    got4 = oracle.seed_reads(oracle.fmd(idx), z["reads"], z["offs"], z["lens"], 19, n_threads=4)
+    common.assert_seeds_equal(got4, got)
+
+
+def test_occ_sa_golden(oracle):
+    g, _ = _golden_genome()
+    idx = fmindex.build_fmd_index(g)
+    f = oracle.fmd(idx)
+    z = np.load(os.path.join(G, "occ_kat.npz"))
+    for k, occ, sa in zip(z["k"], z["occ"], z["sa"]):
+        for c in range(4):
+            assert oracle.lib.fmd_occ(f, int(k), c) == int(occ[c])
+        assert oracle.lib.fmd_sa(f, int(k), None) == int(sa)
+
+
+def test_seed_properties(oracle):
+    """Size-independent properties: every located seed is an exact match of the read in the
+    fwd+revcomp text; SMEMs of a read are strictly increasing in begin and end; prefix = scan."""
+    g, idx = common.genome_and_index(150_000, seed=9)
+    text = np.concatenate([g, synth.revcomp(g)])
+    reads, _ = synth.make_reads(g, 600, 150, seed=5)
+    flat, offs, lens = common.flat_reads(reads)
+    s = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
+    assert np.array_equal(np.cumsum(s["n_ref_pos"])[:-1], s["prefix"][1:])
+    for r in range(len(lens)):
+        lo, n = int(s["prefix"][r]), int(s["n_ref_pos"][r])
+        i, last = lo, (-1, -1)
+        while i < lo + n:
+            cnt = int(s["score"][i]); b, e = s["qbeg"][i]
+            assert cnt >= 1 and e - b >= 19 and b > last[0] and e > last[1]
+            last = (b, e)
+            for t in range(cnt):
+                p = int(s["rbeg"][i + t])
+                assert np.array_equal(text[p:p + e - b], reads[r, b:e])
+                assert tuple(s["qbeg"][i + t]) == (b, e) and (t == 0 or s["score"][i + t] == 0)
+            i += cnt
+
+
+def test_oracle_vs_ref_fresh(oracle, ref):
+    g, idx = common.genome_and_index(120_000, seed=77)
+    b = ref.bwt_from_index(idx)
+    reads, _ = synth.make_reads(g, 1200, 150, seed=78, sub_rate=0.03)
+    rows = [r for r in reads] + common.edge_reads(g, np.random.default_rng(8))
+    flat, offs, lens = common.ragged_reads(rows)
+    for k in (19, 10):
+        common.assert_seeds_equal(oracle.seed_reads(oracle.fmd(idx), flat, offs, lens, k), ref.seed_reads(b, flat, offs, lens, k))
+    jobs = common.make_ext_jobs(1500, np.random.default_rng(79))
+    for zd in (0, 30):
+        p = oracle_py.default_params(zdrop=zd)
+        o3, r6, _ = oracle.extend_batch(*jobs, params=p, want_raw=True)
+        ro3, rr6 = ref.extend_batch(*jobs, params=p)
+        assert np.array_equal(r6, rr6) and np.array_equal(o3, ro3)
+
+
+def test_ext_edge_cases(oracle, ref):
+    """empty query, single cells, all-N, all-mismatch, h0 = 1, very long target."""
+    rows = [
+        (np.zeros(0, np.uint8), np.array([0, 1, 2], np.uint8), 10),
+        (np.array([0], np.uint8), np.array([0], np.uint8), 1),
+        (np.array([0], np.uint8), np.array([1], np.uint8), 1),
+        (np.full(50, 4, np.uint8), np.full(60, 4, np.uint8), 30),
+        (np.zeros(40, np.uint8), np.full(90, 3, np.uint8), 25),
+        (np.tile(np.arange(4, dtype=np.uint8), 30), np.tile(np.arange(4, dtype=np.uint8), 100), 19),
+        (np.tile(np.arange(4, dtype=np.uint8), 70), np.tile(np.arange(4, dtype=np.uint8), 10), 150),
+    ]
+    q, qoff, qlen = common.ragged_reads([r[0] for r in rows])
+    t, toff, tlen = common.ragged_reads([r[1] for r in rows])
+    if q.size == 0:
+        q = np.zeros(1, np.uint8)
+    h0 = np.array([r[2] for r in rows], np.uint32)
+    jobs = (q, qoff.astype(np.uint32), qlen, t, toff.astype(np.uint32), tlen, h0)
+    o3, r6, _ = oracle.extend_batch(*jobs, want_raw=True)
+    ro3, rr6 = ref.extend_batch(*jobs)
+    assert np.array_equal(r6, rr6) and np.array_equal(o3, ro3)

@@ -7,9 +7,15 @@
 // previous row's zeros (:963-970), the m==0 break (:946), z-drop (:951-959), the
 // "last column on ties" row maximum (:928) and the "last row on ties" gscore (:943).
 //
-// Mapping: ONE WAVE PER ALIGNMENT, one target row per step, the 64 lanes own the
-// query columns (C consecutive columns per lane, C = ceil(qlen/64), a template
-// parameter).  Because ksw_extend2 opens gaps from the diagonal value M and not
+// Mapping: one target row per step, lanes own the query columns (C consecutive
+// columns per lane, a template parameter).  Two kernels share the row algebra:
+//   extend16_kernel<C>   qlen <= 16*C <= 288: FOUR alignments per wave, one per 16-lane
+//                        DPP row (row_shr scans and quad_perm/row_mirror butterflies are
+//                        natively 16 wide, so the four rows never interact); all per-
+//                        alignment control (beg/end/max/alive) is vector state replicated
+//                        over the row's lanes; jobs are sorted by (class, tlen) so the four
+//                        alignments of a wave end together.
+//   extend_wide_kernel<C> 288 < qlen <= 512: one alignment per wave, 64 lanes x C columns.  Because ksw_extend2 opens gaps from the diagonal value M and not
 // from H (:929-938), M of a whole row depends only on the previous row, and
 // F(i,j+1) = max(F(i,j)-e, max(M(i,j)-oe,0)) is a max-plus prefix scan along the
 // row: F(i,j) = max_{j'<j}(t(j') + e*j') - e*(j-1).  The scan and the row maximum
@@ -20,7 +26,9 @@
 //
 // All row state lives in VGPRs; per alignment the wave reads qlen+tlen bytes and
 // writes 12 (or 36) bytes, so the kernel is integer-VALU bound, not HBM bound.
+#include <cstring>
 #include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
 #include <stdint.h>
 #include "bmh_internal.h"
 
@@ -56,15 +64,16 @@ struct ext_args_t {
 };
 
 template <int C>
-__global__ void __launch_bounds__(256) extend_kernel(ext_args_t A)
+__global__ void __launch_bounds__(256) extend_wide_kernel(ext_args_t A)
 {
 	const int lane = threadIdx.x & 63;
-	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-	const uint32_t n = *A.count;
+	const uint32_t n = A.count[0];
+	const uint32_t *ids = A.ids + A.count[1];      // count[1] = offset of this class in the sorted id list
 	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;
 	for (uint32_t w = wave; w < n; w += n_waves) {
-		const uint32_t id = A.ids[w];
+		const uint32_t id = ids[w];
 		const int qlen = (int)A.qlen[id], tlen = (int)A.tlen[id], h0 = (int)A.h0[id];
 		const uint8_t *qp = A.q + A.qoff[id], *tp = A.t + A.toff[id];
 		int H[C], E[C], qb[C];
@@ -181,35 +190,219 @@ __global__ void __launch_bounds__(256) extend_kernel(ext_args_t A)
 	}
 }
 
-// class of an alignment = columns per lane; 0 marks an unsupported length
-#define EXT_MAX_C 8
-__global__ void __launch_bounds__(256) ext_bin_kernel(const uint32_t *__restrict__ qlen, uint32_t n, uint32_t *__restrict__ ids,
+
+// ------------------------------------------------------------------ 16-lane rows
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
+// inclusive max-scan inside each 16-lane row
+__device__ __forceinline__ int row_scan_max(int v)
+{
+	int t;
+	t = __builtin_amdgcn_update_dpp(NEG_INF, v, 0x111, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(NEG_INF, v, 0x112, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(NEG_INF, v, 0x114, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(NEG_INF, v, 0x118, 0xf, 0xf, false); v = max(v, t);
+	return v;
+}
+// lane-1 inside the row (row_shr:1); lane 0 of each row receives `fill`
+__device__ __forceinline__ int row_shr1(int v, int fill)
+{
+	return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false);
+}
+// all-reduce max over each 16-lane row: xor-1, xor-2 (quad_perm), row_half_mirror, row_mirror
+__device__ __forceinline__ int row_allmax(int v)
+{
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+	return v;
+}
+__device__ __forceinline__ int pk_max(int a, int b)
+{
+	short2_t x = __builtin_bit_cast(short2_t, a), y = __builtin_bit_cast(short2_t, b);
+	return __builtin_bit_cast(int, __builtin_elementwise_max(x, y));
+}
+// same butterfly on two packed signed 16-bit values
+__device__ __forceinline__ int row_allmax_pk(int v)
+{
+	v = pk_max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+	v = pk_max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+	v = pk_max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+	v = pk_max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+	return v;
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
+{
+	const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+	const uint32_t n = A.count[0];
+	const uint32_t *ids = A.ids + A.count[1];
+	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;
+	const int j0 = l16 * C;                           // first column of this lane
+	for (uint32_t w = wave * 4; w < n; w += n_waves * 4) {
+		const bool have = w + grp < n;
+		const uint32_t id = have ? ids[w + grp] : 0;
+		const int qlen = have ? (int)A.qlen[id] : 0, tlen = have ? (int)A.tlen[id] : 0, h0 = have ? (int)A.h0[id] : 1;
+		const uint8_t *qp = A.q + (have ? A.qoff[id] : 0), *tp = A.t + (have ? A.toff[id] : 0);
+		int H[C], E[C], qb[C];
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const int j = j0 + c;
+			qb[c] = j < qlen ? (int)qp[j] : 4;
+			const int v = h0 - oe_ins - j * A.e_ins;
+			H[c] = (j < qlen && v > 0) ? v : 0;
+			E[c] = 0;
+		}
+		int beg = 0, end = qlen, mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+		bool alive = have;
+		int tchunk = 4;
+		for (int i = 0; __any(alive && i < tlen); ++i) {
+			if ((i & 15) == 0) tchunk = (alive && i + l16 < tlen) ? (int)tp[i + l16] : 4;
+			const int ti = __shfl(tchunk, (lane & 48) | (i & 15));
+			const bool run = alive && i < tlen;
+			const int hm1 = i == 0 ? h0 : max(0, h0 - (A.o_del + A.e_del * i));
+			const int left = row_shr1(H[C - 1], beg == 0 ? hm1 : 0);
+			const unsigned wdt = (unsigned)(end - beg);
+			int M[C], g[C];
+			int agg = NEG_INF;
+#pragma unroll
+			for (int c = 0; c < C; ++c) {
+				const int j = j0 + c;
+				const bool act = run && (unsigned)(j - beg) < wdt;
+				const int hd = c == 0 ? left : H[c - 1];
+				const int sc = (ti > 3 || qb[c] > 3) ? -1 : (ti == qb[c] ? A.a : -A.b);
+				const int m = (act && hd) ? hd + sc : 0;
+				M[c] = m;
+				g[c] = act ? max(m - oe_ins, 0) + A.e_ins * j : NEG_INF;
+				agg = max(agg, g[c]);
+			}
+			int runmax = row_shr1(row_scan_max(agg), NEG_INF);
+			int key = 0;                                 // (h << 16) | column: row maximum with last-column tie-break
+			int fl = (int)0x80008000;                    // packed {hi: -first index, lo: last index}, both "none"
+#pragma unroll
+			for (int c = 0; c < C; ++c) {
+				const int j = j0 + c;
+				const bool act = run && (unsigned)(j - beg) < wdt;
+				const int f = max(0, runmax - A.e_ins * (j - 1));
+				runmax = max(runmax, g[c]);
+				int h = max(max(M[c], E[c]), f);
+				int e = max(E[c] - A.e_del, max(M[c] - oe_del, 0));
+				h = act ? h : 0;
+				e = act ? e : 0;
+				H[c] = h; E[c] = e;
+				if (act) key = max(key, (h << 16) | j);
+				// eh index j+1 is non-zero through H(i,j), index j through E(i+1,j)
+				if (h) fl = pk_max(fl, ((-(j + 1)) << 16) | (j + 1));
+				if (e) fl = pk_max(fl, ((-j) << 16) | (j & 0xFFFF));
+			}
+			key = row_allmax(key);
+			const int m = key >> 16, mj = key & 0xFFFF;
+			// gscore: H(i, qlen-1) when the row reaches the query end (ksw.c:942-945)
+			{
+				const int jl = qlen - 1;
+				int src = 0;
+#pragma unroll
+				for (int c = 0; c < C; ++c) if (jl % C == c) src = H[c];
+				int h1 = __shfl(src, (lane & 48) | ((jl < 0 ? 0 : jl) / C));
+				if (qlen == 0) h1 = beg == 0 ? max(0, h0 - (A.o_del + A.e_del * (i + 1))) : 0;
+				if (run && end == qlen) {
+					if (!(gscore > h1)) max_ie = i;
+					gscore = max(gscore, h1);
+				}
+			}
+			const bool upd = run && m != 0;
+			if (run && m == 0) alive = false;              // ksw.c:946
+			if (upd) {
+				if (m > mx) {
+					mx = m; max_i = i; max_j = mj;
+					max_off = max(max_off, abs(mj - i));
+				} else if (A.zdrop > 0) {
+					const int di = i - max_i, dj = mj - max_j;
+					const int pen = di > dj ? (di - dj) * A.e_del : (dj - di) * A.e_ins;
+					if (mx - m - pen > A.zdrop) alive = false;
+				}
+			}
+			fl = row_allmax_pk(fl);
+			{
+				const int h1i = beg == 0 ? max(0, h0 - (A.o_del + A.e_del * (i + 1))) : 0;
+				int fidx = -(fl >> 16), lidx = (int)(short)(fl & 0xFFFF);
+				if ((fl >> 16) == (int)(short)0x8000) fidx = 1 << 20;          // no non-zero entry
+				if (lidx == (int)(short)0x8000) lidx = -1;
+				if (h1i) { fidx = min(fidx, beg); lidx = max(lidx, beg); }
+				const int nbeg = min(fidx, end);
+				const int nend = min(qlen, max(lidx, nbeg - 1) + 2);
+				if (upd) { beg = nbeg; end = nend; }
+			}
+		}
+		if (have && l16 == 0) {
+			const int qle = max_j + 1, tle = max_i + 1, gtle = max_ie + 1;
+			int32_t *o = A.out + 3 * (size_t)id;
+			if (gscore <= 0 || gscore <= mx - A.end_bonus) { o[0] = mx; o[1] = qle; o[2] = tle; }
+			else { o[0] = gscore; o[1] = qlen; o[2] = gtle; }
+			if (A.raw) {
+				int32_t *r = A.raw + 6 * (size_t)id;
+				r[0] = mx; r[1] = qle; r[2] = tle; r[3] = gtle; r[4] = gscore; r[5] = max_off;
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------ host side
+
+// classes: 0 = unsupported length; 1..18 = extend16_kernel<C>; 19..22 = extend_wide_kernel<5..8>
+#define EXT_N_CLS 23
+#define EXT16_MAX_C 18
+
+__device__ __forceinline__ int ext_class(uint32_t ql)
+{
+	if (ql <= 16 * EXT16_MAX_C) return ql <= 16 ? 1 : (int)((ql + 15) / 16);
+	const int wc = (int)((ql + 63) / 64);
+	return wc <= 8 ? 19 + (wc - 5) : 0;
+}
+
+// sort key = class << 20 | tlen, plus a per-class histogram
+__global__ void __launch_bounds__(256) ext_key_kernel(const uint32_t *__restrict__ qlen, const uint32_t *__restrict__ tlen, uint32_t n,
+                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                       uint32_t *__restrict__ counts, int32_t *__restrict__ out)
 {
+	__shared__ uint32_t hist[EXT_N_CLS];
+	if (threadIdx.x < EXT_N_CLS) hist[threadIdx.x] = 0;
+	__syncthreads();
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	int cls = -1;
 	if (t < n) {
-		uint32_t ql = qlen[t];
-		cls = ql <= 64 ? 1 : (int)((ql + 63) / 64);
-		if (cls > EXT_MAX_C) { cls = 0; out[3 * (size_t)t] = out[3 * (size_t)t + 1] = out[3 * (size_t)t + 2] = INT32_MIN; }
+		const int cls = ext_class(qlen[t]);
+		if (cls == 0) out[3 * (size_t)t] = out[3 * (size_t)t + 1] = out[3 * (size_t)t + 2] = INT32_MIN;
+		uint32_t tl = tlen[t];
+		keys[t] = ((uint32_t)cls << 20) | (tl > 0xFFFFFu ? 0xFFFFFu : tl);
+		vals[t] = t;
+		atomicAdd(&hist[cls], 1u);
 	}
-	int lane = threadIdx.x & 63;
-	for (int c = 0; c <= EXT_MAX_C; ++c) {
-		unsigned long long mk = __ballot(cls == c);
-		if (!mk) continue;
-		int leader = __builtin_ctzll(mk);
-		uint32_t base = 0;
-		if (lane == leader) base = atomicAdd(&counts[c], (uint32_t)__popcll(mk));
-		base = __shfl(base, leader);
-		if (cls == c) ids[(size_t)c * n + base + __popcll(mk & ((1ull << lane) - 1))] = t;
+	__syncthreads();
+	if (threadIdx.x < EXT_N_CLS && hist[threadIdx.x]) atomicAdd(&counts[2 * threadIdx.x], hist[threadIdx.x]);
+}
+
+// counts[2c] = size of class c -> counts[2c+1] = its offset in the sorted list
+__global__ void ext_offsets_kernel(uint32_t *counts)
+{
+	if (threadIdx.x == 0) {
+		uint32_t acc = 0;
+		for (int c = 0; c < EXT_N_CLS; ++c) { counts[2 * c + 1] = acc; acc += counts[2 * c]; }
 	}
 }
 
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
 
-// per-stream scratch for the class lists (grown on demand, reused across calls)
-struct ext_scratch_t { uint32_t *ids; uint32_t *counts; size_t cap; int dev; hipEvent_t ev0, ev1; bool have_ev; };
-static thread_local ext_scratch_t g_scr = {nullptr, nullptr, 0, -1, nullptr, nullptr, false};
+// per-thread scratch for the sorted job list (grown on demand, reused across calls)
+struct ext_scratch_t {
+	uint32_t *keys, *vals, *keys2, *vals2, *counts; void *tmp; size_t tmp_bytes; size_t cap; int dev;
+	hipEvent_t ev0, ev1; bool have_ev;
+};
+static thread_local ext_scratch_t g_scr = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1, nullptr, nullptr, false};
 
 // device time of the DP kernels of the last bmh_extend_batch on this thread (HIP events on its stream)
 extern "C" float bmh_extend_last_ms(void)
@@ -222,12 +415,18 @@ extern "C" float bmh_extend_last_ms(void)
 }
 
 template <int C>
-static void launch_class(const ext_args_t &base, uint32_t n, hipStream_t st, unsigned grid)
+static void launch16(const ext_args_t &base, hipStream_t st, unsigned grid)
 {
 	ext_args_t a = base;
-	a.ids = base.ids + (size_t)C * n;
-	a.count = base.count + C;
-	extend_kernel<C><<<grid, 256, 0, st>>>(a);
+	a.count = base.count + 2 * C;
+	extend16_kernel<C><<<grid, 256, 0, st>>>(a);
+}
+template <int C>
+static void launch_wide(const ext_args_t &base, hipStream_t st, unsigned grid)
+{
+	ext_args_t a = base;
+	a.count = base.count + 2 * (19 + C - 5);
+	extend_wide_kernel<C><<<grid, 256, 0, st>>>(a);
 }
 
 extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, const uint32_t *d_qlen, const uint8_t *d_t,
@@ -243,31 +442,43 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 	int dev = 0;
 	HIPCK(hipGetDevice(&dev));
 	if (g_scr.cap < n || g_scr.dev != dev) {
-		if (g_scr.ids) { (void)hipFree(g_scr.ids); (void)hipFree(g_scr.counts); g_scr.ids = nullptr; g_scr.counts = nullptr; g_scr.cap = 0; }
-		HIPCK(hipMalloc((void **)&g_scr.ids, sizeof(uint32_t) * (size_t)n * (EXT_MAX_C + 1)));
-		HIPCK(hipMalloc((void **)&g_scr.counts, sizeof(uint32_t) * 16));
-		g_scr.cap = n; g_scr.dev = dev;
+		void *ps[] = {g_scr.keys, g_scr.vals, g_scr.keys2, g_scr.vals2, g_scr.counts, g_scr.tmp};
+		for (void *q : ps) if (q) (void)hipFree(q);
+		g_scr.keys = g_scr.vals = g_scr.keys2 = g_scr.vals2 = g_scr.counts = nullptr; g_scr.tmp = nullptr; g_scr.cap = 0;
+		HIPCK(hipMalloc((void **)&g_scr.keys, 4 * (size_t)n)); HIPCK(hipMalloc((void **)&g_scr.vals, 4 * (size_t)n));
+		HIPCK(hipMalloc((void **)&g_scr.keys2, 4 * (size_t)n)); HIPCK(hipMalloc((void **)&g_scr.vals2, 4 * (size_t)n));
+		HIPCK(hipMalloc((void **)&g_scr.counts, 4 * 2 * EXT_N_CLS));
+		size_t tb = 0;
+		HIPCK(rocprim::radix_sort_pairs(nullptr, tb, g_scr.keys, g_scr.keys2, g_scr.vals, g_scr.vals2, (size_t)n, 0, 25, st));
+		HIPCK(hipMalloc(&g_scr.tmp, tb + 256));
+		g_scr.tmp_bytes = tb; g_scr.cap = n; g_scr.dev = dev;
 	}
 	if (!g_scr.have_ev) { HIPCK(hipEventCreate(&g_scr.ev0)); HIPCK(hipEventCreate(&g_scr.ev1)); g_scr.have_ev = true; }
-	HIPCK(hipMemsetAsync(g_scr.counts, 0, sizeof(uint32_t) * 16, st));
-	ext_bin_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_qlen, n, g_scr.ids, g_scr.counts, d_out);
+	HIPCK(hipEventRecord(g_scr.ev0, st));
+	HIPCK(hipMemsetAsync(g_scr.counts, 0, 4 * 2 * EXT_N_CLS, st));
+	ext_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_qlen, d_tlen, n, g_scr.keys, g_scr.vals, g_scr.counts, d_out);
+	ext_offsets_kernel<<<1, 64, 0, st>>>(g_scr.counts);
+	{
+		size_t tb = g_scr.tmp_bytes;
+		HIPCK(rocprim::radix_sort_pairs(g_scr.tmp, tb, g_scr.keys, g_scr.keys2, g_scr.vals, g_scr.vals2, (size_t)n, 0, 25, st));
+	}
 	ext_args_t a;
 	a.q = d_q; a.t = d_t; a.qoff = d_qoff; a.qlen = d_qlen; a.toff = d_toff; a.tlen = d_tlen; a.h0 = d_h0;
-	a.ids = g_scr.ids; a.count = g_scr.counts; a.out = d_out; a.raw = d_raw;
+	a.ids = g_scr.vals2; a.count = g_scr.counts; a.out = d_out; a.raw = d_raw;
 	a.a = p->a; a.b = p->b; a.o_del = p->o_del; a.e_del = p->e_del; a.o_ins = p->o_ins; a.e_ins = p->e_ins;
 	a.zdrop = p->zdrop; a.end_bonus = p->end_bonus;
-	// one wave per alignment, 4 per block; waves stride over their class list
-	HIPCK(hipEventRecord(g_scr.ev0, st));
-	unsigned grid = (unsigned)((n + 3) / 4);
+	// class sizes stay on the device (no host sync): every class kernel is launched with a grid
+	// that covers the whole batch and its waves stride over the class's slice of the sorted list
+	unsigned g16 = (unsigned)((n + 15) / 16), gw = (unsigned)((n + 3) / 4);
 	const unsigned max_grid = 256 * 8;
-	if (grid > max_grid) grid = max_grid;
-	// class lists are sized by n each; the per-class counts stay on the device (no host sync)
-	{
-		// rebase: ids of class c live at ids + c*n (launch_class adds C*n)
-		launch_class<1>(a, n, st, grid); launch_class<2>(a, n, st, grid); launch_class<3>(a, n, st, grid);
-		launch_class<4>(a, n, st, grid); launch_class<5>(a, n, st, grid); launch_class<6>(a, n, st, grid);
-		launch_class<7>(a, n, st, grid); launch_class<8>(a, n, st, grid);
-	}
+	if (g16 > max_grid) g16 = max_grid;
+	if (gw > max_grid) gw = max_grid;
+	launch16<1>(a, st, g16); launch16<2>(a, st, g16); launch16<3>(a, st, g16); launch16<4>(a, st, g16);
+	launch16<5>(a, st, g16); launch16<6>(a, st, g16); launch16<7>(a, st, g16); launch16<8>(a, st, g16);
+	launch16<9>(a, st, g16); launch16<10>(a, st, g16); launch16<11>(a, st, g16); launch16<12>(a, st, g16);
+	launch16<13>(a, st, g16); launch16<14>(a, st, g16); launch16<15>(a, st, g16); launch16<16>(a, st, g16);
+	launch16<17>(a, st, g16); launch16<18>(a, st, g16);
+	launch_wide<5>(a, st, gw); launch_wide<6>(a, st, gw); launch_wide<7>(a, st, gw); launch_wide<8>(a, st, gw);
 	HIPCK(hipEventRecord(g_scr.ev1, st));
 	HIPCK(hipGetLastError());
 	return BMH_OK;

@@ -401,8 +401,9 @@ __global__ void ext_offsets_kernel(uint32_t *counts)
 struct ext_scratch_t {
 	uint32_t *keys, *vals, *keys2, *vals2, *counts; void *tmp; size_t tmp_bytes; size_t cap; int dev;
 	hipEvent_t ev0, ev1; bool have_ev;
+	hipStream_t side[4]; hipEvent_t fork, join[4];     // class kernels run concurrently on side streams
 };
-static thread_local ext_scratch_t g_scr = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1, nullptr, nullptr, false};
+static thread_local ext_scratch_t g_scr = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1, nullptr, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, nullptr, {nullptr, nullptr, nullptr, nullptr}};
 
 // device time of the DP kernels of the last bmh_extend_batch on this thread (HIP events on its stream)
 extern "C" float bmh_extend_last_ms(void)
@@ -453,7 +454,15 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 		HIPCK(hipMalloc(&g_scr.tmp, tb + 256));
 		g_scr.tmp_bytes = tb; g_scr.cap = n; g_scr.dev = dev;
 	}
-	if (!g_scr.have_ev) { HIPCK(hipEventCreate(&g_scr.ev0)); HIPCK(hipEventCreate(&g_scr.ev1)); g_scr.have_ev = true; }
+	if (!g_scr.have_ev) {
+		HIPCK(hipEventCreate(&g_scr.ev0)); HIPCK(hipEventCreate(&g_scr.ev1));
+		HIPCK(hipEventCreateWithFlags(&g_scr.fork, hipEventDisableTiming));
+		for (int i = 0; i < 4; ++i) {
+			HIPCK(hipStreamCreateWithFlags(&g_scr.side[i], hipStreamNonBlocking));
+			HIPCK(hipEventCreateWithFlags(&g_scr.join[i], hipEventDisableTiming));
+		}
+		g_scr.have_ev = true;
+	}
 	HIPCK(hipEventRecord(g_scr.ev0, st));
 	HIPCK(hipMemsetAsync(g_scr.counts, 0, 4 * 2 * EXT_N_CLS, st));
 	ext_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_qlen, d_tlen, n, g_scr.keys, g_scr.vals, g_scr.counts, d_out);
@@ -473,12 +482,18 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 	const unsigned max_grid = 256 * 8;
 	if (g16 > max_grid) g16 = max_grid;
 	if (gw > max_grid) gw = max_grid;
-	launch16<1>(a, st, g16); launch16<2>(a, st, g16); launch16<3>(a, st, g16); launch16<4>(a, st, g16);
-	launch16<5>(a, st, g16); launch16<6>(a, st, g16); launch16<7>(a, st, g16); launch16<8>(a, st, g16);
-	launch16<9>(a, st, g16); launch16<10>(a, st, g16); launch16<11>(a, st, g16); launch16<12>(a, st, g16);
-	launch16<13>(a, st, g16); launch16<14>(a, st, g16); launch16<15>(a, st, g16); launch16<16>(a, st, g16);
-	launch16<17>(a, st, g16); launch16<18>(a, st, g16);
-	launch_wide<5>(a, st, gw); launch_wide<6>(a, st, gw); launch_wide<7>(a, st, gw); launch_wide<8>(a, st, gw);
+	// the class kernels are independent: fork them over four side streams so that the tail of one
+	// class overlaps the body of the next, then join back into the caller's stream
+	HIPCK(hipEventRecord(g_scr.fork, st));
+	for (int i = 0; i < 4; ++i) HIPCK(hipStreamWaitEvent(g_scr.side[i], g_scr.fork, 0));
+	hipStream_t *S = g_scr.side;
+	launch16<1>(a, S[0], g16); launch16<2>(a, S[1], g16); launch16<3>(a, S[2], g16); launch16<4>(a, S[3], g16);
+	launch16<5>(a, S[0], g16); launch16<6>(a, S[1], g16); launch16<7>(a, S[2], g16); launch16<8>(a, S[3], g16);
+	launch16<9>(a, S[0], g16); launch16<10>(a, S[1], g16); launch16<11>(a, S[2], g16); launch16<12>(a, S[3], g16);
+	launch16<13>(a, S[0], g16); launch16<14>(a, S[1], g16); launch16<15>(a, S[2], g16); launch16<16>(a, S[3], g16);
+	launch16<17>(a, S[0], g16); launch16<18>(a, S[1], g16);
+	launch_wide<5>(a, S[2], gw); launch_wide<6>(a, S[3], gw); launch_wide<7>(a, S[2], gw); launch_wide<8>(a, S[3], gw);
+	for (int i = 0; i < 4; ++i) { HIPCK(hipEventRecord(g_scr.join[i], g_scr.side[i])); HIPCK(hipStreamWaitEvent(st, g_scr.join[i], 0)); }
 	HIPCK(hipEventRecord(g_scr.ev1, st));
 	HIPCK(hipGetLastError());
 	return BMH_OK;

@@ -58,27 +58,44 @@ __device__ __forceinline__ int ascii_code(uint8_t ch)
 	return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
 }
 
-// one lane per (read, 32-base group): writes two 2-bit words and one mask word
+// 64 consecutive reads per 256-thread block.  The block's ASCII span (reads are back to back in
+// the input, seed_gen.cu:1715-1716) is staged into LDS with coalesced dword loads, then each
+// thread packs (read, 32-base group) items from LDS: two 2-bit words and one N-mask word,
+// stored transposed [word][read].  Reads that are not contiguous fall back to global byte loads.
+#define PACK_READS_PER_BLOCK 64
 __global__ void __launch_bounds__(256) pack_reads_kernel(const uint8_t *__restrict__ ascii, const uint32_t *__restrict__ offs,
                                                          const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t n_grp,
-                                                         uint32_t *__restrict__ pk, uint32_t *__restrict__ nm)
+                                                         uint32_t lds_bytes, uint32_t *__restrict__ pk, uint32_t *__restrict__ nm)
 {
-	size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (tid >= (size_t)n_reads * n_grp) return;
-	uint32_t r = (uint32_t)(tid % n_reads), g = (uint32_t)(tid / n_reads);
-	uint32_t len = lens[r];
-	const uint8_t *p = ascii + offs[r];
-	uint32_t w0 = 0, w1 = 0, m = 0;
-	for (int t = 0; t < 32; ++t) {
-		uint32_t i = g * 32 + t;
-		int c = i < len ? ascii_code(p[i]) : 4;
-		if (c > 3) m |= 1u << t;
-		else if (t < 16) w0 |= (uint32_t)c << (2 * t);
-		else w1 |= (uint32_t)c << (2 * (t - 16));
+	extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+	const uint32_t r0 = blockIdx.x * PACK_READS_PER_BLOCK;
+	const uint32_t nr = min((uint32_t)PACK_READS_PER_BLOCK, n_reads - r0);
+	const uint32_t first = offs[r0], last = offs[r0 + nr - 1] + lens[r0 + nr - 1];
+	const uint32_t abase = first & ~3u;                      // dword-aligned start of the span
+	const bool staged = last >= first && (last - abase) + 4 <= lds_bytes && (((uintptr_t)ascii) & 3) == 0;
+	if (staged) {
+		const uint32_t nw = (last - abase + 3) >> 2;
+		const uint32_t *src = (const uint32_t *)(ascii + abase);
+		for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) ((uint32_t *)stage)[i] = src[i];
 	}
-	pk[(size_t)(2 * g) * n_reads + r] = w0;
-	pk[(size_t)(2 * g + 1) * n_reads + r] = w1;
-	nm[(size_t)g * n_reads + r] = m;
+	__syncthreads();
+	for (uint32_t it = threadIdx.x; it < nr * n_grp; it += blockDim.x) {
+		const uint32_t rr = it % nr, g = it / nr, r = r0 + rr;
+		const uint32_t len = lens[r], o = offs[r];
+		const bool in_lds = staged && o >= first && o + len <= last;
+		const uint8_t *p = in_lds ? stage + (o - abase) : ascii + o;
+		uint32_t w0 = 0, w1 = 0, m = 0;
+		for (int t = 0; t < 32; ++t) {
+			const uint32_t i = g * 32 + t;
+			const int c = i < len ? ascii_code(p[i]) : 4;
+			if (c > 3) m |= 1u << t;
+			else if (t < 16) w0 |= (uint32_t)c << (2 * t);
+			else w1 |= (uint32_t)c << (2 * (t - 16));
+		}
+		pk[(size_t)(2 * g) * n_reads + r] = w0;
+		pk[(size_t)(2 * g + 1) * n_reads + r] = w1;
+		nm[(size_t)g * n_reads + r] = m;
+	}
 }
 
 // ---------------------------------------------------------------- forward
@@ -203,20 +220,48 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 
 struct res_t { uint32_t read, be, s, pad; };   // be = begin<<16 | end; s == 0: dropped
 
-__global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_view_t rv, const cand_t *__restrict__ in_a,
-                                                            const uint64_t *__restrict__ in_k, uint64_t n_cands,
-                                                            const uint32_t *__restrict__ cand_base, int min_seed_len,
+// list order -> (read, ordinal) order: slot cand_base[read] + ordinal.  After this the candidates of
+// one forward pass (same read, same start) sit in adjacent slots, shortest first.
+__global__ void __launch_bounds__(256) cand_scatter_kernel(const cand_t *__restrict__ in_a, const uint64_t *__restrict__ in_k,
+                                                           uint64_t n_list, const uint32_t *__restrict__ cand_base,
+                                                           cand_t *__restrict__ out_a, uint64_t *__restrict__ out_k)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_list) return;
+	cand_t c = in_a[t];
+	if (c.read == CAND_INVALID) return;
+	size_t d = (size_t)cand_base[c.read] + c.j;
+	out_a[d] = c;
+	out_k[d] = in_k[t];
+}
+
+// One lane per candidate, in (read, ordinal) order, in place: slot t holds the candidate on entry
+// and its result on exit.  Unidirectional backward search from start-1 to the maximal begin.
+// Contained-match early exit (the `ok[c].x[2] != curr->a[curr->n-1].x[2]` test of bwt_smem1,
+// src/bwt.c:543): the candidates of one pass walk back in lockstep in adjacent lanes; when a
+// candidate's interval size equals that of the nearest still-active longer candidate of its pass,
+// both have the same occurrences from here on, so it ends at the same begin and the filter would
+// drop it -- it stops now and is marked dropped.  Lanes of a pass split across two waves simply
+// miss this shortcut (the filter still drops them).
+__global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_view_t rv, uint64_t n_cands, int min_seed_len,
                                                             res_t *__restrict__ res_a, uint64_t *__restrict__ res_k)
 {
 	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = __lane_id();
 	bool live = t < n_cands;
-	cand_t c = {0, 0, 0, 0};
+	cand_t c = {CAND_INVALID, 0, 0, 0};
 	uint64_t lo = 0, hi = 0;
-	if (live) { c = in_a[t]; live = c.read != CAND_INVALID; }
-	if (live) { lo = in_k[t]; hi = lo + c.s - 1; }
+	if (live) { c = ((const cand_t *)res_a)[t]; lo = res_k[t]; hi = lo + c.s - 1; }
 	int x = (int)(c.xe >> 16), end = (int)(c.xe & 0xFFFF);
 	int i = x - 1, beg = x;
-	bool act = live && i >= 0;
+	bool act = live && i >= 0, dropped = false;
+	// last lane of my pass segment inside this wave
+	const uint32_t nread = __shfl_down(c.read, 1), nx = __shfl_down((uint32_t)x, 1);
+	const bool last_of_seg = lane == 63 || !live || nread != c.read || nx != (uint32_t)x;
+	const unsigned long long segb = __ballot(last_of_seg);
+	const int seg_end = lane + __builtin_ctzll(segb >> lane);      // >= lane, bit 63 is always set
+	const unsigned long long above = seg_end > lane ? ((~0ull >> (63 - (seg_end - lane - 1))) << 1 << lane) : 0ull;  // lanes lane+1..seg_end
+	uint32_t size = c.s;
 	while (__any(act)) {
 		if (act) {
 			int b = read_base(rv, c.read, i);
@@ -226,24 +271,30 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 				fmd_occ1_pair(f, lo - 1, hi, b, ol, ou);
 				uint64_t nl = fmd_L2(f, b) + ol + 1, nu = fmd_L2(f, b) + ou;
 				if (nl > nu) act = false;
-				else { lo = nl; hi = nu; beg = i; --i; act = i >= 0; }
+				else { lo = nl; hi = nu; beg = i; --i; size = (uint32_t)(hi - lo + 1); act = i >= 0; }
 			}
 		}
+		// nearest longer candidate of my pass that is still searching, after this step
+		const unsigned long long am = __ballot(act) & above;
+		const int nxt = am ? __builtin_ctzll(am) : lane;
+		const uint32_t nsize = __shfl(size, nxt);
+		if (act && am && nsize == size) { act = false; dropped = true; }
 	}
 	if (live) {
 		res_t o;
 		o.read = c.read; o.be = ((uint32_t)beg << 16) | (uint32_t)end;
-		o.s = (end - beg >= min_seed_len) ? (uint32_t)(hi - lo + 1) : 0u;
+		o.s = (!dropped && end - beg >= min_seed_len) ? (uint32_t)(hi - lo + 1) : 0u;
 		o.pad = 0;
-		size_t d = (size_t)cand_base[c.read] + c.j;
-		res_a[d] = o;
-		res_k[d] = lo;
+		res_a[t] = o;
+		res_k[t] = lo;
 	}
 }
 
 // ---------------------------------------------------------------- filter
 
-// keep result t unless the next result of the same read is valid and has the same begin
+// keep result t unless the next VALID result of the same read has the same begin (results dropped by
+// the backward kernel's early exit, or too short, are skipped: an early-dropped candidate ends where
+// the next longer one does, so the comparison partner is the first survivor after it)
 __global__ void __launch_bounds__(256) smem_filter_kernel(const res_t *__restrict__ res_a, uint64_t n, uint32_t *__restrict__ occ,
                                                           uint32_t *__restrict__ keep)
 {
@@ -252,9 +303,14 @@ __global__ void __launch_bounds__(256) smem_filter_kernel(const res_t *__restric
 	if (t == n) { occ[t] = 0; keep[t] = 0; return; }
 	res_t e = res_a[t];
 	bool k = e.s > 0;
-	if (k && t + 1 < n) {
-		res_t nx = res_a[t + 1];
-		if (nx.read == e.read && nx.s > 0 && (nx.be >> 16) == (e.be >> 16)) k = false;
+	if (k) {
+		for (uint64_t u = t + 1; u < n; ++u) {
+			res_t nx = res_a[u];
+			if (nx.read != e.read) break;
+			if (nx.s == 0) continue;
+			if ((nx.be >> 16) == (e.be >> 16)) k = false;
+			break;
+		}
 	}
 	occ[t] = k ? e.s : 0u;
 	keep[t] = k ? 1u : 0u;
@@ -426,7 +482,10 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 	read_view_t rv = {w->pk, w->nm, n_reads};
 
 	HIPCK(hipEventRecord(w->ev[0], st));
-	pack_reads_kernel<<<nblk((uint64_t)n_reads * n_grp, 256), 256, 0, st>>>(d_reads, d_offs, d_lens, n_reads, n_grp, w->pk, w->nm);
+	{
+		const uint32_t lds_bytes = PACK_READS_PER_BLOCK * n_grp * 32 + 64;   // 64 reads of the longest length, + alignment slack
+		pack_reads_kernel<<<nblk(n_reads, PACK_READS_PER_BLOCK), 256, lds_bytes <= 65536 ? lds_bytes : 0, st>>>(d_reads, d_offs, d_lens, n_reads, n_grp, lds_bytes <= 65536 ? lds_bytes : 0, w->pk, w->nm);
+	}
 	HIPCK(hipEventRecord(w->ev[1], st));
 	HIPCK(hipMemsetAsync(w->counter, 0, 8, st));
 	HIPCK(hipMemsetAsync(w->n_cand + n_reads, 0, 4, st));
@@ -445,7 +504,9 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 	out->n_cands = n_cands;
 	if (n_list > w->max_cands) { bmh_set_error("bmh_seed_batch: %llu candidate slots > capacity %llu", n_list, (unsigned long long)w->max_cands); return BMH_ECAPACITY; }
 	if (n_list)
-		smem_backward_kernel<<<nblk(n_list, 256), 256, 0, st>>>(f, rv, w->cand_a, w->cand_k, n_list, w->cand_base, min_seed_len, w->res_a, w->res_k);
+		cand_scatter_kernel<<<nblk(n_list, 256), 256, 0, st>>>(w->cand_a, w->cand_k, n_list, w->cand_base, (cand_t *)w->res_a, w->res_k);
+	if (n_cands)
+		smem_backward_kernel<<<nblk(n_cands, 256), 256, 0, st>>>(f, rv, n_cands, min_seed_len, w->res_a, w->res_k);
 	HIPCK(hipEventRecord(w->ev[3], st));
 	smem_filter_kernel<<<nblk(n_cands + 1, 256), 256, 0, st>>>(w->res_a, n_cands, w->occ, w->keep);
 	{

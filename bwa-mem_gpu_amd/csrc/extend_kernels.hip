@@ -338,6 +338,21 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 				const int nend = min(qlen, max(lidx, nbeg - 1) + 2);
 				if (upd) { beg = nbeg; end = nend; }
 			}
+			// Exact early stop.  Phi(v at column c) = v + a*(qlen-1-c) never increases along a DP
+			// transition (diagonal: +s <= +a and one column right; E: same column, minus a gap
+			// cost; F: right, minus a gap cost), so every H of every later row is <= U = max Phi
+			// over this row's frontier {H(i,j), E(i+1,j), first-column value}.  Once U <= max and
+			// U < gscore no later row can change max/max_i/max_j/max_off (strict >, ksw.c:948) nor
+			// gscore/max_ie (>=, ksw.c:943): the remaining rows are dead work.  Checked every 4 rows.
+			if ((i & 3) == 3) {
+				int u = 0;
+#pragma unroll
+				for (int c = 0; c < C; ++c) u = max(u, max(H[c], E[c]) + A.a * (qlen - 1 - (j0 + c)));
+				const int h1n = beg == 0 ? max(0, h0 - (A.o_del + A.e_del * (i + 1))) : 0;
+				u = max(u, h1n + A.a * qlen);
+				u = row_allmax(u);
+				if (u <= mx && u < gscore) alive = false;
+			}
 		}
 		if (have && l16 == 0) {
 			const int qle = max_j + 1, tle = max_i + 1, gtle = max_ie + 1;

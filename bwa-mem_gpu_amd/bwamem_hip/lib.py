@@ -22,7 +22,7 @@ def lib_path() -> str:
 EXPORTED_SYMBOLS = [
     "bmh_last_error", "bmh_device_count", "bmh_set_device", "bmh_index_upload", "bmh_index_from_device",
     "bmh_index_free", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
-    "bmh_extend_batch", "bmh_extend_last_ms",
+    "bmh_extend_batch", "bmh_extend_last_ms", "bmh_calib_gather",
     "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
     "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
 ]
@@ -95,6 +95,8 @@ def load_library() -> C.CDLL:
     L.bmh_extend_batch.restype = C.c_int
     L.bmh_extend_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32, C.POINTER(ExtParams), C.c_void_p, C.c_void_p, C.c_void_p]
     L.bmh_extend_last_ms.restype = C.c_float
+    L.bmh_calib_gather.restype = C.c_int
+    L.bmh_calib_gather.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
     L.bwt_restore_bwt_gpu.restype = C.POINTER(BwtTGpu)
     L.bwt_restore_bwt_gpu.argtypes = [C.c_char_p]
     L.bwt_restore_sa_gpu.argtypes = [C.c_char_p, C.POINTER(BwtTGpu)]

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include <stdint.h>
+#include <stdlib.h>
 #include "bmh_internal.h"
 
 #define NEG_INF (-(1 << 29))
@@ -494,7 +495,7 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 	// class sizes stay on the device (no host sync): every class kernel is launched with a grid
 	// that covers the whole batch and its waves stride over the class's slice of the sorted list
 	unsigned g16 = (unsigned)((n + 15) / 16), gw = (unsigned)((n + 3) / 4);
-	const unsigned max_grid = 256 * 8;
+	static const unsigned max_grid = [] { const char *e = getenv("BMH_EXT_GRID"); unsigned v = e ? (unsigned)atoi(e) : 0; return v ? v : 256u * 8; }();
 	if (g16 > max_grid) g16 = max_grid;
 	if (gw > max_grid) gw = max_grid;
 	// the class kernels are independent: fork them over four side streams so that the tail of one

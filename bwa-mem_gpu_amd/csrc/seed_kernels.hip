@@ -299,21 +299,29 @@ __global__ void __launch_bounds__(256) smem_filter_kernel(const res_t *__restric
                                                           uint32_t *__restrict__ keep)
 {
 	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (t > n) return;
-	if (t == n) { occ[t] = 0; keep[t] = 0; return; }
-	res_t e = res_a[t];
+	res_t e = {0xFFFFFFFEu, 0, 0, 0};
+	if (t < n) e = res_a[t];
 	bool k = e.s > 0;
+	// comparison partner = next valid result; inside the wave it comes from a ballot + shuffle,
+	// only lanes behind the wave's last valid result walk global memory
+	const int lane = __lane_id();
+	const unsigned long long vm = __ballot(k);
+	const unsigned long long ab = lane < 63 ? (vm >> (lane + 1)) << (lane + 1) : 0ull;
+	const int nl = ab ? __builtin_ctzll(ab) : lane;
+	const uint32_t nread = __shfl(e.read, nl), nbe = __shfl(e.be, nl);
 	if (k) {
-		for (uint64_t u = t + 1; u < n; ++u) {
-			res_t nx = res_a[u];
-			if (nx.read != e.read) break;
-			if (nx.s == 0) continue;
-			if ((nx.be >> 16) == (e.be >> 16)) k = false;
-			break;
+		if (ab) { if (nread == e.read && (nbe >> 16) == (e.be >> 16)) k = false; }
+		else {
+			for (uint64_t u = t - lane + 64; u < n; ++u) {
+				res_t nx = res_a[u];
+				if (nx.read != e.read) break;
+				if (nx.s == 0) continue;
+				if ((nx.be >> 16) == (e.be >> 16)) k = false;
+				break;
+			}
 		}
 	}
-	occ[t] = k ? e.s : 0u;
-	keep[t] = k ? 1u : 0u;
+	if (t <= n) { occ[t] = k ? e.s : 0u; keep[t] = k ? 1u : 0u; }
 }
 
 __global__ void __launch_bounds__(256) per_read_counts_kernel(const uint32_t *__restrict__ cand_base, const uint64_t *__restrict__ occ_off,
@@ -360,23 +368,45 @@ __global__ void __launch_bounds__(256) expand_kernel(const res_t *__restrict__ r
 
 // ---------------------------------------------------------------- locate
 
+// Each wave owns LOCATE_PER_WAVE consecutive occurrences and keeps its 64 lanes busy: a lane whose
+// walk reaches a sampled row stores its position and takes the next unclaimed occurrence of the
+// wave's chunk (wave-uniform cursor + ballot prefix, no atomics), so lanes do not idle behind the
+// longest walk of the wave (walk lengths are 0..sa_intv-1 and unpredictable).
+#define LOCATE_PER_WAVE 512
 __global__ void __launch_bounds__(256) locate_kernel(fmd_dev_t f, uint64_t *__restrict__ rows, uint64_t n)
 {
-	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	bool live = t < n;
-	uint64_t k = live ? rows[t] : 0, steps = 0, mask = (1ull << f.sa_shift) - 1;
-	bool act = live && (k & mask);
-	while (__any(act)) {
-		if (act) { k = fmd_inv_psi(f, k); ++steps; act = (k & mask) != 0; }
-	}
-	if (live) {
-		uint64_t idx = k >> f.sa_shift, pos;
-		if (idx == 0) pos = steps - 1;
-		else {
-			uint64_t hb = (f.sa_bits[idx >> 5] >> (idx & 31)) & 1u;
-			pos = ((uint64_t)f.sa[idx] | (hb << 32)) + steps;
+	const int lane = __lane_id();
+	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint64_t c0 = wave * LOCATE_PER_WAVE;
+	if (c0 >= n) return;
+	const uint64_t c1 = min(n, c0 + (uint64_t)LOCATE_PER_WAVE);
+	const uint64_t mask = (1ull << f.sa_shift) - 1;
+	uint64_t cur = c0;                 // wave-uniform: next unclaimed occurrence
+	uint64_t t = 0, k = 0, steps = 0;
+	bool busy = false;
+	for (;;) {
+		// finished or idle lanes claim new work
+		const bool need = !busy;
+		const unsigned long long nm = __ballot(need);
+		if (nm) {
+			const uint64_t mine = cur + __popcll(nm & ((1ull << lane) - 1));
+			if (need && mine < c1) { t = mine; k = rows[t]; steps = 0; busy = true; }
+			cur += __popcll(nm);
 		}
-		rows[t] = pos;
+		if (!__any(busy)) break;
+		if (busy) {
+			if (k & mask) { k = fmd_inv_psi(f, k); ++steps; }
+			else {
+				uint64_t idx = k >> f.sa_shift, pos;
+				if (idx == 0) pos = steps - 1;
+				else {
+					uint64_t hb = (f.sa_bits[idx >> 5] >> (idx & 31)) & 1u;
+					pos = ((uint64_t)f.sa[idx] | (hb << 32)) + steps;
+				}
+				rows[t] = pos;
+				busy = false;
+			}
+		}
 	}
 }
 
@@ -513,11 +543,11 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 		size_t tb = w->scan_tmp_bytes;
 		HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->occ, w->occ_off, (uint64_t)0, (size_t)n_cands + 1, rocprim::plus<uint64_t>(), st));
 		tb = w->scan_tmp_bytes;
-		HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->keep, w->keep_off, (uint64_t)0, (size_t)n_cands + 1, rocprim::plus<uint64_t>(), st));
+		HIPCK(rocprim::reduce(w->scan_tmp, tb, w->keep, w->keep_off, (uint64_t)0, (size_t)n_cands + 1, rocprim::plus<uint64_t>(), st));
 	}
 	uint64_t tot[2] = {0, 0};
 	HIPCK(hipMemcpyAsync(&tot[0], w->occ_off + n_cands, 8, hipMemcpyDeviceToHost, st));
-	HIPCK(hipMemcpyAsync(&tot[1], w->keep_off + n_cands, 8, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(&tot[1], w->keep_off, 8, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));
 	out->n_seeds = tot[0]; out->n_smems = tot[1];
 	if (tot[0] > w->max_occ) { bmh_set_error("bmh_seed_batch: %llu occurrences > capacity %llu", (unsigned long long)tot[0], (unsigned long long)w->max_occ); return BMH_ECAPACITY; }
@@ -528,11 +558,49 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 		expand_kernel<<<nblk(n_cands, 256), 256, 0, st>>>(w->res_a, w->res_k, w->occ, w->occ_off, n_cands, w->rows, w->qbeg, w->score);
 	HIPCK(hipEventRecord(w->ev[5], st));
 	if (tot[0])
-		locate_kernel<<<nblk(tot[0], 256), 256, 0, st>>>(f, w->rows, tot[0]);
+		locate_kernel<<<nblk(nblk(tot[0], LOCATE_PER_WAVE) * 64ull, 256), 256, 0, st>>>(f, w->rows, tot[0]);
 	HIPCK(hipEventRecord(w->ev[6], st));
 	HIPCK(hipStreamSynchronize(st));
 	HIPCK(hipGetLastError());
 	for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&w->ms[i], w->ev[i], w->ev[i + 1]);
 	(void)hipEventElapsedTime(&w->ms[6], w->ev[0], w->ev[6]);
+	return BMH_OK;
+}
+
+// ---------------------------------------------------------------- calibration
+
+// Random 32-byte block gathers over the index with a known count: the access pattern of the
+// seeding kernels without their arithmetic.  Used (a) to calibrate rocprofv3's FETCH_SIZE for this
+// pattern (MI355X_MICROARCH.md, HBM: the counter is only calibrated for wide streams) and (b) to
+// measure the practical ceiling of random block gathers that the seeding kernels are held against.
+// dependent != 0 chains each address on the previous block's contents, like a rank walk.
+__global__ void __launch_bounds__(256) calib_gather_kernel(fmd_dev_t f, uint64_t n_blocks, int iters, int dependent, uint32_t *sink)
+{
+	uint64_t x = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+	uint32_t acc = 0;
+	for (int i = 0; i < iters; ++i) {
+		x = x * 6364136223846793005ull + 1442695040888963407ull;
+		blk_t b = fmd_load_block(f, (x >> 20) % n_blocks);
+		acc += b.occ.x ^ b.w.w;
+		if (dependent) x ^= (uint64_t)(b.occ.y + b.w.x) << 24;
+	}
+	if (acc == 0x12345678u) sink[0] = acc;    // keeps the loads alive
+}
+
+extern "C" int bmh_calib_gather(const bmh_index_t *idx, uint64_t n_lanes, int iters, int dependent, void *stream_, float *ms)
+{
+	if (!idx || !ms || iters < 1) { bmh_set_error("bmh_calib_gather: bad argument"); return BMH_EINVAL; }
+	hipStream_t st = (hipStream_t)stream_;
+	uint32_t *sink = nullptr;
+	HIPCK(hipMalloc((void **)&sink, 64));
+	hipEvent_t e0, e1;
+	HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
+	const uint64_t n_blocks = (idx->dev.seq_len + 63) / 64;
+	HIPCK(hipEventRecord(e0, st));
+	calib_gather_kernel<<<nblk(n_lanes, 256), 256, 0, st>>>(idx->dev, n_blocks, iters, dependent, sink);
+	HIPCK(hipEventRecord(e1, st));
+	HIPCK(hipEventSynchronize(e1));
+	HIPCK(hipEventElapsedTime(ms, e0, e1));
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
 	return BMH_OK;
 }

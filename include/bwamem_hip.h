@@ -91,6 +91,12 @@ int bmh_seed_batch(bmh_seed_ws_t *ws, const bmh_index_t *idx, const uint8_t *d_r
  * [0]=pack [1]=forward [2]=backward [3]=filter+scans [4]=expand [5]=locate [6]=total */
 void bmh_seed_last_timing(const bmh_seed_ws_t *ws, float ms[7]);
 
+/* Calibration: n_lanes lanes each gather `iters` random 32-byte index blocks (dependent != 0:
+ * each address depends on the previous block, like a rank walk).  *ms = kernel time.  Known
+ * byte count = n_lanes * iters * 32; used to calibrate rocprofv3 FETCH_SIZE for this access
+ * pattern and to measure the practical random-gather ceiling of the chip. */
+int bmh_calib_gather(const bmh_index_t *idx, uint64_t n_lanes, int iters, int dependent, void *stream, float *ms);
+
 /* -------------------------------------------------------------- extension */
 
 /* Scoring of ksw_extend2 (src/ksw.c:864) as used by the GPU pipeline

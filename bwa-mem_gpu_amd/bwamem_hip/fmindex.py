@@ -188,3 +188,21 @@ def read_index(prefix: str) -> FMDIndex:
         bits = np.frombuffer(f.read(4 * (pack_size * n_sa // 32 + 1)), dtype="<u4").copy()
         bits[0] |= 1
     return FMDIndex(primary, L2, seq_len, words, sa_intv, n_sa, sa, bits, pack_size)
+
+
+def write_bns(prefix: str, genome_fwd: np.ndarray, name: str = "chrS") -> None:
+    """.pac / .ann / .amb of a single N-free sequence, byte-identical to what the reference's
+    `bwa index` writes (bwa_index/bntseq.c:66-95 bns_dump, :300-326 pac tail)."""
+    l_pac = int(genome_fwd.shape[0])
+    pad = (-l_pac) % 4
+    codes = np.concatenate([genome_fwd, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    pac = ((codes[:, 0] << 6) | (codes[:, 1] << 4) | (codes[:, 2] << 2) | codes[:, 3]).astype(np.uint8)
+    with open(prefix + ".pac", "wb") as f:
+        f.write(pac.tobytes())
+        if l_pac % 4 == 0:
+            f.write(b"\x00")
+        f.write(bytes([l_pac % 4]))
+    with open(prefix + ".ann", "w") as f:
+        f.write(f"{l_pac} 1 11\n0 {name} (null)\n0 {l_pac} 0\n")
+    with open(prefix + ".amb", "w") as f:
+        f.write(f"{l_pac} 1 0\n")

@@ -31,6 +31,9 @@
 #include <rocprim/rocprim.hpp>
 #include <stdint.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "bmh_internal.h"
 
 #define NEG_INF (-(1 << 29))
@@ -413,21 +416,36 @@ __global__ void ext_offsets_kernel(uint32_t *counts)
 
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
 
-// per-thread scratch for the sorted job list (grown on demand, reused across calls)
+// scratch for the sorted job list: one per (device, stream), grown on demand and reused across calls, so
+// that batches in flight on different streams never share it
 struct ext_scratch_t {
 	uint32_t *keys, *vals, *keys2, *vals2, *counts; void *tmp; size_t tmp_bytes; size_t cap; int dev;
 	hipEvent_t ev0, ev1; bool have_ev;
 	hipStream_t side[4]; hipEvent_t fork, join[4];     // class kernels run concurrently on side streams
 };
-static thread_local ext_scratch_t g_scr = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1, nullptr, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, nullptr, {nullptr, nullptr, nullptr, nullptr}};
+static std::mutex g_scr_mu;
+static std::map<std::pair<int, void *>, ext_scratch_t *> g_scr_map;
+static thread_local ext_scratch_t *g_last = nullptr;
 
-// device time of the DP kernels of the last bmh_extend_batch on this thread (HIP events on its stream)
+static ext_scratch_t *scratch_for(int dev, void *stream)
+{
+	std::lock_guard<std::mutex> lk(g_scr_mu);
+	auto key = std::make_pair(dev, stream);
+	auto it = g_scr_map.find(key);
+	if (it != g_scr_map.end()) return it->second;
+	ext_scratch_t *s = (ext_scratch_t *)calloc(1, sizeof(ext_scratch_t));
+	s->dev = dev;
+	g_scr_map[key] = s;
+	return s;
+}
+
+// device time of the last bmh_extend_batch issued by this thread (HIP events on its stream)
 extern "C" float bmh_extend_last_ms(void)
 {
-	if (!g_scr.have_ev) return -1.f;
+	if (!g_last || !g_last->have_ev) return -1.f;
 	float ms = -1.f;
-	if (hipEventSynchronize(g_scr.ev1) != hipSuccess) return -1.f;
-	if (hipEventElapsedTime(&ms, g_scr.ev0, g_scr.ev1) != hipSuccess) return -1.f;
+	if (hipEventSynchronize(g_last->ev1) != hipSuccess) return -1.f;
+	if (hipEventElapsedTime(&ms, g_last->ev0, g_last->ev1) != hipSuccess) return -1.f;
 	return ms;
 }
 
@@ -458,7 +476,9 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 	hipStream_t st = (hipStream_t)stream_;
 	int dev = 0;
 	HIPCK(hipGetDevice(&dev));
-	if (g_scr.cap < n || g_scr.dev != dev) {
+	ext_scratch_t &g_scr = *scratch_for(dev, stream_);
+	g_last = &g_scr;
+	if (g_scr.cap < n) {
 		void *ps[] = {g_scr.keys, g_scr.vals, g_scr.keys2, g_scr.vals2, g_scr.counts, g_scr.tmp};
 		for (void *q : ps) if (q) (void)hipFree(q);
 		g_scr.keys = g_scr.vals = g_scr.keys2 = g_scr.vals2 = g_scr.counts = nullptr; g_scr.tmp = nullptr; g_scr.cap = 0;

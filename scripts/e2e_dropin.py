@@ -1,0 +1,60 @@
+"""End-to-end drop-in run: the REFERENCE's own `bwa-gasal2 gase_aln` host code (compiled unchanged by
+scripts/build_dropin.sh, linked against libbwamem_hip.so) on BASELINE.json configs[0]'s shape:
+10k synthetic 150 bp single-end reads vs an E. coli-size (4.64 Mbp) seeded genome.  Checks the SAM
+against the simulation truth (position/strand of every read)."""
+import os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))
+import numpy as np
+import torch
+from bwamem_hip import fmindex, synth
+
+exe = os.path.join(ROOT, "build", "dropin", "bwa-gasal2")
+if not os.path.exists(exe):
+    sys.exit("build/dropin/bwa-gasal2 missing: run scripts/build_dropin.sh in the build container")
+work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/e2e_dropin"
+n_genome = int(float(sys.argv[2])) if len(sys.argv) > 2 else 4_640_000
+n_reads = int(float(sys.argv[3])) if len(sys.argv) > 3 else 10_000
+threads = sys.argv[4] if len(sys.argv) > 4 else "1"
+os.makedirs(work, exist_ok=True)
+prefix = os.path.join(work, "g.fa")
+g = synth.make_genome(n_genome, seed=42)
+t = time.time()
+idx = fmindex.build_fmd_index(g, device="cuda:0" if torch.cuda.is_available() else None)
+fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g)
+print("index built+written in %.1fs" % (time.time() - t), flush=True)
+reads, truth = synth.make_reads(g, n_reads, 150, seed=7)
+fq = os.path.join(work, "reads.fa")
+synth.write_fasta_reads(fq, reads)
+sam = os.path.join(work, "out.sam")
+t = time.time()
+with open(sam, "w") as f:
+    r = subprocess.run([exe, "gase_aln", "-t", threads, "-l", "150", prefix, fq], stdout=f, stderr=subprocess.PIPE, cwd=work)
+dt = time.time() - t
+print("gase_aln rc=%d in %.2fs" % (r.returncode, dt))
+print(r.stderr.decode()[-1500:])
+if r.returncode != 0:
+    sys.exit(1)
+ok = mapped = n = 0
+flags = {}
+for line in open(sam):
+    if line[0] == "@":
+        continue
+    c = line.split("\t")
+    flag = int(c[1])
+    if flag & 0x900:
+        continue
+    n += 1
+    i = int(c[0][1:])
+    if flag & 4:
+        continue
+    mapped += 1
+    pos = int(c[3]) - 1
+    rev = bool(flag & 16)
+    if abs(pos - int(truth["pos"][i])) <= 8 and rev == bool(truth["rev"][i]):
+        ok += 1
+print(f"reads {n} mapped {mapped} ({mapped/max(n,1):.4f}) correct position+strand {ok} ({ok/max(n,1):.4f})")
+lines = [l for l in open(sam) if l[0] != "@"][:3]
+print("".join(l[:200] + "\n" for l in lines))
+assert n == n_reads and ok / n > 0.97, "end-to-end accuracy too low"
+print("E2E DROP-IN OK")

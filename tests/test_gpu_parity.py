@@ -122,3 +122,41 @@ def test_seed_gpu_file_api(hip, oracle, tmp_path):
     flat, offs, lens = common.flat_reads(reads)
     want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
     common.assert_seeds_equal(got, want)
+
+
+def test_gasal_shim_matches_oracle(hip, oracle, tmp_path):
+    """The GASAL2-source-compatible API (include/gasal2_root) driven like the reference's host code."""
+    import os, struct, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "gasal_shim_driver")
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-fpermissive", "-w", "-I", os.path.join(root, "include", "gasal2_root", "src"),
+                           os.path.join(root, "tests", "gasal_shim_driver.cpp"), "-o", exe,
+                           "-L", os.path.join(root, "bwa-mem_gpu_amd"), "-lbwamem_hip", "-Wl,-rpath," + os.path.join(root, "bwa-mem_gpu_amd"),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    jobs = common.make_ext_jobs(3001, np.random.default_rng(31), maxq=150)
+    q, qoff, qlen, t, toff, tlen, h0 = jobs
+    inp, outp = str(tmp_path / "jobs.bin"), str(tmp_path / "res.bin")
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<I", len(qlen)))
+        for a in (qoff, qlen, toff, tlen, h0):
+            f.write(np.ascontiguousarray(a, dtype="<u4").tobytes())
+        f.write(struct.pack("<I", q.size)); f.write(q.tobytes())
+        f.write(struct.pack("<I", t.size)); f.write(t.tobytes())
+    subprocess.check_call([exe, inp, outp])
+    got = np.fromfile(outp, dtype="<i4").reshape(-1, 3)
+    want3, _, _ = oracle.extend_batch(*jobs)
+    assert np.array_equal(got, want3)
+
+
+def test_reference_gase_aln_end_to_end(hip, tmp_path):
+    """BASELINE configs[0] shape through the REFERENCE's own host code: build/dropin/bwa-gasal2 is the
+    reference's src/*.c compiled unchanged against include/seed_gen.h + include/gasal2_root and linked
+    with libbwamem_hip.so (scripts/build_dropin.sh, build container only)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "build", "dropin", "bwa-gasal2")):
+        pytest.skip("build/dropin/bwa-gasal2 not built (needs /root/reference at build time)")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "e2e_dropin.py"), str(tmp_path), "2000000", "4000"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "E2E DROP-IN OK" in out, out[-3000:]

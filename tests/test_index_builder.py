@@ -13,7 +13,8 @@ def test_builder_matches_reference_index_files(tmp_path):
     idx = fmindex.build_fmd_index(g)
     p = str(tmp_path / "g")
     fmindex.write_index(p, idx)
-    for ext in (".bwt", ".sa"):
+    fmindex.write_bns(p, g)
+    for ext in (".bwt", ".sa", ".pac", ".ann", ".amb"):
         want = open(os.path.join(common.GOLDEN, "ref_index_g20011" + ext), "rb").read()
         got = open(p + ext, "rb").read()
         assert got == want, ext

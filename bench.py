@@ -83,8 +83,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     B.load_library().bmh_set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    distributed = world > 1 or "RANK" in os.environ      # under torchrun even one rank goes through RCCL
+    if distributed:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---------------- setup (untimed): genome, index (rank 0) -> RCCL broadcast, reads shard, jobs
     n_genome = int(a.genome_mbp * 1e6)
@@ -125,7 +126,7 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -137,11 +138,11 @@ def main():
         for k, v in tm.items():
             stage_ms[k] = stage_ms.get(k, 0.0) + v
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -199,7 +200,7 @@ def main():
                                    for k in kernel_bytes}
             res["extension_gcups"] = round(cb["cells"] / cb["n_jobs"] * jobs.n / (stage_ms["extend"] * 1e-3) / 1e9, 1)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

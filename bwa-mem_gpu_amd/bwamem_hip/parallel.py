@@ -41,14 +41,15 @@ def broadcast_index(idx, device, src: int = 0, world: int | None = None):
     tensor padded to whole 32-byte blocks (+1) as bmh_index_from_device requires."""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if (world > 1 and dist.is_initialized()) else 0
+    use_dist = dist.is_initialized()
+    rank = dist.get_rank() if use_dist else 0
     hdr = torch.zeros(12, dtype=torch.int64)
     if rank == src:
         hdr[0] = idx.primary
         hdr[1:6] = torch.from_numpy(np.asarray(idx.L2, dtype=np.int64))
         hdr[6] = idx.seq_len; hdr[7] = idx.sa_intv; hdr[8] = idx.n_sa
         hdr[9] = idx.bwt_words.shape[0]; hdr[10] = idx.sa_bits.shape[0]
-    if world > 1:
+    if use_dist:
         h = hdr.to(device)
         dist.broadcast(h, src)
         hdr = h.cpu()
@@ -62,7 +63,7 @@ def broadcast_index(idx, device, src: int = 0, world: int | None = None):
         bwt[: w.numel()] = w.to(device)
         sa.copy_(torch.from_numpy(idx.sa.view(np.int32)))
         bits.copy_(torch.from_numpy(idx.sa_bits.view(np.int32)))
-    if world > 1:
+    if use_dist:
         # three large point-to-multipoint transfers, issued back to back (one ring/tree each)
         dist.broadcast(bwt, src)
         dist.broadcast(sa, src)

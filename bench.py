@@ -31,6 +31,9 @@ from bwamem_hip import pipeline as P  # noqa: E402
 from bwamem_hip.parallel import broadcast_index, shard_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# measured ceiling of random 32-byte block gathers on this chip (scripts/calib.py, bmh_calib_gather):
+# 56.8 G gathers/s = 1818 GB/s of useful bytes (each gather moves one 64-byte sector: 3.6 TB/s of traffic)
+GATHER_CEILING_GBS = 1818.0
 
 
 def cpu_baseline(g, idx, reads, sample: int, n_threads: int):
@@ -178,11 +181,11 @@ def main():
                                    "sample": f"first {cb['n']} reads of the same batch: oracle seeding {cb['t_seed']:.2f}s + "
                                              f"oracle extension {cb['t_ext']:.2f}s on {ncores} threads"}
             res["speedup_vs_cpu_baseline"] = round(value / cpu_mreads, 1)
+            res["oracle_work_per_read"] = {k: round(v / cb["n"], 2) for k, v in cb["work"].items()}
             # algorithmic bytes per read, counted by the oracle on the sample
             wk, n = cb["work"], cb["n"]
             per_read = {
-                "forward": 32.0 * wk["n_blk_fwd"] / n + a.read_len / 4 + 8,
-                "backward": 32.0 * wk["n_blk_back"] / n,
+                "smem": 32.0 * (wk["n_blk_fwd"] + wk["n_blk_back"]) / n + a.read_len / 4 + 8,
                 "locate": (32.0 * wk["n_blk_lf"] + 4.0 * wk["n_sa"] + 20.0 * cb["n_seeds"]) / n,
             }
             q, t = jobs.qlen.long(), jobs.tlen.long()
@@ -191,10 +194,11 @@ def main():
             kernel_bytes["extend"] = ext_bytes
             dom = max(kernel_bytes.keys(), key=lambda k: stage_ms.get(k, 0.0))
             ach = kernel_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9
-            res["roofline"] = {"bound": "hbm", "kernel": {"forward": "smem_forward_kernel", "backward": "smem_backward_kernel",
-                                                           "locate": "locate_kernel", "extend": "extend_kernel<1>"}[dom],
+            res["roofline"] = {"bound": "hbm", "kernel": {"smem": "smem_fused_kernel", "locate": "locate_kernel",
+                                                           "extend": "extend16_kernel<*> (all classes, concurrent streams)"}[dom],
                                "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                                "traffic": None, "avg_ms": round(stage_ms[dom], 3),
+                               "gather_ceiling_GBps": GATHER_CEILING_GBS, "frac_of_gather_ceiling": round(ach / GATHER_CEILING_GBS, 4),
                                "algorithmic_bytes_per_launch": int(kernel_bytes[dom])}
             res["roofline_all"] = {k: {"ms": round(stage_ms[k], 3), "algorithmic_GBps": round(kernel_bytes[k] / (stage_ms[k] * 1e-3) / 1e9, 2)}
                                    for k in kernel_bytes}

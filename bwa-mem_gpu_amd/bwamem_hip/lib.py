@@ -178,7 +178,8 @@ class SeedWorkspace:
     def timing(self):
         ms = (C.c_float * 7)()
         load_library().bmh_seed_last_timing(self.handle, ms)
-        return dict(zip(("pack", "forward", "backward", "filter_scan", "expand", "locate", "total"), list(ms)))
+        names = ("pack", "smem", "sort", "gather_scan", "expand", "locate", "total") if os.environ.get("BMH_SEED_FUSED") else ("pack", "forward", "backward", "filter_scan", "expand", "locate", "total")
+        return dict(zip(names, list(ms)))
 
     def free(self):
         if self.handle:

@@ -34,6 +34,7 @@
 #include <rocprim/rocprim.hpp>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "bmh_internal.h"
 #include "fmd_dev.h"
 
@@ -410,6 +411,213 @@ __global__ void __launch_bounds__(256) locate_kernel(fmd_dev_t f, uint64_t *__re
 	}
 }
 
+// ---------------------------------------------------------------- fused forward + backward
+
+// One lane per read runs the WHOLE SMEM search of its read: forward pass, then the backward search of
+// that pass's candidates (longest first), then the next pass.  The candidates of the current pass live
+// in a per-read scratch column in HBM ([slot][read], 16 bytes each: written once, read once, mostly
+// served by L2 / Infinity Cache) instead of going through a global list, a scan, a scatter and a second
+// kernel; only the SMEMs themselves (~2-3 per read instead of ~35 candidates) leave the kernel.
+//
+// Every loop iteration a lane issues at most ONE rank pair (the only HBM-missing access), and the rank
+// pair is computed by code common to both phases, so the lanes of a wave stay convergent on the
+// 32-byte block gathers whatever phase each lane is in.
+//
+// Contained matches (src/bwt.c:535-543): candidates are searched longest first, so a lane needs only an
+// O(1) summary of the last longer candidate that finished its own search: final interval size s_fin,
+// the position p1 from which it had that size, and its begin b.  A shorter candidate whose interval
+// size equals s_fin at a position in [b, p1] has the same occurrences from there on, ends at the same
+// begin and is dropped on the spot (bwt_smem1 drops it at the first equal size, never later than p1).
+// A candidate that finishes at the same begin as that summary is contained too (both stopped at an
+// ambiguous base or at the read start).
+enum { FS_OPEN = 0, FS_FWD, FS_BINIT, FS_BWD, FS_IDLE };
+
+// Work distribution: a persistent grid (one resident wave per wave slot) pulls 64-read chunks from a
+// global queue; inside a wave every lane that finishes its read immediately takes the next read of
+// the wave's chunk (wave-uniform cursor + ballot prefix).  Reads differ a lot in cost (reads from
+// repeat families have many more candidates), and a static read-per-lane mapping leaves most lanes
+// of every wave idle behind its slowest read.
+#define FUSED_CHUNK 64u
+
+__global__ void __launch_bounds__(256) smem_fused_kernel(fmd_dev_t f, read_view_t rv, const uint32_t *__restrict__ lens, int min_seed_len,
+                                                         uint4 *__restrict__ scratch, cand_t *__restrict__ out_a, uint64_t *__restrict__ out_k,
+                                                         unsigned long long *counter, uint64_t cap, uint32_t *__restrict__ n_ref_pos,
+                                                         unsigned long long *n_cand_total, unsigned int *queue)
+{
+	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t stride = (size_t)gridDim.x * blockDim.x;      // scratch columns are per resident lane
+	const int lane = __lane_id();
+	uint32_t r = 0;
+	int len = 0;
+	int st = FS_IDLE;
+	int i = 0, x = 0;                 // forward / resume position, pass start
+	uint64_t k = 0, l = 0, s = 0;     // forward bi-interval (k, l, s); backward: [k, l] = SA interval
+	int nc = 0, cidx = -1;            // candidates of the pass; next one to search backward
+	int bi = 0, beg = 0, cend = 0, p1 = 0;
+	uint32_t size = 0;
+	bool ref_valid = false; uint32_t ref_s = 0; int ref_p1 = 0, ref_b = 0;
+	uint32_t occ_sum = 0, cand_sum = 0;
+	cand_cursor_t cc = {0, 0};
+	uint32_t ch_cur = 0, ch_end = 0;  // wave-uniform: unclaimed reads of the wave's current chunk
+	bool drained = false;             // wave-uniform: the global queue is empty
+	unsigned long long n_iter = 0, n_rank = 0;
+#define FS_PUSH(END_) do { if ((END_) >= min_seed_len) { \
+		scratch[(size_t)nc * stride + gtid] = make_uint4((uint32_t)k, (uint32_t)s, (uint32_t)(k >> 32) | ((uint32_t)(END_) << 16), 0u); ++nc; } } while (0)
+	for (;;) {
+		// ---- refill: idle lanes take the next reads of the chunk; an empty chunk is replaced from the queue
+		{
+			const unsigned long long im = __ballot(st == FS_IDLE);
+			if (im) {
+				if (ch_cur == ch_end && !drained) {
+					uint32_t b0 = 0;
+					if (lane == 0) b0 = atomicAdd(queue, FUSED_CHUNK);
+					b0 = __shfl(b0, 0);
+					if (b0 >= rv.n_reads) drained = true;
+					else { ch_cur = b0; ch_end = min(b0 + FUSED_CHUNK, rv.n_reads); }
+				}
+				const uint32_t avail = ch_end - ch_cur;
+				if (avail) {
+					const uint32_t rank = (uint32_t)__popcll(im & ((1ull << lane) - 1));
+					if (st == FS_IDLE && rank < avail) {
+						r = ch_cur + rank; len = (int)lens[r];
+						i = 0; occ_sum = 0;
+						if (len > 0) st = FS_OPEN; else n_ref_pos[r] = 0;
+					}
+					ch_cur += min(avail, (uint32_t)__popcll(im));
+				}
+			}
+			if (drained && ch_cur == ch_end && !__any(st != FS_IDLE)) break;
+		}
+		// ---- A: at most one base fetch (+ one scratch fetch) per iteration, issued together
+		if (st == FS_BINIT && cidx < 0) st = FS_OPEN;                 // pass finished: resume the forward scan at i
+		const bool fetch_cand = st == FS_BINIT;
+		const int pos = fetch_cand ? x - 1 : (st == FS_BWD ? bi : i);
+		const bool at_end = st == FS_OPEN && i >= len;
+		const bool need_base = (st == FS_OPEN && !at_end) || st == FS_FWD || ((st == FS_BWD || fetch_cand) && pos >= 0);
+		int base = 4;
+		if (need_base) base = read_base(rv, r, pos);
+		if (fetch_cand) {
+			const uint4 c = scratch[(size_t)cidx * stride + gtid];
+			k = (uint64_t)c.x | ((uint64_t)(c.z & 0xFFFFu) << 32);
+			size = c.y; cend = (int)(c.z >> 16);
+			l = k + size - 1;
+			bi = x - 1; beg = x; p1 = x;
+			st = FS_BWD;
+		}
+		bool want_rank = false, fin = false, merged = false;
+		uint64_t q1 = 0, q2 = 0;
+		if (st == FS_OPEN) {
+			if (at_end) { n_ref_pos[r] = occ_sum; st = FS_IDLE; }
+			else {
+				++i;
+				if (base < 4) {
+					x = i - 1;
+					k = fmd_L2(f, base) + 1; s = fmd_L2(f, base + 1) - fmd_L2(f, base); l = fmd_L2(f, 3 - base) + 1;
+					nc = 0;
+					if (i == len) { FS_PUSH(i); cidx = nc - 1; cand_sum += (uint32_t)nc; ref_valid = false; st = FS_BINIT; }
+					else st = FS_FWD;
+				}
+			}
+		} else if (st == FS_FWD) {
+			if (base < 4) { want_rank = true; q1 = l - 1; q2 = l - 1 + s; }
+			else { FS_PUSH(i); cidx = nc - 1; cand_sum += (uint32_t)nc; ref_valid = false; st = FS_BINIT; }   // next pass opens at i
+		} else if (st == FS_BWD) {
+			if (bi < 0 || base > 3) fin = true;
+			else { want_rank = true; q1 = k - 1; q2 = l; }
+		}
+		// ---- B: the rank pair, common to both phases
+		uint64_t tk[4] = {0, 0, 0, 0}, tl[4] = {0, 0, 0, 0};
+		if (want_rank) fmd_occ4_pair(f, q1, q2, tk, tl);
+		++n_iter; n_rank += (unsigned long long)__popcll(__ballot(want_rank));
+		// ---- C: apply
+		if (want_rank && st == FS_FWD) {
+			const int cb = 3 - base;
+			uint64_t os[4];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) os[q] = tl[q] - tk[q];
+			const uint64_t nk3 = k + ((l <= f.primary) & (l + s - 1 >= f.primary));
+			const uint64_t nk2 = nk3 + os[3], nk1 = nk2 + os[2], nk0 = nk1 + os[1];
+			const uint64_t ns = cb == 0 ? os[0] : cb == 1 ? os[1] : cb == 2 ? os[2] : os[3];
+			const uint64_t nk = cb == 0 ? nk0 : cb == 1 ? nk1 : cb == 2 ? nk2 : nk3;
+			const uint64_t nl = fmd_L2(f, cb) + 1 + (cb == 0 ? tk[0] : cb == 1 ? tk[1] : cb == 2 ? tk[2] : tk[3]);
+			bool pass_end = false;
+			if (ns != s) FS_PUSH(i);                                   // interval size changes: [x, i) is a candidate
+			if (ns == 0) pass_end = true;                              // next pass opens at i (src/bwt.c:519)
+			else {
+				k = nk; l = nl; s = ns; ++i;
+				if (i == len) { FS_PUSH(i); pass_end = true; }          // reached the read end: push the last interval
+			}
+			if (pass_end) { cidx = nc - 1; cand_sum += (uint32_t)nc; ref_valid = false; st = FS_BINIT; }
+		}
+		bool keep = false;
+		cand_t o = {r, 0, 0, 0};
+		uint64_t ok = 0;
+		if (st == FS_BWD) {
+			if (want_rank) {
+				const uint64_t ol = base == 0 ? tk[0] : base == 1 ? tk[1] : base == 2 ? tk[2] : tk[3];
+				const uint64_t ou = base == 0 ? tl[0] : base == 1 ? tl[1] : base == 2 ? tl[2] : tl[3];
+				const uint64_t nl = fmd_L2(f, base) + ol + 1, nu = fmd_L2(f, base) + ou;
+				if (nl > nu) fin = true;
+				else {
+					const uint32_t nsz = (uint32_t)(nu - nl + 1);
+					if (nsz != size) p1 = bi;
+					k = nl; l = nu; size = nsz; beg = bi;
+					if (ref_valid && bi >= ref_b && bi <= ref_p1 && size == ref_s) { fin = true; merged = true; }
+					else { --bi; if (bi < 0) fin = true; }
+				}
+			}
+			if (fin) {
+				keep = !merged && (cend - beg >= min_seed_len) && !(ref_valid && beg == ref_b);
+				if (!merged) { ref_valid = true; ref_s = size; ref_p1 = p1; ref_b = beg; }
+				o.xe = ((uint32_t)beg << 16) | (uint32_t)cend; o.s = size; ok = k;
+				if (keep) occ_sum += size;
+				--cidx;
+				st = FS_BINIT;
+			}
+		}
+		cand_append(keep, o, ok, out_a, out_k, counter, cap, cc);
+	}
+#undef FS_PUSH
+	cand_fill_invalid(cc, out_a, cap);
+	// candidate count statistic: one atomic per wave
+	unsigned long long tot = cand_sum;
+	for (int off = 32; off; off >>= 1) tot += __shfl_down(tot, off);
+	if (lane == 0 && tot) atomicAdd(n_cand_total, tot);
+	if (lane == 0) { atomicAdd(n_cand_total + 3, n_iter); atomicAdd(n_cand_total + 4, n_rank); atomicAdd(n_cand_total + 5, 1ull); }
+}
+
+// sort key of an SMEM record: (read << 16) | end; fillers sort to the end
+__global__ void __launch_bounds__(256) smem_key_kernel(const cand_t *__restrict__ in_a, uint64_t n_list, uint64_t *__restrict__ keys,
+                                                       uint32_t *__restrict__ vals, unsigned long long *n_valid)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	bool v = false;
+	if (t < n_list) {
+		cand_t c = in_a[t];
+		v = c.read != CAND_INVALID;
+		keys[t] = v ? (((uint64_t)c.read << 16) | (c.xe & 0xFFFFu)) : ~0ull;
+		vals[t] = (uint32_t)t;
+	}
+	unsigned long long m = __ballot(v);
+	if (__lane_id() == 0 && m) atomicAdd(n_valid, (unsigned long long)__popcll(m));
+}
+
+// sorted order -> result arrays + occurrence counts
+__global__ void __launch_bounds__(256) smem_gather_kernel(const cand_t *__restrict__ in_a, const uint64_t *__restrict__ in_k,
+                                                          const uint32_t *__restrict__ vals, uint64_t n_valid, res_t *__restrict__ res_a,
+                                                          uint64_t *__restrict__ res_k, uint32_t *__restrict__ occ)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t > n_valid) return;
+	if (t == n_valid) { occ[t] = 0; return; }
+	const uint32_t src = vals[t];
+	const cand_t c = in_a[src];
+	res_t o = {c.read, c.xe, c.s, 0};
+	res_a[t] = o;
+	res_k[t] = in_k[src];
+	occ[t] = c.s;
+}
+
 // ---------------------------------------------------------------- host side
 
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
@@ -426,6 +634,8 @@ struct bmh_seed_ws {
 	uint64_t *rows; int2 *qbeg; uint32_t *score;   // [max_occ]
 	uint32_t *n_ref_pos, *prefix;       // [max_reads]
 	unsigned long long *counter;
+	uint4 *scratch; size_t scratch_entries;       // fused kernel: [slot][read] candidate columns
+	uint64_t *skeys, *skeys2; uint32_t *svals, *svals2;   // SMEM sort
 	void *scan_tmp; size_t scan_tmp_bytes;
 	hipEvent_t ev[8];
 	float ms[7];
@@ -450,11 +660,14 @@ extern "C" bmh_seed_ws_t *bmh_seed_ws_create(uint32_t max_reads, uint64_t max_ba
 	A(w->occ_off, 8 * (w->max_cands + 1)); A(w->keep_off, 8 * (w->max_cands + 1));
 	A(w->rows, 8 * w->max_occ); A(w->qbeg, 8 * w->max_occ); A(w->score, 4 * w->max_occ);
 	A(w->n_ref_pos, 4 * (size_t)max_reads); A(w->prefix, 4 * (size_t)max_reads);
-	A(w->counter, 16);
-	size_t t1 = 0, t2 = 0;
+	A(w->counter, 128);
+	A(w->skeys, 8 * w->max_cands); A(w->skeys2, 8 * w->max_cands); A(w->svals, 4 * w->max_cands); A(w->svals2, 4 * w->max_cands);
+	size_t t1 = 0, t2 = 0, t3 = 0;
+	rocprim::radix_sort_pairs(nullptr, t3, w->skeys, w->skeys2, w->svals, w->svals2, (size_t)w->max_cands, 0, 64, 0);
 	rocprim::exclusive_scan(nullptr, t1, w->n_cand, w->cand_base, 0u, (size_t)max_reads + 1, rocprim::plus<uint32_t>(), 0);
 	rocprim::exclusive_scan(nullptr, t2, w->occ, w->occ_off, (uint64_t)0, w->max_cands + 1, rocprim::plus<uint64_t>(), 0);
 	w->scan_tmp_bytes = t1 > t2 ? t1 : t2;
+	if (t3 > w->scan_tmp_bytes) w->scan_tmp_bytes = t3;
 	A(w->scan_tmp, w->scan_tmp_bytes + 256);
 #undef A
 	for (int i = 0; i < 8; ++i) ok = ok && hipEventCreate(&w->ev[i]) == hipSuccess;
@@ -466,7 +679,8 @@ extern "C" void bmh_seed_ws_free(bmh_seed_ws_t *w)
 {
 	if (!w) return;
 	void *ps[] = {w->pk, w->nm, w->cand_a, w->cand_k, w->res_a, w->res_k, w->n_cand, w->cand_base, w->occ, w->keep,
-	              w->occ_off, w->keep_off, w->rows, w->qbeg, w->score, w->n_ref_pos, w->prefix, w->counter, w->scan_tmp};
+	              w->occ_off, w->keep_off, w->rows, w->qbeg, w->score, w->n_ref_pos, w->prefix, w->counter, w->scan_tmp,
+	              w->scratch, w->skeys, w->skeys2, w->svals, w->svals2};
 	for (void *p : ps) if (p) (void)hipFree(p);
 	for (int i = 0; i < 8; ++i) if (w->ev[i]) (void)hipEventDestroy(w->ev[i]);
 	free(w);
@@ -515,6 +729,80 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 	{
 		const uint32_t lds_bytes = PACK_READS_PER_BLOCK * n_grp * 32 + 64;   // 64 reads of the longest length, + alignment slack
 		pack_reads_kernel<<<nblk(n_reads, PACK_READS_PER_BLOCK), 256, lds_bytes <= 65536 ? lds_bytes : 0, st>>>(d_reads, d_offs, d_lens, n_reads, n_grp, lds_bytes <= 65536 ? lds_bytes : 0, w->pk, w->nm);
+	}
+	// Two pipelines produce identical output (both are run by the GPU parity tests):
+	//   default      pack | forward | scan | scatter | backward (lane per candidate) | filter | scans | expand | locate
+	//   BMH_SEED_FUSED=1  pack | fused forward+backward (lane per read, persistent grid) | sort | scans | expand | locate
+	// The fused form moves ~15x fewer bytes between kernels but keeps fewer gathers in flight per CU; on MI355X
+	// both are bound by the random 32-byte gather rate and the split form is currently faster.
+	static const bool use_fused = getenv("BMH_SEED_FUSED") != nullptr;
+	if (use_fused) {
+		// ---- fused pipeline: pack | fused forward+backward | sort SMEMs by (read, end) | scans | expand | locate
+		const uint32_t depth = max_len >= (uint32_t)min_seed_len ? max_len - (uint32_t)min_seed_len + 1 : 1;
+		// persistent grid: as many 256-thread blocks as the chip keeps resident, never more than the reads need
+		static int blocks_per_cu = 0, n_cu = 0;
+		if (!blocks_per_cu) {
+			int dev = 0; hipDeviceProp_t prop;
+			HIPCK(hipGetDevice(&dev)); HIPCK(hipGetDeviceProperties(&prop, dev));
+			n_cu = prop.multiProcessorCount;
+			HIPCK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, smem_fused_kernel, 256, 0));
+			if (blocks_per_cu < 1) blocks_per_cu = 1;
+		}
+		unsigned grid = (unsigned)(n_cu * blocks_per_cu);
+		if (grid > nblk(n_reads, 256)) grid = nblk(n_reads, 256);
+		const size_t want = (size_t)depth * grid * 256;
+		if (want > w->scratch_entries) {
+			if (w->scratch) (void)hipFree(w->scratch);
+			w->scratch = nullptr; w->scratch_entries = 0;
+			HIPCK(hipMalloc((void **)&w->scratch, want * sizeof(uint4)));
+			w->scratch_entries = want;
+		}
+		HIPCK(hipEventRecord(w->ev[1], st));
+		HIPCK(hipMemsetAsync(w->counter, 0, 64, st));
+		smem_fused_kernel<<<grid, 256, 0, st>>>(f, rv, d_lens, min_seed_len, w->scratch, w->cand_a, w->cand_k, w->counter,
+		                                        w->max_cands, w->n_ref_pos, w->counter + 1, (unsigned int *)(w->counter + 3));
+		HIPCK(hipEventRecord(w->ev[2], st));
+		unsigned long long cnt[8] = {0};
+		HIPCK(hipMemcpyAsync(cnt, w->counter, 64, hipMemcpyDeviceToHost, st));
+		HIPCK(hipStreamSynchronize(st));
+		const unsigned long long n_list = cnt[0];
+		out->n_cands = cnt[1];
+		if (getenv("BMH_SEED_STATS")) fprintf(stderr, "[fused] grid %u blocks, waves %llu, wave-iterations %llu (%.0f per wave), rank requests %llu (%.1f per iteration), cands %llu\n", grid, cnt[6], cnt[4], (double)cnt[4] / (double)(cnt[6] ? cnt[6] : 1), cnt[5], (double)cnt[5] / (double)(cnt[4] ? cnt[4] : 1), cnt[1]);
+		if (n_list > w->max_cands) { bmh_set_error("bmh_seed_batch: %llu SMEM slots > capacity %llu", n_list, (unsigned long long)w->max_cands); return BMH_ECAPACITY; }
+		unsigned long long n_valid = 0;
+		if (n_list) {
+			smem_key_kernel<<<nblk(n_list, 256), 256, 0, st>>>(w->cand_a, n_list, w->skeys, w->svals, w->counter + 2);
+			size_t tb = w->scan_tmp_bytes;
+			HIPCK(rocprim::radix_sort_pairs(w->scan_tmp, tb, w->skeys, w->skeys2, w->svals, w->svals2, (size_t)n_list, 0, 64, st));
+			HIPCK(hipMemcpyAsync(&n_valid, w->counter + 2, 8, hipMemcpyDeviceToHost, st));
+			HIPCK(hipStreamSynchronize(st));
+		}
+		HIPCK(hipEventRecord(w->ev[3], st));
+		smem_gather_kernel<<<nblk(n_valid + 1, 256), 256, 0, st>>>(w->cand_a, w->cand_k, w->svals2, n_valid, w->res_a, w->res_k, w->occ);
+		{
+			size_t tb = w->scan_tmp_bytes;
+			HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->occ, w->occ_off, (uint64_t)0, (size_t)n_valid + 1, rocprim::plus<uint64_t>(), st));
+			tb = w->scan_tmp_bytes;
+			HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->n_ref_pos, w->prefix, 0u, (size_t)n_reads, rocprim::plus<uint32_t>(), st));
+		}
+		uint64_t tot = 0;
+		HIPCK(hipMemcpyAsync(&tot, w->occ_off + n_valid, 8, hipMemcpyDeviceToHost, st));
+		HIPCK(hipStreamSynchronize(st));
+		out->n_seeds = tot; out->n_smems = n_valid;
+		if (tot > w->max_occ) { bmh_set_error("bmh_seed_batch: %llu occurrences > capacity %llu", (unsigned long long)tot, (unsigned long long)w->max_occ); return BMH_ECAPACITY; }
+		if (tot >> 32) { bmh_set_error("bmh_seed_batch: more than 2^32 occurrences in one batch"); return BMH_ECAPACITY; }
+		HIPCK(hipEventRecord(w->ev[4], st));
+		if (n_valid)
+			expand_kernel<<<nblk(n_valid, 256), 256, 0, st>>>(w->res_a, w->res_k, w->occ, w->occ_off, n_valid, w->rows, w->qbeg, w->score);
+		HIPCK(hipEventRecord(w->ev[5], st));
+		if (tot)
+			locate_kernel<<<nblk(nblk(tot, LOCATE_PER_WAVE) * 64ull, 256), 256, 0, st>>>(f, w->rows, tot);
+		HIPCK(hipEventRecord(w->ev[6], st));
+		HIPCK(hipStreamSynchronize(st));
+		HIPCK(hipGetLastError());
+		for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&w->ms[i], w->ev[i], w->ev[i + 1]);
+		(void)hipEventElapsedTime(&w->ms[6], w->ev[0], w->ev[6]);
+		return BMH_OK;
 	}
 	HIPCK(hipEventRecord(w->ev[1], st));
 	HIPCK(hipMemsetAsync(w->counter, 0, 8, st));

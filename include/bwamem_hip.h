@@ -88,7 +88,8 @@ int bmh_seed_batch(bmh_seed_ws_t *ws, const bmh_index_t *idx, const uint8_t *d_r
                    int min_seed_len, void *stream, bmh_seeds_t *out);
 
 /* per-kernel time of the last bmh_seed_batch, in ms (HIP events on the launch stream):
- * [0]=pack [1]=forward [2]=backward [3]=filter+scans [4]=expand [5]=locate [6]=total */
+ * [0]=pack [1]=forward [2]=scatter+backward [3]=filter+scans [4]=expand [5]=locate [6]=total
+ * (with BMH_SEED_FUSED=1: [1]=fused forward+backward [2]=sort of the SMEMs [3]=gather+scans) */
 void bmh_seed_last_timing(const bmh_seed_ws_t *ws, float ms[7]);
 
 /* Calibration: n_lanes lanes each gather `iters` random 32-byte index blocks (dependent != 0:

@@ -184,17 +184,20 @@ def main():
             res["oracle_work_per_read"] = {k: round(v / cb["n"], 2) for k, v in cb["work"].items()}
             # algorithmic bytes per read, counted by the oracle on the sample
             wk, n = cb["work"], cb["n"]
-            per_read = {
-                "smem": 32.0 * (wk["n_blk_fwd"] + wk["n_blk_back"]) / n + a.read_len / 4 + 8,
-                "locate": (32.0 * wk["n_blk_lf"] + 4.0 * wk["n_sa"] + 20.0 * cb["n_seeds"]) / n,
-            }
+            fused = "smem" in stage_ms
+            per_read = {"locate": (32.0 * wk["n_blk_lf"] + 4.0 * wk["n_sa"] + 20.0 * cb["n_seeds"]) / n}
+            if fused:
+                per_read["smem"] = 32.0 * (wk["n_blk_fwd"] + wk["n_blk_back"]) / n + a.read_len / 4 + 8
+            else:
+                per_read["forward"] = 32.0 * wk["n_blk_fwd"] / n + a.read_len / 4 + 8
+                per_read["backward"] = 32.0 * wk["n_blk_back"] / n
             q, t = jobs.qlen.long(), jobs.tlen.long()
             ext_bytes = float(((q + 3) // 4 + (t + 3) // 4 + (q + t + 7) // 8 + 28).sum().item())
             kernel_bytes = {k: v * n_reads for k, v in per_read.items()}
             kernel_bytes["extend"] = ext_bytes
             dom = max(kernel_bytes.keys(), key=lambda k: stage_ms.get(k, 0.0))
             ach = kernel_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9
-            res["roofline"] = {"bound": "hbm", "kernel": {"smem": "smem_fused_kernel", "locate": "locate_kernel",
+            res["roofline"] = {"bound": "hbm", "kernel": {"smem": "smem_fused_kernel", "forward": "smem_forward_kernel", "backward": "smem_backward_kernel", "locate": "locate_kernel",
                                                            "extend": "extend16_kernel<*> (all classes, concurrent streams)"}[dom],
                                "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                                "traffic": None, "avg_ms": round(stage_ms[dom], 3),

@@ -40,7 +40,27 @@ def gpu_seed(B, idx, flat, offs, lens, min_seed_len=19):
     return out
 
 
-def test_seeding_matches_oracle_150bp(hip, oracle):
+@pytest.fixture(params=["split", "fused"])
+def pipeline(request):
+    """Both seeding pipelines of libbwamem_hip.so (the choice is read once per process, so the fused
+    one runs in a child process)."""
+    return request.param
+
+
+def _run_fused_child(test_name):
+    import os, subprocess, sys
+    env = dict(os.environ, BMH_SEED_FUSED="1", BMH_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__) + "::" + test_name + "[split]"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+def test_seeding_matches_oracle_150bp(hip, oracle, pipeline):
+    import os
+    if pipeline == "fused":
+        if os.environ.get("BMH_CHILD"):
+            pytest.skip("already inside the fused child")
+        return _run_fused_child("test_seeding_matches_oracle_150bp")
     g, idx = common.genome_and_index(300_000)
     reads, _ = hip.synth.make_reads(g, 4000, 150, seed=11)
     flat, offs, lens = common.flat_reads(reads)
@@ -50,7 +70,12 @@ def test_seeding_matches_oracle_150bp(hip, oracle):
     common.assert_seeds_equal(got, want)
 
 
-def test_seeding_edge_cases(hip, oracle):
+def test_seeding_edge_cases(hip, oracle, pipeline):
+    import os
+    if pipeline == "fused":
+        if os.environ.get("BMH_CHILD"):
+            pytest.skip("already inside the fused child")
+        return _run_fused_child("test_seeding_edge_cases")
     g, idx = common.genome_and_index(300_000)
     rows = common.edge_reads(g, np.random.default_rng(3))
     flat, offs, lens = common.ragged_reads(rows)

@@ -52,17 +52,16 @@ def cpu_baseline(g, idx, reads, sample: int, n_threads: int):
     t0 = time.time()
     s = orc.seed_reads(f, flat, offs, lens, 19, n_threads=n_threads)
     t_seed = time.time() - t0
-    # the same first-seed extension jobs as the GPU leg, built on the CPU from the oracle's seeds
-    dev = torch.device("cpu")
-    seeds = {k: torch.from_numpy(s[k].astype(np.int64) if s[k].dtype in (np.uint64, np.uint32) else s[k]) for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")}
-    seeds["qbeg"] = seeds["qbeg"].to(torch.int32); seeds["score"] = seeds["score"].to(torch.int32)
-    dr = P.DeviceReads(None, None, torch.from_numpy(lens.astype(np.int32)), torch.from_numpy(np.ascontiguousarray(sub)))
-    jobs = P.first_seed_jobs(seeds, dr, torch.from_numpy(g))
-    arr = [x.numpy().astype(np.uint32) if x.dtype == torch.int32 else x.numpy() for x in (jobs.q, jobs.qoff, jobs.qlen, jobs.t, jobs.toff, jobs.tlen, jobs.h0)]
+    # the same extension jobs as the GPU leg (host job builder on the oracle's seeds; untimed on both legs)
+    from bwamem_hip.lib import HostJobs
+    hj = HostJobs(g, flat, offs, lens, s)
+    arr = [x.copy() for x in hj.jobs()]
+    n_jobs = hj.n_jobs
+    hj.free()
     t0 = time.time()
     _, _, cells = orc.extend_batch(*arr, n_threads=n_threads)
     t_ext = time.time() - t0
-    return dict(t_seed=t_seed, t_ext=t_ext, n=sub.shape[0], work=s["work"], cells=cells, n_jobs=jobs.n,
+    return dict(t_seed=t_seed, t_ext=t_ext, n=sub.shape[0], work=s["work"], cells=cells, n_jobs=n_jobs,
                 n_seeds=int(len(s["rbeg"])))
 
 
@@ -107,10 +106,17 @@ def main():
     n_reads = dr.n
     ws = B.SeedWorkspace(n_reads, n_reads * a.read_len)
     s = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19)
-    seeds = P.seeds_to_torch(s, n_reads, dev)
-    gdev = torch.from_numpy(g).to(dev)
-    jobs = P.first_seed_jobs(seeds, dr, gdev)
-    del gdev, seeds
+    # extension jobs of the batch: the host job builder (chain -> chain_flt -> chain2aln restatement, parity-checked
+    # against the reference's own host code) on all host cores, then uploaded; untimed, like the reference's host stage
+    from bwamem_hip.lib import HostJobs, seeds_to_host
+    t0 = time.time()
+    flat = reads.reshape(-1)
+    hj = HostJobs(g, flat, np.arange(n_reads, dtype=np.uint64) * a.read_len, np.full(n_reads, a.read_len, np.uint32), seeds_to_host(s, n_reads))
+    t_jobs = time.time() - t0
+    jobs = P.ExtJobs(*[torch.from_numpy(np.ascontiguousarray(x).view(np.int32) if x.dtype == np.uint32 else np.ascontiguousarray(x)).to(dev)
+                       for x in hj.jobs()], torch.from_numpy(hj.job_read.view(np.int32).copy()).to(dev), torch.from_numpy(hj.job_side.view(np.int32).copy()).to(dev))
+    n_regs = hj.n_regs
+    hj.free()
     out = torch.zeros(max(jobs.n, 1), 3, dtype=torch.int32, device=dev)
     params = B.ExtParams.default()
     L = B.load_library()
@@ -165,10 +171,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{a.reads_per_gpu} synthetic {a.read_len} bp single-end reads per GPU vs seeded synthetic "
                                    f"{a.genome_mbp:g} Mbp genome (hg38 stand-in: uniform + 10% diverged repeat families); "
-                                   "seeding = all SMEMs >= 19 bp + locate; extension = left/right jobs of each read's longest seed",
+                                   "seeding = all SMEMs >= 19 bp + locate; extension = every left/right job the reference's chaining (mem_chain, mem_chain_flt, mem_chain2aln) produces",
                        "reads_per_gpu": n_reads, "read_len": a.read_len, "genome_mbp": a.genome_mbp,
                        "index_bytes": int(bwt_t.numel() * 4 + sa_t.numel() * 4 + bits_t.numel() * 4),
-                       "ext_jobs_per_gpu": jobs.n, "seeds_per_gpu": int(s.n_seeds), "min_seed_len": 19,
+                       "ext_jobs_per_gpu": jobs.n, "regions_per_gpu": n_regs, "host_job_build_s": round(t_jobs, 2), "seeds_per_gpu": int(s.n_seeds), "min_seed_len": 19,
                        "scoring": "a1 b4 o6 e1 clip5 zdrop0", "streams": "seeding || extension" if a.overlap else "single", "index_build_s": round(t_index, 2)},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         }

@@ -23,6 +23,7 @@ EXPORTED_SYMBOLS = [
     "bmh_last_error", "bmh_device_count", "bmh_set_device", "bmh_index_upload", "bmh_index_from_device",
     "bmh_index_free", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
     "bmh_extend_batch", "bmh_extend_last_ms", "bmh_calib_gather",
+    "bmh_chain_opt_default", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
     "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
     "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
 ]
@@ -41,6 +42,12 @@ class ExtParams(C.Structure):
     @classmethod
     def default(cls, zdrop: int = 0) -> "ExtParams":
         return cls(1, 4, 6, 1, 6, 1, zdrop, 5)
+
+
+class ChainOpt(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "w", "min_seed_len", "max_occ",
+                                       "max_chain_gap", "min_chain_weight", "max_chain_extend")] + \
+               [("mask_level", C.c_float), ("drop_ratio", C.c_float)]
 
 
 # mirrors of include/seed_gen.h
@@ -97,6 +104,15 @@ def load_library() -> C.CDLL:
     L.bmh_extend_last_ms.restype = C.c_float
     L.bmh_calib_gather.restype = C.c_int
     L.bmh_calib_gather.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+    L.bmh_chain_opt_default.argtypes = [C.POINTER(ChainOpt)]
+    L.bmh_build_jobs.restype = C.c_void_p
+    L.bmh_build_jobs.argtypes = [C.POINTER(ChainOpt), C.c_int64, _u8p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, _u8p, _u64p, _u32p,
+                                 _u64p, _i32p, _u32p, _u32p, _u32p, C.c_int]
+    L.bmh_jobs_free.argtypes = [C.c_void_p]
+    L.bmh_jobs_sizes.argtypes = [C.c_void_p, _u64p, _u64p, _u64p, _u64p]
+    L.bmh_jobs_arrays.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 11
+    L.bmh_merge_regs.restype = C.c_int
+    L.bmh_merge_regs.argtypes = [C.c_void_p, _i32p, _i32p]
     L.bwt_restore_bwt_gpu.restype = C.POINTER(BwtTGpu)
     L.bwt_restore_bwt_gpu.argtypes = [C.c_char_p]
     L.bwt_restore_sa_gpu.argtypes = [C.c_char_p, C.POINTER(BwtTGpu)]
@@ -255,3 +271,59 @@ def seed_file(index_prefix: str, read_file: str, min_seed_len: int = 19) -> dict
         libc.free(C.cast(p, C.c_void_p))
     libc.free(C.cast(res, C.c_void_p))
     return out
+
+
+class HostJobs:
+    """Host job builder (bmh_build_jobs): chains -> filtered chains -> extension jobs, per read."""
+
+    def __init__(self, genome_fwd: np.ndarray, reads: np.ndarray, read_offs: np.ndarray, read_lens: np.ndarray, seeds: dict,
+                 n_threads: int = 0, opt: "ChainOpt | None" = None):
+        L = load_library()
+        self.L = L
+        o = opt or ChainOpt()
+        if opt is None:
+            L.bmh_chain_opt_default(C.byref(o))
+        l_pac = int(genome_fwd.shape[0])
+        pad = (-l_pac) % 4
+        codes = np.concatenate([genome_fwd, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+        pac = np.ascontiguousarray(((codes[:, 0] << 6) | (codes[:, 1] << 4) | (codes[:, 2] << 2) | codes[:, 3]).astype(np.uint8))
+        a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)
+        self._keep = [pac, a(reads, np.uint8), a(read_offs, np.uint64), a(read_lens, np.uint32), a(seeds["rbeg"], np.uint64),
+                      a(seeds["qbeg"], np.int32), a(seeds["score"], np.uint32), a(seeds["n_ref_pos"], np.uint32), a(seeds["prefix"], np.uint32)]
+        k = self._keep
+        self.h = L.bmh_build_jobs(C.byref(o), l_pac, _np_ptr(k[0], _u8p), 1, None, None, len(k[3]), _np_ptr(k[1], _u8p),
+                                  _np_ptr(k[2], _u64p), _np_ptr(k[3], _u32p), _np_ptr(k[4], _u64p), _np_ptr(k[5], _i32p),
+                                  _np_ptr(k[6], _u32p), _np_ptr(k[7], _u32p), _np_ptr(k[8], _u32p), n_threads or (os.cpu_count() or 1))
+        if not self.h:
+            raise RuntimeError("bmh_build_jobs: " + _err(L))
+        sz = [C.c_uint64() for _ in range(4)]
+        L.bmh_jobs_sizes(self.h, *[C.byref(x) for x in sz])
+        self.n_jobs, self.n_regs, qb, tb = (int(x.value) for x in sz)
+        ptrs = [C.c_void_p() for _ in range(11)]
+        L.bmh_jobs_arrays(self.h, *[C.byref(p) for p in ptrs])
+
+        def view(p, n, dt):
+            if n == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8 if dt == np.uint8 else C.c_uint32)), shape=(n,)).view(dt)
+        nj = self.n_jobs
+        self.q = view(ptrs[0], qb, np.uint8); self.qoff = view(ptrs[1], nj, np.uint32); self.qlen = view(ptrs[2], nj, np.uint32)
+        self.t = view(ptrs[3], tb, np.uint8); self.toff = view(ptrs[4], nj, np.uint32); self.tlen = view(ptrs[5], nj, np.uint32)
+        self.h0 = view(ptrs[6], nj, np.uint32); self.job_read = view(ptrs[7], nj, np.uint32); self.job_reg = view(ptrs[8], nj, np.uint32)
+        self.job_side = view(ptrs[9], nj, np.uint32); self.regs_per_read = view(ptrs[10], len(k[3]), np.uint32)
+
+    def jobs(self):
+        q = self.q if self.q.size else np.zeros(1, np.uint8)
+        t = self.t if self.t.size else np.zeros(1, np.uint8)
+        return q, self.qoff, self.qlen, t, self.toff, self.tlen, self.h0
+
+    def merge(self, out3: np.ndarray) -> np.ndarray:
+        out3 = np.ascontiguousarray(out3, dtype=np.int32)
+        regs = np.zeros((max(self.n_regs, 1), 8), np.int32)
+        self.L.bmh_merge_regs(self.h, _np_ptr(out3, _i32p), _np_ptr(regs, _i32p))
+        return regs[: self.n_regs]
+
+    def free(self):
+        if self.h:
+            self.L.bmh_jobs_free(self.h)
+            self.h = None

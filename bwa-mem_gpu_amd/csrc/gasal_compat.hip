@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include "bmh_internal.h"
 #include "../../include/gasal2_root/GASAL2/include/gasal.h"
 #include "../../include/gasal2_root/GASAL2/include/args_parser.h"
@@ -202,6 +203,23 @@ void gasal_aln_async(gasal_gpu_storage_t *s, const uint32_t qb, const uint32_t t
 	if (n > s->host_max_n_alns) FATAL("gasal_aln_async: %u alignments > host_max_n_alns %u", n, s->host_max_n_alns);
 	if (qb > s->extensible_host_unpacked_query_batch->data_size || tb > s->extensible_host_unpacked_target_batch->data_size)
 		FATAL("gasal_aln_async: batch bytes beyond what was filled");
+	// BMH_GASAL_DUMP=<file>: append every submitted job (qlen, tlen, h0, bases) -- lets tests compare the job
+	// stream of the reference's own host code with bmh_build_jobs
+	static const char *dump = getenv("BMH_GASAL_DUMP");
+	if (dump) {
+		static std::mutex mu;
+		std::lock_guard<std::mutex> lk(mu);
+		FILE *f = fopen(dump, "ab");
+		if (f) {
+			for (uint32_t i = 0; i < n; ++i) {
+				uint32_t h[3] = {s->host_query_batch_lens[i], s->host_target_batch_lens[i], s->host_seed_scores[i]};
+				fwrite(h, 4, 3, f);
+				fwrite(s->extensible_host_unpacked_query_batch->data + s->host_query_batch_offsets[i], 1, h[0], f);
+				fwrite(s->extensible_host_unpacked_target_batch->data + s->host_target_batch_offsets[i], 1, h[1], f);
+			}
+			fclose(f);
+		}
+	}
 	dev_reserve(m, qb, tb, n);
 	hipStream_t st = m->stream;
 	HIPX(hipMemcpyAsync(m->d_q, s->extensible_host_unpacked_query_batch->data, qb, hipMemcpyHostToDevice, st));

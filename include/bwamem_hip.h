@@ -124,6 +124,39 @@ int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, const uint32_t 
  * bmh_extend_batch (HIP events on that call's stream; waits for them). */
 float bmh_extend_last_ms(void);
 
+/* ------------------------------------------------- host job builder */
+
+/* The options of mem_opt_t this stage reads; bmh_chain_opt_default() = mem_opt_init()
+ * (src/bwamem.c:101-146). */
+typedef struct {
+	int a, b, o_del, e_del, o_ins, e_ins, w;
+	int min_seed_len, max_occ, max_chain_gap, min_chain_weight, max_chain_extend;
+	float mask_level, drop_ratio;
+} bmh_chain_opt_t;
+void bmh_chain_opt_default(bmh_chain_opt_t *o);
+
+/* seeds (host copies of the mem_seed_v_gpu arrays) -> chains -> filtered chains -> extension jobs,
+ * restating mem_chain / mem_chain_flt / mem_chain2aln (src/bwamem.c:404-477, 487-559, 1170-1479).
+ * reads: nt4 codes; pac: 2-bit forward strand (the .pac file body); contigs: n_contigs offsets/lens
+ * (n_contigs <= 1: one sequence of l_pac bases).  Jobs come out per read, per region, LEFT then RIGHT. */
+typedef struct bmh_jobs bmh_jobs_t;
+bmh_jobs_t *bmh_build_jobs(const bmh_chain_opt_t *opt, int64_t l_pac, const uint8_t *pac, int n_contigs,
+                           const int64_t *contig_offset, const int32_t *contig_len, uint32_t n_reads,
+                           const uint8_t *reads, const uint64_t *read_offs, const uint32_t *read_lens,
+                           const uint64_t *rbeg, const int32_t *qbeg, const uint32_t *score,
+                           const uint32_t *n_ref_pos, const uint32_t *prefix, int n_threads);
+void bmh_jobs_free(bmh_jobs_t *j);
+void bmh_jobs_sizes(const bmh_jobs_t *j, uint64_t *n_jobs, uint64_t *n_regs, uint64_t *q_bytes, uint64_t *t_bytes);
+/* borrowed pointers into the job batch (valid until bmh_jobs_free): the bmh_extend_batch inputs, the
+ * read / region / side (0 left, 1 right) of every job, and the number of regions of every read */
+void bmh_jobs_arrays(const bmh_jobs_t *j, const uint8_t **q, const uint32_t **qoff, const uint32_t **qlen,
+                     const uint8_t **t, const uint32_t **toff, const uint32_t **tlen, const uint32_t **h0,
+                     const uint32_t **job_read, const uint32_t **job_reg, const uint32_t **job_side,
+                     const uint32_t **regs_per_read);
+/* extension results -> alignment regions (src/bwamem.c:2297-2303): regs_out[n_regs][8] =
+ * {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi} */
+int bmh_merge_regs(const bmh_jobs_t *j, const int32_t *out3, int32_t *regs_out);
+
 #ifdef __cplusplus
 }
 #endif

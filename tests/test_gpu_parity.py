@@ -185,3 +185,17 @@ def test_reference_gase_aln_end_to_end(hip, tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     out = r.stdout.decode()
     assert r.returncode == 0 and "E2E DROP-IN OK" in out, out[-3000:]
+
+
+def test_host_job_builder_matches_reference_host_code(hip, tmp_path):
+    """bmh_build_jobs (chain -> chain_flt -> chain2aln restatement) vs the job stream the REFERENCE's own host
+    code submits (build/dropin/bwa-gasal2 with BMH_GASAL_DUMP), and best region score vs the SAM AS tag."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "build", "dropin", "bwa-gasal2")):
+        pytest.skip("build/dropin/bwa-gasal2 not built (needs /root/reference at build time)")
+    for args in (["1500000", "3000", "150"], ["1500000", "1500", "300"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_jobs_vs_reference.py"), str(tmp_path)] + args,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        out = r.stdout.decode()
+        assert r.returncode == 0 and "JOBS VS REFERENCE OK" in out, out[-3000:]

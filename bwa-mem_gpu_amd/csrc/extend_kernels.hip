@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <map>
 #include <mutex>
@@ -65,6 +66,7 @@ struct ext_args_t {
 	const uint32_t *count;        // how many
 	int32_t *out, *raw;
 	int a, b, o_del, e_del, o_ins, e_ins, zdrop, end_bonus;
+	unsigned long long *stats;    // debug (BMH_EXT_STATS): [0] rows executed, [1] sum of tlen, [2] alignments, [3] wave-rows
 };
 
 template <int C>
@@ -238,6 +240,29 @@ __device__ __forceinline__ int row_allmax_pk(int v)
 	return v;
 }
 
+// fused DPP forms: one VALU op per step (dst = max(dst, dpp(dst))), wait states for the VALU-write ->
+// DPP-read hazard inside the string (hipcc does not pad inline asm)
+__device__ __forceinline__ int row_allmax_f(int v)
+{
+	asm volatile("s_nop 1\n\t"
+	             "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+	             : "+v"(v));
+	return v;
+}
+__device__ __forceinline__ int row_scan_max_f(int v)     // inclusive; lanes without a source keep their value
+{
+	asm volatile("s_nop 1\n\t"
+	             "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+	             : "+v"(v));
+	return v;
+}
+
 template <int C>
 __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 {
@@ -247,115 +272,131 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 	const uint32_t n = A.count[0];
 	const uint32_t *ids = A.ids + A.count[1];
 	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;
-	const int j0 = l16 * C;                           // first column of this lane
+	const int j0 = l16 * C;                                    // first column of this lane
+	const int ej0 = A.e_ins * j0;
+	const int bp_base = (lane & 48) << 2;                      // byte address of this row's lane 0 for ds_bpermute
 	for (uint32_t w = wave * 4; w < n; w += n_waves * 4) {
 		const bool have = w + grp < n;
 		const uint32_t id = have ? ids[w + grp] : 0;
 		const int qlen = have ? (int)A.qlen[id] : 0, tlen = have ? (int)A.tlen[id] : 0, h0 = have ? (int)A.h0[id] : 1;
 		const uint8_t *qp = A.q + (have ? A.qoff[id] : 0), *tp = A.t + (have ? A.toff[id] : 0);
-		int H[C], E[C], qb[C];
+		// column state; query N is code 4, target N is made 5 below so that N never "matches" (mat[4][4] = -1, bwa.c:99-108)
+		int H[C], E[C], qb[C], mm[C];
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			const int j = j0 + c;
 			qb[c] = j < qlen ? (int)qp[j] : 4;
+			mm[c] = qb[c] > 3 ? -1 : -A.b;                   // mismatch score of this column
 			const int v = h0 - oe_ins - j * A.e_ins;
 			H[c] = (j < qlen && v > 0) ? v : 0;
 			E[c] = 0;
 		}
+		const int jl = qlen - 1, jl_lane = bp_base + (((jl < 0 ? 0 : jl) / C) << 2), jl_c = (jl < 0 ? 0 : jl) % C;
 		int beg = 0, end = qlen, mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
 		bool alive = have;
-		int tchunk = 4;
+		int tchunk = 5;
+		int rows_done = 0, wave_rows = 0;
 		for (int i = 0; __any(alive && i < tlen); ++i) {
-			if ((i & 15) == 0) tchunk = (alive && i + l16 < tlen) ? (int)tp[i + l16] : 4;
-			const int ti = __shfl(tchunk, (lane & 48) | (i & 15));
+			++wave_rows;
+			if ((i & 15) == 0) { const int tb = (alive && i + l16 < tlen) ? (int)tp[i + l16] : 5; tchunk = tb > 3 ? 5 : tb; }
+			const int ti = __builtin_amdgcn_ds_bpermute(bp_base + ((i & 15) << 2), tchunk);
 			const bool run = alive && i < tlen;
-			const int hm1 = i == 0 ? h0 : max(0, h0 - (A.o_del + A.e_del * i));
+			rows_done += run ? 1 : 0;
+			const int dsub = i == 0 ? 0 : A.o_del + A.e_del * i;          // wave-uniform
+			const int hm1 = max(0, h0 - dsub);
 			const int left = row_shr1(H[C - 1], beg == 0 ? hm1 : 0);
 			const unsigned wdt = (unsigned)(end - beg);
+			const int jb0 = j0 - beg;
+			const bool tN = ti > 3;
 			int M[C], g[C];
+			bool act[C];
 			int agg = NEG_INF;
 #pragma unroll
 			for (int c = 0; c < C; ++c) {
-				const int j = j0 + c;
-				const bool act = run && (unsigned)(j - beg) < wdt;
+				act[c] = run && (unsigned)(jb0 + c) < wdt;
 				const int hd = c == 0 ? left : H[c - 1];
-				const int sc = (ti > 3 || qb[c] > 3) ? -1 : (ti == qb[c] ? A.a : -A.b);
-				const int m = (act && hd) ? hd + sc : 0;
+				const int sc = ti == qb[c] ? A.a : (tN ? -1 : mm[c]);
+				const int m = (act[c] && hd != 0) ? hd + sc : 0;
 				M[c] = m;
-				g[c] = act ? max(m - oe_ins, 0) + A.e_ins * j : NEG_INF;
+				g[c] = act[c] ? max(m - oe_ins, 0) + (ej0 + A.e_ins * c) : NEG_INF;
 				agg = max(agg, g[c]);
 			}
-			int runmax = row_shr1(row_scan_max(agg), NEG_INF);
-			int key = 0;                                 // (h << 16) | column: row maximum with last-column tie-break
-			int fl = (int)0x80008000;                    // packed {hi: -first index, lo: last index}, both "none"
+			int runmax = row_shr1(row_scan_max_f(agg), NEG_INF);
+			int key = 0;                                        // (h << 16) | column: row maximum, last column on ties
+			int fl = (int)0x80008000;                           // packed {hi: -(first non-zero H column), lo: last non-zero H column}
+			int efirst = 0;                                     // E of this lane's first non-zero H column
 #pragma unroll
 			for (int c = 0; c < C; ++c) {
 				const int j = j0 + c;
-				const bool act = run && (unsigned)(j - beg) < wdt;
-				const int f = max(0, runmax - A.e_ins * (j - 1));
+				const int f = max(0, runmax - (ej0 + A.e_ins * (c - 1)));
 				runmax = max(runmax, g[c]);
-				int h = max(max(M[c], E[c]), f);
-				int e = max(E[c] - A.e_del, max(M[c] - oe_del, 0));
-				h = act ? h : 0;
-				e = act ? e : 0;
+				const int h = act[c] ? max(max(M[c], E[c]), f) : 0;
+				const int e = act[c] ? max(max(E[c] - A.e_del, M[c] - oe_del), 0) : 0;
 				H[c] = h; E[c] = e;
-				if (act) key = max(key, (h << 16) | j);
-				// eh index j+1 is non-zero through H(i,j), index j through E(i+1,j)
-				if (h) fl = pk_max(fl, ((-(j + 1)) << 16) | (j + 1));
-				if (e) fl = pk_max(fl, ((-j) << 16) | (j & 0xFFFF));
+				key = max(key, act[c] ? ((h << 16) | j) : 0);
+				// E(i+1,j) != 0 implies H(i,j) != 0 (H >= E(i,j) and H >= M), so the non-zero span of eh[] follows
+				// from the non-zero H columns alone: last index = last column + 1, first = first column (+1 if its E is 0)
+				const int pk = ((-j) << 16) | j;
+				const bool nzh = h != 0;
+				efirst = (nzh && fl == (int)0x80008000) ? e : efirst;
+				fl = nzh ? pk_max(fl, pk) : fl;
 			}
-			key = row_allmax(key);
+			key = row_allmax_f(key);
 			const int m = key >> 16, mj = key & 0xFFFF;
 			// gscore: H(i, qlen-1) when the row reaches the query end (ksw.c:942-945)
 			{
-				const int jl = qlen - 1;
-				int src = 0;
+				int src = H[0];
 #pragma unroll
-				for (int c = 0; c < C; ++c) if (jl % C == c) src = H[c];
-				int h1 = __shfl(src, (lane & 48) | ((jl < 0 ? 0 : jl) / C));
-				if (qlen == 0) h1 = beg == 0 ? max(0, h0 - (A.o_del + A.e_del * (i + 1))) : 0;
-				if (run && end == qlen) {
-					if (!(gscore > h1)) max_ie = i;
-					gscore = max(gscore, h1);
-				}
+				for (int c = 1; c < C; ++c) src = jl_c == c ? H[c] : src;
+				int h1 = __builtin_amdgcn_ds_bpermute(jl_lane, src);
+				h1 = qlen == 0 ? (beg == 0 ? max(0, h0 - (A.o_del + A.e_del * (i + 1))) : 0) : h1;
+				const bool ge = run && end == qlen;
+				max_ie = (ge && !(gscore > h1)) ? i : max_ie;
+				gscore = ge ? max(gscore, h1) : gscore;
 			}
 			const bool upd = run && m != 0;
-			if (run && m == 0) alive = false;              // ksw.c:946
-			if (upd) {
-				if (m > mx) {
-					mx = m; max_i = i; max_j = mj;
-					max_off = max(max_off, abs(mj - i));
-				} else if (A.zdrop > 0) {
-					const int di = i - max_i, dj = mj - max_j;
-					const int pen = di > dj ? (di - dj) * A.e_del : (dj - di) * A.e_ins;
-					if (mx - m - pen > A.zdrop) alive = false;
-				}
+			alive = alive && !(run && m == 0);                  // ksw.c:946
+			const bool better = upd && m > mx;
+			max_off = better ? max(max_off, abs(mj - i)) : max_off;
+			max_i = better ? i : max_i;
+			max_j = better ? mj : max_j;
+			if (A.zdrop > 0) {                                  // wave-uniform branch (ksw.c:951-959)
+				const int di = i - max_i, dj = mj - max_j;
+				const int pen = di > dj ? (di - dj) * A.e_del : (dj - di) * A.e_ins;
+				alive = alive && !(upd && !better && mx - m - pen > A.zdrop);
 			}
-			fl = row_allmax_pk(fl);
+			mx = better ? m : mx;
+			// next row's [beg,end) (ksw.c:963-970): first / last non-zero of eh[beg..end]
 			{
+				// this lane's candidate for the first index: its first non-zero H column, +1 if E there is 0
+				const int myfirst = -(fl >> 16) + (efirst == 0 ? 1 : 0);
+				const int packed = fl == (int)0x80008000 ? fl : ((((-myfirst) << 16)) | ((fl & 0xFFFF) + 1));
+				const int red = row_allmax_pk(packed);
 				const int h1i = beg == 0 ? max(0, h0 - (A.o_del + A.e_del * (i + 1))) : 0;
-				int fidx = -(fl >> 16), lidx = (int)(short)(fl & 0xFFFF);
-				if ((fl >> 16) == (int)(short)0x8000) fidx = 1 << 20;          // no non-zero entry
-				if (lidx == (int)(short)0x8000) lidx = -1;
-				if (h1i) { fidx = min(fidx, beg); lidx = max(lidx, beg); }
+				const bool none = (red >> 16) == (int)(short)0x8000;
+				int fidx = none ? (1 << 20) : -(red >> 16);
+				int lidx = none ? -1 : (int)(short)(red & 0xFFFF);
+				fidx = h1i ? min(fidx, beg) : fidx;
+				lidx = h1i ? max(lidx, beg) : lidx;
 				const int nbeg = min(fidx, end);
 				const int nend = min(qlen, max(lidx, nbeg - 1) + 2);
-				if (upd) { beg = nbeg; end = nend; }
+				beg = upd ? nbeg : beg;
+				end = upd ? nend : end;
 			}
-			// Exact early stop.  Phi(v at column c) = v + a*(qlen-1-c) never increases along a DP
-			// transition (diagonal: +s <= +a and one column right; E: same column, minus a gap
-			// cost; F: right, minus a gap cost), so every H of every later row is <= U = max Phi
-			// over this row's frontier {H(i,j), E(i+1,j), first-column value}.  Once U <= max and
-			// U < gscore no later row can change max/max_i/max_j/max_off (strict >, ksw.c:948) nor
-			// gscore/max_ie (>=, ksw.c:943): the remaining rows are dead work.  Checked every 4 rows.
+			// Exact early stop.  Phi(v at column c) = v + a*(qlen-1-c) never increases along a DP transition
+			// (diagonal: +s <= +a and one column right; E: same column minus a gap cost; F: right minus a gap
+			// cost), so every H of every later row is <= U = max Phi over this row's frontier {H(i,j), E(i+1,j),
+			// first-column value}.  Once U <= max and U < gscore no later row can change max/max_i/max_j/max_off
+			// (strict >, ksw.c:948) nor gscore/max_ie (>=, ksw.c:943): the remaining rows are dead work.
 			if ((i & 3) == 3) {
+				const int aq = A.a * (qlen - 1 - j0);
 				int u = 0;
 #pragma unroll
-				for (int c = 0; c < C; ++c) u = max(u, max(H[c], E[c]) + A.a * (qlen - 1 - (j0 + c)));
+				for (int c = 0; c < C; ++c) u = max(u, max(H[c], E[c]) + (aq - A.a * c));
 				const int h1n = beg == 0 ? max(0, h0 - (A.o_del + A.e_del * (i + 1))) : 0;
 				u = max(u, h1n + A.a * qlen);
-				u = row_allmax(u);
-				if (u <= mx && u < gscore) alive = false;
+				u = row_allmax_f(u);
+				alive = alive && !(u <= mx && u < gscore);
 			}
 		}
 		if (have && l16 == 0) {
@@ -367,6 +408,7 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 				int32_t *r = A.raw + 6 * (size_t)id;
 				r[0] = mx; r[1] = qle; r[2] = tle; r[3] = gtle; r[4] = gscore; r[5] = max_off;
 			}
+			if (A.stats) { atomicAdd(A.stats, (unsigned long long)rows_done); atomicAdd(A.stats + 1, (unsigned long long)tlen); atomicAdd(A.stats + 2, 1ull); if (grp == 0) atomicAdd(A.stats + 3, (unsigned long long)wave_rows); }
 		}
 	}
 }
@@ -512,6 +554,14 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 	a.ids = g_scr.vals2; a.count = g_scr.counts; a.out = d_out; a.raw = d_raw;
 	a.a = p->a; a.b = p->b; a.o_del = p->o_del; a.e_del = p->e_del; a.o_ins = p->o_ins; a.e_ins = p->e_ins;
 	a.zdrop = p->zdrop; a.end_bonus = p->end_bonus;
+	a.stats = nullptr;
+	static const bool want_stats = getenv("BMH_EXT_STATS") != nullptr;
+	static unsigned long long *d_stats = nullptr;
+	if (want_stats) {
+		if (!d_stats) HIPCK(hipMalloc((void **)&d_stats, 64));
+		HIPCK(hipMemsetAsync(d_stats, 0, 64, st));
+		a.stats = d_stats;
+	}
 	// class sizes stay on the device (no host sync): every class kernel is launched with a grid
 	// that covers the whole batch and its waves stride over the class's slice of the sorted list
 	unsigned g16 = (unsigned)((n + 15) / 16), gw = (unsigned)((n + 3) / 4);
@@ -532,5 +582,11 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 	for (int i = 0; i < 4; ++i) { HIPCK(hipEventRecord(g_scr.join[i], g_scr.side[i])); HIPCK(hipStreamWaitEvent(st, g_scr.join[i], 0)); }
 	HIPCK(hipEventRecord(g_scr.ev1, st));
 	HIPCK(hipGetLastError());
+	if (want_stats) {
+		unsigned long long h[4];
+		HIPCK(hipStreamSynchronize(st));
+		HIPCK(hipMemcpy(h, d_stats, 32, hipMemcpyDeviceToHost));
+		fprintf(stderr, "[ext] alignments %llu, rows executed %llu of %llu target rows (%.1f%%), wave-rows %llu (%.2f alignments per wave-row)\n", h[2], h[0], h[1], 100.0 * h[0] / (h[1] ? h[1] : 1), h[3], (double)h[0] / (h[3] ? h[3] : 1));
+	}
 	return BMH_OK;
 }

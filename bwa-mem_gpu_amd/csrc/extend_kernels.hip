@@ -413,10 +413,74 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 	}
 }
 
+
+// ------------------------------------------------------------------ closed-form prefilter
+
+// Closed form for flanks with at most ONE substitution and no gap.  Let the only mismatch sit at column p
+// (none: p = qlen) and target[0..qlen) otherwise equal query[0..qlen), no N.  The diagonal cell of row i holds
+//   D(i) = h0 + (i+1)a  for i < p,      D(i) = h0 + i*a - b  for i >= p        (needs h0 + p*a - b > 0),
+// while any other cell of row i lies on a path with at least one gap (cost >= min(oe_del, oe_ins)) and at most
+// i+1 matches, i.e. is <= h0 + (i+1)a - min(oe) < D(i) as long as a + b < min(oe_del, oe_ins).  So the diagonal
+// is the strict, unique maximum of every row (mj = i, max_off = 0), the row maxima are D(i), the running
+// maximum is updated exactly where D exceeds its previous values, row qlen-1 has end == qlen and gives
+// gscore = D(qlen-1) with no later tie (a later H(i,qlen-1) <= h0 + qlen*a - oe_del < D(qlen-1)).  The DP's
+// outputs follow without running it.  A flank starts right after a maximal exact match, so its first base is
+// usually the mismatch that ended the seed: about half of the 150 bp jobs at 1 % error have no second one.
+// One 16-lane row per job; jobs decided here get done[id] = 1 and never reach the DP kernels.
+__global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint32_t n, uint8_t *__restrict__ done)
+{
+	const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;
+	const int min_oe = oe_del < oe_ins ? oe_del : oe_ins;
+	for (uint32_t w = wave * 4; w < n; w += n_waves * 4) {
+		const uint32_t id = w + grp;
+		const bool have = id < n;
+		const int qlen = have ? (int)A.qlen[id] : 0, tlen = have ? (int)A.tlen[id] : 0, h0 = have ? (int)A.h0[id] : 1;
+		const uint8_t *qp = A.q + (have ? A.qoff[id] : 0), *tp = A.t + (have ? A.toff[id] : 0);
+		// z-drop (ksw.c:951-959) sees max - m = b at the mismatch row: it must not fire there
+		const bool elig = have && qlen > 0 && tlen >= qlen && A.a > 0 && A.a + A.b < min_oe && (A.zdrop <= 0 || A.b <= A.zdrop);
+		int hi = -1, lo = -0x7000;          // largest / (negated) smallest mismatching column seen by this lane
+		for (int j = l16; __any(elig && j < qlen); j += 16) {
+			if (elig && j < qlen) {
+				const int qb = (int)qp[j], tb = (int)tp[j];
+				const bool bad = qb > 3 || tb > 3;                      // N on either side: not eligible
+				const bool mis = tb != qb;
+				hi = bad ? 0x7000 : (mis ? max(hi, j) : hi);
+				lo = bad ? 0 : (mis ? max(lo, -j) : lo);
+			}
+		}
+		hi = row_allmax_f(hi); lo = row_allmax_f(lo);
+		const bool none = hi == -1, one = hi == -lo && hi >= 0 && hi < 0x7000;
+		bool ok = elig && (none || one);
+		const int p = none ? qlen : hi;
+		ok = ok && (none || h0 + p * A.a - A.b > 0);
+		if (have && l16 == 0) {
+			done[id] = ok ? 1 : 0;
+			if (ok) {
+				const int dlast = none ? h0 + qlen * A.a : h0 + (qlen - 1) * A.a - A.b;       // D(qlen-1)
+				const int before = h0 + p * A.a;                                                // running max when row p starts
+				const bool top = none || dlast > before;
+				const int mx = top ? dlast : before, mi = top ? qlen - 1 : p - 1;
+				const int gscore = dlast, qle = mi + 1, tle = mi + 1, gtle = qlen;
+				int32_t *o = A.out + 3 * (size_t)id;
+				if (gscore <= 0 || gscore <= mx - A.end_bonus) { o[0] = mx; o[1] = qle; o[2] = tle; }
+				else { o[0] = gscore; o[1] = qlen; o[2] = gtle; }
+				if (A.raw) {
+					int32_t *r = A.raw + 6 * (size_t)id;
+					r[0] = mx; r[1] = qle; r[2] = tle; r[3] = gtle; r[4] = gscore; r[5] = 0;
+				}
+			}
+		}
+	}
+}
+
 // ------------------------------------------------------------------ host side
 
 // classes: 0 = unsupported length; 1..18 = extend16_kernel<C>; 19..22 = extend_wide_kernel<5..8>
-#define EXT_N_CLS 23
+#define EXT_N_CLS 24
+#define EXT_DONE_CLS 23     // decided by the closed-form prefilter: no DP
 #define EXT16_MAX_C 18
 
 __device__ __forceinline__ int ext_class(uint32_t ql)
@@ -427,7 +491,7 @@ __device__ __forceinline__ int ext_class(uint32_t ql)
 }
 
 // sort key = class << 20 | tlen, plus a per-class histogram
-__global__ void __launch_bounds__(256) ext_key_kernel(const uint32_t *__restrict__ qlen, const uint32_t *__restrict__ tlen, uint32_t n,
+__global__ void __launch_bounds__(256) ext_key_kernel(const uint32_t *__restrict__ qlen, const uint32_t *__restrict__ tlen, const uint8_t *__restrict__ done, uint32_t n,
                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                       uint32_t *__restrict__ counts, int32_t *__restrict__ out)
 {
@@ -436,7 +500,7 @@ __global__ void __launch_bounds__(256) ext_key_kernel(const uint32_t *__restrict
 	__syncthreads();
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t < n) {
-		const int cls = ext_class(qlen[t]);
+		const int cls = done[t] ? EXT_DONE_CLS : ext_class(qlen[t]);
 		if (cls == 0) out[3 * (size_t)t] = out[3 * (size_t)t + 1] = out[3 * (size_t)t + 2] = INT32_MIN;
 		uint32_t tl = tlen[t];
 		keys[t] = ((uint32_t)cls << 20) | (tl > 0xFFFFFu ? 0xFFFFFu : tl);
@@ -461,7 +525,7 @@ __global__ void ext_offsets_kernel(uint32_t *counts)
 // scratch for the sorted job list: one per (device, stream), grown on demand and reused across calls, so
 // that batches in flight on different streams never share it
 struct ext_scratch_t {
-	uint32_t *keys, *vals, *keys2, *vals2, *counts; void *tmp; size_t tmp_bytes; size_t cap; int dev;
+	uint32_t *keys, *vals, *keys2, *vals2, *counts; uint8_t *done; void *tmp; size_t tmp_bytes; size_t cap; int dev;
 	hipEvent_t ev0, ev1; bool have_ev;
 	hipStream_t side[4]; hipEvent_t fork, join[4];     // class kernels run concurrently on side streams
 };
@@ -521,12 +585,13 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 	ext_scratch_t &g_scr = *scratch_for(dev, stream_);
 	g_last = &g_scr;
 	if (g_scr.cap < n) {
-		void *ps[] = {g_scr.keys, g_scr.vals, g_scr.keys2, g_scr.vals2, g_scr.counts, g_scr.tmp};
+		void *ps[] = {g_scr.keys, g_scr.vals, g_scr.keys2, g_scr.vals2, g_scr.counts, g_scr.tmp, g_scr.done};
 		for (void *q : ps) if (q) (void)hipFree(q);
-		g_scr.keys = g_scr.vals = g_scr.keys2 = g_scr.vals2 = g_scr.counts = nullptr; g_scr.tmp = nullptr; g_scr.cap = 0;
+		g_scr.keys = g_scr.vals = g_scr.keys2 = g_scr.vals2 = g_scr.counts = nullptr; g_scr.tmp = nullptr; g_scr.done = nullptr; g_scr.cap = 0;
 		HIPCK(hipMalloc((void **)&g_scr.keys, 4 * (size_t)n)); HIPCK(hipMalloc((void **)&g_scr.vals, 4 * (size_t)n));
 		HIPCK(hipMalloc((void **)&g_scr.keys2, 4 * (size_t)n)); HIPCK(hipMalloc((void **)&g_scr.vals2, 4 * (size_t)n));
 		HIPCK(hipMalloc((void **)&g_scr.counts, 4 * 2 * EXT_N_CLS));
+		HIPCK(hipMalloc((void **)&g_scr.done, (size_t)n));
 		size_t tb = 0;
 		HIPCK(rocprim::radix_sort_pairs(nullptr, tb, g_scr.keys, g_scr.keys2, g_scr.vals, g_scr.vals2, (size_t)n, 0, 25, st));
 		HIPCK(hipMalloc(&g_scr.tmp, tb + 256));
@@ -541,14 +606,6 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 		}
 		g_scr.have_ev = true;
 	}
-	HIPCK(hipEventRecord(g_scr.ev0, st));
-	HIPCK(hipMemsetAsync(g_scr.counts, 0, 4 * 2 * EXT_N_CLS, st));
-	ext_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_qlen, d_tlen, n, g_scr.keys, g_scr.vals, g_scr.counts, d_out);
-	ext_offsets_kernel<<<1, 64, 0, st>>>(g_scr.counts);
-	{
-		size_t tb = g_scr.tmp_bytes;
-		HIPCK(rocprim::radix_sort_pairs(g_scr.tmp, tb, g_scr.keys, g_scr.keys2, g_scr.vals, g_scr.vals2, (size_t)n, 0, 25, st));
-	}
 	ext_args_t a;
 	a.q = d_q; a.t = d_t; a.qoff = d_qoff; a.qlen = d_qlen; a.toff = d_toff; a.tlen = d_tlen; a.h0 = d_h0;
 	a.ids = g_scr.vals2; a.count = g_scr.counts; a.out = d_out; a.raw = d_raw;
@@ -561,6 +618,19 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 		if (!d_stats) HIPCK(hipMalloc((void **)&d_stats, 64));
 		HIPCK(hipMemsetAsync(d_stats, 0, 64, st));
 		a.stats = d_stats;
+	}
+	HIPCK(hipEventRecord(g_scr.ev0, st));
+	HIPCK(hipMemsetAsync(g_scr.counts, 0, 4 * 2 * EXT_N_CLS, st));
+	{
+		unsigned gp = (unsigned)((n + 15) / 16);
+		if (gp > 4096) gp = 4096;
+		ext_closed_form_kernel<<<gp, 256, 0, st>>>(a, n, g_scr.done);
+	}
+	ext_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_qlen, d_tlen, g_scr.done, n, g_scr.keys, g_scr.vals, g_scr.counts, d_out);
+	ext_offsets_kernel<<<1, 64, 0, st>>>(g_scr.counts);
+	{
+		size_t tb = g_scr.tmp_bytes;
+		HIPCK(rocprim::radix_sort_pairs(g_scr.tmp, tb, g_scr.keys, g_scr.keys2, g_scr.vals, g_scr.vals2, (size_t)n, 0, 25, st));
 	}
 	// class sizes stay on the device (no host sync): every class kernel is launched with a grid
 	// that covers the whole batch and its waves stride over the class's slice of the sorted list

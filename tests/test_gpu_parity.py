@@ -199,3 +199,44 @@ def test_host_job_builder_matches_reference_host_code(hip, tmp_path):
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         out = r.stdout.decode()
         assert r.returncode == 0 and "JOBS VS REFERENCE OK" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("zdrop", [0, 100, 3])
+def test_extension_closed_form_jobs(hip, oracle, zdrop):
+    """Jobs the closed-form prefilter decides without DP (<= 1 substitution, no gap, no N) and their near misses:
+    mismatch at every kind of position, tiny h0 (the diagonal dies at the mismatch), tlen == qlen, N bases,
+    two mismatches, low-complexity sequence where off-diagonal paths are strong."""
+    import oracle_py
+    rng = np.random.default_rng(77)
+    qs, ts, h0s = [], [], []
+    for it in range(6000):
+        ql = int(rng.integers(1, 132))
+        tl = ql + int(rng.integers(0, ql + 20))
+        kind = it % 8
+        if kind == 7:
+            t = np.full(tl, rng.integers(0, 4), np.uint8)            # homopolymer
+        elif kind == 6:
+            t = np.tile(rng.integers(0, 4, size=2).astype(np.uint8), tl // 2 + 1)[:tl]   # dinucleotide repeat
+        else:
+            t = rng.integers(0, 4, size=tl).astype(np.uint8)
+        q = t[:ql].copy()
+        nm = [0, 1, 1, 1, 2, 1, 1, 1][kind]
+        if nm >= 1:
+            pos = [0, ql - 1, int(rng.integers(0, ql))][it % 3]
+            q[pos] = (q[pos] + rng.integers(1, 4)) & 3
+        if nm == 2:
+            pos2 = int(rng.integers(0, ql)); q[pos2] = (q[pos2] + rng.integers(1, 4)) & 3
+        if it % 50 == 0:
+            q[int(rng.integers(0, ql))] = 4
+        if it % 50 == 1:
+            t[int(rng.integers(0, tl))] = 4
+        qs.append(q); ts.append(t)
+        h0s.append(int(rng.integers(1, 8)) if it % 5 == 0 else int(rng.integers(1, 151)))
+    qlen = np.array([len(x) for x in qs], np.uint32); tlen = np.array([len(x) for x in ts], np.uint32)
+    qoff = np.concatenate([[0], np.cumsum(qlen)[:-1]]).astype(np.uint32); toff = np.concatenate([[0], np.cumsum(tlen)[:-1]]).astype(np.uint32)
+    jobs = (np.concatenate(qs), qoff, qlen, np.concatenate(ts), toff, tlen, np.array(h0s, np.uint32))
+    want3, want6, _ = oracle.extend_batch(*jobs, params=oracle_py.default_params(zdrop=zdrop), want_raw=True)
+    got3, got6 = gpu_extend(hip, jobs, zdrop=zdrop)
+    bad = np.nonzero((got6 != want6).any(1))[0]
+    assert bad.size == 0, f"{bad.size} mismatches, first {bad[:5]}: got {got6[bad[:5]]} want {want6[bad[:5]]} qlen {qlen[bad[:5]]} tlen {tlen[bad[:5]]} h0 {np.array(h0s)[bad[:5]]}"
+    assert np.array_equal(got3, want3)

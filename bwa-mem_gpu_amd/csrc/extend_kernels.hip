@@ -416,16 +416,53 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 
 // ------------------------------------------------------------------ closed-form prefilter
 
-// Closed form for flanks with at most ONE substitution and no gap.  Let the only mismatch sit at column p
-// (none: p = qlen) and target[0..qlen) otherwise equal query[0..qlen), no N.  The diagonal cell of row i holds
-//   D(i) = h0 + (i+1)a  for i < p,      D(i) = h0 + i*a - b  for i >= p        (needs h0 + p*a - b > 0),
-// while any other cell of row i lies on a path with at least one gap (cost >= min(oe_del, oe_ins)) and at most
-// i+1 matches, i.e. is <= h0 + (i+1)a - min(oe) < D(i) as long as a + b < min(oe_del, oe_ins).  So the diagonal
-// is the strict, unique maximum of every row (mj = i, max_off = 0), the row maxima are D(i), the running
-// maximum is updated exactly where D exceeds its previous values, row qlen-1 has end == qlen and gives
-// gscore = D(qlen-1) with no later tie (a later H(i,qlen-1) <= h0 + qlen*a - oe_del < D(qlen-1)).  The DP's
-// outputs follow without running it.  A flank starts right after a maximal exact match, so its first base is
-// usually the mismatch that ended the seed: about half of the 150 bp jobs at 1 % error have no second one.
+__device__ __forceinline__ int row_allsum_f(int v)
+{
+	asm volatile("s_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+	             : "+v"(v));
+	return v;
+}
+__device__ __forceinline__ int row_allor_f(int v)
+{
+	asm volatile("s_nop 1\n\t"
+	             "v_or_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_or_b32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_or_b32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_or_b32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+	             : "+v"(v));
+	return v;
+}
+
+// Closed form for flanks whose main diagonal has at most TWO substitutions and that need no gap.
+// H(i,j) is bounded by the best score of a path from the origin (value h0) made of diagonal steps (+a / -b)
+// and gaps (o + L*e); the zero floor, the "M == 0 stays 0" rule and the [beg,end) trimming only lower values,
+// and a positive diagonal cell is always inside [beg,end) (eh[i] is non-zero in row i-1).  Write
+// delta = a + b, D(i) for the value of the gap-free path at (i,i), and let the main diagonal mismatch only at
+// columns p1 < p2 (no N anywhere, tlen >= qlen).
+//  * A path with two or more gaps loses >= 2*min(oe) against the gap-free path and can win back at most
+//    2*delta: with delta < min(oe) it stays strictly below every comparison target.
+//  * A path with ONE gap of length L that leaves the diagonal after (r,r) reaches its end cell with at most as
+//    many diagonal steps as the gap-free path to the comparison target; it ties or beats the target only if
+//    delta*(k' - m_alt) >= o + e*L + a*(lost steps), k' = main mismatches it bypasses, m_alt = mismatches on its
+//    own steps.  With one bypassed mismatch (k' <= 1) that is impossible (delta < o + e).  With k' = 2 it needs
+//    m_alt = 0 and L <= Lmax = (2*delta - o)/e: the path leaves before p1, runs on the diagonal shifted by
+//    d = +-L, |d| <= Lmax, and ALL its steps match, in particular those in rows [p1 + Lmax, p2].
+//  * gscore compares H(i, qlen-1) of EVERY row with D(qlen-1): a cell above the diagonal in that column ends a
+//    right-shifted diagonal early (it loses L steps: a*L more), so only L <= Lg = max{L: o + (e+a)L < 2*delta} can
+//    beat D(qlen-1), and only if its steps up to row qlen-1-L all match.
+// Hence: with <= 1 mismatch the diagonal is the strict maximum of every row; with 2 mismatches the same holds
+// as soon as every shifted diagonal |d| <= Lmax has a mismatch somewhere in rows [p1 + Lmax, p2] (for right
+// shifts: before the diagonal leaves the query) -- eight short byte comparisons for the default scoring, which random sequence passes and
+// tandem repeats fail (those go to the DP).  The targets are D(i) for cells of row i < qlen, and D(qlen-1) for
+// the rows below the diagonal and for the gscore column, so max/max_i/max_j follow the gap-free values
+// (strict > updates: the end of each mismatch-free segment that exceeds all earlier ones), max_off = 0,
+// gscore = D(qlen-1), max_ie = qlen-1.  z-drop (ksw.c:951-959) is handled by requiring the draw-down at the
+// mismatch rows to stay within zdrop.  A flank starts right after a maximal exact match, so its first base is
+// usually the mismatch that ended the seed; most 150 bp flanks at 1 % error have at most one more.
 // One 16-lane row per job; jobs decided here get done[id] = 1 and never reach the DP kernels.
 __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint32_t n, uint8_t *__restrict__ done)
 {
@@ -434,14 +471,21 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
 	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;
 	const int min_oe = oe_del < oe_ins ? oe_del : oe_ins;
+	const int min_o = A.o_del < A.o_ins ? A.o_del : A.o_ins, min_e = A.e_del < A.e_ins ? A.e_del : A.e_ins;
+	const int delta = A.a + A.b;
+	// longest single gap that two bypassed mismatches could pay for (ties count); -1: two-mismatch form disabled
+	const int lmax = (min_e > 0 && 2 * delta >= min_o) ? (2 * delta - min_o) / min_e : (2 * delta < min_o + min_e ? 0 : -1);
+	const bool two_ok = lmax >= 0 && lmax <= 6;
+	// longest insertion whose end cell in the gscore column can still beat D(qlen-1): o + (e + a)*L < 2*delta
+	const int lg = (2 * delta - min_o - 1 >= 0 && min_e + A.a > 0) ? (2 * delta - min_o - 1) / (min_e + A.a) : 0;
+	const bool params_ok = A.a > 0 && delta < min_oe && (A.zdrop <= 0 || A.b <= A.zdrop);
 	for (uint32_t w = wave * 4; w < n; w += n_waves * 4) {
 		const uint32_t id = w + grp;
 		const bool have = id < n;
 		const int qlen = have ? (int)A.qlen[id] : 0, tlen = have ? (int)A.tlen[id] : 0, h0 = have ? (int)A.h0[id] : 1;
 		const uint8_t *qp = A.q + (have ? A.qoff[id] : 0), *tp = A.t + (have ? A.toff[id] : 0);
-		// z-drop (ksw.c:951-959) sees max - m = b at the mismatch row: it must not fire there
-		const bool elig = have && qlen > 0 && tlen >= qlen && A.a > 0 && A.a + A.b < min_oe && (A.zdrop <= 0 || A.b <= A.zdrop);
-		int hi = -1, lo = -0x7000;          // largest / (negated) smallest mismatching column seen by this lane
+		const bool elig = have && qlen > 0 && tlen >= qlen && params_ok;
+		int hi = -1, lo = -0x7000, cnt = 0;   // largest / (negated) smallest mismatching column, mismatch count of this lane
 		for (int j = l16; __any(elig && j < qlen); j += 16) {
 			if (elig && j < qlen) {
 				const int qb = (int)qp[j], tb = (int)tp[j];
@@ -449,21 +493,56 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 				const bool mis = tb != qb;
 				hi = bad ? 0x7000 : (mis ? max(hi, j) : hi);
 				lo = bad ? 0 : (mis ? max(lo, -j) : lo);
+				cnt += (mis || bad) ? 1 : 0;
 			}
 		}
-		hi = row_allmax_f(hi); lo = row_allmax_f(lo);
-		const bool none = hi == -1, one = hi == -lo && hi >= 0 && hi < 0x7000;
-		bool ok = elig && (none || one);
-		const int p = none ? qlen : hi;
-		ok = ok && (none || h0 + p * A.a - A.b > 0);
+		hi = row_allmax_f(hi); lo = row_allmax_f(lo); cnt = row_allsum_f(cnt);
+		const bool clean = hi < 0x7000;
+		const int p1 = -lo, p2 = hi;
+		// two mismatches: every diagonal shifted by 0 < |d| <= lmax needs a mismatch in rows [p1+lmax, p2].  A diagonal
+		// shifted to the right (d = +L, reached by an insertion) ends at row qlen-1-L in the gscore column: if it ends
+		// before row p2 it cannot beat its own row's diagonal cell (only one mismatch bypassed), but for L <= lg it can
+		// still beat D(qlen-1) -- the gscore comparison of ksw.c:942-945 -- so there the mismatch must come before its end.
+		bool two = elig && clean && cnt == 2 && two_ok && p2 - p1 >= (lmax > 0 ? lmax : 1);
+		if (__any(two) && lmax > 0) {
+			int bits = 0;
+			for (int i = p1 + lmax + l16; __any(two && i <= p2); i += 16) {
+				if (two && i <= p2) {
+					const int tb = (int)tp[i];
+					for (int L = 1; L <= lmax; ++L) {
+						const int cm = i - L, cp = i + L;
+						const bool mm = cm < 0 || (int)qp[cm] != tb;       // d = -L
+						const bool mp = cp < qlen && (int)qp[cp] != tb;    // d = +L: rows past the end of that diagonal do not count
+						bits |= (mm ? 1 : 0) << (2 * (L - 1)) | (mp ? 1 : 0) << (2 * (L - 1) + 1);
+					}
+				}
+			}
+			bits = row_allor_f(bits);
+			for (int L = 1; L <= lmax; ++L) {
+				const bool minus_ok = (bits >> (2 * (L - 1))) & 1;
+				const bool plus_ok = ((bits >> (2 * (L - 1) + 1)) & 1) || (L > lg && p2 > qlen - 1 - L);
+				two = two && minus_ok && plus_ok;
+			}
+		}
+		const bool none = elig && clean && cnt == 0, one = elig && clean && cnt == 1;
+		// gap-free values: V1 = value before row p1, V2 = before row p2, V3 = D(qlen-1)
+		const int pa = none ? qlen : p1;
+		const int V1 = h0 + pa * A.a;
+		const int V2 = (one || two) ? V1 - A.b + ((two ? p2 : qlen) - p1 - 1) * A.a : V1;      // one: this is already D(qlen-1)
+		const int V3 = two ? V2 - A.b + (qlen - 1 - p2) * A.a : V2;
+		bool ok = none || one || two;
+		ok = ok && (none || V1 - A.b > 0) && (!two || V2 - A.b > 0);
+		if (A.zdrop > 0 && two) ok = ok && (max(V1, V2) - V2 + A.b <= A.zdrop);
 		if (have && l16 == 0) {
 			done[id] = ok ? 1 : 0;
 			if (ok) {
-				const int dlast = none ? h0 + qlen * A.a : h0 + (qlen - 1) * A.a - A.b;       // D(qlen-1)
-				const int before = h0 + p * A.a;                                                // running max when row p starts
-				const bool top = none || dlast > before;
-				const int mx = top ? dlast : before, mi = top ? qlen - 1 : p - 1;
-				const int gscore = dlast, qle = mi + 1, tle = mi + 1, gtle = qlen;
+				// running maximum with strict updates: start (h0, -1); segment ends (V1, p1-1), (V2, p2-1) [two only], (V3, qlen-1)
+				int mx = h0, mi = -1;
+				if (pa > 0) { mx = V1; mi = pa - 1; }
+				if (two && p2 - p1 - 1 > 0 && V2 > mx) { mx = V2; mi = p2 - 1; }
+				const int lastseg = none ? 0 : qlen - 1 - (two ? p2 : p1);
+				if (lastseg > 0 && V3 > mx) { mx = V3; mi = qlen - 1; }
+				const int gscore = V3, qle = mi + 1, tle = mi + 1, gtle = qlen;
 				int32_t *o = A.out + 3 * (size_t)id;
 				if (gscore <= 0 || gscore <= mx - A.end_bonus) { o[0] = mx; o[1] = qle; o[2] = tle; }
 				else { o[0] = gscore; o[1] = qlen; o[2] = gtle; }

@@ -103,7 +103,7 @@ def test_seeding_odd_genome_length(hip, oracle):
     common.assert_seeds_equal(got, want)
 
 
-def gpu_extend(B, jobs, zdrop=0, want_raw=True):
+def gpu_extend(B, jobs, zdrop=0, want_raw=True, scoring=None):
     import torch
     q, qoff, qlen, t, toff, tlen, h0 = jobs
     n = len(qlen)
@@ -111,7 +111,11 @@ def gpu_extend(B, jobs, zdrop=0, want_raw=True):
     d = [x.to(torch.int32).cuda() if x.dtype == torch.int64 else x.cuda() for x in d]
     out = torch.zeros(n, 3, dtype=torch.int32, device="cuda")
     raw = torch.zeros(n, 6, dtype=torch.int32, device="cuda") if want_raw else None
-    B.extend_batch(*d, out, params=B.ExtParams.default(zdrop=zdrop), raw_t=raw)
+    prm = B.ExtParams.default(zdrop=zdrop)
+    if scoring is not None:
+        a_, b_, o_, e_ = scoring
+        prm = B.ExtParams(a_, b_, o_, e_, o_, e_, zdrop, 5)
+    B.extend_batch(*d, out, params=prm, raw_t=raw)
     torch.cuda.synchronize()
     return out.cpu().numpy(), raw.cpu().numpy() if want_raw else None
 
@@ -240,3 +244,44 @@ def test_extension_closed_form_jobs(hip, oracle, zdrop):
     bad = np.nonzero((got6 != want6).any(1))[0]
     assert bad.size == 0, f"{bad.size} mismatches, first {bad[:5]}: got {got6[bad[:5]]} want {want6[bad[:5]]} qlen {qlen[bad[:5]]} tlen {tlen[bad[:5]]} h0 {np.array(h0s)[bad[:5]]}"
     assert np.array_equal(got3, want3)
+
+
+def test_extension_two_mismatch_closed_form(hip, oracle):
+    """Two-substitution flanks (closed form + its shifted-diagonal guard): random sequence, tandem repeats of
+    period 1..6 (where a gapped path can tie or beat the diagonal), mismatches at every spacing, short h0."""
+    rng = np.random.default_rng(99)
+    qs, ts, h0s = [], [], []
+    for it in range(40000):
+        ql = int(rng.integers(2, 132))
+        tl = ql + int(rng.integers(0, ql + 12))
+        kind = it % 4
+        if kind == 0:
+            t = rng.integers(0, 4, size=tl).astype(np.uint8)
+        else:
+            per = int(rng.integers(1, 7))
+            unit = rng.integers(0, 4, size=per).astype(np.uint8)
+            t = np.tile(unit, tl // per + 1)[:tl]
+            if kind == 2:                                   # repeat with a few random bases sprinkled in
+                k = rng.integers(0, tl, size=max(1, tl // 12)); t[k] = rng.integers(0, 4, size=k.size)
+            if kind == 3:                                   # random left part, periodic right part
+                cut = int(rng.integers(0, tl)); t[:cut] = rng.integers(0, 4, size=cut)
+        q = t[:ql].copy()
+        p1 = int(rng.integers(0, ql))
+        gap = int(rng.integers(1, 12)) if it % 3 else int(rng.integers(1, ql + 1))
+        p2 = min(ql - 1, p1 + gap)
+        for pp in {p1, p2}:
+            q[pp] = (q[pp] + rng.integers(1, 4)) & 3
+        qs.append(q); ts.append(t)
+        h0s.append(int(rng.integers(1, 12)) if it % 7 == 0 else int(rng.integers(1, 151)))
+    qlen = np.array([len(x) for x in qs], np.uint32); tlen = np.array([len(x) for x in ts], np.uint32)
+    qoff = np.concatenate([[0], np.cumsum(qlen)[:-1]]).astype(np.uint32); toff = np.concatenate([[0], np.cumsum(tlen)[:-1]]).astype(np.uint32)
+    jobs = (np.concatenate(qs), qoff, qlen, np.concatenate(ts), toff, tlen, np.array(h0s, np.uint32))
+    import oracle_py
+    # default scoring with and without z-drop, then other scorings (different Lmax / Lg of the closed-form guard)
+    for (a, b, o, e, zdrop) in ((1, 4, 6, 1, 0), (1, 4, 6, 1, 7), (2, 3, 5, 2, 0), (1, 3, 4, 2, 0), (3, 2, 6, 1, 0), (1, 1, 6, 1, 0), (1, 4, 6, 1, 3)):
+        op = oracle_py.KswParams(a, b, o, e, o, e, zdrop, 5, 1)
+        want3, want6, _ = oracle.extend_batch(*jobs, params=op, want_raw=True, n_threads=8)
+        got3, got6 = gpu_extend(hip, jobs, zdrop=zdrop, scoring=(a, b, o, e))
+        bad = np.nonzero((got6 != want6).any(1))[0]
+        assert bad.size == 0, f"scoring {(a, b, o, e, zdrop)}: {bad.size} mismatches, first {bad[:5]}: got {got6[bad[:5]]} want {want6[bad[:5]]} qlen {qlen[bad[:5]]} h0 {np.array(h0s)[bad[:5]]}"
+        assert np.array_equal(got3, want3)

@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("BENCH_GENOME_MBP", "1000")))
     ap.add_argument("--reads-per-gpu", type=int, default=int(os.environ.get("BENCH_READS_PER_GPU", "1000000")))
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--paired", action="store_true", help="interleaved 2 x read-len pairs (configs[3]); reads-per-gpu counts reads, shards stay on pair boundaries")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="run extension and seeding on one stream")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BENCH_CPU_SAMPLE", "200000")))
     a = ap.parse_args()
@@ -117,8 +118,11 @@ def main():
     torch.cuda.empty_cache()
     hdr, bwt_t, sa_t, bits_t = broadcast_index(idx, dev, src=0, world=world)
     dindex = B.Index.from_device(hdr["primary"], hdr["L2"], hdr["seq_len"], bwt_t, hdr["sa_intv"], sa_t, bits_t)
-    lo, hi = shard_range(a.reads_per_gpu * world, rank, world)
-    reads, _ = B.synth.make_reads(g, hi - lo, a.read_len, seed=7 + rank)
+    lo, hi = shard_range(a.reads_per_gpu * world, rank, world, multiple=2 if a.paired else 1)
+    if a.paired:
+        reads, _ = B.synth.make_pairs(g, (hi - lo) // 2, a.read_len, seed=7 + rank)
+    else:
+        reads, _ = B.synth.make_reads(g, hi - lo, a.read_len, seed=7 + rank)
     dr = P.reads_to_device(reads, dev)
     n_reads = dr.n
     ws = B.SeedWorkspace(n_reads, n_reads * a.read_len)
@@ -200,7 +204,7 @@ def main():
             "config": {"workload": f"{a.reads_per_gpu} synthetic {a.read_len} bp single-end reads per GPU vs seeded synthetic "
                                    f"{a.genome_mbp:g} Mbp genome (hg38 stand-in: uniform + 10% diverged repeat families); "
                                    "seeding = all SMEMs >= 19 bp + locate; extension = every left/right job the reference's chaining (mem_chain, mem_chain_flt, mem_chain2aln) produces",
-                       "reads_per_gpu": n_reads, "read_len": a.read_len, "genome_mbp": a.genome_mbp,
+                       "reads_per_gpu": n_reads, "read_len": a.read_len, "paired_interleaved": bool(a.paired), "genome_mbp": a.genome_mbp,
                        "index_bytes": int(bwt_t.numel() * 4 + sa_t.numel() * 4 + bits_t.numel() * 4),
                        "ext_jobs_per_gpu": jobs.n, "regions_per_gpu": n_regs, "host_job_build_s": round(t_jobs, 2), "seeds_per_gpu": int(s.n_seeds), "min_seed_len": 19,
                        "scoring": "a1 b4 o6 e1 clip5 zdrop0", "streams": "seeding || extension" if a.overlap else "single", "index_build_s": round(t_index, 2)},

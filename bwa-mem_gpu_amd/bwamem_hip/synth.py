@@ -97,6 +97,30 @@ def make_reads(genome: np.ndarray, n_reads: int, read_len: int, seed: int = 7,
     return reads, {"pos": pos, "rev": rev, "has_indel": has_indel}
 
 
+def make_pairs(genome: np.ndarray, n_pairs: int, read_len: int, seed: int = 7, insert_mean: float = 350.0,
+               insert_sd: float = 35.0, sub_rate: float = 0.01, n_rate: float = 0.001):
+    """Interleaved FR pairs (read 2i = first mate, 2i+1 = second mate): fragment of length ~N(insert_mean,
+    insert_sd) at a uniform position, either strand; mate 1 = fragment start, mate 2 = reverse complement of
+    the fragment end; substitutions / N as in make_reads.  Returns (reads uint8 [2*n_pairs, read_len], truth)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = genome.shape[0]
+    ins = np.clip(np.rint(rng.normal(insert_mean, insert_sd, size=n_pairs)).astype(np.int64), read_len, None)
+    pos = rng.integers(0, n - ins.max() - 1, size=n_pairs)
+    ar = np.arange(read_len)
+    m1 = genome[pos[:, None] + ar[None, :]]
+    m2f = genome[(pos + ins - read_len)[:, None] + ar[None, :]]
+    m2 = (3 - m2f)[:, ::-1]
+    flip = rng.random(n_pairs) < 0.5                       # fragment from the reverse strand: swap mate roles
+    a = np.where(flip[:, None], m2, m1)
+    b = np.where(flip[:, None], m1, m2)
+    reads = np.empty((2 * n_pairs, read_len), np.uint8)
+    reads[0::2] = a; reads[1::2] = b
+    sub = rng.random(reads.shape) < sub_rate
+    reads[sub] = (reads[sub] + rng.integers(1, 4, size=int(sub.sum()), dtype=np.uint8)) & 3
+    reads[rng.random(reads.shape) < n_rate] = 4
+    return reads, {"pos": pos, "insert": ins, "flip": flip}
+
+
 def codes_to_ascii(codes: np.ndarray) -> np.ndarray:
     return _ASCII[codes]
 

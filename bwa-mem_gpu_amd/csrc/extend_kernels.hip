@@ -634,12 +634,17 @@ extern "C" float bmh_extend_last_ms(void)
 	return ms;
 }
 
+// Occupancy cap for co-scheduling: a block that reserves `g_ext_lds` bytes of (unused) dynamic LDS limits the DP
+// kernels to 160 KiB / g_ext_lds blocks per CU, which leaves wave slots for the gather-bound seeding kernels of
+// another stream to become resident beside them (BMH_EXT_LDS_KB; 0 = no cap).
+static unsigned g_ext_lds = [] { const char *e = getenv("BMH_EXT_LDS_KB"); return e ? (unsigned)atoi(e) * 1024u : 0u; }();
+
 template <int C>
 static void launch16(const ext_args_t &base, hipStream_t st, unsigned grid)
 {
 	ext_args_t a = base;
 	a.count = base.count + 2 * C;
-	extend16_kernel<C><<<grid, 256, 0, st>>>(a);
+	extend16_kernel<C><<<grid, 256, g_ext_lds, st>>>(a);
 }
 template <int C>
 static void launch_wide(const ext_args_t &base, hipStream_t st, unsigned grid)

@@ -185,10 +185,11 @@ def test_reference_gase_aln_end_to_end(hip, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists(os.path.join(root, "build", "dropin", "bwa-gasal2")):
         pytest.skip("build/dropin/bwa-gasal2 not built (needs /root/reference at build time)")
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "e2e_dropin.py"), str(tmp_path), "2000000", "4000"],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    out = r.stdout.decode()
-    assert r.returncode == 0 and "E2E DROP-IN OK" in out, out[-3000:]
+    for extra in ([], ["1", "pe"]):          # single-end (configs[0] shape) and interleaved paired-end with -p (configs[3] shape)
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "e2e_dropin.py"), str(tmp_path), "2000000", "4000"] + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        out = r.stdout.decode()
+        assert r.returncode == 0 and "E2E DROP-IN OK" in out, out[-3000:]
 
 
 def test_host_job_builder_matches_reference_host_code(hip, tmp_path):

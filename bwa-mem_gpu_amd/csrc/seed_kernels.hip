@@ -879,16 +879,15 @@ extern "C" int bmh_calib_gather(const bmh_index_t *idx, uint64_t n_lanes, int it
 {
 	if (!idx || !ms || iters < 1) { bmh_set_error("bmh_calib_gather: bad argument"); return BMH_EINVAL; }
 	hipStream_t st = (hipStream_t)stream_;
-	uint32_t *sink = nullptr;
-	HIPCK(hipMalloc((void **)&sink, 64));
-	hipEvent_t e0, e1;
-	HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
+	// no allocation / free in here: hipFree is a device-wide synchronisation point
+	static thread_local uint32_t *sink = nullptr;
+	static thread_local hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (!sink) { HIPCK(hipMalloc((void **)&sink, 64)); HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1)); }
 	const uint64_t n_blocks = (idx->dev.seq_len + 63) / 64;
 	HIPCK(hipEventRecord(e0, st));
 	calib_gather_kernel<<<nblk(n_lanes, 256), 256, 0, st>>>(idx->dev, n_blocks, iters, dependent, sink);
 	HIPCK(hipEventRecord(e1, st));
 	HIPCK(hipEventSynchronize(e1));
 	HIPCK(hipEventElapsedTime(ms, e0, e1));
-	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
 	return BMH_OK;
 }

@@ -38,11 +38,11 @@ GATHER_CEILING_GBS = 1818.0
 
 def pmc_traffic(kernel_name: str):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_final_pmc_fetch_write.json: FETCH_SIZE + WRITE_SIZE, KB).  For this library's access patterns
+    (profiles/r01b_pmc_fetch_write.json: FETCH_SIZE + WRITE_SIZE, KB).  For this library's access patterns
     FETCH_SIZE needs no correction: the calibration kernel (bmh_calib_gather under --pmc FETCH_SIZE) reads back
     63.9 B per 32-byte gather, i.e. exactly one 64-byte sector each.  None if the profile is absent."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_fetch_write.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_fetch_write.json")))
         key = kernel_name.split("<")[0].split(" ")[0]
         f = [v["avg_per_launch_KB"] for k, v in d["FETCH_SIZE"].items() if key in k]
         w = [v["avg_per_launch_KB"] for k, v in d["WRITE_SIZE"].items() if key in k]

@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = [
     "bmh_index_free", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
     "bmh_extend_batch", "bmh_extend_last_ms", "bmh_calib_gather",
     "bmh_chain_opt_default", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
+    "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_batch", "bmh_chain_merge",
     "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
     "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
 ]
@@ -48,6 +49,13 @@ class ChainOpt(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "w", "min_seed_len", "max_occ",
                                        "max_chain_gap", "min_chain_weight", "max_chain_extend")] + \
                [("mask_level", C.c_float), ("drop_ratio", C.c_float)]
+
+
+class DevJobsT(C.Structure):
+    """bmh_dev_jobs_t"""
+    _fields_ = [(n, C.c_uint64) for n in ("n_jobs", "n_regs", "q_bytes", "t_bytes", "n_heavy_reads")] + \
+               [(n, C.c_void_p) for n in ("d_q", "d_qoff", "d_qlen", "d_t", "d_toff", "d_tlen", "d_h0", "d_job_read", "d_job_reg",
+                                          "d_job_side", "d_regs_per_read")]
 
 
 # mirrors of include/seed_gen.h
@@ -113,6 +121,16 @@ def load_library() -> C.CDLL:
     L.bmh_jobs_arrays.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 11
     L.bmh_merge_regs.restype = C.c_int
     L.bmh_merge_regs.argtypes = [C.c_void_p, _i32p, _i32p]
+    L.bmh_chain_ws_create.restype = C.c_void_p
+    L.bmh_chain_ws_create.argtypes = [C.c_uint32, C.c_uint64]
+    L.bmh_chain_ws_free.argtypes = [C.c_void_p]
+    L.bmh_chain_set_contigs.restype = C.c_int
+    L.bmh_chain_set_contigs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.bmh_chain_batch.restype = C.c_int
+    L.bmh_chain_batch.argtypes = [C.c_void_p, C.POINTER(ChainOpt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                  C.POINTER(SeedsT), C.c_void_p, C.POINTER(DevJobsT)]
+    L.bmh_chain_merge.restype = C.c_int
+    L.bmh_chain_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwt_restore_bwt_gpu.restype = C.POINTER(BwtTGpu)
     L.bwt_restore_bwt_gpu.argtypes = [C.c_char_p]
     L.bwt_restore_sa_gpu.argtypes = [C.c_char_p, C.POINTER(BwtTGpu)]
@@ -201,6 +219,57 @@ class SeedWorkspace:
         if self.handle:
             load_library().bmh_seed_ws_free(self.handle)
             self.handle = None
+
+
+class ChainWorkspace:
+    """Device job builder (bmh_chain_batch / bmh_chain_merge): seeds in HBM -> extension jobs in HBM -> regions."""
+
+    def __init__(self, max_reads: int, max_seeds: int, opt: "ChainOpt | None" = None):
+        L = load_library()
+        self.handle = L.bmh_chain_ws_create(max_reads, max_seeds)
+        if not self.handle:
+            raise RuntimeError("bmh_chain_ws_create: " + _err(L))
+        self.opt = opt or ChainOpt()
+        if opt is None:
+            L.bmh_chain_opt_default(C.byref(self.opt))
+
+    def chain_batch(self, index: Index, reads_t, offs_t, lens_t, seeds: SeedsT, stream: int = 0) -> DevJobsT:
+        L = load_library()
+        out = DevJobsT()
+        rc = L.bmh_chain_batch(self.handle, C.byref(self.opt), index.handle, reads_t.data_ptr(), offs_t.data_ptr(), lens_t.data_ptr(),
+                               lens_t.numel(), C.byref(seeds), stream, C.byref(out))
+        if rc != 0:
+            raise RuntimeError(f"bmh_chain_batch rc={rc}: " + _err(L))
+        return out
+
+    def merge(self, out3_t, regs_t, stream: int = 0) -> None:
+        L = load_library()
+        rc = L.bmh_chain_merge(self.handle, out3_t.data_ptr(), regs_t.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError(f"bmh_chain_merge rc={rc}: " + _err(L))
+
+    def free(self):
+        if self.handle:
+            load_library().bmh_chain_ws_free(self.handle)
+            self.handle = None
+
+
+def dev_jobs_to_host(j: DevJobsT, n_reads: int) -> dict:
+    """Copy a bmh_dev_jobs_t to numpy arrays (test helper)."""
+    import torch
+
+    def rd(ptr, n, dt, tdt):
+        if n == 0 or not ptr:
+            return np.zeros(0, dt)
+        buf = torch.empty(n, dtype=tdt, device="cuda")
+        _memcpy_d2d(buf.data_ptr(), ptr, n * buf.element_size())
+        return buf.cpu().numpy().view(dt)
+    nj = int(j.n_jobs)
+    out = {k: rd(getattr(j, "d_" + k), nj, np.uint32, torch.int32) for k in ("qoff", "qlen", "toff", "tlen", "h0", "job_read", "job_reg", "job_side")}
+    out["q"] = rd(j.d_q, int(j.q_bytes), np.uint8, torch.uint8)
+    out["t"] = rd(j.d_t, int(j.t_bytes), np.uint8, torch.uint8)
+    out["regs_per_read"] = rd(j.d_regs_per_read, n_reads, np.uint32, torch.int32)
+    return out
 
 
 def seeds_to_host(s: SeedsT, n_reads: int) -> dict:

@@ -1,0 +1,457 @@
+// Per-read chaining core of the device job builder: seeds -> chains -> filtered chains -> alignment regions with
+// their LEFT/RIGHT extension-job geometry.  Restates, for one read and with flat scratch arrays instead of
+// kbtree/kvec, the reference's host stage between its two kernels:
+//   mem_chain          /root/reference/src/bwamem.c:404-477  (+ test_and_merge :337-364)
+//   mem_chain_weight   :366-392      mem_chain_flt  :487-559  (ks_introsort(mem_flt), src/ksort.h:146-226)
+//   mem_chain2aln      :1170-1479    (which seeds become regions; job geometry :1300-1434)
+//   cal_max_gap        :996-1002     bns_pos2rid / bns_intv2rid  src/bntseq.c:349-373
+// Same decisions in the same order as csrc/host_jobs.cpp (which is pinned to the reference's own host code), so the
+// two produce identical batches.  Floating point appears exactly where the reference has it (double in cal_max_gap
+// and the 0.85/0.95/0.1 factors, float in mask_level/drop_ratio); there is no multiply-add for the compiler to fuse.
+//
+// The function is templated on COOP: false = one lane (or one host thread) does everything serially; true = all 64
+// lanes of a wave execute it redundantly on one read (same addresses, same values) and the loops that are
+// quadratic in the number of seeds of a read -- the sorted insert, the kept-chain scan, the "already covered by a
+// region" scan -- are split across the lanes.  Reads with few seeds (almost all) take the lane form, the rare read
+// inside a high-copy repeat takes the wave form.
+//
+// Compiles as plain C++ too (tests/chain_core_host.cpp) so the logic is testable without a GPU.
+#pragma once
+#include <stdint.h>
+#include "../../include/bwamem_hip.h"
+
+#if defined(__HIPCC__)
+#define CH_HD __host__ __device__
+#else
+#define CH_HD
+#endif
+
+struct ch_seed_t { int64_t rbeg; int32_t qbeg, len; uint32_t next, pad; };                       // 24 B
+struct ch_chain_t { uint32_t head, tail, n; int32_t rid, w, first, beg, end; uint32_t kept, pad; };   // 40 B
+struct ch_reg_t {                                                                                // 64 B
+	int64_t rb_est, re_est, seed_rbeg, rmax0;
+	int32_t qb_est, qe_est, seed_qbeg, seedlen0, lr, rr, rq, pad;
+};
+
+struct ch_ctx_t {
+	bmh_chain_opt_t o;
+	int64_t l_pac; int n_contigs; const int64_t *ctg_off; const int32_t *ctg_len;
+	const uint64_t *rbeg; const int32_t *qbeg; const uint32_t *score, *n_ref, *prefix;   // mem_seed_v_gpu arrays
+	const uint32_t *read_lens;
+	// scratch, every array indexed by prefix[read] + local index (a read never needs more entries than it has seeds)
+	ch_seed_t *seeds; ch_chain_t *chains; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx;
+	ch_reg_t *regs;
+	uint32_t *regs_per_read, *jobs_per_read;
+	int *err;                     // != 0: a read was longer than 700 bp (mem_flt_chained_seeds is not restated)
+};
+
+#define CH_MAX_READ_LEN 700
+
+namespace chain_core {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int ch_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ void ch_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0); }
+#endif
+
+CH_HD inline int pos2rid(const ch_ctx_t &x, int64_t pos_f)
+{
+	if (pos_f >= x.l_pac) return -1;
+	if (x.n_contigs <= 1) return 0;
+	int left = 0, mid = 0, right = x.n_contigs;
+	while (left < right) {
+		mid = (left + right) >> 1;
+		if (pos_f >= x.ctg_off[mid]) {
+			if (mid == x.n_contigs - 1) break;
+			if (pos_f < x.ctg_off[mid + 1]) break;
+			left = mid + 1;
+		} else right = mid;
+	}
+	return mid;
+}
+CH_HD inline int64_t depos(const ch_ctx_t &x, int64_t pos, int *is_rev) { return (*is_rev = (pos >= x.l_pac)) ? (x.l_pac << 1) - 1 - pos : pos; }
+CH_HD inline int intv2rid(const ch_ctx_t &x, int64_t rb, int64_t re)
+{
+	int is_rev;
+	if (rb < x.l_pac && re > x.l_pac) return -2;
+	const int rid_b = pos2rid(x, depos(x, rb, &is_rev));
+	const int rid_e = rb < re ? pos2rid(x, depos(x, re - 1, &is_rev)) : rid_b;
+	return rid_b == rid_e ? rid_b : -1;
+}
+CH_HD inline int cal_max_gap(const bmh_chain_opt_t &o, int qlen)
+{
+	const int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
+	const int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+	int l = l_del > l_ins ? l_del : l_ins;
+	l = l > 1 ? l : 1;
+	return l < o.w << 1 ? l : o.w << 1;
+}
+
+// ---- order-sensitive sort of the chains by weight: klib introsort restated on 64-bit keys (weight << 32 | chain),
+// compared on the weight only, descending -- ties must fall as they do in the reference.
+CH_HD inline bool wlt(uint64_t a, uint64_t b) { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); }
+CH_HD inline void wswap(uint64_t *a, int i, int j) { const uint64_t t = a[i]; a[i] = a[j]; a[j] = t; }
+CH_HD inline void w_insertion(uint64_t *a, int s, int t)          // [s, t)
+{
+	for (int i = s + 1; i < t; ++i)
+		for (int j = i; j > s && wlt(a[j], a[j - 1]); --j) wswap(a, j, j - 1);
+}
+CH_HD inline void w_comb(uint64_t *a, int n)
+{
+	const double shrink = 1.2473309501039786540366528676643;
+	bool swapped; int gap = n;
+	do {
+		if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+		swapped = false;
+		for (int i = 0; i < n - gap; ++i) { const int j = i + gap; if (wlt(a[j], a[i])) { wswap(a, i, j); swapped = true; } }
+	} while (swapped || gap > 2);
+	if (gap != 1) w_insertion(a, 0, n);
+}
+CH_HD inline bool w_introsort(uint64_t *a, int n)
+{
+	if (n < 1) return true;
+	if (n == 2) { if (wlt(a[1], a[0])) wswap(a, 0, 1); return true; }
+	int d;
+	for (d = 2; (1l << d) < n; ++d) ;
+	int st_l[40], st_r[40], st_d[40], sp = 0;
+	int s = 0, t = n - 1;
+	d <<= 1;
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) { w_comb(a + s, t - s + 1); t = s; continue; }
+			int i = s, j = t, k = i + ((j - i) >> 1) + 1;
+			if (wlt(a[k], a[i])) { if (wlt(a[k], a[j])) k = j; }
+			else k = wlt(a[j], a[i]) ? i : j;
+			const uint64_t rp = a[k];
+			if (k != t) wswap(a, k, t);
+			for (;;) {
+				do ++i; while (wlt(a[i], rp));
+				do --j; while (i <= j && wlt(rp, a[j]));
+				if (j <= i) break;
+				wswap(a, i, j);
+			}
+			wswap(a, i, t);
+			if (i - s > t - i) {
+				if (i - s > 16) { if (sp >= 40) return false; st_l[sp] = s; st_r[sp] = i - 1; st_d[sp] = d; ++sp; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { if (sp >= 40) return false; st_l[sp] = i + 1; st_r[sp] = t; st_d[sp] = d; ++sp; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (sp == 0) { w_insertion(a, 0, n); return true; }
+			--sp; s = st_l[sp]; t = st_r[sp]; d = st_d[sp];
+		}
+	}
+}
+
+// ---- helpers that are split across the wave when COOP
+// insert (cv, pv) at position at of order/opos[0..nc)
+template <bool COOP> CH_HD inline void sorted_insert(uint32_t *order, int64_t *opos, int nc, int at, uint32_t cv, int64_t pv)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (COOP) {
+		const int lane = ch_lane();
+		for (int hi = nc; hi > at; hi -= 64) {
+			const int j = hi - 1 - lane;
+			const bool act = j >= at;
+			uint32_t v = 0; int64_t p = 0;
+			if (act) { v = order[j]; p = opos[j]; }
+			ch_wave_fence();
+			if (act) { order[j + 1] = v; opos[j + 1] = p; }
+			ch_wave_fence();
+		}
+		order[at] = cv; opos[at] = pv;
+		ch_wave_fence();
+		return;
+	}
+#endif
+	for (int j = nc; j > at; --j) { order[j] = order[j - 1]; opos[j] = opos[j - 1]; }
+	order[at] = cv; opos[at] = pv;
+}
+
+// first index in [lo, hi) for which f is true, hi if none; f must be free of side effects
+template <bool COOP, class F> CH_HD inline int first_true(int lo, int hi, F f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (COOP) {
+		const int lane = ch_lane();
+		for (int b = lo; b < hi; b += 64) {
+			const int i = b + lane;
+			const bool p = i < hi && f(i);
+			const unsigned long long m = __ballot(p);
+			if (m) return b + (int)__builtin_ctzll(m);
+		}
+		return hi;
+	}
+#endif
+	for (int i = lo; i < hi; ++i) if (f(i)) return i;
+	return hi;
+}
+
+// sort n distinct 64-bit keys ascending (any algorithm gives the same result)
+template <bool COOP> CH_HD inline void sort_distinct(uint64_t *a, uint64_t *tmp, int n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (COOP && n > 24) {          // rank sort: element i goes to the number of keys below it
+		const int lane = ch_lane();
+		for (int b = 0; b < n; b += 64) {
+			const int i = b + lane;
+			if (i < n) {
+				const uint64_t v = a[i]; int rank = 0;
+				for (int j = 0; j < n; ++j) rank += a[j] < v;
+				tmp[rank] = v;
+			}
+		}
+		ch_wave_fence();
+		for (int b = 0; b < n; b += 64) { const int i = b + lane; if (i < n) a[i] = tmp[i]; }
+		ch_wave_fence();
+		return;
+	}
+#endif
+	(void)tmp;
+	for (int i = 1; i < n; ++i) {
+		const uint64_t v = a[i]; int j = i;
+		for (; j > 0 && a[j - 1] > v; --j) a[j] = a[j - 1];
+		a[j] = v;
+	}
+}
+
+// The read: returns through x.regs (slot order = creation order), x.regs_per_read[r], x.jobs_per_read[r].
+template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r)
+{
+	const bmh_chain_opt_t &o = x.o;
+	const uint32_t base = x.prefix[r];
+	const int n = (int)x.n_ref[r];
+	const int l_query = (int)x.read_lens[r];
+	const int64_t l_pac = x.l_pac;
+	ch_seed_t *S = x.seeds + base; ch_chain_t *CH = x.chains + base; uint32_t *order = x.order + base; int64_t *opos = x.opos + base;
+	uint32_t *klist = x.klist + base; uint64_t *srt = x.srt + base; uint32_t *cidx = x.cidx + base; ch_reg_t *R = x.regs + base;
+	x.regs_per_read[r] = 0; x.jobs_per_read[r] = 0;
+	if (n == 0 || l_query < o.min_seed_len) return;
+	if (l_query > CH_MAX_READ_LEN) { *x.err = 1; return; }
+	const uint64_t *g_rbeg = x.rbeg + base; const int32_t *g_qbeg = x.qbeg + 2 * (size_t)base; const uint32_t *g_score = x.score + base;
+
+	// ---------------------------------------------------------------- mem_chain
+	int nc = 0, ns = 0;
+	for (int i = 0; i < n;) {
+		const uint32_t cnt = g_score[i];
+		if (cnt == 0) break;                               // malformed group head; cannot happen with bmh_seed_batch output
+		const int sb = g_qbeg[2 * i], slen = g_qbeg[2 * i + 1] - sb;
+		const int step = cnt > (uint32_t)o.max_occ ? (int)(cnt / o.max_occ) : 1;
+		int count = 0;
+		for (int64_t k = 0; k < (int64_t)cnt && count < o.max_occ; k += step, ++count) {
+			const int64_t rb = (int64_t)g_rbeg[i + k];
+			const int rid = intv2rid(x, rb, rb + slen);
+			if (rid < 0) continue;
+			// closest chain at or below the seed: upper bound over opos[0..nc), then one back
+			int lo = 0, hi = nc;
+			while (lo < hi) { const int mid = (lo + hi) >> 1; if (opos[mid] <= rb) lo = mid + 1; else hi = mid; }
+			bool to_add = true;
+			if (lo > 0) {
+				ch_chain_t &c = CH[order[lo - 1]];
+				const ch_seed_t first = S[c.head], last = S[c.tail];
+				const int64_t qend = last.qbeg + last.len, rend = last.rbeg + last.len;
+				if (rid == c.rid) {                            // test_and_merge
+					if (sb >= first.qbeg && sb + slen <= qend && rb >= first.rbeg && rb + slen <= rend) to_add = false;   // contained
+					else if (!((last.rbeg < l_pac || first.rbeg < l_pac) && rb >= l_pac)) {
+						const int64_t xq = sb - last.qbeg, y = rb - last.rbeg;
+						if (y >= 0 && xq - y <= o.w && y - xq <= o.w && xq - last.len < o.max_chain_gap && y - last.len < o.max_chain_gap) {
+							ch_seed_t s; s.rbeg = rb; s.qbeg = sb; s.len = slen; s.next = 0xFFFFFFFFu; s.pad = 0;
+							S[ns] = s; S[c.tail].next = (uint32_t)ns; c.tail = (uint32_t)ns; ++c.n; ++ns;
+							to_add = false;
+						}
+					}
+				}
+			}
+			if (to_add) {
+				ch_seed_t s; s.rbeg = rb; s.qbeg = sb; s.len = slen; s.next = 0xFFFFFFFFu; s.pad = 0;
+				S[ns] = s;
+				ch_chain_t c; c.head = c.tail = (uint32_t)ns; c.n = 1; c.rid = rid; c.w = 0; c.first = -1; c.beg = c.end = 0; c.kept = 0; c.pad = 0;
+				CH[nc] = c;
+				sorted_insert<COOP>(order, opos, nc, lo, (uint32_t)nc, rb);
+				++ns; ++nc;
+			}
+		}
+		i += (int)cnt;
+	}
+	if (nc == 0) return;
+
+	// ---------------------------------------------------------------- mem_chain_flt
+	int na = 0;
+	for (int i = 0; i < nc; ++i) {
+		const uint32_t ci = order[i];
+		ch_chain_t &c = CH[ci];
+		int64_t end = 0; int w = 0;
+		for (uint32_t p = c.head; p != 0xFFFFFFFFu; p = S[p].next) {       // mem_chain_weight: query cover
+			const ch_seed_t s = S[p];
+			if (s.qbeg >= end) w += s.len;
+			else if (s.qbeg + s.len > end) w += (int)(s.qbeg + s.len - end);
+			end = end > s.qbeg + s.len ? end : s.qbeg + s.len;
+		}
+		const int tmp = w; w = 0; end = 0;
+		for (uint32_t p = c.head; p != 0xFFFFFFFFu; p = S[p].next) {       // reference cover
+			const ch_seed_t s = S[p];
+			if (s.rbeg >= end) w += s.len;
+			else if (s.rbeg + s.len > end) w += (int)(s.rbeg + s.len - end);
+			end = end > s.rbeg + s.len ? end : s.rbeg + s.len;
+		}
+		w = w < tmp ? w : tmp;
+		w = w < 1 << 30 ? w : (1 << 30) - 1;
+		c.w = w; c.first = -1; c.kept = 0;
+		c.beg = S[c.head].qbeg; c.end = S[c.tail].qbeg + S[c.tail].len;
+		if (w >= o.min_chain_weight) srt[na++] = (uint64_t)(uint32_t)w << 32 | ci;
+	}
+	if (na == 0) return;
+	if (!w_introsort(srt, na)) { *x.err = 2; return; }
+	for (int i = 0; i < na; ++i) order[i] = (uint32_t)srt[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (COOP) ch_wave_fence();
+#endif
+	int nk = 0;
+	CH[order[0]].kept = 3; klist[nk++] = 0;
+	for (int i = 1; i < na; ++i) {
+		const ch_chain_t ai = CH[order[i]];
+		bool large_ovlp = false, broke = false;
+		auto test = [&](int k, bool &ovl, bool &brk) {
+			const ch_chain_t aj = CH[order[klist[k]]];
+			ovl = brk = false;
+			const int b_max = aj.beg > ai.beg ? aj.beg : ai.beg;
+			const int e_min = aj.end < ai.end ? aj.end : ai.end;
+			if (e_min > b_max) {
+				const int li = ai.end - ai.beg, lj = aj.end - aj.beg;
+				const int min_l = li < lj ? li : lj;
+				if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap) {
+					ovl = true;
+					if (ai.w < aj.w * o.drop_ratio && aj.w - ai.w >= o.min_seed_len << 1) brk = true;
+				}
+			}
+		};
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (COOP) {
+			const int lane = ch_lane();
+			for (int b = 0; b < nk && !broke; b += 64) {
+				const int k = b + lane;
+				bool ovl = false, brk = false;
+				if (k < nk) test(k, ovl, brk);
+				const unsigned long long mb = __ballot(brk), mo = __ballot(ovl);
+				unsigned long long vm = ~0ull;
+				if (mb) { const int f = (int)__builtin_ctzll(mb); vm = f == 63 ? ~0ull : ((1ull << (f + 1)) - 1); broke = true; }
+				if (ovl && ((vm >> lane) & 1)) { ch_chain_t &cj = CH[order[klist[k]]]; if (cj.first < 0) cj.first = i; }
+				if (mo & vm) large_ovlp = true;
+			}
+			ch_wave_fence();
+		} else
+#endif
+		{
+			for (int k = 0; k < nk; ++k) {
+				bool ovl, brk;
+				test(k, ovl, brk);
+				if (ovl) { large_ovlp = true; ch_chain_t &cj = CH[order[klist[k]]]; if (cj.first < 0) cj.first = i; }
+				if (brk) { broke = true; break; }
+			}
+		}
+		if (!broke) { klist[nk++] = (uint32_t)i; CH[order[i]].kept = large_ovlp ? 2 : 3; }
+	}
+	for (int k = 0; k < nk; ++k) { const int f = CH[order[klist[k]]].first; if (f >= 0) CH[order[f]].kept = 1; }
+	{
+		int i, k;
+		for (i = k = 0; i < na; ++i) {
+			const uint32_t kp = CH[order[i]].kept;
+			if (kp == 0 || kp == 3) continue;
+			if (++k >= o.max_chain_extend) break;
+		}
+		for (; i < na; ++i) if (CH[order[i]].kept < 3) CH[order[i]].kept = 0;
+	}
+
+	// ---------------------------------------------------------------- mem_chain2aln, chain by chain in filtered order
+	int n_regs = 0, n_jobs = 0;
+	for (int ia = 0; ia < na; ++ia) {
+		const ch_chain_t c = CH[order[ia]];
+		if (c.kept == 0) continue;
+		const int cn = (int)c.n;
+		int64_t rmax0 = l_pac << 1, rmax1 = 0;
+		{
+			int i = 0;
+			for (uint32_t p = c.head; p != 0xFFFFFFFFu; p = S[p].next, ++i) {
+				const ch_seed_t t = S[p];
+				const int64_t b = t.rbeg - (t.qbeg + cal_max_gap(o, t.qbeg));
+				const int64_t e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + cal_max_gap(o, l_query - t.qbeg - t.len));
+				rmax0 = rmax0 < b ? rmax0 : b;
+				rmax1 = rmax1 > e ? rmax1 : e;
+				cidx[i] = p;
+				srt[i] = (uint64_t)(uint32_t)t.len << 32 | (uint32_t)i;           // score == len
+			}
+		}
+		rmax0 = rmax0 > 0 ? rmax0 : 0;
+		rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+		const ch_seed_t s0 = S[c.head];
+		if (rmax0 < l_pac && l_pac < rmax1) { if (s0.rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
+		{   // bns_fetch_seq clips the window to the contig of the first seed (src/bntseq.c:531-556)
+			int is_rev;
+			const int rid = pos2rid(x, depos(x, s0.rbeg, &is_rev));
+			int64_t far_beg = x.n_contigs > 1 ? x.ctg_off[rid] : 0, far_end = far_beg + (x.n_contigs > 1 ? x.ctg_len[rid] : l_pac);
+			if (is_rev) { const int64_t tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
+			rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+			rmax1 = rmax1 < far_end ? rmax1 : far_end;
+		}
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (COOP) ch_wave_fence();
+#endif
+		sort_distinct<COOP>(srt, (uint64_t *)(opos), cn);       // opos is free by now (8 bytes per entry)
+		for (int k = cn - 1; k >= 0; --k) {
+			const ch_seed_t s = S[cidx[(uint32_t)srt[k]]];
+			const int hit = first_true<COOP>(0, n_regs, [&](int i) {              // extension (estimated) made before? :1235-1256
+				const ch_reg_t p = R[i];
+				if (s.rbeg < p.rb_est || s.rbeg + s.len > p.re_est || s.qbeg < p.qb_est || s.qbeg + s.len > p.qe_est) return false;
+				if (s.len - p.seedlen0 > .1 * l_query) return false;
+				int qd = s.qbeg - p.qb_est; int64_t rd = s.rbeg - p.rb_est;
+				int max_gap = cal_max_gap(o, qd < rd ? qd : (int)rd);
+				int w = max_gap < o.w ? max_gap : o.w;
+				if (qd - rd < w && rd - qd < w) return true;
+				qd = p.qe_est - (s.qbeg + s.len); rd = p.re_est - (s.rbeg + s.len);
+				max_gap = cal_max_gap(o, qd < rd ? qd : (int)rd);
+				w = max_gap < o.w ? max_gap : o.w;
+				return qd - rd < w && rd - qd < w;
+			});
+			if (hit < n_regs) {                                                   // :1258-1276
+				const int j = first_true<COOP>(k + 1, cn, [&](int j) {
+					if (srt[j] == 0) return false;
+					const ch_seed_t t = S[cidx[(uint32_t)srt[j]]];
+					if (t.len < s.len * .95) return false;
+					if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) return true;
+					if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) return true;
+					return false;
+				});
+				if (j == cn) {
+					srt[k] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+					if (COOP) ch_wave_fence();
+#endif
+					continue;
+				}
+			}
+			ch_reg_t a;
+			const int fwd = (int)(0.85 * (l_query - (s.qbeg + s.len)));           // FILTER_COEF, :52, :1285-1298
+			a.qe_est = (s.qbeg + s.len) + fwd < l_query ? (s.qbeg + s.len) + fwd : l_query;
+			a.re_est = (s.rbeg + s.len) + fwd < l_pac << 1 ? (s.rbeg + s.len) + fwd : l_pac << 1;
+			const int back = (int)(0.85 * (s.qbeg + 1));
+			a.qb_est = (s.qbeg - back) > 0 ? (s.qbeg - back) : 0;
+			a.rb_est = (s.rbeg - back) > 0 ? (s.rbeg - back) : 0;
+			if (a.rb_est < l_pac && l_pac < a.qe_est) { if (s.rbeg < l_pac) a.re_est = l_pac; else a.rb_est = l_pac; }   // (sic) qe_est, :1292
+			a.seed_rbeg = s.rbeg; a.seed_qbeg = s.qbeg; a.seedlen0 = s.len; a.rmax0 = rmax0;
+			a.lr = (int)(s.rbeg - rmax0);
+			a.rq = l_query - (s.qbeg + s.len);
+			a.rr = (int)(rmax1 - rmax0) - (a.lr + s.len);
+			a.pad = 0;
+			R[n_regs++] = a;
+			n_jobs += (s.qbeg > 0) + (a.rq > 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (COOP) ch_wave_fence();
+#endif
+		}
+	}
+	x.regs_per_read[r] = (uint32_t)n_regs; x.jobs_per_read[r] = (uint32_t)n_jobs;
+}
+
+} // namespace chain_core

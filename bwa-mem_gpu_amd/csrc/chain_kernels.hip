@@ -1,0 +1,313 @@
+// Device job builder: the stage between the two kernels of the hot path, on
+// the GPU so that a batch goes reads -> seeds -> extension jobs -> regions without leaving HBM.
+//   chain_lane_kernel / chain_wave_kernel   per-read chaining core (chain_core.h): mem_chain, mem_chain_flt,
+//                                           mem_chain2aln of /root/reference/src/bwamem.c:404-477, 487-559, 1170-1479
+//   emit_kernel                             regions and job descriptors in batch order (per read, per region,
+//                                           LEFT then RIGHT -- the order of bmh_build_jobs)
+//   materialize_kernel                      on-device reference fetch: query bases from the reads, target bases from
+//                                           the 2-bit pac incl. the reverse strand and the LEFT reversal
+//                                           (bns_get_seq src/bntseq.c:558-580; bwamem.c:1328-1334)
+//   merge_kernel                            extension results -> regions (src/bwamem.c:2297-2303)
+// The batch it produces is byte-identical to bmh_build_jobs' (tests/test_gpu_parity.py).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <stdlib.h>
+#include "bmh_internal.h"
+#include "chain_core.h"
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
+
+struct ch_outreg_t { int64_t seed_rbeg; int32_t seed_qbeg, seedlen0, job0, job1; uint32_t read; int32_t l_query; };   // 32 B
+
+struct chain_args_t {
+	ch_ctx_t x;
+	uint32_t n_reads, heavy_thresh;
+	uint32_t *heavy_list; uint32_t *heavy_n;
+};
+
+__global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A)
+{
+	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+	if (r >= A.n_reads) return;
+	if (A.x.n_ref[r] > A.heavy_thresh) { A.heavy_list[atomicAdd(A.heavy_n, 1u)] = r; return; }
+	chain_core::chain_read<false>(A.x, r);
+}
+
+// one wave per heavy read; the list was filled by chain_lane_kernel (earlier on the same stream)
+__global__ void __launch_bounds__(64) chain_wave_kernel(chain_args_t A)
+{
+	const uint32_t nh = *A.heavy_n;
+	for (uint32_t i = blockIdx.x; i < nh; i += gridDim.x) chain_core::chain_read<true>(A.x, A.heavy_list[i]);
+}
+
+struct emit_args_t {
+	const ch_reg_t *regs; const uint32_t *prefix, *regs_per_read, *reg_off, *job_off, *read_offs, *read_lens;
+	uint32_t n_reads;
+	ch_outreg_t *outregs;
+	uint32_t *qlen, *tlen, *h0, *job_read, *job_reg, *job_side, *jq_src; int64_t *jt0;
+};
+
+__global__ void __launch_bounds__(256) emit_kernel(emit_args_t A)
+{
+	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+	if (r >= A.n_reads) return;
+	const uint32_t nr = A.regs_per_read[r];
+	if (nr == 0) return;
+	const ch_reg_t *R = A.regs + A.prefix[r];
+	uint32_t g = A.reg_off[r], j = A.job_off[r];
+	const uint32_t roff = A.read_offs[r]; const int lq_ = (int)A.read_lens[r];
+	for (uint32_t i = 0; i < nr; ++i, ++g) {
+		const ch_reg_t a = R[i];
+		ch_outreg_t o; o.seed_rbeg = a.seed_rbeg; o.seed_qbeg = a.seed_qbeg; o.seedlen0 = a.seedlen0; o.job0 = o.job1 = -1; o.read = r; o.l_query = lq_;
+		if (a.seed_qbeg > 0) {
+			o.job0 = (int32_t)j;
+			A.qlen[j] = (uint32_t)a.seed_qbeg; A.tlen[j] = (uint32_t)a.lr; A.h0[j] = (uint32_t)a.seedlen0;
+			A.job_read[j] = r; A.job_reg[j] = g; A.job_side[j] = 0; A.jq_src[j] = roff; A.jt0[j] = a.rmax0; ++j;
+		}
+		if (a.rq > 0) {
+			o.job1 = (int32_t)j;
+			A.qlen[j] = (uint32_t)a.rq; A.tlen[j] = (uint32_t)a.rr; A.h0[j] = (uint32_t)a.seedlen0;
+			A.job_read[j] = r; A.job_reg[j] = g; A.job_side[j] = 1; A.jq_src[j] = roff + (uint32_t)(a.seed_qbeg + a.seedlen0);
+			A.jt0[j] = a.seed_rbeg + a.seedlen0; ++j;
+		}
+		A.outregs[g] = o;
+	}
+}
+
+__device__ __forceinline__ int ch_ascii_code(uint8_t ch)      // nst_nt4_table for the letters a read can hold
+{
+	ch &= 0xDF;
+	return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+}
+
+struct mat_args_t {
+	const uint8_t *reads; const uint8_t *pac; int64_t l_pac;
+	const uint32_t *qlen, *tlen, *job_side, *jq_src; const int64_t *jt0; const uint64_t *qoff64, *toff64;
+	uint32_t n_jobs;
+	uint8_t *q, *t; uint32_t *qoff, *toff;
+};
+
+// 16 lanes per job
+__global__ void __launch_bounds__(256) materialize_kernel(mat_args_t A)
+{
+	const uint32_t l16 = threadIdx.x & 15u;
+	for (uint64_t j = (uint64_t)blockIdx.x * 16u + (threadIdx.x >> 4); j < A.n_jobs; j += (uint64_t)gridDim.x * 16u) {
+		const int qn = (int)A.qlen[j], tn = (int)A.tlen[j];
+		const bool left = A.job_side[j] == 0;
+		const uint64_t qo = A.qoff64[j], to = A.toff64[j];
+		if (l16 == 0) { A.qoff[j] = (uint32_t)qo; A.toff[j] = (uint32_t)to; }
+		const uint8_t *src = A.reads + A.jq_src[j];
+		for (int i = (int)l16; i < qn; i += 16) A.q[qo + i] = (uint8_t)ch_ascii_code(src[left ? qn - 1 - i : i]);
+		const int64_t t0 = A.jt0[j];
+		for (int i = (int)l16; i < tn; i += 16) {
+			const int64_t p = left ? t0 + tn - 1 - i : t0 + i;           // position in fwd . revcomp(fwd)
+			const bool rev = p >= A.l_pac;
+			const int64_t f = rev ? (A.l_pac << 1) - 1 - p : p;
+			const int c = (A.pac[f >> 2] >> ((~f & 3) << 1)) & 3;
+			A.t[to + i] = (uint8_t)(rev ? 3 - c : c);
+		}
+	}
+}
+
+__global__ void __launch_bounds__(256) merge_kernel(const ch_outreg_t *__restrict__ regs, uint32_t n_regs, const int32_t *__restrict__ out3, int32_t *__restrict__ regs_out)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n_regs) return;
+	const ch_outreg_t a = regs[i];
+	int score, qb, qe; int64_t rb, re;
+	const int sides = (a.job0 >= 0) + (a.job1 >= 0);
+	if (sides > 0) {
+		int ls = 0, lq = 0, lt = 0, rs = 0, rq = 0, rt = 0;
+		if (a.job0 >= 0) { ls = out3[3 * (size_t)a.job0]; lq = out3[3 * (size_t)a.job0 + 1]; lt = out3[3 * (size_t)a.job0 + 2]; }
+		if (a.job1 >= 0) { rs = out3[3 * (size_t)a.job1]; rq = out3[3 * (size_t)a.job1 + 1]; rt = out3[3 * (size_t)a.job1 + 2]; }
+		score = ls + rs - (sides == 2 ? a.seedlen0 : 0);
+		qb = a.seed_qbeg - lq; qe = a.seed_qbeg + a.seedlen0 + rq;
+		rb = a.seed_rbeg - lt; re = a.seed_rbeg + a.seedlen0 + rt;
+	} else {
+		score = a.seedlen0; qb = 0; qe = a.l_query; rb = a.seed_rbeg; re = a.seed_rbeg + a.seedlen0;
+	}
+	int32_t *o = regs_out + 8 * (size_t)i;
+	o[0] = (int32_t)a.read; o[1] = score; o[2] = qb; o[3] = qe;
+	o[4] = (int32_t)(uint32_t)rb; o[5] = (int32_t)(rb >> 32); o[6] = (int32_t)(uint32_t)re; o[7] = (int32_t)(re >> 32);
+}
+
+// ------------------------------------------------------------------------------------------------ workspace / API
+
+struct bmh_chain_ws {
+	uint32_t max_reads; uint64_t max_seeds;
+	// per-seed scratch
+	ch_seed_t *seeds; ch_chain_t *chains; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx; ch_reg_t *regs;
+	// per read
+	uint32_t *regs_per_read, *jobs_per_read, *reg_off, *job_off, *heavy_list;
+	uint32_t *counters;            // [0] heavy_n  [1] err
+	// contigs
+	int n_contigs; int64_t *ctg_off; int32_t *ctg_len;
+	// outputs, grown on demand
+	uint64_t cap_regs, cap_jobs, cap_q, cap_t;
+	ch_outreg_t *outregs;
+	uint32_t *qlen, *tlen, *h0, *job_read, *job_reg, *job_side, *jq_src, *qoff, *toff; int64_t *jt0; uint64_t *qoff64, *toff64;
+	uint8_t *q, *t;
+	void *scan_tmp; size_t scan_tmp_bytes;
+	uint64_t n_regs, n_jobs;
+	uint32_t *h_pin;               // pinned host words for the small D2H copies
+};
+
+extern "C" void bmh_chain_ws_free(bmh_chain_ws_t *w)
+{
+	if (!w) return;
+	void *ps[] = {w->seeds, w->chains, w->order, w->opos, w->klist, w->srt, w->cidx, w->regs, w->regs_per_read, w->jobs_per_read, w->reg_off,
+	              w->job_off, w->heavy_list, w->counters, w->ctg_off, w->ctg_len, w->outregs, w->qlen, w->tlen, w->h0, w->job_read, w->job_reg,
+	              w->job_side, w->jq_src, w->qoff, w->toff, w->jt0, w->qoff64, w->toff64, w->q, w->t, w->scan_tmp};
+	for (void *p : ps) if (p) (void)hipFree(p);
+	if (w->h_pin) (void)hipHostFree(w->h_pin);
+	free(w);
+}
+
+extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_seeds)
+{
+	if (max_reads == 0 || max_seeds == 0) { bmh_set_error("bmh_chain_ws_create: empty capacity"); return nullptr; }
+	bmh_chain_ws *w = (bmh_chain_ws *)calloc(1, sizeof(bmh_chain_ws));
+	w->max_reads = max_reads; w->max_seeds = max_seeds;
+	bool ok = true;
+#define A(p, n) ok = ok && hipMalloc((void **)&(p), (size_t)(n)) == hipSuccess
+	const size_t S = (size_t)max_seeds + 1;
+	A(w->seeds, sizeof(ch_seed_t) * S); A(w->chains, sizeof(ch_chain_t) * S); A(w->order, 4 * S); A(w->opos, 8 * S); A(w->klist, 4 * S);
+	A(w->srt, 8 * S); A(w->cidx, 4 * S); A(w->regs, sizeof(ch_reg_t) * S);
+	const size_t Rn = (size_t)max_reads + 1;
+	A(w->regs_per_read, 4 * Rn); A(w->jobs_per_read, 4 * Rn); A(w->reg_off, 4 * Rn); A(w->job_off, 4 * Rn); A(w->heavy_list, 4 * Rn);
+	A(w->counters, 64);
+	size_t t1 = 0, t2 = 0;
+	rocprim::exclusive_scan(nullptr, t1, w->regs_per_read, w->reg_off, 0u, Rn, rocprim::plus<uint32_t>(), 0);
+	rocprim::exclusive_scan(nullptr, t2, (uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0, 2 * S + 1, rocprim::plus<uint64_t>(), 0);
+	w->scan_tmp_bytes = t1 > t2 ? t1 : t2;
+	A(w->scan_tmp, w->scan_tmp_bytes + 256);
+#undef A
+	ok = ok && hipHostMalloc((void **)&w->h_pin, 64) == hipSuccess;
+	if (!ok) { bmh_set_error("bmh_chain_ws_create: hipMalloc failed (%s)", hipGetErrorString(hipGetLastError())); bmh_chain_ws_free(w); return nullptr; }
+	w->n_contigs = 1;
+	return w;
+}
+
+extern "C" int bmh_chain_set_contigs(bmh_chain_ws_t *w, int n_contigs, const int64_t *offset, const int32_t *len)
+{
+	if (!w) { bmh_set_error("bmh_chain_set_contigs: null workspace"); return BMH_EINVAL; }
+	if (w->ctg_off) { (void)hipFree(w->ctg_off); w->ctg_off = nullptr; }
+	if (w->ctg_len) { (void)hipFree(w->ctg_len); w->ctg_len = nullptr; }
+	w->n_contigs = n_contigs > 1 ? n_contigs : 1;
+	if (n_contigs <= 1) return BMH_OK;
+	if (!offset || !len) { bmh_set_error("bmh_chain_set_contigs: null arrays"); return BMH_EINVAL; }
+	HIPCK(hipMalloc((void **)&w->ctg_off, 8 * (size_t)n_contigs)); HIPCK(hipMalloc((void **)&w->ctg_len, 4 * (size_t)n_contigs));
+	HIPCK(hipMemcpy(w->ctg_off, offset, 8 * (size_t)n_contigs, hipMemcpyHostToDevice));
+	HIPCK(hipMemcpy(w->ctg_len, len, 4 * (size_t)n_contigs, hipMemcpyHostToDevice));
+	return BMH_OK;
+}
+
+template <class T> static int grow(T *&p, uint64_t need_elems)
+{
+	if (p) { (void)hipFree(p); p = nullptr; }
+	if (hipMalloc((void **)&p, sizeof(T) * (size_t)need_elems) != hipSuccess) { bmh_set_error("bmh_chain_batch: hipMalloc of %llu bytes failed", (unsigned long long)(sizeof(T) * need_elems)); return BMH_ENOMEM; }
+	return BMH_OK;
+}
+
+static inline unsigned nblk(uint64_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
+
+extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, const bmh_index_t *idx, const uint8_t *d_reads,
+                               const uint32_t *d_offs, const uint32_t *d_lens, uint32_t n_reads, const bmh_seeds_t *seeds,
+                               void *stream_, bmh_dev_jobs_t *out)
+{
+	if (!w || !opt || !idx || !seeds || !out) { bmh_set_error("bmh_chain_batch: null argument"); return BMH_EINVAL; }
+	memset(out, 0, sizeof(*out));
+	if (!idx->dev.pac || idx->dev.l_pac == 0) { bmh_set_error("bmh_chain_batch: the index was uploaded without the 2-bit reference (pac)"); return BMH_EINVAL; }
+	if (idx->dev.l_pac * 2 != idx->dev.seq_len) { bmh_set_error("bmh_chain_batch: l_pac does not match the index"); return BMH_EINVAL; }
+	if (n_reads > w->max_reads) { bmh_set_error("bmh_chain_batch: %u reads > workspace capacity %u", n_reads, w->max_reads); return BMH_ECAPACITY; }
+	if (seeds->n_seeds > w->max_seeds) { bmh_set_error("bmh_chain_batch: %llu seeds > workspace capacity %llu", (unsigned long long)seeds->n_seeds, (unsigned long long)w->max_seeds); return BMH_ECAPACITY; }
+	if (opt->max_occ < 1 || opt->e_del < 1 || opt->e_ins < 1) { bmh_set_error("bmh_chain_batch: bad options"); return BMH_EINVAL; }
+	hipStream_t st = (hipStream_t)stream_;
+	w->n_regs = w->n_jobs = 0;
+	if (n_reads == 0) return BMH_OK;
+	chain_args_t A;
+	memset(&A, 0, sizeof(A));
+	A.x.o = *opt; A.x.l_pac = (int64_t)idx->dev.l_pac; A.x.n_contigs = w->n_contigs; A.x.ctg_off = w->ctg_off; A.x.ctg_len = w->ctg_len;
+	A.x.rbeg = seeds->d_rbeg; A.x.qbeg = seeds->d_qbeg; A.x.score = seeds->d_score; A.x.n_ref = seeds->d_n_ref_pos; A.x.prefix = seeds->d_prefix;
+	A.x.read_lens = d_lens;
+	A.x.seeds = w->seeds; A.x.chains = w->chains; A.x.order = w->order; A.x.opos = w->opos; A.x.klist = w->klist; A.x.srt = w->srt; A.x.cidx = w->cidx;
+	A.x.regs = w->regs; A.x.regs_per_read = w->regs_per_read; A.x.jobs_per_read = w->jobs_per_read; A.x.err = (int *)(w->counters + 1);
+	A.n_reads = n_reads;
+	const char *ht = getenv("BMH_CHAIN_HEAVY");
+	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : 32u;
+	A.heavy_list = w->heavy_list; A.heavy_n = w->counters;
+	HIPCK(hipMemsetAsync(w->counters, 0, 64, st));
+	HIPCK(hipMemsetAsync(w->regs_per_read + n_reads, 0, 4, st));
+	HIPCK(hipMemsetAsync(w->jobs_per_read + n_reads, 0, 4, st));
+	chain_lane_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(A);
+	chain_wave_kernel<<<2048, 64, 0, st>>>(A);
+	size_t tb = w->scan_tmp_bytes;
+	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->regs_per_read, w->reg_off, 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
+	tb = w->scan_tmp_bytes;
+	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->jobs_per_read, w->job_off, 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
+	HIPCK(hipMemcpyAsync(w->h_pin + 0, w->reg_off + n_reads, 4, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(w->h_pin + 1, w->job_off + n_reads, 4, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(w->h_pin + 2, w->counters, 8, hipMemcpyDeviceToHost, st));
+	HIPCK(hipStreamSynchronize(st));
+	HIPCK(hipGetLastError());
+	if (w->h_pin[3] == 1) { bmh_set_error("bmh_chain_batch: a read is longer than %d bp (mem_flt_chained_seeds is not restated)", CH_MAX_READ_LEN); return BMH_EINVAL; }
+	if (w->h_pin[3] != 0) { bmh_set_error("bmh_chain_batch: internal error %u in the chaining kernel", w->h_pin[3]); return BMH_ENODEV; }
+	const uint64_t n_regs = w->h_pin[0], n_jobs = w->h_pin[1];
+	w->n_regs = n_regs; w->n_jobs = n_jobs;
+	out->n_regs = n_regs; out->n_jobs = n_jobs; out->n_heavy_reads = w->h_pin[2];
+	out->d_regs_per_read = w->regs_per_read;
+	if (n_regs > w->cap_regs) {
+		const uint64_t c = n_regs + n_regs / 4 + 1024;
+		if (grow(w->outregs, c) != BMH_OK) return BMH_ENOMEM;
+		w->cap_regs = c;
+	}
+	if (n_jobs + 1 > w->cap_jobs) {
+		const uint64_t c = n_jobs + n_jobs / 4 + 1024;
+		uint32_t **u32s[] = {&w->qlen, &w->tlen, &w->h0, &w->job_read, &w->job_reg, &w->job_side, &w->jq_src, &w->qoff, &w->toff};
+		for (uint32_t **p : u32s) if (grow(*p, c) != BMH_OK) return BMH_ENOMEM;
+		if (grow(w->jt0, c) != BMH_OK || grow(w->qoff64, c) != BMH_OK || grow(w->toff64, c) != BMH_OK) return BMH_ENOMEM;
+		w->cap_jobs = c;
+	}
+	if (n_regs == 0) return BMH_OK;
+	emit_args_t E;
+	E.regs = w->regs; E.prefix = seeds->d_prefix; E.regs_per_read = w->regs_per_read; E.reg_off = w->reg_off; E.job_off = w->job_off;
+	E.read_offs = d_offs; E.read_lens = d_lens; E.n_reads = n_reads; E.outregs = w->outregs;
+	E.qlen = w->qlen; E.tlen = w->tlen; E.h0 = w->h0; E.job_read = w->job_read; E.job_reg = w->job_reg; E.job_side = w->job_side; E.jq_src = w->jq_src; E.jt0 = w->jt0;
+	emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
+	out->d_qlen = w->qlen; out->d_tlen = w->tlen; out->d_h0 = w->h0; out->d_job_read = w->job_read; out->d_job_reg = w->job_reg; out->d_job_side = w->job_side;
+	out->d_qoff = w->qoff; out->d_toff = w->toff;
+	if (n_jobs == 0) return BMH_OK;
+	// one extra (zero) element so the scans also yield the totals
+	HIPCK(hipMemsetAsync(w->qlen + n_jobs, 0, 4, st)); HIPCK(hipMemsetAsync(w->tlen + n_jobs, 0, 4, st));
+	tb = w->scan_tmp_bytes;
+	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->qlen, w->qoff64, (uint64_t)0, (size_t)n_jobs + 1, rocprim::plus<uint64_t>(), st));
+	tb = w->scan_tmp_bytes;
+	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->tlen, w->toff64, (uint64_t)0, (size_t)n_jobs + 1, rocprim::plus<uint64_t>(), st));
+	uint64_t *h64 = (uint64_t *)(w->h_pin + 4);
+	HIPCK(hipMemcpyAsync(h64 + 0, w->qoff64 + n_jobs, 8, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(h64 + 1, w->toff64 + n_jobs, 8, hipMemcpyDeviceToHost, st));
+	HIPCK(hipStreamSynchronize(st));
+	const uint64_t qb = h64[0], tbytes = h64[1];
+	if (qb >= (1ull << 32) || tbytes >= (1ull << 32)) { bmh_set_error("bmh_chain_batch: batch exceeds 4 GiB of bases; split the read set"); return BMH_ECAPACITY; }
+	if (qb + 16 > w->cap_q) { const uint64_t c = qb + qb / 4 + 4096; if (grow(w->q, c) != BMH_OK) return BMH_ENOMEM; w->cap_q = c; }
+	if (tbytes + 16 > w->cap_t) { const uint64_t c = tbytes + tbytes / 4 + 4096; if (grow(w->t, c) != BMH_OK) return BMH_ENOMEM; w->cap_t = c; }
+	mat_args_t M;
+	M.reads = d_reads; M.pac = idx->dev.pac; M.l_pac = (int64_t)idx->dev.l_pac;
+	M.qlen = w->qlen; M.tlen = w->tlen; M.job_side = w->job_side; M.jq_src = w->jq_src; M.jt0 = w->jt0; M.qoff64 = w->qoff64; M.toff64 = w->toff64;
+	M.n_jobs = (uint32_t)n_jobs; M.q = w->q; M.t = w->t; M.qoff = w->qoff; M.toff = w->toff;
+	unsigned gb = nblk(n_jobs, 16); if (gb > 65536u) gb = 65536u;
+	materialize_kernel<<<gb, 256, 0, st>>>(M);
+	HIPCK(hipGetLastError());
+	out->q_bytes = qb; out->t_bytes = tbytes; out->d_q = w->q; out->d_t = w->t;
+	return BMH_OK;
+}
+
+extern "C" int bmh_chain_merge(bmh_chain_ws_t *w, const int32_t *d_out3, int32_t *d_regs_out, void *stream_)
+{
+	if (!w || !d_regs_out || (w->n_jobs && !d_out3)) { bmh_set_error("bmh_chain_merge: null argument"); return BMH_EINVAL; }
+	if (w->n_regs == 0) return BMH_OK;
+	merge_kernel<<<nblk(w->n_regs, 256), 256, 0, (hipStream_t)stream_>>>(w->outregs, (uint32_t)w->n_regs, d_out3, d_regs_out);
+	HIPCK(hipGetLastError());
+	return BMH_OK;
+}

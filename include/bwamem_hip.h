@@ -157,6 +157,38 @@ void bmh_jobs_arrays(const bmh_jobs_t *j, const uint8_t **q, const uint32_t **qo
  * {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi} */
 int bmh_merge_regs(const bmh_jobs_t *j, const int32_t *out3, int32_t *regs_out);
 
+/* ------------------------------------------------- device job builder (SURVEY 8f ranks 1-2 on the GPU) */
+
+/* The same stage as bmh_build_jobs, on the device: seeds of bmh_seed_batch (still in HBM) -> chains -> filtered
+ * chains -> regions and their LEFT/RIGHT extension jobs, with the query bases taken from the reads and the target
+ * bases fetched from the index's 2-bit reference on the device (bns_fetch_seq, src/bntseq.c:531-580, and the
+ * LEFT-side reversal of src/bwamem.c:1328-1334).  The batch is byte-identical to bmh_build_jobs' and feeds
+ * bmh_extend_batch directly; bmh_chain_merge then turns the extension results into regions.
+ * The index must have been uploaded with its pac. */
+typedef struct bmh_chain_ws bmh_chain_ws_t;
+bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_seeds);
+void bmh_chain_ws_free(bmh_chain_ws_t *ws);
+/* contig table of the reference (host arrays, as in bmh_build_jobs); default: one sequence of l_pac bases */
+int bmh_chain_set_contigs(bmh_chain_ws_t *ws, int n_contigs, const int64_t *contig_offset, const int32_t *contig_len);
+
+typedef struct {
+	uint64_t n_jobs, n_regs, q_bytes, t_bytes;
+	uint64_t n_heavy_reads;          /* reads chained by a whole wave (more than BMH_CHAIN_HEAVY=32 seeds) */
+	const uint8_t *d_q; const uint32_t *d_qoff, *d_qlen;          /* the bmh_extend_batch inputs */
+	const uint8_t *d_t; const uint32_t *d_toff, *d_tlen, *d_h0;
+	const uint32_t *d_job_read, *d_job_reg, *d_job_side;           /* read / region / side (0 left, 1 right) per job */
+	const uint32_t *d_regs_per_read;                               /* [n_reads] */
+} bmh_dev_jobs_t;
+
+/* d_reads/d_offs/d_lens: as for bmh_seed_batch; seeds: its output for the same reads.  Pointers in *out stay valid
+ * until the next call on the workspace.  Synchronises the stream (twice: region/job counts, then base counts). */
+int bmh_chain_batch(bmh_chain_ws_t *ws, const bmh_chain_opt_t *opt, const bmh_index_t *idx, const uint8_t *d_reads,
+                    const uint32_t *d_offs, const uint32_t *d_lens, uint32_t n_reads, const bmh_seeds_t *seeds,
+                    void *stream, bmh_dev_jobs_t *out);
+/* d_out3 = bmh_extend_batch results of the batch's jobs -> d_regs_out[n_regs][8] =
+ * {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi} (src/bwamem.c:2297-2303).  Asynchronous on stream. */
+int bmh_chain_merge(bmh_chain_ws_t *ws, const int32_t *d_out3, int32_t *d_regs_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,42 @@
+"""Times the device job builder on the bench workload: seeding -> bmh_chain_batch -> bmh_extend_batch -> bmh_chain_merge."""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))
+import numpy as np, torch
+import bwamem_hip as B
+from bwamem_hip import pipeline as P
+from bwamem_hip.lib import ChainWorkspace, load_library
+mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 1000
+n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 150
+dev = torch.device("cuda:0")
+g = B.synth.make_genome(int(mbp * 1e6), seed=42)
+idx = B.fmindex.build_fmd_index(g, device="cuda:0")
+torch.cuda.empty_cache()
+bwt, sa, bits = P.index_to_device_tensors(idx, dev)
+pad = (-len(g)) % 4
+codes = torch.from_numpy(np.concatenate([g, np.zeros(pad + 4, np.uint8)])).to(dev).view(-1, 4).to(torch.int32)
+pac = ((codes[:, 0] << 6) | (codes[:, 1] << 4) | (codes[:, 2] << 2) | codes[:, 3]).to(torch.uint8).contiguous()
+dindex = B.Index.from_device(idx.primary, idx.L2, idx.seq_len, bwt, idx.sa_intv, sa, bits, pac_t=pac, l_pac=len(g))
+reads, _ = B.synth.make_reads(g, n_reads, L, seed=7)
+dr = P.reads_to_device(reads, dev)
+ws = B.SeedWorkspace(n_reads, n_reads * L)
+s = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19)
+cw = ChainWorkspace(n_reads, int(s.n_seeds) + 1024)
+lib = load_library()
+for it in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    dj = cw.chain_batch(dindex, dr.ascii, dr.offs, dr.lens, s)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    print("chain_batch %.3f ms  jobs %d regs %d heavy %d qbytes %d tbytes %d" % ((t1 - t0) * 1e3, dj.n_jobs, dj.n_regs, dj.n_heavy_reads, dj.q_bytes, dj.t_bytes), flush=True)
+out3 = torch.zeros(int(dj.n_jobs), 3, dtype=torch.int32, device=dev)
+regs = torch.zeros(int(dj.n_regs), 8, dtype=torch.int32, device=dev)
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    lib.bmh_extend_batch(dj.d_q, dj.d_qoff, dj.d_qlen, dj.d_t, dj.d_toff, dj.d_tlen, dj.d_h0, int(dj.n_jobs), C.byref(B.ExtParams.default()), out3.data_ptr(), None, None)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    cw.merge(out3, regs)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    print("extend %.3f ms  merge %.3f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
+r = regs.cpu().numpy()
+print("regs checksum", int(r.astype(np.int64).sum()), "best score mean", float(np.maximum.reduceat(r[:, 1], np.unique(r[:, 0], return_index=True)[1]).mean()))

@@ -286,3 +286,79 @@ def test_extension_two_mismatch_closed_form(hip, oracle):
         bad = np.nonzero((got6 != want6).any(1))[0]
         assert bad.size == 0, f"scoring {(a, b, o, e, zdrop)}: {bad.size} mismatches, first {bad[:5]}: got {got6[bad[:5]]} want {want6[bad[:5]]} qlen {qlen[bad[:5]]} h0 {np.array(h0s)[bad[:5]]}"
         assert np.array_equal(got3, want3)
+
+
+def _pack_pac(g):
+    pad = (-len(g)) % 4
+    codes = np.concatenate([g, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    pac = ((codes[:, 0] << 6) | (codes[:, 1] << 4) | (codes[:, 2] << 2) | codes[:, 3]).astype(np.uint8)
+    return np.ascontiguousarray(np.concatenate([pac, np.zeros(1, np.uint8)]))      # + the .pac tail byte slot
+
+
+def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None):
+    """reads -> bmh_seed_batch -> bmh_chain_batch -> bmh_extend_batch -> bmh_chain_merge, all in HBM, against the
+    host job builder on the same seeds (byte-identical batch) and its merge of the oracle's extension results."""
+    import ctypes as C, os, torch
+    from bwamem_hip import synth
+    from bwamem_hip.lib import ChainOpt, ChainWorkspace, HostJobs, dev_jobs_to_host, seeds_to_host, load_library
+    n, L = reads.shape
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    dindex = B.Index.upload(idx, pac=_pack_pac(g), l_pac=len(g))
+    ws = B.SeedWorkspace(n, n * L, max_cands=n * L, max_occ=1 << 22)
+    r = _to_dev(torch, synth.codes_to_ascii(flat))
+    o = (torch.arange(n, dtype=torch.int64) * L).to(torch.int32).cuda()
+    l = torch.full((n,), L, dtype=torch.int32).cuda()
+    s = ws.seed_batch(dindex, r, o, l, 19)
+    opt = ChainOpt(); load_library().bmh_chain_opt_default(C.byref(opt))
+    for k, v in (opt_over or {}).items():
+        setattr(opt, k, v)
+    cw = ChainWorkspace(n, max(int(s.n_seeds), 1), opt=opt)
+    if heavy is not None:
+        os.environ["BMH_CHAIN_HEAVY"] = str(heavy)
+    try:
+        dj = cw.chain_batch(dindex, r, o, l, s)
+    finally:
+        os.environ.pop("BMH_CHAIN_HEAVY", None)
+    got = dev_jobs_to_host(dj, n)
+    hj = HostJobs(g, flat, np.arange(n, dtype=np.uint64) * L, np.full(n, L, np.uint32), seeds_to_host(s, n), n_threads=4, opt=opt)
+    assert int(dj.n_jobs) == hj.n_jobs and int(dj.n_regs) == hj.n_regs
+    for k in ("qlen", "tlen", "h0", "job_read", "job_reg", "job_side", "qoff", "toff", "regs_per_read", "q", "t"):
+        assert np.array_equal(got[k], getattr(hj, k)), k
+    # extension + merge on the device vs oracle extension + host merge
+    out3 = torch.zeros(max(hj.n_jobs, 1), 3, dtype=torch.int32, device="cuda")
+    regs = torch.zeros(max(hj.n_regs, 1), 8, dtype=torch.int32, device="cuda")
+    if hj.n_jobs:
+        rc = load_library().bmh_extend_batch(dj.d_q, dj.d_qoff, dj.d_qlen, dj.d_t, dj.d_toff, dj.d_tlen, dj.d_h0, int(dj.n_jobs),
+                                             C.byref(B.ExtParams.default()), out3.data_ptr(), None, None)
+        assert rc == 0
+    cw.merge(out3, regs)
+    torch.cuda.synchronize()
+    want3, _, _ = oracle.extend_batch(*hj.jobs()) if hj.n_jobs else (np.zeros((0, 3), np.int32), None, None)
+    assert np.array_equal(out3.cpu().numpy()[: hj.n_jobs], want3)
+    assert np.array_equal(regs.cpu().numpy()[: hj.n_regs], hj.merge(want3))
+    stats = (hj.n_jobs, hj.n_regs, int(dj.n_heavy_reads))
+    hj.free(); cw.free(); ws.free(); dindex.free()
+    return stats
+
+
+def test_device_job_builder_matches_host_builder(hip, oracle):
+    """bmh_chain_batch (chains, chain filter, chain2aln and the on-device reference fetch) produces the same batch,
+    byte for byte, as bmh_build_jobs -- itself pinned to the reference's host code -- in the lane form, in the wave
+    form (every read forced through it), for 300 bp reads, non-default options and a repeat-rich genome."""
+    from bwamem_hip import fmindex, synth
+    g, idx = common.genome_and_index(1_500_000)
+    reads, _ = synth.make_reads(g, 3000, 150, seed=5, sub_rate=0.02, indel_frac=0.2)
+    nj, nr, nh = _device_chain_case(hip, oracle, g, idx, reads)
+    assert nj > 3000 and nr > 2500
+    _, _, nh = _device_chain_case(hip, oracle, g, idx, reads[:1500], heavy=0)          # all reads by the wave kernel
+    assert nh > 1400
+    reads3, _ = synth.make_reads(g, 1000, 300, seed=6, sub_rate=0.03, indel_frac=0.3)
+    _device_chain_case(hip, oracle, g, idx, reads3)
+    _device_chain_case(hip, oracle, g, idx, reads[:1500], opt_over=dict(max_occ=3, max_chain_extend=2, min_chain_weight=25, drop_ratio=0.8))
+    # repeat-rich genome: many copies, little divergence -> reads with hundreds of seeds and chains
+    gr = synth.make_genome(600_000, seed=9, repeat_frac=0.6, repeat_len=(200, 800), repeat_copies=(50, 400), repeat_div=0.02)
+    idxr = fmindex.build_fmd_index(gr)
+    readsr, _ = synth.make_reads(gr, 2000, 150, seed=8, sub_rate=0.01)
+    nj, nr, nh = _device_chain_case(hip, oracle, gr, idxr, readsr)
+    assert nh > 20, nh
+    _device_chain_case(hip, oracle, gr, idxr, readsr[:600], heavy=4, opt_over=dict(max_occ=20))

@@ -40,3 +40,78 @@ def test_jobs_and_region_scores_match_reference_host_code(oracle):
     has = as_tag >= 0
     assert has.sum() > 0.9 * n and np.array_equal(best[has], as_tag[has])
     hj.free(); hj1.free()
+
+
+def _chain_core_lib():
+    """tests/chain_core_host.cpp: the per-read core of the DEVICE job builder (csrc/chain_core.h) compiled as plain C++."""
+    import ctypes as C, subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(here, "_build"); os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "chain_core_host.so")
+    src = [os.path.join(here, "chain_core_host.cpp"), os.path.join(here, "..", "bwa-mem_gpu_amd", "csrc", "chain_core.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(here, "..", "include"), src[0], "-o", so])
+    lib = C.CDLL(so)
+
+    class Res(C.Structure):
+        _fields_ = [(k, C.c_uint64) for k in ("n_regs", "n_jobs", "q_bytes", "t_bytes")] + \
+                   [(k, C.POINTER(C.c_uint32)) for k in ("regs_per_read", "qoff", "qlen", "toff", "tlen", "h0", "job_read", "job_reg", "job_side")] + \
+                   [("q", C.POINTER(C.c_uint8)), ("t", C.POINTER(C.c_uint8)), ("err", C.c_int)]
+    lib.chain_core_run.restype = C.POINTER(Res)
+    lib.chain_core_free.argtypes = [C.POINTER(Res)]
+    return lib
+
+
+def _run_core(lib, opt, g, reads, seeds):
+    import ctypes as C
+    n, L = reads.shape
+    pad = (-len(g)) % 4
+    codes = np.concatenate([g, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    pac = np.ascontiguousarray(((codes[:, 0] << 6) | (codes[:, 1] << 4) | (codes[:, 2] << 2) | codes[:, 3]).astype(np.uint8))
+    a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)
+    keep = [pac, a(reads.reshape(-1), np.uint8), np.arange(n, dtype=np.uint64) * L, np.full(n, L, np.uint32), a(seeds["rbeg"], np.uint64),
+            a(seeds["qbeg"], np.int32), a(seeds["score"], np.uint32), a(seeds["n_ref_pos"], np.uint32), a(seeds["prefix"], np.uint32)]
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    rp = lib.chain_core_run(C.byref(opt), C.c_int64(len(g)), p(keep[0]), C.c_uint32(n), *[p(k) for k in keep[1:]], C.c_uint64(len(keep[4])))
+    r = rp.contents
+    arr = lambda ptr, nn: np.ctypeslib.as_array(ptr, shape=(max(int(nn), 1),))[:int(nn)].copy()
+    out = {k: arr(getattr(r, k), r.n_jobs) for k in ("qoff", "qlen", "toff", "tlen", "h0", "job_read", "job_reg", "job_side")}
+    out.update(q=arr(r.q, r.q_bytes), t=arr(r.t, r.t_bytes), regs_per_read=arr(r.regs_per_read, n), n_jobs=int(r.n_jobs), n_regs=int(r.n_regs), err=int(r.err))
+    lib.chain_core_free(rp)
+    return out
+
+
+def test_device_chain_core_matches_reference_jobs_and_host_builder(oracle):
+    """The chaining core the HIP kernels instantiate (csrc/chain_core.h), compiled for the host: (1) reproduces the
+    golden job multiset of the reference's host code; (2) equals bmh_build_jobs array for array on a repeat-rich
+    genome and with non-default options."""
+    import ctypes as C
+    from bwamem_hip import fmindex
+    from bwamem_hip.lib import ChainOpt, load_library
+    lib = _chain_core_lib()
+    z = np.load(os.path.join(common.GOLDEN, "jobs_golden.npz"))
+    g = synth.make_genome(int(z["n_genome"]), seed=int(z["genome_seed"]))
+    opt = ChainOpt(); load_library().bmh_chain_opt_default(C.byref(opt))
+    seeds = {k: z[k] for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")}
+    c = _run_core(lib, opt, g, z["reads"], seeds)
+    assert c["err"] == 0
+    digs = sorted(hashlib.sha1(bytes([int(c["h0"][i]) & 255, int(c["h0"][i]) >> 8]) + c["q"][c["qoff"][i]:c["qoff"][i] + c["qlen"][i]].tobytes() + b"|" +
+                               c["t"][c["toff"][i]:c["toff"][i] + c["tlen"][i]].tobytes()).digest() for i in range(c["n_jobs"]))
+    assert digs == [bytes(r) for r in z["job_digests"]]
+    # repeat-rich genome, default and non-default options, against the host builder
+    gr = synth.make_genome(400_000, seed=9, repeat_frac=0.6, repeat_len=(200, 800), repeat_copies=(50, 400), repeat_div=0.02)
+    idx = fmindex.build_fmd_index(gr)
+    reads, _ = synth.make_reads(gr, 1500, 150, seed=8, sub_rate=0.01)
+    flat, offs, lens = common.flat_reads(reads)
+    s = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens, 19, n_threads=4)
+    assert s["n_ref_pos"].max() > 100
+    for over in ({}, dict(max_occ=20), dict(max_occ=5, max_chain_extend=3, min_chain_weight=30, drop_ratio=0.9, mask_level=0.2)):
+        o = ChainOpt(); load_library().bmh_chain_opt_default(C.byref(o))
+        for k, v in over.items():
+            setattr(o, k, v)
+        c = _run_core(lib, o, gr, reads, s)
+        hj = HostJobs(gr, flat, offs, lens, s, n_threads=4, opt=o)
+        assert c["n_jobs"] == hj.n_jobs and c["n_regs"] == hj.n_regs
+        for k in ("qoff", "qlen", "toff", "tlen", "h0", "job_read", "job_reg", "job_side", "regs_per_read", "q", "t"):
+            assert np.array_equal(c[k], getattr(hj, k)), (over, k)
+        hj.free()

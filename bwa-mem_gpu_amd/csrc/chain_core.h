@@ -28,9 +28,12 @@
 
 struct ch_seed_t { int64_t rbeg; int32_t qbeg, len; uint32_t next, pad; };                       // 24 B
 struct ch_chain_t { uint32_t head, tail, n; int32_t rid, w, first, beg, end; uint32_t kept, pad; };   // 40 B
-struct ch_reg_t {                                                                                // 64 B
-	int64_t rb_est, re_est, seed_rbeg, rmax0;
-	int32_t qb_est, qe_est, seed_qbeg, seedlen0, lr, rr, rq, pad;
+struct ch_reg_t { int64_t seed_rbeg, rmax0; int32_t seed_qbeg, seedlen0, lr, rr, rq, pad; };        // 40 B: region + job geometry
+struct ch_est_t { int64_t rb_est, re_est; int32_t qb_est, qe_est, seedlen0, pad; };                // 32 B: what the "covered already" test reads
+
+// per-read scratch (a read never needs more entries than it has seeds): global memory, or LDS for a wave-form read
+struct ch_scr_t {
+	ch_seed_t *S; ch_chain_t *CH; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx; ch_est_t *E;
 };
 
 struct ch_ctx_t {
@@ -38,14 +41,22 @@ struct ch_ctx_t {
 	int64_t l_pac; int n_contigs; const int64_t *ctg_off; const int32_t *ctg_len;
 	const uint64_t *rbeg; const int32_t *qbeg; const uint32_t *score, *n_ref, *prefix;   // mem_seed_v_gpu arrays
 	const uint32_t *read_lens;
-	// scratch, every array indexed by prefix[read] + local index (a read never needs more entries than it has seeds)
-	ch_seed_t *seeds; ch_chain_t *chains; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx;
-	ch_reg_t *regs;
+	// global scratch, every array indexed by prefix[read] + local index
+	ch_scr_t g;
+	ch_reg_t *regs;               // output slots, prefix[read] + i in creation order
 	uint32_t *regs_per_read, *jobs_per_read;
 	int *err;                     // != 0: a read was longer than 700 bp (mem_flt_chained_seeds is not restated)
+	long long *prof; uint32_t prof_read;
 };
 
 #define CH_MAX_READ_LEN 700
+
+// optional phase stamps (cycles) of one read, for tuning: compile with -DCH_PROFILE
+#if defined(CH_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define CH_STAMP(i) do { if (x.prof && r == x.prof_read) x.prof[i] = (long long)wall_clock64(); } while (0)
+#else
+#define CH_STAMP(i) do { } while (0)
+#endif
 
 namespace chain_core {
 
@@ -170,6 +181,29 @@ template <bool COOP> CH_HD inline void sorted_insert(uint32_t *order, int64_t *o
 	order[at] = cv; opos[at] = pv;
 }
 
+// upper bound of rb in the ascending opos[0..nc): number of entries <= rb
+template <bool COOP> CH_HD inline int upper_bound_pos(const int64_t *opos, int nc, int64_t rb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (COOP && nc > 8 && nc <= 4096) {          // two 64-way steps instead of log2(nc) dependent ones
+		const int lane = ch_lane();
+		const int stride = (nc + 63) >> 6;
+		const int last = ((lane + 1) * stride < nc ? (lane + 1) * stride : nc) - 1;
+		const bool le = lane * stride < nc && opos[last] <= rb;
+		const int b = __builtin_popcountll(__ballot(le));
+		if (stride == 1) return b;
+		const int base = b * stride;
+		if (base >= nc) return nc;
+		const int idx = base + lane;
+		const bool le2 = lane < stride && idx < nc && opos[idx] <= rb;
+		return base + __builtin_popcountll(__ballot(le2));
+	}
+#endif
+	int lo = 0, hi = nc;
+	while (lo < hi) { const int mid = (lo + hi) >> 1; if (opos[mid] <= rb) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+
 // first index in [lo, hi) for which f is true, hi if none; f must be free of side effects
 template <bool COOP, class F> CH_HD inline int first_true(int lo, int hi, F f)
 {
@@ -217,36 +251,56 @@ template <bool COOP> CH_HD inline void sort_distinct(uint64_t *a, uint64_t *tmp,
 	}
 }
 
+CH_HD inline ch_scr_t global_scratch(const ch_ctx_t &x, uint32_t r)
+{
+	const uint32_t b = x.prefix[r];
+	ch_scr_t s;
+	s.S = x.g.S + b; s.CH = x.g.CH + b; s.order = x.g.order + b; s.opos = x.g.opos + b; s.klist = x.g.klist + b; s.srt = x.g.srt + b;
+	s.cidx = x.g.cidx + b; s.E = x.g.E + b;
+	return s;
+}
+
 // The read: returns through x.regs (slot order = creation order), x.regs_per_read[r], x.jobs_per_read[r].
-template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r)
+template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const ch_scr_t &sc)
 {
 	const bmh_chain_opt_t &o = x.o;
 	const uint32_t base = x.prefix[r];
 	const int n = (int)x.n_ref[r];
 	const int l_query = (int)x.read_lens[r];
 	const int64_t l_pac = x.l_pac;
-	ch_seed_t *S = x.seeds + base; ch_chain_t *CH = x.chains + base; uint32_t *order = x.order + base; int64_t *opos = x.opos + base;
-	uint32_t *klist = x.klist + base; uint64_t *srt = x.srt + base; uint32_t *cidx = x.cidx + base; ch_reg_t *R = x.regs + base;
+	ch_seed_t *S = sc.S; ch_chain_t *CH = sc.CH; uint32_t *order = sc.order; int64_t *opos = sc.opos;
+	uint32_t *klist = sc.klist; uint64_t *srt = sc.srt; uint32_t *cidx = sc.cidx; ch_est_t *E = sc.E; ch_reg_t *R = x.regs + base;
 	x.regs_per_read[r] = 0; x.jobs_per_read[r] = 0;
 	if (n == 0 || l_query < o.min_seed_len) return;
 	if (l_query > CH_MAX_READ_LEN) { *x.err = 1; return; }
 	const uint64_t *g_rbeg = x.rbeg + base; const int32_t *g_qbeg = x.qbeg + 2 * (size_t)base; const uint32_t *g_score = x.score + base;
 
 	// ---------------------------------------------------------------- mem_chain
+	CH_STAMP(0);
 	int nc = 0, ns = 0;
 	for (int i = 0; i < n;) {
 		const uint32_t cnt = g_score[i];
 		if (cnt == 0) break;                               // malformed group head; cannot happen with bmh_seed_batch output
 		const int sb = g_qbeg[2 * i], slen = g_qbeg[2 * i + 1] - sb;
 		const int step = cnt > (uint32_t)o.max_occ ? (int)(cnt / o.max_occ) : 1;
-		int count = 0;
-		for (int64_t k = 0; k < (int64_t)cnt && count < o.max_occ; k += step, ++count) {
-			const int64_t rb = (int64_t)g_rbeg[i + k];
+		// occurrences k = 0, step, 2 step, ... while k < cnt, at most max_occ of them
+		const int n_it = (int)(((int64_t)cnt + step - 1) / step) < o.max_occ ? (int)(((int64_t)cnt + step - 1) / step) : o.max_occ;
+#if defined(__HIP_DEVICE_COMPILE__)
+		long long rbv = 0;                                 // COOP: the wave fetches 64 positions at a time, one per lane
+#endif
+		for (int count = 0; count < n_it; ++count) {
+			int64_t rb;
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (COOP) {
+				if ((count & 63) == 0) { const int c = count + ch_lane(); rbv = c < n_it ? (long long)g_rbeg[i + (int64_t)c * step] : 0; }
+				rb = __shfl(rbv, count & 63);
+			} else
+#endif
+			rb = (int64_t)g_rbeg[i + (int64_t)count * step];
 			const int rid = intv2rid(x, rb, rb + slen);
 			if (rid < 0) continue;
 			// closest chain at or below the seed: upper bound over opos[0..nc), then one back
-			int lo = 0, hi = nc;
-			while (lo < hi) { const int mid = (lo + hi) >> 1; if (opos[mid] <= rb) lo = mid + 1; else hi = mid; }
+			const int lo = upper_bound_pos<COOP>(opos, nc, rb);
 			bool to_add = true;
 			if (lo > 0) {
 				ch_chain_t &c = CH[order[lo - 1]];
@@ -278,12 +332,12 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r)
 	if (nc == 0) return;
 
 	// ---------------------------------------------------------------- mem_chain_flt
+	CH_STAMP(1);
 	int na = 0;
-	for (int i = 0; i < nc; ++i) {
-		const uint32_t ci = order[i];
+	auto weigh = [&](uint32_t ci) {                                       // mem_chain_weight + the chain's query span
 		ch_chain_t &c = CH[ci];
 		int64_t end = 0; int w = 0;
-		for (uint32_t p = c.head; p != 0xFFFFFFFFu; p = S[p].next) {       // mem_chain_weight: query cover
+		for (uint32_t p = c.head; p != 0xFFFFFFFFu; p = S[p].next) {       // query cover
 			const ch_seed_t s = S[p];
 			if (s.qbeg >= end) w += s.len;
 			else if (s.qbeg + s.len > end) w += (int)(s.qbeg + s.len - end);
@@ -300,21 +354,51 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r)
 		w = w < 1 << 30 ? w : (1 << 30) - 1;
 		c.w = w; c.first = -1; c.kept = 0;
 		c.beg = S[c.head].qbeg; c.end = S[c.tail].qbeg + S[c.tail].len;
+		return w;
+	};
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (COOP) {                                                           // one chain per lane, kept in order
+		const int lane = ch_lane();
+		for (int b = 0; b < nc; b += 64) {
+			const int i = b + lane;
+			uint32_t ci = 0; int w = -1;
+			if (i < nc) { ci = order[i]; w = weigh(ci); }
+			const bool keep = i < nc && w >= o.min_chain_weight;
+			const unsigned long long m = __ballot(keep);
+			if (keep) srt[na + __builtin_popcountll(m & ((1ull << lane) - 1))] = (uint64_t)(uint32_t)w << 32 | ci;
+			na += __builtin_popcountll(m);
+		}
+		ch_wave_fence();
+	} else
+#endif
+	for (int i = 0; i < nc; ++i) {
+		const uint32_t ci = order[i];
+		const int w = weigh(ci);
 		if (w >= o.min_chain_weight) srt[na++] = (uint64_t)(uint32_t)w << 32 | ci;
 	}
 	if (na == 0) return;
+	CH_STAMP(2);
 	if (!w_introsort(srt, na)) { *x.err = 2; return; }
+	CH_STAMP(3);
 	for (int i = 0; i < na; ++i) order[i] = (uint32_t)srt[i];
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (COOP) ch_wave_fence();
 #endif
 	int nk = 0;
+	// kept chains: klist[k] = index in the sorted array, ks[k] = {beg, end, w, chain} so the scan reads one entry per k
+	// (E is not in use before mem_chain2aln and has room for it)
+	struct ks_t { int32_t beg, end, w; uint32_t chain; };
+	ks_t *ks = (ks_t *)E;
+	{ const ch_chain_t c0 = CH[order[0]]; ks_t e; e.beg = c0.beg; e.end = c0.end; e.w = c0.w; e.chain = order[0]; ks[0] = e; }
 	CH[order[0]].kept = 3; klist[nk++] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (COOP) ch_wave_fence();
+#endif
 	for (int i = 1; i < na; ++i) {
-		const ch_chain_t ai = CH[order[i]];
+		const uint32_t ci = order[i];
+		const ch_chain_t ai = CH[ci];
 		bool large_ovlp = false, broke = false;
-		auto test = [&](int k, bool &ovl, bool &brk) {
-			const ch_chain_t aj = CH[order[klist[k]]];
+		auto test = [&](const ks_t &aj, bool &ovl, bool &brk) {
 			ovl = brk = false;
 			const int b_max = aj.beg > ai.beg ? aj.beg : ai.beg;
 			const int e_min = aj.end < ai.end ? aj.end : ai.end;
@@ -333,25 +417,32 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r)
 			for (int b = 0; b < nk && !broke; b += 64) {
 				const int k = b + lane;
 				bool ovl = false, brk = false;
-				if (k < nk) test(k, ovl, brk);
+				ks_t aj; aj.chain = 0;
+				if (k < nk) { aj = ks[k]; test(aj, ovl, brk); }
 				const unsigned long long mb = __ballot(brk), mo = __ballot(ovl);
 				unsigned long long vm = ~0ull;
 				if (mb) { const int f = (int)__builtin_ctzll(mb); vm = f == 63 ? ~0ull : ((1ull << (f + 1)) - 1); broke = true; }
-				if (ovl && ((vm >> lane) & 1)) { ch_chain_t &cj = CH[order[klist[k]]]; if (cj.first < 0) cj.first = i; }
+				if (ovl && ((vm >> lane) & 1)) { ch_chain_t &cj = CH[aj.chain]; if (cj.first < 0) cj.first = i; }
 				if (mo & vm) large_ovlp = true;
 			}
-			ch_wave_fence();
 		} else
 #endif
 		{
 			for (int k = 0; k < nk; ++k) {
 				bool ovl, brk;
-				test(k, ovl, brk);
-				if (ovl) { large_ovlp = true; ch_chain_t &cj = CH[order[klist[k]]]; if (cj.first < 0) cj.first = i; }
+				const ks_t aj = ks[k];
+				test(aj, ovl, brk);
+				if (ovl) { large_ovlp = true; ch_chain_t &cj = CH[aj.chain]; if (cj.first < 0) cj.first = i; }
 				if (brk) { broke = true; break; }
 			}
 		}
-		if (!broke) { klist[nk++] = (uint32_t)i; CH[order[i]].kept = large_ovlp ? 2 : 3; }
+		if (!broke) {
+			ks_t e; e.beg = ai.beg; e.end = ai.end; e.w = ai.w; e.chain = ci; ks[nk] = e;
+			klist[nk++] = (uint32_t)i; CH[ci].kept = large_ovlp ? 2 : 3;
+		}
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (COOP) ch_wave_fence();
+#endif
 	}
 	for (int k = 0; k < nk; ++k) { const int f = CH[order[klist[k]]].first; if (f >= 0) CH[order[f]].kept = 1; }
 	{
@@ -365,6 +456,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r)
 	}
 
 	// ---------------------------------------------------------------- mem_chain2aln, chain by chain in filtered order
+	CH_STAMP(4);
 	int n_regs = 0, n_jobs = 0;
 	for (int ia = 0; ia < na; ++ia) {
 		const ch_chain_t c = CH[order[ia]];
@@ -402,7 +494,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r)
 		for (int k = cn - 1; k >= 0; --k) {
 			const ch_seed_t s = S[cidx[(uint32_t)srt[k]]];
 			const int hit = first_true<COOP>(0, n_regs, [&](int i) {              // extension (estimated) made before? :1235-1256
-				const ch_reg_t p = R[i];
+				const ch_est_t p = E[i];
 				if (s.rbeg < p.rb_est || s.rbeg + s.len > p.re_est || s.qbeg < p.qb_est || s.qbeg + s.len > p.qe_est) return false;
 				if (s.len - p.seedlen0 > .1 * l_query) return false;
 				int qd = s.qbeg - p.qb_est; int64_t rd = s.rbeg - p.rb_est;
@@ -431,14 +523,16 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r)
 					continue;
 				}
 			}
-			ch_reg_t a;
+			ch_reg_t a; ch_est_t e;
 			const int fwd = (int)(0.85 * (l_query - (s.qbeg + s.len)));           // FILTER_COEF, :52, :1285-1298
-			a.qe_est = (s.qbeg + s.len) + fwd < l_query ? (s.qbeg + s.len) + fwd : l_query;
-			a.re_est = (s.rbeg + s.len) + fwd < l_pac << 1 ? (s.rbeg + s.len) + fwd : l_pac << 1;
+			e.qe_est = (s.qbeg + s.len) + fwd < l_query ? (s.qbeg + s.len) + fwd : l_query;
+			e.re_est = (s.rbeg + s.len) + fwd < l_pac << 1 ? (s.rbeg + s.len) + fwd : l_pac << 1;
 			const int back = (int)(0.85 * (s.qbeg + 1));
-			a.qb_est = (s.qbeg - back) > 0 ? (s.qbeg - back) : 0;
-			a.rb_est = (s.rbeg - back) > 0 ? (s.rbeg - back) : 0;
-			if (a.rb_est < l_pac && l_pac < a.qe_est) { if (s.rbeg < l_pac) a.re_est = l_pac; else a.rb_est = l_pac; }   // (sic) qe_est, :1292
+			e.qb_est = (s.qbeg - back) > 0 ? (s.qbeg - back) : 0;
+			e.rb_est = (s.rbeg - back) > 0 ? (s.rbeg - back) : 0;
+			if (e.rb_est < l_pac && l_pac < e.qe_est) { if (s.rbeg < l_pac) e.re_est = l_pac; else e.rb_est = l_pac; }   // (sic) qe_est, :1292
+			e.seedlen0 = s.len; e.pad = 0;
+			E[n_regs] = e;
 			a.seed_rbeg = s.rbeg; a.seed_qbeg = s.qbeg; a.seedlen0 = s.len; a.rmax0 = rmax0;
 			a.lr = (int)(s.rbeg - rmax0);
 			a.rq = l_query - (s.qbeg + s.len);
@@ -451,6 +545,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r)
 #endif
 		}
 	}
+	CH_STAMP(5);
 	x.regs_per_read[r] = (uint32_t)n_regs; x.jobs_per_read[r] = (uint32_t)n_jobs;
 }
 

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
+#include <stdio.h>
 #include <stdlib.h>
 #include "bmh_internal.h"
 #include "chain_core.h"
@@ -30,15 +31,41 @@ __global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A)
 {
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
 	if (r >= A.n_reads) return;
-	if (A.x.n_ref[r] > A.heavy_thresh) { A.heavy_list[atomicAdd(A.heavy_n, 1u)] = r; return; }
-	chain_core::chain_read<false>(A.x, r);
+	const uint32_t n = A.x.n_ref[r];
+	if (n > A.heavy_thresh) {          // three lists by size so that the wave kernel starts the longest reads first
+		const int cls = n > 192 ? 0 : n > 80 ? 1 : 2;
+		A.heavy_list[(size_t)cls * A.n_reads + atomicAdd(A.heavy_n + cls, 1u)] = r;
+		return;
+	}
+	chain_core::chain_read<false>(A.x, r, chain_core::global_scratch(A.x, r));
 }
 
-// one wave per heavy read; the list was filled by chain_lane_kernel (earlier on the same stream)
-__global__ void __launch_bounds__(64) chain_wave_kernel(chain_args_t A)
+// one wave per heavy read; the list was filled by chain_lane_kernel (earlier on the same stream).  The read's scratch
+// lives in LDS when it fits lds_cap entries (CH_LDS_BYTES_PER_ENTRY each): the wave form is a chain of dependent
+// accesses, so their latency is its run time.
+#define CH_LDS_BYTES_PER_ENTRY (8 + 8 + sizeof(ch_est_t) + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4 + 4 + 4)
+__global__ void __launch_bounds__(64) chain_wave_kernel(chain_args_t A, uint32_t lds_cap)
 {
-	const uint32_t nh = *A.heavy_n;
-	for (uint32_t i = blockIdx.x; i < nh; i += gridDim.x) chain_core::chain_read<true>(A.x, A.heavy_list[i]);
+	extern __shared__ __align__(16) uint8_t ch_lds[];
+	const uint32_t n0 = A.heavy_n[0], n1 = A.heavy_n[1], n2 = A.heavy_n[2], nh = n0 + n1 + n2;
+	ch_scr_t L;
+	{
+		uint8_t *p = ch_lds;
+		L.opos = (int64_t *)p; p += 8 * (size_t)lds_cap;
+		L.srt = (uint64_t *)p; p += 8 * (size_t)lds_cap;
+		L.E = (ch_est_t *)p; p += sizeof(ch_est_t) * (size_t)lds_cap;
+		L.CH = (ch_chain_t *)p; p += sizeof(ch_chain_t) * (size_t)lds_cap;
+		L.S = (ch_seed_t *)p; p += sizeof(ch_seed_t) * (size_t)lds_cap;
+		L.order = (uint32_t *)p; p += 4 * (size_t)lds_cap;
+		L.klist = (uint32_t *)p; p += 4 * (size_t)lds_cap;
+		L.cidx = (uint32_t *)p;
+	}
+	for (uint32_t i = blockIdx.x; i < nh; i += gridDim.x) {
+		const uint32_t r = i < n0 ? A.heavy_list[i] : i < n0 + n1 ? A.heavy_list[(size_t)A.n_reads + (i - n0)] : A.heavy_list[2 * (size_t)A.n_reads + (i - n0 - n1)];
+		if (A.x.n_ref[r] <= lds_cap) chain_core::chain_read<true>(A.x, r, L);
+		else chain_core::chain_read<true>(A.x, r, chain_core::global_scratch(A.x, r));
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	}
 }
 
 struct emit_args_t {
@@ -137,10 +164,10 @@ __global__ void __launch_bounds__(256) merge_kernel(const ch_outreg_t *__restric
 struct bmh_chain_ws {
 	uint32_t max_reads; uint64_t max_seeds;
 	// per-seed scratch
-	ch_seed_t *seeds; ch_chain_t *chains; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx; ch_reg_t *regs;
+	ch_seed_t *seeds; ch_chain_t *chains; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx; ch_reg_t *regs; ch_est_t *est;
 	// per read
 	uint32_t *regs_per_read, *jobs_per_read, *reg_off, *job_off, *heavy_list;
-	uint32_t *counters;            // [0] heavy_n  [1] err
+	uint32_t *counters;            // [0..2] heavy_n per size class  [3] err  [4..15] profile stamps
 	// contigs
 	int n_contigs; int64_t *ctg_off; int32_t *ctg_len;
 	// outputs, grown on demand
@@ -156,7 +183,7 @@ struct bmh_chain_ws {
 extern "C" void bmh_chain_ws_free(bmh_chain_ws_t *w)
 {
 	if (!w) return;
-	void *ps[] = {w->seeds, w->chains, w->order, w->opos, w->klist, w->srt, w->cidx, w->regs, w->regs_per_read, w->jobs_per_read, w->reg_off,
+	void *ps[] = {w->seeds, w->chains, w->order, w->opos, w->klist, w->srt, w->cidx, w->regs, w->est, w->regs_per_read, w->jobs_per_read, w->reg_off,
 	              w->job_off, w->heavy_list, w->counters, w->ctg_off, w->ctg_len, w->outregs, w->qlen, w->tlen, w->h0, w->job_read, w->job_reg,
 	              w->job_side, w->jq_src, w->qoff, w->toff, w->jt0, w->qoff64, w->toff64, w->q, w->t, w->scan_tmp};
 	for (void *p : ps) if (p) (void)hipFree(p);
@@ -173,9 +200,9 @@ extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_
 #define A(p, n) ok = ok && hipMalloc((void **)&(p), (size_t)(n)) == hipSuccess
 	const size_t S = (size_t)max_seeds + 1;
 	A(w->seeds, sizeof(ch_seed_t) * S); A(w->chains, sizeof(ch_chain_t) * S); A(w->order, 4 * S); A(w->opos, 8 * S); A(w->klist, 4 * S);
-	A(w->srt, 8 * S); A(w->cidx, 4 * S); A(w->regs, sizeof(ch_reg_t) * S);
+	A(w->srt, 8 * S); A(w->cidx, 4 * S); A(w->regs, sizeof(ch_reg_t) * S); A(w->est, sizeof(ch_est_t) * S);
 	const size_t Rn = (size_t)max_reads + 1;
-	A(w->regs_per_read, 4 * Rn); A(w->jobs_per_read, 4 * Rn); A(w->reg_off, 4 * Rn); A(w->job_off, 4 * Rn); A(w->heavy_list, 4 * Rn);
+	A(w->regs_per_read, 4 * Rn); A(w->jobs_per_read, 4 * Rn); A(w->reg_off, 4 * Rn); A(w->job_off, 4 * Rn); A(w->heavy_list, 3 * 4 * Rn);
 	A(w->counters, 64);
 	size_t t1 = 0, t2 = 0;
 	rocprim::exclusive_scan(nullptr, t1, w->regs_per_read, w->reg_off, 0u, Rn, rocprim::plus<uint32_t>(), 0);
@@ -231,31 +258,52 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	A.x.o = *opt; A.x.l_pac = (int64_t)idx->dev.l_pac; A.x.n_contigs = w->n_contigs; A.x.ctg_off = w->ctg_off; A.x.ctg_len = w->ctg_len;
 	A.x.rbeg = seeds->d_rbeg; A.x.qbeg = seeds->d_qbeg; A.x.score = seeds->d_score; A.x.n_ref = seeds->d_n_ref_pos; A.x.prefix = seeds->d_prefix;
 	A.x.read_lens = d_lens;
-	A.x.seeds = w->seeds; A.x.chains = w->chains; A.x.order = w->order; A.x.opos = w->opos; A.x.klist = w->klist; A.x.srt = w->srt; A.x.cidx = w->cidx;
-	A.x.regs = w->regs; A.x.regs_per_read = w->regs_per_read; A.x.jobs_per_read = w->jobs_per_read; A.x.err = (int *)(w->counters + 1);
+	A.x.g.S = w->seeds; A.x.g.CH = w->chains; A.x.g.order = w->order; A.x.g.opos = w->opos; A.x.g.klist = w->klist; A.x.g.srt = w->srt; A.x.g.cidx = w->cidx;
+	A.x.g.E = w->est; A.x.regs = w->regs; A.x.regs_per_read = w->regs_per_read; A.x.jobs_per_read = w->jobs_per_read; A.x.err = (int *)(w->counters + 3);
 	A.n_reads = n_reads;
 	const char *ht = getenv("BMH_CHAIN_HEAVY");
 	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : 32u;
 	A.heavy_list = w->heavy_list; A.heavy_n = w->counters;
+#ifdef CH_PROFILE
+	{
+		const char *pr = getenv("BMH_CHAIN_PROF_READ");
+		if (pr) { A.x.prof = (long long *)(w->counters + 4); A.x.prof_read = (uint32_t)atoi(pr); }
+	}
+#endif
 	HIPCK(hipMemsetAsync(w->counters, 0, 64, st));
 	HIPCK(hipMemsetAsync(w->regs_per_read + n_reads, 0, 4, st));
 	HIPCK(hipMemsetAsync(w->jobs_per_read + n_reads, 0, 4, st));
 	chain_lane_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(A);
-	chain_wave_kernel<<<2048, 64, 0, st>>>(A);
+	{
+		const char *lk = getenv("BMH_CHAIN_LDS_ENTRIES");
+		const uint32_t lds_cap = lk ? (uint32_t)atoi(lk) : 1024u;
+		const size_t lds_bytes = (size_t)lds_cap * CH_LDS_BYTES_PER_ENTRY;
+		if (lds_bytes > 160 * 1024 - 512) { bmh_set_error("bmh_chain_batch: BMH_CHAIN_LDS_ENTRIES too large"); return BMH_EINVAL; }
+		HIPCK(hipFuncSetAttribute((const void *)chain_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+		chain_wave_kernel<<<2048, 64, lds_bytes, st>>>(A, lds_cap);
+	}
 	size_t tb = w->scan_tmp_bytes;
 	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->regs_per_read, w->reg_off, 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
 	tb = w->scan_tmp_bytes;
 	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->jobs_per_read, w->job_off, 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
 	HIPCK(hipMemcpyAsync(w->h_pin + 0, w->reg_off + n_reads, 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipMemcpyAsync(w->h_pin + 1, w->job_off + n_reads, 4, hipMemcpyDeviceToHost, st));
-	HIPCK(hipMemcpyAsync(w->h_pin + 2, w->counters, 8, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(w->h_pin + 2, w->counters, 16, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));
 	HIPCK(hipGetLastError());
-	if (w->h_pin[3] == 1) { bmh_set_error("bmh_chain_batch: a read is longer than %d bp (mem_flt_chained_seeds is not restated)", CH_MAX_READ_LEN); return BMH_EINVAL; }
-	if (w->h_pin[3] != 0) { bmh_set_error("bmh_chain_batch: internal error %u in the chaining kernel", w->h_pin[3]); return BMH_ENODEV; }
+	if (w->h_pin[5] == 1) { bmh_set_error("bmh_chain_batch: a read is longer than %d bp (mem_flt_chained_seeds is not restated)", CH_MAX_READ_LEN); return BMH_EINVAL; }
+	if (w->h_pin[5] != 0) { bmh_set_error("bmh_chain_batch: internal error %u in the chaining kernel", w->h_pin[5]); return BMH_ENODEV; }
+#ifdef CH_PROFILE
+	if (A.x.prof) {
+		long long pf[6];
+		HIPCK(hipMemcpy(pf, w->counters + 4, sizeof(pf), hipMemcpyDeviceToHost));
+		fprintf(stderr, "chain phases of read %u (x10ns ticks): chains %lld  weights %lld  sort %lld  kept %lld  chain2aln %lld\n", A.x.prof_read,
+		        pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4]);
+	}
+#endif
 	const uint64_t n_regs = w->h_pin[0], n_jobs = w->h_pin[1];
 	w->n_regs = n_regs; w->n_jobs = n_jobs;
-	out->n_regs = n_regs; out->n_jobs = n_jobs; out->n_heavy_reads = w->h_pin[2];
+	out->n_regs = n_regs; out->n_jobs = n_jobs; out->n_heavy_reads = (uint64_t)w->h_pin[2] + w->h_pin[3] + w->h_pin[4];
 	out->d_regs_per_read = w->regs_per_read;
 	if (n_regs > w->cap_regs) {
 		const uint64_t c = n_regs + n_regs / 4 + 1024;
@@ -284,7 +332,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->qlen, w->qoff64, (uint64_t)0, (size_t)n_jobs + 1, rocprim::plus<uint64_t>(), st));
 	tb = w->scan_tmp_bytes;
 	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->tlen, w->toff64, (uint64_t)0, (size_t)n_jobs + 1, rocprim::plus<uint64_t>(), st));
-	uint64_t *h64 = (uint64_t *)(w->h_pin + 4);
+	uint64_t *h64 = (uint64_t *)(w->h_pin + 8);
 	HIPCK(hipMemcpyAsync(h64 + 0, w->qoff64 + n_jobs, 8, hipMemcpyDeviceToHost, st));
 	HIPCK(hipMemcpyAsync(h64 + 1, w->toff64 + n_jobs, 8, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));

@@ -23,12 +23,17 @@ dr = P.reads_to_device(reads, dev)
 ws = B.SeedWorkspace(n_reads, n_reads * L)
 s = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19)
 cw = ChainWorkspace(n_reads, int(s.n_seeds) + 1024)
+from bwamem_hip.lib import seeds_to_host
+nr = seeds_to_host(s, n_reads)["n_ref_pos"]
+os.environ["BMH_CHAIN_PROF_READ"] = str(int(nr.argmax()))
+print("seeds/read: max", nr.max(), "top", np.sort(nr)[-8:], ">32:", int((nr > 32).sum()), ">64:", int((nr > 64).sum()), ">128:", int((nr > 128).sum()), ">256:", int((nr > 256).sum()))
 lib = load_library()
-for it in range(4):
+for it in range(12):
+    os.environ["BMH_CHAIN_HEAVY"] = ["32", "16", "64", "128", "256", "100000"][it // 2]
     torch.cuda.synchronize(); t0 = time.perf_counter()
     dj = cw.chain_batch(dindex, dr.ascii, dr.offs, dr.lens, s)
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    print("chain_batch %.3f ms  jobs %d regs %d heavy %d qbytes %d tbytes %d" % ((t1 - t0) * 1e3, dj.n_jobs, dj.n_regs, dj.n_heavy_reads, dj.q_bytes, dj.t_bytes), flush=True)
+    print("heavy>%s chain_batch %.3f ms  jobs %d regs %d heavy %d qbytes %d tbytes %d" % (os.environ["BMH_CHAIN_HEAVY"], (t1 - t0) * 1e3, dj.n_jobs, dj.n_regs, dj.n_heavy_reads, dj.q_bytes, dj.t_bytes), flush=True)
 out3 = torch.zeros(int(dj.n_jobs), 3, dtype=torch.int32, device=dev)
 regs = torch.zeros(int(dj.n_regs), 8, dtype=torch.int32, device=dev)
 for it in range(3):

@@ -7,13 +7,17 @@ torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
   1 M synthetic 150 bp single-end reads per GPU against a seeded synthetic genome standing in
   for hg38 (no network, no hg38 on the box; see DESIGN.md "workload").  A step = one pass of the
-  hot path over the batch: SMEM seeding (pack, forward, backward, filter, expand, locate kernels)
-  + seed extension (ksw_extend2 kernel) of the batch's extension jobs.  Reads, index and
-  extension jobs are resident in HBM when the timed region starts.
+  hot path over the batch, reads in -> alignment regions out, entirely on the device:
+  SMEM seeding (pack, forward, backward, filter, expand, locate kernels) -> chaining, chain filter and
+  extension-job construction with on-device reference fetch (bmh_chain_batch) -> seed extension
+  (ksw_extend2 kernels) -> region merge.  Only reads and index are resident in HBM when the timed
+  region starts; nothing of the batch is prepared on the host.  (--host-jobs = the earlier mode:
+  jobs prebuilt by the host job builder outside the timed region, seeding || extension.)
 Multi-GPU: reads shard across ranks (weak scaling: READS_PER_GPU per rank); rank 0 builds the
 index and broadcasts it over RCCL once, outside the timed region; no data-path collective.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -71,14 +75,16 @@ def cpu_baseline(g, idx, reads, sample: int, n_threads: int):
     t_seed = time.time() - t0
     # the same extension jobs as the GPU leg (host job builder on the oracle's seeds; untimed on both legs)
     from bwamem_hip.lib import HostJobs
-    hj = HostJobs(g, flat, offs, lens, s)
+    t0 = time.time()
+    hj = HostJobs(g, flat, offs, lens, s, n_threads=n_threads)
+    t_chain = time.time() - t0
     arr = [x.copy() for x in hj.jobs()]
     n_jobs = hj.n_jobs
     hj.free()
     t0 = time.time()
     _, _, cells = orc.extend_batch(*arr, n_threads=n_threads)
     t_ext = time.time() - t0
-    return dict(t_seed=t_seed, t_ext=t_ext, n=sub.shape[0], work=s["work"], cells=cells, n_jobs=n_jobs,
+    return dict(t_seed=t_seed, t_ext=t_ext, t_chain=t_chain, n=sub.shape[0], work=s["work"], cells=cells, n_jobs=n_jobs,
                 n_seeds=int(len(s["rbeg"])))
 
 
@@ -91,7 +97,9 @@ def main():
     ap.add_argument("--reads-per-gpu", type=int, default=int(os.environ.get("BENCH_READS_PER_GPU", "1000000")))
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--paired", action="store_true", help="interleaved 2 x read-len pairs (configs[3]); reads-per-gpu counts reads, shards stay on pair boundaries")
-    ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="run extension and seeding on one stream")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="(--host-jobs) run extension and seeding on one stream")
+    ap.add_argument("--host-jobs", action="store_true", help="round-1 mode: extension jobs prebuilt by the host job builder outside the timed region; "
+                    "default: the whole path reads -> seeds -> chains/jobs -> extension -> regions runs on the device inside the timed region")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BENCH_CPU_SAMPLE", "200000")))
     a = ap.parse_args()
 
@@ -117,7 +125,11 @@ def main():
     t_index = time.time() - t0
     torch.cuda.empty_cache()
     hdr, bwt_t, sa_t, bits_t = broadcast_index(idx, dev, src=0, world=world)
-    dindex = B.Index.from_device(hdr["primary"], hdr["L2"], hdr["seq_len"], bwt_t, hdr["sa_intv"], sa_t, bits_t)
+    # 2-bit forward strand (the .pac body) for the on-device reference fetch; every rank packs its own copy
+    gp = torch.from_numpy(np.concatenate([g, np.zeros((-len(g)) % 4 + 4, np.uint8)])).to(dev).view(-1, 4).to(torch.int32)
+    pac_t = ((gp[:, 0] << 6) | (gp[:, 1] << 4) | (gp[:, 2] << 2) | gp[:, 3]).to(torch.uint8).contiguous()
+    del gp
+    dindex = B.Index.from_device(hdr["primary"], hdr["L2"], hdr["seq_len"], bwt_t, hdr["sa_intv"], sa_t, bits_t, pac_t=pac_t, l_pac=len(g))
     lo, hi = shard_range(a.reads_per_gpu * world, rank, world, multiple=2 if a.paired else 1)
     if a.paired:
         reads, _ = B.synth.make_pairs(g, (hi - lo) // 2, a.read_len, seed=7 + rank)
@@ -127,31 +139,55 @@ def main():
     n_reads = dr.n
     ws = B.SeedWorkspace(n_reads, n_reads * a.read_len)
     s = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19)
-    # extension jobs of the batch: the host job builder (chain -> chain_flt -> chain2aln restatement, parity-checked
-    # against the reference's own host code) on all host cores, then uploaded; untimed, like the reference's host stage
-    from bwamem_hip.lib import HostJobs, seeds_to_host
-    t0 = time.time()
-    flat = reads.reshape(-1)
-    hj = HostJobs(g, flat, np.arange(n_reads, dtype=np.uint64) * a.read_len, np.full(n_reads, a.read_len, np.uint32), seeds_to_host(s, n_reads))
-    t_jobs = time.time() - t0
-    jobs = P.ExtJobs(*[torch.from_numpy(np.ascontiguousarray(x).view(np.int32) if x.dtype == np.uint32 else np.ascontiguousarray(x)).to(dev)
-                       for x in hj.jobs()], torch.from_numpy(hj.job_read.view(np.int32).copy()).to(dev), torch.from_numpy(hj.job_side.view(np.int32).copy()).to(dev))
-    n_regs = hj.n_regs
-    hj.free()
-    out = torch.zeros(max(jobs.n, 1), 3, dtype=torch.int32, device=dev)
+    from bwamem_hip.lib import ChainWorkspace, HostJobs, seeds_to_host
     params = B.ExtParams.default()
     L = B.load_library()
+    t_jobs = 0.0
+    if a.host_jobs:
+        # extension jobs of the batch from the host job builder (chain -> chain_flt -> chain2aln restatement, parity-checked
+        # against the reference's own host code) on all host cores, then uploaded; untimed, like the reference's host stage
+        t0 = time.time()
+        flat = reads.reshape(-1)
+        hj = HostJobs(g, flat, np.arange(n_reads, dtype=np.uint64) * a.read_len, np.full(n_reads, a.read_len, np.uint32), seeds_to_host(s, n_reads))
+        t_jobs = time.time() - t0
+        jobs = P.ExtJobs(*[torch.from_numpy(np.ascontiguousarray(x).view(np.int32) if x.dtype == np.uint32 else np.ascontiguousarray(x)).to(dev)
+                           for x in hj.jobs()], torch.from_numpy(hj.job_read.view(np.int32).copy()).to(dev), torch.from_numpy(hj.job_side.view(np.int32).copy()).to(dev))
+        n_regs, n_jobs = hj.n_regs, jobs.n
+        hj.free()
+        out = torch.zeros(max(n_jobs, 1), 3, dtype=torch.int32, device=dev)
+    else:
+        # the device job builder: nothing of the batch is prepared on the host
+        cw = ChainWorkspace(n_reads, int(s.n_seeds * 1.25) + 4096)
+        dj = cw.chain_batch(dindex, dr.ascii, dr.offs, dr.lens, s)
+        n_regs, n_jobs = int(dj.n_regs), int(dj.n_jobs)
+        out = torch.zeros(int(n_jobs * 1.25) + 4096, 3, dtype=torch.int32, device=dev)
+        regs_out = torch.zeros(int(n_regs * 1.25) + 4096, 8, dtype=torch.int32, device=dev)
+        jq = torch.empty(n_jobs, dtype=torch.int32, device=dev); jt = torch.empty(n_jobs, dtype=torch.int32, device=dev)
+        from bwamem_hip.lib import _memcpy_d2d
+        _memcpy_d2d(jq.data_ptr(), dj.d_qlen, 4 * n_jobs); _memcpy_d2d(jt.data_ptr(), dj.d_tlen, 4 * n_jobs)
+        jobs = None
 
-    # Two HIP streams: the extension of a batch (integer-VALU bound) runs beside the seeding of a
-    # batch (HBM-latency bound), as the production pipeline does with consecutive batches.
     torch.cuda.synchronize()
     s_seed, s_ext = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     h_seed = s_seed.cuda_stream
-    h_ext = s_ext.cuda_stream if a.overlap else h_seed
+    h_ext = s_ext.cuda_stream if (a.overlap and a.host_jobs) else h_seed
+    chain_ms = [0.0]
 
-    def step():
-        B.extend_batch(jobs.q, jobs.qoff, jobs.qlen, jobs.t, jobs.toff, jobs.tlen, jobs.h0, out, params=params, stream=h_ext)
-        ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19, stream=h_seed)
+    if a.host_jobs:
+        # Two HIP streams: the extension of a batch runs beside the seeding of a batch.
+        def step():
+            B.extend_batch(jobs.q, jobs.qoff, jobs.qlen, jobs.t, jobs.toff, jobs.tlen, jobs.h0, out, params=params, stream=h_ext)
+            ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19, stream=h_seed)
+    else:
+        # reads -> seeds -> chains / jobs (incl. reference fetch) -> extension -> regions, one stream, all in HBM
+        def step():
+            sd = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19, stream=h_seed)
+            t0 = time.perf_counter()
+            d = cw.chain_batch(dindex, dr.ascii, dr.offs, dr.lens, sd, stream=h_seed)
+            chain_ms[0] = (time.perf_counter() - t0) * 1e3
+            rc = L.bmh_extend_batch(d.d_q, d.d_qoff, d.d_qlen, d.d_t, d.d_toff, d.d_tlen, d.d_h0, int(d.n_jobs), C.byref(params), out.data_ptr(), None, h_seed)
+            assert rc == 0
+            cw.merge(out, regs_out, stream=h_seed)
 
     for _ in range(a.warmup):
         step()
@@ -165,6 +201,8 @@ def main():
         step()
         tm = ws.timing()                       # HIP events on the launch stream, per stage
         tm["extend"] = L.bmh_extend_last_ms()  # idem for the DP kernels (waits for them)
+        if not a.host_jobs:
+            tm["chain"] = chain_ms[0]          # host clock around bmh_chain_batch (it synchronises; the base fetch kernel trails it)
         for k, v in tm.items():
             stage_ms[k] = stage_ms.get(k, 0.0) + v
     torch.cuda.synchronize()
@@ -185,10 +223,17 @@ def main():
     # per-kernel durations without inter-stream interference (HIP events on the launch stream), for the roofline
     iso_ms = {}
     for _ in range(3):
-        ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19, stream=h_seed)
+        sd = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19, stream=h_seed)
         tm = ws.timing()
         torch.cuda.synchronize()
-        B.extend_batch(jobs.q, jobs.qoff, jobs.qlen, jobs.t, jobs.toff, jobs.tlen, jobs.h0, out, params=params, stream=h_seed)
+        if a.host_jobs:
+            B.extend_batch(jobs.q, jobs.qoff, jobs.qlen, jobs.t, jobs.toff, jobs.tlen, jobs.h0, out, params=params, stream=h_seed)
+        else:
+            t0 = time.perf_counter()
+            d = cw.chain_batch(dindex, dr.ascii, dr.offs, dr.lens, sd, stream=h_seed)
+            torch.cuda.synchronize()
+            tm["chain"] = (time.perf_counter() - t0) * 1e3
+            L.bmh_extend_batch(d.d_q, d.d_qoff, d.d_qlen, d.d_t, d.d_toff, d.d_tlen, d.d_h0, int(d.n_jobs), C.byref(params), out.data_ptr(), None, h_seed)
         tm["extend"] = L.bmh_extend_last_ms()
         torch.cuda.synchronize()
         for k, v in tm.items():
@@ -203,11 +248,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{a.reads_per_gpu} synthetic {a.read_len} bp single-end reads per GPU vs seeded synthetic "
                                    f"{a.genome_mbp:g} Mbp genome (hg38 stand-in: uniform + 10% diverged repeat families); "
-                                   "seeding = all SMEMs >= 19 bp + locate; extension = every left/right job the reference's chaining (mem_chain, mem_chain_flt, mem_chain2aln) produces",
+                                   "seeding = all SMEMs >= 19 bp + locate; extension = every left/right job the reference's chaining (mem_chain, mem_chain_flt, mem_chain2aln) produces; "
+                                   + ("jobs prebuilt on the host outside the timed region" if a.host_jobs else
+                                      "chaining, job construction with on-device reference fetch and the region merge run on the device inside the timed region (reads in, regions out)"),
                        "reads_per_gpu": n_reads, "read_len": a.read_len, "paired_interleaved": bool(a.paired), "genome_mbp": a.genome_mbp,
                        "index_bytes": int(bwt_t.numel() * 4 + sa_t.numel() * 4 + bits_t.numel() * 4),
-                       "ext_jobs_per_gpu": jobs.n, "regions_per_gpu": n_regs, "host_job_build_s": round(t_jobs, 2), "seeds_per_gpu": int(s.n_seeds), "min_seed_len": 19,
-                       "scoring": "a1 b4 o6 e1 clip5 zdrop0", "streams": "seeding || extension" if a.overlap else "single", "index_build_s": round(t_index, 2)},
+                       "ext_jobs_per_gpu": n_jobs, "regions_per_gpu": n_regs, "job_builder": "host (untimed)" if a.host_jobs else "device (timed)", "host_job_build_s": round(t_jobs, 2), "seeds_per_gpu": int(s.n_seeds), "min_seed_len": 19,
+                       "scoring": "a1 b4 o6 e1 clip5 zdrop0", "streams": "seeding || extension" if (a.overlap and a.host_jobs) else "single", "index_build_s": round(t_index, 2)},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "stage_ms_isolated": {k: round(v, 3) for k, v in iso_ms.items()},
         }
@@ -215,10 +262,12 @@ def main():
         if world == 1:
             ncores = os.cpu_count() or 1
             cb = cpu_baseline(g, idx, reads, min(a.cpu_sample, n_reads), ncores)
-            cpu_mreads = cb["n"] / (cb["t_seed"] + cb["t_ext"]) / 1e6
+            t_cpu = cb["t_seed"] + cb["t_ext"] + (0.0 if a.host_jobs else cb["t_chain"])
+            cpu_mreads = cb["n"] / t_cpu / 1e6
             res["cpu_baseline"] = {"value": round(cpu_mreads, 5), "unit": "Mreads/s", "cores": ncores, "kind": "port",
                                    "sample": f"first {cb['n']} reads of the same batch: oracle seeding {cb['t_seed']:.2f}s + "
-                                             f"oracle extension {cb['t_ext']:.2f}s on {ncores} threads"}
+                                             + ("" if a.host_jobs else f"host chaining/job builder (bmh_build_jobs) {cb['t_chain']:.2f}s + ")
+                                             + f"oracle extension {cb['t_ext']:.2f}s on {ncores} threads"}
             res["speedup_vs_cpu_baseline"] = round(value / cpu_mreads, 1)
             res["oracle_work_per_read"] = {k: round(v / cb["n"], 2) for k, v in cb["work"].items()}
             # algorithmic bytes per read, counted by the oracle on the sample
@@ -230,7 +279,7 @@ def main():
             else:
                 per_read["forward"] = 32.0 * wk["n_blk_fwd"] / n + a.read_len / 4 + 8
                 per_read["backward"] = 32.0 * wk["n_blk_back"] / n
-            q, t = jobs.qlen.long(), jobs.tlen.long()
+            q, t = (jobs.qlen.long(), jobs.tlen.long()) if a.host_jobs else (jq.long(), jt.long())
             ext_bytes = float(((q + 3) // 4 + (t + 3) // 4 + (q + t + 7) // 8 + 28).sum().item())
             kernel_bytes = {k: v * n_reads for k, v in per_read.items()}
             kernel_bytes["extend"] = ext_bytes
@@ -258,10 +307,10 @@ def main():
                                                   "algorithm touches, cache hits included")
             res["roofline_all"] = {k: {"ms": round(iso_ms[k], 3), "algorithmic_GBps": round(kernel_bytes[k] / (iso_ms[k] * 1e-3) / 1e9, 2)}
                                    for k in kernel_bytes}
-            cells = cb["cells"] / cb["n_jobs"] * jobs.n
+            cells = cb["cells"] / cb["n_jobs"] * n_jobs
             res["extension_stage"] = {"bound": "integer VALU (not HBM, not MFMA)", "ms": round(iso_ms["extend"], 3),
                                       "gcups_reference_cells": round(cells / (iso_ms["extend"] * 1e-3) / 1e9, 1),
-                                      "jobs": jobs.n, "hbm_GBps": round(kernel_bytes["extend"] / (iso_ms["extend"] * 1e-3) / 1e9, 2)}
+                                      "jobs": n_jobs, "hbm_GBps": round(kernel_bytes["extend"] / (iso_ms["extend"] * 1e-3) / 1e9, 2)}
         print(json.dumps(res), flush=True)
     if distributed:
         dist.destroy_process_group()

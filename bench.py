@@ -158,6 +158,7 @@ def main():
     else:
         # the device job builder: nothing of the batch is prepared on the host
         cw = ChainWorkspace(n_reads, int(s.n_seeds * 1.25) + 4096)
+        cw.set_materialize(False)             # jobs stay descriptors: the DP kernels fetch bases from the reads / 2-bit reference
         dj = cw.chain_batch(dindex, dr.ascii, dr.offs, dr.lens, s)
         n_regs, n_jobs = int(dj.n_regs), int(dj.n_jobs)
         out = torch.zeros(int(n_jobs * 1.25) + 4096, 3, dtype=torch.int32, device=dev)
@@ -185,8 +186,7 @@ def main():
             t0 = time.perf_counter()
             d = cw.chain_batch(dindex, dr.ascii, dr.offs, dr.lens, sd, stream=h_seed)
             chain_ms[0] = (time.perf_counter() - t0) * 1e3
-            rc = L.bmh_extend_batch(d.d_q, d.d_qoff, d.d_qlen, d.d_t, d.d_toff, d.d_tlen, d.d_h0, int(d.n_jobs), C.byref(params), out.data_ptr(), None, h_seed)
-            assert rc == 0
+            cw.extend(out, params=params, stream=h_seed)
             cw.merge(out, regs_out, stream=h_seed)
 
     for _ in range(a.warmup):
@@ -233,7 +233,7 @@ def main():
             d = cw.chain_batch(dindex, dr.ascii, dr.offs, dr.lens, sd, stream=h_seed)
             torch.cuda.synchronize()
             tm["chain"] = (time.perf_counter() - t0) * 1e3
-            L.bmh_extend_batch(d.d_q, d.d_qoff, d.d_qlen, d.d_t, d.d_toff, d.d_tlen, d.d_h0, int(d.n_jobs), C.byref(params), out.data_ptr(), None, h_seed)
+            cw.extend(out, params=params, stream=h_seed)
         tm["extend"] = L.bmh_extend_last_ms()
         torch.cuda.synchronize()
         for k, v in tm.items():

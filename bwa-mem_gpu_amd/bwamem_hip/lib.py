@@ -24,7 +24,8 @@ EXPORTED_SYMBOLS = [
     "bmh_index_free", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
     "bmh_extend_batch", "bmh_extend_last_ms", "bmh_calib_gather",
     "bmh_chain_opt_default", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
-    "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_batch", "bmh_chain_merge",
+    "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_materialize", "bmh_chain_batch",
+    "bmh_chain_extend", "bmh_chain_merge",
     "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
     "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
 ]
@@ -129,6 +130,10 @@ def load_library() -> C.CDLL:
     L.bmh_chain_batch.restype = C.c_int
     L.bmh_chain_batch.argtypes = [C.c_void_p, C.POINTER(ChainOpt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                   C.POINTER(SeedsT), C.c_void_p, C.POINTER(DevJobsT)]
+    L.bmh_chain_set_materialize.restype = C.c_int
+    L.bmh_chain_set_materialize.argtypes = [C.c_void_p, C.c_int]
+    L.bmh_chain_extend.restype = C.c_int
+    L.bmh_chain_extend.argtypes = [C.c_void_p, C.POINTER(ExtParams), C.c_void_p, C.c_void_p, C.c_void_p]
     L.bmh_chain_merge.restype = C.c_int
     L.bmh_chain_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwt_restore_bwt_gpu.restype = C.POINTER(BwtTGpu)
@@ -241,6 +246,17 @@ class ChainWorkspace:
         if rc != 0:
             raise RuntimeError(f"bmh_chain_batch rc={rc}: " + _err(L))
         return out
+
+    def set_materialize(self, on: bool) -> None:
+        load_library().bmh_chain_set_materialize(self.handle, 1 if on else 0)
+
+    def extend(self, out3_t, params: "ExtParams | None" = None, raw_t=None, stream: int = 0) -> None:
+        """bmh_chain_extend: extension of the last chain_batch's jobs straight from their descriptors."""
+        L = load_library()
+        p = params or ExtParams.default()
+        rc = L.bmh_chain_extend(self.handle, C.byref(p), out3_t.data_ptr(), raw_t.data_ptr() if raw_t is not None else None, stream)
+        if rc != 0:
+            raise RuntimeError(f"bmh_chain_extend rc={rc}: " + _err(L))
 
     def merge(self, out3_t, regs_t, stream: int = 0) -> None:
         L = load_library()

@@ -27,20 +27,26 @@ struct chain_args_t {
 	uint32_t *heavy_list; uint32_t *heavy_n;
 };
 
-__global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A)
+// reads with more than heavy_thresh seeds go to the wave kernel: three lists by size so that it starts the longest first
+__global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 {
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
 	if (r >= A.n_reads) return;
 	const uint32_t n = A.x.n_ref[r];
-	if (n > A.heavy_thresh) {          // three lists by size so that the wave kernel starts the longest reads first
+	if (n > A.heavy_thresh) {
 		const int cls = n > 192 ? 0 : n > 80 ? 1 : 2;
 		A.heavy_list[(size_t)cls * A.n_reads + atomicAdd(A.heavy_n + cls, 1u)] = r;
-		return;
 	}
+}
+
+__global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A)
+{
+	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+	if (r >= A.n_reads || A.x.n_ref[r] > A.heavy_thresh) return;
 	chain_core::chain_read<false>(A.x, r, chain_core::global_scratch(A.x, r));
 }
 
-// one wave per heavy read; the list was filled by chain_lane_kernel (earlier on the same stream).  The read's scratch
+// one wave per heavy read; the lists were filled by chain_classify_kernel.  Runs on a side stream beside chain_lane_kernel.  The read's scratch
 // lives in LDS when it fits lds_cap entries (CH_LDS_BYTES_PER_ENTRY each): the wave form is a chain of dependent
 // accesses, so their latency is its run time.
 #define CH_LDS_BYTES_PER_ENTRY (8 + 8 + sizeof(ch_est_t) + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4 + 4 + 4)
@@ -178,6 +184,9 @@ struct bmh_chain_ws {
 	void *scan_tmp; size_t scan_tmp_bytes;
 	uint64_t n_regs, n_jobs;
 	uint32_t *h_pin;               // pinned host words for the small D2H copies
+	hipStream_t side; hipEvent_t ev_fork, ev_join;   // the wave kernel runs beside the lane kernel
+	int materialize;               // 1: bmh_chain_batch also writes the base arrays q/t (+ qoff/toff)
+	const uint8_t *last_reads, *last_pac; uint64_t last_l_pac;   // sources of the last batch, for bmh_chain_extend
 };
 
 extern "C" void bmh_chain_ws_free(bmh_chain_ws_t *w)
@@ -188,6 +197,9 @@ extern "C" void bmh_chain_ws_free(bmh_chain_ws_t *w)
 	              w->job_side, w->jq_src, w->qoff, w->toff, w->jt0, w->qoff64, w->toff64, w->q, w->t, w->scan_tmp};
 	for (void *p : ps) if (p) (void)hipFree(p);
 	if (w->h_pin) (void)hipHostFree(w->h_pin);
+	if (w->side) (void)hipStreamDestroy(w->side);
+	if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
+	if (w->ev_join) (void)hipEventDestroy(w->ev_join);
 	free(w);
 }
 
@@ -211,8 +223,11 @@ extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_
 	A(w->scan_tmp, w->scan_tmp_bytes + 256);
 #undef A
 	ok = ok && hipHostMalloc((void **)&w->h_pin, 64) == hipSuccess;
+	ok = ok && hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) == hipSuccess;
 	if (!ok) { bmh_set_error("bmh_chain_ws_create: hipMalloc failed (%s)", hipGetErrorString(hipGetLastError())); bmh_chain_ws_free(w); return nullptr; }
 	w->n_contigs = 1;
+	w->materialize = 1;
 	return w;
 }
 
@@ -227,6 +242,13 @@ extern "C" int bmh_chain_set_contigs(bmh_chain_ws_t *w, int n_contigs, const int
 	HIPCK(hipMalloc((void **)&w->ctg_off, 8 * (size_t)n_contigs)); HIPCK(hipMalloc((void **)&w->ctg_len, 4 * (size_t)n_contigs));
 	HIPCK(hipMemcpy(w->ctg_off, offset, 8 * (size_t)n_contigs, hipMemcpyHostToDevice));
 	HIPCK(hipMemcpy(w->ctg_len, len, 4 * (size_t)n_contigs, hipMemcpyHostToDevice));
+	return BMH_OK;
+}
+
+extern "C" int bmh_chain_set_materialize(bmh_chain_ws_t *w, int on)
+{
+	if (!w) { bmh_set_error("bmh_chain_set_materialize: null workspace"); return BMH_EINVAL; }
+	w->materialize = on ? 1 : 0;
 	return BMH_OK;
 }
 
@@ -252,6 +274,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	if (opt->max_occ < 1 || opt->e_del < 1 || opt->e_ins < 1) { bmh_set_error("bmh_chain_batch: bad options"); return BMH_EINVAL; }
 	hipStream_t st = (hipStream_t)stream_;
 	w->n_regs = w->n_jobs = 0;
+	w->last_reads = d_reads; w->last_pac = idx->dev.pac; w->last_l_pac = idx->dev.l_pac;
 	if (n_reads == 0) return BMH_OK;
 	chain_args_t A;
 	memset(&A, 0, sizeof(A));
@@ -273,6 +296,9 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	HIPCK(hipMemsetAsync(w->counters, 0, 64, st));
 	HIPCK(hipMemsetAsync(w->regs_per_read + n_reads, 0, 4, st));
 	HIPCK(hipMemsetAsync(w->jobs_per_read + n_reads, 0, 4, st));
+	chain_classify_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(A);
+	HIPCK(hipEventRecord(w->ev_fork, st));
+	HIPCK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
 	chain_lane_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(A);
 	{
 		const char *lk = getenv("BMH_CHAIN_LDS_ENTRIES");
@@ -280,7 +306,9 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 		const size_t lds_bytes = (size_t)lds_cap * CH_LDS_BYTES_PER_ENTRY;
 		if (lds_bytes > 160 * 1024 - 512) { bmh_set_error("bmh_chain_batch: BMH_CHAIN_LDS_ENTRIES too large"); return BMH_EINVAL; }
 		HIPCK(hipFuncSetAttribute((const void *)chain_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-		chain_wave_kernel<<<2048, 64, lds_bytes, st>>>(A, lds_cap);
+		chain_wave_kernel<<<2048, 64, lds_bytes, w->side>>>(A, lds_cap);
+		HIPCK(hipEventRecord(w->ev_join, w->side));
+		HIPCK(hipStreamWaitEvent(st, w->ev_join, 0));
 	}
 	size_t tb = w->scan_tmp_bytes;
 	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->regs_per_read, w->reg_off, 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
@@ -325,7 +353,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
 	out->d_qlen = w->qlen; out->d_tlen = w->tlen; out->d_h0 = w->h0; out->d_job_read = w->job_read; out->d_job_reg = w->job_reg; out->d_job_side = w->job_side;
 	out->d_qoff = w->qoff; out->d_toff = w->toff;
-	if (n_jobs == 0) return BMH_OK;
+	if (n_jobs == 0 || !w->materialize) { out->d_qoff = out->d_toff = nullptr; HIPCK(hipGetLastError()); return BMH_OK; }
 	// one extra (zero) element so the scans also yield the totals
 	HIPCK(hipMemsetAsync(w->qlen + n_jobs, 0, 4, st)); HIPCK(hipMemsetAsync(w->tlen + n_jobs, 0, 4, st));
 	tb = w->scan_tmp_bytes;
@@ -349,6 +377,15 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	HIPCK(hipGetLastError());
 	out->q_bytes = qb; out->t_bytes = tbytes; out->d_q = w->q; out->d_t = w->t;
 	return BMH_OK;
+}
+
+extern "C" int bmh_chain_extend(bmh_chain_ws_t *w, const bmh_ext_params_t *p, int32_t *d_out3, int32_t *d_raw, void *stream_)
+{
+	if (!w || !p) { bmh_set_error("bmh_chain_extend: null argument"); return BMH_EINVAL; }
+	if (w->n_jobs == 0) return BMH_OK;
+	bmh_ext_desc_t d;
+	d.reads = w->last_reads; d.pac = w->last_pac; d.l_pac = (long long)w->last_l_pac; d.jq_src = w->jq_src; d.job_side = w->job_side; d.jt0 = w->jt0;
+	return bmh_extend_batch_desc(&d, w->qlen, w->tlen, w->h0, (uint32_t)w->n_jobs, p, d_out3, d_raw, stream_);
 }
 
 extern "C" int bmh_chain_merge(bmh_chain_ws_t *w, const int32_t *d_out3, int32_t *d_regs_out, void *stream_)

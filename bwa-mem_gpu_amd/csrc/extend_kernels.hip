@@ -62,12 +62,49 @@ __device__ __forceinline__ int wave_shr1(int v, int fill)
 struct ext_args_t {
 	const uint8_t *q, *t;
 	const uint32_t *qoff, *qlen, *toff, *tlen, *h0;
+	// descriptor mode (desc != 0; jobs of the device job builder, nothing materialised): query bases are read from the
+	// ASCII reads at reads + jq_src[id], target bases from the 2-bit reference at text position jt0[id] + i; LEFT jobs
+	// (job_side[id] == 0) run both backwards (src/bwamem.c:1328-1334).  q/t/qoff/toff are unused then.
+	int desc;
+	const uint8_t *reads, *pac; long long l_pac;
+	const uint32_t *jq_src, *job_side; const long long *jt0;
 	const uint32_t *ids;          // alignment ids of this class
 	const uint32_t *count;        // how many
 	int32_t *out, *raw;
 	int a, b, o_del, e_del, o_ins, e_ins, zdrop, end_bonus;
 	unsigned long long *stats;    // debug (BMH_EXT_STATS): [0] rows executed, [1] sum of tlen, [2] alignments, [3] wave-rows
 };
+
+// where the bases of one job come from
+struct job_src_t { const uint8_t *qp; int qstep; const uint8_t *tp; long long t0; int tdir; };
+
+__device__ __forceinline__ job_src_t ext_job_src(const ext_args_t &A, uint32_t id, bool have, int qlen, int tlen)
+{
+	job_src_t s;
+	if (A.desc) {
+		const bool left = have && A.job_side[id] == 0;
+		s.qp = A.reads + (have ? A.jq_src[id] : 0) + (left ? qlen - 1 : 0); s.qstep = left ? -1 : 1;
+		s.t0 = (have ? A.jt0[id] : 0) + (left ? tlen - 1 : 0); s.tdir = left ? -1 : 1; s.tp = nullptr;
+	} else {
+		s.qp = A.q + (have ? A.qoff[id] : 0); s.qstep = 1; s.tp = A.t + (have ? A.toff[id] : 0); s.t0 = 0; s.tdir = 1;
+	}
+	return s;
+}
+__device__ __forceinline__ int ext_q_at(const ext_args_t &A, const job_src_t &s, int i)      // query code 0..4
+{
+	int v = (int)s.qp[(long)i * s.qstep];
+	if (A.desc) { v &= 0xDF; v = v == 'A' ? 0 : v == 'C' ? 1 : v == 'G' ? 2 : v == 'T' ? 3 : 4; }
+	return v;
+}
+__device__ __forceinline__ int ext_t_at(const ext_args_t &A, const job_src_t &s, int i)      // target code 0..4
+{
+	if (!A.desc) return (int)s.tp[i];
+	const long long p = s.t0 + (long long)i * s.tdir;
+	const bool rev = p >= A.l_pac;
+	const long long f = rev ? (A.l_pac << 1) - 1 - p : p;
+	const int c = (A.pac[f >> 2] >> ((~f & 3) << 1)) & 3;
+	return rev ? 3 - c : c;
+}
 
 template <int C>
 __global__ void __launch_bounds__(256) extend_wide_kernel(ext_args_t A)
@@ -81,12 +118,12 @@ __global__ void __launch_bounds__(256) extend_wide_kernel(ext_args_t A)
 	for (uint32_t w = wave; w < n; w += n_waves) {
 		const uint32_t id = ids[w];
 		const int qlen = (int)A.qlen[id], tlen = (int)A.tlen[id], h0 = (int)A.h0[id];
-		const uint8_t *qp = A.q + A.qoff[id], *tp = A.t + A.toff[id];
+		const job_src_t src = ext_job_src(A, id, true, qlen, tlen);
 		int H[C], E[C], qb[C];
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			int j = lane * C + c;
-			qb[c] = j < qlen ? (int)qp[j] : 4;
+			qb[c] = j < qlen ? ext_q_at(A, src, j) : 4;
 			int v = h0 - oe_ins - j * A.e_ins;            // H(-1,j), ksw.c:880-883
 			H[c] = (j < qlen && v > 0) ? v : 0;
 			E[c] = 0;
@@ -94,7 +131,7 @@ __global__ void __launch_bounds__(256) extend_wide_kernel(ext_args_t A)
 		int beg = 0, end = qlen, mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
 		int tchunk = 0;
 		for (int i = 0; i < tlen; ++i) {
-			if ((i & 63) == 0) tchunk = (i + lane < tlen) ? (int)tp[i + lane] : 4;
+			if ((i & 63) == 0) tchunk = (i + lane < tlen) ? ext_t_at(A, src, i + lane) : 4;
 			const int ti = __builtin_amdgcn_readlane(tchunk, i & 63);
 			// H(i-1,-1): the first-column value of the previous row (ksw.c:909-914, :880)
 			const int hm1 = i == 0 ? h0 : max(0, h0 - (A.o_del + A.e_del * i));
@@ -279,13 +316,13 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 		const bool have = w + grp < n;
 		const uint32_t id = have ? ids[w + grp] : 0;
 		const int qlen = have ? (int)A.qlen[id] : 0, tlen = have ? (int)A.tlen[id] : 0, h0 = have ? (int)A.h0[id] : 1;
-		const uint8_t *qp = A.q + (have ? A.qoff[id] : 0), *tp = A.t + (have ? A.toff[id] : 0);
+		const job_src_t src = ext_job_src(A, id, have, qlen, tlen);
 		// column state; query N is code 4, target N is made 5 below so that N never "matches" (mat[4][4] = -1, bwa.c:99-108)
 		int H[C], E[C], qb[C], mm[C];
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			const int j = j0 + c;
-			qb[c] = j < qlen ? (int)qp[j] : 4;
+			qb[c] = j < qlen ? ext_q_at(A, src, j) : 4;
 			mm[c] = qb[c] > 3 ? -1 : -A.b;                   // mismatch score of this column
 			const int v = h0 - oe_ins - j * A.e_ins;
 			H[c] = (j < qlen && v > 0) ? v : 0;
@@ -298,7 +335,7 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 		int rows_done = 0, wave_rows = 0;
 		for (int i = 0; __any(alive && i < tlen); ++i) {
 			++wave_rows;
-			if ((i & 15) == 0) { const int tb = (alive && i + l16 < tlen) ? (int)tp[i + l16] : 5; tchunk = tb > 3 ? 5 : tb; }
+			if ((i & 15) == 0) { const int tb = (alive && i + l16 < tlen) ? ext_t_at(A, src, i + l16) : 5; tchunk = tb > 3 ? 5 : tb; }
 			const int ti = __builtin_amdgcn_ds_bpermute(bp_base + ((i & 15) << 2), tchunk);
 			const bool run = alive && i < tlen;
 			rows_done += run ? 1 : 0;
@@ -483,12 +520,12 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 		const uint32_t id = w + grp;
 		const bool have = id < n;
 		const int qlen = have ? (int)A.qlen[id] : 0, tlen = have ? (int)A.tlen[id] : 0, h0 = have ? (int)A.h0[id] : 1;
-		const uint8_t *qp = A.q + (have ? A.qoff[id] : 0), *tp = A.t + (have ? A.toff[id] : 0);
+		const job_src_t src = ext_job_src(A, id, have, qlen, tlen);
 		const bool elig = have && qlen > 0 && tlen >= qlen && params_ok;
 		int hi = -1, lo = -0x7000, cnt = 0;   // largest / (negated) smallest mismatching column, mismatch count of this lane
 		for (int j = l16; __any(elig && j < qlen); j += 16) {
 			if (elig && j < qlen) {
-				const int qb = (int)qp[j], tb = (int)tp[j];
+				const int qb = ext_q_at(A, src, j), tb = ext_t_at(A, src, j);
 				const bool bad = qb > 3 || tb > 3;                      // N on either side: not eligible
 				const bool mis = tb != qb;
 				hi = bad ? 0x7000 : (mis ? max(hi, j) : hi);
@@ -508,11 +545,11 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 			int bits = 0;
 			for (int i = p1 + lmax + l16; __any(two && i <= p2); i += 16) {
 				if (two && i <= p2) {
-					const int tb = (int)tp[i];
+					const int tb = ext_t_at(A, src, i);
 					for (int L = 1; L <= lmax; ++L) {
 						const int cm = i - L, cp = i + L;
-						const bool mm = cm < 0 || (int)qp[cm] != tb;       // d = -L
-						const bool mp = cp < qlen && (int)qp[cp] != tb;    // d = +L: rows past the end of that diagonal do not count
+						const bool mm = cm < 0 || ext_q_at(A, src, cm) != tb;       // d = -L
+						const bool mp = cp < qlen && ext_q_at(A, src, cp) != tb;    // d = +L: rows past the end of that diagonal do not count
 						bits |= (mm ? 1 : 0) << (2 * (L - 1)) | (mp ? 1 : 0) << (2 * (L - 1) + 1);
 					}
 				}
@@ -654,6 +691,10 @@ static void launch_wide(const ext_args_t &base, hipStream_t st, unsigned grid)
 	extend_wide_kernel<C><<<grid, 256, 0, st>>>(a);
 }
 
+static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint32_t *d_qlen, const uint8_t *d_t,
+                         const uint32_t *d_toff, const uint32_t *d_tlen, const uint32_t *d_h0, uint32_t n,
+                         const bmh_ext_params_t *p, int32_t *d_out, int32_t *d_raw, void *stream_, const bmh_ext_desc_t *desc);
+
 extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, const uint32_t *d_qlen, const uint8_t *d_t,
                                 const uint32_t *d_toff, const uint32_t *d_tlen, const uint32_t *d_h0, uint32_t n,
                                 const bmh_ext_params_t *p, int32_t *d_out, int32_t *d_raw, void *stream_)
@@ -661,6 +702,23 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 	if (!p || (n && (!d_q || !d_t || !d_qoff || !d_qlen || !d_toff || !d_tlen || !d_h0 || !d_out))) {
 		bmh_set_error("bmh_extend_batch: null argument"); return BMH_EINVAL;
 	}
+	return extend_launch(d_q, d_qoff, d_qlen, d_t, d_toff, d_tlen, d_h0, n, p, d_out, d_raw, stream_, nullptr);
+}
+
+// descriptor form, used by bmh_chain_extend (chain_kernels.hip)
+int bmh_extend_batch_desc(const bmh_ext_desc_t *desc, const uint32_t *d_qlen, const uint32_t *d_tlen, const uint32_t *d_h0, uint32_t n,
+                          const bmh_ext_params_t *p, int32_t *d_out, int32_t *d_raw, void *stream_)
+{
+	if (!p || !desc || (n && (!d_qlen || !d_tlen || !d_h0 || !d_out || !desc->reads || !desc->pac || !desc->jq_src || !desc->job_side || !desc->jt0))) {
+		bmh_set_error("bmh_extend_batch_desc: null argument"); return BMH_EINVAL;
+	}
+	return extend_launch(nullptr, nullptr, d_qlen, nullptr, nullptr, d_tlen, d_h0, n, p, d_out, d_raw, stream_, desc);
+}
+
+static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint32_t *d_qlen, const uint8_t *d_t,
+                         const uint32_t *d_toff, const uint32_t *d_tlen, const uint32_t *d_h0, uint32_t n,
+                         const bmh_ext_params_t *p, int32_t *d_out, int32_t *d_raw, void *stream_, const bmh_ext_desc_t *desc)
+{
 	if (p->e_del < 0 || p->e_ins < 0 || p->o_del < 0 || p->o_ins < 0) { bmh_set_error("bmh_extend_batch: negative gap penalty"); return BMH_EINVAL; }
 	if (n == 0) return BMH_OK;
 	hipStream_t st = (hipStream_t)stream_;
@@ -692,6 +750,9 @@ extern "C" int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, cons
 	}
 	ext_args_t a;
 	a.q = d_q; a.t = d_t; a.qoff = d_qoff; a.qlen = d_qlen; a.toff = d_toff; a.tlen = d_tlen; a.h0 = d_h0;
+	a.desc = desc ? 1 : 0;
+	a.reads = desc ? desc->reads : nullptr; a.pac = desc ? desc->pac : nullptr; a.l_pac = desc ? desc->l_pac : 0;
+	a.jq_src = desc ? desc->jq_src : nullptr; a.job_side = desc ? desc->job_side : nullptr; a.jt0 = desc ? (const long long *)desc->jt0 : nullptr;
 	a.ids = g_scr.vals2; a.count = g_scr.counts; a.out = d_out; a.raw = d_raw;
 	a.a = p->a; a.b = p->b; a.o_del = p->o_del; a.e_del = p->e_del; a.o_ins = p->o_ins; a.e_ins = p->e_ins;
 	a.zdrop = p->zdrop; a.end_bonus = p->end_bonus;

@@ -180,12 +180,21 @@ typedef struct {
 	const uint32_t *d_regs_per_read;                               /* [n_reads] */
 } bmh_dev_jobs_t;
 
+/* on (default): bmh_chain_batch also materialises the base arrays d_q/d_t/d_qoff/d_toff for bmh_extend_batch;
+ * off: it stops at the job descriptors (those four pointers come back NULL, q_bytes = t_bytes = 0) and the batch is
+ * extended with bmh_chain_extend, which reads the bases where they already are (reads, 2-bit reference). */
+int bmh_chain_set_materialize(bmh_chain_ws_t *ws, int on);
+
 /* d_reads/d_offs/d_lens: as for bmh_seed_batch; seeds: its output for the same reads.  Pointers in *out stay valid
- * until the next call on the workspace.  Synchronises the stream (twice: region/job counts, then base counts). */
+ * until the next call on the workspace.  Synchronises the stream (once for the region/job counts, once more for the
+ * base counts when materialising). */
 int bmh_chain_batch(bmh_chain_ws_t *ws, const bmh_chain_opt_t *opt, const bmh_index_t *idx, const uint8_t *d_reads,
                     const uint32_t *d_offs, const uint32_t *d_lens, uint32_t n_reads, const bmh_seeds_t *seeds,
                     void *stream, bmh_dev_jobs_t *out);
-/* d_out3 = bmh_extend_batch results of the batch's jobs -> d_regs_out[n_regs][8] =
+/* bmh_extend_batch on the jobs of the last bmh_chain_batch, without materialised base arrays: same results (d_out3
+ * [n_jobs][3], optional d_raw [n_jobs][6]).  d_reads and the index of that call must still be alive.  Asynchronous. */
+int bmh_chain_extend(bmh_chain_ws_t *ws, const bmh_ext_params_t *p, int32_t *d_out3, int32_t *d_raw, void *stream);
+/* d_out3 = extension results of the batch's jobs -> d_regs_out[n_regs][8] =
  * {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi} (src/bwamem.c:2297-2303).  Asynchronous on stream. */
 int bmh_chain_merge(bmh_chain_ws_t *ws, const int32_t *d_out3, int32_t *d_regs_out, void *stream);
 

@@ -336,6 +336,18 @@ def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None):
     want3, _, _ = oracle.extend_batch(*hj.jobs()) if hj.n_jobs else (np.zeros((0, 3), np.int32), None, None)
     assert np.array_equal(out3.cpu().numpy()[: hj.n_jobs], want3)
     assert np.array_equal(regs.cpu().numpy()[: hj.n_regs], hj.merge(want3))
+    # the same without materialised base arrays: bmh_chain_extend reads the bases from the reads / 2-bit reference
+    cw.set_materialize(False)
+    dj2 = cw.chain_batch(dindex, r, o, l, s)
+    assert int(dj2.n_jobs) == hj.n_jobs and not dj2.d_q and not dj2.d_t
+    out3b = torch.full((max(hj.n_jobs, 1), 3), -7, dtype=torch.int32, device="cuda")
+    raw6 = torch.zeros(max(hj.n_jobs, 1), 6, dtype=torch.int32, device="cuda")
+    regs2 = torch.zeros(max(hj.n_regs, 1), 8, dtype=torch.int32, device="cuda")
+    cw.extend(out3b, raw_t=raw6)
+    cw.merge(out3b, regs2)
+    torch.cuda.synchronize()
+    assert np.array_equal(out3b.cpu().numpy()[: hj.n_jobs], want3)
+    assert np.array_equal(regs2.cpu().numpy()[: hj.n_regs], hj.merge(want3))
     stats = (hj.n_jobs, hj.n_regs, int(dj.n_heavy_reads))
     hj.free(); cw.free(); ws.free(); dindex.free()
     return stats

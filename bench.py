@@ -42,17 +42,32 @@ GATHER_CEILING_GBS = 1818.0
 
 def pmc_traffic(kernel_name: str):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01b_pmc_fetch_write.json: FETCH_SIZE + WRITE_SIZE, KB).  For this library's access patterns
+    (profiles/r01c_pmc_fetch_write.json: FETCH_SIZE + WRITE_SIZE, KB).  For this library's access patterns
     FETCH_SIZE needs no correction: the calibration kernel (bmh_calib_gather under --pmc FETCH_SIZE) reads back
     63.9 B per 32-byte gather, i.e. exactly one 64-byte sector each.  None if the profile is absent."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_fetch_write.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_fetch_write.json")))
         key = kernel_name.split("<")[0].split(" ")[0]
         f = [v["avg_per_launch_KB"] for k, v in d["FETCH_SIZE"].items() if key in k]
         w = [v["avg_per_launch_KB"] for k, v in d["WRITE_SIZE"].items() if key in k]
         if not f:
             return None
         return int((sum(f) + sum(w)) * 1024)
+    except Exception:
+        return None
+
+
+def pmc_valu_busy(pred):
+    """VALU-busy fraction of a kernel family from the committed SQ counter pass (profiles/r01c_pmc_sq.json):
+    SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs (MI355X_MICROARCH.md),
+    so busy = 4 * sum(ACTIVE_INST_VALU) / (1024 SIMDs * sum(GUI_ACTIVE) / 8).  None if the profile is absent."""
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_sq.json")))
+        a = g = 0.0
+        for k, v in sq.items():
+            if pred(k) and "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
+                a += v["SQ_ACTIVE_INST_VALU"] * v["launches"]; g += v["GRBM_GUI_ACTIVE"] * v["launches"]
+        return round(4.0 * a / (1024.0 * g / 8.0), 4) if g else None
     except Exception:
         return None
 
@@ -297,11 +312,13 @@ def main():
             dom = max(kernel_bytes.keys(), key=lambda k: iso_ms.get(k, 0.0))
             res["roofline"] = hbm_obj(dom, names[dom])
             if dom == "extend":
-                res["roofline"]["note"] = ("integer-VALU bound DP (no MFMA, ~110 B of HBM traffic per job): see extension_stage for its cell "
+                res["roofline"]["note"] = ("integer-VALU bound DP (no MFMA, ~110 B of HBM traffic per job; SQ counters: VALU busy "
+                                           "fraction in extension_stage.valu_busy_frac): see extension_stage for its cell "
                                            "rate and roofline_hbm_kernel for the dominant HBM-bound kernel")
             hb = max((k for k in kernel_bytes if k != "extend"), key=lambda k: iso_ms.get(k, 0.0))
             res["roofline_hbm_kernel"] = hbm_obj(hb, names[hb])
             res["roofline_hbm_kernel"]["gather_ceiling_GBps"] = GATHER_CEILING_GBS
+            res["roofline_hbm_kernel"]["valu_busy_frac"] = pmc_valu_busy(lambda k: names[hb].split("<")[0] in k)
             res["roofline_hbm_kernel"]["note"] = ("random 32-byte index-block gathers; measured chip ceiling for this pattern = 56.8 G gathers/s = "
                                                   "1818 GB/s of useful bytes (scripts/calib.py); algorithmic bytes count every block the CPU "
                                                   "algorithm touches, cache hits included")
@@ -309,6 +326,7 @@ def main():
                                    for k in kernel_bytes}
             cells = cb["cells"] / cb["n_jobs"] * n_jobs
             res["extension_stage"] = {"bound": "integer VALU (not HBM, not MFMA)", "ms": round(iso_ms["extend"], 3),
+                                      "valu_busy_frac": pmc_valu_busy(lambda k: "extend16_kernel" in k or "extend_wide_kernel" in k),
                                       "gcups_reference_cells": round(cells / (iso_ms["extend"] * 1e-3) / 1e9, 1),
                                       "jobs": n_jobs, "hbm_GBps": round(kernel_bytes["extend"] / (iso_ms["extend"] * 1e-3) / 1e9, 2)}
         print(json.dumps(res), flush=True)

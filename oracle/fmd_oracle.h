@@ -101,6 +101,15 @@ uint64_t oracle_extend_batch(uint32_t n, const uint8_t *q, const uint32_t *qoff,
                              const uint32_t *h0, const ksw_params_t *p, int32_t *out3, int32_t *raw6,
                              int n_threads);
 
+/* ---- region -> CIGAR / NM / MD (cigar_oracle.c; ksw_global2, bwa_gen_cigar2, mem_reg2aln) */
+int oracle_ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const ksw_params_t *p, int w,
+                       int *n_cigar, uint32_t *cigar, int cap);
+int oracle_gen_cigar2(const ksw_params_t *p, int w_, int64_t l_pac, const uint8_t *pac, int l_query, const uint8_t *query,
+                      int64_t rb, int64_t re, int *score, int *n_cigar, uint32_t *cigar, int cap, int *NM, char *md, int md_cap);
+int oracle_reg2aln(const ksw_params_t *p, int opt_w, int64_t l_pac, const uint8_t *pac, int l_query, const uint8_t *read,
+                   int qb, int qe, int64_t rb, int64_t re, int truesc, int reg_w,
+                   int64_t *pos, int *is_rev, int *n_cigar, uint32_t *cigar, int cap, int *NM, char *md, int md_cap, int *score);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,29 @@ class Oracle:
         L.fmd_inv_psi.argtypes = [C.POINTER(FmdT), C.c_uint64]
         L.fmd_sa.restype = C.c_uint64
         L.fmd_sa.argtypes = [C.POINTER(FmdT), C.c_uint64, C.c_void_p]
+        L.oracle_ksw_global2.restype = C.c_int
+        L.oracle_ksw_global2.argtypes = [C.c_int, _u8p, C.c_int, _u8p, C.POINTER(KswParams), C.c_int, _i32p, _u32p, C.c_int]
+        L.oracle_reg2aln.restype = C.c_int
+        L.oracle_reg2aln.argtypes = [C.POINTER(KswParams), C.c_int, C.c_int64, _u8p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                     C.c_int, C.c_int, C.POINTER(C.c_int64), _i32p, _i32p, _u32p, C.c_int, _i32p, C.c_char_p, C.c_int, _i32p]
+
+    def global2(self, query, target, w, params: "KswParams | None" = None, cap: int = 1024):
+        """oracle_ksw_global2 -> (score, cigar ops uint32[len<<4|op])"""
+        p = params or default_params()
+        q = np.ascontiguousarray(query, dtype=np.uint8); t = np.ascontiguousarray(target, dtype=np.uint8)
+        n = np.zeros(1, np.int32); cg = np.zeros(cap, np.uint32)
+        sc = self.lib.oracle_ksw_global2(len(q), _ptr(q, _u8p), len(t), _ptr(t, _u8p), C.byref(p), int(w), _ptr(n, _i32p), _ptr(cg, _u32p), cap)
+        return int(sc), cg[: int(n[0])].copy()
+
+    def reg2aln(self, pac, l_pac, read, qb, qe, rb, re, truesc, reg_w=300, opt_w=300, params: "KswParams | None" = None, cap: int = 512):
+        """oracle_reg2aln -> dict(pos, is_rev, cigar, NM, MD, score)"""
+        p = params or default_params()
+        rd = np.ascontiguousarray(read, dtype=np.uint8)
+        pos = C.c_int64(); isr = np.zeros(1, np.int32); n = np.zeros(1, np.int32); nm = np.zeros(1, np.int32); sc = np.zeros(1, np.int32)
+        cg = np.zeros(cap, np.uint32); md = C.create_string_buffer(1024)
+        self.lib.oracle_reg2aln(C.byref(p), opt_w, l_pac, _ptr(pac, _u8p), len(rd), _ptr(rd, _u8p), int(qb), int(qe), int(rb), int(re), int(truesc),
+                                int(reg_w), C.byref(pos), _ptr(isr, _i32p), _ptr(n, _i32p), _ptr(cg, _u32p), cap, _ptr(nm, _i32p), md, 1024, _ptr(sc, _i32p))
+        return dict(pos=int(pos.value), is_rev=int(isr[0]), cigar=cg[: int(n[0])].copy(), NM=int(nm[0]), MD=md.value.decode(), score=int(sc[0]))
 
     def fmd(self, idx) -> FmdT:
         """idx: bwamem_hip.fmindex.FMDIndex (arrays are kept alive on the returned struct)."""
@@ -153,6 +176,19 @@ class Ref:
         L.ref_smems_free.argtypes = [C.c_void_p]
         L.ref_locate.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, _u64p]
         L.ref_extend_batch.argtypes = [C.c_uint32, _u8p, _u32p, _u32p, _u8p, _u32p, _u32p, _u32p] + [C.c_int] * 9 + [_i32p, _i32p]
+        if hasattr(L, "ref_global2"):
+            L.ref_global2.restype = C.c_int
+            L.ref_global2.argtypes = [C.c_int, _u8p, C.c_int, _u8p] + [C.c_int] * 7 + [_i32p, _u32p, C.c_int]
+
+    def global2(self, query, target, w, params: "KswParams | None" = None, cap: int = 1024):
+        """the reference's ksw_global2 -> (score, cigar ops)"""
+        p = params or default_params()
+        q = np.ascontiguousarray(query, dtype=np.uint8); t = np.ascontiguousarray(target, dtype=np.uint8)
+        sc = np.zeros(1, np.int32); cg = np.zeros(cap, np.uint32)
+        assert p.n_penalty == 1
+        n = self.lib.ref_global2(len(q), _ptr(q, _u8p), len(t), _ptr(t, _u8p), p.a, p.b, p.o_del, p.e_del, p.o_ins, p.e_ins, int(w),
+                                 _ptr(sc, _i32p), _ptr(cg, _u32p), cap)
+        return int(sc[0]), cg[:n].copy()
 
     def bwt_from_index(self, idx):
         """Vanilla-layout bwt_t built from the BWT symbols of a GPU-layout FMDIndex."""

@@ -123,3 +123,21 @@ void ref_extend_batch(uint32_t n, const uint8_t *q, const uint32_t *qoff, const 
 		else { o[0] = gscore; o[1] = (int32_t)qlen[x]; o[2] = gtle; }
 	}
 }
+
+/* reference ksw_global2 (src/ksw.c:1120): score + CIGAR; returns the number of ops (copies at most cap) */
+int ref_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int a, int bmis, int o_del, int e_del, int o_ins, int e_ins,
+                int w, int *score, uint32_t *cigar, int cap)
+{
+	int8_t mat[25];
+	int i, j, k, n_cigar = 0;
+	uint32_t *cg = 0;
+	for (i = k = 0; i < 4; ++i) {
+		for (j = 0; j < 4; ++j) mat[k++] = i == j ? a : -bmis;
+		mat[k++] = -1;
+	}
+	for (j = 0; j < 5; ++j) mat[k++] = -1;
+	*score = ksw_global2(qlen, query, tlen, target, 5, mat, o_del, e_del, o_ins, e_ins, w, &n_cigar, &cg);
+	for (i = 0; i < n_cigar && i < cap; ++i) cigar[i] = cg[i];
+	free(cg);
+	return n_cigar;
+}

@@ -28,14 +28,21 @@ while p < raw.size:
     digs.append(hashlib.sha1(bytes([h0 & 255, h0 >> 8]) + raw[p:p + ql].tobytes() + b"|" + raw[p + ql:p + ql + tl].tobytes()).digest()); p += int(ql) + int(tl)
 digs.sort()
 as_tag = np.full(n_reads, -1, np.int32)
+sam_flag = np.zeros(n_reads, np.int32); sam_pos = np.zeros(n_reads, np.int64); sam_nm = np.full(n_reads, -1, np.int32)
+sam_cigar = [""] * n_reads; sam_md = [""] * n_reads
 for line in open(sam):
     if line[0] == "@": continue
     c = line.rstrip("\n").split("\t")
     if int(c[1]) & 0x900: continue
+    r = int(c[0][1:])
+    sam_flag[r] = int(c[1]); sam_pos[r] = int(c[3]); sam_cigar[r] = c[5]
     for tag in c[11:]:
-        if tag.startswith("AS:i:"): as_tag[int(c[0][1:])] = int(tag[5:])
+        if tag.startswith("AS:i:"): as_tag[r] = int(tag[5:])
+        if tag.startswith("NM:i:"): sam_nm[r] = int(tag[5:])
+        if tag.startswith("MD:Z:"): sam_md[r] = tag[5:]
 seeds = B.seed_file(prefix, fq, 19)
 np.savez_compressed(os.path.join(ROOT, "gpurun_out", "jobs_golden.npz"), n_genome=n_genome, genome_seed=42, reads=reads,
                     job_digests=np.frombuffer(b"".join(digs), dtype=np.uint8).reshape(-1, 20), as_tag=as_tag,
+                    sam_flag=sam_flag, sam_pos=sam_pos, sam_nm=sam_nm, sam_cigar=np.array(sam_cigar), sam_md=np.array(sam_md),
                     **{k: seeds[k] for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")})
 print("wrote jobs_golden.npz:", len(digs), "jobs")

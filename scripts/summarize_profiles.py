@@ -1,9 +1,11 @@
 """Condense rocprofv3 output directories into the small summaries committed under profiles/.
-usage: summarize_profiles.py <tag> <stats_dir> <pmc_fetch_dir> <pmc_write_dir>"""
+usage: summarize_profiles.py <tag> <stats_dir> <pmc_fetch_dir> <pmc_write_dir> [<pmc_sq_dir>]"""
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OURS = ("pack_reads", "smem_", "cand_", "per_read_counts", "expand_kernel", "locate_kernel", "extend16", "extend_wide", "ext_", "calib_gather")
+OURS = ("pack_reads", "smem_", "cand_", "per_read_counts", "expand_kernel", "locate_kernel", "extend16", "extend_wide", "ext_", "calib_gather",
+        "chain_", "emit_kernel", "materialize_kernel", "merge_kernel")
 tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
+sq_dir = sys.argv[5] if len(sys.argv) > 5 else None
 
 def find(d, suffix):
     r = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
@@ -26,5 +28,16 @@ def pmc(d, counter):
     return {k: {"launches": v[0], "avg_per_launch_KB": round(v[1] / v[0], 1)} for k, v in acc.items()}
 
 out = {"FETCH_SIZE": pmc(fetch_dir, "FETCH_SIZE"), "WRITE_SIZE": pmc(write_dir, "WRITE_SIZE")}
+if sq_dir:
+    # raw SQ counters per launch (sums over the XCDs / SEs as rocprofv3 reports them); SQ_*_CYCLES and SQ_ACTIVE_INST_* count
+    # quad-cycles (MI355X_MICROARCH.md), GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    sq = {}
+    for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE"):
+        try:
+            for k, v in pmc(sq_dir, c).items():
+                sq.setdefault(k, {"launches": v["launches"]})[c] = v["avg_per_launch_KB"]
+        except Exception as e:
+            print("no", c, e)
+    json.dump(sq, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch_write.json"), "w"), indent=1)
 print("kernels:", len(keep) - 1, "pmc kernels:", len(out["FETCH_SIZE"]))

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "bmh_extend_batch", "bmh_extend_last_ms", "bmh_calib_gather",
     "bmh_chain_opt_default", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
     "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_materialize", "bmh_chain_batch",
-    "bmh_chain_extend", "bmh_chain_merge",
+    "bmh_chain_extend", "bmh_chain_merge", "bmh_cigar_batch",
     "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
     "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
 ]
@@ -136,6 +136,9 @@ def load_library() -> C.CDLL:
     L.bmh_chain_extend.argtypes = [C.c_void_p, C.POINTER(ExtParams), C.c_void_p, C.c_void_p, C.c_void_p]
     L.bmh_chain_merge.restype = C.c_int
     L.bmh_chain_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bmh_cigar_batch.restype = C.c_int
+    L.bmh_cigar_batch.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.POINTER(ExtParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_void_p]
     L.bwt_restore_bwt_gpu.restype = C.POINTER(BwtTGpu)
     L.bwt_restore_bwt_gpu.argtypes = [C.c_char_p]
     L.bwt_restore_sa_gpu.argtypes = [C.c_char_p, C.POINTER(BwtTGpu)]
@@ -268,6 +271,24 @@ class ChainWorkspace:
         if self.handle:
             load_library().bmh_chain_ws_free(self.handle)
             self.handle = None
+
+
+def cigar_batch(index: Index, reads_t, offs_t, lens_t, regs_t, n: int, sel_t=None, params: "ExtParams | None" = None, opt_w: int = 300,
+                max_cigar: int = 32, md_cap: int = 128, stream: int = 0):
+    """bmh_cigar_batch on torch CUDA tensors; returns (cigar uint32 [n, max_cigar], aln int32 [n, 8], md uint8 [n, md_cap]) tensors."""
+    import torch
+    L = load_library()
+    p = params or ExtParams.default()
+    dev = regs_t.device
+    cigar = torch.zeros(max(n, 1), max_cigar, dtype=torch.int32, device=dev)
+    aln = torch.zeros(max(n, 1), 8, dtype=torch.int32, device=dev)
+    md = torch.zeros(max(n, 1), md_cap, dtype=torch.uint8, device=dev)
+    rc = L.bmh_cigar_batch(index.handle, reads_t.data_ptr(), offs_t.data_ptr(), lens_t.data_ptr(), regs_t.data_ptr(),
+                           sel_t.data_ptr() if sel_t is not None else None, n, C.byref(p), opt_w, max_cigar, cigar.data_ptr(), aln.data_ptr(),
+                           md_cap, md.data_ptr(), stream)
+    if rc != 0:
+        raise RuntimeError(f"bmh_cigar_batch rc={rc}: " + _err(L))
+    return cigar, aln, md
 
 
 def dev_jobs_to_host(j: DevJobsT, n_reads: int) -> dict:

@@ -1,0 +1,360 @@
+// Region -> CIGAR / NM / MD on the device: the step right after the hot path.
+//   ksw_global2      /root/reference/src/ksw.c:1120-1241   banded global alignment, 6-bit direction matrix, traceback
+//   bwa_gen_cigar2   src/bwa.c:111-216                     band width, reverse-strand flip, NM and MD
+//   mem_reg2aln      src/bwamem.c:2344-2440 (+ infer_bw :1486-1494)   retry with doubled band, squeeze, soft clips, position
+// One wave per region.  Rows of the DP matrix are computed by the 64 lanes at once (C columns per lane): gaps open
+// from the diagonal value M, so F along a row is a max-plus prefix scan exactly as in the extension kernels; cells
+// outside the band carry the reference's MINUS_INF arithmetic so that every in-band cell holds the reference's value.
+// The direction matrix (one byte per in-band cell) lives in LDS when it fits, else in a per-wave slab in HBM; the
+// traceback, the run-length CIGAR, NM and the MD string are produced by the wave in lock step (one lane writes).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <stdio.h>
+#include <stdlib.h>
+#include "bmh_internal.h"
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
+
+#define G_NEG (-0x40000000)          // MINUS_INF of ksw.c:997
+#define G_SENT (-0x60000000)         // below every value the reference arithmetic can produce; only ever max()ed and shifted a little
+
+__device__ __forceinline__ int g_wave_scan_max(int v)
+{
+	int t;
+	t = __builtin_amdgcn_update_dpp(G_SENT, v, 0x111, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(G_SENT, v, 0x112, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(G_SENT, v, 0x114, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(G_SENT, v, 0x118, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(G_SENT, v, 0x142, 0xa, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(G_SENT, v, 0x143, 0xc, 0xf, false); v = max(v, t);
+	return v;
+}
+__device__ __forceinline__ int g_wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+
+struct cigar_args_t {
+	const uint8_t *reads; const uint32_t *offs, *lens;
+	const uint8_t *pac; long long l_pac;
+	const int32_t *regs;            // [n][8] = {read, truesc, qb, qe, rb_lo, rb_hi, re_lo, re_hi}
+	const uint32_t *sel; uint32_t n; // optional list of region indices; n = number of jobs
+	int a, b, o_del, e_del, o_ins, e_ins, opt_w;
+	int max_cigar, md_cap;
+	uint32_t *cigar; int32_t *aln; char *md;
+	uint32_t z_lds_bytes;           // direction-matrix bytes available in LDS per wave
+	uint8_t *z_slab; unsigned long long z_slab_stride;   // per-wave fallback in HBM
+	uint32_t max_len;               // LDS room for query / target bases (each)
+};
+
+__device__ __forceinline__ int g_code(uint8_t ch) { ch &= 0xDF; return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4; }
+__device__ __forceinline__ int g_text(const cigar_args_t &A, long long p)
+{
+	const bool rev = p >= A.l_pac;
+	const long long f = rev ? (A.l_pac << 1) - 1 - p : p;
+	const int c = (A.pac[f >> 2] >> ((~f & 3) << 1)) & 3;
+	return rev ? 3 - c : c;
+}
+__device__ __forceinline__ int g_sc(const cigar_args_t &A, int t, int q) { return (t > 3 || q > 3) ? -1 : (t == q ? A.a : -A.b); }
+
+__device__ __forceinline__ int g_infer_bw(int l1, int l2, int score, int a, int q, int r)
+{
+	const int d = l1 > l2 ? l1 - l2 : l2 - l1;
+	if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+	const int w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+	return w < d ? d : w;
+}
+
+// banded global DP of the wave's job: fills z, returns the score.  qs/ts = bases in LDS.
+template <int C>
+__device__ int g_fill(const cigar_args_t &A, const uint8_t *qs, const uint8_t *ts, int qlen, int rlen, int w, uint8_t *z, int n_col, int lane)
+{
+	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;
+	int Hc[C], E[C], qv[C];
+#pragma unroll
+	for (int c = 0; c < C; ++c) {
+		const int j = lane * C + c;
+		qv[c] = j < qlen ? (int)qs[j] : 4;
+		Hc[c] = (j + 1 <= w) ? -(A.o_ins + A.e_ins * (j + 1)) : G_NEG;      // H(-1, j)
+		E[c] = G_NEG;
+	}
+	for (int i = 0; i < rlen; ++i) {
+		const int ti = (int)ts[i];
+		const int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		const int fill0 = i == 0 ? 0 : (i - 1 > w ? G_NEG : -(A.o_del + A.e_del * i));           // H(i-1, -1)
+		const int left = g_wave_shr1(Hc[C - 1], fill0);
+		int M[C], g[C];
+		int agg = G_SENT;
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const int j = lane * C + c;
+			const bool act = j >= beg && j < end;
+			const int hd = c == 0 ? left : Hc[c - 1];
+			const int m = hd + g_sc(A, ti, qv[c]);
+			M[c] = m;
+			g[c] = act ? m - oe_ins + A.e_ins * j : G_SENT;
+			agg = max(agg, g[c]);
+		}
+		const int incl = g_wave_scan_max(agg);
+		int run = max(g_wave_shr1(incl, G_SENT), G_NEG + A.e_ins * (beg - 1));      // the seed f(beg) = MINUS_INF in the same form
+		uint8_t *zr = z + (size_t)i * n_col - beg;
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const int j = lane * C + c;
+			const bool act = j >= beg && j < end;
+			const int f = run - A.e_ins * (j - 1);
+			run = max(run, g[c]);
+			const int m = M[c], e = E[c];
+			int d = m >= e ? 0 : 1;
+			int h = max(m, e);
+			d = h >= f ? d : 2;
+			h = max(h, f);
+			int t = m - oe_del, e2 = e - A.e_del;
+			d |= e2 > t ? 1 << 2 : 0;
+			e2 = max(e2, t);
+			t = m - oe_ins;
+			d |= (f - A.e_ins) > t ? 2 << 4 : 0;
+			if (act) { E[c] = e2; zr[j] = (uint8_t)d; }
+			Hc[c] = h;
+		}
+	}
+	const int jl = qlen - 1;
+	int src = 0;
+#pragma unroll
+	for (int c = 0; c < C; ++c) if (jl % C == c) src = Hc[c];
+	return __builtin_amdgcn_readlane(src, jl / C);
+}
+
+struct md_out_t { char *p; int len, cap; };
+__device__ __forceinline__ void md_putc(md_out_t &m, char c, int lane) { if (m.len + 1 < m.cap && lane == 0) m.p[m.len] = c; ++m.len; }
+__device__ __forceinline__ void md_putw(md_out_t &m, int v, int lane)
+{
+	char buf[12]; int n = 0;
+	do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+	while (n) md_putc(m, buf[--n], lane);
+}
+
+template <int C, int CLO>       // handles jobs with CLO < ceil(qlen / 64) <= C
+__global__ void __launch_bounds__(64) cigar_kernel(cigar_args_t A)
+{
+	extern __shared__ __align__(16) uint8_t g_lds[];
+	const int lane = threadIdx.x;
+	uint8_t *qs = g_lds, *ts = g_lds + A.max_len;
+	uint32_t *rev = (uint32_t *)(g_lds + 2 * (size_t)A.max_len);
+	uint8_t *z_l = g_lds + 2 * (size_t)A.max_len + 4 * (size_t)A.max_cigar;
+	uint8_t *z_g = A.z_slab + (size_t)blockIdx.x * A.z_slab_stride;
+	for (uint32_t job = blockIdx.x; job < A.n; job += gridDim.x) {
+		const uint32_t id = A.sel ? A.sel[job] : job;
+		const int32_t *R = A.regs + 8 * (size_t)id;
+		const uint32_t read = (uint32_t)R[0];
+		const int truesc = R[1], qb = R[2], qe = R[3];
+		const long long rb = (long long)(uint32_t)R[4] | (long long)R[5] << 32, re = (long long)(uint32_t)R[6] | (long long)R[7] << 32;
+		const int qlen = qe - qb, l_query = (int)A.lens[read];
+		const int need = (qlen + 63) >> 6;
+		if (need <= CLO || need > C) { if (!(CLO == 0 && need <= 0)) continue; }
+		int32_t *out = A.aln + 8 * (size_t)job;
+		uint32_t *cg = A.cigar + (size_t)job * A.max_cigar;
+		md_out_t md; md.p = A.md ? A.md + (size_t)job * A.md_cap : nullptr; md.len = 0; md.cap = A.md ? A.md_cap : 0;
+		const long long rlen_ll = re - rb;
+		// rejected by bwa_gen_cigar2 (empty, or bridging the strands) -- or beyond this build's limits
+		if (qlen <= 0 || rb >= re || (rb < A.l_pac && re > A.l_pac) || rlen_ll > (long long)A.max_len || qlen > (int)A.max_len) {
+			if (lane == 0) { out[0] = out[1] = 0; out[2] = 0; out[3] = 0; out[4] = -1; out[5] = 0; out[6] = 0; out[7] = (qlen > (int)A.max_len || rlen_ll > (long long)A.max_len) ? 4 : 2; if (md.p) md.p[0] = 0; }
+			continue;
+		}
+		const int rlen = (int)rlen_ll;
+		const bool flip = rb >= A.l_pac;          // reverse strand: align the reversed sequences so that gaps go leftmost
+		{
+			const uint8_t *rp = A.reads + A.offs[read] + qb;
+			for (int k = lane; k < qlen; k += 64) qs[k] = (uint8_t)g_code(rp[flip ? qlen - 1 - k : k]);
+			for (int k = lane; k < rlen; k += 64) ts[k] = (uint8_t)g_text(A, flip ? re - 1 - k : rb + k);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0);
+		int w2 = g_infer_bw(qlen, rlen, truesc, A.a, A.o_ins, A.e_ins);
+		{ const int tmp = g_infer_bw(qlen, rlen, truesc, A.a, A.o_del, A.e_del); w2 = w2 > tmp ? w2 : tmp; }
+		if (w2 > A.opt_w) w2 = w2 < A.opt_w ? w2 : A.opt_w;          // ar->w == opt->w in the GPU pipeline (src/bwamem.c:1280)
+		int score = 0, last_sc = -(1 << 30), n_ops = 0, flags = 0, it = 0;
+		bool lds_z = true;
+		do {
+			if (w2 > A.opt_w << 2) w2 = A.opt_w << 2;
+			n_ops = 0;
+			if (qlen == rlen && w2 == 0) {                          // no gap possible: one M run
+				int s = 0;
+				for (int k = lane; k < qlen; k += 64) s += g_sc(A, ts[k], qs[k]);
+				for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+				score = s;
+				if (lane == 0) rev[0] = (uint32_t)qlen << 4;
+				n_ops = 1;
+			} else {
+				int max_ins = (int)((double)(((qlen + 1) >> 1) * A.a - A.o_ins) / A.e_ins + 1.);
+				int max_del = (int)((double)(((qlen + 1) >> 1) * A.a - A.o_del) / A.e_del + 1.);
+				int max_gap = max_ins > max_del ? max_ins : max_del;
+				max_gap = max_gap > 1 ? max_gap : 1;
+				const int diff = rlen > qlen ? rlen - qlen : qlen - rlen;
+				int w = (max_gap + diff + 1) >> 1;
+				w = w < w2 ? w : w2;
+				w = w > diff + 3 ? w : diff + 3;
+				const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+				lds_z = (size_t)n_col * rlen <= A.z_lds_bytes;
+				uint8_t *z = lds_z ? z_l : z_g;
+				if (!lds_z && (unsigned long long)n_col * rlen > A.z_slab_stride) { flags |= 4; break; }
+				score = g_fill<C>(A, qs, ts, qlen, rlen, w, z, n_col, lane);
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0);
+				// traceback (ksw.c:1213-1235): state 0 = H (bits 0-1), 1 = E (bits 2-3), 2 = F (bits 4-5); ops come out reversed
+				int i = rlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, state = 0, cur_op = -1, cur_len = 0;
+#define G_PUSH(op_, len_) do { if ((op_) == cur_op) cur_len += (len_); else { if (cur_op >= 0) { if (n_ops < A.max_cigar - 2) { if (lane == 0) rev[n_ops] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; } else flags |= 1; ++n_ops; } cur_op = (op_); cur_len = (len_); } } while (0)
+				while (i >= 0 && k >= 0) {
+					const int beg = i > w ? i - w : 0;
+					state = (int)z[(size_t)i * n_col + (k - beg)] >> (state << 1) & 3;
+					const int op = state == 0 ? 0 : state == 1 ? 2 : 1;
+					G_PUSH(op, 1);
+					i -= state != 2; k -= state != 1;
+				}
+				if (i >= 0) G_PUSH(2, i + 1);
+				if (k >= 0) G_PUSH(1, k + 1);
+				G_PUSH(-2, 0);                                      // flush
+#undef G_PUSH
+			}
+			if (score == last_sc || w2 == A.opt_w << 2) break;
+			last_sc = score;
+			w2 <<= 1;
+		} while (++it < 3 && score < truesc - A.a);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0);
+		if (n_ops > A.max_cigar - 2) n_ops = A.max_cigar - 2;
+		// NM and MD along the CIGAR in forward order (op k = rev[n_ops-1-k]); bwa.c:171-204
+		int n_mm = 0, n_gap = 0, x = 0, y = 0, u = 0;
+		const bool fwd = rb < A.l_pac;
+		for (int k = 0; k < n_ops; ++k) {
+			const uint32_t c = rev[n_ops - 1 - k];
+			const int op = (int)(c & 0xf), len = (int)(c >> 4);
+			if (op == 0) {
+				for (int b = 0; b < len; b += 64) {
+					const int i = b + lane;
+					const bool mis = i < len && qs[x + i] != ts[y + i];
+					unsigned long long mm = __ballot(mis);
+					int prev = b;
+					while (mm) {
+						const int bit = __builtin_ctzll(mm); mm &= mm - 1;
+						const int pos = b + bit;
+						u += pos - prev; prev = pos + 1;
+						const int tb = (int)ts[y + pos];
+						md_putw(md, u, lane);
+						md_putc(md, fwd ? "ACGTN"[tb] : "TGCAN"[tb], lane);
+						++n_mm; u = 0;
+					}
+					const int lim = b + 64 < len ? b + 64 : len;
+					u += lim - prev;
+				}
+				x += len; y += len;
+			} else if (op == 2) {
+				if (k > 0 && k < n_ops - 1) {
+					md_putw(md, u, lane); md_putc(md, '^', lane);
+					for (int i = 0; i < len; ++i) { const int tb = (int)ts[y + i]; md_putc(md, fwd ? "ACGTN"[tb] : "TGCAN"[tb], lane); }
+					u = 0; n_gap += len;
+				}
+				y += len;
+			} else { x += len; n_gap += len; }
+		}
+		md_putw(md, u, lane);
+		if (md.p && lane == 0) md.p[md.len < md.cap ? md.len : md.cap - 1] = 0;
+		if (md.len + 1 > md.cap && md.cap) flags |= 8;
+		// mem_reg2aln tail: position, squeeze of a leading / trailing deletion, soft clips
+		const long long xx = rb < A.l_pac ? rb : re - 1;
+		const int is_rev = xx >= A.l_pac;
+		long long pos = is_rev ? (A.l_pac << 1) - 1 - xx : xx;
+		int first = 0, last = n_ops;                              // forward-order op range kept
+		if (n_ops > 0) {
+			const uint32_t c0 = rev[n_ops - 1], c1 = rev[0];
+			if ((c0 & 0xf) == 2) { pos += c0 >> 4; first = 1; }
+			else if ((c1 & 0xf) == 2) last = n_ops - 1;
+		}
+		int n_out = 0;
+		const int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
+		if (clip5) { if (lane == 0) cg[n_out] = (uint32_t)clip5 << 4 | 3; ++n_out; }
+		for (int k = first + lane; k < last; k += 64) cg[n_out + (k - first)] = rev[n_ops - 1 - k];
+		n_out += last - first;
+		if (clip3) { if (lane == 0) cg[n_out] = (uint32_t)clip3 << 4 | 3; ++n_out; }
+		if (lane == 0) {
+			out[0] = (int32_t)(uint32_t)pos; out[1] = (int32_t)(pos >> 32); out[2] = is_rev; out[3] = n_out;
+			out[4] = n_mm + n_gap; out[5] = score; out[6] = md.len; out[7] = flags;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0);
+	}
+}
+
+// largest direction matrix (the whole rectangle bounds every retry) and longest sequence of the batch
+__global__ void __launch_bounds__(256) cigar_size_kernel(const int32_t *regs, const uint32_t *sel, uint32_t n, unsigned long long *out)
+{
+	const uint32_t job = blockIdx.x * 256u + threadIdx.x;
+	unsigned long long zb = 0, ml = 0;
+	if (job < n) {
+		const int32_t *R = regs + 8 * (size_t)(sel ? sel[job] : job);
+		const long long rb = (long long)(uint32_t)R[4] | (long long)R[5] << 32, re = (long long)(uint32_t)R[6] | (long long)R[7] << 32;
+		const long long ql = (long long)R[3] - R[2], rl = re - rb;
+		if (ql > 0 && rl > 0 && ql < (1 << 20) && rl < (1 << 20)) { zb = (unsigned long long)(ql * rl); ml = (unsigned long long)(ql > rl ? ql : rl); }
+	}
+	for (int o = 32; o; o >>= 1) { zb = max(zb, (unsigned long long)__shfl_xor((long long)zb, o)); ml = max(ml, (unsigned long long)__shfl_xor((long long)ml, o)); }
+	if ((threadIdx.x & 63) == 0) { atomicMax(out, zb); atomicMax(out + 1, ml); }
+}
+
+struct cigar_scratch_t { unsigned long long *d_sizes; uint8_t *slab; size_t slab_bytes; };
+static thread_local cigar_scratch_t g_cs = {nullptr, nullptr, 0};
+
+template <int C, int CLO>
+static int launch_cigar(const cigar_args_t &a, unsigned grid, size_t lds, hipStream_t st)
+{
+	HIPCK(hipFuncSetAttribute((const void *)cigar_kernel<C, CLO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	cigar_kernel<C, CLO><<<grid, 64, lds, st>>>(a);
+	return BMH_OK;
+}
+
+extern "C" int bmh_cigar_batch(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, const uint32_t *d_lens,
+                               const int32_t *d_regs, const uint32_t *d_sel, uint32_t n, const bmh_ext_params_t *p, int opt_w,
+                               int max_cigar, uint32_t *d_cigar, int32_t *d_aln, int md_cap, char *d_md, void *stream_)
+{
+	if (!idx || !p || (n && (!d_reads || !d_offs || !d_lens || !d_regs || !d_cigar || !d_aln))) { bmh_set_error("bmh_cigar_batch: null argument"); return BMH_EINVAL; }
+	if (!idx->dev.pac || idx->dev.l_pac == 0) { bmh_set_error("bmh_cigar_batch: the index was uploaded without the 2-bit reference (pac)"); return BMH_EINVAL; }
+	if (max_cigar < 4 || (d_md && md_cap < 2) || p->e_del < 1 || p->e_ins < 1 || opt_w < 1) { bmh_set_error("bmh_cigar_batch: bad argument"); return BMH_EINVAL; }
+	if (n == 0) return BMH_OK;
+	hipStream_t st = (hipStream_t)stream_;
+	if (!g_cs.d_sizes) HIPCK(hipMalloc((void **)&g_cs.d_sizes, 16));
+	HIPCK(hipMemsetAsync(g_cs.d_sizes, 0, 16, st));
+	cigar_size_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_regs, d_sel, n, g_cs.d_sizes);
+	unsigned long long h[2];
+	HIPCK(hipMemcpyAsync(h, g_cs.d_sizes, 16, hipMemcpyDeviceToHost, st));
+	HIPCK(hipStreamSynchronize(st));
+	const uint32_t max_len = (uint32_t)((h[1] + 15) & ~15ull);
+	if (max_len > 704) { bmh_set_error("bmh_cigar_batch: a region spans %llu bases (limit 704)", h[1]); return BMH_ECAPACITY; }
+	cigar_args_t a;
+	a.reads = d_reads; a.offs = d_offs; a.lens = d_lens; a.pac = idx->dev.pac; a.l_pac = (long long)idx->dev.l_pac;
+	a.regs = d_regs; a.sel = d_sel; a.n = n;
+	a.a = p->a; a.b = p->b; a.o_del = p->o_del; a.e_del = p->e_del; a.o_ins = p->o_ins; a.e_ins = p->e_ins; a.opt_w = opt_w;
+	a.max_cigar = max_cigar; a.md_cap = d_md ? md_cap : 0; a.cigar = d_cigar; a.aln = d_aln; a.md = d_md;
+	a.max_len = max_len;
+	// LDS per wave: bases + reversed ops + the direction matrix of a first try (band ~ qlen/2); larger matrices go to HBM
+	size_t z_lds = (size_t)h[0] * 6 / 10 + 256;
+	const size_t fixed = 2 * (size_t)max_len + 4 * (size_t)max_cigar;
+	if (z_lds + fixed > 40 * 1024) z_lds = 40 * 1024 > fixed ? 40 * 1024 - fixed : 0;
+	z_lds &= ~(size_t)15;
+	a.z_lds_bytes = (uint32_t)z_lds;
+	const size_t lds = fixed + z_lds;
+	unsigned grid = 256u * (unsigned)(lds ? (160 * 1024) / lds : 16);
+	if (grid > 256u * 16) grid = 256u * 16;
+	if (grid > n) grid = n;
+	a.z_slab_stride = (h[0] + 255) & ~255ull;
+	const size_t slab = (size_t)a.z_slab_stride * grid;
+	if (g_cs.slab_bytes < slab) {
+		if (g_cs.slab) (void)hipFree(g_cs.slab);
+		g_cs.slab = nullptr; g_cs.slab_bytes = 0;
+		if (hipMalloc((void **)&g_cs.slab, slab) != hipSuccess) { bmh_set_error("bmh_cigar_batch: hipMalloc of %zu bytes failed", slab); return BMH_ENOMEM; }
+		g_cs.slab_bytes = slab;
+	}
+	a.z_slab = g_cs.slab;
+	int rc = BMH_OK;
+	rc = launch_cigar<1, 0>(a, grid, lds, st);
+	if (rc == BMH_OK && max_len > 64) rc = launch_cigar<2, 1>(a, grid, lds, st);
+	if (rc == BMH_OK && max_len > 128) rc = launch_cigar<3, 2>(a, grid, lds, st);
+	if (rc == BMH_OK && max_len > 192) rc = launch_cigar<5, 3>(a, grid, lds, st);
+	if (rc == BMH_OK && max_len > 320) rc = launch_cigar<8, 5>(a, grid, lds, st);
+	if (rc == BMH_OK && max_len > 512) rc = launch_cigar<11, 8>(a, grid, lds, st);
+	if (rc != BMH_OK) return rc;
+	HIPCK(hipGetLastError());
+	return BMH_OK;
+}

@@ -1,4 +1,5 @@
 """GPU parity tests proper: HIP kernels (through the C ABI) vs the CPU oracle, bit-exact."""
+import os
 import numpy as np
 import pytest
 
@@ -374,3 +375,103 @@ def test_device_job_builder_matches_host_builder(hip, oracle):
     nj, nr, nh = _device_chain_case(hip, oracle, gr, idxr, readsr)
     assert nh > 20, nh
     _device_chain_case(hip, oracle, gr, idxr, readsr[:600], heavy=4, opt_over=dict(max_occ=20))
+
+
+def _cigar_case(B, oracle, g, idx, reads, scoring=None, max_regs=4000):
+    """bmh_cigar_batch on the regions of the device pipeline (every region, not only the best ones) vs the oracle's
+    mem_reg2aln restatement (pinned to the reference's SAM output and to its compiled ksw_global2)."""
+    import ctypes as C, torch
+    import oracle_py
+    from bwamem_hip import synth
+    from bwamem_hip.lib import ChainWorkspace, cigar_batch
+    n, L = reads.shape
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    pac = _pack_pac(g)
+    dindex = B.Index.upload(idx, pac=pac, l_pac=len(g))
+    ws = B.SeedWorkspace(n, n * L, max_cands=n * L, max_occ=1 << 22)
+    r = _to_dev(torch, synth.codes_to_ascii(flat))
+    o = (torch.arange(n, dtype=torch.int64) * L).to(torch.int32).cuda()
+    l = torch.full((n,), L, dtype=torch.int32).cuda()
+    s = ws.seed_batch(dindex, r, o, l, 19)
+    cw = ChainWorkspace(n, max(int(s.n_seeds), 1))
+    cw.set_materialize(False)
+    dj = cw.chain_batch(dindex, r, o, l, s)
+    nr = int(dj.n_regs)
+    out3 = torch.zeros(max(int(dj.n_jobs), 1), 3, dtype=torch.int32, device="cuda")
+    regs = torch.zeros(max(nr, 1), 8, dtype=torch.int32, device="cuda")
+    ep = B.ExtParams.default() if scoring is None else B.ExtParams(*scoring)
+    cw.extend(out3, params=ep)
+    cw.merge(out3, regs)
+    nr = min(nr, max_regs)
+    cigar, aln, md = cigar_batch(dindex, r, o, l, regs, nr, params=ep, max_cigar=48, md_cap=640)
+    torch.cuda.synchronize()
+    cigar = cigar.cpu().numpy().view(np.uint32); aln = aln.cpu().numpy(); md = md.cpu().numpy(); rg = regs.cpu().numpy()
+    kp = oracle_py.default_params() if scoring is None else oracle_py.KswParams(*scoring, 1)
+    n_gap = 0
+    for i in range(nr):
+        c = rg[i]
+        rb = int(np.uint32(c[4])) | (int(c[5]) << 32); re = int(np.uint32(c[6])) | (int(c[7]) << 32)
+        want = oracle.reg2aln(pac, len(g), reads[c[0]], c[2], c[3], rb, re, c[1], params=kp)
+        a = aln[i]
+        pos = int(np.uint32(a[0])) | (int(a[1]) << 32)
+        got_md = bytes(md[i][: a[6]]).decode()
+        assert a[7] == 0, (i, a)
+        assert (pos, int(a[2]), int(a[4]), int(a[5])) == (want["pos"], want["is_rev"], want["NM"], want["score"]), (i, a, want, c)
+        assert np.array_equal(cigar[i][: a[3]], want["cigar"]), (i, cigar[i][: a[3]], want["cigar"], c)
+        assert got_md == want["MD"], (i, got_md, want["MD"])
+        n_gap += int(((want["cigar"] & 0xf) == 1).any() or ((want["cigar"] & 0xf) == 2).any())
+    cw.free(); ws.free(); dindex.free()
+    return nr, n_gap
+
+
+def test_cigar_batch_matches_oracle(hip, oracle):
+    """Region -> CIGAR / NM / MD (bmh_cigar_batch) against the oracle's restatement of mem_reg2aln / bwa_gen_cigar2 /
+    ksw_global2: 150 bp with indels, 300 bp, a non-default scoring, both strands, clipped and full-length regions."""
+    from bwamem_hip import synth
+    g, idx = common.genome_and_index(1_500_000)
+    reads, _ = synth.make_reads(g, 1500, 150, seed=11, sub_rate=0.02, indel_frac=0.5)
+    nr, ngap = _cigar_case(hip, oracle, g, idx, reads)
+    assert nr > 1500 and ngap > 300
+    reads3, _ = synth.make_reads(g, 400, 300, seed=12, sub_rate=0.03, indel_frac=0.6)
+    _cigar_case(hip, oracle, g, idx, reads3)
+    _cigar_case(hip, oracle, g, idx, reads[:500], scoring=(2, 3, 5, 2, 4, 1, 0, 5))
+
+
+def test_cigar_batch_matches_reference_sam(hip, oracle):
+    """The same stage against the SAM records the REFERENCE's own host code wrote for the golden read set
+    (tests/golden/jobs_golden.npz: POS, CIGAR, NM, MD, strand of every primary alignment)."""
+    import torch
+    from bwamem_hip import synth
+    from bwamem_hip.lib import HostJobs, cigar_batch
+    z = np.load(os.path.join(common.GOLDEN, "jobs_golden.npz"))
+    g = synth.make_genome(int(z["n_genome"]), seed=int(z["genome_seed"]))
+    _, idx = common.genome_and_index(int(z["n_genome"]))
+    reads = z["reads"]; n, L = reads.shape
+    seeds = {k: z[k] for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")}
+    hj = HostJobs(g, reads.reshape(-1), np.arange(n, dtype=np.uint64) * L, np.full(n, L, np.uint32), seeds, n_threads=4)
+    out3, _, _ = oracle.extend_batch(*hj.jobs())
+    regs = hj.merge(out3)
+    sel = []
+    for r in range(n):                       # the primary alignment = the best region (duplicates of it are identical)
+        idxs = np.nonzero(regs[:, 0] == r)[0]
+        if len(idxs) == 0 or z["as_tag"][r] < 0:
+            continue
+        best = idxs[regs[idxs, 1] == regs[idxs, 1].max()]
+        if len(np.unique(regs[best][:, 2:], axis=0)) == 1:
+            sel.append(int(best[0]))
+    assert len(sel) > 0.95 * n
+    dindex = hip.Index.upload(idx, pac=_pack_pac(g), l_pac=len(g))
+    rt = _to_dev(torch, synth.codes_to_ascii(reads.reshape(-1)))
+    o = (torch.arange(n, dtype=torch.int64) * L).to(torch.int32).cuda()
+    l = torch.full((n,), L, dtype=torch.int32).cuda()
+    cigar, aln, md = cigar_batch(dindex, rt, o, l, torch.from_numpy(regs.copy()).cuda(), len(sel), sel_t=torch.tensor(sel, dtype=torch.int32).cuda(),
+                                 max_cigar=48, md_cap=640)
+    torch.cuda.synchronize()
+    cigar = cigar.cpu().numpy().view(np.uint32); aln = aln.cpu().numpy(); md = md.cpu().numpy()
+    for k, ri in enumerate(sel):
+        r = int(regs[ri, 0]); a = aln[k]
+        cs = "".join(f"{int(x) >> 4}{'MIDSH'[int(x) & 0xf]}" for x in cigar[k][: a[3]])
+        got = (int(np.uint32(a[0])) + 1, cs, int(a[4]), bytes(md[k][: a[6]]).decode(), int(a[2]))
+        want = (int(z["sam_pos"][r]), str(z["sam_cigar"][r]), int(z["sam_nm"][r]), str(z["sam_md"][r]), (int(z["sam_flag"][r]) >> 4) & 1)
+        assert got == want, (r, got, want)
+    hj.free(); dindex.free()

@@ -112,3 +112,66 @@ def test_ext_edge_cases(oracle, ref):
     o3, r6, _ = oracle.extend_batch(*jobs, want_raw=True)
     ro3, rr6 = ref.extend_batch(*jobs)
     assert np.array_equal(r6, rr6) and np.array_equal(o3, ro3)
+
+
+def test_global_alignment_restatement_matches_reference(oracle, ref):
+    """oracle_ksw_global2 (score and CIGAR, i.e. every direction bit the traceback visits) == the reference's compiled
+    ksw_global2 (src/ksw.c:1120) on seeded cases with substitutions, indels, N bases, two scorings, bands >= |tlen - qlen|
+    (the only bands bwa_gen_cigar2 produces: w >= |rlen - l_query| + 3, src/bwa.c:160-166)."""
+    import oracle_py
+    rng = np.random.default_rng(3)
+    for it in range(4000):
+        ql = int(rng.integers(1, 160))
+        t = rng.integers(0, 4, size=ql + int(rng.integers(0, 30))).astype(np.uint8)
+        q = t[:ql].copy()
+        for _ in range(int(rng.integers(0, 4))):
+            pos = int(rng.integers(0, len(q))); q[pos] = (q[pos] + rng.integers(1, 4)) & 3
+        if it % 3 == 0 and len(q) > 10:
+            pos = int(rng.integers(1, len(q) - 1)); k = int(rng.integers(1, 6))
+            q = np.concatenate([q[:pos], rng.integers(0, 4, size=k).astype(np.uint8), q[pos:]]) if it % 2 else np.concatenate([q[:pos], q[pos + k:]])
+        if it % 40 == 0 and len(q) > 0:
+            q[int(rng.integers(0, len(q)))] = 4
+        if it % 7 == 0:
+            t = t[: max(1, len(q) + int(rng.integers(-5, 6)))]
+        if len(q) == 0:
+            continue
+        d = abs(len(t) - len(q))
+        w = d + int(rng.integers(0, 60)) if it % 5 else d + 3
+        p = oracle_py.default_params() if it % 4 else oracle_py.KswParams(2, 3, 5, 2, 4, 1, 0, 5, 1)
+        a = oracle.global2(q, t, w, p); b = ref.global2(q, t, w, p)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]), (it, len(q), len(t), w)
+
+
+def test_reg2aln_restatement_matches_reference_sam(oracle):
+    """oracle_reg2aln (mem_reg2aln + bwa_gen_cigar2 restated) reproduces POS, CIGAR, NM, MD and strand of every primary
+    SAM record the reference's own host code wrote for the golden read set (scripts/make_jobs_golden.py)."""
+    from bwamem_hip import synth
+    from bwamem_hip.lib import HostJobs
+    z = np.load(os.path.join(common.GOLDEN, "jobs_golden.npz"))
+    g = synth.make_genome(int(z["n_genome"]), seed=int(z["genome_seed"]))
+    reads = z["reads"]; n, L = reads.shape
+    seeds = {k: z[k] for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")}
+    hj = HostJobs(g, reads.reshape(-1), np.arange(n, dtype=np.uint64) * L, np.full(n, L, np.uint32), seeds, n_threads=4)
+    out3, _, _ = oracle.extend_batch(*hj.jobs())
+    regs = hj.merge(out3)
+    pad = (-len(g)) % 4
+    codes = np.concatenate([g, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    pac = np.ascontiguousarray(((codes[:, 0] << 6) | (codes[:, 1] << 4) | (codes[:, 2] << 2) | codes[:, 3]).astype(np.uint8))
+    checked = n_indel = 0
+    for r in range(n):
+        rr = regs[regs[:, 0] == r]
+        if len(rr) == 0 or z["as_tag"][r] < 0:
+            continue
+        cand = np.unique(rr[rr[:, 1] == rr[:, 1].max()][:, 1:], axis=0)      # the primary = the best region
+        if len(cand) != 1:
+            continue
+        c = cand[0]
+        rb = int(np.uint32(c[3])) | (int(c[4]) << 32); re = int(np.uint32(c[5])) | (int(c[6]) << 32)
+        a = oracle.reg2aln(pac, len(g), reads[r], c[1], c[2], rb, re, c[0])
+        cs = "".join(f"{int(x) >> 4}{'MIDSH'[int(x) & 0xf]}" for x in a["cigar"])
+        got = (a["pos"] + 1, cs, a["NM"], a["MD"], a["is_rev"])
+        want = (int(z["sam_pos"][r]), str(z["sam_cigar"][r]), int(z["sam_nm"][r]), str(z["sam_md"][r]), (int(z["sam_flag"][r]) >> 4) & 1)
+        assert got == want, (r, got, want)
+        checked += 1; n_indel += ("I" in cs) or ("D" in cs)
+    hj.free()
+    assert checked > 0.95 * n and n_indel > 50

@@ -45,11 +45,12 @@ __device__ __forceinline__ blk_t fmd_load_block(const fmd_dev_t &f, uint64_t b)
 	return r;
 }
 
-// per-symbol match bits (in the 0x55555555 lanes) of the first nsym symbols
-__device__ __forceinline__ uint32_t prefix_mask(int nsym)   // nsym in 0..16
+// per-symbol match bits (in the 0x55555555 lanes) of the first nsym symbols; any nsym (<= 0: none, >= 16: all)
+__device__ __forceinline__ uint32_t prefix_mask(int nsym)
 {
-	// low bit of symbol t sits at bit 30-2t
-	return nsym <= 0 ? 0u : (0x55555555u & (0xFFFFFFFFu << (32 - 2 * (nsym > 16 ? 16 : nsym))));
+	// low bit of symbol t sits at bit 30-2t; one 64-bit shift instead of a compare-and-select
+	const int n = min(max(nsym, 0), 16);
+	return (uint32_t)(0xFFFFFFFF00000000ull >> (2 * n)) & 0x55555555u;
 }
 
 // counts of A,C,G,T among symbols [0..off] (inclusive) of the block, plus the block's occ
@@ -110,22 +111,29 @@ __device__ __forceinline__ void fmd_occ4(const fmd_dev_t &f, uint64_t k, uint64_
 	for (int c = 0; c < 4; ++c) cnt[c] = c4[c];
 }
 
-// Occ(k,c) and Occ(l,c), k <= l, sharing the block when both fall in one
+// Occ(k,.) and Occ(l,.) for k <= l, l a valid row, k possibly (uint64_t)-1 (all counts 0).  Written without
+// divergent paths: row seq_len needs no special case (after the primary adjustment it is the last BWT symbol, whose
+// inclusive count is the total), row -1 becomes "nothing of block 0" (whose occ is 0), and the second block is only
+// fetched when it differs from the first -- the arithmetic is the same two block counts for every lane.
+__device__ __forceinline__ void fmd_pair_blocks(const fmd_dev_t &f, uint64_t k, uint64_t l, blk_t &A, blk_t &B, int &koff, int &loff)
+{
+	const bool km1 = k == (uint64_t)-1;
+	const uint64_t k2 = km1 ? 0 : k - (k >= f.primary), l2 = l - (l >= f.primary);
+	koff = km1 ? -1 : (int)(k2 & 63); loff = (int)(l2 & 63);
+	const uint64_t kb = k2 >> 6, lb = l2 >> 6;
+	A = fmd_load_block(f, kb);
+	B = A;
+	if (lb != kb) B = fmd_load_block(f, lb);
+}
 __device__ __forceinline__ void fmd_occ4_pair(const fmd_dev_t &f, uint64_t k, uint64_t l, uint64_t ck[4], uint64_t cl[4])
 {
-	bool sk = (k == f.seq_len) | (k == (uint64_t)-1), sl = (l == f.seq_len) | (l == (uint64_t)-1);
-	uint64_t k2 = k - (k >= f.primary), l2 = l - (l >= f.primary);
-	if (!sk && !sl && (k2 >> 6) == (l2 >> 6)) {
-		blk_t b = fmd_load_block(f, k2 >> 6);
-		uint32_t a4[4], b4[4];
-		blk_occ4(b, (int)(k2 & 63), a4);
-		blk_occ4(b, (int)(l2 & 63), b4);
+	blk_t A, B; int koff, loff;
+	fmd_pair_blocks(f, k, l, A, B, koff, loff);
+	uint32_t a4[4], b4[4];
+	blk_occ4(A, koff, a4);
+	blk_occ4(B, loff, b4);
 #pragma unroll
-		for (int c = 0; c < 4; ++c) { ck[c] = a4[c]; cl[c] = b4[c]; }
-	} else {
-		fmd_occ4(f, k, ck);
-		fmd_occ4(f, l, cl);
-	}
+	for (int c = 0; c < 4; ++c) { ck[c] = a4[c]; cl[c] = b4[c]; }
 }
 
 __device__ __forceinline__ uint64_t fmd_occ1(const fmd_dev_t &f, uint64_t k, int c)
@@ -139,16 +147,10 @@ __device__ __forceinline__ uint64_t fmd_occ1(const fmd_dev_t &f, uint64_t k, int
 
 __device__ __forceinline__ void fmd_occ1_pair(const fmd_dev_t &f, uint64_t k, uint64_t l, int c, uint64_t &ok, uint64_t &ol)
 {
-	bool sk = (k == f.seq_len) | (k == (uint64_t)-1), sl = (l == f.seq_len) | (l == (uint64_t)-1);
-	uint64_t k2 = k - (k >= f.primary), l2 = l - (l >= f.primary);
-	if (!sk && !sl && (k2 >> 6) == (l2 >> 6)) {
-		blk_t b = fmd_load_block(f, k2 >> 6);
-		ok = blk_occ1(b, (int)(k2 & 63), c);
-		ol = blk_occ1(b, (int)(l2 & 63), c);
-	} else {
-		ok = fmd_occ1(f, k, c);
-		ol = fmd_occ1(f, l, c);
-	}
+	blk_t A, B; int koff, loff;
+	fmd_pair_blocks(f, k, l, A, B, koff, loff);
+	ok = blk_occ1(A, koff, c);
+	ol = blk_occ1(B, loff, c);
 }
 
 // LF step, CPU form (src/bwt.c:64-70)

@@ -245,7 +245,8 @@ __global__ void __launch_bounds__(256) cand_scatter_kernel(const cand_t *__restr
 // drop it -- it stops now and is marked dropped.  Lanes of a pass split across two waves simply
 // miss this shortcut (the filter still drops them).
 __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_view_t rv, uint64_t n_cands, int min_seed_len,
-                                                            res_t *__restrict__ res_a, uint64_t *__restrict__ res_k)
+                                                            res_t *__restrict__ res_a, uint64_t *__restrict__ res_k,
+                                                            unsigned long long *__restrict__ stats)
 {
 	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int lane = __lane_id();
@@ -263,16 +264,27 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 	const int seg_end = lane + __builtin_ctzll(segb >> lane);      // >= lane, bit 63 is always set
 	const unsigned long long above = seg_end > lane ? ((~0ull >> (63 - (seg_end - lane - 1))) << 1 << lane) : 0ull;  // lanes lane+1..seg_end
 	uint32_t size = c.s;
+	unsigned st_iter = 0, st_steps = 0;
+	// the read's packed words are re-fetched only when the walk crosses into the next one (16 / 32 bases)
+	uint32_t rw = 0, rm = 0;
+	if (act) { rw = rv.pk[(size_t)(i >> 4) * rv.n_reads + c.read]; rm = rv.nm[(size_t)(i >> 5) * rv.n_reads + c.read]; }
 	while (__any(act)) {
+		if (stats) { ++st_iter; st_steps += act ? 1u : 0u; }
 		if (act) {
-			int b = read_base(rv, c.read, i);
-			if (b > 3) act = false;
-			else {
-				uint64_t ol, ou;
-				fmd_occ1_pair(f, lo - 1, hi, b, ol, ou);
-				uint64_t nl = fmd_L2(f, b) + ol + 1, nu = fmd_L2(f, b) + ou;
-				if (nl > nu) act = false;
-				else { lo = nl; hi = nu; beg = i; --i; size = (uint32_t)(hi - lo + 1); act = i >= 0; }
+			const int b = (int)((rw >> ((i & 15) << 1)) & 3);
+			const bool isn = (rm >> (i & 31)) & 1;
+			uint64_t ol, ou;
+			fmd_occ1_pair(f, lo - 1, hi, b, ol, ou);
+			const uint64_t L2b = fmd_L2(f, b);
+			const uint64_t nl = L2b + ol + 1, nu = L2b + ou;
+			const bool ok = !isn && nl <= nu;
+			lo = ok ? nl : lo; hi = ok ? nu : hi; beg = ok ? i : beg;
+			size = ok ? (uint32_t)(nu - nl + 1) : size;
+			i -= ok ? 1 : 0;
+			act = ok && i >= 0;
+			if (act && (i & 15) == 15) {
+				rw = rv.pk[(size_t)(i >> 4) * rv.n_reads + c.read];
+				if ((i & 31) == 31) rm = rv.nm[(size_t)(i >> 5) * rv.n_reads + c.read];
 			}
 		}
 		// nearest longer candidate of my pass that is still searching, after this step
@@ -280,6 +292,10 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 		const int nxt = am ? __builtin_ctzll(am) : lane;
 		const uint32_t nsize = __shfl(size, nxt);
 		if (act && am && nsize == size) { act = false; dropped = true; }
+	}
+	if (stats) {
+		atomicAdd(stats + 1, (unsigned long long)st_steps);
+		if (lane == 0) { atomicAdd(stats, (unsigned long long)st_iter); atomicAdd(stats + 2, 1ull); atomicMax(stats + 3, (unsigned long long)st_iter); }
 	}
 	if (live) {
 		res_t o;
@@ -823,8 +839,19 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 	if (n_list > w->max_cands) { bmh_set_error("bmh_seed_batch: %llu candidate slots > capacity %llu", n_list, (unsigned long long)w->max_cands); return BMH_ECAPACITY; }
 	if (n_list)
 		cand_scatter_kernel<<<nblk(n_list, 256), 256, 0, st>>>(w->cand_a, w->cand_k, n_list, w->cand_base, (cand_t *)w->res_a, w->res_k);
-	if (n_cands)
-		smem_backward_kernel<<<nblk(n_cands, 256), 256, 0, st>>>(f, rv, n_cands, min_seed_len, w->res_a, w->res_k);
+	{
+		static const bool want_stats = getenv("BMH_SEED_STATS") != nullptr;
+		unsigned long long *d_st = want_stats ? (unsigned long long *)w->counter + 8 : nullptr;
+		if (want_stats) HIPCK(hipMemsetAsync(d_st, 0, 32, st));
+		if (n_cands) smem_backward_kernel<<<nblk(n_cands, 256), 256, 0, st>>>(f, rv, n_cands, min_seed_len, w->res_a, w->res_k, d_st);
+		if (want_stats) {
+			unsigned long long h[4];
+			HIPCK(hipStreamSynchronize(st));
+			HIPCK(hipMemcpy(h, d_st, 32, hipMemcpyDeviceToHost));
+			fprintf(stderr, "[backward] candidates %llu, waves %llu, wave-iterations %llu (%.1f per wave, max %llu), lane-steps %llu (%.1f per candidate): lane utilisation %.1f%%\n",
+			        (unsigned long long)n_cands, h[2], h[0], (double)h[0] / (h[2] ? h[2] : 1), h[3], h[1], (double)h[1] / (n_cands ? n_cands : 1), 100.0 * h[1] / (64.0 * (h[0] ? h[0] : 1)));
+		}
+	}
 	HIPCK(hipEventRecord(w->ev[3], st));
 	smem_filter_kernel<<<nblk(n_cands + 1, 256), 256, 0, st>>>(w->res_a, n_cands, w->occ, w->keep);
 	{

@@ -45,3 +45,21 @@ for it in range(3):
     print("extend %.3f ms  merge %.3f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
 r = regs.cpu().numpy()
 print("regs checksum", int(r.astype(np.int64).sum()), "best score mean", float(np.maximum.reduceat(r[:, 1], np.unique(r[:, 0], return_index=True)[1]).mean()))
+# CIGAR stage on the batch's regions: all of them, and one (the first) per read
+from bwamem_hip.lib import cigar_batch
+nr = int(dj.n_regs)
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    cg, aln, md = cigar_batch(dindex, dr.ascii, dr.offs, dr.lens, regs, nr, max_cigar=16, md_cap=64)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    print("cigar_batch all %d regions: %.3f ms" % (nr, (t1 - t0) * 1e3), flush=True)
+a = aln.cpu().numpy()
+print("flags", np.bincount(a[:, 7], minlength=9)[:9], "mean n_cigar", a[:, 3].mean(), "mean NM", a[:, 4].mean())
+rd = regs[:, 0].cpu().numpy()
+first = np.unique(rd, return_index=True)[1].astype(np.int32)
+sel = torch.from_numpy(first).to(dev)
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    cg, aln, md = cigar_batch(dindex, dr.ascii, dr.offs, dr.lens, regs, len(first), sel_t=sel, max_cigar=16, md_cap=64)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    print("cigar_batch first region of %d reads: %.3f ms" % (len(first), (t1 - t0) * 1e3), flush=True)

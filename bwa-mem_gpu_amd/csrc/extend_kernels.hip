@@ -38,6 +38,7 @@
 #include "bmh_internal.h"
 
 #define NEG_INF (-(1 << 29))
+#define EXT_T_CAP 1024        // target bases of an alignment staged in LDS by extend16_kernel
 
 // inclusive max-scan over the 64 lanes (Kogge-Stone inside 16-lane rows on DPP
 // row_shr, then row_bcast:15 / row_bcast:31 across rows); lane 63 ends with the total
@@ -70,6 +71,7 @@ struct ext_args_t {
 	const uint32_t *jq_src, *job_side; const long long *jt0;
 	const uint32_t *ids;          // alignment ids of this class
 	const uint32_t *count;        // how many
+	uint32_t *ctr;                // next unassigned job of this class (extend16_kernel draws from it)
 	int32_t *out, *raw;
 	int a, b, o_del, e_del, o_ins, e_ins, zdrop, end_bonus;
 	unsigned long long *stats;    // debug (BMH_EXT_STATS): [0] rows executed, [1] sum of tlen, [2] alignments, [3] wave-rows
@@ -300,8 +302,13 @@ __device__ __forceinline__ int row_scan_max_f(int v)     // inclusive; lanes wit
 	return v;
 }
 
+// Two forms of the 16-lane-row kernel.  extend16_static_kernel: a wave takes four consecutive jobs of the sorted list
+// and runs them side by side to the end of the longest -- one set of loads per four jobs, which suits the short
+// alignments of the small classes (few rows per job, the fetch latency of a job is a large part of it).
+// extend16_kernel: every row draws its next job from a counter as soon as its alignment ends -- no waiting for the
+// slowest of four (3.0 -> 3.8 live alignments per wave-row), which pays once a job is long enough to hide the draw.
 template <int C>
-__global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
+__global__ void __launch_bounds__(256) extend16_static_kernel(ext_args_t A)
 {
 	const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -448,6 +455,193 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 			if (A.stats) { atomicAdd(A.stats, (unsigned long long)rows_done); atomicAdd(A.stats + 1, (unsigned long long)tlen); atomicAdd(A.stats + 2, 1ull); if (grp == 0) atomicAdd(A.stats + 3, (unsigned long long)wave_rows); }
 		}
 	}
+}
+
+
+template <int C>
+__global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
+{
+	const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+	const uint32_t n = A.count[0];
+	const uint32_t *ids = A.ids + A.count[1];
+	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;
+	const int j0 = l16 * C;                                    // first column of this lane
+	const int ej0 = A.e_ins * j0;
+	const int bp_base = (lane & 48) << 2;                      // byte address of this row's lane 0 for ds_bpermute
+	// Each 16-lane row works on its own alignment and row index; a row whose alignment has ended takes the next job
+	// of the class from a global counter (longest first), so the four rows of a wave never wait for the slowest.
+	// the target of a row's alignment is staged in LDS when the row takes the job (EXT_T_CAP bases; longer targets
+	// read the rest straight from memory), so the row loop itself has no global loads to wait for
+	__shared__ uint8_t t_lds[16][EXT_T_CAP];
+	uint8_t *tl = t_lds[threadIdx.x >> 4];
+	bool have = false, alive = false;
+	uint32_t id = 0;
+	int qlen = 0, tlen = 0, h0 = 1, i = 0;
+	int hfc = 0, dn = 0;          // first-column value H(i-1,-1) of the current row; o_del + e_del*(i+1)
+	const uint8_t *tp = tl;
+	job_src_t src = ext_job_src(A, 0, false, 0, 0);
+	int H[C], E[C], qb[C], mm[C];
+#pragma unroll
+	for (int c = 0; c < C; ++c) { H[c] = E[c] = 0; qb[c] = 4; mm[c] = -1; }
+	int jl_lane = bp_base, jl_c = 0;
+	int beg = 0, end = 0, mx = 0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+	int rows_done = 0, wave_rows = 0;
+	bool more = true;                                          // the class still has unassigned jobs (wave-uniform)
+	for (;;) {
+		// one bit per row that has something to do here (results to write and / or a job to draw), at lanes 0/16/32/48
+		const unsigned long long nb = __ballot(!alive && l16 == 0 && (more || have));
+		if (nb) {
+			if (!alive && have && l16 == 0) {                   // results of the alignment that just ended
+				const int qle = max_j + 1, tle = max_i + 1, gtle = max_ie + 1;
+				int32_t *o = A.out + 3 * (size_t)id;
+				if (gscore <= 0 || gscore <= mx - A.end_bonus) { o[0] = mx; o[1] = qle; o[2] = tle; }
+				else { o[0] = gscore; o[1] = qlen; o[2] = gtle; }
+				if (A.raw) {
+					int32_t *r = A.raw + 6 * (size_t)id;
+					r[0] = mx; r[1] = qle; r[2] = tle; r[3] = gtle; r[4] = gscore; r[5] = max_off;
+				}
+				if (A.stats) { atomicAdd(A.stats, (unsigned long long)rows_done); atomicAdd(A.stats + 1, (unsigned long long)tlen); atomicAdd(A.stats + 2, 1ull); }
+			}
+			uint32_t base = n;
+			if (more) {
+				const uint32_t cnt = (uint32_t)__builtin_popcountll(nb);
+				uint32_t b0 = 0;
+				if (lane == (int)__builtin_ctzll(nb)) b0 = atomicAdd(A.ctr, cnt);
+				base = __builtin_amdgcn_readlane(b0, (int)__builtin_ctzll(nb));
+				more = base + cnt < n;
+			}
+			if (!alive) {
+				const uint32_t k = base + (uint32_t)__builtin_popcountll(nb & ((1ull << (lane & 48)) - 1));
+				have = k < n;
+				id = have ? ids[n - 1 - k] : 0;
+				qlen = have ? (int)A.qlen[id] : 0; tlen = have ? (int)A.tlen[id] : 0; h0 = have ? (int)A.h0[id] : 1;
+				src = ext_job_src(A, id, have, qlen, tlen);
+				// column state; query N is code 4, target N is made 5 below so that N never "matches" (mat[4][4] = -1, bwa.c:99-108)
+#pragma unroll
+				for (int c = 0; c < C; ++c) {
+					const int j = j0 + c;
+					qb[c] = j < qlen ? ext_q_at(A, src, j) : 4;
+					mm[c] = qb[c] > 3 ? -1 : -A.b;               // mismatch score of this column
+					const int v = h0 - oe_ins - j * A.e_ins;
+					H[c] = (j < qlen && v > 0) ? v : 0;
+					E[c] = 0;
+				}
+				const int jl = qlen - 1;
+				jl_lane = bp_base + (((jl < 0 ? 0 : jl) / C) << 2); jl_c = (jl < 0 ? 0 : jl) % C;
+				beg = 0; end = qlen; mx = h0; max_i = -1; max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
+				i = 0; rows_done = 0; hfc = h0; dn = oe_del; tp = tl;
+				for (int k = l16; k < tlen && k < EXT_T_CAP; k += 16) { const int tb = ext_t_at(A, src, k); tl[k] = (uint8_t)(tb > 3 ? 5 : tb); }
+				alive = have && tlen > 0;
+			}
+		}
+		if (!__any(alive)) {
+			if (!more) break;
+			continue;                                           // every row drew a zero-row job: draw again
+		}
+		++wave_rows;
+		const int ti = (int)*tp;                                // targets longer than EXT_T_CAP never reach this kernel (ext_key_kernel)
+		const bool run = alive;
+		rows_done += run ? 1 : 0;
+		const int hnx = max(0, h0 - dn);                        // first-column value of the next row: max(0, h0 - (o_del + e_del*(i+1)))
+		const int left = row_shr1(H[C - 1], beg == 0 ? hfc : 0);
+		const unsigned wdt = (unsigned)(end - beg);
+		const int jb0 = j0 - beg;
+		const bool tN = ti > 3;
+		int M[C], g[C];
+		bool act[C];
+		int agg = NEG_INF;
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			act[c] = run && (unsigned)(jb0 + c) < wdt;
+			const int hd = c == 0 ? left : H[c - 1];
+			const int sc = ti == qb[c] ? A.a : (tN ? -1 : mm[c]);
+			const int m = (act[c] && hd != 0) ? hd + sc : 0;
+			M[c] = m;
+			g[c] = act[c] ? max(m - oe_ins, 0) + (ej0 + A.e_ins * c) : NEG_INF;
+			agg = max(agg, g[c]);
+		}
+		int runmax = row_shr1(row_scan_max_f(agg), NEG_INF);
+		int key = 0;                                        // (h << 16) | column: row maximum, last column on ties
+		int fl = (int)0x80008000;                           // packed {hi: -(first non-zero H column), lo: last non-zero H column}
+		int efirst = 0;                                     // E of this lane's first non-zero H column
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const int j = j0 + c;
+			const int f = max(0, runmax - (ej0 + A.e_ins * (c - 1)));
+			runmax = max(runmax, g[c]);
+			const int h = act[c] ? max(max(M[c], E[c]), f) : 0;
+			const int e = act[c] ? max(max(E[c] - A.e_del, M[c] - oe_del), 0) : 0;
+			H[c] = h; E[c] = e;
+			key = max(key, act[c] ? ((h << 16) | j) : 0);
+			// E(i+1,j) != 0 implies H(i,j) != 0 (H >= E(i,j) and H >= M), so the non-zero span of eh[] follows
+			// from the non-zero H columns alone: last index = last column + 1, first = first column (+1 if its E is 0)
+			const int pk = ((-j) << 16) | j;
+			const bool nzh = h != 0;
+			efirst = (nzh && fl == (int)0x80008000) ? e : efirst;
+			fl = nzh ? pk_max(fl, pk) : fl;
+		}
+		key = row_allmax_f(key);
+		const int m = key >> 16, mj = key & 0xFFFF;
+		// gscore: H(i, qlen-1) when the row reaches the query end (ksw.c:942-945)
+		{
+			int hs = H[0];
+#pragma unroll
+			for (int c = 1; c < C; ++c) hs = jl_c == c ? H[c] : hs;
+			int h1 = __builtin_amdgcn_ds_bpermute(jl_lane, hs);
+			h1 = qlen == 0 ? (beg == 0 ? hnx : 0) : h1;
+			const bool ge = run && end == qlen;
+			max_ie = (ge && !(gscore > h1)) ? i : max_ie;
+			gscore = ge ? max(gscore, h1) : gscore;
+		}
+		const bool upd = run && m != 0;
+		alive = alive && !(run && m == 0);                  // ksw.c:946
+		const bool better = upd && m > mx;
+		max_off = better ? max(max_off, abs(mj - i)) : max_off;
+		max_i = better ? i : max_i;
+		max_j = better ? mj : max_j;
+		if (A.zdrop > 0) {                                  // wave-uniform branch (ksw.c:951-959)
+			const int di = i - max_i, dj = mj - max_j;
+			const int pen = di > dj ? (di - dj) * A.e_del : (dj - di) * A.e_ins;
+			alive = alive && !(upd && !better && mx - m - pen > A.zdrop);
+		}
+		mx = better ? m : mx;
+		// next row's [beg,end) (ksw.c:963-970): first / last non-zero of eh[beg..end]
+		{
+			// this lane's candidate for the first index: its first non-zero H column, +1 if E there is 0
+			const int myfirst = -(fl >> 16) + (efirst == 0 ? 1 : 0);
+			const int packed = fl == (int)0x80008000 ? fl : ((((-myfirst) << 16)) | ((fl & 0xFFFF) + 1));
+			const int red = row_allmax_pk(packed);
+			const int h1i = beg == 0 ? hnx : 0;
+			const bool none = (red >> 16) == (int)(short)0x8000;
+			int fidx = none ? (1 << 20) : -(red >> 16);
+			int lidx = none ? -1 : (int)(short)(red & 0xFFFF);
+			fidx = h1i ? min(fidx, beg) : fidx;
+			lidx = h1i ? max(lidx, beg) : lidx;
+			const int nbeg = min(fidx, end);
+			const int nend = min(qlen, max(lidx, nbeg - 1) + 2);
+			beg = upd ? nbeg : beg;
+			end = upd ? nend : end;
+		}
+		// Exact early stop.  Phi(v at column c) = v + a*(qlen-1-c) never increases along a DP transition
+		// (diagonal: +s <= +a and one column right; E: same column minus a gap cost; F: right minus a gap
+		// cost), so every H of every later row is <= U = max Phi over this row's frontier {H(i,j), E(i+1,j),
+		// first-column value}.  Once U <= max and U < gscore no later row can change max/max_i/max_j/max_off
+		// (strict >, ksw.c:948) nor gscore/max_ie (>=, ksw.c:943): the remaining rows are dead work.
+		// (evaluated every fourth iteration of the wave for all its rows: the bound is exact at any row)
+		if ((wave_rows & 3) == 0) {
+			const int aq = A.a * (qlen - 1 - j0);
+			int u = 0;
+#pragma unroll
+			for (int c = 0; c < C; ++c) u = max(u, max(H[c], E[c]) + (aq - A.a * c));
+			const int h1n = beg == 0 ? hnx : 0;
+			u = max(u, h1n + A.a * qlen);
+			u = row_allmax_f(u);
+			alive = alive && !(u <= mx && u < gscore);
+		}
+		if (run) { ++i; ++tp; hfc = hnx; dn += A.e_del; }
+		alive = alive && i < tlen;
+	}
+	if (A.stats && lane == 0) atomicAdd(A.stats + 3, (unsigned long long)wave_rows);
 }
 
 
@@ -616,7 +810,8 @@ __global__ void __launch_bounds__(256) ext_key_kernel(const uint32_t *__restrict
 	__syncthreads();
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t < n) {
-		const int cls = done[t] ? EXT_DONE_CLS : ext_class(qlen[t]);
+		int cls = done[t] ? EXT_DONE_CLS : ext_class(qlen[t]);
+		if (cls >= 1 && cls <= EXT16_MAX_C && tlen[t] > EXT_T_CAP) cls = 19;     // very long target: wide kernel (streams it)
 		if (cls == 0) out[3 * (size_t)t] = out[3 * (size_t)t + 1] = out[3 * (size_t)t + 2] = INT32_MIN;
 		uint32_t tl = tlen[t];
 		keys[t] = ((uint32_t)cls << 20) | (tl > 0xFFFFFu ? 0xFFFFFu : tl);
@@ -676,12 +871,17 @@ extern "C" float bmh_extend_last_ms(void)
 // another stream to become resident beside them (BMH_EXT_LDS_KB; 0 = no cap).
 static unsigned g_ext_lds = [] { const char *e = getenv("BMH_EXT_LDS_KB"); return e ? (unsigned)atoi(e) * 1024u : 0u; }();
 
+// classes with at least this many columns per lane use the job-drawing form (BMH_EXT_REFILL_FROM; 19 = never)
+static int g_ext_refill_from = [] { const char *e = getenv("BMH_EXT_REFILL_FROM"); return e ? atoi(e) : 5; }();
+
 template <int C>
 static void launch16(const ext_args_t &base, hipStream_t st, unsigned grid)
 {
 	ext_args_t a = base;
 	a.count = base.count + 2 * C;
-	extend16_kernel<C><<<grid, 256, g_ext_lds, st>>>(a);
+	a.ctr = base.ctr + C;
+	if (C >= g_ext_refill_from) extend16_kernel<C><<<grid, 256, g_ext_lds, st>>>(a);
+	else extend16_static_kernel<C><<<grid, 256, g_ext_lds, st>>>(a);
 }
 template <int C>
 static void launch_wide(const ext_args_t &base, hipStream_t st, unsigned grid)
@@ -732,7 +932,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		g_scr.keys = g_scr.vals = g_scr.keys2 = g_scr.vals2 = g_scr.counts = nullptr; g_scr.tmp = nullptr; g_scr.done = nullptr; g_scr.cap = 0;
 		HIPCK(hipMalloc((void **)&g_scr.keys, 4 * (size_t)n)); HIPCK(hipMalloc((void **)&g_scr.vals, 4 * (size_t)n));
 		HIPCK(hipMalloc((void **)&g_scr.keys2, 4 * (size_t)n)); HIPCK(hipMalloc((void **)&g_scr.vals2, 4 * (size_t)n));
-		HIPCK(hipMalloc((void **)&g_scr.counts, 4 * 2 * EXT_N_CLS));
+		HIPCK(hipMalloc((void **)&g_scr.counts, 4 * 3 * EXT_N_CLS));
 		HIPCK(hipMalloc((void **)&g_scr.done, (size_t)n));
 		size_t tb = 0;
 		HIPCK(rocprim::radix_sort_pairs(nullptr, tb, g_scr.keys, g_scr.keys2, g_scr.vals, g_scr.vals2, (size_t)n, 0, 25, st));
@@ -753,7 +953,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	a.desc = desc ? 1 : 0;
 	a.reads = desc ? desc->reads : nullptr; a.pac = desc ? desc->pac : nullptr; a.l_pac = desc ? desc->l_pac : 0;
 	a.jq_src = desc ? desc->jq_src : nullptr; a.job_side = desc ? desc->job_side : nullptr; a.jt0 = desc ? (const long long *)desc->jt0 : nullptr;
-	a.ids = g_scr.vals2; a.count = g_scr.counts; a.out = d_out; a.raw = d_raw;
+	a.ids = g_scr.vals2; a.count = g_scr.counts; a.ctr = g_scr.counts + 2 * EXT_N_CLS; a.out = d_out; a.raw = d_raw;
 	a.a = p->a; a.b = p->b; a.o_del = p->o_del; a.e_del = p->e_del; a.o_ins = p->o_ins; a.e_ins = p->e_ins;
 	a.zdrop = p->zdrop; a.end_bonus = p->end_bonus;
 	a.stats = nullptr;
@@ -765,7 +965,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		a.stats = d_stats;
 	}
 	HIPCK(hipEventRecord(g_scr.ev0, st));
-	HIPCK(hipMemsetAsync(g_scr.counts, 0, 4 * 2 * EXT_N_CLS, st));
+	HIPCK(hipMemsetAsync(g_scr.counts, 0, 4 * 3 * EXT_N_CLS, st));
 	{
 		unsigned gp = (unsigned)((n + 15) / 16);
 		if (gp > 4096) gp = 4096;

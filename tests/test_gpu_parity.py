@@ -137,6 +137,24 @@ def test_extension_long_queries(hip, oracle):
     want3, want6, _ = oracle.extend_batch(*jobs, want_raw=True)
     got3, got6 = gpu_extend(hip, jobs)
     assert np.array_equal(got6, want6) and np.array_equal(got3, want3)
+    # short queries against very long targets (beyond the LDS staging of the 16-lane-row kernel)
+    rng = np.random.default_rng(23)
+    qs, ts, h0 = [], [], []
+    for it in range(200):
+        tl = int(rng.integers(1000, 1600)); ql = int(rng.integers(20, 280))
+        t = rng.integers(0, 4, size=tl).astype(np.uint8)
+        q = t[:ql].copy()
+        for _ in range(int(rng.integers(0, 6))):
+            p = int(rng.integers(0, ql)); q[p] = (q[p] + rng.integers(1, 4)) & 3
+        if it % 3 == 0:
+            k = int(rng.integers(1, 8)); p = int(rng.integers(5, ql - 5)); q = np.concatenate([q[:p], q[p + k:]])
+        qs.append(q); ts.append(t); h0.append(int(rng.integers(19, 120)))
+    qlen = np.array([len(x) for x in qs], np.uint32); tlen = np.array([len(x) for x in ts], np.uint32)
+    qoff = np.concatenate([[0], np.cumsum(qlen)[:-1]]).astype(np.uint32); toff = np.concatenate([[0], np.cumsum(tlen)[:-1]]).astype(np.uint32)
+    jobs = (np.concatenate(qs), qoff, qlen, np.concatenate(ts), toff, tlen, np.array(h0, np.uint32))
+    want3, want6, _ = oracle.extend_batch(*jobs, want_raw=True)
+    got3, got6 = gpu_extend(hip, jobs)
+    assert np.array_equal(got6, want6) and np.array_equal(got3, want3)
 
 
 def test_seed_gpu_file_api(hip, oracle, tmp_path):

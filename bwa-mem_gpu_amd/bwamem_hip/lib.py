@@ -23,6 +23,7 @@ EXPORTED_SYMBOLS = [
     "bmh_last_error", "bmh_device_count", "bmh_set_device", "bmh_index_upload", "bmh_index_from_device",
     "bmh_index_free", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
     "bmh_extend_batch", "bmh_extend_last_ms", "bmh_calib_gather",
+    "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs",
     "bmh_chain_opt_default", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
     "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_materialize", "bmh_chain_batch",
     "bmh_chain_extend", "bmh_chain_merge", "bmh_cigar_batch",
@@ -50,6 +51,12 @@ class ChainOpt(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "w", "min_seed_len", "max_occ",
                                        "max_chain_gap", "min_chain_weight", "max_chain_extend")] + \
                [("mask_level", C.c_float), ("drop_ratio", C.c_float)]
+
+
+class PostOpt(C.Structure):
+    """bmh_post_opt_t"""
+    _fields_ = [("T", C.c_int), ("mask_level_redun", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int),
+                ("flag_all", C.c_int), ("id0", C.c_int64)]
 
 
 class DevJobsT(C.Structure):
@@ -120,6 +127,12 @@ def load_library() -> C.CDLL:
     L.bmh_jobs_free.argtypes = [C.c_void_p]
     L.bmh_jobs_sizes.argtypes = [C.c_void_p, _u64p, _u64p, _u64p, _u64p]
     L.bmh_jobs_arrays.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 11
+    L.bmh_jobs_frac_rep.restype = C.POINTER(C.c_float)
+    L.bmh_jobs_frac_rep.argtypes = [C.c_void_p]
+    L.bmh_post_opt_default.argtypes = [C.POINTER(PostOpt)]
+    L.bmh_finalize_regs.restype = C.c_int64
+    L.bmh_finalize_regs.argtypes = [C.POINTER(ChainOpt), C.POINTER(ExtParams), C.POINTER(PostOpt), C.c_int64, _u8p, C.c_uint32, _u8p, _u64p,
+                                    _i32p, _u32p, C.POINTER(C.c_float), _i32p, _u32p, C.c_int]
     L.bmh_merge_regs.restype = C.c_int
     L.bmh_merge_regs.argtypes = [C.c_void_p, _i32p, _i32p]
     L.bmh_chain_ws_create.restype = C.c_void_p
@@ -389,6 +402,8 @@ class HostJobs:
         o = opt or ChainOpt()
         if opt is None:
             L.bmh_chain_opt_default(C.byref(o))
+        self.opt = o
+        self._genome = genome_fwd
         l_pac = int(genome_fwd.shape[0])
         pad = (-l_pac) % 4
         codes = np.concatenate([genome_fwd, np.zeros(pad, np.uint8)]).reshape(-1, 4)
@@ -428,6 +443,27 @@ class HostJobs:
         regs = np.zeros((max(self.n_regs, 1), 8), np.int32)
         self.L.bmh_merge_regs(self.h, _np_ptr(out3, _i32p), _np_ptr(regs, _i32p))
         return regs[: self.n_regs]
+
+    def frac_rep(self) -> np.ndarray:
+        n = len(self._keep[3])
+        return np.ctypeslib.as_array(self.L.bmh_jobs_frac_rep(self.h), shape=(max(n, 1),))[:n].copy()
+
+    def finalize(self, regs: np.ndarray, flag_all: bool = False, id0: int = 0, params: "ExtParams | None" = None, n_threads: int = 1):
+        """bmh_finalize_regs on the regions of merge(): -> (out int32 [m, 16], out_per_read uint32 [n_reads])"""
+        L = self.L
+        po = PostOpt(); L.bmh_post_opt_default(C.byref(po)); po.flag_all = 1 if flag_all else 0; po.id0 = id0
+        co = self.opt
+        ep = params or ExtParams.default()
+        k = self._keep
+        regs = np.ascontiguousarray(regs, dtype=np.int32)
+        out = np.zeros((max(len(regs), 1), 16), np.int32); opr = np.zeros(max(len(k[3]), 1), np.uint32)
+        fr = np.ascontiguousarray(self.frac_rep(), dtype=np.float32)
+        m = L.bmh_finalize_regs(C.byref(co), C.byref(ep), C.byref(po), len(self._genome), _np_ptr(k[0], _u8p), len(k[3]), _np_ptr(k[1], _u8p),
+                                _np_ptr(k[2], _u64p), _np_ptr(regs, _i32p), _np_ptr(np.ascontiguousarray(self.regs_per_read), _u32p),
+                                fr.ctypes.data_as(C.POINTER(C.c_float)), _np_ptr(out, _i32p), _np_ptr(opr, _u32p), n_threads)
+        if m < 0:
+            raise RuntimeError("bmh_finalize_regs: " + _err(L))
+        return out[:m], opr[: len(k[3])]
 
     def free(self):
         if self.h:

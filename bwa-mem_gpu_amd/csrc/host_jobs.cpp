@@ -19,6 +19,7 @@
 #include <thread>
 #include <vector>
 #include "bmh_internal.h"
+#include "klib_sort.h"
 
 namespace {
 
@@ -115,66 +116,6 @@ int chain_weight(const Chain &c)                                    // mem_chain
 	return w < 1 << 30 ? w : (1 << 30) - 1;
 }
 
-// The reference sorts chains with klib's introsort, which is not stable; chains of equal weight therefore
-// end in an order that depends on its exact steps.  This is the same procedure (median-of-three partition of
-// the whole range, sub-ranges of <= 16 left to a final insertion sort, comb sort when the depth budget runs
-// out; src/ksort.h:146-226) so that ties fall the same way.
-template <class T, class LT> void insertion_sort(T *s, T *t, LT lt)
-{
-	for (T *i = s + 1; i < t; ++i)
-		for (T *j = i; j > s && lt(*j, *(j - 1)); --j) std::swap(*j, *(j - 1));
-}
-template <class T, class LT> void comb_sort(size_t n, T *a, LT lt)
-{
-	const double shrink = 1.2473309501039786540366528676643;
-	bool swapped; size_t gap = n;
-	do {
-		if (gap > 2) { gap = (size_t)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
-		swapped = false;
-		for (T *i = a; i < a + n - gap; ++i) { T *j = i + gap; if (lt(*j, *i)) { std::swap(*i, *j); swapped = true; } }
-	} while (swapped || gap > 2);
-	if (gap != 1) insertion_sort(a, a + n, lt);
-}
-template <class T, class LT> void klib_introsort(size_t n, T *a, LT lt)
-{
-	if (n < 1) return;
-	if (n == 2) { if (lt(a[1], a[0])) std::swap(a[0], a[1]); return; }
-	int d;
-	for (d = 2; 1ul << d < n; ++d) ;
-	struct Fr { T *l, *r; int depth; };
-	std::vector<Fr> stack;
-	T *s = a, *t = a + (n - 1);
-	d <<= 1;
-	for (;;) {
-		if (s < t) {
-			if (--d == 0) { comb_sort((size_t)(t - s + 1), s, lt); t = s; continue; }
-			T *i = s, *j = t, *k = i + ((j - i) >> 1) + 1;
-			if (lt(*k, *i)) { if (lt(*k, *j)) k = j; }
-			else k = lt(*j, *i) ? i : j;
-			T rp = *k;
-			if (k != t) std::swap(*k, *t);
-			for (;;) {
-				do ++i; while (lt(*i, rp));
-				do --j; while (i <= j && lt(rp, *j));
-				if (j <= i) break;
-				std::swap(*i, *j);
-			}
-			std::swap(*i, *t);
-			if (i - s > t - i) {
-				if (i - s > 16) stack.push_back({s, i - 1, d});
-				s = t - i > 16 ? i + 1 : t;
-			} else {
-				if (t - i > 16) stack.push_back({i + 1, t, d});
-				t = i - s > 16 ? i - 1 : s;
-			}
-		} else {
-			if (stack.empty()) { insertion_sort(a, a + n, lt); return; }
-			Fr f = stack.back(); stack.pop_back();
-			s = f.l; t = f.r; d = f.depth;
-		}
-	}
-}
-
 inline int chn_beg(const Chain &c) { return c.seeds.front().qbeg; }
 inline int chn_end(const Chain &c) { return c.seeds.back().qbeg + c.seeds.back().len; }
 
@@ -191,7 +132,7 @@ void chain_flt(const bmh_chain_opt_t &o, std::vector<Chain> &a)     // mem_chain
 		a.resize(k);
 	}
 	if (a.empty()) return;
-	klib_introsort(a.size(), a.data(), [](const Chain &x, const Chain &y) { return x.w > y.w; });
+	klib::klib_introsort(a.size(), a.data(), [](const Chain &x, const Chain &y) { return x.w > y.w; });
 	const int n = (int)a.size();
 	std::vector<int> chains;
 	a[0].kept = 3;
@@ -233,6 +174,7 @@ struct Out {
 	std::vector<Reg> regs;
 	std::vector<uint32_t> reg_read;
 	std::vector<uint32_t> regs_per_read;
+	std::vector<float> frac_rep;        // per read: fraction of the read covered by over-represented SMEMs (mem_chain :415-459)
 };
 
 struct Ctx {
@@ -386,10 +328,12 @@ void worker(const Ctx &x, uint32_t r0, uint32_t r1, Out &O)
 {
 	std::vector<Chain> chains;
 	O.regs_per_read.assign(r1 - r0, 0);
+	O.frac_rep.assign(r1 - r0, 0.f);
 	for (uint32_t r = r0; r < r1; ++r) {
 		const int len = (int)x.rlens[r];
 		const uint8_t *query = x.reads + x.roffs[r];
 		make_chains(x, r, len, chains);
+		if (!chains.empty()) O.frac_rep[r - r0] = chains[0].frac_rep;
 		chain_flt(*x.o, chains);
 		const size_t reg0 = O.regs.size();
 		for (const Chain &c : chains) chain2aln(x, r, len, query, c, reg0, O);
@@ -453,6 +397,7 @@ extern "C" bmh_jobs_t *bmh_build_jobs(const bmh_chain_opt_t *opt, int64_t l_pac,
 		for (Reg a : P.regs) { if (a.job[0] >= 0) a.job[0] += jb; if (a.job[1] >= 0) a.job[1] += jb; O.regs.push_back(a); }
 		O.reg_read.insert(O.reg_read.end(), P.reg_read.begin(), P.reg_read.end());
 		O.regs_per_read.insert(O.regs_per_read.end(), P.regs_per_read.begin(), P.regs_per_read.end());
+		O.frac_rep.insert(O.frac_rep.end(), P.frac_rep.begin(), P.frac_rep.end());
 	}
 	return J;
 }
@@ -477,6 +422,8 @@ extern "C" void bmh_jobs_arrays(const bmh_jobs_t *j, const uint8_t **q, const ui
 	if (job_read) *job_read = O.job_read.data(); if (job_reg) *job_reg = O.job_reg.data(); if (job_side) *job_side = O.job_side.data();
 	if (regs_per_read) *regs_per_read = O.regs_per_read.data();
 }
+
+extern "C" const float *bmh_jobs_frac_rep(const bmh_jobs_t *j) { return j->o.frac_rep.data(); }
 
 // job results -> alignment regions (src/bwamem.c:2297-2303); out3 = {aln_score, query_end, target_end} per job.
 // regs_out[n_regs][8] = {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi}; rb/re split into two 32-bit halves.

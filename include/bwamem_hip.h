@@ -157,6 +157,35 @@ void bmh_jobs_arrays(const bmh_jobs_t *j, const uint8_t **q, const uint32_t **qo
  * {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi} */
 int bmh_merge_regs(const bmh_jobs_t *j, const int32_t *out3, int32_t *regs_out);
 
+/* per read: the frac_rep of its chains (mem_chain, src/bwamem.c:415-459), needed by the MAPQ estimate */
+const float *bmh_jobs_frac_rep(const bmh_jobs_t *j);
+
+/* ------------------------------------------------- after the extension: which regions are reported (SURVEY 8f rank 1 tail, rank 4) */
+
+/* the options of mem_opt_t this stage reads beyond bmh_chain_opt_t / bmh_ext_params_t; bmh_post_opt_default() = mem_opt_init() */
+typedef struct {
+	int T;                      /* minimum score of a reported alignment (30) */
+	float mask_level_redun;     /* 0.95 */
+	float mapQ_coef_len;        /* 50 */
+	int mapQ_coef_fac;          /* (int)log(50) = 3 */
+	int flag_all;               /* MEM_F_ALL (-a): report secondary alignments too */
+	int64_t id0;                /* index of the batch's first read in the run (n_processed): seeds the tie-break hash */
+} bmh_post_opt_t;
+void bmh_post_opt_default(bmh_post_opt_t *o);
+
+/* Per read: mem_sort_dedup_patch (redundant regions removed, colinear ones merged when a global alignment across both
+ * scores well enough), mem_mark_primary_se (primary / secondary, sub-optimal score), mem_approx_mapq_se and the
+ * selection of mem_reg2sam (src/bwamem.c:620-680, 685-760, 1690-1717, 1721-1770).  Host code, like the reference's.
+ * regs_in[..][8] = bmh_merge_regs / bmh_chain_merge layout, grouped by read (regs_per_read); frac_rep per read.
+ * out[..][16] = {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi, truesc, w, sub (XS), sub_n, secondary (index within
+ * the read's output, -1 = primary line), MAPQ, flag (0x100 secondary, 0x800 supplementary), reported (0/1)} in the
+ * reference's order, capacity = the number of input regions; out_per_read[n_reads].  Returns the number of output
+ * regions or a negative BMH_E* code.  Single-sequence references only (rid = 0). */
+int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, int64_t l_pac,
+                          const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                          const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
+                          int32_t *out, uint32_t *out_per_read, int n_threads);
+
 /* ------------------------------------------------- device job builder (SURVEY 8f ranks 1-2 on the GPU) */
 
 /* The same stage as bmh_build_jobs, on the device: seeds of bmh_seed_batch (still in HBM) -> chains -> filtered

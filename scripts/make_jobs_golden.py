@@ -9,9 +9,14 @@ sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))
 import numpy as np, torch
 import bwamem_hip as B
 from bwamem_hip import fmindex, synth
-work = "/tmp/jobs_golden"; os.makedirs(work, exist_ok=True)
+# usage: make_jobs_golden.py            -> jobs_golden.npz  (plain genome)
+#        make_jobs_golden.py repeats    -> post_golden.npz  (repeat-rich genome: secondary / supplementary alignments, XS, low MAPQ)
+REPEATS = len(sys.argv) > 1 and sys.argv[1] == "repeats"
+OUT = "post_golden.npz" if REPEATS else "jobs_golden.npz"
+work = "/tmp/jobs_golden" + ("_rep" if REPEATS else ""); os.makedirs(work, exist_ok=True)
 n_genome, n_reads, L = 300_000, 600, 150
-g = synth.make_genome(n_genome, seed=42)
+GENOME_KW = dict(repeat_frac=0.45, repeat_len=(150, 1500), repeat_copies=(3, 40), repeat_div=0.03) if REPEATS else {}
+g = synth.make_genome(n_genome, seed=42, **GENOME_KW)
 idx = fmindex.build_fmd_index(g, device="cuda:0")
 prefix = os.path.join(work, "g.fa"); fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g)
 reads, _ = synth.make_reads(g, n_reads, L, seed=21, sub_rate=0.02, indel_frac=0.2)
@@ -40,9 +45,29 @@ for line in open(sam):
         if tag.startswith("AS:i:"): as_tag[r] = int(tag[5:])
         if tag.startswith("NM:i:"): sam_nm[r] = int(tag[5:])
         if tag.startswith("MD:Z:"): sam_md[r] = tag[5:]
+# every SAM line of the default run and of a run with -a (all alignments, secondary ones included): the regions that survive
+# mem_sort_dedup_patch, their primary / secondary / supplementary status (mem_mark_primary_se) and MAPQ
+def sam_lines(path):
+    rows = []
+    for line in open(path):
+        if line[0] == "@": continue
+        c = line.rstrip("\n").split("\t")
+        tags = {t[:2]: t[5:] for t in c[11:]}
+        rows.append((int(c[0][1:]), int(c[1]), int(c[3]), int(c[4]), c[5], int(tags.get("NM", -1)), int(tags.get("AS", -1)), int(tags.get("XS", -1)), tags.get("MD", "")))
+    return rows
+sam_a = os.path.join(work, "o_all.sam")
+with open(sam_a, "w") as f:
+    subprocess.check_call([os.path.join(ROOT, "build", "dropin", "bwa-gasal2"), "gase_aln", "-a", "-t", "1", "-l", str(L), prefix, fq], stdout=f,
+                          stderr=subprocess.DEVNULL, cwd=work)
+def pack(rows):
+    return dict(read=np.array([r[0] for r in rows], np.int32), flag=np.array([r[1] for r in rows], np.int32), pos=np.array([r[2] for r in rows], np.int64),
+                mapq=np.array([r[3] for r in rows], np.int32), cigar=np.array([r[4] for r in rows]), nm=np.array([r[5] for r in rows], np.int32),
+                as_=np.array([r[6] for r in rows], np.int32), xs=np.array([r[7] for r in rows], np.int32), md=np.array([r[8] for r in rows]))
+lines_def = pack(sam_lines(sam)); lines_all = pack(sam_lines(sam_a))
 seeds = B.seed_file(prefix, fq, 19)
-np.savez_compressed(os.path.join(ROOT, "gpurun_out", "jobs_golden.npz"), n_genome=n_genome, genome_seed=42, reads=reads,
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", OUT), n_genome=n_genome, genome_seed=42, genome_kw=repr(GENOME_KW), reads=reads,
                     job_digests=np.frombuffer(b"".join(digs), dtype=np.uint8).reshape(-1, 20), as_tag=as_tag,
+                    **{"def_" + k: v for k, v in lines_def.items()}, **{"all_" + k: v for k, v in lines_all.items()},
                     sam_flag=sam_flag, sam_pos=sam_pos, sam_nm=sam_nm, sam_cigar=np.array(sam_cigar), sam_md=np.array(sam_md),
                     **{k: seeds[k] for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")})
-print("wrote jobs_golden.npz:", len(digs), "jobs")
+print("wrote", OUT, ":", len(digs), "jobs")

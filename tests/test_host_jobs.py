@@ -115,3 +115,52 @@ def test_device_chain_core_matches_reference_jobs_and_host_builder(oracle):
         for k in ("qoff", "qlen", "toff", "tlen", "h0", "job_read", "job_reg", "job_side", "regs_per_read", "q", "t"):
             assert np.array_equal(c[k], getattr(hj, k)), (over, k)
         hj.free()
+
+
+def _golden_regions(oracle, z):
+    """regions of the golden read set: host job builder on the stored seeds, oracle extension, host merge"""
+    import ast
+    g = synth.make_genome(int(z["n_genome"]), seed=int(z["genome_seed"]), **(ast.literal_eval(str(z["genome_kw"])) if "genome_kw" in z.files else {}))
+    reads = z["reads"]; n, L = reads.shape
+    seeds = {k: z[k] for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")}
+    hj = HostJobs(g, reads.reshape(-1), np.arange(n, dtype=np.uint64) * L, np.full(n, L, np.uint32), seeds, n_threads=4)
+    out3, _, _ = oracle.extend_batch(*hj.jobs())
+    return g, reads, hj, hj.merge(out3)
+
+
+def _pac(g):
+    pad = (-len(g)) % 4
+    codes = np.concatenate([g, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    return np.ascontiguousarray(((codes[:, 0] << 6) | (codes[:, 1] << 4) | (codes[:, 2] << 2) | codes[:, 3]).astype(np.uint8))
+
+
+def test_finalize_regs_matches_reference_sam(oracle):
+    """bmh_finalize_regs (mem_sort_dedup_patch, mem_mark_primary_se, mem_approx_mapq_se, the selection of mem_reg2sam)
+    + the oracle's mem_reg2aln reproduce EVERY SAM record the reference's own host code wrote for a repeat-rich read
+    set -- default run and -a run (secondary alignments): flag, POS, MAPQ, CIGAR, NM, AS, XS, MD, in file order."""
+    z = np.load(os.path.join(common.GOLDEN, "post_golden.npz"))
+    g, reads, hj, regs = _golden_regions(oracle, z)
+    pac = _pac(g)
+    for tag, flag_all in (("def_", False), ("all_", True)):
+        out, per_read = hj.finalize(regs, flag_all=flag_all, n_threads=2)
+        assert per_read.sum() == len(out)
+        got = []
+        seen = set()
+        for q in out:
+            if not q[15]:
+                continue
+            rb = int(np.uint32(q[4])) | (int(q[5]) << 32); re = int(np.uint32(q[6])) | (int(q[7]) << 32)
+            a = oracle.reg2aln(pac, len(g), reads[q[0]], q[2], q[3], rb, re, q[8], reg_w=int(q[9]))
+            cs = "".join(f"{int(x) >> 4}{'MIDSH'[int(x) & 0xf]}" for x in a["cigar"])
+            if int(q[0]) in seen:
+                cs = cs.replace("S", "H")                       # every record of a read after its first is hard-clipped (mem_aln2sam)
+            seen.add(int(q[0]))
+            got.append((int(q[0]), (16 if a["is_rev"] else 0) | int(q[14]), a["pos"] + 1, int(q[13]), cs, a["NM"], int(q[1]),
+                        int(q[10]) if q[12] < 0 else -1, a["MD"]))
+        want = list(zip(z[tag + "read"].tolist(), z[tag + "flag"].tolist(), z[tag + "pos"].tolist(), z[tag + "mapq"].tolist(), [str(x) for x in z[tag + "cigar"]],
+                        z[tag + "nm"].tolist(), z[tag + "as_"].tolist(), z[tag + "xs"].tolist(), [str(x) for x in z[tag + "md"]]))
+        assert len(got) == len(want), (tag, len(got), len(want))
+        bad = [(a, b) for a, b in zip(got, want) if a != b]
+        assert not bad, (tag, len(bad), bad[:3])
+    assert (z["all_flag"] & 0x100).sum() > 100 and (z["def_xs"] > 0).sum() > 100
+    hj.free()

@@ -63,7 +63,7 @@ class DevJobsT(C.Structure):
     """bmh_dev_jobs_t"""
     _fields_ = [(n, C.c_uint64) for n in ("n_jobs", "n_regs", "q_bytes", "t_bytes", "n_heavy_reads")] + \
                [(n, C.c_void_p) for n in ("d_q", "d_qoff", "d_qlen", "d_t", "d_toff", "d_tlen", "d_h0", "d_job_read", "d_job_reg",
-                                          "d_job_side", "d_regs_per_read")]
+                                          "d_job_side", "d_regs_per_read", "d_frac_rep")]
 
 
 # mirrors of include/seed_gen.h
@@ -150,8 +150,8 @@ def load_library() -> C.CDLL:
     L.bmh_chain_merge.restype = C.c_int
     L.bmh_chain_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bmh_cigar_batch.restype = C.c_int
-    L.bmh_cigar_batch.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.POINTER(ExtParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
-                                  C.c_void_p, C.c_void_p]
+    L.bmh_cigar_batch.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_uint32, C.POINTER(ExtParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_void_p, C.c_void_p]
     L.bwt_restore_bwt_gpu.restype = C.POINTER(BwtTGpu)
     L.bwt_restore_bwt_gpu.argtypes = [C.c_char_p]
     L.bwt_restore_sa_gpu.argtypes = [C.c_char_p, C.POINTER(BwtTGpu)]
@@ -296,7 +296,7 @@ def cigar_batch(index: Index, reads_t, offs_t, lens_t, regs_t, n: int, sel_t=Non
     cigar = torch.zeros(max(n, 1), max_cigar, dtype=torch.int32, device=dev)
     aln = torch.zeros(max(n, 1), 8, dtype=torch.int32, device=dev)
     md = torch.zeros(max(n, 1), md_cap, dtype=torch.uint8, device=dev)
-    rc = L.bmh_cigar_batch(index.handle, reads_t.data_ptr(), offs_t.data_ptr(), lens_t.data_ptr(), regs_t.data_ptr(),
+    rc = L.bmh_cigar_batch(index.handle, reads_t.data_ptr(), offs_t.data_ptr(), lens_t.data_ptr(), regs_t.data_ptr(), int(regs_t.shape[1]),
                            sel_t.data_ptr() if sel_t is not None else None, n, C.byref(p), opt_w, max_cigar, cigar.data_ptr(), aln.data_ptr(),
                            md_cap, md.data_ptr(), stream)
     if rc != 0:
@@ -319,6 +319,7 @@ def dev_jobs_to_host(j: DevJobsT, n_reads: int) -> dict:
     out["q"] = rd(j.d_q, int(j.q_bytes), np.uint8, torch.uint8)
     out["t"] = rd(j.d_t, int(j.t_bytes), np.uint8, torch.uint8)
     out["regs_per_read"] = rd(j.d_regs_per_read, n_reads, np.uint32, torch.int32)
+    out["frac_rep"] = rd(j.d_frac_rep, n_reads, np.float32, torch.float32)
     return out
 
 

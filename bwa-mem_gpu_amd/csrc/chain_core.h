@@ -45,6 +45,7 @@ struct ch_ctx_t {
 	ch_scr_t g;
 	ch_reg_t *regs;               // output slots, prefix[read] + i in creation order
 	uint32_t *regs_per_read, *jobs_per_read;
+	float *frac_rep;              // per read: part of the read covered by SMEMs with more than max_occ occurrences (mem_chain :415-459)
 	int *err;                     // != 0: a read was longer than 700 bp (mem_flt_chained_seeds is not restated)
 	long long *prof; uint32_t prof_read;
 };
@@ -270,13 +271,28 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 	const int64_t l_pac = x.l_pac;
 	ch_seed_t *S = sc.S; ch_chain_t *CH = sc.CH; uint32_t *order = sc.order; int64_t *opos = sc.opos;
 	uint32_t *klist = sc.klist; uint64_t *srt = sc.srt; uint32_t *cidx = sc.cidx; ch_est_t *E = sc.E; ch_reg_t *R = x.regs + base;
-	x.regs_per_read[r] = 0; x.jobs_per_read[r] = 0;
+	x.regs_per_read[r] = 0; x.jobs_per_read[r] = 0; x.frac_rep[r] = 0.f;
 	if (n == 0 || l_query < o.min_seed_len) return;
 	if (l_query > CH_MAX_READ_LEN) { *x.err = 1; return; }
 	const uint64_t *g_rbeg = x.rbeg + base; const int32_t *g_qbeg = x.qbeg + 2 * (size_t)base; const uint32_t *g_score = x.score + base;
 
 	// ---------------------------------------------------------------- mem_chain
 	CH_STAMP(0);
+	{
+		int b = 0, e = 0, l_rep = 0;
+		for (int i = 0; i < n;) {
+			const uint32_t cnt = g_score[i];
+			if (cnt == 0) break;
+			if (cnt > (uint32_t)o.max_occ) {
+				const int sb = g_qbeg[2 * i], se = g_qbeg[2 * i + 1];
+				if (sb > e) { l_rep += e - b; b = sb; e = se; }
+				else e = e > se ? e : se;
+			}
+			i += (int)cnt;
+		}
+		l_rep += e - b;
+		x.frac_rep[r] = (float)l_rep / l_query;
+	}
 	int nc = 0, ns = 0;
 	for (int i = 0; i < n;) {
 		const uint32_t cnt = g_score[i];

@@ -172,7 +172,7 @@ struct bmh_chain_ws {
 	// per-seed scratch
 	ch_seed_t *seeds; ch_chain_t *chains; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx; ch_reg_t *regs; ch_est_t *est;
 	// per read
-	uint32_t *regs_per_read, *jobs_per_read, *reg_off, *job_off, *heavy_list;
+	uint32_t *regs_per_read, *jobs_per_read, *reg_off, *job_off, *heavy_list; float *frac_rep;
 	uint32_t *counters;            // [0..2] heavy_n per size class  [3] err  [4..15] profile stamps
 	// contigs
 	int n_contigs; int64_t *ctg_off; int32_t *ctg_len;
@@ -193,7 +193,7 @@ extern "C" void bmh_chain_ws_free(bmh_chain_ws_t *w)
 {
 	if (!w) return;
 	void *ps[] = {w->seeds, w->chains, w->order, w->opos, w->klist, w->srt, w->cidx, w->regs, w->est, w->regs_per_read, w->jobs_per_read, w->reg_off,
-	              w->job_off, w->heavy_list, w->counters, w->ctg_off, w->ctg_len, w->outregs, w->qlen, w->tlen, w->h0, w->job_read, w->job_reg,
+	              w->job_off, w->heavy_list, w->frac_rep, w->counters, w->ctg_off, w->ctg_len, w->outregs, w->qlen, w->tlen, w->h0, w->job_read, w->job_reg,
 	              w->job_side, w->jq_src, w->qoff, w->toff, w->jt0, w->qoff64, w->toff64, w->q, w->t, w->scan_tmp};
 	for (void *p : ps) if (p) (void)hipFree(p);
 	if (w->h_pin) (void)hipHostFree(w->h_pin);
@@ -214,7 +214,7 @@ extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_
 	A(w->seeds, sizeof(ch_seed_t) * S); A(w->chains, sizeof(ch_chain_t) * S); A(w->order, 4 * S); A(w->opos, 8 * S); A(w->klist, 4 * S);
 	A(w->srt, 8 * S); A(w->cidx, 4 * S); A(w->regs, sizeof(ch_reg_t) * S); A(w->est, sizeof(ch_est_t) * S);
 	const size_t Rn = (size_t)max_reads + 1;
-	A(w->regs_per_read, 4 * Rn); A(w->jobs_per_read, 4 * Rn); A(w->reg_off, 4 * Rn); A(w->job_off, 4 * Rn); A(w->heavy_list, 3 * 4 * Rn);
+	A(w->regs_per_read, 4 * Rn); A(w->jobs_per_read, 4 * Rn); A(w->reg_off, 4 * Rn); A(w->job_off, 4 * Rn); A(w->heavy_list, 3 * 4 * Rn); A(w->frac_rep, 4 * Rn);
 	A(w->counters, 64);
 	size_t t1 = 0, t2 = 0;
 	rocprim::exclusive_scan(nullptr, t1, w->regs_per_read, w->reg_off, 0u, Rn, rocprim::plus<uint32_t>(), 0);
@@ -282,7 +282,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	A.x.rbeg = seeds->d_rbeg; A.x.qbeg = seeds->d_qbeg; A.x.score = seeds->d_score; A.x.n_ref = seeds->d_n_ref_pos; A.x.prefix = seeds->d_prefix;
 	A.x.read_lens = d_lens;
 	A.x.g.S = w->seeds; A.x.g.CH = w->chains; A.x.g.order = w->order; A.x.g.opos = w->opos; A.x.g.klist = w->klist; A.x.g.srt = w->srt; A.x.g.cidx = w->cidx;
-	A.x.g.E = w->est; A.x.regs = w->regs; A.x.regs_per_read = w->regs_per_read; A.x.jobs_per_read = w->jobs_per_read; A.x.err = (int *)(w->counters + 3);
+	A.x.g.E = w->est; A.x.regs = w->regs; A.x.regs_per_read = w->regs_per_read; A.x.jobs_per_read = w->jobs_per_read; A.x.frac_rep = w->frac_rep; A.x.err = (int *)(w->counters + 3);
 	A.n_reads = n_reads;
 	const char *ht = getenv("BMH_CHAIN_HEAVY");
 	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : 32u;
@@ -332,7 +332,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	const uint64_t n_regs = w->h_pin[0], n_jobs = w->h_pin[1];
 	w->n_regs = n_regs; w->n_jobs = n_jobs;
 	out->n_regs = n_regs; out->n_jobs = n_jobs; out->n_heavy_reads = (uint64_t)w->h_pin[2] + w->h_pin[3] + w->h_pin[4];
-	out->d_regs_per_read = w->regs_per_read;
+	out->d_regs_per_read = w->regs_per_read; out->d_frac_rep = w->frac_rep;
 	if (n_regs > w->cap_regs) {
 		const uint64_t c = n_regs + n_regs / 4 + 1024;
 		if (grow(w->outregs, c) != BMH_OK) return BMH_ENOMEM;

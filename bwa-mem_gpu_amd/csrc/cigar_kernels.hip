@@ -35,7 +35,8 @@ __device__ __forceinline__ int g_wave_shr1(int v, int fill) { return __builtin_a
 struct cigar_args_t {
 	const uint8_t *reads; const uint32_t *offs, *lens;
 	const uint8_t *pac; long long l_pac;
-	const int32_t *regs;            // [n][8] = {read, truesc, qb, qe, rb_lo, rb_hi, re_lo, re_hi}
+	const int32_t *regs;            // [n][stride]: {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi} (+ {truesc, w, ...} when stride == 16)
+	int stride;
 	const uint32_t *sel; uint32_t n; // optional list of region indices; n = number of jobs
 	int a, b, o_del, e_del, o_ins, e_ins, opt_w;
 	int max_cigar, md_cap;
@@ -143,9 +144,9 @@ __global__ void __launch_bounds__(64) cigar_kernel(cigar_args_t A)
 	uint8_t *z_g = A.z_slab + (size_t)blockIdx.x * A.z_slab_stride;
 	for (uint32_t job = blockIdx.x; job < A.n; job += gridDim.x) {
 		const uint32_t id = A.sel ? A.sel[job] : job;
-		const int32_t *R = A.regs + 8 * (size_t)id;
+		const int32_t *R = A.regs + (size_t)A.stride * id;
 		const uint32_t read = (uint32_t)R[0];
-		const int truesc = R[1], qb = R[2], qe = R[3];
+		const int truesc = A.stride >= 16 ? R[8] : R[1], reg_w = A.stride >= 16 ? R[9] : A.opt_w, qb = R[2], qe = R[3];
 		const long long rb = (long long)(uint32_t)R[4] | (long long)R[5] << 32, re = (long long)(uint32_t)R[6] | (long long)R[7] << 32;
 		const int qlen = qe - qb, l_query = (int)A.lens[read];
 		const int need = (qlen + 63) >> 6;
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(64) cigar_kernel(cigar_args_t A)
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0);
 		int w2 = g_infer_bw(qlen, rlen, truesc, A.a, A.o_ins, A.e_ins);
 		{ const int tmp = g_infer_bw(qlen, rlen, truesc, A.a, A.o_del, A.e_del); w2 = w2 > tmp ? w2 : tmp; }
-		if (w2 > A.opt_w) w2 = w2 < A.opt_w ? w2 : A.opt_w;          // ar->w == opt->w in the GPU pipeline (src/bwamem.c:1280)
+		if (w2 > A.opt_w) w2 = w2 < reg_w ? w2 : reg_w;              // ar->w: opt->w (src/bwamem.c:1280) unless the region was patched
 		int score = 0, last_sc = -(1 << 30), n_ops = 0, flags = 0, it = 0;
 		bool lds_z = true;
 		do {
@@ -280,12 +281,12 @@ __global__ void __launch_bounds__(64) cigar_kernel(cigar_args_t A)
 }
 
 // largest direction matrix (the whole rectangle bounds every retry) and longest sequence of the batch
-__global__ void __launch_bounds__(256) cigar_size_kernel(const int32_t *regs, const uint32_t *sel, uint32_t n, unsigned long long *out)
+__global__ void __launch_bounds__(256) cigar_size_kernel(const int32_t *regs, int stride, const uint32_t *sel, uint32_t n, unsigned long long *out)
 {
 	const uint32_t job = blockIdx.x * 256u + threadIdx.x;
 	unsigned long long zb = 0, ml = 0;
 	if (job < n) {
-		const int32_t *R = regs + 8 * (size_t)(sel ? sel[job] : job);
+		const int32_t *R = regs + (size_t)stride * (sel ? sel[job] : job);
 		const long long rb = (long long)(uint32_t)R[4] | (long long)R[5] << 32, re = (long long)(uint32_t)R[6] | (long long)R[7] << 32;
 		const long long ql = (long long)R[3] - R[2], rl = re - rb;
 		if (ql > 0 && rl > 0 && ql < (1 << 20) && rl < (1 << 20)) { zb = (unsigned long long)(ql * rl); ml = (unsigned long long)(ql > rl ? ql : rl); }
@@ -306,17 +307,17 @@ static int launch_cigar(const cigar_args_t &a, unsigned grid, size_t lds, hipStr
 }
 
 extern "C" int bmh_cigar_batch(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, const uint32_t *d_lens,
-                               const int32_t *d_regs, const uint32_t *d_sel, uint32_t n, const bmh_ext_params_t *p, int opt_w,
+                               const int32_t *d_regs, int reg_stride, const uint32_t *d_sel, uint32_t n, const bmh_ext_params_t *p, int opt_w,
                                int max_cigar, uint32_t *d_cigar, int32_t *d_aln, int md_cap, char *d_md, void *stream_)
 {
 	if (!idx || !p || (n && (!d_reads || !d_offs || !d_lens || !d_regs || !d_cigar || !d_aln))) { bmh_set_error("bmh_cigar_batch: null argument"); return BMH_EINVAL; }
 	if (!idx->dev.pac || idx->dev.l_pac == 0) { bmh_set_error("bmh_cigar_batch: the index was uploaded without the 2-bit reference (pac)"); return BMH_EINVAL; }
-	if (max_cigar < 4 || (d_md && md_cap < 2) || p->e_del < 1 || p->e_ins < 1 || opt_w < 1) { bmh_set_error("bmh_cigar_batch: bad argument"); return BMH_EINVAL; }
+	if ((reg_stride != 8 && reg_stride != 16) || max_cigar < 4 || (d_md && md_cap < 2) || p->e_del < 1 || p->e_ins < 1 || opt_w < 1) { bmh_set_error("bmh_cigar_batch: bad argument"); return BMH_EINVAL; }
 	if (n == 0) return BMH_OK;
 	hipStream_t st = (hipStream_t)stream_;
 	if (!g_cs.d_sizes) HIPCK(hipMalloc((void **)&g_cs.d_sizes, 16));
 	HIPCK(hipMemsetAsync(g_cs.d_sizes, 0, 16, st));
-	cigar_size_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_regs, d_sel, n, g_cs.d_sizes);
+	cigar_size_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_regs, reg_stride, d_sel, n, g_cs.d_sizes);
 	unsigned long long h[2];
 	HIPCK(hipMemcpyAsync(h, g_cs.d_sizes, 16, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));
@@ -324,7 +325,7 @@ extern "C" int bmh_cigar_batch(const bmh_index_t *idx, const uint8_t *d_reads, c
 	if (max_len > 704) { bmh_set_error("bmh_cigar_batch: a region spans %llu bases (limit 704)", h[1]); return BMH_ECAPACITY; }
 	cigar_args_t a;
 	a.reads = d_reads; a.offs = d_offs; a.lens = d_lens; a.pac = idx->dev.pac; a.l_pac = (long long)idx->dev.l_pac;
-	a.regs = d_regs; a.sel = d_sel; a.n = n;
+	a.regs = d_regs; a.stride = reg_stride; a.sel = d_sel; a.n = n;
 	a.a = p->a; a.b = p->b; a.o_del = p->o_del; a.e_del = p->e_del; a.o_ins = p->o_ins; a.e_ins = p->e_ins; a.opt_w = opt_w;
 	a.max_cigar = max_cigar; a.md_cap = d_md ? md_cap : 0; a.cigar = d_cigar; a.aln = d_aln; a.md = d_md;
 	a.max_len = max_len;

@@ -207,6 +207,7 @@ typedef struct {
 	const uint8_t *d_t; const uint32_t *d_toff, *d_tlen, *d_h0;
 	const uint32_t *d_job_read, *d_job_reg, *d_job_side;           /* read / region / side (0 left, 1 right) per job */
 	const uint32_t *d_regs_per_read;                               /* [n_reads] */
+	const float *d_frac_rep;                                       /* [n_reads] frac_rep of the read's chains (for bmh_finalize_regs) */
 } bmh_dev_jobs_t;
 
 /* on (default): bmh_chain_batch also materialises the base arrays d_q/d_t/d_qoff/d_toff for bmh_extend_batch;
@@ -232,14 +233,16 @@ int bmh_chain_merge(bmh_chain_ws_t *ws, const int32_t *d_out3, int32_t *d_regs_o
 /* mem_reg2aln (src/bwamem.c:2344-2440) for n regions: banded global alignment ksw_global2 (src/ksw.c:1120-1241) of
  * read[qb,qe) against the reference text [rb,re) with the band of bwa_gen_cigar2 (src/bwa.c:111-216), the retry with a
  * doubled band, NM, the MD string, the squeeze of a leading / trailing deletion, soft clips and the position.
- * d_regs: [..][8] = {read, truesc, qb, qe, rb_lo, rb_hi, re_lo, re_hi} -- the layout bmh_chain_merge / bmh_merge_regs
- * write; d_sel (optional): n indices into d_regs, NULL = the first n regions.  opt_w = mem_opt_t.w (300).
+ * d_regs: records of reg_stride int32: 8 = {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi}, the layout bmh_chain_merge /
+ * bmh_merge_regs write (truesc = score, region band = opt_w); 16 = the records of bmh_finalize_regs (truesc and the
+ * region's band at [8], [9]: a patched region carries a wider band).  d_sel (optional): n indices into d_regs, NULL = the
+ * first n regions.  opt_w = mem_opt_t.w (300).
  * Out, per job: d_cigar[max_cigar] (len << 4 | op, op 0 M, 1 I, 2 D, 3 S), d_aln[8] = {pos_lo, pos_hi (0-based,
  * forward strand of the concatenated reference), is_rev, n_cigar, NM, global score, MD length, flags (1 = more than
  * max_cigar-2 ops, 2 = interval rejected by bwa_gen_cigar2, 4 = too large, 8 = MD longer than md_cap)}, d_md[md_cap]
  * (NUL-terminated; d_md may be NULL).  The index must carry its pac.  Synchronises the stream once (sizes). */
 int bmh_cigar_batch(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, const uint32_t *d_lens,
-                    const int32_t *d_regs, const uint32_t *d_sel, uint32_t n, const bmh_ext_params_t *p, int opt_w,
+                    const int32_t *d_regs, int reg_stride, const uint32_t *d_sel, uint32_t n, const bmh_ext_params_t *p, int opt_w,
                     int max_cigar, uint32_t *d_cigar, int32_t *d_aln, int md_cap, char *d_md, void *stream);
 
 #ifdef __cplusplus

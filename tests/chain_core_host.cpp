@@ -24,13 +24,13 @@ extern "C" result_t *chain_core_run(const bmh_chain_opt_t *opt, int64_t l_pac, c
 	const size_t S = n_seeds + 1;
 	std::vector<ch_seed_t> seeds(S); std::vector<ch_chain_t> chains(S); std::vector<uint32_t> order(S), klist(S), cidx(S);
 	std::vector<int64_t> opos(S); std::vector<uint64_t> srt(S); std::vector<ch_reg_t> regs(S); std::vector<ch_est_t> est(S);
-	std::vector<uint32_t> rpr(n_reads + 1), jpr(n_reads + 1);
+	std::vector<uint32_t> rpr(n_reads + 1), jpr(n_reads + 1); std::vector<float> frep(n_reads + 1);
 	int err = 0;
 	ch_ctx_t x; memset(&x, 0, sizeof(x));
 	x.o = *opt; x.l_pac = l_pac; x.n_contigs = 1;
 	x.rbeg = rbeg; x.qbeg = qbeg; x.score = score; x.n_ref = n_ref; x.prefix = prefix; x.read_lens = read_lens;
 	x.g.S = seeds.data(); x.g.CH = chains.data(); x.g.order = order.data(); x.g.opos = opos.data(); x.g.klist = klist.data(); x.g.srt = srt.data();
-	x.g.cidx = cidx.data(); x.g.E = est.data(); x.regs = regs.data(); x.regs_per_read = rpr.data(); x.jobs_per_read = jpr.data(); x.err = &err;
+	x.g.cidx = cidx.data(); x.g.E = est.data(); x.regs = regs.data(); x.regs_per_read = rpr.data(); x.jobs_per_read = jpr.data(); x.frac_rep = frep.data(); x.err = &err;
 	for (uint32_t r = 0; r < n_reads; ++r) chain_core::chain_read<false>(x, r, chain_core::global_scratch(x, r));
 	std::vector<uint32_t> qoff, qlen, toff, tlen, h0, job_read, job_reg, job_side;
 	std::vector<uint8_t> q, t;

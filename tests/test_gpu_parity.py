@@ -343,6 +343,7 @@ def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None):
     assert int(dj.n_jobs) == hj.n_jobs and int(dj.n_regs) == hj.n_regs
     for k in ("qlen", "tlen", "h0", "job_read", "job_reg", "job_side", "qoff", "toff", "regs_per_read", "q", "t"):
         assert np.array_equal(got[k], getattr(hj, k)), k
+    assert np.array_equal(got["frac_rep"], hj.frac_rep())
     # extension + merge on the device vs oracle extension + host merge
     out3 = torch.zeros(max(hj.n_jobs, 1), 3, dtype=torch.int32, device="cuda")
     regs = torch.zeros(max(hj.n_regs, 1), 8, dtype=torch.int32, device="cuda")
@@ -493,3 +494,66 @@ def test_cigar_batch_matches_reference_sam(hip, oracle):
         want = (int(z["sam_pos"][r]), str(z["sam_cigar"][r]), int(z["sam_nm"][r]), str(z["sam_md"][r]), (int(z["sam_flag"][r]) >> 4) & 1)
         assert got == want, (r, got, want)
     hj.free(); dindex.free()
+
+
+def test_reads_to_sam_fields_match_reference(hip, oracle):
+    """The whole chain on the repeat-rich golden read set: device seeding -> device chaining / jobs -> device extension
+    -> device merge -> bmh_finalize_regs (host, like the reference) -> bmh_cigar_batch (device) reproduces every SAM record
+    the reference's own host code wrote (flag, POS, MAPQ, CIGAR, NM, AS, XS, MD), default run and -a."""
+    import ast, ctypes as C, torch
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.lib import ChainOpt, ChainWorkspace, PostOpt, cigar_batch, load_library, _np_ptr, _u8p, _u64p, _i32p, _u32p
+    z = np.load(os.path.join(common.GOLDEN, "post_golden.npz"))
+    g = synth.make_genome(int(z["n_genome"]), seed=int(z["genome_seed"]), **ast.literal_eval(str(z["genome_kw"])))
+    idx = fmindex.build_fmd_index(g)
+    reads = z["reads"]; n, L = reads.shape
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    pac = _pack_pac(g)
+    dindex = hip.Index.upload(idx, pac=pac, l_pac=len(g))
+    ws = hip.SeedWorkspace(n, n * L, max_cands=n * L, max_occ=1 << 22)
+    r = _to_dev(torch, synth.codes_to_ascii(flat))
+    o = (torch.arange(n, dtype=torch.int64) * L).to(torch.int32).cuda()
+    l = torch.full((n,), L, dtype=torch.int32).cuda()
+    s = ws.seed_batch(dindex, r, o, l, 19)
+    cw = ChainWorkspace(n, max(int(s.n_seeds), 1)); cw.set_materialize(False)
+    dj = cw.chain_batch(dindex, r, o, l, s)
+    nr = int(dj.n_regs)
+    out3 = torch.zeros(max(int(dj.n_jobs), 1), 3, dtype=torch.int32, device="cuda")
+    regs = torch.zeros(max(nr, 1), 8, dtype=torch.int32, device="cuda")
+    cw.extend(out3); cw.merge(out3, regs)
+    torch.cuda.synchronize()
+    from bwamem_hip.lib import dev_jobs_to_host
+    dh = dev_jobs_to_host(dj, n)                       # per-read region counts and frac_rep of the device job builder
+    regs_h = regs.cpu().numpy()[:nr]
+    Lb = load_library()
+    co = ChainOpt(); Lb.bmh_chain_opt_default(C.byref(co)); ep = hip.ExtParams.default()
+    for tag, flag_all in (("def_", 0), ("all_", 1)):
+        po = PostOpt(); Lb.bmh_post_opt_default(C.byref(po)); po.flag_all = flag_all
+        out = np.zeros((max(nr, 1), 16), np.int32); opr = np.zeros(n, np.uint32)
+        fr = np.ascontiguousarray(dh["frac_rep"], dtype=np.float32)
+        m = Lb.bmh_finalize_regs(C.byref(co), C.byref(ep), C.byref(po), len(g), _np_ptr(pac, _u8p), n, _np_ptr(flat, _u8p),
+                                 _np_ptr(np.arange(n, dtype=np.uint64) * L, _u64p), _np_ptr(np.ascontiguousarray(regs_h), _i32p),
+                                 _np_ptr(np.ascontiguousarray(dh["regs_per_read"]), _u32p), fr.ctypes.data_as(C.POINTER(C.c_float)),
+                                 _np_ptr(out, _i32p), _np_ptr(opr, _u32p), 2)
+        assert m >= 0
+        out = out[:m]
+        sel = np.nonzero(out[:, 15])[0].astype(np.int32)
+        cigar, aln, md = cigar_batch(dindex, r, o, l, torch.from_numpy(out.copy()).cuda(), len(sel), sel_t=torch.from_numpy(sel).cuda(),
+                                     max_cigar=48, md_cap=640)
+        torch.cuda.synchronize()
+        cigar = cigar.cpu().numpy().view(np.uint32); aln = aln.cpu().numpy(); md = md.cpu().numpy()
+        got, seen = [], set()
+        for k, i in enumerate(sel):
+            q = out[i]; a = aln[k]
+            cs = "".join(f"{int(x) >> 4}{'MIDSH'[int(x) & 0xf]}" for x in cigar[k][: a[3]])
+            if int(q[0]) in seen:
+                cs = cs.replace("S", "H")
+            seen.add(int(q[0]))
+            got.append((int(q[0]), (16 if a[2] else 0) | int(q[14]), int(np.uint32(a[0])) + 1, int(q[13]), cs, int(a[4]), int(q[1]),
+                        int(q[10]) if q[12] < 0 else -1, bytes(md[k][: a[6]]).decode()))
+        want = list(zip(z[tag + "read"].tolist(), z[tag + "flag"].tolist(), z[tag + "pos"].tolist(), z[tag + "mapq"].tolist(), [str(x) for x in z[tag + "cigar"]],
+                        z[tag + "nm"].tolist(), z[tag + "as_"].tolist(), z[tag + "xs"].tolist(), [str(x) for x in z[tag + "md"]]))
+        assert len(got) == len(want), (tag, len(got), len(want))
+        bad = [(a, b) for a, b in zip(got, want) if a != b]
+        assert not bad, (tag, len(bad), bad[:3])
+    cw.free(); ws.free(); dindex.free()

@@ -72,6 +72,48 @@ def pmc_valu_busy(pred):
         return None
 
 
+def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, reads, params):
+    """The rows after the hot path, measured on the same batch and reported beside the metric, not in it:
+    bmh_finalize_regs (host: sort/dedup/patch, primary marking, MAPQ, selection -- the reference runs it on host threads too)
+    and bmh_cigar_batch (device: CIGAR / NM / MD of every reported alignment)."""
+    from bwamem_hip.lib import ChainOpt, PostOpt, cigar_batch, dev_jobs_to_host, _np_ptr, _u8p, _u64p, _i32p, _u32p
+    dev = regs_out.device
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    regs_h = regs_out[:n_regs].cpu().numpy()
+    t_d2h = time.perf_counter() - t0
+    rpr = torch.empty(n_reads, dtype=torch.int32, device=dev); fr = torch.empty(n_reads, dtype=torch.float32, device=dev)
+    dj = cw.last_jobs
+    B.lib._memcpy_d2d(rpr.data_ptr(), dj.d_regs_per_read, 4 * n_reads); B.lib._memcpy_d2d(fr.data_ptr(), dj.d_frac_rep, 4 * n_reads)
+    rpr_h = rpr.cpu().numpy().view(np.uint32); fr_h = fr.cpu().numpy()
+    co = ChainOpt(); L.bmh_chain_opt_default(C.byref(co)); po = PostOpt(); L.bmh_post_opt_default(C.byref(po))
+    pac_h = pac_t.cpu().numpy()
+    flat = np.ascontiguousarray(reads.reshape(-1)); rl = reads.shape[1]
+    offs = np.arange(n_reads, dtype=np.uint64) * rl
+    out = np.zeros((max(n_regs, 1), 16), np.int32); opr = np.zeros(n_reads, np.uint32)
+    nth = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    m = L.bmh_finalize_regs(C.byref(co), C.byref(params), C.byref(po), len(g), _np_ptr(pac_h, _u8p), n_reads, _np_ptr(flat, _u8p), _np_ptr(offs, _u64p),
+                            _np_ptr(np.ascontiguousarray(regs_h), _i32p), _np_ptr(np.ascontiguousarray(rpr_h), _u32p), fr_h.ctypes.data_as(C.POINTER(C.c_float)),
+                            _np_ptr(out, _i32p), _np_ptr(opr, _u32p), nth)
+    t_fin = time.perf_counter() - t0
+    if m < 0:
+        raise RuntimeError("bmh_finalize_regs failed")
+    out = out[:m]
+    sel = np.nonzero(out[:, 15])[0].astype(np.int32)
+    out_t = torch.from_numpy(out.copy()).to(dev); sel_t = torch.from_numpy(sel).to(dev)
+    ms = []
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        cg, aln, md = cigar_batch(dindex, dr.ascii, dr.offs, dr.lens, out_t, len(sel), sel_t=sel_t, params=params, max_cigar=24, md_cap=128)
+        torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
+    fl = aln[:, 7].cpu().numpy()
+    return {"finalize_regs_host": {"ms": round(t_fin * 1e3, 2), "threads": nth, "regions_in": int(n_regs), "regions_out": int(m), "reported": int(len(sel)),
+                                   "d2h_regions_ms": round(t_d2h * 1e3, 2)},
+            "cigar_batch_device": {"ms": round(min(ms), 3), "alignments": int(len(sel)), "M_alignments_per_s": round(len(sel) / (min(ms) * 1e-3) / 1e6, 1),
+                                   "flagged": int((fl != 0).sum())}}
+
+
 def cpu_baseline(g, idx, reads, sample: int, n_threads: int):
     """Oracle (our C restatement of the reference CPU path, parity-pinned to the compiled
     reference) timed on the host cores on a bounded sample of the same workload."""
@@ -329,6 +371,11 @@ def main():
                                       "valu_busy_frac": pmc_valu_busy(lambda k: "extend16_kernel" in k or "extend_wide_kernel" in k),
                                       "gcups_reference_cells": round(cells / (iso_ms["extend"] * 1e-3) / 1e9, 1),
                                       "jobs": n_jobs, "hbm_GBps": round(kernel_bytes["extend"] / (iso_ms["extend"] * 1e-3) / 1e9, 2)}
+            if not a.host_jobs:
+                try:
+                    res["next_rows"] = downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, reads, params)
+                except Exception as e:                      # never lose the bench line over the extras
+                    res["next_rows"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     if distributed:
         dist.destroy_process_group()

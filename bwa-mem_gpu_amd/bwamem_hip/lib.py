@@ -261,6 +261,7 @@ class ChainWorkspace:
                                lens_t.numel(), C.byref(seeds), stream, C.byref(out))
         if rc != 0:
             raise RuntimeError(f"bmh_chain_batch rc={rc}: " + _err(L))
+        self.last_jobs = out
         return out
 
     def set_materialize(self, on: bool) -> None:

@@ -190,10 +190,14 @@ def read_index(prefix: str) -> FMDIndex:
     return FMDIndex(primary, L2, seq_len, words, sa_intv, n_sa, sa, bits, pack_size)
 
 
-def write_bns(prefix: str, genome_fwd: np.ndarray, name: str = "chrS") -> None:
-    """.pac / .ann / .amb of a single N-free sequence, byte-identical to what the reference's
-    `bwa index` writes (bwa_index/bntseq.c:66-95 bns_dump, :300-326 pac tail)."""
+def write_bns(prefix: str, genome_fwd: np.ndarray, name: str = "chrS", contigs=None) -> None:
+    """.pac / .ann / .amb of N-free sequences, byte-identical to what the reference's `bwa index` writes
+    (bwa_index/bntseq.c:66-95 bns_dump, :300-326 pac tail).  contigs: optional list of (name, length) whose lengths
+    sum to len(genome_fwd) -- the concatenation is the packed reference; default one sequence `name`."""
     l_pac = int(genome_fwd.shape[0])
+    if contigs is None:
+        contigs = [(name, l_pac)]
+    assert sum(int(c[1]) for c in contigs) == l_pac
     pad = (-l_pac) % 4
     codes = np.concatenate([genome_fwd, np.zeros(pad, np.uint8)]).reshape(-1, 4)
     pac = ((codes[:, 0] << 6) | (codes[:, 1] << 4) | (codes[:, 2] << 2) | codes[:, 3]).astype(np.uint8)
@@ -203,6 +207,10 @@ def write_bns(prefix: str, genome_fwd: np.ndarray, name: str = "chrS") -> None:
             f.write(b"\x00")
         f.write(bytes([l_pac % 4]))
     with open(prefix + ".ann", "w") as f:
-        f.write(f"{l_pac} 1 11\n0 {name} (null)\n0 {l_pac} 0\n")
+        f.write(f"{l_pac} {len(contigs)} 11\n")
+        off = 0
+        for cname, clen in contigs:
+            f.write(f"0 {cname} (null)\n{off} {int(clen)} 0\n")
+            off += int(clen)
     with open(prefix + ".amb", "w") as f:
-        f.write(f"{l_pac} 1 0\n")
+        f.write(f"{l_pac} {len(contigs)} 0\n")

@@ -132,7 +132,7 @@ def load_library() -> C.CDLL:
     L.bmh_post_opt_default.argtypes = [C.POINTER(PostOpt)]
     L.bmh_finalize_regs.restype = C.c_int64
     L.bmh_finalize_regs.argtypes = [C.POINTER(ChainOpt), C.POINTER(ExtParams), C.POINTER(PostOpt), C.c_int64, _u8p, C.c_uint32, _u8p, _u64p,
-                                    _i32p, _u32p, C.POINTER(C.c_float), _i32p, _u32p, C.c_int]
+                                    _i32p, _u32p, C.POINTER(C.c_float), C.c_int, C.c_void_p, _i32p, _u32p, C.c_int]
     L.bmh_merge_regs.restype = C.c_int
     L.bmh_merge_regs.argtypes = [C.c_void_p, _i32p, _i32p]
     L.bmh_chain_ws_create.restype = C.c_void_p
@@ -253,6 +253,15 @@ class ChainWorkspace:
         self.opt = opt or ChainOpt()
         if opt is None:
             L.bmh_chain_opt_default(C.byref(self.opt))
+
+    def set_contigs(self, contigs) -> None:
+        """contigs: list of (name, length) of the packed reference's sequences (bmh_chain_set_contigs)"""
+        L = load_library()
+        ln = np.ascontiguousarray([c[1] for c in contigs], dtype=np.int32)
+        off = np.ascontiguousarray(np.concatenate([[0], np.cumsum(ln)[:-1]]), dtype=np.int64)
+        rc = L.bmh_chain_set_contigs(self.handle, len(contigs), off.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError("bmh_chain_set_contigs: " + _err(L))
 
     def chain_batch(self, index: Index, reads_t, offs_t, lens_t, seeds: SeedsT, stream: int = 0) -> DevJobsT:
         L = load_library()
@@ -398,7 +407,8 @@ class HostJobs:
     """Host job builder (bmh_build_jobs): chains -> filtered chains -> extension jobs, per read."""
 
     def __init__(self, genome_fwd: np.ndarray, reads: np.ndarray, read_offs: np.ndarray, read_lens: np.ndarray, seeds: dict,
-                 n_threads: int = 0, opt: "ChainOpt | None" = None):
+                 n_threads: int = 0, opt: "ChainOpt | None" = None, contigs=None):
+        """contigs: optional list of (name, length) -- the sequences of the packed reference, in order"""
         L = load_library()
         self.L = L
         o = opt or ChainOpt()
@@ -414,7 +424,12 @@ class HostJobs:
         self._keep = [pac, a(reads, np.uint8), a(read_offs, np.uint64), a(read_lens, np.uint32), a(seeds["rbeg"], np.uint64),
                       a(seeds["qbeg"], np.int32), a(seeds["score"], np.uint32), a(seeds["n_ref_pos"], np.uint32), a(seeds["prefix"], np.uint32)]
         k = self._keep
-        self.h = L.bmh_build_jobs(C.byref(o), l_pac, _np_ptr(k[0], _u8p), 1, None, None, len(k[3]), _np_ptr(k[1], _u8p),
+        self.n_contigs = len(contigs) if contigs else 1
+        self.ctg_len = np.ascontiguousarray([c[1] for c in contigs], dtype=np.int32) if contigs else None
+        self.ctg_off = np.ascontiguousarray(np.concatenate([[0], np.cumsum(self.ctg_len)[:-1]]), dtype=np.int64) if contigs else None
+        self.h = L.bmh_build_jobs(C.byref(o), l_pac, _np_ptr(k[0], _u8p), self.n_contigs,
+                                  self.ctg_off.ctypes.data_as(C.c_void_p) if contigs else None, self.ctg_len.ctypes.data_as(C.c_void_p) if contigs else None,
+                                  len(k[3]), _np_ptr(k[1], _u8p),
                                   _np_ptr(k[2], _u64p), _np_ptr(k[3], _u32p), _np_ptr(k[4], _u64p), _np_ptr(k[5], _i32p),
                                   _np_ptr(k[6], _u32p), _np_ptr(k[7], _u32p), _np_ptr(k[8], _u32p), n_threads or (os.cpu_count() or 1))
         if not self.h:
@@ -462,7 +477,9 @@ class HostJobs:
         fr = np.ascontiguousarray(self.frac_rep(), dtype=np.float32)
         m = L.bmh_finalize_regs(C.byref(co), C.byref(ep), C.byref(po), len(self._genome), _np_ptr(k[0], _u8p), len(k[3]), _np_ptr(k[1], _u8p),
                                 _np_ptr(k[2], _u64p), _np_ptr(regs, _i32p), _np_ptr(np.ascontiguousarray(self.regs_per_read), _u32p),
-                                fr.ctypes.data_as(C.POINTER(C.c_float)), _np_ptr(out, _i32p), _np_ptr(opr, _u32p), n_threads)
+                                fr.ctypes.data_as(C.POINTER(C.c_float)), self.n_contigs,
+                                self.ctg_off.ctypes.data_as(C.c_void_p) if self.ctg_off is not None else None,
+                                _np_ptr(out, _i32p), _np_ptr(opr, _u32p), n_threads)
         if m < 0:
             raise RuntimeError("bmh_finalize_regs: " + _err(L))
         return out[:m], opr[: len(k[3])]

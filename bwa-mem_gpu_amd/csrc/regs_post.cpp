@@ -77,7 +77,24 @@ int gen_score(const bmh_ext_params_t &p, int w_, int64_t l_pac, const uint8_t *p
 	return global_score(p, l_query, qs.data(), rlen, rs.data(), w);
 }
 
-struct Ctx { const bmh_chain_opt_t *co; const bmh_ext_params_t *ep; const bmh_post_opt_t *po; int64_t l_pac; const uint8_t *pac; };
+struct Ctx { const bmh_chain_opt_t *co; const bmh_ext_params_t *ep; const bmh_post_opt_t *po; int64_t l_pac; const uint8_t *pac;
+             int n_contigs; const int64_t *ctg_off; };
+
+int pos2rid(const Ctx &x, int64_t pos_f)          // bns_pos2rid, src/bntseq.c:349-363
+{
+	if (pos_f >= x.l_pac) return -1;
+	if (x.n_contigs <= 1) return 0;
+	int left = 0, mid = 0, right = x.n_contigs;
+	while (left < right) {
+		mid = (left + right) >> 1;
+		if (pos_f >= x.ctg_off[mid]) {
+			if (mid == x.n_contigs - 1) break;
+			if (pos_f < x.ctg_off[mid + 1]) break;
+			left = mid + 1;
+		} else right = mid;
+	}
+	return mid;
+}
 
 int patch_reg(const Ctx &x, const uint8_t *query, const Reg &a, const Reg &b, int *w_out)        // mem_patch_reg
 {
@@ -216,13 +233,15 @@ extern "C" void bmh_post_opt_default(bmh_post_opt_t *o)        // mem_opt_init, 
 extern "C" int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, int64_t l_pac,
                                      const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
                                      const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
+                                     int n_contigs, const int64_t *contig_offset,
                                      int32_t *out, uint32_t *out_per_read, int n_threads)
 {
 	if (!copt || !ep || !popt || !pac || (n_reads && (!reads || !read_offs || !regs_in || !regs_per_read || !out || !out_per_read))) {
 		bmh_set_error("bmh_finalize_regs: null argument"); return BMH_EINVAL;
 	}
 	if (!(popt->mapQ_coef_len > 0)) { bmh_set_error("bmh_finalize_regs: mapQ_coef_len <= 0 (the seed-coverage form of MAPQ) is not restated"); return BMH_EINVAL; }
-	Ctx x = {copt, ep, popt, l_pac, pac};
+	if (n_contigs > 1 && !contig_offset) { bmh_set_error("bmh_finalize_regs: null contig table"); return BMH_EINVAL; }
+	Ctx x = {copt, ep, popt, l_pac, pac, n_contigs, contig_offset};
 	std::vector<uint64_t> in_off((size_t)n_reads + 1, 0);
 	for (uint32_t r = 0; r < n_reads; ++r) in_off[r + 1] = in_off[r] + regs_per_read[r];
 	if (n_threads < 1) n_threads = 1;
@@ -236,7 +255,8 @@ extern "C" int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_
 				Reg &p = a[i]; memset(&p, 0, sizeof(p));
 				p.score = p.truesc = g[1]; p.qb = g[2]; p.qe = g[3];
 				p.rb = (int64_t)(uint32_t)g[4] | (int64_t)g[5] << 32; p.re = (int64_t)(uint32_t)g[6] | (int64_t)g[7] << 32;
-				p.rid = 0; p.w = copt->w; p.secondary = -1; p.frac_rep = frac_rep ? frac_rep[r] : 0.f;
+				// the sequence of the region = that of its chain's seeds: the extension windows never leave it (bns_fetch_seq)
+				p.rid = pos2rid(x, p.rb < l_pac ? p.rb : (l_pac << 1) - 1 - (p.re - 1)); p.w = copt->w; p.secondary = -1; p.frac_rep = frac_rep ? frac_rep[r] : 0.f;
 			}
 			int n = sort_dedup_patch(x, reads + read_offs[r], n_in, a.data());
 			mark_primary(x, n, a.data(), popt->id0 + r);

@@ -180,10 +180,12 @@ void bmh_post_opt_default(bmh_post_opt_t *o);
  * out[..][16] = {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi, truesc, w, sub (XS), sub_n, secondary (index within
  * the read's output, -1 = primary line), MAPQ, flag (0x100 secondary, 0x800 supplementary), reported (0/1)} in the
  * reference's order, capacity = the number of input regions; out_per_read[n_reads].  Returns the number of output
- * regions or a negative BMH_E* code.  Single-sequence references only (rid = 0). */
+ * regions or a negative BMH_E* code.  contig_offset: start of every sequence in the packed reference (bns->anns[i].offset;
+ * n_contigs <= 1: one sequence).  ALT contigs are not modelled. */
 int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, int64_t l_pac,
                           const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
                           const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
+                          int n_contigs, const int64_t *contig_offset,
                           int32_t *out, uint32_t *out_per_read, int n_threads);
 
 /* ------------------------------------------------- device job builder (SURVEY 8f ranks 1-2 on the GPU) */

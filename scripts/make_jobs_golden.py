@@ -11,15 +11,25 @@ import bwamem_hip as B
 from bwamem_hip import fmindex, synth
 # usage: make_jobs_golden.py            -> jobs_golden.npz  (plain genome)
 #        make_jobs_golden.py repeats    -> post_golden.npz  (repeat-rich genome: secondary / supplementary alignments, XS, low MAPQ)
-REPEATS = len(sys.argv) > 1 and sys.argv[1] == "repeats"
-OUT = "post_golden.npz" if REPEATS else "jobs_golden.npz"
-work = "/tmp/jobs_golden" + ("_rep" if REPEATS else ""); os.makedirs(work, exist_ok=True)
+#        make_jobs_golden.py contigs    -> contigs_golden.npz (the same repeat-rich genome cut into three sequences; reads cross the cuts)
+MODE = sys.argv[1] if len(sys.argv) > 1 else "plain"
+REPEATS = MODE in ("repeats", "contigs")
+OUT = {"plain": "jobs_golden.npz", "repeats": "post_golden.npz", "contigs": "contigs_golden.npz"}[MODE]
+CONTIGS = [("ctgA", 120_000), ("ctgB", 100_037), ("ctgC", 79_963)] if MODE == "contigs" else None
+work = "/tmp/jobs_golden_" + MODE; os.makedirs(work, exist_ok=True)
 n_genome, n_reads, L = 300_000, 600, 150
 GENOME_KW = dict(repeat_frac=0.45, repeat_len=(150, 1500), repeat_copies=(3, 40), repeat_div=0.03) if REPEATS else {}
 g = synth.make_genome(n_genome, seed=42, **GENOME_KW)
 idx = fmindex.build_fmd_index(g, device="cuda:0")
-prefix = os.path.join(work, "g.fa"); fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g)
+prefix = os.path.join(work, "g.fa"); fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g, contigs=CONTIGS)
 reads, _ = synth.make_reads(g, n_reads, L, seed=21, sub_rate=0.02, indel_frac=0.2)
+if CONTIGS:                                   # every eighth read straddles a cut between two sequences
+    rng = np.random.default_rng(5)
+    cuts = np.cumsum([c[1] for c in CONTIGS])[:-1]
+    for i in range(0, n_reads, 8):
+        c = int(cuts[i // 8 % len(cuts)]); p = c - int(rng.integers(10, L - 10))
+        x = g[p:p + L].copy()
+        reads[i] = x if i % 16 else synth.revcomp(x)
 fq = os.path.join(work, "r.fa"); synth.write_fasta_reads(fq, reads)
 dump = os.path.join(work, "jobs.bin")
 if os.path.exists(dump): os.remove(dump)
@@ -53,7 +63,7 @@ def sam_lines(path):
         if line[0] == "@": continue
         c = line.rstrip("\n").split("\t")
         tags = {t[:2]: t[5:] for t in c[11:]}
-        rows.append((int(c[0][1:]), int(c[1]), int(c[3]), int(c[4]), c[5], int(tags.get("NM", -1)), int(tags.get("AS", -1)), int(tags.get("XS", -1)), tags.get("MD", "")))
+        rows.append((int(c[0][1:]), int(c[1]), int(c[3]), int(c[4]), c[5], int(tags.get("NM", -1)), int(tags.get("AS", -1)), int(tags.get("XS", -1)), tags.get("MD", ""), c[2]))
     return rows
 sam_a = os.path.join(work, "o_all.sam")
 with open(sam_a, "w") as f:
@@ -62,10 +72,11 @@ with open(sam_a, "w") as f:
 def pack(rows):
     return dict(read=np.array([r[0] for r in rows], np.int32), flag=np.array([r[1] for r in rows], np.int32), pos=np.array([r[2] for r in rows], np.int64),
                 mapq=np.array([r[3] for r in rows], np.int32), cigar=np.array([r[4] for r in rows]), nm=np.array([r[5] for r in rows], np.int32),
-                as_=np.array([r[6] for r in rows], np.int32), xs=np.array([r[7] for r in rows], np.int32), md=np.array([r[8] for r in rows]))
+                as_=np.array([r[6] for r in rows], np.int32), xs=np.array([r[7] for r in rows], np.int32), md=np.array([r[8] for r in rows]),
+                rname=np.array([r[9] for r in rows]))
 lines_def = pack(sam_lines(sam)); lines_all = pack(sam_lines(sam_a))
 seeds = B.seed_file(prefix, fq, 19)
-np.savez_compressed(os.path.join(ROOT, "gpurun_out", OUT), n_genome=n_genome, genome_seed=42, genome_kw=repr(GENOME_KW), reads=reads,
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", OUT), n_genome=n_genome, genome_seed=42, genome_kw=repr(GENOME_KW), contigs=repr(CONTIGS), reads=reads,
                     job_digests=np.frombuffer(b"".join(digs), dtype=np.uint8).reshape(-1, 20), as_tag=as_tag,
                     **{"def_" + k: v for k, v in lines_def.items()}, **{"all_" + k: v for k, v in lines_all.items()},
                     sam_flag=sam_flag, sam_pos=sam_pos, sam_nm=sam_nm, sam_cigar=np.array(sam_cigar), sam_md=np.array(sam_md),

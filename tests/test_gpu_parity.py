@@ -320,13 +320,18 @@ def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None):
     import ctypes as C, os, torch
     from bwamem_hip import synth
     from bwamem_hip.lib import ChainOpt, ChainWorkspace, HostJobs, dev_jobs_to_host, seeds_to_host, load_library
-    n, L = reads.shape
-    flat = np.ascontiguousarray(reads.reshape(-1))
+    if isinstance(reads, np.ndarray):
+        n, L = reads.shape
+        flat = np.ascontiguousarray(reads.reshape(-1))
+        offs_h = np.arange(n, dtype=np.uint64) * L; lens_h = np.full(n, L, np.uint32)
+    else:                                                    # ragged: a list of reads of different lengths
+        flat, offs_h, lens_h = common.ragged_reads(reads)
+        n = len(reads)
     dindex = B.Index.upload(idx, pac=_pack_pac(g), l_pac=len(g))
-    ws = B.SeedWorkspace(n, n * L, max_cands=n * L, max_occ=1 << 22)
+    ws = B.SeedWorkspace(n, max(int(flat.size), 1), max_cands=max(int(flat.size), 64), max_occ=1 << 22)
     r = _to_dev(torch, synth.codes_to_ascii(flat))
-    o = (torch.arange(n, dtype=torch.int64) * L).to(torch.int32).cuda()
-    l = torch.full((n,), L, dtype=torch.int32).cuda()
+    o = torch.from_numpy(offs_h.astype(np.int64)).to(torch.int32).cuda()
+    l = torch.from_numpy(lens_h.astype(np.int64)).to(torch.int32).cuda()
     s = ws.seed_batch(dindex, r, o, l, 19)
     opt = ChainOpt(); load_library().bmh_chain_opt_default(C.byref(opt))
     for k, v in (opt_over or {}).items():
@@ -339,7 +344,7 @@ def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None):
     finally:
         os.environ.pop("BMH_CHAIN_HEAVY", None)
     got = dev_jobs_to_host(dj, n)
-    hj = HostJobs(g, flat, np.arange(n, dtype=np.uint64) * L, np.full(n, L, np.uint32), seeds_to_host(s, n), n_threads=4, opt=opt)
+    hj = HostJobs(g, flat, offs_h, lens_h, seeds_to_host(s, n), n_threads=4, opt=opt)
     assert int(dj.n_jobs) == hj.n_jobs and int(dj.n_regs) == hj.n_regs
     for k in ("qlen", "tlen", "h0", "job_read", "job_reg", "job_side", "qoff", "toff", "regs_per_read", "q", "t"):
         assert np.array_equal(got[k], getattr(hj, k)), k
@@ -393,6 +398,19 @@ def test_device_job_builder_matches_host_builder(hip, oracle):
     readsr, _ = synth.make_reads(gr, 2000, 150, seed=8, sub_rate=0.01)
     nj, nr, nh = _device_chain_case(hip, oracle, gr, idxr, readsr)
     assert nh > 20, nh
+    # ragged batch: reads of 30..250 bases (some shorter than a seed), N bases, the edge cases of the seeding tests
+    rng = np.random.default_rng(31)
+    rows = common.edge_reads(g, rng)
+    for _ in range(600):
+        ln = int(rng.integers(30, 251)); p = int(rng.integers(0, len(g) - ln))
+        x = g[p:p + ln].copy()
+        m = rng.random(ln) < 0.03; x[m] = (x[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+        if rng.random() < 0.5:
+            x = synth.revcomp(x)
+        if rng.random() < 0.1:
+            x[int(rng.integers(0, ln))] = 4
+        rows.append(x)
+    _device_chain_case(hip, oracle, g, idx, rows)
     _device_chain_case(hip, oracle, gr, idxr, readsr[:600], heavy=4, opt_over=dict(max_occ=20))
 
 
@@ -496,15 +514,18 @@ def test_cigar_batch_matches_reference_sam(hip, oracle):
     hj.free(); dindex.free()
 
 
-def test_reads_to_sam_fields_match_reference(hip, oracle):
-    """The whole chain on the repeat-rich golden read set: device seeding -> device chaining / jobs -> device extension
+@pytest.mark.parametrize("golden", ["post_golden.npz", "contigs_golden.npz"])
+def test_reads_to_sam_fields_match_reference(hip, oracle, golden):
+    """The whole chain on the repeat-rich golden read sets (one sequence / three sequences with reads across the cuts): device seeding -> device chaining / jobs -> device extension
     -> device merge -> bmh_finalize_regs (host, like the reference) -> bmh_cigar_batch (device) reproduces every SAM record
     the reference's own host code wrote (flag, POS, MAPQ, CIGAR, NM, AS, XS, MD), default run and -a."""
     import ast, ctypes as C, torch
     from bwamem_hip import fmindex, synth
     from bwamem_hip.lib import ChainOpt, ChainWorkspace, PostOpt, cigar_batch, load_library, _np_ptr, _u8p, _u64p, _i32p, _u32p
-    z = np.load(os.path.join(common.GOLDEN, "post_golden.npz"))
+    z = np.load(os.path.join(common.GOLDEN, golden))
     g = synth.make_genome(int(z["n_genome"]), seed=int(z["genome_seed"]), **ast.literal_eval(str(z["genome_kw"])))
+    contigs = ast.literal_eval(str(z["contigs"])) or [("chrS", len(g))]
+    c_off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([c[1] for c in contigs])]), dtype=np.int64)
     idx = fmindex.build_fmd_index(g)
     reads = z["reads"]; n, L = reads.shape
     flat = np.ascontiguousarray(reads.reshape(-1))
@@ -516,6 +537,8 @@ def test_reads_to_sam_fields_match_reference(hip, oracle):
     l = torch.full((n,), L, dtype=torch.int32).cuda()
     s = ws.seed_batch(dindex, r, o, l, 19)
     cw = ChainWorkspace(n, max(int(s.n_seeds), 1)); cw.set_materialize(False)
+    if len(contigs) > 1:
+        cw.set_contigs(contigs)
     dj = cw.chain_batch(dindex, r, o, l, s)
     nr = int(dj.n_regs)
     out3 = torch.zeros(max(int(dj.n_jobs), 1), 3, dtype=torch.int32, device="cuda")
@@ -534,6 +557,7 @@ def test_reads_to_sam_fields_match_reference(hip, oracle):
         m = Lb.bmh_finalize_regs(C.byref(co), C.byref(ep), C.byref(po), len(g), _np_ptr(pac, _u8p), n, _np_ptr(flat, _u8p),
                                  _np_ptr(np.arange(n, dtype=np.uint64) * L, _u64p), _np_ptr(np.ascontiguousarray(regs_h), _i32p),
                                  _np_ptr(np.ascontiguousarray(dh["regs_per_read"]), _u32p), fr.ctypes.data_as(C.POINTER(C.c_float)),
+                                 len(contigs), c_off.ctypes.data_as(C.c_void_p),
                                  _np_ptr(out, _i32p), _np_ptr(opr, _u32p), 2)
         assert m >= 0
         out = out[:m]
@@ -549,10 +573,16 @@ def test_reads_to_sam_fields_match_reference(hip, oracle):
             if int(q[0]) in seen:
                 cs = cs.replace("S", "H")
             seen.add(int(q[0]))
-            got.append((int(q[0]), (16 if a[2] else 0) | int(q[14]), int(np.uint32(a[0])) + 1, int(q[13]), cs, int(a[4]), int(q[1]),
-                        int(q[10]) if q[12] < 0 else -1, bytes(md[k][: a[6]]).decode()))
+            pos = int(np.uint32(a[0])) | (int(a[1]) << 32)
+            rid = int(np.searchsorted(c_off, pos, side="right") - 1)
+            got.append((int(q[0]), (16 if a[2] else 0) | int(q[14]), pos - int(c_off[rid]) + 1, int(q[13]), cs, int(a[4]), int(q[1]),
+                        int(q[10]) if q[12] < 0 else -1, bytes(md[k][: a[6]]).decode(), contigs[rid][0]))
+        for rd in sorted(set(range(n)) - seen):
+            got.append((rd, 4, 0, 0, "*", -1, 0, 0, "", "*"))
+        got.sort(key=lambda t: t[0])
+        rn = [str(x) for x in z[tag + "rname"]]
         want = list(zip(z[tag + "read"].tolist(), z[tag + "flag"].tolist(), z[tag + "pos"].tolist(), z[tag + "mapq"].tolist(), [str(x) for x in z[tag + "cigar"]],
-                        z[tag + "nm"].tolist(), z[tag + "as_"].tolist(), z[tag + "xs"].tolist(), [str(x) for x in z[tag + "md"]]))
+                        z[tag + "nm"].tolist(), z[tag + "as_"].tolist(), z[tag + "xs"].tolist(), [str(x) for x in z[tag + "md"]], rn))
         assert len(got) == len(want), (tag, len(got), len(want))
         bad = [(a, b) for a, b in zip(got, want) if a != b]
         assert not bad, (tag, len(bad), bad[:3])

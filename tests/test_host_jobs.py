@@ -7,6 +7,7 @@ import hashlib
 import os
 
 import numpy as np
+import pytest
 
 import common
 from bwamem_hip import synth
@@ -123,7 +124,8 @@ def _golden_regions(oracle, z):
     g = synth.make_genome(int(z["n_genome"]), seed=int(z["genome_seed"]), **(ast.literal_eval(str(z["genome_kw"])) if "genome_kw" in z.files else {}))
     reads = z["reads"]; n, L = reads.shape
     seeds = {k: z[k] for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")}
-    hj = HostJobs(g, reads.reshape(-1), np.arange(n, dtype=np.uint64) * L, np.full(n, L, np.uint32), seeds, n_threads=4)
+    contigs = ast.literal_eval(str(z["contigs"])) if "contigs" in z.files else None
+    hj = HostJobs(g, reads.reshape(-1), np.arange(n, dtype=np.uint64) * L, np.full(n, L, np.uint32), seeds, n_threads=4, contigs=contigs)
     out3, _, _ = oracle.extend_batch(*hj.jobs())
     return g, reads, hj, hj.merge(out3)
 
@@ -134,13 +136,23 @@ def _pac(g):
     return np.ascontiguousarray(((codes[:, 0] << 6) | (codes[:, 1] << 4) | (codes[:, 2] << 2) | codes[:, 3]).astype(np.uint8))
 
 
-def test_finalize_regs_matches_reference_sam(oracle):
+@pytest.mark.parametrize("golden", ["post_golden.npz", "contigs_golden.npz"])
+def test_finalize_regs_matches_reference_sam(oracle, golden):
     """bmh_finalize_regs (mem_sort_dedup_patch, mem_mark_primary_se, mem_approx_mapq_se, the selection of mem_reg2sam)
     + the oracle's mem_reg2aln reproduce EVERY SAM record the reference's own host code wrote for a repeat-rich read
-    set -- default run and -a run (secondary alignments): flag, POS, MAPQ, CIGAR, NM, AS, XS, MD, in file order."""
-    z = np.load(os.path.join(common.GOLDEN, "post_golden.npz"))
+    set -- default run and -a run (secondary alignments): flag, RNAME, POS, MAPQ, CIGAR, NM, AS, XS, MD, in file order.
+    contigs_golden: the same genome cut into three sequences, an eighth of the reads across a cut (the job builder drops
+    seeds that bridge two sequences and clips extension windows to one, src/bwamem.c:437, src/bntseq.c:531-556)."""
+    import ast
+    z = np.load(os.path.join(common.GOLDEN, golden))
     g, reads, hj, regs = _golden_regions(oracle, z)
     pac = _pac(g)
+    contigs = ast.literal_eval(str(z["contigs"])) or [("chrS", len(g))]
+    c_off = np.concatenate([[0], np.cumsum([c[1] for c in contigs])])
+    # the extension jobs themselves: same multiset as the reference submitted
+    digs = sorted(hashlib.sha1(bytes([int(hj.h0[i]) & 255, int(hj.h0[i]) >> 8]) + hj.q[hj.qoff[i]:hj.qoff[i] + hj.qlen[i]].tobytes() + b"|" +
+                               hj.t[hj.toff[i]:hj.toff[i] + hj.tlen[i]].tobytes()).digest() for i in range(hj.n_jobs))
+    assert digs == [bytes(r) for r in z["job_digests"]]
     for tag, flag_all in (("def_", False), ("all_", True)):
         out, per_read = hj.finalize(regs, flag_all=flag_all, n_threads=2)
         assert per_read.sum() == len(out)
@@ -155,12 +167,19 @@ def test_finalize_regs_matches_reference_sam(oracle):
             if int(q[0]) in seen:
                 cs = cs.replace("S", "H")                       # every record of a read after its first is hard-clipped (mem_aln2sam)
             seen.add(int(q[0]))
-            got.append((int(q[0]), (16 if a["is_rev"] else 0) | int(q[14]), a["pos"] + 1, int(q[13]), cs, a["NM"], int(q[1]),
-                        int(q[10]) if q[12] < 0 else -1, a["MD"]))
+            rid = int(np.searchsorted(c_off, a["pos"], side="right") - 1)
+            got.append((int(q[0]), (16 if a["is_rev"] else 0) | int(q[14]), a["pos"] - int(c_off[rid]) + 1, int(q[13]), cs, a["NM"], int(q[1]),
+                        int(q[10]) if q[12] < 0 else -1, a["MD"], contigs[rid][0]))
+        for r in sorted(set(range(len(reads))) - seen):             # reads without a reported alignment: the unmapped record
+            got.append((r, 4, 0, 0, "*", -1, 0, 0, "", "*"))                 # mem_aln2sam prints AS:i:0 XS:i:0 for it
+        got.sort(key=lambda t: t[0])                                # (stable: the records of a read keep their order)
+        rn = [str(x) for x in z[tag + "rname"]] if tag + "rname" in z.files else [contigs[0][0]] * len(z[tag + "read"])
         want = list(zip(z[tag + "read"].tolist(), z[tag + "flag"].tolist(), z[tag + "pos"].tolist(), z[tag + "mapq"].tolist(), [str(x) for x in z[tag + "cigar"]],
-                        z[tag + "nm"].tolist(), z[tag + "as_"].tolist(), z[tag + "xs"].tolist(), [str(x) for x in z[tag + "md"]]))
+                        z[tag + "nm"].tolist(), z[tag + "as_"].tolist(), z[tag + "xs"].tolist(), [str(x) for x in z[tag + "md"]], rn))
         assert len(got) == len(want), (tag, len(got), len(want))
         bad = [(a, b) for a, b in zip(got, want) if a != b]
         assert not bad, (tag, len(bad), bad[:3])
     assert (z["all_flag"] & 0x100).sum() > 100 and (z["def_xs"] > 0).sum() > 100
+    if golden.startswith("contigs"):
+        assert len(set(str(x) for x in z["def_rname"])) == 4        # three sequences and '*'
     hj.free()

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "bmh_last_error", "bmh_device_count", "bmh_set_device", "bmh_index_upload", "bmh_index_from_device",
     "bmh_index_free", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
     "bmh_extend_batch", "bmh_extend_last_ms", "bmh_calib_gather",
-    "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs",
+    "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
     "bmh_chain_opt_default", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
     "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_materialize", "bmh_chain_batch",
     "bmh_chain_extend", "bmh_chain_merge", "bmh_cigar_batch",
@@ -56,7 +56,7 @@ class ChainOpt(C.Structure):
 class PostOpt(C.Structure):
     """bmh_post_opt_t"""
     _fields_ = [("T", C.c_int), ("mask_level_redun", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int),
-                ("flag_all", C.c_int), ("id0", C.c_int64)]
+                ("flag_all", C.c_int), ("id0", C.c_int64), ("XA_drop_ratio", C.c_float), ("max_XA_hits", C.c_int)]
 
 
 class DevJobsT(C.Structure):
@@ -133,6 +133,12 @@ def load_library() -> C.CDLL:
     L.bmh_finalize_regs.restype = C.c_int64
     L.bmh_finalize_regs.argtypes = [C.POINTER(ChainOpt), C.POINTER(ExtParams), C.POINTER(PostOpt), C.c_int64, _u8p, C.c_uint32, _u8p, _u64p,
                                     _i32p, _u32p, C.POINTER(C.c_float), C.c_int, C.c_void_p, _i32p, _u32p, C.c_int]
+    L.bmh_sam_need_cigar.restype = C.c_int64
+    L.bmh_sam_need_cigar.argtypes = [C.POINTER(PostOpt), _i32p, _u32p, C.c_uint32, _u8p]
+    L.bmh_format_sam.restype = C.c_void_p
+    L.bmh_format_sam.argtypes = [C.POINTER(PostOpt), C.c_uint32, C.POINTER(C.c_char_p), _u8p, _u64p, _u32p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p,
+                                 _i32p, _u32p, C.c_void_p, _i32p, _u32p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+    L.bmh_free.argtypes = [C.c_void_p]
     L.bmh_merge_regs.restype = C.c_int
     L.bmh_merge_regs.argtypes = [C.c_void_p, _i32p, _i32p]
     L.bmh_chain_ws_create.restype = C.c_void_p
@@ -312,6 +318,28 @@ def cigar_batch(index: Index, reads_t, offs_t, lens_t, regs_t, n: int, sel_t=Non
     if rc != 0:
         raise RuntimeError(f"bmh_cigar_batch rc={rc}: " + _err(L))
     return cigar, aln, md
+
+
+def format_sam(po: "PostOpt", names, reads_flat: np.ndarray, read_offs: np.ndarray, read_lens: np.ndarray, contigs, fin: np.ndarray,
+               fin_per_read: np.ndarray, slot: np.ndarray, aln: np.ndarray, cigar: np.ndarray, md: np.ndarray) -> str:
+    """bmh_format_sam on numpy arrays; contigs = list of (name, length)"""
+    L = load_library()
+    nm = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    cn = (C.c_char_p * len(contigs))(*[c[0].encode() for c in contigs])
+    off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([c[1] for c in contigs])[:-1]]), dtype=np.int64)
+    a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)
+    keep = [a(reads_flat, np.uint8), a(read_offs, np.uint64), a(read_lens, np.uint32), a(fin, np.int32), a(fin_per_read, np.uint32), a(slot, np.int64),
+            a(aln, np.int32), a(cigar, np.uint32), a(md, np.uint8)]
+    ln = C.c_size_t()
+    p = L.bmh_format_sam(C.byref(po), len(names), nm, _np_ptr(keep[0], _u8p), _np_ptr(keep[1], _u64p), _np_ptr(keep[2], _u32p), len(contigs), cn,
+                         off.ctypes.data_as(C.c_void_p), _np_ptr(keep[3], _i32p), _np_ptr(keep[4], _u32p), keep[5].ctypes.data_as(C.c_void_p),
+                         _np_ptr(keep[6], _i32p), _np_ptr(keep[7], _u32p), int(keep[7].shape[1]), keep[8].ctypes.data_as(C.c_void_p), int(keep[8].shape[1]),
+                         C.byref(ln))
+    if not p:
+        raise RuntimeError("bmh_format_sam: " + _err(L))
+    txt = C.string_at(p, ln.value).decode()
+    L.bmh_free(p)
+    return txt
 
 
 def dev_jobs_to_host(j: DevJobsT, n_reads: int) -> dict:

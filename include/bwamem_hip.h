@@ -170,6 +170,8 @@ typedef struct {
 	int mapQ_coef_fac;          /* (int)log(50) = 3 */
 	int flag_all;               /* MEM_F_ALL (-a): report secondary alignments too */
 	int64_t id0;                /* index of the batch's first read in the run (n_processed): seeds the tie-break hash */
+	float XA_drop_ratio;        /* 0.80: secondary hits scoring at least this share of their primary go to its XA tag */
+	int max_XA_hits;            /* 5: ... when there are no more than this many */
 } bmh_post_opt_t;
 void bmh_post_opt_default(bmh_post_opt_t *o);
 
@@ -187,6 +189,19 @@ int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *e
                           const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
                           int n_contigs, const int64_t *contig_offset,
                           int32_t *out, uint32_t *out_per_read, int n_threads);
+
+/* SAM records of single-end reads (mem_aln2sam, src/bwamem.c:1506-1683; XA tag: mem_gen_alt, src/bwamem_extra.c:97-150).
+ * bmh_sam_need_cigar marks (need[i] = 1) the records of bmh_finalize_regs that must go through bmh_cigar_batch first --
+ * the reported ones and the XA candidates -- and returns their number.  bmh_format_sam then takes, per record, its slot
+ * in the bmh_cigar_batch outputs (slot[i], -1 = none) and returns the text (malloc'd; free with bmh_free), one line per
+ * record in the reference's order, an unmapped record for reads without a reported alignment.  reads: nt4 codes (the
+ * path reads FASTA: QUAL is '*').  Pairing and ALT contigs are not modelled. */
+int64_t bmh_sam_need_cigar(const bmh_post_opt_t *po, const int32_t *fin, const uint32_t *fin_per_read, uint32_t n_reads, uint8_t *need);
+char *bmh_format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *const *names, const uint8_t *reads,
+                     const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
+                     const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
+                     const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap, size_t *len_out);
+void bmh_free(void *p);
 
 /* ------------------------------------------------- device job builder (SURVEY 8f ranks 1-2 on the GPU) */
 

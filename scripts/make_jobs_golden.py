@@ -23,12 +23,22 @@ g = synth.make_genome(n_genome, seed=42, **GENOME_KW)
 idx = fmindex.build_fmd_index(g, device="cuda:0")
 prefix = os.path.join(work, "g.fa"); fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g, contigs=CONTIGS)
 reads, _ = synth.make_reads(g, n_reads, L, seed=21, sub_rate=0.02, indel_frac=0.2)
+if REPEATS:                                   # chimeric reads (two loci, either strand): supplementary records and SA tags
+    rng = np.random.default_rng(6)
+    for i in range(3, n_reads, 25):
+        k = int(rng.integers(50, 100)); p1, p2 = (int(x) for x in rng.integers(0, n_genome - L, size=2))
+        a, b = g[p1:p1 + k].copy(), g[p2:p2 + L - k].copy()
+        if rng.random() < 0.5: a = synth.revcomp(a)
+        if rng.random() < 0.5: b = synth.revcomp(b)
+        reads[i] = np.concatenate([a, b])
 if CONTIGS:                                   # every eighth read straddles a cut between two sequences
     rng = np.random.default_rng(5)
     cuts = np.cumsum([c[1] for c in CONTIGS])[:-1]
     for i in range(0, n_reads, 8):
         c = int(cuts[i // 8 % len(cuts)]); p = c - int(rng.integers(10, L - 10))
         x = g[p:p + L].copy()
+        if i % 24 == 0:                        # some of them with two substitutions, so that parts still seed and align
+            for q in rng.integers(20, L - 20, size=2): x[q] = (x[q] + 1) & 3
         reads[i] = x if i % 16 else synth.revcomp(x)
 fq = os.path.join(work, "r.fa"); synth.write_fasta_reads(fq, reads)
 dump = os.path.join(work, "jobs.bin")
@@ -75,10 +85,13 @@ def pack(rows):
                 as_=np.array([r[6] for r in rows], np.int32), xs=np.array([r[7] for r in rows], np.int32), md=np.array([r[8] for r in rows]),
                 rname=np.array([r[9] for r in rows]))
 lines_def = pack(sam_lines(sam)); lines_all = pack(sam_lines(sam_a))
+sam_text = np.frombuffer("".join(l for l in open(sam) if l[0] != "@").encode(), dtype=np.uint8)       # the records, verbatim
+sam_header = np.frombuffer("".join(l for l in open(sam) if l.startswith("@SQ")).encode(), dtype=np.uint8)
 seeds = B.seed_file(prefix, fq, 19)
 np.savez_compressed(os.path.join(ROOT, "gpurun_out", OUT), n_genome=n_genome, genome_seed=42, genome_kw=repr(GENOME_KW), contigs=repr(CONTIGS), reads=reads,
                     job_digests=np.frombuffer(b"".join(digs), dtype=np.uint8).reshape(-1, 20), as_tag=as_tag,
                     **{"def_" + k: v for k, v in lines_def.items()}, **{"all_" + k: v for k, v in lines_all.items()},
+                    sam_text=sam_text, sam_header=sam_header,
                     sam_flag=sam_flag, sam_pos=sam_pos, sam_nm=sam_nm, sam_cigar=np.array(sam_cigar), sam_md=np.array(sam_md),
                     **{k: seeds[k] for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")})
 print("wrote", OUT, ":", len(digs), "jobs")

@@ -515,7 +515,7 @@ def test_cigar_batch_matches_reference_sam(hip, oracle):
 
 
 @pytest.mark.parametrize("golden", ["post_golden.npz", "contigs_golden.npz"])
-def test_reads_to_sam_fields_match_reference(hip, oracle, golden):
+def test_reads_to_sam_text_matches_reference(hip, oracle, golden):
     """The whole chain on the repeat-rich golden read sets (one sequence / three sequences with reads across the cuts): device seeding -> device chaining / jobs -> device extension
     -> device merge -> bmh_finalize_regs (host, like the reference) -> bmh_cigar_batch (device) reproduces every SAM record
     the reference's own host code wrote (flag, POS, MAPQ, CIGAR, NM, AS, XS, MD), default run and -a."""
@@ -586,4 +586,28 @@ def test_reads_to_sam_fields_match_reference(hip, oracle, golden):
         assert len(got) == len(want), (tag, len(got), len(want))
         bad = [(a, b) for a, b in zip(got, want) if a != b]
         assert not bad, (tag, len(bad), bad[:3])
+    # ... and the SAM text itself, byte for byte (default run): host finalize -> device CIGAR of every record the formatter
+    # needs (reported ones and XA candidates) -> bmh_format_sam
+    from bwamem_hip.lib import format_sam
+    po = PostOpt(); Lb.bmh_post_opt_default(C.byref(po))
+    out = np.zeros((max(nr, 1), 16), np.int32); opr = np.zeros(n, np.uint32)
+    fr = np.ascontiguousarray(dh["frac_rep"], dtype=np.float32)
+    m = Lb.bmh_finalize_regs(C.byref(co), C.byref(ep), C.byref(po), len(g), _np_ptr(pac, _u8p), n, _np_ptr(flat, _u8p),
+                             _np_ptr(np.arange(n, dtype=np.uint64) * L, _u64p), _np_ptr(np.ascontiguousarray(regs_h), _i32p),
+                             _np_ptr(np.ascontiguousarray(dh["regs_per_read"]), _u32p), fr.ctypes.data_as(C.POINTER(C.c_float)),
+                             len(contigs), c_off.ctypes.data_as(C.c_void_p), _np_ptr(out, _i32p), _np_ptr(opr, _u32p), 2)
+    out = np.ascontiguousarray(out[:m])
+    need = np.zeros(max(m, 1), np.uint8)
+    k = Lb.bmh_sam_need_cigar(C.byref(po), _np_ptr(out, _i32p), _np_ptr(opr, _u32p), n, _np_ptr(need, _u8p))
+    sel = np.nonzero(need[:m])[0].astype(np.int32)
+    assert k == len(sel)
+    cigar, aln, md = cigar_batch(dindex, r, o, l, torch.from_numpy(out.copy()).cuda(), len(sel), sel_t=torch.from_numpy(sel).cuda(), max_cigar=48, md_cap=640)
+    torch.cuda.synchronize()
+    slot = np.full(max(m, 1), -1, np.int64); slot[sel] = np.arange(len(sel))
+    txt = format_sam(po, [f"r{i}" for i in range(n)], flat, np.arange(n, dtype=np.uint64) * L, np.full(n, L, np.uint32), contigs, out, opr, slot,
+                     aln.cpu().numpy(), cigar.cpu().numpy().view(np.uint32), md.cpu().numpy())
+    want = bytes(z["sam_text"]).decode()
+    if txt != want:
+        gl, wl = txt.split("\n"), want.split("\n")
+        assert False, (len(gl), len(wl), [(a, b) for a, b in zip(gl, wl) if a != b][:2])
     cw.free(); ws.free(); dindex.free()

@@ -183,3 +183,42 @@ def test_finalize_regs_matches_reference_sam(oracle, golden):
     if golden.startswith("contigs"):
         assert len(set(str(x) for x in z["def_rname"])) == 4        # three sequences and '*'
     hj.free()
+
+
+@pytest.mark.parametrize("golden", ["jobs_golden.npz", "post_golden.npz", "contigs_golden.npz"])
+def test_sam_text_matches_reference(oracle, golden):
+    """bmh_finalize_regs + bmh_sam_need_cigar + bmh_format_sam (CIGARs from the oracle here; from the device in the GPU
+    suite) write the records of the reference's SAM file BYTE FOR BYTE: plain, repeat-rich (XS, XA tags, low MAPQ) and
+    three-sequence golden read sets."""
+    import ast, ctypes as C
+    from bwamem_hip.lib import PostOpt, format_sam, load_library, _np_ptr, _i32p, _u32p, _u8p
+    z = np.load(os.path.join(common.GOLDEN, golden))
+    g, reads, hj, regs = _golden_regions(oracle, z)
+    pac = _pac(g)
+    contigs = (ast.literal_eval(str(z["contigs"])) if "contigs" in z.files else None) or [("chrS", len(g))]
+    fin, per_read = hj.finalize(regs, flag_all=False, n_threads=2)
+    L = load_library()
+    po = PostOpt(); L.bmh_post_opt_default(C.byref(po))
+    need = np.zeros(max(len(fin), 1), np.uint8)
+    fin_c = np.ascontiguousarray(fin); pr_c = np.ascontiguousarray(per_read)
+    m = L.bmh_sam_need_cigar(C.byref(po), _np_ptr(fin_c, _i32p), _np_ptr(pr_c, _u32p), len(per_read), _np_ptr(need, _u8p))
+    idx = np.nonzero(need[: len(fin)])[0]
+    assert m == len(idx)
+    slot = np.full(max(len(fin), 1), -1, np.int64); slot[idx] = np.arange(len(idx))
+    aln = np.zeros((max(len(idx), 1), 8), np.int32); cigar = np.zeros((max(len(idx), 1), 48), np.uint32); md = np.zeros((max(len(idx), 1), 640), np.uint8)
+    for k, i in enumerate(idx):
+        q = fin[i]
+        rb = int(np.uint32(q[4])) | (int(q[5]) << 32); re = int(np.uint32(q[6])) | (int(q[7]) << 32)
+        a = oracle.reg2aln(pac, len(g), reads[q[0]], q[2], q[3], rb, re, q[8], reg_w=int(q[9]))
+        aln[k] = [a["pos"] & 0xFFFFFFFF if a["pos"] < 2 ** 31 else a["pos"] - 2 ** 32, a["pos"] >> 32, a["is_rev"], len(a["cigar"]), a["NM"], a["score"], len(a["MD"]), 0]
+        cigar[k, : len(a["cigar"])] = a["cigar"]
+        md[k, : len(a["MD"])] = np.frombuffer(a["MD"].encode(), np.uint8)
+    n, rl = reads.shape
+    txt = format_sam(po, [f"r{i}" for i in range(n)], reads.reshape(-1), np.arange(n, dtype=np.uint64) * rl, np.full(n, rl, np.uint32), contigs,
+                     fin, per_read, slot, aln, cigar, md)
+    want = bytes(z["sam_text"]).decode()
+    if txt != want:
+        gl, wl = txt.split("\n"), want.split("\n")
+        bad = [(a, b) for a, b in zip(gl, wl) if a != b]
+        assert False, (len(gl), len(wl), bad[:2])
+    hj.free()

@@ -87,4 +87,18 @@ print(f"reads {n} mapped {mapped} ({mapped/max(n,1):.4f}) correct position+stran
 lines = [l for l in open(sam) if l[0] != "@"][:3]
 print("".join(l[:200] + "\n" for l in lines))
 assert n == n_reads and ok / n > 0.97, "end-to-end accuracy too low"
+# the same job through the device-resident path (bwamem_hip.aligner): the records must equal the reference's, byte for byte
+from bwamem_hip.aligner import Aligner
+import io
+t = time.time()
+al = Aligner(prefix)
+buf = io.StringIO()
+al.align_file(fq, buf, batch_reads=4096)                  # several batches: the tie-break hash depends on the global read index
+dt2 = time.time() - t
+ours = [l for l in buf.getvalue().split("\n") if l and l[0] != "@"]
+theirs = [l.rstrip("\n") for l in open(sam) if l[0] != "@"]
+diff = [(a, b) for a, b in zip(ours, theirs) if a != b]
+print(f"device-resident path: {len(ours)} records in {dt2:.2f}s (reference host code: {len(theirs)} records in {dt:.2f}s); differing records: {len(diff)}")
+assert len(ours) == len(theirs) and not diff, diff[:2]
+print("SAM IDENTICAL")
 print("E2E DROP-IN OK")

@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(256) extend16_static_kernel(ext_args_t A)
 template <int C>
 __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 {
-	const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+	const int lane = threadIdx.x & 63, l16 = lane & 15;
 	const uint32_t n = A.count[0];
 	const uint32_t *ids = A.ids + A.count[1];
 	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;

@@ -389,7 +389,9 @@ __global__ void __launch_bounds__(256) expand_kernel(const res_t *__restrict__ r
 // walk reaches a sampled row stores its position and takes the next unclaimed occurrence of the
 // wave's chunk (wave-uniform cursor + ballot prefix, no atomics), so lanes do not idle behind the
 // longest walk of the wave (walk lengths are 0..sa_intv-1 and unpredictable).
+#ifndef LOCATE_PER_WAVE
 #define LOCATE_PER_WAVE 512
+#endif
 __global__ void __launch_bounds__(256) locate_kernel(fmd_dev_t f, uint64_t *__restrict__ rows, uint64_t n)
 {
 	const int lane = __lane_id();

@@ -28,8 +28,9 @@ nr = seeds_to_host(s, n_reads)["n_ref_pos"]
 os.environ["BMH_CHAIN_PROF_READ"] = str(int(nr.argmax()))
 print("seeds/read: max", nr.max(), "top", np.sort(nr)[-8:], ">32:", int((nr > 32).sum()), ">64:", int((nr > 64).sum()), ">128:", int((nr > 128).sum()), ">256:", int((nr > 256).sum()))
 lib = load_library()
-for it in range(12):
-    os.environ["BMH_CHAIN_HEAVY"] = ["32", "16", "64", "128", "256", "100000"][it // 2]
+SWEEP = os.environ.get("BMH_PROBE_SWEEP") is not None           # try several lane/wave thresholds of the device job builder
+for it in range(12 if SWEEP else 4):
+    os.environ["BMH_CHAIN_HEAVY"] = ["32", "16", "64", "128", "256", "100000"][it // 2] if SWEEP else "32"
     torch.cuda.synchronize(); t0 = time.perf_counter()
     dj = cw.chain_batch(dindex, dr.ascii, dr.offs, dr.lens, s)
     torch.cuda.synchronize(); t1 = time.perf_counter()

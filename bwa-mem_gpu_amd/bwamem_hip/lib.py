@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = [
     "bmh_index_free", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
     "bmh_extend_batch", "bmh_extend_last_ms", "bmh_calib_gather",
     "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
+    "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
     "bmh_chain_opt_default", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
     "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_materialize", "bmh_chain_batch",
     "bmh_chain_extend", "bmh_chain_merge", "bmh_cigar_batch",
@@ -57,6 +58,11 @@ class PostOpt(C.Structure):
     """bmh_post_opt_t"""
     _fields_ = [("T", C.c_int), ("mask_level_redun", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int),
                 ("flag_all", C.c_int), ("id0", C.c_int64), ("XA_drop_ratio", C.c_float), ("max_XA_hits", C.c_int)]
+
+
+class PeOpt(C.Structure):
+    """bmh_pe_opt_t"""
+    _fields_ = [("pen_unpaired", C.c_int), ("max_ins", C.c_int), ("max_matesw", C.c_int)]
 
 
 class DevJobsT(C.Structure):
@@ -139,6 +145,16 @@ def load_library() -> C.CDLL:
     L.bmh_format_sam.argtypes = [C.POINTER(PostOpt), C.c_uint32, C.POINTER(C.c_char_p), _u8p, _u64p, _u32p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p,
                                  _i32p, _u32p, C.c_void_p, _i32p, _u32p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
     L.bmh_free.argtypes = [C.c_void_p]
+    L.bmh_pe_opt_default.argtypes = [C.POINTER(PeOpt)]
+    L.bmh_finalize_pairs.restype = C.c_int64
+    L.bmh_finalize_pairs.argtypes = [C.POINTER(ChainOpt), C.POINTER(ExtParams), C.POINTER(PostOpt), C.POINTER(PeOpt), C.c_int64, _u8p, C.c_uint32, _u8p, _u64p,
+                                     _u32p, _i32p, _u32p, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p, _i32p, C.c_uint64, _u32p, _i32p, _i32p,
+                                     C.c_void_p, C.c_int]
+    L.bmh_sam_need_cigar_pe.restype = C.c_int64
+    L.bmh_sam_need_cigar_pe.argtypes = [C.POINTER(PostOpt), _i32p, _u32p, _i32p, C.c_uint32, _u8p]
+    L.bmh_format_sam_pe.restype = C.c_void_p
+    L.bmh_format_sam_pe.argtypes = [C.POINTER(PostOpt), C.c_uint32, C.POINTER(C.c_char_p), _u8p, _u64p, _u32p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p,
+                                    _i32p, _u32p, _i32p, _i32p, C.c_void_p, _i32p, _u32p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
     L.bmh_merge_regs.restype = C.c_int
     L.bmh_merge_regs.argtypes = [C.c_void_p, _i32p, _i32p]
     L.bmh_chain_ws_create.restype = C.c_void_p
@@ -320,9 +336,33 @@ def cigar_batch(index: Index, reads_t, offs_t, lens_t, regs_t, n: int, sel_t=Non
     return cigar, aln, md
 
 
+def finalize_pairs(copt, ep, po, genome_len: int, pac: np.ndarray, reads_flat: np.ndarray, read_offs: np.ndarray, read_lens: np.ndarray,
+                   regs: np.ndarray, regs_per_read: np.ndarray, frac_rep: np.ndarray, contigs=None, n_threads: int = 1):
+    """bmh_finalize_pairs -> (fin [m,16], per_read, h_rec, unflag, pes [4,5])"""
+    L = load_library()
+    pe = PeOpt(); L.bmh_pe_opt_default(C.byref(pe))
+    n = len(read_lens)
+    a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)
+    regs = a(regs, np.int32)
+    cap = len(regs) + 16 * n + 16
+    out = np.zeros((cap, 16), np.int32); opr = np.zeros(max(n, 1), np.uint32); h = np.zeros(max(n, 1), np.int32); uf = np.zeros(max(n, 1), np.int32)
+    pes = np.zeros((4, 5), np.float64)
+    ln = a([c[1] for c in contigs], np.int32) if contigs else None
+    off = a(np.concatenate([[0], np.cumsum(ln)[:-1]]), np.int64) if contigs else None
+    keep = [a(pac, np.uint8), a(reads_flat, np.uint8), a(read_offs, np.uint64), a(read_lens, np.uint32), a(regs_per_read, np.uint32), a(frac_rep, np.float32)]
+    m = L.bmh_finalize_pairs(C.byref(copt), C.byref(ep), C.byref(po), C.byref(pe), genome_len, _np_ptr(keep[0], _u8p), n, _np_ptr(keep[1], _u8p),
+                             _np_ptr(keep[2], _u64p), _np_ptr(keep[3], _u32p), _np_ptr(regs, _i32p), _np_ptr(keep[4], _u32p),
+                             keep[5].ctypes.data_as(C.POINTER(C.c_float)), len(contigs) if contigs else 1,
+                             off.ctypes.data_as(C.c_void_p) if contigs else None, ln.ctypes.data_as(C.c_void_p) if contigs else None,
+                             _np_ptr(out, _i32p), cap, _np_ptr(opr, _u32p), _np_ptr(h, _i32p), _np_ptr(uf, _i32p), pes.ctypes.data_as(C.c_void_p), n_threads)
+    if m < 0:
+        raise RuntimeError("bmh_finalize_pairs: " + _err(L))
+    return out[:m], opr[:n], h[:n], uf[:n], pes
+
+
 def format_sam(po: "PostOpt", names, reads_flat: np.ndarray, read_offs: np.ndarray, read_lens: np.ndarray, contigs, fin: np.ndarray,
-               fin_per_read: np.ndarray, slot: np.ndarray, aln: np.ndarray, cigar: np.ndarray, md: np.ndarray) -> str:
-    """bmh_format_sam on numpy arrays; contigs = list of (name, length)"""
+               fin_per_read: np.ndarray, slot: np.ndarray, aln: np.ndarray, cigar: np.ndarray, md: np.ndarray, h_rec=None, unflag=None) -> str:
+    """bmh_format_sam (or bmh_format_sam_pe when h_rec / unflag are given) on numpy arrays; contigs = list of (name, length)"""
     L = load_library()
     nm = (C.c_char_p * len(names))(*[n.encode() for n in names])
     cn = (C.c_char_p * len(contigs))(*[c[0].encode() for c in contigs])
@@ -331,10 +371,17 @@ def format_sam(po: "PostOpt", names, reads_flat: np.ndarray, read_offs: np.ndarr
     keep = [a(reads_flat, np.uint8), a(read_offs, np.uint64), a(read_lens, np.uint32), a(fin, np.int32), a(fin_per_read, np.uint32), a(slot, np.int64),
             a(aln, np.int32), a(cigar, np.uint32), a(md, np.uint8)]
     ln = C.c_size_t()
-    p = L.bmh_format_sam(C.byref(po), len(names), nm, _np_ptr(keep[0], _u8p), _np_ptr(keep[1], _u64p), _np_ptr(keep[2], _u32p), len(contigs), cn,
-                         off.ctypes.data_as(C.c_void_p), _np_ptr(keep[3], _i32p), _np_ptr(keep[4], _u32p), keep[5].ctypes.data_as(C.c_void_p),
-                         _np_ptr(keep[6], _i32p), _np_ptr(keep[7], _u32p), int(keep[7].shape[1]), keep[8].ctypes.data_as(C.c_void_p), int(keep[8].shape[1]),
-                         C.byref(ln))
+    if h_rec is not None:
+        hh, uu = a(h_rec, np.int32), a(unflag, np.int32)
+        p = L.bmh_format_sam_pe(C.byref(po), len(names), nm, _np_ptr(keep[0], _u8p), _np_ptr(keep[1], _u64p), _np_ptr(keep[2], _u32p), len(contigs), cn,
+                                off.ctypes.data_as(C.c_void_p), _np_ptr(keep[3], _i32p), _np_ptr(keep[4], _u32p), _np_ptr(hh, _i32p), _np_ptr(uu, _i32p),
+                                keep[5].ctypes.data_as(C.c_void_p), _np_ptr(keep[6], _i32p), _np_ptr(keep[7], _u32p), int(keep[7].shape[1]),
+                                keep[8].ctypes.data_as(C.c_void_p), int(keep[8].shape[1]), C.byref(ln))
+    else:
+        p = L.bmh_format_sam(C.byref(po), len(names), nm, _np_ptr(keep[0], _u8p), _np_ptr(keep[1], _u64p), _np_ptr(keep[2], _u32p), len(contigs), cn,
+                             off.ctypes.data_as(C.c_void_p), _np_ptr(keep[3], _i32p), _np_ptr(keep[4], _u32p), keep[5].ctypes.data_as(C.c_void_p),
+                             _np_ptr(keep[6], _i32p), _np_ptr(keep[7], _u32p), int(keep[7].shape[1]), keep[8].ctypes.data_as(C.c_void_p), int(keep[8].shape[1]),
+                             C.byref(ln))
     if not p:
         raise RuntimeError("bmh_format_sam: " + _err(L))
     txt = C.string_at(p, ln.value).decode()

@@ -1,0 +1,421 @@
+// Host restatement of the reference's paired-end tail (BASELINE configs[3]):
+//   mem_pestat    /root/reference/src/bwamem_pair.c:46-117    insert-size distribution of the batch per orientation
+//   mem_matesw    :119-188   mate rescue: local alignment of the mate in the window the distribution predicts
+//                            (ksw_align2 -> local_sw.cpp), new regions merged into the mate's list
+//   mem_pair      :190-251   best pair of regions under the distribution (score + log-likelihood of the insert size)
+//   mem_sam_pe    :257-397   which regions are written for the two reads, their MAPQ and pair flags
+// Runs on host threads like the reference; regions come from bmh_merge_regs / bmh_chain_merge, CIGARs are added
+// afterwards by bmh_cigar_batch and the text by bmh_format_sam_pe (sam_format.cpp).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "bmh_internal.h"
+#include "klib_sort.h"
+#include "local_sw.h"
+#include "regs_post.h"
+
+using namespace rp;
+
+namespace {
+
+struct Pes { int low, high, failed; double avg, std; };
+
+struct PCtx {
+	Ctx x; const bmh_pe_opt_t *pe; Pes pes[4];
+	const int64_t *ctg_off; const int32_t *ctg_len;
+	const uint8_t *reads; const uint64_t *offs; const uint32_t *lens;
+};
+
+inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)      // mem_infer_dir
+{
+	const int r1 = b1 >= l_pac, r2 = b2 >= l_pac;
+	const int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+	*dist = p2 > b1 ? p2 - b1 : b1 - p2;
+	return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+
+int cal_sub(const PCtx &c, const std::vector<Reg> &r)
+{
+	size_t j;
+	for (j = 1; j < r.size(); ++j) {
+		const int b_max = r[j].qb > r[0].qb ? r[j].qb : r[0].qb;
+		const int e_min = r[j].qe < r[0].qe ? r[j].qe : r[0].qe;
+		if (e_min > b_max) {
+			const int min_l = r[j].qe - r[j].qb < r[0].qe - r[0].qb ? r[j].qe - r[j].qb : r[0].qe - r[0].qb;
+			if (e_min - b_max >= min_l * c.x.co->mask_level) break;
+		}
+	}
+	return j < r.size() ? r[j].score : c.x.co->min_seed_len * c.x.ep->a;
+}
+
+void pestat(PCtx &c, const std::vector<std::vector<Reg>> &regs)                // mem_pestat
+{
+	std::vector<uint64_t> isize[4];
+	memset(c.pes, 0, sizeof(c.pes));
+	const size_t n = regs.size();
+	for (size_t i = 0; i < n >> 1; ++i) {
+		const std::vector<Reg> &r0 = regs[i << 1], &r1 = regs[i << 1 | 1];
+		if (r0.empty() || r1.empty()) continue;
+		if (cal_sub(c, r0) > 0.8 * r0[0].score) continue;
+		if (cal_sub(c, r1) > 0.8 * r1[0].score) continue;
+		if (r0[0].rid != r1[0].rid) continue;
+		int64_t is;
+		const int dir = infer_dir(c.x.l_pac, r0[0].rb, r1[0].rb, &is);
+		if (is && is <= c.pe->max_ins) isize[dir].push_back((uint64_t)is);
+	}
+	for (int d = 0; d < 4; ++d) {
+		Pes *r = &c.pes[d];
+		std::vector<uint64_t> &q = isize[d];
+		if (q.size() < 10) { r->failed = 1; continue; }
+		std::sort(q.begin(), q.end());
+		const int p25 = (int)q[(int)(.25 * q.size() + .499)], p50 = (int)q[(int)(.50 * q.size() + .499)], p75 = (int)q[(int)(.75 * q.size() + .499)];
+		(void)p50;
+		r->low = (int)(p25 - 2.0 * (p75 - p25) + .499);
+		if (r->low < 1) r->low = 1;
+		r->high = (int)(p75 + 2.0 * (p75 - p25) + .499);
+		size_t x = 0;
+		r->avg = 0;
+		for (uint64_t v : q) if (v >= (uint64_t)r->low && v <= (uint64_t)r->high) { r->avg += v; ++x; }
+		r->avg /= x;
+		r->std = 0;
+		for (uint64_t v : q) if (v >= (uint64_t)r->low && v <= (uint64_t)r->high) r->std += (v - r->avg) * (v - r->avg);
+		r->std = sqrt(r->std / x);
+		r->low = (int)(p25 - 3.0 * (p75 - p25) + .499);
+		r->high = (int)(p75 + 3.0 * (p75 - p25) + .499);
+		if (r->low > r->avg - 4.0 * r->std) r->low = (int)(r->avg - 4.0 * r->std + .499);
+		if (r->high < r->avg - 4.0 * r->std) r->high = (int)(r->avg + 4.0 * r->std + .499);
+		if (r->low < 1) r->low = 1;
+	}
+	size_t mx = 0;
+	for (int d = 0; d < 4; ++d) mx = mx > isize[d].size() ? mx : isize[d].size();
+	for (int d = 0; d < 4; ++d) if (c.pes[d].failed == 0 && isize[d].size() < mx * 0.05) c.pes[d].failed = 1;
+}
+
+int pos2rid_c(const PCtx &c, int64_t pos_f) { return pos2rid(c.x, pos_f); }
+
+// bns_fetch_seq (src/bntseq.c:531-556): [beg, end) clipped to the sequence (and strand) that holds mid
+bool fetch_window(const PCtx &c, int64_t *beg, int64_t mid, int64_t *end, int *rid, std::vector<uint8_t> &seq)
+{
+	if (*end < *beg) std::swap(*beg, *end);
+	const int64_t l_pac = c.x.l_pac;
+	const bool is_rev = mid >= l_pac;
+	*rid = pos2rid_c(c, is_rev ? (l_pac << 1) - 1 - mid : mid);
+	int64_t far_beg = c.x.n_contigs > 1 ? c.ctg_off[*rid] : 0, far_end = far_beg + (c.x.n_contigs > 1 ? c.ctg_len[*rid] : l_pac);
+	if (is_rev) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
+	*beg = *beg > far_beg ? *beg : far_beg;
+	*end = *end < far_end ? *end : far_end;
+	if (*beg >= *end) { seq.clear(); return false; }
+	seq.resize((size_t)(*end - *beg));
+	for (int64_t i = *beg; i < *end; ++i) seq[(size_t)(i - *beg)] = (uint8_t)text_base(c.x.pac, l_pac, i);
+	return true;
+}
+
+int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector<Reg> &ma)        // mem_matesw
+{
+	const int64_t l_pac = c.x.l_pac;
+	int skip[4], n = 0;
+	for (int r = 0; r < 4; ++r) skip[r] = c.pes[r].failed ? 1 : 0;
+	for (const Reg &m : ma) {
+		int64_t dist;
+		const int r = infer_dir(l_pac, a.rb, m.rb, &dist);
+		if (dist >= c.pes[r].low && dist <= c.pes[r].high) skip[r] = 1;
+	}
+	if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
+	std::vector<uint8_t> rev, ref, seqbuf;
+	for (int r = 0; r < 4; ++r) {
+		if (skip[r]) continue;
+		const int is_rev = (r >> 1 != (r & 1)), is_larger = !(r >> 1);
+		const uint8_t *seq = ms;
+		if (is_rev) {
+			rev.resize(l_ms);
+			for (int i = 0; i < l_ms; ++i) rev[l_ms - 1 - i] = ms[i] < 4 ? 3 - ms[i] : 4;
+			seq = rev.data();
+		}
+		int64_t rb, re;
+		if (!is_rev) {
+			rb = is_larger ? a.rb + c.pes[r].low : a.rb - c.pes[r].high;
+			re = (is_larger ? a.rb + c.pes[r].high : a.rb - c.pes[r].low) + l_ms;
+		} else {
+			rb = (is_larger ? a.rb + c.pes[r].low : a.rb - c.pes[r].high) - l_ms;
+			re = is_larger ? a.rb + c.pes[r].high : a.rb - c.pes[r].low;
+		}
+		if (rb < 0) rb = 0;
+		if (re > l_pac << 1) re = l_pac << 1;
+		int rid = -1;
+		bool have = false;
+		if (rb < re) have = fetch_window(c, &rb, (rb + re) >> 1, &re, &rid, ref);
+		if (have && a.rid == rid && re - rb >= c.x.co->min_seed_len) {
+			const int xtra = BMH_SW_XSUBO | BMH_SW_XSTART | (l_ms * c.x.ep->a < 250 ? BMH_SW_XBYTE : 0) | (c.x.co->min_seed_len * c.x.ep->a);
+			seqbuf.assign(seq, seq + l_ms);
+			const bmh_sw_result_t aln = bmh_local_sw(l_ms, seqbuf.data(), (int)(re - rb), ref.data(), *c.x.ep, xtra);
+			if (aln.score >= c.x.co->min_seed_len && aln.qb >= 0) {
+				Reg b; memset(&b, 0, sizeof(b));
+				b.rid = a.rid; b.is_alt = a.is_alt;
+				b.qb = is_rev ? l_ms - (aln.qe + 1) : aln.qb;
+				b.qe = is_rev ? l_ms - aln.qb : aln.qe + 1;
+				b.rb = is_rev ? (l_pac << 1) - (rb + aln.te + 1) : rb + aln.tb;
+				b.re = is_rev ? (l_pac << 1) - (rb + aln.tb) : rb + aln.te + 1;
+				b.score = aln.score; b.csub = aln.score2; b.secondary = -1;
+				b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+				size_t i;
+				for (i = 0; i < ma.size(); ++i) if (ma[i].score < b.score) break;     // keep ma sorted by score
+				ma.insert(ma.begin() + (long)i, b);
+			}
+			++n;
+		}
+		if (n) { const int m = sort_dedup_patch(c.x, nullptr, (int)ma.size(), ma.data()); ma.resize((size_t)m); }
+	}
+	return n;
+}
+
+struct P64 { uint64_t x, y; };
+inline bool p64_lt(const P64 &a, const P64 &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); }
+
+int pair_regs(const PCtx &c, std::vector<Reg> a[2], int id, int *sub, int *n_sub, int z[2], const int n_pri[2])     // mem_pair
+{
+	const int64_t l_pac = c.x.l_pac;
+	std::vector<P64> v, u;
+	for (int r = 0; r < 2; ++r)
+		for (int i = 0; i < n_pri[r]; ++i) {
+			const Reg &e = a[r][i];
+			P64 key;
+			key.x = (uint64_t)(e.rb < l_pac ? e.rb : (l_pac << 1) - 1 - e.rb);
+			key.x = (uint64_t)e.rid << 32 | (key.x - (uint64_t)(c.x.n_contigs > 1 ? c.ctg_off[e.rid] : 0));
+			key.y = (uint64_t)e.score << 32 | (uint64_t)(i << 2) | (uint64_t)((e.rb >= l_pac) << 1) | (uint64_t)r;
+			v.push_back(key);
+		}
+	std::sort(v.begin(), v.end(), p64_lt);
+	int y[4] = {-1, -1, -1, -1};
+	for (size_t i = 0; i < v.size(); ++i) {
+		for (int r = 0; r < 2; ++r) {
+			const int dir = r << 1 | (int)(v[i].y >> 1 & 1);
+			if (c.pes[dir].failed) continue;
+			const int which = r << 1 | (int)((v[i].y & 1) ^ 1);
+			if (y[which] < 0) continue;
+			for (int k = y[which]; k >= 0; --k) {
+				if ((int)(v[k].y & 3) != which) continue;
+				const int64_t dist = (int64_t)v[i].x - (int64_t)v[k].x;
+				if (dist > c.pes[dir].high) break;
+				if (dist < c.pes[dir].low) continue;
+				const double ns = (dist - c.pes[dir].avg) / c.pes[dir].std;
+				int q = (int)((v[i].y >> 32) + (v[k].y >> 32) + .721 * log(2. * erfc(fabs(ns) * M_SQRT1_2)) * c.x.ep->a + .499);
+				if (q < 0) q = 0;
+				P64 p;
+				p.y = (uint64_t)k << 32 | (uint64_t)i;
+				p.x = (uint64_t)q << 32 | (hash64(p.y ^ (uint64_t)(id << 8)) & 0xffffffffU);
+				u.push_back(p);
+			}
+		}
+		y[v[i].y & 3] = (int)i;
+	}
+	int ret;
+	if (!u.empty()) {
+		int tmp = c.x.ep->a + c.x.ep->b;
+		tmp = tmp > c.x.ep->o_del + c.x.ep->e_del ? tmp : c.x.ep->o_del + c.x.ep->e_del;
+		tmp = tmp > c.x.ep->o_ins + c.x.ep->e_ins ? tmp : c.x.ep->o_ins + c.x.ep->e_ins;
+		std::sort(u.begin(), u.end(), p64_lt);
+		const size_t i = (size_t)(u.back().y >> 32), k = (size_t)(u.back().y << 32 >> 32);
+		z[v[i].y & 1] = (int)(v[i].y << 32 >> 34);
+		z[v[k].y & 1] = (int)(v[k].y << 32 >> 34);
+		ret = (int)(u.back().x >> 32);
+		*sub = u.size() > 1 ? (int)(u[u.size() - 2].x >> 32) : 0;
+		*n_sub = 0;
+		for (long j = (long)u.size() - 2; j >= 0; --j) if (*sub - (int)(u[(size_t)j].x >> 32) <= tmp) ++*n_sub;
+	} else { ret = 0; *sub = 0; *n_sub = 0; }
+	return ret;
+}
+
+inline int raw_mapq(int diff, int a) { return (int)(6.02 * diff / a + .499); }
+
+struct ReadOut { std::vector<Reg> regs; std::vector<int> mapq, flag, rep, sec_all; int h; };     // h: record of the read's own alignment, -1 unmapped
+
+// mem_reg2sam's selection for one read (flags without strand; extra = pair flags)
+void select_se(const PCtx &c, ReadOut &o, int extra)
+{
+	const int n = (int)o.regs.size();
+	o.mapq.assign(n, 0); o.flag.assign(n, 0); o.rep.assign(n, 0);
+	int l = 0, mapq0 = 0;
+	for (int k = 0; k < n; ++k) {
+		const Reg &p = o.regs[k];
+		int mapq = p.secondary < 0 ? approx_mapq(c.x, p) : 0, flag = p.secondary >= 0 ? 0x100 : 0, rep = 1;
+		if (p.score < c.x.po->T) rep = 0;
+		else if (p.secondary >= 0 && !c.x.po->flag_all) rep = 0;
+		else if (p.secondary >= 0 && p.score < o.regs[p.secondary].score * c.x.co->drop_ratio) rep = 0;
+		if (rep) {
+			if (l && p.secondary < 0) flag |= 0x800;
+			if (l && mapq > mapq0) mapq = mapq0;
+			if (l == 0) mapq0 = mapq;
+			++l;
+			flag |= extra;
+		}
+		o.mapq[k] = mapq; o.flag[k] = flag; o.rep[k] = rep;
+	}
+}
+
+void sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // mem_sam_pe, decisions only
+{
+	std::vector<Reg> *a[2] = {&out[0].regs, &out[1].regs};
+	const uint8_t *seq[2] = {c.reads + c.offs[r0], c.reads + c.offs[r0 + 1]};
+	const int l_seq[2] = {(int)c.lens[r0], (int)c.lens[r0 + 1]};
+	int z[2] = {0, 0}, o, subo = 0, n_sub = 0, extra_flag = 1, n_pri[2];
+	{   // mate rescue for the best regions of each end
+		std::vector<Reg> b[2];
+		for (int i = 0; i < 2; ++i)
+			for (const Reg &r : *a[i]) if (r.score >= (*a[i])[0].score - c.pe->pen_unpaired) b[i].push_back(r);
+		for (int i = 0; i < 2; ++i)
+			for (size_t j = 0; j < b[i].size() && (int)j < c.pe->max_matesw; ++j)
+				matesw(c, b[i][j], l_seq[!i], seq[!i], *a[!i]);
+	}
+	for (int i = 0; i < 2; ++i) { mark_primary(c.x, (int)a[i]->size(), a[i]->data(), (int64_t)(id << 1 | (uint64_t)i)); n_pri[i] = (int)a[i]->size(); }
+	for (int i = 0; i < 2; ++i) { out[i].sec_all.resize(a[i]->size()); for (size_t j = 0; j < a[i]->size(); ++j) out[i].sec_all[j] = (*a[i])[j].secondary; }
+	bool paired = false;
+	if (n_pri[0] && n_pri[1]) {
+		std::vector<Reg> av[2] = {*a[0], *a[1]};
+		o = pair_regs(c, av, (int)id, &subo, &n_sub, z, n_pri);
+		if (o > 0) {
+			int is_multi[2];
+			for (int i = 0; i < 2; ++i) {
+				int j;
+				for (j = 1; j < n_pri[i]; ++j) if ((*a[i])[j].secondary < 0 && (*a[i])[j].score >= c.x.po->T) break;
+				is_multi[i] = j < n_pri[i] ? 1 : 0;
+			}
+			if (!is_multi[0] && !is_multi[1]) {
+				paired = true;
+				int q_pe, q_se[2];
+				const int score_un = (*a[0])[0].score + (*a[1])[0].score - c.pe->pen_unpaired;
+				subo = subo > score_un ? subo : score_un;
+				q_pe = raw_mapq(o - subo, c.x.ep->a);
+				if (n_sub > 0) q_pe -= (int)(4.343 * log(n_sub + 1) + .499);
+				if (q_pe < 0) q_pe = 0;
+				if (q_pe > 60) q_pe = 60;
+				q_pe = (int)(q_pe * (1. - .5 * ((*a[0])[0].frac_rep + (*a[1])[0].frac_rep)) + .499);
+				if (o > score_un) {
+					Reg *cc[2] = {&(*a[0])[z[0]], &(*a[1])[z[1]]};
+					for (int i = 0; i < 2; ++i) {
+						if (cc[i]->secondary >= 0) { cc[i]->sub = (*a[i])[cc[i]->secondary].score; cc[i]->secondary = -2; }
+						q_se[i] = approx_mapq(c.x, *cc[i]);
+					}
+					q_se[0] = q_se[0] > q_pe ? q_se[0] : q_pe < q_se[0] + 40 ? q_pe : q_se[0] + 40;
+					q_se[1] = q_se[1] > q_pe ? q_se[1] : q_pe < q_se[1] + 40 ? q_pe : q_se[1] + 40;
+					extra_flag |= 2;
+					q_se[0] = q_se[0] < raw_mapq(cc[0]->score - cc[0]->csub, c.x.ep->a) ? q_se[0] : raw_mapq(cc[0]->score - cc[0]->csub, c.x.ep->a);
+					q_se[1] = q_se[1] < raw_mapq(cc[1]->score - cc[1]->csub, c.x.ep->a) ? q_se[1] : raw_mapq(cc[1]->score - cc[1]->csub, c.x.ep->a);
+				} else {
+					z[0] = z[1] = 0;
+					q_se[0] = approx_mapq(c.x, (*a[0])[0]);
+					q_se[1] = approx_mapq(c.x, (*a[1])[0]);
+				}
+				for (int i = 0; i < 2; ++i) {             // the chosen region becomes the primary of its group (for the XA tag)
+					const int k = out[i].sec_all[z[i]];
+					if (k >= 0 && k < n_pri[i]) {
+						for (size_t j = 0; j < a[i]->size(); ++j) if (out[i].sec_all[j] == k || (int)j == k) out[i].sec_all[j] = z[i];
+						out[i].sec_all[z[i]] = -1;
+					}
+				}
+				for (int i = 0; i < 2; ++i) {
+					const int n = (int)a[i]->size();
+					out[i].mapq.assign(n, 0); out[i].flag.assign(n, 0); out[i].rep.assign(n, 0);
+					out[i].rep[z[i]] = 1; out[i].mapq[z[i]] = q_se[i];
+					out[i].flag[z[i]] = ((*a[i])[z[i]].secondary >= 0 ? 0x100 : 0) | 0x40 << i | extra_flag;
+					out[i].h = z[i];
+				}
+			}
+		}
+	}
+	if (!paired) {
+		int hh[2];
+		for (int i = 0; i < 2; ++i) hh[i] = (!a[i]->empty() && (*a[i])[0].score >= c.x.po->T) ? 0 : -1;
+		if (hh[0] >= 0 && hh[1] >= 0 && (*a[0])[0].rid == (*a[1])[0].rid) {
+			int64_t dist;
+			const int d = infer_dir(c.x.l_pac, (*a[0])[0].rb, (*a[1])[0].rb, &dist);
+			if (!c.pes[d].failed && dist >= c.pes[d].low && dist <= c.pes[d].high) extra_flag |= 2;
+		}
+		for (int i = 0; i < 2; ++i) { select_se(c, out[i], (i ? 0x81 : 0x41) | extra_flag); out[i].h = hh[i]; }
+	}
+}
+
+} // namespace
+
+extern "C" void bmh_pe_opt_default(bmh_pe_opt_t *o) { o->pen_unpaired = 17; o->max_ins = 10000; o->max_matesw = 50; }
+
+// Interleaved pairs (read 2i, 2i+1).  out[..][16] as bmh_finalize_regs (flag carries the pair bits 0x1 0x2 0x40 0x80 too,
+// [12] = the record's primary for the XA tag or -1); out_h[r] = record of read r's own alignment within its list (what the
+// mate's RNEXT / PNEXT / TLEN are taken from) or -1 if unmapped; out_unflag[r] = flag bits of the unmapped record of a read
+// without reported alignment; pes_out[4][5] = {low, high, failed, avg, std} as doubles.  Returns the record count (<= cap).
+extern "C" int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
+                                      int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                                      const uint32_t *read_lens, const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
+                                      int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
+                                      int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
+                                      int n_threads)
+{
+	if (!copt || !ep || !popt || !pe || !pac || !reads || !read_offs || !read_lens || !regs_per_read || !out || !out_per_read || !out_h || !out_unflag ||
+	    (n_contigs > 1 && (!contig_offset || !contig_len))) { bmh_set_error("bmh_finalize_pairs: null argument"); return BMH_EINVAL; }
+	if (n_reads & 1) { bmh_set_error("bmh_finalize_pairs: odd number of reads (pairs are interleaved)"); return BMH_EINVAL; }
+	if (!(popt->mapQ_coef_len > 0)) { bmh_set_error("bmh_finalize_pairs: mapQ_coef_len <= 0 is not restated"); return BMH_EINVAL; }
+	PCtx c;
+	c.x = {copt, ep, popt, l_pac, pac, n_contigs, contig_offset};
+	c.pe = pe; c.ctg_off = contig_offset; c.ctg_len = contig_len; c.reads = reads; c.offs = read_offs; c.lens = read_lens;
+	std::vector<uint64_t> in_off((size_t)n_reads + 1, 0);
+	for (uint32_t r = 0; r < n_reads; ++r) in_off[r + 1] = in_off[r] + regs_per_read[r];
+	std::vector<std::vector<Reg>> regs(n_reads);
+	if (n_threads < 1) n_threads = 1;
+	auto par = [&](auto fn, uint32_t n_units) {
+		if (n_threads == 1 || n_units < 2) { fn(0u, n_units); return; }
+		std::vector<std::thread> th;
+		for (int t = 0; t < n_threads; ++t) th.emplace_back(fn, (uint32_t)((uint64_t)n_units * t / n_threads), (uint32_t)((uint64_t)n_units * (t + 1) / n_threads));
+		for (auto &t : th) t.join();
+	};
+	par([&](uint32_t r0, uint32_t r1) {                         // per read: mem_sort_dedup_patch
+		for (uint32_t r = r0; r < r1; ++r) {
+			const int n_in = (int)regs_per_read[r];
+			regs[r].resize(n_in);
+			for (int i = 0; i < n_in; ++i) reg_from_record(c.x, regs_in + 8 * (in_off[r] + i), frac_rep ? frac_rep[r] : 0.f, regs[r][i]);
+			regs[r].resize((size_t)sort_dedup_patch(c.x, reads + read_offs[r], n_in, regs[r].data()));
+		}
+	}, n_reads);
+	pestat(c, regs);
+	if (pes_out) for (int d = 0; d < 4; ++d) { pes_out[5 * d] = c.pes[d].low; pes_out[5 * d + 1] = c.pes[d].high; pes_out[5 * d + 2] = c.pes[d].failed; pes_out[5 * d + 3] = c.pes[d].avg; pes_out[5 * d + 4] = c.pes[d].std; }
+	std::vector<ReadOut> ro(n_reads);
+	par([&](uint32_t p0, uint32_t p1) {
+		for (uint32_t p = p0; p < p1; ++p) {
+			ReadOut o2[2];
+			o2[0].regs.swap(regs[2 * p]); o2[1].regs.swap(regs[2 * p + 1]);
+			o2[0].h = o2[1].h = -1;
+			sam_pe(c, (uint64_t)(popt->id0 / 2) + p, 2 * p, o2);
+			ro[2 * p] = std::move(o2[0]); ro[2 * p + 1] = std::move(o2[1]);
+		}
+	}, n_reads / 2);
+	uint64_t w = 0;
+	for (uint32_t r = 0; r < n_reads; ++r) {
+		const ReadOut &o = ro[r];
+		const size_t n = o.regs.size();
+		if (w + n > cap) { bmh_set_error("bmh_finalize_pairs: more than %llu output regions", (unsigned long long)cap); return BMH_ECAPACITY; }
+		bool any = false;
+		for (size_t k = 0; k < n; ++k) {
+			const Reg &p = o.regs[k];
+			int32_t *q = out + 16 * (w + k);
+			q[0] = (int32_t)r; q[1] = p.score; q[2] = p.qb; q[3] = p.qe;
+			q[4] = (int32_t)(uint32_t)p.rb; q[5] = (int32_t)(p.rb >> 32); q[6] = (int32_t)(uint32_t)p.re; q[7] = (int32_t)(p.re >> 32);
+			q[8] = p.truesc; q[9] = p.w;            /* 0 / 0 for a rescued region (src/bwamem_pair.c:161: memset) */
+			q[10] = p.sub > p.csub ? p.sub : p.csub; q[11] = p.sub_n;
+			q[12] = o.sec_all.empty() ? p.secondary : o.sec_all[k];
+			q[13] = o.mapq[k]; q[14] = o.flag[k]; q[15] = o.rep[k];
+			any = any || o.rep[k];
+		}
+		out_per_read[r] = (uint32_t)n; out_h[r] = o.h;
+		// the unmapped record of a read without reported alignment carries the pair flags of its mem_reg2sam call
+		int uf = (r & 1) ? 0x81 : 0x41;
+		{   // extra_flag of the pair: recover the proper-pair bit from the mate's reported records (same value for both reads)
+			const ReadOut &m = ro[r ^ 1];
+			for (size_t k = 0; k < m.flag.size(); ++k) if (m.rep[k] && (m.flag[k] & 2)) uf |= 2;
+		}
+		out_unflag[r] = any ? 0 : uf;
+		w += n;
+	}
+	return (int64_t)w;
+}

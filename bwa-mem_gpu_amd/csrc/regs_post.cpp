@@ -15,25 +15,21 @@
 #include <vector>
 #include "bmh_internal.h"
 #include "klib_sort.h"
+#include "regs_post.h"
 
-namespace {
+namespace rp {
 
-struct Reg {
-	int64_t rb, re; int qb, qe, rid, score, truesc, sub, csub, sub_n, w, seedcov, secondary, n_comp, is_alt;
-	float frac_rep; uint64_t hash;
-};
-
-inline int text_base(const uint8_t *pac, int64_t l_pac, int64_t i)
+int text_base(const uint8_t *pac, int64_t l_pac, int64_t i)
 {
 	const bool rev = i >= l_pac;
 	const int64_t p = rev ? (l_pac << 1) - 1 - i : i;
 	const int c = (pac[p >> 2] >> ((~p & 3) << 1)) & 3;
 	return rev ? 3 - c : c;
 }
-inline int sc(const bmh_ext_params_t &p, int t, int q) { return (t > 3 || q > 3) ? -1 : (t == q ? p.a : -p.b); }
+static inline int sc(const bmh_ext_params_t &p, int t, int q) { return (t > 3 || q > 3) ? -1 : (t == q ? p.a : -p.b); }
 
 // score of ksw_global2 (no traceback)
-int global_score(const bmh_ext_params_t &p, int qlen, const uint8_t *q, int tlen, const uint8_t *t, int w)
+static int global_score(const bmh_ext_params_t &p, int qlen, const uint8_t *q, int tlen, const uint8_t *t, int w)
 {
 	const int NEG = -0x40000000, oe_del = p.o_del + p.e_del, oe_ins = p.o_ins + p.e_ins;
 	std::vector<int> Hd(qlen + 2), E(qlen + 2);
@@ -57,7 +53,7 @@ int global_score(const bmh_ext_params_t &p, int qlen, const uint8_t *q, int tlen
 }
 
 // the score bwa_gen_cigar2 returns for read[qb, qb+l_query) against text [rb, re)
-int gen_score(const bmh_ext_params_t &p, int w_, int64_t l_pac, const uint8_t *pac, int l_query, const uint8_t *query, int64_t rb, int64_t re)
+static int gen_score(const bmh_ext_params_t &p, int w_, int64_t l_pac, const uint8_t *pac, int l_query, const uint8_t *query, int64_t rb, int64_t re)
 {
 	if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return 0;
 	const int rlen = (int)(re - rb);
@@ -77,9 +73,6 @@ int gen_score(const bmh_ext_params_t &p, int w_, int64_t l_pac, const uint8_t *p
 	return global_score(p, l_query, qs.data(), rlen, rs.data(), w);
 }
 
-struct Ctx { const bmh_chain_opt_t *co; const bmh_ext_params_t *ep; const bmh_post_opt_t *po; int64_t l_pac; const uint8_t *pac;
-             int n_contigs; const int64_t *ctg_off; };
-
 int pos2rid(const Ctx &x, int64_t pos_f)          // bns_pos2rid, src/bntseq.c:349-363
 {
 	if (pos_f >= x.l_pac) return -1;
@@ -96,8 +89,9 @@ int pos2rid(const Ctx &x, int64_t pos_f)          // bns_pos2rid, src/bntseq.c:3
 	return mid;
 }
 
-int patch_reg(const Ctx &x, const uint8_t *query, const Reg &a, const Reg &b, int *w_out)        // mem_patch_reg
+static int patch_reg(const Ctx &x, const uint8_t *query, const Reg &a, const Reg &b, int *w_out)        // mem_patch_reg
 {
+	if (!query) return 0;                                   // mem_patch_reg without bns/pac/query (mem_matesw's call) never merges
 	if (a.rb < x.l_pac && b.rb >= x.l_pac) return 0;
 	if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
 	int w = (int)((a.re - b.rb) - (a.qe - b.qb));
@@ -160,7 +154,7 @@ int sort_dedup_patch(const Ctx &x, const uint8_t *query, int n, Reg *a)        /
 	return m;
 }
 
-inline uint64_t hash64(uint64_t key)
+uint64_t hash64(uint64_t key)
 {
 	key += ~(key << 32); key ^= (key >> 22); key += ~(key << 13); key ^= (key >> 8);
 	key += (key << 3); key ^= (key >> 15); key += ~(key << 27); key ^= (key >> 31);
@@ -219,7 +213,18 @@ int approx_mapq(const Ctx &x, const Reg &a)        // mem_approx_mapq_se, mapQ_c
 	return mapq;
 }
 
-} // namespace
+void reg_from_record(const Ctx &x, const int32_t *g, float frac_rep, Reg &p)
+{
+	memset(&p, 0, sizeof(p));
+	p.score = p.truesc = g[1]; p.qb = g[2]; p.qe = g[3];
+	p.rb = (int64_t)(uint32_t)g[4] | (int64_t)g[5] << 32; p.re = (int64_t)(uint32_t)g[6] | (int64_t)g[7] << 32;
+	// the sequence of the region = that of its chain's seeds: the extension windows never leave it (bns_fetch_seq)
+	p.rid = pos2rid(x, p.rb < x.l_pac ? p.rb : (x.l_pac << 1) - 1 - (p.re - 1)); p.w = x.co->w; p.secondary = -1; p.frac_rep = frac_rep;
+}
+
+} // namespace rp
+
+using namespace rp;
 
 extern "C" void bmh_post_opt_default(bmh_post_opt_t *o)        // mem_opt_init, src/bwamem.c:101-146
 {
@@ -252,12 +257,7 @@ extern "C" int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_
 			const int n_in = (int)regs_per_read[r];
 			a.resize(n_in);
 			for (int i = 0; i < n_in; ++i) {
-				const int32_t *g = regs_in + 8 * (in_off[r] + i);
-				Reg &p = a[i]; memset(&p, 0, sizeof(p));
-				p.score = p.truesc = g[1]; p.qb = g[2]; p.qe = g[3];
-				p.rb = (int64_t)(uint32_t)g[4] | (int64_t)g[5] << 32; p.re = (int64_t)(uint32_t)g[6] | (int64_t)g[7] << 32;
-				// the sequence of the region = that of its chain's seeds: the extension windows never leave it (bns_fetch_seq)
-				p.rid = pos2rid(x, p.rb < l_pac ? p.rb : (l_pac << 1) - 1 - (p.re - 1)); p.w = copt->w; p.secondary = -1; p.frac_rep = frac_rep ? frac_rep[r] : 0.f;
+				reg_from_record(x, regs_in + 8 * (in_off[r] + i), frac_rep ? frac_rep[r] : 0.f, a[i]);
 			}
 			int n = sort_dedup_patch(x, reads + read_offs[r], n_in, a.data());
 			mark_primary(x, n, a.data(), popt->id0 + r);

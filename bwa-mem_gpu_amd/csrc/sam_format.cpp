@@ -41,10 +41,20 @@ void put_cigar(std::string &s, const Rec &r, bool hard)
 	}
 }
 
+struct Mate { bool present; int rid; long long pos; int is_rev, n_cigar; const uint32_t *cigar; };
+
+int ref_len(int n, const uint32_t *cg)               // get_rlen, src/bwamem.c:1496-1504
+{
+	int l = 0;
+	for (int k = 0; k < n; ++k) { const int op = (int)(cg[k] & 0xf); if (op == 0 || op == 2) l += (int)(cg[k] >> 4); }
+	return l;
+}
+
 } // namespace
 
 extern "C" void bmh_free(void *p) { free(p); }
 
+// (get_pri_idx takes XA_drop_ratio as a double: the float 0.8 widened, so a hit at exactly 80 % of its primary is out)
 // need[i] = 1 for every record of bmh_finalize_regs that must go through bmh_cigar_batch before formatting: the reported
 // ones and the XA candidates (mem_gen_alt's two passes).  Returns their number.
 extern "C" int64_t bmh_sam_need_cigar(const bmh_post_opt_t *po, const int32_t *fin, const uint32_t *fin_per_read, uint32_t n_reads, uint8_t *need)
@@ -58,7 +68,7 @@ extern "C" int64_t bmh_sam_need_cigar(const bmh_post_opt_t *po, const int32_t *f
 		cnt.assign(n, 0);
 		for (int i = 0; i < n; ++i) need[base + i] = a[16 * i + 15] ? 1 : 0;
 		if (!po->flag_all) {
-			auto pri = [&](int i) { const int k = a[16 * i + 12]; return (k >= 0 && a[16 * i + 1] >= a[16 * k + 1] * po->XA_drop_ratio) ? k : -1; };
+			auto pri = [&](int i) { const int k = a[16 * i + 12]; return (k >= 0 && a[16 * i + 1] >= a[16 * k + 1] * (double)po->XA_drop_ratio) ? k : -1; };
 			for (int i = 0; i < n; ++i) { const int k = pri(i); if (k >= 0) ++cnt[k]; }
 			for (int i = 0; i < n; ++i) { const int k = pri(i); if (k >= 0 && cnt[k] <= po->max_XA_hits) need[base + i] = 1; }
 		}
@@ -69,34 +79,47 @@ extern "C" int64_t bmh_sam_need_cigar(const bmh_post_opt_t *po, const int32_t *f
 }
 
 // slot[i] = index of record i in the bmh_cigar_batch outputs (aln [..][8], cigar [..][max_cigar], md [..][md_cap]) or -1.
-// names / contig_names: arrays of C strings.  reads: nt4 codes.  Returns malloc'd text (bmh_free), *len_out its length.
-extern "C" char *bmh_format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *const *names, const uint8_t *reads,
-                                const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
-                                const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
-                                const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap, size_t *len_out)
+// names / contig_names: arrays of C strings.  reads: nt4 codes.  h_rec / unflag: NULL for single-end reads; for interleaved
+// pairs the outputs of bmh_finalize_pairs (own-alignment record per read, flags of the unmapped record).
+static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *const *names, const uint8_t *reads,
+                        const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
+                        const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
+                        const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap,
+                        const int32_t *h_rec, const int32_t *unflag, size_t *len_out)
 {
-	if (!po || !names || !reads || !read_offs || !read_lens || !contig_names || !fin_per_read || !len_out || (n_contigs > 1 && !contig_offset)) {
-		bmh_set_error("bmh_format_sam: null argument"); return nullptr;
-	}
 	std::string out;
 	out.reserve((size_t)n_reads * 400);
-	uint64_t base = 0;
+	std::vector<uint64_t> bases((size_t)n_reads + 1, 0);
+	for (uint32_t r = 0; r < n_reads; ++r) bases[r + 1] = bases[r] + fin_per_read[r];
 	std::vector<int> cnt, list;
 	std::vector<std::string> xa;
+	const bool pe = h_rec != nullptr;
+	auto rec_at = [&](uint64_t base, const int32_t *a, int i) {
+		Rec x; x.fin = a + 16 * i;
+		const int64_t s = slot[base + i];
+		x.aln = s >= 0 ? aln + 8 * s : nullptr; x.cigar = s >= 0 ? cigar + (size_t)max_cigar * s : nullptr; x.md = (s >= 0 && md) ? md + (size_t)md_cap * s : "";
+		return x;
+	};
 	for (uint32_t r = 0; r < n_reads; ++r) {
+		const uint64_t base = bases[r];
 		const int n = (int)fin_per_read[r];
 		const int32_t *a = fin + 16 * base;
-		auto rec = [&](int i) {
-			Rec x; x.fin = a + 16 * i;
-			const int64_t s = slot[base + i];
-			x.aln = s >= 0 ? aln + 8 * s : nullptr; x.cigar = s >= 0 ? cigar + (size_t)max_cigar * s : nullptr; x.md = (s >= 0 && md) ? md + (size_t)md_cap * s : "";
-			return x;
-		};
+		auto rec = [&](int i) { return rec_at(base, a, i); };
+		// the mate's own alignment (mem_sam_pe's h[!i])
+		Mate m; m.present = pe; m.rid = -1; m.pos = 0; m.is_rev = 0; m.n_cigar = 0; m.cigar = nullptr;
+		if (pe) {
+			const uint32_t mr = r ^ 1u;
+			if (h_rec[mr] >= 0) {
+				const Rec y = rec_at(bases[mr], fin + 16 * bases[mr], h_rec[mr]);
+				if (!y.aln) { bmh_set_error("bmh_format_sam_pe: the alignment record of read %u has no CIGAR", mr); return nullptr; }
+				m.pos = aln_pos(y.aln); m.rid = rid_of(n_contigs, contig_offset, m.pos); m.is_rev = y.aln[2]; m.n_cigar = y.aln[3]; m.cigar = y.cigar;
+			}
+		}
 		// XA strings per primary (mem_gen_alt)
 		xa.assign(n, std::string());
 		if (!po->flag_all) {
 			cnt.assign(n, 0);
-			auto pri = [&](int i) { const int k = a[16 * i + 12]; return (k >= 0 && a[16 * i + 1] >= a[16 * k + 1] * po->XA_drop_ratio) ? k : -1; };
+			auto pri = [&](int i) { const int k = a[16 * i + 12]; return (k >= 0 && a[16 * i + 1] >= a[16 * k + 1] * (double)po->XA_drop_ratio) ? k : -1; };
 			for (int i = 0; i < n; ++i) { const int k = pri(i); if (k >= 0) ++cnt[k]; }
 			for (int i = 0; i < n; ++i) {
 				const int k = pri(i);
@@ -115,26 +138,53 @@ extern "C" char *bmh_format_sam(const bmh_post_opt_t *po, uint32_t n_reads, cons
 		for (int i = 0; i < n; ++i) if (a[16 * i + 15]) list.push_back(i);
 		const uint8_t *seq = reads + read_offs[r];
 		const int l_seq = (int)read_lens[r];
-		if (list.empty()) {                                   // unmapped record
-			out += names[r]; out += "\t4\t*\t0\t0\t*\t*\t0\t0\t";
-			for (int i = 0; i < l_seq; ++i) out += "ACGTN"[seq[i] > 4 ? 4 : seq[i]];
+		auto mate_fields = [&](int p_rid, long long p_pos, int p_rev, int p_ncig, const uint32_t *p_cig, bool mate_mapped, int m_rid, long long m_pos, int m_rev,
+		                       int m_ncig, const uint32_t *m_cig) {
+			if (pe && mate_mapped) {
+				if (p_rid == m_rid) out += '='; else out += contig_names[m_rid];
+				out += '\t'; put_int(out, m_pos - (n_contigs > 1 ? contig_offset[m_rid] : 0) + 1); out += '\t';
+				if (p_rid == m_rid) {
+					const long long p0 = p_pos + (p_rev ? ref_len(p_ncig, p_cig) - 1 : 0), p1 = m_pos + (m_rev ? ref_len(m_ncig, m_cig) - 1 : 0);
+					if (m_ncig == 0 || p_ncig == 0) out += '0';
+					else put_int(out, -(p0 - p1 + (p0 > p1 ? 1 : p0 < p1 ? -1 : 0)));
+				} else out += '0';
+			} else out += "*\t0\t0";
+			out += '\t';
+		};
+		if (list.empty()) {                                   // unmapped record (mem_reg2sam's aa.n == 0 branch)
+			int flag = 4 | (unflag ? unflag[r] : 0);
+			const bool mm = pe && m.rid >= 0;
+			if (pe && m.rid < 0) flag |= 8;
+			const int p_rev = mm ? m.is_rev : 0;                 // an unmapped read takes its mate's coordinate and strand
+			if (p_rev) flag |= 0x10;
+			if (mm && m.is_rev) flag |= 0x20;
+			out += names[r]; out += '\t'; put_int(out, flag); out += '\t';
+			if (mm) { out += contig_names[m.rid]; out += '\t'; put_int(out, m.pos - (n_contigs > 1 ? contig_offset[m.rid] : 0) + 1); out += "\t0\t*\t"; }
+			else out += "*\t0\t0\t*\t";
+			mate_fields(mm ? m.rid : -1, m.pos, p_rev, 0, nullptr, mm, m.rid, m.pos, m.is_rev, m.n_cigar, m.cigar);
+			if (!p_rev) for (int i = 0; i < l_seq; ++i) out += "ACGTN"[seq[i] > 4 ? 4 : seq[i]];
+			else for (int i = l_seq - 1; i >= 0; --i) out += "TGCAN"[seq[i] > 4 ? 4 : seq[i]];
 			out += "\t*\tAS:i:0\tXS:i:0\n";
-			base += n;
 			continue;
 		}
 		for (size_t which = 0; which < list.size(); ++which) {
 			const int i = list[which];
 			const Rec x = rec(i);
 			if (!x.aln) { bmh_set_error("bmh_format_sam: record %d of read %u has no CIGAR (see bmh_sam_need_cigar)", i, r); return nullptr; }
-			const int flag = (x.aln[2] ? 0x10 : 0) | x.fin[14];
 			const long long pos = aln_pos(x.aln);
 			const int rid = rid_of(n_contigs, contig_offset, pos);
+			// a mapped read whose mate is unmapped lends it its coordinate and strand (mem_aln2sam :1518-1521)
+			const bool mate_mapped = pe && m.rid >= 0;
+			const int m_rid = mate_mapped ? m.rid : rid; const long long m_pos = mate_mapped ? m.pos : pos; const int m_rev = mate_mapped ? m.is_rev : (x.aln[2] ? 1 : 0);
+			int flag = (x.aln[2] ? 0x10 : 0) | x.fin[14];
+			if (pe) { if (m.rid < 0) flag |= 8; if (m_rev) flag |= 0x20; }
 			const bool hard = which > 0;
 			out += names[r]; out += '\t'; put_int(out, flag); out += '\t';
 			out += contig_names[rid]; out += '\t'; put_int(out, pos - (n_contigs > 1 ? contig_offset[rid] : 0) + 1); out += '\t';
 			put_int(out, x.fin[13]); out += '\t';
 			if (x.aln[3]) put_cigar(out, x, hard); else out += '*';
-			out += "\t*\t0\t0\t";
+			out += '\t';
+			mate_fields(rid, pos, x.aln[2] ? 1 : 0, x.aln[3], x.cigar, pe, m_rid, m_pos, m_rev, mate_mapped ? m.n_cigar : 0, mate_mapped ? m.cigar : nullptr);
 			if (flag & 0x100) out += "*\t*";
 			else {
 				int qb = 0, qe = l_seq;
@@ -171,11 +221,51 @@ extern "C" char *bmh_format_sam(const bmh_post_opt_t *po, uint32_t n_reads, cons
 			if (!xa[i].empty()) { out += "\tXA:Z:"; out += xa[i]; }
 			out += '\n';
 		}
-		base += n;
 	}
 	char *res = (char *)malloc(out.size() + 1);
 	if (!res) { bmh_set_error("bmh_format_sam: out of memory"); return nullptr; }
 	memcpy(res, out.data(), out.size()); res[out.size()] = 0;
 	*len_out = out.size();
 	return res;
+}
+
+extern "C" char *bmh_format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *const *names, const uint8_t *reads,
+                                const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
+                                const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
+                                const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap, size_t *len_out)
+{
+	if (!po || !names || !reads || !read_offs || !read_lens || !contig_names || !fin_per_read || !len_out || (n_contigs > 1 && !contig_offset)) {
+		bmh_set_error("bmh_format_sam: null argument"); return nullptr;
+	}
+	return format_sam(po, n_reads, names, reads, read_offs, read_lens, n_contigs, contig_names, contig_offset, fin, fin_per_read, slot, aln, cigar, max_cigar,
+	                  md, md_cap, nullptr, nullptr, len_out);
+}
+
+// interleaved pairs: fin / fin_per_read / h_rec / unflag from bmh_finalize_pairs (mem_aln2sam with the mate: flags 0x8 0x20,
+// RNEXT, PNEXT, TLEN; an unmapped read takes its mate's coordinate and strand)
+extern "C" char *bmh_format_sam_pe(const bmh_post_opt_t *po, uint32_t n_reads, const char *const *names, const uint8_t *reads,
+                                   const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
+                                   const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int32_t *h_rec,
+                                   const int32_t *unflag, const int64_t *slot, const int32_t *aln, const uint32_t *cigar, int max_cigar,
+                                   const char *md, int md_cap, size_t *len_out)
+{
+	if (!po || !names || !reads || !read_offs || !read_lens || !contig_names || !fin_per_read || !h_rec || !unflag || !len_out || (n_reads & 1) ||
+	    (n_contigs > 1 && !contig_offset)) { bmh_set_error("bmh_format_sam_pe: bad argument"); return nullptr; }
+	return format_sam(po, n_reads, names, reads, read_offs, read_lens, n_contigs, contig_names, contig_offset, fin, fin_per_read, slot, aln, cigar, max_cigar,
+	                  md, md_cap, h_rec, unflag, len_out);
+}
+
+// bmh_sam_need_cigar for pairs: additionally the own-alignment record of every read (the mate fields come from it)
+extern "C" int64_t bmh_sam_need_cigar_pe(const bmh_post_opt_t *po, const int32_t *fin, const uint32_t *fin_per_read, const int32_t *h_rec,
+                                         uint32_t n_reads, uint8_t *need)
+{
+	if (!h_rec) { bmh_set_error("bmh_sam_need_cigar_pe: null argument"); return BMH_EINVAL; }
+	int64_t total = bmh_sam_need_cigar(po, fin, fin_per_read, n_reads, need);
+	if (total < 0) return total;
+	uint64_t base = 0;
+	for (uint32_t r = 0; r < n_reads; ++r) {
+		if (h_rec[r] >= 0 && !need[base + h_rec[r]]) { need[base + h_rec[r]] = 1; ++total; }
+		base += fin_per_read[r];
+	}
+	return total;
 }

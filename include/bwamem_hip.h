@@ -203,6 +203,28 @@ char *bmh_format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *con
                      const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap, size_t *len_out);
 void bmh_free(void *p);
 
+/* ---- interleaved pairs (read 2i, 2i+1): mem_pestat, mem_matesw (mate rescue, host local alignment), mem_pair, mem_sam_pe
+ * (src/bwamem_pair.c).  Same inputs as bmh_finalize_regs plus read_lens and contig_len; out has room for `cap` records
+ * (mate rescue adds regions: regions_in + 16 per read is ample).  out_h[r]: the record of read r's own alignment within
+ * its list (-1 unmapped); out_unflag[r]: pair flags of the unmapped record of a read without reported alignment;
+ * pes_out[4][5] (optional) = {low, high, failed, avg, std} per orientation FF, FR, RF, RR.  popt->id0 = index of the
+ * batch's first READ in the run.  The insert-size statistics are those of the batch, as in the reference. */
+typedef struct { int pen_unpaired, max_ins, max_matesw; } bmh_pe_opt_t;       /* 17, 10000, 50 */
+void bmh_pe_opt_default(bmh_pe_opt_t *o);
+int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
+                           int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                           const uint32_t *read_lens, const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
+                           int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
+                           int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
+                           int n_threads);
+int64_t bmh_sam_need_cigar_pe(const bmh_post_opt_t *po, const int32_t *fin, const uint32_t *fin_per_read, const int32_t *h_rec,
+                              uint32_t n_reads, uint8_t *need);
+char *bmh_format_sam_pe(const bmh_post_opt_t *po, uint32_t n_reads, const char *const *names, const uint8_t *reads,
+                        const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
+                        const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int32_t *h_rec,
+                        const int32_t *unflag, const int64_t *slot, const int32_t *aln, const uint32_t *cigar, int max_cigar,
+                        const char *md, int md_cap, size_t *len_out);
+
 /* ------------------------------------------------- device job builder (SURVEY 8f ranks 1-2 on the GPU) */
 
 /* The same stage as bmh_build_jobs, on the device: seeds of bmh_seed_batch (still in HBM) -> chains -> filtered

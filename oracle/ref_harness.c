@@ -141,3 +141,17 @@ int ref_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
 	free(cg);
 	return n_cigar;
 }
+
+/* reference ksw_align2 (src/ksw.c:698), scalar SSE2 kernels (avx2 = 0), as mem_matesw calls it */
+void ref_align2(int qlen, uint8_t *query, int tlen, uint8_t *target, int a, int bmis, int o_del, int e_del, int o_ins, int e_ins, int xtra, int32_t out[7])
+{
+	int8_t mat[25];
+	int i, j, k;
+	for (i = k = 0; i < 4; ++i) {
+		for (j = 0; j < 4; ++j) mat[k++] = i == j ? a : -bmis;
+		mat[k++] = -1;
+	}
+	for (j = 0; j < 5; ++j) mat[k++] = -1;
+	kswr_t r = ksw_align2(qlen, query, tlen, target, 5, mat, o_del, e_del, o_ins, e_ins, xtra, 0, 0);
+	out[0] = r.score; out[1] = r.te; out[2] = r.qe; out[3] = r.score2; out[4] = r.te2; out[5] = r.tb; out[6] = r.qb;
+}

@@ -12,9 +12,11 @@ from bwamem_hip import fmindex, synth
 # usage: make_jobs_golden.py            -> jobs_golden.npz  (plain genome)
 #        make_jobs_golden.py repeats    -> post_golden.npz  (repeat-rich genome: secondary / supplementary alignments, XS, low MAPQ)
 #        make_jobs_golden.py contigs    -> contigs_golden.npz (the same repeat-rich genome cut into three sequences; reads cross the cuts)
+#        make_jobs_golden.py pe         -> pe_golden.npz (interleaved pairs, run with -p: insert-size statistics, mate rescue, pairing)
 MODE = sys.argv[1] if len(sys.argv) > 1 else "plain"
-REPEATS = MODE in ("repeats", "contigs")
-OUT = {"plain": "jobs_golden.npz", "repeats": "post_golden.npz", "contigs": "contigs_golden.npz"}[MODE]
+REPEATS = MODE in ("repeats", "contigs", "pe")
+PE = MODE == "pe"
+OUT = {"plain": "jobs_golden.npz", "repeats": "post_golden.npz", "contigs": "contigs_golden.npz", "pe": "pe_golden.npz"}[MODE]
 CONTIGS = [("ctgA", 120_000), ("ctgB", 100_037), ("ctgC", 79_963)] if MODE == "contigs" else None
 work = "/tmp/jobs_golden_" + MODE; os.makedirs(work, exist_ok=True)
 n_genome, n_reads, L = 300_000, 600, 150
@@ -23,7 +25,19 @@ g = synth.make_genome(n_genome, seed=42, **GENOME_KW)
 idx = fmindex.build_fmd_index(g, device="cuda:0")
 prefix = os.path.join(work, "g.fa"); fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g, contigs=CONTIGS)
 reads, _ = synth.make_reads(g, n_reads, L, seed=21, sub_rate=0.02, indel_frac=0.2)
-if REPEATS:                                   # chimeric reads (two loci, either strand): supplementary records and SA tags
+if PE:
+    reads, _ = synth.make_pairs(g, n_reads // 2, L, seed=21, sub_rate=0.02)
+    rng = np.random.default_rng(8)
+    for i in range(0, n_reads, 2):
+        kind = (i // 2) % 10
+        m = i + int(rng.integers(0, 2))                    # one mate of the pair
+        if kind == 3:                                      # a mate too diverged to seed: found only by mate rescue
+            x = reads[m]; q = rng.random(L) < 0.12; x[q] = (x[q] + rng.integers(1, 4, size=int(q.sum()))) & 3
+        elif kind == 5:                                    # discordant: the mate comes from elsewhere
+            p0 = int(rng.integers(0, n_genome - L)); x = g[p0:p0 + L].copy(); reads[m] = x if rng.random() < 0.5 else synth.revcomp(x)
+        elif kind == 7:                                    # unalignable mate
+            reads[m] = rng.integers(0, 4, size=L).astype(np.uint8)
+if REPEATS and not PE:                                   # chimeric reads (two loci, either strand): supplementary records and SA tags
     rng = np.random.default_rng(6)
     for i in range(3, n_reads, 25):
         k = int(rng.integers(50, 100)); p1, p2 = (int(x) for x in rng.integers(0, n_genome - L, size=2))
@@ -40,12 +54,20 @@ if CONTIGS:                                   # every eighth read straddles a cu
         if i % 24 == 0:                        # some of them with two substitutions, so that parts still seed and align
             for q in rng.integers(20, L - 20, size=2): x[q] = (x[q] + 1) & 3
         reads[i] = x if i % 16 else synth.revcomp(x)
-fq = os.path.join(work, "r.fa"); synth.write_fasta_reads(fq, reads)
+fq = os.path.join(work, "r.fa")
+if PE:
+    asc = synth.codes_to_ascii(reads)
+    with open(fq, "wb") as f:
+        for i in range(n_reads):
+            f.write(b">p%d\n" % (i // 2)); f.write(asc[i].tobytes()); f.write(b"\n")
+else:
+    synth.write_fasta_reads(fq, reads)
+EXTRA = ["-p"] if PE else []
 dump = os.path.join(work, "jobs.bin")
 if os.path.exists(dump): os.remove(dump)
 sam = os.path.join(work, "o.sam")
 with open(sam, "w") as f:
-    subprocess.check_call([os.path.join(ROOT, "build", "dropin", "bwa-gasal2"), "gase_aln", "-t", "1", "-l", str(L), prefix, fq], stdout=f,
+    subprocess.check_call([os.path.join(ROOT, "build", "dropin", "bwa-gasal2"), "gase_aln", "-t", "1", "-l", str(L)] + EXTRA + [prefix, fq], stdout=f,
                           stderr=subprocess.DEVNULL, cwd=work, env=dict(os.environ, BMH_GASAL_DUMP=dump))
 raw = np.fromfile(dump, dtype=np.uint8); p = 0; digs = []
 while p < raw.size:
@@ -59,7 +81,7 @@ for line in open(sam):
     if line[0] == "@": continue
     c = line.rstrip("\n").split("\t")
     if int(c[1]) & 0x900: continue
-    r = int(c[0][1:])
+    r = int(c[0][1:]) if not PE else 2 * int(c[0][1:]) + (1 if int(c[1]) & 0x80 else 0)
     sam_flag[r] = int(c[1]); sam_pos[r] = int(c[3]); sam_cigar[r] = c[5]
     for tag in c[11:]:
         if tag.startswith("AS:i:"): as_tag[r] = int(tag[5:])
@@ -73,11 +95,11 @@ def sam_lines(path):
         if line[0] == "@": continue
         c = line.rstrip("\n").split("\t")
         tags = {t[:2]: t[5:] for t in c[11:]}
-        rows.append((int(c[0][1:]), int(c[1]), int(c[3]), int(c[4]), c[5], int(tags.get("NM", -1)), int(tags.get("AS", -1)), int(tags.get("XS", -1)), tags.get("MD", ""), c[2]))
+        rows.append((int(c[0][1:]) if not PE else 2 * int(c[0][1:]) + (1 if int(c[1]) & 0x80 else 0), int(c[1]), int(c[3]), int(c[4]), c[5], int(tags.get("NM", -1)), int(tags.get("AS", -1)), int(tags.get("XS", -1)), tags.get("MD", ""), c[2]))
     return rows
 sam_a = os.path.join(work, "o_all.sam")
 with open(sam_a, "w") as f:
-    subprocess.check_call([os.path.join(ROOT, "build", "dropin", "bwa-gasal2"), "gase_aln", "-a", "-t", "1", "-l", str(L), prefix, fq], stdout=f,
+    subprocess.check_call([os.path.join(ROOT, "build", "dropin", "bwa-gasal2"), "gase_aln", "-a", "-t", "1", "-l", str(L)] + EXTRA + [prefix, fq], stdout=f,
                           stderr=subprocess.DEVNULL, cwd=work)
 def pack(rows):
     return dict(read=np.array([r[0] for r in rows], np.int32), flag=np.array([r[1] for r in rows], np.int32), pos=np.array([r[2] for r in rows], np.int64),

@@ -222,3 +222,42 @@ def test_sam_text_matches_reference(oracle, golden):
         bad = [(a, b) for a, b in zip(gl, wl) if a != b]
         assert False, (len(gl), len(wl), bad[:2])
     hj.free()
+
+
+def test_paired_end_sam_text_matches_reference(oracle):
+    """bmh_finalize_pairs (insert-size statistics, mate rescue with the host local alignment, pairing, mem_sam_pe's choices)
+    + bmh_format_sam_pe write the reference's PAIRED-END SAM records (gase_aln -p on interleaved pairs) byte for byte:
+    proper pairs, a mate found only by rescue, discordant and unmapped mates."""
+    import ctypes as C
+    from bwamem_hip.lib import ChainOpt, ExtParams, PostOpt, finalize_pairs, format_sam, load_library, _np_ptr, _i32p, _u32p, _u8p
+    z = np.load(os.path.join(common.GOLDEN, "pe_golden.npz"))
+    g, reads, hj, regs = _golden_regions(oracle, z)
+    pac = _pac(g)
+    contigs = [("chrS", len(g))]
+    n, rl = reads.shape
+    L = load_library()
+    co = ChainOpt(); L.bmh_chain_opt_default(C.byref(co)); ep = ExtParams.default(); po = PostOpt(); L.bmh_post_opt_default(C.byref(po))
+    flat = np.ascontiguousarray(reads.reshape(-1)); offs = np.arange(n, dtype=np.uint64) * rl; lens = np.full(n, rl, np.uint32)
+    fin, per_read, h_rec, unflag, pes = finalize_pairs(co, ep, po, len(g), pac, flat, offs, lens, regs, hj.regs_per_read, hj.frac_rep(), n_threads=2)
+    assert pes[1][2] == 0 and 300 < pes[1][3] < 400          # FR orientation: mean insert ~350
+    need = np.zeros(max(len(fin), 1), np.uint8)
+    fin_c = np.ascontiguousarray(fin); pr_c = np.ascontiguousarray(per_read); h_c = np.ascontiguousarray(h_rec)
+    m = L.bmh_sam_need_cigar_pe(C.byref(po), _np_ptr(fin_c, _i32p), _np_ptr(pr_c, _u32p), _np_ptr(h_c, _i32p), n, _np_ptr(need, _u8p))
+    idx = np.nonzero(need[: len(fin)])[0]
+    assert m == len(idx)
+    slot = np.full(max(len(fin), 1), -1, np.int64); slot[idx] = np.arange(len(idx))
+    aln = np.zeros((max(len(idx), 1), 8), np.int32); cigar = np.zeros((max(len(idx), 1), 48), np.uint32); md = np.zeros((max(len(idx), 1), 640), np.uint8)
+    for k, i in enumerate(idx):
+        q = fin[i]
+        rb = int(np.uint32(q[4])) | (int(q[5]) << 32); re = int(np.uint32(q[6])) | (int(q[7]) << 32)
+        a = oracle.reg2aln(pac, len(g), reads[q[0]], q[2], q[3], rb, re, q[8], reg_w=int(q[9]))
+        aln[k] = [a["pos"], a["pos"] >> 32, a["is_rev"], len(a["cigar"]), a["NM"], a["score"], len(a["MD"]), 0]
+        cigar[k, : len(a["cigar"])] = a["cigar"]
+        md[k, : len(a["MD"])] = np.frombuffer(a["MD"].encode(), np.uint8)
+    txt = format_sam(po, [f"p{i // 2}" for i in range(n)], flat, offs, lens, contigs, fin, per_read, slot, aln, cigar, md, h_rec=h_rec, unflag=unflag)
+    want = bytes(z["sam_text"]).decode()
+    if txt != want:
+        gl, wl = txt.split("\n"), want.split("\n")
+        bad = [(a, b) for a, b in zip(gl, wl) if a != b]
+        assert False, (len(gl), len(wl), len(bad), bad[:3])
+    hj.free()

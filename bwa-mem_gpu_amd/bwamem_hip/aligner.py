@@ -5,7 +5,9 @@ is the same job done through the device-level C ABI instead -- seeding, chaining
 region merge on the GPU (bmh_seed_batch, bmh_chain_batch, bmh_chain_extend, bmh_chain_merge), the region tail on host
 threads as in the reference (bmh_finalize_regs), CIGAR / NM / MD on the GPU (bmh_cigar_batch), SAM text on the host
 (bmh_format_sam).  It writes the records the reference writes, byte for byte (tests/test_gpu_parity.py).  torch is used
-for device memory only.  Paired-end reads, ALT contigs, read groups and FASTQ qualities are not handled.
+for device memory only.  Interleaved pairs (gase_aln -p) go through bmh_finalize_pairs / bmh_format_sam_pe; their
+insert-size statistics are per batch as in the reference, so identical output needs the reference's batching (one batch
+here = batch_reads reads).  ALT contigs, read groups and FASTQ qualities are not handled.
 """
 from __future__ import annotations
 
@@ -17,7 +19,7 @@ import torch
 
 from . import fmindex
 from .lib import (ChainOpt, ChainWorkspace, ExtParams, Index, PostOpt, SeedWorkspace, _memcpy_d2d, _np_ptr, _i32p, _u32p, _u64p, _u8p,
-                  cigar_batch, format_sam, load_library)
+                  cigar_batch, finalize_pairs, format_sam, load_library)
 
 _NT4 = np.full(256, 4, np.uint8)
 for _i, _c in enumerate(b"ACGT"):
@@ -68,8 +70,9 @@ class Aligner:
     def header(self) -> str:
         return "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in self.contigs)
 
-    def align_batch(self, names, seqs, id0: int = 0) -> str:
-        """SAM records of one batch of reads (ASCII uint8 arrays); id0 = index of its first read in the run"""
+    def align_batch(self, names, seqs, id0: int = 0, paired: bool = False) -> str:
+        """SAM records of one batch of reads (ASCII uint8 arrays); id0 = index of its first read in the run.
+        paired: the batch holds interleaved pairs (gase_aln -p); the insert-size statistics are those of the batch."""
         L, dev, n = self.L, self.dev, len(seqs)
         if n == 0:
             return ""
@@ -97,6 +100,8 @@ class Aligner:
         regs_h = np.ascontiguousarray(regs[:nr].cpu().numpy())
         rpr_h = np.ascontiguousarray(rpr.cpu().numpy().view(np.uint32)); fr_h = np.ascontiguousarray(fr.cpu().numpy())
         po = PostOpt(); L.bmh_post_opt_default(C.byref(po)); po.id0 = id0
+        if paired:
+            return self._finish_pairs(names, codes, offs, lens, r, o, l, regs_h, rpr_h, fr_h, po, cw, ws)
         fin = np.zeros((max(nr, 1), 16), np.int32); opr = np.zeros(n, np.uint32)
         m = L.bmh_finalize_regs(C.byref(self.copt), C.byref(self.ep), C.byref(po), self.l_pac, _np_ptr(self.pac, _u8p), n, _np_ptr(codes, _u8p),
                                 _np_ptr(offs, _u64p), _np_ptr(regs_h, _i32p), _np_ptr(rpr_h, _u32p), fr_h.ctypes.data_as(C.POINTER(C.c_float)),
@@ -121,11 +126,37 @@ class Aligner:
         cw.free(); ws.free()
         return txt
 
-    def align_file(self, reads_fa: str, out, batch_reads: int = 500_000) -> int:
+    def _finish_pairs(self, names, codes, offs, lens, r, o, l, regs_h, rpr_h, fr_h, po, cw, ws) -> str:
+        L, dev, n = self.L, self.dev, len(lens)
+        fin, opr, h_rec, unflag, _ = finalize_pairs(self.copt, self.ep, po, self.l_pac, self.pac, codes, offs, lens, regs_h, rpr_h, fr_h,
+                                                    contigs=self.contigs if len(self.contigs) > 1 else None, n_threads=self.n_threads)
+        fin = np.ascontiguousarray(fin); m = len(fin)
+        need = np.zeros(max(m, 1), np.uint8)
+        L.bmh_sam_need_cigar_pe(C.byref(po), _np_ptr(fin if m else np.zeros((1, 16), np.int32), _i32p), _np_ptr(np.ascontiguousarray(opr), _u32p),
+                                _np_ptr(np.ascontiguousarray(h_rec), _i32p), n, _np_ptr(need, _u8p))
+        sel = np.nonzero(need[:m])[0].astype(np.int32)
+        slot = np.full(max(m, 1), -1, np.int64); slot[sel] = np.arange(len(sel))
+        max_cigar, md_cap = 64, 1024
+        if len(sel):
+            cg, aln, md = cigar_batch(self.index, r, o, l, torch.from_numpy(fin.copy()).to(dev), len(sel), sel_t=torch.from_numpy(sel).to(dev),
+                                      params=self.ep, opt_w=self.copt.w, max_cigar=max_cigar, md_cap=md_cap)
+            aln_h = aln.cpu().numpy(); cg_h = cg.cpu().numpy().view(np.uint32); md_h = md.cpu().numpy()
+            if (aln_h[:, 7] & ~2).any():
+                raise RuntimeError("bmh_cigar_batch flagged an alignment (CIGAR or MD longer than the buffers)")
+        else:
+            aln_h = np.zeros((1, 8), np.int32); cg_h = np.zeros((1, max_cigar), np.uint32); md_h = np.zeros((1, md_cap), np.uint8)
+        txt = format_sam(po, names, codes, offs, lens, self.contigs, fin if m else np.zeros((1, 16), np.int32), opr, slot, aln_h, cg_h, md_h,
+                         h_rec=h_rec, unflag=unflag)
+        cw.free(); ws.free()
+        return txt
+
+    def align_file(self, reads_fa: str, out, batch_reads: int = 500_000, paired: bool = False) -> int:
         names, seqs = read_fasta_reads(reads_fa)
         out.write(self.header())
+        if paired:
+            batch_reads -= batch_reads & 1
         for b in range(0, len(seqs), batch_reads):
-            out.write(self.align_batch(names[b:b + batch_reads], seqs[b:b + batch_reads], id0=b))
+            out.write(self.align_batch(names[b:b + batch_reads], seqs[b:b + batch_reads], id0=b, paired=paired))
         return len(seqs)
 
     def close(self):

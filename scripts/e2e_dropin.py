@@ -63,6 +63,18 @@ if paired:
             okpos += 1
     print(f"PE reads {n} mapped {mapped} properly paired {proper} ({proper/max(n,1):.4f}) inside the simulated fragment {okpos} ({okpos/max(n,1):.4f})")
     assert n == 2 * (n_reads // 2) and proper / n > 0.95 and okpos / n > 0.97
+    # the same job through the device-resident path: one batch like the reference's (its insert-size statistics are per batch)
+    from bwamem_hip.aligner import Aligner
+    import io
+    al = Aligner(prefix)
+    buf = io.StringIO()
+    al.align_file(fq, buf, batch_reads=1 << 30, paired=True)
+    ours = [l for l in buf.getvalue().split("\n") if l and l[0] != "@"]
+    theirs = [l.rstrip("\n") for l in open(sam) if l[0] != "@"]
+    diff = [(a, b) for a, b in zip(ours, theirs) if a != b]
+    print(f"device-resident path: {len(ours)} records; reference host code: {len(theirs)} records; differing records: {len(diff)}")
+    assert len(ours) == len(theirs) and not diff, diff[:2]
+    print("SAM IDENTICAL")
     print("E2E DROP-IN OK")
     sys.exit(0)
 ok = mapped = n = 0

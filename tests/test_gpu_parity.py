@@ -209,8 +209,7 @@ def test_reference_gase_aln_end_to_end(hip, tmp_path):
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         out = r.stdout.decode()
         assert r.returncode == 0 and "E2E DROP-IN OK" in out, out[-3000:]
-        if "pe" not in extra:
-            assert "SAM IDENTICAL" in out, out[-3000:]       # bwamem_hip.aligner wrote the reference's records byte for byte
+        assert "SAM IDENTICAL" in out, out[-3000:]           # bwamem_hip.aligner wrote the reference's records byte for byte
 
 
 def test_host_job_builder_matches_reference_host_code(hip, tmp_path):
@@ -613,3 +612,34 @@ def test_reads_to_sam_text_matches_reference(hip, oracle, golden):
         gl, wl = txt.split("\n"), want.split("\n")
         assert False, (len(gl), len(wl), [(a, b) for a, b in zip(gl, wl) if a != b][:2])
     cw.free(); ws.free(); dindex.free()
+
+
+@pytest.mark.parametrize("golden", ["post_golden.npz", "contigs_golden.npz", "pe_golden.npz"])
+def test_aligner_writes_reference_sam(hip, tmp_path, golden):
+    """bwamem_hip.aligner (index files + FASTA -> SAM over the device-resident path) against the SAM text recorded from the
+    reference binary: single-end (repeat-rich, three sequences) and interleaved paired-end (-p)."""
+    import ast, io
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.aligner import Aligner
+    z = np.load(os.path.join(common.GOLDEN, golden))
+    g = synth.make_genome(int(z["n_genome"]), seed=int(z["genome_seed"]), **ast.literal_eval(str(z["genome_kw"])))
+    contigs = ast.literal_eval(str(z["contigs"])) if "contigs" in z.files else None
+    prefix = str(tmp_path / "g.fa")
+    fmindex.write_index(prefix, fmindex.build_fmd_index(g)); fmindex.write_bns(prefix, g, contigs=contigs)
+    reads = z["reads"]
+    pe = golden.startswith("pe_")
+    fq = str(tmp_path / "r.fa")
+    asc = synth.codes_to_ascii(reads)
+    with open(fq, "wb") as f:
+        for i in range(len(asc)):
+            f.write((b">p%d\n" % (i // 2)) if pe else (b">r%d\n" % i)); f.write(asc[i].tobytes()); f.write(b"\n")
+    al = Aligner(prefix, n_threads=2)
+    buf = io.StringIO()
+    al.align_file(fq, buf, batch_reads=1 << 30 if pe else 256, paired=pe)       # single-end: several batches
+    al.close()
+    body = "".join(l + "\n" for l in buf.getvalue().split("\n") if l and l[0] != "@")
+    want = bytes(z["sam_text"]).decode()
+    if body != want:
+        gl, wl = body.split("\n"), want.split("\n")
+        assert False, (len(gl), len(wl), [(a, b) for a, b in zip(gl, wl) if a != b][:2])
+    assert buf.getvalue().startswith(bytes(z["sam_header"]).decode())

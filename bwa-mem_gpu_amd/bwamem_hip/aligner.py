@@ -39,52 +39,132 @@ def read_ann(prefix: str):
     return contigs, int(l_pac)
 
 
-def read_fasta_reads(path: str):
-    names, seqs = [], []
-    with open(path, "rb") as f:
-        for line in f:
-            line = line.rstrip(b"\r\n")
-            if not line:
-                continue
-            if line[:1] == b">":
-                names.append(line[1:].split()[0].decode())
-            else:
-                seqs.append(np.frombuffer(line, dtype=np.uint8))
-    return names, seqs
+class ReadSet:
+    """reads of a FASTA file as flat arrays: ascii bases back to back + offsets / lengths, names as a NUL-separated blob"""
+
+    def __init__(self, ascii_, offs, lens, name_blob, name_off):
+        self.ascii, self.offs, self.lens, self.name_blob, self.name_off = ascii_, offs, lens, name_blob, name_off
+
+    def __len__(self):
+        return len(self.lens)
+
+    def slice(self, b0: int, b1: int) -> "ReadSet":
+        b1 = min(b1, len(self))
+        a0 = int(self.offs[b0]); a1 = int(self.offs[b1 - 1] + self.lens[b1 - 1])
+        n0 = int(self.name_off[b0]); n1 = int(self.name_off[b1]) if b1 < len(self) else len(self.name_blob)
+        return ReadSet(self.ascii[a0:a1], self.offs[b0:b1] - np.uint64(a0), self.lens[b0:b1], self.name_blob[n0:n1], self.name_off[b0:b1] - np.uint64(n0))
+
+    @classmethod
+    def from_lists(cls, names, seqs) -> "ReadSet":
+        lens = np.array([len(s) for s in seqs], np.uint32)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) if len(seqs) else np.zeros(0, np.uint64)
+        ascii_ = np.concatenate(seqs) if len(seqs) and lens.sum() else np.zeros(1, np.uint8)
+        enc = [n.encode() + b"\0" for n in names]
+        blob = np.frombuffer(b"".join(enc), dtype=np.uint8) if enc else np.zeros(1, np.uint8)
+        noff = np.concatenate([[0], np.cumsum([len(e) for e in enc])[:-1]]).astype(np.uint64) if enc else np.zeros(0, np.uint64)
+        return cls(ascii_, offs, lens, blob, noff)
+
+
+def read_fasta_reads(path: str) -> ReadSet:
+    """one '>' header line and one sequence line per read (the only layout the reference's seeding library parses,
+    src/GPUSeed/seed_gen.cu:1698-1728); parsed with array operations, no per-read Python work"""
+    buf = np.fromfile(path, dtype=np.uint8)
+    if buf.size == 0:
+        return ReadSet.from_lists([], [])
+    if buf[-1] != 10:
+        buf = np.concatenate([buf, np.array([10], np.uint8)])
+    nl = np.flatnonzero(buf == 10)
+    starts = np.concatenate([[0], nl[:-1] + 1]); ends = nl.copy()
+    cr = (ends > starts) & (buf[np.maximum(ends - 1, 0)] == 13)
+    ends = ends - cr
+    keep = ends > starts
+    starts, ends = starts[keep], ends[keep]
+    is_hdr = buf[starts] == ord(">")
+    if (~is_hdr).sum() != is_hdr.sum() or not is_hdr[0::2].all() or is_hdr[1::2].any():
+        raise ValueError("reads file: expected alternating '>' header and sequence lines")
+    hs, he = starts[0::2] + 1, ends[0::2]
+    ss, se = starts[1::2], ends[1::2]
+    lens = (se - ss).astype(np.uint32)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    # gather the sequence bytes (drop headers / newlines): a mask over the buffer
+    mark = np.zeros(buf.size + 1, np.int8); np.add.at(mark, ss, 1); np.add.at(mark, se, -1)
+    ascii_ = buf[np.cumsum(mark[:-1]) > 0]
+    # names: header up to the first blank, NUL-terminated in place
+    hb = buf.copy()
+    blank = (hb == 32) | (hb == 9)
+    first_blank = np.full(len(hs), -1, np.int64)
+    bl = np.flatnonzero(blank)
+    if bl.size:
+        j = np.searchsorted(bl, hs)
+        ok = (j < bl.size)
+        cand = np.where(ok, bl[np.minimum(j, bl.size - 1)], -1)
+        first_blank = np.where(ok & (cand < he), cand, -1)
+    name_end = np.where(first_blank >= 0, first_blank, he)
+    nlen = (name_end - hs).astype(np.int64)
+    noff = np.concatenate([[0], np.cumsum(nlen + 1)[:-1]]).astype(np.uint64)
+    blob = np.zeros(int((nlen + 1).sum()), np.uint8)
+    nmark = np.zeros(buf.size + 1, np.int8); np.add.at(nmark, hs, 1); np.add.at(nmark, name_end, -1)
+    src = np.flatnonzero(np.cumsum(nmark[:-1]) > 0)
+    dst = np.arange(src.size) + np.repeat(np.arange(len(hs)), nlen)          # one NUL after every name
+    blob[dst] = buf[src]
+    return ReadSet(ascii_ if ascii_.size else np.zeros(1, np.uint8), offs, lens, blob, noff)
 
 
 class Aligner:
-    def __init__(self, prefix: str, device: str = "cuda:0", n_threads: int = 0):
+    def __init__(self, prefix: str | None, device: str = "cuda:0", n_threads: int = 0, _mem=None):
         self.L = load_library()
         self.dev = torch.device(device)
-        idx = fmindex.read_index(prefix)
-        self.contigs, self.l_pac = read_ann(prefix)
-        pac = np.fromfile(prefix + ".pac", dtype=np.uint8)
-        self.pac = np.ascontiguousarray(np.concatenate([pac[: (self.l_pac + 3) // 4], np.zeros(2, np.uint8)]))
+        if _mem is not None:                                  # (index, contigs, packed reference) already in memory: from_memory()
+            idx, self.contigs, self.pac = _mem
+            self.l_pac = sum(c[1] for c in self.contigs)
+        else:
+            idx = fmindex.read_index(prefix)
+            self.contigs, self.l_pac = read_ann(prefix)
+            pac = np.fromfile(prefix + ".pac", dtype=np.uint8)
+            self.pac = np.ascontiguousarray(np.concatenate([pac[: (self.l_pac + 3) // 4], np.zeros(2, np.uint8)]))
         self.index = Index.upload(idx, pac=self.pac, l_pac=self.l_pac)
         self.copt = ChainOpt(); self.L.bmh_chain_opt_default(C.byref(self.copt))
         self.ep = ExtParams.default()
         self.n_threads = n_threads or (os.cpu_count() or 1)
+        self.profile = bool(os.environ.get("BMH_ALIGNER_PROFILE"))
         self.c_off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([c[1] for c in self.contigs])]), dtype=np.int64)
+
+    @classmethod
+    def from_memory(cls, idx, genome_fwd: np.ndarray, contigs=None, **kw) -> "Aligner":
+        """idx: fmindex.FMDIndex of genome_fwd (nt4 codes); contigs: [(name, length)], default one sequence chrS"""
+        pad = (-len(genome_fwd)) % 4
+        codes = np.concatenate([genome_fwd, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+        pac = ((codes[:, 0] << 6) | (codes[:, 1] << 4) | (codes[:, 2] << 2) | codes[:, 3]).astype(np.uint8)
+        pac = np.ascontiguousarray(np.concatenate([pac, np.zeros(2, np.uint8)]))
+        return cls(None, _mem=(idx, contigs or [("chrS", int(len(genome_fwd)))], pac), **kw)
 
     def header(self) -> str:
         return "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in self.contigs)
 
-    def align_batch(self, names, seqs, id0: int = 0, paired: bool = False) -> str:
-        """SAM records of one batch of reads (ASCII uint8 arrays); id0 = index of its first read in the run.
-        paired: the batch holds interleaved pairs (gase_aln -p); the insert-size statistics are those of the batch."""
-        L, dev, n = self.L, self.dev, len(seqs)
+    def align_batch(self, names, seqs=None, id0: int = 0, paired: bool = False, as_bytes: bool = False):
+        """SAM records of one batch of reads: a ReadSet, or (names, seqs) lists of str / ASCII uint8 arrays; id0 = index of
+        its first read in the run.  paired: interleaved pairs (gase_aln -p); the insert-size statistics are the batch's."""
+        rs = names if isinstance(names, ReadSet) else ReadSet.from_lists(names, seqs)
+        L, dev, n = self.L, self.dev, len(rs)
+        self._as_bytes = as_bytes
         if n == 0:
-            return ""
-        lens = np.array([len(s) for s in seqs], np.uint32)
-        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
-        ascii_ = np.concatenate(seqs) if lens.sum() else np.zeros(1, np.uint8)
+            return b"" if as_bytes else ""
+        names = (rs.name_blob, rs.name_off)
+        import time
+        _t = [time.perf_counter()]; _nm = []
+        def _lap(name):
+            if self.profile:
+                torch.cuda.synchronize(); _t.append(time.perf_counter()); _nm.append(name)
+        lens, offs, ascii_ = rs.lens, np.ascontiguousarray(rs.offs), rs.ascii
         codes = _NT4[ascii_]
         r = torch.from_numpy(ascii_.copy()).to(dev)
         o = torch.from_numpy(offs.astype(np.int64)).to(torch.int32).to(dev)
         l = torch.from_numpy(lens.astype(np.int64)).to(torch.int32).to(dev)
+        _lap("host prep + H2D")
         ws = SeedWorkspace(n, max(int(lens.sum()), 1))
+        _lap("seed workspace")
         s = ws.seed_batch(self.index, r, o, l, self.copt.min_seed_len)
+        _lap("seeding")
         cw = ChainWorkspace(n, max(int(s.n_seeds), 1), opt=self.copt)
         cw.set_materialize(False)
         if len(self.contigs) > 1:
@@ -93,13 +173,17 @@ class Aligner:
         nr, nj = int(dj.n_regs), int(dj.n_jobs)
         out3 = torch.zeros(max(nj, 1), 3, dtype=torch.int32, device=dev)
         regs = torch.zeros(max(nr, 1), 8, dtype=torch.int32, device=dev)
+        _lap("chain")
         cw.extend(out3, params=self.ep)
         cw.merge(out3, regs)
+        _lap("extend+merge")
         rpr = torch.empty(n, dtype=torch.int32, device=dev); fr = torch.empty(n, dtype=torch.float32, device=dev)
         _memcpy_d2d(rpr.data_ptr(), dj.d_regs_per_read, 4 * n); _memcpy_d2d(fr.data_ptr(), dj.d_frac_rep, 4 * n)
         regs_h = np.ascontiguousarray(regs[:nr].cpu().numpy())
         rpr_h = np.ascontiguousarray(rpr.cpu().numpy().view(np.uint32)); fr_h = np.ascontiguousarray(fr.cpu().numpy())
+        _lap("D2H regions")
         po = PostOpt(); L.bmh_post_opt_default(C.byref(po)); po.id0 = id0
+        self._lap = _lap; self._prof = (_t, _nm)
         if paired:
             return self._finish_pairs(names, codes, offs, lens, r, o, l, regs_h, rpr_h, fr_h, po, cw, ws)
         fin = np.zeros((max(nr, 1), 16), np.int32); opr = np.zeros(n, np.uint32)
@@ -109,22 +193,45 @@ class Aligner:
         if m < 0:
             raise RuntimeError("bmh_finalize_regs: " + (L.bmh_last_error() or b"").decode())
         fin = np.ascontiguousarray(fin[:m])
+        _lap("finalize (host)")
         need = np.zeros(max(m, 1), np.uint8)
         L.bmh_sam_need_cigar(C.byref(po), _np_ptr(fin, _i32p), _np_ptr(opr, _u32p), n, _np_ptr(need, _u8p))
         sel = np.nonzero(need[:m])[0].astype(np.int32)
         slot = np.full(max(m, 1), -1, np.int64); slot[sel] = np.arange(len(sel))
-        max_cigar, md_cap = 64, 1024
-        if len(sel):
-            cg, aln, md = cigar_batch(self.index, r, o, l, torch.from_numpy(fin.copy()).to(dev), len(sel), sel_t=torch.from_numpy(sel).to(dev),
-                                      params=self.ep, opt_w=self.copt.w, max_cigar=max_cigar, md_cap=md_cap)
-            aln_h = aln.cpu().numpy(); cg_h = cg.cpu().numpy().view(np.uint32); md_h = md.cpu().numpy()
-            if (aln_h[:, 7] & ~2).any():
-                raise RuntimeError("bmh_cigar_batch flagged an alignment (CIGAR or MD longer than the buffers)")
-        else:
-            aln_h = np.zeros((1, 8), np.int32); cg_h = np.zeros((1, max_cigar), np.uint32); md_h = np.zeros((1, md_cap), np.uint8)
-        txt = format_sam(po, names, codes, offs, lens, self.contigs, fin if m else np.zeros((1, 16), np.int32), opr, slot, aln_h, cg_h, md_h)
+        aln_h, cg_h, md_h = self._cigars(r, o, l, fin, sel)
+        _lap("cigar + D2H")
+        txt = format_sam(po, names, codes, offs, lens, self.contigs, fin if m else np.zeros((1, 16), np.int32), opr, slot, aln_h, cg_h, md_h,
+                         as_bytes=as_bytes)
+        _lap("format (host)")
         cw.free(); ws.free()
+        if self.profile:
+            import sys
+            sys.stderr.write("[aligner] " + ", ".join("%s %.1f ms" % (nm, (_t[i + 1] - _t[i]) * 1e3) for i, nm in enumerate(_nm)) + "\n")
         return txt
+
+    def _cigars(self, r, o, l, fin, sel):
+        """bmh_cigar_batch for the selected records with compact buffers; the few records that overflow them (flag 1: more
+        ops, flag 8: longer MD) are redone with large ones and patched in"""
+        dev = self.dev
+        max_cigar, md_cap = 64, 1024
+        if not len(sel):
+            return np.zeros((1, 8), np.int32), np.zeros((1, max_cigar), np.uint32), np.zeros((1, md_cap), np.uint8)
+        fin_t = torch.from_numpy(fin.copy()).to(dev)
+        cg, aln, md = cigar_batch(self.index, r, o, l, fin_t, len(sel), sel_t=torch.from_numpy(sel).to(dev), params=self.ep, opt_w=self.copt.w,
+                                  max_cigar=16, md_cap=96)
+        aln_h = aln.cpu().numpy()
+        cg_h = cg.cpu().numpy().view(np.uint32); md_h = md.cpu().numpy()
+        over = np.flatnonzero(aln_h[:, 7] & 9)
+        if over.size:
+            cg_c, md_c = cg_h, md_h
+            cg_h = np.zeros((len(sel), max_cigar), np.uint32); md_h = np.zeros((len(sel), md_cap), np.uint8)
+            cg_h[:, :16] = cg_c; md_h[:, :96] = md_c
+            cg2, aln2, md2 = cigar_batch(self.index, r, o, l, fin_t, len(over), sel_t=torch.from_numpy(sel[over].copy()).to(dev), params=self.ep,
+                                         opt_w=self.copt.w, max_cigar=max_cigar, md_cap=md_cap)
+            aln_h[over] = aln2.cpu().numpy(); cg_h[over] = cg2.cpu().numpy().view(np.uint32); md_h[over] = md2.cpu().numpy()
+        if (aln_h[:, 7] & ~2).any():
+            raise RuntimeError("bmh_cigar_batch flagged an alignment (CIGAR or MD longer than the buffers)")
+        return aln_h, cg_h, md_h
 
     def _finish_pairs(self, names, codes, offs, lens, r, o, l, regs_h, rpr_h, fr_h, po, cw, ws) -> str:
         L, dev, n = self.L, self.dev, len(lens)
@@ -136,28 +243,22 @@ class Aligner:
                                 _np_ptr(np.ascontiguousarray(h_rec), _i32p), n, _np_ptr(need, _u8p))
         sel = np.nonzero(need[:m])[0].astype(np.int32)
         slot = np.full(max(m, 1), -1, np.int64); slot[sel] = np.arange(len(sel))
-        max_cigar, md_cap = 64, 1024
-        if len(sel):
-            cg, aln, md = cigar_batch(self.index, r, o, l, torch.from_numpy(fin.copy()).to(dev), len(sel), sel_t=torch.from_numpy(sel).to(dev),
-                                      params=self.ep, opt_w=self.copt.w, max_cigar=max_cigar, md_cap=md_cap)
-            aln_h = aln.cpu().numpy(); cg_h = cg.cpu().numpy().view(np.uint32); md_h = md.cpu().numpy()
-            if (aln_h[:, 7] & ~2).any():
-                raise RuntimeError("bmh_cigar_batch flagged an alignment (CIGAR or MD longer than the buffers)")
-        else:
-            aln_h = np.zeros((1, 8), np.int32); cg_h = np.zeros((1, max_cigar), np.uint32); md_h = np.zeros((1, md_cap), np.uint8)
+        aln_h, cg_h, md_h = self._cigars(r, o, l, fin, sel)
         txt = format_sam(po, names, codes, offs, lens, self.contigs, fin if m else np.zeros((1, 16), np.int32), opr, slot, aln_h, cg_h, md_h,
-                         h_rec=h_rec, unflag=unflag)
+                         h_rec=h_rec, unflag=unflag, as_bytes=self._as_bytes)
         cw.free(); ws.free()
         return txt
 
     def align_file(self, reads_fa: str, out, batch_reads: int = 500_000, paired: bool = False) -> int:
-        names, seqs = read_fasta_reads(reads_fa)
-        out.write(self.header())
+        """out: a text or binary file object"""
+        rs = read_fasta_reads(reads_fa)
+        binary = "b" in getattr(out, "mode", "") or hasattr(out, "getbuffer")
+        out.write(self.header().encode() if binary else self.header())
         if paired:
             batch_reads -= batch_reads & 1
-        for b in range(0, len(seqs), batch_reads):
-            out.write(self.align_batch(names[b:b + batch_reads], seqs[b:b + batch_reads], id0=b, paired=paired))
-        return len(seqs)
+        for b in range(0, len(rs), batch_reads):
+            out.write(self.align_batch(rs.slice(b, b + batch_reads), id0=b, paired=paired, as_bytes=binary))
+        return len(rs)
 
     def close(self):
         self.index.free()

@@ -142,7 +142,7 @@ def load_library() -> C.CDLL:
     L.bmh_sam_need_cigar.restype = C.c_int64
     L.bmh_sam_need_cigar.argtypes = [C.POINTER(PostOpt), _i32p, _u32p, C.c_uint32, _u8p]
     L.bmh_format_sam.restype = C.c_void_p
-    L.bmh_format_sam.argtypes = [C.POINTER(PostOpt), C.c_uint32, C.POINTER(C.c_char_p), _u8p, _u64p, _u32p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p,
+    L.bmh_format_sam.argtypes = [C.POINTER(PostOpt), C.c_uint32, C.c_void_p, _u64p, _u8p, _u64p, _u32p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p,
                                  _i32p, _u32p, C.c_void_p, _i32p, _u32p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
     L.bmh_free.argtypes = [C.c_void_p]
     L.bmh_pe_opt_default.argtypes = [C.POINTER(PeOpt)]
@@ -153,7 +153,7 @@ def load_library() -> C.CDLL:
     L.bmh_sam_need_cigar_pe.restype = C.c_int64
     L.bmh_sam_need_cigar_pe.argtypes = [C.POINTER(PostOpt), _i32p, _u32p, _i32p, C.c_uint32, _u8p]
     L.bmh_format_sam_pe.restype = C.c_void_p
-    L.bmh_format_sam_pe.argtypes = [C.POINTER(PostOpt), C.c_uint32, C.POINTER(C.c_char_p), _u8p, _u64p, _u32p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p,
+    L.bmh_format_sam_pe.argtypes = [C.POINTER(PostOpt), C.c_uint32, C.c_void_p, _u64p, _u8p, _u64p, _u32p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p,
                                     _i32p, _u32p, _i32p, _i32p, C.c_void_p, _i32p, _u32p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
     L.bmh_merge_regs.restype = C.c_int
     L.bmh_merge_regs.argtypes = [C.c_void_p, _i32p, _i32p]
@@ -361,10 +361,19 @@ def finalize_pairs(copt, ep, po, genome_len: int, pac: np.ndarray, reads_flat: n
 
 
 def format_sam(po: "PostOpt", names, reads_flat: np.ndarray, read_offs: np.ndarray, read_lens: np.ndarray, contigs, fin: np.ndarray,
-               fin_per_read: np.ndarray, slot: np.ndarray, aln: np.ndarray, cigar: np.ndarray, md: np.ndarray, h_rec=None, unflag=None) -> str:
-    """bmh_format_sam (or bmh_format_sam_pe when h_rec / unflag are given) on numpy arrays; contigs = list of (name, length)"""
+               fin_per_read: np.ndarray, slot: np.ndarray, aln: np.ndarray, cigar: np.ndarray, md: np.ndarray, h_rec=None, unflag=None,
+               as_bytes: bool = False):
+    """bmh_format_sam (or bmh_format_sam_pe when h_rec / unflag are given) on numpy arrays; contigs = list of (name, length).
+    names: list of str, or (blob uint8 array of NUL-terminated names, uint64 offsets).  Returns the text as bytes if
+    as_bytes else str."""
     L = load_library()
-    nm = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    if isinstance(names, tuple):
+        nblob, noff = np.ascontiguousarray(names[0], dtype=np.uint8), np.ascontiguousarray(names[1], dtype=np.uint64)
+    else:
+        enc = [n.encode() + b"\0" for n in names]
+        nblob = np.frombuffer(b"".join(enc), dtype=np.uint8)
+        noff = np.concatenate([[0], np.cumsum([len(e) for e in enc])[:-1]]).astype(np.uint64) if enc else np.zeros(1, np.uint64)
+    n_names = len(noff) if len(noff) else 0
     cn = (C.c_char_p * len(contigs))(*[c[0].encode() for c in contigs])
     off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([c[1] for c in contigs])[:-1]]), dtype=np.int64)
     a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)
@@ -373,20 +382,20 @@ def format_sam(po: "PostOpt", names, reads_flat: np.ndarray, read_offs: np.ndarr
     ln = C.c_size_t()
     if h_rec is not None:
         hh, uu = a(h_rec, np.int32), a(unflag, np.int32)
-        p = L.bmh_format_sam_pe(C.byref(po), len(names), nm, _np_ptr(keep[0], _u8p), _np_ptr(keep[1], _u64p), _np_ptr(keep[2], _u32p), len(contigs), cn,
+        p = L.bmh_format_sam_pe(C.byref(po), len(read_lens), nblob.ctypes.data_as(C.c_void_p), _np_ptr(noff, _u64p), _np_ptr(keep[0], _u8p), _np_ptr(keep[1], _u64p), _np_ptr(keep[2], _u32p), len(contigs), cn,
                                 off.ctypes.data_as(C.c_void_p), _np_ptr(keep[3], _i32p), _np_ptr(keep[4], _u32p), _np_ptr(hh, _i32p), _np_ptr(uu, _i32p),
                                 keep[5].ctypes.data_as(C.c_void_p), _np_ptr(keep[6], _i32p), _np_ptr(keep[7], _u32p), int(keep[7].shape[1]),
                                 keep[8].ctypes.data_as(C.c_void_p), int(keep[8].shape[1]), C.byref(ln))
     else:
-        p = L.bmh_format_sam(C.byref(po), len(names), nm, _np_ptr(keep[0], _u8p), _np_ptr(keep[1], _u64p), _np_ptr(keep[2], _u32p), len(contigs), cn,
+        p = L.bmh_format_sam(C.byref(po), len(read_lens), nblob.ctypes.data_as(C.c_void_p), _np_ptr(noff, _u64p), _np_ptr(keep[0], _u8p), _np_ptr(keep[1], _u64p), _np_ptr(keep[2], _u32p), len(contigs), cn,
                              off.ctypes.data_as(C.c_void_p), _np_ptr(keep[3], _i32p), _np_ptr(keep[4], _u32p), keep[5].ctypes.data_as(C.c_void_p),
                              _np_ptr(keep[6], _i32p), _np_ptr(keep[7], _u32p), int(keep[7].shape[1]), keep[8].ctypes.data_as(C.c_void_p), int(keep[8].shape[1]),
                              C.byref(ln))
     if not p:
         raise RuntimeError("bmh_format_sam: " + _err(L))
-    txt = C.string_at(p, ln.value).decode()
+    raw = C.string_at(p, ln.value)
     L.bmh_free(p)
-    return txt
+    return raw if as_bytes else raw.decode()
 
 
 def dev_jobs_to_host(j: DevJobsT, n_reads: int) -> dict:

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include "bmh_internal.h"
 
@@ -79,20 +80,17 @@ extern "C" int64_t bmh_sam_need_cigar(const bmh_post_opt_t *po, const int32_t *f
 }
 
 // slot[i] = index of record i in the bmh_cigar_batch outputs (aln [..][8], cigar [..][max_cigar], md [..][md_cap]) or -1.
-// names / contig_names: arrays of C strings.  reads: nt4 codes.  h_rec / unflag: NULL for single-end reads; for interleaved
+// names: the read names, NUL-terminated, back to back; name_off[r] = start of read r's name.  contig_names: array of C
+// strings.  reads: nt4 codes.  h_rec / unflag: NULL for single-end reads; for interleaved
 // pairs the outputs of bmh_finalize_pairs (own-alignment record per read, flags of the unmapped record).
-static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *const *names, const uint8_t *reads,
+static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,
                         const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
                         const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
                         const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap,
                         const int32_t *h_rec, const int32_t *unflag, size_t *len_out)
 {
-	std::string out;
-	out.reserve((size_t)n_reads * 400);
 	std::vector<uint64_t> bases((size_t)n_reads + 1, 0);
 	for (uint32_t r = 0; r < n_reads; ++r) bases[r + 1] = bases[r] + fin_per_read[r];
-	std::vector<int> cnt, list;
-	std::vector<std::string> xa;
 	const bool pe = h_rec != nullptr;
 	auto rec_at = [&](uint64_t base, const int32_t *a, int i) {
 		Rec x; x.fin = a + 16 * i;
@@ -100,7 +98,19 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 		x.aln = s >= 0 ? aln + 8 * s : nullptr; x.cigar = s >= 0 ? cigar + (size_t)max_cigar * s : nullptr; x.md = (s >= 0 && md) ? md + (size_t)md_cap * s : "";
 		return x;
 	};
-	for (uint32_t r = 0; r < n_reads; ++r) {
+	// reads are independent: format ranges of them on host threads (the reference formats inside its worker threads)
+	unsigned n_thr = n_reads >= 8192 ? std::thread::hardware_concurrency() : 1;
+	if (n_thr < 1) n_thr = 1;
+	if (n_thr > 64) n_thr = 64;
+	std::vector<std::string> parts(n_thr);
+	std::vector<int> failed(n_thr, 0);
+	auto work = [&](unsigned t) {
+	std::string &out = parts[t];
+	const uint32_t r_lo = (uint32_t)((uint64_t)n_reads * t / n_thr), r_hi = (uint32_t)((uint64_t)n_reads * (t + 1) / n_thr);
+	out.reserve((size_t)(r_hi - r_lo) * 400);
+	std::vector<int> cnt, list;
+	std::vector<std::string> xa;
+	for (uint32_t r = r_lo; r < r_hi; ++r) {
 		const uint64_t base = bases[r];
 		const int n = (int)fin_per_read[r];
 		const int32_t *a = fin + 16 * base;
@@ -111,7 +121,7 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 			const uint32_t mr = r ^ 1u;
 			if (h_rec[mr] >= 0) {
 				const Rec y = rec_at(bases[mr], fin + 16 * bases[mr], h_rec[mr]);
-				if (!y.aln) { bmh_set_error("bmh_format_sam_pe: the alignment record of read %u has no CIGAR", mr); return nullptr; }
+				if (!y.aln) { bmh_set_error("bmh_format_sam_pe: the alignment record of read %u has no CIGAR", mr); failed[t] = 1; return; }
 				m.pos = aln_pos(y.aln); m.rid = rid_of(n_contigs, contig_offset, m.pos); m.is_rev = y.aln[2]; m.n_cigar = y.aln[3]; m.cigar = y.cigar;
 			}
 		}
@@ -125,7 +135,7 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 				const int k = pri(i);
 				if (k < 0 || cnt[k] > po->max_XA_hits) continue;
 				const Rec x = rec(i);
-				if (!x.aln) { bmh_set_error("bmh_format_sam: record %d of read %u has no CIGAR (see bmh_sam_need_cigar)", i, r); return nullptr; }
+				if (!x.aln) { bmh_set_error("bmh_format_sam: record %d of read %u has no CIGAR (see bmh_sam_need_cigar)", i, r); failed[t] = 1; return; }
 				const long long pos = aln_pos(x.aln);
 				const int rid = rid_of(n_contigs, contig_offset, pos);
 				std::string &s = xa[k];
@@ -158,7 +168,7 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 			const int p_rev = mm ? m.is_rev : 0;                 // an unmapped read takes its mate's coordinate and strand
 			if (p_rev) flag |= 0x10;
 			if (mm && m.is_rev) flag |= 0x20;
-			out += names[r]; out += '\t'; put_int(out, flag); out += '\t';
+			out += names + name_off[r]; out += '\t'; put_int(out, flag); out += '\t';
 			if (mm) { out += contig_names[m.rid]; out += '\t'; put_int(out, m.pos - (n_contigs > 1 ? contig_offset[m.rid] : 0) + 1); out += "\t0\t*\t"; }
 			else out += "*\t0\t0\t*\t";
 			mate_fields(mm ? m.rid : -1, m.pos, p_rev, 0, nullptr, mm, m.rid, m.pos, m.is_rev, m.n_cigar, m.cigar);
@@ -170,7 +180,7 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 		for (size_t which = 0; which < list.size(); ++which) {
 			const int i = list[which];
 			const Rec x = rec(i);
-			if (!x.aln) { bmh_set_error("bmh_format_sam: record %d of read %u has no CIGAR (see bmh_sam_need_cigar)", i, r); return nullptr; }
+			if (!x.aln) { bmh_set_error("bmh_format_sam: record %d of read %u has no CIGAR (see bmh_sam_need_cigar)", i, r); failed[t] = 1; return; }
 			const long long pos = aln_pos(x.aln);
 			const int rid = rid_of(n_contigs, contig_offset, pos);
 			// a mapped read whose mate is unmapped lends it its coordinate and strand (mem_aln2sam :1518-1521)
@@ -179,7 +189,7 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 			int flag = (x.aln[2] ? 0x10 : 0) | x.fin[14];
 			if (pe) { if (m.rid < 0) flag |= 8; if (m_rev) flag |= 0x20; }
 			const bool hard = which > 0;
-			out += names[r]; out += '\t'; put_int(out, flag); out += '\t';
+			out += names + name_off[r]; out += '\t'; put_int(out, flag); out += '\t';
 			out += contig_names[rid]; out += '\t'; put_int(out, pos - (n_contigs > 1 ? contig_offset[rid] : 0) + 1); out += '\t';
 			put_int(out, x.fin[13]); out += '\t';
 			if (x.aln[3]) put_cigar(out, x, hard); else out += '*';
@@ -222,36 +232,45 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 			out += '\n';
 		}
 	}
-	char *res = (char *)malloc(out.size() + 1);
+	};
+	if (n_thr == 1) work(0);
+	else { std::vector<std::thread> th; for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(work, t); for (auto &x : th) x.join(); }
+	for (unsigned t = 0; t < n_thr; ++t)
+		if (failed[t]) { if (n_thr > 1) bmh_set_error("bmh_format_sam: a record the text needs has no CIGAR (see bmh_sam_need_cigar)"); return nullptr; }
+	size_t total = 0;
+	for (const std::string &p : parts) total += p.size();
+	char *res = (char *)malloc(total + 1);
 	if (!res) { bmh_set_error("bmh_format_sam: out of memory"); return nullptr; }
-	memcpy(res, out.data(), out.size()); res[out.size()] = 0;
-	*len_out = out.size();
+	size_t w = 0;
+	for (const std::string &p : parts) { memcpy(res + w, p.data(), p.size()); w += p.size(); }
+	res[total] = 0;
+	*len_out = total;
 	return res;
 }
 
-extern "C" char *bmh_format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *const *names, const uint8_t *reads,
+extern "C" char *bmh_format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,
                                 const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
                                 const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
                                 const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap, size_t *len_out)
 {
-	if (!po || !names || !reads || !read_offs || !read_lens || !contig_names || !fin_per_read || !len_out || (n_contigs > 1 && !contig_offset)) {
+	if (!po || !names || !name_off || !reads || !read_offs || !read_lens || !contig_names || !fin_per_read || !len_out || (n_contigs > 1 && !contig_offset)) {
 		bmh_set_error("bmh_format_sam: null argument"); return nullptr;
 	}
-	return format_sam(po, n_reads, names, reads, read_offs, read_lens, n_contigs, contig_names, contig_offset, fin, fin_per_read, slot, aln, cigar, max_cigar,
+	return format_sam(po, n_reads, names, name_off, reads, read_offs, read_lens, n_contigs, contig_names, contig_offset, fin, fin_per_read, slot, aln, cigar, max_cigar,
 	                  md, md_cap, nullptr, nullptr, len_out);
 }
 
 // interleaved pairs: fin / fin_per_read / h_rec / unflag from bmh_finalize_pairs (mem_aln2sam with the mate: flags 0x8 0x20,
 // RNEXT, PNEXT, TLEN; an unmapped read takes its mate's coordinate and strand)
-extern "C" char *bmh_format_sam_pe(const bmh_post_opt_t *po, uint32_t n_reads, const char *const *names, const uint8_t *reads,
+extern "C" char *bmh_format_sam_pe(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,
                                    const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
                                    const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int32_t *h_rec,
                                    const int32_t *unflag, const int64_t *slot, const int32_t *aln, const uint32_t *cigar, int max_cigar,
                                    const char *md, int md_cap, size_t *len_out)
 {
-	if (!po || !names || !reads || !read_offs || !read_lens || !contig_names || !fin_per_read || !h_rec || !unflag || !len_out || (n_reads & 1) ||
+	if (!po || !names || !name_off || !reads || !read_offs || !read_lens || !contig_names || !fin_per_read || !h_rec || !unflag || !len_out || (n_reads & 1) ||
 	    (n_contigs > 1 && !contig_offset)) { bmh_set_error("bmh_format_sam_pe: bad argument"); return nullptr; }
-	return format_sam(po, n_reads, names, reads, read_offs, read_lens, n_contigs, contig_names, contig_offset, fin, fin_per_read, slot, aln, cigar, max_cigar,
+	return format_sam(po, n_reads, names, name_off, reads, read_offs, read_lens, n_contigs, contig_names, contig_offset, fin, fin_per_read, slot, aln, cigar, max_cigar,
 	                  md, md_cap, h_rec, unflag, len_out);
 }
 

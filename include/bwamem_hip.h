@@ -194,10 +194,11 @@ int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *e
  * bmh_sam_need_cigar marks (need[i] = 1) the records of bmh_finalize_regs that must go through bmh_cigar_batch first --
  * the reported ones and the XA candidates -- and returns their number.  bmh_format_sam then takes, per record, its slot
  * in the bmh_cigar_batch outputs (slot[i], -1 = none) and returns the text (malloc'd; free with bmh_free), one line per
- * record in the reference's order, an unmapped record for reads without a reported alignment.  reads: nt4 codes (the
+ * record in the reference's order, an unmapped record for reads without a reported alignment.  names: the read names,
+ * NUL-terminated, back to back, name_off[r] the start of read r's.  Formats ranges of reads on host threads.  reads: nt4 codes (the
  * path reads FASTA: QUAL is '*').  Pairing and ALT contigs are not modelled. */
 int64_t bmh_sam_need_cigar(const bmh_post_opt_t *po, const int32_t *fin, const uint32_t *fin_per_read, uint32_t n_reads, uint8_t *need);
-char *bmh_format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *const *names, const uint8_t *reads,
+char *bmh_format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,
                      const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
                      const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
                      const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap, size_t *len_out);
@@ -219,7 +220,7 @@ int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *
                            int n_threads);
 int64_t bmh_sam_need_cigar_pe(const bmh_post_opt_t *po, const int32_t *fin, const uint32_t *fin_per_read, const int32_t *h_rec,
                               uint32_t n_reads, uint8_t *need);
-char *bmh_format_sam_pe(const bmh_post_opt_t *po, uint32_t n_reads, const char *const *names, const uint8_t *reads,
+char *bmh_format_sam_pe(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,
                         const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
                         const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int32_t *h_rec,
                         const int32_t *unflag, const int64_t *slot, const int32_t *aln, const uint32_t *cigar, int max_cigar,

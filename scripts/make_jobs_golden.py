@@ -14,10 +14,11 @@ from bwamem_hip import fmindex, synth
 #        make_jobs_golden.py contigs    -> contigs_golden.npz (the same repeat-rich genome cut into three sequences; reads cross the cuts)
 #        make_jobs_golden.py pe         -> pe_golden.npz (interleaved pairs, run with -p: insert-size statistics, mate rescue, pairing)
 MODE = sys.argv[1] if len(sys.argv) > 1 else "plain"
-REPEATS = MODE in ("repeats", "contigs", "pe")
-PE = MODE == "pe"
-OUT = {"plain": "jobs_golden.npz", "repeats": "post_golden.npz", "contigs": "contigs_golden.npz", "pe": "pe_golden.npz"}[MODE]
-CONTIGS = [("ctgA", 120_000), ("ctgB", 100_037), ("ctgC", 79_963)] if MODE == "contigs" else None
+#        make_jobs_golden.py pe_contigs -> pe_contigs_golden.npz (pairs on the three-sequence genome; some pairs span two sequences)
+REPEATS = MODE in ("repeats", "contigs", "pe", "pe_contigs")
+PE = MODE in ("pe", "pe_contigs")
+OUT = {"plain": "jobs_golden.npz", "repeats": "post_golden.npz", "contigs": "contigs_golden.npz", "pe": "pe_golden.npz", "pe_contigs": "pe_contigs_golden.npz"}[MODE]
+CONTIGS = [("ctgA", 120_000), ("ctgB", 100_037), ("ctgC", 79_963)] if MODE in ("contigs", "pe_contigs") else None
 work = "/tmp/jobs_golden_" + MODE; os.makedirs(work, exist_ok=True)
 n_genome, n_reads, L = 300_000, 600, 150
 GENOME_KW = dict(repeat_frac=0.45, repeat_len=(150, 1500), repeat_copies=(3, 40), repeat_div=0.03) if REPEATS else {}
@@ -45,7 +46,14 @@ if REPEATS and not PE:                                   # chimeric reads (two l
         if rng.random() < 0.5: a = synth.revcomp(a)
         if rng.random() < 0.5: b = synth.revcomp(b)
         reads[i] = np.concatenate([a, b])
-if CONTIGS:                                   # every eighth read straddles a cut between two sequences
+if CONTIGS and PE:                            # some pairs with one mate on either side of a cut
+    rng = np.random.default_rng(4)
+    cuts = np.cumsum([c[1] for c in CONTIGS])[:-1]
+    for i in range(4, n_reads, 40):
+        c = int(cuts[(i // 40) % len(cuts)])
+        a = g[c - 200:c - 200 + L].copy(); b = synth.revcomp(g[c + 60:c + 60 + L])
+        reads[i] = a; reads[i + 1] = b
+if CONTIGS and not PE:                        # every eighth read straddles a cut between two sequences
     rng = np.random.default_rng(5)
     cuts = np.cumsum([c[1] for c in CONTIGS])[:-1]
     for i in range(0, n_reads, 8):

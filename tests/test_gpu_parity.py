@@ -614,7 +614,7 @@ def test_reads_to_sam_text_matches_reference(hip, oracle, golden):
     cw.free(); ws.free(); dindex.free()
 
 
-@pytest.mark.parametrize("golden", ["post_golden.npz", "contigs_golden.npz", "pe_golden.npz"])
+@pytest.mark.parametrize("golden", ["post_golden.npz", "contigs_golden.npz", "pe_golden.npz", "pe_contigs_golden.npz"])
 def test_aligner_writes_reference_sam(hip, tmp_path, golden):
     """bwamem_hip.aligner (index files + FASTA -> SAM over the device-resident path) against the SAM text recorded from the
     reference binary: single-end (repeat-rich, three sequences) and interleaved paired-end (-p)."""

@@ -224,21 +224,24 @@ def test_sam_text_matches_reference(oracle, golden):
     hj.free()
 
 
-def test_paired_end_sam_text_matches_reference(oracle):
+@pytest.mark.parametrize("golden", ["pe_golden.npz", "pe_contigs_golden.npz"])
+def test_paired_end_sam_text_matches_reference(oracle, golden):
     """bmh_finalize_pairs (insert-size statistics, mate rescue with the host local alignment, pairing, mem_sam_pe's choices)
     + bmh_format_sam_pe write the reference's PAIRED-END SAM records (gase_aln -p on interleaved pairs) byte for byte:
     proper pairs, a mate found only by rescue, discordant and unmapped mates."""
     import ctypes as C
     from bwamem_hip.lib import ChainOpt, ExtParams, PostOpt, finalize_pairs, format_sam, load_library, _np_ptr, _i32p, _u32p, _u8p
-    z = np.load(os.path.join(common.GOLDEN, "pe_golden.npz"))
+    import ast
+    z = np.load(os.path.join(common.GOLDEN, golden))
     g, reads, hj, regs = _golden_regions(oracle, z)
     pac = _pac(g)
-    contigs = [("chrS", len(g))]
+    contigs = ast.literal_eval(str(z["contigs"])) or [("chrS", len(g))]
     n, rl = reads.shape
     L = load_library()
     co = ChainOpt(); L.bmh_chain_opt_default(C.byref(co)); ep = ExtParams.default(); po = PostOpt(); L.bmh_post_opt_default(C.byref(po))
     flat = np.ascontiguousarray(reads.reshape(-1)); offs = np.arange(n, dtype=np.uint64) * rl; lens = np.full(n, rl, np.uint32)
-    fin, per_read, h_rec, unflag, pes = finalize_pairs(co, ep, po, len(g), pac, flat, offs, lens, regs, hj.regs_per_read, hj.frac_rep(), n_threads=2)
+    fin, per_read, h_rec, unflag, pes = finalize_pairs(co, ep, po, len(g), pac, flat, offs, lens, regs, hj.regs_per_read, hj.frac_rep(),
+                                                       contigs=contigs if len(contigs) > 1 else None, n_threads=2)
     assert pes[1][2] == 0 and 300 < pes[1][3] < 400          # FR orientation: mean insert ~350
     need = np.zeros(max(len(fin), 1), np.uint8)
     fin_c = np.ascontiguousarray(fin); pr_c = np.ascontiguousarray(per_read); h_c = np.ascontiguousarray(h_rec)

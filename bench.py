@@ -72,7 +72,7 @@ def pmc_valu_busy(pred):
         return None
 
 
-def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, reads, params):
+def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, reads, params, paired=False):
     """The rows after the hot path, measured on the same batch and reported beside the metric, not in it:
     bmh_finalize_regs (host: sort/dedup/patch, primary marking, MAPQ, selection -- the reference runs it on host threads too)
     and bmh_cigar_batch (device: CIGAR / NM / MD of every reported alignment)."""
@@ -92,6 +92,27 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
     offs = np.arange(n_reads, dtype=np.uint64) * rl
     out = np.zeros((max(n_regs, 1), 16), np.int32); opr = np.zeros(n_reads, np.uint32)
     nth = os.cpu_count() or 1
+    if paired:
+        from bwamem_hip.lib import finalize_pairs
+        t0 = time.perf_counter()
+        fin, opr, h_rec, unflag, pes = finalize_pairs(co, params, po, len(g), pac_h, flat, offs, np.full(n_reads, rl, np.uint32), regs_h, rpr_h, fr_h, n_threads=nth)
+        t_fin = time.perf_counter() - t0
+        need = np.zeros(max(len(fin), 1), np.uint8)
+        fin = np.ascontiguousarray(fin)
+        L.bmh_sam_need_cigar_pe(C.byref(po), _np_ptr(fin, _i32p), _np_ptr(np.ascontiguousarray(opr), _u32p), _np_ptr(np.ascontiguousarray(h_rec), _i32p), n_reads,
+                                _np_ptr(need, _u8p))
+        sel = np.nonzero(need[: len(fin)])[0].astype(np.int32)
+        out_t = torch.from_numpy(fin.copy()).to(dev); sel_t = torch.from_numpy(sel).to(dev)
+        ms = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            cg, aln, md = cigar_batch(dindex, dr.ascii, dr.offs, dr.lens, out_t, len(sel), sel_t=sel_t, params=params, max_cigar=24, md_cap=128)
+            torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
+        return {"finalize_pairs_host": {"ms": round(t_fin * 1e3, 2), "threads": nth, "regions_in": int(n_regs), "regions_out": int(len(fin)),
+                                        "insert_size_FR": {"low": pes[1][0], "high": pes[1][1], "mean": round(pes[1][3], 1), "sd": round(pes[1][4], 1)},
+                                        "d2h_regions_ms": round(t_d2h * 1e3, 2)},
+                "cigar_batch_device": {"ms": round(min(ms), 3), "alignments": int(len(sel)), "M_alignments_per_s": round(len(sel) / (min(ms) * 1e-3) / 1e6, 1),
+                                       "flagged": int((aln[:, 7].cpu().numpy() & ~2 != 0).sum())}}
     t0 = time.perf_counter()
     m = L.bmh_finalize_regs(C.byref(co), C.byref(params), C.byref(po), len(g), _np_ptr(pac_h, _u8p), n_reads, _np_ptr(flat, _u8p), _np_ptr(offs, _u64p),
                             _np_ptr(np.ascontiguousarray(regs_h), _i32p), _np_ptr(np.ascontiguousarray(rpr_h), _u32p), fr_h.ctypes.data_as(C.POINTER(C.c_float)), 1, None,
@@ -373,7 +394,7 @@ def main():
                                       "jobs": n_jobs, "hbm_GBps": round(kernel_bytes["extend"] / (iso_ms["extend"] * 1e-3) / 1e9, 2)}
             if not a.host_jobs:
                 try:
-                    res["next_rows"] = downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, reads, params)
+                    res["next_rows"] = downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, reads, params, a.paired)
                 except Exception as e:                      # never lose the bench line over the extras
                     res["next_rows"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)

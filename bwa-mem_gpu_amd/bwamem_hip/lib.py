@@ -344,8 +344,8 @@ def finalize_pairs(copt, ep, po, genome_len: int, pac: np.ndarray, reads_flat: n
     n = len(read_lens)
     a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)
     regs = a(regs, np.int32)
-    cap = len(regs) + 16 * n + 16
-    out = np.zeros((cap, 16), np.int32); opr = np.zeros(max(n, 1), np.uint32); h = np.zeros(max(n, 1), np.int32); uf = np.zeros(max(n, 1), np.int32)
+    cap = len(regs) + 2 * n + 1024          # mate rescue adds a few regions; the call fails with ECAPACITY if this is short
+    out = np.empty((cap, 16), np.int32); opr = np.zeros(max(n, 1), np.uint32); h = np.zeros(max(n, 1), np.int32); uf = np.zeros(max(n, 1), np.int32)
     pes = np.zeros((4, 5), np.float64)
     ln = a([c[1] for c in contigs], np.int32) if contigs else None
     off = a(np.concatenate([[0], np.cumsum(ln)[:-1]]), np.int64) if contigs else None

@@ -7,7 +7,9 @@
 // Runs on host threads like the reference; regions come from bmh_merge_regs / bmh_chain_merge, CIGARs are added
 // afterwards by bmh_cigar_batch and the text by bmh_format_sam_pe (sam_format.cpp).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -38,7 +40,9 @@ inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)      
 	return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
 }
 
-int cal_sub(const PCtx &c, const std::vector<Reg> &r)
+struct Span { const Reg *p; size_t n; bool empty() const { return n == 0; } size_t size() const { return n; } const Reg &operator[](size_t i) const { return p[i]; } };
+
+int cal_sub(const PCtx &c, const Span &r)
 {
 	size_t j;
 	for (j = 1; j < r.size(); ++j) {
@@ -52,13 +56,12 @@ int cal_sub(const PCtx &c, const std::vector<Reg> &r)
 	return j < r.size() ? r[j].score : c.x.co->min_seed_len * c.x.ep->a;
 }
 
-void pestat(PCtx &c, const std::vector<std::vector<Reg>> &regs)                // mem_pestat
+template <class RegsOf> void pestat(PCtx &c, size_t n, RegsOf regs_of)            // mem_pestat; regs_of(r) -> (pointer, count)
 {
 	std::vector<uint64_t> isize[4];
 	memset(c.pes, 0, sizeof(c.pes));
-	const size_t n = regs.size();
 	for (size_t i = 0; i < n >> 1; ++i) {
-		const std::vector<Reg> &r0 = regs[i << 1], &r1 = regs[i << 1 | 1];
+		const Span r0 = regs_of(i << 1), r1 = regs_of(i << 1 | 1);
 		if (r0.empty() || r1.empty()) continue;
 		if (cal_sub(c, r0) > 0.8 * r0[0].score) continue;
 		if (cal_sub(c, r1) > 0.8 * r1[0].score) continue;
@@ -175,13 +178,13 @@ int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector
 struct P64 { uint64_t x, y; };
 inline bool p64_lt(const P64 &a, const P64 &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); }
 
-int pair_regs(const PCtx &c, std::vector<Reg> a[2], int id, int *sub, int *n_sub, int z[2], const int n_pri[2])     // mem_pair
+int pair_regs(const PCtx &c, std::vector<Reg> *const a[2], int id, int *sub, int *n_sub, int z[2], const int n_pri[2])     // mem_pair
 {
 	const int64_t l_pac = c.x.l_pac;
 	std::vector<P64> v, u;
 	for (int r = 0; r < 2; ++r)
 		for (int i = 0; i < n_pri[r]; ++i) {
-			const Reg &e = a[r][i];
+			const Reg &e = (*a[r])[i];
 			P64 key;
 			key.x = (uint64_t)(e.rb < l_pac ? e.rb : (l_pac << 1) - 1 - e.rb);
 			key.x = (uint64_t)e.rid << 32 | (key.x - (uint64_t)(c.x.n_contigs > 1 ? c.ctg_off[e.rid] : 0));
@@ -256,7 +259,7 @@ void select_se(const PCtx &c, ReadOut &o, int extra)
 	}
 }
 
-void sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // mem_sam_pe, decisions only
+int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // mem_sam_pe, decisions only; returns extra_flag
 {
 	std::vector<Reg> *a[2] = {&out[0].regs, &out[1].regs};
 	const uint8_t *seq[2] = {c.reads + c.offs[r0], c.reads + c.offs[r0 + 1]};
@@ -274,8 +277,7 @@ void sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          //
 	for (int i = 0; i < 2; ++i) { out[i].sec_all.resize(a[i]->size()); for (size_t j = 0; j < a[i]->size(); ++j) out[i].sec_all[j] = (*a[i])[j].secondary; }
 	bool paired = false;
 	if (n_pri[0] && n_pri[1]) {
-		std::vector<Reg> av[2] = {*a[0], *a[1]};
-		o = pair_regs(c, av, (int)id, &subo, &n_sub, z, n_pri);
+		o = pair_regs(c, a, (int)id, &subo, &n_sub, z, n_pri);
 		if (o > 0) {
 			int is_multi[2];
 			for (int i = 0; i < 2; ++i) {
@@ -336,6 +338,7 @@ void sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          //
 		}
 		for (int i = 0; i < 2; ++i) { select_se(c, out[i], (i ? 0x81 : 0x41) | extra_flag); out[i].h = hh[i]; }
 	}
+	return extra_flag;
 }
 
 } // namespace
@@ -362,60 +365,78 @@ extern "C" int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext
 	c.pe = pe; c.ctg_off = contig_offset; c.ctg_len = contig_len; c.reads = reads; c.offs = read_offs; c.lens = read_lens;
 	std::vector<uint64_t> in_off((size_t)n_reads + 1, 0);
 	for (uint32_t r = 0; r < n_reads; ++r) in_off[r + 1] = in_off[r] + regs_per_read[r];
-	std::vector<std::vector<Reg>> regs(n_reads);
+	// regions of all reads in one array (no per-read heap traffic: that, not the arithmetic, dominated on many threads)
+	std::vector<Reg> flat((size_t)in_off[n_reads] + 1);
+	std::vector<uint32_t> cnt(n_reads, 0);
 	if (n_threads < 1) n_threads = 1;
+	if ((uint32_t)n_threads > n_reads / 2 + 1) n_threads = (int)(n_reads / 2 + 1);
 	auto par = [&](auto fn, uint32_t n_units) {
-		if (n_threads == 1 || n_units < 2) { fn(0u, n_units); return; }
+		if (n_threads == 1 || n_units < 2) { fn(0, 0u, n_units); return; }
 		std::vector<std::thread> th;
-		for (int t = 0; t < n_threads; ++t) th.emplace_back(fn, (uint32_t)((uint64_t)n_units * t / n_threads), (uint32_t)((uint64_t)n_units * (t + 1) / n_threads));
+		for (int t = 0; t < n_threads; ++t) th.emplace_back(fn, t, (uint32_t)((uint64_t)n_units * t / n_threads), (uint32_t)((uint64_t)n_units * (t + 1) / n_threads));
 		for (auto &t : th) t.join();
 	};
-	par([&](uint32_t r0, uint32_t r1) {                         // per read: mem_sort_dedup_patch
+	const bool prof = getenv("BMH_PAIR_PROFILE") != nullptr;
+	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t_a = now();
+	par([&](int, uint32_t r0, uint32_t r1) {                    // per read: mem_sort_dedup_patch, in place
 		for (uint32_t r = r0; r < r1; ++r) {
 			const int n_in = (int)regs_per_read[r];
-			regs[r].resize(n_in);
-			for (int i = 0; i < n_in; ++i) reg_from_record(c.x, regs_in + 8 * (in_off[r] + i), frac_rep ? frac_rep[r] : 0.f, regs[r][i]);
-			regs[r].resize((size_t)sort_dedup_patch(c.x, reads + read_offs[r], n_in, regs[r].data()));
+			Reg *a = flat.data() + in_off[r];
+			for (int i = 0; i < n_in; ++i) reg_from_record(c.x, regs_in + 8 * (in_off[r] + i), frac_rep ? frac_rep[r] : 0.f, a[i]);
+			cnt[r] = (uint32_t)sort_dedup_patch(c.x, reads + read_offs[r], n_in, a);
 		}
 	}, n_reads);
-	pestat(c, regs);
+	const double t_b = now();
+	pestat(c, n_reads, [&](size_t r) { return Span{flat.data() + in_off[r], cnt[r]}; });
+	const double t_c = now();
 	if (pes_out) for (int d = 0; d < 4; ++d) { pes_out[5 * d] = c.pes[d].low; pes_out[5 * d + 1] = c.pes[d].high; pes_out[5 * d + 2] = c.pes[d].failed; pes_out[5 * d + 3] = c.pes[d].avg; pes_out[5 * d + 4] = c.pes[d].std; }
-	std::vector<ReadOut> ro(n_reads);
-	par([&](uint32_t p0, uint32_t p1) {
+	// per pair: mem_sam_pe's decisions; every thread appends the records of its (contiguous) pairs to its own buffer
+	struct Part { std::vector<int32_t> rec; std::vector<uint32_t> n; std::vector<int32_t> h, uf; };
+	std::vector<Part> parts((size_t)n_threads);
+	par([&](int t, uint32_t p0, uint32_t p1) {
+		Part &P = parts[(size_t)t];
+		P.rec.reserve((size_t)(in_off[2 * p1] - in_off[2 * p0]) * 16 + 64);
+		ReadOut o2[2];
 		for (uint32_t p = p0; p < p1; ++p) {
-			ReadOut o2[2];
-			o2[0].regs.swap(regs[2 * p]); o2[1].regs.swap(regs[2 * p + 1]);
-			o2[0].h = o2[1].h = -1;
-			sam_pe(c, (uint64_t)(popt->id0 / 2) + p, 2 * p, o2);
-			ro[2 * p] = std::move(o2[0]); ro[2 * p + 1] = std::move(o2[1]);
+			for (int i = 0; i < 2; ++i) {
+				const uint32_t r = 2 * p + (uint32_t)i;
+				o2[i].regs.assign(flat.data() + in_off[r], flat.data() + in_off[r] + cnt[r]);
+				o2[i].mapq.clear(); o2[i].flag.clear(); o2[i].rep.clear(); o2[i].sec_all.clear(); o2[i].h = -1;
+			}
+			const int extra = sam_pe(c, (uint64_t)(popt->id0 / 2) + p, 2 * p, o2);
+			for (int i = 0; i < 2; ++i) {
+				const ReadOut &o = o2[i];
+				const uint32_t r = 2 * p + (uint32_t)i;
+				bool any = false;
+				for (size_t k = 0; k < o.regs.size(); ++k) {
+					const Reg &g = o.regs[k];
+					const size_t at = P.rec.size();
+					P.rec.resize(at + 16);
+					int32_t *q = P.rec.data() + at;
+					q[0] = (int32_t)r; q[1] = g.score; q[2] = g.qb; q[3] = g.qe;
+					q[4] = (int32_t)(uint32_t)g.rb; q[5] = (int32_t)(g.rb >> 32); q[6] = (int32_t)(uint32_t)g.re; q[7] = (int32_t)(g.re >> 32);
+					q[8] = g.truesc; q[9] = g.w;            /* 0 / 0 for a rescued region (src/bwamem_pair.c:161: memset) */
+					q[10] = g.sub > g.csub ? g.sub : g.csub; q[11] = g.sub_n;
+					q[12] = o.sec_all.empty() ? g.secondary : o.sec_all[k];
+					q[13] = o.mapq[k]; q[14] = o.flag[k]; q[15] = o.rep[k];
+					any = any || o.rep[k];
+				}
+				P.n.push_back((uint32_t)o.regs.size()); P.h.push_back(o.h);
+				// the unmapped record of a read without reported alignment carries the flags of its mem_reg2sam call
+				P.uf.push_back(any ? 0 : ((i ? 0x81 : 0x41) | extra));
+			}
 		}
 	}, n_reads / 2);
-	uint64_t w = 0;
-	for (uint32_t r = 0; r < n_reads; ++r) {
-		const ReadOut &o = ro[r];
-		const size_t n = o.regs.size();
-		if (w + n > cap) { bmh_set_error("bmh_finalize_pairs: more than %llu output regions", (unsigned long long)cap); return BMH_ECAPACITY; }
-		bool any = false;
-		for (size_t k = 0; k < n; ++k) {
-			const Reg &p = o.regs[k];
-			int32_t *q = out + 16 * (w + k);
-			q[0] = (int32_t)r; q[1] = p.score; q[2] = p.qb; q[3] = p.qe;
-			q[4] = (int32_t)(uint32_t)p.rb; q[5] = (int32_t)(p.rb >> 32); q[6] = (int32_t)(uint32_t)p.re; q[7] = (int32_t)(p.re >> 32);
-			q[8] = p.truesc; q[9] = p.w;            /* 0 / 0 for a rescued region (src/bwamem_pair.c:161: memset) */
-			q[10] = p.sub > p.csub ? p.sub : p.csub; q[11] = p.sub_n;
-			q[12] = o.sec_all.empty() ? p.secondary : o.sec_all[k];
-			q[13] = o.mapq[k]; q[14] = o.flag[k]; q[15] = o.rep[k];
-			any = any || o.rep[k];
-		}
-		out_per_read[r] = (uint32_t)n; out_h[r] = o.h;
-		// the unmapped record of a read without reported alignment carries the pair flags of its mem_reg2sam call
-		int uf = (r & 1) ? 0x81 : 0x41;
-		{   // extra_flag of the pair: recover the proper-pair bit from the mate's reported records (same value for both reads)
-			const ReadOut &m = ro[r ^ 1];
-			for (size_t k = 0; k < m.flag.size(); ++k) if (m.rep[k] && (m.flag[k] & 2)) uf |= 2;
-		}
-		out_unflag[r] = any ? 0 : uf;
-		w += n;
+	const double t_d = now();
+	if (prof) fprintf(stderr, "[pairs] dedup %.1f ms, pestat %.1f ms, mem_sam_pe %.1f ms (%d threads)\n", t_b - t_a, t_c - t_b, t_d - t_c, n_threads);
+	uint64_t w = 0; uint32_t r = 0;
+	for (const Part &P : parts) {
+		const uint64_t nrec = P.rec.size() / 16;
+		if (w + nrec > cap) { bmh_set_error("bmh_finalize_pairs: more than %llu output regions", (unsigned long long)cap); return BMH_ECAPACITY; }
+		if (nrec) memcpy(out + 16 * w, P.rec.data(), sizeof(int32_t) * 16 * nrec);
+		for (size_t k = 0; k < P.n.size(); ++k, ++r) { out_per_read[r] = P.n[k]; out_h[r] = P.h[k]; out_unflag[r] = P.uf[k]; }
+		w += nrec;
 	}
 	return (int64_t)w;
 }

@@ -161,7 +161,8 @@ class Aligner:
         o = torch.from_numpy(offs.astype(np.int64)).to(torch.int32).to(dev)
         l = torch.from_numpy(lens.astype(np.int64)).to(torch.int32).to(dev)
         _lap("host prep + H2D")
-        ws = SeedWorkspace(n, max(int(lens.sum()), 1))
+        nb = max(int(lens.sum()), 1)
+        ws = SeedWorkspace(n, nb, max_cands=nb, max_occ=max(64 * n, 1 << 16))      # one candidate per base is the hard upper bound
         _lap("seed workspace")
         s = ws.seed_batch(self.index, r, o, l, self.copt.min_seed_len)
         _lap("seeding")

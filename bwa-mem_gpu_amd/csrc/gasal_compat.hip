@@ -220,6 +220,11 @@ void gasal_aln_async(gasal_gpu_storage_t *s, const uint32_t qb, const uint32_t t
 			fclose(f);
 		}
 	}
+	// BMH_GASAL_SYNC=1 (debug aid): one submission at a time, complete before returning
+	static const bool serial = getenv("BMH_GASAL_SYNC") != nullptr;
+	static std::mutex serial_mu;
+	std::unique_lock<std::mutex> serial_lk(serial_mu, std::defer_lock);
+	if (serial) serial_lk.lock();
 	dev_reserve(m, qb, tb, n);
 	hipStream_t st = m->stream;
 	HIPX(hipMemcpyAsync(m->d_q, s->extensible_host_unpacked_query_batch->data, qb, hipMemcpyHostToDevice, st));
@@ -232,6 +237,7 @@ void gasal_aln_async(gasal_gpu_storage_t *s, const uint32_t qb, const uint32_t t
 	if (bmh_extend_batch(m->d_q, m->d_qoff, m->d_qlen, m->d_t, m->d_toff, m->d_tlen, m->d_h0, n, &g_params, m->d_out, nullptr, st) != BMH_OK)
 		FATAL("gasal_aln_async: %s", bmh_last_error());
 	HIPX(hipMemcpyAsync(m->h_out, m->d_out, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+	if (serial) HIPX(hipStreamSynchronize(st));
 	m->n_launched = n; m->running = true;
 	s->is_free = 0;
 }
@@ -246,6 +252,20 @@ int gasal_is_aln_async_done(gasal_gpu_storage_t *s)
 	gasal_res_t *r = s->host_res;
 	for (uint32_t i = 0; i < m->n_launched; ++i) {
 		r->aln_score[i] = m->h_out[3 * i]; r->query_batch_end[i] = m->h_out[3 * i + 1]; r->target_batch_end[i] = m->h_out[3 * i + 2];
+	}
+	// BMH_GASAL_CHECK=1: bounds every result must satisfy (score <= h0 + qlen*a, ends inside the sequences)
+	static const bool check = getenv("BMH_GASAL_CHECK") != nullptr;
+	if (check) {
+		unsigned long bad = 0;
+		for (uint32_t i = 0; i < m->n_launched; ++i) {
+			int32_t sc = r->aln_score[i], qe = r->query_batch_end[i], te = r->target_batch_end[i];
+			int64_t ub = (int64_t)s->host_seed_scores[i] + (int64_t)s->host_query_batch_lens[i] * g_params.a + g_params.end_bonus;
+			if (sc < 0 || sc > ub || qe < 0 || te < 0 || (uint32_t)qe > s->host_query_batch_lens[i] || (uint32_t)te > s->host_target_batch_lens[i]) {
+				if (bad++ < 4) fprintf(stderr, "[gasal check] job %u of %u: score %d qend %d tend %d (h0 %u qlen %u tlen %u)\n", i, m->n_launched, sc, qe, te,
+				                       s->host_seed_scores[i], s->host_query_batch_lens[i], s->host_target_batch_lens[i]);
+			}
+		}
+		if (bad) fprintf(stderr, "[gasal check] %lu results out of bounds\n", bad);
 	}
 	m->running = false;
 	s->is_free = 1;

@@ -1,7 +1,12 @@
 """End-to-end drop-in run: the REFERENCE's own `bwa-gasal2 gase_aln` host code (compiled unchanged by
 scripts/build_dropin.sh, linked against libbwamem_hip.so) on BASELINE.json configs[0]'s shape:
 10k synthetic 150 bp single-end reads vs an E. coli-size (4.64 Mbp) seeded genome.  Checks the SAM
-against the simulation truth (position/strand of every read)."""
+against the simulation truth (position/strand of every read).
+-K keeps the whole file in one batch whatever -t is (insert-size statistics are per batch).  NOTE: with -t >= 4 the
+reference's own host code is not deterministic on hard read sets (regions with garbage scores, e.g. AS:i:7227, that
+change from run to run -- also with every library call serialised, and the results the library hands over are
+checked in bounds: BMH_GASAL_CHECK / BMH_GASAL_SYNC, scripts/e2e_race_probe.py); -t 1 and -t 2 are deterministic
+and that is what the byte-for-byte comparison uses."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))
@@ -16,7 +21,8 @@ work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/e2e_dropin"
 n_genome = int(float(sys.argv[2])) if len(sys.argv) > 2 else 4_640_000
 n_reads = int(float(sys.argv[3])) if len(sys.argv) > 3 else 10_000
 threads = sys.argv[4] if len(sys.argv) > 4 else "1"
-paired = len(sys.argv) > 5 and sys.argv[5] == "pe"
+paired = len(sys.argv) > 5 and sys.argv[5] in ("pe", "pe_hard")
+hard = len(sys.argv) > 5 and sys.argv[5] in ("se_hard", "pe_hard")      # diverged / chimeric / unalignable reads mixed in
 os.makedirs(work, exist_ok=True)
 prefix = os.path.join(work, "g.fa")
 g = synth.make_genome(n_genome, seed=42)
@@ -26,18 +32,36 @@ fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g)
 print("index built+written in %.1fs" % (time.time() - t), flush=True)
 fq = os.path.join(work, "reads.fa")
 if paired:   # configs[3]: one interleaved file with -p (the only coherent PE input of the reference, SURVEY.md 8 notes)
-    reads, ptruth = synth.make_pairs(g, n_reads // 2, 150, seed=7)
+    reads, ptruth = synth.make_pairs(g, n_reads // 2, 150, seed=7, sub_rate=0.03 if hard else 0.01)
+    if hard:
+        rng = np.random.default_rng(8); L = 150
+        for i in range(0, len(reads), 2):
+            kind = (i // 2) % 10
+            m = i + int(rng.integers(0, 2))
+            if kind == 3:
+                x = reads[m]; q = rng.random(L) < 0.12; x[q] = (x[q] + rng.integers(1, 4, size=int(q.sum()))) & 3
+            elif kind == 5:
+                p0 = int(rng.integers(0, n_genome - L)); x = g[p0:p0 + L].copy(); reads[m] = x if rng.random() < 0.5 else synth.revcomp(x)
+            elif kind == 7:
+                reads[m] = rng.integers(0, 4, size=L).astype(np.uint8)
+            elif kind == 9:
+                k = int(rng.integers(50, 100)); p1 = int(rng.integers(0, n_genome - L)); reads[m][k:] = g[p1:p1 + L - k]
     asc = synth.codes_to_ascii(reads)
     with open(fq, "wb") as f:
         for i in range(asc.shape[0]):
             f.write(b">p%d\n" % (i // 2)); f.write(asc[i].tobytes()); f.write(b"\n")
 else:
-    reads, truth = synth.make_reads(g, n_reads, 150, seed=7)
+    reads, truth = synth.make_reads(g, n_reads, 150, seed=7, sub_rate=0.04 if hard else 0.01, indel_frac=0.4 if hard else 0.05)
+    if hard:
+        rng = np.random.default_rng(6); L = 150
+        for i in range(3, n_reads, 12):                      # chimeric reads
+            k = int(rng.integers(50, 100)); p1 = int(rng.integers(0, n_genome - L)); b = g[p1:p1 + L - k].copy()
+            reads[i][k:] = synth.revcomp(b) if rng.random() < 0.5 else b
     synth.write_fasta_reads(fq, reads)
 sam = os.path.join(work, "out.sam")
 t = time.time()
 with open(sam, "w") as f:
-    r = subprocess.run([exe, "gase_aln", "-t", threads, "-l", "150"] + (["-p"] if paired else []) + [prefix, fq], stdout=f, stderr=subprocess.PIPE, cwd=work)
+    r = subprocess.run([exe, "gase_aln", "-t", threads, "-K", "2000000000", "-l", "150"] + (["-p"] if paired else []) + [prefix, fq], stdout=f, stderr=subprocess.PIPE, cwd=work)
 dt = time.time() - t
 print("gase_aln rc=%d in %.2fs" % (r.returncode, dt))
 print(r.stderr.decode()[-1500:])
@@ -62,7 +86,7 @@ if paired:
         if not flag & 4 and lo - 8 <= pos <= hi + 8:
             okpos += 1
     print(f"PE reads {n} mapped {mapped} properly paired {proper} ({proper/max(n,1):.4f}) inside the simulated fragment {okpos} ({okpos/max(n,1):.4f})")
-    assert n == 2 * (n_reads // 2) and proper / n > 0.95 and okpos / n > 0.97
+    assert n == 2 * (n_reads // 2) and (hard or (proper / n > 0.95 and okpos / n > 0.97))
     # the same job through the device-resident path: one batch like the reference's (its insert-size statistics are per batch)
     from bwamem_hip.aligner import Aligner
     import io
@@ -73,6 +97,14 @@ if paired:
     theirs = [l.rstrip("\n") for l in open(sam) if l[0] != "@"]
     diff = [(a, b) for a, b in zip(ours, theirs) if a != b]
     print(f"device-resident path: {len(ours)} records; reference host code: {len(theirs)} records; differing records: {len(diff)}")
+    if diff:                                              # keep the evidence: both records and the pair's reads
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/e2e_diff_pe_t%s.txt" % threads, "w") as f:
+            f.write(f"{len(diff)} differing records of {len(ours)}\n")
+            for a, b in diff[:40]:
+                i = int(a.split("\t")[0][1:])
+                f.write("OURS   " + a + "\nTHEIRS " + b + "\n")
+                f.write("R1 " + asc[2 * i].tobytes().decode() + "\nR2 " + asc[2 * i + 1].tobytes().decode() + "\n")
     assert len(ours) == len(theirs) and not diff, diff[:2]
     print("SAM IDENTICAL")
     print("E2E DROP-IN OK")
@@ -98,7 +130,7 @@ for line in open(sam):
 print(f"reads {n} mapped {mapped} ({mapped/max(n,1):.4f}) correct position+strand {ok} ({ok/max(n,1):.4f})")
 lines = [l for l in open(sam) if l[0] != "@"][:3]
 print("".join(l[:200] + "\n" for l in lines))
-assert n == n_reads and ok / n > 0.97, "end-to-end accuracy too low"
+assert n == n_reads and (hard or ok / n > 0.97), "end-to-end accuracy too low"
 # the same job through the device-resident path (bwamem_hip.aligner): the records must equal the reference's, byte for byte
 from bwamem_hip.aligner import Aligner
 import io

@@ -302,12 +302,177 @@ __device__ __forceinline__ int row_scan_max_f(int v)     // inclusive; lanes wit
 	return v;
 }
 
+// three independent all-reduce max butterflies over each 16-lane row, interleaved so that the VALU-write -> DPP-read
+// hazard of one string is covered by the two others (no wait states inside)
+__device__ __forceinline__ void row_allmax3_f(int &x, int &y, int &z)
+{
+	asm volatile("s_nop 1\n\t"
+	             "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_max_i32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_max_i32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_max_i32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_max_i32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+	             "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+	             "v_max_i32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+	             "v_max_i32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+	             "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+	             "v_max_i32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+	             "v_max_i32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+	             : "+v"(x), "+v"(y), "+v"(z));
+}
+
+// Substitution scores as a bit-field table (LUT form, |a|,|b| < 32): five 6-bit signed fields, one per query code;
+// a row's table is the all-mismatch table with the field of its target base flipped to +a (all -1 when the target
+// base is N), so the score of a cell is ONE v_bfe_i32 with the column's precomputed shift.
+struct ext_lut_t { int base, flip, alln; };
+__device__ __forceinline__ ext_lut_t ext_lut(const ext_args_t &A)
+{
+	ext_lut_t L;
+	const int mb = (-A.b) & 63;
+	L.base = mb | (mb << 6) | (mb << 12) | (mb << 18) | (63 << 24);
+	L.flip = (mb ^ A.a) & 63;
+	L.alln = 63 | (63 << 6) | (63 << 12) | (63 << 18) | (63 << 24);
+	return L;
+}
+
+// per-alignment control state, replicated over the 16 lanes of the row
+struct ext_rs_t { int beg, end, mx, max_i, max_j, max_ie, gscore, max_off; };
+
+// One DP row of up to four alignments (one per 16-lane row).  Cells left of `beg` need no mask: their inputs are
+// zero (that is why beg moved past them) and zero inputs give zero outputs; cells at or right of `end` are masked
+// (H = E = 0), and what their unmasked M feeds into the F scan only reaches cells further right, all masked too.
+// F is carried unclamped: max(F,0) is what the reference holds, and H = max(M,E,F) with E >= 0 absorbs the clamp.
+// Returns the new `alive`.
+template <int C, bool LUT>
+__device__ __forceinline__ bool ext_row(const ext_args_t &A, const ext_lut_t &L, const int oe_del, const int oe_ins,
+                                        int (&H)[C], int (&E)[C], const int (&qv)[C], const int (&mmv)[C],
+                                        const int ti, const bool run, const int hfc, const int hnx, const int i, const int qlen,
+                                        const int j0, const int ej0, const int jl_lane, ext_rs_t &S, bool alive, const bool bound)
+{
+	const int wend = run ? S.end - j0 : 0;                      // cells c < wend of this lane are left of `end`
+	const int left = row_shr1(H[C - 1], S.beg == 0 ? hfc : 0);
+	const bool tN = ti > 3;
+	int tbl = 0;
+	if (LUT) tbl = tN ? L.alln : (L.base ^ (L.flip << (6 * ti)));
+	int M[C];
+	int agg = NEG_INF;
+	const int kc0 = ej0 - oe_ins;
+#pragma unroll
+	for (int c = 0; c < C; ++c) {
+		const int hd = c == 0 ? left : H[c - 1];
+		int sc;
+		if (LUT) sc = __builtin_amdgcn_sbfe(tbl, (unsigned)qv[c], 6u);
+		else sc = ti == qv[c] ? A.a : (tN ? -1 : mmv[c]);
+		const int m = hd != 0 ? hd + sc : 0;
+		M[c] = m;
+		agg = max(agg, m + kc0 + A.e_ins * c);                  // (M - oe_ins) + e_ins * j
+	}
+	int f = row_shr1(row_scan_max_f(agg), NEG_INF) - (ej0 - A.e_ins);      // F of this lane's first column
+	int key = 0;                                                // (h << 16) | cell: row maximum, last column on ties
+	int nzm = 0;                                                // bit (C-1-c): H != 0; bit 16 + (C-1-c): E != 0
+	int hl = 0;                                                 // H of this lane's last cell left of `end`
+#pragma unroll
+	for (int c = 0; c < C; ++c) {
+		const bool act = c < wend;
+		const int hraw = max(max(M[c], E[c]), f);
+		const int e = act ? max(max(E[c] - A.e_del, M[c] - oe_del), 0) : 0;
+		f = max(f - A.e_ins, M[c] - oe_ins);
+		const int h = act ? hraw : 0;
+		hl = act ? hraw : hl;
+		H[c] = h; E[c] = e;
+		key = max(key, (h << 16) | c);
+		const short2_t one = {1, 1};
+		const int nz = __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(short2_t, (e << 16) | h), one));
+		nzm = (nzm << 1) | nz;
+	}
+	key += j0;
+	// E(i+1,j) != 0 implies H(i,j) != 0 (H >= E(i,j) and H >= M), so the non-zero span of eh[] follows from the non-zero H
+	// columns alone: last index = last column + 1, first = first column (+1 if its E is 0)
+	const unsigned hm = (unsigned)nzm & 0xFFFFu;
+	const int p_hi = 31 - __clz((int)hm), p_lo = __ffs((int)hm) - 1;          // hm == 0: unused
+	const int enz = (nzm >> (16 + p_hi)) & 1;
+	int nfirst = hm ? -(j0 + (C - 1 - p_hi) + (enz ? 0 : 1)) : NEG_INF;
+	int nlast = hm ? j0 + (C - 1 - p_lo) + 1 : -1;
+	row_allmax3_f(key, nfirst, nlast);
+	const int m = key >> 16, mj = key & 0xFFFF;
+	// gscore: H(i, qlen-1) when the row reaches the query end (ksw.c:942-945)
+	{
+		int h1 = __builtin_amdgcn_ds_bpermute(jl_lane, hl);
+		h1 = qlen == 0 ? (S.beg == 0 ? hnx : 0) : h1;
+		const bool ge = run && S.end == qlen;
+		S.max_ie = (ge && !(S.gscore > h1)) ? i : S.max_ie;
+		S.gscore = ge ? max(S.gscore, h1) : S.gscore;
+	}
+	const bool upd = run && m != 0;
+	alive = alive && !(run && m == 0);                          // ksw.c:946
+	const bool better = upd && m > S.mx;
+	S.max_off = better ? max(S.max_off, abs(mj - i)) : S.max_off;
+	S.max_i = better ? i : S.max_i;
+	S.max_j = better ? mj : S.max_j;
+	if (A.zdrop > 0) {                                          // wave-uniform branch (ksw.c:951-959)
+		const int di = i - S.max_i, dj = mj - S.max_j;
+		const int pen = di > dj ? (di - dj) * A.e_del : (dj - di) * A.e_ins;
+		alive = alive && !(upd && !better && S.mx - m - pen > A.zdrop);
+	}
+	S.mx = better ? m : S.mx;
+	// next row's [beg,end) (ksw.c:963-970): first / last non-zero of eh[beg..end]
+	{
+		const int h1i = S.beg == 0 ? hnx : 0;
+		const bool none = nfirst == NEG_INF;
+		int fidx = none ? (1 << 20) : -nfirst;
+		int lidx = none ? -1 : nlast;
+		fidx = h1i ? min(fidx, S.beg) : fidx;
+		lidx = h1i ? max(lidx, S.beg) : lidx;
+		const int nbeg = min(fidx, S.end);
+		const int nend = min(qlen, max(lidx, nbeg - 1) + 2);
+		S.beg = upd ? nbeg : S.beg;
+		S.end = upd ? nend : S.end;
+	}
+	// Exact early stop.  Phi(v at column c) = v + a*(qlen-1-c) never increases along a DP transition
+	// (diagonal: +s <= +a and one column right; E: same column minus a gap cost; F: right minus a gap
+	// cost), so every H of every later row is <= U = max Phi over this row's frontier {H(i,j), E(i+1,j),
+	// first-column value}.  Once U <= max and U < gscore no later row can change max/max_i/max_j/max_off
+	// (strict >, ksw.c:948) nor gscore/max_ie (>=, ksw.c:943): the remaining rows are dead work.
+	if (bound) {                                                // wave-uniform
+		const int aq = A.a * (qlen - 1 - j0);
+		int u = 0;
+#pragma unroll
+		for (int c = 0; c < C; ++c) u = max(u, max(H[c], E[c]) + (aq - A.a * c));
+		const int h1n = S.beg == 0 ? hnx : 0;
+		u = max(u, h1n + A.a * qlen);
+		u = row_allmax_f(u);
+		alive = alive && !(u <= S.mx && u < S.gscore);
+	}
+	return alive;
+}
+
+// column state of a new alignment; query codes above 3 are N (code 4); the target's N is 5 so that N never "matches"
+// (mat[4][4] = -1, bwa.c:99-108)
+template <int C, bool LUT>
+__device__ __forceinline__ void ext_cols_init(const ext_args_t &A, const job_src_t &src, const int j0, const int qlen, const int h0, const int oe_ins,
+                                              int (&H)[C], int (&E)[C], int (&qv)[C], int (&mmv)[C])
+{
+#pragma unroll
+	for (int c = 0; c < C; ++c) {
+		const int j = j0 + c;
+		int qb = j < qlen ? ext_q_at(A, src, j) : 4;
+		qb = qb > 3 ? 4 : qb;
+		qv[c] = LUT ? 6 * qb : qb;
+		mmv[c] = qb > 3 ? -1 : -A.b;                             // mismatch score of this column (generic form)
+		const int v = h0 - oe_ins - j * A.e_ins;
+		H[c] = (j < qlen && v > 0) ? v : 0;
+		E[c] = 0;
+	}
+}
+
 // Two forms of the 16-lane-row kernel.  extend16_static_kernel: a wave takes four consecutive jobs of the sorted list
 // and runs them side by side to the end of the longest -- one set of loads per four jobs, which suits the short
 // alignments of the small classes (few rows per job, the fetch latency of a job is a large part of it).
 // extend16_kernel: every row draws its next job from a counter as soon as its alignment ends -- no waiting for the
 // slowest of four (3.0 -> 3.8 live alignments per wave-row), which pays once a job is long enough to hide the draw.
-template <int C>
+// LUT: substitution scores from the bit-field table (|a|,|b| < 32); the generic form compares and selects.
+template <int C, bool LUT>
 __global__ void __launch_bounds__(256) extend16_static_kernel(ext_args_t A)
 {
 	const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
@@ -319,24 +484,16 @@ __global__ void __launch_bounds__(256) extend16_static_kernel(ext_args_t A)
 	const int j0 = l16 * C;                                    // first column of this lane
 	const int ej0 = A.e_ins * j0;
 	const int bp_base = (lane & 48) << 2;                      // byte address of this row's lane 0 for ds_bpermute
+	const ext_lut_t L = ext_lut(A);
 	for (uint32_t w = wave * 4; w < n; w += n_waves * 4) {
 		const bool have = w + grp < n;
 		const uint32_t id = have ? ids[w + grp] : 0;
 		const int qlen = have ? (int)A.qlen[id] : 0, tlen = have ? (int)A.tlen[id] : 0, h0 = have ? (int)A.h0[id] : 1;
 		const job_src_t src = ext_job_src(A, id, have, qlen, tlen);
-		// column state; query N is code 4, target N is made 5 below so that N never "matches" (mat[4][4] = -1, bwa.c:99-108)
-		int H[C], E[C], qb[C], mm[C];
-#pragma unroll
-		for (int c = 0; c < C; ++c) {
-			const int j = j0 + c;
-			qb[c] = j < qlen ? ext_q_at(A, src, j) : 4;
-			mm[c] = qb[c] > 3 ? -1 : -A.b;                   // mismatch score of this column
-			const int v = h0 - oe_ins - j * A.e_ins;
-			H[c] = (j < qlen && v > 0) ? v : 0;
-			E[c] = 0;
-		}
-		const int jl = qlen - 1, jl_lane = bp_base + (((jl < 0 ? 0 : jl) / C) << 2), jl_c = (jl < 0 ? 0 : jl) % C;
-		int beg = 0, end = qlen, mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+		int H[C], E[C], qv[C], mmv[C];
+		ext_cols_init<C, LUT>(A, src, j0, qlen, h0, oe_ins, H, E, qv, mmv);
+		const int jl = qlen - 1, jl_lane = bp_base + (((jl < 0 ? 0 : jl) / C) << 2);
+		ext_rs_t S = {0, qlen, h0, -1, -1, -1, -1, 0};
 		bool alive = have;
 		int tchunk = 5;
 		int rows_done = 0, wave_rows = 0;
@@ -346,111 +503,18 @@ __global__ void __launch_bounds__(256) extend16_static_kernel(ext_args_t A)
 			const int ti = __builtin_amdgcn_ds_bpermute(bp_base + ((i & 15) << 2), tchunk);
 			const bool run = alive && i < tlen;
 			rows_done += run ? 1 : 0;
-			const int dsub = i == 0 ? 0 : A.o_del + A.e_del * i;          // wave-uniform
-			const int hm1 = max(0, h0 - dsub);
-			const int left = row_shr1(H[C - 1], beg == 0 ? hm1 : 0);
-			const unsigned wdt = (unsigned)(end - beg);
-			const int jb0 = j0 - beg;
-			const bool tN = ti > 3;
-			int M[C], g[C];
-			bool act[C];
-			int agg = NEG_INF;
-#pragma unroll
-			for (int c = 0; c < C; ++c) {
-				act[c] = run && (unsigned)(jb0 + c) < wdt;
-				const int hd = c == 0 ? left : H[c - 1];
-				const int sc = ti == qb[c] ? A.a : (tN ? -1 : mm[c]);
-				const int m = (act[c] && hd != 0) ? hd + sc : 0;
-				M[c] = m;
-				g[c] = act[c] ? max(m - oe_ins, 0) + (ej0 + A.e_ins * c) : NEG_INF;
-				agg = max(agg, g[c]);
-			}
-			int runmax = row_shr1(row_scan_max_f(agg), NEG_INF);
-			int key = 0;                                        // (h << 16) | column: row maximum, last column on ties
-			int fl = (int)0x80008000;                           // packed {hi: -(first non-zero H column), lo: last non-zero H column}
-			int efirst = 0;                                     // E of this lane's first non-zero H column
-#pragma unroll
-			for (int c = 0; c < C; ++c) {
-				const int j = j0 + c;
-				const int f = max(0, runmax - (ej0 + A.e_ins * (c - 1)));
-				runmax = max(runmax, g[c]);
-				const int h = act[c] ? max(max(M[c], E[c]), f) : 0;
-				const int e = act[c] ? max(max(E[c] - A.e_del, M[c] - oe_del), 0) : 0;
-				H[c] = h; E[c] = e;
-				key = max(key, act[c] ? ((h << 16) | j) : 0);
-				// E(i+1,j) != 0 implies H(i,j) != 0 (H >= E(i,j) and H >= M), so the non-zero span of eh[] follows
-				// from the non-zero H columns alone: last index = last column + 1, first = first column (+1 if its E is 0)
-				const int pk = ((-j) << 16) | j;
-				const bool nzh = h != 0;
-				efirst = (nzh && fl == (int)0x80008000) ? e : efirst;
-				fl = nzh ? pk_max(fl, pk) : fl;
-			}
-			key = row_allmax_f(key);
-			const int m = key >> 16, mj = key & 0xFFFF;
-			// gscore: H(i, qlen-1) when the row reaches the query end (ksw.c:942-945)
-			{
-				int src = H[0];
-#pragma unroll
-				for (int c = 1; c < C; ++c) src = jl_c == c ? H[c] : src;
-				int h1 = __builtin_amdgcn_ds_bpermute(jl_lane, src);
-				h1 = qlen == 0 ? (beg == 0 ? max(0, h0 - (A.o_del + A.e_del * (i + 1))) : 0) : h1;
-				const bool ge = run && end == qlen;
-				max_ie = (ge && !(gscore > h1)) ? i : max_ie;
-				gscore = ge ? max(gscore, h1) : gscore;
-			}
-			const bool upd = run && m != 0;
-			alive = alive && !(run && m == 0);                  // ksw.c:946
-			const bool better = upd && m > mx;
-			max_off = better ? max(max_off, abs(mj - i)) : max_off;
-			max_i = better ? i : max_i;
-			max_j = better ? mj : max_j;
-			if (A.zdrop > 0) {                                  // wave-uniform branch (ksw.c:951-959)
-				const int di = i - max_i, dj = mj - max_j;
-				const int pen = di > dj ? (di - dj) * A.e_del : (dj - di) * A.e_ins;
-				alive = alive && !(upd && !better && mx - m - pen > A.zdrop);
-			}
-			mx = better ? m : mx;
-			// next row's [beg,end) (ksw.c:963-970): first / last non-zero of eh[beg..end]
-			{
-				// this lane's candidate for the first index: its first non-zero H column, +1 if E there is 0
-				const int myfirst = -(fl >> 16) + (efirst == 0 ? 1 : 0);
-				const int packed = fl == (int)0x80008000 ? fl : ((((-myfirst) << 16)) | ((fl & 0xFFFF) + 1));
-				const int red = row_allmax_pk(packed);
-				const int h1i = beg == 0 ? max(0, h0 - (A.o_del + A.e_del * (i + 1))) : 0;
-				const bool none = (red >> 16) == (int)(short)0x8000;
-				int fidx = none ? (1 << 20) : -(red >> 16);
-				int lidx = none ? -1 : (int)(short)(red & 0xFFFF);
-				fidx = h1i ? min(fidx, beg) : fidx;
-				lidx = h1i ? max(lidx, beg) : lidx;
-				const int nbeg = min(fidx, end);
-				const int nend = min(qlen, max(lidx, nbeg - 1) + 2);
-				beg = upd ? nbeg : beg;
-				end = upd ? nend : end;
-			}
-			// Exact early stop.  Phi(v at column c) = v + a*(qlen-1-c) never increases along a DP transition
-			// (diagonal: +s <= +a and one column right; E: same column minus a gap cost; F: right minus a gap
-			// cost), so every H of every later row is <= U = max Phi over this row's frontier {H(i,j), E(i+1,j),
-			// first-column value}.  Once U <= max and U < gscore no later row can change max/max_i/max_j/max_off
-			// (strict >, ksw.c:948) nor gscore/max_ie (>=, ksw.c:943): the remaining rows are dead work.
-			if ((i & 3) == 3) {
-				const int aq = A.a * (qlen - 1 - j0);
-				int u = 0;
-#pragma unroll
-				for (int c = 0; c < C; ++c) u = max(u, max(H[c], E[c]) + (aq - A.a * c));
-				const int h1n = beg == 0 ? max(0, h0 - (A.o_del + A.e_del * (i + 1))) : 0;
-				u = max(u, h1n + A.a * qlen);
-				u = row_allmax_f(u);
-				alive = alive && !(u <= mx && u < gscore);
-			}
+			const int hfc = max(0, h0 - (i == 0 ? 0 : A.o_del + A.e_del * i));        // H(i-1,-1)
+			const int hnx = max(0, h0 - (A.o_del + A.e_del * (i + 1)));
+			alive = ext_row<C, LUT>(A, L, oe_del, oe_ins, H, E, qv, mmv, ti, run, hfc, hnx, i, qlen, j0, ej0, jl_lane, S, alive, (i & 3) == 3);
 		}
 		if (have && l16 == 0) {
-			const int qle = max_j + 1, tle = max_i + 1, gtle = max_ie + 1;
+			const int qle = S.max_j + 1, tle = S.max_i + 1, gtle = S.max_ie + 1;
 			int32_t *o = A.out + 3 * (size_t)id;
-			if (gscore <= 0 || gscore <= mx - A.end_bonus) { o[0] = mx; o[1] = qle; o[2] = tle; }
-			else { o[0] = gscore; o[1] = qlen; o[2] = gtle; }
+			if (S.gscore <= 0 || S.gscore <= S.mx - A.end_bonus) { o[0] = S.mx; o[1] = qle; o[2] = tle; }
+			else { o[0] = S.gscore; o[1] = qlen; o[2] = gtle; }
 			if (A.raw) {
 				int32_t *r = A.raw + 6 * (size_t)id;
-				r[0] = mx; r[1] = qle; r[2] = tle; r[3] = gtle; r[4] = gscore; r[5] = max_off;
+				r[0] = S.mx; r[1] = qle; r[2] = tle; r[3] = gtle; r[4] = S.gscore; r[5] = S.max_off;
 			}
 			if (A.stats) { atomicAdd(A.stats, (unsigned long long)rows_done); atomicAdd(A.stats + 1, (unsigned long long)tlen); atomicAdd(A.stats + 2, 1ull); if (grp == 0) atomicAdd(A.stats + 3, (unsigned long long)wave_rows); }
 		}
@@ -458,7 +522,7 @@ __global__ void __launch_bounds__(256) extend16_static_kernel(ext_args_t A)
 }
 
 
-template <int C>
+template <int C, bool LUT>
 __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 {
 	const int lane = threadIdx.x & 63, l16 = lane & 15;
@@ -468,10 +532,11 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 	const int j0 = l16 * C;                                    // first column of this lane
 	const int ej0 = A.e_ins * j0;
 	const int bp_base = (lane & 48) << 2;                      // byte address of this row's lane 0 for ds_bpermute
+	const ext_lut_t L = ext_lut(A);
 	// Each 16-lane row works on its own alignment and row index; a row whose alignment has ended takes the next job
 	// of the class from a global counter (longest first), so the four rows of a wave never wait for the slowest.
 	// the target of a row's alignment is staged in LDS when the row takes the job (EXT_T_CAP bases; longer targets
-	// read the rest straight from memory), so the row loop itself has no global loads to wait for
+	// never reach this kernel: ext_key_kernel), so the row loop itself has no global loads to wait for
 	__shared__ uint8_t t_lds[16][EXT_T_CAP];
 	uint8_t *tl = t_lds[threadIdx.x >> 4];
 	bool have = false, alive = false;
@@ -480,11 +545,11 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 	int hfc = 0, dn = 0;          // first-column value H(i-1,-1) of the current row; o_del + e_del*(i+1)
 	const uint8_t *tp = tl;
 	job_src_t src = ext_job_src(A, 0, false, 0, 0);
-	int H[C], E[C], qb[C], mm[C];
+	int H[C], E[C], qv[C], mmv[C];
 #pragma unroll
-	for (int c = 0; c < C; ++c) { H[c] = E[c] = 0; qb[c] = 4; mm[c] = -1; }
-	int jl_lane = bp_base, jl_c = 0;
-	int beg = 0, end = 0, mx = 0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+	for (int c = 0; c < C; ++c) { H[c] = E[c] = 0; qv[c] = LUT ? 24 : 4; mmv[c] = -1; }
+	int jl_lane = bp_base;
+	ext_rs_t S = {0, 0, 0, -1, -1, -1, -1, 0};
 	int rows_done = 0, wave_rows = 0;
 	bool more = true;                                          // the class still has unassigned jobs (wave-uniform)
 	for (;;) {
@@ -492,13 +557,13 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 		const unsigned long long nb = __ballot(!alive && l16 == 0 && (more || have));
 		if (nb) {
 			if (!alive && have && l16 == 0) {                   // results of the alignment that just ended
-				const int qle = max_j + 1, tle = max_i + 1, gtle = max_ie + 1;
+				const int qle = S.max_j + 1, tle = S.max_i + 1, gtle = S.max_ie + 1;
 				int32_t *o = A.out + 3 * (size_t)id;
-				if (gscore <= 0 || gscore <= mx - A.end_bonus) { o[0] = mx; o[1] = qle; o[2] = tle; }
-				else { o[0] = gscore; o[1] = qlen; o[2] = gtle; }
+				if (S.gscore <= 0 || S.gscore <= S.mx - A.end_bonus) { o[0] = S.mx; o[1] = qle; o[2] = tle; }
+				else { o[0] = S.gscore; o[1] = qlen; o[2] = gtle; }
 				if (A.raw) {
 					int32_t *r = A.raw + 6 * (size_t)id;
-					r[0] = mx; r[1] = qle; r[2] = tle; r[3] = gtle; r[4] = gscore; r[5] = max_off;
+					r[0] = S.mx; r[1] = qle; r[2] = tle; r[3] = gtle; r[4] = S.gscore; r[5] = S.max_off;
 				}
 				if (A.stats) { atomicAdd(A.stats, (unsigned long long)rows_done); atomicAdd(A.stats + 1, (unsigned long long)tlen); atomicAdd(A.stats + 2, 1ull); }
 			}
@@ -516,19 +581,10 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 				id = have ? ids[n - 1 - k] : 0;
 				qlen = have ? (int)A.qlen[id] : 0; tlen = have ? (int)A.tlen[id] : 0; h0 = have ? (int)A.h0[id] : 1;
 				src = ext_job_src(A, id, have, qlen, tlen);
-				// column state; query N is code 4, target N is made 5 below so that N never "matches" (mat[4][4] = -1, bwa.c:99-108)
-#pragma unroll
-				for (int c = 0; c < C; ++c) {
-					const int j = j0 + c;
-					qb[c] = j < qlen ? ext_q_at(A, src, j) : 4;
-					mm[c] = qb[c] > 3 ? -1 : -A.b;               // mismatch score of this column
-					const int v = h0 - oe_ins - j * A.e_ins;
-					H[c] = (j < qlen && v > 0) ? v : 0;
-					E[c] = 0;
-				}
+				ext_cols_init<C, LUT>(A, src, j0, qlen, h0, oe_ins, H, E, qv, mmv);
 				const int jl = qlen - 1;
-				jl_lane = bp_base + (((jl < 0 ? 0 : jl) / C) << 2); jl_c = (jl < 0 ? 0 : jl) % C;
-				beg = 0; end = qlen; mx = h0; max_i = -1; max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
+				jl_lane = bp_base + (((jl < 0 ? 0 : jl) / C) << 2);
+				S.beg = 0; S.end = qlen; S.mx = h0; S.max_i = -1; S.max_j = -1; S.max_ie = -1; S.gscore = -1; S.max_off = 0;
 				i = 0; rows_done = 0; hfc = h0; dn = oe_del; tp = tl;
 				for (int k = l16; k < tlen && k < EXT_T_CAP; k += 16) { const int tb = ext_t_at(A, src, k); tl[k] = (uint8_t)(tb > 3 ? 5 : tb); }
 				alive = have && tlen > 0;
@@ -539,105 +595,12 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 			continue;                                           // every row drew a zero-row job: draw again
 		}
 		++wave_rows;
-		const int ti = (int)*tp;                                // targets longer than EXT_T_CAP never reach this kernel (ext_key_kernel)
+		const int ti = (int)*tp;
 		const bool run = alive;
 		rows_done += run ? 1 : 0;
 		const int hnx = max(0, h0 - dn);                        // first-column value of the next row: max(0, h0 - (o_del + e_del*(i+1)))
-		const int left = row_shr1(H[C - 1], beg == 0 ? hfc : 0);
-		const unsigned wdt = (unsigned)(end - beg);
-		const int jb0 = j0 - beg;
-		const bool tN = ti > 3;
-		int M[C], g[C];
-		bool act[C];
-		int agg = NEG_INF;
-#pragma unroll
-		for (int c = 0; c < C; ++c) {
-			act[c] = run && (unsigned)(jb0 + c) < wdt;
-			const int hd = c == 0 ? left : H[c - 1];
-			const int sc = ti == qb[c] ? A.a : (tN ? -1 : mm[c]);
-			const int m = (act[c] && hd != 0) ? hd + sc : 0;
-			M[c] = m;
-			g[c] = act[c] ? max(m - oe_ins, 0) + (ej0 + A.e_ins * c) : NEG_INF;
-			agg = max(agg, g[c]);
-		}
-		int runmax = row_shr1(row_scan_max_f(agg), NEG_INF);
-		int key = 0;                                        // (h << 16) | column: row maximum, last column on ties
-		int fl = (int)0x80008000;                           // packed {hi: -(first non-zero H column), lo: last non-zero H column}
-		int efirst = 0;                                     // E of this lane's first non-zero H column
-#pragma unroll
-		for (int c = 0; c < C; ++c) {
-			const int j = j0 + c;
-			const int f = max(0, runmax - (ej0 + A.e_ins * (c - 1)));
-			runmax = max(runmax, g[c]);
-			const int h = act[c] ? max(max(M[c], E[c]), f) : 0;
-			const int e = act[c] ? max(max(E[c] - A.e_del, M[c] - oe_del), 0) : 0;
-			H[c] = h; E[c] = e;
-			key = max(key, act[c] ? ((h << 16) | j) : 0);
-			// E(i+1,j) != 0 implies H(i,j) != 0 (H >= E(i,j) and H >= M), so the non-zero span of eh[] follows
-			// from the non-zero H columns alone: last index = last column + 1, first = first column (+1 if its E is 0)
-			const int pk = ((-j) << 16) | j;
-			const bool nzh = h != 0;
-			efirst = (nzh && fl == (int)0x80008000) ? e : efirst;
-			fl = nzh ? pk_max(fl, pk) : fl;
-		}
-		key = row_allmax_f(key);
-		const int m = key >> 16, mj = key & 0xFFFF;
-		// gscore: H(i, qlen-1) when the row reaches the query end (ksw.c:942-945)
-		{
-			int hs = H[0];
-#pragma unroll
-			for (int c = 1; c < C; ++c) hs = jl_c == c ? H[c] : hs;
-			int h1 = __builtin_amdgcn_ds_bpermute(jl_lane, hs);
-			h1 = qlen == 0 ? (beg == 0 ? hnx : 0) : h1;
-			const bool ge = run && end == qlen;
-			max_ie = (ge && !(gscore > h1)) ? i : max_ie;
-			gscore = ge ? max(gscore, h1) : gscore;
-		}
-		const bool upd = run && m != 0;
-		alive = alive && !(run && m == 0);                  // ksw.c:946
-		const bool better = upd && m > mx;
-		max_off = better ? max(max_off, abs(mj - i)) : max_off;
-		max_i = better ? i : max_i;
-		max_j = better ? mj : max_j;
-		if (A.zdrop > 0) {                                  // wave-uniform branch (ksw.c:951-959)
-			const int di = i - max_i, dj = mj - max_j;
-			const int pen = di > dj ? (di - dj) * A.e_del : (dj - di) * A.e_ins;
-			alive = alive && !(upd && !better && mx - m - pen > A.zdrop);
-		}
-		mx = better ? m : mx;
-		// next row's [beg,end) (ksw.c:963-970): first / last non-zero of eh[beg..end]
-		{
-			// this lane's candidate for the first index: its first non-zero H column, +1 if E there is 0
-			const int myfirst = -(fl >> 16) + (efirst == 0 ? 1 : 0);
-			const int packed = fl == (int)0x80008000 ? fl : ((((-myfirst) << 16)) | ((fl & 0xFFFF) + 1));
-			const int red = row_allmax_pk(packed);
-			const int h1i = beg == 0 ? hnx : 0;
-			const bool none = (red >> 16) == (int)(short)0x8000;
-			int fidx = none ? (1 << 20) : -(red >> 16);
-			int lidx = none ? -1 : (int)(short)(red & 0xFFFF);
-			fidx = h1i ? min(fidx, beg) : fidx;
-			lidx = h1i ? max(lidx, beg) : lidx;
-			const int nbeg = min(fidx, end);
-			const int nend = min(qlen, max(lidx, nbeg - 1) + 2);
-			beg = upd ? nbeg : beg;
-			end = upd ? nend : end;
-		}
-		// Exact early stop.  Phi(v at column c) = v + a*(qlen-1-c) never increases along a DP transition
-		// (diagonal: +s <= +a and one column right; E: same column minus a gap cost; F: right minus a gap
-		// cost), so every H of every later row is <= U = max Phi over this row's frontier {H(i,j), E(i+1,j),
-		// first-column value}.  Once U <= max and U < gscore no later row can change max/max_i/max_j/max_off
-		// (strict >, ksw.c:948) nor gscore/max_ie (>=, ksw.c:943): the remaining rows are dead work.
-		// (evaluated every fourth iteration of the wave for all its rows: the bound is exact at any row)
-		if ((wave_rows & 3) == 0) {
-			const int aq = A.a * (qlen - 1 - j0);
-			int u = 0;
-#pragma unroll
-			for (int c = 0; c < C; ++c) u = max(u, max(H[c], E[c]) + (aq - A.a * c));
-			const int h1n = beg == 0 ? hnx : 0;
-			u = max(u, h1n + A.a * qlen);
-			u = row_allmax_f(u);
-			alive = alive && !(u <= mx && u < gscore);
-		}
+		// (the early-stop bound is evaluated every fourth iteration of the wave for all its rows: it is exact at any row)
+		alive = ext_row<C, LUT>(A, L, oe_del, oe_ins, H, E, qv, mmv, ti, run, hfc, hnx, i, qlen, j0, ej0, jl_lane, S, alive, (wave_rows & 3) == 0);
 		if (run) { ++i; ++tp; hfc = hnx; dn += A.e_del; }
 		alive = alive && i < tlen;
 	}
@@ -788,10 +751,10 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 
 // ------------------------------------------------------------------ host side
 
-// classes: 0 = unsupported length; 1..18 = extend16_kernel<C>; 19..22 = extend_wide_kernel<5..8>
+// classes: 0 = unsupported length; 1..16 = extend16_kernel<C>; 19..22 = extend_wide_kernel<5..8>
 #define EXT_N_CLS 24
 #define EXT_DONE_CLS 23     // decided by the closed-form prefilter: no DP
-#define EXT16_MAX_C 18
+#define EXT16_MAX_C 16
 
 __device__ __forceinline__ int ext_class(uint32_t ql)
 {
@@ -880,8 +843,10 @@ static void launch16(const ext_args_t &base, hipStream_t st, unsigned grid)
 	ext_args_t a = base;
 	a.count = base.count + 2 * C;
 	a.ctr = base.ctr + C;
-	if (C >= g_ext_refill_from) extend16_kernel<C><<<grid, 256, g_ext_lds, st>>>(a);
-	else extend16_static_kernel<C><<<grid, 256, g_ext_lds, st>>>(a);
+	const bool lut = a.a >= 0 && a.a < 32 && a.b >= 0 && a.b < 32;
+	if (!lut) extend16_static_kernel<C, false><<<grid, 256, g_ext_lds, st>>>(a);
+	else if (C >= g_ext_refill_from) extend16_kernel<C, true><<<grid, 256, g_ext_lds, st>>>(a);
+	else extend16_static_kernel<C, true><<<grid, 256, g_ext_lds, st>>>(a);
 }
 template <int C>
 static void launch_wide(const ext_args_t &base, hipStream_t st, unsigned grid)
@@ -992,7 +957,6 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	launch16<5>(a, S[0], g16); launch16<6>(a, S[1], g16); launch16<7>(a, S[2], g16); launch16<8>(a, S[3], g16);
 	launch16<9>(a, S[0], g16); launch16<10>(a, S[1], g16); launch16<11>(a, S[2], g16); launch16<12>(a, S[3], g16);
 	launch16<13>(a, S[0], g16); launch16<14>(a, S[1], g16); launch16<15>(a, S[2], g16); launch16<16>(a, S[3], g16);
-	launch16<17>(a, S[0], g16); launch16<18>(a, S[1], g16);
 	launch_wide<5>(a, S[2], gw); launch_wide<6>(a, S[3], gw); launch_wide<7>(a, S[2], gw); launch_wide<8>(a, S[3], gw);
 	for (int i = 0; i < 4; ++i) { HIPCK(hipEventRecord(g_scr.join[i], g_scr.side[i])); HIPCK(hipStreamWaitEvent(st, g_scr.join[i], 0)); }
 	HIPCK(hipEventRecord(g_scr.ev1, st));

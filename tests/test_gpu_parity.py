@@ -132,6 +132,22 @@ def test_extension_matches_oracle(hip, oracle, zdrop):
     assert np.array_equal(got3, want3)
 
 
+@pytest.mark.parametrize("scoring", [(2, 5, 7, 2), (3, 31, 9, 3), (33, 40, 50, 7)])
+def test_extension_other_scorings(hip, oracle, scoring):
+    """Scores from the bit-field table (|a|,|b| < 32) and from the generic compare/select form (a = 33), with N bases in
+    queries and targets (make_ext_jobs plants them), z-drop on."""
+    import oracle_py
+    a, b, o, e = scoring
+    jobs = common.make_ext_jobs(3000, np.random.default_rng(31 + a))
+    h0 = (jobs[6].astype(np.int64) * a).astype(np.uint32)          # seed scores scale with the match score
+    jobs = jobs[:6] + (h0,)
+    want3, want6, _ = oracle.extend_batch(*jobs, params=oracle_py.KswParams(a, b, o, e, o, e, 100 * a, 5, 1), want_raw=True)
+    got3, got6 = gpu_extend(hip, jobs, zdrop=100 * a, scoring=scoring)
+    bad = np.nonzero((got6 != want6).any(1))[0]
+    assert bad.size == 0, f"{bad.size} raw mismatches, first {bad[:5]}: got {got6[bad[:5]]} want {want6[bad[:5]]} qlen {jobs[2][bad[:5]]} tlen {jobs[5][bad[:5]]}"
+    assert np.array_equal(got3, want3)
+
+
 def test_extension_long_queries(hip, oracle):
     jobs = common.make_ext_jobs(600, np.random.default_rng(22), maxq=512)
     want3, want6, _ = oracle.extend_batch(*jobs, want_raw=True)

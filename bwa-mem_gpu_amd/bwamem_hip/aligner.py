@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import fmindex
-from .lib import (ChainOpt, ChainWorkspace, ExtParams, Index, PostOpt, SeedWorkspace, _memcpy_d2d, _np_ptr, _i32p, _u32p, _u64p, _u8p,
+from .lib import (ChainOpt, ChainWorkspace, ExtParams, Index, PeOpt, PostOpt, SeedWorkspace, _memcpy_d2d, _np_ptr, _i32p, _u32p, _u64p, _u8p,
                   cigar_batch, finalize_pairs, format_sam, load_library)
 
 _NT4 = np.full(256, 4, np.uint8)
@@ -125,6 +125,8 @@ class Aligner:
         self.index = Index.upload(idx, pac=self.pac, l_pac=self.l_pac)
         self.copt = ChainOpt(); self.L.bmh_chain_opt_default(C.byref(self.copt))
         self.ep = ExtParams.default()
+        self.po = PostOpt(); self.L.bmh_post_opt_default(C.byref(self.po))
+        self.pe = PeOpt(); self.L.bmh_pe_opt_default(C.byref(self.pe))
         self.n_threads = n_threads or (os.cpu_count() or 1)
         self.profile = bool(os.environ.get("BMH_ALIGNER_PROFILE"))
         self.c_off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([c[1] for c in self.contigs])]), dtype=np.int64)
@@ -137,6 +139,56 @@ class Aligner:
         pac = ((codes[:, 0] << 6) | (codes[:, 1] << 4) | (codes[:, 2] << 2) | codes[:, 3]).astype(np.uint8)
         pac = np.ascontiguousarray(np.concatenate([pac, np.zeros(2, np.uint8)]))
         return cls(None, _mem=(idx, contigs or [("chrS", int(len(genome_fwd)))], pac), **kw)
+
+    def set_options(self, argv) -> None:
+        """gase_aln's command-line options (src/fastmap.c:166-262) that reach this path, as a list of strings, e.g.
+        ["-k", "23", "-A", "2", "-a"].  The device extension takes -A -B and the DELETION penalties -O -E for both gap
+        kinds, as the reference's GPU extension does (src/fastmap.c:417-424); -O/-E given as "del,ins" keep the pair for
+        the host stages.  Unlike the reference, nothing is rescaled by -A (pass every value you want changed).
+        -d and -L are accepted and ignored (they do not reach the reference's GPU extension either).  Not modelled: -x -r -s
+        -y (seeding variants the GPU seeding of the reference ignores too), -I -R -H -C -V -j."""
+        import math
+        co, ep, po, pe = self.copt, self.ep, self.po, self.pe
+        i = 0
+        def pair(v):
+            a, _, b = v.replace(";", ",").partition(",")
+            return int(a), int(b) if b else int(a)
+        while i < len(argv):
+            f = argv[i]
+            if f in ("-a", "-M", "-Y", "-S", "-P"):
+                if f == "-a": po.flag_all = 1
+                elif f == "-M": po.no_multi = 1
+                elif f == "-Y": po.softclip = 1
+                elif f == "-S": pe.no_rescue = 1
+                else: pe.no_pairing = 1
+                i += 1; continue
+            if i + 1 >= len(argv):
+                raise ValueError(f"option {f} needs a value")
+            v = argv[i + 1]; i += 2
+            if f == "-k": co.min_seed_len = int(v)
+            elif f == "-w": co.w = int(v)
+            elif f == "-c": co.max_occ = int(v)
+            elif f == "-D": co.drop_ratio = float(v)
+            elif f == "-G": co.max_chain_gap = int(v)
+            elif f == "-N": co.max_chain_extend = int(v)
+            elif f == "-W": co.min_chain_weight = int(v)
+            elif f == "-X": co.mask_level = float(v)
+            elif f == "-A":
+                co.a = ep.a = int(v)
+                if int(v) != 1:      # the reference seeds its extensions with the seed LENGTH as score (src/bwamem.c:1338, fill_extension(..., s->len)),
+                    import sys       # so its own scores stop being alignment scores when a != 1; that inconsistency is not reproduced here
+                    sys.stderr.write("[bwamem_hip] -A other than 1: records will not equal the reference's (its seed scores ignore -A)\n")
+            elif f == "-B": co.b = ep.b = int(v)
+            elif f == "-O": co.o_del, co.o_ins = pair(v); ep.o_del, ep.o_ins = co.o_del, co.o_ins
+            elif f == "-E": co.e_del, co.e_ins = pair(v); ep.e_del, ep.e_ins = co.e_del, co.e_ins
+            elif f == "-T": po.T = int(v)
+            elif f == "-h": po.max_XA_hits = pair(v)[0]
+            elif f == "-Q": po.mapQ_coef_len = float(int(v)); po.mapQ_coef_fac = int(math.log(int(v))) if int(v) > 0 else 0
+            elif f == "-U": pe.pen_unpaired = int(v)
+            elif f == "-m": pe.max_matesw = int(v)
+            elif f in ("-t", "-K", "-l", "-v", "-f", "-d", "-L"): pass   # threads, batch size, bookkeeping; -d -L: no effect on the GPU extension
+            else:
+                raise ValueError(f"option {f} is not modelled")
 
     def header(self) -> str:
         return "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in self.contigs)
@@ -175,7 +227,8 @@ class Aligner:
         out3 = torch.zeros(max(nj, 1), 3, dtype=torch.int32, device=dev)
         regs = torch.zeros(max(nr, 1), 8, dtype=torch.int32, device=dev)
         _lap("chain")
-        cw.extend(out3, params=self.ep)
+        e = self.ep                                             # the reference's GPU extension: deletion penalties for both gap kinds
+        cw.extend(out3, params=ExtParams(e.a, e.b, e.o_del, e.e_del, e.o_del, e.e_del, e.zdrop, e.end_bonus))
         cw.merge(out3, regs)
         _lap("extend+merge")
         rpr = torch.empty(n, dtype=torch.int32, device=dev); fr = torch.empty(n, dtype=torch.float32, device=dev)
@@ -183,7 +236,7 @@ class Aligner:
         regs_h = np.ascontiguousarray(regs[:nr].cpu().numpy())
         rpr_h = np.ascontiguousarray(rpr.cpu().numpy().view(np.uint32)); fr_h = np.ascontiguousarray(fr.cpu().numpy())
         _lap("D2H regions")
-        po = PostOpt(); L.bmh_post_opt_default(C.byref(po)); po.id0 = id0
+        po = PostOpt.from_buffer_copy(self.po); po.id0 = id0
         self._lap = _lap; self._prof = (_t, _nm)
         if paired:
             return self._finish_pairs(names, codes, offs, lens, r, o, l, regs_h, rpr_h, fr_h, po, cw, ws)
@@ -237,7 +290,7 @@ class Aligner:
     def _finish_pairs(self, names, codes, offs, lens, r, o, l, regs_h, rpr_h, fr_h, po, cw, ws) -> str:
         L, dev, n = self.L, self.dev, len(lens)
         fin, opr, h_rec, unflag, _ = finalize_pairs(self.copt, self.ep, po, self.l_pac, self.pac, codes, offs, lens, regs_h, rpr_h, fr_h,
-                                                    contigs=self.contigs if len(self.contigs) > 1 else None, n_threads=self.n_threads)
+                                                    contigs=self.contigs if len(self.contigs) > 1 else None, n_threads=self.n_threads, pe=self.pe)
         fin = np.ascontiguousarray(fin); m = len(fin)
         need = np.zeros(max(m, 1), np.uint8)
         L.bmh_sam_need_cigar_pe(C.byref(po), _np_ptr(fin if m else np.zeros((1, 16), np.int32), _i32p), _np_ptr(np.ascontiguousarray(opr), _u32p),

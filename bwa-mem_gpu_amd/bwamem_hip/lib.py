@@ -57,12 +57,13 @@ class ChainOpt(C.Structure):
 class PostOpt(C.Structure):
     """bmh_post_opt_t"""
     _fields_ = [("T", C.c_int), ("mask_level_redun", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int),
-                ("flag_all", C.c_int), ("id0", C.c_int64), ("XA_drop_ratio", C.c_float), ("max_XA_hits", C.c_int)]
+                ("flag_all", C.c_int), ("id0", C.c_int64), ("XA_drop_ratio", C.c_float), ("max_XA_hits", C.c_int),
+                ("no_multi", C.c_int), ("softclip", C.c_int)]
 
 
 class PeOpt(C.Structure):
     """bmh_pe_opt_t"""
-    _fields_ = [("pen_unpaired", C.c_int), ("max_ins", C.c_int), ("max_matesw", C.c_int)]
+    _fields_ = [("pen_unpaired", C.c_int), ("max_ins", C.c_int), ("max_matesw", C.c_int), ("no_rescue", C.c_int), ("no_pairing", C.c_int)]
 
 
 class DevJobsT(C.Structure):
@@ -337,10 +338,11 @@ def cigar_batch(index: Index, reads_t, offs_t, lens_t, regs_t, n: int, sel_t=Non
 
 
 def finalize_pairs(copt, ep, po, genome_len: int, pac: np.ndarray, reads_flat: np.ndarray, read_offs: np.ndarray, read_lens: np.ndarray,
-                   regs: np.ndarray, regs_per_read: np.ndarray, frac_rep: np.ndarray, contigs=None, n_threads: int = 1):
+                   regs: np.ndarray, regs_per_read: np.ndarray, frac_rep: np.ndarray, contigs=None, n_threads: int = 1, pe=None):
     """bmh_finalize_pairs -> (fin [m,16], per_read, h_rec, unflag, pes [4,5])"""
     L = load_library()
-    pe = PeOpt(); L.bmh_pe_opt_default(C.byref(pe))
+    if pe is None:
+        pe = PeOpt(); L.bmh_pe_opt_default(C.byref(pe))
     n = len(read_lens)
     a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)
     regs = a(regs, np.int32)

@@ -249,7 +249,7 @@ void select_se(const PCtx &c, ReadOut &o, int extra)
 		else if (p.secondary >= 0 && !c.x.po->flag_all) rep = 0;
 		else if (p.secondary >= 0 && p.score < o.regs[p.secondary].score * c.x.co->drop_ratio) rep = 0;
 		if (rep) {
-			if (l && p.secondary < 0) flag |= 0x800;
+			if (l && p.secondary < 0) flag |= c.x.po->no_multi ? 0x10000 : 0x800;
 			if (l && mapq > mapq0) mapq = mapq0;
 			if (l == 0) mapq0 = mapq;
 			++l;
@@ -265,7 +265,7 @@ int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // 
 	const uint8_t *seq[2] = {c.reads + c.offs[r0], c.reads + c.offs[r0 + 1]};
 	const int l_seq[2] = {(int)c.lens[r0], (int)c.lens[r0 + 1]};
 	int z[2] = {0, 0}, o, subo = 0, n_sub = 0, extra_flag = 1, n_pri[2];
-	{   // mate rescue for the best regions of each end
+	if (!c.pe->no_rescue) {   // mate rescue for the best regions of each end (src/bwamem_pair.c:273)
 		std::vector<Reg> b[2];
 		for (int i = 0; i < 2; ++i)
 			for (const Reg &r : *a[i]) if (r.score >= (*a[i])[0].score - c.pe->pen_unpaired) b[i].push_back(r);
@@ -276,7 +276,7 @@ int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // 
 	for (int i = 0; i < 2; ++i) { mark_primary(c.x, (int)a[i]->size(), a[i]->data(), (int64_t)(id << 1 | (uint64_t)i)); n_pri[i] = (int)a[i]->size(); }
 	for (int i = 0; i < 2; ++i) { out[i].sec_all.resize(a[i]->size()); for (size_t j = 0; j < a[i]->size(); ++j) out[i].sec_all[j] = (*a[i])[j].secondary; }
 	bool paired = false;
-	if (n_pri[0] && n_pri[1]) {
+	if (!c.pe->no_pairing && n_pri[0] && n_pri[1]) {        // src/bwamem_pair.c:287
 		o = pair_regs(c, a, (int)id, &subo, &n_sub, z, n_pri);
 		if (o > 0) {
 			int is_multi[2];
@@ -331,7 +331,7 @@ int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // 
 	if (!paired) {
 		int hh[2];
 		for (int i = 0; i < 2; ++i) hh[i] = (!a[i]->empty() && (*a[i])[0].score >= c.x.po->T) ? 0 : -1;
-		if (hh[0] >= 0 && hh[1] >= 0 && (*a[0])[0].rid == (*a[1])[0].rid) {
+		if (!c.pe->no_pairing && hh[0] >= 0 && hh[1] >= 0 && (*a[0])[0].rid == (*a[1])[0].rid) {      // src/bwamem_pair.c:386
 			int64_t dist;
 			const int d = infer_dir(c.x.l_pac, (*a[0])[0].rb, (*a[1])[0].rb, &dist);
 			if (!c.pes[d].failed && dist >= c.pes[d].low && dist <= c.pes[d].high) extra_flag |= 2;
@@ -343,7 +343,7 @@ int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // 
 
 } // namespace
 
-extern "C" void bmh_pe_opt_default(bmh_pe_opt_t *o) { o->pen_unpaired = 17; o->max_ins = 10000; o->max_matesw = 50; }
+extern "C" void bmh_pe_opt_default(bmh_pe_opt_t *o) { o->pen_unpaired = 17; o->max_ins = 10000; o->max_matesw = 50; o->no_rescue = 0; o->no_pairing = 0; }
 
 // Interleaved pairs (read 2i, 2i+1).  out[..][16] as bmh_finalize_regs (flag carries the pair bits 0x1 0x2 0x40 0x80 too,
 // [12] = the record's primary for the XA tag or -1); out_h[r] = record of read r's own alignment within its list (what the

@@ -275,7 +275,7 @@ extern "C" int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_
 				else if (p.secondary >= 0 && !popt->flag_all) rep = 0;
 				else if (p.secondary >= 0 && p.score < a[p.secondary].score * copt->drop_ratio) rep = 0;
 				if (rep) {
-					if (l && p.secondary < 0) flag |= 0x800;
+					if (l && p.secondary < 0) flag |= popt->no_multi ? 0x10000 : 0x800;     // src/bwamem.c:1754
 					if (l && mapq > mapq0) mapq = mapq0;
 					if (l == 0) mapq0 = mapq;
 					++l;

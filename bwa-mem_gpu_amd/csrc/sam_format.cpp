@@ -188,8 +188,8 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 			const int m_rid = mate_mapped ? m.rid : rid; const long long m_pos = mate_mapped ? m.pos : pos; const int m_rev = mate_mapped ? m.is_rev : (x.aln[2] ? 1 : 0);
 			int flag = (x.aln[2] ? 0x10 : 0) | x.fin[14];
 			if (pe) { if (m.rid < 0) flag |= 8; if (m_rev) flag |= 0x20; }
-			const bool hard = which > 0;
-			out += names + name_off[r]; out += '\t'; put_int(out, flag); out += '\t';
+			const bool hard = which > 0 && !po->softclip;      // src/bwamem.c:1540,1578
+			out += names + name_off[r]; out += '\t'; put_int(out, (flag & 0xffff) | (flag & 0x10000 ? 0x100 : 0)); out += '\t';
 			out += contig_names[rid]; out += '\t'; put_int(out, pos - (n_contigs > 1 ? contig_offset[rid] : 0) + 1); out += '\t';
 			put_int(out, x.fin[13]); out += '\t';
 			if (x.aln[3]) put_cigar(out, x, hard); else out += '*';

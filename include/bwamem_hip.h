@@ -172,6 +172,8 @@ typedef struct {
 	int64_t id0;                /* index of the batch's first read in the run (n_processed): seeds the tie-break hash */
 	float XA_drop_ratio;        /* 0.80: secondary hits scoring at least this share of their primary go to its XA tag */
 	int max_XA_hits;            /* 5: ... when there are no more than this many */
+	int no_multi;               /* MEM_F_NO_MULTI (-M): shorter split hits are flagged secondary (0x100) instead of supplementary */
+	int softclip;               /* MEM_F_SOFTCLIP (-Y): soft clips on every record (no hard clips on the later ones) */
 } bmh_post_opt_t;
 void bmh_post_opt_default(bmh_post_opt_t *o);
 
@@ -210,7 +212,7 @@ void bmh_free(void *p);
  * its list (-1 unmapped); out_unflag[r]: pair flags of the unmapped record of a read without reported alignment;
  * pes_out[4][5] (optional) = {low, high, failed, avg, std} per orientation FF, FR, RF, RR.  popt->id0 = index of the
  * batch's first READ in the run.  The insert-size statistics are those of the batch, as in the reference. */
-typedef struct { int pen_unpaired, max_ins, max_matesw; } bmh_pe_opt_t;       /* 17, 10000, 50 */
+typedef struct { int pen_unpaired, max_ins, max_matesw; int no_rescue, no_pairing; } bmh_pe_opt_t;       /* 17, 10000, 50; -S, -P */
 void bmh_pe_opt_default(bmh_pe_opt_t *o);
 int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
                            int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,

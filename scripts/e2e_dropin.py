@@ -23,6 +23,7 @@ n_reads = int(float(sys.argv[3])) if len(sys.argv) > 3 else 10_000
 threads = sys.argv[4] if len(sys.argv) > 4 else "1"
 paired = len(sys.argv) > 5 and sys.argv[5] in ("pe", "pe_hard")
 hard = len(sys.argv) > 5 and sys.argv[5] in ("se_hard", "pe_hard")      # diverged / chimeric / unalignable reads mixed in
+opts = sys.argv[6].split() if len(sys.argv) > 6 else []               # gase_aln options given to both sides, e.g. "-k 23 -A 2 -B 5 -a"
 os.makedirs(work, exist_ok=True)
 prefix = os.path.join(work, "g.fa")
 g = synth.make_genome(n_genome, seed=42)
@@ -61,7 +62,7 @@ else:
 sam = os.path.join(work, "out.sam")
 t = time.time()
 with open(sam, "w") as f:
-    r = subprocess.run([exe, "gase_aln", "-t", threads, "-K", "2000000000", "-l", "150"] + (["-p"] if paired else []) + [prefix, fq], stdout=f, stderr=subprocess.PIPE, cwd=work)
+    r = subprocess.run([exe, "gase_aln", "-t", threads, "-K", "2000000000", "-l", "150"] + opts + (["-p"] if paired else []) + [prefix, fq], stdout=f, stderr=subprocess.PIPE, cwd=work)
 dt = time.time() - t
 print("gase_aln rc=%d in %.2fs" % (r.returncode, dt))
 print(r.stderr.decode()[-1500:])
@@ -90,7 +91,7 @@ if paired:
     # the same job through the device-resident path: one batch like the reference's (its insert-size statistics are per batch)
     from bwamem_hip.aligner import Aligner
     import io
-    al = Aligner(prefix)
+    al = Aligner(prefix); al.set_options(opts)
     buf = io.StringIO()
     al.align_file(fq, buf, batch_reads=1 << 30, paired=True)
     ours = [l for l in buf.getvalue().split("\n") if l and l[0] != "@"]
@@ -99,8 +100,8 @@ if paired:
     print(f"device-resident path: {len(ours)} records; reference host code: {len(theirs)} records; differing records: {len(diff)}")
     if diff:                                              # keep the evidence: both records and the pair's reads
         os.makedirs("gpurun_out", exist_ok=True)
-        with open("gpurun_out/e2e_diff_pe_t%s.txt" % threads, "w") as f:
-            f.write(f"{len(diff)} differing records of {len(ours)}\n")
+        with open("gpurun_out/e2e_diff_%s.txt" % os.environ.get("E2E_TAG", "pe_t" + threads), "w") as f:
+            f.write(f"{len(diff)} differing records of {len(ours)}; options {opts}\n")
             for a, b in diff[:40]:
                 i = int(a.split("\t")[0][1:])
                 f.write("OURS   " + a + "\nTHEIRS " + b + "\n")
@@ -135,7 +136,7 @@ assert n == n_reads and (hard or ok / n > 0.97), "end-to-end accuracy too low"
 from bwamem_hip.aligner import Aligner
 import io
 t = time.time()
-al = Aligner(prefix)
+al = Aligner(prefix); al.set_options(opts)
 buf = io.StringIO()
 al.align_file(fq, buf, batch_reads=4096)                  # several batches: the tie-break hash depends on the global read index
 dt2 = time.time() - t
@@ -143,6 +144,16 @@ ours = [l for l in buf.getvalue().split("\n") if l and l[0] != "@"]
 theirs = [l.rstrip("\n") for l in open(sam) if l[0] != "@"]
 diff = [(a, b) for a, b in zip(ours, theirs) if a != b]
 print(f"device-resident path: {len(ours)} records in {dt2:.2f}s (reference host code: {len(theirs)} records in {dt:.2f}s); differing records: {len(diff)}")
+if diff or len(ours) != len(theirs):
+    os.makedirs("gpurun_out", exist_ok=True)
+    tag = os.environ.get("E2E_TAG", "se")
+    with open(f"gpurun_out/e2e_diff_{tag}.txt", "w") as f:
+        f.write(f"{len(diff)} differing records of {len(ours)} / {len(theirs)}; options {opts}\n")
+        bad = sorted({a.split("\t")[0] for a, b in diff})[:15]
+        for tg, S in (("OURS  ", ours), ("THEIRS", theirs)):
+            for l in S:
+                if l.split("\t")[0] in bad:
+                    f.write(tg + " " + l + "\n")
 assert len(ours) == len(theirs) and not diff, diff[:2]
 print("SAM IDENTICAL")
 print("E2E DROP-IN OK")

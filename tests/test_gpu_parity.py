@@ -220,7 +220,9 @@ def test_reference_gase_aln_end_to_end(hip, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists(os.path.join(root, "build", "dropin", "bwa-gasal2")):
         pytest.skip("build/dropin/bwa-gasal2 not built (needs /root/reference at build time)")
-    for extra in ([], ["1", "pe"]):          # single-end (configs[0] shape) and interleaved paired-end with -p (configs[3] shape)
+    # single-end (configs[0] shape), interleaved paired-end with -p (configs[3] shape), and hard pairs (diverged / relocated /
+    # random / chimeric mates) under a non-default option set given to both sides
+    for extra in ([], ["1", "pe"], ["1", "pe_hard", "-k 21 -B 6 -O 8,9 -E 2,3 -T 50 -U 25 -m 20 -M -Y -a"]):
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "e2e_dropin.py"), str(tmp_path), "2000000", "4000"] + extra,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         out = r.stdout.decode()

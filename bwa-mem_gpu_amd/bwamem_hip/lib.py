@@ -15,7 +15,8 @@ class HipLibraryMissing(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_PKG, "libbwamem_hip.so")
+    # BMH_LIB: another build of the same library (A/B runs of kernel variants, scripts/build_variants.sh)
+    return os.environ.get("BMH_LIB") or os.path.join(_PKG, "libbwamem_hip.so")
 
 
 # every symbol include/bwamem_hip.h and include/seed_gen.h declare

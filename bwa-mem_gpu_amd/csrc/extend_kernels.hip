@@ -341,7 +341,7 @@ struct ext_rs_t { int beg, end, mx, max_i, max_j, max_ie, gscore, max_off; };
 
 // One DP row of up to four alignments (one per 16-lane row).  Cells left of `beg` need no mask: their inputs are
 // zero (that is why beg moved past them) and zero inputs give zero outputs; cells at or right of `end` are masked
-// (H = E = 0), and what their unmasked M feeds into the F scan only reaches cells further right, all masked too.
+// (M = 0, which with their stored E = 0 keeps E at 0, and H = 0 whatever F flows in from the left).
 // F is carried unclamped: max(F,0) is what the reference holds, and H = max(M,E,F) with E >= 0 absorbs the clamp.
 // Returns the new `alive`.
 template <int C, bool LUT>
@@ -364,7 +364,7 @@ __device__ __forceinline__ bool ext_row(const ext_args_t &A, const ext_lut_t &L,
 		int sc;
 		if (LUT) sc = __builtin_amdgcn_sbfe(tbl, (unsigned)qv[c], 6u);
 		else sc = ti == qv[c] ? A.a : (tN ? -1 : mmv[c]);
-		const int m = hd != 0 ? hd + sc : 0;
+		const int m = (c < wend && hd != 0) ? hd + sc : 0;          // masked at and right of `end`: E of those cells stays 0 by itself
 		M[c] = m;
 		agg = max(agg, m + kc0 + A.e_ins * c);                  // (M - oe_ins) + e_ins * j
 	}
@@ -376,7 +376,7 @@ __device__ __forceinline__ bool ext_row(const ext_args_t &A, const ext_lut_t &L,
 	for (int c = 0; c < C; ++c) {
 		const bool act = c < wend;
 		const int hraw = max(max(M[c], E[c]), f);
-		const int e = act ? max(max(E[c] - A.e_del, M[c] - oe_del), 0) : 0;
+		const int e = max(max(E[c] - A.e_del, M[c] - oe_del), 0);
 		f = max(f - A.e_ins, M[c] - oe_ins);
 		const int h = act ? hraw : 0;
 		hl = act ? hraw : hl;

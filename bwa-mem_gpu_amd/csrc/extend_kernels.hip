@@ -945,7 +945,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	// class sizes stay on the device (no host sync): every class kernel is launched with a grid
 	// that covers the whole batch and its waves stride over the class's slice of the sorted list
 	unsigned g16 = (unsigned)((n + 15) / 16), gw = (unsigned)((n + 3) / 4);
-	static const unsigned max_grid = [] { const char *e = getenv("BMH_EXT_GRID"); unsigned v = e ? (unsigned)atoi(e) : 0; return v ? v : 256u * 8; }();
+	static const unsigned max_grid = [] { const char *e = getenv("BMH_EXT_GRID"); unsigned v = e ? (unsigned)atoi(e) : 0; return v ? v : 256u * 4; }();
 	if (g16 > max_grid) g16 = max_grid;
 	if (gw > max_grid) gw = max_grid;
 	// the class kernels are independent: fork them over four side streams so that the tail of one
@@ -953,6 +953,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	HIPCK(hipEventRecord(g_scr.fork, st));
 	for (int i = 0; i < 4; ++i) HIPCK(hipStreamWaitEvent(g_scr.side[i], g_scr.fork, 0));
 	hipStream_t *S = g_scr.side;
+	// (narrow classes first measured better than widest first: 10.8 vs 11.1 ms)
 	launch16<1>(a, S[0], g16); launch16<2>(a, S[1], g16); launch16<3>(a, S[2], g16); launch16<4>(a, S[3], g16);
 	launch16<5>(a, S[0], g16); launch16<6>(a, S[1], g16); launch16<7>(a, S[2], g16); launch16<8>(a, S[3], g16);
 	launch16<9>(a, S[0], g16); launch16<10>(a, S[1], g16); launch16<11>(a, S[2], g16); launch16<12>(a, S[3], g16);

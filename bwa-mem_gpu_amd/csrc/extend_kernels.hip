@@ -370,7 +370,7 @@ __device__ __forceinline__ bool ext_row(const ext_args_t &A, const ext_lut_t &L,
 	}
 	int f = row_shr1(row_scan_max_f(agg), NEG_INF) - (ej0 - A.e_ins);      // F of this lane's first column
 	int key = 0;                                                // (h << 16) | cell: row maximum, last column on ties
-	int nzm = 0;                                                // bit (C-1-c): H != 0; bit 16 + (C-1-c): E != 0
+	int nzm = 0, nze = 0;                                       // bit (C-1-c): H != 0; bit 16 + (C-1-c) (C > 16: of nze): E != 0
 	int hl = 0;                                                 // H of this lane's last cell left of `end`
 #pragma unroll
 	for (int c = 0; c < C; ++c) {
@@ -382,16 +382,21 @@ __device__ __forceinline__ bool ext_row(const ext_args_t &A, const ext_lut_t &L,
 		hl = act ? hraw : hl;
 		H[c] = h; E[c] = e;
 		key = max(key, (h << 16) | c);
-		const short2_t one = {1, 1};
-		const int nz = __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(short2_t, (e << 16) | h), one));
-		nzm = (nzm << 1) | nz;
+		if (C <= 16) {
+			const short2_t one = {1, 1};
+			const int nz = __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(short2_t, (e << 16) | h), one));
+			nzm = (nzm << 1) | nz;
+		} else {                                                // more than 16 cells per lane: one mask each
+			nzm = (nzm << 1) | min(h, 1);
+			nze = (nze << 1) | min(e, 1);
+		}
 	}
 	key += j0;
 	// E(i+1,j) != 0 implies H(i,j) != 0 (H >= E(i,j) and H >= M), so the non-zero span of eh[] follows from the non-zero H
 	// columns alone: last index = last column + 1, first = first column (+1 if its E is 0)
-	const unsigned hm = (unsigned)nzm & 0xFFFFu;
+	const unsigned hm = C <= 16 ? ((unsigned)nzm & 0xFFFFu) : (unsigned)nzm;
 	const int p_hi = 31 - __clz((int)hm), p_lo = __ffs((int)hm) - 1;          // hm == 0: unused
-	const int enz = (nzm >> (16 + p_hi)) & 1;
+	const int enz = C <= 16 ? ((nzm >> (16 + p_hi)) & 1) : ((nze >> (p_hi & 31)) & 1);
 	int nfirst = hm ? -(j0 + (C - 1 - p_hi) + (enz ? 0 : 1)) : NEG_INF;
 	int nlast = hm ? j0 + (C - 1 - p_lo) + 1 : -1;
 	row_allmax3_f(key, nfirst, nlast);
@@ -751,10 +756,10 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 
 // ------------------------------------------------------------------ host side
 
-// classes: 0 = unsupported length; 1..16 = extend16_kernel<C>; 19..22 = extend_wide_kernel<5..8>
+// classes: 0 = unsupported length; 1..18 = extend16_kernel<C>; 19..22 = extend_wide_kernel<5..8>
 #define EXT_N_CLS 24
 #define EXT_DONE_CLS 23     // decided by the closed-form prefilter: no DP
-#define EXT16_MAX_C 16
+#define EXT16_MAX_C 18
 
 __device__ __forceinline__ int ext_class(uint32_t ql)
 {
@@ -958,6 +963,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	launch16<5>(a, S[0], g16); launch16<6>(a, S[1], g16); launch16<7>(a, S[2], g16); launch16<8>(a, S[3], g16);
 	launch16<9>(a, S[0], g16); launch16<10>(a, S[1], g16); launch16<11>(a, S[2], g16); launch16<12>(a, S[3], g16);
 	launch16<13>(a, S[0], g16); launch16<14>(a, S[1], g16); launch16<15>(a, S[2], g16); launch16<16>(a, S[3], g16);
+	launch16<17>(a, S[0], g16); launch16<18>(a, S[1], g16);
 	launch_wide<5>(a, S[2], gw); launch_wide<6>(a, S[3], gw); launch_wide<7>(a, S[2], gw); launch_wide<8>(a, S[3], gw);
 	for (int i = 0; i < 4; ++i) { HIPCK(hipEventRecord(g_scr.join[i], g_scr.side[i])); HIPCK(hipStreamWaitEvent(st, g_scr.join[i], 0)); }
 	HIPCK(hipEventRecord(g_scr.ev1, st));

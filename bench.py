@@ -42,11 +42,11 @@ GATHER_CEILING_GBS = 1818.0
 
 def pmc_traffic(kernel_name: str):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01e_pmc_fetch_write.json: FETCH_SIZE + WRITE_SIZE, KB).  For this library's access patterns
+    (profiles/r01f_pmc_fetch_write.json: FETCH_SIZE + WRITE_SIZE, KB).  For this library's access patterns
     FETCH_SIZE needs no correction: the calibration kernel (bmh_calib_gather under --pmc FETCH_SIZE) reads back
     63.9 B per 32-byte gather, i.e. exactly one 64-byte sector each.  None if the profile is absent."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_fetch_write.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_fetch_write.json")))
         key = kernel_name.split("<")[0].split(" ")[0]
         f = [v["avg_per_launch_KB"] for k, v in d["FETCH_SIZE"].items() if key in k]
         w = [v["avg_per_launch_KB"] for k, v in d["WRITE_SIZE"].items() if key in k]
@@ -58,11 +58,11 @@ def pmc_traffic(kernel_name: str):
 
 
 def pmc_valu_busy(pred):
-    """VALU-busy fraction of a kernel family from the committed SQ counter pass (profiles/r01e_pmc_sq.json):
+    """VALU-busy fraction of a kernel family from the committed SQ counter pass (profiles/r01f_pmc_sq.json):
     SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs (MI355X_MICROARCH.md),
     so busy = 4 * sum(ACTIVE_INST_VALU) / (1024 SIMDs * sum(GUI_ACTIVE) / 8).  None if the profile is absent."""
     try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_sq.json")))
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_sq.json")))
         a = g = 0.0
         for k, v in sq.items():
             if pred(k) and "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:

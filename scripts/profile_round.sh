@@ -16,5 +16,5 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES 
 cd $R
 find gpurun_out/prof_${TAG} -name "*kernel_trace.csv" -delete
 python scripts/summarize_profiles.py ${TAG} gpurun_out/prof_${TAG} gpurun_out/pmc_fetch_${TAG} gpurun_out/pmc_write_${TAG} gpurun_out/pmc_sq_${TAG}
-cp profiles/${TAG}_* gpurun_out/
+cp profiles/${TAG}_kernel_stats_bench.csv profiles/${TAG}_pmc_fetch_write.json profiles/${TAG}_pmc_sq.json gpurun_out/
 find gpurun_out/pmc_fetch_${TAG} gpurun_out/pmc_write_${TAG} gpurun_out/pmc_sq_${TAG} -name "*.csv" -size +1M -delete

@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("BENCH_GENOME_MBP", "1000")))
     ap.add_argument("--reads-per-gpu", type=int, default=int(os.environ.get("BENCH_READS_PER_GPU", "1000000")))
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--sa-intv", type=int, default=1, help="suffix-array samples resident in HBM: every N-th row (16 = what the reference's `bwa index` "
+                    "writes for its GPU index, src/bwtindex.c:324; the index is built that way and bmh_index_densify_sa fills in the rest on "
+                    "the device); 1 = the whole suffix array, locating a seed is one gather")
     ap.add_argument("--paired", action="store_true", help="interleaved 2 x read-len pairs (configs[3]); reads-per-gpu counts reads, shards stay on pair boundaries")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="(--host-jobs) run extension and seeding on one stream")
     ap.add_argument("--host-jobs", action="store_true", help="round-1 mode: extension jobs prebuilt by the host job builder outside the timed region; "
@@ -199,7 +202,7 @@ def main():
     idx = None
     t0 = time.time()
     if rank == 0:
-        idx = B.fmindex.build_fmd_index(g, device=str(dev))
+        idx = B.fmindex.build_fmd_index(g, sa_intv=16, device=str(dev))     # the reference's sampling (src/bwtindex.c:324); densified below
     t_index = time.time() - t0
     torch.cuda.empty_cache()
     hdr, bwt_t, sa_t, bits_t = broadcast_index(idx, dev, src=0, world=world)
@@ -208,6 +211,10 @@ def main():
     pac_t = ((gp[:, 0] << 6) | (gp[:, 1] << 4) | (gp[:, 2] << 2) | gp[:, 3]).to(torch.uint8).contiguous()
     del gp
     dindex = B.Index.from_device(hdr["primary"], hdr["L2"], hdr["seq_len"], bwt_t, hdr["sa_intv"], sa_t, bits_t, pac_t=pac_t, l_pac=len(g))
+    t0 = time.time()
+    dindex.densify_sa(a.sa_intv)                 # every rank fills in its own denser samples (device, untimed setup like the index load)
+    torch.cuda.synchronize()
+    t_densify = time.time() - t0
     lo, hi = shard_range(a.reads_per_gpu * world, rank, world, multiple=2 if a.paired else 1)
     if a.paired:
         reads, _ = B.synth.make_pairs(g, (hi - lo) // 2, a.read_len, seed=7 + rank)
@@ -330,7 +337,9 @@ def main():
                                    + ("jobs prebuilt on the host outside the timed region" if a.host_jobs else
                                       "chaining, job construction with on-device reference fetch and the region merge run on the device inside the timed region (reads in, regions out)"),
                        "reads_per_gpu": n_reads, "read_len": a.read_len, "paired_interleaved": bool(a.paired), "genome_mbp": a.genome_mbp,
-                       "index_bytes": int(bwt_t.numel() * 4 + sa_t.numel() * 4 + bits_t.numel() * 4),
+                       "index_bytes": int(bwt_t.numel() * 4 + (hdr["seq_len"] // a.sa_intv + 1) * 4.125),
+                       "sa_intv": a.sa_intv,      # suffix-array samples of every sa_intv-th row resident (reference files: 16; bmh_index_densify_sa fills in)
+                       "sa_densify_s": round(t_densify, 3),
                        "ext_jobs_per_gpu": n_jobs, "regions_per_gpu": n_regs, "job_builder": "host (untimed)" if a.host_jobs else "device (timed)", "host_job_build_s": round(t_jobs, 2), "seeds_per_gpu": int(s.n_seeds), "min_seed_len": 19,
                        "scoring": "a1 b4 o6 e1 clip5 zdrop0", "streams": "seeding || extension" if (a.overlap and a.host_jobs) else "single", "index_build_s": round(t_index, 2)},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},

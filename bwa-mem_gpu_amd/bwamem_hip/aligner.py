@@ -111,7 +111,7 @@ def read_fasta_reads(path: str) -> ReadSet:
 
 
 class Aligner:
-    def __init__(self, prefix: str | None, device: str = "cuda:0", n_threads: int = 0, _mem=None):
+    def __init__(self, prefix: str | None, device: str = "cuda:0", n_threads: int = 0, _mem=None, sa_intv: int | None = 1):
         self.L = load_library()
         self.dev = torch.device(device)
         if _mem is not None:                                  # (index, contigs, packed reference) already in memory: from_memory()
@@ -123,6 +123,8 @@ class Aligner:
             pac = np.fromfile(prefix + ".pac", dtype=np.uint8)
             self.pac = np.ascontiguousarray(np.concatenate([pac[: (self.l_pac + 3) // 4], np.zeros(2, np.uint8)]))
         self.index = Index.upload(idx, pac=self.pac, l_pac=self.l_pac)
+        if sa_intv:                                            # denser suffix-array samples than the files hold (every 16th row): ms on the device
+            self.index.densify_sa(sa_intv)
         self.copt = ChainOpt(); self.L.bmh_chain_opt_default(C.byref(self.copt))
         self.ep = ExtParams.default()
         self.po = PostOpt(); self.L.bmh_post_opt_default(C.byref(self.po))

@@ -22,7 +22,7 @@ def lib_path() -> str:
 # every symbol include/bwamem_hip.h and include/seed_gen.h declare
 EXPORTED_SYMBOLS = [
     "bmh_last_error", "bmh_device_count", "bmh_set_device", "bmh_index_upload", "bmh_index_from_device",
-    "bmh_index_free", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
+    "bmh_index_free", "bmh_index_densify_sa", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
     "bmh_extend_batch", "bmh_extend_last_ms", "bmh_calib_gather",
     "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
     "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
@@ -116,6 +116,8 @@ def load_library() -> C.CDLL:
     L.bmh_index_from_device.argtypes = [C.c_uint64, _u64p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
                                         C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     L.bmh_index_free.argtypes = [C.c_void_p]
+    L.bmh_index_densify_sa.restype = C.c_int
+    L.bmh_index_densify_sa.argtypes = [C.c_void_p, C.c_int]
     L.bmh_seed_ws_create.restype = C.c_void_p
     L.bmh_seed_ws_create.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64]
     L.bmh_seed_ws_free.argtypes = [C.c_void_p]
@@ -230,6 +232,13 @@ class Index:
         if not h:
             raise RuntimeError("bmh_index_from_device: " + _err(L))
         return cls(h, keep=(bwt_t, sa_t, sa_bits_t, pac_t))
+
+    def densify_sa(self, new_intv: int) -> None:
+        """bmh_index_densify_sa: suffix-array samples of every new_intv-th row, computed on the device from the existing ones"""
+        L = load_library()
+        rc = L.bmh_index_densify_sa(self.handle, int(new_intv))
+        if rc != 0:
+            raise RuntimeError(f"bmh_index_densify_sa rc={rc}: " + _err(L))
 
     def free(self):
         if self.handle:

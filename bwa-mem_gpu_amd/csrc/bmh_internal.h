@@ -6,6 +6,7 @@
 struct bmh_index {
 	fmd_dev_t dev;
 	bool owns;             // arrays were hipMalloc'd by bmh_index_upload
+	bool owns_sa;          // sa / sa_bits were replaced by bmh_index_densify_sa (its own allocations)
 	uint64_t n_words;
 };
 

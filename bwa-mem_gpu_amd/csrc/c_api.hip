@@ -108,12 +108,50 @@ extern "C" bmh_index_t *bmh_index_from_device(uint64_t primary, const uint64_t L
 	return ix;
 }
 
+// Denser suffix-array samples, computed on the device from the sparser ones (each new sample walks LF to the next old
+// one, src/bwt.c:105-115).  The reference's GPU index keeps every 16th row (src/bwtindex.c:324) because its cards
+// hold 16-32 GB; with 288 GB the samples of every 4th row -- or all of them -- fit beside the index, and locating a
+// seed costs 2.5 (or 1) index gathers instead of 8.5.  Values are unchanged, so are all results.
+__global__ void __launch_bounds__(256) sa_densify_kernel(fmd_dev_t f, int new_shift, uint64_t n_new, uint32_t *__restrict__ sa, uint32_t *__restrict__ bits)
+{
+	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n_new) return;
+	const uint64_t k = j << new_shift;
+	const uint64_t v = j == 0 ? 0xFFFFFFFFull : fmd_sa(f, k);
+	sa[j] = (uint32_t)v;
+	if (j && ((v >> 32) & 1)) atomicOr(&bits[j >> 5], 1u << (j & 31));
+}
+
+extern "C" int bmh_index_densify_sa(bmh_index_t *ix, int new_intv)
+{
+	if (!ix || new_intv < 1 || (new_intv & (new_intv - 1))) { bmh_set_error("bmh_index_densify_sa: bad argument"); return BMH_EINVAL; }
+	int new_shift = 0;
+	while ((1 << new_shift) < new_intv) ++new_shift;
+	if (new_shift >= ix->dev.sa_shift) return BMH_OK;                      // already that dense
+	const uint64_t n_new = (ix->dev.seq_len + (uint64_t)new_intv) / (uint64_t)new_intv;
+	uint32_t *d_sa = nullptr, *d_bits = nullptr;
+	const size_t bits_words = (size_t)(n_new / 32 + 1);
+	if (hipMalloc((void **)&d_sa, n_new * 4) != hipSuccess || hipMalloc((void **)&d_bits, bits_words * 4) != hipSuccess ||
+	    hipMemset(d_bits, 0, bits_words * 4) != hipSuccess) {
+		bmh_set_error("bmh_index_densify_sa: %s", hipGetErrorString(hipGetLastError()));
+		if (d_sa) (void)hipFree(d_sa); if (d_bits) (void)hipFree(d_bits);
+		return BMH_ENODEV;
+	}
+	sa_densify_kernel<<<(unsigned)((n_new + 255) / 256), 256>>>(ix->dev, new_shift, n_new, d_sa, d_bits);
+	hipError_t e = hipDeviceSynchronize();
+	if (e != hipSuccess) { bmh_set_error("bmh_index_densify_sa: %s", hipGetErrorString(e)); (void)hipFree(d_sa); (void)hipFree(d_bits); return BMH_ENODEV; }
+	if (ix->owns || ix->owns_sa) { (void)hipFree((void *)ix->dev.sa); (void)hipFree((void *)ix->dev.sa_bits); }
+	ix->dev.sa = d_sa; ix->dev.sa_bits = d_bits; ix->dev.n_sa = n_new; ix->dev.sa_shift = new_shift; ix->owns_sa = true;
+	return BMH_OK;
+}
+
 extern "C" void bmh_index_free(bmh_index_t *ix)
 {
 	if (!ix) return;
 	if (ix->owns) {
-		(void)hipFree((void *)ix->dev.blocks); (void)hipFree((void *)ix->dev.sa); (void)hipFree((void *)ix->dev.sa_bits);
+		(void)hipFree((void *)ix->dev.blocks);
 		if (ix->dev.pac) (void)hipFree((void *)ix->dev.pac);
 	}
+	if (ix->owns || ix->owns_sa) { (void)hipFree((void *)ix->dev.sa); (void)hipFree((void *)ix->dev.sa_bits); }
 	free(ix);
 }

@@ -54,6 +54,10 @@ bmh_index_t *bmh_index_from_device(uint64_t primary, const uint64_t L2[5], uint6
                                    const uint32_t *d_sa, uint64_t n_sa, const uint32_t *d_sa_bits,
                                    const uint8_t *d_pac, uint64_t l_pac);
 void bmh_index_free(bmh_index_t *idx);
+/* Replaces the suffix-array samples by denser ones (every new_intv-th row, a power of two; a no-op if the index is that
+ * dense already), computed on the device from the existing ones: same values, fewer LF steps per located seed, more HBM
+ * (4.125 bytes per sample).  The reference's files hold every 16th row (src/bwtindex.c:324). */
+int bmh_index_densify_sa(bmh_index_t *idx, int new_intv);
 
 /* ---------------------------------------------------------------- seeding */
 

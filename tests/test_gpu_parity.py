@@ -24,12 +24,14 @@ def _to_dev(torch, a, dt=None):
     return t.cuda()
 
 
-def gpu_seed(B, idx, flat, offs, lens, min_seed_len=19):
+def gpu_seed(B, idx, flat, offs, lens, min_seed_len=19, densify=None):
     import torch
     from bwamem_hip.lib import seeds_to_host
     from bwamem_hip import synth
     ascii_ = synth.codes_to_ascii(flat) if flat.size else np.zeros(1, np.uint8)
     dindex = B.Index.upload(idx)
+    if densify:
+        dindex.densify_sa(densify)
     ws = B.SeedWorkspace(max(len(lens), 1), max(int(flat.size), 1), max_cands=max(int(flat.size), 64), max_occ=1 << 22)
     r = _to_dev(torch, ascii_)
     o = torch.from_numpy(offs.astype(np.int64)).to(torch.int32).cuda()
@@ -101,6 +103,18 @@ def test_seeding_odd_genome_length(hip, oracle):
     flat, offs, lens = common.flat_reads(reads)
     want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
     got = gpu_seed(hip, idx, flat, offs, lens)
+    common.assert_seeds_equal(got, want)
+
+
+@pytest.mark.parametrize("new_intv", [4, 1])
+def test_seeding_with_denser_sa_samples(hip, oracle, new_intv):
+    """bmh_index_densify_sa: the samples of every 4th row / of every row computed on the device from the file's (every 16th)
+    -- located positions (and everything else) unchanged, odd text length, 33rd-bit values included."""
+    g, idx = common.genome_and_index(100_003, seed=5)
+    reads, _ = hip.synth.make_reads(g, 1500, 101, seed=14)
+    flat, offs, lens = common.flat_reads(reads)
+    want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
+    got = gpu_seed(hip, idx, flat, offs, lens, densify=new_intv)
     common.assert_seeds_equal(got, want)
 
 

@@ -207,7 +207,7 @@ def main():
     torch.cuda.empty_cache()
     hdr, bwt_t, sa_t, bits_t = broadcast_index(idx, dev, src=0, world=world)
     # 2-bit forward strand (the .pac body) for the on-device reference fetch; every rank packs its own copy
-    gp = torch.from_numpy(np.concatenate([g, np.zeros((-len(g)) % 4 + 4, np.uint8)])).to(dev).view(-1, 4).to(torch.int32)
+    gp = torch.from_numpy(np.concatenate([g, np.zeros((-len(g)) % 4 + 64, np.uint8)])).to(dev).view(-1, 4).to(torch.int32)
     pac_t = ((gp[:, 0] << 6) | (gp[:, 1] << 4) | (gp[:, 2] << 2) | gp[:, 3]).to(torch.uint8).contiguous()
     del gp
     dindex = B.Index.from_device(hdr["primary"], hdr["L2"], hdr["seq_len"], bwt_t, hdr["sa_intv"], sa_t, bits_t, pac_t=pac_t, l_pac=len(g))

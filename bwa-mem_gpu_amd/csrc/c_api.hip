@@ -76,7 +76,8 @@ extern "C" bmh_index_t *bmh_index_upload(uint64_t primary, const uint64_t L2[5],
 	uint8_t *d_pac = nullptr;
 	bool ok = hipMalloc((void **)&d_bwt, bwt_bytes) == hipSuccess && hipMalloc((void **)&d_sa, n_sa * 4) == hipSuccess &&
 	          hipMalloc((void **)&d_bits, bits_words * 4) == hipSuccess;
-	if (ok && pac) ok = hipMalloc((void **)&d_pac, (size_t)(l_pac / 4 + 1)) == hipSuccess;
+	// + 16: fmd_text16 reads the text in aligned words and may touch up to 7 bytes past the last symbol's byte
+	if (ok && pac) ok = hipMalloc((void **)&d_pac, (size_t)(l_pac / 4 + 1) + 16) == hipSuccess && hipMemset(d_pac, 0, (size_t)(l_pac / 4 + 1) + 16) == hipSuccess;
 	if (ok) ok = hipMemset(d_bwt, 0, bwt_bytes) == hipSuccess;
 	if (ok) ok = hipMemcpy(d_bwt, bwt_words, (size_t)n_words * 4 < bwt_bytes ? (size_t)n_words * 4 : bwt_bytes, hipMemcpyHostToDevice) == hipSuccess;
 	if (ok) ok = hipMemcpy(d_sa, sa, n_sa * 4, hipMemcpyHostToDevice) == hipSuccess;

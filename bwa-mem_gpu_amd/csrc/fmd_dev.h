@@ -153,6 +153,18 @@ __device__ __forceinline__ void fmd_occ1_pair(const fmd_dev_t &f, uint64_t k, ui
 	ol = blk_occ1(B, loff, c);
 }
 
+// forward extension of the bi-interval (k, l, s) by every symbol (bwt_extend on the swapped interval, src/bwt.c:428-448):
+// the interval of the pattern followed by read symbol b is (nk[3-b], nl[3-b], ns[3-b])
+__device__ __forceinline__ void fmd_forward_ext(const fmd_dev_t &f, uint64_t k, uint64_t l, uint64_t s, uint64_t nk[4], uint64_t nl[4], uint64_t ns[4])
+{
+	uint64_t tk[4], tl[4];
+	fmd_occ4_pair(f, l - 1, l - 1 + s, tk, tl);
+#pragma unroll
+	for (int q = 0; q < 4; ++q) { ns[q] = tl[q] - tk[q]; nl[q] = fmd_L2(f, q) + 1 + tk[q]; }
+	nk[3] = k + ((l <= f.primary) & (l + s - 1 >= f.primary));
+	nk[2] = nk[3] + ns[3]; nk[1] = nk[2] + ns[2]; nk[0] = nk[1] + ns[1];
+}
+
 // LF step, CPU form (src/bwt.c:64-70)
 __device__ __forceinline__ uint64_t fmd_inv_psi(const fmd_dev_t &f, uint64_t k)
 {
@@ -173,6 +185,30 @@ __device__ __forceinline__ uint64_t fmd_sa(const fmd_dev_t &f, uint64_t k)
 	if (idx == 0) return steps - 1;            // sa[0] == (bwtint_t)-1 on the CPU path
 	uint64_t hi = (f.sa_bits[idx >> 5] >> (idx & 31)) & 1u;
 	return ((uint64_t)f.sa[idx] | (hi << 32)) + steps;
+}
+
+// 16 symbols T[t0 .. t0+15] of the indexed text, packed like the reads (symbol j at bits 2j+1:2j).  Two loads when the
+// window lies inside one strand (the reverse strand is the complement of the forward bytes read in their own order:
+// pac is MSB-first, so the mirrored order is already there); symbols at or beyond seq_len read as 0.
+__device__ __forceinline__ int fmd_text(const fmd_dev_t &f, uint64_t i);
+__device__ __forceinline__ uint32_t fmd_text16(const fmd_dev_t &f, uint64_t t0)
+{
+	const uint64_t L = f.l_pac;
+	const bool fwd = t0 + 16 <= L, rev = t0 >= L && t0 + 16 <= 2 * L;
+	if (fwd || rev) {
+		const uint64_t a = fwd ? t0 : 2 * L - 16 - t0;              // forward-strand symbols a .. a+15
+		// two aligned words cover the 5 bytes that hold the 16 symbols (the allocation is padded: bmh_index_upload / callers)
+		const uint64_t byte0 = a >> 2;
+		const uint32_t *wp = (const uint32_t *)(f.pac + (byte0 & ~3ull));
+		const uint64_t two = ((uint64_t)__builtin_bswap32(wp[0]) << 32) | (uint64_t)__builtin_bswap32(wp[1]);    // bytes in text order, first on top
+		const uint32_t v = (uint32_t)(two >> (32 - 8 * (int)(byte0 & 3) - 2 * (int)(a & 3)));   // symbol a in the top two bits
+		if (rev) return ~v;                                           // T[t0+j] = 3 - fwd[a+15-j] sits at bits 2j+1:2j of v already
+		const uint32_t r = __brev(v);
+		return ((r & 0xAAAAAAAAu) >> 1) | ((r & 0x55555555u) << 1);
+	}
+	uint32_t w = 0;
+	for (int j = 0; j < 16; ++j) if (t0 + (uint64_t)j < f.seq_len) w |= (uint32_t)fmd_text(f, t0 + (uint64_t)j) << (2 * j);
+	return w;
 }
 
 // symbol i of the indexed text T = fwd . revcomp(fwd) from the 2-bit pac

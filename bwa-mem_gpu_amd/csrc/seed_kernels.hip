@@ -153,7 +153,12 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 	uint64_t k = 0, l = 0, s = 0;
 	// state machine: one rank-pair (or one candidate append) per iteration, so the
 	// lanes of a wave stay convergent on the loads
-	enum { ST_START, ST_EXT, ST_DONE, ST_TAIL };
+	// ST_UNIQ (needs the 2-bit text, f.pac): once the interval holds ONE suffix, extending the match is comparing the read
+	// with the text behind that suffix -- its position is one suffix-array gather (bmh_index_densify_sa), the text comes 16
+	// symbols per load -- instead of two rank gathers per base; k does not move while a unique match grows forward, so the
+	// candidate pushed at the end is the one the rank walk would push (src/bwt.c:505-519 with x[2] == 1)
+	enum { ST_START, ST_EXT, ST_DONE, ST_TAIL, ST_UNIQ };
+	uint64_t tp = 0;                 // ST_UNIQ: text index that pairs with read position i
 	int st = live && len > 0 ? ST_START : ST_DONE;
 	cand_cursor_t cc = {0, 0};
 	while (__any(st != ST_DONE)) {
@@ -177,16 +182,11 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 			int b = read_base(rv, r, i);
 			if (b < 4) {
 				int cb = 3 - b;
-				uint64_t tk[4], tl[4];
-				fmd_occ4_pair(f, l - 1, l - 1 + s, tk, tl);
-				uint64_t os[4];
-#pragma unroll
-				for (int q = 0; q < 4; ++q) os[q] = tl[q] - tk[q];
-				uint64_t nk3 = k + ((l <= f.primary) & (l + s - 1 >= f.primary));
-				uint64_t nk2 = nk3 + os[3], nk1 = nk2 + os[2], nk0 = nk1 + os[1];
-				uint64_t ns = cb == 0 ? os[0] : cb == 1 ? os[1] : cb == 2 ? os[2] : os[3];
-				uint64_t nk = cb == 0 ? nk0 : cb == 1 ? nk1 : cb == 2 ? nk2 : nk3;
-				uint64_t nl = fmd_L2(f, cb) + 1 + (cb == 0 ? tk[0] : cb == 1 ? tk[1] : cb == 2 ? tk[2] : tk[3]);
+				uint64_t ak[4], al[4], as[4];
+				fmd_forward_ext(f, k, l, s, ak, al, as);
+				const uint64_t ns = cb == 0 ? as[0] : cb == 1 ? as[1] : cb == 2 ? as[2] : as[3];
+				const uint64_t nk = cb == 0 ? ak[0] : cb == 1 ? ak[1] : cb == 2 ? ak[2] : ak[3];
+				const uint64_t nl = cb == 0 ? al[0] : cb == 1 ? al[1] : cb == 2 ? al[2] : al[3];
 				if (ns != s) {
 					want = i >= min_seed_len;
 					c.xe = ((uint32_t)x << 16) | (uint32_t)i; c.j = j; c.s = (uint32_t)s; ck = k;
@@ -198,6 +198,9 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 						// the interval just computed is itself a candidate; it is appended on the
 						// next iteration through ST_TAIL below
 						st = ST_TAIL;
+					} else if (s == 1 && f.pac) {
+						tp = fmd_sa(f, k) + (uint64_t)(i - x);
+						st = ST_UNIQ;
 					}
 				}
 			} else {                                      // ambiguous base ends the pass
@@ -209,6 +212,26 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 			want = i >= min_seed_len;
 			c.xe = ((uint32_t)x << 16) | (uint32_t)i; c.j = j; c.s = (uint32_t)s; ck = k;
 			st = ST_DONE;
+		} else if (st == ST_UNIQ) {
+			// the rest of this read word against the text: stop at the first differing symbol, the first N, the end of the text
+			const int w16 = i & 15;
+			const uint32_t rw = rv.pk[(size_t)(i >> 4) * rv.n_reads + r] >> (2 * w16);
+			const uint32_t rm = rv.nm[(size_t)(i >> 5) * rv.n_reads + r] >> (i & 31);
+			int n_av = min(16 - w16, len - i);
+			const uint64_t room = tp < f.seq_len ? f.seq_len - tp : 0;
+			n_av = (uint64_t)n_av < room ? n_av : (int)room;
+			const uint32_t diff = rw ^ fmd_text16(f, tp);
+			const uint32_t dp = (diff | (diff >> 1)) & 0x55555555u;
+			const int fd = dp ? (__ffs((int)dp) - 1) >> 1 : 16;
+			const int fn = (rm & 0xFFFFu) ? __ffs((int)(rm & 0xFFFFu)) - 1 : 16;
+			const int m = min(min(fd, fn), n_av);
+			const bool stop = m < n_av || n_av == 0;              // mismatch, N, or nothing left of the text: the pass ends at i
+			i += m; tp += (uint64_t)m;
+			if (stop) {
+				want = i >= min_seed_len;
+				c.xe = ((uint32_t)x << 16) | (uint32_t)i; c.j = j; c.s = 1u; ck = k;
+				st = ST_START;
+			} else if (i == len) st = ST_TAIL;
 		}
 		if (want) ++j;
 		cand_append(want, c, ck, out_a, out_k, counter, cap, cc);

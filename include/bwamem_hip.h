@@ -48,7 +48,10 @@ bmh_index_t *bmh_index_upload(uint64_t primary, const uint64_t L2[5], uint64_t s
                               const uint32_t *sa, uint64_t n_sa, const uint32_t *sa_bits,
                               const uint8_t *pac, uint64_t l_pac);
 /* wrap arrays that already live in HBM (e.g. received by an RCCL broadcast);
- * the index does not own them. */
+ * the index does not own them.  d_pac (optional): 4-byte aligned, readable for
+ * l_pac/4 + 9 bytes (the kernels fetch the text in aligned words).  With the
+ * text resident the seeding kernels stop ranking once an interval holds one
+ * suffix and compare the read with the text instead. */
 bmh_index_t *bmh_index_from_device(uint64_t primary, const uint64_t L2[5], uint64_t seq_len,
                                    const uint32_t *d_bwt_words, uint64_t n_words, int sa_intv,
                                    const uint32_t *d_sa, uint64_t n_sa, const uint32_t *d_sa_bits,

@@ -24,12 +24,13 @@ def _to_dev(torch, a, dt=None):
     return t.cuda()
 
 
-def gpu_seed(B, idx, flat, offs, lens, min_seed_len=19, densify=None):
+def gpu_seed(B, idx, flat, offs, lens, min_seed_len=19, densify=None, genome=None):
     import torch
     from bwamem_hip.lib import seeds_to_host
     from bwamem_hip import synth
     ascii_ = synth.codes_to_ascii(flat) if flat.size else np.zeros(1, np.uint8)
-    dindex = B.Index.upload(idx)
+    # genome given: the 2-bit text goes up too, which switches on the unique-interval shortcuts of the seeding kernels
+    dindex = B.Index.upload(idx) if genome is None else B.Index.upload(idx, pac=_pack_pac(genome), l_pac=len(genome))
     if densify:
         dindex.densify_sa(densify)
     ws = B.SeedWorkspace(max(len(lens), 1), max(int(flat.size), 1), max_cands=max(int(flat.size), 64), max_occ=1 << 22)
@@ -115,6 +116,28 @@ def test_seeding_with_denser_sa_samples(hip, oracle, new_intv):
     flat, offs, lens = common.flat_reads(reads)
     want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
     got = gpu_seed(hip, idx, flat, offs, lens, densify=new_intv)
+    common.assert_seeds_equal(got, want)
+
+
+@pytest.mark.parametrize("case", ["150bp", "repeats_N", "short_genome", "sparse_sa"])
+def test_seeding_unique_interval_shortcut(hip, oracle, case):
+    """With the 2-bit text resident the seeding kernels stop ranking once an interval holds a single suffix and compare the
+    read with the text instead (16 symbols per load): same SMEMs, same positions -- reads with N, reads from repeats,
+    matches that run into the end of either strand or across the strand boundary (tiny genome), read ends, sparse SA."""
+    rng = np.random.default_rng(77)
+    if case == "short_genome":
+        g, idx = common.genome_and_index(2_003, seed=9)
+        reads, _ = hip.synth.make_reads(g, 3000, 101, seed=15, sub_rate=0.005)
+    else:
+        g, idx = common.genome_and_index(300_001, seed=8)
+        reads, _ = hip.synth.make_reads(g, 4000, 150, seed=16, sub_rate=0.02 if case == "repeats_N" else 0.01)
+    if case == "repeats_N":
+        reads[::7, 40] = 4; reads[::11, 0] = 4; reads[::13, -1] = 4; reads[::17, 60:63] = 4
+        reads[5::50] = rng.integers(0, 4, size=reads[5::50].shape)              # reads from nowhere
+        rep = g[1000:1150].copy(); reads[3::40] = rep                            # many identical reads
+    flat, offs, lens = common.flat_reads(reads)
+    want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
+    got = gpu_seed(hip, idx, flat, offs, lens, genome=g, densify=None if case == "sparse_sa" else 1)
     common.assert_seeds_equal(got, want)
 
 

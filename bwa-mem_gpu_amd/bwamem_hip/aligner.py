@@ -146,7 +146,8 @@ class Aligner:
         """gase_aln's command-line options (src/fastmap.c:166-262) that reach this path, as a list of strings, e.g.
         ["-k", "23", "-A", "2", "-a"].  The device extension takes -A -B and the DELETION penalties -O -E for both gap
         kinds, as the reference's GPU extension does (src/fastmap.c:417-424); -O/-E given as "del,ins" keep the pair for
-        the host stages.  Unlike the reference, nothing is rescaled by -A (pass every value you want changed).
+        the host stages.  Unlike the reference (update_a, src/fastmap.c), nothing is rescaled by -A: pass every value you want
+        changed (-B -O -E -T -U).
         -d and -L are accepted and ignored (they do not reach the reference's GPU extension either).  Not modelled: -x -r -s
         -y (seeding variants the GPU seeding of the reference ignores too), -I -R -H -C -V -j."""
         import math
@@ -175,11 +176,7 @@ class Aligner:
             elif f == "-N": co.max_chain_extend = int(v)
             elif f == "-W": co.min_chain_weight = int(v)
             elif f == "-X": co.mask_level = float(v)
-            elif f == "-A":
-                co.a = ep.a = int(v)
-                if int(v) != 1:      # the reference seeds its extensions with the seed LENGTH as score (src/bwamem.c:1338, fill_extension(..., s->len)),
-                    import sys       # so its own scores stop being alignment scores when a != 1; that inconsistency is not reproduced here
-                    sys.stderr.write("[bwamem_hip] -A other than 1: records will not equal the reference's (its seed scores ignore -A)\n")
+            elif f == "-A": co.a = ep.a = int(v)
             elif f == "-B": co.b = ep.b = int(v)
             elif f == "-O": co.o_del, co.o_ins = pair(v); ep.o_del, ep.o_ins = co.o_del, co.o_ins
             elif f == "-E": co.e_del, co.e_ins = pair(v); ep.e_del, ep.e_ins = co.e_del, co.e_ins
@@ -210,6 +207,11 @@ class Aligner:
             if self.profile:
                 torch.cuda.synchronize(); _t.append(time.perf_counter()); _nm.append(name)
         lens, offs, ascii_ = rs.lens, np.ascontiguousarray(rs.offs), rs.ascii
+        # the reference's seed filter mem_flt_chained_seeds (src/bwamem.c:970-991) is not restated; it would run for these reads?
+        lmax = float(lens.max())
+        mcw = self.copt.min_chain_weight
+        if not ((2.8 * mcw if mcw else 5.5 * np.log(max(lmax, 2.0))) > 0.05 * lmax):
+            raise NotImplementedError(f"reads of {int(lmax)} bp with -W {mcw} go through the reference's mem_flt_chained_seeds, which is not restated")
         codes = _NT4[ascii_]
         r = torch.from_numpy(ascii_.copy()).to(dev)
         o = torch.from_numpy(offs.astype(np.int64)).to(torch.int32).to(dev)

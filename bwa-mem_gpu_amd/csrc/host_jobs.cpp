@@ -363,8 +363,18 @@ extern "C" bmh_jobs_t *bmh_build_jobs(const bmh_chain_opt_t *opt, int64_t l_pac,
                                       const uint32_t *n_ref_pos, const uint32_t *prefix, int n_threads)
 {
 	if (!opt || !pac || (n_reads && (!reads || !read_offs || !read_lens || !n_ref_pos || !prefix))) { bmh_set_error("bmh_build_jobs: null argument"); return nullptr; }
-	for (uint32_t r = 0; r < n_reads; ++r)
-		if (read_lens[r] > 700) { bmh_set_error("bmh_build_jobs: read %u longer than 700 bp (mem_flt_chained_seeds is not restated)", r); return nullptr; }
+	// mem_flt_chained_seeds (src/bwamem.c:970-991: a local alignment around every seed, seeds re-scored and filtered) is not
+	// restated; the reference skips it when min_l > 0.05 * l_query, which holds for reads up to ~700 bp at the default
+	// -W 0 (min_l = 5.5 ln l) but not for a small explicit -W (min_l = 2.8 W)
+	for (uint32_t r = 0; r < n_reads; ++r) {
+		const double l = (double)read_lens[r];
+		const double min_l = opt->min_chain_weight ? 2.8 * opt->min_chain_weight : 5.5 * log(l > 1 ? l : 1.);
+		if (l > 0 && !(min_l > 0.05 * l)) {
+			bmh_set_error("bmh_build_jobs: read %u (%u bp, min_chain_weight %d) would go through the reference's seed filter mem_flt_chained_seeds, which is not restated",
+			              r, read_lens[r], opt->min_chain_weight);
+			return nullptr;
+		}
+	}
 	Ctx x; x.o = opt; x.ctg = {l_pac, n_contigs, contig_offset, contig_len}; x.pac = pac;
 	x.reads = reads; x.roffs = read_offs; x.rlens = read_lens; x.rbeg = rbeg; x.qbeg = qbeg; x.score = score; x.n_ref = n_ref_pos; x.prefix = prefix;
 	if (n_threads < 1) n_threads = 1;

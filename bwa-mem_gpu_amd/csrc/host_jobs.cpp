@@ -369,7 +369,7 @@ extern "C" bmh_jobs_t *bmh_build_jobs(const bmh_chain_opt_t *opt, int64_t l_pac,
 	for (uint32_t r = 0; r < n_reads; ++r) {
 		const double l = (double)read_lens[r];
 		const double min_l = opt->min_chain_weight ? 2.8 * opt->min_chain_weight : 5.5 * log(l > 1 ? l : 1.);
-		if (l > 0 && !(min_l > 0.05 * l)) {
+		if (read_lens[r] >= (uint32_t)opt->min_seed_len && !(min_l > 0.05 * l)) {        // (shorter reads have no seeds to filter)
 			bmh_set_error("bmh_build_jobs: read %u (%u bp, min_chain_weight %d) would go through the reference's seed filter mem_flt_chained_seeds, which is not restated",
 			              r, read_lens[r], opt->min_chain_weight);
 			return nullptr;

@@ -210,7 +210,7 @@ class Aligner:
         # the reference's seed filter mem_flt_chained_seeds (src/bwamem.c:970-991) is not restated; it would run for these reads?
         lmax = float(lens.max())
         mcw = self.copt.min_chain_weight
-        if lmax >= self.copt.min_seed_len and not ((2.8 * mcw if mcw else 5.5 * np.log(max(lmax, 2.0))) > 0.05 * lmax):
+        if lmax >= self.copt.min_seed_len and not ((1.1 * mcw if mcw else 5.5 * np.log(max(lmax, 2.0))) > 0.05 * lmax):
             raise NotImplementedError(f"reads of {int(lmax)} bp with -W {mcw} go through the reference's mem_flt_chained_seeds, which is not restated")
         codes = _NT4[ascii_]
         r = torch.from_numpy(ascii_.copy()).to(dev)

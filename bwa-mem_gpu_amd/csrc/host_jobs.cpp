@@ -365,10 +365,10 @@ extern "C" bmh_jobs_t *bmh_build_jobs(const bmh_chain_opt_t *opt, int64_t l_pac,
 	if (!opt || !pac || (n_reads && (!reads || !read_offs || !read_lens || !n_ref_pos || !prefix))) { bmh_set_error("bmh_build_jobs: null argument"); return nullptr; }
 	// mem_flt_chained_seeds (src/bwamem.c:970-991: a local alignment around every seed, seeds re-scored and filtered) is not
 	// restated; the reference skips it when min_l > 0.05 * l_query, which holds for reads up to ~700 bp at the default
-	// -W 0 (min_l = 5.5 ln l) but not for a small explicit -W (min_l = 2.8 W)
+	// -W 0 (min_l = 5.5 ln l) but not for a small explicit -W (min_l = 1.1 W, MEM_HSP_COEF of this fork)
 	for (uint32_t r = 0; r < n_reads; ++r) {
 		const double l = (double)read_lens[r];
-		const double min_l = opt->min_chain_weight ? 2.8 * opt->min_chain_weight : 5.5 * log(l > 1 ? l : 1.);
+		const double min_l = opt->min_chain_weight ? 1.1 * opt->min_chain_weight : 5.5 * log(l > 1 ? l : 1.);
 		if (read_lens[r] >= (uint32_t)opt->min_seed_len && !(min_l > 0.05 * l)) {        // (shorter reads have no seeds to filter)
 			bmh_set_error("bmh_build_jobs: read %u (%u bp, min_chain_weight %d) would go through the reference's seed filter mem_flt_chained_seeds, which is not restated",
 			              r, read_lens[r], opt->min_chain_weight);

@@ -147,7 +147,7 @@ void bmh_chain_opt_default(bmh_chain_opt_t *o);
  * reads: nt4 codes; pac: 2-bit forward strand (the .pac file body); contigs: n_contigs offsets/lens
  * (n_contigs <= 1: one sequence of l_pac bases).  Jobs come out per read, per region, LEFT then RIGHT.
  * Not restated: mem_flt_chained_seeds (src/bwamem.c:970-991), which the reference runs when
- * (min_chain_weight ? 2.8 * min_chain_weight : 5.5 ln l_query) <= 0.05 * l_query -- reads beyond ~700 bp, or a small
+ * (min_chain_weight ? 1.1 * min_chain_weight : 5.5 ln l_query) <= 0.05 * l_query -- reads beyond ~700 bp, or a small
  * explicit -W; bmh_build_jobs refuses such input, callers of bmh_chain_batch must not pass it. */
 typedef struct bmh_jobs bmh_jobs_t;
 bmh_jobs_t *bmh_build_jobs(const bmh_chain_opt_t *opt, int64_t l_pac, const uint8_t *pac, int n_contigs,

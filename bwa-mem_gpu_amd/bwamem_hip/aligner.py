@@ -56,6 +56,7 @@ class ReadSet:
 
     @classmethod
     def from_lists(cls, names, seqs) -> "ReadSet":
+        seqs = [np.frombuffer(s.encode(), dtype=np.uint8) if isinstance(s, str) else np.asarray(s, dtype=np.uint8) for s in seqs]
         lens = np.array([len(s) for s in seqs], np.uint32)
         offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) if len(seqs) else np.zeros(0, np.uint64)
         ascii_ = np.concatenate(seqs) if len(seqs) and lens.sum() else np.zeros(1, np.uint8)

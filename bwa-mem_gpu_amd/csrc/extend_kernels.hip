@@ -593,6 +593,17 @@ __global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
 				i = 0; rows_done = 0; hfc = h0; dn = oe_del; tp = tl;
 				for (int k = l16; k < tlen && k < EXT_T_CAP; k += 16) { const int tb = ext_t_at(A, src, k); tl[k] = (uint8_t)(tb > 3 ? 5 : tb); }
 				alive = have && tlen > 0;
+				if (have && tlen == 0) {
+					// a job without target rows (its window was clipped away at a sequence end) is answered on the spot: the
+					// loop below may end before this row comes back to the result writer above
+					if (l16 == 0) {
+						int32_t *o = A.out + 3 * (size_t)id;
+						o[0] = h0; o[1] = 0; o[2] = 0;                   // ksw_extend2 with no rows: max = h0, nothing consumed, gscore -1
+						if (A.raw) { int32_t *r = A.raw + 6 * (size_t)id; r[0] = h0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = -1; r[5] = 0; }
+						if (A.stats) atomicAdd(A.stats + 2, 1ull);
+					}
+					have = false;
+				}
 			}
 		}
 		if (!__any(alive)) {

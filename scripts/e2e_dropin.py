@@ -29,7 +29,15 @@ prefix = os.path.join(work, "g.fa")
 g = synth.make_genome(n_genome, seed=42)
 t = time.time()
 idx = fmindex.build_fmd_index(g, device="cuda:0" if torch.cuda.is_available() else None)
-fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g)
+# E2E_CONTIGS=k: the genome is written as k sequences of unequal lengths (reads that straddle a cut lose the seeds that bridge it
+# and get their extension windows clipped, src/bwamem.c:437, src/bntseq.c:531-556; positions are reported per sequence)
+n_ctg = int(os.environ.get("E2E_CONTIGS", "1"))
+contigs = None
+if n_ctg > 1:
+    cuts = sorted(set(int(x) for x in np.random.default_rng(5).integers(1000, n_genome - 1000, size=n_ctg - 1)))
+    edges = [0] + cuts + [n_genome]
+    contigs = [("ctg%d" % i, edges[i + 1] - edges[i]) for i in range(len(edges) - 1)]
+fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g, contigs=contigs)
 print("index built+written in %.1fs" % (time.time() - t), flush=True)
 fq = os.path.join(work, "reads.fa")
 if paired:   # configs[3]: one interleaved file with -p (the only coherent PE input of the reference, SURVEY.md 8 notes)

@@ -185,6 +185,30 @@ def test_extension_other_scorings(hip, oracle, scoring):
     assert np.array_equal(got3, want3)
 
 
+def test_extension_jobs_without_target_rows(hip, oracle):
+    """tlen == 0 (the window of a seed at the end of a sequence is clipped away, src/bntseq.c:531-556): the answer is
+    (h0, 0, 0).  Such jobs sort last in their class; a class made only of them, one of them alone in the batch, and
+    mixtures with ordinary jobs in every kernel form (static, job-drawing, wide)."""
+    rng = np.random.default_rng(41)
+    def batch(qlens, tlens):
+        qs = [rng.integers(0, 4, size=q).astype(np.uint8) for q in qlens]
+        ts = [np.concatenate([qs[i][:min(len(qs[i]), t)], rng.integers(0, 4, size=max(t - len(qs[i]), 0)).astype(np.uint8)])[:t] for i, t in enumerate(tlens)]
+        qlen = np.array(qlens, np.uint32); tlen = np.array(tlens, np.uint32)
+        qoff = np.concatenate([[0], np.cumsum(qlen)[:-1]]).astype(np.uint32); toff = np.concatenate([[0], np.cumsum(tlen)[:-1]]).astype(np.uint32)
+        cat = lambda xs: np.concatenate(xs) if sum(len(x) for x in xs) else np.zeros(1, np.uint8)
+        return (cat(qs), qoff, qlen, cat(ts), toff, tlen, rng.integers(19, 100, size=len(qlens)).astype(np.uint32))
+    cases = [([70], [0]),                                                # one job, no rows (was lost: the loop ended before its result was written)
+             ([3, 70, 85], [4, 0, 5]),
+             ([5, 20, 40, 60, 70, 100, 130, 200, 280, 300, 400], [0] * 11),            # every class, only empty targets
+             (list(range(1, 300, 7)) * 3, [0 if i % 3 == 0 else int(rng.integers(1, 400)) for i in range(len(range(1, 300, 7)) * 3)])]
+    for qlens, tlens in cases:
+        jobs = batch(qlens, tlens)
+        want3, want6, _ = oracle.extend_batch(*jobs, want_raw=True)
+        got3, got6 = gpu_extend(hip, jobs)
+        assert np.array_equal(got3, want3), (qlens[:12], tlens[:12], got3[:12], want3[:12])
+        assert np.array_equal(got6, want6)
+
+
 def test_extension_long_queries(hip, oracle):
     jobs = common.make_ext_jobs(600, np.random.default_rng(22), maxq=512)
     want3, want6, _ = oracle.extend_batch(*jobs, want_raw=True)

@@ -60,17 +60,26 @@ if paired:   # configs[3]: one interleaved file with -p (the only coherent PE in
         for i in range(asc.shape[0]):
             f.write(b">p%d\n" % (i // 2)); f.write(asc[i].tobytes()); f.write(b"\n")
 else:
-    reads, truth = synth.make_reads(g, n_reads, 150, seed=7, sub_rate=0.04 if hard else 0.01, indel_frac=0.4 if hard else 0.05)
+    RL = int(os.environ.get("E2E_READLEN", "150"))
+    reads, truth = synth.make_reads(g, n_reads, RL, seed=7, sub_rate=0.04 if hard else 0.01, indel_frac=0.4 if hard else 0.05,
+                                    n_rate=float(os.environ.get("E2E_NRATE", "0.001")))
     if hard:
-        rng = np.random.default_rng(6); L = 150
+        rng = np.random.default_rng(6); L = RL
         for i in range(3, n_reads, 12):                      # chimeric reads
             k = int(rng.integers(50, 100)); p1 = int(rng.integers(0, n_genome - L)); b = g[p1:p1 + L - k].copy()
             reads[i][k:] = synth.revcomp(b) if rng.random() < 0.5 else b
-    synth.write_fasta_reads(fq, reads)
+    if os.environ.get("E2E_RAGGED"):          # reads cut to lengths between E2E_RAGGED_MIN (20; the reference itself aborts on some very short reads: ks_resize of 0 bytes) and the full length, hard mode only
+        assert hard
+        asc = synth.codes_to_ascii(reads); lens_r = np.random.default_rng(9).integers(int(os.environ.get("E2E_RAGGED_MIN", "20")), RL + 1, size=n_reads)
+        with open(fq, "wb") as f:
+            for i in range(n_reads):
+                f.write(b">r%d\n" % i); f.write(asc[i, :lens_r[i]].tobytes()); f.write(b"\n")
+    else:
+        synth.write_fasta_reads(fq, reads)
 sam = os.path.join(work, "out.sam")
 t = time.time()
 with open(sam, "w") as f:
-    r = subprocess.run([exe, "gase_aln", "-t", threads, "-K", "2000000000", "-l", "150"] + opts + (["-p"] if paired else []) + [prefix, fq], stdout=f, stderr=subprocess.PIPE, cwd=work)
+    r = subprocess.run([exe, "gase_aln", "-t", threads, "-K", "2000000000", "-l", os.environ.get("E2E_READLEN", "150")] + opts + (["-p"] if paired else []) + [prefix, fq], stdout=f, stderr=subprocess.PIPE, cwd=work)
 dt = time.time() - t
 print("gase_aln rc=%d in %.2fs" % (r.returncode, dt))
 print(r.stderr.decode()[-1500:])

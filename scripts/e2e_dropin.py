@@ -41,9 +41,10 @@ fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g, contigs=contigs)
 print("index built+written in %.1fs" % (time.time() - t), flush=True)
 fq = os.path.join(work, "reads.fa")
 if paired:   # configs[3]: one interleaved file with -p (the only coherent PE input of the reference, SURVEY.md 8 notes)
-    reads, ptruth = synth.make_pairs(g, n_reads // 2, 150, seed=7, sub_rate=0.03 if hard else 0.01)
+    RL = int(os.environ.get("E2E_READLEN", "150"))
+    reads, ptruth = synth.make_pairs(g, n_reads // 2, RL, seed=7, sub_rate=0.03 if hard else 0.01)
     if hard:
-        rng = np.random.default_rng(8); L = 150
+        rng = np.random.default_rng(8); L = RL
         for i in range(0, len(reads), 2):
             kind = (i // 2) % 10
             m = i + int(rng.integers(0, 2))

@@ -149,7 +149,8 @@ extern "C" mem_seed_v_gpu *seed_gpu(gpuseed_storage_vector *d)
 
 	hipStream_t st;
 	HIPX(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-	bmh_seed_ws_t *ws = bmh_seed_ws_create(BATCH_READS, BATCH_BASES, 0, 0);
+	// candidate capacity = the hard bound (one per base): hard read sets need more than the library's default guess
+	bmh_seed_ws_t *ws = bmh_seed_ws_create(BATCH_READS, BATCH_BASES, BATCH_BASES, 0);
 	if (!ws) FATAL("seed_gpu: %s", bmh_last_error());
 	uint8_t *h_bases; uint32_t *h_offs, *h_lens;
 	HIPX(hipHostMalloc((void **)&h_bases, BATCH_BASES, hipHostMallocDefault));

@@ -731,6 +731,23 @@ extern "C" void bmh_seed_last_timing(const bmh_seed_ws_t *w, float ms[7]) { memc
 
 static inline unsigned nblk(uint64_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
 
+// the occurrences of a batch are known before anything is written to the three output arrays: when they do not fit, the arrays
+// are replaced by larger ones (the default capacity, 64 per read, is a guess -- reads from high-copy repeats have thousands)
+static int grow_occ(bmh_seed_ws *w, uint64_t need, bmh_seeds_t *out)
+{
+	if (need <= w->max_occ) return BMH_OK;
+	(void)hipFree(w->rows); (void)hipFree(w->qbeg); (void)hipFree(w->score);
+	w->rows = nullptr; w->qbeg = nullptr; w->score = nullptr; w->max_occ = 0;
+	const uint64_t cap = need + need / 4 + 1024;
+	if (hipMalloc((void **)&w->rows, 8 * cap) != hipSuccess || hipMalloc((void **)&w->qbeg, 8 * cap) != hipSuccess || hipMalloc((void **)&w->score, 4 * cap) != hipSuccess) {
+		bmh_set_error("bmh_seed_batch: %llu occurrences: no memory for the output arrays (%s)", (unsigned long long)need, hipGetErrorString(hipGetLastError()));
+		return BMH_ECAPACITY;
+	}
+	w->max_occ = cap;
+	out->d_rbeg = w->rows; out->d_qbeg = (const int32_t *)w->qbeg; out->d_score = w->score;
+	return BMH_OK;
+}
+
 extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs,
                               const uint32_t *d_lens, uint32_t n_reads, int min_seed_len, void *stream_, bmh_seeds_t *out)
 {
@@ -830,7 +847,7 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 		HIPCK(hipMemcpyAsync(&tot, w->occ_off + n_valid, 8, hipMemcpyDeviceToHost, st));
 		HIPCK(hipStreamSynchronize(st));
 		out->n_seeds = tot; out->n_smems = n_valid;
-		if (tot > w->max_occ) { bmh_set_error("bmh_seed_batch: %llu occurrences > capacity %llu", (unsigned long long)tot, (unsigned long long)w->max_occ); return BMH_ECAPACITY; }
+		if (grow_occ(w, tot, out) != BMH_OK) return BMH_ECAPACITY;
 		if (tot >> 32) { bmh_set_error("bmh_seed_batch: more than 2^32 occurrences in one batch"); return BMH_ECAPACITY; }
 		HIPCK(hipEventRecord(w->ev[4], st));
 		if (n_valid)
@@ -890,7 +907,7 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 	HIPCK(hipMemcpyAsync(&tot[1], w->keep_off, 8, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));
 	out->n_seeds = tot[0]; out->n_smems = tot[1];
-	if (tot[0] > w->max_occ) { bmh_set_error("bmh_seed_batch: %llu occurrences > capacity %llu", (unsigned long long)tot[0], (unsigned long long)w->max_occ); return BMH_ECAPACITY; }
+	if (grow_occ(w, tot[0], out) != BMH_OK) return BMH_ECAPACITY;
 	if (tot[0] >> 32) { bmh_set_error("bmh_seed_batch: more than 2^32 occurrences in one batch"); return BMH_ECAPACITY; }
 	per_read_counts_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(w->cand_base, w->occ_off, n_reads, w->n_ref_pos, w->prefix);
 	HIPCK(hipEventRecord(w->ev[4], st));

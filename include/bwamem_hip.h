@@ -65,9 +65,10 @@ int bmh_index_densify_sa(bmh_index_t *idx, int new_intv);
 /* ---------------------------------------------------------------- seeding */
 
 /* Workspace for batches of up to max_reads reads / max_bases bases.
- * max_cands bounds SMEM candidates per batch, max_occ bounds located
- * occurrences per batch (0 = defaults: 16 per read + 0.4 per base, 64 per read;
- * the hard upper bound on candidates is one per base). */
+ * max_cands bounds SMEM candidates per batch (0 = default guess: 16 per read + 0.4 per base; the hard
+ * upper bound, which never fails, is one per base -- bmh_seed_batch returns BMH_ECAPACITY beyond the
+ * capacity); max_occ sizes the arrays of located occurrences (0 = 64 per read): a batch that needs
+ * more gets larger arrays inside bmh_seed_batch. */
 typedef struct bmh_seed_ws bmh_seed_ws_t;
 bmh_seed_ws_t *bmh_seed_ws_create(uint32_t max_reads, uint64_t max_bases, uint64_t max_cands, uint64_t max_occ);
 void bmh_seed_ws_free(bmh_seed_ws_t *ws);

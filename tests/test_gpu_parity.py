@@ -24,7 +24,7 @@ def _to_dev(torch, a, dt=None):
     return t.cuda()
 
 
-def gpu_seed(B, idx, flat, offs, lens, min_seed_len=19, densify=None, genome=None):
+def gpu_seed(B, idx, flat, offs, lens, min_seed_len=19, densify=None, genome=None, max_occ=1 << 22):
     import torch
     from bwamem_hip.lib import seeds_to_host
     from bwamem_hip import synth
@@ -33,7 +33,7 @@ def gpu_seed(B, idx, flat, offs, lens, min_seed_len=19, densify=None, genome=Non
     dindex = B.Index.upload(idx) if genome is None else B.Index.upload(idx, pac=_pack_pac(genome), l_pac=len(genome))
     if densify:
         dindex.densify_sa(densify)
-    ws = B.SeedWorkspace(max(len(lens), 1), max(int(flat.size), 1), max_cands=max(int(flat.size), 64), max_occ=1 << 22)
+    ws = B.SeedWorkspace(max(len(lens), 1), max(int(flat.size), 1), max_cands=max(int(flat.size), 64), max_occ=max_occ)
     r = _to_dev(torch, ascii_)
     o = torch.from_numpy(offs.astype(np.int64)).to(torch.int32).cuda()
     l = torch.from_numpy(lens.astype(np.int64)).to(torch.int32).cuda()
@@ -104,6 +104,24 @@ def test_seeding_odd_genome_length(hip, oracle):
     flat, offs, lens = common.flat_reads(reads)
     want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
     got = gpu_seed(hip, idx, flat, offs, lens)
+    common.assert_seeds_equal(got, want)
+
+
+def test_seeding_grows_its_occurrence_arrays(hip, oracle):
+    """More located seeds than the workspace was sized for (reads from a 300-copy repeat, capacity 64): the output arrays are
+    replaced by larger ones instead of failing."""
+    rng = np.random.default_rng(3)
+    g = rng.integers(0, 4, size=400_000).astype(np.uint8)
+    rep = rng.integers(0, 4, size=400).astype(np.uint8)
+    for p in rng.integers(0, len(g) - 400, size=300):
+        g[p:p + 400] = rep
+    from bwamem_hip import fmindex
+    idx = fmindex.build_fmd_index(g)
+    reads = np.stack([rep[s:s + 101] for s in rng.integers(0, 299, size=200)])
+    flat, offs, lens = common.flat_reads(reads)
+    want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
+    assert len(want["rbeg"]) > 20000
+    got = gpu_seed(hip, idx, flat, offs, lens, max_occ=64)
     common.assert_seeds_equal(got, want)
 
 

@@ -356,17 +356,22 @@ def finalize_pairs(copt, ep, po, genome_len: int, pac: np.ndarray, reads_flat: n
     n = len(read_lens)
     a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)
     regs = a(regs, np.int32)
-    cap = len(regs) + 2 * n + 1024          # mate rescue adds a few regions; the call fails with ECAPACITY if this is short
-    out = np.empty((cap, 16), np.int32); opr = np.zeros(max(n, 1), np.uint32); h = np.zeros(max(n, 1), np.int32); uf = np.zeros(max(n, 1), np.int32)
+    cap = len(regs) + 2 * n + 1024          # mate rescue adds a few regions per pair; BMH_ECAPACITY (-3) if this is short: retried larger
+    opr = np.zeros(max(n, 1), np.uint32); h = np.zeros(max(n, 1), np.int32); uf = np.zeros(max(n, 1), np.int32)
     pes = np.zeros((4, 5), np.float64)
     ln = a([c[1] for c in contigs], np.int32) if contigs else None
     off = a(np.concatenate([[0], np.cumsum(ln)[:-1]]), np.int64) if contigs else None
     keep = [a(pac, np.uint8), a(reads_flat, np.uint8), a(read_offs, np.uint64), a(read_lens, np.uint32), a(regs_per_read, np.uint32), a(frac_rep, np.float32)]
-    m = L.bmh_finalize_pairs(C.byref(copt), C.byref(ep), C.byref(po), C.byref(pe), genome_len, _np_ptr(keep[0], _u8p), n, _np_ptr(keep[1], _u8p),
-                             _np_ptr(keep[2], _u64p), _np_ptr(keep[3], _u32p), _np_ptr(regs, _i32p), _np_ptr(keep[4], _u32p),
-                             keep[5].ctypes.data_as(C.POINTER(C.c_float)), len(contigs) if contigs else 1,
-                             off.ctypes.data_as(C.c_void_p) if contigs else None, ln.ctypes.data_as(C.c_void_p) if contigs else None,
-                             _np_ptr(out, _i32p), cap, _np_ptr(opr, _u32p), _np_ptr(h, _i32p), _np_ptr(uf, _i32p), pes.ctypes.data_as(C.c_void_p), n_threads)
+    for attempt in range(4):
+        out = np.empty((cap, 16), np.int32)
+        m = L.bmh_finalize_pairs(C.byref(copt), C.byref(ep), C.byref(po), C.byref(pe), genome_len, _np_ptr(keep[0], _u8p), n, _np_ptr(keep[1], _u8p),
+                                 _np_ptr(keep[2], _u64p), _np_ptr(keep[3], _u32p), _np_ptr(regs, _i32p), _np_ptr(keep[4], _u32p),
+                                 keep[5].ctypes.data_as(C.POINTER(C.c_float)), len(contigs) if contigs else 1,
+                                 off.ctypes.data_as(C.c_void_p) if contigs else None, ln.ctypes.data_as(C.c_void_p) if contigs else None,
+                                 _np_ptr(out, _i32p), cap, _np_ptr(opr, _u32p), _np_ptr(h, _i32p), _np_ptr(uf, _i32p), pes.ctypes.data_as(C.c_void_p), n_threads)
+        if m != -3:
+            break
+        cap = cap * 3 + 50 * n               # at most max_matesw rescued regions per read
     if m < 0:
         raise RuntimeError("bmh_finalize_pairs: " + _err(L))
     return out[:m], opr[:n], h[:n], uf[:n], pes

@@ -26,7 +26,8 @@ hard = len(sys.argv) > 5 and sys.argv[5] in ("se_hard", "pe_hard")      # diverg
 opts = sys.argv[6].split() if len(sys.argv) > 6 else []               # gase_aln options given to both sides, e.g. "-k 23 -A 2 -B 5 -a"
 os.makedirs(work, exist_ok=True)
 prefix = os.path.join(work, "g.fa")
-g = synth.make_genome(n_genome, seed=42)
+import ast
+g = synth.make_genome(n_genome, seed=42, **ast.literal_eval(os.environ.get("E2E_GENOME_KW", "{}")))     # e.g. "{'repeat_frac': 0.6, 'repeat_copies': (2000, 5000)}"
 t = time.time()
 idx = fmindex.build_fmd_index(g, device="cuda:0" if torch.cuda.is_available() else None)
 # E2E_CONTIGS=k: the genome is written as k sequences of unequal lengths (reads that straddle a cut lose the seeds that bridge it

@@ -689,16 +689,22 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 	// longest insertion whose end cell in the gscore column can still beat D(qlen-1): o + (e + a)*L < 2*delta
 	const int lg = (2 * delta - min_o - 1 >= 0 && min_e + A.a > 0) ? (2 * delta - min_o - 1) / (min_e + A.a) : 0;
 	const bool params_ok = A.a > 0 && delta < min_oe && (A.zdrop <= 0 || A.b <= A.zdrop);
+	// the codes of the compared columns are kept in LDS (one row pair per job): the shifted-diagonal test of the two-mismatch
+	// form re-reads up to seven of them per row, which as fresh fetches (address arithmetic, ASCII / 2-bit decoding) was most
+	// of this kernel's instructions
+	__shared__ uint8_t q_lds[16][512], t_lds[16][512];
+	uint8_t *qs = q_lds[threadIdx.x >> 4], *ts = t_lds[threadIdx.x >> 4];
 	for (uint32_t w = wave * 4; w < n; w += n_waves * 4) {
 		const uint32_t id = w + grp;
 		const bool have = id < n;
 		const int qlen = have ? (int)A.qlen[id] : 0, tlen = have ? (int)A.tlen[id] : 0, h0 = have ? (int)A.h0[id] : 1;
 		const job_src_t src = ext_job_src(A, id, have, qlen, tlen);
-		const bool elig = have && qlen > 0 && tlen >= qlen && params_ok;
+		const bool elig = have && qlen > 0 && qlen <= 512 && tlen >= qlen && params_ok;     // (512: the LDS rows; longer queries have no DP class either)
 		int hi = -1, lo = -0x7000, cnt = 0;   // largest / (negated) smallest mismatching column, mismatch count of this lane
 		for (int j = l16; __any(elig && j < qlen); j += 16) {
 			if (elig && j < qlen) {
 				const int qb = ext_q_at(A, src, j), tb = ext_t_at(A, src, j);
+				qs[j] = (uint8_t)qb; ts[j] = (uint8_t)tb;
 				const bool bad = qb > 3 || tb > 3;                      // N on either side: not eligible
 				const bool mis = tb != qb;
 				hi = bad ? 0x7000 : (mis ? max(hi, j) : hi);
@@ -718,11 +724,11 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 			int bits = 0;
 			for (int i = p1 + lmax + l16; __any(two && i <= p2); i += 16) {
 				if (two && i <= p2) {
-					const int tb = ext_t_at(A, src, i);
+					const int tb = (int)ts[i];
 					for (int L = 1; L <= lmax; ++L) {
 						const int cm = i - L, cp = i + L;
-						const bool mm = cm < 0 || ext_q_at(A, src, cm) != tb;       // d = -L
-						const bool mp = cp < qlen && ext_q_at(A, src, cp) != tb;    // d = +L: rows past the end of that diagonal do not count
+						const bool mm = cm < 0 || (int)qs[cm] != tb;                // d = -L
+						const bool mp = cp < qlen && (int)qs[cp] != tb;             // d = +L: rows past the end of that diagonal do not count
 						bits |= (mm ? 1 : 0) << (2 * (L - 1)) | (mp ? 1 : 0) << (2 * (L - 1) + 1);
 					}
 				}

@@ -31,10 +31,26 @@ struct fmd_dev_t {
 
 struct blk_t { uint4 occ, w; };
 
+// v[c] for a per-lane c in 0..3 as two levels of conditional moves on the bits of c (a chain of ?: on c == 0, c == 1, ...
+// is compiled into divergent branches around single moves)
+__device__ __forceinline__ uint32_t sel4(int c, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3)
+{
+	const bool b0 = c & 1, b1 = c & 2;
+	const uint32_t lo = b0 ? v1 : v0, hi = b0 ? v3 : v2;
+	return b1 ? hi : lo;
+}
+__device__ __forceinline__ uint64_t sel4(int c, uint64_t v0, uint64_t v1, uint64_t v2, uint64_t v3)
+{
+	const bool b0 = c & 1, b1 = c & 2;
+	const uint64_t lo = b0 ? v1 : v0, hi = b0 ? v3 : v2;
+	return b1 ? hi : lo;
+}
+
 // L2[c] for a per-lane c without indexing the kernel-argument struct dynamically
 __device__ __forceinline__ uint64_t fmd_L2(const fmd_dev_t &f, int c)
 {
-	return c == 0 ? f.L2[0] : c == 1 ? f.L2[1] : c == 2 ? f.L2[2] : c == 3 ? f.L2[3] : f.L2[4];
+	const uint64_t r = sel4(c, f.L2[0], f.L2[1], f.L2[2], f.L2[3]);
+	return c > 3 ? f.L2[4] : r;
 }
 
 __device__ __forceinline__ blk_t fmd_load_block(const fmd_dev_t &f, uint64_t b)
@@ -84,13 +100,13 @@ __device__ __forceinline__ uint32_t blk_occ1(const blk_t &b, int off, int c)
 		x = x & (x >> 1) & prefix_mask(off + 1 - 16 * i);
 		n += __popc(x);
 	}
-	return (c == 0 ? b.occ.x : c == 1 ? b.occ.y : c == 2 ? b.occ.z : b.occ.w) + n;
+	return sel4(c, b.occ.x, b.occ.y, b.occ.z, b.occ.w) + n;
 }
 
 __device__ __forceinline__ int blk_sym(const blk_t &b, int off)
 {
 	int wi = off >> 4;
-	uint32_t w = wi == 0 ? b.w.x : wi == 1 ? b.w.y : wi == 2 ? b.w.z : b.w.w;
+	uint32_t w = sel4(wi, b.w.x, b.w.y, b.w.z, b.w.w);
 	return (w >> (30 - 2 * (off & 15))) & 3;
 }
 

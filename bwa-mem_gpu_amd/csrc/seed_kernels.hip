@@ -244,23 +244,22 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 
 struct res_t { uint32_t read, be, s, pad; };   // be = begin<<16 | end; s == 0: dropped
 
-// list order -> (read, ordinal) order: slot cand_base[read] + ordinal.  After this the candidates of
-// one forward pass (same read, same start) sit in adjacent slots, shortest first.
-__global__ void __launch_bounds__(256) cand_scatter_kernel(const cand_t *__restrict__ in_a, const uint64_t *__restrict__ in_k,
-                                                           uint64_t n_list, const uint32_t *__restrict__ cand_base,
-                                                           cand_t *__restrict__ out_a, uint64_t *__restrict__ out_k)
+// list order -> (read, ordinal) order: slot cand_base[read] + ordinal receives the list index of its candidate (4 bytes
+// scattered instead of the 24-byte candidate; the backward kernel fetches the candidate through it).  In that order the
+// candidates of one forward pass (same read, same start) sit in adjacent slots, shortest first.
+__global__ void __launch_bounds__(256) cand_scatter_kernel(const cand_t *__restrict__ in_a, uint64_t n_list, const uint32_t *__restrict__ cand_base,
+                                                           uint32_t *__restrict__ perm)
 {
 	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= n_list) return;
-	cand_t c = in_a[t];
-	if (c.read == CAND_INVALID) return;
-	size_t d = (size_t)cand_base[c.read] + c.j;
-	out_a[d] = c;
-	out_k[d] = in_k[t];
+	const uint2 h = *(const uint2 *)&in_a[t];               // read, xe
+	const uint32_t j = in_a[t].j;
+	if (h.x == CAND_INVALID) return;
+	perm[(size_t)cand_base[h.x] + j] = (uint32_t)t;
 }
 
-// One lane per candidate, in (read, ordinal) order, in place: slot t holds the candidate on entry
-// and its result on exit.  Unidirectional backward search from start-1 to the maximal begin.
+// One lane per candidate, in (read, ordinal) order: slot t takes its candidate through perm[t] (cand_scatter_kernel)
+// and holds its result on exit.  Unidirectional backward search from start-1 to the maximal begin.
 // Contained-match early exit (the `ok[c].x[2] != curr->a[curr->n-1].x[2]` test of bwt_smem1,
 // src/bwt.c:543): the candidates of one pass walk back in lockstep in adjacent lanes; when a
 // candidate's interval size equals that of the nearest still-active longer candidate of its pass,
@@ -268,6 +267,8 @@ __global__ void __launch_bounds__(256) cand_scatter_kernel(const cand_t *__restr
 // drop it -- it stops now and is marked dropped.  Lanes of a pass split across two waves simply
 // miss this shortcut (the filter still drops them).
 __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_view_t rv, uint64_t n_cands, int min_seed_len,
+                                                            const cand_t *__restrict__ cand_a, const uint64_t *__restrict__ cand_k,
+                                                            const uint32_t *__restrict__ perm,
                                                             res_t *__restrict__ res_a, uint64_t *__restrict__ res_k,
                                                             unsigned long long *__restrict__ stats)
 {
@@ -276,7 +277,7 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 	bool live = t < n_cands;
 	cand_t c = {CAND_INVALID, 0, 0, 0};
 	uint64_t lo = 0, hi = 0;
-	if (live) { c = ((const cand_t *)res_a)[t]; lo = res_k[t]; hi = lo + c.s - 1; }
+	if (live) { const uint32_t src = perm[t]; c = cand_a[src]; lo = cand_k[src]; hi = lo + c.s - 1; }
 	int x = (int)(c.xe >> 16), end = (int)(c.xe & 0xFFFF);
 	int i = x - 1, beg = x;
 	bool act = live && i >= 0, dropped = false;
@@ -880,12 +881,12 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 	out->n_cands = n_cands;
 	if (n_list > w->max_cands) { bmh_set_error("bmh_seed_batch: %llu candidate slots > capacity %llu", n_list, (unsigned long long)w->max_cands); return BMH_ECAPACITY; }
 	if (n_list)
-		cand_scatter_kernel<<<nblk(n_list, 256), 256, 0, st>>>(w->cand_a, w->cand_k, n_list, w->cand_base, (cand_t *)w->res_a, w->res_k);
+		cand_scatter_kernel<<<nblk(n_list, 256), 256, 0, st>>>(w->cand_a, n_list, w->cand_base, w->svals);
 	{
 		static const bool want_stats = getenv("BMH_SEED_STATS") != nullptr;
 		unsigned long long *d_st = want_stats ? (unsigned long long *)w->counter + 8 : nullptr;
 		if (want_stats) HIPCK(hipMemsetAsync(d_st, 0, 32, st));
-		if (n_cands) smem_backward_kernel<<<nblk(n_cands, 256), 256, 0, st>>>(f, rv, n_cands, min_seed_len, w->res_a, w->res_k, d_st);
+		if (n_cands) smem_backward_kernel<<<nblk(n_cands, 256), 256, 0, st>>>(f, rv, n_cands, min_seed_len, w->cand_a, w->cand_k, w->svals, w->res_a, w->res_k, d_st);
 		if (want_stats) {
 			unsigned long long h[4];
 			HIPCK(hipStreamSynchronize(st));

@@ -343,22 +343,32 @@ __global__ void __launch_bounds__(256) smem_filter_kernel(const res_t *__restric
 	res_t e = {0xFFFFFFFEu, 0, 0, 0};
 	if (t < n) e = res_a[t];
 	bool k = e.s > 0;
-	// comparison partner = next valid result; inside the wave it comes from a ballot + shuffle,
-	// only lanes behind the wave's last valid result walk global memory
-	const int lane = __lane_id();
+	// comparison partner = next valid result; inside the wave it comes from a ballot + shuffle, behind the wave's last
+	// valid result from the first valid result of the block's later waves (LDS), and only behind the block's last one
+	// from a walk through global memory
+	__shared__ uint32_t fv_has[4], fv_read[4], fv_be[4];
+	const int lane = __lane_id(), wv = (int)(threadIdx.x >> 6);
 	const unsigned long long vm = __ballot(k);
+	if (lane == 0) fv_has[wv] = vm ? 1u : 0u;
+	if (vm && lane == (int)__builtin_ctzll(vm)) { fv_read[wv] = e.read; fv_be[wv] = e.be; }
+	__syncthreads();
 	const unsigned long long ab = lane < 63 ? (vm >> (lane + 1)) << (lane + 1) : 0ull;
 	const int nl = ab ? __builtin_ctzll(ab) : lane;
 	const uint32_t nread = __shfl(e.read, nl), nbe = __shfl(e.be, nl);
 	if (k) {
 		if (ab) { if (nread == e.read && (nbe >> 16) == (e.be >> 16)) k = false; }
 		else {
-			for (uint64_t u = t - lane + 64; u < n; ++u) {
-				res_t nx = res_a[u];
-				if (nx.read != e.read) break;
-				if (nx.s == 0) continue;
-				if ((nx.be >> 16) == (e.be >> 16)) k = false;
-				break;
+			int w2 = wv + 1;
+			while (w2 < 4 && !fv_has[w2]) ++w2;
+			if (w2 < 4) { if (fv_read[w2] == e.read && (fv_be[w2] >> 16) == (e.be >> 16)) k = false; }
+			else {
+				for (uint64_t u = (uint64_t)(blockIdx.x + 1) * blockDim.x; u < n; ++u) {
+					res_t nx = res_a[u];
+					if (nx.read != e.read) break;
+					if (nx.s == 0) continue;
+					if ((nx.be >> 16) == (e.be >> 16)) k = false;
+					break;
+				}
 			}
 		}
 	}

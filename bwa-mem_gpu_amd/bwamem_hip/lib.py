@@ -348,8 +348,9 @@ def cigar_batch(index: Index, reads_t, offs_t, lens_t, regs_t, n: int, sel_t=Non
 
 
 def finalize_pairs(copt, ep, po, genome_len: int, pac: np.ndarray, reads_flat: np.ndarray, read_offs: np.ndarray, read_lens: np.ndarray,
-                   regs: np.ndarray, regs_per_read: np.ndarray, frac_rep: np.ndarray, contigs=None, n_threads: int = 1, pe=None):
-    """bmh_finalize_pairs -> (fin [m,16], per_read, h_rec, unflag, pes [4,5])"""
+                   regs: np.ndarray, regs_per_read: np.ndarray, frac_rep: np.ndarray, contigs=None, n_threads: int = 1, pe=None, out=None):
+    """bmh_finalize_pairs -> (fin [m,16], per_read, h_rec, unflag, pes [4,5]).  out: optional preallocated int32 [cap,16] buffer
+    (a caller that runs batch after batch keeps one, so the pages are not faulted in on every call)"""
     L = load_library()
     if pe is None:
         pe = PeOpt(); L.bmh_pe_opt_default(C.byref(pe))
@@ -362,8 +363,13 @@ def finalize_pairs(copt, ep, po, genome_len: int, pac: np.ndarray, reads_flat: n
     ln = a([c[1] for c in contigs], np.int32) if contigs else None
     off = a(np.concatenate([[0], np.cumsum(ln)[:-1]]), np.int64) if contigs else None
     keep = [a(pac, np.uint8), a(reads_flat, np.uint8), a(read_offs, np.uint64), a(read_lens, np.uint32), a(regs_per_read, np.uint32), a(frac_rep, np.float32)]
+    if out is not None and out.dtype == np.int32 and out.ndim == 2 and out.shape[1] == 16 and out.flags.c_contiguous and len(out) >= cap:
+        cap = len(out)
+    else:
+        out = None
     for attempt in range(4):
-        out = np.empty((cap, 16), np.int32)
+        if out is None or len(out) < cap:
+            out = np.empty((cap, 16), np.int32)
         m = L.bmh_finalize_pairs(C.byref(copt), C.byref(ep), C.byref(po), C.byref(pe), genome_len, _np_ptr(keep[0], _u8p), n, _np_ptr(keep[1], _u8p),
                                  _np_ptr(keep[2], _u64p), _np_ptr(keep[3], _u32p), _np_ptr(regs, _i32p), _np_ptr(keep[4], _u32p),
                                  keep[5].ctypes.data_as(C.POINTER(C.c_float)), len(contigs) if contigs else 1,

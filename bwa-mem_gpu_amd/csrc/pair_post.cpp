@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 #include "bmh_internal.h"
@@ -56,25 +57,42 @@ int cal_sub(const PCtx &c, const Span &r)
 	return j < r.size() ? r[j].score : c.x.co->min_seed_len * c.x.ep->a;
 }
 
-template <class RegsOf> void pestat(PCtx &c, size_t n, RegsOf regs_of)            // mem_pestat; regs_of(r) -> (pointer, count)
+template <class RegsOf> void pestat(PCtx &c, size_t n, RegsOf regs_of, int n_threads)            // mem_pestat; regs_of(r) -> (pointer, count)
 {
 	std::vector<uint64_t> isize[4];
 	memset(c.pes, 0, sizeof(c.pes));
-	for (size_t i = 0; i < n >> 1; ++i) {
-		const Span r0 = regs_of(i << 1), r1 = regs_of(i << 1 | 1);
-		if (r0.empty() || r1.empty()) continue;
-		if (cal_sub(c, r0) > 0.8 * r0[0].score) continue;
-		if (cal_sub(c, r1) > 0.8 * r1[0].score) continue;
-		if (r0[0].rid != r1[0].rid) continue;
-		int64_t is;
-		const int dir = infer_dir(c.x.l_pac, r0[0].rb, r1[0].rb, &is);
-		if (is && is <= c.pe->max_ins) isize[dir].push_back((uint64_t)is);
-	}
+	// candidate insert sizes of the pairs: ranges of pairs on threads, concatenated in pair order (the values are sorted next, so
+	// only the multiset matters)
+	const size_t n_pairs = n >> 1;
+	int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+	if (n_pairs < 4096) nt = 1;
+	std::vector<std::vector<uint64_t>> loc((size_t)nt * 4);
+	auto collect = [&](int t) {
+		const size_t p0 = n_pairs * (size_t)t / (size_t)nt, p1 = n_pairs * (size_t)(t + 1) / (size_t)nt;
+		for (size_t i = p0; i < p1; ++i) {
+			const Span r0 = regs_of(i << 1), r1 = regs_of(i << 1 | 1);
+			if (r0.empty() || r1.empty()) continue;
+			if (cal_sub(c, r0) > 0.8 * r0[0].score) continue;
+			if (cal_sub(c, r1) > 0.8 * r1[0].score) continue;
+			if (r0[0].rid != r1[0].rid) continue;
+			int64_t is;
+			const int dir = infer_dir(c.x.l_pac, r0[0].rb, r1[0].rb, &is);
+			if (is && is <= c.pe->max_ins) loc[(size_t)t * 4 + (size_t)dir].push_back((uint64_t)is);
+		}
+	};
+	if (nt == 1) collect(0);
+	else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(collect, t); for (auto &x : th) x.join(); }
+	for (int d = 0; d < 4; ++d) for (int t = 0; t < nt; ++t) isize[d].insert(isize[d].end(), loc[(size_t)t * 4 + d].begin(), loc[(size_t)t * 4 + d].end());
 	for (int d = 0; d < 4; ++d) {
 		Pes *r = &c.pes[d];
 		std::vector<uint64_t> &q = isize[d];
 		if (q.size() < 10) { r->failed = 1; continue; }
-		std::sort(q.begin(), q.end());
+		if (c.pe->max_ins > 0 && c.pe->max_ins <= (1 << 22)) {          // values are 1..max_ins: counting sort
+			std::vector<uint32_t> cntv((size_t)c.pe->max_ins + 1, 0);
+			for (uint64_t v : q) ++cntv[(size_t)v];
+			size_t k = 0;
+			for (size_t v = 0; v < cntv.size(); ++v) for (uint32_t m = 0; m < cntv[v]; ++m) q[k++] = (uint64_t)v;
+		} else std::sort(q.begin(), q.end());
 		const int p25 = (int)q[(int)(.25 * q.size() + .499)], p50 = (int)q[(int)(.50 * q.size() + .499)], p75 = (int)q[(int)(.75 * q.size() + .499)];
 		(void)p50;
 		r->low = (int)(p25 - 2.0 * (p75 - p25) + .499);
@@ -366,7 +384,8 @@ extern "C" int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext
 	std::vector<uint64_t> in_off((size_t)n_reads + 1, 0);
 	for (uint32_t r = 0; r < n_reads; ++r) in_off[r + 1] = in_off[r] + regs_per_read[r];
 	// regions of all reads in one array (no per-read heap traffic: that, not the arithmetic, dominated on many threads)
-	std::vector<Reg> flat((size_t)in_off[n_reads] + 1);
+	std::unique_ptr<Reg[]> flat_mem(new Reg[(size_t)in_off[n_reads] + 1]);        // not zeroed: reg_from_record sets every field
+	Reg *const flat = flat_mem.get();
 	std::vector<uint32_t> cnt(n_reads, 0);
 	if (n_threads < 1) n_threads = 1;
 	if ((uint32_t)n_threads > n_reads / 2 + 1) n_threads = (int)(n_reads / 2 + 1);
@@ -382,13 +401,13 @@ extern "C" int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext
 	par([&](int, uint32_t r0, uint32_t r1) {                    // per read: mem_sort_dedup_patch, in place
 		for (uint32_t r = r0; r < r1; ++r) {
 			const int n_in = (int)regs_per_read[r];
-			Reg *a = flat.data() + in_off[r];
+			Reg *a = flat + in_off[r];
 			for (int i = 0; i < n_in; ++i) reg_from_record(c.x, regs_in + 8 * (in_off[r] + i), frac_rep ? frac_rep[r] : 0.f, a[i]);
 			cnt[r] = (uint32_t)sort_dedup_patch(c.x, reads + read_offs[r], n_in, a);
 		}
 	}, n_reads);
 	const double t_b = now();
-	pestat(c, n_reads, [&](size_t r) { return Span{flat.data() + in_off[r], cnt[r]}; });
+	pestat(c, n_reads, [&](size_t r) { return Span{flat + in_off[r], cnt[r]}; }, n_threads);
 	const double t_c = now();
 	if (pes_out) for (int d = 0; d < 4; ++d) { pes_out[5 * d] = c.pes[d].low; pes_out[5 * d + 1] = c.pes[d].high; pes_out[5 * d + 2] = c.pes[d].failed; pes_out[5 * d + 3] = c.pes[d].avg; pes_out[5 * d + 4] = c.pes[d].std; }
 	// per pair: mem_sam_pe's decisions; every thread appends the records of its (contiguous) pairs to its own buffer
@@ -401,7 +420,7 @@ extern "C" int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext
 		for (uint32_t p = p0; p < p1; ++p) {
 			for (int i = 0; i < 2; ++i) {
 				const uint32_t r = 2 * p + (uint32_t)i;
-				o2[i].regs.assign(flat.data() + in_off[r], flat.data() + in_off[r] + cnt[r]);
+				o2[i].regs.assign(flat + in_off[r], flat + in_off[r] + cnt[r]);
 				o2[i].mapq.clear(); o2[i].flag.clear(); o2[i].rep.clear(); o2[i].sec_all.clear(); o2[i].h = -1;
 			}
 			const int extra = sam_pe(c, (uint64_t)(popt->id0 / 2) + p, 2 * p, o2);
@@ -430,13 +449,17 @@ extern "C" int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext
 	}, n_reads / 2);
 	const double t_d = now();
 	if (prof) fprintf(stderr, "[pairs] dedup %.1f ms, pestat %.1f ms, mem_sam_pe %.1f ms (%d threads)\n", t_b - t_a, t_c - t_b, t_d - t_c, n_threads);
-	uint64_t w = 0; uint32_t r = 0;
-	for (const Part &P : parts) {
-		const uint64_t nrec = P.rec.size() / 16;
-		if (w + nrec > cap) { bmh_set_error("bmh_finalize_pairs: more than %llu output regions", (unsigned long long)cap); return BMH_ECAPACITY; }
-		if (nrec) memcpy(out + 16 * w, P.rec.data(), sizeof(int32_t) * 16 * nrec);
-		for (size_t k = 0; k < P.n.size(); ++k, ++r) { out_per_read[r] = P.n[k]; out_h[r] = P.h[k]; out_unflag[r] = P.uf[k]; }
-		w += nrec;
-	}
-	return (int64_t)w;
+	// the parts go out side by side: offsets first, then every thread copies its own part
+	std::vector<uint64_t> w_off(parts.size() + 1, 0), r_off(parts.size() + 1, 0);
+	for (size_t t = 0; t < parts.size(); ++t) { w_off[t + 1] = w_off[t] + parts[t].rec.size() / 16; r_off[t + 1] = r_off[t] + parts[t].n.size(); }
+	if (w_off[parts.size()] > cap) { bmh_set_error("bmh_finalize_pairs: more than %llu output regions", (unsigned long long)cap); return BMH_ECAPACITY; }
+	par([&](int, uint32_t t0, uint32_t t1) {
+		for (uint32_t t = t0; t < t1; ++t) {
+			const Part &P = parts[t];
+			if (!P.rec.empty()) memcpy(out + 16 * w_off[t], P.rec.data(), sizeof(int32_t) * P.rec.size());
+			uint64_t r = r_off[t];
+			for (size_t k = 0; k < P.n.size(); ++k, ++r) { out_per_read[r] = P.n[k]; out_h[r] = P.h[k]; out_unflag[r] = P.uf[k]; }
+		}
+	}, (uint32_t)parts.size());
+	return (int64_t)w_off[parts.size()];
 }

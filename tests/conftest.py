@@ -13,6 +13,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Tests marked gpu are skipped (not failed) where no device is present, so a plain `pytest` run on a CPU box stays green;
+    on a GPU box nothing is skipped and the product library must load (no fallback)."""
+    gpu_items = [it for it in items if "gpu" in it.keywords]
+    if not gpu_items:
+        return
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (no HIP device here)")
+    for it in gpu_items:
+        it.add_marker(skip)
+
+
 def pytest_sessionstart(session):
     """The HIP library is a build product (git-ignored): build it when a fresh checkout has none (hipcc cross-compiles for gfx950
     without a GPU; ~40 s).  The tests never fall back to anything else if this fails."""

@@ -152,6 +152,80 @@ def build_fmd_index(genome_fwd: np.ndarray, sa_intv: int = 16, device: str | Non
                     n_sa=n_sa, sa=sa32, sa_bits=bits, pack_size=pack_size)
 
 
+@dataclass
+class DeviceFMDIndex:
+    """What bmh_index_build leaves in HBM: the arguments of bmh_index_from_device (torch tensors are plumbing: device memory)."""
+    primary: int
+    L2: np.ndarray
+    seq_len: int
+    bwt_t: "torch.Tensor"      # int32 [(ceil(seq_len/64)+1)*8]: whole 32-byte blocks, the last one holds the totals
+    sa_intv: int
+    sa_t: "torch.Tensor"       # int32 [n_sa]
+    bits_t: "torch.Tensor"     # int32 [n_sa/32+1]
+    stats: dict
+
+
+def pack_pac_device(codes_t: torch.Tensor) -> torch.Tensor:
+    """nt4 codes 0..3 (uint8, on the device) -> the .pac body: 4 bases per byte, first base in the top bits; padded by 64 bytes
+    (the kernels fetch the text in aligned words)."""
+    n = int(codes_t.numel())
+    pad = (-n) % 4
+    if pad:
+        codes_t = torch.cat([codes_t, torch.zeros(pad, dtype=torch.uint8, device=codes_t.device)])
+    v = codes_t.view(-1, 4)
+    pac = (v[:, 0] << 6) | (v[:, 1] << 4) | (v[:, 2] << 2) | v[:, 3]
+    return torch.cat([pac, torch.zeros(64, dtype=torch.uint8, device=codes_t.device)]).contiguous()
+
+
+def build_fmd_index_device(pac_t: torch.Tensor, l_pac: int, sa_intv: int = 1, verify: bool = False) -> DeviceFMDIndex:
+    """bmh_index_build: the FMD index of fwd . revcomp(fwd) built by the HIP library in HBM (hg38 scale: seq_len up to 2^33)."""
+    from .lib import BuildStats, _err, _u64p, load_library
+    import ctypes as C
+    L = load_library()
+    dev = pac_t.device
+    n = 2 * int(l_pac)
+    nblk = (n + 63) // 64
+    n_sa = (n + sa_intv) // sa_intv
+    bwt_t = torch.empty((nblk + 1) * 8, dtype=torch.int32, device=dev)
+    sa_t = torch.empty(n_sa, dtype=torch.int32, device=dev)
+    bits_t = torch.empty(n_sa // 32 + 1, dtype=torch.int32, device=dev)
+    primary = C.c_uint64(0)
+    L2 = np.zeros(5, dtype=np.uint64)
+    st = BuildStats()
+    torch.cuda.synchronize(dev)
+    rc = L.bmh_index_build(pac_t.data_ptr(), l_pac, sa_intv, bwt_t.data_ptr(), sa_t.data_ptr(), bits_t.data_ptr(), C.byref(primary),
+                           L2.ctypes.data_as(_u64p), 1 if verify else 0, C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"bmh_index_build rc={rc}: " + _err(L))
+    stats = {k: getattr(st, k) for k, _ in BuildStats._fields_}
+    return DeviceFMDIndex(int(primary.value), L2.astype(np.int64), n, bwt_t, sa_intv, sa_t, bits_t, stats)
+
+
+def device_index_to_host(d: DeviceFMDIndex, sa_intv: int = 16) -> FMDIndex:
+    """Host copy in the reference's file layout (what write_index writes and the oracle reads), with the samples of every
+    sa_intv-th row (a multiple of the device index's interval)."""
+    n = d.seq_len
+    nblk = (n + 63) // 64
+    n16 = (n + 15) // 16
+    n_words_last = n16 - (nblk - 1) * 4
+    w = d.bwt_t[: (nblk - 1) * 8 + 4 + n_words_last].cpu().numpy().view(np.uint32)
+    tot = (d.L2[1:] - d.L2[:-1]).astype(np.uint32)
+    words = np.concatenate([w, tot])
+    assert sa_intv % d.sa_intv == 0
+    step = sa_intv // d.sa_intv
+    n_sa = (n + sa_intv) // sa_intv
+    sa = d.sa_t[::step][:n_sa].cpu().numpy().view(np.uint32).copy()
+    assert sa.shape[0] == n_sa
+    bits = np.zeros(n_sa // 32 + 1, dtype=np.uint32)
+    if n >> 32:
+        rows = torch.arange(0, n_sa, device=d.sa_t.device, dtype=torch.int64) * step
+        hb = ((d.bits_t[rows >> 5] >> (rows & 31).to(torch.int32)) & 1).cpu().numpy().astype(bool)
+        idx = np.nonzero(hb)[0]
+        np.bitwise_or.at(bits, idx // 32, (np.uint32(1) << (idx % 32).astype(np.uint32)))
+    sa[0] = 0xFFFFFFFF
+    return FMDIndex(primary=d.primary, L2=d.L2.copy(), seq_len=n, bwt_words=words, sa_intv=sa_intv, n_sa=n_sa, sa=sa, sa_bits=bits, pack_size=1)
+
+
 def write_index(prefix: str, idx: FMDIndex) -> None:
     with open(prefix + ".bwt", "wb") as f:
         f.write(struct.pack("<Q", idx.primary))

@@ -22,7 +22,7 @@ def lib_path() -> str:
 # every symbol include/bwamem_hip.h and include/seed_gen.h declare
 EXPORTED_SYMBOLS = [
     "bmh_last_error", "bmh_device_count", "bmh_set_device", "bmh_index_upload", "bmh_index_from_device",
-    "bmh_index_free", "bmh_index_densify_sa", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
+    "bmh_index_free", "bmh_index_densify_sa", "bmh_index_build", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
     "bmh_extend_batch", "bmh_extend_last_ms", "bmh_calib_gather",
     "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
     "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
@@ -65,6 +65,12 @@ class PostOpt(C.Structure):
 class PeOpt(C.Structure):
     """bmh_pe_opt_t"""
     _fields_ = [("pen_unpaired", C.c_int), ("max_ins", C.c_int), ("max_matesw", C.c_int), ("no_rescue", C.c_int), ("no_pairing", C.c_int)]
+
+
+class BuildStats(C.Structure):
+    """bmh_build_stats_t"""
+    _fields_ = [("round0_passes", C.c_int), ("doubling_rounds", C.c_int), ("verified", C.c_int), ("unresolved_after_round0", C.c_uint64),
+                ("round0_seconds", C.c_double), ("sa_seconds", C.c_double), ("verify_seconds", C.c_double), ("total_seconds", C.c_double)]
 
 
 class DevJobsT(C.Structure):
@@ -118,6 +124,8 @@ def load_library() -> C.CDLL:
     L.bmh_index_free.argtypes = [C.c_void_p]
     L.bmh_index_densify_sa.restype = C.c_int
     L.bmh_index_densify_sa.argtypes = [C.c_void_p, C.c_int]
+    L.bmh_index_build.restype = C.c_int
+    L.bmh_index_build.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _u64p, _u64p, C.c_int, C.POINTER(BuildStats)]
     L.bmh_seed_ws_create.restype = C.c_void_p
     L.bmh_seed_ws_create.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64]
     L.bmh_seed_ws_free.argtypes = [C.c_void_p]

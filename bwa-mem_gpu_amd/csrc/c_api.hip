@@ -115,12 +115,13 @@ extern "C" bmh_index_t *bmh_index_from_device(uint64_t primary, const uint64_t L
 // seed costs 2.5 (or 1) index gathers instead of 8.5.  Values are unchanged, so are all results.
 __global__ void __launch_bounds__(256) sa_densify_kernel(fmd_dev_t f, int new_shift, uint64_t n_new, uint32_t *__restrict__ sa, uint32_t *__restrict__ bits)
 {
-	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= n_new) return;
-	const uint64_t k = j << new_shift;
-	const uint64_t v = j == 0 ? 0xFFFFFFFFull : fmd_sa(f, k);
-	sa[j] = (uint32_t)v;
-	if (j && ((v >> 32) & 1)) atomicOr(&bits[j >> 5], 1u << (j & 31));
+	// grid-stride: a launch cannot have 2^32 threads, and hg38 has 6.2e9 rows
+	for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_new; j += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t k = j << new_shift;
+		const uint64_t v = j == 0 ? 0xFFFFFFFFull : fmd_sa(f, k);
+		sa[j] = (uint32_t)v;
+		if (j && ((v >> 32) & 1)) atomicOr(&bits[j >> 5], 1u << (j & 31));
+	}
 }
 
 extern "C" int bmh_index_densify_sa(bmh_index_t *ix, int new_intv)
@@ -138,8 +139,10 @@ extern "C" int bmh_index_densify_sa(bmh_index_t *ix, int new_intv)
 		if (d_sa) (void)hipFree(d_sa); if (d_bits) (void)hipFree(d_bits);
 		return BMH_ENODEV;
 	}
-	sa_densify_kernel<<<(unsigned)((n_new + 255) / 256), 256>>>(ix->dev, new_shift, n_new, d_sa, d_bits);
-	hipError_t e = hipDeviceSynchronize();
+	const uint64_t nb = (n_new + 255) / 256;
+	sa_densify_kernel<<<(unsigned)(nb < (1u << 22) ? nb : (1u << 22)), 256>>>(ix->dev, new_shift, n_new, d_sa, d_bits);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipDeviceSynchronize();
 	if (e != hipSuccess) { bmh_set_error("bmh_index_densify_sa: %s", hipGetErrorString(e)); (void)hipFree(d_sa); (void)hipFree(d_bits); return BMH_ENODEV; }
 	if (ix->owns || ix->owns_sa) { (void)hipFree((void *)ix->dev.sa); (void)hipFree((void *)ix->dev.sa_bits); }
 	ix->dev.sa = d_sa; ix->dev.sa_bits = d_bits; ix->dev.n_sa = n_new; ix->dev.sa_shift = new_shift; ix->owns_sa = true;

@@ -62,6 +62,27 @@ void bmh_index_free(bmh_index_t *idx);
  * (4.125 bytes per sample).  The reference's files hold every 16th row (src/bwtindex.c:324). */
 int bmh_index_densify_sa(bmh_index_t *idx, int new_intv);
 
+/* Builds the FMD index of fwd . revcomp(fwd) ON THE DEVICE from the 2-bit forward strand (d_pac: l_pac bases, 4 per byte,
+ * first base in the top bits -- the .pac body; l_pac < 2^32, i.e. texts up to 2^33 symbols: hg38 has 6.2e9).  Replaces the
+ * reference's offline host passes (bwa_index/bwtindex.c:287-358 bwtsw construction, :174-197 GPU re-blocking,
+ * bwa_index/bwt.c:63-148 sampled suffix array) with the same values: the outputs are exactly what bmh_index_from_device
+ * takes and, copied to the host, the bodies of the reference's .bwt / .sa files.
+ * Caller-allocated device outputs (seq_len = 2 l_pac):
+ *   d_bwt_words  (ceil(seq_len/64) + 1) * 8 words, 32-byte aligned: blocks {u32 occ[4]; u32 bwt[4]}, then one block whose occ
+ *                is the totals;  d_sa  n_sa = (seq_len + sa_intv) / sa_intv words (sa[0] = 0xFFFFFFFF);  d_sa_bits  n_sa/32 + 1 words.
+ * sa_intv: power of two; 16 = what the reference's files hold, 1 = the whole suffix array (what the seeding kernels like best).
+ * flags: BMH_BUILD_VERIFY checks the finished suffix array completely (every adjacent pair of rows compared symbol by symbol,
+ * SA a permutation) before anything is written.  Uses about 24 bytes of HBM per symbol of seq_len while it runs (175 GB for
+ * hg38) and synchronises the device.  stats (optional) reports what happened. */
+#define BMH_BUILD_VERIFY 1
+typedef struct {
+	int round0_passes, doubling_rounds, verified;
+	uint64_t unresolved_after_round0;
+	double round0_seconds, sa_seconds, verify_seconds, total_seconds;
+} bmh_build_stats_t;
+int bmh_index_build(const uint8_t *d_pac, uint64_t l_pac, int sa_intv, uint32_t *d_bwt_words, uint32_t *d_sa, uint32_t *d_sa_bits,
+                    uint64_t *primary_out, uint64_t L2_out[5], int flags, bmh_build_stats_t *stats);
+
 /* ---------------------------------------------------------------- seeding */
 
 /* Workspace for batches of up to max_reads reads / max_bases bases.

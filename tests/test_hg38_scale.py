@@ -1,0 +1,150 @@
+"""GPU tests of the device index builder (bmh_index_build) and of the hot path on a text beyond 2^32 symbols --
+BASELINE.json configs[1]'s scale: the reference packs positions in 33 bits because hg38's fwd+revcomp text has 6.2e9 symbols
+(/root/reference/src/GPUSeed/seed_gen.cu:943,1073-1077)."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    import bwamem_hip as B
+    B.load_library()
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return B
+
+
+def _same(h, ref):
+    return (h.primary == ref.primary and np.array_equal(h.L2, ref.L2) and np.array_equal(h.bwt_words, ref.bwt_words)
+            and np.array_equal(h.sa, ref.sa) and np.array_equal(h.sa_bits, ref.sa_bits))
+
+
+def test_device_builder_writes_the_reference_index_files(hip, tmp_path):
+    """bmh_index_build on the genome of tests/golden/ref_index_g20011.fa -> .bwt / .sa byte-identical to the files the
+    reference's own `bwa index` CLI wrote (both passes of build_index.sh; tests/golden/make_golden.py)."""
+    import torch
+    from bwamem_hip import fmindex as F, synth
+    g = synth.make_genome(20011, seed=42)
+    pac = F.pack_pac_device(torch.from_numpy(g).cuda())
+    for cap in (None, "11"):                       # default: one pass; 2^11: 20 bucket passes, group-aligned doubling chunks
+        if cap:
+            os.environ["BMH_BUILD_CAP_LOG2"] = cap
+        try:
+            d = F.build_fmd_index_device(pac, len(g), sa_intv=16, verify=True)
+        finally:
+            os.environ.pop("BMH_BUILD_CAP_LOG2", None)
+        p = str(tmp_path / "g")
+        F.write_index(p, F.device_index_to_host(d, 16))
+        for ext in (".bwt", ".sa"):
+            assert open(p + ext, "rb").read() == open(os.path.join(common.GOLDEN, "ref_index_g20011" + ext), "rb").read(), (ext, cap)
+
+
+def test_device_builder_matches_host_builder_on_hard_texts(hip):
+    """repeat-rich, homopolymer and tandem texts (deep doubling: the depth reaches the text length), every sampling interval,
+    small chunk capacities"""
+    import torch
+    from bwamem_hip import fmindex as F, synth
+    rng = np.random.default_rng(1)
+    cases = {"tiny": rng.integers(0, 4, 37, dtype=np.uint8), "one": np.array([2], np.uint8),
+             "rep": synth.make_genome(100_000, seed=5, repeat_frac=0.5, repeat_div=0.01), "polyA": np.zeros(3000, np.uint8),
+             "tandem": np.tile(rng.integers(0, 4, 171, dtype=np.uint8), 40), "palindrome": np.tile(np.array([0, 3], np.uint8), 500),
+             "m1": synth.make_genome(1_000_000, seed=7, repeat_frac=0.3, repeat_div=0.02)}
+    for name, g in cases.items():
+        ref = F.build_fmd_index(g, sa_intv=16, device="cuda:0")
+        pac = F.pack_pac_device(torch.from_numpy(g).cuda())
+        for cap in ((None, "16") if name == "m1" else (None, "14") if name in ("polyA", "tandem", "palindrome") else (None, "12", "9")):
+            if cap:
+                os.environ["BMH_BUILD_CAP_LOG2"] = cap
+            try:
+                for intv in (16, 4, 1):
+                    d = F.build_fmd_index_device(pac, len(g), sa_intv=intv, verify=True)
+                    assert d.stats["verified"] == 1
+                    assert _same(F.device_index_to_host(d, 16), ref), (name, cap, intv)
+            finally:
+                os.environ.pop("BMH_BUILD_CAP_LOG2", None)
+
+
+def test_builder_reports_a_group_beyond_the_chunk_capacity(hip):
+    import torch
+    from bwamem_hip import fmindex as F
+    pac = F.pack_pac_device(torch.zeros(5000, dtype=torch.uint8).cuda())
+    os.environ["BMH_BUILD_CAP_LOG2"] = "9"
+    try:
+        with pytest.raises(RuntimeError, match="capacity"):
+            F.build_fmd_index_device(pac, 5000, sa_intv=16)
+    finally:
+        os.environ.pop("BMH_BUILD_CAP_LOG2", None)
+
+
+def test_hot_path_on_a_text_beyond_2_pow_32(hip, oracle):
+    """A 2.2 Gbp hg38-like genome (24 contigs, 50 % repeats, N-runs): seq_len = 4.4e9 > 2^32.  Index built and completely
+    verified on the device; seeds, extension jobs, extension results and regions of 3000 reads bit-identical to the oracle
+    (which reads a host copy of the same index); positions beyond 2^32 really occur; reads are found where they were drawn."""
+    import torch
+    B = hip
+    from bwamem_hip import fmindex as F, synth, pipeline as P
+    from bwamem_hip.lib import ChainWorkspace, HostJobs, seeds_to_host
+    dev = torch.device("cuda", 0)
+    n = 2_200_000_000
+    g_t, meta = synth.make_genome_device(n, dev, seed=11, return_meta=True)
+    pac_t = F.pack_pac_device(g_t)
+    g = g_t.cpu().numpy()
+    del g_t
+    torch.cuda.empty_cache()
+    d = F.build_fmd_index_device(pac_t, n, sa_intv=1, verify=True)
+    assert d.seq_len == 2 * n > 1 << 32 and d.stats["verified"] == 1
+    dindex = B.Index.from_device(d.primary, d.L2.astype(np.uint64), d.seq_len, d.bwt_t, 1, d.sa_t, d.bits_t, pac_t=pac_t, l_pac=n)
+    n_reads = 3000
+    reads, truth = synth.make_reads(g, n_reads, 150, seed=7, holes=meta["holes"])
+    # half of the reads from the first 100 Mbp: the reverse-strand text positions 2n - p of those lie beyond 2^32
+    reads2, truth2 = synth.make_reads(g[meta["holes"][0][1]:100_000_000], n_reads // 2, 150, seed=8)
+    reads[n_reads // 2:] = reads2
+    truth["pos"][n_reads // 2:] = truth2["pos"] + meta["holes"][0][1]
+    flat, offs, lens = common.flat_reads(reads)
+    hidx = F.device_index_to_host(d, 16)
+    want = oracle.seed_reads(oracle.fmd(hidx), flat, offs, lens, 19, n_threads=8)
+    dr = P.reads_to_device(reads, dev)
+    ws = B.SeedWorkspace(n_reads, n_reads * 150, max_cands=n_reads * 150)
+    s = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19)
+    common.assert_seeds_equal(seeds_to_host(s, n_reads), want, "beyond 2^32: ")
+    assert int(want["rbeg"].max()) > 1 << 32
+    # the same from the sparser samples of the reference's files (33rd bit of a sample through the packed bit array + LF walk)
+    d16 = B.Index.upload(hidx, pac=None)
+    s16 = ws.seed_batch(d16, dr.ascii, dr.offs, dr.lens, 19)
+    common.assert_seeds_equal(seeds_to_host(s16, n_reads), want, "beyond 2^32, sa_intv 16: ")
+    d16.densify_sa(4)
+    s4 = ws.seed_batch(d16, dr.ascii, dr.offs, dr.lens, 19)
+    common.assert_seeds_equal(seeds_to_host(s4, n_reads), want, "beyond 2^32, densified to 4: ")
+    d16.free()
+    s = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19)
+    cw = ChainWorkspace(n_reads, int(s.n_seeds) + 64)
+    cw.set_contigs(meta["contigs"])
+    cw.set_materialize(False)
+    dj = cw.chain_batch(dindex, dr.ascii, dr.offs, dr.lens, s)
+    hj = HostJobs(g, flat, offs, lens, want, n_threads=8, contigs=meta["contigs"])
+    assert int(dj.n_jobs) == hj.n_jobs and int(dj.n_regs) == hj.n_regs
+    o3 = torch.zeros(hj.n_jobs + 1, 3, dtype=torch.int32, device=dev)
+    r8 = torch.zeros(hj.n_regs + 1, 8, dtype=torch.int32, device=dev)
+    cw.extend(o3)
+    cw.merge(o3, r8)
+    torch.cuda.synchronize()
+    want3, _, _ = oracle.extend_batch(*hj.jobs(), n_threads=8)
+    assert np.array_equal(o3.cpu().numpy()[: hj.n_jobs], want3)
+    rg = r8.cpu().numpy()[: hj.n_regs]
+    assert np.array_equal(rg, hj.merge(want3))
+    rb = rg[:, 4].view(np.uint32).astype(np.int64) | (rg[:, 5].astype(np.int64) << 32)
+    re = rg[:, 6].view(np.uint32).astype(np.int64) | (rg[:, 7].astype(np.int64) << 32)
+    assert (re > 1 << 32).mean() > 0.08
+    fb = np.where(rb >= n, 2 * n - re, rb)
+    fe = np.where(rb >= n, 2 * n - rb, re)
+    tp = truth["pos"][rg[:, 0]]
+    found = np.zeros(n_reads, bool)
+    found[rg[:, 0][(fb < tp + 150) & (fe > tp)]] = True
+    assert found.mean() > 0.99, found.mean()
+    hj.free(); cw.free(); ws.free(); dindex.free()

@@ -177,6 +177,13 @@ def pack_pac_device(codes_t: torch.Tensor) -> torch.Tensor:
     return torch.cat([pac, torch.zeros(64, dtype=torch.uint8, device=codes_t.device)]).contiguous()
 
 
+def unpack_pac_device(pac_t: torch.Tensor, l_pac: int) -> torch.Tensor:
+    """the .pac body on the device -> nt4 codes 0..3 (uint8 [l_pac])"""
+    nb = (l_pac + 3) // 4
+    b = pac_t[:nb]
+    return torch.stack([(b >> 6) & 3, (b >> 4) & 3, (b >> 2) & 3, b & 3], dim=1).reshape(-1)[:l_pac].contiguous()
+
+
 def build_fmd_index_device(pac_t: torch.Tensor, l_pac: int, sa_intv: int = 1, verify: bool = False) -> DeviceFMDIndex:
     """bmh_index_build: the FMD index of fwd . revcomp(fwd) built by the HIP library in HBM (hg38 scale: seq_len up to 2^33)."""
     from .lib import BuildStats, _err, _u64p, load_library
@@ -199,6 +206,20 @@ def build_fmd_index_device(pac_t: torch.Tensor, l_pac: int, sa_intv: int = 1, ve
         raise RuntimeError(f"bmh_index_build rc={rc}: " + _err(L))
     stats = {k: getattr(st, k) for k, _ in BuildStats._fields_}
     return DeviceFMDIndex(int(primary.value), L2.astype(np.int64), n, bwt_t, sa_intv, sa_t, bits_t, stats)
+
+
+def host_index_to_device_form(idx: FMDIndex, device) -> DeviceFMDIndex:
+    """FMDIndex (file layout, host) -> tensors on `device` in the form bmh_index_from_device takes (blocks padded to whole units)"""
+    nblk = (idx.seq_len + 63) // 64 + 1
+    bwt = torch.zeros(nblk * 8, dtype=torch.int32, device=device)
+    n16 = (idx.seq_len + 15) // 16
+    body = (nblk - 2) * 8 + 4 + (n16 - (nblk - 2) * 4)          # words before the trailing totals
+    w = torch.from_numpy(idx.bwt_words.view(np.int32).copy())
+    bwt[:body] = w[:body].to(device)
+    bwt[(nblk - 1) * 8:(nblk - 1) * 8 + 4] = w[body:body + 4].to(device)
+    sa = torch.from_numpy(idx.sa.view(np.int32).copy()).to(device)
+    bits = torch.from_numpy(idx.sa_bits.view(np.int32).copy()).to(device)
+    return DeviceFMDIndex(idx.primary, np.asarray(idx.L2, dtype=np.int64), idx.seq_len, bwt, idx.sa_intv, sa, bits, {})
 
 
 def device_index_to_host(d: DeviceFMDIndex, sa_intv: int = 16) -> FMDIndex:

@@ -71,3 +71,37 @@ def broadcast_index(idx, device, src: int = 0, world: int | None = None):
     header = dict(primary=int(hdr[0]), L2=hdr[1:6].numpy().astype(np.uint64), seq_len=seq_len, sa_intv=int(hdr[7]),
                   n_sa=n_sa)
     return header, bwt, sa, bits
+
+
+def _bcast_chunked(t: torch.Tensor, src: int, chunk: int = 1 << 28) -> None:
+    """one dist.broadcast per <= chunk elements (a dense hg38 suffix array is 6.2e9 words; transfers stay a few GB each)"""
+    flat = t.view(-1)
+    for o in range(0, flat.numel(), chunk):
+        dist.broadcast(flat[o:o + chunk], src)
+
+
+def broadcast_built_index(d, pac_t, meta, device, src: int = 0):
+    """The index bmh_index_build left in rank `src`'s HBM (fmindex.DeviceFMDIndex + the 2-bit pac + the genome's metadata) to
+    every rank: `src` passes them, the others pass None.  One header, one object broadcast (metadata) and the four arrays
+    (pac, Occ/BWT blocks, suffix array, its high bits) over RCCL/xGMI -- the only collective of the run, outside the data path.
+    Returns (DeviceFMDIndex, pac_t, meta) on every rank.  Without an initialised process group it returns its arguments."""
+    from .fmindex import DeviceFMDIndex
+    if not dist.is_initialized():
+        return d, pac_t, meta
+    rank = dist.get_rank()
+    hdr = torch.zeros(16, dtype=torch.int64, device=device)
+    if rank == src:
+        vals = [d.primary, *[int(x) for x in d.L2], d.seq_len, d.sa_intv, d.bwt_t.numel(), d.sa_t.numel(), d.bits_t.numel(), pac_t.numel()]
+        hdr[: len(vals)] = torch.tensor(vals, dtype=torch.int64)
+    dist.broadcast(hdr, src)
+    h = hdr.cpu().tolist()
+    box = [meta if rank == src else None]
+    dist.broadcast_object_list(box, src=src, device=device if device.type != "cpu" else None)
+    if rank != src:
+        d = DeviceFMDIndex(primary=h[0], L2=np.array(h[1:6], dtype=np.int64), seq_len=h[6], bwt_t=torch.empty(h[8], dtype=torch.int32, device=device),
+                           sa_intv=h[7], sa_t=torch.empty(h[9], dtype=torch.int32, device=device),
+                           bits_t=torch.empty(h[10], dtype=torch.int32, device=device), stats={})
+        pac_t = torch.empty(h[11], dtype=torch.uint8, device=device)
+    for t in (pac_t, d.bwt_t, d.sa_t, d.bits_t):
+        _bcast_chunked(t, src)
+    return d, pac_t, box[0]

@@ -66,10 +66,17 @@ __device__ __forceinline__ int ch_lane() { return (int)__builtin_amdgcn_mbcnt_hi
 __device__ __forceinline__ void ch_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0); }
 #endif
 
-CH_HD inline int pos2rid(const ch_ctx_t &x, int64_t pos_f)
+template <bool COOP = false> CH_HD inline int pos2rid(const ch_ctx_t &x, int64_t pos_f)
 {
 	if (pos_f >= x.l_pac) return -1;
 	if (x.n_contigs <= 1) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (COOP && x.n_contigs <= 64) {             // wave form: one contig start per lane, the answer is a ballot (the table sits in LDS)
+		const int lane = ch_lane();
+		const bool le = lane < x.n_contigs && x.ctg_off[lane] <= pos_f;
+		return __builtin_popcountll(__ballot(le)) - 1;
+	}
+#endif
 	int left = 0, mid = 0, right = x.n_contigs;
 	while (left < right) {
 		mid = (left + right) >> 1;
@@ -82,12 +89,12 @@ CH_HD inline int pos2rid(const ch_ctx_t &x, int64_t pos_f)
 	return mid;
 }
 CH_HD inline int64_t depos(const ch_ctx_t &x, int64_t pos, int *is_rev) { return (*is_rev = (pos >= x.l_pac)) ? (x.l_pac << 1) - 1 - pos : pos; }
-CH_HD inline int intv2rid(const ch_ctx_t &x, int64_t rb, int64_t re)
+template <bool COOP = false> CH_HD inline int intv2rid(const ch_ctx_t &x, int64_t rb, int64_t re)
 {
 	int is_rev;
 	if (rb < x.l_pac && re > x.l_pac) return -2;
-	const int rid_b = pos2rid(x, depos(x, rb, &is_rev));
-	const int rid_e = rb < re ? pos2rid(x, depos(x, re - 1, &is_rev)) : rid_b;
+	const int rid_b = pos2rid<COOP>(x, depos(x, rb, &is_rev));
+	const int rid_e = rb < re ? pos2rid<COOP>(x, depos(x, re - 1, &is_rev)) : rid_b;
 	return rid_b == rid_e ? rid_b : -1;
 }
 CH_HD inline int cal_max_gap(const bmh_chain_opt_t &o, int qlen)
@@ -163,14 +170,16 @@ template <bool COOP> CH_HD inline void sorted_insert(uint32_t *order, int64_t *o
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (COOP) {
+		// each round moves the top 256 entries of [at, hi) up by one: four independent loads per lane, then the four stores
+		// (a round of 64 costs the same two LDS latencies)
 		const int lane = ch_lane();
-		for (int hi = nc; hi > at; hi -= 64) {
-			const int j = hi - 1 - lane;
-			const bool act = j >= at;
-			uint32_t v = 0; int64_t p = 0;
-			if (act) { v = order[j]; p = opos[j]; }
+		for (int hi = nc; hi > at; hi -= 256) {
+			uint32_t v[4]; int64_t p[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - 64 * u, jc = j >= at ? j : at; v[u] = order[jc]; p[u] = opos[jc]; }   // no branch: the loads overlap
 			ch_wave_fence();
-			if (act) { order[j + 1] = v; opos[j + 1] = p; }
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - 64 * u; if (j >= at) { order[j + 1] = v[u]; opos[j + 1] = p[u]; } }
 			ch_wave_fence();
 		}
 		order[at] = cv; opos[at] = pv;
@@ -210,12 +219,14 @@ template <bool COOP, class F> CH_HD inline int first_true(int lo, int hi, F f)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (COOP) {
+		// 256 candidates per round: the four predicates are independent, so their LDS loads overlap (f is free of side effects)
 		const int lane = ch_lane();
-		for (int b = lo; b < hi; b += 64) {
-			const int i = b + lane;
-			const bool p = i < hi && f(i);
-			const unsigned long long m = __ballot(p);
-			if (m) return b + (int)__builtin_ctzll(m);
+		for (int b = lo; b < hi; b += 256) {
+			unsigned long long m[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int i = b + 64 * u + lane; m[u] = __ballot(i < hi && f(i)); }
+#pragma unroll
+			for (int u = 0; u < 4; ++u) if (m[u]) return b + 64 * u + (int)__builtin_ctzll(m[u]);
 		}
 		return hi;
 	}
@@ -313,7 +324,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 			} else
 #endif
 			rb = (int64_t)g_rbeg[i + (int64_t)count * step];
-			const int rid = intv2rid(x, rb, rb + slen);
+			const int rid = intv2rid<COOP>(x, rb, rb + slen);
 			if (rid < 0) continue;
 			// closest chain at or below the seed: upper bound over opos[0..nc), then one back
 			const int lo = upper_bound_pos<COOP>(opos, nc, rb);
@@ -429,17 +440,29 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 		};
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (COOP) {
+			// 256 kept chains per round, four per lane with independent loads; the scan ends behind the first chain that drops
+			// chain i (src/bwamem.c:520-535), the marks of `first` stop there too
 			const int lane = ch_lane();
-			for (int b = 0; b < nk && !broke; b += 64) {
-				const int k = b + lane;
-				bool ovl = false, brk = false;
-				ks_t aj; aj.chain = 0;
-				if (k < nk) { aj = ks[k]; test(aj, ovl, brk); }
-				const unsigned long long mb = __ballot(brk), mo = __ballot(ovl);
-				unsigned long long vm = ~0ull;
-				if (mb) { const int f = (int)__builtin_ctzll(mb); vm = f == 63 ? ~0ull : ((1ull << (f + 1)) - 1); broke = true; }
-				if (ovl && ((vm >> lane) & 1)) { ch_chain_t &cj = CH[aj.chain]; if (cj.first < 0) cj.first = i; }
-				if (mo & vm) large_ovlp = true;
+			for (int b = 0; b < nk && !broke; b += 256) {
+				ks_t aj[4]; bool ovl[4]; unsigned long long mb[4], mo[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { const int k = b + 64 * u + lane; aj[u] = ks[k < nk ? k : nk - 1]; }   // four loads in flight
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const int k = b + 64 * u + lane;
+					bool brk = false;
+					test(aj[u], ovl[u], brk);
+					ovl[u] = ovl[u] && k < nk; brk = brk && k < nk;
+					mb[u] = __ballot(brk); mo[u] = __ballot(ovl[u]);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					if (broke) break;
+					unsigned long long vm = ~0ull;
+					if (mb[u]) { const int f = (int)__builtin_ctzll(mb[u]); vm = f == 63 ? ~0ull : ((1ull << (f + 1)) - 1); broke = true; }
+					if (ovl[u] && ((vm >> lane) & 1)) { ch_chain_t &cj = CH[aj[u].chain]; if (cj.first < 0) cj.first = i; }
+					if (mo[u] & vm) large_ovlp = true;
+				}
 			}
 		} else
 #endif
@@ -497,7 +520,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 		if (rmax0 < l_pac && l_pac < rmax1) { if (s0.rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
 		{   // bns_fetch_seq clips the window to the contig of the first seed (src/bntseq.c:531-556)
 			int is_rev;
-			const int rid = pos2rid(x, depos(x, s0.rbeg, &is_rev));
+			const int rid = pos2rid<COOP>(x, depos(x, s0.rbeg, &is_rev));
 			int64_t far_beg = x.n_contigs > 1 ? x.ctg_off[rid] : 0, far_end = far_beg + (x.n_contigs > 1 ? x.ctg_len[rid] : l_pac);
 			if (is_rev) { const int64_t tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
 			rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
@@ -509,8 +532,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 		sort_distinct<COOP>(srt, (uint64_t *)(opos), cn);       // opos is free by now (8 bytes per entry)
 		for (int k = cn - 1; k >= 0; --k) {
 			const ch_seed_t s = S[cidx[(uint32_t)srt[k]]];
-			const int hit = first_true<COOP>(0, n_regs, [&](int i) {              // extension (estimated) made before? :1235-1256
-				const ch_est_t p = E[i];
+			auto covered = [&](const ch_est_t &p) {                                 // extension (estimated) made before? :1235-1256
 				if (s.rbeg < p.rb_est || s.rbeg + s.len > p.re_est || s.qbeg < p.qb_est || s.qbeg + s.len > p.qe_est) return false;
 				if (s.len - p.seedlen0 > .1 * l_query) return false;
 				int qd = s.qbeg - p.qb_est; int64_t rd = s.rbeg - p.rb_est;
@@ -521,7 +543,24 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 				max_gap = cal_max_gap(o, qd < rd ? qd : (int)rd);
 				w = max_gap < o.w ? max_gap : o.w;
 				return qd - rd < w && rd - qd < w;
-			});
+			};
+			int hit = n_regs;
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (COOP) {
+				// 256 regions per round; the four entries of a lane are loaded before any is tested, so the loads overlap
+				const int lane = ch_lane();
+				for (int b = 0; b < n_regs && hit == n_regs; b += 256) {
+					ch_est_t p4[4]; unsigned long long m[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) { const int i = b + 64 * u + lane; p4[u] = E[i < n_regs ? i : n_regs - 1]; }
+#pragma unroll
+					for (int u = 0; u < 4; ++u) { const int i = b + 64 * u + lane; m[u] = __ballot(i < n_regs && covered(p4[u])); }
+#pragma unroll
+					for (int u = 3; u >= 0; --u) if (m[u]) hit = b + 64 * u + (int)__builtin_ctzll(m[u]);
+				}
+			} else
+#endif
+			for (int i = 0; i < n_regs; ++i) if (covered(E[i])) { hit = i; break; }
 			if (hit < n_regs) {                                                   // :1258-1276
 				const int j = first_true<COOP>(k + 1, cn, [&](int j) {
 					if (srt[j] == 0) return false;

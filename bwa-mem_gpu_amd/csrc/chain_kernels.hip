@@ -25,16 +25,40 @@ struct chain_args_t {
 	ch_ctx_t x;
 	uint32_t n_reads, heavy_thresh;
 	uint32_t *heavy_list; uint32_t *heavy_n;
+	uint32_t *need;               // [n_reads] seed occurrences the chaining core will sample
 };
 
-// reads with more than heavy_thresh seeds go to the wave kernel: three lists by size so that it starts the longest first
+// What a read costs the chaining core is the number of seed occurrences mem_chain SAMPLES (at most max_occ per SMEM,
+// src/bwamem.c:430-436), not the number located: on an hg38-like genome 0.25 % of the reads carry SMEMs with thousands of
+// occurrences (90 % of all located seeds) of which 500 each are used.  need[r] = that number; it sizes the read's scratch.
+// Reads that need more than heavy_thresh entries go to the wave kernels, one list per LDS size class.
+#define CH_N_CLASSES 5
+__device__ __forceinline__ int ch_class_of(uint32_t need) { return need <= 128u ? 0 : need <= 512u ? 1 : need <= 1250u ? 2 : need <= 1860u ? 3 : 4; }
+// LDS entries per class; class 3 keeps only the arrays of the sequential phases in LDS (seeds, chains, the sorted chain index,
+// the sort keys: 84 bytes per entry) and the rest in the read's slice of the global scratch; class 4 (a read that samples
+// more than 1860 occurrences: four SMEMs of 465+ hits each) works in global memory altogether
+static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {128u, 512u, 1250u, 1860u, 0u};
+static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {4096u, 1024u, 512u, 256u, 256u};
+
 __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 {
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
 	if (r >= A.n_reads) return;
 	const uint32_t n = A.x.n_ref[r];
-	if (n > A.heavy_thresh) {
-		const int cls = n > 192 ? 0 : n > 80 ? 1 : 2;
+	uint32_t need = n;
+	if (n > (uint32_t)A.x.o.max_occ) {          // only then can a group exceed max_occ
+		const uint32_t *sc = A.x.score + A.x.prefix[r];
+		need = 0;
+		for (uint32_t i = 0; i < n;) {
+			const uint32_t cnt = sc[i];
+			if (cnt == 0) break;
+			need += cnt < (uint32_t)A.x.o.max_occ ? cnt : (uint32_t)A.x.o.max_occ;
+			i += cnt;
+		}
+	}
+	A.need[r] = need;
+	if (need > A.heavy_thresh) {
+		const int cls = ch_class_of(need);
 		A.heavy_list[(size_t)cls * A.n_reads + atomicAdd(A.heavy_n + cls, 1u)] = r;
 	}
 }
@@ -42,34 +66,53 @@ __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 __global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A)
 {
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-	if (r >= A.n_reads || A.x.n_ref[r] > A.heavy_thresh) return;
+	if (r >= A.n_reads || A.need[r] > A.heavy_thresh) return;
 	chain_core::chain_read<false>(A.x, r, chain_core::global_scratch(A.x, r));
 }
 
-// one wave per heavy read; the lists were filled by chain_classify_kernel.  Runs on a side stream beside chain_lane_kernel.  The read's scratch
-// lives in LDS when it fits lds_cap entries (CH_LDS_BYTES_PER_ENTRY each): the wave form is a chain of dependent
-// accesses, so their latency is its run time.
+// one wave per heavy read of one size class (list filled by chain_classify_kernel), on a side stream beside chain_lane_kernel.
+// The read's scratch lives in LDS (lds_cap entries of CH_LDS_BYTES_PER_ENTRY bytes each; lds_cap == 0: the read's slice of the
+// global scratch): the wave form is a chain of dependent accesses, so their latency is its run time -- and the LDS a block asks
+// for decides how many of these waves a CU runs side by side (128 entries: 10, 512: 2, 1250: 1), which is why the classes exist.
 #define CH_LDS_BYTES_PER_ENTRY (8 + 8 + sizeof(ch_est_t) + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4 + 4 + 4)
-__global__ void __launch_bounds__(64) chain_wave_kernel(chain_args_t A, uint32_t lds_cap)
+#define CH_LDS_BYTES_PER_ENTRY_HYBRID (8 + 8 + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4)
+#define CH_LDS_CONTIGS 256         // contig tables up to this size are copied into LDS (3 KB)
+template <bool CTG_LDS>
+__global__ void __launch_bounds__(64) chain_wave_kernel(chain_args_t A, uint32_t cls, uint32_t lds_cap, int hybrid)
 {
 	extern __shared__ __align__(16) uint8_t ch_lds[];
-	const uint32_t n0 = A.heavy_n[0], n1 = A.heavy_n[1], n2 = A.heavy_n[2], nh = n0 + n1 + n2;
+	const uint32_t nh = A.heavy_n[cls];
+	const uint32_t *list = A.heavy_list + (size_t)cls * A.n_reads;
 	ch_scr_t L;
 	{
 		uint8_t *p = ch_lds;
 		L.opos = (int64_t *)p; p += 8 * (size_t)lds_cap;
 		L.srt = (uint64_t *)p; p += 8 * (size_t)lds_cap;
-		L.E = (ch_est_t *)p; p += sizeof(ch_est_t) * (size_t)lds_cap;
 		L.CH = (ch_chain_t *)p; p += sizeof(ch_chain_t) * (size_t)lds_cap;
 		L.S = (ch_seed_t *)p; p += sizeof(ch_seed_t) * (size_t)lds_cap;
 		L.order = (uint32_t *)p; p += 4 * (size_t)lds_cap;
+		L.E = (ch_est_t *)p; p += sizeof(ch_est_t) * (size_t)lds_cap;           // (not there in the hybrid form: replaced below)
 		L.klist = (uint32_t *)p; p += 4 * (size_t)lds_cap;
 		L.cidx = (uint32_t *)p;
 	}
+	// the contig table is looked up twice per seed occurrence (bns_intv2rid): a copy in LDS instead of dependent global loads
+	__shared__ int64_t ctg_off_l[CH_LDS_CONTIGS];
+	__shared__ int32_t ctg_len_l[CH_LDS_CONTIGS];
+	if (CTG_LDS) {                      // (a template parameter: the table pointer must have one address space per instantiation)
+		for (int c = (int)threadIdx.x; c < A.x.n_contigs; c += 64) { ctg_off_l[c] = A.x.ctg_off[c]; ctg_len_l[c] = A.x.ctg_len[c]; }
+		A.x.ctg_off = ctg_off_l; A.x.ctg_len = ctg_len_l;
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0);
+	}
 	for (uint32_t i = blockIdx.x; i < nh; i += gridDim.x) {
-		const uint32_t r = i < n0 ? A.heavy_list[i] : i < n0 + n1 ? A.heavy_list[(size_t)A.n_reads + (i - n0)] : A.heavy_list[2 * (size_t)A.n_reads + (i - n0 - n1)];
-		if (A.x.n_ref[r] <= lds_cap) chain_core::chain_read<true>(A.x, r, L);
-		else chain_core::chain_read<true>(A.x, r, chain_core::global_scratch(A.x, r));
+		const uint32_t r = list[i];
+		// three call sites so that every pointer of a call has ONE address space the compiler can see (a pointer that may be
+		// LDS or global becomes a flat access, several times the latency of ds_read on the LDS side)
+		if (lds_cap && !hybrid) chain_core::chain_read<true>(A.x, r, L);
+		else if (lds_cap) {
+			const ch_scr_t G = chain_core::global_scratch(A.x, r);
+			ch_scr_t H = L; H.E = G.E; H.klist = G.klist; H.cidx = G.cidx;
+			chain_core::chain_read<true>(A.x, r, H);
+		} else chain_core::chain_read<true>(A.x, r, chain_core::global_scratch(A.x, r));
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 	}
 }
@@ -172,8 +215,8 @@ struct bmh_chain_ws {
 	// per-seed scratch
 	ch_seed_t *seeds; ch_chain_t *chains; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx; ch_reg_t *regs; ch_est_t *est;
 	// per read
-	uint32_t *regs_per_read, *jobs_per_read, *reg_off, *job_off, *heavy_list; float *frac_rep;
-	uint32_t *counters;            // [0..2] heavy_n per size class  [3] err  [4..15] profile stamps
+	uint32_t *regs_per_read, *jobs_per_read, *reg_off, *job_off, *heavy_list, *need; float *frac_rep;
+	uint32_t *counters;            // [0..4] heavy_n per size class  [5] err  [6..15] profile stamps
 	// contigs
 	int n_contigs; int64_t *ctg_off; int32_t *ctg_len;
 	// outputs, grown on demand
@@ -184,7 +227,9 @@ struct bmh_chain_ws {
 	void *scan_tmp; size_t scan_tmp_bytes;
 	uint64_t n_regs, n_jobs;
 	uint32_t *h_pin;               // pinned host words for the small D2H copies
-	hipStream_t side; hipEvent_t ev_fork, ev_join;   // the wave kernel runs beside the lane kernel
+	hipStream_t side; hipEvent_t ev_fork, ev_join;   // the wave kernels run beside the lane kernel
+	hipStream_t cls_stream[8]; hipEvent_t cls_done[8]; // ... and beside each other, one stream per size class
+	hipEvent_t ev_t[8]; float ms[8]; uint32_t heavy_per_class[CH_N_CLASSES];                 // kernel times of the last batch (bmh_chain_last_timing)
 	int materialize;               // 1: bmh_chain_batch also writes the base arrays q/t (+ qoff/toff)
 	const uint8_t *last_reads, *last_pac; uint64_t last_l_pac;   // sources of the last batch, for bmh_chain_extend
 };
@@ -193,13 +238,16 @@ extern "C" void bmh_chain_ws_free(bmh_chain_ws_t *w)
 {
 	if (!w) return;
 	void *ps[] = {w->seeds, w->chains, w->order, w->opos, w->klist, w->srt, w->cidx, w->regs, w->est, w->regs_per_read, w->jobs_per_read, w->reg_off,
-	              w->job_off, w->heavy_list, w->frac_rep, w->counters, w->ctg_off, w->ctg_len, w->outregs, w->qlen, w->tlen, w->h0, w->job_read, w->job_reg,
+	              w->job_off, w->heavy_list, w->need, w->frac_rep, w->counters, w->ctg_off, w->ctg_len, w->outregs, w->qlen, w->tlen, w->h0, w->job_read, w->job_reg,
 	              w->job_side, w->jq_src, w->qoff, w->toff, w->jt0, w->qoff64, w->toff64, w->q, w->t, w->scan_tmp};
 	for (void *p : ps) if (p) (void)hipFree(p);
 	if (w->h_pin) (void)hipHostFree(w->h_pin);
 	if (w->side) (void)hipStreamDestroy(w->side);
 	if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
 	if (w->ev_join) (void)hipEventDestroy(w->ev_join);
+	for (hipEvent_t e : w->ev_t) if (e) (void)hipEventDestroy(e);
+	for (hipStream_t q : w->cls_stream) if (q) (void)hipStreamDestroy(q);
+	for (hipEvent_t e : w->cls_done) if (e) (void)hipEventDestroy(e);
 	free(w);
 }
 
@@ -214,8 +262,8 @@ extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_
 	A(w->seeds, sizeof(ch_seed_t) * S); A(w->chains, sizeof(ch_chain_t) * S); A(w->order, 4 * S); A(w->opos, 8 * S); A(w->klist, 4 * S);
 	A(w->srt, 8 * S); A(w->cidx, 4 * S); A(w->regs, sizeof(ch_reg_t) * S); A(w->est, sizeof(ch_est_t) * S);
 	const size_t Rn = (size_t)max_reads + 1;
-	A(w->regs_per_read, 4 * Rn); A(w->jobs_per_read, 4 * Rn); A(w->reg_off, 4 * Rn); A(w->job_off, 4 * Rn); A(w->heavy_list, 3 * 4 * Rn); A(w->frac_rep, 4 * Rn);
-	A(w->counters, 64);
+	A(w->regs_per_read, 4 * Rn); A(w->jobs_per_read, 4 * Rn); A(w->reg_off, 4 * Rn); A(w->job_off, 4 * Rn); A(w->heavy_list, CH_N_CLASSES * 4 * Rn); A(w->need, 4 * Rn); A(w->frac_rep, 4 * Rn);
+	A(w->counters, 128);
 	size_t t1 = 0, t2 = 0;
 	rocprim::exclusive_scan(nullptr, t1, w->regs_per_read, w->reg_off, 0u, Rn, rocprim::plus<uint32_t>(), 0);
 	rocprim::exclusive_scan(nullptr, t2, (uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0, 2 * S + 1, rocprim::plus<uint64_t>(), 0);
@@ -225,10 +273,19 @@ extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_
 	ok = ok && hipHostMalloc((void **)&w->h_pin, 64) == hipSuccess;
 	ok = ok && hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) == hipSuccess;
+	for (hipEvent_t &e : w->ev_t) ok = ok && hipEventCreate(&e) == hipSuccess;
+	for (int c = 0; c < CH_N_CLASSES; ++c)
+		ok = ok && hipStreamCreateWithFlags(&w->cls_stream[c], hipStreamNonBlocking) == hipSuccess && hipEventCreate(&w->cls_done[c]) == hipSuccess;
 	if (!ok) { bmh_set_error("bmh_chain_ws_create: hipMalloc failed (%s)", hipGetErrorString(hipGetLastError())); bmh_chain_ws_free(w); return nullptr; }
 	w->n_contigs = 1;
 	w->materialize = 1;
 	return w;
+}
+
+extern "C" void bmh_chain_last_timing(const bmh_chain_ws_t *w, float ms[8])
+{
+	for (int i = 0; i < 4; ++i) ms[i] = w->ms[i];
+	for (int i = 0; i < 4; ++i) ms[4 + i] = (float)(i < 3 ? w->heavy_per_class[i] : w->heavy_per_class[3] + w->heavy_per_class[4]);
 }
 
 extern "C" int bmh_chain_set_contigs(bmh_chain_ws_t *w, int n_contigs, const int64_t *offset, const int32_t *len)
@@ -282,31 +339,44 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	A.x.rbeg = seeds->d_rbeg; A.x.qbeg = seeds->d_qbeg; A.x.score = seeds->d_score; A.x.n_ref = seeds->d_n_ref_pos; A.x.prefix = seeds->d_prefix;
 	A.x.read_lens = d_lens;
 	A.x.g.S = w->seeds; A.x.g.CH = w->chains; A.x.g.order = w->order; A.x.g.opos = w->opos; A.x.g.klist = w->klist; A.x.g.srt = w->srt; A.x.g.cidx = w->cidx;
-	A.x.g.E = w->est; A.x.regs = w->regs; A.x.regs_per_read = w->regs_per_read; A.x.jobs_per_read = w->jobs_per_read; A.x.frac_rep = w->frac_rep; A.x.err = (int *)(w->counters + 3);
+	A.x.g.E = w->est; A.x.regs = w->regs; A.x.regs_per_read = w->regs_per_read; A.x.jobs_per_read = w->jobs_per_read; A.x.frac_rep = w->frac_rep; A.x.err = (int *)(w->counters + 5);
 	A.n_reads = n_reads;
 	const char *ht = getenv("BMH_CHAIN_HEAVY");
-	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : 32u;
-	A.heavy_list = w->heavy_list; A.heavy_n = w->counters;
+	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : 16u;
+	A.heavy_list = w->heavy_list; A.heavy_n = w->counters; A.need = w->need;
 #ifdef CH_PROFILE
 	{
 		const char *pr = getenv("BMH_CHAIN_PROF_READ");
-		if (pr) { A.x.prof = (long long *)(w->counters + 4); A.x.prof_read = (uint32_t)atoi(pr); }
+		if (pr) { A.x.prof = (long long *)(w->counters + 6); A.x.prof_read = (uint32_t)atoi(pr); }
 	}
 #endif
-	HIPCK(hipMemsetAsync(w->counters, 0, 64, st));
+	HIPCK(hipMemsetAsync(w->counters, 0, 128, st));
 	HIPCK(hipMemsetAsync(w->regs_per_read + n_reads, 0, 4, st));
 	HIPCK(hipMemsetAsync(w->jobs_per_read + n_reads, 0, 4, st));
+	HIPCK(hipEventRecord(w->ev_t[0], st));
 	chain_classify_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(A);
+	HIPCK(hipEventRecord(w->ev_t[1], st));
 	HIPCK(hipEventRecord(w->ev_fork, st));
 	HIPCK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
 	chain_lane_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(A);
+	HIPCK(hipEventRecord(w->ev_t[2], st));
 	{
-		const char *lk = getenv("BMH_CHAIN_LDS_ENTRIES");
-		const uint32_t lds_cap = lk ? (uint32_t)atoi(lk) : 1024u;
-		const size_t lds_bytes = (size_t)lds_cap * CH_LDS_BYTES_PER_ENTRY;
-		if (lds_bytes > 160 * 1024 - 512) { bmh_set_error("bmh_chain_batch: BMH_CHAIN_LDS_ENTRIES too large"); return BMH_EINVAL; }
-		HIPCK(hipFuncSetAttribute((const void *)chain_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-		chain_wave_kernel<<<2048, 64, lds_bytes, w->side>>>(A, lds_cap);
+		// every size class on its own stream: the classes differ in LDS per block, so they fill different gaps of the CUs, and the
+		// largest reads (longest chains of dependent steps) start at once instead of behind the other classes
+		HIPCK(hipEventRecord(w->ev_t[3], w->side));
+		const bool ctg_lds = w->n_contigs > 1 && w->n_contigs <= CH_LDS_CONTIGS;
+		HIPCK(hipFuncSetAttribute(ctg_lds ? (const void *)chain_wave_kernel<true> : (const void *)chain_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[3] * CH_LDS_BYTES_PER_ENTRY_HYBRID)));
+		for (int cls = CH_N_CLASSES - 1; cls >= 0; --cls) {
+			const uint32_t lds_cap = CH_CLASS_CAP[cls];
+			const int hybrid = cls == 3;
+			const size_t lds_bytes = (size_t)lds_cap * (hybrid ? CH_LDS_BYTES_PER_ENTRY_HYBRID : CH_LDS_BYTES_PER_ENTRY);
+			HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->ev_fork, 0));
+			if (ctg_lds) chain_wave_kernel<true><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
+			else chain_wave_kernel<false><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
+			HIPCK(hipEventRecord(w->cls_done[cls], w->cls_stream[cls]));
+			HIPCK(hipStreamWaitEvent(w->side, w->cls_done[cls], 0));
+		}
+		HIPCK(hipEventRecord(w->ev_t[4], w->side));
 		HIPCK(hipEventRecord(w->ev_join, w->side));
 		HIPCK(hipStreamWaitEvent(st, w->ev_join, 0));
 	}
@@ -316,22 +386,34 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->jobs_per_read, w->job_off, 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
 	HIPCK(hipMemcpyAsync(w->h_pin + 0, w->reg_off + n_reads, 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipMemcpyAsync(w->h_pin + 1, w->job_off + n_reads, 4, hipMemcpyDeviceToHost, st));
-	HIPCK(hipMemcpyAsync(w->h_pin + 2, w->counters, 16, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(w->h_pin + 2, w->counters, 24, hipMemcpyDeviceToHost, st));
+	HIPCK(hipEventRecord(w->ev_t[5], st));
 	HIPCK(hipStreamSynchronize(st));
 	HIPCK(hipGetLastError());
-	if (w->h_pin[5] == 1) { bmh_set_error("bmh_chain_batch: a read is longer than %d bp (mem_flt_chained_seeds is not restated)", CH_MAX_READ_LEN); return BMH_EINVAL; }
-	if (w->h_pin[5] != 0) { bmh_set_error("bmh_chain_batch: internal error %u in the chaining kernel", w->h_pin[5]); return BMH_ENODEV; }
+	(void)hipEventElapsedTime(&w->ms[0], w->ev_t[0], w->ev_t[1]); (void)hipEventElapsedTime(&w->ms[1], w->ev_t[1], w->ev_t[2]);
+	(void)hipEventElapsedTime(&w->ms[2], w->ev_t[3], w->ev_t[4]); (void)hipEventElapsedTime(&w->ms[3], w->ev_t[0], w->ev_t[5]);
+	if (getenv("BMH_CHAIN_STATS")) {
+		fprintf(stderr, "[chain] lane kernel %.3f ms; wave kernels %.3f ms beside it:", w->ms[1], w->ms[2]);
+		for (int c = 0; c < CH_N_CLASSES; ++c) {
+			float t = 0; (void)hipEventElapsedTime(&t, w->ev_t[3], w->cls_done[c]);
+			fprintf(stderr, " class %d (%u entries) %u reads done at %.3f ms;", c, CH_CLASS_CAP[c], w->h_pin[2 + c], t);
+		}
+		fprintf(stderr, "\n");
+	}
+	if (w->h_pin[7] == 1) { bmh_set_error("bmh_chain_batch: a read is longer than %d bp (mem_flt_chained_seeds is not restated)", CH_MAX_READ_LEN); return BMH_EINVAL; }
+	if (w->h_pin[7] != 0) { bmh_set_error("bmh_chain_batch: internal error %u in the chaining kernel", w->h_pin[7]); return BMH_ENODEV; }
 #ifdef CH_PROFILE
 	if (A.x.prof) {
 		long long pf[6];
-		HIPCK(hipMemcpy(pf, w->counters + 4, sizeof(pf), hipMemcpyDeviceToHost));
+		HIPCK(hipMemcpy(pf, w->counters + 6, sizeof(pf), hipMemcpyDeviceToHost));
 		fprintf(stderr, "chain phases of read %u (x10ns ticks): chains %lld  weights %lld  sort %lld  kept %lld  chain2aln %lld\n", A.x.prof_read,
 		        pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4]);
 	}
 #endif
 	const uint64_t n_regs = w->h_pin[0], n_jobs = w->h_pin[1];
 	w->n_regs = n_regs; w->n_jobs = n_jobs;
-	out->n_regs = n_regs; out->n_jobs = n_jobs; out->n_heavy_reads = (uint64_t)w->h_pin[2] + w->h_pin[3] + w->h_pin[4];
+	out->n_regs = n_regs; out->n_jobs = n_jobs; out->n_heavy_reads = (uint64_t)w->h_pin[2] + w->h_pin[3] + w->h_pin[4] + w->h_pin[5] + w->h_pin[6];
+	for (int c = 0; c < CH_N_CLASSES; ++c) w->heavy_per_class[c] = w->h_pin[2 + c];
 	out->d_regs_per_read = w->regs_per_read; out->d_frac_rep = w->frac_rep;
 	if (n_regs > w->cap_regs) {
 		const uint64_t c = n_regs + n_regs / 4 + 1024;

@@ -276,13 +276,18 @@ int bmh_chain_set_contigs(bmh_chain_ws_t *ws, int n_contigs, const int64_t *cont
 
 typedef struct {
 	uint64_t n_jobs, n_regs, q_bytes, t_bytes;
-	uint64_t n_heavy_reads;          /* reads chained by a whole wave (more than BMH_CHAIN_HEAVY=32 seeds) */
+	uint64_t n_heavy_reads;          /* reads chained by a whole wave (more than BMH_CHAIN_HEAVY=16 sampled seed occurrences) */
 	const uint8_t *d_q; const uint32_t *d_qoff, *d_qlen;          /* the bmh_extend_batch inputs */
 	const uint8_t *d_t; const uint32_t *d_toff, *d_tlen, *d_h0;
 	const uint32_t *d_job_read, *d_job_reg, *d_job_side;           /* read / region / side (0 left, 1 right) per job */
 	const uint32_t *d_regs_per_read;                               /* [n_reads] */
 	const float *d_frac_rep;                                       /* [n_reads] frac_rep of the read's chains (for bmh_finalize_regs) */
 } bmh_dev_jobs_t;
+
+/* kernel times of the last bmh_chain_batch in ms (HIP events): [0] classify [1] lane kernel (reads that sample at most 16 seed
+ * occurrences) [2] wave kernels (the others, on a side stream beside it) [3] the whole stage up to the counts; [4..7] reads per
+ * wave-kernel size class (scratch of 128 / 512 / 1250 entries in LDS; larger ones: partly or wholly in global memory) */
+void bmh_chain_last_timing(const bmh_chain_ws_t *ws, float ms[8]);
 
 /* on (default): bmh_chain_batch also materialises the base arrays d_q/d_t/d_qoff/d_toff for bmh_extend_batch;
  * off: it stops at the job descriptors (those four pointers come back NULL, q_bytes = t_bytes = 0) and the batch is

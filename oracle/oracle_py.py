@@ -164,6 +164,9 @@ class Ref:
         L.ref_bwt_from_symbols.restype = C.c_void_p
         L.ref_bwt_from_symbols.argtypes = [_u8p, C.c_uint64, C.c_uint64, _u64p, C.c_int]
         L.ref_bwt_free.argtypes = [C.c_void_p]
+        if hasattr(L, "ref_bwt_from_gpu_layout"):
+            L.ref_bwt_from_gpu_layout.restype = C.c_void_p
+            L.ref_bwt_from_gpu_layout.argtypes = [_u32p, C.c_uint64, C.c_uint64, _u64p, C.c_int, _u32p, _u32p]
         L.ref_occ.restype = C.c_uint64
         L.ref_occ.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
         L.ref_sa.restype = C.c_uint64
@@ -195,6 +198,16 @@ class Ref:
         sym = bwt_symbols(idx)
         L2 = np.ascontiguousarray(idx.L2, dtype=np.uint64)
         return self.lib.ref_bwt_from_symbols(_ptr(sym, _u8p), idx.seq_len, idx.primary, _ptr(L2, _u64p), idx.sa_intv)
+
+    def bwt_from_index_fast(self, idx):
+        """Vanilla-layout bwt_t by re-interleaving the GPU-layout words and copying the suffix-array samples (hg38-scale texts)."""
+        w = np.ascontiguousarray(idx.bwt_words, dtype=np.uint32)
+        nblk = (idx.seq_len + 63) // 64
+        if w.shape[0] < (nblk + 1) * 8:                     # file layout: a short last block; pad to whole blocks
+            w = np.concatenate([w[: w.shape[0] - 4], np.zeros((nblk + 1) * 8 - (w.shape[0] - 4), np.uint32)])
+        L2 = np.ascontiguousarray(idx.L2, dtype=np.uint64)
+        sa = np.ascontiguousarray(idx.sa, dtype=np.uint32); bits = np.ascontiguousarray(idx.sa_bits, dtype=np.uint32)
+        return self.lib.ref_bwt_from_gpu_layout(_ptr(w, _u32p), idx.seq_len, idx.primary, _ptr(L2, _u64p), idx.sa_intv, _ptr(sa, _u32p), _ptr(bits, _u32p))
 
     def seed_reads(self, bwt, reads, offs, lens, min_seed_len=19) -> dict:
         reads = np.ascontiguousarray(reads, dtype=np.uint8)

@@ -47,6 +47,46 @@ bwt_t *ref_bwt_from_symbols(const uint8_t *sym, uint64_t seq_len, uint64_t prima
 	return b;
 }
 
+/* The same vanilla-layout bwt_t straight from the GPU-layout words, for hg38-scale texts where the symbol string (6.2 GB) and
+ * the reference's own sequential bwt_cal_sa (6.2e9 dependent LF steps) are too slow to be setup of a benchmark: the 16-symbol
+ * words are identical in both layouts, the 32-bit Occ quadruple of every second 64-symbol block is widened to 64 bits
+ * (src/bwt.h:33-36,91-92), and the suffix-array samples are copied from the 32+1-bit samples of the GPU files (same rows:
+ * multiples of sa_intv, sa[0] = -1; src/bwt.c:105-115).  What runs on it afterwards is the reference's compiled code. */
+bwt_t *ref_bwt_from_gpu_layout(const uint32_t *gw, uint64_t seq_len, uint64_t primary, const uint64_t L2[5], int sa_intv,
+                               const uint32_t *sa32, const uint32_t *sa_bits)
+{
+	bwt_t *b = (bwt_t *)calloc(1, sizeof(bwt_t));
+	uint64_t n_occ = (seq_len + OCC_INTERVAL - 1) / OCC_INTERVAL + 1;
+	uint64_t raw_words = (seq_len + 15) >> 4, nb128 = (seq_len + 127) >> 7, n64 = (seq_len + 63) >> 6, i;
+	int c;
+	b->primary = primary;
+	memcpy(b->L2, L2, 5 * sizeof(uint64_t));
+	b->seq_len = seq_len;
+	b->bwt_size = raw_words + n_occ * sizeof(bwtint_t);
+	b->bwt = (uint32_t *)calloc((nb128 + 1) * 16, 4);
+	for (i = 0; i < nb128; ++i) {
+		const uint32_t *g0 = gw + (2 * i) * 8;
+		uint32_t *o = b->bwt + i * 16;
+		uint64_t occ[4];
+		for (c = 0; c < 4; ++c) occ[c] = g0[c];
+		memcpy(o, occ, 32);
+		memcpy(o + 8, g0 + 4, 16);
+		if (2 * i + 1 < n64) memcpy(o + 12, g0 + 12, 16);
+	}
+	{	/* trailing Occ quadruple = totals */
+		uint64_t tot[4];
+		for (c = 0; c < 4; ++c) tot[c] = L2[c + 1] - L2[c];
+		memcpy(b->bwt + nb128 * 16, tot, 32);
+	}
+	bwt_gen_cnt_table(b);
+	b->sa_intv = sa_intv;
+	b->n_sa = (seq_len + sa_intv) / sa_intv;
+	b->sa = (bwtint_t *)malloc(b->n_sa * sizeof(bwtint_t));
+	b->sa[0] = (bwtint_t)-1;
+	for (i = 1; i < b->n_sa; ++i) b->sa[i] = (uint64_t)sa32[i] | ((uint64_t)((sa_bits[i >> 5] >> (i & 31)) & 1u) << 32);
+	return b;
+}
+
 void ref_bwt_free(bwt_t *b) { if (b) { free(b->sa); free(b->bwt); free(b); } }
 
 uint64_t ref_occ(const bwt_t *b, uint64_t k, int c) { return bwt_occ(b, k, c); }

@@ -84,6 +84,13 @@ def test_oracle_vs_ref_fresh(oracle, ref):
     flat, offs, lens = common.ragged_reads(rows)
     for k in (19, 10):
         common.assert_seeds_equal(oracle.seed_reads(oracle.fmd(idx), flat, offs, lens, k), ref.seed_reads(b, flat, offs, lens, k))
+    # the re-interleaved form of the same index (what bench.py's cpu_baseline hands the reference's code at hg38 scale)
+    for n_g in (120_000, 120_037):
+        g2, idx2 = common.genome_and_index(n_g, seed=77)
+        b2 = ref.bwt_from_index_fast(idx2)
+        r2, _ = synth.make_reads(g2, 300, 150, seed=5)
+        f2, o2, l2 = common.flat_reads(r2)
+        common.assert_seeds_equal(oracle.seed_reads(oracle.fmd(idx2), f2, o2, l2, 19), ref.seed_reads(b2, f2, o2, l2, 19))
     jobs = common.make_ext_jobs(1500, np.random.default_rng(79))
     for zd in (0, 30):
         p = oracle_py.default_params(zdrop=zd)

@@ -213,6 +213,8 @@ class Aligner:
         mcw = self.copt.min_chain_weight
         if lmax >= self.copt.min_seed_len and not ((1.1 * mcw if mcw else 5.5 * np.log(max(lmax, 2.0))) > 0.05 * lmax):
             raise NotImplementedError(f"reads of {int(lmax)} bp with -W {mcw} go through the reference's mem_flt_chained_seeds, which is not restated")
+        if int(lens.sum()) >= 1 << 31:
+            raise ValueError("a batch holds 2^31 bases or more: offsets inside a batch are 32-bit (use a smaller batch_reads)")
         codes = _NT4[ascii_]
         r = torch.from_numpy(ascii_.copy()).to(dev)
         o = torch.from_numpy(offs.astype(np.int64)).to(torch.int32).to(dev)

@@ -23,12 +23,12 @@ def lib_path() -> str:
 EXPORTED_SYMBOLS = [
     "bmh_last_error", "bmh_device_count", "bmh_set_device", "bmh_index_upload", "bmh_index_from_device",
     "bmh_index_free", "bmh_index_densify_sa", "bmh_index_build", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
-    "bmh_extend_batch", "bmh_extend_last_ms", "bmh_calib_gather",
+    "bmh_extend_batch", "bmh_extend_last_ms", "bmh_extend_last_unsupported", "bmh_calib_gather",
     "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
     "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
     "bmh_chain_opt_default", "bmh_chain_last_timing", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
     "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_materialize", "bmh_chain_batch",
-    "bmh_chain_extend", "bmh_chain_merge", "bmh_cigar_batch",
+    "bmh_chain_extend", "bmh_chain_merge", "bmh_chain_extend_merge", "bmh_chain_extend_merge_timing", "bmh_cigar_batch",
     "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
     "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
 ]
@@ -136,6 +136,7 @@ def load_library() -> C.CDLL:
     L.bmh_extend_batch.restype = C.c_int
     L.bmh_extend_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32, C.POINTER(ExtParams), C.c_void_p, C.c_void_p, C.c_void_p]
     L.bmh_extend_last_ms.restype = C.c_float
+    L.bmh_extend_last_unsupported.restype = C.c_int64
     L.bmh_calib_gather.restype = C.c_int
     L.bmh_calib_gather.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
     L.bmh_chain_opt_default.argtypes = [C.POINTER(ChainOpt)]
@@ -181,6 +182,12 @@ def load_library() -> C.CDLL:
     L.bmh_chain_set_materialize.argtypes = [C.c_void_p, C.c_int]
     L.bmh_chain_extend.restype = C.c_int
     L.bmh_chain_extend.argtypes = [C.c_void_p, C.POINTER(ExtParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bmh_chain_extend_merge.restype = C.c_int
+    L.bmh_chain_extend_merge.argtypes = [C.c_void_p, C.POINTER(ChainOpt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                         C.POINTER(SeedsT), C.POINTER(ExtParams), C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(DevJobsT)]
+    L.bmh_chain_extend_merge_timing.restype = C.c_int
+    L.bmh_chain_extend_merge_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), _u64p]
+    L.bmh_chain_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.bmh_chain_merge.restype = C.c_int
     L.bmh_chain_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bmh_cigar_batch.restype = C.c_int
@@ -324,6 +331,29 @@ class ChainWorkspace:
         rc = L.bmh_chain_extend(self.handle, C.byref(p), out3_t.data_ptr(), raw_t.data_ptr() if raw_t is not None else None, stream)
         if rc != 0:
             raise RuntimeError(f"bmh_chain_extend rc={rc}: " + _err(L))
+
+    def extend_merge(self, index: Index, reads_t, offs_t, lens_t, seeds: SeedsT, regs_t, params: "ExtParams | None" = None, stream: int = 0) -> DevJobsT:
+        """bmh_chain_extend_merge: chaining, extension and region merge of one batch in one call (regs_t int32 [cap, 8], read order)"""
+        L = load_library()
+        out = DevJobsT()
+        p = params or ExtParams.default()
+        rc = L.bmh_chain_extend_merge(self.handle, C.byref(self.opt), index.handle, reads_t.data_ptr(), offs_t.data_ptr(), lens_t.data_ptr(),
+                                      lens_t.numel(), C.byref(seeds), C.byref(p), regs_t.data_ptr(), int(regs_t.shape[0]), stream, C.byref(out))
+        if rc != 0:
+            raise RuntimeError(f"bmh_chain_extend_merge rc={rc}: " + _err(L))
+        self.last_jobs = out
+        return out
+
+    def extend_merge_timing(self):
+        L = load_library()
+        ms = (C.c_float * 3)(); jobs = (C.c_uint64 * 2)()
+        L.bmh_chain_extend_merge_timing(self.handle, ms, jobs)
+        return {"extend_a": ms[0], "extend_b": ms[1], "stage": ms[2], "jobs_a": int(jobs[0]), "jobs_b": int(jobs[1])}
+
+    def timing(self):
+        ms = (C.c_float * 8)()
+        load_library().bmh_chain_last_timing(self.handle, ms)
+        return {"classify": ms[0], "lane": ms[1], "wave": ms[2], "to_counts": ms[3], "reads_small_scratch": int(ms[6]), "reads_large_scratch": int(ms[7])}
 
     def merge(self, out3_t, regs_t, stream: int = 0) -> None:
         L = load_library()

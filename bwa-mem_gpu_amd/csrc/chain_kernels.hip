@@ -32,13 +32,14 @@ struct chain_args_t {
 // src/bwamem.c:430-436), not the number located: on an hg38-like genome 0.25 % of the reads carry SMEMs with thousands of
 // occurrences (90 % of all located seeds) of which 500 each are used.  need[r] = that number; it sizes the read's scratch.
 // Reads that need more than heavy_thresh entries go to the wave kernels, one list per LDS size class.
-#define CH_N_CLASSES 5
-__device__ __forceinline__ int ch_class_of(uint32_t need) { return need <= 128u ? 0 : need <= 512u ? 1 : need <= 1250u ? 2 : need <= 1860u ? 3 : 4; }
-// LDS entries per class; class 3 keeps only the arrays of the sequential phases in LDS (seeds, chains, the sorted chain index,
+#define CH_N_CLASSES 7
+#define CH_HYBRID_CLASS 5
+__device__ __forceinline__ int ch_class_of(uint32_t need) { return need <= 64u ? 0 : need <= 128u ? 1 : need <= 256u ? 2 : need <= 512u ? 3 : need <= 1250u ? 4 : need <= 1860u ? 5 : 6; }
+// LDS entries per class; class 5 keeps only the arrays of the sequential phases in LDS (seeds, chains, the sorted chain index,
 // the sort keys: 84 bytes per entry) and the rest in the read's slice of the global scratch; class 4 (a read that samples
 // more than 1860 occurrences: four SMEMs of 465+ hits each) works in global memory altogether
-static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {128u, 512u, 1250u, 1860u, 0u};
-static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {4096u, 1024u, 512u, 256u, 256u};
+static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {64u, 128u, 256u, 512u, 1250u, 1860u, 0u};
+static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {8192u, 4096u, 2048u, 1024u, 512u, 256u, 256u};
 
 __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 {
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A)
 // one wave per heavy read of one size class (list filled by chain_classify_kernel), on a side stream beside chain_lane_kernel.
 // The read's scratch lives in LDS (lds_cap entries of CH_LDS_BYTES_PER_ENTRY bytes each; lds_cap == 0: the read's slice of the
 // global scratch): the wave form is a chain of dependent accesses, so their latency is its run time -- and the LDS a block asks
-// for decides how many of these waves a CU runs side by side (128 entries: 10, 512: 2, 1250: 1), which is why the classes exist.
+// for decides how many of these waves a CU runs side by side (64 entries: 20, 128: 10, 256: 5, 512: 2, 1250: 1), which is why the classes exist.
 #define CH_LDS_BYTES_PER_ENTRY (8 + 8 + sizeof(ch_est_t) + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4 + 4 + 4)
 #define CH_LDS_BYTES_PER_ENTRY_HYBRID (8 + 8 + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4)
 #define CH_LDS_CONTIGS 256         // contig tables up to this size are copied into LDS (3 KB)
@@ -120,6 +121,7 @@ __global__ void __launch_bounds__(64) chain_wave_kernel(chain_args_t A, uint32_t
 struct emit_args_t {
 	const ch_reg_t *regs; const uint32_t *prefix, *regs_per_read, *reg_off, *job_off, *read_offs, *read_lens;
 	uint32_t n_reads;
+	uint32_t reg_base, job_base;      // added to reg_off / job_off (second pass of bmh_chain_extend_merge)
 	ch_outreg_t *outregs;
 	uint32_t *qlen, *tlen, *h0, *job_read, *job_reg, *job_side, *jq_src; int64_t *jt0;
 };
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(256) emit_kernel(emit_args_t A)
 	const uint32_t nr = A.regs_per_read[r];
 	if (nr == 0) return;
 	const ch_reg_t *R = A.regs + A.prefix[r];
-	uint32_t g = A.reg_off[r], j = A.job_off[r];
+	uint32_t g = A.reg_base + A.reg_off[r], j = A.job_base + A.job_off[r];
 	const uint32_t roff = A.read_offs[r]; const int lq_ = (int)A.read_lens[r];
 	for (uint32_t i = 0; i < nr; ++i, ++g) {
 		const ch_reg_t a = R[i];
@@ -216,7 +218,7 @@ struct bmh_chain_ws {
 	ch_seed_t *seeds; ch_chain_t *chains; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx; ch_reg_t *regs; ch_est_t *est;
 	// per read
 	uint32_t *regs_per_read, *jobs_per_read, *reg_off, *job_off, *heavy_list, *need; float *frac_rep;
-	uint32_t *counters;            // [0..4] heavy_n per size class  [5] err  [6..15] profile stamps
+	uint32_t *counters;            // [0..6] heavy_n per size class  [7] err  [8..] profile stamps
 	// contigs
 	int n_contigs; int64_t *ctg_off; int32_t *ctg_len;
 	// outputs, grown on demand
@@ -228,8 +230,14 @@ struct bmh_chain_ws {
 	uint64_t n_regs, n_jobs;
 	uint32_t *h_pin;               // pinned host words for the small D2H copies
 	hipStream_t side; hipEvent_t ev_fork, ev_join;   // the wave kernels run beside the lane kernel
-	hipStream_t cls_stream[8]; hipEvent_t cls_done[8]; // ... and beside each other, one stream per size class
-	hipEvent_t ev_t[8]; float ms[8]; uint32_t heavy_per_class[CH_N_CLASSES];                 // kernel times of the last batch (bmh_chain_last_timing)
+	hipStream_t cls_stream[CH_N_CLASSES]; hipEvent_t cls_done[CH_N_CLASSES]; // ... and beside each other, one stream per size class
+	hipEvent_t ev_t[8]; float ms[8]; uint32_t heavy_per_class[CH_N_CLASSES];
+	// bmh_chain_extend_merge: the batch in two passes (reads of the lane kernel, reads of the wave kernels)
+	uint32_t *cnt2[4], *off2[4];     // [0] regions A [1] jobs A [2] regions B [3] jobs B: per-read counts and their exclusive scans
+	uint64_t *need_sum;              // [0] sampled occurrences of the wave-kernel reads (bound of their regions)
+	int32_t *out3; uint64_t cap_out3;
+	hipStream_t side2; hipEvent_t ev_x[6];
+	uint64_t n_regs_a, n_jobs_a;                 // kernel times of the last batch (bmh_chain_last_timing)
 	int materialize;               // 1: bmh_chain_batch also writes the base arrays q/t (+ qoff/toff)
 	const uint8_t *last_reads, *last_pac; uint64_t last_l_pac;   // sources of the last batch, for bmh_chain_extend
 };
@@ -247,9 +255,16 @@ extern "C" void bmh_chain_ws_free(bmh_chain_ws_t *w)
 	if (w->ev_join) (void)hipEventDestroy(w->ev_join);
 	for (hipEvent_t e : w->ev_t) if (e) (void)hipEventDestroy(e);
 	for (hipStream_t q : w->cls_stream) if (q) (void)hipStreamDestroy(q);
+	for (int i = 0; i < 4; ++i) { if (w->cnt2[i]) (void)hipFree(w->cnt2[i]); if (w->off2[i]) (void)hipFree(w->off2[i]); }
+	if (w->need_sum) (void)hipFree(w->need_sum);
+	if (w->out3) (void)hipFree(w->out3);
+	if (w->side2) (void)hipStreamDestroy(w->side2);
+	for (hipEvent_t e : w->ev_x) if (e) (void)hipEventDestroy(e);
 	for (hipEvent_t e : w->cls_done) if (e) (void)hipEventDestroy(e);
 	free(w);
 }
+
+static int prio_lo_early() { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); return lo; }
 
 extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_seeds)
 {
@@ -264,18 +279,26 @@ extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_
 	const size_t Rn = (size_t)max_reads + 1;
 	A(w->regs_per_read, 4 * Rn); A(w->jobs_per_read, 4 * Rn); A(w->reg_off, 4 * Rn); A(w->job_off, 4 * Rn); A(w->heavy_list, CH_N_CLASSES * 4 * Rn); A(w->need, 4 * Rn); A(w->frac_rep, 4 * Rn);
 	A(w->counters, 128);
+	for (int i = 0; i < 4; ++i) { A(w->cnt2[i], 4 * Rn); A(w->off2[i], 4 * Rn); }
+	A(w->need_sum, 16);
 	size_t t1 = 0, t2 = 0;
 	rocprim::exclusive_scan(nullptr, t1, w->regs_per_read, w->reg_off, 0u, Rn, rocprim::plus<uint32_t>(), 0);
 	rocprim::exclusive_scan(nullptr, t2, (uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0, 2 * S + 1, rocprim::plus<uint64_t>(), 0);
 	w->scan_tmp_bytes = t1 > t2 ? t1 : t2;
 	A(w->scan_tmp, w->scan_tmp_bytes + 256);
 #undef A
-	ok = ok && hipHostMalloc((void **)&w->h_pin, 64) == hipSuccess;
-	ok = ok && hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) == hipSuccess;
+	ok = ok && hipHostMalloc((void **)&w->h_pin, 256) == hipSuccess;
+	ok = ok && hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, prio_lo_early()) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) == hipSuccess;
 	for (hipEvent_t &e : w->ev_t) ok = ok && hipEventCreate(&e) == hipSuccess;
+	for (hipEvent_t &e : w->ev_x) ok = ok && hipEventCreate(&e) == hipSuccess;
+	ok = ok && hipStreamCreateWithFlags(&w->side2, hipStreamNonBlocking) == hipSuccess;
+	// the wave kernels are background work: low-priority streams get hardware queues of their own, so that the short kernels of the
+	// caller's stream (lane kernel, scans, the first pass's extension) are neither queued behind them nor starved of wave slots
+	int prio_lo = 0, prio_hi = 0;
+	(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
 	for (int c = 0; c < CH_N_CLASSES; ++c)
-		ok = ok && hipStreamCreateWithFlags(&w->cls_stream[c], hipStreamNonBlocking) == hipSuccess && hipEventCreate(&w->cls_done[c]) == hipSuccess;
+		ok = ok && hipStreamCreateWithPriority(&w->cls_stream[c], hipStreamNonBlocking, prio_lo) == hipSuccess && hipEventCreate(&w->cls_done[c]) == hipSuccess;
 	if (!ok) { bmh_set_error("bmh_chain_ws_create: hipMalloc failed (%s)", hipGetErrorString(hipGetLastError())); bmh_chain_ws_free(w); return nullptr; }
 	w->n_contigs = 1;
 	w->materialize = 1;
@@ -285,7 +308,9 @@ extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_
 extern "C" void bmh_chain_last_timing(const bmh_chain_ws_t *w, float ms[8])
 {
 	for (int i = 0; i < 4; ++i) ms[i] = w->ms[i];
-	for (int i = 0; i < 4; ++i) ms[4 + i] = (float)(i < 3 ? w->heavy_per_class[i] : w->heavy_per_class[3] + w->heavy_per_class[4]);
+	ms[4] = w->ms[4]; ms[5] = w->ms[5];
+	ms[6] = (float)(w->heavy_per_class[0] + w->heavy_per_class[1] + w->heavy_per_class[2] + w->heavy_per_class[3]);
+	ms[7] = (float)(w->heavy_per_class[4] + w->heavy_per_class[5] + w->heavy_per_class[6]);
 }
 
 extern "C" int bmh_chain_set_contigs(bmh_chain_ws_t *w, int n_contigs, const int64_t *offset, const int32_t *len)
@@ -318,28 +343,15 @@ template <class T> static int grow(T *&p, uint64_t need_elems)
 
 static inline unsigned nblk(uint64_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
 
-extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, const bmh_index_t *idx, const uint8_t *d_reads,
-                               const uint32_t *d_offs, const uint32_t *d_lens, uint32_t n_reads, const bmh_seeds_t *seeds,
-                               void *stream_, bmh_dev_jobs_t *out)
+// arguments of the chaining kernels for one batch
+static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_opt_t *opt, const bmh_index_t *idx, const uint32_t *d_lens, uint32_t n_reads, const bmh_seeds_t *seeds)
 {
-	if (!w || !opt || !idx || !seeds || !out) { bmh_set_error("bmh_chain_batch: null argument"); return BMH_EINVAL; }
-	memset(out, 0, sizeof(*out));
-	if (!idx->dev.pac || idx->dev.l_pac == 0) { bmh_set_error("bmh_chain_batch: the index was uploaded without the 2-bit reference (pac)"); return BMH_EINVAL; }
-	if (idx->dev.l_pac * 2 != idx->dev.seq_len) { bmh_set_error("bmh_chain_batch: l_pac does not match the index"); return BMH_EINVAL; }
-	if (n_reads > w->max_reads) { bmh_set_error("bmh_chain_batch: %u reads > workspace capacity %u", n_reads, w->max_reads); return BMH_ECAPACITY; }
-	if (seeds->n_seeds > w->max_seeds) { bmh_set_error("bmh_chain_batch: %llu seeds > workspace capacity %llu", (unsigned long long)seeds->n_seeds, (unsigned long long)w->max_seeds); return BMH_ECAPACITY; }
-	if (opt->max_occ < 1 || opt->e_del < 1 || opt->e_ins < 1) { bmh_set_error("bmh_chain_batch: bad options"); return BMH_EINVAL; }
-	hipStream_t st = (hipStream_t)stream_;
-	w->n_regs = w->n_jobs = 0;
-	w->last_reads = d_reads; w->last_pac = idx->dev.pac; w->last_l_pac = idx->dev.l_pac;
-	if (n_reads == 0) return BMH_OK;
-	chain_args_t A;
 	memset(&A, 0, sizeof(A));
 	A.x.o = *opt; A.x.l_pac = (int64_t)idx->dev.l_pac; A.x.n_contigs = w->n_contigs; A.x.ctg_off = w->ctg_off; A.x.ctg_len = w->ctg_len;
 	A.x.rbeg = seeds->d_rbeg; A.x.qbeg = seeds->d_qbeg; A.x.score = seeds->d_score; A.x.n_ref = seeds->d_n_ref_pos; A.x.prefix = seeds->d_prefix;
 	A.x.read_lens = d_lens;
 	A.x.g.S = w->seeds; A.x.g.CH = w->chains; A.x.g.order = w->order; A.x.g.opos = w->opos; A.x.g.klist = w->klist; A.x.g.srt = w->srt; A.x.g.cidx = w->cidx;
-	A.x.g.E = w->est; A.x.regs = w->regs; A.x.regs_per_read = w->regs_per_read; A.x.jobs_per_read = w->jobs_per_read; A.x.frac_rep = w->frac_rep; A.x.err = (int *)(w->counters + 5);
+	A.x.g.E = w->est; A.x.regs = w->regs; A.x.regs_per_read = w->regs_per_read; A.x.jobs_per_read = w->jobs_per_read; A.x.frac_rep = w->frac_rep; A.x.err = (int *)(w->counters + CH_N_CLASSES);
 	A.n_reads = n_reads;
 	const char *ht = getenv("BMH_CHAIN_HEAVY");
 	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : 16u;
@@ -347,9 +359,17 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 #ifdef CH_PROFILE
 	{
 		const char *pr = getenv("BMH_CHAIN_PROF_READ");
-		if (pr) { A.x.prof = (long long *)(w->counters + 6); A.x.prof_read = (uint32_t)atoi(pr); }
+		if (pr) { A.x.prof = (long long *)(w->counters + 8); A.x.prof_read = (uint32_t)atoi(pr); }
 	}
 #endif
+}
+
+// classify, then the lane kernel on st and the wave kernels beside it: every size class on its own stream (the classes differ in
+// LDS per block, so they fill different gaps of the CUs, and the largest reads -- the longest chains of dependent steps --
+// start at once); w->ev_join is recorded when all of them are through.  join: st waits for it.
+static int chain_launch(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st, bool join)
+{
+	const uint32_t n_reads = A.n_reads;
 	HIPCK(hipMemsetAsync(w->counters, 0, 128, st));
 	HIPCK(hipMemsetAsync(w->regs_per_read + n_reads, 0, 4, st));
 	HIPCK(hipMemsetAsync(w->jobs_per_read + n_reads, 0, 4, st));
@@ -360,59 +380,88 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	HIPCK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
 	chain_lane_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(A);
 	HIPCK(hipEventRecord(w->ev_t[2], st));
-	{
-		// every size class on its own stream: the classes differ in LDS per block, so they fill different gaps of the CUs, and the
-		// largest reads (longest chains of dependent steps) start at once instead of behind the other classes
-		HIPCK(hipEventRecord(w->ev_t[3], w->side));
-		const bool ctg_lds = w->n_contigs > 1 && w->n_contigs <= CH_LDS_CONTIGS;
-		HIPCK(hipFuncSetAttribute(ctg_lds ? (const void *)chain_wave_kernel<true> : (const void *)chain_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[3] * CH_LDS_BYTES_PER_ENTRY_HYBRID)));
-		for (int cls = CH_N_CLASSES - 1; cls >= 0; --cls) {
-			const uint32_t lds_cap = CH_CLASS_CAP[cls];
-			const int hybrid = cls == 3;
-			const size_t lds_bytes = (size_t)lds_cap * (hybrid ? CH_LDS_BYTES_PER_ENTRY_HYBRID : CH_LDS_BYTES_PER_ENTRY);
-			HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->ev_fork, 0));
-			if (ctg_lds) chain_wave_kernel<true><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
-			else chain_wave_kernel<false><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
-			HIPCK(hipEventRecord(w->cls_done[cls], w->cls_stream[cls]));
-			HIPCK(hipStreamWaitEvent(w->side, w->cls_done[cls], 0));
-		}
-		HIPCK(hipEventRecord(w->ev_t[4], w->side));
-		HIPCK(hipEventRecord(w->ev_join, w->side));
-		HIPCK(hipStreamWaitEvent(st, w->ev_join, 0));
+	HIPCK(hipEventRecord(w->ev_t[3], w->side));
+	const bool ctg_lds = w->n_contigs > 1 && w->n_contigs <= CH_LDS_CONTIGS;
+	HIPCK(hipFuncSetAttribute(ctg_lds ? (const void *)chain_wave_kernel<true> : (const void *)chain_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[CH_HYBRID_CLASS] * CH_LDS_BYTES_PER_ENTRY_HYBRID)));
+	for (int cls = CH_N_CLASSES - 1; cls >= 0; --cls) {
+		const uint32_t lds_cap = CH_CLASS_CAP[cls];
+		const int hybrid = cls == CH_HYBRID_CLASS;
+		const size_t lds_bytes = (size_t)lds_cap * (hybrid ? CH_LDS_BYTES_PER_ENTRY_HYBRID : CH_LDS_BYTES_PER_ENTRY);
+		HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->ev_fork, 0));
+		if (ctg_lds) chain_wave_kernel<true><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
+		else chain_wave_kernel<false><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
+		HIPCK(hipEventRecord(w->cls_done[cls], w->cls_stream[cls]));
+		HIPCK(hipStreamWaitEvent(w->side, w->cls_done[cls], 0));
 	}
+	HIPCK(hipEventRecord(w->ev_t[4], w->side));
+	HIPCK(hipEventRecord(w->ev_join, w->side));
+	if (join) HIPCK(hipStreamWaitEvent(st, w->ev_join, 0));
+	HIPCK(hipGetLastError());
+	return BMH_OK;
+}
+
+static int chain_check_args(const char *fn, bmh_chain_ws *w, const bmh_chain_opt_t *opt, const bmh_index_t *idx, uint32_t n_reads, const bmh_seeds_t *seeds)
+{
+	if (!idx->dev.pac || idx->dev.l_pac == 0) { bmh_set_error("%s: the index was uploaded without the 2-bit reference (pac)", fn); return BMH_EINVAL; }
+	if (idx->dev.l_pac * 2 != idx->dev.seq_len) { bmh_set_error("%s: l_pac does not match the index", fn); return BMH_EINVAL; }
+	if (n_reads > w->max_reads) { bmh_set_error("%s: %u reads > workspace capacity %u", fn, n_reads, w->max_reads); return BMH_ECAPACITY; }
+	if (seeds->n_seeds > w->max_seeds) { bmh_set_error("%s: %llu seeds > workspace capacity %llu", fn, (unsigned long long)seeds->n_seeds, (unsigned long long)w->max_seeds); return BMH_ECAPACITY; }
+	if (opt->max_occ < 1 || opt->e_del < 1 || opt->e_ins < 1) { bmh_set_error("%s: bad options", fn); return BMH_EINVAL; }
+	return BMH_OK;
+}
+
+static void chain_print_stats(bmh_chain_ws *w)
+{
+	fprintf(stderr, "[chain] lane kernel %.3f ms; wave kernels %.3f ms beside it:", w->ms[1], w->ms[2]);
+	for (int c = 0; c < CH_N_CLASSES; ++c) {
+		float t = 0; (void)hipEventElapsedTime(&t, w->ev_t[3], w->cls_done[c]);
+		fprintf(stderr, " class %d (%u entries) %u reads done at %.3f ms;", c, CH_CLASS_CAP[c], w->heavy_per_class[c], t);
+	}
+	fprintf(stderr, "\n");
+}
+
+extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, const bmh_index_t *idx, const uint8_t *d_reads,
+                               const uint32_t *d_offs, const uint32_t *d_lens, uint32_t n_reads, const bmh_seeds_t *seeds,
+                               void *stream_, bmh_dev_jobs_t *out)
+{
+	if (!w || !opt || !idx || !seeds || !out) { bmh_set_error("bmh_chain_batch: null argument"); return BMH_EINVAL; }
+	memset(out, 0, sizeof(*out));
+	{ const int rc = chain_check_args("bmh_chain_batch", w, opt, idx, n_reads, seeds); if (rc != BMH_OK) return rc; }
+	hipStream_t st = (hipStream_t)stream_;
+	w->n_regs = w->n_jobs = 0;
+	w->last_reads = d_reads; w->last_pac = idx->dev.pac; w->last_l_pac = idx->dev.l_pac;
+	if (n_reads == 0) return BMH_OK;
+	chain_args_t A;
+	chain_fill_args(w, A, opt, idx, d_lens, n_reads, seeds);
+	{ const int rc = chain_launch(w, A, st, true); if (rc != BMH_OK) return rc; }
 	size_t tb = w->scan_tmp_bytes;
 	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->regs_per_read, w->reg_off, 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
 	tb = w->scan_tmp_bytes;
 	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->jobs_per_read, w->job_off, 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
 	HIPCK(hipMemcpyAsync(w->h_pin + 0, w->reg_off + n_reads, 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipMemcpyAsync(w->h_pin + 1, w->job_off + n_reads, 4, hipMemcpyDeviceToHost, st));
-	HIPCK(hipMemcpyAsync(w->h_pin + 2, w->counters, 24, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(w->h_pin + 2, w->counters, 4 * (CH_N_CLASSES + 1), hipMemcpyDeviceToHost, st));
 	HIPCK(hipEventRecord(w->ev_t[5], st));
 	HIPCK(hipStreamSynchronize(st));
 	HIPCK(hipGetLastError());
 	(void)hipEventElapsedTime(&w->ms[0], w->ev_t[0], w->ev_t[1]); (void)hipEventElapsedTime(&w->ms[1], w->ev_t[1], w->ev_t[2]);
 	(void)hipEventElapsedTime(&w->ms[2], w->ev_t[3], w->ev_t[4]); (void)hipEventElapsedTime(&w->ms[3], w->ev_t[0], w->ev_t[5]);
-	if (getenv("BMH_CHAIN_STATS")) {
-		fprintf(stderr, "[chain] lane kernel %.3f ms; wave kernels %.3f ms beside it:", w->ms[1], w->ms[2]);
-		for (int c = 0; c < CH_N_CLASSES; ++c) {
-			float t = 0; (void)hipEventElapsedTime(&t, w->ev_t[3], w->cls_done[c]);
-			fprintf(stderr, " class %d (%u entries) %u reads done at %.3f ms;", c, CH_CLASS_CAP[c], w->h_pin[2 + c], t);
-		}
-		fprintf(stderr, "\n");
-	}
-	if (w->h_pin[7] == 1) { bmh_set_error("bmh_chain_batch: a read is longer than %d bp (mem_flt_chained_seeds is not restated)", CH_MAX_READ_LEN); return BMH_EINVAL; }
-	if (w->h_pin[7] != 0) { bmh_set_error("bmh_chain_batch: internal error %u in the chaining kernel", w->h_pin[7]); return BMH_ENODEV; }
+	for (int c = 0; c < CH_N_CLASSES; ++c) w->heavy_per_class[c] = w->h_pin[2 + c];
+	if (getenv("BMH_CHAIN_STATS")) chain_print_stats(w);
+	if (w->h_pin[2 + CH_N_CLASSES] == 1) { bmh_set_error("bmh_chain_batch: a read is longer than %d bp (mem_flt_chained_seeds is not restated)", CH_MAX_READ_LEN); return BMH_EINVAL; }
+	if (w->h_pin[2 + CH_N_CLASSES] != 0) { bmh_set_error("bmh_chain_batch: internal error %u in the chaining kernel", w->h_pin[2 + CH_N_CLASSES]); return BMH_ENODEV; }
 #ifdef CH_PROFILE
 	if (A.x.prof) {
 		long long pf[6];
-		HIPCK(hipMemcpy(pf, w->counters + 6, sizeof(pf), hipMemcpyDeviceToHost));
+		HIPCK(hipMemcpy(pf, w->counters + 8, sizeof(pf), hipMemcpyDeviceToHost));
 		fprintf(stderr, "chain phases of read %u (x10ns ticks): chains %lld  weights %lld  sort %lld  kept %lld  chain2aln %lld\n", A.x.prof_read,
 		        pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4]);
 	}
 #endif
 	const uint64_t n_regs = w->h_pin[0], n_jobs = w->h_pin[1];
 	w->n_regs = n_regs; w->n_jobs = n_jobs;
-	out->n_regs = n_regs; out->n_jobs = n_jobs; out->n_heavy_reads = (uint64_t)w->h_pin[2] + w->h_pin[3] + w->h_pin[4] + w->h_pin[5] + w->h_pin[6];
+	out->n_regs = n_regs; out->n_jobs = n_jobs; out->n_heavy_reads = 0;
+	for (int c = 0; c < CH_N_CLASSES; ++c) out->n_heavy_reads += w->h_pin[2 + c];
 	for (int c = 0; c < CH_N_CLASSES; ++c) w->heavy_per_class[c] = w->h_pin[2 + c];
 	out->d_regs_per_read = w->regs_per_read; out->d_frac_rep = w->frac_rep;
 	if (n_regs > w->cap_regs) {
@@ -430,7 +479,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	if (n_regs == 0) return BMH_OK;
 	emit_args_t E;
 	E.regs = w->regs; E.prefix = seeds->d_prefix; E.regs_per_read = w->regs_per_read; E.reg_off = w->reg_off; E.job_off = w->job_off;
-	E.read_offs = d_offs; E.read_lens = d_lens; E.n_reads = n_reads; E.outregs = w->outregs;
+	E.read_offs = d_offs; E.read_lens = d_lens; E.n_reads = n_reads; E.outregs = w->outregs; E.reg_base = E.job_base = 0;
 	E.qlen = w->qlen; E.tlen = w->tlen; E.h0 = w->h0; E.job_read = w->job_read; E.job_reg = w->job_reg; E.job_side = w->job_side; E.jq_src = w->jq_src; E.jt0 = w->jt0;
 	emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
 	out->d_qlen = w->qlen; out->d_tlen = w->tlen; out->d_h0 = w->h0; out->d_job_read = w->job_read; out->d_job_reg = w->job_reg; out->d_job_side = w->job_side;
@@ -442,7 +491,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->qlen, w->qoff64, (uint64_t)0, (size_t)n_jobs + 1, rocprim::plus<uint64_t>(), st));
 	tb = w->scan_tmp_bytes;
 	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->tlen, w->toff64, (uint64_t)0, (size_t)n_jobs + 1, rocprim::plus<uint64_t>(), st));
-	uint64_t *h64 = (uint64_t *)(w->h_pin + 8);
+	uint64_t *h64 = (uint64_t *)(w->h_pin + 16);
 	HIPCK(hipMemcpyAsync(h64 + 0, w->qoff64 + n_jobs, 8, hipMemcpyDeviceToHost, st));
 	HIPCK(hipMemcpyAsync(h64 + 1, w->toff64 + n_jobs, 8, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));
@@ -476,5 +525,187 @@ extern "C" int bmh_chain_merge(bmh_chain_ws_t *w, const int32_t *d_out3, int32_t
 	if (w->n_regs == 0) return BMH_OK;
 	merge_kernel<<<nblk(w->n_regs, 256), 256, 0, (hipStream_t)stream_>>>(w->outregs, (uint32_t)w->n_regs, d_out3, d_regs_out);
 	HIPCK(hipGetLastError());
+	return BMH_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ the stage in one call
+
+// per-read counts of one pass: pass 0 = reads of the lane kernel, pass 1 = reads of the wave kernels
+__global__ void __launch_bounds__(256) split_counts_kernel(const uint32_t *__restrict__ need, uint32_t thresh, int pass, uint32_t n_reads,
+                                                           const uint32_t *__restrict__ regs_per_read, const uint32_t *__restrict__ jobs_per_read,
+                                                           uint32_t *__restrict__ cr, uint32_t *__restrict__ cj, unsigned long long *__restrict__ need_sum)
+{
+	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+	unsigned long long nd = 0;
+	if (r <= n_reads) {
+		const bool mine = r < n_reads && (need[r] > thresh) == (pass == 1);
+		cr[r] = mine ? regs_per_read[r] : 0u;
+		cj[r] = mine ? jobs_per_read[r] : 0u;
+		if (need_sum && r < n_reads && need[r] > thresh) nd = need[r];
+	}
+	if (need_sum) {
+		for (int o = 32; o; o >>= 1) nd += __shfl_down(nd, o);
+		if ((threadIdx.x & 63) == 0 && nd) atomicAdd(need_sum, nd);
+	}
+}
+
+// extension results -> regions in READ order: the regions of pass A sit at [0, n_a) of the pass-ordered list, those of pass B
+// behind them; a read has regions in one pass only, so its final offset is off_a[read] + off_b[read]
+__global__ void __launch_bounds__(256) merge2_kernel(const ch_outreg_t *__restrict__ regs, uint32_t n_regs, uint32_t n_a, const uint32_t *__restrict__ off_a,
+                                                     const uint32_t *__restrict__ off_b, const int32_t *__restrict__ out3, int32_t *__restrict__ regs_out)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n_regs) return;
+	const ch_outreg_t a = regs[i];
+	int score, qb, qe; int64_t rb, re;
+	const int sides = (a.job0 >= 0) + (a.job1 >= 0);
+	if (sides > 0) {
+		int ls = 0, lq = 0, lt = 0, rs = 0, rq = 0, rt = 0;
+		if (a.job0 >= 0) { ls = out3[3 * (size_t)a.job0]; lq = out3[3 * (size_t)a.job0 + 1]; lt = out3[3 * (size_t)a.job0 + 2]; }
+		if (a.job1 >= 0) { rs = out3[3 * (size_t)a.job1]; rq = out3[3 * (size_t)a.job1 + 1]; rt = out3[3 * (size_t)a.job1 + 2]; }
+		score = ls + rs - (sides == 2 ? a.seedlen0 : 0);
+		qb = a.seed_qbeg - lq; qe = a.seed_qbeg + a.seedlen0 + rq;
+		rb = a.seed_rbeg - lt; re = a.seed_rbeg + a.seedlen0 + rt;
+	} else {
+		score = a.seedlen0; qb = 0; qe = a.l_query; rb = a.seed_rbeg; re = a.seed_rbeg + a.seedlen0;
+	}
+	const uint32_t dest = i < n_a ? i + off_b[a.read] : off_a[a.read] + (i - n_a);
+	int32_t *o = regs_out + 8 * (size_t)dest;
+	o[0] = (int32_t)a.read; o[1] = score; o[2] = qb; o[3] = qe;
+	o[4] = (int32_t)(uint32_t)rb; o[5] = (int32_t)(rb >> 32); o[6] = (int32_t)(uint32_t)re; o[7] = (int32_t)(re >> 32);
+}
+
+static int chain_grow_jobs(bmh_chain_ws *w, uint64_t n_regs, uint64_t n_jobs)
+{
+	if (n_regs > w->cap_regs) {
+		const uint64_t c = n_regs + n_regs / 4 + 1024;
+		if (grow(w->outregs, c) != BMH_OK) return BMH_ENOMEM;
+		w->cap_regs = c;
+	}
+	if (n_jobs + 1 > w->cap_jobs) {
+		const uint64_t c = n_jobs + n_jobs / 4 + 1024;
+		uint32_t **u32s[] = {&w->qlen, &w->tlen, &w->h0, &w->job_read, &w->job_reg, &w->job_side, &w->jq_src, &w->qoff, &w->toff};
+		for (uint32_t **p : u32s) if (grow(*p, c) != BMH_OK) return BMH_ENOMEM;
+		if (grow(w->jt0, c) != BMH_OK || grow(w->qoff64, c) != BMH_OK || grow(w->toff64, c) != BMH_OK) return BMH_ENOMEM;
+		w->cap_jobs = c;
+	}
+	if (n_jobs + 1 > w->cap_out3) {
+		const uint64_t c = n_jobs + n_jobs / 4 + 1024;
+		if (grow(w->out3, 3 * c) != BMH_OK) return BMH_ENOMEM;
+		w->cap_out3 = c;
+	}
+	return BMH_OK;
+}
+
+// bmh_chain_batch + bmh_chain_extend + bmh_chain_merge as ONE call that hides the chaining of the seed-rich reads.  On an
+// hg38-like genome 6 % of the reads sample more than 16 seed occurrences (up to ~1500) and their chaining -- one wave per read,
+// a chain of dependent steps, LDS-bound occupancy -- takes as long as the extension of the whole batch, while the other 94 % are
+// chained in 2 ms.  So the batch goes in two passes: the reads of the lane kernel are chained, turned into jobs and EXTENDED
+// while the wave kernels are still chaining the rest on their side streams; then the rest is extended and everything merged.
+// Regions come out in read order, identical to the three-call form (tests/test_gpu_parity.py); the job arrays in *out are in
+// pass order (all jobs of pass A, then pass B).
+extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, const bmh_index_t *idx, const uint8_t *d_reads,
+                                      const uint32_t *d_offs, const uint32_t *d_lens, uint32_t n_reads, const bmh_seeds_t *seeds,
+                                      const bmh_ext_params_t *ep, int32_t *d_regs_out, uint64_t cap_regs_out, void *stream_, bmh_dev_jobs_t *out)
+{
+	if (!w || !opt || !idx || !seeds || !out || !ep || !d_regs_out) { bmh_set_error("bmh_chain_extend_merge: null argument"); return BMH_EINVAL; }
+	memset(out, 0, sizeof(*out));
+	{ const int rc = chain_check_args("bmh_chain_extend_merge", w, opt, idx, n_reads, seeds); if (rc != BMH_OK) return rc; }
+	hipStream_t st = (hipStream_t)stream_;
+	w->n_regs = w->n_jobs = 0;
+	w->last_reads = d_reads; w->last_pac = idx->dev.pac; w->last_l_pac = idx->dev.l_pac;
+	if (n_reads == 0) return BMH_OK;
+	chain_args_t A;
+	chain_fill_args(w, A, opt, idx, d_lens, n_reads, seeds);
+	{ const int rc = chain_launch(w, A, st, false); if (rc != BMH_OK) return rc; }
+	// ---- pass A: the reads of the lane kernel
+	HIPCK(hipMemsetAsync(w->need_sum, 0, 16, st));
+	split_counts_kernel<<<nblk((uint64_t)n_reads + 1, 256), 256, 0, st>>>(w->need, A.heavy_thresh, 0, n_reads, w->regs_per_read, w->jobs_per_read, w->cnt2[0], w->cnt2[1], (unsigned long long *)w->need_sum);
+	size_t tb = w->scan_tmp_bytes;
+	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->cnt2[0], w->off2[0], 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
+	tb = w->scan_tmp_bytes;
+	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->cnt2[1], w->off2[1], 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
+	uint64_t *h64 = (uint64_t *)(w->h_pin + 16);
+	HIPCK(hipMemcpyAsync(w->h_pin + 0, w->off2[0] + n_reads, 4, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(w->h_pin + 1, w->off2[1] + n_reads, 4, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(h64, w->need_sum, 8, hipMemcpyDeviceToHost, st));
+	HIPCK(hipEventRecord(w->ev_t[5], st));
+	HIPCK(hipStreamSynchronize(st));                          // (the lane kernel; the wave kernels go on)
+	const uint64_t n_regs_a = w->h_pin[0], n_jobs_a = w->h_pin[1], need_b = h64[0];
+	// capacity for both passes now (a reallocation later would wait for everything and have to move pass A): pass B makes at
+	// most one region per sampled occurrence and two jobs per region
+	{ const int rc = chain_grow_jobs(w, n_regs_a + need_b, n_jobs_a + 2 * need_b); if (rc != BMH_OK) return rc; }
+	emit_args_t E;
+	E.regs = w->regs; E.prefix = seeds->d_prefix; E.read_offs = d_offs; E.read_lens = d_lens; E.n_reads = n_reads; E.outregs = w->outregs;
+	E.qlen = w->qlen; E.tlen = w->tlen; E.h0 = w->h0; E.job_read = w->job_read; E.job_reg = w->job_reg; E.job_side = w->job_side; E.jq_src = w->jq_src; E.jt0 = w->jt0;
+	bmh_ext_desc_t d;
+	d.reads = d_reads; d.pac = idx->dev.pac; d.l_pac = (long long)idx->dev.l_pac;
+	HIPCK(hipEventRecord(w->ev_x[0], st));
+	if (n_regs_a) {
+		E.regs_per_read = w->cnt2[0]; E.reg_off = w->off2[0]; E.job_off = w->off2[1]; E.reg_base = E.job_base = 0;
+		emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
+		if (n_jobs_a) {
+			d.jq_src = w->jq_src; d.job_side = w->job_side; d.jt0 = w->jt0;
+			const int rc = bmh_extend_batch_desc(&d, w->qlen, w->tlen, w->h0, (uint32_t)n_jobs_a, ep, w->out3, nullptr, stream_);
+			if (rc != BMH_OK) return rc;
+		}
+	}
+	HIPCK(hipEventRecord(w->ev_x[1], st));
+	// ---- pass B: the reads of the wave kernels, counted on a second stream so that the host does not wait for pass A's extension
+	HIPCK(hipStreamWaitEvent(w->side2, w->ev_join, 0));
+	split_counts_kernel<<<nblk((uint64_t)n_reads + 1, 256), 256, 0, w->side2>>>(w->need, A.heavy_thresh, 1, n_reads, w->regs_per_read, w->jobs_per_read, w->cnt2[2], w->cnt2[3], nullptr);
+	// (its own scan scratch: pass A's extension may still be using nothing of ours, but the scans above share scan_tmp with nothing in flight on st)
+	tb = w->scan_tmp_bytes;
+	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->cnt2[2], w->off2[2], 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), w->side2));
+	tb = w->scan_tmp_bytes;
+	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->cnt2[3], w->off2[3], 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), w->side2));
+	HIPCK(hipMemcpyAsync(w->h_pin + 32, w->off2[2] + n_reads, 4, hipMemcpyDeviceToHost, w->side2));
+	HIPCK(hipMemcpyAsync(w->h_pin + 33, w->off2[3] + n_reads, 4, hipMemcpyDeviceToHost, w->side2));
+	HIPCK(hipMemcpyAsync(w->h_pin + 2, w->counters, 4 * (CH_N_CLASSES + 1), hipMemcpyDeviceToHost, w->side2));
+	HIPCK(hipEventRecord(w->ev_x[2], w->side2));
+	HIPCK(hipStreamSynchronize(w->side2));
+	(void)hipEventElapsedTime(&w->ms[0], w->ev_t[0], w->ev_t[1]); (void)hipEventElapsedTime(&w->ms[1], w->ev_t[1], w->ev_t[2]);
+	(void)hipEventElapsedTime(&w->ms[2], w->ev_t[3], w->ev_t[4]); (void)hipEventElapsedTime(&w->ms[3], w->ev_t[0], w->ev_t[5]);
+	for (int c = 0; c < CH_N_CLASSES; ++c) w->heavy_per_class[c] = w->h_pin[2 + c];
+	if (getenv("BMH_CHAIN_STATS")) chain_print_stats(w);
+	if (w->h_pin[2 + CH_N_CLASSES] == 1) { bmh_set_error("bmh_chain_extend_merge: a read is longer than %d bp (mem_flt_chained_seeds is not restated)", CH_MAX_READ_LEN); return BMH_EINVAL; }
+	if (w->h_pin[2 + CH_N_CLASSES] != 0) { bmh_set_error("bmh_chain_extend_merge: internal error %u in the chaining kernel", w->h_pin[2 + CH_N_CLASSES]); return BMH_ENODEV; }
+	const uint64_t n_regs_b = w->h_pin[32], n_jobs_b = w->h_pin[33];
+	const uint64_t n_regs = n_regs_a + n_regs_b, n_jobs = n_jobs_a + n_jobs_b;
+	if (n_regs_b > need_b || n_jobs_b > 2 * need_b) { bmh_set_error("bmh_chain_extend_merge: internal error: pass B outgrew its bound"); return BMH_ENODEV; }
+	if (n_regs > cap_regs_out) { bmh_set_error("bmh_chain_extend_merge: %llu regions > capacity %llu of the output array", (unsigned long long)n_regs, (unsigned long long)cap_regs_out); return BMH_ECAPACITY; }
+	HIPCK(hipStreamWaitEvent(st, w->ev_x[2], 0));
+	HIPCK(hipEventRecord(w->ev_x[3], st));
+	if (n_regs_b) {
+		E.regs_per_read = w->cnt2[2]; E.reg_off = w->off2[2]; E.job_off = w->off2[3]; E.reg_base = (uint32_t)n_regs_a; E.job_base = (uint32_t)n_jobs_a;
+		emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
+		if (n_jobs_b) {
+			d.jq_src = w->jq_src + n_jobs_a; d.job_side = w->job_side + n_jobs_a; d.jt0 = w->jt0 + n_jobs_a;
+			const int rc = bmh_extend_batch_desc(&d, w->qlen + n_jobs_a, w->tlen + n_jobs_a, w->h0 + n_jobs_a, (uint32_t)n_jobs_b, ep, w->out3 + 3 * n_jobs_a, nullptr, stream_);
+			if (rc != BMH_OK) return rc;
+		}
+	}
+	HIPCK(hipEventRecord(w->ev_x[4], st));
+	if (n_regs) merge2_kernel<<<nblk(n_regs, 256), 256, 0, st>>>(w->outregs, (uint32_t)n_regs, (uint32_t)n_regs_a, w->off2[0], w->off2[2], w->out3, d_regs_out);
+	HIPCK(hipEventRecord(w->ev_x[5], st));
+	HIPCK(hipGetLastError());
+	w->n_regs = n_regs; w->n_jobs = n_jobs; w->n_regs_a = n_regs_a; w->n_jobs_a = n_jobs_a;
+	out->n_regs = n_regs; out->n_jobs = n_jobs;
+	for (int c = 0; c < CH_N_CLASSES; ++c) out->n_heavy_reads += w->h_pin[2 + c];
+	out->d_regs_per_read = w->regs_per_read; out->d_frac_rep = w->frac_rep;
+	out->d_qlen = w->qlen; out->d_tlen = w->tlen; out->d_h0 = w->h0; out->d_job_read = w->job_read; out->d_job_reg = w->job_reg; out->d_job_side = w->job_side;
+	return BMH_OK;
+}
+
+// ms[0] = extension of pass A, ms[1] = extension of pass B, ms[2] = from the start of the stage to the end of the merge (HIP events;
+// waits for the stream), jobs[0..1] = jobs of the two passes -- of the last bmh_chain_extend_merge
+extern "C" int bmh_chain_extend_merge_timing(const bmh_chain_ws_t *w, float ms[3], uint64_t jobs[2])
+{
+	if (!w) return BMH_EINVAL;
+	if (hipEventSynchronize(w->ev_x[5]) != hipSuccess) return BMH_ENODEV;
+	(void)hipEventElapsedTime(&ms[0], w->ev_x[0], w->ev_x[1]); (void)hipEventElapsedTime(&ms[1], w->ev_x[3], w->ev_x[4]);
+	(void)hipEventElapsedTime(&ms[2], w->ev_t[0], w->ev_x[5]);
+	jobs[0] = w->n_jobs_a; jobs[1] = w->n_jobs - w->n_jobs_a;
 	return BMH_OK;
 }

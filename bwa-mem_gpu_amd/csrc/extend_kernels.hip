@@ -773,16 +773,18 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 
 // ------------------------------------------------------------------ host side
 
-// classes: 0 = unsupported length; 1..18 = extend16_kernel<C>; 19..22 = extend_wide_kernel<5..8>
-#define EXT_N_CLS 24
-#define EXT_DONE_CLS 23     // decided by the closed-form prefilter: no DP
+// classes: 0 = unsupported length (query longer than 704 bases: all three outputs INT32_MIN, counted, see
+// bmh_extend_last_unsupported); 1..18 = extend16_kernel<C>; 19..25 = extend_wide_kernel<5..11>
+#define EXT_WIDE_MAX_C 11
+#define EXT_N_CLS 28
+#define EXT_DONE_CLS 27     // decided by the closed-form prefilter: no DP
 #define EXT16_MAX_C 18
 
 __device__ __forceinline__ int ext_class(uint32_t ql)
 {
 	if (ql <= 16 * EXT16_MAX_C) return ql <= 16 ? 1 : (int)((ql + 15) / 16);
 	const int wc = (int)((ql + 63) / 64);
-	return wc <= 8 ? 19 + (wc - 5) : 0;
+	return wc <= EXT_WIDE_MAX_C ? 19 + (wc - 5) : 0;
 }
 
 // sort key = class << 20 | tlen, plus a per-class histogram
@@ -849,6 +851,17 @@ extern "C" float bmh_extend_last_ms(void)
 	if (hipEventSynchronize(g_last->ev1) != hipSuccess) return -1.f;
 	if (hipEventElapsedTime(&ms, g_last->ev0, g_last->ev1) != hipSuccess) return -1.f;
 	return ms;
+}
+
+// number of jobs of the thread's last bmh_extend_batch whose query was longer than the kernels support (704 bases); their
+// outputs are INT32_MIN.  Waits for the batch.
+extern "C" int64_t bmh_extend_last_unsupported(void)
+{
+	if (!g_last || !g_last->have_ev) return 0;
+	uint32_t n0 = 0;
+	if (hipEventSynchronize(g_last->ev1) != hipSuccess) return -1;
+	if (hipMemcpy(&n0, g_last->counts, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return (int64_t)n0;
 }
 
 // Occupancy cap for co-scheduling: a block that reserves `g_ext_lds` bytes of (unused) dynamic LDS limits the DP
@@ -982,6 +995,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	launch16<13>(a, S[0], g16); launch16<14>(a, S[1], g16); launch16<15>(a, S[2], g16); launch16<16>(a, S[3], g16);
 	launch16<17>(a, S[0], g16); launch16<18>(a, S[1], g16);
 	launch_wide<5>(a, S[2], gw); launch_wide<6>(a, S[3], gw); launch_wide<7>(a, S[2], gw); launch_wide<8>(a, S[3], gw);
+	launch_wide<9>(a, S[0], gw); launch_wide<10>(a, S[1], gw); launch_wide<11>(a, S[2], gw);
 	for (int i = 0; i < 4; ++i) { HIPCK(hipEventRecord(g_scr.join[i], g_scr.side[i])); HIPCK(hipStreamWaitEvent(st, g_scr.join[i], 0)); }
 	HIPCK(hipEventRecord(g_scr.ev1, st));
 	HIPCK(hipGetLastError());

@@ -149,6 +149,12 @@ int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, const uint32_t 
                      const uint32_t *d_h0, uint32_t n, const bmh_ext_params_t *p,
                      int32_t *d_out, int32_t *d_raw, void *stream);
 
+/* Queries longer than 704 bases are not supported by the DP kernels (the reference's GASAL2 build has a compile-time
+ * MAX_SEQ_LEN too, README.md:38): such a job gets INT32_MIN in all three outputs and is counted; this returns the count for the
+ * calling thread's last bmh_extend_batch (waits for it; -1 on a HIP error).  The reference-compatible layer (gasal_aln_async)
+ * refuses such a batch up front; bmh_chain_batch only admits reads up to 700 bases, whose flanks always fit. */
+int64_t bmh_extend_last_unsupported(void);
+
 /* device time in ms of the DP kernels launched by the calling thread's last
  * bmh_extend_batch (HIP events on that call's stream; waits for them). */
 float bmh_extend_last_ms(void);
@@ -284,9 +290,9 @@ typedef struct {
 	const float *d_frac_rep;                                       /* [n_reads] frac_rep of the read's chains (for bmh_finalize_regs) */
 } bmh_dev_jobs_t;
 
-/* kernel times of the last bmh_chain_batch in ms (HIP events): [0] classify [1] lane kernel (reads that sample at most 16 seed
- * occurrences) [2] wave kernels (the others, on a side stream beside it) [3] the whole stage up to the counts; [4..7] reads per
- * wave-kernel size class (scratch of 128 / 512 / 1250 entries in LDS; larger ones: partly or wholly in global memory) */
+/* kernel times of the last bmh_chain_batch / bmh_chain_extend_merge in ms (HIP events): [0] classify [1] lane kernel (reads that
+ * sample at most 16 seed occurrences) [2] wave kernels (the others, one wave per read, size classes by LDS scratch of 64 ... 1250
+ * entries on side streams) [3] the stage up to the (first) counts; [6] reads whose scratch has at most 512 entries, [7] the larger ones */
 void bmh_chain_last_timing(const bmh_chain_ws_t *ws, float ms[8]);
 
 /* on (default): bmh_chain_batch also materialises the base arrays d_q/d_t/d_qoff/d_toff for bmh_extend_batch;
@@ -306,6 +312,20 @@ int bmh_chain_extend(bmh_chain_ws_t *ws, const bmh_ext_params_t *p, int32_t *d_o
 /* d_out3 = extension results of the batch's jobs -> d_regs_out[n_regs][8] =
  * {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi} (src/bwamem.c:2297-2303).  Asynchronous on stream. */
 int bmh_chain_merge(bmh_chain_ws_t *ws, const int32_t *d_out3, int32_t *d_regs_out, void *stream);
+
+/* bmh_chain_batch + bmh_chain_extend + bmh_chain_merge in ONE call that hides the chaining of the seed-rich reads behind the
+ * extension of the others (two passes: the reads that sample at most 16 seed occurrences are chained, turned into jobs and
+ * extended while one wave per read is still chaining the rest on side streams; then the rest).  d_regs_out [cap_regs_out][8]
+ * receives the regions in read order -- the same array the three-call form produces; out->n_regs / n_jobs / d_regs_per_read /
+ * d_frac_rep as for bmh_chain_batch; the job arrays in *out are in pass order (all jobs of the first pass, then the second);
+ * d_q / d_t are not materialised.  Synchronises the stream twice (counts); the second extension and the merge are still in
+ * flight on `stream` when it returns.  BMH_ECAPACITY if the batch has more than cap_regs_out regions. */
+int bmh_chain_extend_merge(bmh_chain_ws_t *ws, const bmh_chain_opt_t *opt, const bmh_index_t *idx, const uint8_t *d_reads,
+                           const uint32_t *d_offs, const uint32_t *d_lens, uint32_t n_reads, const bmh_seeds_t *seeds,
+                           const bmh_ext_params_t *ep, int32_t *d_regs_out, uint64_t cap_regs_out, void *stream, bmh_dev_jobs_t *out);
+/* of the last bmh_chain_extend_merge (waits for it): ms[0], ms[1] = extension of the two passes, ms[2] = the whole call's device
+ * time; jobs[0], jobs[1] = extension jobs of the two passes */
+int bmh_chain_extend_merge_timing(const bmh_chain_ws_t *ws, float ms[3], uint64_t jobs[2]);
 
 /* ------------------------------------------------- region -> CIGAR / NM / MD */
 

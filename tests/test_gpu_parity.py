@@ -232,6 +232,21 @@ def test_extension_long_queries(hip, oracle):
     want3, want6, _ = oracle.extend_batch(*jobs, want_raw=True)
     got3, got6 = gpu_extend(hip, jobs)
     assert np.array_equal(got6, want6) and np.array_equal(got3, want3)
+    # up to the supported maximum of 704 bases (flanks of a 700 bp read, the longest the chaining stage admits)
+    jobs = common.make_ext_jobs(500, np.random.default_rng(24), maxq=704)
+    assert (jobs[2] > 512).sum() > 50
+    want3, want6, _ = oracle.extend_batch(*jobs, want_raw=True)
+    got3, got6 = gpu_extend(hip, jobs)
+    assert np.array_equal(got6, want6) and np.array_equal(got3, want3)
+    assert hip.load_library().bmh_extend_last_unsupported() == 0
+    # beyond it: marked, counted, never silently wrong
+    rng = np.random.default_rng(25)
+    q = rng.integers(0, 4, size=705 + 30, dtype=np.uint8); t = rng.integers(0, 4, size=900 + 40, dtype=np.uint8)
+    jobs = (q, np.array([0, 705], np.uint32), np.array([705, 30], np.uint32), t, np.array([0, 900], np.uint32), np.array([900, 40], np.uint32), np.array([30, 25], np.uint32))
+    got3, _ = gpu_extend(hip, jobs)
+    assert (got3[0] == np.iinfo(np.int32).min).all() and hip.load_library().bmh_extend_last_unsupported() == 1
+    want3, _, _ = oracle.extend_batch(*jobs)
+    assert np.array_equal(got3[1], want3[1])
     # short queries against very long targets (beyond the LDS staging of the 16-lane-row kernel)
     rng = np.random.default_rng(23)
     qs, ts, h0 = [], [], []
@@ -471,6 +486,17 @@ def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None):
     torch.cuda.synchronize()
     assert np.array_equal(out3b.cpu().numpy()[: hj.n_jobs], want3)
     assert np.array_equal(regs2.cpu().numpy()[: hj.n_regs], hj.merge(want3))
+    # the one-call form (two passes, the heavy reads' chaining hidden behind the first pass's extension): same regions, read order
+    regs3 = torch.full((hj.n_regs + 3, 8), -9, dtype=torch.int32, device="cuda")
+    dj3 = cw.extend_merge(dindex, r, o, l, s, regs3)
+    torch.cuda.synchronize()
+    assert int(dj3.n_jobs) == hj.n_jobs and int(dj3.n_regs) == hj.n_regs
+    assert np.array_equal(regs3.cpu().numpy()[: hj.n_regs], hj.merge(want3)) and (regs3.cpu().numpy()[hj.n_regs:] == -9).all()
+    tm = cw.extend_merge_timing()
+    assert tm["jobs_a"] + tm["jobs_b"] == hj.n_jobs
+    if hj.n_regs > 1:
+        with pytest.raises(RuntimeError, match="capacity"):
+            cw.extend_merge(dindex, r, o, l, s, regs3[: hj.n_regs - 1])
     stats = (hj.n_jobs, hj.n_regs, int(dj.n_heavy_reads))
     hj.free(); cw.free(); ws.free(); dindex.free()
     return stats

@@ -138,6 +138,10 @@ def test_hot_path_on_a_text_beyond_2_pow_32(hip, oracle):
     assert np.array_equal(o3.cpu().numpy()[: hj.n_jobs], want3)
     rg = r8.cpu().numpy()[: hj.n_regs]
     assert np.array_equal(rg, hj.merge(want3))
+    r8b = torch.zeros(hj.n_regs + 1, 8, dtype=torch.int32, device=dev)
+    cw.extend_merge(dindex, dr.ascii, dr.offs, dr.lens, s, r8b)                  # the one-call, two-pass form
+    torch.cuda.synchronize()
+    assert np.array_equal(r8b.cpu().numpy()[: hj.n_regs], rg)
     rb = rg[:, 4].view(np.uint32).astype(np.int64) | (rg[:, 5].astype(np.int64) << 32)
     re = rg[:, 6].view(np.uint32).astype(np.int64) | (rg[:, 7].astype(np.int64) << 32)
     assert (re > 1 << 32).mean() > 0.08

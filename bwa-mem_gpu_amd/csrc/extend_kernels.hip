@@ -528,7 +528,10 @@ __global__ void __launch_bounds__(256) extend16_static_kernel(ext_args_t A)
 
 
 template <int C, bool LUT>
-__global__ void __launch_bounds__(256) extend16_kernel(ext_args_t A)
+#ifndef EXT_MIN_WAVES
+#define EXT_MIN_WAVES 1
+#endif
+__global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t A)
 {
 	const int lane = threadIdx.x & 63, l16 = lane & 15;
 	const uint32_t n = A.count[0];
@@ -1004,6 +1007,125 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		HIPCK(hipStreamSynchronize(st));
 		HIPCK(hipMemcpy(h, d_stats, 32, hipMemcpyDeviceToHost));
 		fprintf(stderr, "[ext] alignments %llu, rows executed %llu of %llu target rows (%.1f%%), wave-rows %llu (%.2f alignments per wave-row)\n", h[2], h[0], h[1], 100.0 * h[0] / (h[1] ? h[1] : 1), h[3], (double)h[0] / (h[3] ? h[3] : 1));
+	}
+	return BMH_OK;
+}
+
+// ------------------------------------------------------------------ calibration of the integer-VALU roofline
+
+// What the chip sustains on the instruction kinds the DP kernels are made of, measured at a given occupancy: `iters` rounds of
+// 128 instructions per wave, inline asm so that nothing is folded.  mode 0: v_max_i32 / v_add_u32 on eight independent registers
+// (the issue ceiling), 1: one dependent chain of the same, 2: dependent v_max_i32_dpp row_shr:1 (the scans), 3: the same on four
+// independent registers, 4: packed 16-bit v_pk_add_i16 / v_pk_max_i16 on eight registers (two columns per lane-op),
+// 5: v_bfe_i32 on eight registers.  The peak they are held against: 256 CUs x 4 SIMD-32 x 2.4 GHz = 7.86e13 lane-ops/s (a
+// wave64 instruction occupies its SIMD for 2 cycles, MI355X_MICROARCH.md).
+template <int MODE>
+__global__ void __launch_bounds__(256) calib_valu_kernel(int iters, int *sink)
+{
+	const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+	int r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+	const int k = MODE == 5 ? 3 : (blockIdx.x | 1);
+	for (int i = 0; i < iters; ++i) {                      // 128 instructions per trip, nothing else in the loop but its counter
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			if (MODE == 0)
+				asm volatile("v_max_i32 %0, %0, %8\n\tv_add_u32 %1, %1, %8\n\tv_max_i32 %2, %2, %8\n\tv_add_u32 %3, %3, %8\n\t"
+				             "v_max_i32 %4, %4, %8\n\tv_add_u32 %5, %5, %8\n\tv_max_i32 %6, %6, %8\n\tv_add_u32 %7, %7, %8\n\t"
+				             "v_add_u32 %0, %0, %8\n\tv_max_i32 %1, %1, %8\n\tv_add_u32 %2, %2, %8\n\tv_max_i32 %3, %3, %8\n\t"
+				             "v_add_u32 %4, %4, %8\n\tv_max_i32 %5, %5, %8\n\tv_add_u32 %6, %6, %8\n\tv_max_i32 %7, %7, %8"
+				             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(k));
+			else if (MODE == 1)
+				asm volatile("v_max_i32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_max_i32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\t"
+				             "v_max_i32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_max_i32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\t"
+				             "v_max_i32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_max_i32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\t"
+				             "v_max_i32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_max_i32 %0, %0, %1\n\tv_add_u32 %0, %0, %1" : "+v"(r0) : "v"(k));
+			else if (MODE == 2)
+				asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+				             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+				             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+				             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+				             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+				             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+				             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+				             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(r0));
+			else if (MODE == 3)
+				asm volatile("v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+				             "v_max_i32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_i32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+				             "v_max_i32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_i32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+				             "v_max_i32_dpp %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_i32_dpp %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+				             "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+				             "v_max_i32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_i32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+				             "v_max_i32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_i32_dpp %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+				             "v_max_i32_dpp %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_i32_dpp %7, %7, %7 row_shr:2 row_mask:0xf bank_mask:0xf"
+				             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));
+			else if (MODE == 4)
+				asm volatile("v_pk_add_i16 %0, %0, %8\n\tv_pk_max_i16 %1, %1, %8\n\tv_pk_add_i16 %2, %2, %8\n\tv_pk_max_i16 %3, %3, %8\n\t"
+				             "v_pk_add_i16 %4, %4, %8\n\tv_pk_max_i16 %5, %5, %8\n\tv_pk_add_i16 %6, %6, %8\n\tv_pk_max_i16 %7, %7, %8\n\t"
+				             "v_pk_max_i16 %0, %0, %8\n\tv_pk_add_i16 %1, %1, %8\n\tv_pk_max_i16 %2, %2, %8\n\tv_pk_add_i16 %3, %3, %8\n\t"
+				             "v_pk_max_i16 %4, %4, %8\n\tv_pk_add_i16 %5, %5, %8\n\tv_pk_max_i16 %6, %6, %8\n\tv_pk_add_i16 %7, %7, %8"
+				             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(k));
+			else if (MODE == 5)
+				asm volatile("v_bfe_i32 %0, %0, %8, 6\n\tv_bfe_i32 %1, %1, %8, 6\n\tv_bfe_i32 %2, %2, %8, 6\n\tv_bfe_i32 %3, %3, %8, 6\n\t"
+				             "v_bfe_i32 %4, %4, %8, 6\n\tv_bfe_i32 %5, %5, %8, 6\n\tv_bfe_i32 %6, %6, %8, 6\n\tv_bfe_i32 %7, %7, %8, 6\n\t"
+				             "v_bfe_i32 %0, %0, %8, 6\n\tv_bfe_i32 %1, %1, %8, 6\n\tv_bfe_i32 %2, %2, %8, 6\n\tv_bfe_i32 %3, %3, %8, 6\n\t"
+				             "v_bfe_i32 %4, %4, %8, 6\n\tv_bfe_i32 %5, %5, %8, 6\n\tv_bfe_i32 %6, %6, %8, 6\n\tv_bfe_i32 %7, %7, %8, 6"
+				             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(k));
+			else
+				asm volatile("v_fma_f32 %0, %0, %8, %8\n\tv_fma_f32 %1, %1, %8, %8\n\tv_fma_f32 %2, %2, %8, %8\n\tv_fma_f32 %3, %3, %8, %8\n\t"
+				             "v_fma_f32 %4, %4, %8, %8\n\tv_fma_f32 %5, %5, %8, %8\n\tv_fma_f32 %6, %6, %8, %8\n\tv_fma_f32 %7, %7, %8, %8\n\t"
+				             "v_fma_f32 %0, %0, %8, %8\n\tv_fma_f32 %1, %1, %8, %8\n\tv_fma_f32 %2, %2, %8, %8\n\tv_fma_f32 %3, %3, %8, %8\n\t"
+				             "v_fma_f32 %4, %4, %8, %8\n\tv_fma_f32 %5, %5, %8, %8\n\tv_fma_f32 %6, %6, %8, %8\n\tv_fma_f32 %7, %7, %8, %8"
+				             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(k));
+		}
+	}
+	const int acc = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+	if (acc == 0x7fffffff) sink[0] = acc;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {      // shader cycles and 100 MHz ticks of this wave: cycles per instruction, and the clock the chip ran at
+		const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+		((unsigned long long *)sink)[1] = c1 - c0; ((unsigned long long *)sink)[2] = w1 - w0;
+	}
+}
+
+static void calib_launch(int mode, unsigned grid, int iters, int *sink, hipStream_t st)
+{
+	switch (mode) {
+	case 0: calib_valu_kernel<0><<<grid, 256, 0, st>>>(iters, sink); break;
+	case 1: calib_valu_kernel<1><<<grid, 256, 0, st>>>(iters, sink); break;
+	case 2: calib_valu_kernel<2><<<grid, 256, 0, st>>>(iters, sink); break;
+	case 3: calib_valu_kernel<3><<<grid, 256, 0, st>>>(iters, sink); break;
+	case 4: calib_valu_kernel<4><<<grid, 256, 0, st>>>(iters, sink); break;
+	case 5: calib_valu_kernel<5><<<grid, 256, 0, st>>>(iters, sink); break;
+	default: calib_valu_kernel<6><<<grid, 256, 0, st>>>(iters, sink); break;
+	}
+}
+
+// waves_per_simd resident waves on every SIMD of the chip (256-thread blocks, one wave per SIMD each); *ms = kernel time,
+// *lane_ops = 64 lanes x 128 instructions x iters per wave, summed
+extern "C" int bmh_calib_valu(int mode, int waves_per_simd, int iters, void *stream_, float *ms, double *lane_ops)
+{
+	if (mode < 0 || mode > 6 || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !ms || !lane_ops) { bmh_set_error("bmh_calib_valu: bad argument"); return BMH_EINVAL; }
+	hipStream_t st = (hipStream_t)stream_;
+	static thread_local int *sink = nullptr;
+	static thread_local hipEvent_t e0 = nullptr, e1 = nullptr;
+	static thread_local int n_cu = 0;
+	if (!sink) {
+		HIPCK(hipMalloc((void **)&sink, 64)); HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
+		int dev = 0; hipDeviceProp_t prop; HIPCK(hipGetDevice(&dev)); HIPCK(hipGetDeviceProperties(&prop, dev)); n_cu = prop.multiProcessorCount;
+	}
+	const unsigned grid = (unsigned)(n_cu * waves_per_simd);
+	calib_launch(mode, grid, 16, sink, st);                              // warm-up (clocks, code fetch)
+	HIPCK(hipEventRecord(e0, st));
+	calib_launch(mode, grid, iters, sink, st);
+	HIPCK(hipEventRecord(e1, st));
+	HIPCK(hipEventSynchronize(e1));
+	HIPCK(hipEventElapsedTime(ms, e0, e1));
+	HIPCK(hipGetLastError());
+	*lane_ops = (double)grid * 256.0 * 128.0 * (double)iters;
+	if (getenv("BMH_CALIB_VERBOSE")) {
+		unsigned long long h[3];
+		HIPCK(hipMemcpy(h, sink, 24, hipMemcpyDeviceToHost));
+		fprintf(stderr, "[calib] mode %d, %d waves/SIMD: %.2f shader cycles per instruction of one wave, shader clock %.0f MHz\n", mode, waves_per_simd,
+		        (double)h[1] / (128.0 * iters), h[2] ? (double)h[1] / (double)h[2] * 100.0 : 0.0);
 	}
 	return BMH_OK;
 }

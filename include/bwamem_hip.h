@@ -127,6 +127,12 @@ void bmh_seed_last_timing(const bmh_seed_ws_t *ws, float ms[7]);
  * pattern and to measure the practical random-gather ceiling of the chip. */
 int bmh_calib_gather(const bmh_index_t *idx, uint64_t n_lanes, int iters, int dependent, void *stream, float *ms);
 
+/* Calibration of the integer-VALU roofline the extension kernels are held against: waves_per_simd resident waves on every
+ * SIMD execute `iters` rounds of 128 instructions of one kind -- mode 0: independent v_max_i32 / v_add_u32 (the issue ceiling),
+ * 1: one dependent chain, 2: dependent DPP row_shr max (the scans), 3: independent DPP, 4: packed 16-bit add / max,
+ * 5: v_bfe_i32, 6: v_fma_f32.  *ms = kernel time, *lane_ops = 64 x 128 x iters per wave, summed over the waves. */
+int bmh_calib_valu(int mode, int waves_per_simd, int iters, void *stream, float *ms, double *lane_ops);
+
 /* -------------------------------------------------------------- extension */
 
 /* Scoring of ksw_extend2 (src/ksw.c:864) as used by the GPU pipeline

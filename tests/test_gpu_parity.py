@@ -538,6 +538,47 @@ def test_device_job_builder_matches_host_builder(hip, oracle):
     _device_chain_case(hip, oracle, gr, idxr, readsr[:600], heavy=4, opt_over=dict(max_occ=20))
 
 
+def test_device_job_builder_matches_reference_job_stream(hip):
+    """Direct pin of the DEVICE job builder: the seeds recorded with the reference's own run (tests/golden/jobs_golden.npz,
+    scripts/make_jobs_golden.py) go straight into bmh_chain_batch; the extension jobs it builds are, as a multiset of
+    (h0, query, target), the jobs the reference's host code submitted to its extension library, and after bmh_extend_batch +
+    bmh_chain_merge the best region score of every read equals the AS tag of the reference's SAM output."""
+    import ctypes as C, hashlib, torch
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.lib import ChainWorkspace, SeedsT, dev_jobs_to_host, load_library
+    B = hip
+    z = np.load(os.path.join(common.GOLDEN, "jobs_golden.npz"))
+    g = synth.make_genome(int(z["n_genome"]), seed=int(z["genome_seed"]))
+    reads = z["reads"]
+    n, L = reads.shape
+    dindex = B.Index.upload(fmindex.build_fmd_index(g), pac=_pack_pac(g), l_pac=len(g))
+    dev = {k: torch.from_numpy(np.ascontiguousarray(z[k]).view(np.int64 if z[k].dtype == np.uint64 else np.int32)).cuda() for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")}
+    s = SeedsT()
+    s.n_seeds = len(z["rbeg"]); s.n_smems = int((z["score"] > 0).sum()); s.n_cands = 0
+    s.d_rbeg, s.d_qbeg, s.d_score, s.d_n_ref_pos, s.d_prefix = (dev[k].data_ptr() for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix"))
+    r = _to_dev(torch, synth.codes_to_ascii(reads.reshape(-1)))
+    o = (torch.arange(n, dtype=torch.int64) * L).to(torch.int32).cuda()
+    l = torch.full((n,), L, dtype=torch.int32).cuda()
+    cw = ChainWorkspace(n, max(int(s.n_seeds), 1))
+    dj = cw.chain_batch(dindex, r, o, l, s)
+    got = dev_jobs_to_host(dj, n)
+    nj = int(dj.n_jobs)
+    digs = sorted(hashlib.sha1(bytes([int(got["h0"][i]) & 255, int(got["h0"][i]) >> 8]) + got["q"][got["qoff"][i]:got["qoff"][i] + got["qlen"][i]].tobytes() + b"|" +
+                               got["t"][got["toff"][i]:got["toff"][i] + got["tlen"][i]].tobytes()).digest() for i in range(nj))
+    assert digs == [bytes(x) for x in z["job_digests"]]
+    out3 = torch.zeros(nj + 1, 3, dtype=torch.int32, device="cuda")
+    regs = torch.zeros(int(dj.n_regs) + 1, 8, dtype=torch.int32, device="cuda")
+    assert load_library().bmh_extend_batch(dj.d_q, dj.d_qoff, dj.d_qlen, dj.d_t, dj.d_toff, dj.d_tlen, dj.d_h0, nj, C.byref(B.ExtParams.default()), out3.data_ptr(), None, None) == 0
+    cw.merge(out3, regs)
+    torch.cuda.synchronize()
+    rg = regs.cpu().numpy()[: int(dj.n_regs)]
+    best = np.full(n, -1, np.int64)
+    np.maximum.at(best, rg[:, 0], rg[:, 1])
+    has = z["as_tag"] >= 0
+    assert has.sum() > 0.9 * n and np.array_equal(best[has], z["as_tag"][has])
+    cw.free(); dindex.free()
+
+
 def _cigar_case(B, oracle, g, idx, reads, scoring=None, max_regs=4000):
     """bmh_cigar_batch on the regions of the device pipeline (every region, not only the best ones) vs the oracle's
     mem_reg2aln restatement (pinned to the reference's SAM output and to its compiled ksw_global2)."""

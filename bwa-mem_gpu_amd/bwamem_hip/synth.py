@@ -182,6 +182,11 @@ def make_genome_device(n_bases: int, device, seed: int = 42, repeat_frac: float 
     g = torch.randint(0, 4, (n_bases,), dtype=torch.uint8, device=dev, generator=gen)
     scale = n_bases / 3.1e9
 
+    def put(p, src):
+        # slice assignment through an elementwise kernel (codes are 0..3, so `& 3` is the identity): a contiguous
+        # device-to-device copy_ goes through hipMemcpyAsync, which rocprofv3 --pmc crashes on (SIGSEGV inside the tool)
+        torch.bitwise_and(src, 3, out=g[p:p + int(src.numel())])
+
     def plant(cons, n_copies, div_lo, div_hi, trunc=False, budget=None):
         """n_copies copies of cons (uint8 tensor) at distinct slots; returns bases planted"""
         rl = int(cons.numel())
@@ -249,7 +254,7 @@ def make_genome_device(n_bases: int, device, seed: int = 42, repeat_frac: float 
         mut = torch.rand(alen, device=dev, generator=gen) < dv
         arr = torch.where(mut, (arr + torch.randint(1, 4, (alen,), dtype=torch.uint8, device=dev, generator=gen)) & 3, arr)
         p = int(rng.integers(0, n_bases - alen))
-        g[p:p + alen] = arr
+        put(p, arr)
         used += alen; na += 1
     planted["tandem_arrays"] = (na, used)
     # segmental duplications of the genome itself
@@ -266,7 +271,7 @@ def make_genome_device(n_bases: int, device, seed: int = 42, repeat_frac: float 
             if rng.random() < 0.5:
                 c = (3 - c).flip(0)
             p = int(rng.integers(0, n_bases - ln))
-            g[p:p + ln] = c
+            put(p, c)
             used += ln
         nd += 1
     planted["segdups"] = (nd, used)
@@ -283,7 +288,7 @@ def make_genome_device(n_bases: int, device, seed: int = 42, repeat_frac: float 
             hs.append((off + int(rng.integers(tel, cl - tel - hl)), hl))
         for hb, hl in hs:
             if hl > 0:
-                g[hb:hb + hl] = torch.randint(0, 4, (hl,), dtype=torch.uint8, device=dev, generator=gen)
+                put(hb, torch.randint(0, 4, (hl,), dtype=torch.uint8, device=dev, generator=gen))
                 holes.append((hb, hb + hl))
         off += cl
     holes.sort()

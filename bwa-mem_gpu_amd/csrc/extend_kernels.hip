@@ -39,6 +39,7 @@
 
 #define NEG_INF (-(1 << 29))
 #define EXT_T_CAP 1024        // target bases of an alignment staged in LDS by extend16_kernel
+#define EXT_DRAW_CHUNK 32      // jobs a wave takes from its class counter per atomic
 
 // inclusive max-scan over the 64 lanes (Kogge-Stone inside 16-lane rows on DPP
 // row_shr, then row_bcast:15 / row_bcast:31 across rows); lane 63 ends with the total
@@ -559,7 +560,8 @@ __global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t
 	int jl_lane = bp_base;
 	ext_rs_t S = {0, 0, 0, -1, -1, -1, -1, 0};
 	int rows_done = 0, wave_rows = 0;
-	bool more = true;                                          // the class still has unassigned jobs (wave-uniform)
+	bool more = true, more_g = true;                           // jobs left for this wave / on the class counter (wave-uniform)
+	uint32_t qn = 0, qe = 0;
 	for (;;) {
 		// one bit per row that has something to do here (results to write and / or a job to draw), at lanes 0/16/32/48
 		const unsigned long long nb = __ballot(!alive && l16 == 0 && (more || have));
@@ -575,17 +577,24 @@ __global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t
 				}
 				if (A.stats) { atomicAdd(A.stats, (unsigned long long)rows_done); atomicAdd(A.stats + 1, (unsigned long long)tlen); atomicAdd(A.stats + 2, 1ull); }
 			}
-			uint32_t base = n;
-			if (more) {
-				const uint32_t cnt = (uint32_t)__builtin_popcountll(nb);
+			// (wave-local job range refilled (EXT_DRAW_CHUNK / 4) at a time, see extpk_kernel)
+			if (qn == qe && more_g) {
 				uint32_t b0 = 0;
-				if (lane == (int)__builtin_ctzll(nb)) b0 = atomicAdd(A.ctr, cnt);
-				base = __builtin_amdgcn_readlane(b0, (int)__builtin_ctzll(nb));
-				more = base + cnt < n;
+				if (lane == 0) b0 = atomicAdd(A.ctr, (uint32_t)(EXT_DRAW_CHUNK / 4));
+				qn = __builtin_amdgcn_readfirstlane(b0);
+				qe = qn + (EXT_DRAW_CHUNK / 4) < n ? qn + (EXT_DRAW_CHUNK / 4) : n;
+				if (qn >= n) { qn = qe = n; }
+				more_g = qe < n;
 			}
+			const uint32_t base = qn;
+			{
+				const uint32_t cnt = (uint32_t)__builtin_popcountll(nb), avail = qe - qn;
+				qn += cnt < avail ? cnt : avail;
+			}
+			more = more_g || qn < qe;
 			if (!alive) {
 				const uint32_t k = base + (uint32_t)__builtin_popcountll(nb & ((1ull << (lane & 48)) - 1));
-				have = k < n;
+				have = k < qe;
 				id = have ? ids[n - 1 - k] : 0;
 				qlen = have ? (int)A.qlen[id] : 0; tlen = have ? (int)A.tlen[id] : 0; h0 = have ? (int)A.h0[id] : 1;
 				src = ext_job_src(A, id, have, qlen, tlen);
@@ -626,6 +635,8 @@ __global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t
 	if (A.stats && lane == 0) atomicAdd(A.stats + 3, (unsigned long long)wave_rows);
 }
 
+
+#include "extpk_dev.h"
 
 // ------------------------------------------------------------------ closed-form prefilter
 
@@ -779,21 +790,34 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 // classes: 0 = unsupported length (query longer than 704 bases: all three outputs INT32_MIN, counted, see
 // bmh_extend_last_unsupported); 1..18 = extend16_kernel<C>; 19..25 = extend_wide_kernel<5..11>
 #define EXT_WIDE_MAX_C 11
-#define EXT_N_CLS 28
+#define EXT_N_CLS 41
 #define EXT_DONE_CLS 27     // decided by the closed-form prefilter: no DP
 #define EXT16_MAX_C 18
+// 28..34 = extpk_kernel<4, P>, P = 4, 6, .. 16 (queries up to 8 P columns); 35..39 = extpk_kernel<8, P>, P = 9, 10, 12, 14, 16
+// (up to 16 P); 40 = extpk_kernel<16, 9> (up to 288)
+#define EXT_PK_BASE 28
+#define EXT_PK_MAXQ 288
 
+// packed 16-bit class of a query length (0: none)
+__device__ __forceinline__ int ext_pk_class(uint32_t ql)
+{
+	if (ql > EXT_PK_MAXQ) return 0;
+	if (ql <= 128) { const int h = (int)((ql + 15) / 16); return EXT_PK_BASE + (h < 2 ? 2 : h) - 2; }       // P = 2 h
+	return EXT_PK_BASE + (ql <= 144 ? 7 : ql <= 160 ? 8 : ql <= 192 ? 9 : ql <= 224 ? 10 : ql <= 256 ? 11 : 12);
+}
 __device__ __forceinline__ int ext_class(uint32_t ql)
 {
 	if (ql <= 16 * EXT16_MAX_C) return ql <= 16 ? 1 : (int)((ql + 15) / 16);
 	const int wc = (int)((ql + 63) / 64);
 	return wc <= EXT_WIDE_MAX_C ? 19 + (wc - 5) : 0;
 }
+constexpr int ext_pk_cls_of(int G, int P) { return EXT_PK_BASE + (G == 4 ? P / 2 - 2 : G == 16 ? 12 : P == 9 ? 7 : P == 10 ? 8 : P / 2 + 3); }
 
 // sort key = class << 20 | tlen, plus a per-class histogram
 __global__ void __launch_bounds__(256) ext_key_kernel(const uint32_t *__restrict__ qlen, const uint32_t *__restrict__ tlen, const uint8_t *__restrict__ done, uint32_t n,
                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                      uint32_t *__restrict__ counts, int32_t *__restrict__ out)
+                                                      uint32_t *__restrict__ counts, int32_t *__restrict__ out,
+                                                      const uint32_t *__restrict__ h0, int pk_a)      // pk_a > 0: packed 16-bit kernels allowed, match score
 {
 	__shared__ uint32_t hist[EXT_N_CLS];
 	if (threadIdx.x < EXT_N_CLS) hist[threadIdx.x] = 0;
@@ -802,6 +826,11 @@ __global__ void __launch_bounds__(256) ext_key_kernel(const uint32_t *__restrict
 	if (t < n) {
 		int cls = done[t] ? EXT_DONE_CLS : ext_class(qlen[t]);
 		if (cls >= 1 && cls <= EXT16_MAX_C && tlen[t] > EXT_T_CAP) cls = 19;     // very long target: wide kernel (streams it)
+		if (pk_a > 0 && cls != EXT_DONE_CLS && h0[t] + qlen[t] * (uint32_t)pk_a < PK_HMAX) {
+			const uint32_t ql = qlen[t];
+			const int pc = ext_pk_class(ql);
+			if (pc && tlen[t] <= (uint32_t)(ql <= 128 ? PK_TCAP(4) : ql <= 256 ? PK_TCAP(8) : PK_TCAP(16))) cls = pc;
+		}
 		if (cls == 0) out[3 * (size_t)t] = out[3 * (size_t)t + 1] = out[3 * (size_t)t + 2] = INT32_MIN;
 		uint32_t tl = tlen[t];
 		keys[t] = ((uint32_t)cls << 20) | (tl > 0xFFFFFu ? 0xFFFFFu : tl);
@@ -872,6 +901,10 @@ extern "C" int64_t bmh_extend_last_unsupported(void)
 // another stream to become resident beside them (BMH_EXT_LDS_KB; 0 = no cap).
 static unsigned g_ext_lds = [] { const char *e = getenv("BMH_EXT_LDS_KB"); return e ? (unsigned)atoi(e) * 1024u : 0u; }();
 
+// packed 16-bit kernels for the jobs that qualify (bmh_extend_set_packed; BMH_EXT_PACKED=0 starts with them off)
+static int g_ext_packed = [] { const char *e = getenv("BMH_EXT_PACKED"); return e ? atoi(e) : 1; }();
+extern "C" int bmh_extend_set_packed(int on) { const int was = g_ext_packed; g_ext_packed = on ? 1 : 0; return was; }
+
 // classes with at least this many columns per lane use the job-drawing form (BMH_EXT_REFILL_FROM; 19 = never)
 static int g_ext_refill_from = [] { const char *e = getenv("BMH_EXT_REFILL_FROM"); return e ? atoi(e) : 5; }();
 
@@ -885,6 +918,16 @@ static void launch16(const ext_args_t &base, hipStream_t st, unsigned grid)
 	if (!lut) extend16_static_kernel<C, false><<<grid, 256, g_ext_lds, st>>>(a);
 	else if (C >= g_ext_refill_from) extend16_kernel<C, true><<<grid, 256, g_ext_lds, st>>>(a);
 	else extend16_static_kernel<C, true><<<grid, 256, g_ext_lds, st>>>(a);
+}
+template <int G, int P>
+static void launch_pk(const ext_args_t &base, hipStream_t st, unsigned grid)
+{
+	ext_args_t a = base;
+	const int cls = ext_pk_cls_of(G, P);
+	a.count = base.count + 2 * cls;
+	a.ctr = base.ctr + cls;
+	if (a.o_ins + a.e_ins == a.o_del + a.e_del) extpk_kernel<G, P, true><<<grid, 256, 0, st>>>(a);
+	else extpk_kernel<G, P, false><<<grid, 256, 0, st>>>(a);
 }
 template <int C>
 static void launch_wide(const ext_args_t &base, hipStream_t st, unsigned grid)
@@ -938,7 +981,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		HIPCK(hipMalloc((void **)&g_scr.counts, 4 * 3 * EXT_N_CLS));
 		HIPCK(hipMalloc((void **)&g_scr.done, (size_t)n));
 		size_t tb = 0;
-		HIPCK(rocprim::radix_sort_pairs(nullptr, tb, g_scr.keys, g_scr.keys2, g_scr.vals, g_scr.vals2, (size_t)n, 0, 25, st));
+		HIPCK(rocprim::radix_sort_pairs(nullptr, tb, g_scr.keys, g_scr.keys2, g_scr.vals, g_scr.vals2, (size_t)n, 0, 26, st));
 		HIPCK(hipMalloc(&g_scr.tmp, tb + 256));
 		g_scr.tmp_bytes = tb; g_scr.cap = n; g_scr.dev = dev;
 	}
@@ -974,11 +1017,13 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		if (gp > 4096) gp = 4096;
 		ext_closed_form_kernel<<<gp, 256, 0, st>>>(a, n, g_scr.done);
 	}
-	ext_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_qlen, d_tlen, g_scr.done, n, g_scr.keys, g_scr.vals, g_scr.counts, d_out);
+	// packed 16-bit rows need 1 <= b, a + b <= 255 (byte score table), a >= 0 and gap penalties that fit the 16-bit lanes
+	const bool pk_ok = g_ext_packed && p->a > 0 && p->b >= 1 && p->a + p->b <= 255 && p->o_del + p->e_del < 4096 && p->o_ins + p->e_ins < 4096 && p->e_ins * 32 < 4096;
+	ext_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_qlen, d_tlen, g_scr.done, n, g_scr.keys, g_scr.vals, g_scr.counts, d_out, d_h0, pk_ok ? p->a : 0);
 	ext_offsets_kernel<<<1, 64, 0, st>>>(g_scr.counts);
 	{
 		size_t tb = g_scr.tmp_bytes;
-		HIPCK(rocprim::radix_sort_pairs(g_scr.tmp, tb, g_scr.keys, g_scr.keys2, g_scr.vals, g_scr.vals2, (size_t)n, 0, 25, st));
+		HIPCK(rocprim::radix_sort_pairs(g_scr.tmp, tb, g_scr.keys, g_scr.keys2, g_scr.vals, g_scr.vals2, (size_t)n, 0, 26, st));
 	}
 	// class sizes stay on the device (no host sync): every class kernel is launched with a grid
 	// that covers the whole batch and its waves stride over the class's slice of the sorted list
@@ -991,6 +1036,18 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	HIPCK(hipEventRecord(g_scr.fork, st));
 	for (int i = 0; i < 4; ++i) HIPCK(hipStreamWaitEvent(g_scr.side[i], g_scr.fork, 0));
 	hipStream_t *S = g_scr.side;
+	// the packed classes hold the bulk of the jobs when they are enabled: they go first, widest (longest running) first
+	if (pk_ok) {
+		// grids sized to what is resident at once (the waves draw their jobs): 3 waves per SIMD for P >= 9 (768 blocks), 4 below
+		unsigned g4 = (unsigned)((n + 63) / 64), g8 = (unsigned)((n + 31) / 32);
+		if (g4 > max_grid) g4 = max_grid;
+		if (g8 > max_grid) g8 = max_grid;
+		const unsigned g4w = g4 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g4, g8w = g8 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g8, g16w = g16 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g16;
+		launch_pk<4, 16>(a, S[3], g4w); launch_pk<4, 14>(a, S[0], g4w); launch_pk<4, 12>(a, S[1], g4w); launch_pk<4, 10>(a, S[2], g4w);
+		launch_pk<4, 8>(a, S[3], g4); launch_pk<4, 6>(a, S[0], g4); launch_pk<4, 4>(a, S[1], g4);
+		launch_pk<8, 9>(a, S[2], g8w); launch_pk<8, 10>(a, S[3], g8w); launch_pk<8, 12>(a, S[0], g8w); launch_pk<8, 14>(a, S[1], g8w); launch_pk<8, 16>(a, S[2], g8w);
+		launch_pk<16, 9>(a, S[3], g16w);
+	}
 	// (narrow classes first measured better than widest first: 10.8 vs 11.1 ms)
 	launch16<1>(a, S[0], g16); launch16<2>(a, S[1], g16); launch16<3>(a, S[2], g16); launch16<4>(a, S[3], g16);
 	launch16<5>(a, S[0], g16); launch16<6>(a, S[1], g16); launch16<7>(a, S[2], g16); launch16<8>(a, S[3], g16);

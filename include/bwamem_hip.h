@@ -161,6 +161,11 @@ int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, const uint32_t 
  * refuses such a batch up front; bmh_chain_batch only admits reads up to 700 bases, whose flanks always fit. */
 int64_t bmh_extend_last_unsupported(void);
 
+/* Jobs whose scores fit 16 bits (h0 + qlen*a < 4096, qlen <= 288, tlen <= 512; scoring with 1 <= b, a + b <= 255) run on the
+ * packed 16-bit kernels (two DP columns per register, eight alignments per wave), everything else on the 32-bit kernels; results
+ * are identical.  on = 0 sends every job to the 32-bit kernels (tests, A/B timing).  Process-wide; returns the previous setting. */
+int bmh_extend_set_packed(int on);
+
 /* device time in ms of the DP kernels launched by the calling thread's last
  * bmh_extend_batch (HIP events on that call's stream; waits for them). */
 float bmh_extend_last_ms(void);

@@ -159,8 +159,15 @@ def test_seeding_unique_interval_shortcut(hip, oracle, case):
     common.assert_seeds_equal(got, want)
 
 
-def gpu_extend(B, jobs, zdrop=0, want_raw=True, scoring=None):
+def gpu_extend(B, jobs, zdrop=0, want_raw=True, scoring=None, packed=None):
+    """packed: None = the library's default routing (packed 16-bit kernels for the jobs that qualify), 0 = 32-bit kernels only"""
     import torch
+    if packed is not None:
+        was = B.load_library().bmh_extend_set_packed(int(packed))
+        try:
+            return gpu_extend(B, jobs, zdrop, want_raw, scoring)
+        finally:
+            B.load_library().bmh_extend_set_packed(was)
     q, qoff, qlen, t, toff, tlen, h0 = jobs
     n = len(qlen)
     d = [torch.from_numpy(np.ascontiguousarray(x).astype(np.int64) if x.dtype == np.uint32 else np.ascontiguousarray(x)) for x in (q, qoff, qlen, t, toff, tlen, h0)]
@@ -169,19 +176,24 @@ def gpu_extend(B, jobs, zdrop=0, want_raw=True, scoring=None):
     raw = torch.zeros(n, 6, dtype=torch.int32, device="cuda") if want_raw else None
     prm = B.ExtParams.default(zdrop=zdrop)
     if scoring is not None:
-        a_, b_, o_, e_ = scoring
-        prm = B.ExtParams(a_, b_, o_, e_, o_, e_, zdrop, 5)
+        if len(scoring) == 6:
+            a_, b_, od_, ed_, oi_, ei_ = scoring
+            prm = B.ExtParams(a_, b_, od_, ed_, oi_, ei_, zdrop, 5)
+        else:
+            a_, b_, o_, e_ = scoring
+            prm = B.ExtParams(a_, b_, o_, e_, o_, e_, zdrop, 5)
     B.extend_batch(*d, out, params=prm, raw_t=raw)
     torch.cuda.synchronize()
     return out.cpu().numpy(), raw.cpu().numpy() if want_raw else None
 
 
+@pytest.mark.parametrize("packed", [1, 0])
 @pytest.mark.parametrize("zdrop", [0, 100])
-def test_extension_matches_oracle(hip, oracle, zdrop):
+def test_extension_matches_oracle(hip, oracle, zdrop, packed):
     import oracle_py
     jobs = common.make_ext_jobs(6000, np.random.default_rng(21))
     want3, want6, _ = oracle.extend_batch(*jobs, params=oracle_py.default_params(zdrop=zdrop), want_raw=True)
-    got3, got6 = gpu_extend(hip, jobs, zdrop=zdrop)
+    got3, got6 = gpu_extend(hip, jobs, zdrop=zdrop, packed=packed)
     bad = np.nonzero((got6 != want6).any(1))[0]
     assert bad.size == 0, f"{bad.size} raw mismatches, first {bad[:5]}: got {got6[bad[:5]]} want {want6[bad[:5]]} qlen {jobs[2][bad[:5]]} tlen {jobs[5][bad[:5]]}"
     assert np.array_equal(got3, want3)
@@ -201,6 +213,22 @@ def test_extension_other_scorings(hip, oracle, scoring):
     bad = np.nonzero((got6 != want6).any(1))[0]
     assert bad.size == 0, f"{bad.size} raw mismatches, first {bad[:5]}: got {got6[bad[:5]]} want {want6[bad[:5]]} qlen {jobs[2][bad[:5]]} tlen {jobs[5][bad[:5]]}"
     assert np.array_equal(got3, want3)
+
+
+@pytest.mark.parametrize("packed", [1, 0])
+@pytest.mark.parametrize("scoring", [(1, 4, 6, 1, 4, 2), (2, 3, 5, 2, 9, 1), (1, 1, 1, 1, 2, 1)])
+def test_extension_asymmetric_gap_penalties(hip, oracle, scoring, packed):
+    """Different open / extend penalties for deletions and insertions (the packed kernels compute M - oe twice then), N bases,
+    z-drop on and off, on both kernel families."""
+    import oracle_py
+    a, b, od, ed, oi, ei = scoring
+    for zdrop in (0, 60):
+        jobs = common.make_ext_jobs(2500, np.random.default_rng(77 + a + zdrop), maxq=288)
+        want3, want6, _ = oracle.extend_batch(*jobs, params=oracle_py.KswParams(a, b, od, ed, oi, ei, zdrop, 5, 1), want_raw=True)
+        got3, got6 = gpu_extend(hip, jobs, zdrop=zdrop, scoring=scoring, packed=packed)
+        bad = np.nonzero((got6 != want6).any(1))[0]
+        assert bad.size == 0, f"{bad.size} raw mismatches, first {bad[:5]}: got {got6[bad[:5]]} want {want6[bad[:5]]} qlen {jobs[2][bad[:5]]} tlen {jobs[5][bad[:5]]}"
+        assert np.array_equal(got3, want3)
 
 
 def test_extension_jobs_without_target_rows(hip, oracle):

@@ -13,7 +13,9 @@ Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
   A step = one pass of the hot path over one batch, reads in -> alignment regions out, entirely on the device:
   SMEM seeding (pack, forward, backward, filter, expand, locate) -> chaining, chain filter and extension-job construction
   with on-device reference fetch (bmh_chain_batch) -> seed extension (ksw_extend2 kernels) -> region merge.  Steps alternate
-  between two different read batches.  `value` has the reads resident in HBM when the timed region starts (bench contract);
+  between two different read batches; `--inflight` (2) batches are in flight at a time, each on its own stream with its own
+  workspaces and host thread, the way the reference keeps several gpu_storage batches in flight across its host threads
+  (src/fastmap.c:417-534); every timed batch goes through the whole path (--inflight 1: strictly one batch at a time).  `value` has the reads resident in HBM when the timed region starts (bench contract);
   `incl_pcie` times the same steps fed from pinned host memory (reads H2D, regions D2H, double-buffered on copy streams) --
   the reference's boundary, seed_gen.cu:1841-1843,2073-2101 -- and is reported beside it.
 Multi-GPU: reads shard across ranks (weak scaling: READS_PER_GPU per rank); rank 0 builds the index and broadcasts it
@@ -138,6 +140,8 @@ def main():
     ap.add_argument("--no-verify-index", dest="verify", action="store_false", help="skip the complete check of the suffix array after the build")
     ap.add_argument("--index-cache", default=os.environ.get("BENCH_INDEX_CACHE", ""), help="directory: save the built genome + index there / load them from there "
                     "(setup only; used by scripts/profile_round.sh so that the rocprofv3 passes do not rebuild it)")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BENCH_INFLIGHT", "2")), help="batches in flight: each goes through the whole path on its own "
+                    "stream, workspaces and host thread (1 = strictly one batch at a time)")
     ap.add_argument("--no-pcie", dest="pcie", action="store_false", help="skip the second timed loop (steps fed from pinned host memory)")
     ap.add_argument("--no-next-rows", dest="next_rows", action="store_false")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BENCH_CPU_SAMPLE", "100000")), help="reads of the all-cores CPU leg (0 = no CPU baseline)")
@@ -228,7 +232,8 @@ def main():
     for reads, dr in batches:
         s = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19)
         stats.append(dict(n_seeds=int(s.n_seeds), n_smems=int(s.n_smems), n_cands=int(s.n_cands)))
-    cw = ChainWorkspace(n_reads, int(max(x["n_seeds"] for x in stats) * 1.25) + 4096)
+    cap_seeds = int(max(x["n_seeds"] for x in stats) * 1.25) + 4096
+    cw = ChainWorkspace(n_reads, cap_seeds)
     cw.set_contigs(contigs)
     cw.set_materialize(False)             # jobs stay descriptors: the DP kernels fetch bases from the reads / 2-bit reference
     for (reads, dr), stt in zip(batches, stats):
@@ -241,96 +246,121 @@ def main():
     cap_jobs = int(max(x["n_jobs"] for x in stats) * 1.25) + 4096
     cap_regs = int(max(x["n_regs"] for x in stats) * 1.25) + 4096
     out = torch.zeros(cap_jobs, 3, dtype=torch.int32, device=dev)        # (three-call form, used for the isolated kernel times)
-    regs_out = [torch.zeros(cap_regs, 8, dtype=torch.int32, device=dev) for _ in range(2)]
 
     torch.cuda.synchronize()
     s_main = torch.cuda.Stream(device=dev)
     h_main = s_main.cuda_stream
-    last = {}
     # how often each stage ran in this process: divides the per-process counter sums of a rocprofv3 run (scripts/summarize_profiles.py)
     passes = {"seed": 2 * len(batches), "chain": len(batches), "extend": 0}
+    import threading
+    plock = threading.Lock()
 
-    def hot_path(ascii_t, offs_t, lens_t, regs_t):
-        """reads -> seeds -> chains / jobs (incl. reference fetch) -> extension -> regions, one stream, all in HBM"""
-        sd = ws.seed_batch(dindex, ascii_t, offs_t, lens_t, 19, stream=h_main)
-        # chains / jobs -> extension -> regions in one call: the seed-rich reads (6 %: one wave per read, as long as the whole
-        # extension) are chained on side streams WHILE the jobs of the others are extended, then extended themselves
-        dj_ = cw.extend_merge(dindex, ascii_t, offs_t, lens_t, sd, regs_t, params=params, stream=h_main)
-        last["n_regs"] = int(dj_.n_regs)
-        passes["seed"] += 1; passes["chain"] += 1; passes["extend"] += 1
+    # ---------------- batches in flight.  A batch goes through the whole path on its own stream with its own workspaces, driven by
+    # its own host thread; `--inflight` of them run side by side and take the steps in turn (step i -> lane i mod N), the way the
+    # reference keeps several gpu_storage batches in flight across its host threads (src/fastmap.c:417-534, gasal_gpu_storage_v).
+    # The chaining of the seed-rich reads is a long chain of dependent steps on few waves: alone it leaves most of the chip idle
+    # while the rest of its batch waits for it; with a second batch in flight those CUs seed and extend.
+    class Lane:
+        def __init__(self, k):
+            self.k = k
+            self.ws = ws if k == 0 else B.SeedWorkspace(n_reads, n_reads * a.read_len)
+            self.cw = cw if k == 0 else ChainWorkspace(n_reads, cap_seeds)
+            if k:
+                self.cw.set_contigs(contigs); self.cw.set_materialize(False)
+            self.stream = s_main if k == 0 else torch.cuda.Stream(device=dev)
+            self.h = self.stream.cuda_stream
+            self.regs = torch.zeros(cap_regs, 8, dtype=torch.int32, device=dev)
+            self.n_regs = 0
+            self.acc = {}
+            # PCIe form: the lane's own device copy of the reads and pinned host buffer of the regions
+            self.slot = None; self.host_out = None
 
-    def step(i):
-        dr = batches[i & 1][1]
-        hot_path(dr.ascii, dr.offs, dr.lens, regs_out[i & 1])
+        def step(self, i, host_in=None):
+            dr = batches[i & 1][1]
+            ascii_t, offs_t, lens_t = dr.ascii, dr.offs, dr.lens
+            if host_in is not None:                                   # reads arrive over PCIe on the lane's stream
+                if self.slot is None:
+                    self.slot = (torch.empty_like(dr.ascii), torch.empty_like(dr.offs), torch.empty_like(dr.lens))
+                    self.host_out = torch.empty(cap_regs, 8, dtype=torch.int32).pin_memory()
+                with torch.cuda.stream(self.stream):
+                    for dst, src in zip(self.slot, host_in[i & 1]):
+                        dst.copy_(src, non_blocking=True)
+                ascii_t, offs_t, lens_t = self.slot
+            sd = self.ws.seed_batch(dindex, ascii_t, offs_t, lens_t, 19, stream=self.h)
+            tm = self.ws.timing()
+            dj_ = self.cw.extend_merge(dindex, ascii_t, offs_t, lens_t, sd, self.regs, params=params, stream=self.h)
+            self.n_regs = int(dj_.n_regs)
+            if host_in is not None:                                   # regions leave over PCIe, behind the lane's next batch
+                with torch.cuda.stream(self.stream):
+                    self.host_out[: self.n_regs].copy_(self.regs[: self.n_regs], non_blocking=True)
+            xm = self.cw.extend_merge_timing(); cm = self.cw.timing()
+            tm["chain_light"] = cm["to_counts"]    # classify + lane kernel + counts: what the first extension waits for
+            tm["chain_heavy_beside"] = cm["wave"]  # wave kernels on side streams (hidden behind extend_a as far as it lasts)
+            tm["extend_a"] = xm["extend_a"]; tm["extend_b"] = xm["extend_b"]; tm["chain_extend_merge"] = xm["stage"]
+            for kk, v in tm.items():
+                self.acc[kk] = self.acc.get(kk, 0.0) + v
+            with plock:
+                passes["seed"] += 1; passes["chain"] += 1; passes["extend"] += 1
 
-    for i in range(a.warmup):
-        step(i)
+    n_lanes = max(1, a.inflight)
+    lanes = [Lane(k) for k in range(n_lanes)]
+
+    def run_steps(k, host_in=None):
+        """k steps, step i on lane i mod N; returns when all of them are through (device idle)"""
+        errs = []
+
+        def work(lane):
+            try:
+                L.bmh_set_device(dev_id)                              # HIP's current device is per host thread
+                torch.cuda.set_device(dev_id)
+                for i in range(lane.k, k, n_lanes):
+                    lane.step(i, host_in)
+            except Exception as e:                                    # noqa: BLE001 -- re-raised on the main thread
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(ln,)) for ln in lanes[1:]]
+        for t in th:
+            t.start()
+        work(lanes[0])
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        torch.cuda.synchronize()
+
+    run_steps(max(a.warmup, n_lanes if a.warmup else 0))
+    for ln in lanes:
+        ln.acc = {}
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    stage_ms = {}
-    for i in range(a.steps):
-        step(i)
-        tm = ws.timing()                       # HIP events on the launch stream, per stage
-        xm = cw.extend_merge_timing(); cm = cw.timing()
-        tm["chain_light"] = cm["to_counts"]    # classify + lane kernel + counts: what the first extension waits for
-        tm["chain_heavy_beside"] = cm["wave"]  # wave kernels on side streams (hidden behind extend_a as far as it lasts)
-        tm["extend_a"] = xm["extend_a"]; tm["extend_b"] = xm["extend_b"]; tm["chain_extend_merge"] = xm["stage"]
-        for k, v in tm.items():
-            stage_ms[k] = stage_ms.get(k, 0.0) + v
+    run_steps(a.steps)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    stage_ms = {}
+    for ln in lanes:
+        for kk, v in ln.acc.items():
+            stage_ms[kk] = stage_ms.get(kk, 0.0) + v
     stage_ms = {k: v / a.steps for k, v in stage_ms.items()}
+    regs_out = [lanes[0].regs, lanes[-1].regs]
 
-    # ---------------- the same steps fed over PCIe: pinned host reads -> H2D -> path -> D2H of the regions, double-buffered
+    # ---------------- the same steps fed over PCIe: pinned host reads -> H2D -> path -> D2H of the regions, every lane on its own stream
+    # (the copies of one lane overlap the kernels of the others)
     dt_pcie = None
     if a.pcie:
-        s_h2d, s_d2h = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         host_in = []
         for reads, dr in batches:
             host_in.append((dr.ascii.cpu().pin_memory(), dr.offs.cpu().pin_memory(), dr.lens.cpu().pin_memory()))
-        slots = [(torch.empty_like(batches[0][1].ascii), torch.empty_like(batches[0][1].offs), torch.empty_like(batches[0][1].lens)) for _ in range(2)]
-        host_out = [torch.empty(cap_regs, 8, dtype=torch.int32).pin_memory() for _ in range(2)]
-        ev_in = [torch.cuda.Event() for _ in range(2)]        # H2D of the slot finished
-        ev_done = [torch.cuda.Event() for _ in range(2)]      # the path no longer reads the slot / has written its regions
-        ev_out = [torch.cuda.Event() for _ in range(2)]       # D2H of the slot's regions finished
-
-        def upload(i):
-            sl = i & 1
-            with torch.cuda.stream(s_h2d):
-                s_h2d.wait_event(ev_done[sl])                 # the step that used this slot two steps ago is through
-                for dst, src in zip(slots[sl], host_in[i & 1]):
-                    dst.copy_(src, non_blocking=True)
-                ev_in[sl].record(s_h2d)
-
-        def pcie_loop(k):
-            for sl in range(2):
-                ev_done[sl].record(s_main); ev_out[sl].record(s_d2h)
-            upload(0)
-            for i in range(k):
-                sl = i & 1
-                if i + 1 < k:
-                    upload(i + 1)                             # next batch's reads cross PCIe while this batch computes
-                s_main.wait_event(ev_in[sl]); s_main.wait_event(ev_out[sl])
-                hot_path(*slots[sl], regs_out[sl])
-                ev_done[sl].record(s_main)
-                with torch.cuda.stream(s_d2h):
-                    s_d2h.wait_event(ev_done[sl])
-                    host_out[sl][: last["n_regs"]].copy_(regs_out[sl][: last["n_regs"]], non_blocking=True)
-                    ev_out[sl].record(s_d2h)
-            torch.cuda.synchronize()
-
-        pcie_loop(max(a.warmup, 1))
+        run_steps(max(a.warmup, n_lanes), host_in)
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pcie_loop(a.steps)
+        run_steps(a.steps, host_in)
         if distributed:
             dist.barrier()
         dt_pcie = time.perf_counter() - t0
@@ -372,14 +402,14 @@ def main():
         res = {
             "metric": "Mreads/s (150 bp single-end vs hg38-scale index; seed-and-extend hot path)", "value": round(value, 3), "unit": "Mreads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": f"{a.reads_per_gpu} synthetic {a.read_len} bp {'paired-end (interleaved)' if a.paired else 'single-end'} reads per GPU vs an hg38-scale FMD index: seeded synthetic "
                                    f"{a.genome_mbp:g} Mbp genome, 24 contigs, 50% planted repeats (mid-copy families, LINE-like, high-copy SINE-like, satellites, low-divergence segmental "
                                    f"duplications), N-runs; seq_len = {d.seq_len} rows{' > 2^32' if d.seq_len >> 32 else ''}; index built and verified on the device in setup; "
                                    "seeding = all SMEMs >= 19 bp + locate; extension = every left/right job the reference's chaining (mem_chain, mem_chain_flt, mem_chain2aln) produces; "
                                    "chaining, job construction with on-device reference fetch and the region merge run on the device inside the timed region (reads in, regions out); "
                                    "two different read batches alternate",
-                       "workload_key": workload_key, "reads_per_gpu": n_reads, "read_len": a.read_len, "paired_interleaved": bool(a.paired), "genome_mbp": a.genome_mbp,
+                       "batches_in_flight": n_lanes, "workload_key": workload_key, "reads_per_gpu": n_reads, "read_len": a.read_len, "paired_interleaved": bool(a.paired), "genome_mbp": a.genome_mbp,
                        "seq_len": int(d.seq_len), "index_bytes": int(d.bwt_t.numel() * 4 + d.sa_t.numel() * 4 + d.bits_t.numel() * 4 + pac_t.numel()), "sa_intv": a.sa_intv,
                        "seeds_per_read": round(st["n_seeds"] / n_reads, 2), "smems_per_read": round(st["n_smems"] / n_reads, 2), "ext_jobs_per_read": round(st["n_jobs"] / n_reads, 2),
                        "regions_per_read": round(st["n_regs"] / n_reads, 2), "reads_chained_by_a_whole_wave": st["n_heavy"],
@@ -394,8 +424,8 @@ def main():
         if dt_pcie:
             res["incl_pcie"] = {"value": round(total_reads * a.steps / dt_pcie / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(dt_pcie / a.steps * 1e3, 3),
                                 "h2d_bytes_per_step": int(pcie_bytes[0]), "d2h_bytes_per_step": int(pcie_bytes[1]),
-                                "how": "pinned host reads -> H2D -> path -> D2H of the regions into pinned host memory; next batch's H2D and previous batch's D2H "
-                                       "on two copy streams beside the compute stream (double-buffered)"}
+                                "how": "pinned host reads -> H2D -> path -> D2H of the regions into pinned host memory, every batch on its lane's stream: the copies "
+                                       "of one batch in flight overlap the kernels of the other(s)"}
         # ---------------- CPU baseline + roofline of the dominant kernel (N = 1 only)
         if world == 1 and a.cpu_sample > 0:
             ncores = effective_cores()
@@ -438,7 +468,7 @@ def main():
             cells = al["cells"] / max(al["n_jobs"], 1) * n_jobs
             prof = profile_counters(workload_key)
             names = {"forward": "smem_forward_kernel", "backward": "smem_backward_kernel", "locate": "locate_kernel",
-                     "extend": "extension kernel family (ext_closed_form, extend16<C>, extend16_static<C>, extend_wide<C>)", "chain": "chain_lane_kernel + chain_wave_kernel"}
+                     "extend": "extension kernel family (ext_closed_form, extpk<G,P> packed 16-bit, extend16<C> / extend16_static<C> / extend_wide<C> 32-bit)", "chain": "chain_lane_kernel + chain_wave_kernel"}
 
             def from_prof(k, field):
                 if not prof or k not in prof.get("families", {}):
@@ -472,15 +502,21 @@ def main():
                 ms_c = C.c_float(0); ops_c = C.c_double(0)
                 L.bmh_calib_valu.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]
                 cal = {}
-                for mode, nm in ((0, "independent_v_max_add"), (1, "dependent_chain"), (2, "dpp_row_shr_max")):
+                for mode, nm in ((0, "independent_v_max_add"), (1, "dependent_chain"), (2, "dpp_row_shr_max"), (4, "packed_u16_add_max")):
                     if L.bmh_calib_valu(mode, 8, 20000, None, C.byref(ms_c), C.byref(ops_c)) == 0:
                         cal[nm] = round(ops_c.value / (ms_c.value * 1e-3) / VALU_PEAK_LANEOPS, 3)
                 ext["valu"]["calibration_frac_of_peak_measured_now"] = cal
+                if cal.get("independent_v_max_add"):
+                    # what the chip sustains on plain integer VALU instructions, measured in this run: one wave64 instruction per ~4.4 cycles per
+                    # SIMD whatever the number of resident waves (scripts/calib_valu.py), i.e. about half of the 2-cycle figure of the guide
+                    ext["valu"]["measured_ceiling"] = round(cal["independent_v_max_add"] * VALU_PEAK_LANEOPS / 1e12, 2)
+                    ext["valu"]["frac_of_measured_ceiling"] = round(ext["valu"]["frac"] / cal["independent_v_max_add"], 4)
             issued = from_prof("extend", "valu_wave_instr_per_launch")
             if issued is not None:
                 ext["valu"]["issue_slot_frac"] = round(issued * 64.0 / (iso_ms["extend"] * 1e-3) / VALU_PEAK_LANEOPS, 4)
                 ext["valu"]["executed_lane_instr_per_reference_cell"] = round(issued * 64.0 / cells, 2)
                 ext["valu"]["source"] = f"from_profile profiles/{PROFILE_TAG}_pmc.json (SQ_INSTS_VALU summed over the whole family)"
+            ext["dtype_note"] = "DP cells as packed unsigned 16-bit pairs (v_pk_*_u16) where h0 + qlen*a < 4096, 32-bit lanes otherwise; rank arithmetic of the seeding is 32/64-bit popcounts"
             res["extension_stage"] = ext
             if a.next_rows:
                 try:

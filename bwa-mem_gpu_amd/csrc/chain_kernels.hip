@@ -32,14 +32,16 @@ struct chain_args_t {
 // src/bwamem.c:430-436), not the number located: on an hg38-like genome 0.25 % of the reads carry SMEMs with thousands of
 // occurrences (90 % of all located seeds) of which 500 each are used.  need[r] = that number; it sizes the read's scratch.
 // Reads that need more than heavy_thresh entries go to the wave kernels, one list per LDS size class.
-#define CH_N_CLASSES 7
-#define CH_HYBRID_CLASS 5
-__device__ __forceinline__ int ch_class_of(uint32_t need) { return need <= 64u ? 0 : need <= 128u ? 1 : need <= 256u ? 2 : need <= 512u ? 3 : need <= 1250u ? 4 : need <= 1860u ? 5 : 6; }
-// LDS entries per class; class 5 keeps only the arrays of the sequential phases in LDS (seeds, chains, the sorted chain index,
-// the sort keys: 84 bytes per entry) and the rest in the read's slice of the global scratch; class 4 (a read that samples
+#define CH_N_CLASSES 9
+#define CH_HYBRID_CLASS 7
+__device__ __forceinline__ int ch_class_of(uint32_t need) { return need <= 64u ? 0 : need <= 128u ? 1 : need <= 256u ? 2 : need <= 384u ? 3 : need <= 512u ? 4 : need <= 620u ? 5 : need <= 1250u ? 6 : need <= 1860u ? 7 : 8; }
+// LDS entries per class; the hybrid class keeps only the arrays of the sequential phases in LDS (seeds, chains, the sorted chain index,
+// the sort keys: 84 bytes per entry) and the rest in the read's slice of the global scratch; the last class (a read that samples
 // more than 1860 occurrences: four SMEMs of 465+ hits each) works in global memory altogether
-static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {64u, 128u, 256u, 512u, 1250u, 1860u, 0u};
-static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {8192u, 4096u, 2048u, 1024u, 512u, 256u, 256u};
+// (a read that samples one SMEM of 500+ occurrences plus a few more seeds needs 500-600 entries: on the hg38-like genome most of
+// the reads beyond 256 entries sit there, hence the 512 and 620 classes -- 620 entries is what still fits a CU twice)
+static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {64u, 128u, 256u, 384u, 512u, 620u, 1250u, 1860u, 0u};
+static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {8192u, 4096u, 2048u, 1024u, 1024u, 768u, 512u, 256u, 256u};
 
 __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 {
@@ -218,7 +220,7 @@ struct bmh_chain_ws {
 	ch_seed_t *seeds; ch_chain_t *chains; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx; ch_reg_t *regs; ch_est_t *est;
 	// per read
 	uint32_t *regs_per_read, *jobs_per_read, *reg_off, *job_off, *heavy_list, *need; float *frac_rep;
-	uint32_t *counters;            // [0..6] heavy_n per size class  [7] err  [8..] profile stamps
+	uint32_t *counters;            // [0..CH_N_CLASSES) heavy_n per size class  [CH_N_CLASSES] err  [12..] profile stamps
 	// contigs
 	int n_contigs; int64_t *ctg_off; int32_t *ctg_len;
 	// outputs, grown on demand
@@ -309,8 +311,8 @@ extern "C" void bmh_chain_last_timing(const bmh_chain_ws_t *w, float ms[8])
 {
 	for (int i = 0; i < 4; ++i) ms[i] = w->ms[i];
 	ms[4] = w->ms[4]; ms[5] = w->ms[5];
-	ms[6] = (float)(w->heavy_per_class[0] + w->heavy_per_class[1] + w->heavy_per_class[2] + w->heavy_per_class[3]);
-	ms[7] = (float)(w->heavy_per_class[4] + w->heavy_per_class[5] + w->heavy_per_class[6]);
+	ms[6] = ms[7] = 0.f;                                       // reads chained by a wave: up to 512 entries / beyond
+	for (int c = 0; c < CH_N_CLASSES; ++c) ms[c <= 4 ? 6 : 7] += (float)w->heavy_per_class[c];
 }
 
 extern "C" int bmh_chain_set_contigs(bmh_chain_ws_t *w, int n_contigs, const int64_t *offset, const int32_t *len)
@@ -359,7 +361,7 @@ static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_op
 #ifdef CH_PROFILE
 	{
 		const char *pr = getenv("BMH_CHAIN_PROF_READ");
-		if (pr) { A.x.prof = (long long *)(w->counters + 8); A.x.prof_read = (uint32_t)atoi(pr); }
+		if (pr) { A.x.prof = (long long *)(w->counters + 12); A.x.prof_read = (uint32_t)atoi(pr); }
 	}
 #endif
 }
@@ -453,7 +455,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 #ifdef CH_PROFILE
 	if (A.x.prof) {
 		long long pf[6];
-		HIPCK(hipMemcpy(pf, w->counters + 8, sizeof(pf), hipMemcpyDeviceToHost));
+		HIPCK(hipMemcpy(pf, w->counters + 12, sizeof(pf), hipMemcpyDeviceToHost));
 		fprintf(stderr, "chain phases of read %u (x10ns ticks): chains %lld  weights %lld  sort %lld  kept %lld  chain2aln %lld\n", A.x.prof_read,
 		        pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4]);
 	}

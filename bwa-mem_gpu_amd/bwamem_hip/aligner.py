@@ -208,11 +208,12 @@ class Aligner:
             if self.profile:
                 torch.cuda.synchronize(); _t.append(time.perf_counter()); _nm.append(name)
         lens, offs, ascii_ = rs.lens, np.ascontiguousarray(rs.offs), rs.ascii
-        # the reference's seed filter mem_flt_chained_seeds (src/bwamem.c:970-991) is not restated; it would run for these reads?
-        lmax = float(lens.max())
+        # the reference's seed filter mem_flt_chained_seeds (src/bwamem.c:970-991: reads beyond ~730 bp, or a small -W) is host code
+        # there and here: batches it applies to go through bmh_build_jobs (which restates it) instead of the device job builder
         mcw = self.copt.min_chain_weight
-        if lmax >= self.copt.min_seed_len and not ((1.1 * mcw if mcw else 5.5 * np.log(max(lmax, 2.0))) > 0.05 * lmax):
-            raise NotImplementedError(f"reads of {int(lmax)} bp with -W {mcw} go through the reference's mem_flt_chained_seeds, which is not restated")
+        lf = lens.astype(np.float64)
+        min_l = np.full(n, float(np.float32(1.1) * np.float32(mcw))) if mcw else 5.5 * np.log(np.maximum(lf, 2.0))
+        host_jobs = bool(((lens >= self.copt.min_seed_len) & ~(min_l > (np.float32(0.05) * lens.astype(np.float32)).astype(np.float64))).any())
         if int(lens.sum()) >= 1 << 31:
             raise ValueError("a batch holds 2^31 bases or more: offsets inside a batch are 32-bit (use a smaller batch_reads)")
         codes = _NT4[ascii_]
@@ -225,24 +226,41 @@ class Aligner:
         _lap("seed workspace")
         s = ws.seed_batch(self.index, r, o, l, self.copt.min_seed_len)
         _lap("seeding")
-        cw = ChainWorkspace(n, max(int(s.n_seeds), 1), opt=self.copt)
-        cw.set_materialize(False)
-        if len(self.contigs) > 1:
-            cw.set_contigs(self.contigs)
-        dj = cw.chain_batch(self.index, r, o, l, s)
-        nr, nj = int(dj.n_regs), int(dj.n_jobs)
-        out3 = torch.zeros(max(nj, 1), 3, dtype=torch.int32, device=dev)
-        regs = torch.zeros(max(nr, 1), 8, dtype=torch.int32, device=dev)
-        _lap("chain")
         e = self.ep                                             # the reference's GPU extension: deletion penalties for both gap kinds
-        cw.extend(out3, params=ExtParams(e.a, e.b, e.o_del, e.e_del, e.o_del, e.e_del, e.zdrop, e.end_bonus))
-        cw.merge(out3, regs)
-        _lap("extend+merge")
-        rpr = torch.empty(n, dtype=torch.int32, device=dev); fr = torch.empty(n, dtype=torch.float32, device=dev)
-        _memcpy_d2d(rpr.data_ptr(), dj.d_regs_per_read, 4 * n); _memcpy_d2d(fr.data_ptr(), dj.d_frac_rep, 4 * n)
-        regs_h = np.ascontiguousarray(regs[:nr].cpu().numpy())
-        rpr_h = np.ascontiguousarray(rpr.cpu().numpy().view(np.uint32)); fr_h = np.ascontiguousarray(fr.cpu().numpy())
-        _lap("D2H regions")
+        ext_p = ExtParams(e.a, e.b, e.o_del, e.e_del, e.o_del, e.e_del, e.zdrop, e.end_bonus)
+        cw = None
+        if host_jobs:
+            from .lib import HostJobs, seeds_to_host, extend_batch
+            hj = HostJobs(self.l_pac, codes, offs, lens, seeds_to_host(s, n), n_threads=self.n_threads, opt=self.copt,
+                          contigs=self.contigs if len(self.contigs) > 1 else None, pac=self.pac)
+            nr, nj = hj.n_regs, hj.n_jobs
+            _lap("chain (host builder with the seed filter)")
+            out3 = torch.zeros(max(nj, 1), 3, dtype=torch.int32, device=dev)
+            if nj:
+                d = [torch.from_numpy(np.ascontiguousarray(x).view(np.int32) if x.dtype == np.uint32 else np.ascontiguousarray(x)).to(dev) for x in hj.jobs()]
+                extend_batch(*d, out3, params=ext_p)
+            regs_h = np.ascontiguousarray(hj.merge(out3[:nj].cpu().numpy())) if nr else np.zeros((0, 8), np.int32)
+            rpr_h = np.ascontiguousarray(hj.regs_per_read.copy()); fr_h = np.ascontiguousarray(hj.frac_rep(), dtype=np.float32)
+            hj.free()
+            _lap("extend+merge")
+        else:
+            cw = ChainWorkspace(n, max(int(s.n_seeds), 1), opt=self.copt)
+            cw.set_materialize(False)
+            if len(self.contigs) > 1:
+                cw.set_contigs(self.contigs)
+            dj = cw.chain_batch(self.index, r, o, l, s)
+            nr, nj = int(dj.n_regs), int(dj.n_jobs)
+            out3 = torch.zeros(max(nj, 1), 3, dtype=torch.int32, device=dev)
+            regs = torch.zeros(max(nr, 1), 8, dtype=torch.int32, device=dev)
+            _lap("chain")
+            cw.extend(out3, params=ext_p)
+            cw.merge(out3, regs)
+            _lap("extend+merge")
+            rpr = torch.empty(n, dtype=torch.int32, device=dev); fr = torch.empty(n, dtype=torch.float32, device=dev)
+            _memcpy_d2d(rpr.data_ptr(), dj.d_regs_per_read, 4 * n); _memcpy_d2d(fr.data_ptr(), dj.d_frac_rep, 4 * n)
+            regs_h = np.ascontiguousarray(regs[:nr].cpu().numpy())
+            rpr_h = np.ascontiguousarray(rpr.cpu().numpy().view(np.uint32)); fr_h = np.ascontiguousarray(fr.cpu().numpy())
+            _lap("D2H regions")
         po = PostOpt.from_buffer_copy(self.po); po.id0 = id0
         self._lap = _lap; self._prof = (_t, _nm)
         if paired:
@@ -264,7 +282,9 @@ class Aligner:
         txt = format_sam(po, names, codes, offs, lens, self.contigs, fin if m else np.zeros((1, 16), np.int32), opr, slot, aln_h, cg_h, md_h,
                          as_bytes=as_bytes)
         _lap("format (host)")
-        cw.free(); ws.free()
+        if cw is not None:
+            cw.free()
+        ws.free()
         if self.profile:
             import sys
             sys.stderr.write("[aligner] " + ", ".join("%s %.1f ms" % (nm, (_t[i + 1] - _t[i]) * 1e3) for i, nm in enumerate(_nm)) + "\n")
@@ -307,7 +327,9 @@ class Aligner:
         aln_h, cg_h, md_h = self._cigars(r, o, l, fin, sel)
         txt = format_sam(po, names, codes, offs, lens, self.contigs, fin if m else np.zeros((1, 16), np.int32), opr, slot, aln_h, cg_h, md_h,
                          h_rec=h_rec, unflag=unflag, as_bytes=self._as_bytes)
-        cw.free(); ws.free()
+        if cw is not None:
+            cw.free()
+        ws.free()
         return txt
 
     def align_file(self, reads_fa: str, out, batch_reads: int = 500_000, paired: bool = False) -> int:

@@ -565,7 +565,8 @@ class HostJobs:
             L.bmh_chain_opt_default(C.byref(o))
         self.opt = o
         self._genome = genome_fwd
-        l_pac = int(genome_fwd.shape[0])
+        l_pac = int(genome_fwd) if np.isscalar(genome_fwd) else int(genome_fwd.shape[0])       # (a length, when the caller passes the pac)
+        self.l_pac = l_pac
         _t0 = _time.time()
         if pac is None:
             pad = (-l_pac) % 4
@@ -629,7 +630,7 @@ class HostJobs:
         regs = np.ascontiguousarray(regs, dtype=np.int32)
         out = np.zeros((max(len(regs), 1), 16), np.int32); opr = np.zeros(max(len(k[3]), 1), np.uint32)
         fr = np.ascontiguousarray(self.frac_rep(), dtype=np.float32)
-        m = L.bmh_finalize_regs(C.byref(co), C.byref(ep), C.byref(po), len(self._genome), _np_ptr(k[0], _u8p), len(k[3]), _np_ptr(k[1], _u8p),
+        m = L.bmh_finalize_regs(C.byref(co), C.byref(ep), C.byref(po), self.l_pac, _np_ptr(k[0], _u8p), len(k[3]), _np_ptr(k[1], _u8p),
                                 _np_ptr(k[2], _u64p), _np_ptr(regs, _i32p), _np_ptr(np.ascontiguousarray(self.regs_per_read), _u32p),
                                 fr.ctypes.data_as(C.POINTER(C.c_float)), self.n_contigs,
                                 self.ctg_off.ctypes.data_as(C.c_void_p) if self.ctg_off is not None else None,

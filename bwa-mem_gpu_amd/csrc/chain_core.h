@@ -17,6 +17,7 @@
 //
 // Compiles as plain C++ too (tests/chain_core_host.cpp) so the logic is testable without a GPU.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 #include "../../include/bwamem_hip.h"
 
@@ -46,7 +47,7 @@ struct ch_ctx_t {
 	ch_reg_t *regs;               // output slots, prefix[read] + i in creation order
 	uint32_t *regs_per_read, *jobs_per_read;
 	float *frac_rep;              // per read: part of the read covered by SMEMs with more than max_occ occurrences (mem_chain :415-459)
-	int *err;                     // != 0: a read was longer than 700 bp (mem_flt_chained_seeds is not restated)
+	int *err;                     // 1: a read the reference's seed filter applies to (longer than ~730 bp, or a small -W): host builder only
 	long long *prof; uint32_t prof_read;
 };
 
@@ -284,7 +285,11 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 	uint32_t *klist = sc.klist; uint64_t *srt = sc.srt; uint32_t *cidx = sc.cidx; ch_est_t *E = sc.E; ch_reg_t *R = x.regs + base;
 	x.regs_per_read[r] = 0; x.jobs_per_read[r] = 0; x.frac_rep[r] = 0.f;
 	if (n == 0 || l_query < o.min_seed_len) return;
-	if (l_query > CH_MAX_READ_LEN) { *x.err = 1; return; }
+	{   // the reference's seed filter (mem_flt_chained_seeds, src/bwamem.c:970-991) is host code, restated in bmh_build_jobs only: a
+		// read it applies to -- (W ? 1.1f W : 5.5 ln l) <= 0.05f l, i.e. beyond ~730 bp or a small -W -- is refused here
+		const double min_l = o.min_chain_weight ? (double)(1.1f * (float)o.min_chain_weight) : (double)5.5f * log((double)l_query);
+		if (l_query > CH_MAX_READ_LEN || !(min_l > (double)(0.05f * (float)l_query))) { *x.err = 1; return; }
+	}
 	const uint64_t *g_rbeg = x.rbeg + base; const int32_t *g_qbeg = x.qbeg + 2 * (size_t)base; const uint32_t *g_score = x.score + base;
 
 	// ---------------------------------------------------------------- mem_chain

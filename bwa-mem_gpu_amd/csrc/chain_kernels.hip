@@ -450,7 +450,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	(void)hipEventElapsedTime(&w->ms[2], w->ev_t[3], w->ev_t[4]); (void)hipEventElapsedTime(&w->ms[3], w->ev_t[0], w->ev_t[5]);
 	for (int c = 0; c < CH_N_CLASSES; ++c) w->heavy_per_class[c] = w->h_pin[2 + c];
 	if (getenv("BMH_CHAIN_STATS")) chain_print_stats(w);
-	if (w->h_pin[2 + CH_N_CLASSES] == 1) { bmh_set_error("bmh_chain_batch: a read is longer than %d bp (mem_flt_chained_seeds is not restated)", CH_MAX_READ_LEN); return BMH_EINVAL; }
+	if (w->h_pin[2 + CH_N_CLASSES] == 1) { bmh_set_error("bmh_chain_batch: a read is longer than %d bp or goes through the reference's seed filter (mem_flt_chained_seeds: reads beyond ~730 bp, small -W): use bmh_build_jobs for this batch", CH_MAX_READ_LEN); return BMH_EINVAL; }
 	if (w->h_pin[2 + CH_N_CLASSES] != 0) { bmh_set_error("bmh_chain_batch: internal error %u in the chaining kernel", w->h_pin[2 + CH_N_CLASSES]); return BMH_ENODEV; }
 #ifdef CH_PROFILE
 	if (A.x.prof) {
@@ -671,7 +671,7 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	(void)hipEventElapsedTime(&w->ms[2], w->ev_t[3], w->ev_t[4]); (void)hipEventElapsedTime(&w->ms[3], w->ev_t[0], w->ev_t[5]);
 	for (int c = 0; c < CH_N_CLASSES; ++c) w->heavy_per_class[c] = w->h_pin[2 + c];
 	if (getenv("BMH_CHAIN_STATS")) chain_print_stats(w);
-	if (w->h_pin[2 + CH_N_CLASSES] == 1) { bmh_set_error("bmh_chain_extend_merge: a read is longer than %d bp (mem_flt_chained_seeds is not restated)", CH_MAX_READ_LEN); return BMH_EINVAL; }
+	if (w->h_pin[2 + CH_N_CLASSES] == 1) { bmh_set_error("bmh_chain_extend_merge: a read is longer than %d bp or goes through the reference's seed filter (mem_flt_chained_seeds: reads beyond ~730 bp, small -W): use bmh_build_jobs for this batch", CH_MAX_READ_LEN); return BMH_EINVAL; }
 	if (w->h_pin[2 + CH_N_CLASSES] != 0) { bmh_set_error("bmh_chain_extend_merge: internal error %u in the chaining kernel", w->h_pin[2 + CH_N_CLASSES]); return BMH_ENODEV; }
 	const uint64_t n_regs_b = w->h_pin[32], n_jobs_b = w->h_pin[33];
 	const uint64_t n_regs = n_regs_a + n_regs_b, n_jobs = n_jobs_a + n_jobs_b;

@@ -787,9 +787,9 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 
 // ------------------------------------------------------------------ host side
 
-// classes: 0 = unsupported length (query longer than 704 bases: all three outputs INT32_MIN, counted, see
-// bmh_extend_last_unsupported); 1..18 = extend16_kernel<C>; 19..25 = extend_wide_kernel<5..11>
-#define EXT_WIDE_MAX_C 11
+// classes: 0 = unsupported length (query longer than 768 bases: all three outputs INT32_MIN, counted, see
+// bmh_extend_last_unsupported); 1..18 = extend16_kernel<C>; 19..26 = extend_wide_kernel<5..12>
+#define EXT_WIDE_MAX_C 12
 #define EXT_N_CLS 41
 #define EXT_DONE_CLS 27     // decided by the closed-form prefilter: no DP
 #define EXT16_MAX_C 18
@@ -885,7 +885,7 @@ extern "C" float bmh_extend_last_ms(void)
 	return ms;
 }
 
-// number of jobs of the thread's last bmh_extend_batch whose query was longer than the kernels support (704 bases); their
+// number of jobs of the thread's last bmh_extend_batch whose query was longer than the kernels support (768 bases); their
 // outputs are INT32_MIN.  Waits for the batch.
 extern "C" int64_t bmh_extend_last_unsupported(void)
 {
@@ -1055,7 +1055,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	launch16<13>(a, S[0], g16); launch16<14>(a, S[1], g16); launch16<15>(a, S[2], g16); launch16<16>(a, S[3], g16);
 	launch16<17>(a, S[0], g16); launch16<18>(a, S[1], g16);
 	launch_wide<5>(a, S[2], gw); launch_wide<6>(a, S[3], gw); launch_wide<7>(a, S[2], gw); launch_wide<8>(a, S[3], gw);
-	launch_wide<9>(a, S[0], gw); launch_wide<10>(a, S[1], gw); launch_wide<11>(a, S[2], gw);
+	launch_wide<9>(a, S[0], gw); launch_wide<10>(a, S[1], gw); launch_wide<11>(a, S[2], gw); launch_wide<12>(a, S[3], gw);
 	for (int i = 0; i < 4; ++i) { HIPCK(hipEventRecord(g_scr.join[i], g_scr.side[i])); HIPCK(hipStreamWaitEvent(st, g_scr.join[i], 0)); }
 	HIPCK(hipEventRecord(g_scr.ev1, st));
 	HIPCK(hipGetLastError());

@@ -203,9 +203,9 @@ void gasal_aln_async(gasal_gpu_storage_t *s, const uint32_t qb, const uint32_t t
 	if (n > s->host_max_n_alns) FATAL("gasal_aln_async: %u alignments > host_max_n_alns %u", n, s->host_max_n_alns);
 	if (qb > s->extensible_host_unpacked_query_batch->data_size || tb > s->extensible_host_unpacked_target_batch->data_size)
 		FATAL("gasal_aln_async: batch bytes beyond what was filled");
-	// the DP kernels take queries of up to 704 bases (GASAL2 has a compile-time MAX_SEQ_LEN as well, README.md:38): refuse loudly
+	// the DP kernels take queries of up to 768 bases (GASAL2 has a compile-time MAX_SEQ_LEN as well, README.md:38): refuse loudly
 	for (uint32_t i = 0; i < n; ++i)
-		if (s->host_query_batch_lens[i] > 704u) FATAL("gasal_aln_async: alignment %u has a query of %u bases; this library supports up to 704", i, s->host_query_batch_lens[i]);
+		if (s->host_query_batch_lens[i] > 768u) FATAL("gasal_aln_async: alignment %u has a query of %u bases; this library supports up to 768", i, s->host_query_batch_lens[i]);
 	// BMH_GASAL_DUMP=<file>: append every submitted job (qlen, tlen, h0, bases) -- lets tests compare the job
 	// stream of the reference's own host code with bmh_build_jobs
 	static const char *dump = getenv("BMH_GASAL_DUMP");

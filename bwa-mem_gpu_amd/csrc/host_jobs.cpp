@@ -5,8 +5,9 @@
 //   job results -> regions     mem_align1_core    :2297-2303 (score = L + R - seedlen, qb/qe/rb/re from the part ends)
 // (SURVEY.md section 8f rank 1).  The reference runs this per read on its host threads; so do we (std::thread
 // over contiguous read ranges), producing one flat batch of extension jobs for bmh_extend_batch.
-// mem_flt_chained_seeds (:970-990) is a no-op for reads shorter than ~790 bp (min_l > 0.05 * l_query) and is not
-// restated; reads that long are rejected.
+//   seed filter               mem_flt_chained_seeds :970-991 + mem_seed_sw :774-807: a no-op while min_l > 0.05 * l_query (reads
+//                             up to ~730 bp at the default -W 0); beyond that, or with a small explicit -W, every seed of the
+//                             kept chains is re-scored by a local alignment of its neighbourhood (bmh_local_sw = ksw_align2)
 //
 // Job order: per read, per region in creation order, LEFT job then RIGHT job -- the reference's SHORT/LONG split
 // (:1396-1426) only decides which GASAL batch a job rides in, results are matched back by position.
@@ -20,6 +21,7 @@
 #include <vector>
 #include "bmh_internal.h"
 #include "klib_sort.h"
+#include "local_sw.h"
 
 namespace {
 
@@ -166,6 +168,15 @@ void chain_flt(const bmh_chain_opt_t &o, std::vector<Chain> &a)     // mem_chain
 	size_t kk = 0;
 	for (size_t q = 0; q < a.size(); ++q) if (a[q].kept != 0) { if (kk != q) a[kk] = std::move(a[q]); ++kk; }
 	a.resize(kk);
+}
+
+// does the reference's seed filter run for a read of this length?  (src/bwamem.c:972-977; MEM_HSP_COEF 1.1f and MEM_SEEDSW_COEF
+// 0.05f are float constants there: the products are formed in float, the comparison in double)
+inline bool seed_filter_applies(const bmh_chain_opt_t &o, int l_query, int *min_HSP_score)
+{
+	const double min_l = o.min_chain_weight ? (double)(1.1f * (float)o.min_chain_weight) : (double)5.5f * log((double)l_query);
+	if (min_HSP_score) *min_HSP_score = (int)(o.a * min_l + .499);
+	return !(min_l > (double)(0.05f * (float)l_query));
 }
 
 struct Out {
@@ -324,6 +335,59 @@ void chain2aln(const Ctx &x, uint32_t r, int l_query, const uint8_t *query, cons
 	}
 }
 
+// mem_seed_sw :774-807: local alignment score of the seed's neighbourhood (50 bases either side), -1 when the seed or its window
+// is long enough to be trusted as it is
+int seed_sw(const Ctx &x, int l_query, const uint8_t *query, const Seed &s, std::vector<uint8_t> &qbuf, std::vector<uint8_t> &tbuf)
+{
+	const int SHORT_EXT = 50, SHORT_LEN = 200;                      // MEM_SHORT_EXT, MEM_SHORT_LEN
+	const int64_t l_pac = x.ctg.l_pac;
+	if (s.len >= SHORT_LEN) return -1;
+	int qb = s.qbeg, qe = s.qbeg + s.len;
+	int64_t rb = s.rbeg, re = s.rbeg + s.len;
+	const int64_t mid = (rb + re) >> 1;
+	qb -= SHORT_EXT; qb = qb > 0 ? qb : 0;
+	qe += SHORT_EXT; qe = qe < l_query ? qe : l_query;
+	rb -= SHORT_EXT; rb = rb > 0 ? rb : 0;
+	re += SHORT_EXT; re = re < l_pac << 1 ? re : l_pac << 1;
+	if (rb < l_pac && l_pac < re) { if (mid < l_pac) re = l_pac; else rb = l_pac; }
+	if (qe - qb >= SHORT_LEN || re - rb >= SHORT_LEN) return -1;
+	{   // bns_fetch_seq(bns, pac, &rb, mid, &re, &rid): the window is clipped to the sequence that holds mid (src/bntseq.c:531-556)
+		int is_rev;
+		const int rid = pos2rid(x.ctg, depos(x.ctg, mid, &is_rev));
+		int64_t far_beg = x.ctg.n > 1 ? x.ctg.offset[rid] : 0, far_end = far_beg + (x.ctg.n > 1 ? x.ctg.len[rid] : l_pac);
+		if (is_rev) { const int64_t tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
+		rb = rb > far_beg ? rb : far_beg;
+		re = re < far_end ? re : far_end;
+	}
+	qbuf.assign(query + qb, query + qe);
+	tbuf.resize((size_t)(re - rb));
+	for (int64_t i = 0; i < re - rb; ++i) tbuf[(size_t)i] = (uint8_t)text_base(x.pac, l_pac, rb + i);
+	bmh_ext_params_t p; memset(&p, 0, sizeof(p));
+	p.a = x.o->a; p.b = x.o->b; p.o_del = x.o->o_del; p.e_del = x.o->e_del; p.o_ins = x.o->o_ins; p.e_ins = x.o->e_ins;
+	return bmh_local_sw(qe - qb, qbuf.data(), (int)(re - rb), tbuf.data(), p, BMH_SW_XSTART).score;     // ksw_align2(..., KSW_XSTART, 0)
+}
+
+// mem_flt_chained_seeds :970-991: seeds of the kept chains re-scored, the weak ones dropped (chains may end up empty: mem_chain2aln
+// returns at once for those, :1187)
+void flt_chained_seeds(const Ctx &x, int l_query, const uint8_t *query, std::vector<Chain> &a)
+{
+	int min_HSP_score;
+	if (!seed_filter_applies(*x.o, l_query, &min_HSP_score)) return;
+	std::vector<uint8_t> qbuf, tbuf;
+	for (Chain &c : a) {
+		size_t k = 0;
+		for (size_t j = 0; j < c.seeds.size(); ++j) {
+			Seed s = c.seeds[j];
+			s.score = seed_sw(x, l_query, query, s, qbuf, tbuf);
+			if (s.score < 0 || s.score >= min_HSP_score) {
+				s.score = s.score < 0 ? s.len * x.o->a : s.score;
+				c.seeds[k++] = s;
+			}
+		}
+		c.seeds.resize(k);
+	}
+}
+
 void worker(const Ctx &x, uint32_t r0, uint32_t r1, Out &O)
 {
 	std::vector<Chain> chains;
@@ -335,6 +399,7 @@ void worker(const Ctx &x, uint32_t r0, uint32_t r1, Out &O)
 		make_chains(x, r, len, chains);
 		if (!chains.empty()) O.frac_rep[r - r0] = chains[0].frac_rep;
 		chain_flt(*x.o, chains);
+		flt_chained_seeds(x, len, query, chains);
 		const size_t reg0 = O.regs.size();
 		for (const Chain &c : chains) chain2aln(x, r, len, query, c, reg0, O);
 		O.regs_per_read[r - r0] = (uint32_t)(O.regs.size() - reg0);
@@ -363,18 +428,6 @@ extern "C" bmh_jobs_t *bmh_build_jobs(const bmh_chain_opt_t *opt, int64_t l_pac,
                                       const uint32_t *n_ref_pos, const uint32_t *prefix, int n_threads)
 {
 	if (!opt || !pac || (n_reads && (!reads || !read_offs || !read_lens || !n_ref_pos || !prefix))) { bmh_set_error("bmh_build_jobs: null argument"); return nullptr; }
-	// mem_flt_chained_seeds (src/bwamem.c:970-991: a local alignment around every seed, seeds re-scored and filtered) is not
-	// restated; the reference skips it when min_l > 0.05 * l_query, which holds for reads up to ~700 bp at the default
-	// -W 0 (min_l = 5.5 ln l) but not for a small explicit -W (min_l = 1.1 W, MEM_HSP_COEF of this fork)
-	for (uint32_t r = 0; r < n_reads; ++r) {
-		const double l = (double)read_lens[r];
-		const double min_l = opt->min_chain_weight ? 1.1 * opt->min_chain_weight : 5.5 * log(l > 1 ? l : 1.);
-		if (read_lens[r] >= (uint32_t)opt->min_seed_len && !(min_l > 0.05 * l)) {        // (shorter reads have no seeds to filter)
-			bmh_set_error("bmh_build_jobs: read %u (%u bp, min_chain_weight %d) would go through the reference's seed filter mem_flt_chained_seeds, which is not restated",
-			              r, read_lens[r], opt->min_chain_weight);
-			return nullptr;
-		}
-	}
 	Ctx x; x.o = opt; x.ctg = {l_pac, n_contigs, contig_offset, contig_len}; x.pac = pac;
 	x.reads = reads; x.roffs = read_offs; x.rlens = read_lens; x.rbeg = rbeg; x.qbeg = qbeg; x.score = score; x.n_ref = n_ref_pos; x.prefix = prefix;
 	if (n_threads < 1) n_threads = 1;

@@ -155,7 +155,7 @@ int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, const uint32_t 
                      const uint32_t *d_h0, uint32_t n, const bmh_ext_params_t *p,
                      int32_t *d_out, int32_t *d_raw, void *stream);
 
-/* Queries longer than 704 bases are not supported by the DP kernels (the reference's GASAL2 build has a compile-time
+/* Queries longer than 768 bases are not supported by the DP kernels (the reference's GASAL2 build has a compile-time
  * MAX_SEQ_LEN too, README.md:38): such a job gets INT32_MIN in all three outputs and is counted; this returns the count for the
  * calling thread's last bmh_extend_batch (waits for it; -1 on a HIP error).  The reference-compatible layer (gasal_aln_async)
  * refuses such a batch up front; bmh_chain_batch only admits reads up to 700 bases, whose flanks always fit. */
@@ -185,9 +185,10 @@ void bmh_chain_opt_default(bmh_chain_opt_t *o);
  * restating mem_chain / mem_chain_flt / mem_chain2aln (src/bwamem.c:404-477, 487-559, 1170-1479).
  * reads: nt4 codes; pac: 2-bit forward strand (the .pac file body); contigs: n_contigs offsets/lens
  * (n_contigs <= 1: one sequence of l_pac bases).  Jobs come out per read, per region, LEFT then RIGHT.
- * Not restated: mem_flt_chained_seeds (src/bwamem.c:970-991), which the reference runs when
- * (min_chain_weight ? 1.1 * min_chain_weight : 5.5 ln l_query) <= 0.05 * l_query -- reads beyond ~700 bp, or a small
- * explicit -W; bmh_build_jobs refuses such input, callers of bmh_chain_batch must not pass it. */
+ * Includes the seed filter mem_flt_chained_seeds + mem_seed_sw (src/bwamem.c:970-991, 774-807), which the reference runs when
+ * (min_chain_weight ? 1.1f * min_chain_weight : 5.5 ln l_query) <= 0.05f * l_query -- reads beyond ~730 bp, or a small explicit
+ * -W: every seed of the kept chains is re-scored by a local alignment of its neighbourhood (ksw_align2 semantics) and weak
+ * seeds are dropped.  It is host code in the reference and here: bmh_chain_batch refuses such reads (BMH_EINVAL). */
 typedef struct bmh_jobs bmh_jobs_t;
 bmh_jobs_t *bmh_build_jobs(const bmh_chain_opt_t *opt, int64_t l_pac, const uint8_t *pac, int n_contigs,
                            const int64_t *contig_offset, const int32_t *contig_len, uint32_t n_reads,

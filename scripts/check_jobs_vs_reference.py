@@ -19,6 +19,7 @@ work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/jobs_vs_ref"
 n_genome = int(float(sys.argv[2])) if len(sys.argv) > 2 else 2_000_000
 n_reads = int(float(sys.argv[3])) if len(sys.argv) > 3 else 5000
 L = int(sys.argv[4]) if len(sys.argv) > 4 else 150
+extra = sys.argv[5:]                     # further gase_aln options, passed to the reference and mirrored in bmh_chain_opt_t: -W <min_chain_weight>
 os.makedirs(work, exist_ok=True)
 prefix = os.path.join(work, "g.fa")
 g = synth.make_genome(n_genome, seed=42)
@@ -31,7 +32,7 @@ if os.path.exists(dump):
     os.remove(dump)
 sam = os.path.join(work, "out.sam")
 with open(sam, "w") as f:
-    r = subprocess.run([exe, "gase_aln", "-t", "1", "-l", str(L), prefix, fq], stdout=f, stderr=subprocess.PIPE, cwd=work,
+    r = subprocess.run([exe, "gase_aln", "-t", "1", "-l", str(L)] + extra + [prefix, fq], stdout=f, stderr=subprocess.PIPE, cwd=work,
                        env=dict(os.environ, BMH_GASAL_DUMP=dump))
 assert r.returncode == 0, r.stderr.decode()[-2000:]
 raw = np.fromfile(dump, dtype=np.uint8)
@@ -46,7 +47,12 @@ while p < raw.size:
 seeds = B.seed_file(prefix, fq, 19)
 flat = reads.reshape(-1); offs = np.arange(n_reads, dtype=np.uint64) * L; lens = np.full(n_reads, L, np.uint32)
 t0 = time.time()
-hj = HostJobs(g, flat, offs, lens, seeds, n_threads=8)
+from bwamem_hip.lib import ChainOpt
+import ctypes as C
+co = ChainOpt(); B.load_library().bmh_chain_opt_default(C.byref(co))
+if "-W" in extra:
+    co.min_chain_weight = int(extra[extra.index("-W") + 1])
+hj = HostJobs(g, flat, offs, lens, seeds, n_threads=8, opt=co)
 print("bmh_build_jobs: %d jobs, %d regions for %d reads in %.2fs" % (hj.n_jobs, hj.n_regs, n_reads, time.time() - t0))
 ours = collections.Counter()
 for i in range(hj.n_jobs):

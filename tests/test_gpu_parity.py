@@ -260,8 +260,8 @@ def test_extension_long_queries(hip, oracle):
     want3, want6, _ = oracle.extend_batch(*jobs, want_raw=True)
     got3, got6 = gpu_extend(hip, jobs)
     assert np.array_equal(got6, want6) and np.array_equal(got3, want3)
-    # up to the supported maximum of 704 bases (flanks of a 700 bp read, the longest the chaining stage admits)
-    jobs = common.make_ext_jobs(500, np.random.default_rng(24), maxq=704)
+    # up to the supported maximum of 768 bases (flanks of the reads the chaining stages admit)
+    jobs = common.make_ext_jobs(500, np.random.default_rng(24), maxq=768)
     assert (jobs[2] > 512).sum() > 50
     want3, want6, _ = oracle.extend_batch(*jobs, want_raw=True)
     got3, got6 = gpu_extend(hip, jobs)
@@ -269,8 +269,8 @@ def test_extension_long_queries(hip, oracle):
     assert hip.load_library().bmh_extend_last_unsupported() == 0
     # beyond it: marked, counted, never silently wrong
     rng = np.random.default_rng(25)
-    q = rng.integers(0, 4, size=705 + 30, dtype=np.uint8); t = rng.integers(0, 4, size=900 + 40, dtype=np.uint8)
-    jobs = (q, np.array([0, 705], np.uint32), np.array([705, 30], np.uint32), t, np.array([0, 900], np.uint32), np.array([900, 40], np.uint32), np.array([30, 25], np.uint32))
+    q = rng.integers(0, 4, size=769 + 30, dtype=np.uint8); t = rng.integers(0, 4, size=900 + 40, dtype=np.uint8)
+    jobs = (q, np.array([0, 769], np.uint32), np.array([769, 30], np.uint32), t, np.array([0, 900], np.uint32), np.array([900, 40], np.uint32), np.array([30, 25], np.uint32))
     got3, _ = gpu_extend(hip, jobs)
     assert (got3[0] == np.iinfo(np.int32).min).all() and hip.load_library().bmh_extend_last_unsupported() == 1
     want3, _, _ = oracle.extend_batch(*jobs)
@@ -359,7 +359,8 @@ def test_host_job_builder_matches_reference_host_code(hip, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists(os.path.join(root, "build", "dropin", "bwa-gasal2")):
         pytest.skip("build/dropin/bwa-gasal2 not built (needs /root/reference at build time)")
-    for args in (["1500000", "3000", "150"], ["1500000", "1500", "300"]):
+    # (the -W 5 and the 800 bp runs go through the reference's seed filter mem_flt_chained_seeds / mem_seed_sw, src/bwamem.c:970-991)
+    for args in (["1500000", "3000", "150"], ["1500000", "1500", "300"], ["1500000", "2000", "150", "-W", "5"], ["1500000", "300", "740"]):
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_jobs_vs_reference.py"), str(tmp_path)] + args,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         out = r.stdout.decode()

@@ -109,6 +109,57 @@ extern "C" bmh_index_t *bmh_index_from_device(uint64_t primary, const uint64_t L
 	return ix;
 }
 
+// ---- several GPUs from C: the index lives on every device, the reads shard, one host worker thread per
+// device.  The copy goes device to device (hipMemcpyPeer: xGMI between the GPUs of a node); the Python launcher does the same step
+// with one RCCL broadcast per array (bwamem_hip/parallel.py).
+extern "C" int bmh_index_replicate(const bmh_index_t *src, int src_device, int dst_device, bmh_index_t **out)
+{
+	if (!src || !out) { bmh_set_error("bmh_index_replicate: null argument"); return BMH_EINVAL; }
+	*out = nullptr;
+	int prev = 0;
+	if (hipGetDevice(&prev) != hipSuccess) { bmh_set_error("bmh_index_replicate: no HIP device"); return BMH_ENODEV; }
+	const fmd_dev_t &f = src->dev;
+	const size_t bwt_bytes = ((size_t)((f.seq_len + 63) / 64) + 1) * 32, sa_bytes = (size_t)f.n_sa * 4, bits_bytes = (size_t)(f.n_sa / 32 + 1) * 4;
+	const size_t pac_bytes = f.pac ? (size_t)(f.l_pac / 4 + 1) + 16 : 0;
+	bmh_index *ix = (bmh_index *)calloc(1, sizeof(bmh_index));
+	*ix = *src; ix->owns = true; ix->owns_sa = false;
+	void *d_bwt = nullptr, *d_sa = nullptr, *d_bits = nullptr, *d_pac = nullptr;
+	bool ok = hipSetDevice(dst_device) == hipSuccess;
+	ok = ok && hipMalloc(&d_bwt, bwt_bytes) == hipSuccess && hipMalloc(&d_sa, sa_bytes) == hipSuccess && hipMalloc(&d_bits, bits_bytes) == hipSuccess;
+	if (ok && pac_bytes) ok = hipMalloc(&d_pac, pac_bytes) == hipSuccess && hipMemset(d_pac, 0, pac_bytes) == hipSuccess;
+	auto cp = [&](void *dst, const void *s_, size_t n) {
+		return src_device == dst_device ? hipMemcpy(dst, s_, n, hipMemcpyDeviceToDevice) == hipSuccess : hipMemcpyPeer(dst, dst_device, s_, src_device, n) == hipSuccess;
+	};
+	// (the source's bwt buffer may be the caller's: bmh_index_from_device promises whole blocks only, which is what is copied)
+	ok = ok && cp(d_bwt, f.blocks, bwt_bytes) && cp(d_sa, f.sa, sa_bytes) && cp(d_bits, f.sa_bits, bits_bytes);
+	if (ok && pac_bytes) ok = cp(d_pac, f.pac, (size_t)(f.l_pac / 4 + 1));
+	ok = ok && hipDeviceSynchronize() == hipSuccess;
+	if (!ok) {
+		bmh_set_error("bmh_index_replicate (device %d -> %d): %s", src_device, dst_device, hipGetErrorString(hipGetLastError()));
+		void *ps[] = {d_bwt, d_sa, d_bits, d_pac};
+		for (void *p : ps) if (p) (void)hipFree(p);
+		free(ix); (void)hipSetDevice(prev);
+		return BMH_ENOMEM;
+	}
+	ix->dev.blocks = (const uint4 *)d_bwt; ix->dev.sa = (const uint32_t *)d_sa; ix->dev.sa_bits = (const uint32_t *)d_bits; ix->dev.pac = (const uint8_t *)d_pac;
+	(void)hipSetDevice(prev);
+	*out = ix;
+	return BMH_OK;
+}
+
+// contiguous shard of n units for worker `rank` of `world`, cut at multiples of `multiple` (2: interleaved pairs stay together);
+// the same arithmetic as bwamem_hip/parallel.py shard_range
+extern "C" void bmh_shard_range(uint64_t n, int rank, int world, uint32_t multiple, uint64_t *lo, uint64_t *hi)
+{
+	if (multiple < 1) multiple = 1;
+	if (world < 1) world = 1;
+	const uint64_t units = n / multiple;
+	uint64_t a = units * (uint64_t)rank / (uint64_t)world * multiple, b = units * (uint64_t)(rank + 1) / (uint64_t)world * multiple;
+	if (rank == world - 1) b = n;
+	if (lo) *lo = a;
+	if (hi) *hi = b;
+}
+
 // Denser suffix-array samples, computed on the device from the sparser ones (each new sample walks LF to the next old
 // one, src/bwt.c:105-115).  The reference's GPU index keeps every 16th row (src/bwtindex.c:324) because its cards
 // hold 16-32 GB; with 288 GB the samples of every 4th row -- or all of them -- fit beside the index, and locating a

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include "bmh_internal.h"
 #include "../../include/gasal2_root/GASAL2/include/gasal.h"
@@ -45,6 +46,7 @@ void Parameters::fileopen() {}
 void gasal_set_device(int gpu_select, bool) { HIPX(hipSetDevice(gpu_select)); }
 
 struct storage_impl {
+	int dev;                      // the device this storage lives on (BMH_DEVICES=N spreads the storages over the GPUs)
 	hipStream_t stream;
 	uint8_t *d_q, *d_t;
 	uint32_t *d_qoff, *d_toff, *d_qlen, *d_tlen, *d_h0;
@@ -160,10 +162,19 @@ void gasal_init_streams(gasal_gpu_storage_v *v, int host_max_q, int gpu_max_q, i
                         int gpu_max_n, Parameters *params)
 {
 	if (params && params->algo != KSW) FATAL("gasal_init_streams: only algo == KSW is implemented (the reference uses nothing else)");
+	// BMH_DEVICES=N: the storages (the reference creates one vector of them per host thread, src/fastmap.c:487-507) are dealt out
+	// to the N devices in turn, starting from the calling thread's current device; every later call on a storage switches to its
+	// device.  The extension needs nothing but the batch itself on the device, so this is all the multi-GPU support it takes.
+	static const int n_devices_env = [] { const char *e = getenv("BMH_DEVICES"); const int q = e ? atoi(e) : 1; return q >= 1 ? q : 1; }();
+	static std::atomic<unsigned> next_storage{0};
+	int n_dev = 1, home = 0;
+	HIPX(hipGetDeviceCount(&n_dev)); HIPX(hipGetDevice(&home));
 	for (int i = 0; i < v->n; ++i) {
 		gasal_gpu_storage_t *s = &v->a[i];
 		storage_impl *m = (storage_impl *)calloc(1, sizeof(storage_impl));
 		s->impl = m;
+		m->dev = n_devices_env > 1 ? (home + (int)(next_storage++ % (unsigned)n_devices_env)) % n_dev : home;
+		HIPX(hipSetDevice(m->dev));
 		HIPX(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
 		s->host_max_query_batch_bytes = host_max_q; s->host_max_target_batch_bytes = host_max_t;
 		s->gpu_max_query_batch_bytes = gpu_max_q; s->gpu_max_target_batch_bytes = gpu_max_t; s->gpu_max_n_alns = gpu_max_n;
@@ -176,6 +187,7 @@ void gasal_init_streams(gasal_gpu_storage_v *v, int host_max_q, int gpu_max_q, i
 		s->current_n_alns = 0;
 		s->is_free = 1;
 	}
+	HIPX(hipSetDevice(home));
 }
 
 static void dev_reserve(storage_impl *m, uint32_t qb, uint32_t tb, uint32_t n)
@@ -228,6 +240,7 @@ void gasal_aln_async(gasal_gpu_storage_t *s, const uint32_t qb, const uint32_t t
 	static std::mutex serial_mu;
 	std::unique_lock<std::mutex> serial_lk(serial_mu, std::defer_lock);
 	if (serial) serial_lk.lock();
+	HIPX(hipSetDevice(m->dev));
 	dev_reserve(m, qb, tb, n);
 	hipStream_t st = m->stream;
 	HIPX(hipMemcpyAsync(m->d_q, s->extensible_host_unpacked_query_batch->data, qb, hipMemcpyHostToDevice, st));
@@ -249,6 +262,7 @@ int gasal_is_aln_async_done(gasal_gpu_storage_t *s)
 {
 	storage_impl *m = (storage_impl *)s->impl;
 	if (!m || !m->running) return -2;
+	HIPX(hipSetDevice(m->dev));
 	hipError_t e = hipStreamQuery(m->stream);
 	if (e == hipErrorNotReady) return -1;
 	if (e != hipSuccess) FATAL("gasal_is_aln_async_done: %s", hipGetErrorString(e));
@@ -282,6 +296,7 @@ void gasal_destroy_streams(gasal_gpu_storage_v *v, Parameters *)
 		gasal_gpu_storage_t *s = &v->a[i];
 		storage_impl *m = (storage_impl *)s->impl;
 		if (!m) continue;
+		(void)hipSetDevice(m->dev);
 		(void)hipStreamSynchronize(m->stream);
 		void *ps[] = {m->d_q, m->d_t, m->d_qoff, m->d_toff, m->d_qlen, m->d_tlen, m->d_h0, m->d_out};
 		for (void *p : ps) if (p) (void)hipFree(p);

@@ -14,6 +14,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
+#include <algorithm>
 #include <vector>
 #include "bmh_internal.h"
 #include "../../include/seed_gen.h"
@@ -144,63 +146,117 @@ extern "C" mem_seed_v_gpu *seed_gpu(gpuseed_storage_vector *d)
 	uint64_t fsz = (uint64_t)ftell(fp);
 	fseek(fp, (long)d->file_bytes_skip, SEEK_SET);
 	uint64_t left = fsz > d->file_bytes_skip ? fsz - d->file_bytes_skip : 0;
-	const uint32_t BATCH_READS = (uint32_t)(left / 2 + 1 < SEED_BATCH_READS ? left / 2 + 1 : SEED_BATCH_READS);
+	// (BMH_SEED_BATCH_READS: smaller batches, so that a small test file still has several of them for the BMH_DEVICES workers)
+	static const uint32_t batch_reads_cfg = [] { const char *e = getenv("BMH_SEED_BATCH_READS"); const long v = e ? atol(e) : 0; return v > 0 ? (uint32_t)v : (uint32_t)SEED_BATCH_READS; }();
+	const uint32_t BATCH_READS = (uint32_t)(left / 2 + 1 < batch_reads_cfg ? left / 2 + 1 : batch_reads_cfg);
 	const uint64_t BATCH_BASES = left + 1 < SEED_BATCH_BASES ? left + 1 : SEED_BATCH_BASES;
 
-	hipStream_t st;
-	HIPX(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-	// candidate capacity = the hard bound (one per base): hard read sets need more than the library's default guess
-	bmh_seed_ws_t *ws = bmh_seed_ws_create(BATCH_READS, BATCH_BASES, BATCH_BASES, 0);
-	if (!ws) FATAL("seed_gpu: %s", bmh_last_error());
-	uint8_t *h_bases; uint32_t *h_offs, *h_lens;
-	HIPX(hipHostMalloc((void **)&h_bases, BATCH_BASES, hipHostMallocDefault));
-	HIPX(hipHostMalloc((void **)&h_offs, (size_t)BATCH_READS * 4, hipHostMallocDefault));
-	HIPX(hipHostMalloc((void **)&h_lens, (size_t)BATCH_READS * 4, hipHostMallocDefault));
-	uint8_t *d_bases; uint32_t *d_offs, *d_lens;
-	HIPX(hipMalloc((void **)&d_bases, BATCH_BASES));
-	HIPX(hipMalloc((void **)&d_offs, (size_t)BATCH_READS * 4));
-	HIPX(hipMalloc((void **)&d_lens, (size_t)BATCH_READS * 4));
-
-	std::vector<uint64_t> rbeg; std::vector<int2> qbeg; std::vector<uint32_t> score, n_ref;
+	// the batches of the file (host memory), then their seeds; batch b is seeded by worker b mod N
+	struct batch_t {
+		std::vector<uint8_t> bases; std::vector<uint32_t> offs, lens;
+		std::vector<uint64_t> rbeg; std::vector<int2> qbeg; std::vector<uint32_t> score, n_ref;
+	};
+	std::vector<batch_t> batches;
 	uint64_t file_bytes = 0;
-	char *line = nullptr; size_t cap = 0;
-	bool eof = false;
-	while (!eof) {
-		uint32_t nr = 0; uint64_t nb = 0;
-		while (nr < BATCH_READS) {
-			ssize_t n = getline(&line, &cap, fp);
-			if (n < 0) { eof = true; break; }
-			file_bytes += (uint64_t)n;
-			if (line[0] == '>') continue;
-			while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) --n;
-			if (n == 0) continue;                     // blank line (kseq skips it too)
-			if (nb + (uint64_t)n > BATCH_BASES) {  // batch full: push the line back
-				fseek(fp, -(long)(strlen(line)), SEEK_CUR); file_bytes -= strlen(line);
-				break;
+	{
+		char *line = nullptr; size_t cap = 0;
+		bool eof = false;
+		while (!eof) {
+			batch_t b;
+			uint64_t nb = 0;
+			while (b.lens.size() < BATCH_READS) {
+				ssize_t n = getline(&line, &cap, fp);
+				if (n < 0) { eof = true; break; }
+				file_bytes += (uint64_t)n;
+				if (line[0] == '>') continue;
+				while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) --n;
+				if (n == 0) continue;                     // blank line (kseq skips it too)
+				if (nb + (uint64_t)n > BATCH_BASES) {  // batch full: push the line back
+					fseek(fp, -(long)(strlen(line)), SEEK_CUR); file_bytes -= strlen(line);
+					break;
+				}
+				b.bases.insert(b.bases.end(), line, line + n);
+				b.offs.push_back((uint32_t)nb); b.lens.push_back((uint32_t)n);
+				nb += (uint64_t)n;
 			}
-			memcpy(h_bases + nb, line, (size_t)n);
-			h_offs[nr] = (uint32_t)nb; h_lens[nr] = (uint32_t)n;
-			nb += (uint64_t)n; ++nr;
+			if (b.lens.empty()) break;
+			batches.push_back(std::move(b));
 		}
-		if (nr == 0) break;
-		HIPX(hipMemcpyAsync(d_bases, h_bases, nb, hipMemcpyHostToDevice, st));
-		HIPX(hipMemcpyAsync(d_offs, h_offs, (size_t)nr * 4, hipMemcpyHostToDevice, st));
-		HIPX(hipMemcpyAsync(d_lens, h_lens, (size_t)nr * 4, hipMemcpyHostToDevice, st));
-		bmh_seeds_t s;
-		if (bmh_seed_batch(ws, idx, d_bases, d_offs, d_lens, nr, d->min_seed_size, st, &s) != BMH_OK)
-			FATAL("seed_gpu: %s", bmh_last_error());
-		size_t o = rbeg.size(), r0 = n_ref.size();
-		rbeg.resize(o + s.n_seeds); qbeg.resize(o + s.n_seeds); score.resize(o + s.n_seeds); n_ref.resize(r0 + nr);
-		if (s.n_seeds) {
-			HIPX(hipMemcpyAsync(rbeg.data() + o, s.d_rbeg, s.n_seeds * 8, hipMemcpyDeviceToHost, st));
-			HIPX(hipMemcpyAsync(qbeg.data() + o, s.d_qbeg, s.n_seeds * 8, hipMemcpyDeviceToHost, st));
-			HIPX(hipMemcpyAsync(score.data() + o, s.d_score, s.n_seeds * 4, hipMemcpyDeviceToHost, st));
-		}
-		HIPX(hipMemcpyAsync(n_ref.data() + r0, s.d_n_ref_pos, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
-		HIPX(hipStreamSynchronize(st));
+		free(line);
 	}
-	free(line);
 	fclose(fp);
+
+	// BMH_DEVICES=N: N worker threads, worker k on device k mod (devices present), each with its own stream, workspace and --
+	// on another device than the one the index was uploaded to -- its own replica of the index (bmh_index_replicate)
+	static const int n_workers_env = [] { const char *e = getenv("BMH_DEVICES"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();
+	int n_dev = 1, home = 0;
+	HIPX(hipGetDeviceCount(&n_dev)); HIPX(hipGetDevice(&home));
+	const int n_workers = (int)std::min<size_t>((size_t)n_workers_env, std::max<size_t>(batches.size(), 1));
+	std::vector<bmh_index_t *> widx(n_workers, idx);
+	std::vector<int> wdev(n_workers, home);
+	for (int k = 1; k < n_workers; ++k) {
+		wdev[k] = (home + k) % n_dev;
+		if (wdev[k] != home) {
+			int found = -1;
+			for (int q = 1; q < k; ++q) if (wdev[q] == wdev[k]) found = q;
+			if (found >= 0) widx[k] = widx[found];
+			else if (bmh_index_replicate(idx, home, wdev[k], &widx[k]) != BMH_OK) FATAL("seed_gpu: %s", bmh_last_error());
+		}
+	}
+	const int min_seed = d->min_seed_size;
+	auto work = [&](int k) {
+		HIPX(hipSetDevice(wdev[k]));
+		hipStream_t st;
+		HIPX(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+		// candidate capacity = the hard bound (one per base): hard read sets need more than the library's default guess
+		bmh_seed_ws_t *ws = bmh_seed_ws_create(BATCH_READS, BATCH_BASES, BATCH_BASES, 0);
+		if (!ws) FATAL("seed_gpu: %s", bmh_last_error());
+		uint8_t *d_bases; uint32_t *d_offs, *d_lens;
+		HIPX(hipMalloc((void **)&d_bases, BATCH_BASES));
+		HIPX(hipMalloc((void **)&d_offs, (size_t)BATCH_READS * 4));
+		HIPX(hipMalloc((void **)&d_lens, (size_t)BATCH_READS * 4));
+		for (size_t bi = (size_t)k; bi < batches.size(); bi += (size_t)n_workers) {
+			batch_t &b = batches[bi];
+			const uint32_t nr = (uint32_t)b.lens.size();
+			HIPX(hipMemcpyAsync(d_bases, b.bases.data(), b.bases.size(), hipMemcpyHostToDevice, st));
+			HIPX(hipMemcpyAsync(d_offs, b.offs.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+			HIPX(hipMemcpyAsync(d_lens, b.lens.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+			bmh_seeds_t s;
+			if (bmh_seed_batch(ws, widx[k], d_bases, d_offs, d_lens, nr, min_seed, st, &s) != BMH_OK)
+				FATAL("seed_gpu: %s", bmh_last_error());
+			b.rbeg.resize(s.n_seeds); b.qbeg.resize(s.n_seeds); b.score.resize(s.n_seeds); b.n_ref.resize(nr);
+			if (s.n_seeds) {
+				HIPX(hipMemcpyAsync(b.rbeg.data(), s.d_rbeg, s.n_seeds * 8, hipMemcpyDeviceToHost, st));
+				HIPX(hipMemcpyAsync(b.qbeg.data(), s.d_qbeg, s.n_seeds * 8, hipMemcpyDeviceToHost, st));
+				HIPX(hipMemcpyAsync(b.score.data(), s.d_score, s.n_seeds * 4, hipMemcpyDeviceToHost, st));
+			}
+			HIPX(hipMemcpyAsync(b.n_ref.data(), s.d_n_ref_pos, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+			HIPX(hipStreamSynchronize(st));
+			std::vector<uint8_t>().swap(b.bases);
+		}
+		(void)hipFree(d_bases); (void)hipFree(d_offs); (void)hipFree(d_lens);
+		bmh_seed_ws_free(ws);
+		(void)hipStreamDestroy(st);
+	};
+	{
+		std::vector<std::thread> th;
+		for (int k = 1; k < n_workers; ++k) th.emplace_back(work, k);
+		work(0);
+		for (auto &t : th) t.join();
+		HIPX(hipSetDevice(home));
+	}
+	for (int k = 1; k < n_workers; ++k) {
+		if (widx[k] == idx) continue;
+		bool first = true;
+		for (int q = 1; q < k; ++q) if (widx[q] == widx[k]) first = false;
+		if (first) { HIPX(hipSetDevice(wdev[k])); bmh_index_free(widx[k]); HIPX(hipSetDevice(home)); }
+	}
+	std::vector<uint64_t> rbeg; std::vector<int2> qbeg; std::vector<uint32_t> score, n_ref;
+	for (batch_t &b : batches) {
+		rbeg.insert(rbeg.end(), b.rbeg.begin(), b.rbeg.end()); qbeg.insert(qbeg.end(), b.qbeg.begin(), b.qbeg.end());
+		score.insert(score.end(), b.score.begin(), b.score.end()); n_ref.insert(n_ref.end(), b.n_ref.begin(), b.n_ref.end());
+		batch_t().rbeg.swap(b.rbeg);
+	}
 
 	mem_seed_v_gpu *out = (mem_seed_v_gpu *)malloc(sizeof(mem_seed_v_gpu));
 	size_t ns = rbeg.size(), nr = n_ref.size();
@@ -219,10 +275,6 @@ extern "C" mem_seed_v_gpu *seed_gpu(gpuseed_storage_vector *d)
 	out->file_bytes_skip = file_bytes;
 	g_last_n_reads = nr;
 
-	(void)hipFree(d_bases); (void)hipFree(d_offs); (void)hipFree(d_lens);
-	(void)hipHostFree(h_bases); (void)hipHostFree(h_offs); (void)hipHostFree(h_lens);
-	bmh_seed_ws_free(ws);
 	bmh_index_free(idx);
-	(void)hipStreamDestroy(st);
 	return out;
 }

@@ -57,6 +57,19 @@ bmh_index_t *bmh_index_from_device(uint64_t primary, const uint64_t L2[5], uint6
                                    const uint32_t *d_sa, uint64_t n_sa, const uint32_t *d_sa_bits,
                                    const uint8_t *d_pac, uint64_t l_pac);
 void bmh_index_free(bmh_index_t *idx);
+
+/* ---- several GPUs of one node from C: the index on every device, the reads sharded, one host worker thread per device
+ * (the reference has no multi-GPU mode at all: gasal_set_device is commented out at src/fastmap.c:143).
+ * bmh_index_replicate copies an index that lives on src_device into fresh allocations on dst_device (device to device: xGMI
+ * between the GPUs of a node; src_device == dst_device makes a second copy on the same GPU).  The copy owns its arrays (free it
+ * with bmh_index_free while dst_device is current).  bmh_shard_range: the contiguous part [lo, hi) of n reads that worker `rank`
+ * of `world` takes, cut at multiples of `multiple` (2 keeps interleaved pairs together).
+ * The drop-in entry points use them when BMH_DEVICES=N is set: seed_gpu() sends the batches of the read file round-robin to N
+ * worker threads, one per device, and concatenates their seeds in file order; the gasal_gpu_storage_t objects of
+ * gasal_init_streams are spread over the N devices.  With fewer physical devices than N several workers share one. */
+int bmh_index_replicate(const bmh_index_t *src, int src_device, int dst_device, bmh_index_t **out);
+void bmh_shard_range(uint64_t n, int rank, int world, uint32_t multiple, uint64_t *lo, uint64_t *hi);
+
 /* Replaces the suffix-array samples by denser ones (every new_intv-th row, a power of two; a no-op if the index is that
  * dense already), computed on the device from the existing ones: same values, fewer LF steps per located seed, more HBM
  * (4.125 bytes per sample).  The reference's files hold every 16th row (src/bwtindex.c:324). */

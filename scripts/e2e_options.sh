@@ -4,3 +4,5 @@ run pe_hard "-k 21 -B 6 -O 8,9 -E 2,3 -T 50 -U 25 -m 20 -M -Y"
 run pe_hard "-S"
 run pe_hard "-P"
 run se_hard "-M -Y -G 500 -N 10 -X 0.3 -w 30 -Q 30"
+run se_hard "-W 5"
+run pe_hard "-W 8 -a"

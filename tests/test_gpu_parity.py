@@ -24,13 +24,13 @@ def _to_dev(torch, a, dt=None):
     return t.cuda()
 
 
-def gpu_seed(B, idx, flat, offs, lens, min_seed_len=19, densify=None, genome=None, max_occ=1 << 22):
+def gpu_seed(B, idx, flat, offs, lens, min_seed_len=19, densify=None, genome=None, max_occ=1 << 22, index=None):
     import torch
     from bwamem_hip.lib import seeds_to_host
     from bwamem_hip import synth
     ascii_ = synth.codes_to_ascii(flat) if flat.size else np.zeros(1, np.uint8)
     # genome given: the 2-bit text goes up too, which switches on the unique-interval shortcuts of the seeding kernels
-    dindex = B.Index.upload(idx) if genome is None else B.Index.upload(idx, pac=_pack_pac(genome), l_pac=len(genome))
+    dindex = index if index is not None else (B.Index.upload(idx) if genome is None else B.Index.upload(idx, pac=_pack_pac(genome), l_pac=len(genome)))
     if densify:
         dindex.densify_sa(densify)
     ws = B.SeedWorkspace(max(len(lens), 1), max(int(flat.size), 1), max_cands=max(int(flat.size), 64), max_occ=max_occ)
@@ -40,7 +40,9 @@ def gpu_seed(B, idx, flat, offs, lens, min_seed_len=19, densify=None, genome=Non
     s = ws.seed_batch(dindex, r, o, l, min_seed_len)
     out = seeds_to_host(s, len(lens))
     out["n_smems"] = int(s.n_smems)
-    ws.free(); dindex.free()
+    ws.free()
+    if index is None:
+        dindex.free()
     return out
 
 
@@ -350,6 +352,49 @@ def test_reference_gase_aln_end_to_end(hip, tmp_path):
         out = r.stdout.decode()
         assert r.returncode == 0 and "E2E DROP-IN OK" in out, out[-3000:]
         assert "SAM IDENTICAL" in out, out[-3000:]           # bwamem_hip.aligner wrote the reference's records byte for byte
+
+
+def test_dropin_with_several_device_workers(hip, tmp_path):
+    """BMH_DEVICES=2 (SURVEY.md 8e from C: one host worker thread per device; on a one-GPU box both workers share it): seed_gpu
+    deals the batches of the read file to two workers -- the second one on its own replica of the index (bmh_index_replicate when
+    its device differs) -- and the gasal storages are spread over the devices.  The reference binary must write the same SAM."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "build", "dropin", "bwa-gasal2")):
+        pytest.skip("build/dropin/bwa-gasal2 not built (needs /root/reference at build time)")
+    env = dict(os.environ, BMH_DEVICES="2", BMH_SEED_BATCH_READS="700")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "e2e_dropin.py"), str(tmp_path), "2000000", "4000", "2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "E2E DROP-IN OK" in out and "SAM IDENTICAL" in out, out[-3000:]
+
+
+def test_index_replicate_and_shard_range(hip, oracle):
+    """bmh_index_replicate: a second copy of the index (same device here; device to device over xGMI on a node) seeds identically;
+    bmh_shard_range equals bwamem_hip.parallel.shard_range."""
+    import ctypes as C
+    import torch
+    from bwamem_hip.parallel import shard_range
+    L = hip.load_library()
+    L.bmh_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.bmh_shard_range.restype = None
+    for n, world, mult in ((10, 3, 1), (1000001, 8, 2), (7, 8, 1), (0, 2, 2), (999, 4, 2)):
+        for rank in range(world):
+            lo, hi = C.c_uint64(), C.c_uint64()
+            L.bmh_shard_range(n, rank, world, mult, C.byref(lo), C.byref(hi))
+            assert (lo.value, hi.value) == shard_range(n, rank, world, mult)
+    g, idx = common.genome_and_index(100_000)
+    reads, _ = hip.synth.make_reads(g, 600, 150, seed=3)
+    flat, offs, lens = common.flat_reads(reads)
+    want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
+    index = hip.Index.upload(idx, pac=_pack_pac(g), l_pac=len(g))
+    L.bmh_index_replicate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    rep = C.c_void_p()
+    assert L.bmh_index_replicate(index.handle, 0, 0, C.byref(rep)) == 0 and rep.value
+    copy = hip.Index(rep.value)
+    got = gpu_seed(hip, idx, flat, offs, lens, index=copy)
+    common.assert_seeds_equal(got, want, "replicated index: ")
+    copy.free(); index.free()
 
 
 def test_host_job_builder_matches_reference_host_code(hip, tmp_path):

@@ -186,7 +186,9 @@ class Aligner:
             elif f == "-Q": po.mapQ_coef_len = float(int(v)); po.mapQ_coef_fac = int(math.log(int(v))) if int(v) > 0 else 0
             elif f == "-U": pe.pen_unpaired = int(v)
             elif f == "-m": pe.max_matesw = int(v)
-            elif f in ("-t", "-K", "-l", "-v", "-f", "-d", "-L"): pass   # threads, batch size, bookkeeping; -d -L: no effect on the GPU extension
+            elif f == "-t": self.ref_threads = int(v)                   # the reference cuts its batches at chunk_size * n_threads bases (align_file)
+            elif f == "-K": self.ref_chunk_bases = int(v)               # ... or at this fixed size
+            elif f in ("-l", "-v", "-f", "-d", "-L"): pass              # bookkeeping; -d -L: no effect on the GPU extension
             else:
                 raise ValueError(f"option {f} is not modelled")
 
@@ -332,16 +334,35 @@ class Aligner:
         ws.free()
         return txt
 
-    def align_file(self, reads_fa: str, out, batch_reads: int = 500_000, paired: bool = False) -> int:
-        """out: a text or binary file object"""
+    def align_file(self, reads_fa: str, out, batch_reads: int = 0, paired: bool = False, chunk_bases: int = 0) -> int:
+        """out: a text or binary file object.  Batches are cut the way the reference's bseq_read cuts them (src/bwa.c, called with
+        chunk_size * n_threads = 10 Mbases per thread, or -K, src/fastmap.c:527): reads are added until the batch holds at least
+        chunk_bases bases and an even number of reads -- in paired mode the insert-size statistics are those of the batch, so the
+        cut decides flags and MAPQ of borderline pairs.  chunk_bases 0: 10 000 000 x the thread count given with -t (1).
+        batch_reads > 0 cuts by read count instead (the earlier behaviour)."""
         rs = read_fasta_reads(reads_fa)
         binary = "b" in getattr(out, "mode", "") or hasattr(out, "getbuffer")
         out.write(self.header().encode() if binary else self.header())
-        if paired:
-            batch_reads -= batch_reads & 1
-        for b in range(0, len(rs), batch_reads):
-            out.write(self.align_batch(rs.slice(b, b + batch_reads), id0=b, paired=paired, as_bytes=binary))
-        return len(rs)
+        n = len(rs)
+        if batch_reads > 0:
+            if paired:
+                batch_reads -= batch_reads & 1
+            cuts = list(range(0, n, batch_reads)) + [n]
+        else:
+            cb = chunk_bases or int(getattr(self, "ref_chunk_bases", 0)) or 10_000_000 * max(1, int(getattr(self, "ref_threads", 1)))
+            cb = min(cb, (1 << 31) - 1024)                               # offsets inside a batch are 32-bit
+            csum = np.cumsum(rs.lens.astype(np.int64))
+            cuts, b = [0], 0
+            while b < n:
+                base = csum[b - 1] if b else 0
+                e = int(np.searchsorted(csum, base + cb, side="left")) + 1      # first read count whose bases reach chunk_bases
+                e += (e - b) & 1                                             # ... and is even (bseq_read: size >= chunk_size && (n & 1) == 0)
+                e = min(e, n)
+                cuts.append(e); b = e
+        for b, e in zip(cuts[:-1], cuts[1:]):
+            if e > b:
+                out.write(self.align_batch(rs.slice(b, e), id0=b, paired=paired, as_bytes=binary))
+        return n
 
     def close(self):
         self.index.free()

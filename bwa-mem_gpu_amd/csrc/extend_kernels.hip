@@ -875,6 +875,31 @@ static ext_scratch_t *scratch_for(int dev, void *stream)
 	return s;
 }
 
+// Frees the scratch (sorted job list, side streams, events) that bmh_extend_batch keeps per (device, stream); call it before
+// destroying a stream that was used for extensions (a recycled stream handle would otherwise inherit stale scratch).  The
+// stream must be idle.  A stream must not be used for extensions by two host threads at once: they would share this scratch.
+extern "C" void bmh_extend_release(void *stream_)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return;
+	ext_scratch_t *s = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(g_scr_mu);
+		auto it = g_scr_map.find(std::make_pair(dev, stream_));
+		if (it == g_scr_map.end()) return;
+		s = it->second;
+		g_scr_map.erase(it);
+	}
+	if (g_last == s) g_last = nullptr;
+	void *ps[] = {s->keys, s->vals, s->keys2, s->vals2, s->counts, s->tmp, s->done};
+	for (void *q : ps) if (q) (void)hipFree(q);
+	if (s->have_ev) {
+		(void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1); (void)hipEventDestroy(s->fork);
+		for (int i = 0; i < 4; ++i) { (void)hipStreamDestroy(s->side[i]); (void)hipEventDestroy(s->join[i]); }
+	}
+	free(s);
+}
+
 // device time of the last bmh_extend_batch issued by this thread (HIP events on its stream)
 extern "C" float bmh_extend_last_ms(void)
 {

@@ -298,6 +298,7 @@ void gasal_destroy_streams(gasal_gpu_storage_v *v, Parameters *)
 		if (!m) continue;
 		(void)hipSetDevice(m->dev);
 		(void)hipStreamSynchronize(m->stream);
+		bmh_extend_release(m->stream);                         // the extension's per-stream scratch goes with the stream
 		void *ps[] = {m->d_q, m->d_t, m->d_qoff, m->d_toff, m->d_qlen, m->d_tlen, m->d_h0, m->d_out};
 		for (void *p : ps) if (p) (void)hipFree(p);
 		if (m->h_out) (void)hipHostFree(m->h_out);

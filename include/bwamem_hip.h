@@ -179,6 +179,11 @@ int64_t bmh_extend_last_unsupported(void);
  * are identical.  on = 0 sends every job to the 32-bit kernels (tests, A/B timing).  Process-wide; returns the previous setting. */
 int bmh_extend_set_packed(int on);
 
+/* bmh_extend_batch keeps scratch (the sorted job list, four side streams, events) per (device, stream) and reuses it across calls.
+ * Call this before destroying a stream that ran extensions (stream idle, its device current); without it the entry stays until the
+ * process ends and a recycled stream handle would inherit it.  One stream must not run extensions from two host threads at once. */
+void bmh_extend_release(void *stream);
+
 /* device time in ms of the DP kernels launched by the calling thread's last
  * bmh_extend_batch (HIP events on that call's stream; waits for them). */
 float bmh_extend_last_ms(void);

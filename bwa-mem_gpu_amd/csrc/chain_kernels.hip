@@ -299,8 +299,11 @@ extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_
 	// caller's stream (lane kernel, scans, the first pass's extension) are neither queued behind them nor starved of wave slots
 	int prio_lo = 0, prio_hi = 0;
 	(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+	// (BMH_CHAIN_PRIO=hi | normal: experiment knob -- on workloads where these kernels are the critical path of the stage)
+	const char *pe = getenv("BMH_CHAIN_PRIO");
+	const int cls_prio = pe && pe[0] == 'h' ? prio_hi : pe && pe[0] == 'n' ? 0 : prio_lo;
 	for (int c = 0; c < CH_N_CLASSES; ++c)
-		ok = ok && hipStreamCreateWithPriority(&w->cls_stream[c], hipStreamNonBlocking, prio_lo) == hipSuccess && hipEventCreate(&w->cls_done[c]) == hipSuccess;
+		ok = ok && hipStreamCreateWithPriority(&w->cls_stream[c], hipStreamNonBlocking, cls_prio) == hipSuccess && hipEventCreate(&w->cls_done[c]) == hipSuccess;
 	if (!ok) { bmh_set_error("bmh_chain_ws_create: hipMalloc failed (%s)", hipGetErrorString(hipGetLastError())); bmh_chain_ws_free(w); return nullptr; }
 	w->n_contigs = 1;
 	w->materialize = 1;

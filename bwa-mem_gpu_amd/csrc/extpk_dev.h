@@ -169,6 +169,7 @@ struct pk_consts_t {
 	uint32_t b2, oei2, oed2, ei2, ed2;     // splatted
 	uint32_t ab, nrow, tbl_hi;             // a+b; (b-1) in all four bytes (rows whose target base is N); table bytes 4..7: code 4 (N) = b-1, pad = 0
 	int eP, eC, a;                         // e_ins * P, e_ins * 2P
+	uint32_t a2;                           // a splatted
 	bool same_oe;
 };
 template <int P> __device__ __forceinline__ pk_consts_t pk_consts(const ext_args_t &A)
@@ -177,7 +178,7 @@ template <int P> __device__ __forceinline__ pk_consts_t pk_consts(const ext_args
 	K.b2 = pk_splat(A.b); K.oei2 = pk_splat(A.o_ins + A.e_ins); K.oed2 = pk_splat(A.o_del + A.e_del);
 	K.ei2 = pk_splat(A.e_ins); K.ed2 = pk_splat(A.e_del);
 	K.ab = (uint32_t)(A.a + A.b); K.nrow = (uint32_t)(A.b - 1) * 0x01010101u; K.tbl_hi = (uint32_t)(A.b - 1);
-	K.eP = A.e_ins * P; K.eC = A.e_ins * 2 * P; K.a = A.a;
+	K.eP = A.e_ins * P; K.eC = A.e_ins * 2 * P; K.a = A.a; K.a2 = pk_splat(A.a);
 	K.same_oe = A.o_ins + A.e_ins == A.o_del + A.e_del;
 	return K;
 }
@@ -238,12 +239,13 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t &K, const int zdrop, ui
 	}
 	uint32_t key = 0, nzb = 0;
 	pk_pass2<P, SAME_OE>(H, E, NZ, M, em, f, key, nzb, K, std::make_integer_sequence<int, P>());
-	// last non-zero H column of the lane, + 1 (0: none): pair p sits at bit P-1-p of its half of nzb
+	// last non-zero H column of the lane, + 1 (0: none): pair p sits at bit P-1-p of its half of nzb (branch-free)
 	int nlast;
 	{
-		const uint32_t nh = nzb >> 16, nl = nzb & 0xFFFFu;
-		const int ph = P - (int)__builtin_ctz(nh | 0x10000u), pl = P - (int)__builtin_ctz(nl | 0x10000u);      // pair index + 1
-		nlast = nh ? j0 + P + ph : (nl ? j0 + pl : 0);
+		const uint32_t nh = nzb >> 16;
+		const uint32_t pick = nh ? nh : (nzb & 0xFFFFu);
+		const int base = nh ? j0 + 2 * P : j0 + P;                       // column of pair 0 + P
+		nlast = nzb ? base - (int)__builtin_ctz(pick | 0x10000u) : 0;
 	}
 	// lane key (h << 16 | column): the high chain wins ties (its columns are the larger ones)
 	int kk;
@@ -288,9 +290,10 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t &K, const int zdrop, ui
 	S.end = upd ? min(qlen, nlast + 2) : S.end;                 // ksw.c:963-970: last non-zero index of eh[] is the column + 1
 	// Exact early stop (see ext_row): Phi = H + a*(qlen-1-column) over the frontier; E(i+1,j) <= H(i,j), so H alone carries it
 	if (bound) {                                                // wave-uniform
-		uint32_t u2 = H[0];
+		// max over the pairs of H[p] - a*p, as a Horner-style chain from the last pair down (one constant instead of P)
+		uint32_t u2 = H[P - 1];
 #pragma unroll
-		for (int p = 1; p < P; ++p) u2 = pk_maxs(u2, pk_subiK(H[p], pk_splat(K.a * p)));
+		for (int p = P - 2; p >= 0; --p) u2 = pk_maxs(H[p], pk_subiK(u2, K.a2));
 		u2 = pk_addi(u2, phi0);
 		int u = max((int)(short)(u2 & 0xFFFFu), (int)u2 >> 16);
 		u = max(u, hnx + K.a * qlen);

@@ -98,10 +98,12 @@ template <bool COOP = false> CH_HD inline int intv2rid(const ch_ctx_t &x, int64_
 	const int rid_e = rb < re ? pos2rid<COOP>(x, depos(x, re - 1, &is_rev)) : rid_b;
 	return rid_b == rid_e ? rid_b : -1;
 }
+// (an integer form, (n + e) / e, gives the same values but measured slower on the device than the double division)
+CH_HD inline int ch_div_plus1(int n, int e) { return (int)((double)n / e + 1.); }
 CH_HD inline int cal_max_gap(const bmh_chain_opt_t &o, int qlen)
 {
-	const int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
-	const int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+	const int l_del = ch_div_plus1(qlen * o.a - o.o_del, o.e_del);
+	const int l_ins = ch_div_plus1(qlen * o.a - o.o_ins, o.e_ins);
 	int l = l_del > l_ins ? l_del : l_ins;
 	l = l > 1 ? l : 1;
 	return l < o.w << 1 ? l : o.w << 1;
@@ -264,6 +266,97 @@ template <bool COOP> CH_HD inline void sort_distinct(uint64_t *a, uint64_t *tmp,
 	}
 }
 
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t ch_wave_min_u32(uint32_t v)
+{
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, d); v = t < v ? t : v; }
+	return v;
+}
+
+// The kept-chain loop of mem_chain_flt (src/bwamem.c:506-535) for one read on a wave, without scanning the kept list per chain.
+// Three facts make that exact:
+//  * whether chain i "overlaps significantly" with kept chain j depends only on their query spans (beg, end).  The chains of a
+//    seed-rich read have very few distinct spans (one per SMEM): every distinct span is a CLASS, owned by one lane (at most 64
+//    classes, else the caller falls back to the scan);
+//  * chains are visited in descending weight, so the kept list is in descending weight too, and the kept chains heavy enough to
+//    drop chain i (ai.w < aj.w * drop_ratio && aj.w - ai.w >= 2 min_seed_len) are a PREFIX [0, bp) of it that only grows with i.
+//    Chain i is dropped iff a class that overlaps it has its first member inside that prefix; the scan of the reference stops at
+//    the earliest such member (`reach`);
+//  * a kept chain's `first` is set once, by the first later chain whose scan reaches it while overlapping; a scan marks every
+//    unmarked overlapping member up to `reach`, so the unmarked members of a class are always a suffix of its member list: one
+//    pointer per class, advanced as members get marked.
+// kept_w[k] / mem_next[k]: weight of kept chain k and the next kept chain of its class; cls[i]: class of sorted chain i.
+// Returns false (nothing modified but scratch) when the read has more than 64 distinct spans.
+__device__ inline bool ch_kept_by_classes(const bmh_chain_opt_t &o, ch_chain_t *CH, const uint32_t *order, uint32_t *klist, int32_t *kept_w,
+                                          uint32_t *mem_next, uint32_t *cls, int na, int &nk_out)
+{
+	const int lane = ch_lane();
+	const uint32_t NIL = 0xFFFFFFFFu, INF = 0x7FFFFFFFu;
+	uint32_t classkey = 0xFFFFFFFFu;                          // lane t: (beg << 16 | end) of class t
+	int ncls = 0;
+	for (int b = 0; b < na; b += 64) {
+		const int i = b + lane;
+		uint32_t key = 0xFFFFFFFEu;
+		if (i < na) { const ch_chain_t c = CH[order[i]]; key = (uint32_t)c.beg << 16 | (uint32_t)c.end; }
+		int id = -1;
+		for (int t = 0; t < ncls; ++t) { const uint32_t kt = (uint32_t)__shfl((int)classkey, t); if (key == kt) id = t; }
+		unsigned long long un = __ballot(i < na && id < 0);
+		while (un) {
+			if (ncls >= 64) return false;
+			const uint32_t kL = (uint32_t)__shfl((int)key, (int)__builtin_ctzll(un));
+			if (lane == ncls) classkey = kL;
+			if (i < na && id < 0 && key == kL) id = ncls;
+			++ncls;
+			un = __ballot(i < na && id < 0);
+		}
+		if (i < na) cls[i] = (uint32_t)id;
+	}
+	ch_wave_fence();
+	const int cbeg = (int)(classkey >> 16), cend = (int)(classkey & 0xFFFFu);
+	int c_n = 0; uint32_t c_first = INF, c_tail = NIL, c_um = NIL;
+	int nk = 0, bp = 0;
+	for (int b = 0; b < na; b += 64) {
+		int vbeg = 0, vend = 0, vw = 0, vcls = 0; uint32_t vci = 0;
+		if (b + lane < na) { vci = order[b + lane]; const ch_chain_t c = CH[vci]; vbeg = c.beg; vend = c.end; vw = c.w; vcls = (int)cls[b + lane]; }
+		const int m = na - b < 64 ? na - b : 64;
+		for (int u = 0; u < m; ++u) {
+			const int i = b + u;
+			const int ibeg = __shfl(vbeg, u), iend = __shfl(vend, u), iw = __shfl(vw, u), sc = __shfl(vcls, u);
+			const uint32_t ci = (uint32_t)__shfl((int)vci, u);
+			bool broke = false, large = false;
+			if (i > 0) {
+				bool ovl = false;
+				if (lane < ncls && c_n > 0) {
+					const int b_max = cbeg > ibeg ? cbeg : ibeg, e_min = cend < iend ? cend : iend;
+					if (e_min > b_max) {
+						const int li = iend - ibeg, lj = cend - cbeg;
+						const int min_l = li < lj ? li : lj;
+						ovl = e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap;
+					}
+				}
+				while (bp < nk) { const int wj = kept_w[bp]; if (iw < wj * o.drop_ratio && wj - iw >= o.min_seed_len << 1) ++bp; else break; }
+				const uint32_t cand = ch_wave_min_u32((ovl && c_first < (uint32_t)bp) ? c_first : INF);
+				broke = cand != INF;
+				const uint32_t reach = broke ? cand : INF - 1;
+				large = __ballot(ovl) != 0ull;
+				if (ovl) while (c_um != NIL && c_um <= reach) { CH[order[klist[c_um]]].first = i; c_um = mem_next[c_um]; }
+			}
+			if (!broke) {
+				const uint32_t k = (uint32_t)nk;
+				if (lane == 0) { klist[k] = (uint32_t)i; kept_w[k] = iw; mem_next[k] = NIL; CH[ci].kept = large ? 2u : 3u; }
+				if (lane == sc) { if (c_n == 0) c_first = k; else mem_next[c_tail] = k; c_tail = k; if (c_um == NIL) c_um = k; ++c_n; }
+				++nk;
+			}
+			ch_wave_fence();
+		}
+	}
+	nk_out = nk;
+	return true;
+}
+#endif
+
 CH_HD inline ch_scr_t global_scratch(const ch_ctx_t &x, uint32_t r)
 {
 	const uint32_t b = x.prefix[r];
@@ -417,16 +510,27 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 	if (COOP) ch_wave_fence();
 #endif
 	int nk = 0;
+	bool kept_done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+	// seed-rich reads: span classes instead of a scan of the kept list per chain (srt is free between the sort and mem_chain2aln:
+	// its 8 bytes per entry hold the kept weights and the class links)
+#ifndef CH_NO_CLASSES
+	if (COOP && na > 48) kept_done = ch_kept_by_classes(o, CH, order, klist, (int32_t *)srt, (uint32_t *)srt + na, cidx, na, nk);
+	if (COOP && na > 48 && !kept_done) ch_wave_fence();
+#endif
+#endif
 	// kept chains: klist[k] = index in the sorted array, ks[k] = {beg, end, w, chain} so the scan reads one entry per k
 	// (E is not in use before mem_chain2aln and has room for it)
 	struct ks_t { int32_t beg, end, w; uint32_t chain; };
 	ks_t *ks = (ks_t *)E;
-	{ const ch_chain_t c0 = CH[order[0]]; ks_t e; e.beg = c0.beg; e.end = c0.end; e.w = c0.w; e.chain = order[0]; ks[0] = e; }
-	CH[order[0]].kept = 3; klist[nk++] = 0;
+	if (!kept_done) {
+		{ const ch_chain_t c0 = CH[order[0]]; ks_t e; e.beg = c0.beg; e.end = c0.end; e.w = c0.w; e.chain = order[0]; ks[0] = e; }
+		CH[order[0]].kept = 3; klist[nk++] = 0;
+	}
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (COOP) ch_wave_fence();
 #endif
-	for (int i = 1; i < na; ++i) {
+	for (int i = 1; i < na && !kept_done; ++i) {
 		const uint32_t ci = order[i];
 		const ch_chain_t ai = CH[ci];
 		bool large_ovlp = false, broke = false;

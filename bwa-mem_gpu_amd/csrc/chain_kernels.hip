@@ -80,8 +80,11 @@ __global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A)
 #define CH_LDS_BYTES_PER_ENTRY (8 + 8 + sizeof(ch_est_t) + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4 + 4 + 4)
 #define CH_LDS_BYTES_PER_ENTRY_HYBRID (8 + 8 + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4)
 #define CH_LDS_CONTIGS 256         // contig tables up to this size are copied into LDS (3 KB)
+#ifndef CH_WAVE_ATTR
+#define CH_WAVE_ATTR
+#endif
 template <bool CTG_LDS>
-__global__ void __launch_bounds__(64) chain_wave_kernel(chain_args_t A, uint32_t cls, uint32_t lds_cap, int hybrid)
+__global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_t A, uint32_t cls, uint32_t lds_cap, int hybrid)
 {
 	extern __shared__ __align__(16) uint8_t ch_lds[];
 	const uint32_t nh = A.heavy_n[cls];

@@ -487,7 +487,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 		for (int b = 0; b < nc; b += 64) {
 			const int i = b + lane;
 			uint32_t ci = 0; int w = -1;
-			if (i < nc) { ci = order[i]; w = weigh(ci); }
+			if (i < nc) { ci = order[i]; w = weigh(ci); opos[i] |= (int64_t)ci << 40; }       // (position rank -> chain, for the isolation pass below)
 			const bool keep = i < nc && w >= o.min_chain_weight;
 			const unsigned long long m = __ballot(keep);
 			if (keep) srt[na + __builtin_popcountll(m & ((1ull << lane) - 1))] = (uint64_t)(uint32_t)w << 32 | ci;
@@ -605,11 +605,45 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 
 	// ---------------------------------------------------------------- mem_chain2aln, chain by chain in filtered order
 	CH_STAMP(4);
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (COOP) {
+		// Which chains are ISOLATED on the reference?  A region made from seed t covers seed s only if s.rbeg lies within l_query of
+		// t.rbeg (rb_est >= t.rbeg - 0.85 (t.qbeg + 1), re_est <= t.rbeg + t.len + 0.85 (l_query - t.qbeg - t.len), :1235-1256), and
+		// the seeds of a chain lie between its position and its last seed (rbeg never decreases along a chain, test_and_merge
+		// :337-364).  So a chain whose neighbours in position order are farther than 2 l_query from its ends can neither cover nor be
+		// covered by a region of ANOTHER chain: the "made before?" scan of its seeds needs the chain's own regions only.  On a
+		// seed-rich read almost every chain is a single seed at its own locus, and the scan over all earlier regions was half of
+		// this phase.  opos still holds the chains in position order (with the chain index in its high bits since the weights).
+		const int lane = ch_lane();
+		const int64_t PMASK = ((int64_t)1 << 40) - 1;
+		int64_t run_max = -((int64_t)1 << 60);
+		for (int b = 0; b < nc; b += 64) {
+			const int r = b + lane;
+			int64_t pos = 0, tail = -((int64_t)1 << 60), nextpos = (int64_t)1 << 60; uint32_t ci = 0;
+			if (r < nc) {
+				const int64_t v = opos[r]; pos = v & PMASK; ci = (uint32_t)(v >> 40);
+				tail = S[CH[ci].tail].rbeg;
+				if (r + 1 < nc) nextpos = opos[r + 1] & PMASK;
+			}
+			int64_t incl = tail;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) { const int64_t t = __shfl_up(incl, d); if (lane >= d && t > incl) incl = t; }
+			int64_t excl = __shfl_up(incl, 1);
+			if (lane == 0 || excl < run_max) excl = run_max;
+			const bool iso = excl + 2 * (int64_t)l_query < pos && nextpos > tail + 2 * (int64_t)l_query;
+			if (r < nc) CH[ci].pad = iso ? 1u : 0u;
+			const int64_t tot = __shfl(incl, 63);
+			run_max = tot > run_max ? tot : run_max;
+		}
+		ch_wave_fence();
+	}
+#endif
 	int n_regs = 0, n_jobs = 0;
 	for (int ia = 0; ia < na; ++ia) {
 		const ch_chain_t c = CH[order[ia]];
 		if (c.kept == 0) continue;
 		const int cn = (int)c.n;
+		const int scan_from = c.pad ? n_regs : 0;                               // isolated chain: only its own regions can cover its seeds
 		int64_t rmax0 = l_pac << 1, rmax1 = 0;
 		{
 			int i = 0;
@@ -658,7 +692,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 			if (COOP) {
 				// 256 regions per round; the four entries of a lane are loaded before any is tested, so the loads overlap
 				const int lane = ch_lane();
-				for (int b = 0; b < n_regs && hit == n_regs; b += 256) {
+				for (int b = scan_from; b < n_regs && hit == n_regs; b += 256) {
 					ch_est_t p4[4]; unsigned long long m[4];
 #pragma unroll
 					for (int u = 0; u < 4; ++u) { const int i = b + 64 * u + lane; p4[u] = E[i < n_regs ? i : n_regs - 1]; }

@@ -64,7 +64,14 @@ namespace chain_core {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ int ch_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-__device__ __forceinline__ void ch_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0); }
+// Lanes of a wave exchange data through the read's scratch.  With the scratch in global memory the writes must have completed
+// before other lanes read them (vmcnt = 0); with ALL of it in LDS (template flag LDSX) it is enough to order the LDS operations
+// (lgkmcnt = 0) -- and the wave no longer waits for its output stores to global memory (one region per chain: ~1 us each).
+template <bool LDSX = false> __device__ __forceinline__ void ch_wave_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_s_waitcnt(LDSX ? 0xC07F : 0);            // gfx9 encoding: vmcnt 63 / expcnt 7 left alone, lgkmcnt 0
+}
 #endif
 
 template <bool COOP = false> CH_HD inline int pos2rid(const ch_ctx_t &x, int64_t pos_f)
@@ -169,7 +176,7 @@ CH_HD inline bool w_introsort(uint64_t *a, int n)
 
 // ---- helpers that are split across the wave when COOP
 // insert (cv, pv) at position at of order/opos[0..nc)
-template <bool COOP> CH_HD inline void sorted_insert(uint32_t *order, int64_t *opos, int nc, int at, uint32_t cv, int64_t pv)
+template <bool COOP, bool LDSX = false> CH_HD inline void sorted_insert(uint32_t *order, int64_t *opos, int nc, int at, uint32_t cv, int64_t pv)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (COOP) {
@@ -180,13 +187,13 @@ template <bool COOP> CH_HD inline void sorted_insert(uint32_t *order, int64_t *o
 			uint32_t v[4]; int64_t p[4];
 #pragma unroll
 			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - 64 * u, jc = j >= at ? j : at; v[u] = order[jc]; p[u] = opos[jc]; }   // no branch: the loads overlap
-			ch_wave_fence();
+			ch_wave_fence<LDSX>();
 #pragma unroll
 			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - 64 * u; if (j >= at) { order[j + 1] = v[u]; opos[j + 1] = p[u]; } }
-			ch_wave_fence();
+			ch_wave_fence<LDSX>();
 		}
 		order[at] = cv; opos[at] = pv;
-		ch_wave_fence();
+		ch_wave_fence<LDSX>();
 		return;
 	}
 #endif
@@ -239,7 +246,7 @@ template <bool COOP, class F> CH_HD inline int first_true(int lo, int hi, F f)
 }
 
 // sort n distinct 64-bit keys ascending (any algorithm gives the same result)
-template <bool COOP> CH_HD inline void sort_distinct(uint64_t *a, uint64_t *tmp, int n)
+template <bool COOP, bool LDSX = false> CH_HD inline void sort_distinct(uint64_t *a, uint64_t *tmp, int n)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (COOP && n > 24) {          // rank sort: element i goes to the number of keys below it
@@ -252,9 +259,9 @@ template <bool COOP> CH_HD inline void sort_distinct(uint64_t *a, uint64_t *tmp,
 				tmp[rank] = v;
 			}
 		}
-		ch_wave_fence();
+		ch_wave_fence<LDSX>();
 		for (int b = 0; b < n; b += 64) { const int i = b + lane; if (i < n) a[i] = tmp[i]; }
-		ch_wave_fence();
+		ch_wave_fence<LDSX>();
 		return;
 	}
 #endif
@@ -268,11 +275,19 @@ template <bool COOP> CH_HD inline void sort_distinct(uint64_t *a, uint64_t *tmp,
 
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// minimum over the 64 lanes, on DPP (row shifts inside the 16-lane rows, then row_bcast 15 / 31: lane 63 ends with the total) --
+// six register-to-register steps instead of six ds_bpermute round trips of a shuffle butterfly
 __device__ __forceinline__ uint32_t ch_wave_min_u32(uint32_t v)
 {
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, d); v = t < v ? t : v; }
-	return v;
+	int x = (int)v;                                               // values are below 2^31: signed min is the same
+	int t;
+	t = __builtin_amdgcn_update_dpp(0x7FFFFFFF, x, 0x111, 0xf, 0xf, false); x = t < x ? t : x;
+	t = __builtin_amdgcn_update_dpp(0x7FFFFFFF, x, 0x112, 0xf, 0xf, false); x = t < x ? t : x;
+	t = __builtin_amdgcn_update_dpp(0x7FFFFFFF, x, 0x114, 0xf, 0xf, false); x = t < x ? t : x;
+	t = __builtin_amdgcn_update_dpp(0x7FFFFFFF, x, 0x118, 0xf, 0xf, false); x = t < x ? t : x;
+	t = __builtin_amdgcn_update_dpp(0x7FFFFFFF, x, 0x142, 0xa, 0xf, false); x = t < x ? t : x;
+	t = __builtin_amdgcn_update_dpp(0x7FFFFFFF, x, 0x143, 0xc, 0xf, false); x = t < x ? t : x;
+	return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 
 // The kept-chain loop of mem_chain_flt (src/bwamem.c:506-535) for one read on a wave, without scanning the kept list per chain.
@@ -289,7 +304,7 @@ __device__ __forceinline__ uint32_t ch_wave_min_u32(uint32_t v)
 //    pointer per class, advanced as members get marked.
 // kept_w[k] / mem_next[k]: weight of kept chain k and the next kept chain of its class; cls[i]: class of sorted chain i.
 // Returns false (nothing modified but scratch) when the read has more than 64 distinct spans.
-__device__ inline bool ch_kept_by_classes(const bmh_chain_opt_t &o, ch_chain_t *CH, const uint32_t *order, uint32_t *klist, int32_t *kept_w,
+template <bool LDSX> __device__ inline bool ch_kept_by_classes(const bmh_chain_opt_t &o, ch_chain_t *CH, const uint32_t *order, uint32_t *klist, int32_t *kept_w,
                                           uint32_t *mem_next, uint32_t *cls, int na, int &nk_out)
 {
 	const int lane = ch_lane();
@@ -301,11 +316,11 @@ __device__ inline bool ch_kept_by_classes(const bmh_chain_opt_t &o, ch_chain_t *
 		uint32_t key = 0xFFFFFFFEu;
 		if (i < na) { const ch_chain_t c = CH[order[i]]; key = (uint32_t)c.beg << 16 | (uint32_t)c.end; }
 		int id = -1;
-		for (int t = 0; t < ncls; ++t) { const uint32_t kt = (uint32_t)__shfl((int)classkey, t); if (key == kt) id = t; }
+		for (int t = 0; t < ncls; ++t) { const uint32_t kt = (uint32_t)__builtin_amdgcn_readlane((int)classkey, t); if (key == kt) id = t; }
 		unsigned long long un = __ballot(i < na && id < 0);
 		while (un) {
 			if (ncls >= 64) return false;
-			const uint32_t kL = (uint32_t)__shfl((int)key, (int)__builtin_ctzll(un));
+			const uint32_t kL = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(un));
 			if (lane == ncls) classkey = kL;
 			if (i < na && id < 0 && key == kL) id = ncls;
 			++ncls;
@@ -313,7 +328,7 @@ __device__ inline bool ch_kept_by_classes(const bmh_chain_opt_t &o, ch_chain_t *
 		}
 		if (i < na) cls[i] = (uint32_t)id;
 	}
-	ch_wave_fence();
+	ch_wave_fence<LDSX>();
 	const int cbeg = (int)(classkey >> 16), cend = (int)(classkey & 0xFFFFu);
 	int c_n = 0; uint32_t c_first = INF, c_tail = NIL, c_um = NIL;
 	int nk = 0, bp = 0;
@@ -323,8 +338,10 @@ __device__ inline bool ch_kept_by_classes(const bmh_chain_opt_t &o, ch_chain_t *
 		const int m = na - b < 64 ? na - b : 64;
 		for (int u = 0; u < m; ++u) {
 			const int i = b + u;
-			const int ibeg = __shfl(vbeg, u), iend = __shfl(vend, u), iw = __shfl(vw, u), sc = __shfl(vcls, u);
-			const uint32_t ci = (uint32_t)__shfl((int)vci, u);
+			// (u is wave-uniform: v_readlane, not a shuffle through the LDS crossbar)
+			const int ibeg = __builtin_amdgcn_readlane(vbeg, u), iend = __builtin_amdgcn_readlane(vend, u), iw = __builtin_amdgcn_readlane(vw, u),
+			          sc = __builtin_amdgcn_readlane(vcls, u);
+			const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)vci, u);
 			bool broke = false, large = false;
 			if (i > 0) {
 				bool ovl = false;
@@ -349,7 +366,7 @@ __device__ inline bool ch_kept_by_classes(const bmh_chain_opt_t &o, ch_chain_t *
 				if (lane == sc) { if (c_n == 0) c_first = k; else mem_next[c_tail] = k; c_tail = k; if (c_um == NIL) c_um = k; ++c_n; }
 				++nk;
 			}
-			ch_wave_fence();
+			ch_wave_fence<LDSX>();
 		}
 	}
 	nk_out = nk;
@@ -367,7 +384,7 @@ CH_HD inline ch_scr_t global_scratch(const ch_ctx_t &x, uint32_t r)
 }
 
 // The read: returns through x.regs (slot order = creation order), x.regs_per_read[r], x.jobs_per_read[r].
-template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const ch_scr_t &sc)
+template <bool COOP, bool LDSX = false> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const ch_scr_t &sc)
 {
 	const bmh_chain_opt_t &o = x.o;
 	const uint32_t base = x.prefix[r];
@@ -448,7 +465,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 				S[ns] = s;
 				ch_chain_t c; c.head = c.tail = (uint32_t)ns; c.n = 1; c.rid = rid; c.w = 0; c.first = -1; c.beg = c.end = 0; c.kept = 0; c.pad = 0;
 				CH[nc] = c;
-				sorted_insert<COOP>(order, opos, nc, lo, (uint32_t)nc, rb);
+				sorted_insert<COOP, LDSX>(order, opos, nc, lo, (uint32_t)nc, rb);
 				++ns; ++nc;
 			}
 		}
@@ -493,7 +510,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 			if (keep) srt[na + __builtin_popcountll(m & ((1ull << lane) - 1))] = (uint64_t)(uint32_t)w << 32 | ci;
 			na += __builtin_popcountll(m);
 		}
-		ch_wave_fence();
+		ch_wave_fence<LDSX>();
 	} else
 #endif
 	for (int i = 0; i < nc; ++i) {
@@ -507,7 +524,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 	CH_STAMP(3);
 	for (int i = 0; i < na; ++i) order[i] = (uint32_t)srt[i];
 #if defined(__HIP_DEVICE_COMPILE__)
-	if (COOP) ch_wave_fence();
+	if (COOP) ch_wave_fence<LDSX>();
 #endif
 	int nk = 0;
 	bool kept_done = false;
@@ -515,8 +532,8 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 	// seed-rich reads: span classes instead of a scan of the kept list per chain (srt is free between the sort and mem_chain2aln:
 	// its 8 bytes per entry hold the kept weights and the class links)
 #ifndef CH_NO_CLASSES
-	if (COOP && na > 48) kept_done = ch_kept_by_classes(o, CH, order, klist, (int32_t *)srt, (uint32_t *)srt + na, cidx, na, nk);
-	if (COOP && na > 48 && !kept_done) ch_wave_fence();
+	if (COOP && na > 48) kept_done = ch_kept_by_classes<LDSX>(o, CH, order, klist, (int32_t *)srt, (uint32_t *)srt + na, cidx, na, nk);
+	if (COOP && na > 48 && !kept_done) ch_wave_fence<LDSX>();
 #endif
 #endif
 	// kept chains: klist[k] = index in the sorted array, ks[k] = {beg, end, w, chain} so the scan reads one entry per k
@@ -528,7 +545,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 		CH[order[0]].kept = 3; klist[nk++] = 0;
 	}
 #if defined(__HIP_DEVICE_COMPILE__)
-	if (COOP) ch_wave_fence();
+	if (COOP) ch_wave_fence<LDSX>();
 #endif
 	for (int i = 1; i < na && !kept_done; ++i) {
 		const uint32_t ci = order[i];
@@ -589,7 +606,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 			klist[nk++] = (uint32_t)i; CH[ci].kept = large_ovlp ? 2 : 3;
 		}
 #if defined(__HIP_DEVICE_COMPILE__)
-		if (COOP) ch_wave_fence();
+		if (COOP) ch_wave_fence<LDSX>();
 #endif
 	}
 	for (int k = 0; k < nk; ++k) { const int f = CH[order[klist[k]]].first; if (f >= 0) CH[order[f]].kept = 1; }
@@ -635,11 +652,70 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 			const int64_t tot = __shfl(incl, 63);
 			run_max = tot > run_max ? tot : run_max;
 		}
-		ch_wave_fence();
+		ch_wave_fence<LDSX>();
 	}
 #endif
 	int n_regs = 0, n_jobs = 0;
 	for (int ia = 0; ia < na; ++ia) {
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (COOP) {
+			// A run of chains that need no look at any other region -- dropped ones (kept == 0) and ISOLATED chains of a single seed
+			// (their "made before?" scan is empty: no other chain's region can cover the seed and the chain has no earlier region of
+			// its own) -- is handled one chain per lane: the region of such a chain is a function of its seed alone, and its slot is
+			// its rank in the run.  The chains of a seed-rich read are almost all of this kind.
+			const int lane = ch_lane();
+			const int i = ia + lane;
+			const bool in = i < na;
+			ch_chain_t cl; cl.kept = 0; cl.n = 0; cl.pad = 0; cl.head = 0;
+			if (in) cl = CH[order[i]];
+			const unsigned long long im = __ballot(in), slow = im & ~__ballot(in && (cl.kept == 0 || (cl.pad != 0 && cl.n == 1)));
+			const int run = slow ? (int)__builtin_ctzll(slow) : (int)__builtin_popcountll(im);
+			if (run > 0) {
+				const bool me = lane < run && cl.kept != 0;
+				const unsigned long long mm = __ballot(me);
+				bool jl = false, jr = false;
+				if (me) {
+					const int idx = n_regs + (int)__builtin_popcountll(mm & ((1ull << lane) - 1));
+					const ch_seed_t t = S[cl.head];
+					int64_t rmax0 = t.rbeg - (t.qbeg + cal_max_gap(o, t.qbeg));
+					int64_t rmax1 = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + cal_max_gap(o, l_query - t.qbeg - t.len));
+					rmax0 = rmax0 > 0 ? rmax0 : 0;
+					rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+					if (rmax0 < l_pac && l_pac < rmax1) { if (t.rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
+					{
+						int is_rev;
+						const int rid = pos2rid<false>(x, depos(x, t.rbeg, &is_rev));
+						int64_t far_beg = x.n_contigs > 1 ? x.ctg_off[rid] : 0, far_end = far_beg + (x.n_contigs > 1 ? x.ctg_len[rid] : l_pac);
+						if (is_rev) { const int64_t tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
+						rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+						rmax1 = rmax1 < far_end ? rmax1 : far_end;
+					}
+					ch_reg_t a; ch_est_t e;
+					const int fwd = (int)(0.85 * (l_query - (t.qbeg + t.len)));
+					e.qe_est = (t.qbeg + t.len) + fwd < l_query ? (t.qbeg + t.len) + fwd : l_query;
+					e.re_est = (t.rbeg + t.len) + fwd < l_pac << 1 ? (t.rbeg + t.len) + fwd : l_pac << 1;
+					const int back = (int)(0.85 * (t.qbeg + 1));
+					e.qb_est = (t.qbeg - back) > 0 ? (t.qbeg - back) : 0;
+					e.rb_est = (t.rbeg - back) > 0 ? (t.rbeg - back) : 0;
+					if (e.rb_est < l_pac && l_pac < e.qe_est) { if (t.rbeg < l_pac) e.re_est = l_pac; else e.rb_est = l_pac; }
+					e.seedlen0 = t.len; e.pad = 0;
+					E[idx] = e;
+					a.seed_rbeg = t.rbeg; a.seed_qbeg = t.qbeg; a.seedlen0 = t.len; a.rmax0 = rmax0;
+					a.lr = (int)(t.rbeg - rmax0);
+					a.rq = l_query - (t.qbeg + t.len);
+					a.rr = (int)(rmax1 - rmax0) - (a.lr + t.len);
+					a.pad = 0;
+					R[idx] = a;
+					jl = t.qbeg > 0; jr = a.rq > 0;
+				}
+				n_regs += (int)__builtin_popcountll(mm);
+				n_jobs += (int)__builtin_popcountll(__ballot(jl)) + (int)__builtin_popcountll(__ballot(jr));
+				ia += run - 1;                                                    // (the loop adds the last one)
+				ch_wave_fence<LDSX>();
+				continue;
+			}
+		}
+#endif
 		const ch_chain_t c = CH[order[ia]];
 		if (c.kept == 0) continue;
 		const int cn = (int)c.n;
@@ -670,9 +746,9 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 			rmax1 = rmax1 < far_end ? rmax1 : far_end;
 		}
 #if defined(__HIP_DEVICE_COMPILE__)
-		if (COOP) ch_wave_fence();
+		if (COOP) ch_wave_fence<LDSX>();
 #endif
-		sort_distinct<COOP>(srt, (uint64_t *)(opos), cn);       // opos is free by now (8 bytes per entry)
+		sort_distinct<COOP, LDSX>(srt, (uint64_t *)(opos), cn);       // opos is free by now (8 bytes per entry)
 		for (int k = cn - 1; k >= 0; --k) {
 			const ch_seed_t s = S[cidx[(uint32_t)srt[k]]];
 			auto covered = [&](const ch_est_t &p) {                                 // extension (estimated) made before? :1235-1256
@@ -716,7 +792,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 				if (j == cn) {
 					srt[k] = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-					if (COOP) ch_wave_fence();
+					if (COOP) ch_wave_fence<LDSX>();
 #endif
 					continue;
 				}
@@ -739,7 +815,7 @@ template <bool COOP> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const 
 			R[n_regs++] = a;
 			n_jobs += (s.qbeg > 0) + (a.rq > 0);
 #if defined(__HIP_DEVICE_COMPILE__)
-			if (COOP) ch_wave_fence();
+			if (COOP) ch_wave_fence<LDSX>();
 #endif
 		}
 	}

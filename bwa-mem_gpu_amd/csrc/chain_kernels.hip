@@ -113,13 +113,14 @@ __global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_
 		const uint32_t r = list[i];
 		// three call sites so that every pointer of a call has ONE address space the compiler can see (a pointer that may be
 		// LDS or global becomes a flat access, several times the latency of ds_read on the LDS side)
-		if (lds_cap && !hybrid) chain_core::chain_read<true>(A.x, r, L);
+		if (lds_cap && !hybrid) chain_core::chain_read<true, true>(A.x, r, L);
 		else if (lds_cap) {
 			const ch_scr_t G = chain_core::global_scratch(A.x, r);
 			ch_scr_t H = L; H.E = G.E; H.klist = G.klist; H.cidx = G.cidx;
 			chain_core::chain_read<true>(A.x, r, H);
 		} else chain_core::chain_read<true>(A.x, r, chain_core::global_scratch(A.x, r));
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		__builtin_amdgcn_s_waitcnt(0);                           // the read's output stores before the scratch is reused
 	}
 }
 

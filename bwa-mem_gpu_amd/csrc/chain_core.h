@@ -427,20 +427,10 @@ template <bool COOP, bool LDSX = false> CH_HD void chain_read(const ch_ctx_t &x,
 		const int step = cnt > (uint32_t)o.max_occ ? (int)(cnt / o.max_occ) : 1;
 		// occurrences k = 0, step, 2 step, ... while k < cnt, at most max_occ of them
 		const int n_it = (int)(((int64_t)cnt + step - 1) / step) < o.max_occ ? (int)(((int64_t)cnt + step - 1) / step) : o.max_occ;
-#if defined(__HIP_DEVICE_COMPILE__)
-		long long rbv = 0;                                 // COOP: the wave fetches 64 positions at a time, one per lane
-#endif
-		for (int count = 0; count < n_it; ++count) {
-			int64_t rb;
-#if defined(__HIP_DEVICE_COMPILE__)
-			if (COOP) {
-				if ((count & 63) == 0) { const int c = count + ch_lane(); rbv = c < n_it ? (long long)g_rbeg[i + (int64_t)c * step] : 0; }
-				rb = __shfl(rbv, count & 63);
-			} else
-#endif
-			rb = (int64_t)g_rbeg[i + (int64_t)count * step];
+		// one occurrence of the SMEM (sb, slen) at reference position rb, the reference's way: closest chain at or below it, merge or new
+		auto seq_one = [&](const int64_t rb) {
 			const int rid = intv2rid<COOP>(x, rb, rb + slen);
-			if (rid < 0) continue;
+			if (rid < 0) return;
 			// closest chain at or below the seed: upper bound over opos[0..nc), then one back
 			const int lo = upper_bound_pos<COOP>(opos, nc, rb);
 			bool to_add = true;
@@ -468,7 +458,102 @@ template <bool COOP, bool LDSX = false> CH_HD void chain_read(const ch_ctx_t &x,
 				sorted_insert<COOP, LDSX>(order, opos, nc, lo, (uint32_t)nc, rb);
 				++ns; ++nc;
 			}
-		}
+		};
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (COOP) {
+			// 64 occurrences of the SMEM at a time, one per lane.  Each lane SPECULATES its occurrence against the chains as they
+			// stand before the batch (own binary search, own merge test).  The speculation is the sequential outcome unless an earlier
+			// occurrence of the batch changes what a later one sees: (a) it starts a new chain that becomes the later one's closest
+			// chain -- which matters if the later one was going to merge / be contained, or lies within w of it (all occurrences of
+			// a batch share the query interval, so only then can it merge into that one-seed chain); (b) it merges into the chain the
+			// later one is tested against.  Lanes look for such a pair among themselves (64 register reads each); a batch without
+			// one -- the rule on a seed-rich read, whose occurrences lie at loci of their own -- is committed by all lanes at once and
+			// its new chains are merged into the sorted chain index in one pass; any other batch takes the sequential path below.
+			const int lane = ch_lane();
+			for (int c0 = 0; c0 < n_it; c0 += 64) {
+				const int cc = c0 + lane;
+				const bool act = cc < n_it;
+				const long long rbl = act ? (long long)g_rbeg[i + (int64_t)cc * step] : 0;
+				bool done = false;
+				if (n_it - c0 >= 8) {
+					int rid = -1;
+					if (act) rid = intv2rid<false>(x, rbl, rbl + slen);
+					const bool valid = act && rid >= 0;
+					int lo = 0, kind = 0;                               // kind: 0 nothing, 1 new chain, 2 merge, 3 contained
+					uint32_t pc = 0xFFFFFFFFu, ptail = 0; long long ppos = -1;
+					if (valid) {
+						lo = upper_bound_pos<false>(opos, nc, rbl);
+						kind = 1;
+						if (lo > 0) {
+							pc = order[lo - 1]; ppos = opos[lo - 1];
+							const ch_chain_t c = CH[pc];
+							const ch_seed_t first = S[c.head], last = S[c.tail];
+							ptail = c.tail;
+							const int64_t qend = last.qbeg + last.len, rend = last.rbeg + last.len;
+							if (rid == c.rid) {
+								if (sb >= first.qbeg && sb + slen <= qend && rbl >= first.rbeg && rbl + slen <= rend) kind = 3;
+								else if (!((last.rbeg < l_pac || first.rbeg < l_pac) && rbl >= l_pac)) {
+									const int64_t xq = sb - last.qbeg, y = rbl - last.rbeg;
+									if (y >= 0 && xq - y <= o.w && y - xq <= o.w && xq - last.len < o.max_chain_gap && y - last.len < o.max_chain_gap) kind = 2;
+								}
+							}
+						}
+					}
+					bool inter = false; int below = 0;
+					const int rlo = (int)(unsigned)(rbl & 0xFFFFFFFFll), rhi = (int)(rbl >> 32);
+					for (int v = 0; v < 64; ++v) {
+						const int kv = __builtin_amdgcn_readlane(kind, v);
+						if (kv != 1 && kv != 2) continue;                 // (wave-uniform)
+						const long long rv = (long long)(unsigned)__builtin_amdgcn_readlane(rlo, v) | ((long long)__builtin_amdgcn_readlane(rhi, v) << 32);
+						const uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)pc, v);
+						if (valid) {
+							if (v < lane) {
+								if (kv == 1 && rv <= rbl && (lo == 0 || rv >= ppos) && (kind != 1 || rbl - rv <= o.w)) inter = true;
+								if (kv == 2 && lo > 0 && pv == pc) inter = true;
+							}
+							if (kv == 1 && kind == 1 && rv < rbl) ++below;
+						}
+					}
+					if (!__any(inter)) {
+						const bool isnew = kind == 1, ismrg = kind == 2;
+						const unsigned long long lt = (1ull << lane) - 1, mnew = __ballot(isnew), madd = __ballot(isnew || ismrg);
+						const uint32_t my_ns = (uint32_t)ns + (uint32_t)__builtin_popcountll(madd & lt), my_nc = (uint32_t)nc + (uint32_t)__builtin_popcountll(mnew & lt);
+						if (isnew || ismrg) { ch_seed_t sd; sd.rbeg = rbl; sd.qbeg = sb; sd.len = slen; sd.next = 0xFFFFFFFFu; sd.pad = 0; S[my_ns] = sd; }
+						if (ismrg) { S[ptail].next = my_ns; CH[pc].tail = my_ns; CH[pc].n += 1; }
+						if (isnew) {
+							ch_chain_t c; c.head = c.tail = my_ns; c.n = 1; c.rid = rid; c.w = 0; c.first = -1; c.beg = c.end = 0; c.kept = 0; c.pad = 0;
+							CH[my_nc] = c;
+						}
+						const int K = (int)__builtin_popcountll(mnew);
+						if (K) {
+							// the K new chains into the sorted index: old entry j moves up by the number of new chains that go at or below it
+							// (chunks from the top, every chunk read before it is written; moved entries never collide: the shift grows with j)
+							int minlo = 0x7FFFFFFF;
+							for (unsigned long long mm = mnew; mm; mm &= mm - 1) { const int lv = __builtin_amdgcn_readlane(lo, (int)__builtin_ctzll(mm)); minlo = lv < minlo ? lv : minlo; }
+							for (int hi = nc; hi > minlo; hi -= 64) {
+								const int jj = hi - 1 - lane;
+								uint32_t ov = 0; int64_t op = 0; int sh = 0;
+								if (jj >= minlo) { ov = order[jj]; op = opos[jj]; }
+								for (unsigned long long mm = mnew; mm; mm &= mm - 1) { const int lv = __builtin_amdgcn_readlane(lo, (int)__builtin_ctzll(mm)); sh += lv <= jj ? 1 : 0; }
+								ch_wave_fence<LDSX>();
+								if (jj >= minlo && sh) { order[jj + sh] = ov; opos[jj + sh] = op; }
+								ch_wave_fence<LDSX>();
+							}
+							if (isnew) { order[lo + below] = my_nc; opos[lo + below] = rbl; }
+						}
+						nc += K; ns += (int)__builtin_popcountll(madd);
+						ch_wave_fence<LDSX>();
+						done = true;
+					}
+				}
+				if (!done) {
+					const int m = n_it - c0 < 64 ? n_it - c0 : 64;
+					for (int u = 0; u < m; ++u) seq_one((int64_t)__shfl(rbl, u));
+				}
+			}
+		} else
+#endif
+		for (int count = 0; count < n_it; ++count) seq_one((int64_t)g_rbeg[i + (int64_t)count * step]);
 		i += (int)cnt;
 	}
 	if (nc == 0) return;

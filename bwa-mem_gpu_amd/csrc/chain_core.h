@@ -331,7 +331,7 @@ template <bool LDSX> __device__ inline bool ch_kept_by_classes(const bmh_chain_o
 	ch_wave_fence<LDSX>();
 	const int cbeg = (int)(classkey >> 16), cend = (int)(classkey & 0xFFFFu);
 	int c_n = 0; uint32_t c_first = INF, c_tail = NIL, c_um = NIL;
-	int nk = 0, bp = 0;
+	int nk = 0, bp = 0, wbp = 0;                               // wbp = kept_w[bp] while bp < nk (kept in a register: the test runs for every chain)
 	for (int b = 0; b < na; b += 64) {
 		int vbeg = 0, vend = 0, vw = 0, vcls = 0; uint32_t vci = 0;
 		if (b + lane < na) { vci = order[b + lane]; const ch_chain_t c = CH[vci]; vbeg = c.beg; vend = c.end; vw = c.w; vcls = (int)cls[b + lane]; }
@@ -353,20 +353,22 @@ template <bool LDSX> __device__ inline bool ch_kept_by_classes(const bmh_chain_o
 						ovl = e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap;
 					}
 				}
-				while (bp < nk) { const int wj = kept_w[bp]; if (iw < wj * o.drop_ratio && wj - iw >= o.min_seed_len << 1) ++bp; else break; }
+				while (bp < nk) { if (iw < wbp * o.drop_ratio && wbp - iw >= o.min_seed_len << 1) { ++bp; if (bp < nk) wbp = kept_w[bp]; } else break; }
 				const uint32_t cand = ch_wave_min_u32((ovl && c_first < (uint32_t)bp) ? c_first : INF);
 				broke = cand != INF;
 				const uint32_t reach = broke ? cand : INF - 1;
 				large = __ballot(ovl) != 0ull;
-				if (ovl) while (c_um != NIL && c_um <= reach) { CH[order[klist[c_um]]].first = i; c_um = mem_next[c_um]; }
+				if (ovl) while (c_um != NIL && c_um <= reach) { CH[cls[c_um]].first = i; c_um = mem_next[c_um]; }      // cls[k] = chain of kept entry k by now
 			}
 			if (!broke) {
 				const uint32_t k = (uint32_t)nk;
-				if (lane == 0) { klist[k] = (uint32_t)i; kept_w[k] = iw; mem_next[k] = NIL; CH[ci].kept = large ? 2u : 3u; }
+				if (lane == 0) { klist[k] = (uint32_t)i; kept_w[k] = iw; mem_next[k] = NIL; cls[k] = ci; CH[ci].kept = large ? 2u : 3u; }
+				if ((int)k == bp) wbp = iw;                               // the prefix had caught up with the list: its next entry is this one
 				if (lane == sc) { if (c_n == 0) c_first = k; else mem_next[c_tail] = k; c_tail = k; if (c_um == NIL) c_um = k; ++c_n; }
 				++nk;
 			}
-			ch_wave_fence<LDSX>();
+			if (LDSX) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // LDS operations of a wave execute in order: no wait needed
+			else ch_wave_fence<LDSX>();
 		}
 	}
 	nk_out = nk;

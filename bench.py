@@ -142,6 +142,9 @@ def main():
                     "(setup only; used by scripts/profile_round.sh so that the rocprofv3 passes do not rebuild it)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("BENCH_INFLIGHT", "2")), help="batches in flight: each goes through the whole path on its own "
                     "stream, workspaces and host thread (1 = strictly one batch at a time)")
+    ap.add_argument("--passes", type=int, default=int(os.environ.get("BENCH_PASSES", "2")), help="2: bmh_chain_extend_merge (the jobs of the lightly seeded reads are "
+                    "extended while the seed-rich reads are still being chained, then theirs); 1: bmh_chain_batch -> bmh_chain_extend -> bmh_chain_merge "
+                    "(one extension over all jobs of the batch, after all of its chaining: pays with batches in flight, whose work fills the wait)")
     ap.add_argument("--no-pcie", dest="pcie", action="store_false", help="skip the second timed loop (steps fed from pinned host memory)")
     ap.add_argument("--no-next-rows", dest="next_rows", action="store_false")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BENCH_CPU_SAMPLE", "100000")), help="reads of the all-cores CPU leg (0 = no CPU baseline)")
@@ -270,6 +273,7 @@ def main():
             self.stream = s_main if k == 0 else torch.cuda.Stream(device=dev)
             self.h = self.stream.cuda_stream
             self.regs = torch.zeros(cap_regs, 8, dtype=torch.int32, device=dev)
+            self.out3 = torch.zeros(cap_jobs, 3, dtype=torch.int32, device=dev) if a.passes == 1 else None
             self.n_regs = 0
             self.acc = {}
             # PCIe form: the lane's own device copy of the reads and pinned host buffer of the regions
@@ -288,15 +292,25 @@ def main():
                 ascii_t, offs_t, lens_t = self.slot
             sd = self.ws.seed_batch(dindex, ascii_t, offs_t, lens_t, 19, stream=self.h)
             tm = self.ws.timing()
-            dj_ = self.cw.extend_merge(dindex, ascii_t, offs_t, lens_t, sd, self.regs, params=params, stream=self.h)
+            if a.passes == 1:
+                dj_ = self.cw.chain_batch(dindex, ascii_t, offs_t, lens_t, sd, stream=self.h)
+                self.cw.extend(self.out3, params=params, stream=self.h)
+                tm["extend_one_pass"] = 0.0
+                self.cw.merge(self.out3, self.regs, stream=self.h)
+            else:
+                dj_ = self.cw.extend_merge(dindex, ascii_t, offs_t, lens_t, sd, self.regs, params=params, stream=self.h)
             self.n_regs = int(dj_.n_regs)
             if host_in is not None:                                   # regions leave over PCIe, behind the lane's next batch
                 with torch.cuda.stream(self.stream):
                     self.host_out[: self.n_regs].copy_(self.regs[: self.n_regs], non_blocking=True)
-            xm = self.cw.extend_merge_timing(); cm = self.cw.timing()
+            cm = self.cw.timing()
             tm["chain_light"] = cm["to_counts"]    # classify + lane kernel + counts: what the first extension waits for
             tm["chain_heavy_beside"] = cm["wave"]  # wave kernels on side streams (hidden behind extend_a as far as it lasts)
-            tm["extend_a"] = xm["extend_a"]; tm["extend_b"] = xm["extend_b"]; tm["chain_extend_merge"] = xm["stage"]
+            if a.passes == 1:
+                tm["extend_one_pass"] = L.bmh_extend_last_ms()
+            else:
+                xm = self.cw.extend_merge_timing()
+                tm["extend_a"] = xm["extend_a"]; tm["extend_b"] = xm["extend_b"]; tm["chain_extend_merge"] = xm["stage"]
             for kk, v in tm.items():
                 self.acc[kk] = self.acc.get(kk, 0.0) + v
             with plock:
@@ -409,7 +423,7 @@ def main():
                                    "seeding = all SMEMs >= 19 bp + locate; extension = every left/right job the reference's chaining (mem_chain, mem_chain_flt, mem_chain2aln) produces; "
                                    "chaining, job construction with on-device reference fetch and the region merge run on the device inside the timed region (reads in, regions out); "
                                    "two different read batches alternate",
-                       "batches_in_flight": n_lanes, "workload_key": workload_key, "reads_per_gpu": n_reads, "read_len": a.read_len, "paired_interleaved": bool(a.paired), "genome_mbp": a.genome_mbp,
+                       "batches_in_flight": n_lanes, "extension_passes_per_batch": a.passes, "workload_key": workload_key, "reads_per_gpu": n_reads, "read_len": a.read_len, "paired_interleaved": bool(a.paired), "genome_mbp": a.genome_mbp,
                        "seq_len": int(d.seq_len), "index_bytes": int(d.bwt_t.numel() * 4 + d.sa_t.numel() * 4 + d.bits_t.numel() * 4 + pac_t.numel()), "sa_intv": a.sa_intv,
                        "seeds_per_read": round(st["n_seeds"] / n_reads, 2), "smems_per_read": round(st["n_smems"] / n_reads, 2), "ext_jobs_per_read": round(st["n_jobs"] / n_reads, 2),
                        "regions_per_read": round(st["n_regs"] / n_reads, 2), "reads_chained_by_a_whole_wave": st["n_heavy"],

@@ -233,6 +233,36 @@ def test_extension_asymmetric_gap_penalties(hip, oracle, scoring, packed):
         assert np.array_equal(got3, want3)
 
 
+def test_extension_packed_class_boundaries(hip, oracle):
+    """Jobs at the edges of what the packed 16-bit kernels take (csrc/extpk_dev.h): query lengths around every group / pair-count
+    boundary (128|129 columns: 4 -> 8 lanes, 256|257: 8 -> 16, 288|289: packed -> 32-bit), targets around the LDS staging caps
+    (384, 512, 640) and seed scores that push h0 + qlen*a across the 4096 limit of the 16-bit keys -- the router must send each job
+    to a kernel that is exact for it."""
+    import oracle_py
+    rng = np.random.default_rng(99)
+    qs, ts, h0 = [], [], []
+    def add(ql, tl, h):
+        t = rng.integers(0, 4, size=tl).astype(np.uint8)
+        q = np.resize(t, ql).copy() if ql else np.zeros(0, np.uint8)
+        if ql:
+            mut = rng.random(ql) < 0.06
+            q[mut] = (q[mut] + rng.integers(1, 4, size=int(mut.sum()))) & 3
+        qs.append(q); ts.append(t); h0.append(h)
+    for ql in (1, 15, 16, 17, 31, 32, 33, 64, 65, 96, 97, 112, 113, 127, 128, 129, 143, 144, 145, 159, 160, 161, 192, 193, 224, 225, 255, 256, 257, 287, 288, 289, 300):
+        for tl in (ql + 7, 383, 384, 385, 511, 512, 513, 639, 640, 641):
+            for h in (1, 19, 150, 4096 - ql - 1, 4096 - ql, 4096 - ql + 1, 5000):
+                add(ql, tl, h)
+    qlen = np.array([len(x) for x in qs], np.uint32); tlen = np.array([len(x) for x in ts], np.uint32)
+    qoff = np.concatenate([[0], np.cumsum(qlen)[:-1]]).astype(np.uint32); toff = np.concatenate([[0], np.cumsum(tlen)[:-1]]).astype(np.uint32)
+    jobs = (np.concatenate(qs), qoff, qlen, np.concatenate(ts), toff, tlen, np.array(h0, np.uint32))
+    for zdrop in (0, 100):
+        want3, want6, _ = oracle.extend_batch(*jobs, params=oracle_py.default_params(zdrop=zdrop), want_raw=True)
+        got3, got6 = gpu_extend(hip, jobs, zdrop=zdrop)
+        bad = np.nonzero((got6 != want6).any(1))[0]
+        assert bad.size == 0, f"{bad.size} raw mismatches, first {bad[:5]}: got {got6[bad[:5]]} want {want6[bad[:5]]} qlen {jobs[2][bad[:5]]} tlen {jobs[5][bad[:5]]} h0 {jobs[6][bad[:5]]}"
+        assert np.array_equal(got3, want3)
+
+
 def test_extension_jobs_without_target_rows(hip, oracle):
     """tlen == 0 (the window of a seed at the end of a sequence is clipped away, src/bntseq.c:531-556): the answer is
     (h0, 0, 0).  Such jobs sort last in their class; a class made only of them, one of them alone in the batch, and

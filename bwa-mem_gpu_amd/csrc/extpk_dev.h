@@ -34,6 +34,49 @@ __device__ __forceinline__ uint32_t pk_subiK(uint32_t a, uint32_t k) { uint32_t 
 __device__ __forceinline__ uint32_t pk_addi(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ uint32_t pk_splat(int v) { return ((uint32_t)v & 0xFFFFu) * 0x10001u; }
 
+__device__ __forceinline__ uint32_t pk_subsK(uint32_t a, uint32_t k) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "s"(k)); return d; }
+__device__ __forceinline__ unsigned long long pk_readlane64(unsigned long long v, int lane)
+{
+	return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32);
+}
+// byte u of the result = bits 2u+1:2u of z (four 2-bit symbols spread into four bytes)
+__device__ __forceinline__ uint32_t pk_spread4(uint32_t z)
+{
+	const uint32_t a = (z | (z << 12)) & 0x000F000Fu;
+	return (a | (a << 6)) & 0x03030303u;
+}
+// Target codes of rows k0..k0+7 of one job as two dwords (byte u of `lo` = row k0+u; rows at and beyond tlen: don't care).
+// Descriptor jobs decode them from three bytes of the 2-bit text at once (the rows of a job walk ONE strand up or down:
+// chain2aln clips a window that would cross the strand boundary, src/bwamem.c:1261-1264); array jobs read their bytes.
+__device__ __forceinline__ void pk_t8(const ext_args_t &A, const job_src_t &s, const int k0, const int tlen, uint32_t &lo, uint32_t &hi)
+{
+	if (!A.desc) {
+		lo = hi = 0;
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int k = k0 + u;
+			const uint32_t b = k < tlen ? (uint32_t)s.tp[k] : 5u, c = b > 3u ? 5u : b;
+			if (u < 4) lo |= c << (8 * u); else hi |= c << (8 * (u - 4));
+		}
+		return;
+	}
+	const long long p0 = s.t0 + (long long)k0 * s.tdir;
+	const bool rev = p0 >= A.l_pac;
+	const long long f0 = rev ? (A.l_pac << 1) - 1 - p0 : p0;          // forward-strand position of row k0
+	const bool asc = rev ? s.tdir < 0 : s.tdir > 0;                  // the rows walk the forward strand upwards
+	long long fa = asc ? f0 : f0 - 7;                                // lowest position of the eight
+	int D = 7;                                                       // descending: row u is symbol D - u of the window at fa
+	if (fa < 0) { D = (int)f0; fa = 0; }
+	const uint8_t *bp = A.pac + (fa >> 2);
+	const uint32_t v = ((uint32_t)bp[0] << 16) | ((uint32_t)bp[1] << 8) | (uint32_t)bp[2];        // (pac is readable 9 bytes past its end)
+	const uint32_t y = (v << (8 + 2 * ((int)fa & 3))) >> 16;          // eight symbols, position fa+j at bits 15-2j:14-2j
+	const uint32_t z = asc ? y : y >> (2 * (7 - D));
+	const uint32_t w0 = pk_spread4(z & 0xFFu), w1 = pk_spread4((z >> 8) & 0xFFu);
+	lo = asc ? __builtin_bswap32(w1) : w0;
+	hi = asc ? __builtin_bswap32(w0) : w1;
+	if (rev) { lo ^= 0x03030303u; hi ^= 0x03030303u; }
+}
+
 // first pass of a pair: M = hd ? max(hd + score, 0) : 0 and the chain's local F recurrence (6 instructions)
 __device__ __forceinline__ void pk_pair1(uint32_t &M, uint32_t &agg, const uint32_t hd, const uint32_t mask, const uint32_t sel,
                                          const uint32_t tbl_hi, const uint32_t tbl_lo, const uint32_t b2, const uint32_t ei2, const uint32_t oei2)
@@ -320,7 +363,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P >= 9
 	constexpr int TCAP = PK_TCAP(G);
 	// (row strides padded so that the groups of a wave, which read the same offsets of their own rows, hit different banks:
 	// unpadded, the 16 groups' target bytes sat in two banks and every row's read was an 8-way conflict)
-	__shared__ uint8_t t_lds[NG][TCAP + 4];
+	__shared__ __attribute__((aligned(16))) uint8_t t_lds[NG][TCAP + 4];
+	__shared__ __attribute__((aligned(16))) uint8_t q_lds[4][(C * G + 15) & ~15];      // the query codes of the job a wave is staging
 	__shared__ __attribute__((aligned(16))) uint32_t em_tab[(C + 1) * PS];
 	__shared__ __attribute__((aligned(16))) uint32_t h_lds[NG * PS];
 	for (int k = threadIdx.x; k < (C + 1) * PS; k += 256) {
@@ -329,6 +373,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P >= 9
 	}
 	__syncthreads();
 	uint8_t *tl = t_lds[threadIdx.x / G];
+	uint8_t *qw = q_lds[threadIdx.x >> 6];
 	const int hgrp = (int)(threadIdx.x / G) * PS;              // the group's dwords in h_lds
 	uint32_t *hrow = h_lds + hgrp;
 	bool owner = false;                                        // this lane holds column qlen-1
@@ -376,23 +421,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P >= 9
 				qn += cnt < avail ? cnt : avail;            // groups beyond `avail` stay idle this round and ask again
 			}
 			more = more_g || qn < qe;
-			if (!alive) {
+			const bool drawing = !alive;
+			job_src_t src = ext_job_src(A, 0, false, 0, 0);
+			if (drawing) {
 				const uint32_t k = base + (uint32_t)__builtin_popcountll(nb & ((1ull << (lane & ~(G - 1))) - 1));
 				have = k < qe;
 				id = have ? ids[n - 1 - k] : 0;
 				qlen = have ? (int)A.qlen[id] : 0; tlen = have ? (int)A.tlen[id] : 0; h0 = have ? (int)A.h0[id] : 1;
-				const job_src_t src = ext_job_src(A, id, have, qlen, tlen);
-#pragma unroll
-				for (int p = 0; p < P; ++p) {
-					const int jl = j0 + p, jh = j0 + P + p;
-					const int ql = jl < qlen ? min(ext_q_at(A, src, jl), 4) : 7, qh = jh < qlen ? min(ext_q_at(A, src, jh), 4) : 7;      // 4 = N, 7 = pad
-					sel[p] = 0x0C000C00u | (uint32_t)ql | ((uint32_t)qh << 16);
-					const int vl = h0 - oe_ins - jl * A.e_ins, vh = h0 - oe_ins - jh * A.e_ins;       // H(-1,j), ksw.c:880-883
-					const uint32_t hl = (jl < qlen && vl > 0) ? (uint32_t)vl : 0u, hh = (jh < qlen && vh > 0) ? (uint32_t)vh : 0u;
-					H[p] = hl | (hh << 16);
-					NZ[p] = pk_min1(H[p]);
-					E[p] = 0;
-				}
+				src = ext_job_src(A, id, have, qlen, tlen);
 				{
 					const int jq = qlen > 0 ? qlen - 1 : 0, lq = jq / C, r = jq % C;       // lane, chain and pair of column qlen-1
 					goff = 2 * (hgrp + (r >= P ? r - P : r)) + (r >= P ? 1 : 0); owner = l == lq;
@@ -401,14 +437,52 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P >= 9
 				}
 				S.end = qlen; S.mx = h0; S.max_i = -1; S.max_j = -1; S.max_ie = -1; S.gscore = -1; S.max_off = 0;
 				i = 0; rows_done = 0; hfc = h0; dn = oe_del; tp = tl;
-				// the target row codes into LDS, eight loads in flight per lane (one at a time, a draw took ~45 memory round trips
-				// during which the other groups of the wave stood still)
-				for (int k0 = l; k0 < tlen; k0 += 8 * G) {
-					int tb[8];
+			}
+			// The bases of the new jobs, staged by ALL 64 lanes of the wave one job at a time (eight target rows and four query
+			// columns per lane): done by the four lanes of the drawing group alone, a draw cost the wave two to three DP rows
+			// of instructions during which its other fifteen alignments stood still.
+			for (unsigned long long todo = __ballot(drawing && have && g0 && tlen > 0); todo; todo &= todo - 1) {
+				const int gl = (int)__builtin_ctzll(todo);                      // first lane of the group (wave-uniform)
+				const int tlen_g = __builtin_amdgcn_readlane(tlen, gl), qlen_g = __builtin_amdgcn_readlane(qlen, gl);
+				job_src_t sg;
+				sg.qp = (const uint8_t *)pk_readlane64((unsigned long long)src.qp, gl); sg.qstep = __builtin_amdgcn_readlane(src.qstep, gl);
+				sg.tp = (const uint8_t *)pk_readlane64((unsigned long long)src.tp, gl);
+				sg.t0 = (long long)pk_readlane64((unsigned long long)src.t0, gl); sg.tdir = __builtin_amdgcn_readlane(src.tdir, gl);
+				uint8_t *tg = t_lds[(threadIdx.x >> 6) * (64 / G) + gl / G];
+				for (int k0 = 8 * lane; k0 < tlen_g; k0 += 512) {
+					uint32_t lo, hi;
+					pk_t8(A, sg, k0, tlen_g, lo, hi);
+					*(uint32_t *)(tg + k0) = lo;
+					if (k0 + 4 < tlen_g) *(uint32_t *)(tg + k0 + 4) = hi;
+				}
+				for (int c0 = 4 * lane; c0 < C * G; c0 += 256) {
+					uint32_t w = 0;
 #pragma unroll
-					for (int u = 0; u < 8; ++u) { const int k = k0 + u * G; tb[u] = k < tlen ? ext_t_at(A, src, k) : 5; }
+					for (int u = 0; u < 4; ++u) { const int j = c0 + u; w |= (uint32_t)(j < qlen_g ? min(ext_q_at(A, sg, j), 4) : 7) << (8 * u); }      // 4 = N, 7 = pad
+					*(uint32_t *)(qw + c0) = w;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (LDS operations of a wave execute in order; the fences hold the compiler to it)
+				if ((lane & ~(G - 1)) == gl) {
 #pragma unroll
-					for (int u = 0; u < 8; ++u) { const int k = k0 + u * G; if (k < tlen) tl[k] = (uint8_t)(tb[u] > 3 ? 5 : tb[u]); }
+					for (int p = 0; p < P; ++p) sel[p] = 0x0C000C00u | (uint32_t)qw[j0 + p] | ((uint32_t)qw[j0 + P + p] << 16);
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			}
+			if (drawing) {
+				// H(-1, j) = max(0, h0 - o_ins - e_ins*(j+1)) left of qlen (ksw.c:880-883): one saturating packed subtract per pair
+				const int wq = min(max(qlen - j0, 0), C);
+				const uint4 *mrow = (const uint4 *)(em_tab + wq * PS);
+				uint32_t em[PP];
+#pragma unroll
+				for (int k = 0; k < PP / 4; ++k) { const uint4 v = mrow[k]; em[4 * k] = v.x; em[4 * k + 1] = v.y; em[4 * k + 2] = v.z; em[4 * k + 3] = v.w; }
+				uint32_t X = (uint32_t)max(h0 - oe_ins - j0 * A.e_ins, 0) | ((uint32_t)max(h0 - oe_ins - (j0 + P) * A.e_ins, 0) << 16);
+#pragma unroll
+				for (int p = 0; p < P; ++p) {
+					H[p] = X & em[p];
+					NZ[p] = pk_min1(H[p]);
+					E[p] = 0;
+					X = pk_subsK(X, K.ei2);
+					if (!have) sel[p] = 0x0C070C07u;
 				}
 				alive = have && tlen > 0;
 				if (have && tlen == 0) {

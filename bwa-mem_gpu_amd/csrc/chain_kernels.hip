@@ -24,6 +24,7 @@ struct ch_outreg_t { int64_t seed_rbeg; int32_t seed_qbeg, seedlen0, job0, job1;
 struct chain_args_t {
 	ch_ctx_t x;
 	uint32_t n_reads, heavy_thresh;
+	uint32_t lane_max;            // class 0 (lane form over its list) takes the reads of heavy_thresh+1 .. lane_max entries
 	uint32_t *heavy_list; uint32_t *heavy_n;
 	uint32_t *need;               // [n_reads] seed occurrences the chaining core will sample
 };
@@ -32,16 +33,18 @@ struct chain_args_t {
 // src/bwamem.c:430-436), not the number located: on an hg38-like genome 0.25 % of the reads carry SMEMs with thousands of
 // occurrences (90 % of all located seeds) of which 500 each are used.  need[r] = that number; it sizes the read's scratch.
 // Reads that need more than heavy_thresh entries go to the wave kernels, one list per LDS size class.
-#define CH_N_CLASSES 9
-#define CH_HYBRID_CLASS 7
-__device__ __forceinline__ int ch_class_of(uint32_t need) { return need <= 64u ? 0 : need <= 128u ? 1 : need <= 256u ? 2 : need <= 384u ? 3 : need <= 512u ? 4 : need <= 620u ? 5 : need <= 1250u ? 6 : need <= 1860u ? 7 : 8; }
-// LDS entries per class; the hybrid class keeps only the arrays of the sequential phases in LDS (seeds, chains, the sorted chain index,
-// the sort keys: 84 bytes per entry) and the rest in the read's slice of the global scratch; the last class (a read that samples
-// more than 1860 occurrences: four SMEMs of 465+ hits each) works in global memory altogether
+#define CH_N_CLASSES 10
+#define CH_HYBRID_CLASS 5        // classes from here on keep only the arrays of the sequential phases in LDS
+#define CH_LANE_LIST_MAX 32     // class 0: reads of heavy_thresh+1 .. this many entries, chained one per LANE from their compacted list
+__device__ __forceinline__ int ch_class_of(uint32_t need, uint32_t lane_max) { return need <= lane_max ? 0 : need <= 64u ? 1 : need <= 128u ? 2 : need <= 256u ? 3 : need <= 384u ? 4 : need <= 512u ? 5 : need <= 620u ? 6 : need <= 1250u ? 7 : need <= 1860u ? 8 : 9; }
+// LDS entries per class; the hybrid classes (512 entries and up) keep only the arrays of the sequential phases in LDS (seeds, chains,
+// the sorted chain index, the sort keys: 84 bytes per entry instead of 124) and the rest in the read's slice of the global scratch:
+// these classes are LDS-bound -- three reads of 620 entries per CU instead of two was worth 1 ms of a 10 ms stage; the last class
+// (a read that samples more than 1860 occurrences: four SMEMs of 465+ hits each) works in global memory altogether
 // (a read that samples one SMEM of 500+ occurrences plus a few more seeds needs 500-600 entries: on the hg38-like genome most of
-// the reads beyond 256 entries sit there, hence the 512 and 620 classes -- 620 entries is what still fits a CU twice)
-static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {64u, 128u, 256u, 384u, 512u, 620u, 1250u, 1860u, 0u};
-static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {8192u, 4096u, 2048u, 1024u, 1024u, 768u, 512u, 256u, 256u};
+// the reads beyond 256 entries sit there, hence the 512 and 620 classes)
+static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {CH_LANE_LIST_MAX, 64u, 128u, 256u, 384u, 512u, 620u, 1250u, 1860u, 0u};
+static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {0u, 8192u, 4096u, 2048u, 1024u, 1024u, 768u, 512u, 256u, 256u};
 
 __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 {
@@ -61,7 +64,7 @@ __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 	}
 	A.need[r] = need;
 	if (need > A.heavy_thresh) {
-		const int cls = ch_class_of(need);
+		const int cls = ch_class_of(need, A.lane_max);
 		A.heavy_list[(size_t)cls * A.n_reads + atomicAdd(A.heavy_n + cls, 1u)] = r;
 	}
 }
@@ -70,6 +73,18 @@ __global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A)
 {
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
 	if (r >= A.n_reads || A.need[r] > A.heavy_thresh) return;
+	chain_core::chain_read<false>(A.x, r, chain_core::global_scratch(A.x, r));
+}
+
+// Lane form over the list of class 0.  The reads just above the lane kernel's threshold (17 .. 32 entries: most of the "heavy"
+// reads) cost a lane a few milliseconds of dependent steps, too long for the lane kernel, whose waves would all wait for their one
+// such read -- but compacted into their own list they are 64 reads of similar cost per wave, a few hundred waves that leave the
+// CUs (and all of the LDS) to the wave kernels of the larger classes.  One wave per read, they took a third of the stage.
+__global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, uint32_t cls)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= A.heavy_n[cls]) return;
+	const uint32_t r = A.heavy_list[(size_t)cls * A.n_reads + i];
 	chain_core::chain_read<false>(A.x, r, chain_core::global_scratch(A.x, r));
 }
 
@@ -319,7 +334,7 @@ extern "C" void bmh_chain_last_timing(const bmh_chain_ws_t *w, float ms[8])
 	for (int i = 0; i < 4; ++i) ms[i] = w->ms[i];
 	ms[4] = w->ms[4]; ms[5] = w->ms[5];
 	ms[6] = ms[7] = 0.f;                                       // reads chained by a wave: up to 512 entries / beyond
-	for (int c = 0; c < CH_N_CLASSES; ++c) ms[c <= 4 ? 6 : 7] += (float)w->heavy_per_class[c];
+	for (int c = 0; c < CH_N_CLASSES; ++c) ms[c <= 5 ? 6 : 7] += (float)w->heavy_per_class[c];
 }
 
 extern "C" int bmh_chain_set_contigs(bmh_chain_ws_t *w, int n_contigs, const int64_t *offset, const int32_t *len)
@@ -364,6 +379,10 @@ static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_op
 	A.n_reads = n_reads;
 	const char *ht = getenv("BMH_CHAIN_HEAVY");
 	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : 16u;
+	{
+		static const uint32_t lm = [] { const char *e = getenv("BMH_CHAIN_LANE_MAX"); const int v = e ? atoi(e) : CH_LANE_LIST_MAX; return (uint32_t)(v < 0 ? 0 : v > 64 ? 64 : v); }();   // (experiment knob; 0: no lane class)
+		A.lane_max = lm;
+	}
 	A.heavy_list = w->heavy_list; A.heavy_n = w->counters; A.need = w->need;
 #ifdef CH_PROFILE
 	{
@@ -391,13 +410,14 @@ static int chain_launch(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st, 
 	HIPCK(hipEventRecord(w->ev_t[2], st));
 	HIPCK(hipEventRecord(w->ev_t[3], w->side));
 	const bool ctg_lds = w->n_contigs > 1 && w->n_contigs <= CH_LDS_CONTIGS;
-	HIPCK(hipFuncSetAttribute(ctg_lds ? (const void *)chain_wave_kernel<true> : (const void *)chain_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[CH_HYBRID_CLASS] * CH_LDS_BYTES_PER_ENTRY_HYBRID)));
+	HIPCK(hipFuncSetAttribute(ctg_lds ? (const void *)chain_wave_kernel<true> : (const void *)chain_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[CH_N_CLASSES - 2] * CH_LDS_BYTES_PER_ENTRY_HYBRID)));
 	for (int cls = CH_N_CLASSES - 1; cls >= 0; --cls) {
 		const uint32_t lds_cap = CH_CLASS_CAP[cls];
-		const int hybrid = cls == CH_HYBRID_CLASS;
+		const int hybrid = cls >= CH_HYBRID_CLASS && lds_cap != 0;
 		const size_t lds_bytes = (size_t)lds_cap * (hybrid ? CH_LDS_BYTES_PER_ENTRY_HYBRID : CH_LDS_BYTES_PER_ENTRY);
 		HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->ev_fork, 0));
-		if (ctg_lds) chain_wave_kernel<true><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
+		if (cls == 0) chain_lane_list_kernel<<<nblk(n_reads, 256), 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls);     // (blocks beyond the list leave at once)
+		else if (ctg_lds) chain_wave_kernel<true><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
 		else chain_wave_kernel<false><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
 		HIPCK(hipEventRecord(w->cls_done[cls], w->cls_stream[cls]));
 		HIPCK(hipStreamWaitEvent(w->side, w->cls_done[cls], 0));

@@ -265,6 +265,8 @@ def main():
     # reference keeps several gpu_storage batches in flight across its host threads (src/fastmap.c:417-534, gasal_gpu_storage_v).
     # The chaining of the seed-rich reads is a long chain of dependent steps on few waves: alone it leaves most of the chip idle
     # while the rest of its batch waits for it; with a second batch in flight those CUs seed and extend.
+    lane_log = [] if os.environ.get("BENCH_LANE_LOG") else None
+
     class Lane:
         def __init__(self, k):
             self.k = k
@@ -292,7 +294,9 @@ def main():
                     for dst, src in zip(self.slot, host_in[i & 1]):
                         dst.copy_(src, non_blocking=True)
                 ascii_t, offs_t, lens_t = self.slot
+            t_host = [time.time()]
             sd = self.ws.seed_batch(dindex, ascii_t, offs_t, lens_t, 19, stream=self.h)
+            t_host.append(time.time())
             tm = self.ws.timing()
             if a.passes == 1:
                 dj_ = self.cw.chain_batch(dindex, ascii_t, offs_t, lens_t, sd, stream=self.h)
@@ -302,6 +306,9 @@ def main():
             else:
                 dj_ = self.cw.extend_merge(dindex, ascii_t, offs_t, lens_t, sd, self.regs, params=params, stream=self.h)
             self.n_regs = int(dj_.n_regs)
+            t_host.append(time.time())
+            if lane_log is not None:                                  # (BENCH_LANE_LOG=1: host-side begin / seeded / launched of every batch)
+                lane_log.append((self.k, i, *t_host))
             if host_in is not None:                                   # regions leave over PCIe, behind the lane's next batch
                 with torch.cuda.stream(self.stream):
                     self.host_out[: self.n_regs].copy_(self.regs[: self.n_regs], non_blocking=True)
@@ -350,13 +357,18 @@ def main():
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    if lane_log is not None:
+        lane_log.clear()
+    t0 = time.perf_counter(); t0_wall = time.time()
     run_steps(a.steps)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if lane_log:
+        for k_, i_, b_, s_, e_ in sorted(lane_log, key=lambda r: r[2]):
+            print(f"[lane {k_}] batch {i_}: begin {1e3 * (b_ - t0_wall):7.1f} ms  seeded {1e3 * (s_ - t0_wall):7.1f}  chain+extension launched {1e3 * (e_ - t0_wall):7.1f}", file=sys.stderr)
     stage_ms = {}
     for ln in lanes:
         for kk, v in ln.acc.items():

@@ -640,6 +640,15 @@ def test_device_job_builder_matches_host_builder(hip, oracle):
         rows.append(x)
     _device_chain_case(hip, oracle, g, idx, rows)
     _device_chain_case(hip, oracle, gr, idxr, readsr[:600], heavy=4, opt_over=dict(max_occ=20))
+    # reads from the first and the last bases of the reference, both strands: their target windows are clipped at position 0, at
+    # l_pac and at 2 l_pac, where the packed kernels' eight-rows-per-lane fetch of the 2-bit text clamps its three-byte window
+    rows = []
+    for k in range(240):
+        ln = int(rng.integers(60, 200)); p = int(rng.integers(0, 12)) if k & 1 else len(g) - ln - int(rng.integers(0, 12))
+        x = g[p:p + ln].copy()
+        m = rng.random(ln) < 0.04; x[m] = (x[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+        rows.append(synth.revcomp(x) if k & 2 else x)
+    _device_chain_case(hip, oracle, g, idx, rows)
 
 
 def test_device_job_builder_matches_reference_job_stream(hip):

@@ -136,7 +136,8 @@ CH_HD inline void w_comb(uint64_t *a, int n)
 	} while (swapped || gap > 2);
 	if (gap != 1) w_insertion(a, 0, n);
 }
-CH_HD inline bool w_introsort(uint64_t *a, int n)
+// FINAL = false leaves out the closing insertion sort over the whole array (the caller does it: w_place_coop)
+template <bool FINAL = true> CH_HD inline bool w_introsort(uint64_t *a, int n)
 {
 	if (n < 1) return true;
 	if (n == 2) { if (wlt(a[1], a[0])) wswap(a, 0, 1); return true; }
@@ -168,11 +169,135 @@ CH_HD inline bool w_introsort(uint64_t *a, int n)
 				t = i - s > 16 ? i - 1 : s;
 			}
 		} else {
-			if (sp == 0) { w_insertion(a, 0, n); return true; }
+			if (sp == 0) { if (FINAL) w_insertion(a, 0, n); return true; }
 			--sp; s = st_l[sp]; t = st_r[sp]; d = st_d[sp];
 		}
 	}
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// The closing insertion sort of the introsort, by the whole wave.  Insertion sort is stable, so what it produces is the stable
+// order by weight of what the quicksort phase left behind (which may be far from sorted: ks_introsort never looks at the first
+// entry of a partition, the closing pass is what puts it right).  Entry x therefore ends at the number of entries that sort ahead
+// of it: heavier ones, and equally heavy ones on its left -- one comparison on (weight << 16 | 0xFFFF - index).  NU entries per
+// lane against all others, 64 of those at a time through v_readlane; the chain ids go straight to order[] (nothing reads the
+// sorted keys).  Sequentially this pass was about half of the sort, and the sort a third of the chaining of a 500-seed read.
+// (weights are at most the read length, indices below 2^16: mem_chain samples at most max_occ occurrences per SMEM)
+template <int NU> __device__ __forceinline__ void w_place_part(const uint64_t *a, const uint32_t *hi, uint32_t *order, int n, int xb, int lane)
+{
+	uint32_t cx[NU]; int pos[NU];
+#pragma unroll
+	for (int u = 0; u < NU; ++u) {
+		const int x = xb + 64 * u + lane, xc = x < n ? x : n - 1;
+		cx[u] = (hi[2 * xc] << 16) | (0xFFFFu - (uint32_t)xc); pos[u] = 0;
+	}
+	for (int yb = 0; yb < n; yb += 64) {
+		const int y = yb + lane;
+		const uint32_t cy = y < n ? (hi[2 * y] << 16) | (0xFFFFu - (uint32_t)y) : 0u;       // 0 sorts behind every entry
+		const int ke = n - yb < 64 ? n - yb : 64;
+		for (int k = 0; k < ke; ++k) {
+			const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cy, k);
+#pragma unroll
+			for (int u = 0; u < NU; ++u) pos[u] += c > cx[u] ? 1 : 0;
+		}
+	}
+#pragma unroll
+	for (int u = 0; u < NU; ++u) { const int x = xb + 64 * u + lane; if (x < n) order[pos[u]] = (uint32_t)a[x]; }
+}
+// The quicksort phase of the same introsort with its partition loop spread over the wave.  ks_introsort's Hoare partition looks at
+// every entry at most once from either side before the pointers meet, so which entries it exchanges follows from the array as it is
+// when the partition starts: the k-th entry from the left that does not sort ahead of the pivot (weight <= pivot's, positions
+// s+1..t) goes where the k-th entry from the right that does not sort behind it (weight >= pivot's, positions t-1..s) is, as long
+// as the former lies left of the latter.  Pass A lists the right-hand candidates (tmp[s + k]), pass B ranks the left-hand ones,
+// exchanges the pairs and finds where the left pointer stops: at the first candidate without a partner, or on the entry the last
+// exchange brought to the right -- whichever comes first.  64 entries per step instead of one; pivot choice, recursion stack, depth
+// limit and the order of the partitions are the sequential code's.  tmp: n words (order[], not in use before the sort ends).
+template <bool LDSX> __device__ inline int w_partition_coop(uint64_t *a, uint32_t *tmp, const int s, const int t, const uint32_t wp)
+{
+	const int lane = ch_lane();
+	const uint32_t *hi = (const uint32_t *)a + 1;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	int nle = 0;
+	for (int top = t - 1; top >= s; top -= 64) {                       // pass A: lane l looks at position top - l
+		const int x = top - lane;
+		const bool le = x >= s && hi[2 * (x >= s ? x : s)] >= wp;
+		const unsigned long long m = __ballot(le);
+		if (le) tmp[s + nle + (int)__builtin_popcountll(m & below)] = (uint32_t)x;
+		nle += (int)__builtin_popcountll(m);
+	}
+	ch_wave_fence<LDSX>();
+	int k0 = 0, ipos = -1;
+	for (int lo = s + 1; ipos < 0; lo += 64) {                         // pass B (position t holds the pivot: the loop ends there at the latest)
+		const int x = lo + lane;
+		const bool ge = x <= t && hi[2 * (x <= t ? x : t)] <= wp;
+		const unsigned long long m = __ballot(ge);
+		const int k = k0 + (int)__builtin_popcountll(m & below);
+		int r = -1;
+		if (ge && k < nle) r = (int)tmp[s + k];
+		const bool sw = ge && r > x;
+		const unsigned long long ms = __ballot(sw);
+		if (sw) { const uint64_t va = a[x], vb = a[r]; a[x] = vb; a[r] = va; }
+		const unsigned long long stop = m & ~ms;
+		int cand = stop ? lo + (int)__builtin_ctzll(stop) : 0x7FFFFFFF;
+		if (ms) {
+			const int rl = __builtin_amdgcn_readlane(r, 63 - (int)__builtin_clzll(ms));      // where the last exchange put a left-hand entry
+			if (rl <= lo + 63 && rl < cand) cand = rl;
+		}
+		if (cand != 0x7FFFFFFF) ipos = cand;
+		k0 += (int)__builtin_popcountll(m);
+		ch_wave_fence<LDSX>();
+	}
+	return ipos;
+}
+template <bool LDSX> __device__ inline bool w_introsort_coop(uint64_t *a, uint32_t *tmp, int n)
+{
+	if (n < 1) return true;
+	if (n == 2) { if (wlt(a[1], a[0])) wswap(a, 0, 1); ch_wave_fence<LDSX>(); return true; }
+	int d;
+	for (d = 2; (1l << d) < n; ++d) ;
+	int st_l[40], st_r[40], st_d[40], sp = 0;
+	int s = 0, t = n - 1;
+	d <<= 1;
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) { w_comb(a + s, t - s + 1); ch_wave_fence<LDSX>(); t = s; continue; }
+			int i = s, j = t, k = i + ((j - i) >> 1) + 1;
+			{
+				const uint64_t ak = a[k], ai = a[i], aj = a[j];
+				if (wlt(ak, ai)) { if (wlt(ak, aj)) k = j; }
+				else k = wlt(aj, ai) ? i : j;
+			}
+			const uint64_t rp = a[k];
+			if (k != t) { wswap(a, k, t); ch_wave_fence<LDSX>(); }
+			i = w_partition_coop<LDSX>(a, tmp, s, t, (uint32_t)(rp >> 32));
+			if (i != t) { wswap(a, i, t); ch_wave_fence<LDSX>(); }
+			if (i - s > t - i) {
+				if (i - s > 16) { if (sp >= 40) return false; st_l[sp] = s; st_r[sp] = i - 1; st_d[sp] = d; ++sp; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { if (sp >= 40) return false; st_l[sp] = i + 1; st_r[sp] = t; st_d[sp] = d; ++sp; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (sp == 0) return true;
+			--sp; s = st_l[sp]; t = st_r[sp]; d = st_d[sp];
+		}
+	}
+}
+template <bool LDSX> __device__ inline void w_place_coop(const uint64_t *a, uint32_t *order, int n)
+{
+	const int lane = ch_lane();
+	const uint32_t *hi = (const uint32_t *)a + 1;                     // the weights: high words of the keys
+	for (int xb = 0; xb < n; xb += 512) {
+		const int rem = n - xb;
+		if (rem <= 64) w_place_part<1>(a, hi, order, n, xb, lane);
+		else if (rem <= 128) w_place_part<2>(a, hi, order, n, xb, lane);
+		else if (rem <= 256) w_place_part<4>(a, hi, order, n, xb, lane);
+		else w_place_part<8>(a, hi, order, n, xb, lane);
+	}
+	ch_wave_fence<LDSX>();
+}
+#endif
 
 // ---- helpers that are split across the wave when COOP
 // insert (cv, pv) at position at of order/opos[0..nc)
@@ -607,12 +732,17 @@ template <bool COOP, bool LDSX = false> CH_HD void chain_read(const ch_ctx_t &x,
 	}
 	if (na == 0) return;
 	CH_STAMP(2);
-	if (!w_introsort(srt, na)) { *x.err = 2; return; }
-	CH_STAMP(3);
-	for (int i = 0; i < na; ++i) order[i] = (uint32_t)srt[i];
 #if defined(__HIP_DEVICE_COMPILE__)
-	if (COOP) ch_wave_fence<LDSX>();
+	if (COOP) {
+		if (!w_introsort_coop<LDSX>(srt, order, na)) { *x.err = 2; return; }
+		w_place_coop<LDSX>(srt, order, na);
+	} else
 #endif
+	{
+		if (!w_introsort(srt, na)) { *x.err = 2; return; }
+		for (int i = 0; i < na; ++i) order[i] = (uint32_t)srt[i];
+	}
+	CH_STAMP(3);
 	int nk = 0;
 	bool kept_done = false;
 #if defined(__HIP_DEVICE_COMPILE__)

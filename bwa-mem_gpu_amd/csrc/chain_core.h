@@ -494,6 +494,41 @@ template <bool LDSX> __device__ inline bool ch_kept_by_classes(const bmh_chain_o
 			}
 			if (LDSX) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // LDS operations of a wave execute in order: no wait needed
 			else ch_wave_fence<LDSX>();
+			// A RUN of chains of the same class and weight behind chain i (the occurrences of one repetitive SMEM: hundreds of chains
+			// of one seed each) goes the way chain i went, all at once.  Neither the heavy prefix nor the first members of the
+			// classes move inside the run (the entries it appends weigh what its chains weigh), so: chain i dropped -- the run is
+			// dropped, and its scans find nothing left to mark below `reach`; chain i kept -- every chain of the run is kept, in
+			// order, each one's scan marking just the member before it (`first` = the next sorted index), the last one left
+			// unmarked.  One chain per lane instead of one chain per iteration.
+			{
+				const unsigned long long same = __ballot(b + lane < na && vcls == sc && vw == iw);
+				const unsigned long long ahead = u < 63 ? same >> (u + 1) : 0ull;
+				const int run = (int)__builtin_ctzll(~ahead);                      // chains u+1 .. u+run of this block
+				if (run > 0 && i > 0) {
+					if (!broke) {
+						const int len = iend - ibeg;
+						const bool self = len > 0 && len >= len * o.mask_level && len < o.max_chain_gap;      // the class overlaps itself
+						const bool large2 = large || self;
+						const int j = lane - u;                                        // 1 .. run: this lane's place in the run
+						const uint32_t k0 = (uint32_t)nk;                             // kept index of the run's first chain (j = 1); chain i has k0 - 1
+						if (j >= 1 && j <= run) {
+							const uint32_t k = k0 + (uint32_t)(j - 1);
+							klist[k] = (uint32_t)(i + j); kept_w[k] = iw; cls[k] = vci; mem_next[k] = j < run ? k + 1 : NIL;
+							CH[vci].kept = large2 ? 2u : 3u;
+							if (self && j < run) CH[vci].first = i + j + 1;            // marked by the next chain of the run
+						}
+						if (self && lane == u) CH[vci].first = i + 1;                  // chain i, marked by the run's first chain
+						if (lane == sc) {
+							mem_next[c_tail] = k0; c_tail = k0 + (uint32_t)run - 1; c_n += run;
+							c_um = self ? c_tail : c_um;                              // (without self-overlap nothing of the class gets marked)
+						}
+						nk += run;
+					}
+					u += run;
+					if (LDSX) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+					else ch_wave_fence<LDSX>();
+				}
+			}
 		}
 	}
 	nk_out = nk;

@@ -56,8 +56,13 @@ struct ch_ctx_t {
 // optional phase stamps (cycles) of one read, for tuning: compile with -DCH_PROFILE
 #if defined(CH_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define CH_STAMP(i) do { if (x.prof && r == x.prof_read) x.prof[i] = (long long)wall_clock64(); } while (0)
+// (accumulators of the occurrence batches of mem_chain: ticks into slot t, a count into the low / high half of slot c)
+#define CH_ACC_BEGIN() const long long acc_t0_ = (long long)wall_clock64()
+#define CH_ACC_END(t, c) do { if (x.prof && r == x.prof_read && ch_lane() == 0) { x.prof[t] += (long long)wall_clock64() - acc_t0_; x.prof[c] += 1; } } while (0)
 #else
 #define CH_STAMP(i) do { } while (0)
+#define CH_ACC_BEGIN() do { } while (0)
+#define CH_ACC_END(t, c) do { } while (0)
 #endif
 
 namespace chain_core {
@@ -637,6 +642,7 @@ template <bool COOP, bool LDSX = false> CH_HD void chain_read(const ch_ctx_t &x,
 				const bool act = cc < n_it;
 				const long long rbl = act ? (long long)g_rbeg[i + (int64_t)cc * step] : 0;
 				bool done = false;
+				CH_ACC_BEGIN();
 				if (n_it - c0 >= 8) {
 					int rid = -1;
 					if (act) rid = intv2rid<false>(x, rbl, rbl + slen);
@@ -708,9 +714,12 @@ template <bool COOP, bool LDSX = false> CH_HD void chain_read(const ch_ctx_t &x,
 						done = true;
 					}
 				}
+				CH_ACC_END(6, 9);
 				if (!done) {
 					const int m = n_it - c0 < 64 ? n_it - c0 : 64;
+					CH_ACC_BEGIN();
 					for (int u = 0; u < m; ++u) seq_one((int64_t)__shfl(rbl, u));
+					CH_ACC_END(7, 8);
 				}
 			}
 		} else

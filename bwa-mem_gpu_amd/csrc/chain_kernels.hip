@@ -481,10 +481,10 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	if (w->h_pin[2 + CH_N_CLASSES] != 0) { bmh_set_error("bmh_chain_batch: internal error %u in the chaining kernel", w->h_pin[2 + CH_N_CLASSES]); return BMH_ENODEV; }
 #ifdef CH_PROFILE
 	if (A.x.prof) {
-		long long pf[6];
+		long long pf[10];
 		HIPCK(hipMemcpy(pf, w->counters + 12, sizeof(pf), hipMemcpyDeviceToHost));
-		fprintf(stderr, "chain phases of read %u (x10ns ticks): chains %lld  weights %lld  sort %lld  kept %lld  chain2aln %lld\n", A.x.prof_read,
-		        pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4]);
+		fprintf(stderr, "chain phases of read %u (x10ns ticks): chains %lld  weights %lld  sort %lld  kept %lld  chain2aln %lld;  occurrence batches: %lld ticks in %lld lock-step attempts, %lld in %lld sequential ones\n", A.x.prof_read,
+		        pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4], pf[6], pf[9], pf[7], pf[8]);
 	}
 #endif
 	const uint64_t n_regs = w->h_pin[0], n_jobs = w->h_pin[1];

@@ -27,6 +27,7 @@ struct chain_args_t {
 	uint32_t lane_max;            // class 0 (lane form over its list) takes the reads of heavy_thresh+1 .. lane_max entries
 	uint32_t *heavy_list; uint32_t *heavy_n;
 	uint32_t *need;               // [n_reads] seed occurrences the chaining core will sample
+	uint32_t *light_list, *light_n;   // the reads of the lane kernel by need bin: [CH_N_BINS][n_reads], [CH_N_BINS]
 };
 
 // What a read costs the chaining core is the number of seed occurrences mem_chain SAMPLES (at most max_occ per SMEM,
@@ -46,33 +47,52 @@ __device__ __forceinline__ int ch_class_of(uint32_t need, uint32_t lane_max) { r
 static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {CH_LANE_LIST_MAX, 64u, 128u, 256u, 384u, 512u, 620u, 1250u, 1860u, 0u};
 static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {0u, 8192u, 4096u, 2048u, 1024u, 1024u, 768u, 512u, 256u, 256u};
 
+// need, the wave / lane-list class of a seed-rich read -- and, for the reads of the lane kernel, a BIN by need (<= 2, <= 4, <= 8,
+// the rest): the lane kernel walks the bins' compacted lists, so the 64 reads of a wave cost about the same.  In read order every
+// wave had a handful of 9-16 entry reads and took as long as those: 15 600 waves of ~1 ms each for reads most of which need 0.1 ms.
+// (appends aggregated per block: one atomic per bin and block on the global counters)
+#define CH_N_BINS 4
+__device__ __forceinline__ int ch_bin_of(uint32_t need) { return need <= 2u ? 0 : need <= 4u ? 1 : need <= 8u ? 2 : 3; }
 __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 {
+	__shared__ uint32_t l_cnt[CH_N_BINS], l_base[CH_N_BINS];
+	if (threadIdx.x < CH_N_BINS) l_cnt[threadIdx.x] = 0;
+	__syncthreads();
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-	if (r >= A.n_reads) return;
-	const uint32_t n = A.x.n_ref[r];
-	uint32_t need = n;
-	if (n > (uint32_t)A.x.o.max_occ) {          // only then can a group exceed max_occ
-		const uint32_t *sc = A.x.score + A.x.prefix[r];
-		need = 0;
-		for (uint32_t i = 0; i < n;) {
-			const uint32_t cnt = sc[i];
-			if (cnt == 0) break;
-			need += cnt < (uint32_t)A.x.o.max_occ ? cnt : (uint32_t)A.x.o.max_occ;
-			i += cnt;
+	int bin = -1; uint32_t my = 0;
+	if (r < A.n_reads) {
+		const uint32_t n = A.x.n_ref[r];
+		uint32_t need = n;
+		if (n > (uint32_t)A.x.o.max_occ) {          // only then can a group exceed max_occ
+			const uint32_t *sc = A.x.score + A.x.prefix[r];
+			need = 0;
+			for (uint32_t i = 0; i < n;) {
+				const uint32_t cnt = sc[i];
+				if (cnt == 0) break;
+				need += cnt < (uint32_t)A.x.o.max_occ ? cnt : (uint32_t)A.x.o.max_occ;
+				i += cnt;
+			}
 		}
+		A.need[r] = need;
+		if (need > A.heavy_thresh) {
+			const int cls = ch_class_of(need, A.lane_max);
+			A.heavy_list[(size_t)cls * A.n_reads + atomicAdd(A.heavy_n + cls, 1u)] = r;
+		} else { bin = ch_bin_of(need); my = atomicAdd(&l_cnt[bin], 1u); }
 	}
-	A.need[r] = need;
-	if (need > A.heavy_thresh) {
-		const int cls = ch_class_of(need, A.lane_max);
-		A.heavy_list[(size_t)cls * A.n_reads + atomicAdd(A.heavy_n + cls, 1u)] = r;
-	}
+	__syncthreads();
+	if (threadIdx.x < CH_N_BINS && l_cnt[threadIdx.x]) l_base[threadIdx.x] = atomicAdd(A.light_n + threadIdx.x, l_cnt[threadIdx.x]);
+	__syncthreads();
+	if (bin >= 0) A.light_list[(size_t)bin * A.n_reads + l_base[bin] + my] = r;
 }
 
+// one read per lane, the bins from the costliest down as one sequence
 __global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A)
 {
-	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-	if (r >= A.n_reads || A.need[r] > A.heavy_thresh) return;
+	uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	int bin = CH_N_BINS - 1;
+	for (; bin >= 0; --bin) { const uint32_t c = A.light_n[bin]; if (t < c) break; t -= c; }
+	if (bin < 0) return;
+	const uint32_t r = A.light_list[(size_t)bin * A.n_reads + t];
 	chain_core::chain_read<false>(A.x, r, chain_core::global_scratch(A.x, r));
 }
 
@@ -239,7 +259,7 @@ struct bmh_chain_ws {
 	ch_seed_t *seeds; ch_chain_t *chains; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx; ch_reg_t *regs; ch_est_t *est;
 	// per read
 	uint32_t *regs_per_read, *jobs_per_read, *reg_off, *job_off, *heavy_list, *need; float *frac_rep;
-	uint32_t *counters;            // [0..CH_N_CLASSES) heavy_n per size class  [CH_N_CLASSES] err  [12..] profile stamps
+	uint32_t *counters;            // [0..CH_N_CLASSES) heavy_n per size class  [CH_N_CLASSES] err  [12..32) profile stamps  [32..36) reads per need bin of the lane kernel
 	// contigs
 	int n_contigs; int64_t *ctg_off; int32_t *ctg_len;
 	// outputs, grown on demand
@@ -298,8 +318,8 @@ extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_
 	A(w->seeds, sizeof(ch_seed_t) * S); A(w->chains, sizeof(ch_chain_t) * S); A(w->order, 4 * S); A(w->opos, 8 * S); A(w->klist, 4 * S);
 	A(w->srt, 8 * S); A(w->cidx, 4 * S); A(w->regs, sizeof(ch_reg_t) * S); A(w->est, sizeof(ch_est_t) * S);
 	const size_t Rn = (size_t)max_reads + 1;
-	A(w->regs_per_read, 4 * Rn); A(w->jobs_per_read, 4 * Rn); A(w->reg_off, 4 * Rn); A(w->job_off, 4 * Rn); A(w->heavy_list, CH_N_CLASSES * 4 * Rn); A(w->need, 4 * Rn); A(w->frac_rep, 4 * Rn);
-	A(w->counters, 128);
+	A(w->regs_per_read, 4 * Rn); A(w->jobs_per_read, 4 * Rn); A(w->reg_off, 4 * Rn); A(w->job_off, 4 * Rn); A(w->heavy_list, (CH_N_CLASSES + CH_N_BINS) * 4 * Rn); A(w->need, 4 * Rn); A(w->frac_rep, 4 * Rn);
+	A(w->counters, 256);
 	for (int i = 0; i < 4; ++i) { A(w->cnt2[i], 4 * Rn); A(w->off2[i], 4 * Rn); }
 	A(w->need_sum, 16);
 	size_t t1 = 0, t2 = 0;
@@ -384,6 +404,7 @@ static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_op
 		A.lane_max = lm;
 	}
 	A.heavy_list = w->heavy_list; A.heavy_n = w->counters; A.need = w->need;
+	A.light_list = w->heavy_list + (size_t)CH_N_CLASSES * w->max_reads; A.light_n = w->counters + 32;
 #ifdef CH_PROFILE
 	{
 		const char *pr = getenv("BMH_CHAIN_PROF_READ");
@@ -398,7 +419,7 @@ static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_op
 static int chain_launch(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st, bool join)
 {
 	const uint32_t n_reads = A.n_reads;
-	HIPCK(hipMemsetAsync(w->counters, 0, 128, st));
+	HIPCK(hipMemsetAsync(w->counters, 0, 256, st));
 	HIPCK(hipMemsetAsync(w->regs_per_read + n_reads, 0, 4, st));
 	HIPCK(hipMemsetAsync(w->jobs_per_read + n_reads, 0, 4, st));
 	HIPCK(hipEventRecord(w->ev_t[0], st));

@@ -790,7 +790,7 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 // classes: 0 = unsupported length (query longer than 768 bases: all three outputs INT32_MIN, counted, see
 // bmh_extend_last_unsupported); 1..18 = extend16_kernel<C>; 19..26 = extend_wide_kernel<5..12>
 #define EXT_WIDE_MAX_C 12
-#define EXT_N_CLS 41
+#define EXT_N_CLS 42
 #define EXT_DONE_CLS 27     // decided by the closed-form prefilter: no DP
 #define EXT16_MAX_C 18
 // 28..34 = extpk_kernel<4, P>, P = 4, 6, .. 16 (queries up to 8 P columns); 35..39 = extpk_kernel<8, P>, P = 9, 10, 12, 14, 16
@@ -811,7 +811,10 @@ __device__ __forceinline__ int ext_class(uint32_t ql)
 	const int wc = (int)((ql + 63) / 64);
 	return wc <= EXT_WIDE_MAX_C ? 19 + (wc - 5) : 0;
 }
-constexpr int ext_pk_cls_of(int G, int P) { return EXT_PK_BASE + (G == 4 ? P / 2 - 2 : G == 16 ? 12 : P == 9 ? 7 : P == 10 ? 8 : P / 2 + 3); }
+// (G = 4, P = 17: queries of 129..136 columns -- the flank of a 150 bp read whose seed sits at its very end -- on four lanes
+// instead of eight: 26 instead of 34 wave-instructions per alignment row, for 15 % of the extension's time on 150 bp reads)
+#define EXT_PK17_CLS (EXT_PK_BASE + 13)
+constexpr int ext_pk_cls_of(int G, int P) { return G == 4 && P == 17 ? EXT_PK17_CLS : EXT_PK_BASE + (G == 4 ? P / 2 - 2 : G == 16 ? 12 : P == 9 ? 7 : P == 10 ? 8 : P / 2 + 3); }
 
 // sort key = class << 20 | tlen, plus a per-class histogram
 __global__ void __launch_bounds__(256) ext_key_kernel(const uint32_t *__restrict__ qlen, const uint32_t *__restrict__ tlen, const uint8_t *__restrict__ done, uint32_t n,
@@ -830,6 +833,7 @@ __global__ void __launch_bounds__(256) ext_key_kernel(const uint32_t *__restrict
 			const uint32_t ql = qlen[t];
 			const int pc = ext_pk_class(ql);
 			if (pc && tlen[t] <= (uint32_t)(ql <= 128 ? PK_TCAP(4) : ql <= 256 ? PK_TCAP(8) : PK_TCAP(16))) cls = pc;
+			if (pc && ql > 128 && ql <= 136 && tlen[t] <= (uint32_t)PK_TCAP(4) && h0[t] + ql * (uint32_t)pk_a < PK_HMAX17) cls = EXT_PK17_CLS;
 		}
 		if (cls == 0) out[3 * (size_t)t] = out[3 * (size_t)t + 1] = out[3 * (size_t)t + 2] = INT32_MIN;
 		uint32_t tl = tlen[t];
@@ -1068,7 +1072,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		if (g4 > max_grid) g4 = max_grid;
 		if (g8 > max_grid) g8 = max_grid;
 		const unsigned g4w = g4 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g4, g8w = g8 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g8, g16w = g16 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g16;
-		launch_pk<4, 16>(a, S[3], g4w); launch_pk<4, 14>(a, S[0], g4w); launch_pk<4, 12>(a, S[1], g4w); launch_pk<4, 10>(a, S[2], g4w);
+		launch_pk<4, 17>(a, S[2], g4w); launch_pk<4, 16>(a, S[3], g4w); launch_pk<4, 14>(a, S[0], g4w); launch_pk<4, 12>(a, S[1], g4w); launch_pk<4, 10>(a, S[2], g4w);
 		launch_pk<4, 8>(a, S[3], g4); launch_pk<4, 6>(a, S[0], g4); launch_pk<4, 4>(a, S[1], g4);
 		launch_pk<8, 9>(a, S[2], g8w); launch_pk<8, 10>(a, S[3], g8w); launch_pk<8, 12>(a, S[0], g8w); launch_pk<8, 14>(a, S[1], g8w); launch_pk<8, 16>(a, S[2], g8w);
 		launch_pk<16, 9>(a, S[3], g16w);

@@ -22,6 +22,7 @@
 // target bases of an alignment staged in LDS, by group width (the 4-lane groups are the many small queries: 64 of them per block)
 #define PK_TCAP(G) ((G) == 4 ? 384 : (G) == 8 ? 512 : 640)
 #define PK_HMAX 4096          // scores stay below this (keys are h << 4 | pair in 16 bits)
+#define PK_HMAX17 2048        // ... in the 17-pair class (keys h << 5 | pair)
 #define PK_NEG (-(1 << 28))
 
 // The pair steps are spelled out as asm blocks: left to itself the compiler turns min(x, 1) and the 0/1 multiply into per-half
@@ -94,7 +95,7 @@ __device__ __forceinline__ void pk_pair1(uint32_t &M, uint32_t &agg, const uint3
 // second pass of a pair: H = max(M, E, F) masked at `end`, E and F for the next cells, non-zero bits, row-maximum key (12 / 13 instructions).
 // H and NZ are declared read-write although their old values are dead: that ties the new values to the same registers, so the
 // loop-carried pairs are updated in place instead of being copied back at the end of every row.
-template <int SLOT, bool SAME_OE>
+template <int SLOT, bool SAME_OE, int KMUL>
 __device__ __forceinline__ void pk_pair2(uint32_t &H, uint32_t &E, uint32_t &NZ, uint32_t &f, uint32_t &key, uint32_t &nzb, const uint32_t M, const uint32_t em,
                                          const uint32_t ei2, const uint32_t ed2, const uint32_t oei2, const uint32_t oed2)
 {
@@ -109,11 +110,11 @@ __device__ __forceinline__ void pk_pair2(uint32_t &H, uint32_t &E, uint32_t &NZ,
 		    "v_pk_max_u16 %[E], %[E], %[t]\n\t"
 		    "v_pk_max_u16 %[f], %[f], %[t]\n\t"
 		    "v_pk_min_u16 %[NZ], %[H], 1 op_sel_hi:[1,0]\n\t"
-		    "v_pk_mad_u16 %[u], %[H], 16, %[slot] op_sel_hi:[1,0,0]\n\t"
+		    "v_pk_mad_u16 %[u], %[H], %[kmul], %[slot] op_sel_hi:[1,0,0]\n\t"
 		    "v_lshl_or_b32 %[nzb], %[nzb], 1, %[NZ]\n\t"
 		    "v_pk_max_u16 %[key], %[key], %[u]"
 		    : [H] "+v"(H), [E] "+v"(E), [NZ] "+v"(NZ), [f] "+v"(f), [key] "+v"(key), [nzb] "+v"(nzb), [t] "=&v"(t), [u] "=&v"(u)
-		    : [M] "v"(M), [em] "v"(em), [ei] "s"(ei2), [ed] "s"(ed2), [oei] "s"(oei2), [slot] "n"(SLOT));
+		    : [M] "v"(M), [em] "v"(em), [ei] "s"(ei2), [ed] "s"(ed2), [oei] "s"(oei2), [slot] "n"(SLOT), [kmul] "n"(KMUL));
 	else
 		asm("v_pk_max_u16 %[H], %[M], %[E]\n\t"
 		    "v_pk_sub_u16 %[t], %[M], %[oed] clamp\n\t"
@@ -125,11 +126,11 @@ __device__ __forceinline__ void pk_pair2(uint32_t &H, uint32_t &E, uint32_t &NZ,
 		    "v_and_b32 %[H], %[H], %[em]\n\t"
 		    "v_pk_max_u16 %[f], %[f], %[t]\n\t"
 		    "v_pk_min_u16 %[NZ], %[H], 1 op_sel_hi:[1,0]\n\t"
-		    "v_pk_mad_u16 %[u], %[H], 16, %[slot] op_sel_hi:[1,0,0]\n\t"
+		    "v_pk_mad_u16 %[u], %[H], %[kmul], %[slot] op_sel_hi:[1,0,0]\n\t"
 		    "v_lshl_or_b32 %[nzb], %[nzb], 1, %[NZ]\n\t"
 		    "v_pk_max_u16 %[key], %[key], %[u]"
 		    : [H] "+v"(H), [E] "+v"(E), [NZ] "+v"(NZ), [f] "+v"(f), [key] "+v"(key), [nzb] "+v"(nzb), [t] "=&v"(t), [u] "=&v"(u)
-		    : [M] "v"(M), [em] "v"(em), [ei] "s"(ei2), [ed] "s"(ed2), [oei] "s"(oei2), [oed] "s"(oed2), [slot] "n"(SLOT));
+		    : [M] "v"(M), [em] "v"(em), [ei] "s"(ei2), [ed] "s"(ed2), [oei] "s"(oei2), [oed] "s"(oed2), [slot] "n"(SLOT), [kmul] "n"(KMUL));
 }
 
 // ---- group primitives: G = 16 is one DPP row, G = 8 half of one, G = 4 a quad
@@ -231,9 +232,10 @@ struct pk_rs_t { int end, mx, max_i, max_j, max_ie, gscore, max_off; };
 
 template <int P, bool SAME_OE, int PP, int... Is>
 __device__ __forceinline__ void pk_pass2(uint32_t (&H)[P], uint32_t (&E)[P], uint32_t (&NZ)[P], const uint32_t (&M)[P], const uint32_t (&em)[PP],
-                                         uint32_t &f, uint32_t &key, uint32_t &nzb, const pk_consts_t &K, std::integer_sequence<int, Is...>)
+                                         uint32_t &f, uint32_t &key, uint32_t &nzb, uint32_t &nzb2, const pk_consts_t &K, std::integer_sequence<int, Is...>)
 {
-	(pk_pair2<Is, SAME_OE>(H[Is], E[Is], NZ[Is], f, key, nzb, M[Is], em[Is], K.ei2, K.ed2, K.oei2, K.oed2), ...);
+	// (keys are h << 4 | pair up to 16 pairs, h << 5 | pair beyond; the non-zero bits of pairs 16.. go to a second register)
+	(pk_pair2<Is, SAME_OE, (P > 16 ? 32 : 16)>(H[Is], E[Is], NZ[Is], f, key, Is < 16 ? nzb : nzb2, M[Is], em[Is], K.ei2, K.ed2, K.oei2, K.oed2), ...);
 }
 
 // One DP row of the wave's alignments.  em_tab: the end masks, [2P+1][PP] dwords in LDS; hrow: the group's PP dwords of the H
@@ -280,22 +282,30 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t &K, const int zdrop, ui
 		const int fin_hi = max(fin_lo - K.eP, fout_lo);
 		f = (uint32_t)fin_lo | ((uint32_t)fin_hi << 16);
 	}
-	uint32_t key = 0, nzb = 0;
-	pk_pass2<P, SAME_OE>(H, E, NZ, M, em, f, key, nzb, K, std::make_integer_sequence<int, P>());
+	uint32_t key = 0, nzb = 0, nzb2 = 0;
+	pk_pass2<P, SAME_OE>(H, E, NZ, M, em, f, key, nzb, nzb2, K, std::make_integer_sequence<int, P>());
 	// last non-zero H column of the lane, + 1 (0: none): pair p sits at bit P-1-p of its half of nzb (branch-free)
 	int nlast;
 	{
-		const uint32_t nh = nzb >> 16;
-		const uint32_t pick = nh ? nh : (nzb & 0xFFFFu);
-		const int base = nh ? j0 + 2 * P : j0 + P;                       // column of pair 0 + P
-		nlast = nzb ? base - (int)__builtin_ctz(pick | 0x10000u) : 0;
+		if (P <= 16) {
+			const uint32_t nh = nzb >> 16;
+			const uint32_t pick = nh ? nh : (nzb & 0xFFFFu);
+			const int base = nh ? j0 + 2 * P : j0 + P;                   // column of pair 0 + P
+			nlast = nzb ? base - (int)__builtin_ctz(pick | 0x10000u) : 0;
+		} else {                                                     // pairs 16.. (nzb2: pair p at bit P-1-p of its half) below pairs 0..15
+			const uint32_t nh = ((nzb >> 16) << (P - 16)) | (nzb2 >> 16), nl = ((nzb & 0xFFFFu) << (P - 16)) | (nzb2 & 0xFFFFu);
+			const uint32_t pick = nh ? nh : nl;
+			const int base = nh ? j0 + 2 * P : j0 + P;
+			nlast = pick ? base - (int)__builtin_ctz(pick) : 0;
+		}
 	}
 	// lane key (h << 16 | column): the high chain wins ties (its columns are the larger ones)
 	int kk;
 	{
 		const uint32_t kl = key & 0xFFFFu, kh = key >> 16;
-		const int Kl = (int)(((kl << 12) & 0xFFFF0000u) | (uint32_t)(j0 + (int)(kl & 15u)));
-		const int Kh = (int)(((kh << 12) & 0xFFFF0000u) | (uint32_t)(j0 + P + (int)(kh & 15u)));
+		constexpr int KSH = P > 16 ? 5 : 4;
+		const int Kl = (int)(((kl << (16 - KSH)) & 0xFFFF0000u) | (uint32_t)(j0 + (int)(kl & ((1u << KSH) - 1u))));
+		const int Kh = (int)(((kh << (16 - KSH)) & 0xFFFF0000u) | (uint32_t)(j0 + P + (int)(kh & ((1u << KSH) - 1u))));
 		kk = max(Kl, Kh);
 	}
 	grp_allmax2<G>(kk, nlast);

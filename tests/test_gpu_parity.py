@@ -235,7 +235,7 @@ def test_extension_asymmetric_gap_penalties(hip, oracle, scoring, packed):
 
 def test_extension_packed_class_boundaries(hip, oracle):
     """Jobs at the edges of what the packed 16-bit kernels take (csrc/extpk_dev.h): query lengths around every group / pair-count
-    boundary (128|129 columns: 4 -> 8 lanes, 256|257: 8 -> 16, 288|289: packed -> 32-bit), targets around the LDS staging caps
+    boundary (128|129 columns: 16 -> 17 pairs on 4 lanes, 136|137: 4 -> 8 lanes, 256|257: 8 -> 16, 288|289: packed -> 32-bit), targets around the LDS staging caps
     (384, 512, 640) and seed scores that push h0 + qlen*a across the 4096 limit of the 16-bit keys -- the router must send each job
     to a kernel that is exact for it."""
     import oracle_py
@@ -248,9 +248,9 @@ def test_extension_packed_class_boundaries(hip, oracle):
             mut = rng.random(ql) < 0.06
             q[mut] = (q[mut] + rng.integers(1, 4, size=int(mut.sum()))) & 3
         qs.append(q); ts.append(t); h0.append(h)
-    for ql in (1, 15, 16, 17, 31, 32, 33, 64, 65, 96, 97, 112, 113, 127, 128, 129, 143, 144, 145, 159, 160, 161, 192, 193, 224, 225, 255, 256, 257, 287, 288, 289, 300):
+    for ql in (1, 15, 16, 17, 31, 32, 33, 64, 65, 96, 97, 112, 113, 127, 128, 129, 132, 135, 136, 137, 143, 144, 145, 159, 160, 161, 192, 193, 224, 225, 255, 256, 257, 287, 288, 289, 300):
         for tl in (ql + 7, 383, 384, 385, 511, 512, 513, 639, 640, 641):
-            for h in (1, 19, 150, 4096 - ql - 1, 4096 - ql, 4096 - ql + 1, 5000):
+            for h in (1, 19, 150, 2048 - ql - 1, 2048 - ql, 2048 - ql + 1, 4096 - ql - 1, 4096 - ql, 4096 - ql + 1, 5000):       # (2048: the 17-pair class of 129..136 columns)
                 add(ql, tl, h)
     qlen = np.array([len(x) for x in qs], np.uint32); tlen = np.array([len(x) for x in ts], np.uint32)
     qoff = np.concatenate([[0], np.cumsum(qlen)[:-1]]).astype(np.uint32); toff = np.concatenate([[0], np.cumsum(tlen)[:-1]]).astype(np.uint32)

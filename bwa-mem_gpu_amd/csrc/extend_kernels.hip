@@ -687,10 +687,53 @@ __device__ __forceinline__ int row_allor_f(int v)
 // gscore = D(qlen-1), max_ie = qlen-1.  z-drop (ksw.c:951-959) is handled by requiring the draw-down at the
 // mismatch rows to stay within zdrop.  A flank starts right after a maximal exact match, so its first base is
 // usually the mismatch that ended the seed; most 150 bp flanks at 1 % error have at most one more.
-// One 16-lane row per job; jobs decided here get done[id] = 1 and never reach the DP kernels.
+// Eight lanes per job, eight columns per lane and step (the target codes of eight rows decoded at once from the 2-bit text, the query
+// bytes decoded four to a register; one column per lane and step, on sixteen lanes, this prefilter took 15 % of the stage);
+// jobs decided here get done[id] = 1 and never reach the DP kernels.
+__device__ __forceinline__ int grp8_allsum(int v)
+{
+	asm volatile("s_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_add_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+	             : "+v"(v));
+	return v;
+}
+__device__ __forceinline__ int grp8_allor(int v)
+{
+	asm volatile("s_nop 1\n\t"
+	             "v_or_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_or_b32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+	             "v_or_b32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+	             : "+v"(v));
+	return v;
+}
+// query codes of columns j0..j0+7 as two dwords (byte u of `lo` = column j0+u; columns at and beyond qlen: code 0); bad: one of the
+// columns below qlen is not A, C, G or T (descriptor jobs decode the ASCII reads: code = t ^ t >> 1 of t = bits 2:1 of the letter,
+// checked by looking the letter up again) -- array jobs carry their codes, anything above 3 shows in the bytes themselves
+__device__ __forceinline__ void pk_q8(const ext_args_t &A, const job_src_t &s, const int j0, const int qlen, uint32_t &lo, uint32_t &hi, bool &bad)
+{
+	uint32_t w[2] = {0, 0};
+#pragma unroll
+	for (int u = 0; u < 8; ++u) {
+		const int j = j0 + u;
+		const uint32_t b = j < qlen ? (uint32_t)s.qp[(long)j * s.qstep] : (A.desc ? 0x41u : 0u);
+		w[u >> 2] |= b << (8 * (u & 3));
+	}
+	bad = false;
+	if (A.desc) {
+#pragma unroll
+		for (int k = 0; k < 2; ++k) {
+			const uint32_t W = w[k] & 0xDFDFDFDFu, t = (W >> 1) & 0x03030303u, code = t ^ ((t >> 1) & 0x01010101u);
+			bad = bad || __builtin_amdgcn_perm(0u, 0x54474341u, code) != W;
+			w[k] = code;
+		}
+	}
+	lo = w[0]; hi = w[1];
+}
 __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint32_t n, uint8_t *__restrict__ done)
 {
-	const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+	const int lane = threadIdx.x & 63, l8 = lane & 7, grp = lane >> 3;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
 	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;
@@ -706,27 +749,34 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 	// the codes of the compared columns are kept in LDS (one row pair per job): the shifted-diagonal test of the two-mismatch
 	// form re-reads up to seven of them per row, which as fresh fetches (address arithmetic, ASCII / 2-bit decoding) was most
 	// of this kernel's instructions
-	__shared__ uint8_t q_lds[16][512], t_lds[16][512];
-	uint8_t *qs = q_lds[threadIdx.x >> 4], *ts = t_lds[threadIdx.x >> 4];
-	for (uint32_t w = wave * 4; w < n; w += n_waves * 4) {
+	__shared__ __attribute__((aligned(16))) uint8_t q_lds[32][512], t_lds[32][512];
+	uint8_t *qs = q_lds[threadIdx.x >> 3], *ts = t_lds[threadIdx.x >> 3];
+	for (uint32_t w = wave * 8; w < n; w += n_waves * 8) {
 		const uint32_t id = w + grp;
 		const bool have = id < n;
 		const int qlen = have ? (int)A.qlen[id] : 0, tlen = have ? (int)A.tlen[id] : 0, h0 = have ? (int)A.h0[id] : 1;
 		const job_src_t src = ext_job_src(A, id, have, qlen, tlen);
 		const bool elig = have && qlen > 0 && qlen <= 512 && tlen >= qlen && params_ok;     // (512: the LDS rows; longer queries have no DP class either)
 		int hi = -1, lo = -0x7000, cnt = 0;   // largest / (negated) smallest mismatching column, mismatch count of this lane
-		for (int j = l16; __any(elig && j < qlen); j += 16) {
-			if (elig && j < qlen) {
-				const int qb = ext_q_at(A, src, j), tb = ext_t_at(A, src, j);
-				qs[j] = (uint8_t)qb; ts[j] = (uint8_t)tb;
-				const bool bad = qb > 3 || tb > 3;                      // N on either side: not eligible
-				const bool mis = tb != qb;
-				hi = bad ? 0x7000 : (mis ? max(hi, j) : hi);
-				lo = bad ? 0 : (mis ? max(lo, -j) : lo);
-				cnt += (mis || bad) ? 1 : 0;
+		for (int j0 = 8 * l8; __any(elig && j0 < qlen); j0 += 64) {
+			if (elig && j0 < qlen) {
+				uint32_t tlo, thi, qlo, qhi; bool bad;
+				pk_t8(A, src, j0, tlen, tlo, thi);
+				pk_q8(A, src, j0, qlen, qlo, qhi, bad);
+				*(uint2 *)(qs + j0) = make_uint2(qlo, qhi); *(uint2 *)(ts + j0) = make_uint2(tlo, thi);
+				const int nv = qlen - j0 < 8 ? qlen - j0 : 8;                  // columns of this step below qlen
+				const unsigned long long vm = nv == 8 ? ~0ull : (1ull << (8 * nv)) - 1ull;
+				const unsigned long long q64 = (unsigned long long)qhi << 32 | qlo, t64 = (unsigned long long)thi << 32 | tlo;
+				bad = bad || ((q64 | t64) & 0xFCFCFCFCFCFCFCFCull & vm) != 0ull;      // N on either side: not eligible
+				unsigned long long x = (q64 ^ t64) & vm;
+				x = (x | x >> 1 | x >> 2) & 0x0101010101010101ull;            // one bit per mismatching column
+				if (x) { hi = max(hi, j0 + ((63 - (int)__builtin_clzll(x)) >> 3)); lo = max(lo, -(j0 + ((int)__builtin_ctzll(x) >> 3))); }
+				cnt += (int)__builtin_popcountll(x) + (bad ? 1 : 0);
+				hi = bad ? 0x7000 : hi; lo = bad ? 0 : lo;
 			}
 		}
-		hi = row_allmax_f(hi); lo = row_allmax_f(lo); cnt = row_allsum_f(cnt);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");           // the codes in LDS before other lanes read them below
+		hi = grp_allmax<8>(hi); lo = grp_allmax<8>(lo); cnt = grp8_allsum(cnt);
 		const bool clean = hi < 0x7000;
 		const int p1 = -lo, p2 = hi;
 		// two mismatches: every diagonal shifted by 0 < |d| <= lmax needs a mismatch in rows [p1+lmax, p2].  A diagonal
@@ -736,7 +786,7 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 		bool two = elig && clean && cnt == 2 && two_ok && p2 - p1 >= (lmax > 0 ? lmax : 1);
 		if (__any(two) && lmax > 0) {
 			int bits = 0;
-			for (int i = p1 + lmax + l16; __any(two && i <= p2); i += 16) {
+			for (int i = p1 + lmax + l8; __any(two && i <= p2); i += 8) {
 				if (two && i <= p2) {
 					const int tb = (int)ts[i];
 					for (int L = 1; L <= lmax; ++L) {
@@ -747,7 +797,7 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 					}
 				}
 			}
-			bits = row_allor_f(bits);
+			bits = grp8_allor(bits);
 			for (int L = 1; L <= lmax; ++L) {
 				const bool minus_ok = (bits >> (2 * (L - 1))) & 1;
 				const bool plus_ok = ((bits >> (2 * (L - 1) + 1)) & 1) || (L > lg && p2 > qlen - 1 - L);
@@ -763,7 +813,7 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 		bool ok = none || one || two;
 		ok = ok && (none || V1 - A.b > 0) && (!two || V2 - A.b > 0);
 		if (A.zdrop > 0 && two) ok = ok && (max(V1, V2) - V2 + A.b <= A.zdrop);
-		if (have && l16 == 0) {
+		if (have && l8 == 0) {
 			done[id] = ok ? 1 : 0;
 			if (ok) {
 				// running maximum with strict updates: start (h0, -1); segment ends (V1, p1-1), (V2, p2-1) [two only], (V3, qlen-1)
@@ -1042,7 +1092,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	HIPCK(hipEventRecord(g_scr.ev0, st));
 	HIPCK(hipMemsetAsync(g_scr.counts, 0, 4 * 3 * EXT_N_CLS, st));
 	{
-		unsigned gp = (unsigned)((n + 15) / 16);
+		unsigned gp = (unsigned)((n + 31) / 32);
 		if (gp > 4096) gp = 4096;
 		ext_closed_form_kernel<<<gp, 256, 0, st>>>(a, n, g_scr.done);
 	}

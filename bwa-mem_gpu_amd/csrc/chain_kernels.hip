@@ -55,8 +55,10 @@ static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {0u, 8192u, 4096u, 2048u, 10
 __device__ __forceinline__ int ch_bin_of(uint32_t need) { return need <= 2u ? 0 : need <= 4u ? 1 : need <= 8u ? 2 : 3; }
 __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 {
-	__shared__ uint32_t l_cnt[CH_N_BINS], l_base[CH_N_BINS];
-	if (threadIdx.x < CH_N_BINS) l_cnt[threadIdx.x] = 0;
+	// (bins CH_N_BINS.. of the block counters: the wave / lane-list classes -- 50 000 appends to two counters, one atomic each, were
+	// 0.4 ms of same-address atomics)
+	__shared__ uint32_t l_cnt[CH_N_BINS + CH_N_CLASSES], l_base[CH_N_BINS + CH_N_CLASSES];
+	if (threadIdx.x < CH_N_BINS + CH_N_CLASSES) l_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
 	int bin = -1; uint32_t my = 0;
@@ -74,15 +76,15 @@ __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 			}
 		}
 		A.need[r] = need;
-		if (need > A.heavy_thresh) {
-			const int cls = ch_class_of(need, A.lane_max);
-			A.heavy_list[(size_t)cls * A.n_reads + atomicAdd(A.heavy_n + cls, 1u)] = r;
-		} else { bin = ch_bin_of(need); my = atomicAdd(&l_cnt[bin], 1u); }
+		bin = need > A.heavy_thresh ? CH_N_BINS + ch_class_of(need, A.lane_max) : ch_bin_of(need);
+		my = atomicAdd(&l_cnt[bin], 1u);
 	}
 	__syncthreads();
-	if (threadIdx.x < CH_N_BINS && l_cnt[threadIdx.x]) l_base[threadIdx.x] = atomicAdd(A.light_n + threadIdx.x, l_cnt[threadIdx.x]);
+	if (threadIdx.x < CH_N_BINS + CH_N_CLASSES && l_cnt[threadIdx.x])
+		l_base[threadIdx.x] = atomicAdd(threadIdx.x < CH_N_BINS ? A.light_n + threadIdx.x : A.heavy_n + (threadIdx.x - CH_N_BINS), l_cnt[threadIdx.x]);
 	__syncthreads();
-	if (bin >= 0) A.light_list[(size_t)bin * A.n_reads + l_base[bin] + my] = r;
+	if (bin >= CH_N_BINS) A.heavy_list[(size_t)(bin - CH_N_BINS) * A.n_reads + l_base[bin] + my] = r;
+	else if (bin >= 0) A.light_list[(size_t)bin * A.n_reads + l_base[bin] + my] = r;
 }
 
 // one read per lane, the bins from the costliest down as one sequence
@@ -167,12 +169,15 @@ struct emit_args_t {
 	uint32_t *qlen, *tlen, *h0, *job_read, *job_reg, *job_side, *jq_src; int64_t *jt0;
 };
 
+// (reads with more regions than this are emitted by a wave each, emit_wave_kernel: a repetitive read has up to max_occ regions per
+// SMEM, and one lane writing a thousand job descriptors one after the other was what the second extension pass waited for)
+#define CH_EMIT_LANE_MAX 32
 __global__ void __launch_bounds__(256) emit_kernel(emit_args_t A)
 {
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
 	if (r >= A.n_reads) return;
 	const uint32_t nr = A.regs_per_read[r];
-	if (nr == 0) return;
+	if (nr == 0 || nr > CH_EMIT_LANE_MAX) return;
 	const ch_reg_t *R = A.regs + A.prefix[r];
 	uint32_t g = A.reg_base + A.reg_off[r], j = A.job_base + A.job_off[r];
 	const uint32_t roff = A.read_offs[r]; const int lq_ = (int)A.read_lens[r];
@@ -191,6 +196,53 @@ __global__ void __launch_bounds__(256) emit_kernel(emit_args_t A)
 			A.jt0[j] = a.seed_rbeg + a.seedlen0; ++j;
 		}
 		A.outregs[g] = o;
+	}
+}
+
+// the same for the reads of the wave classes' lists that have more than CH_EMIT_LANE_MAX regions (fewer sampled seeds than that
+// cannot make that many): one wave per read, one region per lane, the jobs' places by ballot counts
+__global__ void __launch_bounds__(256) emit_wave_kernel(emit_args_t A, const uint32_t *__restrict__ lists, const uint32_t *__restrict__ list_n, int cls_lo, int cls_hi)
+{
+	const int lane = threadIdx.x & 63;
+	const uint32_t gw = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	for (int cls = cls_lo; cls <= cls_hi; ++cls) {
+		const uint32_t nh = list_n[cls];
+		const uint32_t *list = lists + (size_t)cls * A.n_reads;
+		for (uint32_t k = gw; k < nh; k += n_waves) {
+			const uint32_t r = list[k];
+			const uint32_t nr = A.regs_per_read[r];
+			if (nr <= CH_EMIT_LANE_MAX) continue;
+			const ch_reg_t *R = A.regs + A.prefix[r];
+			const uint32_t g0 = A.reg_base + A.reg_off[r];
+			uint32_t j0 = A.job_base + A.job_off[r];
+			const uint32_t roff = A.read_offs[r]; const int lq_ = (int)A.read_lens[r];
+			for (uint32_t b = 0; b < nr; b += 64) {
+				const uint32_t i = b + (uint32_t)lane;
+				const bool v = i < nr;
+				ch_reg_t a = R[v ? i : nr - 1];
+				const bool has0 = v && a.seed_qbeg > 0, has1 = v && a.rq > 0;
+				const unsigned long long m0 = __ballot(has0), m1 = __ballot(has1);
+				uint32_t j = j0 + (uint32_t)__builtin_popcountll(m0 & lt) + (uint32_t)__builtin_popcountll(m1 & lt);
+				if (v) {
+					const uint32_t g = g0 + i;
+					ch_outreg_t o; o.seed_rbeg = a.seed_rbeg; o.seed_qbeg = a.seed_qbeg; o.seedlen0 = a.seedlen0; o.job0 = o.job1 = -1; o.read = r; o.l_query = lq_;
+					if (has0) {
+						o.job0 = (int32_t)j;
+						A.qlen[j] = (uint32_t)a.seed_qbeg; A.tlen[j] = (uint32_t)a.lr; A.h0[j] = (uint32_t)a.seedlen0;
+						A.job_read[j] = r; A.job_reg[j] = g; A.job_side[j] = 0; A.jq_src[j] = roff; A.jt0[j] = a.rmax0; ++j;
+					}
+					if (has1) {
+						o.job1 = (int32_t)j;
+						A.qlen[j] = (uint32_t)a.rq; A.tlen[j] = (uint32_t)a.rr; A.h0[j] = (uint32_t)a.seedlen0;
+						A.job_read[j] = r; A.job_reg[j] = g; A.job_side[j] = 1; A.jq_src[j] = roff + (uint32_t)(a.seed_qbeg + a.seedlen0);
+						A.jt0[j] = a.seed_rbeg + a.seedlen0;
+					}
+					A.outregs[g] = o;
+				}
+				j0 += (uint32_t)__builtin_popcountll(m0) + (uint32_t)__builtin_popcountll(m1);
+			}
+		}
 	}
 }
 
@@ -532,6 +584,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	E.read_offs = d_offs; E.read_lens = d_lens; E.n_reads = n_reads; E.outregs = w->outregs; E.reg_base = E.job_base = 0;
 	E.qlen = w->qlen; E.tlen = w->tlen; E.h0 = w->h0; E.job_read = w->job_read; E.job_reg = w->job_reg; E.job_side = w->job_side; E.jq_src = w->jq_src; E.jt0 = w->jt0;
 	emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
+	emit_wave_kernel<<<1024, 256, 0, st>>>(E, w->heavy_list, w->counters, 1, CH_N_CLASSES - 1);
 	out->d_qlen = w->qlen; out->d_tlen = w->tlen; out->d_h0 = w->h0; out->d_job_read = w->job_read; out->d_job_reg = w->job_reg; out->d_job_side = w->job_side;
 	out->d_qoff = w->qoff; out->d_toff = w->toff;
 	if (n_jobs == 0 || !w->materialize) { out->d_qoff = out->d_toff = nullptr; HIPCK(hipGetLastError()); return BMH_OK; }
@@ -730,6 +783,7 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	if (n_regs_b) {
 		E.regs_per_read = w->cnt2[2]; E.reg_off = w->off2[2]; E.job_off = w->off2[3]; E.reg_base = (uint32_t)n_regs_a; E.job_base = (uint32_t)n_jobs_a;
 		emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
+		emit_wave_kernel<<<1024, 256, 0, st>>>(E, w->heavy_list, w->counters, 1, CH_N_CLASSES - 1);
 		if (n_jobs_b) {
 			d.jq_src = w->jq_src + n_jobs_a; d.job_side = w->job_side + n_jobs_a; d.jt0 = w->jt0 + n_jobs_a;
 			const int rc = bmh_extend_batch_desc(&d, w->qlen + n_jobs_a, w->tlen + n_jobs_a, w->h0 + n_jobs_a, (uint32_t)n_jobs_b, ep, w->out3 + 3 * n_jobs_a, nullptr, stream_);

@@ -30,8 +30,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))
-# the library's own default (csrc/c_api.hip), set here because torch initialises HIP before the library is loaded
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -20,11 +20,6 @@ extern "C" void bmh_set_error(const char *fmt, ...)
 
 extern "C" const char *bmh_last_error(void) { return g_err; }
 
-// The stages fork their size classes over side streams (up to ten kernels of one batch beside each other, two batches in flight),
-// and HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues, four by default: streams that share a queue
-// take turns.  Eight measured 2 % better on the bench workload, sixteen 10 % worse.  Set when the library is loaded, unless the
-// user has set it; without effect if the process has initialised HIP before loading us.
-__attribute__((constructor)) static void bmh_runtime_defaults(void) { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" int bmh_device_count(void)
 {

@@ -16,7 +16,8 @@ struct bmh_ext_desc_t {
 	const uint8_t *pac; long long l_pac;     // 2-bit forward strand
 	const uint32_t *jq_src;      // [n] offset of the query segment in reads
 	const uint32_t *job_side;    // [n] 0 = LEFT (both sequences run backwards), 1 = RIGHT
-	const int64_t *jt0;          // [n] first text position of the target window
+	const int64_t *jt0;          // [n] first text position of the target window; a window lies on ONE strand of fwd . revcomp(fwd)
+	                             // (mem_chain2aln clips it at l_pac, src/bwamem.c:1261-1264): the kernels decode eight rows at a time on that premise
 };
 int bmh_extend_batch_desc(const bmh_ext_desc_t *desc, const uint32_t *d_qlen, const uint32_t *d_tlen, const uint32_t *d_h0, uint32_t n,
                           const bmh_ext_params_t *p, int32_t *d_out, int32_t *d_raw, void *stream);

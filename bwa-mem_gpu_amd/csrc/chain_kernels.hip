@@ -584,7 +584,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	E.read_offs = d_offs; E.read_lens = d_lens; E.n_reads = n_reads; E.outregs = w->outregs; E.reg_base = E.job_base = 0;
 	E.qlen = w->qlen; E.tlen = w->tlen; E.h0 = w->h0; E.job_read = w->job_read; E.job_reg = w->job_reg; E.job_side = w->job_side; E.jq_src = w->jq_src; E.jt0 = w->jt0;
 	emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
-	emit_wave_kernel<<<1024, 256, 0, st>>>(E, w->heavy_list, w->counters, 1, CH_N_CLASSES - 1);
+	emit_wave_kernel<<<1024, 256, 0, st>>>(E, w->heavy_list, w->counters, 0, CH_N_CLASSES - 1);
 	out->d_qlen = w->qlen; out->d_tlen = w->tlen; out->d_h0 = w->h0; out->d_job_read = w->job_read; out->d_job_reg = w->job_reg; out->d_job_side = w->job_side;
 	out->d_qoff = w->qoff; out->d_toff = w->toff;
 	if (n_jobs == 0 || !w->materialize) { out->d_qoff = out->d_toff = nullptr; HIPCK(hipGetLastError()); return BMH_OK; }
@@ -783,7 +783,7 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	if (n_regs_b) {
 		E.regs_per_read = w->cnt2[2]; E.reg_off = w->off2[2]; E.job_off = w->off2[3]; E.reg_base = (uint32_t)n_regs_a; E.job_base = (uint32_t)n_jobs_a;
 		emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
-		emit_wave_kernel<<<1024, 256, 0, st>>>(E, w->heavy_list, w->counters, 1, CH_N_CLASSES - 1);
+		emit_wave_kernel<<<1024, 256, 0, st>>>(E, w->heavy_list, w->counters, 0, CH_N_CLASSES - 1);
 		if (n_jobs_b) {
 			d.jq_src = w->jq_src + n_jobs_a; d.job_side = w->job_side + n_jobs_a; d.jt0 = w->jt0 + n_jobs_a;
 			const int rc = bmh_extend_batch_desc(&d, w->qlen + n_jobs_a, w->tlen + n_jobs_a, w->h0 + n_jobs_a, (uint32_t)n_jobs_b, ep, w->out3 + 3 * n_jobs_a, nullptr, stream_);

@@ -714,11 +714,17 @@ __device__ __forceinline__ int grp8_allor(int v)
 __device__ __forceinline__ void pk_q8(const ext_args_t &A, const job_src_t &s, const int j0, const int qlen, uint32_t &lo, uint32_t &hi, bool &bad)
 {
 	uint32_t w[2] = {0, 0};
+	if (j0 + 8 <= qlen) {                 // all eight columns exist: two unaligned dword loads, byte-swapped when the job runs backwards
+		const uint8_t *p0 = s.qp + (long)j0 * s.qstep;
+		if (s.qstep > 0) { __builtin_memcpy(&w[0], p0, 4); __builtin_memcpy(&w[1], p0 + 4, 4); }
+		else { uint32_t a, b; __builtin_memcpy(&a, p0 - 3, 4); __builtin_memcpy(&b, p0 - 7, 4); w[0] = __builtin_bswap32(a); w[1] = __builtin_bswap32(b); }
+	} else {
 #pragma unroll
-	for (int u = 0; u < 8; ++u) {
-		const int j = j0 + u;
-		const uint32_t b = j < qlen ? (uint32_t)s.qp[(long)j * s.qstep] : (A.desc ? 0x41u : 0u);
-		w[u >> 2] |= b << (8 * (u & 3));
+		for (int u = 0; u < 8; ++u) {
+			const int j = j0 + u;
+			const uint32_t b = j < qlen ? (uint32_t)s.qp[(long)j * s.qstep] : (A.desc ? 0x41u : 0u);
+			w[u >> 2] |= b << (8 * (u & 3));
+		}
 	}
 	bad = false;
 	if (A.desc) {

@@ -68,8 +68,10 @@ __device__ __forceinline__ void pk_t8(const ext_args_t &A, const job_src_t &s, c
 	long long fa = asc ? f0 : f0 - 7;                                // lowest position of the eight
 	int D = 7;                                                       // descending: row u is symbol D - u of the window at fa
 	if (fa < 0) { D = (int)f0; fa = 0; }
-	const uint8_t *bp = A.pac + (fa >> 2);
-	const uint32_t v = ((uint32_t)bp[0] << 16) | ((uint32_t)bp[1] << 8) | (uint32_t)bp[2];        // (pac is readable 9 bytes past its end)
+	// three bytes of the text as ONE unaligned dword load (the 64 lanes of a staging step read 64 different lines: what such a step
+	// costs is its number of load instructions; pac is readable 9 bytes past its end)
+	uint32_t raw; __builtin_memcpy(&raw, A.pac + (fa >> 2), 4);
+	const uint32_t v = __builtin_bswap32(raw) >> 8;
 	const uint32_t y = (v << (8 + 2 * ((int)fa & 3))) >> 16;          // eight symbols, position fa+j at bits 15-2j:14-2j
 	const uint32_t z = asc ? y : y >> (2 * (7 - D));
 	const uint32_t w0 = pk_spread4(z & 0xFFu), w1 = pk_spread4((z >> 8) & 0xFFu);

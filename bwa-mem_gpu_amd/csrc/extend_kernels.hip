@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t
 	// Each 16-lane row works on its own alignment and row index; a row whose alignment has ended takes the next job
 	// of the class from a global counter (longest first), so the four rows of a wave never wait for the slowest.
 	// the target of a row's alignment is staged in LDS when the row takes the job (EXT_T_CAP bases; longer targets
-	// never reach this kernel: ext_key_kernel), so the row loop itself has no global loads to wait for
+	// never reach this kernel: ext_bin_kernel), so the row loop itself has no global loads to wait for
 	__shared__ uint8_t t_lds[16][EXT_T_CAP];
 	uint8_t *tl = t_lds[threadIdx.x >> 4];
 	bool have = false, alive = false;
@@ -872,14 +872,18 @@ __device__ __forceinline__ int ext_class(uint32_t ql)
 #define EXT_PK17_CLS (EXT_PK_BASE + 13)
 constexpr int ext_pk_cls_of(int G, int P) { return G == 4 && P == 17 ? EXT_PK17_CLS : EXT_PK_BASE + (G == 4 ? P / 2 - 2 : G == 16 ? 12 : P == 9 ? 7 : P == 10 ? 8 : P / 2 + 3); }
 
-// sort key = class << 20 | tlen, plus a per-class histogram
-__global__ void __launch_bounds__(256) ext_key_kernel(const uint32_t *__restrict__ qlen, const uint32_t *__restrict__ tlen, const uint8_t *__restrict__ done, uint32_t n,
-                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                      uint32_t *__restrict__ counts, int32_t *__restrict__ out,
+// The jobs of a batch are grouped by class and, inside a class, by target length in steps of 32 rows (the class kernels draw from
+// the long end, so that their tails are short jobs): a counting sort over EXT_N_BINS = classes x 16 bins in three small kernels --
+// bin of every job + histogram, offsets, scatter -- instead of a radix sort of (class << 20 | tlen) keys (six launches, 0.75 ms of
+// every extension pass for 2 M jobs).  The order inside a bin is whatever the blocks' atomics make it; every job is independent.
+#define EXT_TL_BINS 16
+#define EXT_N_BINS (EXT_N_CLS * EXT_TL_BINS)
+__global__ void __launch_bounds__(256) ext_bin_kernel(const uint32_t *__restrict__ qlen, const uint32_t *__restrict__ tlen, const uint8_t *__restrict__ done, uint32_t n,
+                                                      uint32_t *__restrict__ bin_of, uint32_t *__restrict__ bin_cnt, int32_t *__restrict__ out,
                                                       const uint32_t *__restrict__ h0, int pk_a)      // pk_a > 0: packed 16-bit kernels allowed, match score
 {
-	__shared__ uint32_t hist[EXT_N_CLS];
-	if (threadIdx.x < EXT_N_CLS) hist[threadIdx.x] = 0;
+	__shared__ uint32_t hist[EXT_N_BINS];
+	for (int k = threadIdx.x; k < EXT_N_BINS; k += 256) hist[k] = 0;
 	__syncthreads();
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t < n) {
@@ -892,22 +896,42 @@ __global__ void __launch_bounds__(256) ext_key_kernel(const uint32_t *__restrict
 			if (pc && ql > 128 && ql <= 136 && tlen[t] <= (uint32_t)PK_TCAP(4) && h0[t] + ql * (uint32_t)pk_a < PK_HMAX17) cls = EXT_PK17_CLS;
 		}
 		if (cls == 0) out[3 * (size_t)t] = out[3 * (size_t)t + 1] = out[3 * (size_t)t + 2] = INT32_MIN;
-		uint32_t tl = tlen[t];
-		keys[t] = ((uint32_t)cls << 20) | (tl > 0xFFFFFu ? 0xFFFFFu : tl);
-		vals[t] = t;
-		atomicAdd(&hist[cls], 1u);
+		const uint32_t tb = tlen[t] >> 5;
+		const uint32_t bin = (uint32_t)cls * EXT_TL_BINS + (tb < EXT_TL_BINS - 1 ? tb : EXT_TL_BINS - 1);
+		bin_of[t] = bin;
+		atomicAdd(&hist[bin], 1u);
 	}
 	__syncthreads();
-	if (threadIdx.x < EXT_N_CLS && hist[threadIdx.x]) atomicAdd(&counts[2 * threadIdx.x], hist[threadIdx.x]);
+	for (int k = threadIdx.x; k < EXT_N_BINS; k += 256) if (hist[k]) atomicAdd(&bin_cnt[k], hist[k]);
 }
 
-// counts[2c] = size of class c -> counts[2c+1] = its offset in the sorted list
-__global__ void ext_offsets_kernel(uint32_t *counts)
+// bin_cnt -> bin_base (start of every bin in the grouped list); counts[2c] = size of class c, counts[2c+1] = its offset
+__global__ void ext_offsets_kernel(uint32_t *counts, const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_base)
 {
 	if (threadIdx.x == 0) {
 		uint32_t acc = 0;
-		for (int c = 0; c < EXT_N_CLS; ++c) { counts[2 * c + 1] = acc; acc += counts[2 * c]; }
+		for (int c = 0; c < EXT_N_CLS; ++c) {
+			counts[2 * c + 1] = acc;
+			for (int b = 0; b < EXT_TL_BINS; ++b) { bin_base[c * EXT_TL_BINS + b] = acc; acc += bin_cnt[c * EXT_TL_BINS + b]; }
+			counts[2 * c] = acc - counts[2 * c + 1];
+		}
 	}
+}
+
+// every block takes a range of each of its bins with one atomic, its jobs their places in it with LDS atomics
+__global__ void __launch_bounds__(256) ext_scatter_kernel(const uint32_t *__restrict__ bin_of, uint32_t n, const uint32_t *__restrict__ bin_base,
+                                                          uint32_t *__restrict__ bin_cur, uint32_t *__restrict__ ids)
+{
+	__shared__ uint32_t hist[EXT_N_BINS], base[EXT_N_BINS];
+	for (int k = threadIdx.x; k < EXT_N_BINS; k += 256) hist[k] = 0;
+	__syncthreads();
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t bin = 0, my = 0;
+	if (t < n) { bin = bin_of[t]; my = atomicAdd(&hist[bin], 1u); }
+	__syncthreads();
+	for (int k = threadIdx.x; k < EXT_N_BINS; k += 256) if (hist[k]) base[k] = bin_base[k] + atomicAdd(&bin_cur[k], hist[k]);
+	__syncthreads();
+	if (t < n) ids[base[bin] + my] = t;
 }
 
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
@@ -915,7 +939,7 @@ __global__ void ext_offsets_kernel(uint32_t *counts)
 // scratch for the sorted job list: one per (device, stream), grown on demand and reused across calls, so
 // that batches in flight on different streams never share it
 struct ext_scratch_t {
-	uint32_t *keys, *vals, *keys2, *vals2, *counts; uint8_t *done; void *tmp; size_t tmp_bytes; size_t cap; int dev;
+	uint32_t *keys, *vals2, *counts, *bins; uint8_t *done; size_t cap; int dev;      // keys: bin of every job; vals2: job ids grouped by bin; bins: [3][EXT_N_BINS] count / base / cursor
 	hipEvent_t ev0, ev1; bool have_ev;
 	hipStream_t side[4]; hipEvent_t fork, join[4];     // class kernels run concurrently on side streams
 };
@@ -951,7 +975,7 @@ extern "C" void bmh_extend_release(void *stream_)
 		g_scr_map.erase(it);
 	}
 	if (g_last == s) g_last = nullptr;
-	void *ps[] = {s->keys, s->vals, s->keys2, s->vals2, s->counts, s->tmp, s->done};
+	void *ps[] = {s->keys, s->vals2, s->counts, s->bins, s->done};
 	for (void *q : ps) if (q) (void)hipFree(q);
 	if (s->have_ev) {
 		(void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1); (void)hipEventDestroy(s->fork);
@@ -1058,17 +1082,14 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	ext_scratch_t &g_scr = *scratch_for(dev, stream_);
 	g_last = &g_scr;
 	if (g_scr.cap < n) {
-		void *ps[] = {g_scr.keys, g_scr.vals, g_scr.keys2, g_scr.vals2, g_scr.counts, g_scr.tmp, g_scr.done};
+		void *ps[] = {g_scr.keys, g_scr.vals2, g_scr.counts, g_scr.bins, g_scr.done};
 		for (void *q : ps) if (q) (void)hipFree(q);
-		g_scr.keys = g_scr.vals = g_scr.keys2 = g_scr.vals2 = g_scr.counts = nullptr; g_scr.tmp = nullptr; g_scr.done = nullptr; g_scr.cap = 0;
-		HIPCK(hipMalloc((void **)&g_scr.keys, 4 * (size_t)n)); HIPCK(hipMalloc((void **)&g_scr.vals, 4 * (size_t)n));
-		HIPCK(hipMalloc((void **)&g_scr.keys2, 4 * (size_t)n)); HIPCK(hipMalloc((void **)&g_scr.vals2, 4 * (size_t)n));
+		g_scr.keys = g_scr.vals2 = g_scr.counts = g_scr.bins = nullptr; g_scr.done = nullptr; g_scr.cap = 0;
+		HIPCK(hipMalloc((void **)&g_scr.keys, 4 * (size_t)n)); HIPCK(hipMalloc((void **)&g_scr.vals2, 4 * (size_t)n));
 		HIPCK(hipMalloc((void **)&g_scr.counts, 4 * 3 * EXT_N_CLS));
+		HIPCK(hipMalloc((void **)&g_scr.bins, 4 * 3 * EXT_N_BINS));
 		HIPCK(hipMalloc((void **)&g_scr.done, (size_t)n));
-		size_t tb = 0;
-		HIPCK(rocprim::radix_sort_pairs(nullptr, tb, g_scr.keys, g_scr.keys2, g_scr.vals, g_scr.vals2, (size_t)n, 0, 26, st));
-		HIPCK(hipMalloc(&g_scr.tmp, tb + 256));
-		g_scr.tmp_bytes = tb; g_scr.cap = n; g_scr.dev = dev;
+		g_scr.cap = n; g_scr.dev = dev;
 	}
 	if (!g_scr.have_ev) {
 		HIPCK(hipEventCreate(&g_scr.ev0)); HIPCK(hipEventCreate(&g_scr.ev1));
@@ -1096,7 +1117,12 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		a.stats = d_stats;
 	}
 	HIPCK(hipEventRecord(g_scr.ev0, st));
+	static const bool want_phases = getenv("BMH_EXT_PHASES") != nullptr;      // debug: time of the prefilter / key / sort phases of every call
+	static thread_local hipEvent_t ph[4] = {nullptr, nullptr, nullptr, nullptr};
+	if (want_phases && !ph[0]) for (hipEvent_t &e : ph) HIPCK(hipEventCreate(&e));
+	if (want_phases) HIPCK(hipEventRecord(ph[0], st));
 	HIPCK(hipMemsetAsync(g_scr.counts, 0, 4 * 3 * EXT_N_CLS, st));
+	HIPCK(hipMemsetAsync(g_scr.bins, 0, 4 * 3 * EXT_N_BINS, st));
 	{
 		unsigned gp = (unsigned)((n + 31) / 32);
 		if (gp > 4096) gp = 4096;
@@ -1104,12 +1130,11 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	}
 	// packed 16-bit rows need 1 <= b, a + b <= 255 (byte score table), a >= 0 and gap penalties that fit the 16-bit lanes
 	const bool pk_ok = g_ext_packed && p->a > 0 && p->b >= 1 && p->a + p->b <= 255 && p->o_del + p->e_del < 4096 && p->o_ins + p->e_ins < 4096 && p->e_ins * 32 < 4096;
-	ext_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_qlen, d_tlen, g_scr.done, n, g_scr.keys, g_scr.vals, g_scr.counts, d_out, d_h0, pk_ok ? p->a : 0);
-	ext_offsets_kernel<<<1, 64, 0, st>>>(g_scr.counts);
-	{
-		size_t tb = g_scr.tmp_bytes;
-		HIPCK(rocprim::radix_sort_pairs(g_scr.tmp, tb, g_scr.keys, g_scr.keys2, g_scr.vals, g_scr.vals2, (size_t)n, 0, 26, st));
-	}
+	if (want_phases) HIPCK(hipEventRecord(ph[1], st));
+	ext_bin_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_qlen, d_tlen, g_scr.done, n, g_scr.keys, g_scr.bins, d_out, d_h0, pk_ok ? p->a : 0);
+	if (want_phases) HIPCK(hipEventRecord(ph[2], st));
+	ext_offsets_kernel<<<1, 64, 0, st>>>(g_scr.counts, g_scr.bins, g_scr.bins + EXT_N_BINS);
+	ext_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(g_scr.keys, n, g_scr.bins + EXT_N_BINS, g_scr.bins + 2 * EXT_N_BINS, g_scr.vals2);
 	// class sizes stay on the device (no host sync): every class kernel is launched with a grid
 	// that covers the whole batch and its waves stride over the class's slice of the sorted list
 	unsigned g16 = (unsigned)((n + 15) / 16), gw = (unsigned)((n + 3) / 4);
@@ -1118,6 +1143,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	if (gw > max_grid) gw = max_grid;
 	// the class kernels are independent: fork them over four side streams so that the tail of one
 	// class overlaps the body of the next, then join back into the caller's stream
+	if (want_phases) HIPCK(hipEventRecord(ph[3], st));
 	HIPCK(hipEventRecord(g_scr.fork, st));
 	for (int i = 0; i < 4; ++i) HIPCK(hipStreamWaitEvent(g_scr.side[i], g_scr.fork, 0));
 	hipStream_t *S = g_scr.side;
@@ -1144,6 +1170,12 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	for (int i = 0; i < 4; ++i) { HIPCK(hipEventRecord(g_scr.join[i], g_scr.side[i])); HIPCK(hipStreamWaitEvent(st, g_scr.join[i], 0)); }
 	HIPCK(hipEventRecord(g_scr.ev1, st));
 	HIPCK(hipGetLastError());
+	if (want_phases) {
+		float a = 0, b = 0, c = 0, d = 0;
+		HIPCK(hipEventSynchronize(g_scr.ev1));
+		(void)hipEventElapsedTime(&a, ph[0], ph[1]); (void)hipEventElapsedTime(&b, ph[1], ph[2]); (void)hipEventElapsedTime(&c, ph[2], ph[3]); (void)hipEventElapsedTime(&d, ph[3], g_scr.ev1);
+		fprintf(stderr, "[ext] %u jobs: prefilter %.3f ms, keys %.3f, offsets + sort %.3f, class kernels %.3f\n", n, a, b, c, d);
+	}
 	if (want_stats) {
 		unsigned long long h[4];
 		HIPCK(hipStreamSynchronize(st));

@@ -640,6 +640,56 @@ __global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t
 
 // ------------------------------------------------------------------ closed-form prefilter
 
+// classes: 0 = unsupported length (query longer than 768 bases: all three outputs INT32_MIN, counted, see
+// bmh_extend_last_unsupported); 1..18 = extend16_kernel<C>; 19..26 = extend_wide_kernel<5..12>
+#define EXT_WIDE_MAX_C 12
+#define EXT_N_CLS 42
+#define EXT_DONE_CLS 27     // decided by the closed-form prefilter: no DP
+#define EXT16_MAX_C 18
+// 28..34 = extpk_kernel<4, P>, P = 4, 6, .. 16 (queries up to 8 P columns); 35..39 = extpk_kernel<8, P>, P = 9, 10, 12, 14, 16
+// (up to 16 P); 40 = extpk_kernel<16, 9> (up to 288)
+#define EXT_PK_BASE 28
+#define EXT_PK_MAXQ 288
+
+// packed 16-bit class of a query length (0: none)
+__device__ __forceinline__ int ext_pk_class(uint32_t ql)
+{
+	if (ql > EXT_PK_MAXQ) return 0;
+	if (ql <= 128) { const int h = (int)((ql + 15) / 16); return EXT_PK_BASE + (h < 2 ? 2 : h) - 2; }       // P = 2 h
+	return EXT_PK_BASE + (ql <= 144 ? 7 : ql <= 160 ? 8 : ql <= 192 ? 9 : ql <= 224 ? 10 : ql <= 256 ? 11 : 12);
+}
+__device__ __forceinline__ int ext_class(uint32_t ql)
+{
+	if (ql <= 16 * EXT16_MAX_C) return ql <= 16 ? 1 : (int)((ql + 15) / 16);
+	const int wc = (int)((ql + 63) / 64);
+	return wc <= EXT_WIDE_MAX_C ? 19 + (wc - 5) : 0;
+}
+// (G = 4, P = 17: queries of 129..136 columns -- the flank of a 150 bp read whose seed sits at its very end -- on four lanes
+// instead of eight: 26 instead of 34 wave-instructions per alignment row, for 15 % of the extension's time on 150 bp reads)
+#define EXT_PK17_CLS (EXT_PK_BASE + 13)
+constexpr int ext_pk_cls_of(int G, int P) { return G == 4 && P == 17 ? EXT_PK17_CLS : EXT_PK_BASE + (G == 4 ? P / 2 - 2 : G == 16 ? 12 : P == 9 ? 7 : P == 10 ? 8 : P / 2 + 3); }
+
+// The jobs of a batch are grouped by class and, inside a class, by target length in steps of 32 rows (the class kernels draw from
+// the long end, so that their tails are short jobs): a counting sort over EXT_N_BINS = classes x 16 bins -- the bin of every job and
+// the histogram come out of the prefilter kernel below, then offsets and a scatter -- instead of a radix sort of (class << 20 | tlen)
+// keys behind a key kernel (seven launches, 0.95 ms of every extension pass for 2 M jobs).  The order inside a bin is whatever the
+// blocks' atomics make it; every job is independent.
+#define EXT_TL_BINS 16
+#define EXT_N_BINS (EXT_N_CLS * EXT_TL_BINS)
+// class of a job the prefilter has not decided (pk_a > 0: packed 16-bit kernels allowed, match score)
+__device__ __forceinline__ int ext_route(uint32_t ql, uint32_t tl, uint32_t h0, int pk_a)
+{
+	int cls = ext_class(ql);
+	if (cls >= 1 && cls <= EXT16_MAX_C && tl > EXT_T_CAP) cls = 19;     // very long target: wide kernel (streams it)
+	if (pk_a > 0 && h0 + ql * (uint32_t)pk_a < PK_HMAX) {
+		const int pc = ext_pk_class(ql);
+		if (pc && tl <= (uint32_t)(ql <= 128 ? PK_TCAP(4) : ql <= 256 ? PK_TCAP(8) : PK_TCAP(16))) cls = pc;
+		if (pc && ql > 128 && ql <= 136 && tl <= (uint32_t)PK_TCAP(4) && h0 + ql * (uint32_t)pk_a < PK_HMAX17) cls = EXT_PK17_CLS;
+	}
+	return cls;
+}
+
+
 __device__ __forceinline__ int row_allsum_f(int v)
 {
 	asm volatile("s_nop 1\n\t"
@@ -737,8 +787,11 @@ __device__ __forceinline__ void pk_q8(const ext_args_t &A, const job_src_t &s, c
 	}
 	lo = w[0]; hi = w[1];
 }
-__global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint32_t n, uint8_t *__restrict__ done)
+__global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint32_t n, uint32_t *__restrict__ bin_of, uint32_t *__restrict__ bin_cnt, int pk_a)
 {
+	__shared__ uint32_t hist[EXT_N_BINS];
+	for (int k = threadIdx.x; k < EXT_N_BINS; k += 256) hist[k] = 0;
+	__syncthreads();
 	const int lane = threadIdx.x & 63, l8 = lane & 7, grp = lane >> 3;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -820,7 +873,14 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 		ok = ok && (none || V1 - A.b > 0) && (!two || V2 - A.b > 0);
 		if (A.zdrop > 0 && two) ok = ok && (max(V1, V2) - V2 + A.b <= A.zdrop);
 		if (have && l8 == 0) {
-			done[id] = ok ? 1 : 0;
+			{   // the job's bin: decided here (no DP), or its DP class by query / target length and score range
+				const int cls = ok ? EXT_DONE_CLS : ext_route((uint32_t)qlen, (uint32_t)tlen, (uint32_t)h0, pk_a);
+				if (cls == 0) A.out[3 * (size_t)id] = A.out[3 * (size_t)id + 1] = A.out[3 * (size_t)id + 2] = INT32_MIN;
+				const uint32_t tb = (uint32_t)tlen >> 5;
+				const uint32_t bin = (uint32_t)cls * EXT_TL_BINS + (tb < EXT_TL_BINS - 1 ? tb : EXT_TL_BINS - 1);
+				bin_of[id] = bin;
+				atomicAdd(&hist[bin], 1u);
+			}
 			if (ok) {
 				// running maximum with strict updates: start (h0, -1); segment ends (V1, p1-1), (V2, p2-1) [two only], (V3, qlen-1)
 				int mx = h0, mi = -1;
@@ -839,71 +899,12 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 			}
 		}
 	}
+	__syncthreads();
+	for (int k = threadIdx.x; k < EXT_N_BINS; k += 256) if (hist[k]) atomicAdd(&bin_cnt[k], hist[k]);
 }
 
 // ------------------------------------------------------------------ host side
 
-// classes: 0 = unsupported length (query longer than 768 bases: all three outputs INT32_MIN, counted, see
-// bmh_extend_last_unsupported); 1..18 = extend16_kernel<C>; 19..26 = extend_wide_kernel<5..12>
-#define EXT_WIDE_MAX_C 12
-#define EXT_N_CLS 42
-#define EXT_DONE_CLS 27     // decided by the closed-form prefilter: no DP
-#define EXT16_MAX_C 18
-// 28..34 = extpk_kernel<4, P>, P = 4, 6, .. 16 (queries up to 8 P columns); 35..39 = extpk_kernel<8, P>, P = 9, 10, 12, 14, 16
-// (up to 16 P); 40 = extpk_kernel<16, 9> (up to 288)
-#define EXT_PK_BASE 28
-#define EXT_PK_MAXQ 288
-
-// packed 16-bit class of a query length (0: none)
-__device__ __forceinline__ int ext_pk_class(uint32_t ql)
-{
-	if (ql > EXT_PK_MAXQ) return 0;
-	if (ql <= 128) { const int h = (int)((ql + 15) / 16); return EXT_PK_BASE + (h < 2 ? 2 : h) - 2; }       // P = 2 h
-	return EXT_PK_BASE + (ql <= 144 ? 7 : ql <= 160 ? 8 : ql <= 192 ? 9 : ql <= 224 ? 10 : ql <= 256 ? 11 : 12);
-}
-__device__ __forceinline__ int ext_class(uint32_t ql)
-{
-	if (ql <= 16 * EXT16_MAX_C) return ql <= 16 ? 1 : (int)((ql + 15) / 16);
-	const int wc = (int)((ql + 63) / 64);
-	return wc <= EXT_WIDE_MAX_C ? 19 + (wc - 5) : 0;
-}
-// (G = 4, P = 17: queries of 129..136 columns -- the flank of a 150 bp read whose seed sits at its very end -- on four lanes
-// instead of eight: 26 instead of 34 wave-instructions per alignment row, for 15 % of the extension's time on 150 bp reads)
-#define EXT_PK17_CLS (EXT_PK_BASE + 13)
-constexpr int ext_pk_cls_of(int G, int P) { return G == 4 && P == 17 ? EXT_PK17_CLS : EXT_PK_BASE + (G == 4 ? P / 2 - 2 : G == 16 ? 12 : P == 9 ? 7 : P == 10 ? 8 : P / 2 + 3); }
-
-// The jobs of a batch are grouped by class and, inside a class, by target length in steps of 32 rows (the class kernels draw from
-// the long end, so that their tails are short jobs): a counting sort over EXT_N_BINS = classes x 16 bins in three small kernels --
-// bin of every job + histogram, offsets, scatter -- instead of a radix sort of (class << 20 | tlen) keys (six launches, 0.75 ms of
-// every extension pass for 2 M jobs).  The order inside a bin is whatever the blocks' atomics make it; every job is independent.
-#define EXT_TL_BINS 16
-#define EXT_N_BINS (EXT_N_CLS * EXT_TL_BINS)
-__global__ void __launch_bounds__(256) ext_bin_kernel(const uint32_t *__restrict__ qlen, const uint32_t *__restrict__ tlen, const uint8_t *__restrict__ done, uint32_t n,
-                                                      uint32_t *__restrict__ bin_of, uint32_t *__restrict__ bin_cnt, int32_t *__restrict__ out,
-                                                      const uint32_t *__restrict__ h0, int pk_a)      // pk_a > 0: packed 16-bit kernels allowed, match score
-{
-	__shared__ uint32_t hist[EXT_N_BINS];
-	for (int k = threadIdx.x; k < EXT_N_BINS; k += 256) hist[k] = 0;
-	__syncthreads();
-	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t < n) {
-		int cls = done[t] ? EXT_DONE_CLS : ext_class(qlen[t]);
-		if (cls >= 1 && cls <= EXT16_MAX_C && tlen[t] > EXT_T_CAP) cls = 19;     // very long target: wide kernel (streams it)
-		if (pk_a > 0 && cls != EXT_DONE_CLS && h0[t] + qlen[t] * (uint32_t)pk_a < PK_HMAX) {
-			const uint32_t ql = qlen[t];
-			const int pc = ext_pk_class(ql);
-			if (pc && tlen[t] <= (uint32_t)(ql <= 128 ? PK_TCAP(4) : ql <= 256 ? PK_TCAP(8) : PK_TCAP(16))) cls = pc;
-			if (pc && ql > 128 && ql <= 136 && tlen[t] <= (uint32_t)PK_TCAP(4) && h0[t] + ql * (uint32_t)pk_a < PK_HMAX17) cls = EXT_PK17_CLS;
-		}
-		if (cls == 0) out[3 * (size_t)t] = out[3 * (size_t)t + 1] = out[3 * (size_t)t + 2] = INT32_MIN;
-		const uint32_t tb = tlen[t] >> 5;
-		const uint32_t bin = (uint32_t)cls * EXT_TL_BINS + (tb < EXT_TL_BINS - 1 ? tb : EXT_TL_BINS - 1);
-		bin_of[t] = bin;
-		atomicAdd(&hist[bin], 1u);
-	}
-	__syncthreads();
-	for (int k = threadIdx.x; k < EXT_N_BINS; k += 256) if (hist[k]) atomicAdd(&bin_cnt[k], hist[k]);
-}
 
 // bin_cnt -> bin_base (start of every bin in the grouped list); counts[2c] = size of class c, counts[2c+1] = its offset
 __global__ void ext_offsets_kernel(uint32_t *counts, const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_base)
@@ -939,7 +940,7 @@ __global__ void __launch_bounds__(256) ext_scatter_kernel(const uint32_t *__rest
 // scratch for the sorted job list: one per (device, stream), grown on demand and reused across calls, so
 // that batches in flight on different streams never share it
 struct ext_scratch_t {
-	uint32_t *keys, *vals2, *counts, *bins; uint8_t *done; size_t cap; int dev;      // keys: bin of every job; vals2: job ids grouped by bin; bins: [3][EXT_N_BINS] count / base / cursor
+	uint32_t *keys, *vals2, *counts, *bins; size_t cap; int dev;      // keys: bin of every job; vals2: job ids grouped by bin; bins: [3][EXT_N_BINS] count / base / cursor
 	hipEvent_t ev0, ev1; bool have_ev;
 	hipStream_t side[4]; hipEvent_t fork, join[4];     // class kernels run concurrently on side streams
 };
@@ -975,7 +976,7 @@ extern "C" void bmh_extend_release(void *stream_)
 		g_scr_map.erase(it);
 	}
 	if (g_last == s) g_last = nullptr;
-	void *ps[] = {s->keys, s->vals2, s->counts, s->bins, s->done};
+	void *ps[] = {s->keys, s->vals2, s->counts, s->bins};
 	for (void *q : ps) if (q) (void)hipFree(q);
 	if (s->have_ev) {
 		(void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1); (void)hipEventDestroy(s->fork);
@@ -1082,13 +1083,12 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	ext_scratch_t &g_scr = *scratch_for(dev, stream_);
 	g_last = &g_scr;
 	if (g_scr.cap < n) {
-		void *ps[] = {g_scr.keys, g_scr.vals2, g_scr.counts, g_scr.bins, g_scr.done};
+		void *ps[] = {g_scr.keys, g_scr.vals2, g_scr.counts, g_scr.bins};
 		for (void *q : ps) if (q) (void)hipFree(q);
-		g_scr.keys = g_scr.vals2 = g_scr.counts = g_scr.bins = nullptr; g_scr.done = nullptr; g_scr.cap = 0;
+		g_scr.keys = g_scr.vals2 = g_scr.counts = g_scr.bins = nullptr; g_scr.cap = 0;
 		HIPCK(hipMalloc((void **)&g_scr.keys, 4 * (size_t)n)); HIPCK(hipMalloc((void **)&g_scr.vals2, 4 * (size_t)n));
 		HIPCK(hipMalloc((void **)&g_scr.counts, 4 * 3 * EXT_N_CLS));
 		HIPCK(hipMalloc((void **)&g_scr.bins, 4 * 3 * EXT_N_BINS));
-		HIPCK(hipMalloc((void **)&g_scr.done, (size_t)n));
 		g_scr.cap = n; g_scr.dev = dev;
 	}
 	if (!g_scr.have_ev) {
@@ -1123,16 +1123,14 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	if (want_phases) HIPCK(hipEventRecord(ph[0], st));
 	HIPCK(hipMemsetAsync(g_scr.counts, 0, 4 * 3 * EXT_N_CLS, st));
 	HIPCK(hipMemsetAsync(g_scr.bins, 0, 4 * 3 * EXT_N_BINS, st));
+	// packed 16-bit rows need 1 <= b, a + b <= 255 (byte score table), a >= 0 and gap penalties that fit the 16-bit lanes
+	const bool pk_ok = g_ext_packed && p->a > 0 && p->b >= 1 && p->a + p->b <= 255 && p->o_del + p->e_del < 4096 && p->o_ins + p->e_ins < 4096 && p->e_ins * 32 < 4096;
 	{
 		unsigned gp = (unsigned)((n + 31) / 32);
 		if (gp > 4096) gp = 4096;
-		ext_closed_form_kernel<<<gp, 256, 0, st>>>(a, n, g_scr.done);
+		ext_closed_form_kernel<<<gp, 256, 0, st>>>(a, n, g_scr.keys, g_scr.bins, pk_ok ? p->a : 0);
 	}
-	// packed 16-bit rows need 1 <= b, a + b <= 255 (byte score table), a >= 0 and gap penalties that fit the 16-bit lanes
-	const bool pk_ok = g_ext_packed && p->a > 0 && p->b >= 1 && p->a + p->b <= 255 && p->o_del + p->e_del < 4096 && p->o_ins + p->e_ins < 4096 && p->e_ins * 32 < 4096;
-	if (want_phases) HIPCK(hipEventRecord(ph[1], st));
-	ext_bin_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_qlen, d_tlen, g_scr.done, n, g_scr.keys, g_scr.bins, d_out, d_h0, pk_ok ? p->a : 0);
-	if (want_phases) HIPCK(hipEventRecord(ph[2], st));
+	if (want_phases) { HIPCK(hipEventRecord(ph[1], st)); HIPCK(hipEventRecord(ph[2], st)); }
 	ext_offsets_kernel<<<1, 64, 0, st>>>(g_scr.counts, g_scr.bins, g_scr.bins + EXT_N_BINS);
 	ext_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(g_scr.keys, n, g_scr.bins + EXT_N_BINS, g_scr.bins + 2 * EXT_N_BINS, g_scr.vals2);
 	// class sizes stay on the device (no host sync): every class kernel is launched with a grid

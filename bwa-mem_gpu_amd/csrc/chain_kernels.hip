@@ -28,6 +28,7 @@ struct chain_args_t {
 	uint32_t *heavy_list; uint32_t *heavy_n;
 	uint32_t *need;               // [n_reads] seed occurrences the chaining core will sample
 	uint32_t *light_list, *light_n;   // the reads of the lane kernel by need bin: [CH_N_BINS][n_reads], [CH_N_BINS]
+	unsigned long long *need_sum;     // sum of need over the reads beyond heavy_thresh
 };
 
 // What a read costs the chaining core is the number of seed occurrences mem_chain SAMPLES (at most max_occ per SMEM,
@@ -58,7 +59,9 @@ __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 	// (bins CH_N_BINS.. of the block counters: the wave / lane-list classes -- 50 000 appends to two counters, one atomic each, were
 	// 0.4 ms of same-address atomics)
 	__shared__ uint32_t l_cnt[CH_N_BINS + CH_N_CLASSES], l_base[CH_N_BINS + CH_N_CLASSES];
+	__shared__ uint32_t l_need;          // sampled occurrences of the block's wave / lane-list reads (the bound of their regions: need_sum)
 	if (threadIdx.x < CH_N_BINS + CH_N_CLASSES) l_cnt[threadIdx.x] = 0;
+	if (threadIdx.x == 0) l_need = 0;
 	__syncthreads();
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
 	int bin = -1; uint32_t my = 0;
@@ -78,8 +81,10 @@ __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 		A.need[r] = need;
 		bin = need > A.heavy_thresh ? CH_N_BINS + ch_class_of(need, A.lane_max) : ch_bin_of(need);
 		my = atomicAdd(&l_cnt[bin], 1u);
+		if (need > A.heavy_thresh) atomicAdd(&l_need, need);
 	}
 	__syncthreads();
+	if (threadIdx.x == 0 && l_need) atomicAdd(A.need_sum, (unsigned long long)l_need);
 	if (threadIdx.x < CH_N_BINS + CH_N_CLASSES && l_cnt[threadIdx.x])
 		l_base[threadIdx.x] = atomicAdd(threadIdx.x < CH_N_BINS ? A.light_n + threadIdx.x : A.heavy_n + (threadIdx.x - CH_N_BINS), l_cnt[threadIdx.x]);
 	__syncthreads();
@@ -165,6 +170,7 @@ struct emit_args_t {
 	const ch_reg_t *regs; const uint32_t *prefix, *regs_per_read, *reg_off, *job_off, *read_offs, *read_lens;
 	uint32_t n_reads;
 	uint32_t reg_base, job_base;      // added to reg_off / job_off (second pass of bmh_chain_extend_merge)
+	const uint32_t *need; uint32_t thresh; int pass;      // need != nullptr: only the reads of one pass count (pass 1: need > thresh, pass 0: the others)
 	ch_outreg_t *outregs;
 	uint32_t *qlen, *tlen, *h0, *job_read, *job_reg, *job_side, *jq_src; int64_t *jt0;
 };
@@ -176,7 +182,7 @@ __global__ void __launch_bounds__(256) emit_kernel(emit_args_t A)
 {
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
 	if (r >= A.n_reads) return;
-	const uint32_t nr = A.regs_per_read[r];
+	const uint32_t nr = (A.need && (A.need[r] > A.thresh) != (A.pass == 1)) ? 0u : A.regs_per_read[r];
 	if (nr == 0 || nr > CH_EMIT_LANE_MAX) return;
 	const ch_reg_t *R = A.regs + A.prefix[r];
 	uint32_t g = A.reg_base + A.reg_off[r], j = A.job_base + A.job_off[r];
@@ -211,7 +217,7 @@ __global__ void __launch_bounds__(256) emit_wave_kernel(emit_args_t A, const uin
 		const uint32_t *list = lists + (size_t)cls * A.n_reads;
 		for (uint32_t k = gw; k < nh; k += n_waves) {
 			const uint32_t r = list[k];
-			const uint32_t nr = A.regs_per_read[r];
+			const uint32_t nr = (A.need && (A.need[r] > A.thresh) != (A.pass == 1)) ? 0u : A.regs_per_read[r];
 			if (nr <= CH_EMIT_LANE_MAX) continue;
 			const ch_reg_t *R = A.regs + A.prefix[r];
 			const uint32_t g0 = A.reg_base + A.reg_off[r];
@@ -326,7 +332,7 @@ struct bmh_chain_ws {
 	hipStream_t cls_stream[CH_N_CLASSES]; hipEvent_t cls_done[CH_N_CLASSES]; // ... and beside each other, one stream per size class
 	hipEvent_t ev_t[8]; float ms[8]; uint32_t heavy_per_class[CH_N_CLASSES];
 	// bmh_chain_extend_merge: the batch in two passes (reads of the lane kernel, reads of the wave kernels)
-	uint32_t *cnt2[4], *off2[4];     // [0] regions A [1] jobs A [2] regions B [3] jobs B: per-read counts and their exclusive scans
+	uint32_t *off2[4];               // [0] regions A [1] jobs A [2] regions B [3] jobs B: exclusive scans of the per-read counts of a pass
 	uint64_t *need_sum;              // [0] sampled occurrences of the wave-kernel reads (bound of their regions)
 	int32_t *out3; uint64_t cap_out3;
 	hipStream_t side2; hipEvent_t ev_x[6];
@@ -348,7 +354,7 @@ extern "C" void bmh_chain_ws_free(bmh_chain_ws_t *w)
 	if (w->ev_join) (void)hipEventDestroy(w->ev_join);
 	for (hipEvent_t e : w->ev_t) if (e) (void)hipEventDestroy(e);
 	for (hipStream_t q : w->cls_stream) if (q) (void)hipStreamDestroy(q);
-	for (int i = 0; i < 4; ++i) { if (w->cnt2[i]) (void)hipFree(w->cnt2[i]); if (w->off2[i]) (void)hipFree(w->off2[i]); }
+	for (int i = 0; i < 4; ++i) if (w->off2[i]) (void)hipFree(w->off2[i]);
 	if (w->need_sum) (void)hipFree(w->need_sum);
 	if (w->out3) (void)hipFree(w->out3);
 	if (w->side2) (void)hipStreamDestroy(w->side2);
@@ -372,7 +378,7 @@ extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_
 	const size_t Rn = (size_t)max_reads + 1;
 	A(w->regs_per_read, 4 * Rn); A(w->jobs_per_read, 4 * Rn); A(w->reg_off, 4 * Rn); A(w->job_off, 4 * Rn); A(w->heavy_list, (CH_N_CLASSES + CH_N_BINS) * 4 * Rn); A(w->need, 4 * Rn); A(w->frac_rep, 4 * Rn);
 	A(w->counters, 256);
-	for (int i = 0; i < 4; ++i) { A(w->cnt2[i], 4 * Rn); A(w->off2[i], 4 * Rn); }
+	for (int i = 0; i < 4; ++i) A(w->off2[i], 4 * Rn);
 	A(w->need_sum, 16);
 	size_t t1 = 0, t2 = 0;
 	rocprim::exclusive_scan(nullptr, t1, w->regs_per_read, w->reg_off, 0u, Rn, rocprim::plus<uint32_t>(), 0);
@@ -457,6 +463,7 @@ static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_op
 	}
 	A.heavy_list = w->heavy_list; A.heavy_n = w->counters; A.need = w->need;
 	A.light_list = w->heavy_list + (size_t)CH_N_CLASSES * w->max_reads; A.light_n = w->counters + 32;
+	A.need_sum = (unsigned long long *)w->need_sum;
 #ifdef CH_PROFILE
 	{
 		const char *pr = getenv("BMH_CHAIN_PROF_READ");
@@ -472,6 +479,7 @@ static int chain_launch(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st, 
 {
 	const uint32_t n_reads = A.n_reads;
 	HIPCK(hipMemsetAsync(w->counters, 0, 256, st));
+	HIPCK(hipMemsetAsync(w->need_sum, 0, 16, st));
 	HIPCK(hipMemsetAsync(w->regs_per_read + n_reads, 0, 4, st));
 	HIPCK(hipMemsetAsync(w->jobs_per_read + n_reads, 0, 4, st));
 	HIPCK(hipEventRecord(w->ev_t[0], st));
@@ -580,7 +588,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	}
 	if (n_regs == 0) return BMH_OK;
 	emit_args_t E;
-	E.regs = w->regs; E.prefix = seeds->d_prefix; E.regs_per_read = w->regs_per_read; E.reg_off = w->reg_off; E.job_off = w->job_off;
+	E.regs = w->regs; E.prefix = seeds->d_prefix; E.regs_per_read = w->regs_per_read; E.reg_off = w->reg_off; E.job_off = w->job_off; E.need = nullptr; E.thresh = 0; E.pass = 0;
 	E.read_offs = d_offs; E.read_lens = d_lens; E.n_reads = n_reads; E.outregs = w->outregs; E.reg_base = E.job_base = 0;
 	E.qlen = w->qlen; E.tlen = w->tlen; E.h0 = w->h0; E.job_read = w->job_read; E.job_reg = w->job_reg; E.job_side = w->job_side; E.jq_src = w->jq_src; E.jt0 = w->jt0;
 	emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
@@ -634,23 +642,16 @@ extern "C" int bmh_chain_merge(bmh_chain_ws_t *w, const int32_t *d_out3, int32_t
 
 // ------------------------------------------------------------------------------------------------ the stage in one call
 
-// per-read counts of one pass: pass 0 = reads of the lane kernel, pass 1 = reads of the wave kernels
-__global__ void __launch_bounds__(256) split_counts_kernel(const uint32_t *__restrict__ need, uint32_t thresh, int pass, uint32_t n_reads,
-                                                           const uint32_t *__restrict__ regs_per_read, const uint32_t *__restrict__ jobs_per_read,
-                                                           uint32_t *__restrict__ cr, uint32_t *__restrict__ cj, unsigned long long *__restrict__ need_sum)
+// per-read counts of one pass as a scan input: the count where the read belongs to the pass (pass 1: need > thresh), else 0; one
+// element behind the last read (0) so that the scan also yields the total
+struct ch_pass_count {
+	const uint32_t *need, *cnt; uint32_t thresh, n_reads; int pass;
+	__device__ uint32_t operator()(uint32_t r) const { return (r < n_reads && (need[r] > thresh) == (pass == 1)) ? cnt[r] : 0u; }
+};
+static inline auto ch_pass_iter(const uint32_t *need, const uint32_t *cnt, uint32_t thresh, uint32_t n_reads, int pass)
 {
-	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-	unsigned long long nd = 0;
-	if (r <= n_reads) {
-		const bool mine = r < n_reads && (need[r] > thresh) == (pass == 1);
-		cr[r] = mine ? regs_per_read[r] : 0u;
-		cj[r] = mine ? jobs_per_read[r] : 0u;
-		if (need_sum && r < n_reads && need[r] > thresh) nd = need[r];
-	}
-	if (need_sum) {
-		for (int o = 32; o; o >>= 1) nd += __shfl_down(nd, o);
-		if ((threadIdx.x & 63) == 0 && nd) atomicAdd(need_sum, nd);
-	}
+	ch_pass_count f; f.need = need; f.cnt = cnt; f.thresh = thresh; f.n_reads = n_reads; f.pass = pass;
+	return rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), f);
 }
 
 // extension results -> regions in READ order: the regions of pass A sit at [0, n_a) of the pass-ordered list, those of pass B
@@ -723,12 +724,11 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	chain_fill_args(w, A, opt, idx, d_lens, n_reads, seeds);
 	{ const int rc = chain_launch(w, A, st, false); if (rc != BMH_OK) return rc; }
 	// ---- pass A: the reads of the lane kernel
-	HIPCK(hipMemsetAsync(w->need_sum, 0, 16, st));
-	split_counts_kernel<<<nblk((uint64_t)n_reads + 1, 256), 256, 0, st>>>(w->need, A.heavy_thresh, 0, n_reads, w->regs_per_read, w->jobs_per_read, w->cnt2[0], w->cnt2[1], (unsigned long long *)w->need_sum);
+	// (the counts of a pass are read through a transform iterator: no pass over the reads to mask them first)
 	size_t tb = w->scan_tmp_bytes;
-	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->cnt2[0], w->off2[0], 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
+	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, ch_pass_iter(w->need, w->regs_per_read, A.heavy_thresh, n_reads, 0), w->off2[0], 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
 	tb = w->scan_tmp_bytes;
-	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->cnt2[1], w->off2[1], 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
+	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, ch_pass_iter(w->need, w->jobs_per_read, A.heavy_thresh, n_reads, 0), w->off2[1], 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
 	uint64_t *h64 = (uint64_t *)(w->h_pin + 16);
 	HIPCK(hipMemcpyAsync(w->h_pin + 0, w->off2[0] + n_reads, 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipMemcpyAsync(w->h_pin + 1, w->off2[1] + n_reads, 4, hipMemcpyDeviceToHost, st));
@@ -746,7 +746,7 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	d.reads = d_reads; d.pac = idx->dev.pac; d.l_pac = (long long)idx->dev.l_pac;
 	HIPCK(hipEventRecord(w->ev_x[0], st));
 	if (n_regs_a) {
-		E.regs_per_read = w->cnt2[0]; E.reg_off = w->off2[0]; E.job_off = w->off2[1]; E.reg_base = E.job_base = 0;
+		E.regs_per_read = w->regs_per_read; E.need = w->need; E.thresh = A.heavy_thresh; E.pass = 0; E.reg_off = w->off2[0]; E.job_off = w->off2[1]; E.reg_base = E.job_base = 0;
 		emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
 		if (n_jobs_a) {
 			d.jq_src = w->jq_src; d.job_side = w->job_side; d.jt0 = w->jt0;
@@ -757,12 +757,11 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	HIPCK(hipEventRecord(w->ev_x[1], st));
 	// ---- pass B: the reads of the wave kernels, counted on a second stream so that the host does not wait for pass A's extension
 	HIPCK(hipStreamWaitEvent(w->side2, w->ev_join, 0));
-	split_counts_kernel<<<nblk((uint64_t)n_reads + 1, 256), 256, 0, w->side2>>>(w->need, A.heavy_thresh, 1, n_reads, w->regs_per_read, w->jobs_per_read, w->cnt2[2], w->cnt2[3], nullptr);
 	// (its own scan scratch: pass A's extension may still be using nothing of ours, but the scans above share scan_tmp with nothing in flight on st)
 	tb = w->scan_tmp_bytes;
-	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->cnt2[2], w->off2[2], 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), w->side2));
+	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, ch_pass_iter(w->need, w->regs_per_read, A.heavy_thresh, n_reads, 1), w->off2[2], 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), w->side2));
 	tb = w->scan_tmp_bytes;
-	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->cnt2[3], w->off2[3], 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), w->side2));
+	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, ch_pass_iter(w->need, w->jobs_per_read, A.heavy_thresh, n_reads, 1), w->off2[3], 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), w->side2));
 	HIPCK(hipMemcpyAsync(w->h_pin + 32, w->off2[2] + n_reads, 4, hipMemcpyDeviceToHost, w->side2));
 	HIPCK(hipMemcpyAsync(w->h_pin + 33, w->off2[3] + n_reads, 4, hipMemcpyDeviceToHost, w->side2));
 	HIPCK(hipMemcpyAsync(w->h_pin + 2, w->counters, 4 * (CH_N_CLASSES + 1), hipMemcpyDeviceToHost, w->side2));
@@ -781,7 +780,7 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	HIPCK(hipStreamWaitEvent(st, w->ev_x[2], 0));
 	HIPCK(hipEventRecord(w->ev_x[3], st));
 	if (n_regs_b) {
-		E.regs_per_read = w->cnt2[2]; E.reg_off = w->off2[2]; E.job_off = w->off2[3]; E.reg_base = (uint32_t)n_regs_a; E.job_base = (uint32_t)n_jobs_a;
+		E.regs_per_read = w->regs_per_read; E.need = w->need; E.thresh = A.heavy_thresh; E.pass = 1; E.reg_off = w->off2[2]; E.job_off = w->off2[3]; E.reg_base = (uint32_t)n_regs_a; E.job_base = (uint32_t)n_jobs_a;
 		emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
 		emit_wave_kernel<<<1024, 256, 0, st>>>(E, w->heavy_list, w->counters, 0, CH_N_CLASSES - 1);
 		if (n_jobs_b) {

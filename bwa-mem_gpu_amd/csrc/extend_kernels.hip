@@ -39,7 +39,9 @@
 
 #define NEG_INF (-(1 << 29))
 #define EXT_T_CAP 1024        // target bases of an alignment staged in LDS by extend16_kernel
-#define EXT_DRAW_CHUNK 32      // jobs a wave takes from its class counter per atomic
+#ifndef EXT_DRAW_CHUNK
+#define EXT_DRAW_CHUNK 32
+#endif      // jobs a wave takes from its class counter per atomic
 
 // inclusive max-scan over the 64 lanes (Kogge-Stone inside 16-lane rows on DPP
 // row_shr, then row_bcast:15 / row_bcast:31 across rows); lane 63 ends with the total

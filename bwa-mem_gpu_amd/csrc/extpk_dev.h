@@ -21,6 +21,9 @@
 
 // target bases of an alignment staged in LDS, by group width (the 4-lane groups are the many small queries: 64 of them per block)
 #define PK_TCAP(G) ((G) == 4 ? 384 : (G) == 8 ? 512 : 640)
+#ifndef PK_BOUND_MASK
+#define PK_BOUND_MASK 15      // the exact early-stop bound is evaluated every (mask + 1)-th row of a wave (every 2nd / 4th / 8th / 16th / 32nd: 17.6 / 17.3 / 17.2 / 17.1 / 17.4 ms)
+#endif
 #define PK_HMAX 4096          // scores stay below this (keys are h << 4 | pair in 16 bits)
 #define PK_HMAX17 2048        // ... in the 17-pair class (keys h << 5 | pair)
 #define PK_NEG (-(1 << 28))
@@ -516,7 +519,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P >= 9
 		const bool run = alive;
 		rows_done += run ? 1 : 0;
 		const int hnx = max(0, h0 - dn);
-		alive = pk_row<G, P, SAME_OE>(K, A.zdrop, H, E, NZ, sel, ti, run, hfc, hnx, i, qlen, j0, eCl, g0, phi0, em_tab, hrow, owner, (const uint16_t *)h_lds, goff, S, alive, (wave_rows & 3) == 0);
+		alive = pk_row<G, P, SAME_OE>(K, A.zdrop, H, E, NZ, sel, ti, run, hfc, hnx, i, qlen, j0, eCl, g0, phi0, em_tab, hrow, owner, (const uint16_t *)h_lds, goff, S, alive, (wave_rows & PK_BOUND_MASK) == 0);
 		if (run) { ++i; ++tp; hfc = hnx; dn += A.e_del; }
 		alive = alive && i < tlen;
 	}

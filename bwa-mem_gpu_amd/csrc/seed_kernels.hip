@@ -336,8 +336,7 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 // keep result t unless the next VALID result of the same read has the same begin (results dropped by
 // the backward kernel's early exit, or too short, are skipped: an early-dropped candidate ends where
 // the next longer one does, so the comparison partner is the first survivor after it)
-__global__ void __launch_bounds__(256) smem_filter_kernel(const res_t *__restrict__ res_a, uint64_t n, uint32_t *__restrict__ occ,
-                                                          uint32_t *__restrict__ keep)
+__global__ void __launch_bounds__(256) smem_filter_kernel(const res_t *__restrict__ res_a, uint64_t n, uint32_t *__restrict__ occ)
 {
 	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	res_t e = {0xFFFFFFFEu, 0, 0, 0};
@@ -372,15 +371,23 @@ __global__ void __launch_bounds__(256) smem_filter_kernel(const res_t *__restric
 			}
 		}
 	}
-	if (t <= n) { occ[t] = k ? e.s : 0u; keep[t] = k ? 1u : 0u; }
+	if (t <= n) occ[t] = k ? e.s : 0u;                  // (a kept result has at least one occurrence: occ != 0 is the keep flag)
 }
 
+// The scan over the occurrence counts carries the number of kept results in its high bits (one pass instead of a second array and
+// a reduction): element t contributes occ[t] | (occ[t] != 0) << 36; totals stay below 2^32 occurrences (checked) / 2^28 results.
+#define OCC_OFF_SHIFT 36
+#define OCC_OFF_MASK ((1ull << OCC_OFF_SHIFT) - 1ull)
+struct occ_keep_in {
+	const uint32_t *occ;
+	__device__ uint64_t operator()(uint64_t t) const { const uint32_t v = occ[t]; return (uint64_t)v | ((uint64_t)(v != 0u) << OCC_OFF_SHIFT); }
+};
 __global__ void __launch_bounds__(256) per_read_counts_kernel(const uint32_t *__restrict__ cand_base, const uint64_t *__restrict__ occ_off,
                                                               uint32_t n_reads, uint32_t *__restrict__ n_ref_pos, uint32_t *__restrict__ prefix)
 {
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n_reads) return;
-	uint64_t a = occ_off[cand_base[r]], b = occ_off[cand_base[r + 1]];
+	uint64_t a = occ_off[cand_base[r]] & OCC_OFF_MASK, b = occ_off[cand_base[r + 1]] & OCC_OFF_MASK;
 	prefix[r] = (uint32_t)a;
 	n_ref_pos[r] = (uint32_t)(b - a);
 }
@@ -399,7 +406,7 @@ __global__ void __launch_bounds__(256) expand_kernel(const res_t *__restrict__ r
 	int2 qb = make_int2(0, 0);
 	if (t < n) {
 		s = occ[t];
-		if (s) { res_t e = res_a[t]; k = res_k[t]; off = occ_off[t]; qb = make_int2((int)(e.be >> 16), (int)(e.be & 0xFFFF)); }
+		if (s) { res_t e = res_a[t]; k = res_k[t]; off = occ_off[t] & OCC_OFF_MASK; qb = make_int2((int)(e.be >> 16), (int)(e.be & 0xFFFF)); }
 	}
 	const uint32_t SMALL = 4;
 	if (s && s <= SMALL) {
@@ -681,8 +688,8 @@ struct bmh_seed_ws {
 	cand_t *cand_a; uint64_t *cand_k;
 	res_t *res_a; uint64_t *res_k;
 	uint32_t *n_cand, *cand_base;       // [max_reads+1]
-	uint32_t *occ, *keep;               // [max_cands+1]
-	uint64_t *occ_off, *keep_off;       // [max_cands+1]
+	uint32_t *occ;                      // [max_cands+1]
+	uint64_t *occ_off;                  // [max_cands+1]
 	uint64_t *rows; int2 *qbeg; uint32_t *score;   // [max_occ]
 	uint32_t *n_ref_pos, *prefix;       // [max_reads]
 	unsigned long long *counter;
@@ -708,8 +715,8 @@ extern "C" bmh_seed_ws_t *bmh_seed_ws_create(uint32_t max_reads, uint64_t max_ba
 	A(w->cand_a, sizeof(cand_t) * w->max_cands); A(w->cand_k, 8 * w->max_cands);
 	A(w->res_a, sizeof(res_t) * (w->max_cands + 1)); A(w->res_k, 8 * (w->max_cands + 1));
 	A(w->n_cand, 4 * ((size_t)max_reads + 1)); A(w->cand_base, 4 * ((size_t)max_reads + 1));
-	A(w->occ, 4 * (w->max_cands + 1)); A(w->keep, 4 * (w->max_cands + 1));
-	A(w->occ_off, 8 * (w->max_cands + 1)); A(w->keep_off, 8 * (w->max_cands + 1));
+	A(w->occ, 4 * (w->max_cands + 1));
+	A(w->occ_off, 8 * (w->max_cands + 1));
 	A(w->rows, 8 * w->max_occ); A(w->qbeg, 8 * w->max_occ); A(w->score, 4 * w->max_occ);
 	A(w->n_ref_pos, 4 * (size_t)max_reads); A(w->prefix, 4 * (size_t)max_reads);
 	A(w->counter, 128);
@@ -730,8 +737,8 @@ extern "C" bmh_seed_ws_t *bmh_seed_ws_create(uint32_t max_reads, uint64_t max_ba
 extern "C" void bmh_seed_ws_free(bmh_seed_ws_t *w)
 {
 	if (!w) return;
-	void *ps[] = {w->pk, w->nm, w->cand_a, w->cand_k, w->res_a, w->res_k, w->n_cand, w->cand_base, w->occ, w->keep,
-	              w->occ_off, w->keep_off, w->rows, w->qbeg, w->score, w->n_ref_pos, w->prefix, w->counter, w->scan_tmp,
+	void *ps[] = {w->pk, w->nm, w->cand_a, w->cand_k, w->res_a, w->res_k, w->n_cand, w->cand_base, w->occ,
+	              w->occ_off, w->rows, w->qbeg, w->score, w->n_ref_pos, w->prefix, w->counter, w->scan_tmp,
 	              w->scratch, w->skeys, w->skeys2, w->svals, w->svals2};
 	for (void *p : ps) if (p) (void)hipFree(p);
 	for (int i = 0; i < 8; ++i) if (w->ev[i]) (void)hipEventDestroy(w->ev[i]);
@@ -906,17 +913,18 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 		}
 	}
 	HIPCK(hipEventRecord(w->ev[3], st));
-	smem_filter_kernel<<<nblk(n_cands + 1, 256), 256, 0, st>>>(w->res_a, n_cands, w->occ, w->keep);
+	smem_filter_kernel<<<nblk(n_cands + 1, 256), 256, 0, st>>>(w->res_a, n_cands, w->occ);
 	{
 		size_t tb = w->scan_tmp_bytes;
-		HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->occ, w->occ_off, (uint64_t)0, (size_t)n_cands + 1, rocprim::plus<uint64_t>(), st));
-		tb = w->scan_tmp_bytes;
-		HIPCK(rocprim::reduce(w->scan_tmp, tb, w->keep, w->keep_off, (uint64_t)0, (size_t)n_cands + 1, rocprim::plus<uint64_t>(), st));
+		occ_keep_in fin; fin.occ = w->occ;
+		HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, rocprim::make_transform_iterator(rocprim::counting_iterator<uint64_t>(0), fin), w->occ_off, (uint64_t)0,
+		                              (size_t)n_cands + 1, rocprim::plus<uint64_t>(), st));
 	}
 	uint64_t tot[2] = {0, 0};
 	HIPCK(hipMemcpyAsync(&tot[0], w->occ_off + n_cands, 8, hipMemcpyDeviceToHost, st));
-	HIPCK(hipMemcpyAsync(&tot[1], w->keep_off, 8, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));
+	tot[1] = tot[0] >> OCC_OFF_SHIFT; tot[0] &= OCC_OFF_MASK;
+	if (n_cands >> 28) { bmh_set_error("bmh_seed_batch: more than 2^28 candidates in one batch"); return BMH_ECAPACITY; }
 	out->n_seeds = tot[0]; out->n_smems = tot[1];
 	if (grow_occ(w, tot[0], out) != BMH_OK) return BMH_ECAPACITY;
 	if (tot[0] >> 32) { bmh_set_error("bmh_seed_batch: more than 2^32 occurrences in one batch"); return BMH_ECAPACITY; }

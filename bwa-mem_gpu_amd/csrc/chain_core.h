@@ -779,7 +779,12 @@ template <bool COOP, bool LDSX = false> CH_HD void chain_read(const ch_ctx_t &x,
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (COOP) {
 		if (!w_introsort_coop<LDSX>(srt, order, na)) { *x.err = 2; return; }
-		w_place_coop<LDSX>(srt, order, na);
+		if (na < 65536) w_place_coop<LDSX>(srt, order, na);
+		else {                                                        // (more chains than the 16-bit index of the rank keys holds: a huge -c)
+			w_insertion(srt, 0, na);
+			for (int i = 0; i < na; ++i) order[i] = (uint32_t)srt[i];
+			ch_wave_fence<LDSX>();
+		}
 	} else
 #endif
 	{

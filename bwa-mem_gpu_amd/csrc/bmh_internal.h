@@ -16,6 +16,7 @@ struct bmh_ext_desc_t {
 	const uint8_t *pac; long long l_pac;     // 2-bit forward strand
 	const uint32_t *jq_src;      // [n] offset of the query segment in reads
 	const uint32_t *job_side;    // [n] 0 = LEFT (both sequences run backwards), 1 = RIGHT
+	uint32_t max_qlen;           // 0, or an upper bound of every query length of the batch (the longest read): classes no job can reach are not launched
 	const int64_t *jt0;          // [n] first text position of the target window; a window lies on ONE strand of fwd . revcomp(fwd)
 	                             // (mem_chain2aln clips it at l_pac, src/bwamem.c:1261-1264): the kernels decode eight rows at a time on that premise
 };

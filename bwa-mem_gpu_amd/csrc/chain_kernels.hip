@@ -59,9 +59,10 @@ __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 	// (bins CH_N_BINS.. of the block counters: the wave / lane-list classes -- 50 000 appends to two counters, one atomic each, were
 	// 0.4 ms of same-address atomics)
 	__shared__ uint32_t l_cnt[CH_N_BINS + CH_N_CLASSES], l_base[CH_N_BINS + CH_N_CLASSES];
+	__shared__ uint32_t l_maxlen;
 	__shared__ uint32_t l_need;          // sampled occurrences of the block's wave / lane-list reads (the bound of their regions: need_sum)
 	if (threadIdx.x < CH_N_BINS + CH_N_CLASSES) l_cnt[threadIdx.x] = 0;
-	if (threadIdx.x == 0) l_need = 0;
+	if (threadIdx.x == 0) { l_need = 0; l_maxlen = 0; }
 	__syncthreads();
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
 	int bin = -1; uint32_t my = 0;
@@ -82,9 +83,11 @@ __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 		bin = need > A.heavy_thresh ? CH_N_BINS + ch_class_of(need, A.lane_max) : ch_bin_of(need);
 		my = atomicAdd(&l_cnt[bin], 1u);
 		if (need > A.heavy_thresh) atomicAdd(&l_need, need);
+		atomicMax(&l_maxlen, A.x.read_lens[r]);
 	}
 	__syncthreads();
 	if (threadIdx.x == 0 && l_need) atomicAdd(A.need_sum, (unsigned long long)l_need);
+	if (threadIdx.x == 0) atomicMax(A.light_n + CH_N_BINS, l_maxlen);      // the longest read of the batch: a bound of every query length of its jobs
 	if (threadIdx.x < CH_N_BINS + CH_N_CLASSES && l_cnt[threadIdx.x])
 		l_base[threadIdx.x] = atomicAdd(threadIdx.x < CH_N_BINS ? A.light_n + threadIdx.x : A.heavy_n + (threadIdx.x - CH_N_BINS), l_cnt[threadIdx.x]);
 	__syncthreads();
@@ -317,7 +320,7 @@ struct bmh_chain_ws {
 	ch_seed_t *seeds; ch_chain_t *chains; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx; ch_reg_t *regs; ch_est_t *est;
 	// per read
 	uint32_t *regs_per_read, *jobs_per_read, *reg_off, *job_off, *heavy_list, *need; float *frac_rep;
-	uint32_t *counters;            // [0..CH_N_CLASSES) heavy_n per size class  [CH_N_CLASSES] err  [12..32) profile stamps  [32..36) reads per need bin of the lane kernel
+	uint32_t *counters;            // [0..CH_N_CLASSES) heavy_n per size class  [CH_N_CLASSES] err  [12..32) profile stamps  [32..36) reads per need bin of the lane kernel  [36] longest read
 	// contigs
 	int n_contigs; int64_t *ctg_off; int32_t *ctg_len;
 	// outputs, grown on demand
@@ -626,7 +629,7 @@ extern "C" int bmh_chain_extend(bmh_chain_ws_t *w, const bmh_ext_params_t *p, in
 	if (!w || !p) { bmh_set_error("bmh_chain_extend: null argument"); return BMH_EINVAL; }
 	if (w->n_jobs == 0) return BMH_OK;
 	bmh_ext_desc_t d;
-	d.reads = w->last_reads; d.pac = w->last_pac; d.l_pac = (long long)w->last_l_pac; d.jq_src = w->jq_src; d.job_side = w->job_side; d.jt0 = w->jt0;
+	d.reads = w->last_reads; d.pac = w->last_pac; d.l_pac = (long long)w->last_l_pac; d.jq_src = w->jq_src; d.job_side = w->job_side; d.jt0 = w->jt0; d.max_qlen = 0;
 	return bmh_extend_batch_desc(&d, w->qlen, w->tlen, w->h0, (uint32_t)w->n_jobs, p, d_out3, d_raw, stream_);
 }
 
@@ -733,6 +736,7 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	HIPCK(hipMemcpyAsync(w->h_pin + 0, w->off2[0] + n_reads, 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipMemcpyAsync(w->h_pin + 1, w->off2[1] + n_reads, 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipMemcpyAsync(h64, w->need_sum, 8, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(w->h_pin + 40, w->counters + 32 + CH_N_BINS, 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipEventRecord(w->ev_t[5], st));
 	HIPCK(hipStreamSynchronize(st));                          // (the lane kernel; the wave kernels go on)
 	const uint64_t n_regs_a = w->h_pin[0], n_jobs_a = w->h_pin[1], need_b = h64[0];
@@ -744,6 +748,7 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	E.qlen = w->qlen; E.tlen = w->tlen; E.h0 = w->h0; E.job_read = w->job_read; E.job_reg = w->job_reg; E.job_side = w->job_side; E.jq_src = w->jq_src; E.jt0 = w->jt0;
 	bmh_ext_desc_t d;
 	d.reads = d_reads; d.pac = idx->dev.pac; d.l_pac = (long long)idx->dev.l_pac;
+	d.max_qlen = w->h_pin[40];                                  // (the longest read: the extension skips the classes beyond it)
 	HIPCK(hipEventRecord(w->ev_x[0], st));
 	if (n_regs_a) {
 		E.regs_per_read = w->regs_per_read; E.need = w->need; E.thresh = A.heavy_thresh; E.pass = 0; E.reg_off = w->off2[0]; E.job_off = w->off2[1]; E.reg_base = E.job_base = 0;

@@ -1147,6 +1147,9 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	HIPCK(hipEventRecord(g_scr.fork, st));
 	for (int i = 0; i < 4; ++i) HIPCK(hipStreamWaitEvent(g_scr.side[i], g_scr.fork, 0));
 	hipStream_t *S = g_scr.side;
+	// (a caller that knows a bound of the query lengths -- the device job builder: the longest read -- spares the launches of the
+	// classes beyond it: they would find their lists empty, but each occupies its side stream until it has had its turn on the chip)
+	const uint32_t mq = desc && desc->max_qlen ? desc->max_qlen : 0xFFFFFFFFu;
 	// the packed classes hold the bulk of the jobs when they are enabled: they go first, widest (longest running) first
 	if (pk_ok) {
 		// grids sized to what is resident at once (the waves draw their jobs): 3 waves per SIMD for P >= 9 (768 blocks), 4 below
@@ -1154,19 +1157,36 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		if (g4 > max_grid) g4 = max_grid;
 		if (g8 > max_grid) g8 = max_grid;
 		const unsigned g4w = g4 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g4, g8w = g8 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g8, g16w = g16 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g16;
-		launch_pk<4, 17>(a, S[2], g4w); launch_pk<4, 16>(a, S[3], g4w); launch_pk<4, 14>(a, S[0], g4w); launch_pk<4, 12>(a, S[1], g4w); launch_pk<4, 10>(a, S[2], g4w);
-		launch_pk<4, 8>(a, S[3], g4); launch_pk<4, 6>(a, S[0], g4); launch_pk<4, 4>(a, S[1], g4);
-		launch_pk<8, 9>(a, S[2], g8w); launch_pk<8, 10>(a, S[3], g8w); launch_pk<8, 12>(a, S[0], g8w); launch_pk<8, 14>(a, S[1], g8w); launch_pk<8, 16>(a, S[2], g8w);
-		launch_pk<16, 9>(a, S[3], g16w);
+		if (mq > 128) launch_pk<4, 17>(a, S[2], g4w);
+		if (mq > 112) launch_pk<4, 16>(a, S[3], g4w);
+		if (mq > 96) launch_pk<4, 14>(a, S[0], g4w);
+		if (mq > 80) launch_pk<4, 12>(a, S[1], g4w);
+		if (mq > 64) launch_pk<4, 10>(a, S[2], g4w);
+		if (mq > 48) launch_pk<4, 8>(a, S[3], g4);
+		if (mq > 32) launch_pk<4, 6>(a, S[0], g4);
+		launch_pk<4, 4>(a, S[1], g4);
+		if (mq > 128) launch_pk<8, 9>(a, S[2], g8w);
+		if (mq > 144) launch_pk<8, 10>(a, S[3], g8w);
+		if (mq > 160) launch_pk<8, 12>(a, S[0], g8w);
+		if (mq > 192) launch_pk<8, 14>(a, S[1], g8w);
+		if (mq > 224) launch_pk<8, 16>(a, S[2], g8w);
+		if (mq > 256) launch_pk<16, 9>(a, S[3], g16w);
 	}
 	// (narrow classes first measured better than widest first: 10.8 vs 11.1 ms)
-	launch16<1>(a, S[0], g16); launch16<2>(a, S[1], g16); launch16<3>(a, S[2], g16); launch16<4>(a, S[3], g16);
-	launch16<5>(a, S[0], g16); launch16<6>(a, S[1], g16); launch16<7>(a, S[2], g16); launch16<8>(a, S[3], g16);
-	launch16<9>(a, S[0], g16); launch16<10>(a, S[1], g16); launch16<11>(a, S[2], g16); launch16<12>(a, S[3], g16);
-	launch16<13>(a, S[0], g16); launch16<14>(a, S[1], g16); launch16<15>(a, S[2], g16); launch16<16>(a, S[3], g16);
-	launch16<17>(a, S[0], g16); launch16<18>(a, S[1], g16);
-	launch_wide<5>(a, S[2], gw); launch_wide<6>(a, S[3], gw); launch_wide<7>(a, S[2], gw); launch_wide<8>(a, S[3], gw);
-	launch_wide<9>(a, S[0], gw); launch_wide<10>(a, S[1], gw); launch_wide<11>(a, S[2], gw); launch_wide<12>(a, S[3], gw);
+	// class C of extend16 holds the queries of 16 (C - 1) + 1 .. 16 C columns; wide class C those of 64 (C - 1) + 1 .. 64 C, and class 5
+	// also every job whose target is longer than EXT_T_CAP rows
+	#define L16(C, s_) do { if (mq > 16u * ((C) - 1)) launch16<C>(a, S[s_], g16); } while (0)
+	L16(1, 0); L16(2, 1); L16(3, 2); L16(4, 3); L16(5, 0); L16(6, 1); L16(7, 2); L16(8, 3); L16(9, 0); L16(10, 1); L16(11, 2); L16(12, 3);
+	L16(13, 0); L16(14, 1); L16(15, 2); L16(16, 3); L16(17, 0); L16(18, 1);
+	#undef L16
+	launch_wide<5>(a, S[2], gw);
+	if (mq > 320) launch_wide<6>(a, S[3], gw);
+	if (mq > 384) launch_wide<7>(a, S[2], gw);
+	if (mq > 448) launch_wide<8>(a, S[3], gw);
+	if (mq > 512) launch_wide<9>(a, S[0], gw);
+	if (mq > 576) launch_wide<10>(a, S[1], gw);
+	if (mq > 640) launch_wide<11>(a, S[2], gw);
+	if (mq > 704) launch_wide<12>(a, S[3], gw);
 	for (int i = 0; i < 4; ++i) { HIPCK(hipEventRecord(g_scr.join[i], g_scr.side[i])); HIPCK(hipStreamWaitEvent(st, g_scr.join[i], 0)); }
 	HIPCK(hipEventRecord(g_scr.ev1, st));
 	HIPCK(hipGetLastError());

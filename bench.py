@@ -42,20 +42,23 @@ from bwamem_hip.parallel import broadcast_built_index, shard_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz: a wave64 instruction issues in 2 cycles (MI355X_MICROARCH.md)
-PROFILE_TAG = "r02"          # profiles/<tag>_pmc.json: counters collected by scripts/profile_round.sh with this same command
+PROFILE_TAG = "r03"          # profiles/<tag>_pmc*.json: counters collected by scripts/profile_round.sh with this same command (one file per workload)
 
 
 def profile_counters(workload_key: str):
     """Per-kernel-family counters of the committed rocprofv3 PMC passes (profiles/<tag>_pmc.json, written by
     scripts/summarize_profiles.py from separate --pmc runs of this command).  They are NOT measured by this run: every
     field taken from them is labelled from_profile and dropped when the profile's workload differs from this run's."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc.json")))
-        if d.get("workload_key") != workload_key:
-            return None
-        return d
-    except Exception:
-        return None
+    import glob
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc*.json"))):
+        try:
+            d = json.load(open(fn))
+        except Exception:
+            continue
+        if d.get("workload_key") == workload_key:
+            d["_file"] = os.path.relpath(fn, ROOT)
+            return d
+    return None
 
 
 def cpu_model():
@@ -106,12 +109,17 @@ def cpu_baseline(g, pac_h, hidx, reads, contigs, n_all: int, n_one: int, n_threa
         flat = np.ascontiguousarray(sub.reshape(-1)); offs = np.arange(n, dtype=np.uint64) * L; lens = np.full(n, L, np.uint32)
         t0 = time.time(); s = orc.seed_reads(f, flat, offs, lens, 19, n_threads=nth); t_seed = time.time() - t0
         t0 = time.time(); hj = HostJobs(g, flat, offs, lens, s, n_threads=nth, contigs=contigs, pac=pac_h); t_chain = time.time() - t0 - hj.t_pack
-        arr = [x.copy() for x in hj.jobs()]; n_jobs = hj.n_jobs; hj.free()
+        arr = [x.copy() for x in hj.jobs()]; n_jobs = hj.n_jobs
         t0 = time.time(); o3, _, cells = orc.extend_batch(*arr, n_threads=nth); t_ext = time.time() - t0
+        regs = hj.merge(o3).copy(); hj.free()             # (src/bwamem.c:2297-2303: the regions the reference's host code would hold after its extension)
         out[tag] = dict(n=n, threads=nth, t_seed=t_seed, t_chain=t_chain, t_ext=t_ext, n_jobs=n_jobs, cells=cells, n_seeds=int(len(s["rbeg"])), work=s["work"])
+        if tag == "all":
+            out["_check"] = dict(n=n, seeds=s, regs=regs)
         return flat, offs, lens, s, arr, o3
 
     run(n_all, n_threads, "all")
+    if n_one <= 0:
+        return out
     flat, offs, lens, s, arr, o3 = run(n_one, 1, "one")
     if oracle_py.Ref.available():
         ref = oracle_py.Ref()
@@ -124,6 +132,20 @@ def cpu_baseline(g, pac_h, hidx, reads, contigs, n_all: int, n_one: int, n_threa
             out["ref"] = dict(n=n_one, threads=1, t_seed=t_seed, t_ext=t_ext, identical_to_port=bool(same))
             ref.lib.ref_bwt_free(b)
     return out
+
+
+def verify_against_oracle(check, gpu_seeds, gpu_regs):
+    """The GPU's seeds and alignment regions of the first check['n'] reads of a batch against the CPU checker's (oracle seeding ->
+    bmh_build_jobs -> oracle ksw_extend2 -> bmh_merge_regs, i.e. what the reference's host code holds at src/bwamem.c:2297-2303).
+    Both sides are in read order, so the checker's arrays must equal the leading rows of the GPU's.  Returns the `verified` object."""
+    n, s, regs = check["n"], check["seeds"], check["regs"]
+    ns = int(len(s["rbeg"]))
+    seeds_ok = bool(np.array_equal(gpu_seeds["n_ref_pos"][:n], s["n_ref_pos"]) and np.array_equal(gpu_seeds["prefix"][:n], s["prefix"]) and
+                    np.array_equal(gpu_seeds["rbeg"][:ns], s["rbeg"]) and np.array_equal(gpu_seeds["qbeg"][:ns], s["qbeg"]) and
+                    np.array_equal(gpu_seeds["score"][:ns], s["score"]))
+    m = int(len(regs))
+    regs_ok = bool(len(gpu_regs) >= m and np.array_equal(gpu_regs[:m], regs) and (len(gpu_regs) == m or int(gpu_regs[m, 0]) >= n))
+    return {"reads": int(n), "seeds": ns, "regions": m, "seeds_identical": seeds_ok, "regions_identical": regs_ok}
 
 
 def main():
@@ -149,12 +171,26 @@ def main():
     ap.add_argument("--no-next-rows", dest="next_rows", action="store_false")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BENCH_CPU_SAMPLE", "100000")), help="reads of the all-cores CPU leg (0 = no CPU baseline)")
     ap.add_argument("--cpu-sample-1t", type=int, default=int(os.environ.get("BENCH_CPU_SAMPLE_1T", "3000")), help="reads of the one-thread CPU legs")
+    ap.add_argument("--verify-sample", type=int, default=int(os.environ.get("BENCH_VERIFY_SAMPLE", "-1")), help="reads of the last timed batch whose GPU seeds and regions are "
+                    "compared with the oracle after the timed loops (-1: the CPU sample at N = 1, 10000 per rank at N > 1; 0: off)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (torch.distributed.run) BEFORE this
+        # process touches the GPU, hand their output through and leave with their exit code.  Rank 0 of the children prints the line.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE {world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE {world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     n_dev = torch.cuda.device_count()
     dev_id = local_rank % n_dev              # several ranks may share a device (BENCH_SHARE_GPU runs of the N > 1 path on one GPU)
@@ -303,7 +339,7 @@ def main():
                 self.cw.merge(self.out3, self.regs, stream=self.h)
             else:
                 dj_ = self.cw.extend_merge(dindex, ascii_t, offs_t, lens_t, sd, self.regs, params=params, stream=self.h)
-            self.n_regs = int(dj_.n_regs)
+            self.n_regs = int(dj_.n_regs); self.last_batch = i & 1; self.last_pcie = host_in is not None
             t_host.append(time.time())
             if lane_log is not None:                                  # (BENCH_LANE_LOG=1: host-side begin / seeded / launched of every batch)
                 lane_log.append((self.k, i, *t_host))
@@ -392,6 +428,15 @@ def main():
         dt_pcie = time.perf_counter() - t0
         pcie_bytes = (host_in[0][0].numel() + 8 * n_reads, 32 * n_regs)
 
+    # ---------------- the regions of the LAST TIMED step of the last lane, as they left the timed loop (over PCIe when that loop ran):
+    # what the self-check below compares with the oracle.  The check is made on batch 1; a lane whose last step was batch 0 runs
+    # one more (untimed) step of the same code path on batch 1.
+    vlane = lanes[-1]
+    if getattr(vlane, "last_batch", 0) != 1:
+        vlane.step(1, host_in if a.pcie else None)
+    torch.cuda.synchronize()
+    last_regs_h = vlane.host_out[: vlane.n_regs].numpy().copy() if vlane.last_pcie else vlane.regs[: vlane.n_regs].cpu().numpy()
+
     if distributed:
         tt = torch.tensor([dt, dt_pcie or 0.0], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -420,10 +465,39 @@ def main():
         for k, v in tm.items():
             iso_ms[k] = iso_ms.get(k, 0.0) + v / 3
 
+    # ---------------- CPU checker on a bounded sample of batch 1: the CPU baseline (N = 1) and the self-check of the timed batch (every rank)
+    n_check = a.verify_sample if a.verify_sample >= 0 else (min(a.cpu_sample, n_reads) if world == 1 else min(10000, n_reads))
+    n_cpu_all = min(a.cpu_sample, n_reads) if world == 1 else 0
+    cb = verified = None
+    t_cpu_setup = 0.0
+    if max(n_check, n_cpu_all) > 0:
+        from bwamem_hip.lib import SeedsT, seeds_to_host
+        ncores = max(1, effective_cores() // (world if n_dev >= world else 1))
+        t0 = time.time()
+        hidx = F.device_index_to_host(d, max(16, a.sa_intv))
+        cb = cpu_baseline(g, pac_t.cpu().numpy(), hidx, batches[1][0], contigs, max(n_check, n_cpu_all), max(1, min(a.cpu_sample_1t, n_reads)) if world == 1 and n_cpu_all else 0, ncores)
+        t_cpu_setup = time.time() - t0 - sum(cb[k][t] for k in ("all", "one") if k in cb for t in ("t_seed", "t_chain", "t_ext"))
+        del hidx
+        if n_check > 0:
+            ck = cb["_check"]
+            sd_v = ws.seed_batch(dindex, batches[1][1].ascii, batches[1][1].offs, batches[1][1].lens, 19, stream=h_main)
+            torch.cuda.synchronize()
+            head = SeedsT.from_buffer_copy(bytes(sd_v)); head.n_seeds = min(int(sd_v.n_seeds), len(ck["seeds"]["rbeg"]))      # only the sample's seeds travel to the host
+            verified = verify_against_oracle(ck, seeds_to_host(head, ck["n"]), last_regs_h)
+            verified["what"] = ("GPU seeds and alignment regions of the first reads of the last timed batch (regions as they left the timed loop"
+                                + (", D2H over PCIe" if vlane.last_pcie else "") + ") vs oracle seeding -> bmh_build_jobs -> oracle ksw_extend2 -> bmh_merge_regs")
+            if distributed:
+                ok = torch.tensor([int(verified["seeds_identical"]), int(verified["regions_identical"]), verified["reads"]], dtype=torch.int64, device=tt.device)
+                mn = ok.clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN); dist.all_reduce(ok)
+                verified.update(seeds_identical=bool(mn[0]), regions_identical=bool(mn[1]), reads=int(ok[2]), ranks=world)
+    failed = verified is not None and not (verified["seeds_identical"] and verified["regions_identical"])
+
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = total_reads * a.steps / dt / 1e6
         st = stats[-1]
+        index_how = ("loaded from --index-cache (built on the device by an earlier run of this command)" if build_stats.get("loaded_from_cache") else
+                     "built on the device in setup" + (" and verified completely (every adjacent pair of suffix-array rows)" if build_stats.get("verified") else ", not verified (--no-verify-index)"))
         workload_key = f"g{a.genome_mbp:g}_r{n_reads}_l{a.read_len}_{'pe' if a.paired else 'se'}_sa{a.sa_intv}"
         res = {
             "metric": "Mreads/s (150 bp single-end vs hg38-scale index; seed-and-extend hot path)", "value": round(value, 3), "unit": "Mreads/s",
@@ -431,7 +505,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": f"{a.reads_per_gpu} synthetic {a.read_len} bp {'paired-end (interleaved)' if a.paired else 'single-end'} reads per GPU vs an hg38-scale FMD index: seeded synthetic "
                                    f"{a.genome_mbp:g} Mbp genome, 24 contigs, 50% planted repeats (mid-copy families, LINE-like, high-copy SINE-like, satellites, low-divergence segmental "
-                                   f"duplications), N-runs; seq_len = {d.seq_len} rows{' > 2^32' if d.seq_len >> 32 else ''}; index built and verified on the device in setup; "
+                                   f"duplications), N-runs; seq_len = {d.seq_len} rows{' > 2^32' if d.seq_len >> 32 else ''}; index {index_how}; "
                                    "seeding = all SMEMs >= 19 bp + locate; extension = every left/right job the reference's chaining (mem_chain, mem_chain_flt, mem_chain2aln) produces; "
                                    "chaining, job construction with on-device reference fetch and the region merge run on the device inside the timed region (reads in, regions out); "
                                    "two different read batches alternate",
@@ -452,12 +526,12 @@ def main():
                                 "h2d_bytes_per_step": int(pcie_bytes[0]), "d2h_bytes_per_step": int(pcie_bytes[1]),
                                 "how": "pinned host reads -> H2D -> path -> D2H of the regions into pinned host memory, every batch on its lane's stream: the copies "
                                        "of one batch in flight overlap the kernels of the other(s)"}
+        if verified is not None:
+            res["verified"] = verified
+        if world > 1:
+            res["note"] = "N > 1 line: `roofline` and `cpu_baseline` are reported by the N = 1 run only (rank 0 at N = 1, bench contract)"
         # ---------------- CPU baseline + roofline of the dominant kernel (N = 1 only)
-        if world == 1 and a.cpu_sample > 0:
-            ncores = effective_cores()
-            t0 = time.time()
-            hidx = F.device_index_to_host(d, max(16, a.sa_intv))
-            cb = cpu_baseline(g, pac_t.cpu().numpy(), hidx, batches[1][0], contigs, min(a.cpu_sample, n_reads), min(a.cpu_sample_1t, n_reads), ncores)
+        if world == 1 and n_cpu_all > 0:
             al, on = cb["all"], cb["one"]
             rate = lambda x: x["n"] / (x["t_seed"] + x.get("t_chain", 0.0) + x["t_ext"]) / 1e6
             res["cpu_baseline"] = {
@@ -468,7 +542,9 @@ def main():
                 "one_thread": {"value": round(rate(on), 6), "reads": on["n"], "t_seed_s": round(on["t_seed"], 3), "t_chain_s": round(on["t_chain"], 3), "t_ext_s": round(on["t_ext"], 3)},
                 "all_cores": {"value": round(rate(al), 5), "reads": al["n"], "t_seed_s": round(al["t_seed"], 3), "t_chain_s": round(al["t_chain"], 3), "t_ext_s": round(al["t_ext"], 3),
                               "scaling_vs_one_thread": round(rate(al) / rate(on), 1)},
-                "setup_s": round(time.time() - t0, 1)}
+                "setup_s": round(t_cpu_setup, 1)}
+            if verified is not None:
+                res["cpu_baseline"]["checked_against_gpu"] = {k: verified[k] for k in ("reads", "seeds_identical", "regions_identical")}
             if "ref" in cb:
                 rf = cb["ref"]
                 res["cpu_baseline"]["reference_code_one_thread"] = {
@@ -507,23 +583,27 @@ def main():
                      "frac": round(ach_ / HBM_PEAK_GBS, 5), "traffic": from_prof(k, "hbm_bytes_per_launch"), "avg_ms": round(iso_ms[k], 3),
                      "algorithmic_bytes_per_launch": int(kernel_bytes[k])}
                 if o["traffic"] is not None:
-                    o["traffic_source"] = f"from_profile profiles/{PROFILE_TAG}_pmc.json (same command, separate --pmc passes; not measured by this run)"
+                    o["traffic_source"] = f"from_profile {prof['_file']} (same command under rocprofv3, separate --pmc passes; not measured by this run)"
                 return o
+            prof_src = f"from_profile {prof['_file']} (same command under rocprofv3, separate --pmc passes; not measured by this run)" if prof else None
             timed = {k: iso_ms.get(k, 0.0) for k in ("forward", "backward", "locate", "extend")}
             dom = max(timed, key=timed.get)
-            res["roofline"] = hbm_obj(dom)
-            if dom == "extend":
-                res["roofline"]["note"] = "integer-VALU bound DP (no MFMA; ~110 B of HBM traffic per job): its binding roofline is extension_stage.valu"
             hb = max((k for k in timed if k != "extend"), key=timed.get)
             res["roofline_hbm_kernel"] = hbm_obj(hb)
             res["roofline_all"] = {k: {"ms": round(iso_ms[k], 3), "algorithmic_GBps": round(kernel_bytes[k] / (iso_ms[k] * 1e-3) / 1e9, 2)} for k in kernel_bytes}
-            # the extension's binding roofline: integer VALU issue.  Algorithmic lane-ops = reference cells x 12
+            # the extension's binding roofline: integer VALU issue.  Algorithmic lane-ops = reference cells x 12; reference
+            # cells = sum over rows of (end - beg) as ksw_extend2 executes them, counted by the oracle on the CPU sample and scaled to the batch
+            t_ext_s = iso_ms["extend"] * 1e-3
             lane_ops = cells * 12.0
-            ext = {"bound": "integer VALU (not HBM, not MFMA)", "ms": round(iso_ms["extend"], 3), "jobs": n_jobs,
-                   "gcups_reference_cells": round(cells / (iso_ms["extend"] * 1e-3) / 1e9, 1),
-                   "valu": {"algorithmic_lane_ops": int(lane_ops), "achieved": round(lane_ops / (iso_ms["extend"] * 1e-3) / 1e12, 2), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
-                            "unit": "T lane-ops/s", "frac": round(lane_ops / (iso_ms["extend"] * 1e-3) / VALU_PEAK_LANEOPS, 4),
-                            "peak_definition": "256 CUs x 4 SIMD-32 x 2.4 GHz: one wave64 VALU instruction per 2 cycles per SIMD"}}
+            valu = {"bound": "int-valu", "kernel": names["extend"], "achieved": round(lane_ops / t_ext_s / 1e12, 2), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
+                    "unit": "T lane-ops/s", "frac": round(lane_ops / t_ext_s / VALU_PEAK_LANEOPS, 4), "traffic": from_prof("extend", "hbm_bytes_per_launch"),
+                    "avg_ms": round(iso_ms["extend"], 3), "algorithmic_lane_ops_per_launch": int(lane_ops), "reference_cells_per_launch": int(cells),
+                    "gcups_reference_cells": round(cells / t_ext_s / 1e9, 1), "jobs_per_launch": n_jobs,
+                    "peak_definition": "256 CUs x 4 SIMD-32 x 2.4 GHz: one wave64 VALU instruction per 2 cycles per SIMD (MI355X_MICROARCH.md); no MFMA: integer DP, not a contraction",
+                    "hbm_view": {"algorithmic_bytes_per_launch": int(kernel_bytes["extend"]), "GBps": round(kernel_bytes["extend"] / t_ext_s / 1e9, 2),
+                                 "frac_of_hbm_peak": round(kernel_bytes["extend"] / t_ext_s / 1e9 / HBM_PEAK_GBS, 5)}}
+            if valu["traffic"] is not None:
+                valu["traffic_source"] = prof_src
             if hasattr(L, "bmh_calib_valu"):
                 ms_c = C.c_float(0); ops_c = C.c_double(0)
                 L.bmh_calib_valu.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]
@@ -531,19 +611,21 @@ def main():
                 for mode, nm in ((0, "independent_v_max_add"), (1, "dependent_chain"), (2, "dpp_row_shr_max"), (4, "packed_u16_add_max")):
                     if L.bmh_calib_valu(mode, 8, 20000, None, C.byref(ms_c), C.byref(ops_c)) == 0:
                         cal[nm] = round(ops_c.value / (ms_c.value * 1e-3) / VALU_PEAK_LANEOPS, 3)
-                ext["valu"]["calibration_frac_of_peak_measured_now"] = cal
+                valu["calibration_frac_of_peak_measured_now"] = cal
                 if cal.get("independent_v_max_add"):
                     # what the chip sustains on plain integer VALU instructions, measured in this run: one wave64 instruction per ~4.4 cycles per
                     # SIMD whatever the number of resident waves (scripts/calib_valu.py), i.e. about half of the 2-cycle figure of the guide
-                    ext["valu"]["measured_ceiling"] = round(cal["independent_v_max_add"] * VALU_PEAK_LANEOPS / 1e12, 2)
-                    ext["valu"]["frac_of_measured_ceiling"] = round(ext["valu"]["frac"] / cal["independent_v_max_add"], 4)
+                    valu["measured_ceiling"] = round(cal["independent_v_max_add"] * VALU_PEAK_LANEOPS / 1e12, 2)
+                    valu["frac_of_measured_ceiling"] = round(valu["frac"] / cal["independent_v_max_add"], 4)
             issued = from_prof("extend", "valu_wave_instr_per_launch")
             if issued is not None:
-                ext["valu"]["issue_slot_frac"] = round(issued * 64.0 / (iso_ms["extend"] * 1e-3) / VALU_PEAK_LANEOPS, 4)
-                ext["valu"]["executed_lane_instr_per_reference_cell"] = round(issued * 64.0 / cells, 2)
-                ext["valu"]["source"] = f"from_profile profiles/{PROFILE_TAG}_pmc.json (SQ_INSTS_VALU summed over the whole family)"
-            ext["dtype_note"] = "DP cells as packed unsigned 16-bit pairs (v_pk_*_u16) where h0 + qlen*a < 4096, 32-bit lanes otherwise; rank arithmetic of the seeding is 32/64-bit popcounts"
-            res["extension_stage"] = ext
+                valu["issue_slot_frac"] = round(issued * 64.0 / t_ext_s / VALU_PEAK_LANEOPS, 4)
+                valu["executed_lane_instr_per_reference_cell"] = round(issued * 64.0 / cells, 2)
+                valu["issue_source"] = "SQ_INSTS_VALU summed over the whole family, " + prof_src
+            valu["dtype_note"] = "DP cells as packed unsigned 16-bit pairs (v_pk_*_u16) where h0 + qlen*a < 4096, 32-bit lanes otherwise; rank arithmetic of the seeding is 32/64-bit popcounts"
+            # `roofline` = the dominant kernel family with the bound that binds it: integer VALU for the extension, HBM gathers for a seeding kernel
+            res["roofline"] = valu if dom == "extend" else res["roofline_hbm_kernel"]
+            res["extension_stage"] = valu
             if a.next_rows:
                 try:
                     res["next_rows"] = downstream_stages(L, dindex, batches[1][1], cw, regs_out[1], st["n_regs"], n_reads, g, pac_t, batches[1][0], params, contigs, a.paired)
@@ -553,6 +635,9 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        print("bench.py: the timed batch does NOT match the oracle: " + json.dumps(verified), file=sys.stderr)
+        sys.exit(3)
 
 
 def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, reads, params, contigs, paired=False):

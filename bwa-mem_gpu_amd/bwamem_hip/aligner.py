@@ -241,6 +241,13 @@ class Aligner:
             if nj:
                 d = [torch.from_numpy(np.ascontiguousarray(x).view(np.int32) if x.dtype == np.uint32 else np.ascontiguousarray(x)).to(dev) for x in hj.jobs()]
                 extend_batch(*d, out3, params=ext_p)
+                # a flank longer than the DP kernels take (768 query bases: a read beyond ~790 bp seeded near one end) comes back as
+                # INT32_MIN and must never reach the merge; the device builder refuses such reads itself
+                n_bad = int(L.bmh_extend_last_unsupported())
+                if n_bad:
+                    hj.free(); ws.free()
+                    raise NotImplementedError(f"{n_bad} extension job(s) of this batch have a query side longer than 768 bases: reads this long are beyond the "
+                                              "extension kernels (the reference's own GASAL2 build is sized by MAX_SEQ_LEN, README.md:38)")
             regs_h = np.ascontiguousarray(hj.merge(out3[:nj].cpu().numpy())) if nr else np.zeros((0, 8), np.int32)
             rpr_h = np.ascontiguousarray(hj.regs_per_read.copy()); fr_h = np.ascontiguousarray(hj.frac_rep(), dtype=np.float32)
             hj.free()

@@ -351,7 +351,7 @@ template <int C, bool LUT>
 __device__ __forceinline__ bool ext_row(const ext_args_t &A, const ext_lut_t &L, const int oe_del, const int oe_ins,
                                         int (&H)[C], int (&E)[C], const int (&qv)[C], const int (&mmv)[C],
                                         const int ti, const bool run, const int hfc, const int hnx, const int i, const int qlen,
-                                        const int j0, const int ej0, const int jl_lane, ext_rs_t &S, bool alive, const bool bound)
+                                        const int j0, const int ej0, const int jl_lane, ext_rs_t &S, bool alive, const bool bound, const int rl)
 {
 	const int wend = run ? S.end - j0 : 0;                      // cells c < wend of this lane are left of `end`
 	const int left = row_shr1(H[C - 1], S.beg == 0 ? hfc : 0);
@@ -439,18 +439,25 @@ __device__ __forceinline__ bool ext_row(const ext_args_t &A, const ext_lut_t &L,
 	}
 	// Exact early stop.  Phi(v at column c) = v + a*(qlen-1-c) never increases along a DP transition
 	// (diagonal: +s <= +a and one column right; E: same column minus a gap cost; F: right minus a gap
-	// cost), so every H of every later row is <= U = max Phi over this row's frontier {H(i,j), E(i+1,j),
-	// first-column value}.  Once U <= max and U < gscore no later row can change max/max_i/max_j/max_off
-	// (strict >, ksw.c:948) nor gscore/max_ie (>=, ksw.c:943): the remaining rows are dead work.
+	// cost), and only a NON-ZERO cell starts anything (M == 0 stays 0, ksw.c:924; E(i+1,j) != 0 implies H(i,j) != 0), so
+	// every H of every later row is <= U = max Phi over the non-zero cells of this row's frontier {H(i,j), E(i+1,j),
+	// first-column value}; a path also gains at most a per remaining target row, so U <= (row maximum) + a * rows left.
+	// Once U <= max and U < gscore no later row can change max/max_i/max_j/max_off (strict >, ksw.c:948) nor
+	// gscore/max_ie (>=, ksw.c:943): the remaining rows are dead work.  (Round 2 let zero cells carry a*(qlen-1-c): U never
+	// fell below a*(qlen-1-beg) and the rule fired for near-perfect flanks only.)  Callers that take only the three
+	// GASAL2 results (no raw 6-tuple) stop as well once the local-vs-to-end rule (src/bwamem.c:1893-1901) is decided:
+	// U <= max - end_bonus and gscore <= max - end_bonus mean that no later gscore reaches max - end_bonus either.
 	if (bound) {                                                // wave-uniform
 		const int aq = A.a * (qlen - 1 - j0);
 		int u = 0;
 #pragma unroll
-		for (int c = 0; c < C; ++c) u = max(u, max(H[c], E[c]) + (aq - A.a * c));
+		for (int c = 0; c < C; ++c) { const int v = max(H[c], E[c]); u = max(u, v ? v + (aq - A.a * c) : 0); }
 		const int h1n = S.beg == 0 ? hnx : 0;
-		u = max(u, h1n + A.a * qlen);
+		u = max(u, h1n ? h1n + A.a * qlen : 0);
 		u = row_allmax_f(u);
-		alive = alive && !(u <= S.mx && u < S.gscore);
+		u = min(u, max(m, h1n) + A.a * rl);
+		const bool fin = u < S.gscore || (A.raw == nullptr && u <= S.mx - A.end_bonus && S.gscore <= S.mx - A.end_bonus);
+		alive = alive && !(u <= S.mx && fin);
 	}
 	return alive;
 }
@@ -513,7 +520,7 @@ __global__ void __launch_bounds__(256) extend16_static_kernel(ext_args_t A)
 			rows_done += run ? 1 : 0;
 			const int hfc = max(0, h0 - (i == 0 ? 0 : A.o_del + A.e_del * i));        // H(i-1,-1)
 			const int hnx = max(0, h0 - (A.o_del + A.e_del * (i + 1)));
-			alive = ext_row<C, LUT>(A, L, oe_del, oe_ins, H, E, qv, mmv, ti, run, hfc, hnx, i, qlen, j0, ej0, jl_lane, S, alive, (i & 3) == 3);
+			alive = ext_row<C, LUT>(A, L, oe_del, oe_ins, H, E, qv, mmv, ti, run, hfc, hnx, i, qlen, j0, ej0, jl_lane, S, alive, (i & 3) == 3, tlen - 1 - i);
 		}
 		if (have && l16 == 0) {
 			const int qle = S.max_j + 1, tle = S.max_i + 1, gtle = S.max_ie + 1;
@@ -630,7 +637,7 @@ __global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t
 		rows_done += run ? 1 : 0;
 		const int hnx = max(0, h0 - dn);                        // first-column value of the next row: max(0, h0 - (o_del + e_del*(i+1)))
 		// (the early-stop bound is evaluated every fourth iteration of the wave for all its rows: it is exact at any row)
-		alive = ext_row<C, LUT>(A, L, oe_del, oe_ins, H, E, qv, mmv, ti, run, hfc, hnx, i, qlen, j0, ej0, jl_lane, S, alive, (wave_rows & 3) == 0);
+		alive = ext_row<C, LUT>(A, L, oe_del, oe_ins, H, E, qv, mmv, ti, run, hfc, hnx, i, qlen, j0, ej0, jl_lane, S, alive, (wave_rows & 3) == 0, tlen - 1 - i);
 		if (run) { ++i; ++tp; hfc = hnx; dn += A.e_del; }
 		alive = alive && i < tlen;
 	}

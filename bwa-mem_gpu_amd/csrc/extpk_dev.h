@@ -36,6 +36,7 @@ __device__ __forceinline__ uint32_t pk_min1(uint32_t a) { uint32_t d; asm("v_pk_
 __device__ __forceinline__ uint32_t pk_maxs(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ uint32_t pk_subiK(uint32_t a, uint32_t k) { uint32_t d; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k)); return d; }
 __device__ __forceinline__ uint32_t pk_addi(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_madK(uint32_t a, uint32_t k, uint32_t c) { uint32_t d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c)); return d; }
 __device__ __forceinline__ uint32_t pk_splat(int v) { return ((uint32_t)v & 0xFFFFu) * 0x10001u; }
 
 __device__ __forceinline__ uint32_t pk_subsK(uint32_t a, uint32_t k) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "s"(k)); return d; }
@@ -251,7 +252,7 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t &K, const int zdrop, ui
                                        const int ti, const bool run, const int hfc, const int hnx, const int i, const int qlen,
                                        const int j0, const int eCl, const bool g0, const uint32_t phi0,
                                        const uint32_t *em_tab, uint32_t *hrow, const bool owner, const uint16_t *h16, const int goff,
-                                       pk_rs_t &S, bool alive, const bool bound)
+                                       pk_rs_t &S, bool alive, const bool bound, const int rl, const bool o3only, const int end_bonus)
 {
 	constexpr int C = 2 * P, PP = (P + 3) & ~3, PS = PP + 4;      // PS: LDS row stride in dwords (odd multiple of 4: rows start in different banks)
 	// end masks of this lane: cells [0, wend) of the lane are left of `end`
@@ -346,17 +347,20 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t &K, const int zdrop, ui
 	}
 	S.mx = better ? m : S.mx;
 	S.end = upd ? min(qlen, nlast + 2) : S.end;                 // ksw.c:963-970: last non-zero index of eh[] is the column + 1
-	// Exact early stop (see ext_row): Phi = H + a*(qlen-1-column) over the frontier; E(i+1,j) <= H(i,j), so H alone carries it
+	// Exact early stop (see ext_row): Phi = H + a*(qlen-1-column) over the NON-ZERO cells of the frontier; E(i+1,j) <= H(i,j), so H
+	// alone carries it.  Zero cells are lifted out of the maximum by an offset that the non-zero ones carry (NZ * 0x4000).
 	if (bound) {                                                // wave-uniform
 		// max over the pairs of H[p] - a*p, as a Horner-style chain from the last pair down (one constant instead of P)
-		uint32_t u2 = H[P - 1];
+		uint32_t u2 = pk_madK(NZ[P - 1], 0x40004000u, H[P - 1]);
 #pragma unroll
-		for (int p = P - 2; p >= 0; --p) u2 = pk_maxs(H[p], pk_subiK(u2, K.a2));
-		u2 = pk_addi(u2, phi0);
-		int u = max((int)(short)(u2 & 0xFFFFu), (int)u2 >> 16);
-		u = max(u, hnx + K.a * qlen);
+		for (int p = P - 2; p >= 0; --p) u2 = pk_maxs(pk_madK(NZ[p], 0x40004000u, H[p]), pk_subiK(u2, K.a2));
+		u2 = pk_subiK(pk_addi(u2, phi0), 0x40004000u);
+		int u = max(max((int)(short)(u2 & 0xFFFFu), (int)u2 >> 16), 0);
+		u = max(u, hnx ? hnx + K.a * qlen : 0);
 		u = grp_allmax<G>(u);
-		alive = alive && !(u <= S.mx && u < S.gscore);
+		u = min(u, max(m, hnx) + K.a * rl);
+		const bool fin = u < S.gscore || (o3only && u <= S.mx - end_bonus && S.gscore <= S.mx - end_bonus);
+		alive = alive && !(u <= S.mx && fin);
 	}
 	return alive;
 }
@@ -519,7 +523,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P >= 9
 		const bool run = alive;
 		rows_done += run ? 1 : 0;
 		const int hnx = max(0, h0 - dn);
-		alive = pk_row<G, P, SAME_OE>(K, A.zdrop, H, E, NZ, sel, ti, run, hfc, hnx, i, qlen, j0, eCl, g0, phi0, em_tab, hrow, owner, (const uint16_t *)h_lds, goff, S, alive, (wave_rows & PK_BOUND_MASK) == 0);
+		alive = pk_row<G, P, SAME_OE>(K, A.zdrop, H, E, NZ, sel, ti, run, hfc, hnx, i, qlen, j0, eCl, g0, phi0, em_tab, hrow, owner, (const uint16_t *)h_lds, goff, S, alive, (wave_rows & PK_BOUND_MASK) == 0, tlen - 1 - i, A.raw == nullptr, A.end_bonus);
 		if (run) { ++i; ++tp; hfc = hnx; dn += A.e_del; }
 		alive = alive && i < tlen;
 	}

@@ -1,4 +1,5 @@
-// klib's introsort (src/ksort.h:146-226 of the reference), restated as a template: it is not a stable sort, so
+// klib's introsort (src/ksort.h:146-226 of the reference; klib is (c) 2008-2011 Attractive Chaos <attractor@live.co.uk>, MIT
+// license -- the algorithm and its exact exchange sequence are klib's), restated as a template: it is not a stable sort, so
 // wherever the reference sorts records that can compare equal the order of the ties depends on its exact steps.
 #pragma once
 #include <cstddef>

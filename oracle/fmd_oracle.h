@@ -101,6 +101,10 @@ uint64_t oracle_extend_batch(uint32_t n, const uint8_t *q, const uint32_t *qoff,
                              const uint32_t *h0, const ksw_params_t *p, int32_t *out3, int32_t *raw6,
                              int n_threads);
 
+uint64_t oracle_extend_trace(uint32_t n, const uint8_t *q, const uint32_t *qoff, const uint32_t *qlen,
+                             const uint8_t *t, const uint32_t *toff, const uint32_t *tlen,
+                             const uint32_t *h0, const ksw_params_t *p, uint32_t *rows, int16_t *trace, uint64_t cap);
+
 /* ---- region -> CIGAR / NM / MD (cigar_oracle.c; ksw_global2, bwa_gen_cigar2, mem_reg2aln) */
 int oracle_ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const ksw_params_t *p, int w,
                        int *n_cigar, uint32_t *cigar, int cap);

@@ -12,6 +12,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* optional per-row trace of the trimmed range [beg,end) (analysis of the band geometry, scripts/band_probe.py) */
+static __thread int16_t *g_trace; static __thread uint64_t g_ntrace, g_trace_cap;
+
 static inline int sc(const ksw_params_t *p, int t, int q)
 {
 	if (t > 3 || q > 3) return -p->n_penalty;
@@ -50,6 +53,8 @@ int oracle_ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *
 			f -= p->e_ins; if (f < t) f = t;
 		}
 		nc += (uint64_t)(end > beg ? end - beg : 0);
+		int16_t *tr = 0;
+		if (g_trace && g_ntrace + 5 <= g_trace_cap) { tr = g_trace + g_ntrace; tr[0] = (int16_t)beg; tr[1] = (int16_t)end; tr[2] = 0; tr[3] = (int16_t)max; tr[4] = (int16_t)gscore; g_ntrace += 5; }
 		H[end] = h1; E[end] = 0;
 		if (j == qlen) {
 			if (!(gscore > h1)) max_ie = i;
@@ -71,6 +76,13 @@ int oracle_ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *
 		beg = j;
 		for (j = end; j >= beg && H[j] == 0 && E[j] == 0; --j) ;
 		end = j + 2 < qlen ? j + 2 : qlen;
+		if (tr) {   /* the potential bound of the HIP kernels after this row: U = max over the NON-ZERO frontier cells of
+		             * H + a * min(columns left, rows left) (a zero cell starts nothing: M == 0 stays 0), plus the first-column value */
+			int phi = 0, hn = beg == 0 ? h0 - (p->o_del + p->e_del * (i + 1)) : 0, rl = tlen - 1 - i;
+			if (hn > 0) { int g = qlen < rl ? qlen : rl; phi = hn + p->a * g; }
+			for (j = 1; j <= qlen; ++j) if (H[j]) { int cl = qlen - 1 - (j - 1), g = cl < rl ? cl : rl, v = H[j] + p->a * g; if (v > phi) phi = v; }
+			tr[2] = (int16_t)phi; tr[3] = (int16_t)max; tr[4] = (int16_t)gscore;
+		}
 	}
 	free(H); free(E);
 	if (qle) *qle = max_j + 1;
@@ -130,4 +142,21 @@ uint64_t oracle_extend_batch(uint32_t n, const uint8_t *q, const uint32_t *qoff,
 	}
 	free(jobs); free(tid);
 	return cells;
+}
+
+/* per-row [beg,end) of every job, rows[i] = rows executed (incl. the row that ends with m == 0); trace = (beg, end, potential bound U after the row, max, gscore) per row, in job order.
+ * Returns the number of int16 entries written (stops recording, not computing, at cap). */
+uint64_t oracle_extend_trace(uint32_t n, const uint8_t *q, const uint32_t *qoff, const uint32_t *qlen,
+                             const uint8_t *t, const uint32_t *toff, const uint32_t *tlen,
+                             const uint32_t *h0, const ksw_params_t *p, uint32_t *rows, int16_t *trace, uint64_t cap)
+{
+	g_trace = trace; g_ntrace = 0; g_trace_cap = cap;
+	for (uint32_t i = 0; i < n; ++i) {
+		uint64_t before = g_ntrace, cells = 0;
+		int qle, tle, gtle, gscore, max_off;
+		oracle_ksw_extend2((int)qlen[i], q + qoff[i], (int)tlen[i], t + toff[i], p, (int)h0[i], &qle, &tle, &gtle, &gscore, &max_off, &cells);
+		rows[i] = (uint32_t)((g_ntrace - before) / 5);
+	}
+	g_trace = 0;
+	return g_ntrace;
 }

@@ -186,6 +186,14 @@ def gpu_extend(B, jobs, zdrop=0, want_raw=True, scoring=None, packed=None):
             prm = B.ExtParams(a_, b_, o_, e_, o_, e_, zdrop, 5)
     B.extend_batch(*d, out, params=prm, raw_t=raw)
     torch.cuda.synchronize()
+    if want_raw:
+        # the production form (three results per job, no raw 6-tuple) may stop a job earlier -- as soon as the local-vs-to-end
+        # rule is decided -- and must return the same three numbers
+        out_b = torch.full((n, 3), -77, dtype=torch.int32, device="cuda")
+        B.extend_batch(*d, out_b, params=prm, raw_t=None)
+        torch.cuda.synchronize()
+        diff = (out_b != out).any(1).nonzero().flatten()[:5].cpu().numpy()
+        assert diff.size == 0, f"three-result form differs from the raw form at {diff}: {out_b.cpu().numpy()[diff]} vs {out.cpu().numpy()[diff]}"
     return out.cpu().numpy(), raw.cpu().numpy() if want_raw else None
 
 
@@ -920,3 +928,30 @@ def test_aligner_writes_reference_sam(hip, tmp_path, golden):
         gl, wl = body.split("\n"), want.split("\n")
         assert False, (len(gl), len(wl), [(a, b) for a, b in zip(gl, wl) if a != b][:2])
     assert buf.getvalue().startswith(bytes(z["sam_header"]).decode())
+
+
+def test_aligner_refuses_flanks_beyond_the_extension_kernels(hip, tmp_path):
+    """Reads of 1000 bp seeded near one end need a query side longer than the 768 bases the DP kernels take: the aligner must
+    raise instead of folding the kernels' INT32_MIN placeholders into regions and SAM (and still aligns 700 bp reads)."""
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.aligner import Aligner
+    g = synth.make_genome(300_000, seed=3)
+    prefix = str(tmp_path / "g.fa")
+    fmindex.write_index(prefix, fmindex.build_fmd_index(g)); fmindex.write_bns(prefix, g)
+    rng = np.random.default_rng(2)
+
+    def reads_of(ln, n):
+        rows = []
+        for _ in range(n):
+            p = int(rng.integers(0, len(g) - ln))
+            x = g[p:p + ln].copy()
+            x[40:ln:23] = (x[40:ln:23] + 1) & 3            # exact only over the first 40 bases: the right flank is ~ln - 40 long
+            rows.append(synth.codes_to_ascii(x))
+        return rows
+    al = Aligner(prefix, n_threads=2)
+    names = [f"r{i}" for i in range(8)]
+    txt = al.align_batch(names, reads_of(700, 8))
+    assert txt.count("\n") >= 8 and "\t0\t" in txt or "\t16\t" in txt
+    with pytest.raises(NotImplementedError, match="768"):
+        al.align_batch(names, reads_of(1000, 8))
+    al.close()

@@ -351,6 +351,16 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t &K, const int zdrop, ui
 	// alone carries it.  Zero cells are lifted out of the maximum by an offset that the non-zero ones carry (NZ * 0x4000).
 	if (bound) {                                                // wave-uniform
 		// max over the pairs of H[p] - a*p, as a Horner-style chain from the last pair down (one constant instead of P)
+#ifdef PK_BOUND_R2      // (A/B builds: round 2's rule, zero cells carry potential too)
+		uint32_t u2 = H[P - 1];
+#pragma unroll
+		for (int p = P - 2; p >= 0; --p) u2 = pk_maxs(H[p], pk_subiK(u2, K.a2));
+		u2 = pk_addi(u2, phi0);
+		int u = max((int)(short)(u2 & 0xFFFFu), (int)u2 >> 16);
+		u = max(u, hnx + K.a * qlen);
+		u = grp_allmax<G>(u);
+		alive = alive && !(u <= S.mx && u < S.gscore);
+#else
 		uint32_t u2 = pk_madK(NZ[P - 1], 0x40004000u, H[P - 1]);
 #pragma unroll
 		for (int p = P - 2; p >= 0; --p) u2 = pk_maxs(pk_madK(NZ[p], 0x40004000u, H[p]), pk_subiK(u2, K.a2));
@@ -361,6 +371,7 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t &K, const int zdrop, ui
 		u = min(u, max(m, hnx) + K.a * rl);
 		const bool fin = u < S.gscore || (o3only && u <= S.mx - end_bonus && S.gscore <= S.mx - end_bonus);
 		alive = alive && !(u <= S.mx && fin);
+#endif
 	}
 	return alive;
 }

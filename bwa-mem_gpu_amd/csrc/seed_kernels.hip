@@ -288,12 +288,12 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 	const int seg_end = lane + __builtin_ctzll(segb >> lane);      // >= lane, bit 63 is always set
 	const unsigned long long above = seg_end > lane ? ((~0ull >> (63 - (seg_end - lane - 1))) << 1 << lane) : 0ull;  // lanes lane+1..seg_end
 	uint32_t size = c.s;
-	unsigned st_iter = 0, st_steps = 0;
+	unsigned st_iter = 0, st_steps = 0, st_uniq = 0, st_u0 = (live && i >= 0 && c.s == 1) ? 1u : 0u, st_x0 = (live && i < 0) ? 1u : 0u;
 	// the read's packed words are re-fetched only when the walk crosses into the next one (16 / 32 bases)
 	uint32_t rw = 0, rm = 0;
 	if (act) { rw = rv.pk[(size_t)(i >> 4) * rv.n_reads + c.read]; rm = rv.nm[(size_t)(i >> 5) * rv.n_reads + c.read]; }
 	while (__any(act)) {
-		if (stats) { ++st_iter; st_steps += act ? 1u : 0u; }
+		if (stats) { ++st_iter; st_steps += act ? 1u : 0u; st_uniq += (act && size == 1) ? 1u : 0u; }
 		if (act) {
 			const int b = (int)((rw >> ((i & 15) << 1)) & 3);
 			const bool isn = (rm >> (i & 31)) & 1;
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 		if (act && am && nsize == size) { act = false; dropped = true; }
 	}
 	if (stats) {
-		atomicAdd(stats + 1, (unsigned long long)st_steps);
+		atomicAdd(stats + 1, (unsigned long long)st_steps); atomicAdd(stats + 4, (unsigned long long)st_uniq); atomicAdd(stats + 5, (unsigned long long)st_u0); atomicAdd(stats + 6, (unsigned long long)st_x0); { const bool nowalk = !__any(live && !st_x0); if (lane == 0 && nowalk) atomicAdd(stats + 7, 1ull); }
 		if (lane == 0) { atomicAdd(stats, (unsigned long long)st_iter); atomicAdd(stats + 2, 1ull); atomicMax(stats + 3, (unsigned long long)st_iter); }
 	}
 	if (live) {
@@ -902,12 +902,14 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 	{
 		static const bool want_stats = getenv("BMH_SEED_STATS") != nullptr;
 		unsigned long long *d_st = want_stats ? (unsigned long long *)w->counter + 8 : nullptr;
-		if (want_stats) HIPCK(hipMemsetAsync(d_st, 0, 32, st));
+		if (want_stats) HIPCK(hipMemsetAsync(d_st, 0, 64, st));
 		if (n_cands) smem_backward_kernel<<<nblk(n_cands, 256), 256, 0, st>>>(f, rv, n_cands, min_seed_len, w->cand_a, w->cand_k, w->svals, w->res_a, w->res_k, d_st);
 		if (want_stats) {
-			unsigned long long h[4];
+			unsigned long long h[8];
 			HIPCK(hipStreamSynchronize(st));
-			HIPCK(hipMemcpy(h, d_st, 32, hipMemcpyDeviceToHost));
+			HIPCK(hipMemcpy(h, d_st, 64, hipMemcpyDeviceToHost));
+			fprintf(stderr, "[backward] lane-steps on a one-row interval %llu (%.1f%%), candidates that start on one %llu (%.1f%%)\n", h[4], 100.0 * h[4] / (h[1] ? h[1] : 1), h[5], 100.0 * h[5] / (n_cands ? n_cands : 1));
+			fprintf(stderr, "[backward] candidates of a pass that starts at read position 0 (no walk) %llu (%.1f%%); waves made of such only %llu\n", h[6], 100.0 * h[6] / (n_cands ? n_cands : 1), h[7]);
 			fprintf(stderr, "[backward] candidates %llu, waves %llu, wave-iterations %llu (%.1f per wave, max %llu), lane-steps %llu (%.1f per candidate): lane utilisation %.1f%%\n",
 			        (unsigned long long)n_cands, h[2], h[0], (double)h[0] / (h[2] ? h[2] : 1), h[3], h[1], (double)h[1] / (n_cands ? n_cands : 1), 100.0 * h[1] / (64.0 * (h[0] ? h[0] : 1)));
 		}

@@ -384,8 +384,10 @@ def test_reference_gase_aln_end_to_end(hip, tmp_path):
         pytest.skip("build/dropin/bwa-gasal2 not built (needs /root/reference at build time)")
     # single-end (configs[0] shape), interleaved paired-end with -p (configs[3] shape), and hard pairs (diverged / relocated /
     # random / chimeric mates) under a non-default option set given to both sides
-    for extra in ([], ["1", "pe"], ["1", "pe_hard", "-k 21 -B 6 -O 8,9 -E 2,3 -T 50 -U 25 -m 20 -M -Y -a"]):
-        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "e2e_dropin.py"), str(tmp_path), "2000000", "4000"] + extra,
+    # (the first run is configs[0] at its stated size: 10 000 reads vs a 4.64 Mbp genome, -t 1)
+    for size, extra in ((["4640000", "10000"], []), (["2000000", "4000"], ["1", "pe"]),
+                        (["2000000", "4000"], ["1", "pe_hard", "-k 21 -B 6 -O 8,9 -E 2,3 -T 50 -U 25 -m 20 -M -Y -a"])):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "e2e_dropin.py"), str(tmp_path)] + size + extra,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         out = r.stdout.decode()
         assert r.returncode == 0 and "E2E DROP-IN OK" in out, out[-3000:]
@@ -955,3 +957,54 @@ def test_aligner_refuses_flanks_beyond_the_extension_kernels(hip, tmp_path):
     with pytest.raises(NotImplementedError, match="768"):
         al.align_batch(names, reads_of(1000, 8))
     al.close()
+
+
+def test_device_job_builder_with_more_than_65535_chains(hip, oracle):
+    """A read whose one SMEM has 66 000 occurrences 460 bp apart (no two of them chain together: the reference windows differ by
+    more than w), with -c / max_occ raised above that: 66 000 chains of one seed each pass mem_chain_flt, more than the 16-bit
+    index of the wave sort's rank keys holds, so the closing pass of the sort runs in its sequential form (chain_core.h).  The
+    batch must still equal the host builder's, byte for byte, and the regions the oracle's."""
+    import ctypes as C, torch
+    from bwamem_hip import fmindex as F, synth, pipeline as P
+    from bwamem_hip.lib import ChainOpt, ChainWorkspace, HostJobs, dev_jobs_to_host, seeds_to_host, load_library
+    B = hip
+    rng = np.random.default_rng(65)
+    unit = rng.integers(0, 4, size=60).astype(np.uint8)
+    n_copies, period = 66_000, 460
+    g = rng.integers(0, 4, size=n_copies * period + 1000).astype(np.uint8)
+    for k in range(n_copies):
+        g[500 + k * period: 500 + k * period + 60] = unit
+        g[500 + k * period - 1] = 0; g[500 + k * period + 60] = 1      # every copy sits between an A and a C ...
+    n = len(g)
+    dev = torch.device("cuda", 0)
+    pac_t = F.pack_pac_device(torch.from_numpy(g).to(dev))
+    d = F.build_fmd_index_device(pac_t, n, sa_intv=1, verify=True)
+    dindex = B.Index.from_device(d.primary, d.L2.astype(np.uint64), d.seq_len, d.bwt_t, 1, d.sa_t, d.bits_t, pac_t=pac_t, l_pac=n)
+    reads = rng.integers(0, 4, size=(4, 150)).astype(np.uint8)
+    reads[1, 40:100] = unit                                   # the seed-rich read ...
+    reads[1, 39] = 3; reads[1, 100] = 2                       # ... between a T and a G: no copy extends the match, the SMEM is the unit itself
+    reads[2] = g[700_000:700_150]                             # ordinary reads around it
+    reads[3] = synth.revcomp(g[900_000:900_150])
+    flat, offs, lens = common.flat_reads(reads)
+    dr = P.reads_to_device(reads, dev)
+    ws = B.SeedWorkspace(4, 600, max_cands=600, max_occ=1 << 20)
+    s = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19)
+    sh = seeds_to_host(s, 4)
+    assert int(sh["n_ref_pos"][1]) >= n_copies
+    opt = ChainOpt(); load_library().bmh_chain_opt_default(C.byref(opt))
+    opt.max_occ = 1 << 20
+    cw = ChainWorkspace(4, int(s.n_seeds) + 64, opt=opt)
+    dj = cw.chain_batch(dindex, dr.ascii, dr.offs, dr.lens, s)
+    got = dev_jobs_to_host(dj, 4)
+    hj = HostJobs(g, flat, offs, lens, sh, n_threads=4, opt=opt)
+    assert int(dj.n_regs) == hj.n_regs and hj.n_regs > 65536 and int(dj.n_jobs) == hj.n_jobs
+    for k in ("qlen", "tlen", "h0", "job_read", "job_reg", "job_side", "regs_per_read", "q", "t"):
+        assert np.array_equal(got[k], getattr(hj, k)), k
+    out3 = torch.zeros(hj.n_jobs + 1, 3, dtype=torch.int32, device=dev)
+    regs = torch.zeros(hj.n_regs + 1, 8, dtype=torch.int32, device=dev)
+    cw.extend(out3); cw.merge(out3, regs)
+    torch.cuda.synchronize()
+    want3, _, _ = oracle.extend_batch(*hj.jobs(), n_threads=4)
+    assert np.array_equal(out3.cpu().numpy()[: hj.n_jobs], want3)
+    assert np.array_equal(regs.cpu().numpy()[: hj.n_regs], hj.merge(want3))
+    hj.free(); cw.free(); ws.free(); dindex.free()

@@ -682,15 +682,27 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
         if m < 0:
             raise RuntimeError("bmh_finalize_regs failed")
         fin = fin[:m]
+        # the same tail on the device (csrc/regs_kernels.hip), on the regions where the merge kernel left them
+        from bwamem_hip.lib import finalize_regs_device
+        d_out = torch.empty(max(n_regs, 1), 16, dtype=torch.int32, device=dev); d_opr = torch.empty(n_reads, dtype=torch.int32, device=dev)
+        ms_dev = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            fd, _o = finalize_regs_device(dindex, co, params, po, dr.ascii, dr.offs, regs_out, n_regs, dj.d_regs_per_read, dj.d_frac_rep, n_reads, contigs=contigs, out_t=d_out, opr_t=d_opr)
+            ms_dev.append(((time.perf_counter() - t0) * 1e3, L.bmh_finalize_regs_device_last_ms()))
+        same = bool(fd.shape[0] == m and torch.equal(fd.cpu(), torch.from_numpy(fin)) and np.array_equal(d_opr.cpu().numpy().view(np.uint32), opr))
         sel = np.nonzero(fin[:, 15])[0].astype(np.int32)
         name, extra = "finalize_regs_host", {"reported": int(len(sel))}
+        dev_row = {"finalize_regs_device": {"ms": round(min(x[0] for x in ms_dev), 3), "kernel_ms": round(min(x[1] for x in ms_dev), 3), "regions_in": int(n_regs), "regions_out": int(fd.shape[0]),
+                                            "identical_to_host_form": same, "what": "mem_sort_dedup_patch + mem_mark_primary_se + mem_approx_mapq_se + the selection of mem_reg2sam on the device "
+                                            "(lane per read, wave per read for reads with more than 8 regions), regions in HBM -> records in HBM"}}
     out_t = torch.from_numpy(fin.copy()).to(dev); sel_t = torch.from_numpy(sel).to(dev)
     ms = []
     for _ in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         cg, aln, md = cigar_batch(dindex, dr.ascii, dr.offs, dr.lens, out_t, len(sel), sel_t=sel_t, params=params, max_cigar=24, md_cap=128)
         torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
-    return {name: dict({"ms": round(t_fin * 1e3, 2), "threads": nth, "regions_in": int(n_regs), "regions_out": int(m), "d2h_regions_ms": round(t_d2h * 1e3, 2)}, **extra),
+    return {**(dev_row if not paired else {}), name: dict({"ms": round(t_fin * 1e3, 2), "threads": nth, "regions_in": int(n_regs), "regions_out": int(m), "d2h_regions_ms": round(t_d2h * 1e3, 2)}, **extra),
             "cigar_batch_device": {"ms": round(min(ms), 3), "alignments": int(len(sel)), "M_alignments_per_s": round(len(sel) / (min(ms) * 1e-3) / 1e6, 1),
                                    "flagged": int((aln[:, 7].cpu().numpy() & ~2 != 0).sum())}}
 

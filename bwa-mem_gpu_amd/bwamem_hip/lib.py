@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "bmh_last_error", "bmh_device_count", "bmh_set_device", "bmh_index_upload", "bmh_index_from_device",
     "bmh_index_free", "bmh_index_replicate", "bmh_shard_range", "bmh_index_densify_sa", "bmh_index_build", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
     "bmh_extend_batch", "bmh_extend_last_ms", "bmh_extend_last_unsupported", "bmh_extend_set_packed", "bmh_extend_release", "bmh_calib_gather", "bmh_calib_valu",
-    "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
+    "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_finalize_regs_device", "bmh_finalize_regs_device_last_ms", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
     "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
     "bmh_chain_opt_default", "bmh_chain_last_timing", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
     "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_materialize", "bmh_chain_batch",
@@ -154,6 +154,10 @@ def load_library() -> C.CDLL:
     L.bmh_finalize_regs.restype = C.c_int64
     L.bmh_finalize_regs.argtypes = [C.POINTER(ChainOpt), C.POINTER(ExtParams), C.POINTER(PostOpt), C.c_int64, _u8p, C.c_uint32, _u8p, _u64p,
                                     _i32p, _u32p, C.POINTER(C.c_float), C.c_int, C.c_void_p, _i32p, _u32p, C.c_int]
+    L.bmh_finalize_regs_device.restype = C.c_int64
+    L.bmh_finalize_regs_device.argtypes = [C.c_void_p, C.POINTER(ChainOpt), C.POINTER(ExtParams), C.POINTER(PostOpt), C.c_void_p, C.c_void_p, C.c_uint32,
+                                           C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bmh_finalize_regs_device_last_ms.restype = C.c_float
     L.bmh_sam_need_cigar.restype = C.c_int64
     L.bmh_sam_need_cigar.argtypes = [C.POINTER(PostOpt), _i32p, _u32p, C.c_uint32, _u8p]
     L.bmh_format_sam.restype = C.c_void_p
@@ -385,6 +389,26 @@ def cigar_batch(index: Index, reads_t, offs_t, lens_t, regs_t, n: int, sel_t=Non
     if rc != 0:
         raise RuntimeError(f"bmh_cigar_batch rc={rc}: " + _err(L))
     return cigar, aln, md
+
+
+def finalize_regs_device(index: "Index", copt, ep, po, reads_t, offs_t, regs_t, n_regs: int, regs_per_read_ptr: int, frac_rep_ptr: int, n_reads: int,
+                         contigs=None, out_t=None, opr_t=None, stream: int = 0):
+    """bmh_finalize_regs_device on torch CUDA tensors / device pointers (regs_per_read_ptr, frac_rep_ptr: bmh_dev_jobs_t.d_regs_per_read /
+    d_frac_rep).  Returns (out int32 [m, 16] view, out_per_read int32 [n_reads]) on the device."""
+    import torch
+    L = load_library()
+    dev = regs_t.device
+    if out_t is None:
+        out_t = torch.empty(max(n_regs, 1), 16, dtype=torch.int32, device=dev)
+    if opr_t is None:
+        opr_t = torch.empty(max(n_reads, 1), dtype=torch.int32, device=dev)
+    off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([c[1] for c in contigs])[:-1]]), dtype=np.int64) if contigs and len(contigs) > 1 else None
+    m = L.bmh_finalize_regs_device(index.handle, C.byref(copt), C.byref(ep), C.byref(po), reads_t.data_ptr(), offs_t.data_ptr(), n_reads,
+                                   regs_t.data_ptr(), n_regs, regs_per_read_ptr, frac_rep_ptr, len(contigs) if off is not None else 1,
+                                   off.ctypes.data_as(C.c_void_p) if off is not None else None, out_t.data_ptr(), opr_t.data_ptr(), stream)
+    if m < 0:
+        raise RuntimeError(f"bmh_finalize_regs_device rc={m}: " + _err(L))
+    return out_t[:m], opr_t
 
 
 def finalize_pairs(copt, ep, po, genome_len: int, pac: np.ndarray, reads_flat: np.ndarray, read_offs: np.ndarray, read_lens: np.ndarray,

@@ -7,7 +7,9 @@
 //   mem_reg2sam            :1721-1770 which regions become SAM records, supplementary flag, MAPQ cap
 // Global alignment score for the patch test: ksw_global2 without traceback under bwa_gen_cigar2's band (src/bwa.c:111-216).
 // Sorting goes through klib_sort.h so that ties fall as in the reference.
+#include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +20,9 @@
 #include "regs_post.h"
 
 namespace rp {
+
+// BMH_POST_STATS: how often the patch test reaches its global alignment, and how large those are
+static std::atomic<unsigned long long> g_st_patch_calls{0}, g_st_dp_calls{0}, g_st_dp_cells{0}, g_st_pairs{0}, g_st_reads_dp{0};
 
 int text_base(const uint8_t *pac, int64_t l_pac, int64_t i)
 {
@@ -70,6 +75,7 @@ static int gen_score(const bmh_ext_params_t &p, int w_, int64_t l_pac, const uin
 	int w = (max_gap + diff + 1) >> 1;
 	w = w < w_ ? w : w_;
 	w = w > diff + 3 ? w : diff + 3;
+	g_st_dp_calls++; g_st_dp_cells += (unsigned long long)rlen * (unsigned long long)((2 * w + 1) < l_query ? 2 * w + 1 : l_query);
 	return global_score(p, l_query, qs.data(), rlen, rs.data(), w);
 }
 
@@ -102,6 +108,7 @@ static int patch_reg(const Ctx &x, const uint8_t *query, const Reg &a, const Reg
 	else if (w > x.co->w << 2 || r >= 0.05f * 2) return 0;
 	w += a.w + b.w;
 	w = w < x.co->w << 2 ? w : x.co->w << 2;
+	g_st_patch_calls++;
 	const int score = gen_score(*x.ep, w, x.l_pac, x.pac, b.qe - a.qb, query + a.qb, a.rb, b.re);
 	const int q_s = (int)((double)(b.qe - a.qb) / ((b.qe - b.qb) + (a.qe - a.qb)) * (b.score + a.score) + .499);
 	const int r_s = (int)((double)(b.re - a.rb) / ((b.re - b.rb) + (a.re - a.rb)) * (b.score + a.score) + .499);
@@ -291,6 +298,9 @@ extern "C" int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_
 		for (int t = 0; t < n_threads; ++t) th.emplace_back(work, (uint32_t)((uint64_t)n_reads * t / n_threads), (uint32_t)((uint64_t)n_reads * (t + 1) / n_threads));
 		for (auto &t : th) t.join();
 	}
+	if (getenv("BMH_POST_STATS"))
+		fprintf(stderr, "[finalize] %u reads: patch tests that reach the alignment %llu, of them with a DP %llu (%.1f cells each)\n", n_reads,
+		        (unsigned long long)g_st_patch_calls.exchange(0), (unsigned long long)g_st_dp_calls.load(), (double)g_st_dp_cells.exchange(0) / (double)(g_st_dp_calls.load() ? g_st_dp_calls.load() : 1)), g_st_dp_calls = 0;
 	// compact to the front (every read wrote at its input offset)
 	uint64_t w = 0;
 	for (uint32_t r = 0; r < n_reads; ++r) {

@@ -260,6 +260,18 @@ int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *e
                           int n_contigs, const int64_t *contig_offset,
                           int32_t *out, uint32_t *out_per_read, int n_threads);
 
+/* The same tail ON THE DEVICE (csrc/regs_kernels.hip; reads -> reportable alignments without leaving HBM): every pointer except
+ * contig_offset is device memory.  d_regs[n_regs][8], d_regs_per_read, d_frac_rep: what bmh_chain_merge / bmh_chain_extend_merge
+ * left (bmh_dev_jobs_t); d_reads / d_offs: the batch's ASCII reads; the index must carry the 2-bit reference.  d_out[n_regs][16]:
+ * the records of bmh_finalize_regs, in the same order; d_out_per_read[n_reads].  Returns their number or a negative BMH_E* code;
+ * waits for the stream.  Same results as bmh_finalize_regs, record for record (the logarithms of the MAPQ formula come from a
+ * table computed by the host's libm).  Interleaved pairs still go through bmh_finalize_pairs. */
+int64_t bmh_finalize_regs_device(const bmh_index_t *idx, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt,
+                                 const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
+                                 const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read, const float *d_frac_rep,
+                                 int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream);
+float bmh_finalize_regs_device_last_ms(void);       /* device time of the thread's last bmh_finalize_regs_device (HIP events) */
+
 /* SAM records of single-end reads (mem_aln2sam, src/bwamem.c:1506-1683; XA tag: mem_gen_alt, src/bwamem_extra.c:97-150).
  * bmh_sam_need_cigar marks (need[i] = 1) the records of bmh_finalize_regs that must go through bmh_cigar_batch first --
  * the reported ones and the XA candidates -- and returns their number.  bmh_format_sam then takes, per record, its slot

@@ -805,7 +805,7 @@ def test_cigar_batch_matches_reference_sam(hip, oracle):
 @pytest.mark.parametrize("golden", ["post_golden.npz", "contigs_golden.npz"])
 def test_reads_to_sam_text_matches_reference(hip, oracle, golden):
     """The whole chain on the repeat-rich golden read sets (one sequence / three sequences with reads across the cuts): device seeding -> device chaining / jobs -> device extension
-    -> device merge -> bmh_finalize_regs (host, like the reference) -> bmh_cigar_batch (device) reproduces every SAM record
+    -> device merge -> bmh_finalize_regs (host, like the reference) and bmh_finalize_regs_device (the same on the device) -> bmh_cigar_batch (device) reproduces every SAM record
     the reference's own host code wrote (flag, POS, MAPQ, CIGAR, NM, AS, XS, MD), default run and -a."""
     import ast, ctypes as C, torch
     from bwamem_hip import fmindex, synth
@@ -849,8 +849,12 @@ def test_reads_to_sam_text_matches_reference(hip, oracle, golden):
                                  _np_ptr(out, _i32p), _np_ptr(opr, _u32p), 2)
         assert m >= 0
         out = out[:m]
+        # the same tail on the device, from the regions where the merge kernel left them: record for record the host's
+        from bwamem_hip.lib import finalize_regs_device
+        d_out, d_opr = finalize_regs_device(dindex, co, ep, po, r, o, regs, nr, dj.d_regs_per_read, dj.d_frac_rep, n, contigs=contigs)
+        assert np.array_equal(d_opr.cpu().numpy().view(np.uint32)[:n], opr) and np.array_equal(d_out.cpu().numpy(), out)
         sel = np.nonzero(out[:, 15])[0].astype(np.int32)
-        cigar, aln, md = cigar_batch(dindex, r, o, l, torch.from_numpy(out.copy()).cuda(), len(sel), sel_t=torch.from_numpy(sel).cuda(),
+        cigar, aln, md = cigar_batch(dindex, r, o, l, d_out.contiguous(), len(sel), sel_t=torch.from_numpy(sel).cuda(),
                                      max_cigar=48, md_cap=640)
         torch.cuda.synchronize()
         cigar = cigar.cpu().numpy().view(np.uint32); aln = aln.cpu().numpy(); md = md.cpu().numpy()
@@ -874,17 +878,12 @@ def test_reads_to_sam_text_matches_reference(hip, oracle, golden):
         assert len(got) == len(want), (tag, len(got), len(want))
         bad = [(a, b) for a, b in zip(got, want) if a != b]
         assert not bad, (tag, len(bad), bad[:3])
-    # ... and the SAM text itself, byte for byte (default run): host finalize -> device CIGAR of every record the formatter
-    # needs (reported ones and XA candidates) -> bmh_format_sam
+    # ... and the SAM text itself, byte for byte (default run): DEVICE finalize -> device CIGAR of every record the formatter
+    # needs (reported ones and XA candidates) -> bmh_format_sam: nothing between the reads and the records leaves HBM
     from bwamem_hip.lib import format_sam
     po = PostOpt(); Lb.bmh_post_opt_default(C.byref(po))
-    out = np.zeros((max(nr, 1), 16), np.int32); opr = np.zeros(n, np.uint32)
-    fr = np.ascontiguousarray(dh["frac_rep"], dtype=np.float32)
-    m = Lb.bmh_finalize_regs(C.byref(co), C.byref(ep), C.byref(po), len(g), _np_ptr(pac, _u8p), n, _np_ptr(flat, _u8p),
-                             _np_ptr(np.arange(n, dtype=np.uint64) * L, _u64p), _np_ptr(np.ascontiguousarray(regs_h), _i32p),
-                             _np_ptr(np.ascontiguousarray(dh["regs_per_read"]), _u32p), fr.ctypes.data_as(C.POINTER(C.c_float)),
-                             len(contigs), c_off.ctypes.data_as(C.c_void_p), _np_ptr(out, _i32p), _np_ptr(opr, _u32p), 2)
-    out = np.ascontiguousarray(out[:m])
+    d_out, d_opr = finalize_regs_device(dindex, co, ep, po, r, o, regs, nr, dj.d_regs_per_read, dj.d_frac_rep, n, contigs=contigs)
+    out = np.ascontiguousarray(d_out.cpu().numpy()); opr = np.ascontiguousarray(d_opr.cpu().numpy().view(np.uint32)[:n]); m = len(out)
     need = np.zeros(max(m, 1), np.uint8)
     k = Lb.bmh_sam_need_cigar(C.byref(po), _np_ptr(out, _i32p), _np_ptr(opr, _u32p), n, _np_ptr(need, _u8p))
     sel = np.nonzero(need[:m])[0].astype(np.int32)
@@ -1008,3 +1007,86 @@ def test_device_job_builder_with_more_than_65535_chains(hip, oracle):
     assert np.array_equal(out3.cpu().numpy()[: hj.n_jobs], want3)
     assert np.array_equal(regs.cpu().numpy()[: hj.n_regs], hj.merge(want3))
     hj.free(); cw.free(); ws.free(); dindex.free()
+
+
+def test_region_tail_on_the_device_equals_the_host_form(hip, oracle):
+    """bmh_finalize_regs_device (lane per read; wave per read with the regions in LDS; in HBM beyond 512 regions) vs bmh_finalize_regs
+    on the regions of the device pipeline: plain reads, a repeat-rich genome (reads with hundreds of regions), reads with a long
+    deletion (two colinear regions merged through the patch test's global alignment), -a / another -T, three sequences, and a read
+    with more regions than the wave kernel keeps in LDS."""
+    import ctypes as C, torch
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.lib import ChainOpt, ChainWorkspace, PostOpt, dev_jobs_to_host, finalize_regs_device, load_library, _np_ptr, _u8p, _u64p, _i32p, _u32p
+    B = hip
+    Lb = load_library()
+    rng = np.random.default_rng(12)
+
+    def run(g, reads, contigs=None, po_over=None, co_over=None, want_wave=0, want_big=0):
+        idx = fmindex.build_fmd_index(g)
+        n, L = reads.shape
+        flat = np.ascontiguousarray(reads.reshape(-1))
+        pac = _pack_pac(g)
+        dindex = B.Index.upload(idx, pac=pac, l_pac=len(g))
+        ws = B.SeedWorkspace(n, n * L, max_cands=n * L, max_occ=1 << 22)
+        r = _to_dev(torch, synth.codes_to_ascii(flat))
+        o = (torch.arange(n, dtype=torch.int64) * L).to(torch.int32).cuda()
+        l = torch.full((n,), L, dtype=torch.int32).cuda()
+        s = ws.seed_batch(dindex, r, o, l, 19)
+        co = ChainOpt(); Lb.bmh_chain_opt_default(C.byref(co))
+        for k, v in (co_over or {}).items():
+            setattr(co, k, v)
+        cw = ChainWorkspace(n, max(int(s.n_seeds), 1), opt=co); cw.set_materialize(False)
+        if contigs:
+            cw.set_contigs(contigs)
+        dj = cw.chain_batch(dindex, r, o, l, s)
+        nr = int(dj.n_regs)
+        regs = torch.zeros(nr + 1, 8, dtype=torch.int32, device="cuda")
+        dj = cw.extend_merge(dindex, r, o, l, s, regs)
+        torch.cuda.synchronize()
+        dh = dev_jobs_to_host(dj, n)
+        assert (dh["regs_per_read"] > 8).sum() >= want_wave and (dh["regs_per_read"] > 512).sum() >= want_big
+        ep = B.ExtParams.default()
+        po = PostOpt(); Lb.bmh_post_opt_default(C.byref(po)); po.id0 = 1234567
+        for k, v in (po_over or {}).items():
+            setattr(po, k, v)
+        ctg = contigs or [("chrS", len(g))]
+        c_off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([c[1] for c in ctg])[:-1]]), dtype=np.int64)
+        out = np.zeros((max(nr, 1), 16), np.int32); opr = np.zeros(n, np.uint32)
+        fr = np.ascontiguousarray(dh["frac_rep"], dtype=np.float32)
+        m = Lb.bmh_finalize_regs(C.byref(co), C.byref(ep), C.byref(po), len(g), _np_ptr(pac, _u8p), n, _np_ptr(flat, _u8p),
+                                 _np_ptr(np.arange(n, dtype=np.uint64) * L, _u64p), _np_ptr(np.ascontiguousarray(regs.cpu().numpy()[:nr]), _i32p),
+                                 _np_ptr(np.ascontiguousarray(dh["regs_per_read"]), _u32p), fr.ctypes.data_as(C.POINTER(C.c_float)),
+                                 len(ctg), c_off.ctypes.data_as(C.c_void_p), _np_ptr(out, _i32p), _np_ptr(opr, _u32p), 4)
+        assert m >= 0
+        d_out, d_opr = finalize_regs_device(dindex, co, ep, po, r, o, regs, nr, dj.d_regs_per_read, dj.d_frac_rep, n, contigs=contigs)
+        assert np.array_equal(d_opr.cpu().numpy().view(np.uint32)[:n], opr)
+        got = d_out.cpu().numpy()
+        assert got.shape == (m, 16) and np.array_equal(got, out[:m]), np.nonzero((got != out[:m]).any(1))[0][:5]
+        cw.free(); ws.free(); dindex.free()
+        return m, nr
+
+    g = synth.make_genome(1_200_000, seed=3)
+    reads, _ = synth.make_reads(g, 3000, 150, seed=9, sub_rate=0.02, indel_frac=0.3)
+    for i in range(0, 500):                                  # a long deletion in the middle: two colinear regions -> the patch test
+        p0 = int(rng.integers(0, len(g) - 400)); d = int(rng.integers(12, 60))
+        x = np.concatenate([g[p0:p0 + 75], g[p0 + 75 + d:p0 + 150 + d]])
+        reads[i] = x if i & 1 else synth.revcomp(x)
+    m, nr = run(g, reads)
+    assert m < nr - 100                                      # regions were merged
+    run(g, reads, po_over=dict(flag_all=1, T=20))
+    cuts = [0, 300_000, 700_000, len(g)]
+    run(g, reads, contigs=[("c%d" % i, cuts[i + 1] - cuts[i]) for i in range(3)])
+    gr = synth.make_genome(600_000, seed=9, repeat_frac=0.6, repeat_len=(200, 800), repeat_copies=(50, 400), repeat_div=0.02)
+    readsr, _ = synth.make_reads(gr, 2000, 150, seed=8, sub_rate=0.01)
+    run(gr, readsr, want_wave=50)
+    run(gr, readsr, po_over=dict(flag_all=1), co_over=dict(max_occ=50, mask_level=0.3), want_wave=50)
+    # 900 copies of a 60 bp unit, 460 bp apart, between an A and a C; the read carries it between a T and a G: one SMEM, 900 chains
+    unit = rng.integers(0, 4, size=60).astype(np.uint8)
+    gb = rng.integers(0, 4, size=900 * 460 + 1000).astype(np.uint8)
+    for k in range(900):
+        gb[500 + k * 460: 560 + k * 460] = unit; gb[499 + k * 460] = 0; gb[560 + k * 460] = 1
+    rb = rng.integers(0, 4, size=(64, 150)).astype(np.uint8)
+    for i in range(0, 64, 7):
+        rb[i, 40:100] = unit; rb[i, 39] = 3; rb[i, 100] = 2
+        rb[i, 50 + i % 40] = (rb[i, 50 + i % 40] + 1) & 3 if i % 14 == 0 else rb[i, 50 + i % 40]
+    run(gb, rb, co_over=dict(max_occ=2000), want_big=3)

@@ -265,6 +265,17 @@ class Aligner:
             cw.extend(out3, params=ext_p)
             cw.merge(out3, regs)
             _lap("extend+merge")
+            if not paired:
+                # single-end: the region tail runs on the device too (bmh_finalize_regs_device); what comes back over PCIe are the records
+                po = PostOpt.from_buffer_copy(self.po); po.id0 = id0
+                from .lib import finalize_regs_device
+                d_fin, d_opr = finalize_regs_device(self.index, self.copt, self.ep, po, r, o, regs, nr, dj.d_regs_per_read, dj.d_frac_rep, n,
+                                                    contigs=self.contigs if len(self.contigs) > 1 else None)
+                _lap("finalize (device)")
+                fin = np.ascontiguousarray(d_fin.cpu().numpy()); opr = np.ascontiguousarray(d_opr.cpu().numpy().view(np.uint32)[:n]); m = len(fin)
+                _lap("D2H records")
+                self._lap = _lap; self._prof = (_t, _nm)
+                return self._finish_single(names, codes, offs, lens, r, o, l, fin, opr, m, po, cw, ws, _lap, _t, _nm, as_bytes, fin_t=d_fin)
             rpr = torch.empty(n, dtype=torch.int32, device=dev); fr = torch.empty(n, dtype=torch.float32, device=dev)
             _memcpy_d2d(rpr.data_ptr(), dj.d_regs_per_read, 4 * n); _memcpy_d2d(fr.data_ptr(), dj.d_frac_rep, 4 * n)
             regs_h = np.ascontiguousarray(regs[:nr].cpu().numpy())
@@ -282,11 +293,16 @@ class Aligner:
             raise RuntimeError("bmh_finalize_regs: " + (L.bmh_last_error() or b"").decode())
         fin = np.ascontiguousarray(fin[:m])
         _lap("finalize (host)")
+        return self._finish_single(names, codes, offs, lens, r, o, l, fin, opr, m, po, cw, ws, _lap, _t, _nm, as_bytes)
+
+    def _finish_single(self, names, codes, offs, lens, r, o, l, fin, opr, m, po, cw, ws, _lap, _t, _nm, as_bytes, fin_t=None):
+        """records of the region tail -> CIGARs of the ones the formatter needs (device) -> SAM text (host)"""
+        L, n = self.L, len(lens)
         need = np.zeros(max(m, 1), np.uint8)
         L.bmh_sam_need_cigar(C.byref(po), _np_ptr(fin, _i32p), _np_ptr(opr, _u32p), n, _np_ptr(need, _u8p))
         sel = np.nonzero(need[:m])[0].astype(np.int32)
         slot = np.full(max(m, 1), -1, np.int64); slot[sel] = np.arange(len(sel))
-        aln_h, cg_h, md_h = self._cigars(r, o, l, fin, sel)
+        aln_h, cg_h, md_h = self._cigars(r, o, l, fin, sel, fin_t=fin_t)
         _lap("cigar + D2H")
         txt = format_sam(po, names, codes, offs, lens, self.contigs, fin if m else np.zeros((1, 16), np.int32), opr, slot, aln_h, cg_h, md_h,
                          as_bytes=as_bytes)
@@ -299,14 +315,15 @@ class Aligner:
             sys.stderr.write("[aligner] " + ", ".join("%s %.1f ms" % (nm, (_t[i + 1] - _t[i]) * 1e3) for i, nm in enumerate(_nm)) + "\n")
         return txt
 
-    def _cigars(self, r, o, l, fin, sel):
+    def _cigars(self, r, o, l, fin, sel, fin_t=None):
         """bmh_cigar_batch for the selected records with compact buffers; the few records that overflow them (flag 1: more
         ops, flag 8: longer MD) are redone with large ones and patched in"""
         dev = self.dev
         max_cigar, md_cap = 64, 1024
         if not len(sel):
             return np.zeros((1, 8), np.int32), np.zeros((1, max_cigar), np.uint32), np.zeros((1, md_cap), np.uint8)
-        fin_t = torch.from_numpy(fin.copy()).to(dev)
+        if fin_t is None or not len(fin_t):
+            fin_t = torch.from_numpy(fin.copy()).to(dev)
         cg, aln, md = cigar_batch(self.index, r, o, l, fin_t, len(sel), sel_t=torch.from_numpy(sel).to(dev), params=self.ep, opt_w=self.copt.w,
                                   max_cigar=16, md_cap=96)
         aln_h = aln.cpu().numpy()

@@ -42,6 +42,7 @@ from bwamem_hip.parallel import broadcast_built_index, shard_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz: a wave64 instruction issues in 2 cycles (MI355X_MICROARCH.md)
+CACHE_VERSION = "v3"          # bump when synth.make_genome_device or the index layout changes
 PROFILE_TAG = "r03"          # profiles/<tag>_pmc*.json: counters collected by scripts/profile_round.sh with this same command (one file per workload)
 
 
@@ -50,7 +51,7 @@ def profile_counters(workload_key: str):
     scripts/summarize_profiles.py from separate --pmc runs of this command).  They are NOT measured by this run: every
     field taken from them is labelled from_profile and dropped when the profile's workload differs from this run's."""
     import glob
-    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc*.json"))):
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "*_pmc.json"))):
         try:
             d = json.load(open(fn))
         except Exception:
@@ -173,7 +174,10 @@ def main():
     ap.add_argument("--cpu-sample-1t", type=int, default=int(os.environ.get("BENCH_CPU_SAMPLE_1T", "3000")), help="reads of the one-thread CPU legs")
     ap.add_argument("--verify-sample", type=int, default=int(os.environ.get("BENCH_VERIFY_SAMPLE", "-1")), help="reads of the last timed batch whose GPU seeds and regions are "
                     "compared with the oracle after the timed loops (-1: the CPU sample at N = 1, 10000 per rank at N > 1; 0: off)")
+    ap.add_argument("--print-cache-dir", action="store_true", help="print the --index-cache directory this command would use and exit (for the profile scripts)")
     a = ap.parse_args()
+    if a.print_cache_dir:
+        print(os.path.join(a.index_cache, f"g{a.genome_mbp:g}_sa{a.sa_intv}_seed42_{CACHE_VERSION}") if a.index_cache else ""); return
 
     if a.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (torch.distributed.run) BEFORE this
@@ -207,7 +211,9 @@ def main():
     n_genome = int(a.genome_mbp * 1e6)
     t_gen = t_index = 0.0
     d = pac_t = meta = None
-    cache = a.index_cache and os.path.join(a.index_cache, f"g{a.genome_mbp:g}_sa{a.sa_intv}_seed42")
+    # (the key names the genome generator + index layout version: a cache written by another build of either is not picked up)
+    cache = a.index_cache and os.path.join(a.index_cache, f"g{a.genome_mbp:g}_sa{a.sa_intv}_seed42_{CACHE_VERSION}")
+
     if rank == 0 and cache and os.path.exists(os.path.join(cache, "meta.json")):
         # setup shortcut for repeated runs on one box (the profile passes): the SAME genome + index, written by an earlier run of this command
         t0 = time.time()

@@ -18,6 +18,9 @@
 #include <vector>
 #include "bmh_internal.h"
 #include "klib_sort.h"
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include "local_sw.h"
 #include "regs_post.h"
 
@@ -135,8 +138,12 @@ bool fetch_window(const PCtx &c, int64_t *beg, int64_t mid, int64_t *end, int *r
 	return true;
 }
 
+// BMH_POST_STATS: how much local alignment the mate rescue does
+static std::atomic<unsigned long long> g_ms_calls{0}, g_ms_sw{0}, g_ms_cells{0}, g_ms_hits{0};
+
 int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector<Reg> &ma)        // mem_matesw
 {
+	g_ms_calls++;
 	const int64_t l_pac = c.x.l_pac;
 	int skip[4], n = 0;
 	for (int r = 0; r < 4; ++r) skip[r] = c.pes[r].failed ? 1 : 0;
@@ -173,6 +180,7 @@ int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector
 			const int xtra = BMH_SW_XSUBO | BMH_SW_XSTART | (l_ms * c.x.ep->a < 250 ? BMH_SW_XBYTE : 0) | (c.x.co->min_seed_len * c.x.ep->a);
 			seqbuf.assign(seq, seq + l_ms);
 			const bmh_sw_result_t aln = bmh_local_sw(l_ms, seqbuf.data(), (int)(re - rb), ref.data(), *c.x.ep, xtra);
+			g_ms_sw++; g_ms_cells += (unsigned long long)l_ms * (unsigned long long)(re - rb);
 			if (aln.score >= c.x.co->min_seed_len && aln.qb >= 0) {
 				Reg b; memset(&b, 0, sizeof(b));
 				b.rid = a.rid; b.is_alt = a.is_alt;
@@ -183,6 +191,7 @@ int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector
 				b.score = aln.score; b.csub = aln.score2; b.secondary = -1;
 				b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
 				size_t i;
+				g_ms_hits++;
 				for (i = 0; i < ma.size(); ++i) if (ma[i].score < b.score) break;     // keep ma sorted by score
 				ma.insert(ma.begin() + (long)i, b);
 			}
@@ -461,5 +470,9 @@ extern "C" int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext
 			for (size_t k = 0; k < P.n.size(); ++k, ++r) { out_per_read[r] = P.n[k]; out_h[r] = P.h[k]; out_unflag[r] = P.uf[k]; }
 		}
 	}, (uint32_t)parts.size());
+	if (getenv("BMH_POST_STATS"))
+		fprintf(stderr, "[finalize_pairs] %u reads: mem_matesw calls %llu, local alignments %llu (%.0f cells each), rescued regions %llu\n", n_reads,
+		        (unsigned long long)g_ms_calls.exchange(0), (unsigned long long)g_ms_sw.load(), (double)g_ms_cells.exchange(0) / (double)(g_ms_sw.load() ? g_ms_sw.load() : 1),
+		        (unsigned long long)g_ms_hits.exchange(0)), g_ms_sw = 0;
 	return (int64_t)w_off[parts.size()];
 }

@@ -4,7 +4,8 @@ MIN=${1:-0.05}; shift
 R=$GRAFT_REPO_ROOT; cd $R
 export BENCH_INDEX_CACHE=${BENCH_INDEX_CACHE:-/tmp/bmh_cache}
 A="--cpu-sample 0 --no-next-rows --no-pcie --inflight 1 $*"
-[ -f $BENCH_INDEX_CACHE/*/meta.json ] || python bench.py $A --steps 1 --warmup 0 > /dev/null 2>&1
+# (the exact cache directory of THIS command: genome size, sample interval and generator version are in its name)
+[ -f "$(python bench.py $A --print-cache-dir)/meta.json" ] || python bench.py $A --steps 1 --warmup 0 > /dev/null 2>&1
 D=$R/gpurun_out/bt; rm -rf $D; mkdir -p $D
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $D -- python3 $R/bench.py --steps 2 --warmup 1 $A > $D/bench.json 2> $D/err.log || { tail -5 $D/err.log; exit 1; }

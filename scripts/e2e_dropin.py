@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from bwamem_hip import fmindex, synth
 
-exe = os.path.join(ROOT, "build", "dropin", "bwa-gasal2")
+exe = os.path.join(ROOT, "build", "dropin", os.environ.get("E2E_EXE", "bwa-gasal2"))      # E2E_EXE=bwa-gasal2-seqidx: the build with the reference's four batch-relative seq[] indices corrected (scripts/build_dropin.sh)
 if not os.path.exists(exe):
     sys.exit("build/dropin/bwa-gasal2 missing: run scripts/build_dropin.sh in the build container")
 work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/e2e_dropin"
@@ -70,6 +70,12 @@ else:
         for i in range(3, n_reads, 12):                      # chimeric reads
             k = int(rng.integers(50, 100)); p1 = int(rng.integers(0, n_genome - L)); b = g[p1:p1 + L - k].copy()
             reads[i][k:] = synth.revcomp(b) if rng.random() < 0.5 else b
+    if os.environ.get("E2E_LONGDEL"):         # every E2E_LONGDEL-th read spans a 12..60 bp deletion: two colinear regions -> mem_patch_reg's global alignment
+        rng = np.random.default_rng(10)
+        for i in range(1, n_reads, int(os.environ["E2E_LONGDEL"])):
+            p0 = int(rng.integers(0, n_genome - RL - 80)); d = int(rng.integers(12, 60)); h = RL // 2
+            x = np.concatenate([g[p0:p0 + h], g[p0 + h + d:p0 + RL + d]])
+            reads[i] = x if rng.random() < 0.5 else synth.revcomp(x)
     if os.environ.get("E2E_RAGGED"):          # reads cut to lengths between E2E_RAGGED_MIN (20; the reference itself aborts on some very short reads: ks_resize of 0 bytes) and the full length, hard mode only
         assert hard
         asc = synth.codes_to_ascii(reads); lens_r = np.random.default_rng(9).integers(int(os.environ.get("E2E_RAGGED_MIN", "20")), RL + 1, size=n_reads)

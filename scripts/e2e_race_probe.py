@@ -2,7 +2,7 @@
 report run-to-run differences plus the shim's result check (BMH_GASAL_CHECK)."""
 import sys, os, subprocess
 work = sys.argv[1]; threads = sys.argv[2]; n = int(sys.argv[3])
-exe = os.path.abspath("build/dropin/bwa-gasal2")
+exe = os.path.abspath(os.path.join("build", "dropin", os.environ.get("E2E_EXE", "bwa-gasal2")))      # E2E_EXE=bwa-gasal2-seqidx: scripts/build_dropin.sh
 prefix = os.path.join(work, "g.fa"); fq = os.path.join(work, "reads.fa")
 env = dict(os.environ, BMH_GASAL_CHECK="1")
 env.update({k: v for k, v in (a.split("=", 1) for a in sys.argv[4:] if "=" in a)})

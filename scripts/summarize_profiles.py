@@ -12,7 +12,7 @@ import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OURS = ("pack_reads", "smem_", "cand_", "per_read_counts", "expand_kernel", "locate_kernel", "extend16", "extend_wide", "ext_", "calib_",
-        "chain_", "emit_kernel", "materialize_kernel", "merge_kernel", "merge2_kernel", "split_counts", "extpk", "reblock", "densify")
+        "chain_", "emit_kernel", "materialize_kernel", "merge_kernel", "merge2_kernel", "split_counts", "extpk", "reblock", "densify", "fin_")
 # kernel family -> (substrings, which `passes` counter of the bench line divides its sums)
 FAMILIES = {
     "forward": (("smem_forward_kernel",), "seed"),

@@ -392,6 +392,21 @@ def test_reference_gase_aln_end_to_end(hip, tmp_path):
         out = r.stdout.decode()
         assert r.returncode == 0 and "E2E DROP-IN OK" in out, out[-3000:]
         assert "SAM IDENTICAL" in out, out[-3000:]           # bwamem_hip.aligner wrote the reference's records byte for byte
+    # the reference's real mode: -t 8, every kt_for worker with its own 2 x 2 gasal_gpu_storage_t (src/kthread.c:158-161).  On the clean
+    # read set its output is deterministic and equals ours ...
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "e2e_dropin.py"), str(tmp_path), "2000000", "4000", "8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "SAM IDENTICAL" in out, out[-3000:]
+    # ... and on a hard set (4 % substitutions, indels, chimeric reads, every 7th read across a 12-60 bp deletion) it does so once the four
+    # batch-relative seq[] indices of mem_align1_core (src/bwamem.c:2228, 2251, 2295, 2313) are made absolute -- the build
+    # bwa-gasal2-seqidx of scripts/build_dropin.sh; as shipped, :2313 hands mem_sort_dedup_patch ANOTHER read's bases, which a second
+    # worker may be converting in place at that moment (:2052-2053): the garbage scores of INTEGRATION.md section 2
+    if os.path.exists(os.path.join(root, "build", "dropin", "bwa-gasal2-seqidx")):
+        env = dict(os.environ, E2E_EXE="bwa-gasal2-seqidx", E2E_LONGDEL="7", E2E_TAG="seqidx_t8")
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "e2e_dropin.py"), str(tmp_path), "2000000", "30000", "8", "se_hard"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+        out = r.stdout.decode()
+        assert r.returncode == 0 and "SAM IDENTICAL" in out, out[-3000:]
 
 
 def test_dropin_with_several_device_workers(hip, tmp_path):

@@ -672,11 +672,20 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
         t0 = time.perf_counter()
         fin, opr, h_rec, unflag, pes = finalize_pairs(co, params, po, len(g), pac_h, flat, offs, np.full(n_reads, rl, np.uint32), regs_h, rpr_h, fr_h, contigs=contigs, n_threads=nth, out=buf)
         t_fin = time.perf_counter() - t0
+        # the same with the mate rescue's local alignments as one batch on the device (bmh_finalize_pairs_dev)
+        buf2 = np.zeros_like(buf)
+        t0 = time.perf_counter()
+        fin2, opr2, h2, uf2, _ = finalize_pairs(co, params, po, len(g), pac_h, flat, offs, np.full(n_reads, rl, np.uint32), regs_h, rpr_h, fr_h, contigs=contigs, n_threads=nth, out=buf2,
+                                                device=(dindex, dr.ascii, dr.offs, None))
+        t_fin2 = time.perf_counter() - t0
+        same = bool(np.array_equal(fin, fin2) and np.array_equal(opr, opr2) and np.array_equal(h_rec, h2) and np.array_equal(unflag, uf2))
         need = np.zeros(max(len(fin), 1), np.uint8)
         fin = np.ascontiguousarray(fin)
         L.bmh_sam_need_cigar_pe(C.byref(po), _np_ptr(fin, _i32p), _np_ptr(np.ascontiguousarray(opr), _u32p), _np_ptr(np.ascontiguousarray(h_rec), _i32p), n_reads, _np_ptr(need, _u8p))
         sel = np.nonzero(need[: len(fin)])[0].astype(np.int32)
-        name, extra = "finalize_pairs_host", {"insert_size_FR": {"low": pes[1][0], "high": pes[1][1], "mean": round(pes[1][3], 1), "sd": round(pes[1][4], 1)}}
+        name, extra = "finalize_pairs_host", {"insert_size_FR": {"low": pes[1][0], "high": pes[1][1], "mean": round(pes[1][3], 1), "sd": round(pes[1][4], 1)},
+                                               "with_mate_rescue_on_the_device": {"ms": round(t_fin2 * 1e3, 2), "identical": same,
+                                                                                  "what": "bmh_finalize_pairs_dev: the ksw_align2 calls of mem_matesw as one batch of 16-lane jobs on the device, the rest on host threads"}}
         m = len(fin)
     else:
         fin = np.zeros((max(n_regs, 1), 16), np.int32); opr = np.zeros(n_reads, np.uint32)

@@ -342,8 +342,10 @@ class Aligner:
 
     def _finish_pairs(self, names, codes, offs, lens, r, o, l, regs_h, rpr_h, fr_h, po, cw, ws) -> str:
         L, dev, n = self.L, self.dev, len(lens)
+        # (the mate rescue's local alignments go to the device as one batch: bmh_finalize_pairs_dev)
         fin, opr, h_rec, unflag, _ = finalize_pairs(self.copt, self.ep, po, self.l_pac, self.pac, codes, offs, lens, regs_h, rpr_h, fr_h,
-                                                    contigs=self.contigs if len(self.contigs) > 1 else None, n_threads=self.n_threads, pe=self.pe)
+                                                    contigs=self.contigs if len(self.contigs) > 1 else None, n_threads=self.n_threads, pe=self.pe,
+                                                    device=(self.index, r, o, None))
         fin = np.ascontiguousarray(fin); m = len(fin)
         need = np.zeros(max(m, 1), np.uint8)
         L.bmh_sam_need_cigar_pe(C.byref(po), _np_ptr(fin if m else np.zeros((1, 16), np.int32), _i32p), _np_ptr(np.ascontiguousarray(opr), _u32p),

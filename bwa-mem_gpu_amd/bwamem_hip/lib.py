@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "bmh_index_free", "bmh_index_replicate", "bmh_shard_range", "bmh_index_densify_sa", "bmh_index_build", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
     "bmh_extend_batch", "bmh_extend_last_ms", "bmh_extend_last_unsupported", "bmh_extend_set_packed", "bmh_extend_release", "bmh_calib_gather", "bmh_calib_valu",
     "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_finalize_regs_device", "bmh_finalize_regs_device_last_ms", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
-    "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
+    "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_finalize_pairs_dev", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
     "bmh_chain_opt_default", "bmh_chain_last_timing", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
     "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_materialize", "bmh_chain_batch",
     "bmh_chain_extend", "bmh_chain_merge", "bmh_chain_extend_merge", "bmh_chain_extend_merge_timing", "bmh_cigar_batch",
@@ -169,6 +169,8 @@ def load_library() -> C.CDLL:
     L.bmh_finalize_pairs.argtypes = [C.POINTER(ChainOpt), C.POINTER(ExtParams), C.POINTER(PostOpt), C.POINTER(PeOpt), C.c_int64, _u8p, C.c_uint32, _u8p, _u64p,
                                      _u32p, _i32p, _u32p, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p, _i32p, C.c_uint64, _u32p, _i32p, _i32p,
                                      C.c_void_p, C.c_int]
+    L.bmh_finalize_pairs_dev.restype = C.c_int64
+    L.bmh_finalize_pairs_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + list(L.bmh_finalize_pairs.argtypes)
     L.bmh_sam_need_cigar_pe.restype = C.c_int64
     L.bmh_sam_need_cigar_pe.argtypes = [C.POINTER(PostOpt), _i32p, _u32p, _i32p, C.c_uint32, _u8p]
     L.bmh_format_sam_pe.restype = C.c_void_p
@@ -412,9 +414,10 @@ def finalize_regs_device(index: "Index", copt, ep, po, reads_t, offs_t, regs_t, 
 
 
 def finalize_pairs(copt, ep, po, genome_len: int, pac: np.ndarray, reads_flat: np.ndarray, read_offs: np.ndarray, read_lens: np.ndarray,
-                   regs: np.ndarray, regs_per_read: np.ndarray, frac_rep: np.ndarray, contigs=None, n_threads: int = 1, pe=None, out=None):
+                   regs: np.ndarray, regs_per_read: np.ndarray, frac_rep: np.ndarray, contigs=None, n_threads: int = 1, pe=None, out=None, device=None):
     """bmh_finalize_pairs -> (fin [m,16], per_read, h_rec, unflag, pes [4,5]).  out: optional preallocated int32 [cap,16] buffer
-    (a caller that runs batch after batch keeps one, so the pages are not faulted in on every call)"""
+    (a caller that runs batch after batch keeps one, so the pages are not faulted in on every call).
+    device = (Index, reads_t ASCII, offs_t, stream): bmh_finalize_pairs_dev -- the mate rescue's local alignments as one batch on the device"""
     L = load_library()
     if pe is None:
         pe = PeOpt(); L.bmh_pe_opt_default(C.byref(pe))
@@ -434,7 +437,10 @@ def finalize_pairs(copt, ep, po, genome_len: int, pac: np.ndarray, reads_flat: n
     for attempt in range(4):
         if out is None or len(out) < cap:
             out = np.empty((cap, 16), np.int32)
-        m = L.bmh_finalize_pairs(C.byref(copt), C.byref(ep), C.byref(po), C.byref(pe), genome_len, _np_ptr(keep[0], _u8p), n, _np_ptr(keep[1], _u8p),
+        fn, head = L.bmh_finalize_pairs, ()
+        if device is not None:
+            fn, head = L.bmh_finalize_pairs_dev, (device[0].handle, device[1].data_ptr(), device[2].data_ptr(), device[3] if len(device) > 3 else None)
+        m = fn(*head, C.byref(copt), C.byref(ep), C.byref(po), C.byref(pe), genome_len, _np_ptr(keep[0], _u8p), n, _np_ptr(keep[1], _u8p),
                                  _np_ptr(keep[2], _u64p), _np_ptr(keep[3], _u32p), _np_ptr(regs, _i32p), _np_ptr(keep[4], _u32p),
                                  keep[5].ctypes.data_as(C.POINTER(C.c_float)), len(contigs) if contigs else 1,
                                  off.ctypes.data_as(C.c_void_p) if contigs else None, ln.ctypes.data_as(C.c_void_p) if contigs else None,

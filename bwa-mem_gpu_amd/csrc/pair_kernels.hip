@@ -1,0 +1,276 @@
+// Mate rescue's local alignments on the device (BASELINE configs[3]): the ksw_align2 calls of mem_matesw
+// (/root/reference/src/bwamem_pair.c:119-188; ksw_align2 with KSW_XSUBO | KSW_XSTART [| KSW_XBYTE], src/ksw.c:389-740) as one batch of
+// jobs.  pair_post.cpp walks the pairs twice -- once to collect the alignments mem_matesw is going to ask for, once to take their
+// results -- and this kernel computes them in between; on the host they were 98 % of bmh_finalize_pairs on an hg38-like batch
+// (107 000 alignments of 150 x 480 cells per million reads: 2.7 s on 16 threads).
+//
+// The reference computes a striped SSE2 kernel (Farrar) whose results depend on the striping in two places (local_sw.cpp): E(i+1,j) is
+// taken from H(i,j) BEFORE the lazy-F correction, and zero-score padding lanes take part in the row maximum.  To return the same
+// numbers a job runs on 16 GPU lanes that ARE the 16 byte lanes of the SSE register (8 of them the 16-bit lanes of ksw_i16): lane l
+// owns query positions l * slen .. l * slen + slen - 1, walks its slen segments in the reference's order, takes H of the previous
+// segment row from lane l - 1 (the byte shift of the SSE code) and runs the lazy-F loop with the reference's exit test.  The lane's
+// columns of H / E live in LDS (lane-private: no synchronisation), four jobs per wave.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
+#include "bmh_internal.h"
+#include "local_sw.h"
+#include "pair_kernels.h"
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
+
+#define MSW_SLEN 40            // segments per lane the kernel keeps in LDS: queries up to 16 * 40 columns in byte mode (which ends at 249), 8 * 40 = 320 in 16-bit mode
+#define MSW_JOBS_PER_BLOCK 8   // 128 threads
+#define MSW_TBUF 64            // target rows staged per refill
+
+struct msw_args_t {
+	const bmh_msw_job_t *jobs; uint32_t n_jobs;
+	const uint8_t *reads; const uint32_t *read_offs;      // ASCII reads of the batch
+	const uint8_t *pac; long long l_pac;
+	int a, b, o_del, e_del, o_ins, e_ins;
+	uint32_t *blist;                                      // per job: room for tlen entries (val << 16 | row) of the second-best bookkeeping
+	int32_t *out;                                         // [n_jobs][7] = {score, te, qe, score2, te2, tb, qb}
+};
+
+__device__ __forceinline__ int msw_text(const msw_args_t &A, long long p)
+{
+	const bool rev = p >= A.l_pac;
+	const long long f = rev ? (A.l_pac << 1) - 1 - p : p;
+	const int c = (A.pac[f >> 2] >> ((~f & 3) << 1)) & 3;
+	return rev ? 3 - c : c;
+}
+__device__ __forceinline__ int msw_nt4(uint8_t c) { c &= 0xDF; return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
+__device__ __forceinline__ int msw_sat0(int v) { return v < 0 ? 0 : v; }
+// value of lane l - 1 of the 16-lane group (lane 0 of the group: 0)
+__device__ __forceinline__ int msw_shl(int v, int l) { const int t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); return l == 0 ? 0 : t; }
+__device__ __forceinline__ int msw_gmax(int v)
+{
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+	return v;
+}
+
+struct msw_res_t { int score, te, qe, score2, te2; };
+
+// One pass of the striped kernel for the job of this 16-lane group (sw_pass of local_sw.cpp).  All lanes of the wave call it together;
+// `on`: this group has a job.  query position k of the pass = qbase[k * qstep] through qmap (ASCII read, optionally complemented);
+// target row i = trow(i).  xtra as in ksw_align2.
+template <class QF, class TF>
+__device__ void msw_pass(const msw_args_t &A, const bool on, const int lanes, const int qlen, const int tlen, QF qcode, TF trow, const int xtra,
+                         uint16_t *H0, uint16_t *H1, uint16_t *E, uint16_t *Hm, uint8_t *qc, uint8_t *tbuf, uint32_t *blist, msw_res_t &R)
+{
+	const int lane = threadIdx.x & 63, l = lane & 15;
+	const unsigned long long gmask = 0xFFFFull << (lane & 48);
+	const bool byte = lanes == 16;
+	const bool lact = on && l < lanes;                         // this lane is one of the job's SSE lanes
+	const int slen = on ? (qlen + lanes - 1) / lanes : 0;
+	const int minsc = (xtra & BMH_SW_XSUBO) ? xtra & 0xffff : 0x10000, endsc = (xtra & BMH_SW_XSTOP) ? xtra & 0xffff : 0x10000;
+	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;
+	int mn = min(min(A.a, -A.b), -1), mx = max(max(A.a, -A.b), -1);
+	const int shift = byte ? (256 - (mn & 0xff)) & 0xff : 0;
+	// lane-private columns: element j of lane l at [j * 16 + l]
+	for (int j = 0; j < slen; ++j) {
+		const int k = j + l * slen;
+		H0[j * 16 + l] = 0; H1[j * 16 + l] = 0; E[j * 16 + l] = 0; Hm[j * 16 + l] = 0;
+		qc[j * 16 + l] = (uint8_t)((lact && k < qlen) ? qcode(k) : 5);      // 5: padding, scores 0 against everything
+	}
+	int gmax = 0, te = -1;
+	int bl_n = 0, bl_val = 0, bl_i = -2;                       // second-best bookkeeping (lane 0 of the group): entries written so far, the open one
+	uint16_t *h0 = H0, *h1 = H1;
+	bool alive = on && tlen > 0;
+	const int slen_w = __builtin_amdgcn_readfirstlane(max(max(__shfl(slen, 0), __shfl(slen, 16)), max(__shfl(slen, 32), __shfl(slen, 48))));
+	for (int i = 0; __any(alive); ++i) {
+		if ((i & (MSW_TBUF - 1)) == 0) {                        // next MSW_TBUF target rows of every job, four per lane
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			for (int u = l; u < MSW_TBUF; u += 16) tbuf[u] = (uint8_t)((alive && i + u < tlen) ? trow(i + u) : 4);
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		}
+		const bool run = alive && i < tlen;
+		const int t = tbuf[i & (MSW_TBUF - 1)];
+		int hv = msw_shl(run ? (int)h0[(slen > 0 ? slen - 1 : 0) * 16 + l] : 0, l);
+		int f = 0, mxv = 0;
+		for (int j = 0; j < slen_w; ++j) {
+			if (run && j < slen) {
+				const int q = qc[j * 16 + l];
+				const int S = q == 5 ? 0 : ((t > 3 || q > 3) ? -1 : (t == q ? A.a : -A.b));
+				int h = byte ? msw_sat0(min(hv + S + shift, 255) - shift) : max(min(hv + S, 32767), -32768);
+				int e = E[j * 16 + l];
+				h = max(h, e); h = max(h, f);
+				mxv = max(mxv, h);
+				h1[j * 16 + l] = (uint16_t)h;
+				e = max(msw_sat0(e - A.e_del), msw_sat0(h - oe_del));
+				E[j * 16 + l] = (uint16_t)e;
+				f = max(msw_sat0(f - A.e_ins), msw_sat0(h - oe_ins));
+				hv = h0[j * 16 + l];
+			}
+		}
+		// lazy F (ksw.c:497-511, 627-638): at most 16 rounds; a round ends the whole loop at the first segment where no lane's F can still raise H
+		{
+			int k = 0, j = 0;
+			bool lz = run && slen > 0;
+			f = msw_shl(f, l);
+			while (__any(lz)) {
+				bool more = false;
+				if (lz) {
+					const int h = max((int)h1[j * 16 + l], f);
+					h1[j * 16 + l] = (uint16_t)h;
+					const int hh = msw_sat0(h - oe_ins);
+					f = msw_sat0(f - A.e_ins);
+					more = lact && f > hh;
+				}
+				const bool any = (__ballot(more) & gmask) != 0;
+				bool shiftf = false;
+				if (lz) {
+					if (!any) lz = false;
+					else if (++j == slen) { j = 0; if (++k == 16) lz = false; else shiftf = true; }
+				}
+				const int fs = msw_shl(f, l);
+				f = shiftf ? fs : f;
+			}
+		}
+		int imax = msw_gmax(lact ? mxv : 0);
+		if (run) {
+			if (imax >= minsc && l == 0) {                       // ksw.c:519-527: consecutive rows keep one entry, at the row of their maximum so far
+				if (bl_i + 1 != i) { if (bl_i >= 0) blist[bl_n++] = (uint32_t)bl_val << 16 | (uint32_t)bl_i; bl_val = imax; bl_i = i; }
+				else if (bl_val < imax) { bl_val = imax; bl_i = i; }
+			}
+			if (imax > gmax) {
+				gmax = imax; te = i;
+				for (int j = 0; j < slen; ++j) Hm[j * 16 + l] = h1[j * 16 + l];
+				if ((byte && gmax + shift >= 255) || gmax >= endsc) alive = false;
+			}
+			uint16_t *tsw = h0; h0 = h1; h1 = tsw;
+			if (i + 1 >= tlen) alive = false;
+		}
+	}
+	if (l == 0 && bl_i >= 0) blist[bl_n++] = (uint32_t)bl_val << 16 | (uint32_t)bl_i;
+	bl_n = __shfl(bl_n, lane & 48);
+	R.score = byte ? (gmax + shift < 255 ? gmax : 255) : gmax;
+	R.te = te; R.qe = -1; R.score2 = -1; R.te2 = -1;
+	if (on && (!byte || R.score != 255)) {
+		// end of the query: the largest H of the best row, the smallest position among equals (ksw.c:540-547)
+		int bv = -1, bp = 0x7FFFFFFF;
+		for (int j = 0; j < slen; ++j) if (l < lanes) { const int v = Hm[j * 16 + l], pos = j + l * slen; if (v > bv || (v == bv && pos < bp)) { bv = v; bp = pos; } }
+		int key = l < lanes ? (bv << 12 | (0xFFF - min(bp, 0xFFF))) : -1;        // positions < 4096 (MSW_SLEN * 16 = 640)
+		key = msw_gmax(key);
+		R.qe = 0xFFF - (key & 0xFFF);
+		if (bl_n > 0) {
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			__builtin_amdgcn_s_waitcnt(0);
+			const int d = (R.score + mx - 1) / mx, low = te - d, high = te + d;
+			// best entry outside [low, high], the first of equals: key = val << 16 | (0xFFFF - index)
+			int best = -1;
+			for (int u = l; u < bl_n; u += 16) {
+				const uint32_t x = blist[u];
+				const int e = (int)(x & 0xFFFF), v = (int)(x >> 16);
+				if (e < low || e > high) best = max(best, (v << 16) | (0xFFFF - min(u, 0xFFFF)));
+			}
+			best = msw_gmax(best);
+			if (best >= 0) { R.score2 = best >> 16; R.te2 = (int)(blist[0xFFFF - (best & 0xFFFF)] & 0xFFFF); }
+		}
+	}
+}
+
+__global__ void __launch_bounds__(16 * MSW_JOBS_PER_BLOCK) msw_kernel(msw_args_t A)
+{
+	__shared__ uint16_t sH0[MSW_JOBS_PER_BLOCK][MSW_SLEN * 16], sH1[MSW_JOBS_PER_BLOCK][MSW_SLEN * 16], sE[MSW_JOBS_PER_BLOCK][MSW_SLEN * 16], sHm[MSW_JOBS_PER_BLOCK][MSW_SLEN * 16];
+	__shared__ uint8_t sq[MSW_JOBS_PER_BLOCK][MSW_SLEN * 16], st[MSW_JOBS_PER_BLOCK][MSW_TBUF];
+	const int g = threadIdx.x >> 4;
+	const uint32_t jid = blockIdx.x * MSW_JOBS_PER_BLOCK + g;
+	const bool on = jid < A.n_jobs;
+	bmh_msw_job_t J;
+	memset(&J, 0, sizeof(J));
+	if (on) J = A.jobs[jid];
+	const int lanes = (J.xtra & BMH_SW_XBYTE) ? 16 : 8;
+	const uint8_t *rd = A.reads + (on ? A.read_offs[J.read] : 0);
+	const int l_ms = J.l_ms, is_rev = J.is_rev;
+	const long long rb = J.rb;
+	const int tlen = (int)(J.re - J.rb);
+	// the mate as mem_matesw aligns it: itself, or its reverse complement
+	auto qfwd = [&](int k) { const int c = msw_nt4(rd[is_rev ? l_ms - 1 - k : k]); return is_rev ? (c < 4 ? 3 - c : 4) : c; };
+	auto tfwd = [&](int i) { return msw_text(A, rb + i); };
+	msw_res_t R1;
+	uint32_t *bl = A.blist + (on ? J.bl_off : 0);
+	msw_pass(A, on, lanes, l_ms, tlen, qfwd, tfwd, J.xtra, sH0[g], sH1[g], sE[g], sHm[g], sq[g], st[g], bl, R1);
+	int tb = -1, qb = -1;
+	const bool second = on && (J.xtra & BMH_SW_XSTART) && !((J.xtra & BMH_SW_XSUBO) && R1.score < (J.xtra & 0xffff));
+	if (__any(second)) {
+		// start positions: the same pass over the reversed prefixes, stopped at the score (ksw.c:722-736; the target keeps its full length,
+		// its rows beyond the reversed prefix are the original ones)
+		const int qe = R1.qe, te = R1.te;
+		auto qrev = [&](int k) { return qfwd(qe - k); };
+		auto trev = [&](int i) { return i <= te ? msw_text(A, rb + (te - i)) : msw_text(A, rb + i); };
+		msw_res_t R2;
+		msw_pass(A, second, lanes, qe + 1, tlen, qrev, trev, BMH_SW_XSTOP | R1.score, sH0[g], sH1[g], sE[g], sHm[g], sq[g], st[g], bl, R2);
+		if (second && R1.score == R2.score) { tb = R1.te - R2.te; qb = R1.qe - R2.qe; }
+	}
+	if (on && (threadIdx.x & 15) == 0) {
+		int32_t *o = A.out + 7 * (size_t)jid;
+		o[0] = R1.score; o[1] = R1.te; o[2] = R1.qe; o[3] = R1.score2; o[4] = R1.te2; o[5] = tb; o[6] = qb;
+	}
+}
+
+// ---- host side
+struct msw_scratch_t { bmh_msw_job_t *d_jobs; int32_t *d_out; uint32_t *d_bl; size_t cap_jobs, cap_bl; };
+static std::mutex g_msw_mu;
+static std::map<std::pair<int, void *>, msw_scratch_t *> g_msw_map;
+
+// can the kernel take this job? (the host computes the others itself)
+extern "C" int bmh_matesw_device_takes(int l_ms, int64_t tlen, int xtra)
+{
+	const int lanes = (xtra & BMH_SW_XBYTE) ? 16 : 8;
+	return l_ms > 0 && (l_ms + lanes - 1) / lanes <= MSW_SLEN && tlen > 0 && tlen < 65536;
+}
+
+extern "C" int bmh_matesw_batch_device(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, const bmh_ext_params_t *ep,
+                                       bmh_msw_job_t *jobs, uint64_t n_jobs, int32_t *out, void *stream_)
+{
+	if (!idx || !idx->dev.pac || !d_reads || !d_offs || !ep || (n_jobs && (!jobs || !out))) { bmh_set_error("bmh_matesw_batch_device: null argument"); return BMH_EINVAL; }
+	if (n_jobs == 0) return BMH_OK;
+	if (n_jobs >> 31) { bmh_set_error("bmh_matesw_batch_device: too many jobs"); return BMH_ECAPACITY; }
+	hipStream_t st = (hipStream_t)stream_;
+	int dev = 0;
+	HIPCK(hipGetDevice(&dev));
+	msw_scratch_t *S;
+	{
+		std::lock_guard<std::mutex> lk(g_msw_mu);
+		auto key = std::make_pair(dev, stream_);
+		auto it = g_msw_map.find(key);
+		if (it == g_msw_map.end()) { S = (msw_scratch_t *)calloc(1, sizeof(msw_scratch_t)); g_msw_map[key] = S; }
+		else S = it->second;
+	}
+	uint64_t bl = 0;
+	for (uint64_t k = 0; k < n_jobs; ++k) { jobs[k].bl_off = (uint32_t)bl; bl += (uint64_t)(jobs[k].re - jobs[k].rb) / 2 + 2; if (bl >> 32) { bmh_set_error("bmh_matesw_batch_device: windows too long"); return BMH_ECAPACITY; } }
+	if (n_jobs > S->cap_jobs) {
+		if (S->d_jobs) (void)hipFree(S->d_jobs);
+		if (S->d_out) (void)hipFree(S->d_out);
+		S->d_jobs = nullptr; S->d_out = nullptr; S->cap_jobs = 0;
+		const size_t c = n_jobs + n_jobs / 4 + 1024;
+		HIPCK(hipMalloc((void **)&S->d_jobs, sizeof(bmh_msw_job_t) * c)); HIPCK(hipMalloc((void **)&S->d_out, sizeof(int32_t) * 7 * c));
+		S->cap_jobs = c;
+	}
+	if (bl > S->cap_bl) {
+		if (S->d_bl) (void)hipFree(S->d_bl);
+		S->d_bl = nullptr; S->cap_bl = 0;
+		const size_t c = bl + bl / 4 + 1024;
+		HIPCK(hipMalloc((void **)&S->d_bl, 4 * c));
+		S->cap_bl = c;
+	}
+	HIPCK(hipMemcpyAsync(S->d_jobs, jobs, sizeof(bmh_msw_job_t) * n_jobs, hipMemcpyHostToDevice, st));
+	msw_args_t A;
+	A.jobs = S->d_jobs; A.n_jobs = (uint32_t)n_jobs; A.reads = d_reads; A.read_offs = d_offs; A.pac = idx->dev.pac; A.l_pac = (long long)idx->dev.l_pac;
+	A.a = ep->a; A.b = ep->b; A.o_del = ep->o_del; A.e_del = ep->e_del; A.o_ins = ep->o_ins; A.e_ins = ep->e_ins;
+	A.blist = S->d_bl; A.out = S->d_out;
+	msw_kernel<<<(unsigned)((n_jobs + MSW_JOBS_PER_BLOCK - 1) / MSW_JOBS_PER_BLOCK), 16 * MSW_JOBS_PER_BLOCK, 0, st>>>(A);
+	HIPCK(hipMemcpyAsync(out, S->d_out, sizeof(int32_t) * 7 * n_jobs, hipMemcpyDeviceToHost, st));
+	HIPCK(hipStreamSynchronize(st));
+	HIPCK(hipGetLastError());
+	return BMH_OK;
+}

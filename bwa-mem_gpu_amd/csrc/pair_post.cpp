@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "local_sw.h"
+#include "pair_kernels.h"
 #include "regs_post.h"
 
 using namespace rp;
@@ -30,10 +31,18 @@ namespace {
 
 struct Pes { int low, high, failed; double avg, std; };
 
+// The local alignments of mem_matesw can be computed as one batch on the device (pair_kernels.hip): the pairs are then walked twice.
+// sw_mode 1: an alignment that is about to be computed is written down instead (and answered "nothing found"); sw_mode 2: it is taken
+// from the batch's results (or computed here, if the first walk did not foresee it -- the regions a rescue adds can change which
+// orientations later calls of the same pair skip); sw_mode 0: computed on the spot (the host-only form).
+struct SwKey { uint32_t pair; uint16_t j; uint8_t i, r; };
 struct PCtx {
 	Ctx x; const bmh_pe_opt_t *pe; Pes pes[4];
 	const int64_t *ctg_off; const int32_t *ctg_len;
 	const uint8_t *reads; const uint64_t *offs; const uint32_t *lens;
+	int sw_mode = 0;
+	std::vector<SwKey> *col_keys = nullptr; std::vector<bmh_msw_job_t> *col_jobs = nullptr;      // sw_mode 1 (per thread)
+	const SwKey *keys = nullptr; const uint64_t *pair_off = nullptr; const int32_t *res = nullptr;   // sw_mode 2
 };
 
 inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)      // mem_infer_dir
@@ -122,7 +131,7 @@ template <class RegsOf> void pestat(PCtx &c, size_t n, RegsOf regs_of, int n_thr
 int pos2rid_c(const PCtx &c, int64_t pos_f) { return pos2rid(c.x, pos_f); }
 
 // bns_fetch_seq (src/bntseq.c:531-556): [beg, end) clipped to the sequence (and strand) that holds mid
-bool fetch_window(const PCtx &c, int64_t *beg, int64_t mid, int64_t *end, int *rid, std::vector<uint8_t> &seq)
+bool fetch_window(const PCtx &c, int64_t *beg, int64_t mid, int64_t *end, int *rid, std::vector<uint8_t> &seq, bool want_bases = true)
 {
 	if (*end < *beg) std::swap(*beg, *end);
 	const int64_t l_pac = c.x.l_pac;
@@ -133,6 +142,7 @@ bool fetch_window(const PCtx &c, int64_t *beg, int64_t mid, int64_t *end, int *r
 	*beg = *beg > far_beg ? *beg : far_beg;
 	*end = *end < far_end ? *end : far_end;
 	if (*beg >= *end) { seq.clear(); return false; }
+	if (!want_bases) return true;
 	seq.resize((size_t)(*end - *beg));
 	for (int64_t i = *beg; i < *end; ++i) seq[(size_t)(i - *beg)] = (uint8_t)text_base(c.x.pac, l_pac, i);
 	return true;
@@ -141,7 +151,7 @@ bool fetch_window(const PCtx &c, int64_t *beg, int64_t mid, int64_t *end, int *r
 // BMH_POST_STATS: how much local alignment the mate rescue does
 static std::atomic<unsigned long long> g_ms_calls{0}, g_ms_sw{0}, g_ms_cells{0}, g_ms_hits{0};
 
-int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector<Reg> &ma)        // mem_matesw
+int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector<Reg> &ma, SwKey key = SwKey{0, 0, 0, 0}, uint32_t mate_read = 0)        // mem_matesw
 {
 	g_ms_calls++;
 	const int64_t l_pac = c.x.l_pac;
@@ -175,12 +185,33 @@ int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector
 		if (re > l_pac << 1) re = l_pac << 1;
 		int rid = -1;
 		bool have = false;
-		if (rb < re) have = fetch_window(c, &rb, (rb + re) >> 1, &re, &rid, ref);
+		if (rb < re) have = fetch_window(c, &rb, (rb + re) >> 1, &re, &rid, ref, false);
 		if (have && a.rid == rid && re - rb >= c.x.co->min_seed_len) {
 			const int xtra = BMH_SW_XSUBO | BMH_SW_XSTART | (l_ms * c.x.ep->a < 250 ? BMH_SW_XBYTE : 0) | (c.x.co->min_seed_len * c.x.ep->a);
-			seqbuf.assign(seq, seq + l_ms);
-			const bmh_sw_result_t aln = bmh_local_sw(l_ms, seqbuf.data(), (int)(re - rb), ref.data(), *c.x.ep, xtra);
-			g_ms_sw++; g_ms_cells += (unsigned long long)l_ms * (unsigned long long)(re - rb);
+			bmh_sw_result_t aln = {0, -1, -1, -1, -1, -1, -1};
+			bool done = false;
+			key.r = (uint8_t)r;
+			if (c.sw_mode == 1 && bmh_matesw_device_takes(l_ms, re - rb, xtra)) {       // written down for the batch; this walk goes on as if nothing were found
+				bmh_msw_job_t jb; memset(&jb, 0, sizeof(jb));
+				jb.rb = rb; jb.re = re; jb.read = mate_read; jb.l_ms = l_ms; jb.is_rev = is_rev; jb.xtra = xtra;
+				c.col_keys->push_back(key); c.col_jobs->push_back(jb);
+				done = true;
+			} else if (c.sw_mode == 2) {
+				for (uint64_t t = c.pair_off[key.pair]; t < c.pair_off[key.pair + 1]; ++t)
+					if (c.keys[t].i == key.i && c.keys[t].j == key.j && c.keys[t].r == key.r) {
+						const int32_t *o = c.res + 7 * t;
+						aln.score = o[0]; aln.te = o[1]; aln.qe = o[2]; aln.score2 = o[3]; aln.te2 = o[4]; aln.tb = o[5]; aln.qb = o[6];
+						done = true;
+						break;
+					}
+			}
+			if (!done && c.sw_mode != 1) {
+				ref.resize((size_t)(re - rb));
+				for (int64_t t = rb; t < re; ++t) ref[(size_t)(t - rb)] = (uint8_t)text_base(c.x.pac, l_pac, t);
+				seqbuf.assign(seq, seq + l_ms);
+				aln = bmh_local_sw(l_ms, seqbuf.data(), (int)(re - rb), ref.data(), *c.x.ep, xtra);
+				g_ms_sw++; g_ms_cells += (unsigned long long)l_ms * (unsigned long long)(re - rb);
+			}
 			if (aln.score >= c.x.co->min_seed_len && aln.qb >= 0) {
 				Reg b; memset(&b, 0, sizeof(b));
 				b.rid = a.rid; b.is_alt = a.is_alt;
@@ -298,8 +329,9 @@ int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // 
 			for (const Reg &r : *a[i]) if (r.score >= (*a[i])[0].score - c.pe->pen_unpaired) b[i].push_back(r);
 		for (int i = 0; i < 2; ++i)
 			for (size_t j = 0; j < b[i].size() && (int)j < c.pe->max_matesw; ++j)
-				matesw(c, b[i][j], l_seq[!i], seq[!i], *a[!i]);
+				matesw(c, b[i][j], l_seq[!i], seq[!i], *a[!i], SwKey{(uint32_t)(r0 >> 1), (uint16_t)j, (uint8_t)i, 0}, r0 + (uint32_t)!i);
 	}
+	if (c.sw_mode == 1) return 0;
 	for (int i = 0; i < 2; ++i) { mark_primary(c.x, (int)a[i]->size(), a[i]->data(), (int64_t)(id << 1 | (uint64_t)i)); n_pri[i] = (int)a[i]->size(); }
 	for (int i = 0; i < 2; ++i) { out[i].sec_all.resize(a[i]->size()); for (size_t j = 0; j < a[i]->size(); ++j) out[i].sec_all[j] = (*a[i])[j].secondary; }
 	bool paired = false;
@@ -376,12 +408,12 @@ extern "C" void bmh_pe_opt_default(bmh_pe_opt_t *o) { o->pen_unpaired = 17; o->m
 // [12] = the record's primary for the XA tag or -1); out_h[r] = record of read r's own alignment within its list (what the
 // mate's RNEXT / PNEXT / TLEN are taken from) or -1 if unmapped; out_unflag[r] = flag bits of the unmapped record of a read
 // without reported alignment; pes_out[4][5] = {low, high, failed, avg, std} as doubles.  Returns the record count (<= cap).
-extern "C" int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
-                                      int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
-                                      const uint32_t *read_lens, const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
-                                      int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
-                                      int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
-                                      int n_threads)
+static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
+                                   int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                                   const uint32_t *read_lens, const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
+                                   int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
+                                   int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
+                                   int n_threads, const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream)
 {
 	if (!copt || !ep || !popt || !pe || !pac || !reads || !read_offs || !read_lens || !regs_per_read || !out || !out_per_read || !out_h || !out_unflag ||
 	    (n_contigs > 1 && (!contig_offset || !contig_len))) { bmh_set_error("bmh_finalize_pairs: null argument"); return BMH_EINVAL; }
@@ -419,6 +451,32 @@ extern "C" int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext
 	pestat(c, n_reads, [&](size_t r) { return Span{flat + in_off[r], cnt[r]}; }, n_threads);
 	const double t_c = now();
 	if (pes_out) for (int d = 0; d < 4; ++d) { pes_out[5 * d] = c.pes[d].low; pes_out[5 * d + 1] = c.pes[d].high; pes_out[5 * d + 2] = c.pes[d].failed; pes_out[5 * d + 3] = c.pes[d].avg; pes_out[5 * d + 4] = c.pes[d].std; }
+	// With a device: the local alignments of the mate rescue as one batch (pair_kernels.hip).  First walk: which alignments mem_matesw asks
+	// for (ranges of pairs on threads; their lists concatenate in pair order); then the kernel; the walk below takes the results.
+	std::vector<SwKey> all_keys; std::vector<bmh_msw_job_t> all_jobs; std::vector<uint64_t> pair_off; std::vector<int32_t> sw_res;
+	double t_sw0 = now(), t_sw1 = t_sw0, t_sw2 = t_sw0;
+	if (idx && !pe->no_rescue && n_reads) {
+		std::vector<std::vector<SwKey>> tk((size_t)n_threads); std::vector<std::vector<bmh_msw_job_t>> tj((size_t)n_threads);
+		par([&](int t, uint32_t p0, uint32_t p1) {
+			PCtx cl = c;
+			cl.sw_mode = 1; cl.col_keys = &tk[(size_t)t]; cl.col_jobs = &tj[(size_t)t];
+			ReadOut o2[2];
+			for (uint32_t p = p0; p < p1; ++p) {
+				for (int i = 0; i < 2; ++i) { const uint32_t r = 2 * p + (uint32_t)i; o2[i].regs.assign(flat + in_off[r], flat + in_off[r] + cnt[r]); }
+				sam_pe(cl, (uint64_t)(popt->id0 / 2) + p, 2 * p, o2);
+			}
+		}, n_reads / 2);
+		for (int t = 0; t < n_threads; ++t) { all_keys.insert(all_keys.end(), tk[(size_t)t].begin(), tk[(size_t)t].end()); all_jobs.insert(all_jobs.end(), tj[(size_t)t].begin(), tj[(size_t)t].end()); }
+		pair_off.assign((size_t)n_reads / 2 + 1, 0);
+		for (const SwKey &k : all_keys) ++pair_off[(size_t)k.pair + 1];
+		for (size_t p = 0; p < (size_t)n_reads / 2; ++p) pair_off[p + 1] += pair_off[p];
+		t_sw1 = now();
+		sw_res.resize(7 * all_jobs.size() + 7);
+		const int rc = bmh_matesw_batch_device(idx, d_reads, d_offs, ep, all_jobs.data(), all_jobs.size(), sw_res.data(), stream);
+		if (rc != BMH_OK) return rc;
+		t_sw2 = now();
+		c.sw_mode = 2; c.keys = all_keys.data(); c.pair_off = pair_off.data(); c.res = sw_res.data();
+	}
 	// per pair: mem_sam_pe's decisions; every thread appends the records of its (contiguous) pairs to its own buffer
 	struct Part { std::vector<int32_t> rec; std::vector<uint32_t> n; std::vector<int32_t> h, uf; };
 	std::vector<Part> parts((size_t)n_threads);
@@ -457,7 +515,7 @@ extern "C" int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext
 		}
 	}, n_reads / 2);
 	const double t_d = now();
-	if (prof) fprintf(stderr, "[pairs] dedup %.1f ms, pestat %.1f ms, mem_sam_pe %.1f ms (%d threads)\n", t_b - t_a, t_c - t_b, t_d - t_c, n_threads);
+	if (prof) fprintf(stderr, "[pairs] dedup %.1f ms, pestat %.1f ms, rescue jobs collected %.1f ms (%zu), on the device %.1f ms, mem_sam_pe %.1f ms (%d threads)\n", t_b - t_a, t_c - t_b, t_sw1 - t_sw0, all_jobs.size(), t_sw2 - t_sw1, t_d - t_sw2, n_threads);
 	// the parts go out side by side: offsets first, then every thread copies its own part
 	std::vector<uint64_t> w_off(parts.size() + 1, 0), r_off(parts.size() + 1, 0);
 	for (size_t t = 0; t < parts.size(); ++t) { w_off[t + 1] = w_off[t] + parts[t].rec.size() / 16; r_off[t + 1] = r_off[t] + parts[t].n.size(); }
@@ -471,8 +529,34 @@ extern "C" int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext
 		}
 	}, (uint32_t)parts.size());
 	if (getenv("BMH_POST_STATS"))
-		fprintf(stderr, "[finalize_pairs] %u reads: mem_matesw calls %llu, local alignments %llu (%.0f cells each), rescued regions %llu\n", n_reads,
+		fprintf(stderr, "[finalize_pairs] %u reads: mem_matesw calls %llu, local alignments on the host %llu (%.0f cells each), rescued regions %llu\n", n_reads,
 		        (unsigned long long)g_ms_calls.exchange(0), (unsigned long long)g_ms_sw.load(), (double)g_ms_cells.exchange(0) / (double)(g_ms_sw.load() ? g_ms_sw.load() : 1),
 		        (unsigned long long)g_ms_hits.exchange(0)), g_ms_sw = 0;
 	return (int64_t)w_off[parts.size()];
+}
+
+extern "C" int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
+                                      int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                                      const uint32_t *read_lens, const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
+                                      int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
+                                      int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
+                                      int n_threads)
+{
+	return finalize_pairs_impl(copt, ep, popt, pe, l_pac, pac, n_reads, reads, read_offs, read_lens, regs_in, regs_per_read, frac_rep, n_contigs, contig_offset, contig_len,
+	                           out, cap, out_per_read, out_h, out_unflag, pes_out, n_threads, nullptr, nullptr, nullptr, nullptr);
+}
+
+// The same with the local alignments of the mate rescue computed on the device (idx: the index with its 2-bit reference in HBM;
+// d_reads / d_offs: the batch's ASCII reads in HBM, the same reads as `reads`; stream: a HIP stream, waited for).  Same results.
+extern "C" int64_t bmh_finalize_pairs_dev(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream,
+                                          const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
+                                          int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                                          const uint32_t *read_lens, const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
+                                          int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
+                                          int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
+                                          int n_threads)
+{
+	if (!idx || !d_reads || !d_offs) { bmh_set_error("bmh_finalize_pairs_dev: null argument"); return BMH_EINVAL; }
+	return finalize_pairs_impl(copt, ep, popt, pe, l_pac, pac, n_reads, reads, read_offs, read_lens, regs_in, regs_per_read, frac_rep, n_contigs, contig_offset, contig_len,
+	                           out, cap, out_per_read, out_h, out_unflag, pes_out, n_threads, idx, d_reads, d_offs, stream);
 }

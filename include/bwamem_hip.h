@@ -300,6 +300,17 @@ int64_t bmh_finalize_pairs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *
                            int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
                            int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
                            int n_threads);
+/* bmh_finalize_pairs with the local alignments of the mate rescue (mem_matesw's ksw_align2 calls, 98 % of its time on a repeat-rich
+ * batch) computed as ONE batch on the device (csrc/pair_kernels.hip: the striped kernel's lanes as GPU lanes).  idx: the index with
+ * its 2-bit reference in HBM; d_reads / d_offs: the batch's ASCII reads in HBM (the same reads as `reads`); stream: waited for.
+ * Same results as bmh_finalize_pairs, record for record. */
+int64_t bmh_finalize_pairs_dev(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream,
+                               const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
+                               int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                               const uint32_t *read_lens, const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
+                               int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
+                               int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
+                               int n_threads);
 int64_t bmh_sam_need_cigar_pe(const bmh_post_opt_t *po, const int32_t *fin, const uint32_t *fin_per_read, const int32_t *h_rec,
                               uint32_t n_reads, uint8_t *need);
 char *bmh_format_sam_pe(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,

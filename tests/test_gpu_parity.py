@@ -1105,3 +1105,66 @@ def test_region_tail_on_the_device_equals_the_host_form(hip, oracle):
         rb[i, 40:100] = unit; rb[i, 39] = 3; rb[i, 100] = 2
         rb[i, 50 + i % 40] = (rb[i, 50 + i % 40] + 1) & 3 if i % 14 == 0 else rb[i, 50 + i % 40]
     run(gb, rb, co_over=dict(max_occ=2000), want_big=3)
+
+
+def test_mate_rescue_alignments_on_the_device(hip):
+    """The ksw_align2 emulation of the mate rescue (csrc/pair_kernels.hip: 16 GPU lanes = the 16 byte lanes / 8 word lanes of the
+    reference's striped SSE2 kernel) against the host walk of the same kernel (local_sw.cpp, itself checked against the compiled
+    ksw_align2): score, ends, second-best score and row, start positions, for both widths, both strands, windows with and without
+    the mate, repeats inside the window (second-best hits), N bases."""
+    import ctypes as C, torch
+    from bwamem_hip import fmindex, synth
+    B = hip
+    L = B.load_library()
+    rng = np.random.default_rng(77)
+    g = synth.make_genome(400_000, seed=5, repeat_frac=0.3, repeat_len=(100, 400), repeat_copies=(5, 40), repeat_div=0.03)
+    idx = fmindex.build_fmd_index(g)
+    dindex = B.Index.upload(idx, pac=_pack_pac(g), l_pac=len(g))
+    n = len(g)
+    text = np.concatenate([g, 3 - g[::-1]])                      # the 2 l_pac text the windows are cut from
+
+    class Job(C.Structure):
+        _fields_ = [("rb", C.c_int64), ("re", C.c_int64), ("read", C.c_uint32), ("l_ms", C.c_int32), ("is_rev", C.c_int32), ("xtra", C.c_int32), ("bl_off", C.c_uint32), ("pad", C.c_uint32)]
+    XBYTE, XSUBO, XSTART = 0x10000, 0x40000, 0x80000
+    for rl in (150, 100, 249, 300, 37):
+        n_reads = 600
+        reads = np.zeros((n_reads, rl), np.uint8)
+        jobs = (Job * n_reads)()
+        for i in range(n_reads):
+            p0 = int(rng.integers(1000, n - rl - 1000))
+            x = g[p0:p0 + rl].copy()
+            m = rng.random(rl) < (0.02 if i % 3 else 0.12); x[m] = (x[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+            if i % 11 == 0:
+                x[int(rng.integers(0, rl))] = 4
+            if i % 7 == 0 and rl >= 60:                             # a deletion in the mate
+                k = int(rng.integers(20, rl - 20)); x = np.concatenate([x[:k], g[p0 + k + 3:p0 + rl + 3]])[:rl]
+            is_rev = int(rng.integers(0, 2))
+            reads[i] = synth.revcomp(x) if is_rev else x         # the job aligns the read's reverse complement when is_rev
+            w0 = p0 - int(rng.integers(0, 400)) if i % 5 else int(rng.integers(0, n - 1000))       # every 5th window misses the mate
+            w1 = w0 + int(rng.integers(rl // 2, 700))
+            if i % 13 == 0:                                         # a window on the reverse strand of the text: the mate's complement lies there
+                w0, w1 = 2 * n - w1, 2 * n - w0
+                reads[i] = x if is_rev else synth.revcomp(x)
+            jobs[i].rb, jobs[i].re, jobs[i].read, jobs[i].l_ms, jobs[i].is_rev = max(w0, 0), min(w1, 2 * n), i, rl, is_rev
+            jobs[i].xtra = XSUBO | XSTART | (XBYTE if rl < 250 else 0) | 19
+        r = _to_dev(torch, synth.codes_to_ascii(reads.reshape(-1)))
+        o = (torch.arange(n_reads, dtype=torch.int64) * rl).to(torch.int32).cuda()
+        out = np.zeros((n_reads, 7), np.int32)
+        ep = B.ExtParams.default()
+        L.bmh_matesw_batch_device.restype = C.c_int
+        L.bmh_matesw_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        rc = L.bmh_matesw_batch_device(dindex.handle, r.data_ptr(), o.data_ptr(), C.byref(ep), C.byref(jobs), n_reads, out.ctypes.data_as(C.c_void_p), None)
+        assert rc == 0, L.bmh_last_error()
+        L.bmh_local_sw_c.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        n_hit = n_sub = 0
+        for i in range(n_reads):
+            q = reads[i].copy()
+            if jobs[i].is_rev:
+                q = synth.revcomp(q)
+            t = np.ascontiguousarray(text[jobs[i].rb:jobs[i].re]); q = np.ascontiguousarray(q)
+            want = np.zeros(7, np.int32)
+            L.bmh_local_sw_c(rl, q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), C.byref(ep), jobs[i].xtra, want.ctypes.data_as(C.c_void_p))
+            assert np.array_equal(out[i], want), (rl, i, out[i], want, jobs[i].rb, jobs[i].re, jobs[i].is_rev)
+            n_hit += want[0] >= 19 and want[6] >= 0; n_sub += want[3] > 0
+        assert n_hit > 200 and (rl < 100 or n_sub > 3), (rl, n_hit, n_sub)
+    dindex.free()

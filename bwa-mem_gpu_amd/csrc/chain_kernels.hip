@@ -402,8 +402,17 @@ extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_
 	// (BMH_CHAIN_PRIO=hi | normal: experiment knob -- on workloads where these kernels are the critical path of the stage)
 	const char *pe = getenv("BMH_CHAIN_PRIO");
 	const int cls_prio = pe && pe[0] == 'h' ? prio_hi : pe && pe[0] == 'n' ? 0 : prio_lo;
-	for (int c = 0; c < CH_N_CLASSES; ++c)
-		ok = ok && hipStreamCreateWithPriority(&w->cls_stream[c], hipStreamNonBlocking, cls_prio) == hipSuccess && hipEventCreate(&w->cls_done[c]) == hipSuccess;
+	// (BMH_CHAIN_CUS=n: experiment knob -- the wave kernels' streams confined to n of the chip's compute units, evenly spread, so that
+	// their LDS-hungry waves displace extension waves on those units only; measured in DESIGN.md section 5)
+	const char *cue = getenv("BMH_CHAIN_CUS");
+	const int n_cus = cue ? atoi(cue) : 0;
+	uint32_t cumask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	if (n_cus > 0 && n_cus < 256) for (int i = 0; i < 256; ++i) if ((long)i * n_cus / 256 != (long)(i + 1) * n_cus / 256) cumask[i >> 5] |= 1u << (i & 31);
+	for (int c = 0; c < CH_N_CLASSES; ++c) {
+		if (n_cus > 0 && n_cus < 256) ok = ok && hipExtStreamCreateWithCUMask(&w->cls_stream[c], 8, cumask) == hipSuccess;
+		else ok = ok && hipStreamCreateWithPriority(&w->cls_stream[c], hipStreamNonBlocking, cls_prio) == hipSuccess;
+		ok = ok && hipEventCreate(&w->cls_done[c]) == hipSuccess;
+	}
 	if (!ok) { bmh_set_error("bmh_chain_ws_create: hipMalloc failed (%s)", hipGetErrorString(hipGetLastError())); bmh_chain_ws_free(w); return nullptr; }
 	w->n_contigs = 1;
 	w->materialize = 1;

@@ -144,25 +144,41 @@ struct lt_score_hash {       // (is_alt is 0 everywhere: ALT contigs are not mod
 
 // ---- the patch test's global alignment: ksw_global2's score under bwa_gen_cigar2's band (src/bwa.c:111-216, src/ksw.c:1120-1241),
 // bases read where they are (2-bit reference, the read)
+// what bwa_gen_cigar2 does with read[.., l_query) against text [rb, re) under band w_ (src/bwa.c:111-150): 0 = nothing (score 0),
+// 1 = the ungapped sum (equal lengths, w_ == 0), 2 = ksw_global2 with band *w; *flip: both sequences are walked backwards (a window
+// on the reverse strand)
+RC_HD inline int gen_plan(const ctx_t &x, int w_, int l_query, int64_t rb, int64_t re, int *rlen, bool *flip, int *w_out)
+{
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+	const bmh_ext_params_t &p = x.ep;
+	if (l_query <= 0 || rb >= re || (rb < x.l_pac && re > x.l_pac)) return 0;
+	*rlen = (int)(re - rb);
+	*flip = rb >= x.l_pac;
+	if (l_query == *rlen && w_ == 0) return 1;
+	int max_ins = (int)((double)(((l_query + 1) >> 1) * p.a - p.o_ins) / p.e_ins + 1.);
+	int max_del = (int)((double)(((l_query + 1) >> 1) * p.a - p.o_del) / p.e_del + 1.);
+	int max_gap = max_ins > max_del ? max_ins : max_del;
+	max_gap = max_gap > 1 ? max_gap : 1;
+	const int diff = *rlen > l_query ? *rlen - l_query : l_query - *rlen;
+	int w = (max_gap + diff + 1) >> 1;
+	w = w < w_ ? w : w_;
+	w = w > diff + 3 ? w : diff + 3;
+	*w_out = w;
+	return 2;
+}
 template <bool ASCII>
 RC_HD inline int gen_score(const ctx_t &x, int w_, int l_query, const uint8_t *query, int64_t rb, int64_t re, int *err)
 {
 	const bmh_ext_params_t &p = x.ep;
 	const int64_t l_pac = x.l_pac;
-	if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return 0;
-	const int rlen = (int)(re - rb);
-	const bool flip = rb >= l_pac;
+	int rlen = 0, w = 0; bool flip = false;
+	const int plan = gen_plan(x, w_, l_query, rb, re, &rlen, &flip, &w);
+	if (plan == 0) return 0;
 	auto tb = [&](int i) { return text_base(x.pac, l_pac, flip ? re - 1 - i : rb + i); };
 	auto qb = [&](int i) { return qbase<ASCII>(query, flip ? l_query - 1 - i : i); };
-	if (l_query == rlen && w_ == 0) { int s = 0; for (int i = 0; i < l_query; ++i) s += sc(p, tb(i), qb(i)); return s; }
-	int max_ins = (int)((double)(((l_query + 1) >> 1) * p.a - p.o_ins) / p.e_ins + 1.);
-	int max_del = (int)((double)(((l_query + 1) >> 1) * p.a - p.o_del) / p.e_del + 1.);
-	int max_gap = max_ins > max_del ? max_ins : max_del;
-	max_gap = max_gap > 1 ? max_gap : 1;
-	const int diff = rlen > l_query ? rlen - l_query : l_query - rlen;
-	int w = (max_gap + diff + 1) >> 1;
-	w = w < w_ ? w : w_;
-	w = w > diff + 3 ? w : diff + 3;
+	if (plan == 1) { int s = 0; for (int i = 0; i < l_query; ++i) s += sc(p, tb(i), qb(i)); return s; }
 	if (!x.dp_h) { *err = NEED_DP; return 0; }
 	if (l_query + 2 > x.dp_cap) { *err = E_DPCAP; return 0; }
 	const int NEG = -0x40000000, oe_del = p.o_del + p.e_del, oe_ins = p.o_ins + p.e_ins, qlen = l_query;
@@ -209,23 +225,28 @@ RC_HD inline bool patch_pre(const ctx_t &x, const rec_t &a, const rec_t &b, int 
 	*w_out = w;
 	return true;
 }
-template <bool ASCII>
-RC_HD inline int patch_reg(const ctx_t &x, const uint8_t *query, const rec_t &a, const rec_t &b, int *w_out, int *err)        // mem_patch_reg
+// mem_patch_reg's verdict on the alignment across both regions (src/bwamem.c:606-612): its score, or 0
+RC_HD inline int patch_accept(const rec_t &a, const rec_t &b, int score)
 {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
-	int w;
-	if (!patch_pre(x, a, b, &w)) return 0;
 	const int64_t arb = r_rb(a), are = r_re(a), brb = r_rb(b), bre = r_re(b);
 	const int aqb = a.v[2], aqe = a.v[3], bqb = b.v[2], bqe = b.v[3];
-	const int score = gen_score<ASCII>(x, w, bqe - aqb, query + aqb, arb, bre, err);
-	if (*err) return 0;
 	const int q_s = (int)((double)(bqe - aqb) / ((bqe - bqb) + (aqe - aqb)) * (b.v[1] + a.v[1]) + .499);
 	const int r_s = (int)((double)(bre - arb) / ((bre - brb) + (are - arb)) * (b.v[1] + a.v[1]) + .499);
 	if ((double)score / (q_s > r_s ? q_s : r_s) < 0.90f) return 0;
-	*w_out = w;
 	return score;
+}
+template <bool ASCII>
+RC_HD inline int patch_reg(const ctx_t &x, const uint8_t *query, const rec_t &a, const rec_t &b, int *w_out, int *err)        // mem_patch_reg
+{
+	int w;
+	if (!patch_pre(x, a, b, &w)) return 0;
+	const int score = gen_score<ASCII>(x, w, b.v[3] - a.v[2], query + a.v[2], r_rb(a), r_re(b), err);
+	if (*err) return 0;
+	*w_out = w;
+	return patch_accept(a, b, score);
 }
 
 // does region i of the lt_re-sorted list have a predecessor close enough to be looked at at all?  (the test reads only fields the
@@ -249,6 +270,15 @@ RC_HD inline bool dedup_redundant(const ctx_t &x, const rec_t &p, const rec_t &q
 	const int64_t mq = q.v[3] - q.v[2] < p.v[3] - p.v[2] ? q.v[3] - q.v[2] : p.v[3] - p.v[2];
 	return pr > x.po.mask_level_redun * mr && pq > x.po.mask_level_redun * mq;
 }
+// region q is merged into region p (src/bwamem.c:650-658)
+RC_HD inline void dedup_patch_apply(rec_t *p, rec_t *q, int score, int w)
+{
+	p->v[10] = p->v[10] > q->v[10] ? p->v[10] : q->v[10];
+	p->v[2] = q->v[2]; r_set_rb(*p, r_rb(*q));
+	p->v[8] = p->v[1] = score;
+	p->v[9] = w;
+	q->v[2] = q->v[3];
+}
 // one pair (i, j) of the scan; *stop: region i has been emptied, its scan ends.  Returns 0 or an error
 template <bool ASCII>
 RC_HD inline int dedup_pair(const ctx_t &x, const uint8_t *query, rec_t *p, rec_t *q, bool *stop)
@@ -259,13 +289,7 @@ RC_HD inline int dedup_pair(const ctx_t &x, const uint8_t *query, rec_t *p, rec_
 	if (dedup_redundant(x, *p, *q)) {
 		if (p->v[1] < q->v[1]) { p->v[3] = p->v[2]; *stop = true; }
 		else q->v[3] = q->v[2];
-	} else if (r_rb(*q) < r_rb(*p) && (score = patch_reg<ASCII>(x, query, *q, *p, &w, &err)) > 0) {
-		p->v[10] = p->v[10] > q->v[10] ? p->v[10] : q->v[10];
-		p->v[2] = q->v[2]; r_set_rb(*p, r_rb(*q));
-		p->v[8] = p->v[1] = score;
-		p->v[9] = w;
-		q->v[2] = q->v[3];
-	}
+	} else if (r_rb(*q) < r_rb(*p) && (score = patch_reg<ASCII>(x, query, *q, *p, &w, &err)) > 0) dedup_patch_apply(p, q, score, w);
 	return err;
 }
 template <bool ASCII>

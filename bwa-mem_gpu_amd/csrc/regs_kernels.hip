@@ -32,12 +32,13 @@ using namespace regs_core;
 
 #define FIN_NL 8          // regions of a read the lane kernel takes
 #define FIN_NMAX 512      // regions of a read the wave kernels keep in LDS (classes of 32, 128 and 512 records; in HBM beyond)
-#define FIN_NCLS 4
+#define FIN_NCLS 5
 #define FIN_DPCAP 1024    // query columns (+2) of the patch test's alignment (scratch in HBM, one pair of rows per block: the alignment is rare)
 #define FIN_WAVE_GRID 2048
 #define FIN_CTG_LDS 512     // contig tables up to this size are copied to LDS by the wave kernels
 #define FIN_NLOG 65536
 
+#define FIN_NCLS_PROF 5
 // optional phase stamps of the wave kernels (100 MHz ticks summed over the reads of a class), for tuning: compile with -DFIN_PROFILE
 // (collected in LDS by the block's one wave, flushed when the block ends)
 #if defined(FIN_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -48,7 +49,7 @@ __shared__ unsigned long long g_lprof[16];
 #define FIN_STAMP(k) do { } while (0)
 #define FIN_STAMP_BEGIN() do { } while (0)
 #endif
-__device__ unsigned long long g_fin_prof[4][16];
+__device__ unsigned long long g_fin_prof[FIN_NCLS_PROF][16];
 
 struct fin_args_t {
 	ctx_t x;
@@ -57,10 +58,10 @@ struct fin_args_t {
 	int32_t *work, *work2;            // [n_regs][16] records at in_off; work2 + the arrays below: scratch of reads beyond FIN_NMAX regions
 	uint64_t *g_keys, *g_k128; uint32_t *g_tmp, *g_order; int32_t *g_z;
 	uint32_t *opr; uint32_t n_reads;
-	uint32_t *defer, *ctr;            // defer[c * n_reads ..]: reads handed to wave class c; ctr[c] their number, ctr[4 + c] next to be drawn, ctr[8] error
+	uint32_t *defer, *ctr;            // defer[c * n_reads ..]: reads handed to wave class c; ctr[c] their number, ctr[8 + c] next to be drawn, ctr[16] error
 	int32_t *g_dp;                    // [FIN_NCLS][FIN_WAVE_GRID][2][FIN_DPCAP]
 };
-__device__ __forceinline__ int fin_class(int n) { return n <= 32 ? 0 : n <= 128 ? 1 : n <= FIN_NMAX ? 2 : 3; }
+__device__ __forceinline__ int fin_class(int n) { return n <= 32 ? 0 : n <= 128 ? 1 : n <= 256 ? 2 : n <= FIN_NMAX ? 3 : 4; }
 
 __global__ void __launch_bounds__(256) fin_lane_kernel(fin_args_t A)
 {
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(256) fin_lane_kernel(fin_args_t A)
 		}
 		const int n = finalize_read<true, 1>(A.x, A.reads + A.read_offs[r], r, A.x.po.id0 + r, A.frac_rep[r], n_in, a, z);
 		if (n == -NEED_DP) defer = true;
-		else if (n < 0) { A.ctr[8] = (uint32_t)-n; A.opr[r] = 0; return; }
+		else if (n < 0) { A.ctr[16] = (uint32_t)-n; A.opr[r] = 0; return; }
 		else {
 			for (int i = 0; i < n; ++i) {
 				int4 *dst = (int4 *)(A.work + 16 * (size_t)(off + i));
@@ -237,6 +238,84 @@ template <class KEEP> __device__ int fin_wave_compact(wptr_t &P, const int n, KE
 	return m;
 }
 
+// The patch test's global alignment (regs_core.h: gen_score) by the wave, one target row per step: M of a row depends on the previous
+// row only, E on the column above, and F(j) = max over k < j of M(k) - oe_ins - e_ins (j - 1 - k) is a max-plus prefix scan along
+// the row (ksw_global2 opens its gaps from M, src/ksw.c:1190-1200), so the band's columns are spread over the lanes.  Values that
+// the sequential code carries at "minus infinity" (-0x40000000 less a few gap extensions) may differ here by such small amounts;
+// they never reach the result: every step adds less than 2^20 to a value, a band of w >= |rlen - qlen| + 3 always holds a real path.
+__device__ int fin_wave_gen_score(const ctx_t &x, int w_, int l_query, const uint8_t *query, int64_t rb, int64_t re, int *err)
+{
+	int result = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	using namespace chain_core;
+	const bmh_ext_params_t &p = x.ep;
+	const int lane = ch_lane();
+	int rlen = 0, w = 0; bool flip = false;
+	const int plan = gen_plan(x, w_, l_query, rb, re, &rlen, &flip, &w);
+	if (plan == 0) return 0;
+	auto tb = [&](int i) { return text_base(x.pac, x.l_pac, flip ? re - 1 - i : rb + i); };
+	auto qb = [&](int i) { return qbase<true>(query, flip ? l_query - 1 - i : i); };
+	if (plan == 1) {
+		int sum = 0;
+		for (int i = lane; i < l_query; i += 64) sum += sc(p, tb(i), qb(i));
+		for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
+		return sum;
+	}
+	if (l_query + 2 > x.dp_cap) { *err = E_DPCAP; return 0; }
+	if (2 * w + 1 > 512) {                                        // a band beyond eight columns per lane: lane 0 alone, as in the core
+		int sc1 = 0, e1 = 0;
+		if (lane == 0) sc1 = gen_score<true>(x, w_, l_query, query, rb, re, &e1);
+		*err = __builtin_amdgcn_readfirstlane(e1);
+		ch_wave_fence<false>();
+		return __builtin_amdgcn_readfirstlane(sc1);
+	}
+	const int NEG = -0x40000000, oe_del = p.o_del + p.e_del, oe_ins = p.o_ins + p.e_ins, qlen = l_query;
+	int32_t *Hd = x.dp_h, *E = x.dp_e;
+	for (int j = lane; j <= qlen; j += 64) { Hd[j] = j == 0 ? 0 : (j <= w ? -(p.o_ins + p.e_ins * j) : NEG); E[j] = NEG; }
+	ch_wave_fence<false>();
+	for (int i = 0; i < rlen; ++i) {
+		const int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		const int ti = tb(i);
+		const int C = (end - beg + 63) >> 6;                       // columns per lane (<= 8), contiguous: lane l owns beg + l C .. beg + l C + C - 1
+		const int j0 = beg + lane * C;
+		int mbuf[8], ebuf[8];
+		int gown = NEG;                                           // largest g = M + e_ins k of the lane's columns: what they send to the columns on their right
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			const int j = j0 + c;
+			mbuf[c] = NEG; ebuf[c] = NEG;
+			if (c < C && j < end) {
+				mbuf[c] = Hd[j] + sc(p, ti, qb(j)); ebuf[c] = E[j];
+				const int gk = mbuf[c] + p.e_ins * j; gown = gown > gk ? gown : gk;
+			}
+		}
+		int incl = gown;                                          // inclusive max-scan over the lanes, then the exclusive value
+		for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl = incl > t ? incl : t; }
+		int G = __shfl_up(incl, 1);
+		if (lane == 0) G = NEG;
+		ch_wave_fence<false>();                                   // every lane has read its Hd / E: Hd[j + 1] below is the next lane's first column
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			const int j = j0 + c;
+			if (c < C && j < end) {
+				const int m = mbuf[c];
+				int e = ebuf[c];
+				const int f = G <= NEG ? NEG : G - oe_ins - p.e_ins * (j - 1);
+				int h = m >= e ? m : e;
+				h = h >= f ? h : f;
+				Hd[j + 1] = h;
+				const int y = m - oe_del; e -= p.e_del; E[j] = e > y ? e : y;
+				const int gk = m + p.e_ins * j; G = G > gk ? G : gk;
+			}
+		}
+		if (lane == 0) { Hd[beg] = beg == 0 ? -(p.o_del + p.e_del * (i + 1)) : NEG; E[end] = NEG; }
+		ch_wave_fence<false>();
+	}
+	result = Hd[qlen];
+#endif
+	return result;
+}
+
 // Iteration i of mem_sort_dedup_patch's scan (regs_core.h: dedup_one) with the regions of its window looked at 64 at a time.  What
 // happens to a pair (i, j) depends on the other pairs only through region i itself, and region i changes only when it is emptied
 // (the scan ends) or when the patch test reaches its global alignment (rare): up to the first such pair of a step every lane settles
@@ -271,12 +350,20 @@ __device__ int fin_wave_dedup_one(const ctx_t &x, const uint8_t *query, const in
 		ch_wave_fence<false>();
 		if (first_ev < 64) {
 			const int jev = jtop - first_ev;
-			int err = 0, stop = 0;
-			if (lane == 0) { bool st; err = dedup_pair<true>(x, query, &a[i], &a[jev], &st); stop = st ? 1 : 0; }
-			err = __builtin_amdgcn_readfirstlane(err); stop = __builtin_amdgcn_readfirstlane(stop);
-			ch_wave_fence<false>();
+			const bool ev_dies = __builtin_amdgcn_readlane(pdies ? 1 : 0, first_ev) != 0;
+			if (ev_dies) {                                            // region i is the lower-scoring one of a redundant pair: emptied, its scan ends
+				if (lane == 0) a[i].v[3] = a[i].v[2];
+				ch_wave_fence<false>();
+				return 0;
+			}
+			// the patch test reaches its global alignment: the alignment by the whole wave, the verdict and the merge by lane 0
+			int w = 0, err = 0;
+			const rec_t pe = a[i], qe = a[jev];
+			patch_pre(x, qe, pe, &w);
+			const int score = fin_wave_gen_score(x, w, pe.v[3] - qe.v[2], query + qe.v[2], r_rb(qe), r_re(pe), &err);
 			if (err) return err;
-			if (stop) return 0;
+			if (lane == 0 && patch_accept(qe, pe, score) > 0) dedup_patch_apply(&a[i], &a[jev], score, w);
+			ch_wave_fence<false>();
 			jtop = jev - 1;
 			continue;
 		}
@@ -449,7 +536,7 @@ __global__ void __launch_bounds__(64) fin_wave_kernel(fin_args_t A)
 	const uint32_t *list = A.defer + (size_t)CLS * A.n_reads;
 	for (;;) {
 		uint32_t t = 0;
-		if (lane == 0) t = atomicAdd(&A.ctr[4 + CLS], 1u);
+		if (lane == 0) t = atomicAdd(&A.ctr[8 + CLS], 1u);
 		t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
 		if (t >= n_def) break;
 		const uint32_t r = list[t];
@@ -469,7 +556,7 @@ __global__ void __launch_bounds__(64) fin_wave_kernel(fin_args_t A)
 		}
 		ch_wave_fence<false>();
 		const int n = fin_wave_read<NMAX == 0>(x, A.reads + A.read_offs[r], r, x.po.id0 + r, A.frac_rep[r], n_in, P, lstage);
-		if (n < 0) { if (lane == 0) { A.ctr[8] = (uint32_t)-n; A.opr[r] = 0; } continue; }
+		if (n < 0) { if (lane == 0) { A.ctr[16] = (uint32_t)-n; A.opr[r] = 0; } continue; }
 		rec_t *dst = (rec_t *)(A.work + 16 * (size_t)off);
 		if (P.a != dst) for (int i = lane; i < n; i += 64) dst[i] = P.a[i];
 		if (lane == 0) A.opr[r] = (uint32_t)n;
@@ -558,7 +645,7 @@ extern "C" int64_t bmh_finalize_regs_device(const bmh_index_t *idx, const bmh_ch
 		free(h);
 		HIPCK(hipEventCreate(&S->ev0)); HIPCK(hipEventCreate(&S->ev1));
 		HIPCK(hipHostMalloc((void **)&S->h_pin, 128));
-		if (fin_grow(S->ctr, 16) != BMH_OK || fin_grow(S->g_dp, (size_t)FIN_NCLS * FIN_WAVE_GRID * 2 * FIN_DPCAP) != BMH_OK) return BMH_ENOMEM;
+		if (fin_grow(S->ctr, 32) != BMH_OK || fin_grow(S->g_dp, (size_t)FIN_NCLS * FIN_WAVE_GRID * 2 * FIN_DPCAP) != BMH_OK) return BMH_ENOMEM;
 		HIPCK(hipEventCreateWithFlags(&S->fork, hipEventDisableTiming));
 		for (int i = 0; i < 3; ++i) { HIPCK(hipStreamCreateWithFlags(&S->side[i], hipStreamNonBlocking)); HIPCK(hipEventCreateWithFlags(&S->join[i], hipEventDisableTiming)); }
 	}
@@ -591,7 +678,7 @@ extern "C" int64_t bmh_finalize_regs_device(const bmh_index_t *idx, const bmh_ch
 	A.work = S->work; A.work2 = S->work2; A.g_keys = S->g_keys; A.g_k128 = S->g_k128; A.g_tmp = S->g_tmp; A.g_order = S->g_order; A.g_z = S->g_z;
 	A.opr = d_out_per_read; A.n_reads = n_reads; A.defer = S->defer; A.ctr = S->ctr; A.g_dp = S->g_dp;
 	HIPCK(hipEventRecord(S->ev0, st));
-	HIPCK(hipMemsetAsync(S->ctr, 0, 64, st));
+	HIPCK(hipMemsetAsync(S->ctr, 0, 128, st));
 	size_t tb = S->scan_bytes;
 	HIPCK(rocprim::exclusive_scan(S->scan_tmp, tb, d_regs_per_read, S->in_off, 0u, (size_t)n_reads, rocprim::plus<uint32_t>(), st));
 	static const bool want_phases = getenv("BMH_FIN_PHASES") != nullptr;      // debug: time of the kernels of every call
@@ -601,20 +688,22 @@ extern "C" int64_t bmh_finalize_regs_device(const bmh_index_t *idx, const bmh_ch
 	fin_lane_kernel<<<(n_reads + 255) / 256, 256, 0, st>>>(A);
 	if (want_phases) HIPCK(hipEventRecord(ph[1], st));
 	// the wave classes side by side (their lists are short and uneven: the class of the largest reads is a handful of long jobs)
-	static thread_local hipEvent_t pc[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	static thread_local hipEvent_t pc[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	if (want_phases) {                       // (debug: one class after the other, each timed)
 		if (!pc[0]) for (hipEvent_t &e : pc) HIPCK(hipEventCreate(&e));
 		HIPCK(hipEventRecord(pc[0], st));
 		fin_wave_kernel<32, 0><<<FIN_WAVE_GRID, 64, 0, st>>>(A); HIPCK(hipEventRecord(pc[1], st));
 		fin_wave_kernel<128, 1><<<FIN_WAVE_GRID, 64, 0, st>>>(A); HIPCK(hipEventRecord(pc[2], st));
-		fin_wave_kernel<FIN_NMAX, 2><<<FIN_WAVE_GRID, 64, 0, st>>>(A); HIPCK(hipEventRecord(pc[3], st));
-		fin_wave_kernel<0, 3><<<FIN_WAVE_GRID, 64, 0, st>>>(A); HIPCK(hipEventRecord(pc[4], st));
+		fin_wave_kernel<256, 2><<<FIN_WAVE_GRID, 64, 0, st>>>(A); HIPCK(hipEventRecord(pc[3], st));
+		fin_wave_kernel<FIN_NMAX, 3><<<FIN_WAVE_GRID, 64, 0, st>>>(A); HIPCK(hipEventRecord(pc[4], st));
+		fin_wave_kernel<0, 4><<<FIN_WAVE_GRID, 64, 0, st>>>(A); HIPCK(hipEventRecord(pc[5], st));
 	} else {
 		HIPCK(hipEventRecord(S->fork, st));
 		for (int i = 0; i < 3; ++i) HIPCK(hipStreamWaitEvent(S->side[i], S->fork, 0));
-		fin_wave_kernel<FIN_NMAX, 2><<<FIN_WAVE_GRID, 64, 0, S->side[0]>>>(A);
-		fin_wave_kernel<0, 3><<<FIN_WAVE_GRID, 64, 0, S->side[1]>>>(A);
-		fin_wave_kernel<128, 1><<<FIN_WAVE_GRID, 64, 0, S->side[2]>>>(A);
+		fin_wave_kernel<FIN_NMAX, 3><<<FIN_WAVE_GRID, 64, 0, S->side[0]>>>(A);
+		fin_wave_kernel<0, 4><<<FIN_WAVE_GRID, 64, 0, S->side[1]>>>(A);
+		fin_wave_kernel<256, 2><<<FIN_WAVE_GRID, 64, 0, S->side[2]>>>(A);
+		fin_wave_kernel<128, 1><<<FIN_WAVE_GRID, 64, 0, S->side[0]>>>(A);
 		fin_wave_kernel<32, 0><<<FIN_WAVE_GRID, 64, 0, st>>>(A);
 		for (int i = 0; i < 3; ++i) { HIPCK(hipEventRecord(S->join[i], S->side[i])); HIPCK(hipStreamWaitEvent(st, S->join[i], 0)); }
 	}
@@ -624,33 +713,33 @@ extern "C" int64_t bmh_finalize_regs_device(const bmh_index_t *idx, const bmh_ch
 	fin_compact_kernel<<<(n_reads + 255) / 256, 256, 0, st>>>(S->work, S->in_off, S->out_off, d_out_per_read, n_reads, d_out);
 	HIPCK(hipMemcpyAsync(S->h_pin, S->out_off + (n_reads - 1), 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipMemcpyAsync(S->h_pin + 1, d_out_per_read + (n_reads - 1), 4, hipMemcpyDeviceToHost, st));
-	HIPCK(hipMemcpyAsync(S->h_pin + 2, S->ctr, 36, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(S->h_pin + 2, S->ctr, 68, hipMemcpyDeviceToHost, st));
 	HIPCK(hipEventRecord(S->ev1, st));
 	HIPCK(hipStreamSynchronize(st));
 	HIPCK(hipGetLastError());
 	if (want_phases) {
 		float a = 0, b = 0, c = 0;
 		(void)hipEventElapsedTime(&a, ph[0], ph[1]); (void)hipEventElapsedTime(&b, ph[1], ph[2]); (void)hipEventElapsedTime(&c, ph[2], S->ev1);
-		float q[4] = {0, 0, 0, 0};
-		for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&q[i], pc[i], pc[i + 1]);
+		float q[5] = {0, 0, 0, 0, 0};
+		for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&q[i], pc[i], pc[i + 1]);
 #ifdef FIN_PROFILE
 		{
-			unsigned long long hh[4][16];
+			unsigned long long hh[5][16];
 			(void)hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_fin_prof), sizeof(hh));
-			unsigned long long z16[4][16] = {{0}};
+			unsigned long long z16[5][16] = {{0}};
 			(void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_prof), z16, sizeof(z16));
-			for (int c = 0; c < 4; ++c) {
+			for (int c = 0; c < 5; ++c) {
 				const unsigned long long *h = hh[c];
 				fprintf(stderr, "[finalize] class %d wave-ms: blocks alive %.1f (longest %.3f) | init %.1f | sort1 %.1f dedup %.1f compact %.1f | sort2 %.1f equal+compact %.1f | sort3 %.1f mark %.1f emit %.1f || in the sorts: keys+ranks %.1f introsort %.1f place %.1f permute %.1f\n", c,
 				        h[15] / 1e5, h[14] / 1e5, h[0] / 1e5, h[1] / 1e5, h[2] / 1e5, h[3] / 1e5, h[4] / 1e5, h[5] / 1e5, h[6] / 1e5, h[7] / 1e5, h[8] / 1e5, h[10] / 1e5, h[11] / 1e5, h[12] / 1e5, h[13] / 1e5);
 			}
 		}
 #endif
-		fprintf(stderr, "[finalize] wave classes one after the other: %.3f / %.3f / %.3f / %.3f ms\n", q[0], q[1], q[2], q[3]);
-		fprintf(stderr, "[finalize] %u reads, %llu regions: lane kernel %.3f ms, wave kernels %.3f ms (%u / %u / %u / %u reads with up to 32 / 128 / 512 / more regions), scan + compaction %.3f ms\n", n_reads, (unsigned long long)n_regs, a, b, S->h_pin[2], S->h_pin[3], S->h_pin[4], S->h_pin[5], c);
+		fprintf(stderr, "[finalize] wave classes one after the other: %.3f / %.3f / %.3f / %.3f / %.3f ms\n", q[0], q[1], q[2], q[3], q[4]);
+		fprintf(stderr, "[finalize] %u reads, %llu regions: lane kernel %.3f ms, wave kernels %.3f ms (%u / %u / %u / %u / %u reads with up to 32 / 128 / 256 / 512 / more regions), scan + compaction %.3f ms\n", n_reads, (unsigned long long)n_regs, a, b, S->h_pin[2], S->h_pin[3], S->h_pin[4], S->h_pin[5], S->h_pin[6], c);
 	}
-	if (S->h_pin[10] != 0) {
-		const uint32_t e = S->h_pin[10];
+	if (S->h_pin[18] != 0) {
+		const uint32_t e = S->h_pin[18];
 		bmh_set_error("bmh_finalize_regs_device: %s", e == E_LOG ? "a region longer than the logarithm table (65535)" : e == E_DPCAP ? "a patch alignment beyond the kernel's capacity (query side of 1022 bases) or a sort beyond its stack" : "internal error");
 		return BMH_ECAPACITY;
 	}

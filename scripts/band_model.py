@@ -88,3 +88,26 @@ for lo, hi in ((3, 3), (4, 4), (5, 6), (7, 9), (10, 19), (20, 39), (40, 999)):
     print(f"  mm {lo:3d}-{hi:3d}: jobs {m.sum():6d} share of computed {(kr * cc)[m].sum() / tot:.3f} mean rows {kr[m].mean():.0f} mean qlen {ql[m].mean():.0f} reached end (gscore>0) {(np.maximum.reduceat(GS, off[:-1][rows>0])[m[rows>0]] > 0).mean() if m.any() else 0:.2f}")
 m = dp & ~((mm <= 2)) 
 print("  tlen < qlen jobs among DP:", (dp & (tl < ql)).sum())
+
+# ---- a narrow sliding window for the flanks that look unrelated: W columns as four lane blocks that follow `beg`; a job whose band
+# outgrows the window is redone in its full class.  Routed by the mismatches among the first 32 diagonal columns (the prefilter sees them).
+if len(sys.argv) > 2 and sys.argv[2] == "window":
+    kr = rules["non-zero frontier + out3 rule"]
+    mm32 = np.zeros(nj, np.int64)
+    for i in range(nj):
+        n = min(int(ql[i]), int(tl[i]), 32)
+        a = q[qoff[i]: qoff[i] + n]; b = t[toff[i]: toff[i] + n]
+        mm32[i] = int(((a != b) | (a > 3) | (b > 3)).sum())
+    first = rowidx == 0
+    end2 = np.where(first, np.minimum(end, np.minimum(ql[jobid], np.maximum(hh[jobid] - 6, 0) + 1)), end)
+    inr = (rowidx < kr[jobid]) & dp[jobid]
+    base_cost = (kr * cc)[dp].sum()
+    for W in (32, 48, 64):
+        B = W // 4
+        over = (end2 > (beg // B) * B + W) & inr
+        fo = np.full(nj, 10 ** 9); np.minimum.at(fo, jobid[over], rowidx[over])
+        fits = fo == 10 ** 9
+        for T in (6, 8, 10, 12, 16):
+            use = dp & (cc > W) & (mm32 >= T)
+            cost = np.where(use, np.where(fits, kr * W, np.minimum(fo, kr) * W + kr * cc), kr * cc)
+            print(f"  W={W} mm32>={T}: routed {use.sum():6d} fit {(use & fits).sum():6d}  cost ratio {cost[dp].sum() / base_cost:.3f}")

@@ -4,9 +4,10 @@ scripts/build_dropin.sh, linked against libbwamem_hip.so) on BASELINE.json confi
 against the simulation truth (position/strand of every read).
 -K keeps the whole file in one batch whatever -t is (insert-size statistics are per batch).  NOTE: with -t >= 4 the
 reference's own host code is not deterministic on hard read sets (regions with garbage scores, e.g. AS:i:7227, that
-change from run to run -- also with every library call serialised, and the results the library hands over are
-checked in bounds: BMH_GASAL_CHECK / BMH_GASAL_SYNC, scripts/e2e_race_probe.py); -t 1 and -t 2 are deterministic
-and that is what the byte-for-byte comparison uses."""
+change from run to run): mem_align1_core indexes seq[] with a batch-relative read index where it collects its results
+(src/bwamem.c:2228, 2251, 2295, 2313), so the patch test aligns another worker's read, possibly while that worker converts
+it in place (scripts/e2e_seqidx_probe.sh; E2E_EXE=bwa-gasal2-seqidx runs the build with those four
+subscripts corrected).  The stock build is compared at -t 1 with -K, where relative and absolute index coincide."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))

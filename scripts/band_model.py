@@ -111,3 +111,27 @@ if len(sys.argv) > 2 and sys.argv[2] == "window":
             use = dp & (cc > W) & (mm32 >= T)
             cost = np.where(use, np.where(fits, kr * W, np.minimum(fo, kr) * W + kr * cc), kr * cc)
             print(f"  W={W} mm32>={T}: routed {use.sum():6d} fit {(use & fits).sum():6d}  cost ratio {cost[dp].sum() / base_cost:.3f}")
+
+# ---- re-binning at row checkpoints: every K rows a job whose leftmost lane blocks are dead (beg past them) continues in the class that
+# is narrower by those blocks; each move is charged MOVE rows of the job's current width.  Upper part of the wedge (end still growing)
+# stays as it is.
+if len(sys.argv) > 2 and sys.argv[2] == "rebin":
+    kr = rules["non-zero frontier + out3 rule"]
+    inr = (rowidx < kr[jobid]) & dp[jobid]
+    base_cost = (kr * cc)[dp].sum()
+    Bw = np.maximum(cc // 4, 8)[jobid]                       # lane block of the job's class (4-lane groups; wider groups: same quarter)
+    for K in (16, 32, 64):
+        for MOVE in (4, 8, 16):
+            ck = (rowidx // K) * K                            # last checkpoint row
+            # beg at the last checkpoint: take beg of row ck of the same job
+            idx_ck = off[jobid] + np.minimum(ck, rows[jobid] - 1)
+            beg_ck = np.where(ck > 0, beg[idx_ck], 0)
+            dead = (beg_ck // Bw) * Bw
+            width = (cc[jobid] - dead).clip(8)
+            cost_rows = (width * inr).sum()
+            # number of moves: checkpoints where dead blocks increased
+            prev_idx = off[jobid] + np.minimum(np.maximum(ck - K, 0), rows[jobid] - 1)
+            dead_prev = np.where(ck - K > 0, (beg[prev_idx] // Bw) * Bw, 0)
+            moved = inr & (rowidx == ck) & (ck > 0) & (dead > dead_prev)
+            cost_moves = (MOVE * cc[jobid] * moved).sum()
+            print(f"  checkpoint every {K:2d} rows, a move costs {MOVE:2d} rows: moves per DP job {moved.sum() / dp.sum():.2f}  cost ratio {(cost_rows + cost_moves) / base_cost:.3f}")

@@ -210,12 +210,10 @@ class Aligner:
             if self.profile:
                 torch.cuda.synchronize(); _t.append(time.perf_counter()); _nm.append(name)
         lens, offs, ascii_ = rs.lens, np.ascontiguousarray(rs.offs), rs.ascii
-        # the reference's seed filter mem_flt_chained_seeds (src/bwamem.c:970-991: reads beyond ~730 bp, or a small -W) is host code
-        # there and here: batches it applies to go through bmh_build_jobs (which restates it) instead of the device job builder
-        mcw = self.copt.min_chain_weight
-        lf = lens.astype(np.float64)
-        min_l = np.full(n, float(np.float32(1.1) * np.float32(mcw))) if mcw else 5.5 * np.log(np.maximum(lf, 2.0))
-        host_jobs = bool(((lens >= self.copt.min_seed_len) & ~(min_l > (np.float32(0.05) * lens.astype(np.float32)).astype(np.float64))).any())
+        # the device job builder takes reads of up to 700 bases (CH_MAX_READ_LEN, csrc/chain_core.h: the extension kernels' classes end at
+        # 768 columns), the reference's seed filter mem_flt_chained_seeds (src/bwamem.c:970-991) included when a small -W makes it apply;
+        # a batch with a longer read (where the filter applies without -W, beyond ~730 bp) goes through bmh_build_jobs
+        host_jobs = bool((lens > 700).any())
         if int(lens.sum()) >= 1 << 31:
             raise ValueError("a batch holds 2^31 bases or more: offsets inside a batch are 32-bit (use a smaller batch_reads)")
         codes = _NT4[ascii_]
@@ -236,7 +234,7 @@ class Aligner:
             hj = HostJobs(self.l_pac, codes, offs, lens, seeds_to_host(s, n), n_threads=self.n_threads, opt=self.copt,
                           contigs=self.contigs if len(self.contigs) > 1 else None, pac=self.pac)
             nr, nj = hj.n_regs, hj.n_jobs
-            _lap("chain (host builder with the seed filter)")
+            _lap("chain (host builder: a read beyond 700 bp)")
             out3 = torch.zeros(max(nj, 1), 3, dtype=torch.int32, device=dev)
             if nj:
                 d = [torch.from_numpy(np.ascontiguousarray(x).view(np.int32) if x.dtype == np.uint32 else np.ascontiguousarray(x)).to(dev) for x in hj.jobs()]

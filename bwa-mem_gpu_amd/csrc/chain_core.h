@@ -42,12 +42,14 @@ struct ch_ctx_t {
 	int64_t l_pac; int n_contigs; const int64_t *ctg_off; const int32_t *ctg_len;
 	const uint64_t *rbeg; const int32_t *qbeg; const uint32_t *score, *n_ref, *prefix;   // mem_seed_v_gpu arrays
 	const uint32_t *read_lens;
+	// the seed filter (FLT forms of chain_read only): the reads (letters or nt4 codes, both are understood), their offsets, the 2-bit reference
+	const uint8_t *reads; const uint32_t *read_offs; const uint8_t *pac;
 	// global scratch, every array indexed by prefix[read] + local index
 	ch_scr_t g;
 	ch_reg_t *regs;               // output slots, prefix[read] + i in creation order
 	uint32_t *regs_per_read, *jobs_per_read;
 	float *frac_rep;              // per read: part of the read covered by SMEMs with more than max_occ occurrences (mem_chain :415-459)
-	int *err;                     // 1: a read the reference's seed filter applies to (longer than ~730 bp, or a small -W): host builder only
+	int *err;                     // 1: a read longer than CH_MAX_READ_LEN, or one the reference's seed filter applies to in a form compiled without it
 	long long *prof; uint32_t prof_read;
 };
 
@@ -541,6 +543,114 @@ template <bool LDSX> __device__ inline bool ch_kept_by_classes(const bmh_chain_o
 }
 #endif
 
+// ---------------------------------------------------------------- mem_flt_chained_seeds (src/bwamem.c:970-991) + mem_seed_sw (:774-807)
+// Does the filter run for a read of this length?  (:972-977; MEM_HSP_COEF 1.1f and MEM_SEEDSW_COEF 0.05f are float constants there:
+// the products are formed in float, the comparison in double.)  The logarithm only matters without -W, i.e. beyond ~730 bp.
+CH_HD inline bool seed_filter_applies(const bmh_chain_opt_t &o, int l_query, int *min_HSP_score)
+{
+	const double min_l = o.min_chain_weight ? (double)(1.1f * (float)o.min_chain_weight) : (double)5.5f * log((double)l_query);
+	if (min_HSP_score) *min_HSP_score = (int)(o.a * min_l + .499);
+	return !(min_l > (double)(0.05f * (float)l_query));
+}
+CH_HD inline int ch_nt4(uint8_t c) { if (c <= 4) return c; c &= 0xDF; return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
+CH_HD inline int ch_text_base(const uint8_t *pac, int64_t l_pac, int64_t i)    // symbol i of fwd . revcomp(fwd); bns_get_seq src/bntseq.c:558-580
+{
+	const bool rev = i >= l_pac;
+	const int64_t p = rev ? (l_pac << 1) - 1 - i : i;
+	const int c = (pac[p >> 2] >> ((~p & 3) << 1)) & 3;
+	return rev ? 3 - c : c;
+}
+// Score of ksw_align2(qlen, query, tlen, target, 5, mat, ..., KSW_XSTART, 0) (src/ksw.c:389-740 through ksw_i16 :539-665): the striped
+// SSE2 kernel walked by one thread, lane by lane -- eight 16-bit lanes, lane l owning the query positions l slen .. l slen + slen - 1,
+// E taken before the lazy-F correction, the lazy-F loop with its exit test, as csrc/local_sw.cpp (the host form, pinned to the
+// reference binary's records) and csrc/pair_kernels.hip (sixteen GPU lanes per alignment) do.  Only the score is wanted here.
+#define CH_SW_MAXQ 200          // MEM_SHORT_LEN: mem_seed_sw gives up on windows of 200 bases or more
+template <class QB, class TB> CH_HD inline int seed_sw_score(const bmh_chain_opt_t &o, int qlen, QB qbase, int tlen, TB tbase)
+{
+	constexpr int L = 8;
+	const int slen = (qlen + L - 1) / L, n = slen * L;
+	int16_t H0[CH_SW_MAXQ + L], H1[CH_SW_MAXQ + L], Ev[CH_SW_MAXQ + L]; int8_t Q[CH_SW_MAXQ + L];
+	for (int j = 0; j < slen; ++j)
+		for (int l = 0; l < L; ++l) { const int k = j + l * slen; H0[j * L + l] = H1[j * L + l] = Ev[j * L + l] = 0; Q[j * L + l] = (int8_t)(k < qlen ? qbase(k) : 5); }
+	const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins;
+	auto sat0 = [](int v) { return v < 0 ? 0 : v; };
+	int16_t *h0 = H0, *h1 = H1;
+	int gmax = 0;
+	for (int i = 0; i < tlen; ++i) {
+		const int t = tbase(i);
+		int hv[L], f[L], mxv[L];
+		for (int l = 0; l < L; ++l) { hv[l] = l ? h0[(slen - 1) * L + l - 1] : 0; f[l] = 0; mxv[l] = 0; }
+		for (int j = 0; j < slen; ++j) {
+			for (int l = 0; l < L; ++l) {
+				const int q = Q[j * L + l];
+				const int sc = q == 5 ? 0 : (t > 3 || q > 3) ? -1 : (t == q ? o.a : -o.b);
+				int h = hv[l] + sc; h = h > 32767 ? 32767 : h < -32768 ? -32768 : h;
+				int e = Ev[j * L + l];
+				h = h > e ? h : e; h = h > f[l] ? h : f[l];
+				mxv[l] = mxv[l] > h ? mxv[l] : h;
+				h1[j * L + l] = (int16_t)h;
+				const int hu = h & 0xffff;                               // _mm_subs_epu16 reads the 16 bits as unsigned
+				const int e1 = sat0(e - o.e_del), e2 = sat0(hu - oe_del);
+				Ev[j * L + l] = (int16_t)(e1 > e2 ? e1 : e2);
+				const int f1 = sat0(f[l] - o.e_ins), f2 = sat0(hu - oe_ins);
+				f[l] = f1 > f2 ? f1 : f2;
+				hv[l] = h0[j * L + l];
+			}
+		}
+		for (int k = 0; k < 16; ++k) {                                   // lazy F (src/ksw.c:627-638)
+			for (int l = L - 1; l > 0; --l) f[l] = f[l - 1];
+			f[0] = 0;
+			bool done = false;
+			for (int j = 0; j < slen; ++j) {
+				bool any = false;
+				for (int l = 0; l < L; ++l) {
+					int h = h1[j * L + l]; h = h > f[l] ? h : f[l];
+					h1[j * L + l] = (int16_t)h;
+					h = sat0((h & 0xffff) - oe_ins);
+					f[l] = sat0(f[l] - o.e_ins);
+					if (f[l] > h) any = true;
+				}
+				if (!any) { done = true; break; }
+			}
+			if (done) break;
+		}
+		int imax = 0;
+		for (int l = 0; l < L; ++l) imax = imax > mxv[l] ? imax : mxv[l];
+		if (imax > gmax) gmax = imax;
+		int16_t *tmp = h0; h0 = h1; h1 = tmp;
+	}
+	(void)n;
+	return gmax;
+}
+// mem_seed_sw :774-807: local alignment score of the seed's neighbourhood (50 bases either side), -1 when the seed or its window is
+// long enough to be trusted as it is
+CH_HD inline int seed_sw(const ch_ctx_t &x, uint32_t r, int l_query, const ch_seed_t &s)
+{
+	const int SHORT_EXT = 50, SHORT_LEN = CH_SW_MAXQ;                    // MEM_SHORT_EXT, MEM_SHORT_LEN
+	const int64_t l_pac = x.l_pac;
+	if (s.len >= SHORT_LEN) return -1;
+	int qb = s.qbeg, qe = s.qbeg + s.len;
+	int64_t rb = s.rbeg, re = s.rbeg + s.len;
+	const int64_t mid = (rb + re) >> 1;
+	qb -= SHORT_EXT; qb = qb > 0 ? qb : 0;
+	qe += SHORT_EXT; qe = qe < l_query ? qe : l_query;
+	rb -= SHORT_EXT; rb = rb > 0 ? rb : 0;
+	re += SHORT_EXT; re = re < l_pac << 1 ? re : l_pac << 1;
+	if (rb < l_pac && l_pac < re) { if (mid < l_pac) re = l_pac; else rb = l_pac; }
+	if (qe - qb >= SHORT_LEN || re - rb >= SHORT_LEN) return -1;
+	{   // bns_fetch_seq(bns, pac, &rb, mid, &re, &rid): the window is clipped to the sequence that holds mid (src/bntseq.c:531-556)
+		int is_rev;
+		const int rid = pos2rid<false>(x, depos(x, mid, &is_rev));
+		int64_t far_beg = x.n_contigs > 1 ? x.ctg_off[rid] : 0, far_end = far_beg + (x.n_contigs > 1 ? x.ctg_len[rid] : l_pac);
+		if (is_rev) { const int64_t tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
+		rb = rb > far_beg ? rb : far_beg;
+		re = re < far_end ? re : far_end;
+	}
+	const uint8_t *query = x.reads + x.read_offs[r] + qb;
+	const uint8_t *pac = x.pac;
+	return seed_sw_score(x.o, qe - qb, [&](int k) { return ch_nt4(query[k]); }, (int)(re - rb), [&](int i) { return ch_text_base(pac, l_pac, rb + i); });
+}
+
 CH_HD inline ch_scr_t global_scratch(const ch_ctx_t &x, uint32_t r)
 {
 	const uint32_t b = x.prefix[r];
@@ -551,7 +661,7 @@ CH_HD inline ch_scr_t global_scratch(const ch_ctx_t &x, uint32_t r)
 }
 
 // The read: returns through x.regs (slot order = creation order), x.regs_per_read[r], x.jobs_per_read[r].
-template <bool COOP, bool LDSX = false> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const ch_scr_t &sc)
+template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const ch_scr_t &sc)
 {
 	const bmh_chain_opt_t &o = x.o;
 	const uint32_t base = x.prefix[r];
@@ -562,11 +672,12 @@ template <bool COOP, bool LDSX = false> CH_HD void chain_read(const ch_ctx_t &x,
 	uint32_t *klist = sc.klist; uint64_t *srt = sc.srt; uint32_t *cidx = sc.cidx; ch_est_t *E = sc.E; ch_reg_t *R = x.regs + base;
 	x.regs_per_read[r] = 0; x.jobs_per_read[r] = 0; x.frac_rep[r] = 0.f;
 	if (n == 0 || l_query < o.min_seed_len) return;
-	{   // the reference's seed filter (mem_flt_chained_seeds, src/bwamem.c:970-991) is host code, restated in bmh_build_jobs only: a
-		// read it applies to -- (W ? 1.1f W : 5.5 ln l) <= 0.05f l, i.e. beyond ~730 bp or a small -W -- is refused here
-		const double min_l = o.min_chain_weight ? (double)(1.1f * (float)o.min_chain_weight) : (double)5.5f * log((double)l_query);
-		if (l_query > CH_MAX_READ_LEN || !(min_l > (double)(0.05f * (float)l_query))) { *x.err = 1; return; }
-	}
+	// the reference's seed filter (mem_flt_chained_seeds, src/bwamem.c:970-991) applies to a read with (W ? 1.1f W : 5.5 ln l) <= 0.05f l,
+	// i.e. a small -W or more than ~730 bp: the FLT forms run it (below, between mem_chain_flt and mem_chain2aln), the others refuse
+	// the read, and so does every form a read longer than the extension kernels' classes reach
+	int min_HSP_score = 0;
+	const bool flt_on = seed_filter_applies(o, l_query, &min_HSP_score);
+	if (l_query > CH_MAX_READ_LEN || (flt_on && !FLT)) { *x.err = 1; return; }
 	const uint64_t *g_rbeg = x.rbeg + base; const int32_t *g_qbeg = x.qbeg + 2 * (size_t)base; const uint32_t *g_score = x.score + base;
 
 	// ---------------------------------------------------------------- mem_chain
@@ -886,6 +997,50 @@ template <bool COOP, bool LDSX = false> CH_HD void chain_read(const ch_ctx_t &x,
 		for (; i < na; ++i) if (CH[order[i]].kept < 3) CH[order[i]].kept = 0;
 	}
 
+	// ---------------------------------------------------------------- mem_flt_chained_seeds :970-991
+	if (FLT && flt_on) {
+		// the seeds of the kept chains, flat (cidx is free until mem_chain2aln); every seed's score is independent of the others
+		int nsd = 0;
+		for (int ia = 0; ia < na; ++ia) {
+			const ch_chain_t c = CH[order[ia]];
+			if (c.kept == 0) continue;
+			for (uint32_t p = c.head; p != 0xFFFFFFFFu; p = S[p].next) cidx[nsd++] = p;
+		}
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (COOP) {
+			ch_wave_fence<LDSX>();
+			for (int k = ch_lane(); k < nsd; k += 64) { const uint32_t p = cidx[k]; S[p].pad = (uint32_t)seed_sw(x, r, l_query, S[p]); }
+			ch_wave_fence<LDSX>();
+		} else
+#endif
+		for (int k = 0; k < nsd; ++k) { const uint32_t p = cidx[k]; S[p].pad = (uint32_t)seed_sw(x, r, l_query, S[p]); }
+		// the weak seeds leave their chains (:979-987); a chain may end up empty: mem_chain2aln returns at once for it (:1187)
+		for (int ia = 0; ia < na; ++ia) {
+			ch_chain_t c = CH[order[ia]];
+			if (c.kept == 0) continue;
+			uint32_t head = 0xFFFFFFFFu, last = 0xFFFFFFFFu, cnt = 0;
+			for (uint32_t p = c.head; p != 0xFFFFFFFFu;) {
+				const uint32_t nx = S[p].next;
+				const int scv = (int)S[p].pad;
+				if (scv < 0 || scv >= min_HSP_score) {
+					S[p].pad = (uint32_t)(scv < 0 ? S[p].len * o.a : scv);
+					if (last == 0xFFFFFFFFu) head = p; else S[last].next = p;
+					last = p; ++cnt;
+				}
+				p = nx;
+			}
+			if (last != 0xFFFFFFFFu) S[last].next = 0xFFFFFFFFu;
+			if (cnt != c.n) {
+				if (cnt == 0) c.kept = 0; else { c.head = head; c.tail = last; }
+				c.n = cnt;
+				CH[order[ia]] = c;
+			}
+		}
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (COOP) ch_wave_fence<LDSX>();
+#endif
+	}
+
 	// ---------------------------------------------------------------- mem_chain2aln, chain by chain in filtered order
 	CH_STAMP(4);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -996,7 +1151,7 @@ template <bool COOP, bool LDSX = false> CH_HD void chain_read(const ch_ctx_t &x,
 				rmax0 = rmax0 < b ? rmax0 : b;
 				rmax1 = rmax1 > e ? rmax1 : e;
 				cidx[i] = p;
-				srt[i] = (uint64_t)(uint32_t)t.len << 32 | (uint32_t)i;           // score == len
+				srt[i] = (uint64_t)(FLT && flt_on ? t.pad : (uint32_t)t.len) << 32 | (uint32_t)i;   // score == len unless the seed filter re-scored it
 			}
 		}
 		rmax0 = rmax0 > 0 ? rmax0 : 0;

@@ -96,39 +96,67 @@ __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 }
 
 // one read per lane, the bins from the costliest down as one sequence
-__global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A)
+template <bool FLT>
+__global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A, const uint32_t skip_bins)
 {
 	uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	int bin = CH_N_BINS - 1;
-	for (; bin >= 0; --bin) { const uint32_t c = A.light_n[bin]; if (t < c) break; t -= c; }
+	for (; bin >= 0; --bin) { const uint32_t c = (skip_bins >> bin & 1u) ? 0u : A.light_n[bin]; if (t < c) break; t -= c; }
 	if (bin < 0) return;
 	const uint32_t r = A.light_list[(size_t)bin * A.n_reads + t];
-	chain_core::chain_read<false>(A.x, r, chain_core::global_scratch(A.x, r));
+	chain_core::chain_read<false, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
 }
 
-// Lane form over the list of class 0.  The reads just above the lane kernel's threshold (17 .. 32 entries: most of the "heavy"
+#define CH_LDS_BYTES_PER_ENTRY (8 + 8 + sizeof(ch_est_t) + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4 + 4 + 4)
+// The same with the lane's scratch in LDS (bins of at most CAP entries a read): the lane form's global scratch is one cache line
+// per lane and access -- 64 lines per wave instruction, 3.4 GB of HBM traffic per million reads for arrays nobody reads afterwards.
+// A lane's slice holds its eight arrays back to back; its stride is an odd number of 8-byte words, so that the 64 lanes of an
+// access spread over the banks (2-way at worst for 4-byte accesses).  Only the regions (x.regs) leave the kernel.
+#define CH_LANE_LDS_SLICE(cap) ((((uint32_t)(cap) * (uint32_t)CH_LDS_BYTES_PER_ENTRY + 7u) / 8u | 1u) * 8u)
+template <int CAP>
+__global__ void __launch_bounds__(64) chain_lane_lds_kernel(chain_args_t A, int bin)
+{
+	extern __shared__ __align__(16) uint8_t ch_lds[];
+	const uint32_t n = A.light_n[bin];
+	ch_scr_t L;
+	{
+		uint8_t *p = ch_lds + (size_t)threadIdx.x * CH_LANE_LDS_SLICE(CAP);
+		L.opos = (int64_t *)p; p += 8 * CAP;
+		L.srt = (uint64_t *)p; p += 8 * CAP;
+		L.CH = (ch_chain_t *)p; p += sizeof(ch_chain_t) * CAP;
+		L.S = (ch_seed_t *)p; p += sizeof(ch_seed_t) * CAP;
+		L.E = (ch_est_t *)p; p += sizeof(ch_est_t) * CAP;
+		L.order = (uint32_t *)p; p += 4 * CAP;
+		L.klist = (uint32_t *)p; p += 4 * CAP;
+		L.cidx = (uint32_t *)p;
+	}
+	for (uint32_t t = blockIdx.x * 64u + threadIdx.x; t < n; t += gridDim.x * 64u)
+		chain_core::chain_read<false>(A.x, A.light_list[(size_t)bin * A.n_reads + t], L);
+}
+
+// Lane form over the list of class 0.  The reads just above the lane kernel's threshold (9 .. 32 entries: most of the "heavy"
 // reads) cost a lane a few milliseconds of dependent steps, too long for the lane kernel, whose waves would all wait for their one
 // such read -- but compacted into their own list they are 64 reads of similar cost per wave, a few hundred waves that leave the
 // CUs (and all of the LDS) to the wave kernels of the larger classes.  One wave per read, they took a third of the stage.
+template <bool FLT>
 __global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, uint32_t cls)
 {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= A.heavy_n[cls]) return;
 	const uint32_t r = A.heavy_list[(size_t)cls * A.n_reads + i];
-	chain_core::chain_read<false>(A.x, r, chain_core::global_scratch(A.x, r));
+	chain_core::chain_read<false, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
 }
 
 // one wave per heavy read of one size class (list filled by chain_classify_kernel), on a side stream beside chain_lane_kernel.
 // The read's scratch lives in LDS (lds_cap entries of CH_LDS_BYTES_PER_ENTRY bytes each; lds_cap == 0: the read's slice of the
 // global scratch): the wave form is a chain of dependent accesses, so their latency is its run time -- and the LDS a block asks
 // for decides how many of these waves a CU runs side by side (64 entries: 20, 128: 10, 256: 5, 512: 2, 1250: 1), which is why the classes exist.
-#define CH_LDS_BYTES_PER_ENTRY (8 + 8 + sizeof(ch_est_t) + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4 + 4 + 4)
 #define CH_LDS_BYTES_PER_ENTRY_HYBRID (8 + 8 + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4)
 #define CH_LDS_CONTIGS 256         // contig tables up to this size are copied into LDS (3 KB)
 #ifndef CH_WAVE_ATTR
 #define CH_WAVE_ATTR
 #endif
-template <bool CTG_LDS>
+template <bool CTG_LDS, bool FLT>
 __global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_t A, uint32_t cls, uint32_t lds_cap, int hybrid)
 {
 	extern __shared__ __align__(16) uint8_t ch_lds[];
@@ -158,12 +186,12 @@ __global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_
 		const uint32_t r = list[i];
 		// three call sites so that every pointer of a call has ONE address space the compiler can see (a pointer that may be
 		// LDS or global becomes a flat access, several times the latency of ds_read on the LDS side)
-		if (lds_cap && !hybrid) chain_core::chain_read<true, true>(A.x, r, L);
+		if (lds_cap && !hybrid) chain_core::chain_read<true, true, FLT>(A.x, r, L);
 		else if (lds_cap) {
 			const ch_scr_t G = chain_core::global_scratch(A.x, r);
 			ch_scr_t H = L; H.E = G.E; H.klist = G.klist; H.cidx = G.cidx;
-			chain_core::chain_read<true>(A.x, r, H);
-		} else chain_core::chain_read<true>(A.x, r, chain_core::global_scratch(A.x, r));
+			chain_core::chain_read<true, false, FLT>(A.x, r, H);
+		} else chain_core::chain_read<true, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 		__builtin_amdgcn_s_waitcnt(0);                           // the read's output stores before the scratch is reused
 	}
@@ -290,7 +318,14 @@ __global__ void __launch_bounds__(256) materialize_kernel(mat_args_t A)
 	}
 }
 
-__global__ void __launch_bounds__(256) merge_kernel(const ch_outreg_t *__restrict__ regs, uint32_t n_regs, const int32_t *__restrict__ out3, int32_t *__restrict__ regs_out)
+// score of a region whose seed spans the whole read (no extension on either side): a->score = s->score (src/bwamem.c:1435), which is the
+// seed's length (mem_chain :444) unless the seed filter re-scored it -- to len * a: the window is too long for the local alignment
+// (-1 -> s->len * opt->a, :985) or the read matches it end to end (:774-807)
+__device__ __forceinline__ int ch_bare_seed_score(const bmh_chain_opt_t &o, int seedlen0, int l_query)
+{
+	return o.min_chain_weight > 0 && chain_core::seed_filter_applies(o, l_query, nullptr) ? seedlen0 * o.a : seedlen0;
+}
+__global__ void __launch_bounds__(256) merge_kernel(const ch_outreg_t *__restrict__ regs, uint32_t n_regs, const int32_t *__restrict__ out3, int32_t *__restrict__ regs_out, const bmh_chain_opt_t copt)
 {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_regs) return;
@@ -305,7 +340,7 @@ __global__ void __launch_bounds__(256) merge_kernel(const ch_outreg_t *__restric
 		qb = a.seed_qbeg - lq; qe = a.seed_qbeg + a.seedlen0 + rq;
 		rb = a.seed_rbeg - lt; re = a.seed_rbeg + a.seedlen0 + rt;
 	} else {
-		score = a.seedlen0; qb = 0; qe = a.l_query; rb = a.seed_rbeg; re = a.seed_rbeg + a.seedlen0;
+		score = ch_bare_seed_score(copt, a.seedlen0, a.l_query); qb = 0; qe = a.l_query; rb = a.seed_rbeg; re = a.seed_rbeg + a.seedlen0;
 	}
 	int32_t *o = regs_out + 8 * (size_t)i;
 	o[0] = (int32_t)a.read; o[1] = score; o[2] = qb; o[3] = qe;
@@ -331,6 +366,7 @@ struct bmh_chain_ws {
 	void *scan_tmp; size_t scan_tmp_bytes;
 	uint64_t n_regs, n_jobs;
 	uint32_t *h_pin;               // pinned host words for the small D2H copies
+	bmh_chain_opt_t last_opt;      // the options of the last batch (the merge kernels' score of a bare seed depends on them)
 	hipStream_t side; hipEvent_t ev_fork, ev_join;   // the wave kernels run beside the lane kernel
 	hipStream_t cls_stream[CH_N_CLASSES]; hipEvent_t cls_done[CH_N_CLASSES]; // ... and beside each other, one stream per size class
 	hipEvent_t ev_t[8]; float ms[8]; uint32_t heavy_per_class[CH_N_CLASSES];
@@ -458,9 +494,12 @@ template <class T> static int grow(T *&p, uint64_t need_elems)
 static inline unsigned nblk(uint64_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
 
 // arguments of the chaining kernels for one batch
-static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_opt_t *opt, const bmh_index_t *idx, const uint32_t *d_lens, uint32_t n_reads, const bmh_seeds_t *seeds)
+static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_opt_t *opt, const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs,
+                            const uint32_t *d_lens, uint32_t n_reads, const bmh_seeds_t *seeds)
 {
 	memset(&A, 0, sizeof(A));
+	A.x.reads = d_reads; A.x.read_offs = d_offs; A.x.pac = idx->dev.pac;
+	w->last_opt = *opt;
 	A.x.o = *opt; A.x.l_pac = (int64_t)idx->dev.l_pac; A.x.n_contigs = w->n_contigs; A.x.ctg_off = w->ctg_off; A.x.ctg_len = w->ctg_len;
 	A.x.rbeg = seeds->d_rbeg; A.x.qbeg = seeds->d_qbeg; A.x.score = seeds->d_score; A.x.n_ref = seeds->d_n_ref_pos; A.x.prefix = seeds->d_prefix;
 	A.x.read_lens = d_lens;
@@ -468,7 +507,9 @@ static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_op
 	A.x.g.E = w->est; A.x.regs = w->regs; A.x.regs_per_read = w->regs_per_read; A.x.jobs_per_read = w->jobs_per_read; A.x.frac_rep = w->frac_rep; A.x.err = (int *)(w->counters + CH_N_CLASSES);
 	A.n_reads = n_reads;
 	const char *ht = getenv("BMH_CHAIN_HEAVY");
-	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : 16u;
+	// (8: measured on the bench workload -- with the 9..16-entry reads on the lane-list stream, beside the first extension pass instead
+	// of ahead of it, the step is 2.5 % shorter than with 16 (five interleaved pairs of runs); paired and 300 bp: no difference)
+	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : 8u;
 	{
 		static const uint32_t lm = [] { const char *e = getenv("BMH_CHAIN_LANE_MAX"); const int v = e ? atoi(e) : CH_LANE_LIST_MAX; return (uint32_t)(v < 0 ? 0 : v > 64 ? 64 : v); }();   // (experiment knob; 0: no lane class)
 		A.lane_max = lm;
@@ -487,7 +528,8 @@ static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_op
 // classify, then the lane kernel on st and the wave kernels beside it: every size class on its own stream (the classes differ in
 // LDS per block, so they fill different gaps of the CUs, and the largest reads -- the longest chains of dependent steps --
 // start at once); w->ev_join is recorded when all of them are through.  join: st waits for it.
-static int chain_launch(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st, bool join)
+template <bool FLT>
+static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st, bool join)
 {
 	const uint32_t n_reads = A.n_reads;
 	HIPCK(hipMemsetAsync(w->counters, 0, 256, st));
@@ -499,19 +541,35 @@ static int chain_launch(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st, 
 	HIPCK(hipEventRecord(w->ev_t[1], st));
 	HIPCK(hipEventRecord(w->ev_fork, st));
 	HIPCK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
-	chain_lane_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(A);
+	static const int lane_lds_env = [] { const char *e = getenv("BMH_CHAIN_LANE_LDS"); return e ? atoi(e) : 0; }();    // (experiment knob)
+	if (lane_lds_env && A.heavy_thresh <= 16u && !FLT) {                // the bins from the costliest down, each with the LDS its reads need
+		static const uint32_t grid_cap[CH_N_BINS] = {1u << 20, 1u << 20, 2048u, 1024u};
+		for (int bin = CH_N_BINS - 1; bin >= 0; --bin) {
+			if (!(lane_lds_env >> bin & 1)) continue;
+			const uint32_t g = nblk(n_reads, 64) < grid_cap[bin] ? nblk(n_reads, 64) : grid_cap[bin];
+			if (bin == CH_N_BINS - 1) HIPCK(hipFuncSetAttribute((const void *)chain_lane_lds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * CH_LANE_LDS_SLICE(16))));
+			switch (bin) {
+			case 0: chain_lane_lds_kernel<2><<<g, 64, 64 * CH_LANE_LDS_SLICE(2), st>>>(A, bin); break;
+			case 1: chain_lane_lds_kernel<4><<<g, 64, 64 * CH_LANE_LDS_SLICE(4), st>>>(A, bin); break;
+			case 2: chain_lane_lds_kernel<8><<<g, 64, 64 * CH_LANE_LDS_SLICE(8), st>>>(A, bin); break;
+			default: chain_lane_lds_kernel<16><<<g, 64, 64 * CH_LANE_LDS_SLICE(16), st>>>(A, bin); break;
+			}
+		}
+		if ((lane_lds_env & 15) != 15) chain_lane_kernel<false><<<nblk(n_reads, 256), 256, 0, st>>>(A, (uint32_t)lane_lds_env);
+	} else
+	chain_lane_kernel<FLT><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
 	HIPCK(hipEventRecord(w->ev_t[2], st));
 	HIPCK(hipEventRecord(w->ev_t[3], w->side));
 	const bool ctg_lds = w->n_contigs > 1 && w->n_contigs <= CH_LDS_CONTIGS;
-	HIPCK(hipFuncSetAttribute(ctg_lds ? (const void *)chain_wave_kernel<true> : (const void *)chain_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[CH_N_CLASSES - 2] * CH_LDS_BYTES_PER_ENTRY_HYBRID)));
+	HIPCK(hipFuncSetAttribute(ctg_lds ? (const void *)chain_wave_kernel<true, FLT> : (const void *)chain_wave_kernel<false, FLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[CH_N_CLASSES - 2] * CH_LDS_BYTES_PER_ENTRY_HYBRID)));
 	for (int cls = CH_N_CLASSES - 1; cls >= 0; --cls) {
 		const uint32_t lds_cap = CH_CLASS_CAP[cls];
 		const int hybrid = cls >= CH_HYBRID_CLASS && lds_cap != 0;
 		const size_t lds_bytes = (size_t)lds_cap * (hybrid ? CH_LDS_BYTES_PER_ENTRY_HYBRID : CH_LDS_BYTES_PER_ENTRY);
 		HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->ev_fork, 0));
-		if (cls == 0) chain_lane_list_kernel<<<nblk(n_reads, 256), 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls);     // (blocks beyond the list leave at once)
-		else if (ctg_lds) chain_wave_kernel<true><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
-		else chain_wave_kernel<false><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
+		if (cls == 0) chain_lane_list_kernel<FLT><<<nblk(n_reads, 256), 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls);     // (blocks beyond the list leave at once)
+		else if (ctg_lds) chain_wave_kernel<true, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
+		else chain_wave_kernel<false, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
 		HIPCK(hipEventRecord(w->cls_done[cls], w->cls_stream[cls]));
 		HIPCK(hipStreamWaitEvent(w->side, w->cls_done[cls], 0));
 	}
@@ -520,6 +578,15 @@ static int chain_launch(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st, 
 	if (join) HIPCK(hipStreamWaitEvent(st, w->ev_join, 0));
 	HIPCK(hipGetLastError());
 	return BMH_OK;
+}
+
+// The forms with the reference's seed filter (mem_flt_chained_seeds) are launched only when the options let it apply to a read the
+// device path takes at all (a -W small enough for some read of at most CH_MAX_READ_LEN bases; without -W it starts beyond ~730 bp):
+// they carry the local alignment's rows in private memory.
+static bool chain_filter_possible(const bmh_chain_opt_t &o) { return o.min_chain_weight > 0 && chain_core::seed_filter_applies(o, CH_MAX_READ_LEN, nullptr); }
+static int chain_launch(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st, bool join)
+{
+	return chain_filter_possible(A.x.o) ? chain_launch_t<true>(w, A, st, join) : chain_launch_t<false>(w, A, st, join);
 }
 
 static int chain_check_args(const char *fn, bmh_chain_ws *w, const bmh_chain_opt_t *opt, const bmh_index_t *idx, uint32_t n_reads, const bmh_seeds_t *seeds)
@@ -554,7 +621,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	w->last_reads = d_reads; w->last_pac = idx->dev.pac; w->last_l_pac = idx->dev.l_pac;
 	if (n_reads == 0) return BMH_OK;
 	chain_args_t A;
-	chain_fill_args(w, A, opt, idx, d_lens, n_reads, seeds);
+	chain_fill_args(w, A, opt, idx, d_reads, d_offs, d_lens, n_reads, seeds);
 	{ const int rc = chain_launch(w, A, st, true); if (rc != BMH_OK) return rc; }
 	size_t tb = w->scan_tmp_bytes;
 	HIPCK(rocprim::exclusive_scan(w->scan_tmp, tb, w->regs_per_read, w->reg_off, 0u, (size_t)n_reads + 1, rocprim::plus<uint32_t>(), st));
@@ -570,7 +637,7 @@ extern "C" int bmh_chain_batch(bmh_chain_ws_t *w, const bmh_chain_opt_t *opt, co
 	(void)hipEventElapsedTime(&w->ms[2], w->ev_t[3], w->ev_t[4]); (void)hipEventElapsedTime(&w->ms[3], w->ev_t[0], w->ev_t[5]);
 	for (int c = 0; c < CH_N_CLASSES; ++c) w->heavy_per_class[c] = w->h_pin[2 + c];
 	if (getenv("BMH_CHAIN_STATS")) chain_print_stats(w);
-	if (w->h_pin[2 + CH_N_CLASSES] == 1) { bmh_set_error("bmh_chain_batch: a read is longer than %d bp or goes through the reference's seed filter (mem_flt_chained_seeds: reads beyond ~730 bp, small -W): use bmh_build_jobs for this batch", CH_MAX_READ_LEN); return BMH_EINVAL; }
+	if (w->h_pin[2 + CH_N_CLASSES] == 1) { bmh_set_error("bmh_chain_batch: a read is longer than %d bp (the extension kernels' classes end at 768 columns): use bmh_build_jobs for this batch", CH_MAX_READ_LEN); return BMH_EINVAL; }
 	if (w->h_pin[2 + CH_N_CLASSES] != 0) { bmh_set_error("bmh_chain_batch: internal error %u in the chaining kernel", w->h_pin[2 + CH_N_CLASSES]); return BMH_ENODEV; }
 #ifdef CH_PROFILE
 	if (A.x.prof) {
@@ -646,7 +713,7 @@ extern "C" int bmh_chain_merge(bmh_chain_ws_t *w, const int32_t *d_out3, int32_t
 {
 	if (!w || !d_regs_out || (w->n_jobs && !d_out3)) { bmh_set_error("bmh_chain_merge: null argument"); return BMH_EINVAL; }
 	if (w->n_regs == 0) return BMH_OK;
-	merge_kernel<<<nblk(w->n_regs, 256), 256, 0, (hipStream_t)stream_>>>(w->outregs, (uint32_t)w->n_regs, d_out3, d_regs_out);
+	merge_kernel<<<nblk(w->n_regs, 256), 256, 0, (hipStream_t)stream_>>>(w->outregs, (uint32_t)w->n_regs, d_out3, d_regs_out, w->last_opt);
 	HIPCK(hipGetLastError());
 	return BMH_OK;
 }
@@ -669,7 +736,7 @@ static inline auto ch_pass_iter(const uint32_t *need, const uint32_t *cnt, uint3
 // extension results -> regions in READ order: the regions of pass A sit at [0, n_a) of the pass-ordered list, those of pass B
 // behind them; a read has regions in one pass only, so its final offset is off_a[read] + off_b[read]
 __global__ void __launch_bounds__(256) merge2_kernel(const ch_outreg_t *__restrict__ regs, uint32_t n_regs, uint32_t n_a, const uint32_t *__restrict__ off_a,
-                                                     const uint32_t *__restrict__ off_b, const int32_t *__restrict__ out3, int32_t *__restrict__ regs_out)
+                                                     const uint32_t *__restrict__ off_b, const int32_t *__restrict__ out3, int32_t *__restrict__ regs_out, const bmh_chain_opt_t copt)
 {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_regs) return;
@@ -684,7 +751,7 @@ __global__ void __launch_bounds__(256) merge2_kernel(const ch_outreg_t *__restri
 		qb = a.seed_qbeg - lq; qe = a.seed_qbeg + a.seedlen0 + rq;
 		rb = a.seed_rbeg - lt; re = a.seed_rbeg + a.seedlen0 + rt;
 	} else {
-		score = a.seedlen0; qb = 0; qe = a.l_query; rb = a.seed_rbeg; re = a.seed_rbeg + a.seedlen0;
+		score = ch_bare_seed_score(copt, a.seedlen0, a.l_query); qb = 0; qe = a.l_query; rb = a.seed_rbeg; re = a.seed_rbeg + a.seedlen0;
 	}
 	const uint32_t dest = i < n_a ? i + off_b[a.read] : off_a[a.read] + (i - n_a);
 	int32_t *o = regs_out + 8 * (size_t)dest;
@@ -733,7 +800,7 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	w->last_reads = d_reads; w->last_pac = idx->dev.pac; w->last_l_pac = idx->dev.l_pac;
 	if (n_reads == 0) return BMH_OK;
 	chain_args_t A;
-	chain_fill_args(w, A, opt, idx, d_lens, n_reads, seeds);
+	chain_fill_args(w, A, opt, idx, d_reads, d_offs, d_lens, n_reads, seeds);
 	{ const int rc = chain_launch(w, A, st, false); if (rc != BMH_OK) return rc; }
 	// ---- pass A: the reads of the lane kernel
 	// (the counts of a pass are read through a transform iterator: no pass over the reads to mask them first)
@@ -785,7 +852,7 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	(void)hipEventElapsedTime(&w->ms[2], w->ev_t[3], w->ev_t[4]); (void)hipEventElapsedTime(&w->ms[3], w->ev_t[0], w->ev_t[5]);
 	for (int c = 0; c < CH_N_CLASSES; ++c) w->heavy_per_class[c] = w->h_pin[2 + c];
 	if (getenv("BMH_CHAIN_STATS")) chain_print_stats(w);
-	if (w->h_pin[2 + CH_N_CLASSES] == 1) { bmh_set_error("bmh_chain_extend_merge: a read is longer than %d bp or goes through the reference's seed filter (mem_flt_chained_seeds: reads beyond ~730 bp, small -W): use bmh_build_jobs for this batch", CH_MAX_READ_LEN); return BMH_EINVAL; }
+	if (w->h_pin[2 + CH_N_CLASSES] == 1) { bmh_set_error("bmh_chain_extend_merge: a read is longer than %d bp (the extension kernels' classes end at 768 columns): use bmh_build_jobs for this batch", CH_MAX_READ_LEN); return BMH_EINVAL; }
 	if (w->h_pin[2 + CH_N_CLASSES] != 0) { bmh_set_error("bmh_chain_extend_merge: internal error %u in the chaining kernel", w->h_pin[2 + CH_N_CLASSES]); return BMH_ENODEV; }
 	const uint64_t n_regs_b = w->h_pin[32], n_jobs_b = w->h_pin[33];
 	const uint64_t n_regs = n_regs_a + n_regs_b, n_jobs = n_jobs_a + n_jobs_b;
@@ -804,7 +871,7 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 		}
 	}
 	HIPCK(hipEventRecord(w->ev_x[4], st));
-	if (n_regs) merge2_kernel<<<nblk(n_regs, 256), 256, 0, st>>>(w->outregs, (uint32_t)n_regs, (uint32_t)n_regs_a, w->off2[0], w->off2[2], w->out3, d_regs_out);
+	if (n_regs) merge2_kernel<<<nblk(n_regs, 256), 256, 0, st>>>(w->outregs, (uint32_t)n_regs, (uint32_t)n_regs_a, w->off2[0], w->off2[2], w->out3, d_regs_out, w->last_opt);
 	HIPCK(hipEventRecord(w->ev_x[5], st));
 	HIPCK(hipGetLastError());
 	w->n_regs = n_regs; w->n_jobs = n_jobs; w->n_regs_a = n_regs_a; w->n_jobs_a = n_jobs_a;

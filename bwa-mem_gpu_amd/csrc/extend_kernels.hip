@@ -1045,8 +1045,10 @@ static void launch_pk(const ext_args_t &base, hipStream_t st, unsigned grid)
 	const int cls = ext_pk_cls_of(G, P);
 	a.count = base.count + 2 * cls;
 	a.ctr = base.ctr + cls;
-	if (a.o_ins + a.e_ins == a.o_del + a.e_del) extpk_kernel<G, P, true><<<grid, 256, 0, st>>>(a);
-	else extpk_kernel<G, P, false><<<grid, 256, 0, st>>>(a);
+	// (BMH_EXT_LDS_PAD=bytes: experiment knob -- unused dynamic LDS per block, i.e. fewer extension waves per CU, room for other kernels' waves)
+	static const unsigned lds_pad = [] { const char *e = getenv("BMH_EXT_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+	if (a.o_ins + a.e_ins == a.o_del + a.e_del) extpk_kernel<G, P, true><<<grid, 256, lds_pad, st>>>(a);
+	else extpk_kernel<G, P, false><<<grid, 256, lds_pad, st>>>(a);
 }
 template <int C>
 static void launch_wide(const ext_args_t &base, hipStream_t st, unsigned grid)

@@ -206,7 +206,8 @@ void bmh_chain_opt_default(bmh_chain_opt_t *o);
  * Includes the seed filter mem_flt_chained_seeds + mem_seed_sw (src/bwamem.c:970-991, 774-807), which the reference runs when
  * (min_chain_weight ? 1.1f * min_chain_weight : 5.5 ln l_query) <= 0.05f * l_query -- reads beyond ~730 bp, or a small explicit
  * -W: every seed of the kept chains is re-scored by a local alignment of its neighbourhood (ksw_align2 semantics) and weak
- * seeds are dropped.  It is host code in the reference and here: bmh_chain_batch refuses such reads (BMH_EINVAL). */
+ * seeds are dropped.  bmh_chain_batch runs the same filter on the device (round 3) for the reads it admits (up to 700 bases, i.e.
+ * whenever a small -W switches it on); a batch with a longer read is refused there (BMH_EINVAL) and belongs here. */
 typedef struct bmh_jobs bmh_jobs_t;
 bmh_jobs_t *bmh_build_jobs(const bmh_chain_opt_t *opt, int64_t l_pac, const uint8_t *pac, int n_contigs,
                            const int64_t *contig_offset, const int32_t *contig_len, uint32_t n_reads,

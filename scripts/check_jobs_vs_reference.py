@@ -60,6 +60,24 @@ for i in range(hj.n_jobs):
 only_ref = ref_jobs - ours; only_ours = ours - ref_jobs
 print("reference jobs %d, ours %d, only-reference %d, only-ours %d" % (sum(ref_jobs.values()), sum(ours.values()), sum(only_ref.values()), sum(only_ours.values())))
 assert not only_ref and not only_ours, "job multisets differ"
+# the DEVICE job builder (bmh_chain_batch; with -W small enough, its forms with the reference's seed filter) on the same reads: the same multiset
+if L <= 700:
+    from bwamem_hip.lib import ChainWorkspace, dev_jobs_to_host
+    import test_gpu_parity as tp_
+    dindex = B.Index.upload(idx, pac=tp_._pack_pac(g), l_pac=len(g))
+    ws = B.SeedWorkspace(n_reads, int(flat.size), max_cands=int(flat.size), max_occ=1 << 22)
+    r_t = torch.from_numpy(synth.codes_to_ascii(flat)).cuda()
+    o_t = torch.from_numpy(offs.astype(np.int64)).to(torch.int32).cuda(); l_t = torch.from_numpy(lens.astype(np.int64)).to(torch.int32).cuda()
+    s_d = ws.seed_batch(dindex, r_t, o_t, l_t, 19)
+    cw = ChainWorkspace(n_reads, max(int(s_d.n_seeds), 1), opt=co)
+    dj = cw.chain_batch(dindex, r_t, o_t, l_t, s_d)
+    got = dev_jobs_to_host(dj, n_reads)
+    dev = collections.Counter()
+    for i in range(int(dj.n_jobs)):
+        dev[(int(got["h0"][i]), got["q"][got["qoff"][i]:got["qoff"][i] + got["qlen"][i]].tobytes(), got["t"][got["toff"][i]:got["toff"][i] + got["tlen"][i]].tobytes())] += 1
+    print("device builder jobs %d, only-reference %d, only-device %d" % (sum(dev.values()), sum((ref_jobs - dev).values()), sum((dev - ref_jobs).values())))
+    assert dev == ref_jobs, "device job builder: job multiset differs from the reference's"
+    cw.free(); ws.free(); dindex.free()
 # extend on the GPU, merge, compare best score per read with the SAM AS tag
 import importlib
 tp = importlib.import_module("test_gpu_parity")

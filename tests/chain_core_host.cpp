@@ -31,7 +31,11 @@ extern "C" result_t *chain_core_run(const bmh_chain_opt_t *opt, int64_t l_pac, c
 	x.rbeg = rbeg; x.qbeg = qbeg; x.score = score; x.n_ref = n_ref; x.prefix = prefix; x.read_lens = read_lens;
 	x.g.S = seeds.data(); x.g.CH = chains.data(); x.g.order = order.data(); x.g.opos = opos.data(); x.g.klist = klist.data(); x.g.srt = srt.data();
 	x.g.cidx = cidx.data(); x.g.E = est.data(); x.regs = regs.data(); x.regs_per_read = rpr.data(); x.jobs_per_read = jpr.data(); x.frac_rep = frep.data(); x.err = &err;
-	for (uint32_t r = 0; r < n_reads; ++r) chain_core::chain_read<false>(x, r, chain_core::global_scratch(x, r));
+	std::vector<uint32_t> offs32(n_reads + 1);
+	for (uint32_t r = 0; r < n_reads; ++r) offs32[r] = (uint32_t)read_offs[r];
+	x.reads = reads; x.read_offs = offs32.data(); x.pac = pac;
+	// (the form with the reference's seed filter: it runs for the reads the options make it apply to, as in the kernels launched for such options)
+	for (uint32_t r = 0; r < n_reads; ++r) chain_core::chain_read<false, false, true>(x, r, chain_core::global_scratch(x, r));
 	std::vector<uint32_t> qoff, qlen, toff, tlen, h0, job_read, job_reg, job_side;
 	std::vector<uint8_t> q, t;
 	auto text = [&](int64_t p) { const bool rev = p >= l_pac; const int64_t f = rev ? (l_pac << 1) - 1 - p : p; const int c = (pac[f >> 2] >> ((~f & 3) << 1)) & 3; return (uint8_t)(rev ? 3 - c : c); };

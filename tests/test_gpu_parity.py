@@ -556,7 +556,7 @@ def _pack_pac(g):
     return np.ascontiguousarray(np.concatenate([pac, np.zeros(1, np.uint8)]))      # + the .pac tail byte slot
 
 
-def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None):
+def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None, scoring=False):
     """reads -> bmh_seed_batch -> bmh_chain_batch -> bmh_extend_batch -> bmh_chain_merge, all in HBM, against the
     host job builder on the same seeds (byte-identical batch) and its merge of the oracle's extension results."""
     import ctypes as C, os, torch
@@ -579,6 +579,10 @@ def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None):
     for k, v in (opt_over or {}).items():
         setattr(opt, k, v)
     cw = ChainWorkspace(n, max(int(s.n_seeds), 1), opt=opt)
+    # scoring: the extension runs with the chain options' scores too (otherwise with the defaults, whatever opt_over says)
+    ext_p = B.ExtParams(opt.a, opt.b, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, 0, 5) if scoring else B.ExtParams.default()
+    import oracle_py
+    ksw_p = oracle_py.KswParams(ext_p.a, ext_p.b, ext_p.o_del, ext_p.e_del, ext_p.o_ins, ext_p.e_ins, 0, 5, 1)
     if heavy is not None:
         os.environ["BMH_CHAIN_HEAVY"] = str(heavy)
     try:
@@ -596,11 +600,11 @@ def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None):
     regs = torch.zeros(max(hj.n_regs, 1), 8, dtype=torch.int32, device="cuda")
     if hj.n_jobs:
         rc = load_library().bmh_extend_batch(dj.d_q, dj.d_qoff, dj.d_qlen, dj.d_t, dj.d_toff, dj.d_tlen, dj.d_h0, int(dj.n_jobs),
-                                             C.byref(B.ExtParams.default()), out3.data_ptr(), None, None)
+                                             C.byref(ext_p), out3.data_ptr(), None, None)
         assert rc == 0
     cw.merge(out3, regs)
     torch.cuda.synchronize()
-    want3, _, _ = oracle.extend_batch(*hj.jobs()) if hj.n_jobs else (np.zeros((0, 3), np.int32), None, None)
+    want3, _, _ = oracle.extend_batch(*hj.jobs(), params=ksw_p) if hj.n_jobs else (np.zeros((0, 3), np.int32), None, None)
     assert np.array_equal(out3.cpu().numpy()[: hj.n_jobs], want3)
     assert np.array_equal(regs.cpu().numpy()[: hj.n_regs], hj.merge(want3))
     # the same without materialised base arrays: bmh_chain_extend reads the bases from the reads / 2-bit reference
@@ -610,14 +614,14 @@ def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None):
     out3b = torch.full((max(hj.n_jobs, 1), 3), -7, dtype=torch.int32, device="cuda")
     raw6 = torch.zeros(max(hj.n_jobs, 1), 6, dtype=torch.int32, device="cuda")
     regs2 = torch.zeros(max(hj.n_regs, 1), 8, dtype=torch.int32, device="cuda")
-    cw.extend(out3b, raw_t=raw6)
+    cw.extend(out3b, params=ext_p, raw_t=raw6)
     cw.merge(out3b, regs2)
     torch.cuda.synchronize()
     assert np.array_equal(out3b.cpu().numpy()[: hj.n_jobs], want3)
     assert np.array_equal(regs2.cpu().numpy()[: hj.n_regs], hj.merge(want3))
     # the one-call form (two passes, the heavy reads' chaining hidden behind the first pass's extension): same regions, read order
     regs3 = torch.full((hj.n_regs + 3, 8), -9, dtype=torch.int32, device="cuda")
-    dj3 = cw.extend_merge(dindex, r, o, l, s, regs3)
+    dj3 = cw.extend_merge(dindex, r, o, l, s, regs3, params=ext_p)
     torch.cuda.synchronize()
     assert int(dj3.n_jobs) == hj.n_jobs and int(dj3.n_regs) == hj.n_regs
     assert np.array_equal(regs3.cpu().numpy()[: hj.n_regs], hj.merge(want3)) and (regs3.cpu().numpy()[hj.n_regs:] == -9).all()
@@ -645,12 +649,19 @@ def test_device_job_builder_matches_host_builder(hip, oracle):
     reads3, _ = synth.make_reads(g, 1000, 300, seed=6, sub_rate=0.03, indel_frac=0.3)
     _device_chain_case(hip, oracle, g, idx, reads3)
     _device_chain_case(hip, oracle, g, idx, reads[:1500], opt_over=dict(max_occ=3, max_chain_extend=2, min_chain_weight=25, drop_ratio=0.8))
+    # the reference's seed filter (mem_flt_chained_seeds / mem_seed_sw, src/bwamem.c:970-991, 774-807) on the device: 1.1 W <= 0.05 l
+    # (W = 5 and 6 at 150 bp, 13 at 300 bp), lane and wave forms, default and other scores (the local alignment's and the extension's)
+    _device_chain_case(hip, oracle, g, idx, reads[:1500], opt_over=dict(min_chain_weight=5))
+    _device_chain_case(hip, oracle, g, idx, reads[:800], opt_over=dict(min_chain_weight=5), heavy=0)
+    _device_chain_case(hip, oracle, g, idx, reads3[:500], opt_over=dict(min_chain_weight=13))
+    _device_chain_case(hip, oracle, g, idx, reads[:1000], opt_over=dict(min_chain_weight=6, a=2, b=5, o_del=4, e_del=2, o_ins=7, e_ins=1), scoring=True)
     # repeat-rich genome: many copies, little divergence -> reads with hundreds of seeds and chains
     gr = synth.make_genome(600_000, seed=9, repeat_frac=0.6, repeat_len=(200, 800), repeat_copies=(50, 400), repeat_div=0.02)
     idxr = fmindex.build_fmd_index(gr)
     readsr, _ = synth.make_reads(gr, 2000, 150, seed=8, sub_rate=0.01)
     nj, nr, nh = _device_chain_case(hip, oracle, gr, idxr, readsr)
     assert nh > 20, nh
+    _device_chain_case(hip, oracle, gr, idxr, readsr[:800], opt_over=dict(min_chain_weight=5))      # seed-rich reads through the filter
     # ragged batch: reads of 30..250 bases (some shorter than a seed), N bases, the edge cases of the seeding tests
     rng = np.random.default_rng(31)
     rows = common.edge_reads(g, rng)

@@ -106,7 +106,9 @@ def test_device_chain_core_matches_reference_jobs_and_host_builder(oracle):
     flat, offs, lens = common.flat_reads(reads)
     s = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens, 19, n_threads=4)
     assert s["n_ref_pos"].max() > 100
-    for over in ({}, dict(max_occ=20), dict(max_occ=5, max_chain_extend=3, min_chain_weight=30, drop_ratio=0.9, mask_level=0.2)):
+    # (min_chain_weight 5 and 6: 1.1 W <= 0.05 * 150, so the reference's seed filter mem_flt_chained_seeds / mem_seed_sw runs, src/bwamem.c:970-991)
+    for over in ({}, dict(max_occ=20), dict(max_occ=5, max_chain_extend=3, min_chain_weight=30, drop_ratio=0.9, mask_level=0.2),
+                 dict(min_chain_weight=5), dict(min_chain_weight=6, max_occ=20, a=2, b=5, o_del=4, e_del=2, o_ins=7, e_ins=1)):
         o = ChainOpt(); load_library().bmh_chain_opt_default(C.byref(o))
         for k, v in over.items():
             setattr(o, k, v)

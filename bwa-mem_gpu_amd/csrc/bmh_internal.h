@@ -22,6 +22,8 @@ struct bmh_ext_desc_t {
 };
 int bmh_extend_batch_desc(const bmh_ext_desc_t *desc, const uint32_t *d_qlen, const uint32_t *d_tlen, const uint32_t *d_h0, uint32_t n,
                           const bmh_ext_params_t *p, int32_t *d_out, int32_t *d_raw, void *stream);
+// sizes the extension's per-(device, stream) scratch for batches of up to n jobs (a later growth frees device memory, which waits for the device)
+int bmh_extend_reserve(void *stream, uint64_t n);
 
 #ifdef __cplusplus
 extern "C" {

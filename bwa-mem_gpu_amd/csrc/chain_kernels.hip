@@ -819,6 +819,7 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	// capacity for both passes now (a reallocation later would wait for everything and have to move pass A): pass B makes at
 	// most one region per sampled occurrence and two jobs per region
 	{ const int rc = chain_grow_jobs(w, n_regs_a + need_b, n_jobs_a + 2 * need_b); if (rc != BMH_OK) return rc; }
+	{ const int rc = bmh_extend_reserve(stream_, n_jobs_a > 2 * need_b ? n_jobs_a : 2 * need_b); if (rc != BMH_OK) return rc; }   // (the extension's own scratch likewise)
 	emit_args_t E;
 	E.regs = w->regs; E.prefix = seeds->d_prefix; E.read_offs = d_offs; E.read_lens = d_lens; E.n_reads = n_reads; E.outregs = w->outregs;
 	E.qlen = w->qlen; E.tlen = w->tlen; E.h0 = w->h0; E.job_read = w->job_read; E.job_reg = w->job_reg; E.job_side = w->job_side; E.jq_src = w->jq_src; E.jt0 = w->jt0;

@@ -969,6 +969,29 @@ static ext_scratch_t *scratch_for(int dev, void *stream)
 	return s;
 }
 
+// room for n jobs; grown by a quarter beyond the request, so that batches of slowly growing size do not reallocate every time
+// (hipFree waits for the whole device: a reallocation between the two extension passes of bmh_chain_extend_merge would serialise them)
+static int scratch_reserve(ext_scratch_t &g_scr, int dev, size_t n)
+{
+	if (g_scr.cap >= n) return BMH_OK;
+	const size_t c = n + n / 4 + 1024;
+	void *ps[] = {g_scr.keys, g_scr.vals2, g_scr.counts, g_scr.bins};
+	for (void *q : ps) if (q) (void)hipFree(q);
+	g_scr.keys = g_scr.vals2 = g_scr.counts = g_scr.bins = nullptr; g_scr.cap = 0;
+	HIPCK(hipMalloc((void **)&g_scr.keys, 4 * c)); HIPCK(hipMalloc((void **)&g_scr.vals2, 4 * c));
+	HIPCK(hipMalloc((void **)&g_scr.counts, 4 * 3 * EXT_N_CLS));
+	HIPCK(hipMalloc((void **)&g_scr.bins, 4 * 3 * EXT_N_BINS));
+	g_scr.cap = c; g_scr.dev = dev;
+	return BMH_OK;
+}
+// (internal, bmh_internal.h) the scratch of (current device, stream) sized for batches of up to n jobs before any of them is launched
+int bmh_extend_reserve(void *stream_, uint64_t n)
+{
+	int dev = 0;
+	HIPCK(hipGetDevice(&dev));
+	return scratch_reserve(*scratch_for(dev, stream_), dev, (size_t)n);
+}
+
 // Frees the scratch (sorted job list, side streams, events) that bmh_extend_batch keeps per (device, stream); call it before
 // destroying a stream that was used for extensions (a recycled stream handle would otherwise inherit stale scratch).  The
 // stream must be idle.  A stream must not be used for extensions by two host threads at once: they would share this scratch.
@@ -1093,15 +1116,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	HIPCK(hipGetDevice(&dev));
 	ext_scratch_t &g_scr = *scratch_for(dev, stream_);
 	g_last = &g_scr;
-	if (g_scr.cap < n) {
-		void *ps[] = {g_scr.keys, g_scr.vals2, g_scr.counts, g_scr.bins};
-		for (void *q : ps) if (q) (void)hipFree(q);
-		g_scr.keys = g_scr.vals2 = g_scr.counts = g_scr.bins = nullptr; g_scr.cap = 0;
-		HIPCK(hipMalloc((void **)&g_scr.keys, 4 * (size_t)n)); HIPCK(hipMalloc((void **)&g_scr.vals2, 4 * (size_t)n));
-		HIPCK(hipMalloc((void **)&g_scr.counts, 4 * 3 * EXT_N_CLS));
-		HIPCK(hipMalloc((void **)&g_scr.bins, 4 * 3 * EXT_N_BINS));
-		g_scr.cap = n; g_scr.dev = dev;
-	}
+	{ const int rc = scratch_reserve(g_scr, dev, n); if (rc != BMH_OK) return rc; }
 	if (!g_scr.have_ev) {
 		HIPCK(hipEventCreate(&g_scr.ev0)); HIPCK(hipEventCreate(&g_scr.ev1));
 		HIPCK(hipEventCreateWithFlags(&g_scr.fork, hipEventDisableTiming));

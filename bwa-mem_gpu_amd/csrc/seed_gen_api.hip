@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
+#include <memory>
+#include <mutex>
 #include <algorithm>
 #include <vector>
 #include "bmh_internal.h"
@@ -151,47 +153,49 @@ extern "C" mem_seed_v_gpu *seed_gpu(gpuseed_storage_vector *d)
 	const uint32_t BATCH_READS = (uint32_t)(left / 2 + 1 < batch_reads_cfg ? left / 2 + 1 : batch_reads_cfg);
 	const uint64_t BATCH_BASES = left + 1 < SEED_BATCH_BASES ? left + 1 : SEED_BATCH_BASES;
 
-	// the batches of the file (host memory), then their seeds; batch b is seeded by worker b mod N
-	struct batch_t {
-		std::vector<uint8_t> bases; std::vector<uint32_t> offs, lens;
-		std::vector<uint64_t> rbeg; std::vector<int2> qbeg; std::vector<uint32_t> score, n_ref;
-	};
-	std::vector<batch_t> batches;
+	// The file is read batch by batch, by whichever worker is free next, straight into that worker's pinned staging buffers (so
+	// the H2D copy is one asynchronous DMA and the host never holds more reads than the workers are seeding); what stays per
+	// batch is its seeds, in file order.
+	struct batch_t { std::vector<uint64_t> rbeg; std::vector<int2> qbeg; std::vector<uint32_t> score, n_ref; };
+	std::vector<std::unique_ptr<batch_t>> batches;
+	std::mutex rd_mu;
 	uint64_t file_bytes = 0;
-	{
-		char *line = nullptr; size_t cap = 0;
-		bool eof = false;
-		while (!eof) {
-			batch_t b;
-			uint64_t nb = 0;
-			while (b.lens.size() < BATCH_READS) {
-				ssize_t n = getline(&line, &cap, fp);
-				if (n < 0) { eof = true; break; }
-				file_bytes += (uint64_t)n;
-				if (line[0] == '>') continue;
-				while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) --n;
-				if (n == 0) continue;                     // blank line (kseq skips it too)
-				if (nb + (uint64_t)n > BATCH_BASES) {  // batch full: push the line back
-					fseek(fp, -(long)(strlen(line)), SEEK_CUR); file_bytes -= strlen(line);
-					break;
-				}
-				b.bases.insert(b.bases.end(), line, line + n);
-				b.offs.push_back((uint32_t)nb); b.lens.push_back((uint32_t)n);
-				nb += (uint64_t)n;
+	bool rd_eof = false;
+	char *rd_line = nullptr; size_t rd_cap = 0;
+	// next batch of the file into (bases, offs, lens); returns its index, or -1 at the end of the file
+	auto read_batch = [&](uint8_t *bases, uint32_t *offs, uint32_t *lens, uint32_t *n_reads, uint64_t *n_bases) -> long {
+		std::lock_guard<std::mutex> lk(rd_mu);
+		uint64_t nb = 0; uint32_t nr = 0;
+		while (!rd_eof && nr < BATCH_READS) {
+			ssize_t n = getline(&rd_line, &rd_cap, fp);
+			if (n < 0) { rd_eof = true; break; }
+			const size_t raw = (size_t)n;
+			file_bytes += raw;
+			if (rd_line[0] == '>') continue;
+			while (n > 0 && (rd_line[n - 1] == '\n' || rd_line[n - 1] == '\r')) --n;
+			if (n == 0) continue;                     // blank line (kseq skips it too)
+			if (nb + (uint64_t)n > BATCH_BASES) {  // batch full: push the line back
+				fseek(fp, -(long)raw, SEEK_CUR); file_bytes -= raw;
+				break;
 			}
-			if (b.lens.empty()) break;
-			batches.push_back(std::move(b));
+			memcpy(bases + nb, rd_line, (size_t)n);
+			offs[nr] = (uint32_t)nb; lens[nr] = (uint32_t)n; ++nr;
+			nb += (uint64_t)n;
 		}
-		free(line);
-	}
-	fclose(fp);
+		*n_reads = nr; *n_bases = nb;
+		if (nr == 0) return -1;
+		batches.emplace_back(new batch_t());
+		return (long)batches.size() - 1;
+	};
 
 	// BMH_DEVICES=N: N worker threads, worker k on device k mod (devices present), each with its own stream, workspace and --
 	// on another device than the one the index was uploaded to -- its own replica of the index (bmh_index_replicate)
 	static const int n_workers_env = [] { const char *e = getenv("BMH_DEVICES"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();
 	int n_dev = 1, home = 0;
 	HIPX(hipGetDeviceCount(&n_dev)); HIPX(hipGetDevice(&home));
-	const int n_workers = (int)std::min<size_t>((size_t)n_workers_env, std::max<size_t>(batches.size(), 1));
+	// (no more workers than the file can have batches)
+	const uint64_t max_batches = std::max<uint64_t>(1, std::max<uint64_t>((left / 2 + BATCH_READS) / BATCH_READS, (left + BATCH_BASES) / BATCH_BASES));
+	const int n_workers = (int)std::min<uint64_t>((uint64_t)n_workers_env, max_batches);
 	std::vector<bmh_index_t *> widx(n_workers, idx);
 	std::vector<int> wdev(n_workers, home);
 	for (int k = 1; k < n_workers; ++k) {
@@ -215,25 +219,45 @@ extern "C" mem_seed_v_gpu *seed_gpu(gpuseed_storage_vector *d)
 		HIPX(hipMalloc((void **)&d_bases, BATCH_BASES));
 		HIPX(hipMalloc((void **)&d_offs, (size_t)BATCH_READS * 4));
 		HIPX(hipMalloc((void **)&d_lens, (size_t)BATCH_READS * 4));
-		for (size_t bi = (size_t)k; bi < batches.size(); bi += (size_t)n_workers) {
-			batch_t &b = batches[bi];
-			const uint32_t nr = (uint32_t)b.lens.size();
-			HIPX(hipMemcpyAsync(d_bases, b.bases.data(), b.bases.size(), hipMemcpyHostToDevice, st));
-			HIPX(hipMemcpyAsync(d_offs, b.offs.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
-			HIPX(hipMemcpyAsync(d_lens, b.lens.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+		// pinned staging: the batch's reads on the way in, its seeds on the way out (grown by half beyond the need when a batch has more)
+		uint8_t *h_bases; uint32_t *h_offs, *h_lens;
+		HIPX(hipHostMalloc((void **)&h_bases, BATCH_BASES, hipHostMallocDefault));
+		HIPX(hipHostMalloc((void **)&h_offs, (size_t)BATCH_READS * 4, hipHostMallocDefault));
+		HIPX(hipHostMalloc((void **)&h_lens, (size_t)BATCH_READS * 4, hipHostMallocDefault));
+		uint8_t *h_out = nullptr; size_t h_out_cap = 0;
+		for (;;) {
+			uint32_t nr = 0; uint64_t nbases = 0;
+			const long bi = read_batch(h_bases, h_offs, h_lens, &nr, &nbases);
+			if (bi < 0) break;
+			HIPX(hipMemcpyAsync(d_bases, h_bases, nbases, hipMemcpyHostToDevice, st));
+			HIPX(hipMemcpyAsync(d_offs, h_offs, (size_t)nr * 4, hipMemcpyHostToDevice, st));
+			HIPX(hipMemcpyAsync(d_lens, h_lens, (size_t)nr * 4, hipMemcpyHostToDevice, st));
 			bmh_seeds_t s;
 			if (bmh_seed_batch(ws, widx[k], d_bases, d_offs, d_lens, nr, min_seed, st, &s) != BMH_OK)
 				FATAL("seed_gpu: %s", bmh_last_error());
-			b.rbeg.resize(s.n_seeds); b.qbeg.resize(s.n_seeds); b.score.resize(s.n_seeds); b.n_ref.resize(nr);
-			if (s.n_seeds) {
-				HIPX(hipMemcpyAsync(b.rbeg.data(), s.d_rbeg, s.n_seeds * 8, hipMemcpyDeviceToHost, st));
-				HIPX(hipMemcpyAsync(b.qbeg.data(), s.d_qbeg, s.n_seeds * 8, hipMemcpyDeviceToHost, st));
-				HIPX(hipMemcpyAsync(b.score.data(), s.d_score, s.n_seeds * 4, hipMemcpyDeviceToHost, st));
+			const size_t need = (size_t)s.n_seeds * 20 + (size_t)nr * 4;
+			if (need > h_out_cap) {
+				if (h_out) HIPX(hipHostFree(h_out));
+				h_out_cap = need + need / 2;
+				HIPX(hipHostMalloc((void **)&h_out, h_out_cap, hipHostMallocDefault));
 			}
-			HIPX(hipMemcpyAsync(b.n_ref.data(), s.d_n_ref_pos, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+			uint8_t *p_rbeg = h_out, *p_qbeg = p_rbeg + (size_t)s.n_seeds * 8, *p_score = p_qbeg + (size_t)s.n_seeds * 8, *p_nref = p_score + (size_t)s.n_seeds * 4;
+			if (s.n_seeds) {
+				HIPX(hipMemcpyAsync(p_rbeg, s.d_rbeg, s.n_seeds * 8, hipMemcpyDeviceToHost, st));
+				HIPX(hipMemcpyAsync(p_qbeg, s.d_qbeg, s.n_seeds * 8, hipMemcpyDeviceToHost, st));
+				HIPX(hipMemcpyAsync(p_score, s.d_score, s.n_seeds * 4, hipMemcpyDeviceToHost, st));
+			}
+			HIPX(hipMemcpyAsync(p_nref, s.d_n_ref_pos, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
 			HIPX(hipStreamSynchronize(st));
-			std::vector<uint8_t>().swap(b.bases);
+			batch_t *b;
+			{ std::lock_guard<std::mutex> lk(rd_mu); b = batches[(size_t)bi].get(); }
+			b->rbeg.assign((const uint64_t *)p_rbeg, (const uint64_t *)p_rbeg + s.n_seeds);
+			b->qbeg.assign((const int2 *)p_qbeg, (const int2 *)p_qbeg + s.n_seeds);
+			b->score.assign((const uint32_t *)p_score, (const uint32_t *)p_score + s.n_seeds);
+			b->n_ref.assign((const uint32_t *)p_nref, (const uint32_t *)p_nref + nr);
 		}
+		if (h_out) HIPX(hipHostFree(h_out));
+		HIPX(hipHostFree(h_bases)); HIPX(hipHostFree(h_offs)); HIPX(hipHostFree(h_lens));
 		(void)hipFree(d_bases); (void)hipFree(d_offs); (void)hipFree(d_lens);
 		bmh_seed_ws_free(ws);
 		(void)hipStreamDestroy(st);
@@ -245,31 +269,35 @@ extern "C" mem_seed_v_gpu *seed_gpu(gpuseed_storage_vector *d)
 		for (auto &t : th) t.join();
 		HIPX(hipSetDevice(home));
 	}
+	free(rd_line);
+	fclose(fp);
 	for (int k = 1; k < n_workers; ++k) {
 		if (widx[k] == idx) continue;
 		bool first = true;
 		for (int q = 1; q < k; ++q) if (widx[q] == widx[k]) first = false;
 		if (first) { HIPX(hipSetDevice(wdev[k])); bmh_index_free(widx[k]); HIPX(hipSetDevice(home)); }
 	}
-	std::vector<uint64_t> rbeg; std::vector<int2> qbeg; std::vector<uint32_t> score, n_ref;
-	for (batch_t &b : batches) {
-		rbeg.insert(rbeg.end(), b.rbeg.begin(), b.rbeg.end()); qbeg.insert(qbeg.end(), b.qbeg.begin(), b.qbeg.end());
-		score.insert(score.end(), b.score.begin(), b.score.end()); n_ref.insert(n_ref.end(), b.n_ref.begin(), b.n_ref.end());
-		batch_t().rbeg.swap(b.rbeg);
-	}
-
-	mem_seed_v_gpu *out = (mem_seed_v_gpu *)malloc(sizeof(mem_seed_v_gpu));
-	size_t ns = rbeg.size(), nr = n_ref.size();
+	// the run's arrays (caller frees with free(), src/fastmap.c:537-542): the batches' seeds in file order, each copied once
+	size_t ns = 0, nr = 0;
+	for (const auto &b : batches) { ns += b->rbeg.size(); nr += b->n_ref.size(); }
 	if ((uint64_t)ns >> 32) FATAL("seed_gpu: more than 2^32 seeds in one run (32-bit prefix sums, seed_gen.h:73)");
+	mem_seed_v_gpu *out = (mem_seed_v_gpu *)malloc(sizeof(mem_seed_v_gpu));
 	out->rbeg = (bwtint_t_gpu *)malloc((ns + 1) * 8);
 	out->qbeg = (int2 *)malloc((ns + 1) * sizeof(int2));
 	out->score = (uint32_t *)malloc((ns + 1) * 4);
 	out->n_ref_pos_fow_rev_results = (uint32_t *)malloc((nr + 1) * 4);
 	out->n_ref_pos_fow_rev_prefix_sums = (uint32_t *)malloc((nr + 1) * 4);
-	memcpy(out->rbeg, rbeg.data(), ns * 8);
-	memcpy(out->qbeg, qbeg.data(), ns * sizeof(int2));
-	memcpy(out->score, score.data(), ns * 4);
-	memcpy(out->n_ref_pos_fow_rev_results, n_ref.data(), nr * 4);
+	{
+		size_t so = 0, ro = 0;
+		for (auto &b : batches) {
+			const size_t bs = b->rbeg.size(), br = b->n_ref.size();
+			if (bs) { memcpy(out->rbeg + so, b->rbeg.data(), bs * 8); memcpy(out->qbeg + so, b->qbeg.data(), bs * sizeof(int2)); memcpy(out->score + so, b->score.data(), bs * 4); }
+			if (br) memcpy(out->n_ref_pos_fow_rev_results + ro, b->n_ref.data(), br * 4);
+			so += bs; ro += br;
+			b.reset();
+		}
+	}
+	const uint32_t *n_ref = out->n_ref_pos_fow_rev_results;
 	uint32_t acc = 0;
 	for (size_t i = 0; i < nr; ++i) { out->n_ref_pos_fow_rev_prefix_sums[i] = acc; acc += n_ref[i]; }
 	out->file_bytes_skip = file_bytes;

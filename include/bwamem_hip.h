@@ -174,9 +174,10 @@ int bmh_extend_batch(const uint8_t *d_q, const uint32_t *d_qoff, const uint32_t 
  * refuses such a batch up front; bmh_chain_batch only admits reads up to 700 bases, whose flanks always fit. */
 int64_t bmh_extend_last_unsupported(void);
 
-/* Jobs whose scores fit 16 bits (h0 + qlen*a < 4096, qlen <= 288, tlen <= 512; scoring with 1 <= b, a + b <= 255) run on the
- * packed 16-bit kernels (two DP columns per register, eight alignments per wave), everything else on the 32-bit kernels; results
- * are identical.  on = 0 sends every job to the 32-bit kernels (tests, A/B timing).  Process-wide; returns the previous setting. */
+/* Jobs whose scores fit 16 bits (h0 + qlen*a < 4096; scoring with 1 <= b, a + b <= 255) and whose sides fit a packed class -- qlen <= 128
+ * with tlen <= 384 (4 lanes per job, 16 jobs per wave; qlen 129..136 too while h0 + qlen*a < 2048: the 17-pair class), qlen <= 256
+ * with tlen <= 512 (8 lanes, 8 jobs per wave), qlen <= 288 with tlen <= 640 (16 lanes, 4 jobs per wave) -- run on the packed 16-bit
+ * kernels (two DP columns per register), everything else on the 32-bit kernels; results are identical.  on = 0 sends every job to the 32-bit kernels (tests, A/B timing).  Process-wide; returns the previous setting. */
 int bmh_extend_set_packed(int on);
 
 /* bmh_extend_batch keeps scratch (the sorted job list, four side streams, events) per (device, stream) and reuses it across calls.

@@ -627,6 +627,10 @@ def main():
             if issued is not None:
                 valu["issue_slot_frac"] = round(issued * 64.0 / t_ext_s / VALU_PEAK_LANEOPS, 4)
                 valu["executed_lane_instr_per_reference_cell"] = round(issued * 64.0 / cells, 2)
+                if valu.get("measured_ceiling"):
+                    # how full the VALU issue port is: executed instructions against what the chip sustains on plain integer instructions --
+                    # near 1 means the family is issue-bound as it stands, and only fewer instructions per reference cell can make it faster
+                    valu["issue_slot_frac_of_measured_ceiling"] = round(valu["issue_slot_frac"] / cal["independent_v_max_add"], 4)
                 valu["issue_source"] = "SQ_INSTS_VALU summed over the whole family, " + prof_src
             valu["dtype_note"] = "DP cells as packed unsigned 16-bit pairs (v_pk_*_u16) where h0 + qlen*a < 4096, 32-bit lanes otherwise; rank arithmetic of the seeding is 32/64-bit popcounts"
             # `roofline` = the dominant kernel family with the bound that binds it: integer VALU for the extension, HBM gathers for a seeding kernel

@@ -42,8 +42,9 @@ def read_ann(prefix: str):
 class ReadSet:
     """reads of a FASTA file as flat arrays: ascii bases back to back + offsets / lengths, names as a NUL-separated blob"""
 
-    def __init__(self, ascii_, offs, lens, name_blob, name_off):
+    def __init__(self, ascii_, offs, lens, name_blob, name_off, codes=None):
         self.ascii, self.offs, self.lens, self.name_blob, self.name_off = ascii_, offs, lens, name_blob, name_off
+        self.codes = codes                      # nt4 codes of the letters when the loader made them (bmh_reads_load_fasta), else None
 
     def __len__(self):
         return len(self.lens)
@@ -52,7 +53,8 @@ class ReadSet:
         b1 = min(b1, len(self))
         a0 = int(self.offs[b0]); a1 = int(self.offs[b1 - 1] + self.lens[b1 - 1])
         n0 = int(self.name_off[b0]); n1 = int(self.name_off[b1]) if b1 < len(self) else len(self.name_blob)
-        return ReadSet(self.ascii[a0:a1], self.offs[b0:b1] - np.uint64(a0), self.lens[b0:b1], self.name_blob[n0:n1], self.name_off[b0:b1] - np.uint64(n0))
+        return ReadSet(self.ascii[a0:a1], self.offs[b0:b1] - np.uint64(a0), self.lens[b0:b1], self.name_blob[n0:n1], self.name_off[b0:b1] - np.uint64(n0),
+                       codes=None if self.codes is None else self.codes[a0:a1])
 
     @classmethod
     def from_lists(cls, names, seqs) -> "ReadSet":
@@ -68,7 +70,16 @@ class ReadSet:
 
 def read_fasta_reads(path: str) -> ReadSet:
     """one '>' header line and one sequence line per read (the only layout the reference's seeding library parses,
-    src/GPUSeed/seed_gen.cu:1698-1728); parsed with array operations, no per-read Python work"""
+    src/GPUSeed/seed_gen.cu:1698-1728), through the library's loader (bmh_reads_load_fasta: host threads, letters + nt4 codes)"""
+    from .lib import load_fasta_reads
+    d = load_fasta_reads(path)
+    if len(d["lens"]) == 0:
+        return ReadSet.from_lists([], [])
+    return ReadSet(d["ascii"], d["offs"], d["lens"], d["names"], d["name_offs"], codes=d["codes"])
+
+
+def read_fasta_reads_numpy(path: str) -> ReadSet:
+    """the same parse with numpy array operations (what read_fasta_reads was before the library had a loader; kept as its cross-check)"""
     buf = np.fromfile(path, dtype=np.uint8)
     if buf.size == 0:
         return ReadSet.from_lists([], [])
@@ -202,7 +213,7 @@ class Aligner:
         L, dev, n = self.L, self.dev, len(rs)
         self._as_bytes = as_bytes
         if n == 0:
-            return b"" if as_bytes else ""
+            return (np.zeros(0, np.uint8) if as_bytes == "view" else b"") if as_bytes else ""
         names = (rs.name_blob, rs.name_off)
         import time
         _t = [time.perf_counter()]; _nm = []
@@ -216,13 +227,13 @@ class Aligner:
         host_jobs = bool((lens > 700).any())
         if int(lens.sum()) >= 1 << 31:
             raise ValueError("a batch holds 2^31 bases or more: offsets inside a batch are 32-bit (use a smaller batch_reads)")
-        codes = _NT4[ascii_]
+        codes = rs.codes if getattr(rs, "codes", None) is not None else _NT4[ascii_]
         r = torch.from_numpy(ascii_.copy()).to(dev)
         o = torch.from_numpy(offs.astype(np.int64)).to(torch.int32).to(dev)
         l = torch.from_numpy(lens.astype(np.int64)).to(torch.int32).to(dev)
         _lap("host prep + H2D")
         nb = max(int(lens.sum()), 1)
-        ws = SeedWorkspace(n, nb, max_cands=nb, max_occ=max(64 * n, 1 << 16))      # one candidate per base is the hard upper bound
+        ws = self._seed_ws(n, nb)
         _lap("seed workspace")
         s = ws.seed_batch(self.index, r, o, l, self.copt.min_seed_len)
         _lap("seeding")
@@ -243,7 +254,7 @@ class Aligner:
                 # INT32_MIN and must never reach the merge; the device builder refuses such reads itself
                 n_bad = int(L.bmh_extend_last_unsupported())
                 if n_bad:
-                    hj.free(); ws.free()
+                    hj.free()
                     raise NotImplementedError(f"{n_bad} extension job(s) of this batch have a query side longer than 768 bases: reads this long are beyond the "
                                               "extension kernels (the reference's own GASAL2 build is sized by MAX_SEQ_LEN, README.md:38)")
             regs_h = np.ascontiguousarray(hj.merge(out3[:nj].cpu().numpy())) if nr else np.zeros((0, 8), np.int32)
@@ -251,10 +262,7 @@ class Aligner:
             hj.free()
             _lap("extend+merge")
         else:
-            cw = ChainWorkspace(n, max(int(s.n_seeds), 1), opt=self.copt)
-            cw.set_materialize(False)
-            if len(self.contigs) > 1:
-                cw.set_contigs(self.contigs)
+            cw = self._chain_ws(n, max(int(s.n_seeds), 1))
             dj = cw.chain_batch(self.index, r, o, l, s)
             nr, nj = int(dj.n_regs), int(dj.n_jobs)
             out3 = torch.zeros(max(nj, 1), 3, dtype=torch.int32, device=dev)
@@ -270,7 +278,7 @@ class Aligner:
                 d_fin, d_opr = finalize_regs_device(self.index, self.copt, self.ep, po, r, o, regs, nr, dj.d_regs_per_read, dj.d_frac_rep, n,
                                                     contigs=self.contigs if len(self.contigs) > 1 else None)
                 _lap("finalize (device)")
-                fin = np.ascontiguousarray(d_fin.cpu().numpy()); opr = np.ascontiguousarray(d_opr.cpu().numpy().view(np.uint32)[:n]); m = len(fin)
+                fin = self._d2h("fin", d_fin); opr = np.ascontiguousarray(d_opr.cpu().numpy().view(np.uint32)[:n]); m = len(fin)
                 _lap("D2H records")
                 self._lap = _lap; self._prof = (_t, _nm)
                 return self._finish_single(names, codes, offs, lens, r, o, l, fin, opr, m, po, cw, ws, _lap, _t, _nm, as_bytes, fin_t=d_fin)
@@ -305,9 +313,6 @@ class Aligner:
         txt = format_sam(po, names, codes, offs, lens, self.contigs, fin if m else np.zeros((1, 16), np.int32), opr, slot, aln_h, cg_h, md_h,
                          as_bytes=as_bytes)
         _lap("format (host)")
-        if cw is not None:
-            cw.free()
-        ws.free()
         if self.profile:
             import sys
             sys.stderr.write("[aligner] " + ", ".join("%s %.1f ms" % (nm, (_t[i + 1] - _t[i]) * 1e3) for i, nm in enumerate(_nm)) + "\n")
@@ -324,8 +329,8 @@ class Aligner:
             fin_t = torch.from_numpy(fin.copy()).to(dev)
         cg, aln, md = cigar_batch(self.index, r, o, l, fin_t, len(sel), sel_t=torch.from_numpy(sel).to(dev), params=self.ep, opt_w=self.copt.w,
                                   max_cigar=16, md_cap=96)
-        aln_h = aln.cpu().numpy()
-        cg_h = cg.cpu().numpy().view(np.uint32); md_h = md.cpu().numpy()
+        aln_h = self._d2h("aln", aln)
+        cg_h = self._d2h("cg", cg).view(np.uint32); md_h = self._d2h("md", md)
         over = np.flatnonzero(aln_h[:, 7] & 9)
         if over.size:
             cg_c, md_c = cg_h, md_h
@@ -353,9 +358,6 @@ class Aligner:
         aln_h, cg_h, md_h = self._cigars(r, o, l, fin, sel)
         txt = format_sam(po, names, codes, offs, lens, self.contigs, fin if m else np.zeros((1, 16), np.int32), opr, slot, aln_h, cg_h, md_h,
                          h_rec=h_rec, unflag=unflag, as_bytes=self._as_bytes)
-        if cw is not None:
-            cw.free()
-        ws.free()
         return txt
 
     def align_file(self, reads_fa: str, out, batch_reads: int = 0, paired: bool = False, chunk_bases: int = 0) -> int:
@@ -385,8 +387,66 @@ class Aligner:
                 cuts.append(e); b = e
         for b, e in zip(cuts[:-1], cuts[1:]):
             if e > b:
-                out.write(self.align_batch(rs.slice(b, e), id0=b, paired=paired, as_bytes=binary))
+                out.write(self.align_batch(rs.slice(b, e), id0=b, paired=paired, as_bytes="view" if binary else False))   # (binary: the library's buffer, uncopied)
         return n
 
+    # The seeding and chaining workspaces are kept between batches (allocating and freeing a few GB of HBM per batch cost more than
+    # the kernels of an easy batch); a batch that needs more gets a new one, a quarter larger than it asked for.
+    def _d2h(self, key: str, t):
+        """device tensor -> numpy array in a PINNED host buffer kept per key (one DMA instead of a staged pageable copy: the CIGAR /
+        MD / record arrays of a million reads are 200 MB).  The array is valid until the next call with the same key."""
+        t = t.contiguous()
+        nbytes = t.numel() * t.element_size()
+        if nbytes == 0:
+            return t.cpu().numpy()
+        c = getattr(self, "_pin", None)
+        if c is None:
+            c = self._pin = {}
+        buf = c.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = c[key] = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, pin_memory=True)
+        dst = buf[:nbytes].view(t.dtype).view(t.shape)
+        dst.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return dst.numpy()
+
+    def _seed_ws(self, n: int, nb: int):
+        c = getattr(self, "_ws_cache", None)
+        if c is not None and n <= c[1] and nb <= c[2]:
+            return c[0]
+        if c is not None:
+            c[0].free()
+        cn, cb = (n, nb) if c is None else (n + n // 4, nb + nb // 4)
+        ws = SeedWorkspace(cn, cb, max_cands=cb, max_occ=max(64 * cn, 1 << 16))       # one candidate per base is the hard upper bound
+        self._ws_cache = (ws, cn, cb)
+        return ws
+
+    def _chain_ws(self, n: int, n_seeds: int):
+        c = getattr(self, "_cw_cache", None)
+        if c is not None and n <= c[1] and n_seeds <= c[2]:
+            return c[0]
+        if c is not None:
+            c[0].free()
+        cn, cs = (n, n_seeds + n_seeds // 8) if c is None else (n + n // 4, n_seeds + n_seeds // 4)
+        cw = ChainWorkspace(cn, cs, opt=self.copt)
+        cw.set_materialize(False)
+        if len(self.contigs) > 1:
+            cw.set_contigs(self.contigs)
+        self._cw_cache = (cw, cn, cs)
+        return cw
+
+    def __del__(self):                      # an Aligner dropped without close() must not keep its workspaces in HBM
+        try:
+            for nm in ("_ws_cache", "_cw_cache"):
+                c = getattr(self, nm, None)
+                if c is not None:
+                    c[0].free(); setattr(self, nm, None)
+        except Exception:
+            pass
+
     def close(self):
+        for nm in ("_ws_cache", "_cw_cache"):
+            c = getattr(self, nm, None)
+            if c is not None:
+                c[0].free(); setattr(self, nm, None)
         self.index.free()

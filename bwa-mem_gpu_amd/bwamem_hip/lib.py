@@ -31,7 +31,49 @@ EXPORTED_SYMBOLS = [
     "bmh_chain_extend", "bmh_chain_merge", "bmh_chain_extend_merge", "bmh_chain_extend_merge_timing", "bmh_cigar_batch",
     "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
     "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
+    "bmh_reads_load_fasta", "bmh_reads_free",
 ]
+
+
+class ReadSetT(C.Structure):
+    """bmh_read_set_t"""
+    _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_name_bytes", C.c_uint64), ("ascii", C.c_void_p), ("codes", C.c_void_p),
+                ("offs", C.c_void_p), ("lens", C.c_void_p), ("names", C.c_void_p), ("name_offs", C.c_void_p)]
+
+
+class _ReadSetOwner:
+    """keeps a bmh_read_set_t alive for the numpy arrays that look into it; frees it with the last of them"""
+
+    def __init__(self, L, rs):
+        self.L, self.rs = L, rs
+
+    def __del__(self):
+        try:
+            self.L.bmh_reads_free(C.byref(self.rs))
+        except Exception:
+            pass
+
+
+def load_fasta_reads(path: str, n_threads: int = 0) -> dict:
+    """bmh_reads_load_fasta: the read file as numpy arrays over the library's own arrays (no copies; freed with the last array)"""
+    L = load_library()
+    rs = ReadSetT()
+    L.bmh_reads_load_fasta.argtypes = [C.c_char_p, C.c_int, C.POINTER(ReadSetT)]
+    L.bmh_reads_free.argtypes = [C.POINTER(ReadSetT)]
+    if L.bmh_reads_load_fasta(path.encode(), n_threads, C.byref(rs)) != 0:
+        msg = _err(L)
+        raise ValueError(msg) if "expected alternating" in msg else RuntimeError("bmh_reads_load_fasta: " + msg)
+    owner = _ReadSetOwner(L, rs)
+
+    def arr(ptr, n, dt):
+        n = int(n)
+        if n == 0 or not ptr:
+            return np.zeros(0, dt)
+        buf = (C.c_uint8 * (n * np.dtype(dt).itemsize)).from_address(ptr)
+        buf._owner = owner
+        return np.frombuffer(buf, dtype=dt)
+    return dict(ascii=arr(rs.ascii, rs.n_bases, np.uint8), codes=arr(rs.codes, rs.n_bases, np.uint8), offs=arr(rs.offs, rs.n_reads, np.uint64),
+                lens=arr(rs.lens, rs.n_reads, np.uint32), names=arr(rs.names, rs.n_name_bytes, np.uint8), name_offs=arr(rs.name_offs, rs.n_reads, np.uint64))
 
 
 class SeedsT(C.Structure):
@@ -458,7 +500,7 @@ def format_sam(po: "PostOpt", names, reads_flat: np.ndarray, read_offs: np.ndarr
                as_bytes: bool = False):
     """bmh_format_sam (or bmh_format_sam_pe when h_rec / unflag are given) on numpy arrays; contigs = list of (name, length).
     names: list of str, or (blob uint8 array of NUL-terminated names, uint64 offsets).  Returns the text as bytes if
-    as_bytes else str."""
+    as_bytes, as a uint8 array over the library's own buffer if as_bytes == "view", else as str."""
     L = load_library()
     if isinstance(names, tuple):
         nblob, noff = np.ascontiguousarray(names[0], dtype=np.uint8), np.ascontiguousarray(names[1], dtype=np.uint64)
@@ -486,6 +528,11 @@ def format_sam(po: "PostOpt", names, reads_flat: np.ndarray, read_offs: np.ndarr
                              C.byref(ln))
     if not p:
         raise RuntimeError("bmh_format_sam: " + _err(L))
+    if as_bytes == "view":                  # the library's buffer itself as a uint8 array (freed with the array): no copy of the text
+        import weakref
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(int(ln.value), 1),))[: int(ln.value)]
+        weakref.finalize(arr.base if arr.base is not None else arr, L.bmh_free, C.c_void_p(p))
+        return arr
     raw = C.string_at(p, ln.value)
     L.bmh_free(p)
     return raw if as_bytes else raw.decode()

@@ -17,7 +17,28 @@
 
 namespace {
 
-inline void put_int(std::string &s, long long v) { char b[24]; snprintf(b, sizeof(b), "%lld", v); s += b; }
+// decimal digits by hand: a record holds nine or more numbers, and snprintf was a third of the formatting time
+inline void put_int(std::string &s, long long v)
+{
+	char b[24]; int n = 0;
+	unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+	do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+	if (v < 0) b[n++] = '-';
+	const size_t at = s.size();
+	s.resize(at + (size_t)n);
+	char *d = &s[at];
+	for (int i = 0; i < n; ++i) d[i] = b[n - 1 - i];
+}
+// SEQ: bases [qb, qe) of the read as letters, reverse-complemented for the reverse strand (one resize, then a table walk)
+inline void put_seq(std::string &s, const uint8_t *seq, int qb, int qe, bool rev)
+{
+	if (qe <= qb) return;
+	const size_t at = s.size();
+	s.resize(at + (size_t)(qe - qb));
+	char *d = &s[at];
+	if (!rev) for (int k = qb; k < qe; ++k) *d++ = "ACGTN"[seq[k] > 4 ? 4 : seq[k]];
+	else for (int k = qe - 1; k >= qb; --k) *d++ = "TGCAN"[seq[k] > 4 ? 4 : seq[k]];
+}
 
 struct Rec { const int32_t *fin; const int32_t *aln; const uint32_t *cigar; const char *md; };
 
@@ -126,7 +147,8 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 			}
 		}
 		// XA strings per primary (mem_gen_alt)
-		xa.assign(n, std::string());
+		if ((int)xa.size() < n) xa.resize(n);
+		for (int i = 0; i < n; ++i) xa[i].clear();                  // (capacity kept: no allocation per read)
 		if (!po->flag_all) {
 			cnt.assign(n, 0);
 			auto pri = [&](int i) { const int k = a[16 * i + 12]; return (k >= 0 && a[16 * i + 1] >= a[16 * k + 1] * (double)po->XA_drop_ratio) ? k : -1; };
@@ -172,8 +194,7 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 			if (mm) { out += contig_names[m.rid]; out += '\t'; put_int(out, m.pos - (n_contigs > 1 ? contig_offset[m.rid] : 0) + 1); out += "\t0\t*\t"; }
 			else out += "*\t0\t0\t*\t";
 			mate_fields(mm ? m.rid : -1, m.pos, p_rev, 0, nullptr, mm, m.rid, m.pos, m.is_rev, m.n_cigar, m.cigar);
-			if (!p_rev) for (int i = 0; i < l_seq; ++i) out += "ACGTN"[seq[i] > 4 ? 4 : seq[i]];
-			else for (int i = l_seq - 1; i >= 0; --i) out += "TGCAN"[seq[i] > 4 ? 4 : seq[i]];
+			put_seq(out, seq, 0, l_seq, p_rev != 0);
 			out += "\t*\tAS:i:0\tXS:i:0\n";
 			continue;
 		}
@@ -204,8 +225,7 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 					if (!x.aln[2]) { if (c0 == 3 || c0 == 4) qb += x.cigar[0] >> 4; if (c1 == 3 || c1 == 4) qe -= x.cigar[nc - 1] >> 4; }
 					else { if (c0 == 3 || c0 == 4) qe -= x.cigar[0] >> 4; if (c1 == 3 || c1 == 4) qb += x.cigar[nc - 1] >> 4; }
 				}
-				if (!x.aln[2]) for (int k = qb; k < qe; ++k) out += "ACGTN"[seq[k] > 4 ? 4 : seq[k]];
-				else for (int k = qe - 1; k >= qb; --k) out += "TGCAN"[seq[k] > 4 ? 4 : seq[k]];
+				put_seq(out, seq, qb, qe, x.aln[2] != 0);
 				out += "\t*";
 			}
 			if (x.aln[3]) { out += "\tNM:i:"; put_int(out, x.aln[4]); out += "\tMD:Z:"; out += x.md; }
@@ -241,8 +261,13 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 	for (const std::string &p : parts) total += p.size();
 	char *res = (char *)malloc(total + 1);
 	if (!res) { bmh_set_error("bmh_format_sam: out of memory"); return nullptr; }
-	size_t w = 0;
-	for (const std::string &p : parts) { memcpy(res + w, p.data(), p.size()); w += p.size(); }
+	{   // the parts into their places, on the same threads (the text of a million reads is a quarter of a gigabyte)
+		std::vector<size_t> at(n_thr, 0);
+		for (unsigned t = 1; t < n_thr; ++t) at[t] = at[t - 1] + parts[t - 1].size();
+		auto put = [&](unsigned t) { memcpy(res + at[t], parts[t].data(), parts[t].size()); std::string().swap(parts[t]); };
+		if (n_thr == 1) put(0);
+		else { std::vector<std::thread> th; for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(put, t); for (auto &x : th) x.join(); }
+	}
 	res[total] = 0;
 	*len_out = total;
 	return res;

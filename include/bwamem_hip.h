@@ -288,6 +288,23 @@ char *bmh_format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *nam
                      const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap, size_t *len_out);
 void bmh_free(void *p);
 
+/* ---- the read file: one '>' header line and one sequence line per read, the only layout the reference's seeding library parses
+ * (src/GPUSeed/seed_gen.cu:1698-1728; the host takes the same file through kseq, bseq_read src/bwa.c:48-66).  Loads it into the flat
+ * arrays this API takes: the letters back to back (what bmh_seed_batch / bmh_chain_* read in HBM), their nt4 codes (nst_nt4_table,
+ * src/bntseq.c: what the host tail and bmh_format_sam read), offsets, lengths, and the names (the header up to the first blank,
+ * NUL-terminated, back to back: bmh_format_sam's names / name_off).  Blank lines are skipped, CR LF line ends accepted; headers and
+ * sequence lines that do not alternate: BMH_EINVAL.  n_threads <= 0: all host threads.  Arrays are malloc'd: bmh_reads_free. */
+typedef struct {
+	uint64_t n_reads, n_bases, n_name_bytes;
+	uint8_t *ascii, *codes;        /* [n_bases] */
+	uint64_t *offs;                /* [n_reads] start of read r in ascii / codes */
+	uint32_t *lens;                /* [n_reads] */
+	uint8_t *names;                /* [n_name_bytes] */
+	uint64_t *name_offs;           /* [n_reads] */
+} bmh_read_set_t;
+int bmh_reads_load_fasta(const char *path, int n_threads, bmh_read_set_t *out);
+void bmh_reads_free(bmh_read_set_t *r);
+
 /* ---- interleaved pairs (read 2i, 2i+1): mem_pestat, mem_matesw (mate rescue, host local alignment), mem_pair, mem_sam_pe
  * (src/bwamem_pair.c).  Same inputs as bmh_finalize_regs plus read_lens and contig_len; out has room for `cap` records
  * (mate rescue adds regions: regions_in + 16 per read is ample).  out_h[r]: the record of read r's own alignment within

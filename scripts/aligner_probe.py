@@ -28,7 +28,7 @@ for it in range(3):
     t0 = time.perf_counter()
     rs = read_fasta_reads(fa)
     t1 = time.perf_counter()
-    txt = al.align_batch(rs, id0=0, paired=pe, as_bytes=True)
+    txt = al.align_batch(rs, id0=0, paired=pe, as_bytes="view")
     dt = time.perf_counter() - t1
     print("%s: %d reads: FASTA parse %.1f ms; reads in host memory -> %d bytes of SAM in %.1f ms = %.2f Mreads/s end to end" %
           ("PE" if pe else "SE", len(rs), (t1 - t0) * 1e3, len(txt), dt * 1e3, len(rs) / dt / 1e6), flush=True)

@@ -565,61 +565,81 @@ CH_HD inline int ch_text_base(const uint8_t *pac, int64_t l_pac, int64_t i)    /
 // E taken before the lazy-F correction, the lazy-F loop with its exit test, as csrc/local_sw.cpp (the host form, pinned to the
 // reference binary's records) and csrc/pair_kernels.hip (sixteen GPU lanes per alignment) do.  Only the score is wanted here.
 #define CH_SW_MAXQ 200          // MEM_SHORT_LEN: mem_seed_sw gives up on windows of 200 bases or more
+// (the rows live in the thread's private memory: one 16-byte vector per segment position -- the eight lanes of the SSE register it
+// stands for -- so that a position costs one load or store instead of eight; on the device that memory is what the walk waits for)
+struct ch_sw_v8 { int16_t v[8]; } __attribute__((aligned(16)));
+struct ch_sw_q8 { int8_t v[8]; } __attribute__((aligned(8)));
 template <class QB, class TB> CH_HD inline int seed_sw_score(const bmh_chain_opt_t &o, int qlen, QB qbase, int tlen, TB tbase)
 {
-	constexpr int L = 8;
-	const int slen = (qlen + L - 1) / L, n = slen * L;
-	int16_t H0[CH_SW_MAXQ + L], H1[CH_SW_MAXQ + L], Ev[CH_SW_MAXQ + L]; int8_t Q[CH_SW_MAXQ + L];
-	for (int j = 0; j < slen; ++j)
-		for (int l = 0; l < L; ++l) { const int k = j + l * slen; H0[j * L + l] = H1[j * L + l] = Ev[j * L + l] = 0; Q[j * L + l] = (int8_t)(k < qlen ? qbase(k) : 5); }
+	constexpr int L = 8, SMAX = (CH_SW_MAXQ + L - 1) / L;
+	const int slen = (qlen + L - 1) / L;
+	ch_sw_v8 H0[SMAX], H1[SMAX], Ev[SMAX]; ch_sw_q8 Q[SMAX];
+	for (int j = 0; j < slen; ++j) {
+		ch_sw_v8 z; ch_sw_q8 q;
+#pragma unroll
+		for (int l = 0; l < L; ++l) { const int k = j + l * slen; z.v[l] = 0; q.v[l] = (int8_t)(k < qlen ? qbase(k) : 5); }
+		H0[j] = z; H1[j] = z; Ev[j] = z; Q[j] = q;
+	}
 	const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins;
 	auto sat0 = [](int v) { return v < 0 ? 0 : v; };
-	int16_t *h0 = H0, *h1 = H1;
+	ch_sw_v8 *h0 = H0, *h1 = H1;
 	int gmax = 0;
 	for (int i = 0; i < tlen; ++i) {
 		const int t = tbase(i);
 		int hv[L], f[L], mxv[L];
-		for (int l = 0; l < L; ++l) { hv[l] = l ? h0[(slen - 1) * L + l - 1] : 0; f[l] = 0; mxv[l] = 0; }
+		{
+			const ch_sw_v8 last = h0[slen - 1];
+#pragma unroll
+			for (int l = 0; l < L; ++l) { hv[l] = l ? last.v[l - 1] : 0; f[l] = 0; mxv[l] = 0; }
+		}
 		for (int j = 0; j < slen; ++j) {
+			const ch_sw_q8 q8 = Q[j]; const ch_sw_v8 e8 = Ev[j], p8 = h0[j];
+			ch_sw_v8 hn, en;
+#pragma unroll
 			for (int l = 0; l < L; ++l) {
-				const int q = Q[j * L + l];
+				const int q = q8.v[l];
 				const int sc = q == 5 ? 0 : (t > 3 || q > 3) ? -1 : (t == q ? o.a : -o.b);
 				int h = hv[l] + sc; h = h > 32767 ? 32767 : h < -32768 ? -32768 : h;
-				int e = Ev[j * L + l];
+				const int e = e8.v[l];
 				h = h > e ? h : e; h = h > f[l] ? h : f[l];
 				mxv[l] = mxv[l] > h ? mxv[l] : h;
-				h1[j * L + l] = (int16_t)h;
+				hn.v[l] = (int16_t)h;
 				const int hu = h & 0xffff;                               // _mm_subs_epu16 reads the 16 bits as unsigned
 				const int e1 = sat0(e - o.e_del), e2 = sat0(hu - oe_del);
-				Ev[j * L + l] = (int16_t)(e1 > e2 ? e1 : e2);
+				en.v[l] = (int16_t)(e1 > e2 ? e1 : e2);
 				const int f1 = sat0(f[l] - o.e_ins), f2 = sat0(hu - oe_ins);
 				f[l] = f1 > f2 ? f1 : f2;
-				hv[l] = h0[j * L + l];
+				hv[l] = p8.v[l];
 			}
+			h1[j] = hn; Ev[j] = en;
 		}
 		for (int k = 0; k < 16; ++k) {                                   // lazy F (src/ksw.c:627-638)
+#pragma unroll
 			for (int l = L - 1; l > 0; --l) f[l] = f[l - 1];
 			f[0] = 0;
 			bool done = false;
 			for (int j = 0; j < slen; ++j) {
+				ch_sw_v8 h8 = h1[j];
 				bool any = false;
+#pragma unroll
 				for (int l = 0; l < L; ++l) {
-					int h = h1[j * L + l]; h = h > f[l] ? h : f[l];
-					h1[j * L + l] = (int16_t)h;
+					int h = h8.v[l]; h = h > f[l] ? h : f[l];
+					h8.v[l] = (int16_t)h;
 					h = sat0((h & 0xffff) - oe_ins);
 					f[l] = sat0(f[l] - o.e_ins);
 					if (f[l] > h) any = true;
 				}
+				h1[j] = h8;
 				if (!any) { done = true; break; }
 			}
 			if (done) break;
 		}
 		int imax = 0;
+#pragma unroll
 		for (int l = 0; l < L; ++l) imax = imax > mxv[l] ? imax : mxv[l];
 		if (imax > gmax) gmax = imax;
-		int16_t *tmp = h0; h0 = h1; h1 = tmp;
+		ch_sw_v8 *tmp = h0; h0 = h1; h1 = tmp;
 	}
-	(void)n;
 	return gmax;
 }
 // mem_seed_sw :774-807: local alignment score of the seed's neighbourhood (50 bases either side), -1 when the seed or its window is

@@ -27,6 +27,7 @@
 #define MSW_SLEN 40            // segments per lane the kernel keeps in LDS: queries up to 16 * 40 columns in byte mode (which ends at 249), 8 * 40 = 320 in 16-bit mode
 #define MSW_JOBS_PER_BLOCK 8   // 128 threads
 #define MSW_TBUF 64            // target rows staged per refill
+#define MSW_ROW (16 * MSW_JOBS_PER_BLOCK)   // elements of one LDS row: the block's jobs, sixteen lanes each
 
 struct msw_args_t {
 	const bmh_msw_job_t *jobs; uint32_t n_jobs;
@@ -75,11 +76,11 @@ __device__ void msw_pass(const msw_args_t &A, const bool on, const int lanes, co
 	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;
 	int mn = min(min(A.a, -A.b), -1), mx = max(max(A.a, -A.b), -1);
 	const int shift = byte ? (256 - (mn & 0xff)) & 0xff : 0;
-	// lane-private columns: element j of lane l at [j * 16 + l]
+	// lane-private columns: element j of lane l at [j * MSW_ROW + l]
 	for (int j = 0; j < slen; ++j) {
 		const int k = j + l * slen;
-		H0[j * 16 + l] = 0; H1[j * 16 + l] = 0; E[j * 16 + l] = 0; Hm[j * 16 + l] = 0;
-		qc[j * 16 + l] = (uint8_t)((lact && k < qlen) ? qcode(k) : 5);      // 5: padding, scores 0 against everything
+		H0[j * MSW_ROW + l] = 0; H1[j * MSW_ROW + l] = 0; E[j * MSW_ROW + l] = 0; Hm[j * MSW_ROW + l] = 0;
+		qc[j * MSW_ROW + l] = (uint8_t)((lact && k < qlen) ? qcode(k) : 5);      // 5: padding, scores 0 against everything
 	}
 	int gmax = 0, te = -1;
 	int bl_n = 0, bl_val = 0, bl_i = -2;                       // second-best bookkeeping (lane 0 of the group): entries written so far, the open one
@@ -94,21 +95,21 @@ __device__ void msw_pass(const msw_args_t &A, const bool on, const int lanes, co
 		}
 		const bool run = alive && i < tlen;
 		const int t = tbuf[i & (MSW_TBUF - 1)];
-		int hv = msw_shl(run ? (int)h0[(slen > 0 ? slen - 1 : 0) * 16 + l] : 0, l);
+		int hv = msw_shl(run ? (int)h0[(slen > 0 ? slen - 1 : 0) * MSW_ROW + l] : 0, l);
 		int f = 0, mxv = 0;
 		for (int j = 0; j < slen_w; ++j) {
 			if (run && j < slen) {
-				const int q = qc[j * 16 + l];
+				const int q = qc[j * MSW_ROW + l];
 				const int S = q == 5 ? 0 : ((t > 3 || q > 3) ? -1 : (t == q ? A.a : -A.b));
 				int h = byte ? msw_sat0(min(hv + S + shift, 255) - shift) : max(min(hv + S, 32767), -32768);
-				int e = E[j * 16 + l];
+				int e = E[j * MSW_ROW + l];
 				h = max(h, e); h = max(h, f);
 				mxv = max(mxv, h);
-				h1[j * 16 + l] = (uint16_t)h;
+				h1[j * MSW_ROW + l] = (uint16_t)h;
 				e = max(msw_sat0(e - A.e_del), msw_sat0(h - oe_del));
-				E[j * 16 + l] = (uint16_t)e;
+				E[j * MSW_ROW + l] = (uint16_t)e;
 				f = max(msw_sat0(f - A.e_ins), msw_sat0(h - oe_ins));
-				hv = h0[j * 16 + l];
+				hv = h0[j * MSW_ROW + l];
 			}
 		}
 		// lazy F (ksw.c:497-511, 627-638): at most 16 rounds; a round ends the whole loop at the first segment where no lane's F can still raise H
@@ -119,8 +120,8 @@ __device__ void msw_pass(const msw_args_t &A, const bool on, const int lanes, co
 			while (__any(lz)) {
 				bool more = false;
 				if (lz) {
-					const int h = max((int)h1[j * 16 + l], f);
-					h1[j * 16 + l] = (uint16_t)h;
+					const int h = max((int)h1[j * MSW_ROW + l], f);
+					h1[j * MSW_ROW + l] = (uint16_t)h;
 					const int hh = msw_sat0(h - oe_ins);
 					f = msw_sat0(f - A.e_ins);
 					more = lact && f > hh;
@@ -143,7 +144,7 @@ __device__ void msw_pass(const msw_args_t &A, const bool on, const int lanes, co
 			}
 			if (imax > gmax) {
 				gmax = imax; te = i;
-				for (int j = 0; j < slen; ++j) Hm[j * 16 + l] = h1[j * 16 + l];
+				for (int j = 0; j < slen; ++j) Hm[j * MSW_ROW + l] = h1[j * MSW_ROW + l];
 				if ((byte && gmax + shift >= 255) || gmax >= endsc) alive = false;
 			}
 			uint16_t *tsw = h0; h0 = h1; h1 = tsw;
@@ -157,7 +158,7 @@ __device__ void msw_pass(const msw_args_t &A, const bool on, const int lanes, co
 	if (on && (!byte || R.score != 255)) {
 		// end of the query: the largest H of the best row, the smallest position among equals (ksw.c:540-547)
 		int bv = -1, bp = 0x7FFFFFFF;
-		for (int j = 0; j < slen; ++j) if (l < lanes) { const int v = Hm[j * 16 + l], pos = j + l * slen; if (v > bv || (v == bv && pos < bp)) { bv = v; bp = pos; } }
+		for (int j = 0; j < slen; ++j) if (l < lanes) { const int v = Hm[j * MSW_ROW + l], pos = j + l * slen; if (v > bv || (v == bv && pos < bp)) { bv = v; bp = pos; } }
 		int key = l < lanes ? (bv << 12 | (0xFFF - min(bp, 0xFFF))) : -1;        // positions < 4096 (MSW_SLEN * 16 = 640)
 		key = msw_gmax(key);
 		R.qe = 0xFFF - (key & 0xFFF);
@@ -178,10 +179,14 @@ __device__ void msw_pass(const msw_args_t &A, const bool on, const int lanes, co
 	}
 }
 
-__global__ void __launch_bounds__(16 * MSW_JOBS_PER_BLOCK) msw_kernel(msw_args_t A)
+// LDS: four 16-bit arrays and the query codes, each [cap][MSW_JOBS_PER_BLOCK][16]: segment j of the block's eight jobs side by side,
+// so that a wave's four jobs read one row of 64 dwords -- every bank once (with the jobs' columns one after the other all four hit
+// the same banks) -- and `cap`, the longest column of the batch, sizes the block: 12 KB for 150 bp mates instead of 46 KB for the
+// longest the kernel takes, four times the waves per CU for a loop that waits for its LDS round trips.
+__global__ void __launch_bounds__(16 * MSW_JOBS_PER_BLOCK) msw_kernel(msw_args_t A, const int cap)
 {
-	__shared__ uint16_t sH0[MSW_JOBS_PER_BLOCK][MSW_SLEN * 16], sH1[MSW_JOBS_PER_BLOCK][MSW_SLEN * 16], sE[MSW_JOBS_PER_BLOCK][MSW_SLEN * 16], sHm[MSW_JOBS_PER_BLOCK][MSW_SLEN * 16];
-	__shared__ uint8_t sq[MSW_JOBS_PER_BLOCK][MSW_SLEN * 16], st[MSW_JOBS_PER_BLOCK][MSW_TBUF];
+	extern __shared__ __align__(16) uint8_t msw_lds[];
+	__shared__ uint8_t st[MSW_JOBS_PER_BLOCK][MSW_TBUF];
 	const int g = threadIdx.x >> 4;
 	const uint32_t jid = blockIdx.x * MSW_JOBS_PER_BLOCK + g;
 	const bool on = jid < A.n_jobs;
@@ -198,7 +203,9 @@ __global__ void __launch_bounds__(16 * MSW_JOBS_PER_BLOCK) msw_kernel(msw_args_t
 	auto tfwd = [&](int i) { return msw_text(A, rb + i); };
 	msw_res_t R1;
 	uint32_t *bl = A.blist + (on ? J.bl_off : 0);
-	msw_pass(A, on, lanes, l_ms, tlen, qfwd, tfwd, J.xtra, sH0[g], sH1[g], sE[g], sHm[g], sq[g], st[g], bl, R1);
+	uint16_t *sH0 = (uint16_t *)msw_lds + g * 16, *sH1 = sH0 + (size_t)cap * MSW_ROW, *sE = sH1 + (size_t)cap * MSW_ROW, *sHm = sE + (size_t)cap * MSW_ROW;
+	uint8_t *sq = msw_lds + (size_t)cap * MSW_ROW * 8 + g * 16;
+	msw_pass(A, on, lanes, l_ms, tlen, qfwd, tfwd, J.xtra, sH0, sH1, sE, sHm, sq, st[g], bl, R1);
 	int tb = -1, qb = -1;
 	const bool second = on && (J.xtra & BMH_SW_XSTART) && !((J.xtra & BMH_SW_XSUBO) && R1.score < (J.xtra & 0xffff));
 	if (__any(second)) {
@@ -208,7 +215,7 @@ __global__ void __launch_bounds__(16 * MSW_JOBS_PER_BLOCK) msw_kernel(msw_args_t
 		auto qrev = [&](int k) { return qfwd(qe - k); };
 		auto trev = [&](int i) { return i <= te ? msw_text(A, rb + (te - i)) : msw_text(A, rb + i); };
 		msw_res_t R2;
-		msw_pass(A, second, lanes, qe + 1, tlen, qrev, trev, BMH_SW_XSTOP | R1.score, sH0[g], sH1[g], sE[g], sHm[g], sq[g], st[g], bl, R2);
+		msw_pass(A, second, lanes, qe + 1, tlen, qrev, trev, BMH_SW_XSTOP | R1.score, sH0, sH1, sE, sHm, sq, st[g], bl, R2);
 		if (second && R1.score == R2.score) { tb = R1.te - R2.te; qb = R1.qe - R2.qe; }
 	}
 	if (on && (threadIdx.x & 15) == 0) {
@@ -247,6 +254,9 @@ extern "C" int bmh_matesw_batch_device(const bmh_index_t *idx, const uint8_t *d_
 		else S = it->second;
 	}
 	uint64_t bl = 0;
+	int cap = 1;                                             // the longest lane-private column of the batch, in segments
+	for (uint64_t k = 0; k < n_jobs; ++k) { const int lanes = (jobs[k].xtra & BMH_SW_XBYTE) ? 16 : 8; const int sl = (jobs[k].l_ms + lanes - 1) / lanes; cap = sl > cap ? sl : cap; }
+	if (cap > MSW_SLEN) { bmh_set_error("bmh_matesw_batch_device: a job the kernel does not take (see bmh_matesw_device_takes)"); return BMH_EINVAL; }
 	for (uint64_t k = 0; k < n_jobs; ++k) { jobs[k].bl_off = (uint32_t)bl; bl += (uint64_t)(jobs[k].re - jobs[k].rb) / 2 + 2; if (bl >> 32) { bmh_set_error("bmh_matesw_batch_device: windows too long"); return BMH_ECAPACITY; } }
 	if (n_jobs > S->cap_jobs) {
 		if (S->d_jobs) (void)hipFree(S->d_jobs);
@@ -268,7 +278,7 @@ extern "C" int bmh_matesw_batch_device(const bmh_index_t *idx, const uint8_t *d_
 	A.jobs = S->d_jobs; A.n_jobs = (uint32_t)n_jobs; A.reads = d_reads; A.read_offs = d_offs; A.pac = idx->dev.pac; A.l_pac = (long long)idx->dev.l_pac;
 	A.a = ep->a; A.b = ep->b; A.o_del = ep->o_del; A.e_del = ep->e_del; A.o_ins = ep->o_ins; A.e_ins = ep->e_ins;
 	A.blist = S->d_bl; A.out = S->d_out;
-	msw_kernel<<<(unsigned)((n_jobs + MSW_JOBS_PER_BLOCK - 1) / MSW_JOBS_PER_BLOCK), 16 * MSW_JOBS_PER_BLOCK, 0, st>>>(A);
+	msw_kernel<<<(unsigned)((n_jobs + MSW_JOBS_PER_BLOCK - 1) / MSW_JOBS_PER_BLOCK), 16 * MSW_JOBS_PER_BLOCK, (size_t)cap * MSW_ROW * 9, st>>>(A, cap);
 	HIPCK(hipMemcpyAsync(out, S->d_out, sizeof(int32_t) * 7 * n_jobs, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));
 	HIPCK(hipGetLastError());

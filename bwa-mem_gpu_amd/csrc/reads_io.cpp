@@ -87,6 +87,7 @@ extern "C" int bmh_reads_load_fasta(const char *path, int n_threads, bmh_read_se
 	// chunks that begin at a header: the first '>' that follows a newline at or behind the nominal cut
 	unsigned T = n_threads > 0 ? (unsigned)n_threads : std::thread::hardware_concurrency();
 	if (T == 0) T = 1;
+	if (T > 32) T = 32;                                    // (memory-bound beyond a few threads; the host may show hundreds of hardware threads)
 	if (sz < (1u << 20)) T = 1;
 	std::vector<size_t> cut(T + 1, sz);
 	cut[0] = 0;

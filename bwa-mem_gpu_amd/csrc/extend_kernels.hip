@@ -1176,7 +1176,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	const uint32_t mq = desc && desc->max_qlen ? desc->max_qlen : 0xFFFFFFFFu;
 	// the packed classes hold the bulk of the jobs when they are enabled: they go first, widest (longest running) first
 	if (pk_ok) {
-		// grids sized to what is resident at once (the waves draw their jobs): 3 waves per SIMD for P >= 9 (768 blocks), 4 below
+		// grids sized to what is resident at once (the waves draw their jobs): 3 waves per SIMD beyond PK_WAVES4_MAXP pairs per lane (768 blocks), 4 up to there
 		unsigned g4 = (unsigned)((n + 63) / 64), g8 = (unsigned)((n + 31) / 32);
 		if (g4 > max_grid) g4 = max_grid;
 		if (g8 > max_grid) g8 = max_grid;
@@ -1185,16 +1185,16 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		if (mq > 112) launch_pk<4, 16>(a, S[3], g4w);
 		if (mq > 96) launch_pk<4, 14>(a, S[0], g4w);
 		if (mq > 80) launch_pk<4, 12>(a, S[1], g4w);
-		if (mq > 64) launch_pk<4, 10>(a, S[2], g4w);
+		if (mq > 64) launch_pk<4, 10>(a, S[2], PK_WAVES4_MAXP >= 10 ? g4 : g4w);
 		if (mq > 48) launch_pk<4, 8>(a, S[3], g4);
 		if (mq > 32) launch_pk<4, 6>(a, S[0], g4);
 		launch_pk<4, 4>(a, S[1], g4);
-		if (mq > 128) launch_pk<8, 9>(a, S[2], g8w);
-		if (mq > 144) launch_pk<8, 10>(a, S[3], g8w);
+		if (mq > 128) launch_pk<8, 9>(a, S[2], PK_WAVES4_MAXP >= 9 ? g8 : g8w);
+		if (mq > 144) launch_pk<8, 10>(a, S[3], PK_WAVES4_MAXP >= 10 ? g8 : g8w);
 		if (mq > 160) launch_pk<8, 12>(a, S[0], g8w);
 		if (mq > 192) launch_pk<8, 14>(a, S[1], g8w);
 		if (mq > 224) launch_pk<8, 16>(a, S[2], g8w);
-		if (mq > 256) launch_pk<16, 9>(a, S[3], g16w);
+		if (mq > 256) launch_pk<16, 9>(a, S[3], PK_WAVES4_MAXP >= 9 ? g16 : g16w);
 	}
 	// (narrow classes first measured better than widest first: 10.8 vs 11.1 ms)
 	// class C of extend16 holds the queries of 16 (C - 1) + 1 .. 16 C columns; wide class C those of 64 (C - 1) + 1 .. 64 C, and class 5

@@ -21,6 +21,9 @@
 
 // target bases of an alignment staged in LDS, by group width (the 4-lane groups are the many small queries: 64 of them per block)
 #define PK_TCAP(G) ((G) == 4 ? 384 : (G) == 8 ? 512 : 640)
+#ifndef PK_WAVES4_MAXP
+#define PK_WAVES4_MAXP 10     // classes of up to this many pairs per lane run four waves per SIMD (registers and grid; 120 VGPRs at 10 pairs), the larger ones three (8 -> 10: -0.5 % at 150 bp, -0.7 % at 300 bp)
+#endif
 #ifndef PK_BOUND_MASK
 #define PK_BOUND_MASK 15      // the exact early-stop bound is evaluated every (mask + 1)-th row of a wave (every 2nd / 4th / 8th / 16th / 32nd: 17.6 / 17.3 / 17.2 / 17.1 / 17.4 ms)
 #endif
@@ -379,7 +382,7 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t &K, const int zdrop, ui
 // The kernel: every group of G lanes runs its own alignment and row index and draws its next job from the class counter when
 // the alignment ends (as extend16_kernel does with its four rows).
 template <int G, int P, bool SAME_OE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P >= 9 ? 3 : 4))) extpk_kernel(ext_args_t A)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P > PK_WAVES4_MAXP ? 3 : 4))) extpk_kernel(ext_args_t A)
 {
 	constexpr int C = 2 * P, PP = (P + 3) & ~3, PS = PP + 4, NG = 256 / G;
 	const int lane = threadIdx.x & 63, l = lane & (G - 1);

@@ -30,6 +30,8 @@
 // sector; all state is in registers, there is no LDS use in these kernels
 // (the index is far larger than LDS and each block is used once).
 #include <cstring>
+#include <string>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include <stdint.h>
@@ -266,33 +268,60 @@ __global__ void __launch_bounds__(256) cand_scatter_kernel(const cand_t *__restr
 // both have the same occurrences from here on, so it ends at the same begin and the filter would
 // drop it -- it stops now and is marked dropped.  Lanes of a pass split across two waves simply
 // miss this shortcut (the filter still drops them).
+// Phases (round 3): the kernel is bound by instruction issue (197 instructions per wave step at 38 % lane utilisation: a wave steps
+// until its longest walk ends, 22.7 times for 8.8 steps per candidate), so the walk is cut into phases: after max_iter steps the
+// lanes that are still searching park their state (32 bytes) in a list -- in lane order, so the candidates of a pass stay
+// adjacent and in step -- and the next launch (RESUME) continues that list with full waves.
+// The list is BWD_NSUB lists, block b appending to list b mod BWD_NSUB (one counter each: appends to a single address run at ~90 per
+// microsecond, 650 000 waves would take 7 ms); a list holds at most the lanes of the blocks that feed it (sub_cap).
+#define BWD_NSUB 64
+struct bwd_state_t { uint64_t lo, hi; uint32_t read, t; uint16_t x, end, i, beg; };     // 32 B (a parked lane has i >= 0)
+template <bool RESUME>
 __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_view_t rv, uint64_t n_cands, int min_seed_len,
                                                             const cand_t *__restrict__ cand_a, const uint64_t *__restrict__ cand_k,
                                                             const uint32_t *__restrict__ perm,
                                                             res_t *__restrict__ res_a, uint64_t *__restrict__ res_k,
-                                                            unsigned long long *__restrict__ stats)
+                                                            unsigned long long *__restrict__ stats,
+                                                            const bwd_state_t *__restrict__ in_state, const uint32_t *__restrict__ in_count,
+                                                            bwd_state_t *__restrict__ out_state, uint32_t *__restrict__ out_count, const uint32_t sub_cap, const int max_iter)
 {
 	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int lane = __lane_id();
+	const uint32_t sub = blockIdx.x % BWD_NSUB;                              // the list this block appends to (and, resumed, reads from)
+	if (RESUME) {
+		n_cands = in_count[sub];
+		t = (uint64_t)(blockIdx.x / BWD_NSUB) * blockDim.x + threadIdx.x;    // index inside the list
+		in_state += (size_t)sub * sub_cap;
+		if ((uint64_t)(blockIdx.x / BWD_NSUB) * blockDim.x >= n_cands) return;   // (a resumed launch is sized by the lists' upper bound)
+	}
+	if (out_state) { out_state += (size_t)sub * sub_cap; out_count += sub; }
 	bool live = t < n_cands;
 	cand_t c = {CAND_INVALID, 0, 0, 0};
 	uint64_t lo = 0, hi = 0;
-	if (live) { const uint32_t src = perm[t]; c = cand_a[src]; lo = cand_k[src]; hi = lo + c.s - 1; }
-	int x = (int)(c.xe >> 16), end = (int)(c.xe & 0xFFFF);
-	int i = x - 1, beg = x;
+	int x = 0, end = 0, i = -1, beg = 0;
+	uint32_t t_out = (uint32_t)t;
+	if (RESUME) {
+		if (live) { const bwd_state_t s = in_state[t]; lo = s.lo; hi = s.hi; c.read = s.read; t_out = s.t; x = s.x; end = s.end; i = s.i; beg = s.beg; c.s = (uint32_t)(hi - lo + 1); }
+	} else {
+		if (live) { const uint32_t src = perm[t]; c = cand_a[src]; lo = cand_k[src]; hi = lo + c.s - 1; }
+		x = (int)(c.xe >> 16); end = (int)(c.xe & 0xFFFF);
+		i = x - 1; beg = x;
+	}
 	bool act = live && i >= 0, dropped = false;
 	// last lane of my pass segment inside this wave
-	const uint32_t nread = __shfl_down(c.read, 1), nx = __shfl_down((uint32_t)x, 1);
-	const bool last_of_seg = lane == 63 || !live || nread != c.read || nx != (uint32_t)x;
+	// (a parked list holds the waves' survivors in the order the waves finished: two parts of one pass may meet in it the wrong way
+	// round, and the lanes above must be the LONGER candidates -- so a segment also ends where the original index does not grow)
+	const uint32_t nread = __shfl_down(c.read, 1), nx = __shfl_down((uint32_t)x, 1), nt = __shfl_down(t_out, 1);
+	const bool last_of_seg = lane == 63 || !live || nread != c.read || nx != (uint32_t)x || nt <= t_out;
 	const unsigned long long segb = __ballot(last_of_seg);
 	const int seg_end = lane + __builtin_ctzll(segb >> lane);      // >= lane, bit 63 is always set
 	const unsigned long long above = seg_end > lane ? ((~0ull >> (63 - (seg_end - lane - 1))) << 1 << lane) : 0ull;  // lanes lane+1..seg_end
 	uint32_t size = c.s;
-	unsigned st_iter = 0, st_steps = 0, st_uniq = 0, st_u0 = (live && i >= 0 && c.s == 1) ? 1u : 0u, st_x0 = (live && i < 0) ? 1u : 0u;
+	unsigned st_iter = 0, st_steps = 0, st_uniq = 0, st_u0 = (!RESUME && live && i >= 0 && c.s == 1) ? 1u : 0u, st_x0 = (!RESUME && live && i < 0) ? 1u : 0u;
 	// the read's packed words are re-fetched only when the walk crosses into the next one (16 / 32 bases)
 	uint32_t rw = 0, rm = 0;
 	if (act) { rw = rv.pk[(size_t)(i >> 4) * rv.n_reads + c.read]; rm = rv.nm[(size_t)(i >> 5) * rv.n_reads + c.read]; }
-	while (__any(act)) {
+	for (int it = 0; it < max_iter && __any(act); ++it) {
 		if (stats) { ++st_iter; st_steps += act ? 1u : 0u; st_uniq += (act && size == 1) ? 1u : 0u; }
 		if (act) {
 			const int b = (int)((rw >> ((i & 15) << 1)) & 3);
@@ -318,16 +347,28 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 		if (act && am && nsize == size) { act = false; dropped = true; }
 	}
 	if (stats) {
-		atomicAdd(stats + 1, (unsigned long long)st_steps); atomicAdd(stats + 4, (unsigned long long)st_uniq); atomicAdd(stats + 5, (unsigned long long)st_u0); atomicAdd(stats + 6, (unsigned long long)st_x0); { const bool nowalk = !__any(live && !st_x0); if (lane == 0 && nowalk) atomicAdd(stats + 7, 1ull); }
+		atomicAdd(stats + 1, (unsigned long long)st_steps); atomicAdd(stats + 4, (unsigned long long)st_uniq); atomicAdd(stats + 5, (unsigned long long)st_u0); atomicAdd(stats + 6, (unsigned long long)st_x0); { const bool nowalk = !__any(live && !st_x0); if (!RESUME && lane == 0 && nowalk) atomicAdd(stats + 7, 1ull); }
 		if (lane == 0) { atomicAdd(stats, (unsigned long long)st_iter); atomicAdd(stats + 2, 1ull); atomicMax(stats + 3, (unsigned long long)st_iter); }
 	}
-	if (live) {
+	// still searching when the phase ends: parked for the next launch, in lane order
+	const unsigned long long sm = __ballot(act);
+	if (sm) {
+		const int first = (int)__builtin_ctzll(sm);
+		uint32_t base = 0;
+		if (lane == first) base = atomicAdd(out_count, (uint32_t)__builtin_popcountll(sm));
+		base = __shfl(base, first);
+		if (act) {
+			bwd_state_t s; s.lo = lo; s.hi = hi; s.read = c.read; s.t = t_out; s.x = (uint16_t)x; s.end = (uint16_t)end; s.i = (uint16_t)i; s.beg = (uint16_t)beg;
+			out_state[base + (uint32_t)__builtin_popcountll(sm & ((1ull << lane) - 1ull))] = s;
+		}
+	}
+	if (live && !act) {
 		res_t o;
 		o.read = c.read; o.be = ((uint32_t)beg << 16) | (uint32_t)end;
 		o.s = (!dropped && end - beg >= min_seed_len) ? (uint32_t)(hi - lo + 1) : 0u;
 		o.pad = 0;
-		res_a[t] = o;
-		res_k[t] = lo;
+		res_a[t_out] = o;
+		res_k[t_out] = lo;
 	}
 }
 
@@ -695,6 +736,8 @@ struct bmh_seed_ws {
 	unsigned long long *counter;
 	uint4 *scratch; size_t scratch_entries;       // fused kernel: [slot][read] candidate columns
 	uint64_t *skeys, *skeys2; uint32_t *svals, *svals2;   // SMEM sort
+	bwd_state_t *bwd_state[2]; uint64_t bwd_state_cap;   // parked walks between the phases of the backward search (allocated on first use)
+	uint32_t *bwd_cnt;                                   // [8][BWD_NSUB] list lengths per phase
 	void *scan_tmp; size_t scan_tmp_bytes;
 	hipEvent_t ev[8];
 	float ms[7];
@@ -720,6 +763,7 @@ extern "C" bmh_seed_ws_t *bmh_seed_ws_create(uint32_t max_reads, uint64_t max_ba
 	A(w->rows, 8 * w->max_occ); A(w->qbeg, 8 * w->max_occ); A(w->score, 4 * w->max_occ);
 	A(w->n_ref_pos, 4 * (size_t)max_reads); A(w->prefix, 4 * (size_t)max_reads);
 	A(w->counter, 128);
+	A(w->bwd_cnt, 4 * 8 * BWD_NSUB);
 	A(w->skeys, 8 * w->max_cands); A(w->skeys2, 8 * w->max_cands); A(w->svals, 4 * w->max_cands); A(w->svals2, 4 * w->max_cands);
 	size_t t1 = 0, t2 = 0, t3 = 0;
 	rocprim::radix_sort_pairs(nullptr, t3, w->skeys, w->skeys2, w->svals, w->svals2, (size_t)w->max_cands, 0, 64, 0);
@@ -739,7 +783,7 @@ extern "C" void bmh_seed_ws_free(bmh_seed_ws_t *w)
 	if (!w) return;
 	void *ps[] = {w->pk, w->nm, w->cand_a, w->cand_k, w->res_a, w->res_k, w->n_cand, w->cand_base, w->occ,
 	              w->occ_off, w->rows, w->qbeg, w->score, w->n_ref_pos, w->prefix, w->counter, w->scan_tmp,
-	              w->scratch, w->skeys, w->skeys2, w->svals, w->svals2};
+	              w->scratch, w->skeys, w->skeys2, w->svals, w->svals2, w->bwd_state[0], w->bwd_state[1], w->bwd_cnt};
 	for (void *p : ps) if (p) (void)hipFree(p);
 	for (int i = 0; i < 8; ++i) if (w->ev[i]) (void)hipEventDestroy(w->ev[i]);
 	free(w);
@@ -748,6 +792,19 @@ extern "C" void bmh_seed_ws_free(bmh_seed_ws_t *w)
 extern "C" void bmh_seed_last_timing(const bmh_seed_ws_t *w, float ms[7]) { memcpy(ms, w->ms, sizeof(float) * 7); }
 
 static inline unsigned nblk(uint64_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
+
+// room for the walks a phase of the backward search parks (at most every candidate), two lists used in turn
+static int bwd_state_reserve(bmh_seed_ws *w, uint64_t n)
+{
+	if (n <= w->bwd_state_cap) return BMH_OK;
+	for (int k = 0; k < 2; ++k) { if (w->bwd_state[k]) (void)hipFree(w->bwd_state[k]); w->bwd_state[k] = nullptr; }
+	w->bwd_state_cap = 0;
+	const uint64_t cap = n + n / 8 + 1024;
+	for (int k = 0; k < 2; ++k)
+		if (hipMalloc((void **)&w->bwd_state[k], sizeof(bwd_state_t) * cap) != hipSuccess) { bmh_set_error("bmh_seed_batch: no memory for %llu parked walks of the backward search", (unsigned long long)cap); return BMH_ENOMEM; }
+	w->bwd_state_cap = cap;
+	return BMH_OK;
+}
 
 // the occurrences of a batch are known before anything is written to the three output arrays: when they do not fit, the arrays
 // are replaced by larger ones (the default capacity, 64 per read, is a guess -- reads from high-copy repeats have thousands)
@@ -903,14 +960,36 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 		static const bool want_stats = getenv("BMH_SEED_STATS") != nullptr;
 		unsigned long long *d_st = want_stats ? (unsigned long long *)w->counter + 8 : nullptr;
 		if (want_stats) HIPCK(hipMemsetAsync(d_st, 0, 64, st));
-		if (n_cands) smem_backward_kernel<<<nblk(n_cands, 256), 256, 0, st>>>(f, rv, n_cands, min_seed_len, w->cand_a, w->cand_k, w->svals, w->res_a, w->res_k, d_st);
+		if (n_cands) {
+			// phases of the walk (BMH_SEED_BWD_PHASES="k1,k2,..": steps per phase, the last phase runs to the end).  Default: one launch --
+			// measured on the bench workload, "6,12,24,48" takes the wave-iterations from 14.7 M to 9.2 M (lane utilisation 38.5 -> 61.7 %)
+			// and the kernel from 6.14 to 6.69 ms: what it waits for is its gathers, not its instructions
+			const std::vector<int> phases = [] {
+				std::vector<int> v; const char *e = getenv("BMH_SEED_BWD_PHASES"); std::string t = e ? e : "";
+				for (size_t p = 0; p < t.size();) { size_t q = t.find(',', p); if (q == std::string::npos) q = t.size(); const int k = atoi(t.substr(p, q - p).c_str()); if (k > 0) v.push_back(k); p = q + 1; }
+				return v; }();
+			const int np = (int)(phases.size() < 7 ? phases.size() : 7);
+			const unsigned nb = nblk(n_cands, 256);
+			const uint32_t sub_cap = ((nb + BWD_NSUB - 1) / BWD_NSUB) * 256u;        // lanes of the blocks that feed one list
+			if (np && bwd_state_reserve(w, (uint64_t)sub_cap * BWD_NSUB) != BMH_OK) return BMH_ENOMEM;
+			uint32_t *cnt = w->bwd_cnt;                                              // [np][BWD_NSUB] survivors of every phase
+			if (np) HIPCK(hipMemsetAsync(cnt, 0, 4 * (size_t)np * BWD_NSUB, st));
+			const int big = 0x7FFFFFFF;
+			smem_backward_kernel<false><<<nb, 256, 0, st>>>(f, rv, n_cands, min_seed_len, w->cand_a, w->cand_k, w->svals, w->res_a, w->res_k, d_st,
+			                                                nullptr, nullptr, np ? w->bwd_state[0] : nullptr, np ? cnt : nullptr, sub_cap, np ? phases[0] : big);
+			// (a resumed launch is sized by an upper bound of its lists -- every lane of the first launch -- and the blocks beyond a list leave at once)
+			for (int ph = 1; ph <= np; ++ph)
+				smem_backward_kernel<true><<<(sub_cap / 256u) * BWD_NSUB, 256, 0, st>>>(f, rv, n_cands, min_seed_len, w->cand_a, w->cand_k, w->svals, w->res_a, w->res_k, d_st,
+				                                                                       w->bwd_state[(ph - 1) & 1], cnt + (size_t)(ph - 1) * BWD_NSUB, ph < np ? w->bwd_state[ph & 1] : nullptr,
+				                                                                       ph < np ? cnt + (size_t)ph * BWD_NSUB : nullptr, sub_cap, ph < np ? phases[ph] : big);
+		}
 		if (want_stats) {
 			unsigned long long h[8];
 			HIPCK(hipStreamSynchronize(st));
 			HIPCK(hipMemcpy(h, d_st, 64, hipMemcpyDeviceToHost));
 			fprintf(stderr, "[backward] lane-steps on a one-row interval %llu (%.1f%%), candidates that start on one %llu (%.1f%%)\n", h[4], 100.0 * h[4] / (h[1] ? h[1] : 1), h[5], 100.0 * h[5] / (n_cands ? n_cands : 1));
 			fprintf(stderr, "[backward] candidates of a pass that starts at read position 0 (no walk) %llu (%.1f%%); waves made of such only %llu\n", h[6], 100.0 * h[6] / (n_cands ? n_cands : 1), h[7]);
-			fprintf(stderr, "[backward] candidates %llu, waves %llu, wave-iterations %llu (%.1f per wave, max %llu), lane-steps %llu (%.1f per candidate): lane utilisation %.1f%%\n",
+			fprintf(stderr, "[backward] candidates %llu, waves %llu (all phases), wave-iterations %llu (%.1f per wave, max %llu), lane-steps %llu (%.1f per candidate): lane utilisation %.1f%%\n",
 			        (unsigned long long)n_cands, h[2], h[0], (double)h[0] / (h[2] ? h[2] : 1), h[3], h[1], (double)h[1] / (n_cands ? n_cands : 1), 100.0 * h[1] / (64.0 * (h[0] ? h[0] : 1)));
 		}
 	}

@@ -1,13 +1,13 @@
 #!/bin/bash
 # A/B of environment knobs on one box: scripts/env_ab.sh <rounds> <config> <config> ...
-# a config is "-" (nothing set) or VAR=value[,VAR=value...]; every round runs every config once (interleaved)
+# a config is "-" (nothing set) or VAR=value[;VAR=value...]; every round runs every config once (interleaved)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R
 rounds=$1; shift
 export BENCH_INDEX_CACHE=${BENCH_INDEX_CACHE:-/tmp/bmh_cache}
 ARGS=${AB_ARGS:---no-pcie --cpu-sample 0 --no-next-rows --steps 10 --warmup 2}
 for r in $(seq 1 $rounds); do
   for c in "$@"; do
-    ( if [ "$c" != "-" ]; then for kv in ${c//,/ }; do export "$kv"; done; fi
+    ( if [ "$c" != "-" ]; then for kv in ${c//;/ }; do export "$kv"; done; fi
     python bench.py $ARGS 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); i=d['stage_ms_isolated']; s=d['stage_ms']

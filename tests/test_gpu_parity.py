@@ -159,6 +159,15 @@ def test_seeding_unique_interval_shortcut(hip, oracle, case):
     want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
     got = gpu_seed(hip, idx, flat, offs, lens, genome=g, densify=None if case == "sparse_sa" else 1)
     common.assert_seeds_equal(got, want)
+    # the backward search in phases (the walks that are still searching after k steps parked and resumed in full waves: an
+    # experiment knob, off by default): same seeds, also with a phase per step and with lists that meet out of order
+    for phases in ("1", "2,3,5", "6,12,24,48"):
+        os.environ["BMH_SEED_BWD_PHASES"] = phases
+        try:
+            got = gpu_seed(hip, idx, flat, offs, lens, genome=g, densify=None if case == "sparse_sa" else 1)
+        finally:
+            os.environ.pop("BMH_SEED_BWD_PHASES", None)
+        common.assert_seeds_equal(got, want, "phases " + phases + ": ")
 
 
 def gpu_extend(B, jobs, zdrop=0, want_raw=True, scoring=None, packed=None):

@@ -32,3 +32,14 @@ for it in range(3):
     dt = time.perf_counter() - t1
     print("%s: %d reads: FASTA parse %.1f ms; reads in host memory -> %d bytes of SAM in %.1f ms = %.2f Mreads/s end to end" %
           ("PE" if pe else "SE", len(rs), (t1 - t0) * 1e3, len(txt), dt * 1e3, len(rs) / dt / 1e6), flush=True)
+# the whole file through align_file in four batches (single-end: the two-stage pipeline; paired: one batch after the other)
+class _Sink:
+    mode = "wb"
+    def __init__(self): self.n = 0
+    def write(self, b): self.n += len(b)
+for it in range(2):
+    sink = _Sink()
+    t0 = time.perf_counter()
+    al.align_file(fa, sink, batch_reads=n_reads // 4, paired=pe)
+    dt = time.perf_counter() - t0
+    print("%s: align_file, %d reads in 4 batches, FASTA on disk -> %d bytes of SAM: %.1f ms = %.2f Mreads/s" % ("PE" if pe else "SE", n_reads, sink.n, dt * 1e3, n_reads / dt / 1e6), flush=True)

@@ -143,6 +143,9 @@ __device__ __forceinline__ void cand_append(bool want, const cand_t &c, uint64_t
 	cc.cur += n;
 }
 
+#ifndef FWD_UNIQ_WORDS
+#define FWD_UNIQ_WORDS 1
+#endif
 __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_view_t rv, const uint32_t *__restrict__ lens,
                                                            int min_seed_len, cand_t *__restrict__ out_a, uint64_t *__restrict__ out_k,
                                                            unsigned long long *counter, uint64_t cap, uint32_t *__restrict__ n_cand)
@@ -215,20 +218,24 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 			c.xe = ((uint32_t)x << 16) | (uint32_t)i; c.j = j; c.s = (uint32_t)s; ck = k;
 			st = ST_DONE;
 		} else if (st == ST_UNIQ) {
-			// the rest of this read word against the text: stop at the first differing symbol, the first N, the end of the text
-			const int w16 = i & 15;
-			const uint32_t rw = rv.pk[(size_t)(i >> 4) * rv.n_reads + r] >> (2 * w16);
-			const uint32_t rm = rv.nm[(size_t)(i >> 5) * rv.n_reads + r] >> (i & 31);
-			int n_av = min(16 - w16, len - i);
-			const uint64_t room = tp < f.seq_len ? f.seq_len - tp : 0;
-			n_av = (uint64_t)n_av < room ? n_av : (int)room;
-			const uint32_t diff = rw ^ fmd_text16(f, tp);
-			const uint32_t dp = (diff | (diff >> 1)) & 0x55555555u;
-			const int fd = dp ? (__ffs((int)dp) - 1) >> 1 : 16;
-			const int fn = (rm & 0xFFFFu) ? __ffs((int)(rm & 0xFFFFu)) - 1 : 16;
-			const int m = min(min(fd, fn), n_av);
-			const bool stop = m < n_av || n_av == 0;              // mismatch, N, or nothing left of the text: the pass ends at i
-			i += m; tp += (uint64_t)m;
+			// the rest of this read word against the text: stop at the first differing symbol, the first N, the end of the text;
+			// up to FWD_UNIQ_WORDS read words per iteration (an iteration costs the wave the rank step of its other lanes too)
+			bool stop = false;
+			for (int rep = 0; rep < FWD_UNIQ_WORDS && !stop && i < len; ++rep) {
+				const int w16 = i & 15;
+				const uint32_t rw = rv.pk[(size_t)(i >> 4) * rv.n_reads + r] >> (2 * w16);
+				const uint32_t rm = rv.nm[(size_t)(i >> 5) * rv.n_reads + r] >> (i & 31);
+				int n_av = min(16 - w16, len - i);
+				const uint64_t room = tp < f.seq_len ? f.seq_len - tp : 0;
+				n_av = (uint64_t)n_av < room ? n_av : (int)room;
+				const uint32_t diff = rw ^ fmd_text16(f, tp);
+				const uint32_t dp = (diff | (diff >> 1)) & 0x55555555u;
+				const int fd = dp ? (__ffs((int)dp) - 1) >> 1 : 16;
+				const int fn = (rm & 0xFFFFu) ? __ffs((int)(rm & 0xFFFFu)) - 1 : 16;
+				const int m = min(min(fd, fn), n_av);
+				stop = m < n_av || n_av == 0;                     // mismatch, N, or nothing left of the text: the pass ends at i
+				i += m; tp += (uint64_t)m;
+			}
 			if (stop) {
 				want = i >= min_seed_len;
 				c.xe = ((uint32_t)x << 16) | (uint32_t)i; c.j = j; c.s = 1u; ck = k;

@@ -87,19 +87,25 @@ __device__ __forceinline__ void pk_t8(const ext_args_t &A, const job_src_t &s, c
 	if (rev) { lo ^= 0x03030303u; hi ^= 0x03030303u; }
 }
 
-// first pass of a pair: M = hd ? max(hd + score, 0) : 0 and the chain's local F recurrence (6 instructions)
-__device__ __forceinline__ void pk_pair1(uint32_t &M, uint32_t &agg, const uint32_t hd, const uint32_t mask, const uint32_t sel,
-                                         const uint32_t tbl_hi, const uint32_t tbl_lo, const uint32_t b2, const uint32_t ei2, const uint32_t oei2)
+// first pass of a pair: M = hd ? max(hd + score, 0) : 0 and the chain's local F, i.e. what the chain's own cells send out of its last
+// column if nothing flows in: max(0, max_k (M_k - oe - e (P-1-k))) -- the recurrence F = max(F - e, max(M - oe, 0)) unrolled; kept as
+// max_k (M_k + kf_k) with kf_k = 0x4000 - oe - e (P-1-k), ONE scalar register stepped by e from pair to pair inside the block (sixteen
+// constants of their own do not fit the scalar registers: the compiler parks them in a vector register and reads them back lane by
+// lane, one v_readlane per pair), the 0x4000 taken off with a saturating subtraction after the last pair.  5 vector instructions
+// (6 as a recurrence) + 1 scalar
+__device__ __forceinline__ void pk_pair1(uint32_t &M, uint32_t &agg, uint32_t &kf, const uint32_t hd, const uint32_t mask, const uint32_t sel,
+                                         const uint32_t tbl_hi, const uint32_t tbl_lo, const uint32_t b2, const uint32_t ei2)
 {
 	uint32_t t;
 	asm("v_perm_b32 %[t], %[thi], %[tlo], %[sel]\n\t"
 	    "v_pk_mad_u16 %[M], %[mask], %[t], %[hd]\n\t"
 	    "v_pk_sub_u16 %[M], %[M], %[b2] clamp\n\t"
-	    "v_pk_sub_u16 %[agg], %[agg], %[ei] clamp\n\t"
-	    "v_pk_sub_u16 %[t], %[M], %[oei] clamp\n\t"
+	    "v_pk_add_u16 %[t], %[M], %[kf]\n\t"
+	    "s_add_u32 %[kf], %[kf], %[ei]\n\t"
 	    "v_pk_max_u16 %[agg], %[agg], %[t]"
-	    : [M] "=&v"(M), [agg] "+v"(agg), [t] "=&v"(t)
-	    : [hd] "v"(hd), [mask] "v"(mask), [sel] "v"(sel), [thi] "s"(tbl_hi), [tlo] "v"(tbl_lo), [b2] "s"(b2), [ei] "s"(ei2), [oei] "s"(oei2));
+	    : [M] "=&v"(M), [agg] "+v"(agg), [t] "=&v"(t), [kf] "+s"(kf)
+	    : [hd] "v"(hd), [mask] "v"(mask), [sel] "v"(sel), [thi] "s"(tbl_hi), [tlo] "v"(tbl_lo), [b2] "s"(b2), [ei] "s"(ei2)
+	    : "scc");
 }
 // second pass of a pair: H = max(M, E, F) masked at `end`, E and F for the next cells, non-zero bits, row-maximum key (12 / 13 instructions).
 // H and NZ are declared read-write although their old values are dead: that ties the new values to the same registers, so the
@@ -218,16 +224,18 @@ template <int G> __device__ __forceinline__ int grp_allmax(int v)
 }
 
 // scoring constants, wave-uniform (SGPRs)
-struct pk_consts_t {
+template <int P> struct pk_consts_t {
+	uint32_t kf0;                          // 0x4000 - oe_ins - e_ins (P-1), splatted: pk_pair1's F constant of pair 0
 	uint32_t b2, oei2, oed2, ei2, ed2;     // splatted
 	uint32_t ab, nrow, tbl_hi;             // a+b; (b-1) in all four bytes (rows whose target base is N); table bytes 4..7: code 4 (N) = b-1, pad = 0
 	int eP, eC, a;                         // e_ins * P, e_ins * 2P
 	uint32_t a2;                           // a splatted
 	bool same_oe;
 };
-template <int P> __device__ __forceinline__ pk_consts_t pk_consts(const ext_args_t &A)
+template <int P> __device__ __forceinline__ pk_consts_t<P> pk_consts(const ext_args_t &A)
 {
-	pk_consts_t K;
+	pk_consts_t<P> K;
+	K.kf0 = pk_splat(0x4000 - (A.o_ins + A.e_ins) - A.e_ins * (P - 1));
 	K.b2 = pk_splat(A.b); K.oei2 = pk_splat(A.o_ins + A.e_ins); K.oed2 = pk_splat(A.o_del + A.e_del);
 	K.ei2 = pk_splat(A.e_ins); K.ed2 = pk_splat(A.e_del);
 	K.ab = (uint32_t)(A.a + A.b); K.nrow = (uint32_t)(A.b - 1) * 0x01010101u; K.tbl_hi = (uint32_t)(A.b - 1);
@@ -241,7 +249,7 @@ struct pk_rs_t { int end, mx, max_i, max_j, max_ie, gscore, max_off; };
 
 template <int P, bool SAME_OE, int PP, int... Is>
 __device__ __forceinline__ void pk_pass2(uint32_t (&H)[P], uint32_t (&E)[P], uint32_t (&NZ)[P], const uint32_t (&M)[P], const uint32_t (&em)[PP],
-                                         uint32_t &f, uint32_t &key, uint32_t &nzb, uint32_t &nzb2, const pk_consts_t &K, std::integer_sequence<int, Is...>)
+                                         uint32_t &f, uint32_t &key, uint32_t &nzb, uint32_t &nzb2, const pk_consts_t<P> &K, std::integer_sequence<int, Is...>)
 {
 	// (keys are h << 4 | pair up to 16 pairs, h << 5 | pair beyond; the non-zero bits of pairs 16.. go to a second register)
 	(pk_pair2<Is, SAME_OE, (P > 16 ? 32 : 16)>(H[Is], E[Is], NZ[Is], f, key, Is < 16 ? nzb : nzb2, M[Is], em[Is], K.ei2, K.ed2, K.oei2, K.oed2), ...);
@@ -251,7 +259,7 @@ __device__ __forceinline__ void pk_pass2(uint32_t (&H)[P], uint32_t (&E)[P], uin
 // parking area, written by the lane that owns column qlen-1 (`owner`); h16[goff]: where the group finds H(i, qlen-1) in it.
 // Returns the new `alive`.
 template <int G, int P, bool SAME_OE>
-__device__ __forceinline__ bool pk_row(const pk_consts_t &K, const int zdrop, uint32_t (&H)[P], uint32_t (&E)[P], uint32_t (&NZ)[P], const uint32_t (&sel)[P],
+__device__ __forceinline__ bool pk_row(const pk_consts_t<P> &K, const int zdrop, uint32_t (&H)[P], uint32_t (&E)[P], uint32_t (&NZ)[P], const uint32_t (&sel)[P],
                                        const int ti, const bool run, const int hfc, const int hnx, const int i, const int qlen,
                                        const int j0, const int eCl, const bool g0, const uint32_t phi0,
                                        const uint32_t *em_tab, uint32_t *hrow, const bool owner, const uint16_t *h16, const int goff,
@@ -275,11 +283,13 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t &K, const int zdrop, ui
 	uint32_t mask = pk_min1(hd);
 	uint32_t M[P];
 	uint32_t agg = 0;                                          // F leaving each chain if nothing flowed in
+	uint32_t kf = K.kf0;
 #pragma unroll
 	for (int p = 0; p < P; ++p) {
-		pk_pair1(M[p], agg, hd, mask, sel[p], K.tbl_hi, tbl_lo, K.b2, K.ei2, K.oei2);
+		pk_pair1(M[p], agg, kf, hd, mask, sel[p], K.tbl_hi, tbl_lo, K.b2, K.ei2);
 		hd = H[p]; mask = NZ[p];
 	}
+	agg = pk_subsK(agg, 0x40004000u);
 	// F entering the lane: max-plus scan over the lanes of T + e*C*lane, T = what the lane's own cells send to its right neighbour
 	uint32_t f;
 	{
@@ -391,7 +401,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P > PK
 	const uint32_t *ids = A.ids + A.count[1];
 	const int oe_ins = A.o_ins + A.e_ins, oe_del = A.o_del + A.e_del;
 	const int j0 = l * C;
-	const pk_consts_t K = pk_consts<P>(A);
+	const pk_consts_t<P> K = pk_consts<P>(A);
 	const int eCl = K.eC * l;
 	constexpr int TCAP = PK_TCAP(G);
 	// (row strides padded so that the groups of a wave, which read the same offsets of their own rows, hit different banks:

@@ -294,6 +294,10 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 {
 	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int lane = __lane_id();
+	// L2[b] for a per-lane b: one LDS read per step instead of a conditional-move tree over four 64-bit scalars
+	__shared__ uint64_t l2_lds[4];
+	if (threadIdx.x < 4) l2_lds[threadIdx.x] = f.L2[threadIdx.x];
+	__syncthreads();
 	const uint32_t sub = blockIdx.x % BWD_NSUB;                              // the list this block appends to (and, resumed, reads from)
 	if (RESUME) {
 		n_cands = in_count[sub];
@@ -335,7 +339,7 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 			const bool isn = (rm >> (i & 31)) & 1;
 			uint64_t ol, ou;
 			fmd_occ1_pair(f, lo - 1, hi, b, ol, ou);
-			const uint64_t L2b = fmd_L2(f, b);
+			const uint64_t L2b = l2_lds[b];
 			const uint64_t nl = L2b + ol + 1, nu = L2b + ou;
 			const bool ok = !isn && nl <= nu;
 			lo = ok ? nl : lo; hi = ok ? nu : hi; beg = ok ? i : beg;

@@ -161,12 +161,35 @@ __device__ __forceinline__ uint64_t fmd_occ1(const fmd_dev_t &f, uint64_t k, int
 	return blk_occ1(b, (int)(k & 63), c);
 }
 
+// count of symbol c among symbols [0..off] of the 64 symbols in w (the block's second half), plus occ_c
+__device__ __forceinline__ uint32_t words_occ1(const uint4 &w, uint32_t occ_c, int off, int c)
+{
+	const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+	const uint32_t pat = 0x55555555u * (uint32_t)c;
+	uint32_t n = occ_c;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		uint32_t x = ~(wv[i] ^ pat);
+		x = x & (x >> 1) & prefix_mask(off + 1 - 16 * i);
+		n += __popc(x);
+	}
+	return n;
+}
+// Occ(k, c) and Occ(l, c) (as fmd_occ4_pair, one symbol): of every block only the counter of c (one dword at its place) and the 64
+// symbols are fetched -- no selection among four counters afterwards
 __device__ __forceinline__ void fmd_occ1_pair(const fmd_dev_t &f, uint64_t k, uint64_t l, int c, uint64_t &ok, uint64_t &ol)
 {
-	blk_t A, B; int koff, loff;
-	fmd_pair_blocks(f, k, l, A, B, koff, loff);
-	ok = blk_occ1(A, koff, c);
-	ol = blk_occ1(B, loff, c);
+	const bool km1 = k == (uint64_t)-1;
+	const uint64_t k2 = km1 ? 0 : k - (k >= f.primary), l2 = l - (l >= f.primary);
+	const int koff = km1 ? -1 : (int)(k2 & 63), loff = (int)(l2 & 63);
+	const uint64_t kb = k2 >> 6, lb = l2 >> 6;
+	const uint32_t *base = (const uint32_t *)f.blocks;
+	uint32_t oa = base[kb * 8 + (uint32_t)c];
+	uint4 wa = f.blocks[2 * kb + 1];
+	uint32_t ob = oa; uint4 wb = wa;
+	if (lb != kb) { ob = base[lb * 8 + (uint32_t)c]; wb = f.blocks[2 * lb + 1]; }
+	ok = words_occ1(wa, oa, koff, c);
+	ol = words_occ1(wb, ob, loff, c);
 }
 
 // forward extension of the bi-interval (k, l, s) by every symbol (bwt_extend on the swapped interval, src/bwt.c:428-448):

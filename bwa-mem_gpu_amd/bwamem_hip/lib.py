@@ -22,8 +22,8 @@ def lib_path() -> str:
 # every symbol include/bwamem_hip.h and include/seed_gen.h declare
 EXPORTED_SYMBOLS = [
     "bmh_last_error", "bmh_device_count", "bmh_set_device", "bmh_index_upload", "bmh_index_from_device",
-    "bmh_index_free", "bmh_index_replicate", "bmh_shard_range", "bmh_index_densify_sa", "bmh_index_build", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
-    "bmh_extend_batch", "bmh_extend_last_ms", "bmh_extend_last_unsupported", "bmh_extend_set_packed", "bmh_extend_release", "bmh_calib_gather", "bmh_calib_valu",
+    "bmh_index_free", "bmh_index_probe", "bmh_index_replicate", "bmh_shard_range", "bmh_index_densify_sa", "bmh_index_build", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
+    "bmh_extend_batch", "bmh_extend_last_ms", "bmh_extend_last_unsupported", "bmh_extend_set_packed", "bmh_extend_release", "bmh_calib_gather", "bmh_calib_valu", "bmh_calib_valu_placed",
     "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_finalize_regs_device", "bmh_finalize_regs_device_last_ms", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
     "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_finalize_pairs_dev", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
     "bmh_chain_opt_default", "bmh_chain_last_timing", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
@@ -164,6 +164,8 @@ def load_library() -> C.CDLL:
     L.bmh_index_from_device.argtypes = [C.c_uint64, _u64p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
                                         C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     L.bmh_index_free.argtypes = [C.c_void_p]
+    L.bmh_index_probe.restype = C.c_int
+    L.bmh_index_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
     L.bmh_index_densify_sa.restype = C.c_int
     L.bmh_index_densify_sa.argtypes = [C.c_void_p, C.c_int]
     L.bmh_index_build.restype = C.c_int
@@ -183,6 +185,8 @@ def load_library() -> C.CDLL:
     L.bmh_calib_gather.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
     L.bmh_calib_valu.restype = C.c_int
     L.bmh_calib_valu.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+    L.bmh_calib_valu_placed.restype = C.c_int
+    L.bmh_calib_valu_placed.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_uint)]
     L.bmh_chain_opt_default.argtypes = [C.POINTER(ChainOpt)]
     L.bmh_build_jobs.restype = C.c_void_p
     L.bmh_build_jobs.argtypes = [C.POINTER(ChainOpt), C.c_int64, _u8p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, _u8p, _u64p, _u32p,
@@ -304,6 +308,20 @@ class Index:
         rc = L.bmh_index_densify_sa(self.handle, int(new_intv))
         if rc != 0:
             raise RuntimeError(f"bmh_index_densify_sa rc={rc}: " + _err(L))
+
+    def probe(self, rows, what: str) -> np.ndarray:
+        """bmh_index_probe: 'occ4' -> [n, 4] Occ counts, 'lf' -> LF(row), 'sa' -> SA[row] at the given rows (u64)"""
+        import torch
+        L = load_library()
+        r = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.uint64).view(np.int64)).cuda()
+        code = {"occ4": 0, "lf": 1, "sa": 2}[what]
+        out = torch.empty(r.numel() * (4 if code == 0 else 1), dtype=torch.int64, device="cuda")
+        rc = L.bmh_index_probe(self.handle, r.data_ptr(), r.numel(), code, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"bmh_index_probe rc={rc}: " + _err(L))
+        torch.cuda.synchronize()
+        o = out.cpu().numpy().view(np.uint64)
+        return o.reshape(-1, 4) if code == 0 else o
 
     def free(self):
         if self.handle:

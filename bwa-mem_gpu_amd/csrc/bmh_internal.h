@@ -7,6 +7,7 @@ struct bmh_index {
 	fmd_dev_t dev;
 	bool owns;             // arrays were hipMalloc'd by bmh_index_upload
 	bool owns_sa;          // sa / sa_bits were replaced by bmh_index_densify_sa (its own allocations)
+	bool owns_blocks;      // dev.blocks is the handle's own native re-encoding of a caller's buffer (bmh_index_from_device)
 	uint64_t n_words;
 };
 

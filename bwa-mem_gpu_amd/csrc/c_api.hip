@@ -49,6 +49,32 @@ static int check_geometry(uint64_t seq_len, const uint64_t L2[5], uint64_t n_wor
 	return BMH_OK;
 }
 
+// Reference blocks {occ[4]; bwt[4]} -> native blocks {occ[4]; lo; hi} (fmd_dev.h), one thread per block; src == dst converts in
+// place (a thread reads its whole block before it writes it).
+__global__ void __launch_bounds__(256) fmd_native_blocks_kernel(const uint4 *__restrict__ src, uint4 *dst, uint64_t n_blocks)
+{
+	for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+		const uint4 occ = src[2 * b], w = src[2 * b + 1];
+		const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+		uint64_t lo = 0, hi = 0;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const uint32_t r = __brev(wv[i]);                  // symbol t: high bit at 2t, low bit at 2t + 1
+			hi |= (uint64_t)fmd_even_bits16(r) << (16 * i);
+			lo |= (uint64_t)fmd_even_bits16(r >> 1) << (16 * i);
+		}
+		dst[2 * b] = occ;
+		dst[2 * b + 1] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+	}
+}
+
+static bool native_blocks(const void *src, void *dst, uint64_t seq_len)
+{
+	const uint64_t n_blocks = (seq_len + 63) / 64 + 1, nb = (n_blocks + 255) / 256;
+	fmd_native_blocks_kernel<<<(unsigned)(nb < (1u << 20) ? nb : (1u << 20)), 256>>>((const uint4 *)src, (uint4 *)dst, n_blocks);
+	return hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+}
+
 static void fill_dev(bmh_index *ix, uint64_t primary, const uint64_t L2[5], uint64_t seq_len, int sa_intv, uint64_t n_sa, uint64_t l_pac)
 {
 	ix->dev.primary = primary;
@@ -84,6 +110,7 @@ extern "C" bmh_index_t *bmh_index_upload(uint64_t primary, const uint64_t L2[5],
 	if (ok) ok = hipMemcpy(d_sa, sa, n_sa * 4, hipMemcpyHostToDevice) == hipSuccess;
 	if (ok) ok = hipMemcpy(d_bits, sa_bits, bits_words * 4, hipMemcpyHostToDevice) == hipSuccess;
 	if (ok && pac) ok = hipMemcpy(d_pac, pac, (size_t)(l_pac / 4 + 1), hipMemcpyHostToDevice) == hipSuccess;
+	if (ok) ok = native_blocks(d_bwt, d_bwt, seq_len);            // the file layout becomes the native one in place
 	if (!ok) {
 		bmh_set_error("bmh_index_upload: %s", hipGetErrorString(hipGetLastError()));
 		if (d_bwt) (void)hipFree(d_bwt); if (d_sa) (void)hipFree(d_sa); if (d_bits) (void)hipFree(d_bits); if (d_pac) (void)hipFree(d_pac);
@@ -103,10 +130,19 @@ extern "C" bmh_index_t *bmh_index_from_device(uint64_t primary, const uint64_t L
 	if (((uintptr_t)d_bwt_words & 31) != 0) { bmh_set_error("bmh_index_from_device: bwt words must be 32-byte aligned"); return nullptr; }
 	// whole 32-byte blocks must be readable: the caller's buffer has to cover ceil(seq_len/64)+1 blocks
 	if (n_words < (((seq_len + 63) / 64) + 1) * 8) { bmh_set_error("bmh_index_from_device: buffer must be padded to %llu words", (unsigned long long)((((seq_len + 63) / 64) + 1) * 8)); return nullptr; }
+	// the caller's buffer keeps the reference layout (it may write it to a file or broadcast it); the handle searches its own native
+	// re-encoding of the blocks (seq_len / 2 bytes: 3.1 GB for hg38, of 288)
+	const size_t bwt_bytes = ((size_t)((seq_len + 63) / 64) + 1) * 32;
+	void *d_native = nullptr;
+	if (hipMalloc(&d_native, bwt_bytes) != hipSuccess || !native_blocks(d_bwt_words, d_native, seq_len)) {
+		bmh_set_error("bmh_index_from_device: native blocks: %s", hipGetErrorString(hipGetLastError()));
+		if (d_native) (void)hipFree(d_native);
+		return nullptr;
+	}
 	bmh_index *ix = (bmh_index *)calloc(1, sizeof(bmh_index));
-	ix->owns = false; ix->n_words = n_words;
+	ix->owns = false; ix->owns_blocks = true; ix->n_words = n_words;
 	fill_dev(ix, primary, L2, seq_len, sa_intv, n_sa, d_pac ? l_pac : 0);
-	ix->dev.blocks = (const uint4 *)d_bwt_words; ix->dev.sa = d_sa; ix->dev.sa_bits = d_sa_bits; ix->dev.pac = d_pac;
+	ix->dev.blocks = (const uint4 *)d_native; ix->dev.sa = d_sa; ix->dev.sa_bits = d_sa_bits; ix->dev.pac = d_pac;
 	return ix;
 }
 
@@ -123,7 +159,7 @@ extern "C" int bmh_index_replicate(const bmh_index_t *src, int src_device, int d
 	const size_t bwt_bytes = ((size_t)((f.seq_len + 63) / 64) + 1) * 32, sa_bytes = (size_t)f.n_sa * 4, bits_bytes = (size_t)(f.n_sa / 32 + 1) * 4;
 	const size_t pac_bytes = f.pac ? (size_t)(f.l_pac / 4 + 1) + 16 : 0;
 	bmh_index *ix = (bmh_index *)calloc(1, sizeof(bmh_index));
-	*ix = *src; ix->owns = true; ix->owns_sa = false;
+	*ix = *src; ix->owns = true; ix->owns_sa = false; ix->owns_blocks = false;
 	void *d_bwt = nullptr, *d_sa = nullptr, *d_bits = nullptr, *d_pac = nullptr;
 	bool ok = hipSetDevice(dst_device) == hipSuccess;
 	ok = ok && hipMalloc(&d_bwt, bwt_bytes) == hipSuccess && hipMalloc(&d_sa, sa_bytes) == hipSuccess && hipMalloc(&d_bits, bits_bytes) == hipSuccess;
@@ -204,10 +240,36 @@ extern "C" int bmh_index_densify_sa(bmh_index_t *ix, int new_intv)
 extern "C" void bmh_index_free(bmh_index_t *ix)
 {
 	if (!ix) return;
-	if (ix->owns) {
-		(void)hipFree((void *)ix->dev.blocks);
-		if (ix->dev.pac) (void)hipFree((void *)ix->dev.pac);
-	}
+	if (ix->owns || ix->owns_blocks) (void)hipFree((void *)ix->dev.blocks);
+	if (ix->owns && ix->dev.pac) (void)hipFree((void *)ix->dev.pac);
 	if (ix->owns || ix->owns_sa) { (void)hipFree((void *)ix->dev.sa); (void)hipFree((void *)ix->dev.sa_bits); }
 	free(ix);
+}
+
+// Rank primitives at given rows, for direct pins against the reference's known-answer vectors (tests/golden/occ_kat.npz) and for
+// callers that want single queries: what = 0: out[4 i .. 4 i + 3] = Occ(rows[i], A / C / G / T) (bwt_occ4, src/bwt.c:309-330);
+// 1: out[i] = LF(rows[i]) (bwt_invPsi, src/bwt.c:64-70);  2: out[i] = SA[rows[i]] (bwt_sa, src/bwt.c:105-115).
+__global__ void __launch_bounds__(256) index_probe_kernel(fmd_dev_t f, const uint64_t *__restrict__ rows, uint64_t n, int what, uint64_t *__restrict__ out)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	const uint64_t k = rows[t];
+	if (what == 0) {
+		uint64_t c4[4];
+		fmd_occ4(f, k, c4);
+		// the one-symbol form must agree with the four-symbol one: report a mismatch as an impossible value
+		for (int c = 0; c < 4; ++c) out[4 * t + c] = fmd_occ1(f, k, c) == c4[c] ? c4[c] : ~0ull;
+	} else if (what == 1) out[t] = fmd_inv_psi(f, k);
+	else out[t] = fmd_sa(f, k);
+}
+
+extern "C" int bmh_index_probe(const bmh_index_t *ix, const uint64_t *d_rows, uint64_t n, int what, uint64_t *d_out, void *stream)
+{
+	if (!ix || !d_rows || !d_out || what < 0 || what > 2) { bmh_set_error("bmh_index_probe: bad argument"); return BMH_EINVAL; }
+	if (n == 0) return BMH_OK;
+	if (n >> 31) { bmh_set_error("bmh_index_probe: too many rows"); return BMH_EINVAL; }
+	index_probe_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(ix->dev, d_rows, n, what, d_out);
+	const hipError_t e = hipGetLastError();
+	if (e != hipSuccess) { bmh_set_error("bmh_index_probe: %s", hipGetErrorString(e)); return BMH_ENODEV; }
+	return BMH_OK;
 }

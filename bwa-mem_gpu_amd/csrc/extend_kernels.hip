@@ -1238,9 +1238,15 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 // 5: v_bfe_i32 on eight registers.  The peak they are held against: 256 CUs x 4 SIMD-32 x 2.4 GHz = 7.86e13 lane-ops/s (a
 // wave64 instruction occupies its SIMD for 2 cycles, MI355X_MICROARCH.md).
 template <int MODE>
-__global__ void __launch_bounds__(256) calib_valu_kernel(int iters, int *sink)
+__global__ void __launch_bounds__(256) calib_valu_kernel(int iters, int *sink, unsigned long long *place)
 {
 	const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+	if (place && (threadIdx.x & 63) == 0) {                 // where this wave runs: HW_ID (wave / SIMD / CU / SH / SE) and the XCC
+		unsigned hw, xcc;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+		place[blockIdx.x * 4 + (threadIdx.x >> 6)] = ((unsigned long long)xcc << 32) | hw;
+	}
+	double d0 = threadIdx.x, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3, d4 = d0 + 4, d5 = d0 + 5, d6 = d0 + 6, d7 = d0 + 7;    // register pairs of mode 7
 	int r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
 	const int k = MODE == 5 ? 3 : (blockIdx.x | 1);
 	for (int i = 0; i < iters; ++i) {                      // 128 instructions per trip, nothing else in the loop but its counter
@@ -1288,6 +1294,18 @@ __global__ void __launch_bounds__(256) calib_valu_kernel(int iters, int *sink)
 				             "v_bfe_i32 %0, %0, %8, 6\n\tv_bfe_i32 %1, %1, %8, 6\n\tv_bfe_i32 %2, %2, %8, 6\n\tv_bfe_i32 %3, %3, %8, 6\n\t"
 				             "v_bfe_i32 %4, %4, %8, 6\n\tv_bfe_i32 %5, %5, %8, 6\n\tv_bfe_i32 %6, %6, %8, 6\n\tv_bfe_i32 %7, %7, %8, 6"
 				             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(k));
+			else if (MODE == 7)
+				asm volatile("v_pk_fma_f32 %0, %0, %8, %8\n\tv_pk_fma_f32 %1, %1, %8, %8\n\tv_pk_fma_f32 %2, %2, %8, %8\n\tv_pk_fma_f32 %3, %3, %8, %8\n\t"
+				             "v_pk_fma_f32 %4, %4, %8, %8\n\tv_pk_fma_f32 %5, %5, %8, %8\n\tv_pk_fma_f32 %6, %6, %8, %8\n\tv_pk_fma_f32 %7, %7, %8, %8\n\t"
+				             "v_pk_fma_f32 %0, %0, %8, %8\n\tv_pk_fma_f32 %1, %1, %8, %8\n\tv_pk_fma_f32 %2, %2, %8, %8\n\tv_pk_fma_f32 %3, %3, %8, %8\n\t"
+				             "v_pk_fma_f32 %4, %4, %8, %8\n\tv_pk_fma_f32 %5, %5, %8, %8\n\tv_pk_fma_f32 %6, %6, %8, %8\n\tv_pk_fma_f32 %7, %7, %8, %8"
+				             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(d7 + 1.0));
+			else if (MODE == 8)           // the DP kernels' own mix: v_perm, packed u16 mad / saturating sub / max, plain and, v_bfi
+				asm volatile("v_pk_mad_u16 %0, %0, %8, %8\n\tv_pk_sub_u16 %1, %1, %8 clamp\n\tv_pk_max_u16 %2, %2, %8\n\tv_perm_b32 %3, %3, %8, %8\n\t"
+				             "v_pk_max_u16 %4, %4, %8\n\tv_pk_add_u16 %5, %5, %8\n\tv_and_b32 %6, %6, %8\n\tv_pk_min_u16 %7, %7, %8\n\t"
+				             "v_pk_sub_u16 %0, %0, %8 clamp\n\tv_pk_max_u16 %1, %1, %8\n\tv_pk_mad_u16 %2, %2, %8, %8\n\tv_pk_max_u16 %3, %3, %8\n\t"
+				             "v_pk_add_u16 %4, %4, %8\n\tv_perm_b32 %5, %5, %8, %8\n\tv_pk_min_u16 %6, %6, %8\n\tv_and_b32 %7, %7, %8"
+				             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(k));
 			else
 				asm volatile("v_fma_f32 %0, %0, %8, %8\n\tv_fma_f32 %1, %1, %8, %8\n\tv_fma_f32 %2, %2, %8, %8\n\tv_fma_f32 %3, %3, %8, %8\n\t"
 				             "v_fma_f32 %4, %4, %8, %8\n\tv_fma_f32 %5, %5, %8, %8\n\tv_fma_f32 %6, %6, %8, %8\n\tv_fma_f32 %7, %7, %8, %8\n\t"
@@ -1296,7 +1314,7 @@ __global__ void __launch_bounds__(256) calib_valu_kernel(int iters, int *sink)
 				             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(k));
 		}
 	}
-	const int acc = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+	const int acc = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7 ^ (int)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 == 0.125);
 	if (acc == 0x7fffffff) sink[0] = acc;
 	if (blockIdx.x == 0 && threadIdx.x == 0) {      // shader cycles and 100 MHz ticks of this wave: cycles per instruction, and the clock the chip ran at
 		const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
@@ -1304,24 +1322,33 @@ __global__ void __launch_bounds__(256) calib_valu_kernel(int iters, int *sink)
 	}
 }
 
-static void calib_launch(int mode, unsigned grid, int iters, int *sink, hipStream_t st)
+static void calib_launch(int mode, unsigned grid, int iters, int *sink, unsigned long long *place, hipStream_t st)
 {
 	switch (mode) {
-	case 0: calib_valu_kernel<0><<<grid, 256, 0, st>>>(iters, sink); break;
-	case 1: calib_valu_kernel<1><<<grid, 256, 0, st>>>(iters, sink); break;
-	case 2: calib_valu_kernel<2><<<grid, 256, 0, st>>>(iters, sink); break;
-	case 3: calib_valu_kernel<3><<<grid, 256, 0, st>>>(iters, sink); break;
-	case 4: calib_valu_kernel<4><<<grid, 256, 0, st>>>(iters, sink); break;
-	case 5: calib_valu_kernel<5><<<grid, 256, 0, st>>>(iters, sink); break;
-	default: calib_valu_kernel<6><<<grid, 256, 0, st>>>(iters, sink); break;
+	case 0: calib_valu_kernel<0><<<grid, 256, 0, st>>>(iters, sink, place); break;
+	case 1: calib_valu_kernel<1><<<grid, 256, 0, st>>>(iters, sink, place); break;
+	case 2: calib_valu_kernel<2><<<grid, 256, 0, st>>>(iters, sink, place); break;
+	case 3: calib_valu_kernel<3><<<grid, 256, 0, st>>>(iters, sink, place); break;
+	case 4: calib_valu_kernel<4><<<grid, 256, 0, st>>>(iters, sink, place); break;
+	case 5: calib_valu_kernel<5><<<grid, 256, 0, st>>>(iters, sink, place); break;
+	case 6: calib_valu_kernel<6><<<grid, 256, 0, st>>>(iters, sink, place); break;
+	case 7: calib_valu_kernel<7><<<grid, 256, 0, st>>>(iters, sink, place); break;
+	default: calib_valu_kernel<8><<<grid, 256, 0, st>>>(iters, sink, place); break;
 	}
 }
 
 // waves_per_simd resident waves on every SIMD of the chip (256-thread blocks, one wave per SIMD each); *ms = kernel time,
 // *lane_ops = 64 lanes x 128 instructions x iters per wave, summed
+// bmh_calib_valu_placed: the same, and place[grid * 4] (host memory, may be NULL) receives for every wave of the timed launch
+// (xcc_id << 32 | HW_ID): which SIMD of which CU it ran on -- the evidence that the launch covered every SIMD evenly.
+extern "C" int bmh_calib_valu_placed(int mode, int waves_per_simd, int iters, void *stream_, float *ms, double *lane_ops, unsigned long long *place, unsigned *n_place);
 extern "C" int bmh_calib_valu(int mode, int waves_per_simd, int iters, void *stream_, float *ms, double *lane_ops)
 {
-	if (mode < 0 || mode > 6 || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !ms || !lane_ops) { bmh_set_error("bmh_calib_valu: bad argument"); return BMH_EINVAL; }
+	return bmh_calib_valu_placed(mode, waves_per_simd, iters, stream_, ms, lane_ops, nullptr, nullptr);
+}
+extern "C" int bmh_calib_valu_placed(int mode, int waves_per_simd, int iters, void *stream_, float *ms, double *lane_ops, unsigned long long *place, unsigned *n_place)
+{
+	if (mode < 0 || mode > 8 || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !ms || !lane_ops) { bmh_set_error("bmh_calib_valu: bad argument"); return BMH_EINVAL; }
 	hipStream_t st = (hipStream_t)stream_;
 	static thread_local int *sink = nullptr;
 	static thread_local hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1331,13 +1358,20 @@ extern "C" int bmh_calib_valu(int mode, int waves_per_simd, int iters, void *str
 		int dev = 0; hipDeviceProp_t prop; HIPCK(hipGetDevice(&dev)); HIPCK(hipGetDeviceProperties(&prop, dev)); n_cu = prop.multiProcessorCount;
 	}
 	const unsigned grid = (unsigned)(n_cu * waves_per_simd);
-	calib_launch(mode, grid, 16, sink, st);                              // warm-up (clocks, code fetch)
+	unsigned long long *d_place = nullptr;
+	if (place) HIPCK(hipMalloc((void **)&d_place, (size_t)grid * 4 * 8));
+	calib_launch(mode, grid, 16, sink, nullptr, st);                     // warm-up (clocks, code fetch)
 	HIPCK(hipEventRecord(e0, st));
-	calib_launch(mode, grid, iters, sink, st);
+	calib_launch(mode, grid, iters, sink, d_place, st);
 	HIPCK(hipEventRecord(e1, st));
 	HIPCK(hipEventSynchronize(e1));
 	HIPCK(hipEventElapsedTime(ms, e0, e1));
 	HIPCK(hipGetLastError());
+	if (place) {
+		HIPCK(hipMemcpy(place, d_place, (size_t)grid * 4 * 8, hipMemcpyDeviceToHost));
+		HIPCK(hipFree(d_place));
+		if (n_place) *n_place = grid * 4;
+	}
 	*lane_ops = (double)grid * 256.0 * 128.0 * (double)iters;
 	if (getenv("BMH_CALIB_VERBOSE")) {
 		unsigned long long h[3];

@@ -1,11 +1,16 @@
 // Device-side FMD-index arithmetic for gfx950 (wave64).
 //
-// Index layout in HBM is the reference's GPU layout, kept bit-for-bit so the
-// reference's index files upload without conversion
-// (/root/reference/src/GPUSeed/seed_gen.cu:28-48): one 32-byte block per 64
-// BWT symbols = u32 occ[4] (counts of A,C,G,T before the block) + u32 bwt[4]
-// (16 symbols per word, 2 bits, MSB first).  A block is fetched with two
-// 16-byte loads from one 32-byte-aligned address, i.e. one 64-byte HBM sector.
+// Index FILES and the arrays that cross the C ABI keep the reference's GPU layout
+// (/root/reference/src/GPUSeed/seed_gen.cu:28-48): one 32-byte block per 64 BWT
+// symbols = u32 occ[4] (counts of A,C,G,T before the block) + u32 bwt[4] (16 symbols
+// per word, 2 bits, MSB first).  In HBM the blocks are re-encoded once, when an index
+// handle is made (fmd_native_blocks_kernel, c_api.hip), into the MI355X-native form of
+// the same 32 bytes:
+//     u32 occ[4];  u64 lo;  u64 hi;          bit t of lo / hi = low / high bit of symbol t
+// so that a rank inside a block is  occ[c] + popcount((hi ^ ~Hc) & (lo ^ ~Lc) & mask64(off))
+// -- one 64-bit mask and ~12 vector instructions instead of four 16-symbol words with a
+// mask, a shift, an xor and two ands each (~48).  Same sector count (a block is still one
+// 32-byte-aligned unit = one 64-byte HBM sector), same values.
 //
 // Rank semantics follow the CPU statement of the reference
 // (src/bwt.c:235-261 bwt_occ, :363-405 bwt_2occ4, :64-70 bwt_invPsi), not the
@@ -18,7 +23,7 @@ struct fmd_dev_t {
 	uint64_t primary;
 	uint64_t L2[5];
 	uint64_t seq_len;
-	const uint4 *blocks;      // 2 x uint4 per block: [2b] = occ, [2b+1] = bwt words
+	const uint4 *blocks;      // NATIVE blocks, 2 x uint4 each: [2b] = occ, [2b+1] = {lo[31:0], lo[63:32], hi[31:0], hi[63:32]}
 	const uint32_t *sa;       // sa[0] = 0xFFFFFFFF
 	const uint32_t *sa_bits;  // 33rd bit of each sample
 	uint64_t n_sa;
@@ -29,7 +34,7 @@ struct fmd_dev_t {
 	uint64_t l_pac;
 };
 
-struct blk_t { uint4 occ, w; };
+struct blk_t { uint4 occ; uint64_t lo, hi; };
 
 // v[c] for a per-lane c in 0..3 as two levels of conditional moves on the bits of c (a chain of ?: on c == 0, c == 1, ...
 // is compiled into divergent branches around single moves)
@@ -53,61 +58,84 @@ __device__ __forceinline__ uint64_t fmd_L2(const fmd_dev_t &f, int c)
 	return c > 3 ? f.L2[4] : r;
 }
 
+__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
+
 __device__ __forceinline__ blk_t fmd_load_block(const fmd_dev_t &f, uint64_t b)
 {
 	blk_t r;
 	r.occ = f.blocks[2 * b];
-	r.w = f.blocks[2 * b + 1];
+	const uint4 p = f.blocks[2 * b + 1];
+	r.lo = u64_of(p.x, p.y); r.hi = u64_of(p.z, p.w);
 	return r;
 }
 
-// per-symbol match bits (in the 0x55555555 lanes) of the first nsym symbols; any nsym (<= 0: none, >= 16: all)
-__device__ __forceinline__ uint32_t prefix_mask(int nsym)
+// reference word (16 symbols, symbol t at bits 31-2t : 30-2t) -> its 16 low bits and 16 high bits, symbol t at bit t
+__host__ __device__ __forceinline__ uint32_t fmd_even_bits16(uint32_t x)
 {
-	// low bit of symbol t sits at bit 30-2t; one 64-bit shift instead of a compare-and-select
-	const int n = min(max(nsym, 0), 16);
-	return (uint32_t)(0xFFFFFFFF00000000ull >> (2 * n)) & 0x55555555u;
+	x &= 0x55555555u;
+	x = (x | (x >> 1)) & 0x33333333u;
+	x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+	x = (x | (x >> 4)) & 0x00FF00FFu;
+	x = (x | (x >> 8)) & 0x0000FFFFu;
+	return x;
+}
+__host__ __device__ __forceinline__ uint32_t fmd_brev32(uint32_t x)
+{
+	x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+	x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+	x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+	x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+	return (x >> 16) | (x << 16);
+}
+// the four reference words of a block -> the two bit planes
+__host__ __device__ __forceinline__ void fmd_words_to_planes(const uint32_t w[4], uint64_t &lo, uint64_t &hi)
+{
+	lo = 0; hi = 0;
+	for (int i = 0; i < 4; ++i) {
+		const uint32_t r = fmd_brev32(w[i]);              // symbol t: high bit at 2t, low bit at 2t+1
+		hi |= (uint64_t)fmd_even_bits16(r) << (16 * i);
+		lo |= (uint64_t)fmd_even_bits16(r >> 1) << (16 * i);
+	}
+}
+
+// bits 0..off set, off in 0..63 (M1: off may also be -1 -> no bit)
+template <bool M1 = true>
+__device__ __forceinline__ uint64_t mask_incl(int off)
+{
+	const uint64_t m = ~0ull >> (63 - off);
+	return (M1 && off < 0) ? 0ull : m;
 }
 
 // counts of A,C,G,T among symbols [0..off] (inclusive) of the block, plus the block's occ
+template <bool M1 = true>
 __device__ __forceinline__ void blk_occ4(const blk_t &b, int off, uint32_t cnt[4])
 {
-	const uint32_t wv[4] = {b.w.x, b.w.y, b.w.z, b.w.w};
-	uint32_t c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		uint32_t m = prefix_mask(off + 1 - 16 * i);
-		uint32_t lo = wv[i] & m, hi = (wv[i] >> 1) & m;
-		c1 += __popc(lo & ~hi);
-		c2 += __popc(hi & ~lo);
-		c3 += __popc(hi & lo);
-	}
+	const uint64_t m = mask_incl<M1>(off);
+	const uint64_t h = b.hi & m, l = b.lo & m, both = h & l;
+	const uint32_t c3 = (uint32_t)__popcll(both), c2 = (uint32_t)__popcll(h ^ both), c1 = (uint32_t)__popcll(l ^ both);
 	cnt[0] = b.occ.x + (uint32_t)(off + 1) - c1 - c2 - c3;
 	cnt[1] = b.occ.y + c1;
 	cnt[2] = b.occ.z + c2;
 	cnt[3] = b.occ.w + c3;
 }
 
+// count of symbol c among symbols [0..off] of the planes, plus occ_c
+template <bool M1 = true>
+__device__ __forceinline__ uint32_t planes_occ1(uint64_t lo, uint64_t hi, uint32_t occ_c, int off, int c)
+{
+	const uint64_t xl = (c & 1) ? 0ull : ~0ull, xh = (c & 2) ? 0ull : ~0ull;
+	return occ_c + (uint32_t)__popcll((hi ^ xh) & (lo ^ xl) & mask_incl<M1>(off));
+}
+
 // count of symbol c among symbols [0..off] of the block, plus the block's occ[c]
 __device__ __forceinline__ uint32_t blk_occ1(const blk_t &b, int off, int c)
 {
-	const uint32_t wv[4] = {b.w.x, b.w.y, b.w.z, b.w.w};
-	const uint32_t pat = 0x55555555u * (uint32_t)c;
-	uint32_t n = 0;
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		uint32_t x = ~(wv[i] ^ pat);
-		x = x & (x >> 1) & prefix_mask(off + 1 - 16 * i);
-		n += __popc(x);
-	}
-	return sel4(c, b.occ.x, b.occ.y, b.occ.z, b.occ.w) + n;
+	return planes_occ1(b.lo, b.hi, sel4(c, b.occ.x, b.occ.y, b.occ.z, b.occ.w), off, c);
 }
 
 __device__ __forceinline__ int blk_sym(const blk_t &b, int off)
 {
-	int wi = off >> 4;
-	uint32_t w = sel4(wi, b.w.x, b.w.y, b.w.z, b.w.w);
-	return (w >> (30 - 2 * (off & 15))) & 3;
+	return (int)(((b.hi >> off) & 1) << 1 | ((b.lo >> off) & 1));
 }
 
 // Occ for all four symbols at full-matrix row k (src/bwt.c:235-261 semantics)
@@ -127,27 +155,23 @@ __device__ __forceinline__ void fmd_occ4(const fmd_dev_t &f, uint64_t k, uint64_
 	for (int c = 0; c < 4; ++c) cnt[c] = c4[c];
 }
 
-// Occ(k,.) and Occ(l,.) for k <= l, l a valid row, k possibly (uint64_t)-1 (all counts 0).  Written without
-// divergent paths: row seq_len needs no special case (after the primary adjustment it is the last BWT symbol, whose
-// inclusive count is the total), row -1 becomes "nothing of block 0" (whose occ is 0), and the second block is only
-// fetched when it differs from the first -- the arithmetic is the same two block counts for every lane.
-__device__ __forceinline__ void fmd_pair_blocks(const fmd_dev_t &f, uint64_t k, uint64_t l, blk_t &A, blk_t &B, int &koff, int &loff)
-{
-	const bool km1 = k == (uint64_t)-1;
-	const uint64_t k2 = km1 ? 0 : k - (k >= f.primary), l2 = l - (l >= f.primary);
-	koff = km1 ? -1 : (int)(k2 & 63); loff = (int)(l2 & 63);
-	const uint64_t kb = k2 >> 6, lb = l2 >> 6;
-	A = fmd_load_block(f, kb);
-	B = A;
-	if (lb != kb) B = fmd_load_block(f, lb);
-}
+// Occ(k,.) and Occ(l,.) for k <= l, l a valid row, k possibly (uint64_t)-1 (all counts 0; M1 = false: the caller knows k is a
+// row -- the searches' k is `first row of a non-empty interval - 1` >= 0).  Written without divergent paths: row seq_len needs
+// no special case (after the primary adjustment it is the last BWT symbol, whose inclusive count is the total), row -1 becomes
+// "nothing of block 0" (whose occ is 0), and the second block is only fetched when it differs from the first -- the arithmetic
+// is the same two block counts for every lane.
+template <bool M1 = true>
 __device__ __forceinline__ void fmd_occ4_pair(const fmd_dev_t &f, uint64_t k, uint64_t l, uint64_t ck[4], uint64_t cl[4])
 {
-	blk_t A, B; int koff, loff;
-	fmd_pair_blocks(f, k, l, A, B, koff, loff);
+	const bool km1 = M1 && k == (uint64_t)-1;
+	const uint64_t k2 = km1 ? 0 : k - (k >= f.primary), l2 = l - (l >= f.primary);
+	const int koff = km1 ? -1 : (int)(k2 & 63), loff = (int)(l2 & 63);
+	const uint64_t kb = k2 >> 6, lb = l2 >> 6;
+	blk_t A = fmd_load_block(f, kb), B = A;
+	if (lb != kb) B = fmd_load_block(f, lb);
 	uint32_t a4[4], b4[4];
-	blk_occ4(A, koff, a4);
-	blk_occ4(B, loff, b4);
+	blk_occ4<M1>(A, koff, a4);
+	blk_occ4<false>(B, loff, b4);
 #pragma unroll
 	for (int c = 0; c < 4; ++c) { ck[c] = a4[c]; cl[c] = b4[c]; }
 }
@@ -161,35 +185,28 @@ __device__ __forceinline__ uint64_t fmd_occ1(const fmd_dev_t &f, uint64_t k, int
 	return blk_occ1(b, (int)(k & 63), c);
 }
 
-// count of symbol c among symbols [0..off] of the 64 symbols in w (the block's second half), plus occ_c
-__device__ __forceinline__ uint32_t words_occ1(const uint4 &w, uint32_t occ_c, int off, int c)
-{
-	const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
-	const uint32_t pat = 0x55555555u * (uint32_t)c;
-	uint32_t n = occ_c;
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		uint32_t x = ~(wv[i] ^ pat);
-		x = x & (x >> 1) & prefix_mask(off + 1 - 16 * i);
-		n += __popc(x);
-	}
-	return n;
-}
-// Occ(k, c) and Occ(l, c) (as fmd_occ4_pair, one symbol): of every block only the counter of c (one dword at its place) and the 64
-// symbols are fetched -- no selection among four counters afterwards
+// Occ(k, c) and Occ(l, c) (as fmd_occ4_pair, one symbol): of every block only the counter of c (one dword at its place) and the
+// two planes are fetched -- no selection among four counters afterwards
+template <bool M1 = true>
 __device__ __forceinline__ void fmd_occ1_pair(const fmd_dev_t &f, uint64_t k, uint64_t l, int c, uint64_t &ok, uint64_t &ol)
 {
-	const bool km1 = k == (uint64_t)-1;
+	const bool km1 = M1 && k == (uint64_t)-1;
 	const uint64_t k2 = km1 ? 0 : k - (k >= f.primary), l2 = l - (l >= f.primary);
 	const int koff = km1 ? -1 : (int)(k2 & 63), loff = (int)(l2 & 63);
 	const uint64_t kb = k2 >> 6, lb = l2 >> 6;
 	const uint32_t *base = (const uint32_t *)f.blocks;
 	uint32_t oa = base[kb * 8 + (uint32_t)c];
-	uint4 wa = f.blocks[2 * kb + 1];
-	uint32_t ob = oa; uint4 wb = wa;
-	if (lb != kb) { ob = base[lb * 8 + (uint32_t)c]; wb = f.blocks[2 * lb + 1]; }
-	ok = words_occ1(wa, oa, koff, c);
-	ol = words_occ1(wb, ob, loff, c);
+	uint4 pa = f.blocks[2 * kb + 1];
+	uint32_t ob = oa; uint4 pb = pa;
+	if (lb != kb) {
+		ob = base[lb * 8 + (uint32_t)c]; pb = f.blocks[2 * lb + 1];
+		asm volatile("" : "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w));     // one 16-byte load (left alone the compiler hoists half of it out of the branch as dword loads)
+	}
+	const uint64_t xl = (c & 1) ? 0ull : ~0ull, xh = (c & 2) ? 0ull : ~0ull;
+	const uint64_t ma = (u64_of(pa.z, pa.w) ^ xh) & (u64_of(pa.x, pa.y) ^ xl) & mask_incl<M1>(koff);
+	const uint64_t mb = (u64_of(pb.z, pb.w) ^ xh) & (u64_of(pb.x, pb.y) ^ xl) & mask_incl<false>(loff);
+	ok = oa + (uint32_t)__popcll(ma);
+	ol = ob + (uint32_t)__popcll(mb);
 }
 
 // forward extension of the bi-interval (k, l, s) by every symbol (bwt_extend on the swapped interval, src/bwt.c:428-448):
@@ -197,7 +214,7 @@ __device__ __forceinline__ void fmd_occ1_pair(const fmd_dev_t &f, uint64_t k, ui
 __device__ __forceinline__ void fmd_forward_ext(const fmd_dev_t &f, uint64_t k, uint64_t l, uint64_t s, uint64_t nk[4], uint64_t nl[4], uint64_t ns[4])
 {
 	uint64_t tk[4], tl[4];
-	fmd_occ4_pair(f, l - 1, l - 1 + s, tk, tl);
+	fmd_occ4_pair<false>(f, l - 1, l - 1 + s, tk, tl);      // l >= 1: the first row of an interval of a non-empty pattern
 #pragma unroll
 	for (int q = 0; q < 4; ++q) { ns[q] = tl[q] - tk[q]; nl[q] = fmd_L2(f, q) + 1 + tk[q]; }
 	nk[3] = k + ((l <= f.primary) & (l + s - 1 >= f.primary));

@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 			const int b = (int)((rw >> ((i & 15) << 1)) & 3);
 			const bool isn = (rm >> (i & 31)) & 1;
 			uint64_t ol, ou;
-			fmd_occ1_pair(f, lo - 1, hi, b, ol, ou);
+			fmd_occ1_pair<false>(f, lo - 1, hi, b, ol, ou);       // lo >= 1: first row of a non-empty pattern's interval
 			const uint64_t L2b = l2_lds[b];
 			const uint64_t nl = L2b + ol + 1, nu = L2b + ou;
 			const bool ok = !isn && nl <= nu;
@@ -1049,8 +1049,8 @@ __global__ void __launch_bounds__(256) calib_gather_kernel(fmd_dev_t f, uint64_t
 	for (int i = 0; i < iters; ++i) {
 		x = x * 6364136223846793005ull + 1442695040888963407ull;
 		blk_t b = fmd_load_block(f, (x >> 20) % n_blocks);
-		acc += b.occ.x ^ b.w.w;
-		if (dependent) x ^= (uint64_t)(b.occ.y + b.w.x) << 24;
+		acc += b.occ.x ^ (uint32_t)(b.hi >> 32);
+		if (dependent) x ^= (uint64_t)(b.occ.y + (uint32_t)b.lo) << 24;
 	}
 	if (acc == 0x12345678u) sink[0] = acc;    // keeps the loads alive
 }

@@ -35,8 +35,12 @@ int bmh_set_device(int dev);
 
 /* ------------------------------------------------------------------ index */
 
-/* FMD index resident in HBM.  Layout = the reference's GPU layout
- * (seed_gen.cu:28-48; seed_gen.h:21-33 bwt_t_gpu). */
+/* FMD index resident in HBM.  The arrays that cross this interface have the reference's
+ * GPU layout (seed_gen.cu:28-48; seed_gen.h:21-33 bwt_t_gpu): blocks {u32 occ[4]; u32 bwt[4]}.
+ * A handle keeps the blocks re-encoded as {u32 occ[4]; u64 low bit plane; u64 high bit plane}
+ * (same 32 bytes per 64 symbols; csrc/fmd_dev.h) -- bmh_index_upload converts its device copy
+ * in place, bmh_index_from_device makes its own converted copy (seq_len / 2 bytes of HBM) and
+ * leaves the caller's buffer as it is. */
 typedef struct bmh_index bmh_index_t;
 
 /* host arrays -> HBM (replaces gpu_cpy_wrapper, seed_gen.cu:1524-1556).
@@ -57,6 +61,12 @@ bmh_index_t *bmh_index_from_device(uint64_t primary, const uint64_t L2[5], uint6
                                    const uint32_t *d_sa, uint64_t n_sa, const uint32_t *d_sa_bits,
                                    const uint8_t *d_pac, uint64_t l_pac);
 void bmh_index_free(bmh_index_t *idx);
+/* Rank primitives at n given rows (d_rows, d_out: device memory), asynchronous on `stream`:
+ *   what = 0: d_out[4 i + c] = Occ(rows[i], c), c = A,C,G,T  (bwt_occ4, src/bwt.c:309-330; rows -1 and seq_len allowed)
+ *   what = 1: d_out[i] = LF(rows[i])                         (bwt_invPsi, src/bwt.c:64-70)
+ *   what = 2: d_out[i] = SA[rows[i]]                         (bwt_sa, src/bwt.c:105-115)
+ * rows of 1 / 2 must lie in [0, seq_len]. */
+int bmh_index_probe(const bmh_index_t *idx, const uint64_t *d_rows, uint64_t n, int what, uint64_t *d_out, void *stream);
 
 /* ---- several GPUs of one node from C: the index on every device, the reads sharded, one host worker thread per device
  * (the reference has no multi-GPU mode at all: gasal_set_device is commented out at src/fastmap.c:143).
@@ -143,8 +153,14 @@ int bmh_calib_gather(const bmh_index_t *idx, uint64_t n_lanes, int iters, int de
 /* Calibration of the integer-VALU roofline the extension kernels are held against: waves_per_simd resident waves on every
  * SIMD execute `iters` rounds of 128 instructions of one kind -- mode 0: independent v_max_i32 / v_add_u32 (the issue ceiling),
  * 1: one dependent chain, 2: dependent DPP row_shr max (the scans), 3: independent DPP, 4: packed 16-bit add / max,
- * 5: v_bfe_i32, 6: v_fma_f32.  *ms = kernel time, *lane_ops = 64 x 128 x iters per wave, summed over the waves. */
+ * 5: v_bfe_i32, 6: v_fma_f32, 7: v_pk_fma_f32 (two fp32 lanes per instruction: the form the chip's 157 TFLOP/s vector figure
+ * needs), 8: the packed DP kernels' own mix (v_pk_mad / sub / max / min / add_u16, v_perm_b32, v_and_b32).
+ * *ms = kernel time, *lane_ops = 64 x 128 x iters per wave, summed over the waves (instructions x 64: a packed instruction
+ * counts once).  bmh_calib_valu_placed also returns, for every wave of the timed launch, (XCC_ID << 32 | HW_ID) in place[]
+ * (host memory for 4 x 256-thread-blocks words; *n_place = how many): which SIMD of which CU of which XCD the wave ran on. */
 int bmh_calib_valu(int mode, int waves_per_simd, int iters, void *stream, float *ms, double *lane_ops);
+int bmh_calib_valu_placed(int mode, int waves_per_simd, int iters, void *stream, float *ms, double *lane_ops,
+                          unsigned long long *place, unsigned *n_place);
 
 /* -------------------------------------------------------------- extension */
 

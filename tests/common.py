@@ -101,3 +101,28 @@ def assert_seeds_equal(a: dict, b: dict, what: str = ""):
         if not np.array_equal(x, y):
             bad = np.nonzero(x.reshape(len(x), -1) != y.reshape(len(y), -1))[0][:5]
             raise AssertionError(f"{what}{k}: first mismatches at {bad}: {x[bad]} vs {y[bad]}")
+
+
+def make_ext_jobs_fast(n: int, rng, maxq: int = 281):
+    """Vectorised job generator for large differential runs (hundreds of thousands of jobs): the query is the start of the target
+    with per-job substitution rates and one indel (a shift of the copy source behind a breakpoint), or unrelated; a few N."""
+    qlen = rng.integers(1, maxq + 1, size=n).astype(np.uint32)
+    tlen = (rng.integers(1, 2 * qlen.astype(np.int64) + 20)).astype(np.uint32)
+    qoff = np.concatenate([[0], np.cumsum(qlen)[:-1]]).astype(np.uint32)
+    toff = np.concatenate([[0], np.cumsum(tlen)[:-1]]).astype(np.uint32)
+    t = rng.integers(0, 4, size=int(tlen.sum())).astype(np.uint8)
+    job = np.repeat(np.arange(n), qlen)
+    j = np.arange(int(qlen.sum())) - np.repeat(qoff.astype(np.int64), qlen)
+    bp = rng.integers(0, qlen.astype(np.int64) + 1)
+    shift = rng.integers(-3, 4, size=n) * (rng.random(n) < 0.4)
+    src = j + np.where(j >= bp[job], shift[job], 0)
+    ok = (src >= 0) & (src < tlen.astype(np.int64)[job])
+    q = rng.integers(0, 4, size=j.shape[0]).astype(np.uint8)
+    q[ok] = t[toff.astype(np.int64)[job[ok]] + src[ok]]
+    rate = rng.choice([0.0, 0.01, 0.03, 0.08, 0.25, 1.0], size=n, p=[0.2, 0.25, 0.2, 0.15, 0.1, 0.1])
+    m = rng.random(j.shape[0]) < rate[job]
+    q[m] = (q[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+    q[rng.random(q.shape[0]) < 0.002] = 4
+    t[rng.random(t.shape[0]) < 0.002] = 4
+    h0 = rng.integers(1, 200, size=n).astype(np.uint32)
+    return q, qoff, qlen, t, toff, tlen, h0

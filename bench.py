@@ -214,6 +214,20 @@ def main():
     # (the key names the genome generator + index layout version: a cache written by another build of either is not picked up)
     cache = a.index_cache and os.path.join(a.index_cache, f"g{a.genome_mbp:g}_sa{a.sa_intv}_seed42_{CACHE_VERSION}")
 
+    def draw_batches(g_host, holes_):
+        lo_, hi_ = shard_range(a.reads_per_gpu * world, rank, world, multiple=2 if a.paired else 1)
+        out_ = []
+        for bseed in (7, 1007):                 # two different batches, alternated step by step
+            if a.paired:
+                reads_, _ = B.synth.make_pairs(g_host, (hi_ - lo_) // 2, a.read_len, seed=bseed + rank, holes=holes_)
+            else:
+                reads_, _ = B.synth.make_reads(g_host, hi_ - lo_, a.read_len, seed=bseed + rank, holes=holes_)
+            out_.append(reads_)
+        return out_
+
+    g = None
+    my_reads = None
+    t_reads_early = 0.0
     if rank == 0 and cache and os.path.exists(os.path.join(cache, "meta.json")):
         # setup shortcut for repeated runs on one box (the profile passes): the SAME genome + index, written by an earlier run of this command
         t0 = time.time()
@@ -240,34 +254,57 @@ def main():
                 t.cpu().numpy().tofile(os.path.join(cache, nm))
             json.dump({"primary": int(d.primary), "L2": [int(x) for x in d.L2], "seq_len": int(d.seq_len), "sa_intv": int(d.sa_intv), "stats": d.stats,
                        "contigs": meta["contigs"], "holes": meta["holes"]}, open(os.path.join(cache, "meta.json"), "w"))
+    else:
+        # the other ranks do not wait for rank 0's index with idle hands: the genome generator is deterministic (seed 42), so every rank
+        # makes the same 2-bit text on its own GPU and draws its shard's reads while rank 0 builds; only the index arrays travel
+        t0 = time.time()
+        g_t, meta = B.synth.make_genome_device(n_genome, dev, seed=42, return_meta=True)
+        pac_t = F.pack_pac_device(g_t)
+        g = g_t.cpu().numpy()
+        del g_t
+        torch.cuda.synchronize(); t_gen = time.time() - t0
+        torch.cuda.empty_cache()
+        t0 = time.time()
+        my_reads = draw_batches(g, meta["holes"])
+        t_reads_early = time.time() - t0
     t0 = time.time()
-    if distributed and dist.get_backend() == "gloo":
+    gloo_shared = distributed and dist.get_backend() == "gloo"
+    same_text = False
+    if distributed and world > 1:
+        # did every rank arrive at rank 0's text?  (a 64-bit sum of the packed text; if not -- another generator build, a cache from
+        # elsewhere -- the text and its metadata are broadcast like the index)
+        cdev = torch.device("cpu") if gloo_shared else dev
+        chk = pac_t.sum(dtype=torch.int64).reshape(1).to(cdev) + (pac_t.numel() << 40)
+        ref_chk = chk.clone(); dist.broadcast(ref_chk, 0)
+        agree = (chk == ref_chk).to(torch.int64); dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        same_text = bool(agree.item())
+        if not same_text and rank != 0:
+            pac_t = None; g = None; my_reads = None
+    if gloo_shared:
         # ranks share one GPU: the broadcast goes through host memory (gloo), the arrays land in each rank's own HBM allocation
         cpu = torch.device("cpu")
         if rank == 0:
             dc = F.DeviceFMDIndex(d.primary, d.L2, d.seq_len, d.bwt_t.cpu(), d.sa_intv, d.sa_t.cpu(), d.bits_t.cpu(), d.stats)
-            dc, pc, meta = broadcast_built_index(dc, pac_t.cpu(), meta, cpu, src=0)
+            dc, pc, meta = broadcast_built_index(dc, pac_t.cpu(), meta, cpu, src=0, with_text=not same_text)
         else:
-            dc, pc, meta = broadcast_built_index(None, None, None, cpu, src=0)
+            dc, pc, meta = broadcast_built_index(None, None if not same_text else pac_t.cpu(), meta if same_text else None, cpu, src=0, with_text=not same_text)
             d = F.DeviceFMDIndex(dc.primary, dc.L2, dc.seq_len, dc.bwt_t.to(dev), dc.sa_intv, dc.sa_t.to(dev), dc.bits_t.to(dev), {})
             pac_t = pc.to(dev)
         del dc, pc
     else:
-        d, pac_t, meta = broadcast_built_index(d, pac_t, meta, dev, src=0)
+        d, pac_t, meta = broadcast_built_index(d, pac_t, meta, dev, src=0, with_text=not same_text)
     torch.cuda.synchronize(); t_bcast = time.time() - t0
     build_stats = d.stats
     contigs, holes = meta["contigs"], meta["holes"]
     dindex = B.Index.from_device(d.primary, d.L2.astype(np.uint64), d.seq_len, d.bwt_t, d.sa_intv, d.sa_t, d.bits_t, pac_t=pac_t, l_pac=n_genome)
-    g = F.unpack_pac_device(pac_t, n_genome).cpu().numpy()      # host copy of the genome: read sampling, CPU baseline, host rows
+    if g is None:
+        g = F.unpack_pac_device(pac_t, n_genome).cpu().numpy()      # host copy of the genome: read sampling, CPU baseline, host rows
     torch.cuda.empty_cache()
     lo, hi = shard_range(a.reads_per_gpu * world, rank, world, multiple=2 if a.paired else 1)
-    batches = []
-    for bseed in (7, 1007):                 # two different batches, alternated step by step
-        if a.paired:
-            reads, _ = B.synth.make_pairs(g, (hi - lo) // 2, a.read_len, seed=bseed + rank, holes=holes)
-        else:
-            reads, _ = B.synth.make_reads(g, hi - lo, a.read_len, seed=bseed + rank, holes=holes)
-        batches.append((reads, P.reads_to_device(reads, dev)))
+    if my_reads is None:
+        my_reads = draw_batches(g, holes)
+    batches = [(reads, P.reads_to_device(reads, dev)) for reads in my_reads]
+    del my_reads
     n_reads = batches[0][1].n
     from bwamem_hip.lib import ChainWorkspace, _memcpy_d2d
     params = B.ExtParams.default()
@@ -445,6 +482,10 @@ def main():
 
     if distributed:
         tt = torch.tensor([dt, dt_pcie or 0.0], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        mine = tt[:1].clone()
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        per_rank_ms = [float(x[0]) / a.steps * 1e3 for x in per_rank]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, dt_pcie = float(tt[0]), (float(tt[1]) if a.pcie else None)
         tot = torch.tensor([n_reads], dtype=torch.int64, device=tt.device)
@@ -534,6 +575,11 @@ def main():
                                        "of one batch in flight overlap the kernels of the other(s)"}
         if verified is not None:
             res["verified"] = verified
+        if distributed:
+            res["distributed"] = {"backend": dist.get_backend(), "ranks": world, "devices_on_this_node": n_dev, "index_broadcast_s": round(t_bcast, 2),
+                                  "text_generated_on_every_rank": bool(same_text), "ms_per_step_per_rank": {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3)},
+                                  "what": "one process per GPU; rank 0 builds the index while the others generate the same genome and draw their shards' reads, then ONE broadcast "
+                                          "of the index arrays (RCCL over xGMI with backend nccl); no collective on the data path; `value` = reads of all ranks / slowest rank's time"}
         if world > 1:
             res["note"] = "N > 1 line: `roofline` and `cpu_baseline` are reported by the N = 1 run only (rank 0 at N = 1, bench contract)"
         # ---------------- CPU baseline + roofline of the dominant kernel (N = 1 only)
@@ -596,6 +642,11 @@ def main():
             dom = max(timed, key=timed.get)
             hb = max((k for k in timed if k != "extend"), key=timed.get)
             res["roofline_hbm_kernel"] = hbm_obj(hb)
+            # SURVEY.md 8d's figure for the path as a whole: (sum of the algorithmic bytes of seeding and extension) / step time / HBM peak
+            path_bytes = float(sum(kernel_bytes.values()))
+            res["roofline_path_hbm"] = {"algorithmic_bytes_per_step": int(path_bytes), "GBps": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                        "frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "what": "SURVEY 8d: (B_seed + B_ext) / t / HBM peak over the pipelined step; low by nature -- half of the step is integer DP that touches 110 B per job"}
             res["roofline_all"] = {k: {"ms": round(iso_ms[k], 3), "algorithmic_GBps": round(kernel_bytes[k] / (iso_ms[k] * 1e-3) / 1e9, 2)} for k in kernel_bytes}
             # the extension's binding roofline: integer VALU issue.  Algorithmic lane-ops = reference cells x 12; reference
             # cells = sum over rows of (end - beg) as ksw_extend2 executes them, counted by the oracle on the CPU sample and scaled to the batch
@@ -605,7 +656,10 @@ def main():
                     "unit": "T lane-ops/s", "frac": round(lane_ops / t_ext_s / VALU_PEAK_LANEOPS, 4), "traffic": from_prof("extend", "hbm_bytes_per_launch"),
                     "avg_ms": round(iso_ms["extend"], 3), "algorithmic_lane_ops_per_launch": int(lane_ops), "reference_cells_per_launch": int(cells),
                     "gcups_reference_cells": round(cells / t_ext_s / 1e9, 1), "jobs_per_launch": n_jobs,
-                    "peak_definition": "256 CUs x 4 SIMD-32 x 2.4 GHz: one wave64 VALU instruction per 2 cycles per SIMD (MI355X_MICROARCH.md); no MFMA: integer DP, not a contraction",
+                    "peak_definition": "16-bit lane-ops: 256 CUs x 4 SIMDs x 16 lanes per clock x 2 packed halves x 2.4 GHz.  A wave64 VALU instruction occupies its SIMD for 4 cycles "
+                                       "(measured: no instruction kind exceeds 0.53 of one-per-2-cycles at 1-8 waves per SIMD with every SIMD of every XCD evenly loaded, "
+                                       "profiles/r04_calib_valu_placement.txt; v_pk_fma_f32 at 0.45 x 2 lanes = the chip's 157 TFLOP/s), so 78.6 T is what PACKED 16-bit "
+                                       "instructions can retire and 39.3 T what 32-bit ones can; no MFMA: integer DP, not a contraction",
                     "hbm_view": {"algorithmic_bytes_per_launch": int(kernel_bytes["extend"]), "GBps": round(kernel_bytes["extend"] / t_ext_s / 1e9, 2),
                                  "frac_of_hbm_peak": round(kernel_bytes["extend"] / t_ext_s / 1e9 / HBM_PEAK_GBS, 5)}}
             if valu["traffic"] is not None:

@@ -80,11 +80,13 @@ def _bcast_chunked(t: torch.Tensor, src: int, chunk: int = 1 << 28) -> None:
         dist.broadcast(flat[o:o + chunk], src)
 
 
-def broadcast_built_index(d, pac_t, meta, device, src: int = 0):
+def broadcast_built_index(d, pac_t, meta, device, src: int = 0, with_text: bool = True):
     """The index bmh_index_build left in rank `src`'s HBM (fmindex.DeviceFMDIndex + the 2-bit pac + the genome's metadata) to
     every rank: `src` passes them, the others pass None.  One header, one object broadcast (metadata) and the four arrays
     (pac, Occ/BWT blocks, suffix array, its high bits) over RCCL/xGMI -- the only collective of the run, outside the data path.
-    Returns (DeviceFMDIndex, pac_t, meta) on every rank.  Without an initialised process group it returns its arguments."""
+    Returns (DeviceFMDIndex, pac_t, meta) on every rank.  Without an initialised process group it returns its arguments.
+    with_text=False: every rank already holds the 2-bit text and the metadata (it generated the same genome itself while `src`
+    built the index); only the header and the three index arrays travel, pac_t / meta come back as they were passed."""
     from .fmindex import DeviceFMDIndex
     if not dist.is_initialized():
         return d, pac_t, meta
@@ -95,13 +97,16 @@ def broadcast_built_index(d, pac_t, meta, device, src: int = 0):
         hdr[: len(vals)] = torch.tensor(vals, dtype=torch.int64)
     dist.broadcast(hdr, src)
     h = hdr.cpu().tolist()
-    box = [meta if rank == src else None]
-    dist.broadcast_object_list(box, src=src, device=device if device.type != "cpu" else None)
+    box = [meta]
+    if with_text:
+        box = [meta if rank == src else None]
+        dist.broadcast_object_list(box, src=src, device=device if device.type != "cpu" else None)
     if rank != src:
         d = DeviceFMDIndex(primary=h[0], L2=np.array(h[1:6], dtype=np.int64), seq_len=h[6], bwt_t=torch.empty(h[8], dtype=torch.int32, device=device),
                            sa_intv=h[7], sa_t=torch.empty(h[9], dtype=torch.int32, device=device),
                            bits_t=torch.empty(h[10], dtype=torch.int32, device=device), stats={})
-        pac_t = torch.empty(h[11], dtype=torch.uint8, device=device)
-    for t in (pac_t, d.bwt_t, d.sa_t, d.bits_t):
+        if with_text:
+            pac_t = torch.empty(h[11], dtype=torch.uint8, device=device)
+    for t in ((pac_t,) if with_text else ()) + (d.bwt_t, d.sa_t, d.bits_t):
         _bcast_chunked(t, src)
     return d, pac_t, box[0]

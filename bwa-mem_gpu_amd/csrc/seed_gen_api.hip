@@ -198,15 +198,9 @@ extern "C" mem_seed_v_gpu *seed_gpu(gpuseed_storage_vector *d)
 	const int n_workers = (int)std::min<uint64_t>((uint64_t)n_workers_env, max_batches);
 	std::vector<bmh_index_t *> widx(n_workers, idx);
 	std::vector<int> wdev(n_workers, home);
-	for (int k = 1; k < n_workers; ++k) {
-		wdev[k] = (home + k) % n_dev;
-		if (wdev[k] != home) {
-			int found = -1;
-			for (int q = 1; q < k; ++q) if (wdev[q] == wdev[k]) found = q;
-			if (found >= 0) widx[k] = widx[found];
-			else if (bmh_index_replicate(idx, home, wdev[k], &widx[k]) != BMH_OK) FATAL("seed_gpu: %s", bmh_last_error());
-		}
-	}
+	for (int k = 1; k < n_workers; ++k) wdev[k] = (home + k) % n_dev;
+	// the index on every worker's device: one grouped RCCL broadcast per array over xGMI (hipMemcpyPeer copies where RCCL is absent)
+	if (n_workers > 1 && bmh_index_replicate_all(idx, home, wdev.data(), n_workers, widx.data(), nullptr) != BMH_OK) FATAL("seed_gpu: %s", bmh_last_error());
 	const int min_seed = d->min_seed_size;
 	auto work = [&](int k) {
 		HIPX(hipSetDevice(wdev[k]));

@@ -78,6 +78,24 @@ int bmh_index_probe(const bmh_index_t *idx, const uint64_t *d_rows, uint64_t n, 
  * worker threads, one per device, and concatenates their seeds in file order; the gasal_gpu_storage_t objects of
  * gasal_init_streams are spread over the N devices.  With fewer physical devices than N several workers share one. */
 int bmh_index_replicate(const bmh_index_t *src, int src_device, int dst_device, bmh_index_t **out);
+
+/* ---- the same with RCCL over xGMI (csrc/rccl_bcast.hip).  RCCL is resolved at run time -- the symbols already in the process (a
+ * host linked with -lrccl), then $BMH_RCCL_LIB, then librccl.so.1 of the loader path -- because a communicator is only valid in
+ * the library instance that made it; bmh_rccl_where() names the instance in use (NULL: none found, bmh_last_error says why).
+ * One process per GPU: rank 0 calls bmh_rccl_unique_id and hands the 128 bytes to the others by its own means (a file, MPI, a
+ * socket), every rank calls bmh_rccl_comm_init_rank on its device and then bmh_index_broadcast_rccl: the root passes its index
+ * (out == NULL: send only; out != NULL: it receives a fresh copy like the others), the others receive theirs in *out (owned:
+ * bmh_index_free).  One 128-byte header, then the blocks (native layout), the suffix array, its high bits and the 2-bit text in
+ * ONE grouped broadcast, in pieces of at most 1 GiB, on `stream`; returns when the arrays have arrived.
+ * One process, n devices: bmh_index_replicate_all makes out[k] the index on devices[k] (src itself on src_device; duplicates in
+ * the list share a copy) with ncclCommInitAll and the same grouped broadcast; *used_rccl (optional) says whether RCCL carried it
+ * or the hipMemcpyPeer fallback did (RCCL not found, or BMH_REPLICATE=peer).  BMH_DEVICES=N of the drop-in uses this. */
+const char *bmh_rccl_where(void);
+int bmh_rccl_unique_id(void *id128);
+int bmh_rccl_comm_init_rank(void **comm, int nranks, const void *id128, int rank);
+void bmh_rccl_comm_destroy(void *comm);
+int bmh_index_broadcast_rccl(void *comm, int root, const bmh_index_t *src, bmh_index_t **out, void *stream);
+int bmh_index_replicate_all(const bmh_index_t *src, int src_device, const int *devices, int n, bmh_index_t **out, int *used_rccl);
 void bmh_shard_range(uint64_t n, int rank, int world, uint32_t multiple, uint64_t *lo, uint64_t *hi);
 
 /* Replaces the suffix-array samples by denser ones (every new_intv-th row, a power of two; a no-op if the index is that

@@ -9,6 +9,7 @@ import pytest
 import common
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -152,3 +153,25 @@ def test_hot_path_on_a_text_beyond_2_pow_32(hip, oracle):
     found[rg[:, 0][(fb < tp + 150) & (fe > tp)]] = True
     assert found.mean() > 0.99, found.mean()
     hj.free(); cw.free(); ws.free(); dindex.free()
+
+
+@pytest.mark.parametrize("variant", ["paired", "300bp"])
+def test_baseline_configs_3_and_4_at_full_size(variant):
+    """BASELINE.json configs[3] (1 M x 150 bp pairs, interleaved) and configs[4] (1 M x 300 bp) at their stated size against the
+    3.1 Gbp index (seq_len 6.2e9 > 2^32, built on the device in the run's setup): the bench command itself, two timed steps, the
+    first 100 000 reads of the last timed batch compared with the oracle inside the run (seeds and regions identical or exit 3)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    extra = ["--paired"] if variant == "paired" else ["--read-len", "300"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--verify-sample", "100000", "--no-next-rows", "--cpu-sample", "0",
+                        "--no-pcie"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    cfg = res["config"]
+    assert cfg["reads_per_gpu"] == 1_000_000 and cfg["seq_len"] > 2**32 and cfg["genome_mbp"] == 3100
+    assert cfg["read_len"] == (300 if variant == "300bp" else 150) and cfg["paired_interleaved"] == (variant == "paired")
+    v = res["verified"]
+    assert v["reads"] == 100_000 and v["seeds_identical"] and v["regions_identical"], v
+    assert res["value"] > 0

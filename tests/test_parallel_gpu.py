@@ -80,3 +80,57 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
     v = res["verified"]
     assert v["seeds_identical"] and v["regions_identical"] and v["ranks"] == 2 and v["reads"] == 4000
+
+
+def test_index_broadcast_over_rccl_from_c(oracle):
+    """bmh_rccl_* + bmh_index_broadcast_rccl: RCCL driven from the C ABI (no torch.distributed).  The box has one GPU, so the
+    communicator has one rank -- the code path (run-time resolution of librccl, unique id, ncclCommInitRank, header + grouped
+    ncclBroadcast of the four arrays out of place, ownership of the received copy) is the one N ranks run; the received index
+    seeds like the original.  bmh_index_replicate_all with a device list that repeats device 0 shares the source."""
+    import ctypes as C
+    import torch
+    import bwamem_hip as B
+    from test_gpu_parity import _pack_pac, gpu_seed
+    L = B.load_library()
+    assert torch.cuda.is_available()
+    where = L.bmh_rccl_where()
+    assert where, B.lib._err(L)
+    g, idx = common.genome_and_index(200_000, seed=17)
+    reads, _ = B.synth.make_reads(g, 1500, 150, seed=18)
+    flat, offs, lens = common.flat_reads(reads)
+    want = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens)
+    src = B.Index.upload(idx, pac=_pack_pac(g), l_pac=len(g))
+    src.densify_sa(4)
+    uid = (C.c_uint8 * 128)()
+    assert L.bmh_rccl_unique_id(uid) == 0, B.lib._err(L)
+    comm = C.c_void_p()
+    assert L.bmh_rccl_comm_init_rank(C.byref(comm), 1, uid, 0) == 0, B.lib._err(L)
+    try:
+        got_h = C.c_void_p()
+        st = torch.cuda.Stream()
+        assert L.bmh_index_broadcast_rccl(comm, 0, src.handle, C.byref(got_h), st.cuda_stream) == 0, B.lib._err(L)
+        assert got_h.value and got_h.value != src.handle
+        rep = B.Index(got_h.value)
+        # send-only form on the root: nothing comes back
+        assert L.bmh_index_broadcast_rccl(comm, 0, src.handle, None, st.cuda_stream) == 0, B.lib._err(L)
+        src.free()                                          # the copy stands on its own
+        common.assert_seeds_equal(gpu_seed(B, idx, flat, offs, lens, index=rep), want, what="index received over RCCL: ")
+        outs = (C.c_void_p * 3)(); devs = (C.c_int * 3)(0, 0, 0); used = C.c_int(-1)
+        assert L.bmh_index_replicate_all(rep.handle, 0, devs, 3, outs, C.byref(used)) == 0, B.lib._err(L)
+        assert [outs[k] for k in range(3)] == [rep.handle] * 3 and used.value == 0
+        rep.free()
+    finally:
+        L.bmh_rccl_comm_destroy(comm)
+
+
+def test_bench_under_torchrun_takes_the_rccl_branch():
+    """One rank under torch.distributed.run: bench.py's `nccl` branch (RCCL process group, index broadcast, barriers, reductions
+    of the timing and of the verdict) executes on the device -- with one rank, the most this box can hold."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HIP_VISIBLE_DEVICES")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--genome-mbp", "40", "--reads-per-gpu", "20000",
+                        "--verify-sample", "2000", "--no-next-rows", "--cpu-sample", "0", "--no-pcie"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["distributed"]["backend"] == "nccl" and res["distributed"]["ranks"] == 1
+    assert res["verified"]["seeds_identical"] and res["verified"]["regions_identical"]

@@ -275,14 +275,21 @@ class Aligner:
             if not paired:
                 # single-end: the region tail runs on the device too (bmh_finalize_regs_device); what comes back over PCIe are the records
                 po = PostOpt.from_buffer_copy(self.po); po.id0 = id0
-                from .lib import finalize_regs_device
-                d_fin, d_opr = finalize_regs_device(self.index, self.copt, self.ep, po, r, o, regs, nr, dj.d_regs_per_read, dj.d_frac_rep, n,
-                                                    contigs=self.contigs if len(self.contigs) > 1 else None)
-                _lap("finalize (device)")
-                fin = self._d2h("fin", d_fin); opr = np.ascontiguousarray(d_opr.cpu().numpy().view(np.uint32)[:n]); m = len(fin)
-                _lap("D2H records")
-                self._lap = _lap; self._prof = (_t, _nm)
-                return self._finish_single(names, codes, offs, lens, r, o, l, fin, opr, m, po, cw, ws, _lap, _t, _nm, as_bytes, fin_t=d_fin)
+                from .lib import CapacityError, finalize_regs_device
+                try:
+                    d_fin, d_opr = finalize_regs_device(self.index, self.copt, self.ep, po, r, o, regs, nr, dj.d_regs_per_read, dj.d_frac_rep, n,
+                                                        contigs=self.contigs if len(self.contigs) > 1 else None)
+                except CapacityError:
+                    # a read beyond the device tail's fixed limits (65 535 near-equal regions, a patch alignment of more than 1 022
+                    # bases): this batch takes the host form below, which has none of them -- same records
+                    d_fin = None
+                    self.host_tail_batches = getattr(self, "host_tail_batches", 0) + 1
+                if d_fin is not None:
+                    _lap("finalize (device)")
+                    fin = self._d2h("fin", d_fin); opr = np.ascontiguousarray(d_opr.cpu().numpy().view(np.uint32)[:n]); m = len(fin)
+                    _lap("D2H records")
+                    self._lap = _lap; self._prof = (_t, _nm)
+                    return self._finish_single(names, codes, offs, lens, r, o, l, fin, opr, m, po, cw, ws, _lap, _t, _nm, as_bytes, fin_t=d_fin)
             rpr = torch.empty(n, dtype=torch.int32, device=dev); fr = torch.empty(n, dtype=torch.float32, device=dev)
             _memcpy_d2d(rpr.data_ptr(), dj.d_regs_per_read, 4 * n); _memcpy_d2d(fr.data_ptr(), dj.d_frac_rep, 4 * n)
             regs_h = np.ascontiguousarray(regs[:nr].cpu().numpy())

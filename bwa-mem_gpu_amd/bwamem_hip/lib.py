@@ -23,7 +23,7 @@ def lib_path() -> str:
 EXPORTED_SYMBOLS = [
     "bmh_last_error", "bmh_device_count", "bmh_set_device", "bmh_index_upload", "bmh_index_from_device",
     "bmh_index_free", "bmh_index_probe", "bmh_index_replicate", "bmh_rccl_where", "bmh_rccl_unique_id", "bmh_rccl_comm_init_rank", "bmh_rccl_comm_destroy", "bmh_index_broadcast_rccl", "bmh_index_replicate_all", "bmh_shard_range", "bmh_index_densify_sa", "bmh_index_build", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
-    "bmh_extend_batch", "bmh_extend_last_ms", "bmh_extend_last_unsupported", "bmh_extend_set_packed", "bmh_extend_release", "bmh_calib_gather", "bmh_calib_valu", "bmh_calib_valu_placed",
+    "bmh_extend_batch", "bmh_extend_last_ms", "bmh_extend_last_unsupported", "bmh_extend_set_packed", "bmh_extend_release", "bmh_finalize_release", "bmh_matesw_release", "bmh_calib_gather", "bmh_calib_valu", "bmh_calib_valu_placed",
     "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_finalize_regs_device", "bmh_finalize_regs_device_last_ms", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
     "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_finalize_pairs_dev", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
     "bmh_chain_opt_default", "bmh_chain_last_timing", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
@@ -463,6 +463,10 @@ def cigar_batch(index: Index, reads_t, offs_t, lens_t, regs_t, n: int, sel_t=Non
     return cigar, aln, md
 
 
+class CapacityError(RuntimeError):
+    """a BMH_ECAPACITY return: the device form of a stage met a read beyond its fixed limits; the caller may take the host form"""
+
+
 def finalize_regs_device(index: "Index", copt, ep, po, reads_t, offs_t, regs_t, n_regs: int, regs_per_read_ptr: int, frac_rep_ptr: int, n_reads: int,
                          contigs=None, out_t=None, opr_t=None, stream: int = 0):
     """bmh_finalize_regs_device on torch CUDA tensors / device pointers (regs_per_read_ptr, frac_rep_ptr: bmh_dev_jobs_t.d_regs_per_read /
@@ -478,6 +482,8 @@ def finalize_regs_device(index: "Index", copt, ep, po, reads_t, offs_t, regs_t, 
     m = L.bmh_finalize_regs_device(index.handle, C.byref(copt), C.byref(ep), C.byref(po), reads_t.data_ptr(), offs_t.data_ptr(), n_reads,
                                    regs_t.data_ptr(), n_regs, regs_per_read_ptr, frac_rep_ptr, len(contigs) if off is not None else 1,
                                    off.ctypes.data_as(C.c_void_p) if off is not None else None, out_t.data_ptr(), opr_t.data_ptr(), stream)
+    if m == -3:
+        raise CapacityError(f"bmh_finalize_regs_device rc={m}: " + _err(L))
     if m < 0:
         raise RuntimeError(f"bmh_finalize_regs_device rc={m}: " + _err(L))
     return out_t[:m], opr_t

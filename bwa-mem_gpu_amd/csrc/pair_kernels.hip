@@ -229,6 +229,25 @@ struct msw_scratch_t { bmh_msw_job_t *d_jobs; int32_t *d_out; uint32_t *d_bl; si
 static std::mutex g_msw_mu;
 static std::map<std::pair<int, void *>, msw_scratch_t *> g_msw_map;
 
+// the (device, stream) scratch of bmh_matesw_batch_device: freed when the caller retires the stream (stream idle, its device current)
+extern "C" void bmh_matesw_release(void *stream_)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return;
+	msw_scratch_t *S = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(g_msw_mu);
+		auto it = g_msw_map.find(std::make_pair(dev, stream_));
+		if (it == g_msw_map.end()) return;
+		S = it->second;
+		g_msw_map.erase(it);
+	}
+	if (S->d_jobs) (void)hipFree(S->d_jobs);
+	if (S->d_out) (void)hipFree(S->d_out);
+	if (S->d_bl) (void)hipFree(S->d_bl);
+	free(S);
+}
+
 // can the kernel take this job? (the host computes the others itself)
 extern "C" int bmh_matesw_device_takes(int l_ms, int64_t tlen, int xtra)
 {

@@ -150,10 +150,11 @@ bool fetch_window(const PCtx &c, int64_t *beg, int64_t mid, int64_t *end, int *r
 
 // BMH_POST_STATS: how much local alignment the mate rescue does
 static std::atomic<unsigned long long> g_ms_calls{0}, g_ms_sw{0}, g_ms_cells{0}, g_ms_hits{0};
+static const bool g_pair_stats = getenv("BMH_POST_STATS") != nullptr;      // the counters are only read (and only bumped) with it set
 
 int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector<Reg> &ma, SwKey key = SwKey{0, 0, 0, 0}, uint32_t mate_read = 0)        // mem_matesw
 {
-	g_ms_calls++;
+	if (g_pair_stats) g_ms_calls++;
 	const int64_t l_pac = c.x.l_pac;
 	int skip[4], n = 0;
 	for (int r = 0; r < 4; ++r) skip[r] = c.pes[r].failed ? 1 : 0;
@@ -210,7 +211,7 @@ int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector
 				for (int64_t t = rb; t < re; ++t) ref[(size_t)(t - rb)] = (uint8_t)text_base(c.x.pac, l_pac, t);
 				seqbuf.assign(seq, seq + l_ms);
 				aln = bmh_local_sw(l_ms, seqbuf.data(), (int)(re - rb), ref.data(), *c.x.ep, xtra);
-				g_ms_sw++; g_ms_cells += (unsigned long long)l_ms * (unsigned long long)(re - rb);
+				if (g_pair_stats) g_ms_sw++, g_ms_cells += (unsigned long long)l_ms * (unsigned long long)(re - rb);
 			}
 			if (aln.score >= c.x.co->min_seed_len && aln.qb >= 0) {
 				Reg b; memset(&b, 0, sizeof(b));
@@ -222,7 +223,7 @@ int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector
 				b.score = aln.score; b.csub = aln.score2; b.secondary = -1;
 				b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
 				size_t i;
-				g_ms_hits++;
+				if (g_pair_stats) g_ms_hits++;
 				for (i = 0; i < ma.size(); ++i) if (ma[i].score < b.score) break;     // keep ma sorted by score
 				ma.insert(ma.begin() + (long)i, b);
 			}

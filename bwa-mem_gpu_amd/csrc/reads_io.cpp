@@ -75,9 +75,15 @@ extern "C" int bmh_reads_load_fasta(const char *path, int n_threads, bmh_read_se
 	auto tp = now();
 	FILE *fp = fopen(path, "rb");
 	if (!fp) { bmh_set_error("bmh_reads_load_fasta: cannot open %s", path); return BMH_EINVAL; }
-	fseek(fp, 0, SEEK_END);
-	const size_t sz = (size_t)ftell(fp);
-	fseek(fp, 0, SEEK_SET);
+	// the file is read whole and cut at headers by several threads: it has to be a regular, seekable file (a FIFO or a process
+	// substitution makes ftello return -1)
+	off_t fsz = -1;
+	if (fseeko(fp, 0, SEEK_END) != 0 || (fsz = ftello(fp)) < 0 || fseeko(fp, 0, SEEK_SET) != 0) {
+		fclose(fp);
+		bmh_set_error("bmh_reads_load_fasta: %s is not a regular, seekable file", path);
+		return BMH_EINVAL;
+	}
+	const size_t sz = (size_t)fsz;
 	uint8_t *buf = (uint8_t *)malloc(sz + 1);
 	if (!buf) { fclose(fp); bmh_set_error("bmh_reads_load_fasta: out of memory (%zu bytes)", sz); return BMH_ENOMEM; }
 	const size_t got = sz ? fread(buf, 1, sz, fp) : 0;

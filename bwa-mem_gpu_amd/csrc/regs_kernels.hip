@@ -595,12 +595,38 @@ struct fin_scratch_t {
 	double *logtab; int64_t *ctg; int cap_ctg;
 	uint32_t *h_pin;
 	hipEvent_t ev0, ev1;
+	bool inited;             // the one-time part below went through completely
 };
 static std::mutex g_fin_mu;
 static std::map<std::pair<int, void *>, fin_scratch_t *> g_fin_map;
 static thread_local fin_scratch_t *g_fin_last = nullptr;
 
 template <class T> static int fin_grow(T *&p, size_t n) { if (p) (void)hipFree(p); p = nullptr; return hipMalloc((void **)&p, sizeof(T) * n) == hipSuccess ? BMH_OK : BMH_ENOMEM; }
+
+// the (device, stream) scratch of bmh_finalize_regs_device (device buffers, three side streams, events, pinned words): freed when
+// the caller retires the stream (stream idle, its device current)
+extern "C" void bmh_finalize_release(void *stream_)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return;
+	fin_scratch_t *S = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(g_fin_mu);
+		auto it = g_fin_map.find(std::make_pair(dev, stream_));
+		if (it == g_fin_map.end()) return;
+		S = it->second;
+		g_fin_map.erase(it);
+	}
+	if (g_fin_last == S) g_fin_last = nullptr;
+	void *ps[] = {S->in_off, S->out_off, S->opr_tmp, S->defer, S->ctr, S->g_dp, S->work, S->work2, S->g_keys, S->g_k128, S->g_tmp, S->g_order, S->g_z, S->scan_tmp, S->logtab, S->ctg};
+	for (void *q : ps) if (q) (void)hipFree(q);
+	if (S->h_pin) (void)hipHostFree(S->h_pin);
+	if (S->ev0) (void)hipEventDestroy(S->ev0);
+	if (S->ev1) (void)hipEventDestroy(S->ev1);
+	if (S->fork) (void)hipEventDestroy(S->fork);
+	for (int i = 0; i < 3; ++i) { if (S->side[i]) (void)hipStreamDestroy(S->side[i]); if (S->join[i]) (void)hipEventDestroy(S->join[i]); }
+	free(S);
+}
 
 extern "C" float bmh_finalize_regs_device_last_ms(void)
 {
@@ -624,6 +650,7 @@ extern "C" int64_t bmh_finalize_regs_device(const bmh_index_t *idx, const bmh_ch
 	if (n_contigs > 1 && !contig_offset) { bmh_set_error("bmh_finalize_regs_device: null contig table"); return BMH_EINVAL; }
 	if (n_regs >> 31) { bmh_set_error("bmh_finalize_regs_device: 2^31 regions or more in one batch"); return BMH_ECAPACITY; }
 	if (n_reads == 0) return 0;
+	if (getenv("BMH_FIN_FORCE_ECAPACITY")) { bmh_set_error("bmh_finalize_regs_device: capacity error forced by BMH_FIN_FORCE_ECAPACITY (test hook of the callers' host fallback)"); return BMH_ECAPACITY; }
 	hipStream_t st = (hipStream_t)stream_;
 	int dev = 0;
 	HIPCK(hipGetDevice(&dev));
@@ -636,18 +663,31 @@ extern "C" int64_t bmh_finalize_regs_device(const bmh_index_t *idx, const bmh_ch
 		else S = it->second;
 	}
 	g_fin_last = S;
-	if (!S->logtab) {
-		// log(k) by the host's libm (the reference's MAPQ is computed there): the device reads these values, it never calls log()
-		double *h = (double *)malloc(sizeof(double) * FIN_NLOG);
-		for (int k = 0; k < FIN_NLOG; ++k) h[k] = log((double)k);
-		if (fin_grow(S->logtab, FIN_NLOG) != BMH_OK) { free(h); return BMH_ENOMEM; }
-		HIPCK(hipMemcpy(S->logtab, h, sizeof(double) * FIN_NLOG, hipMemcpyHostToDevice));
-		free(h);
-		HIPCK(hipEventCreate(&S->ev0)); HIPCK(hipEventCreate(&S->ev1));
-		HIPCK(hipHostMalloc((void **)&S->h_pin, 128));
-		if (fin_grow(S->ctr, 32) != BMH_OK || fin_grow(S->g_dp, (size_t)FIN_NCLS * FIN_WAVE_GRID * 2 * FIN_DPCAP) != BMH_OK) return BMH_ENOMEM;
-		HIPCK(hipEventCreateWithFlags(&S->fork, hipEventDisableTiming));
-		for (int i = 0; i < 3; ++i) { HIPCK(hipStreamCreateWithFlags(&S->side[i], hipStreamNonBlocking)); HIPCK(hipEventCreateWithFlags(&S->join[i], hipEventDisableTiming)); }
+	if (!S->inited) {
+		// one-time part of a (device, stream) pair; a step that fails leaves `inited` false and the next call starts over (what was
+		// created so far is kept and not created twice)
+		if (!S->logtab) {
+			// log(k) by the host's libm (the reference's MAPQ is computed there): the device reads these values, it never calls log()
+			double *h = (double *)malloc(sizeof(double) * FIN_NLOG);
+			if (!h) { bmh_set_error("bmh_finalize_regs_device: out of host memory"); return BMH_ENOMEM; }
+			for (int k = 0; k < FIN_NLOG; ++k) h[k] = log((double)k);
+			double *d_log = nullptr;
+			const bool ok = fin_grow(d_log, FIN_NLOG) == BMH_OK && hipMemcpy(d_log, h, sizeof(double) * FIN_NLOG, hipMemcpyHostToDevice) == hipSuccess;
+			free(h);
+			if (!ok) { if (d_log) (void)hipFree(d_log); bmh_set_error("bmh_finalize_regs_device: log table: %s", hipGetErrorString(hipGetLastError())); return BMH_ENOMEM; }
+			S->logtab = d_log;
+		}
+		if (!S->ev0) HIPCK(hipEventCreate(&S->ev0));
+		if (!S->ev1) HIPCK(hipEventCreate(&S->ev1));
+		if (!S->h_pin) HIPCK(hipHostMalloc((void **)&S->h_pin, 128));
+		if (!S->ctr && fin_grow(S->ctr, 32) != BMH_OK) return BMH_ENOMEM;
+		if (!S->g_dp && fin_grow(S->g_dp, (size_t)FIN_NCLS * FIN_WAVE_GRID * 2 * FIN_DPCAP) != BMH_OK) return BMH_ENOMEM;
+		if (!S->fork) HIPCK(hipEventCreateWithFlags(&S->fork, hipEventDisableTiming));
+		for (int i = 0; i < 3; ++i) {
+			if (!S->side[i]) HIPCK(hipStreamCreateWithFlags(&S->side[i], hipStreamNonBlocking));
+			if (!S->join[i]) HIPCK(hipEventCreateWithFlags(&S->join[i], hipEventDisableTiming));
+		}
+		S->inited = true;
 	}
 	if ((size_t)n_reads + 1 > S->cap_reads) {
 		const size_t c = (size_t)n_reads + n_reads / 4 + 1024;

@@ -22,7 +22,8 @@
 namespace rp {
 
 // BMH_POST_STATS: how often the patch test reaches its global alignment, and how large those are
-static std::atomic<unsigned long long> g_st_patch_calls{0}, g_st_dp_calls{0}, g_st_dp_cells{0}, g_st_pairs{0}, g_st_reads_dp{0};
+static std::atomic<unsigned long long> g_st_patch_calls{0}, g_st_dp_calls{0}, g_st_dp_cells{0};
+static const bool g_post_stats = getenv("BMH_POST_STATS") != nullptr;      // the counters are only read (and only bumped) with it set
 
 int text_base(const uint8_t *pac, int64_t l_pac, int64_t i)
 {
@@ -75,7 +76,7 @@ static int gen_score(const bmh_ext_params_t &p, int w_, int64_t l_pac, const uin
 	int w = (max_gap + diff + 1) >> 1;
 	w = w < w_ ? w : w_;
 	w = w > diff + 3 ? w : diff + 3;
-	g_st_dp_calls++; g_st_dp_cells += (unsigned long long)rlen * (unsigned long long)((2 * w + 1) < l_query ? 2 * w + 1 : l_query);
+	if (g_post_stats) g_st_dp_calls++, g_st_dp_cells += (unsigned long long)rlen * (unsigned long long)((2 * w + 1) < l_query ? 2 * w + 1 : l_query);
 	return global_score(p, l_query, qs.data(), rlen, rs.data(), w);
 }
 
@@ -108,7 +109,7 @@ static int patch_reg(const Ctx &x, const uint8_t *query, const Reg &a, const Reg
 	else if (w > x.co->w << 2 || r >= 0.05f * 2) return 0;
 	w += a.w + b.w;
 	w = w < x.co->w << 2 ? w : x.co->w << 2;
-	g_st_patch_calls++;
+	if (g_post_stats) g_st_patch_calls++;
 	const int score = gen_score(*x.ep, w, x.l_pac, x.pac, b.qe - a.qb, query + a.qb, a.rb, b.re);
 	const int q_s = (int)((double)(b.qe - a.qb) / ((b.qe - b.qb) + (a.qe - a.qb)) * (b.score + a.score) + .499);
 	const int r_s = (int)((double)(b.re - a.rb) / ((b.re - b.rb) + (a.re - a.rb)) * (b.score + a.score) + .499);

@@ -216,8 +216,13 @@ int bmh_extend_set_packed(int on);
 
 /* bmh_extend_batch keeps scratch (the sorted job list, four side streams, events) per (device, stream) and reuses it across calls.
  * Call this before destroying a stream that ran extensions (stream idle, its device current); without it the entry stays until the
- * process ends and a recycled stream handle would inherit it.  One stream must not run extensions from two host threads at once. */
+ * process ends and a recycled stream handle would inherit it.  One stream must not run extensions from two host threads at once.
+ * bmh_finalize_regs_device and bmh_finalize_pairs_dev / bmh_matesw_batch_device keep scratch by the same rule (device buffers, side
+ * streams, events, pinned words per (device, stream); ONE host thread per stream at a time): bmh_finalize_release and
+ * bmh_matesw_release free theirs, and bmh_extend_release calls both. */
 void bmh_extend_release(void *stream);
+void bmh_finalize_release(void *stream);
+void bmh_matesw_release(void *stream);
 
 /* device time in ms of the DP kernels launched by the calling thread's last
  * bmh_extend_batch (HIP events on that call's stream; waits for them). */

@@ -972,6 +972,14 @@ def test_aligner_writes_reference_sam(hip, tmp_path, golden):
         cuts = [0, 50, min(700, n - 20), min(710, n - 10), n]
         parts = [bytes(al.align_batch(rs.slice(b, e), id0=b, as_bytes="view")) for b, e in zip(cuts[:-1], cuts[1:]) if e > b]
         assert b"".join(parts).decode() == want
+        # a batch the device tail refuses (BMH_ECAPACITY: a read beyond its fixed limits) takes the host tail instead of failing the run
+        os.environ["BMH_FIN_FORCE_ECAPACITY"] = "1"
+        try:
+            before = getattr(al, "host_tail_batches", 0)
+            assert bytes(al.align_batch(rs.slice(0, n), id0=0, as_bytes="view")).decode() == want
+            assert al.host_tail_batches == before + 1
+        finally:
+            del os.environ["BMH_FIN_FORCE_ECAPACITY"]
     al.close()
 
 

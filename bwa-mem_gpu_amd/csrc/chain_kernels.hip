@@ -95,8 +95,18 @@ __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 	else if (bin >= 0) A.light_list[(size_t)bin * A.n_reads + l_base[bin] + my] = r;
 }
 
-// one read per lane, the bins from the costliest down as one sequence
-template <bool FLT>
+// A lane's scratch as PRIVATE memory (CAP entries of every array): the hardware interleaves private memory dword by dword over the
+// lanes of a wave, so the 64 lanes' accesses to entry i of an array are consecutive addresses -- 256 bytes in one to four cache
+// lines -- where the per-read slices of the global scratch are 64 lines per wave instruction (round 2 measured 3.4 GB of the chain
+// family's 5.7 GB of HBM traffic there, for arrays nobody reads afterwards).  Only the regions (x.regs) leave the kernel.
+template <int CAP> struct ch_private_t {
+	ch_seed_t S[CAP]; ch_chain_t CH[CAP]; ch_est_t E[CAP]; int64_t opos[CAP]; uint64_t srt[CAP]; uint32_t order[CAP], klist[CAP], cidx[CAP];
+	__device__ __forceinline__ ch_scr_t scr() { ch_scr_t L; L.S = S; L.CH = CH; L.E = E; L.opos = opos; L.srt = srt; L.order = order; L.klist = klist; L.cidx = cidx; return L; }
+};
+
+// one read per lane, the bins from the costliest down as one sequence (CAP > 0: private scratch of CAP entries -- the caller makes sure
+// no read of the launch needs more; CAP == 0: the read's slice of the global scratch)
+template <bool FLT, int CAP>
 __global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A, const uint32_t skip_bins)
 {
 	uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -104,7 +114,10 @@ __global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A, const u
 	for (; bin >= 0; --bin) { const uint32_t c = (skip_bins >> bin & 1u) ? 0u : A.light_n[bin]; if (t < c) break; t -= c; }
 	if (bin < 0) return;
 	const uint32_t r = A.light_list[(size_t)bin * A.n_reads + t];
-	chain_core::chain_read<false, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
+	if (CAP > 0) {
+		ch_private_t<(CAP > 0 ? CAP : 1)> P;
+		chain_core::chain_read<false, false, FLT>(A.x, r, P.scr());
+	} else chain_core::chain_read<false, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
 }
 
 #define CH_LDS_BYTES_PER_ENTRY (8 + 8 + sizeof(ch_est_t) + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4 + 4 + 4)
@@ -138,13 +151,16 @@ __global__ void __launch_bounds__(64) chain_lane_lds_kernel(chain_args_t A, int 
 // reads) cost a lane a few milliseconds of dependent steps, too long for the lane kernel, whose waves would all wait for their one
 // such read -- but compacted into their own list they are 64 reads of similar cost per wave, a few hundred waves that leave the
 // CUs (and all of the LDS) to the wave kernels of the larger classes.  One wave per read, they took a third of the stage.
-template <bool FLT>
+template <bool FLT, int CAP>
 __global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, uint32_t cls)
 {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= A.heavy_n[cls]) return;
 	const uint32_t r = A.heavy_list[(size_t)cls * A.n_reads + i];
-	chain_core::chain_read<false, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
+	if (CAP > 0) {
+		ch_private_t<(CAP > 0 ? CAP : 1)> P;
+		chain_core::chain_read<false, false, FLT>(A.x, r, P.scr());
+	} else chain_core::chain_read<false, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
 }
 
 // one wave per heavy read of one size class (list filled by chain_classify_kernel), on a side stream beside chain_lane_kernel.
@@ -542,6 +558,12 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 	HIPCK(hipEventRecord(w->ev_fork, st));
 	HIPCK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
 	static const int lane_lds_env = [] { const char *e = getenv("BMH_CHAIN_LANE_LDS"); return e ? atoi(e) : 0; }();    // (experiment knob)
+	// lane forms with their scratch in private memory; BMH_CHAIN_LANE_PRIVATE bit 0: lane kernel, bit 1: lane-list kernel (A/B runs).  Measured on
+	// the bench workload (round 4): the lane kernel (reads of at most 8 entries, lanes nearly in step) 1.10 -> 0.74 ms and the step 29.1-29.7 ->
+	// 28.7 ms; the lane-list kernel (9..32 entries, 4.5 KB per lane) 4.2-4.5 -> 5.9-6.0 ms -- its lanes walk their arrays out of step, and
+	// in the interleaved layout the dwords of ONE lane's entry lie 256 bytes apart (a 24-byte seed is six lines), so it keeps the global slices
+	static const int lane_private_env = [] { const char *e = getenv("BMH_CHAIN_LANE_PRIVATE"); return e ? atoi(e) : 1; }();
+	const bool lane_private = (lane_private_env & 1) != 0, list_private = (lane_private_env & 2) != 0;
 	if (lane_lds_env && A.heavy_thresh <= 16u && !FLT) {                // the bins from the costliest down, each with the LDS its reads need
 		static const uint32_t grid_cap[CH_N_BINS] = {1u << 20, 1u << 20, 2048u, 1024u};
 		for (int bin = CH_N_BINS - 1; bin >= 0; --bin) {
@@ -555,9 +577,10 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 			default: chain_lane_lds_kernel<16><<<g, 64, 64 * CH_LANE_LDS_SLICE(16), st>>>(A, bin); break;
 			}
 		}
-		if ((lane_lds_env & 15) != 15) chain_lane_kernel<false><<<nblk(n_reads, 256), 256, 0, st>>>(A, (uint32_t)lane_lds_env);
-	} else
-	chain_lane_kernel<FLT><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
+		if ((lane_lds_env & 15) != 15) chain_lane_kernel<false, 0><<<nblk(n_reads, 256), 256, 0, st>>>(A, (uint32_t)lane_lds_env);
+	} else if (lane_private && !FLT && A.heavy_thresh <= 8u) chain_lane_kernel<FLT, 8><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
+	else if (lane_private && !FLT && A.heavy_thresh <= 16u) chain_lane_kernel<FLT, 16><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
+	else chain_lane_kernel<FLT, 0><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
 	HIPCK(hipEventRecord(w->ev_t[2], st));
 	HIPCK(hipEventRecord(w->ev_t[3], w->side));
 	const bool ctg_lds = w->n_contigs > 1 && w->n_contigs <= CH_LDS_CONTIGS;
@@ -567,7 +590,10 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 		const int hybrid = cls >= CH_HYBRID_CLASS && lds_cap != 0;
 		const size_t lds_bytes = (size_t)lds_cap * (hybrid ? CH_LDS_BYTES_PER_ENTRY_HYBRID : CH_LDS_BYTES_PER_ENTRY);
 		HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->ev_fork, 0));
-		if (cls == 0) chain_lane_list_kernel<FLT><<<nblk(n_reads, 256), 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls);     // (blocks beyond the list leave at once)
+		if (cls == 0) {                                                                                                   // (blocks beyond the list leave at once)
+			if (list_private && !FLT && A.lane_max <= 32u) chain_lane_list_kernel<FLT, 32><<<nblk(n_reads, 256), 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls);
+			else chain_lane_list_kernel<FLT, 0><<<nblk(n_reads, 256), 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls);
+		}
 		else if (ctg_lds) chain_wave_kernel<true, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
 		else chain_wave_kernel<false, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
 		HIPCK(hipEventRecord(w->cls_done[cls], w->cls_stream[cls]));

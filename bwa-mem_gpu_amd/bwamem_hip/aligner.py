@@ -7,7 +7,7 @@ threads as in the reference (bmh_finalize_regs), CIGAR / NM / MD on the GPU (bmh
 (bmh_format_sam).  It writes the records the reference writes, byte for byte (tests/test_gpu_parity.py).  torch is used
 for device memory only.  Interleaved pairs (gase_aln -p) go through bmh_finalize_pairs / bmh_format_sam_pe; their
 insert-size statistics are per batch as in the reference, so identical output needs the reference's batching (one batch
-here = batch_reads reads).  ALT contigs, read groups and FASTQ qualities are not handled.
+here = batch_reads reads).  ALT contigs come from <prefix>.alt as in the reference; read groups and FASTQ qualities are not handled.
 """
 from __future__ import annotations
 
@@ -37,6 +37,29 @@ def read_ann(prefix: str):
             _, ln, _ = f.readline().split()
             contigs.append((name, int(ln)))
     return contigs, int(l_pac)
+
+
+def read_alt(prefix: str, contigs) -> np.ndarray:
+    """is_alt per sequence from <prefix>.alt, the reference's way (bns_restore, src/bntseq.c:179-200): the first field of every line
+    that does not start with '@' names an ALT contig; names the index does not hold are ignored.  No file: no ALT contigs."""
+    alt = np.zeros(len(contigs), np.uint8)
+    path = prefix + ".alt"
+    if not os.path.exists(path):
+        return alt
+    where = {}
+    for i, c in enumerate(contigs):
+        where[c[0]] = i                                   # (kh_put keeps one entry per name; a later duplicate overwrites its value)
+    import re
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    for k, line in enumerate(lines):
+        parts = re.split(rb"[\t\r]", line, maxsplit=1)
+        if k == len(lines) - 1 and len(parts) == 1:
+            break                                         # (the reference completes a name at a tab, CR or LF: a bare name before EOF is never looked up)
+        tok = parts[0].decode("latin-1")
+        if tok and tok[0] != "@" and tok in where:
+            alt[where[tok]] = 1
+    return alt
 
 
 class ReadSet:
@@ -129,9 +152,12 @@ class Aligner:
         if _mem is not None:                                  # (index, contigs, packed reference) already in memory: from_memory()
             idx, self.contigs, self.pac = _mem
             self.l_pac = sum(c[1] for c in self.contigs)
+            self.alt = np.ascontiguousarray([1 if (len(c) > 2 and c[2]) else 0 for c in self.contigs], dtype=np.uint8)
+            self.contigs = [(c[0], c[1]) for c in self.contigs]
         else:
             idx = fmindex.read_index(prefix)
             self.contigs, self.l_pac = read_ann(prefix)
+            self.alt = read_alt(prefix, self.contigs)
             pac = np.fromfile(prefix + ".pac", dtype=np.uint8)
             self.pac = np.ascontiguousarray(np.concatenate([pac[: (self.l_pac + 3) // 4], np.zeros(2, np.uint8)]))
         self.index = Index.upload(idx, pac=self.pac, l_pac=self.l_pac)
@@ -141,6 +167,11 @@ class Aligner:
         self.ep = ExtParams.default()
         self.po = PostOpt(); self.L.bmh_post_opt_default(C.byref(self.po))
         self.pe = PeOpt(); self.L.bmh_pe_opt_default(C.byref(self.pe))
+        # ALT contigs (<prefix>.alt): the chain filter, the marking of primary hits, MAPQ, the XA / pa tags and the clipping depend on them
+        # (src/bwamem.c:446,518,571-574,702,714-760,1540,1663,1742,1755); the region tail of such an index runs on the host
+        self.has_alt = bool(self.alt.any())
+        if self.has_alt:
+            self.copt.contig_is_alt = self.alt.ctypes.data; self.po.contig_is_alt = self.alt.ctypes.data
         self.n_threads = n_threads or (os.cpu_count() or 1)
         self.profile = bool(os.environ.get("BMH_ALIGNER_PROFILE"))
         self.c_off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([c[1] for c in self.contigs])]), dtype=np.int64)
@@ -193,7 +224,7 @@ class Aligner:
             elif f == "-O": co.o_del, co.o_ins = pair(v); ep.o_del, ep.o_ins = co.o_del, co.o_ins
             elif f == "-E": co.e_del, co.e_ins = pair(v); ep.e_del, ep.e_ins = co.e_del, co.e_ins
             elif f == "-T": po.T = int(v)
-            elif f == "-h": po.max_XA_hits = pair(v)[0]
+            elif f == "-h": po.max_XA_hits, po.max_XA_hits_alt = pair(v)
             elif f == "-Q": po.mapQ_coef_len = float(int(v)); po.mapQ_coef_fac = int(math.log(int(v))) if int(v) > 0 else 0
             elif f == "-U": pe.pen_unpaired = int(v)
             elif f == "-m": pe.max_matesw = int(v)
@@ -272,7 +303,7 @@ class Aligner:
             cw.extend(out3, params=ext_p)
             cw.merge(out3, regs)
             _lap("extend+merge")
-            if not paired:
+            if not paired and not self.has_alt:
                 # single-end: the region tail runs on the device too (bmh_finalize_regs_device); what comes back over PCIe are the records
                 po = PostOpt.from_buffer_copy(self.po); po.id0 = id0
                 from .lib import CapacityError, finalize_regs_device
@@ -440,6 +471,8 @@ class Aligner:
         cw.set_materialize(False)
         if len(self.contigs) > 1:
             cw.set_contigs(self.contigs)
+            if self.has_alt:
+                cw.set_alt(self.alt)
         self._cw_cache = (cw, cn, cs)
         return cw
 

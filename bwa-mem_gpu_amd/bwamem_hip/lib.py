@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_finalize_regs_device", "bmh_finalize_regs_device_last_ms", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
     "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_finalize_pairs_dev", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
     "bmh_chain_opt_default", "bmh_chain_last_timing", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
-    "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_materialize", "bmh_chain_batch",
+    "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_alt", "bmh_chain_set_materialize", "bmh_chain_batch",
     "bmh_chain_extend", "bmh_chain_merge", "bmh_chain_extend_merge", "bmh_chain_extend_merge_timing", "bmh_cigar_batch",
     "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
     "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
@@ -94,14 +94,14 @@ class ExtParams(C.Structure):
 class ChainOpt(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "w", "min_seed_len", "max_occ",
                                        "max_chain_gap", "min_chain_weight", "max_chain_extend")] + \
-               [("mask_level", C.c_float), ("drop_ratio", C.c_float)]
+               [("mask_level", C.c_float), ("drop_ratio", C.c_float), ("contig_is_alt", C.c_void_p)]
 
 
 class PostOpt(C.Structure):
     """bmh_post_opt_t"""
     _fields_ = [("T", C.c_int), ("mask_level_redun", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int),
                 ("flag_all", C.c_int), ("id0", C.c_int64), ("XA_drop_ratio", C.c_float), ("max_XA_hits", C.c_int),
-                ("no_multi", C.c_int), ("softclip", C.c_int)]
+                ("no_multi", C.c_int), ("softclip", C.c_int), ("max_XA_hits_alt", C.c_int), ("contig_is_alt", C.c_void_p)]
 
 
 class PeOpt(C.Structure):
@@ -239,6 +239,8 @@ def load_library() -> C.CDLL:
     L.bmh_chain_ws_free.argtypes = [C.c_void_p]
     L.bmh_chain_set_contigs.restype = C.c_int
     L.bmh_chain_set_contigs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.bmh_chain_set_alt.restype = C.c_int
+    L.bmh_chain_set_alt.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.bmh_chain_batch.restype = C.c_int
     L.bmh_chain_batch.argtypes = [C.c_void_p, C.POINTER(ChainOpt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                   C.POINTER(SeedsT), C.c_void_p, C.POINTER(DevJobsT)]
@@ -388,6 +390,14 @@ class ChainWorkspace:
         rc = L.bmh_chain_set_contigs(self.handle, len(contigs), off.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p))
         if rc != 0:
             raise RuntimeError("bmh_chain_set_contigs: " + _err(L))
+
+    def set_alt(self, is_alt) -> None:
+        """is_alt: one flag per sequence of set_contigs' table (bmh_chain_set_alt; the .alt file of the index)"""
+        L = load_library()
+        a = np.ascontiguousarray(is_alt, dtype=np.uint8)
+        rc = L.bmh_chain_set_alt(self.handle, len(a), a.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError("bmh_chain_set_alt: " + _err(L))
 
     def chain_batch(self, index: Index, reads_t, offs_t, lens_t, seeds: SeedsT, stream: int = 0) -> DevJobsT:
         L = load_library()

@@ -40,6 +40,7 @@ struct ch_scr_t {
 struct ch_ctx_t {
 	bmh_chain_opt_t o;
 	int64_t l_pac; int n_contigs; const int64_t *ctg_off; const int32_t *ctg_len;
+	const uint8_t *ctg_alt;       // per sequence: is it an ALT contig (bns->anns[rid].is_alt, read from the .alt file, src/bntseq.c:179-200)?  null: none is
 	const uint64_t *rbeg; const int32_t *qbeg; const uint32_t *score, *n_ref, *prefix;   // mem_seed_v_gpu arrays
 	const uint32_t *read_lens;
 	// the seed filter (FLT forms of chain_read only): the reads (letters or nt4 codes, both are understood), their offsets, the 2-bit reference
@@ -54,6 +55,8 @@ struct ch_ctx_t {
 };
 
 #define CH_MAX_READ_LEN 700
+// tmp.is_alt of mem_chain (src/bwamem.c:446): a function of the chain's sequence
+CH_HD inline uint32_t chain_is_alt(const ch_ctx_t &x, int rid) { return (x.ctg_alt && rid >= 0 && x.ctg_alt[rid]) ? 1u : 0u; }
 
 // optional phase stamps (cycles) of one read, for tuning: compile with -DCH_PROFILE
 #if defined(CH_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -929,16 +932,17 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 	// seed-rich reads: span classes instead of a scan of the kept list per chain (srt is free between the sort and mem_chain2aln:
 	// its 8 bytes per entry hold the kept weights and the class links)
 #ifndef CH_NO_CLASSES
-	if (COOP && na > 48) kept_done = ch_kept_by_classes<LDSX>(o, CH, order, klist, (int32_t *)srt, (uint32_t *)srt + na, cidx, na, nk);
-	if (COOP && na > 48 && !kept_done) ch_wave_fence<LDSX>();
+	// (with ALT contigs whether two chains "overlap" also depends on which of them is ALT, src/bwamem.c:518: not a function of the spans alone)
+	if (COOP && na > 48 && !x.ctg_alt) kept_done = ch_kept_by_classes<LDSX>(o, CH, order, klist, (int32_t *)srt, (uint32_t *)srt + na, cidx, na, nk);
+	if (COOP && na > 48 && !x.ctg_alt && !kept_done) ch_wave_fence<LDSX>();
 #endif
 #endif
 	// kept chains: klist[k] = index in the sorted array, ks[k] = {beg, end, w, chain} so the scan reads one entry per k
 	// (E is not in use before mem_chain2aln and has room for it)
-	struct ks_t { int32_t beg, end, w; uint32_t chain; };
+	struct ks_t { int32_t beg, end, w; uint32_t chain; };                 // chain: index | is_alt << 31
 	ks_t *ks = (ks_t *)E;
 	if (!kept_done) {
-		{ const ch_chain_t c0 = CH[order[0]]; ks_t e; e.beg = c0.beg; e.end = c0.end; e.w = c0.w; e.chain = order[0]; ks[0] = e; }
+		{ const ch_chain_t c0 = CH[order[0]]; ks_t e; e.beg = c0.beg; e.end = c0.end; e.w = c0.w; e.chain = order[0] | chain_is_alt(x, c0.rid) << 31; ks[0] = e; }
 		CH[order[0]].kept = 3; klist[nk++] = 0;
 	}
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -947,12 +951,13 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 	for (int i = 1; i < na && !kept_done; ++i) {
 		const uint32_t ci = order[i];
 		const ch_chain_t ai = CH[ci];
+		const uint32_t ai_alt = chain_is_alt(x, ai.rid);
 		bool large_ovlp = false, broke = false;
 		auto test = [&](const ks_t &aj, bool &ovl, bool &brk) {
 			ovl = brk = false;
 			const int b_max = aj.beg > ai.beg ? aj.beg : ai.beg;
 			const int e_min = aj.end < ai.end ? aj.end : ai.end;
-			if (e_min > b_max) {
+			if (e_min > b_max && (!(aj.chain >> 31) || ai_alt)) {        // (an overlap where the kept chain is ALT and this one is not does not count, :518)
 				const int li = ai.end - ai.beg, lj = aj.end - aj.beg;
 				const int min_l = li < lj ? li : lj;
 				if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap) {
@@ -983,7 +988,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 					if (broke) break;
 					unsigned long long vm = ~0ull;
 					if (mb[u]) { const int f = (int)__builtin_ctzll(mb[u]); vm = f == 63 ? ~0ull : ((1ull << (f + 1)) - 1); broke = true; }
-					if (ovl[u] && ((vm >> lane) & 1)) { ch_chain_t &cj = CH[aj[u].chain]; if (cj.first < 0) cj.first = i; }
+					if (ovl[u] && ((vm >> lane) & 1)) { ch_chain_t &cj = CH[aj[u].chain & 0x7FFFFFFFu]; if (cj.first < 0) cj.first = i; }
 					if (mo[u] & vm) large_ovlp = true;
 				}
 			}
@@ -994,12 +999,12 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 				bool ovl, brk;
 				const ks_t aj = ks[k];
 				test(aj, ovl, brk);
-				if (ovl) { large_ovlp = true; ch_chain_t &cj = CH[aj.chain]; if (cj.first < 0) cj.first = i; }
+				if (ovl) { large_ovlp = true; ch_chain_t &cj = CH[aj.chain & 0x7FFFFFFFu]; if (cj.first < 0) cj.first = i; }
 				if (brk) { broke = true; break; }
 			}
 		}
 		if (!broke) {
-			ks_t e; e.beg = ai.beg; e.end = ai.end; e.w = ai.w; e.chain = ci; ks[nk] = e;
+			ks_t e; e.beg = ai.beg; e.end = ai.end; e.w = ai.w; e.chain = ci | ai_alt << 31; ks[nk] = e;
 			klist[nk++] = (uint32_t)i; CH[ci].kept = large_ovlp ? 2 : 3;
 		}
 #if defined(__HIP_DEVICE_COMPILE__)

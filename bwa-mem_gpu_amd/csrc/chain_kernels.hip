@@ -373,7 +373,7 @@ struct bmh_chain_ws {
 	uint32_t *regs_per_read, *jobs_per_read, *reg_off, *job_off, *heavy_list, *need; float *frac_rep;
 	uint32_t *counters;            // [0..CH_N_CLASSES) heavy_n per size class  [CH_N_CLASSES] err  [12..32) profile stamps  [32..36) reads per need bin of the lane kernel  [36] longest read
 	// contigs
-	int n_contigs; int64_t *ctg_off; int32_t *ctg_len;
+	int n_contigs; int64_t *ctg_off; int32_t *ctg_len; uint8_t *ctg_alt;
 	// outputs, grown on demand
 	uint64_t cap_regs, cap_jobs, cap_q, cap_t;
 	ch_outreg_t *outregs;
@@ -400,7 +400,7 @@ extern "C" void bmh_chain_ws_free(bmh_chain_ws_t *w)
 {
 	if (!w) return;
 	void *ps[] = {w->seeds, w->chains, w->order, w->opos, w->klist, w->srt, w->cidx, w->regs, w->est, w->regs_per_read, w->jobs_per_read, w->reg_off,
-	              w->job_off, w->heavy_list, w->need, w->frac_rep, w->counters, w->ctg_off, w->ctg_len, w->outregs, w->qlen, w->tlen, w->h0, w->job_read, w->job_reg,
+	              w->job_off, w->heavy_list, w->need, w->frac_rep, w->counters, w->ctg_off, w->ctg_len, w->ctg_alt, w->outregs, w->qlen, w->tlen, w->h0, w->job_read, w->job_reg,
 	              w->job_side, w->jq_src, w->qoff, w->toff, w->jt0, w->qoff64, w->toff64, w->q, w->t, w->scan_tmp};
 	for (void *p : ps) if (p) (void)hipFree(p);
 	if (w->h_pin) (void)hipHostFree(w->h_pin);
@@ -484,12 +484,28 @@ extern "C" int bmh_chain_set_contigs(bmh_chain_ws_t *w, int n_contigs, const int
 	if (!w) { bmh_set_error("bmh_chain_set_contigs: null workspace"); return BMH_EINVAL; }
 	if (w->ctg_off) { (void)hipFree(w->ctg_off); w->ctg_off = nullptr; }
 	if (w->ctg_len) { (void)hipFree(w->ctg_len); w->ctg_len = nullptr; }
+	if (w->ctg_alt) { (void)hipFree(w->ctg_alt); w->ctg_alt = nullptr; }            // (a new table: its ALT flags are set again, bmh_chain_set_alt)
 	w->n_contigs = n_contigs > 1 ? n_contigs : 1;
 	if (n_contigs <= 1) return BMH_OK;
 	if (!offset || !len) { bmh_set_error("bmh_chain_set_contigs: null arrays"); return BMH_EINVAL; }
 	HIPCK(hipMalloc((void **)&w->ctg_off, 8 * (size_t)n_contigs)); HIPCK(hipMalloc((void **)&w->ctg_len, 4 * (size_t)n_contigs));
 	HIPCK(hipMemcpy(w->ctg_off, offset, 8 * (size_t)n_contigs, hipMemcpyHostToDevice));
 	HIPCK(hipMemcpy(w->ctg_len, len, 4 * (size_t)n_contigs, hipMemcpyHostToDevice));
+	return BMH_OK;
+}
+
+// which sequences of the table are ALT contigs (the .alt file, src/bntseq.c:179-200): mem_chain_flt treats an overlap with a kept ALT
+// chain differently (src/bwamem.c:518).  is_alt[n_contigs], n_contigs as in bmh_chain_set_contigs; null or all zero: none.
+extern "C" int bmh_chain_set_alt(bmh_chain_ws_t *w, int n_contigs, const uint8_t *is_alt)
+{
+	if (!w) { bmh_set_error("bmh_chain_set_alt: null workspace"); return BMH_EINVAL; }
+	if (w->ctg_alt) { (void)hipFree(w->ctg_alt); w->ctg_alt = nullptr; }
+	bool any = false;
+	for (int c = 0; is_alt && c < n_contigs; ++c) any = any || is_alt[c] != 0;
+	if (!any) return BMH_OK;
+	if (n_contigs != w->n_contigs) { bmh_set_error("bmh_chain_set_alt: %d flags for a table of %d sequences (bmh_chain_set_contigs first)", n_contigs, w->n_contigs); return BMH_EINVAL; }
+	HIPCK(hipMalloc((void **)&w->ctg_alt, (size_t)n_contigs));
+	HIPCK(hipMemcpy(w->ctg_alt, is_alt, (size_t)n_contigs, hipMemcpyHostToDevice));
 	return BMH_OK;
 }
 
@@ -516,7 +532,7 @@ static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_op
 	memset(&A, 0, sizeof(A));
 	A.x.reads = d_reads; A.x.read_offs = d_offs; A.x.pac = idx->dev.pac;
 	w->last_opt = *opt;
-	A.x.o = *opt; A.x.l_pac = (int64_t)idx->dev.l_pac; A.x.n_contigs = w->n_contigs; A.x.ctg_off = w->ctg_off; A.x.ctg_len = w->ctg_len;
+	A.x.o = *opt; A.x.l_pac = (int64_t)idx->dev.l_pac; A.x.n_contigs = w->n_contigs; A.x.ctg_off = w->ctg_off; A.x.ctg_len = w->ctg_len; A.x.ctg_alt = w->ctg_alt;
 	A.x.rbeg = seeds->d_rbeg; A.x.qbeg = seeds->d_qbeg; A.x.score = seeds->d_score; A.x.n_ref = seeds->d_n_ref_pos; A.x.prefix = seeds->d_prefix;
 	A.x.read_lens = d_lens;
 	A.x.g.S = w->seeds; A.x.g.CH = w->chains; A.x.g.order = w->order; A.x.g.opos = w->opos; A.x.g.klist = w->klist; A.x.g.srt = w->srt; A.x.g.cidx = w->cidx;

@@ -230,7 +230,7 @@ void make_chains(const Ctx &x, uint32_t r, int len, std::vector<Chain> &out)    
 				else { --it; if (!test_and_merge(o, x.ctg.l_pac, pool[it->second], s, rid)) to_add = true; }
 			} else to_add = true;
 			if (to_add) {
-				Chain c; c.pos = s.rbeg; c.rid = rid; c.is_alt = false; c.seeds.push_back(s);
+				Chain c; c.pos = s.rbeg; c.rid = rid; c.is_alt = o.contig_is_alt && o.contig_is_alt[rid]; c.seeds.push_back(s);      // tmp.is_alt = !!bns->anns[rid].is_alt (src/bwamem.c:446)
 				pool.push_back(std::move(c));
 				tree.emplace(s.rbeg, pool.size() - 1);
 			}

@@ -305,11 +305,11 @@ void select_se(const PCtx &c, ReadOut &o, int extra)
 		const Reg &p = o.regs[k];
 		int mapq = p.secondary < 0 ? approx_mapq(c.x, p) : 0, flag = p.secondary >= 0 ? 0x100 : 0, rep = 1;
 		if (p.score < c.x.po->T) rep = 0;
-		else if (p.secondary >= 0 && !c.x.po->flag_all) rep = 0;
-		else if (p.secondary >= 0 && p.score < o.regs[p.secondary].score * c.x.co->drop_ratio) rep = 0;
+		else if (p.secondary >= 0 && (p.is_alt || !c.x.po->flag_all)) rep = 0;                                    // src/bwamem.c:1742
+		else if (p.secondary >= 0 && p.secondary < INT32_MAX && p.score < o.regs[p.secondary].score * c.x.co->drop_ratio) rep = 0;
 		if (rep) {
 			if (l && p.secondary < 0) flag |= c.x.po->no_multi ? 0x10000 : 0x800;
-			if (l && mapq > mapq0) mapq = mapq0;
+			if (l && !p.is_alt && mapq > mapq0) mapq = mapq0;                                                        // :1755
 			if (l == 0) mapq0 = mapq;
 			++l;
 			flag |= extra;
@@ -333,8 +333,8 @@ int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // 
 				matesw(c, b[i][j], l_seq[!i], seq[!i], *a[!i], SwKey{(uint32_t)(r0 >> 1), (uint16_t)j, (uint8_t)i, 0}, r0 + (uint32_t)!i);
 	}
 	if (c.sw_mode == 1) return 0;
-	for (int i = 0; i < 2; ++i) { mark_primary(c.x, (int)a[i]->size(), a[i]->data(), (int64_t)(id << 1 | (uint64_t)i)); n_pri[i] = (int)a[i]->size(); }
-	for (int i = 0; i < 2; ++i) { out[i].sec_all.resize(a[i]->size()); for (size_t j = 0; j < a[i]->size(); ++j) out[i].sec_all[j] = (*a[i])[j].secondary; }
+	for (int i = 0; i < 2; ++i) n_pri[i] = mark_primary(c.x, (int)a[i]->size(), a[i]->data(), (int64_t)(id << 1 | (uint64_t)i));
+	for (int i = 0; i < 2; ++i) { out[i].sec_all.resize(a[i]->size()); for (size_t j = 0; j < a[i]->size(); ++j) out[i].sec_all[j] = (*a[i])[j].secondary_all; }
 	bool paired = false;
 	if (!c.pe->no_pairing && n_pri[0] && n_pri[1]) {        // src/bwamem_pair.c:287
 		o = pair_regs(c, a, (int)id, &subo, &n_sub, z, n_pri);
@@ -384,6 +384,13 @@ int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // 
 					out[i].rep[z[i]] = 1; out[i].mapq[z[i]] = q_se[i];
 					out[i].flag[z[i]] = ((*a[i])[z[i]].secondary >= 0 ? 0x100 : 0) | 0x40 << i | extra_flag;
 					out[i].h = z[i];
+					if (n_pri[i] < n) {                          // the read has ALT hits: the best of them is written as a supplementary record (src/bwamem_pair.c:349-356)
+						const Reg &p = (*a[i])[n_pri[i]];
+						if (!(p.score < c.x.po->T || p.secondary >= 0 || !p.is_alt)) {
+							out[i].rep[n_pri[i]] = 1; out[i].mapq[n_pri[i]] = approx_mapq(c.x, p);
+							out[i].flag[n_pri[i]] = 0x800 | 0x40 << i | extra_flag;
+						}
+					}
 				}
 			}
 		}
@@ -446,6 +453,7 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 			Reg *a = flat + in_off[r];
 			for (int i = 0; i < n_in; ++i) reg_from_record(c.x, regs_in + 8 * (in_off[r] + i), frac_rep ? frac_rep[r] : 0.f, a[i]);
 			cnt[r] = (uint32_t)sort_dedup_patch(c.x, reads + read_offs[r], n_in, a);
+			set_is_alt(c.x, (int)cnt[r], a);                            // src/bwamem.c:2321-2325
 		}
 	}, n_reads);
 	const double t_b = now();
@@ -504,9 +512,10 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 					q[0] = (int32_t)r; q[1] = g.score; q[2] = g.qb; q[3] = g.qe;
 					q[4] = (int32_t)(uint32_t)g.rb; q[5] = (int32_t)(g.rb >> 32); q[6] = (int32_t)(uint32_t)g.re; q[7] = (int32_t)(g.re >> 32);
 					q[8] = g.truesc; q[9] = g.w;            /* 0 / 0 for a rescued region (src/bwamem_pair.c:161: memset) */
-					q[10] = g.sub > g.csub ? g.sub : g.csub; q[11] = g.sub_n;
+					q[10] = g.sub > g.csub ? g.sub : g.csub;
 					q[12] = o.sec_all.empty() ? g.secondary : o.sec_all[k];
-					q[13] = o.mapq[k]; q[14] = o.flag[k]; q[15] = o.rep[k];
+					q[11] = alt_mode(c.x) ? q[12] : g.sub_n;
+					q[13] = o.mapq[k]; q[14] = o.flag[k]; q[15] = o.rep[k] | (g.is_alt ? 2 : 0) | (g.alt_sc > 0 ? g.alt_sc << 2 : 0);
 					any = any || o.rep[k];
 				}
 				P.n.push_back((uint32_t)o.regs.size()); P.h.push_back(o.h);

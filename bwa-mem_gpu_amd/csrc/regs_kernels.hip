@@ -650,6 +650,11 @@ extern "C" int64_t bmh_finalize_regs_device(const bmh_index_t *idx, const bmh_ch
 	if (n_contigs > 1 && !contig_offset) { bmh_set_error("bmh_finalize_regs_device: null contig table"); return BMH_EINVAL; }
 	if (n_regs >> 31) { bmh_set_error("bmh_finalize_regs_device: 2^31 regions or more in one batch"); return BMH_ECAPACITY; }
 	if (n_reads == 0) return 0;
+	if (popt->contig_is_alt) {
+		// ALT contigs (a second marking round over the primary assembly's hits, secondary_all, alt_sc: src/bwamem.c:714-760) are the host tail's
+		bmh_set_error("bmh_finalize_regs_device: ALT contigs are not modelled on the device: this batch belongs to bmh_finalize_regs");
+		return BMH_ECAPACITY;
+	}
 	if (getenv("BMH_FIN_FORCE_ECAPACITY")) { bmh_set_error("bmh_finalize_regs_device: capacity error forced by BMH_FIN_FORCE_ECAPACITY (test hook of the callers' host fallback)"); return BMH_ECAPACITY; }
 	hipStream_t st = (hipStream_t)stream_;
 	int dev = 0;

@@ -169,17 +169,19 @@ uint64_t hash64(uint64_t key)
 	return key;
 }
 
-void mark_primary(const Ctx &x, int n, Reg *a, int64_t id)        // mem_mark_primary_se (no ALT contigs: n_pri == n)
+void set_is_alt(const Ctx &x, int n, Reg *a)
 {
-	if (n == 0) return;
-	for (int i = 0; i < n; ++i) { a[i].sub = 0; a[i].secondary = -1; a[i].hash = hash64((uint64_t)(id + i)); }
-	klib::klib_introsort((size_t)n, a, [](const Reg &p, const Reg &q) {
-		return p.score > q.score || (p.score == q.score && (p.is_alt < q.is_alt || (p.is_alt == q.is_alt && p.hash < q.hash)));
-	});
+	const uint8_t *alt = x.po->contig_is_alt;
+	for (int i = 0; i < n; ++i) a[i].is_alt = (alt && a[i].rid >= 0 && alt[a[i].rid]) ? 1 : 0;
+}
+
+// mem_mark_primary_se_core, src/bwamem.c:685-712 (sub_n is NOT reset between the two rounds of mem_mark_primary_se: it adds up, as there)
+static void mark_primary_core(const Ctx &x, int n, Reg *a, std::vector<int> &z)
+{
 	int tmp = x.ep->a + x.ep->b;
 	tmp = x.ep->o_del + x.ep->e_del > tmp ? x.ep->o_del + x.ep->e_del : tmp;
 	tmp = x.ep->o_ins + x.ep->e_ins > tmp ? x.ep->o_ins + x.ep->e_ins : tmp;
-	std::vector<int> z;
+	z.clear();
 	z.push_back(0);
 	for (int i = 1; i < n; ++i) {
 		size_t k;
@@ -199,6 +201,47 @@ void mark_primary(const Ctx &x, int n, Reg *a, int64_t id)        // mem_mark_pr
 		if (k == z.size()) z.push_back(i);
 		else a[i].secondary = z[k];
 	}
+}
+
+int mark_primary(const Ctx &x, int n, Reg *a, int64_t id)        // mem_mark_primary_se, src/bwamem.c:714-760
+{
+	if (n == 0) return 0;
+	int n_pri = 0;
+	for (int i = 0; i < n; ++i) {
+		a[i].sub = a[i].alt_sc = 0; a[i].secondary = a[i].secondary_all = -1; a[i].hash = hash64((uint64_t)(id + i));
+		if (!a[i].is_alt) ++n_pri;
+	}
+	klib::klib_introsort((size_t)n, a, [](const Reg &p, const Reg &q) {           // alnreg_hlt
+		return p.score > q.score || (p.score == q.score && (p.is_alt < q.is_alt || (p.is_alt == q.is_alt && p.hash < q.hash)));
+	});
+	std::vector<int> z;
+	mark_primary_core(x, n, a, z);
+	for (int i = 0; i < n; ++i) {
+		Reg *p = &a[i];
+		p->secondary_all = i;                                                      // keep the rank of the first round
+		if (!p->is_alt && p->secondary >= 0 && a[p->secondary].is_alt) p->alt_sc = a[p->secondary].score;
+	}
+	if (n_pri >= 0 && n_pri < n) {                                                // there are ALT hits
+		z.assign((size_t)n, 0);
+		if (n_pri > 0)
+			klib::klib_introsort((size_t)n, a, [](const Reg &p, const Reg &q) {     // alnreg_hlt2: the primary assembly first
+				return p.is_alt < q.is_alt || (p.is_alt == q.is_alt && (p.score > q.score || (p.score == q.score && p.hash < q.hash)));
+			});
+		for (int i = 0; i < n; ++i) z[(size_t)a[i].secondary_all] = i;
+		for (int i = 0; i < n; ++i) {
+			if (a[i].secondary >= 0) {
+				a[i].secondary_all = z[(size_t)a[i].secondary];
+				if (a[i].is_alt) a[i].secondary = INT32_MAX;
+			} else a[i].secondary_all = -1;
+		}
+		if (n_pri > 0) {                                                            // mark primary for hits to the primary assembly only
+			for (int i = 0; i < n_pri; ++i) { a[i].sub = 0; a[i].secondary = -1; }
+			mark_primary_core(x, n_pri, a, z);
+		}
+	} else {
+		for (int i = 0; i < n; ++i) a[i].secondary_all = a[i].secondary;
+	}
+	return n_pri;
 }
 
 int approx_mapq(const Ctx &x, const Reg &a)        // mem_approx_mapq_se, mapQ_coef_len > 0 form
@@ -238,7 +281,7 @@ extern "C" void bmh_post_opt_default(bmh_post_opt_t *o)        // mem_opt_init, 
 {
 	memset(o, 0, sizeof(*o));
 	o->T = 30; o->mask_level_redun = 0.95f; o->mapQ_coef_len = 50.f; o->mapQ_coef_fac = (int)log(50.f); o->flag_all = 0; o->id0 = 0;
-	o->XA_drop_ratio = 0.80f; o->max_XA_hits = 5;
+	o->XA_drop_ratio = 0.80f; o->max_XA_hits = 5; o->max_XA_hits_alt = 200; o->contig_is_alt = nullptr;
 }
 
 // regs_in[n][8] = {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi} grouped by read (regs_per_read); frac_rep per read.
@@ -268,7 +311,9 @@ extern "C" int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_
 				reg_from_record(x, regs_in + 8 * (in_off[r] + i), frac_rep ? frac_rep[r] : 0.f, a[i]);
 			}
 			int n = sort_dedup_patch(x, reads + read_offs[r], n_in, a.data());
+			set_is_alt(x, n, a.data());
 			mark_primary(x, n, a.data(), popt->id0 + r);
+			const bool altm = alt_mode(x);
 			// mem_reg2sam: which regions are reported, supplementary flag, MAPQ cap
 			int32_t *o = out + 16 * in_off[r];
 			int l = 0, mapq0 = 0;
@@ -277,18 +322,18 @@ extern "C" int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_
 				int32_t *q = o + 16 * k;
 				q[0] = (int32_t)r; q[1] = p.score; q[2] = p.qb; q[3] = p.qe;
 				q[4] = (int32_t)(uint32_t)p.rb; q[5] = (int32_t)(p.rb >> 32); q[6] = (int32_t)(uint32_t)p.re; q[7] = (int32_t)(p.re >> 32);
-				q[8] = p.truesc; q[9] = p.w; q[10] = p.sub > p.csub ? p.sub : p.csub; q[11] = p.sub_n; q[12] = p.secondary;
+				q[8] = p.truesc; q[9] = p.w; q[10] = p.sub > p.csub ? p.sub : p.csub; q[11] = altm ? p.secondary_all : p.sub_n; q[12] = p.secondary;
 				int mapq = p.secondary < 0 ? approx_mapq(x, p) : 0, flag = p.secondary >= 0 ? 0x100 : 0, rep = 1;
 				if (p.score < popt->T) rep = 0;
-				else if (p.secondary >= 0 && !popt->flag_all) rep = 0;
-				else if (p.secondary >= 0 && p.score < a[p.secondary].score * copt->drop_ratio) rep = 0;
+				else if (p.secondary >= 0 && (p.is_alt || !popt->flag_all)) rep = 0;                        // src/bwamem.c:1742
+				else if (p.secondary >= 0 && p.secondary < INT32_MAX && p.score < a[p.secondary].score * copt->drop_ratio) rep = 0;
 				if (rep) {
 					if (l && p.secondary < 0) flag |= popt->no_multi ? 0x10000 : 0x800;     // src/bwamem.c:1754
-					if (l && mapq > mapq0) mapq = mapq0;
+					if (l && !p.is_alt && mapq > mapq0) mapq = mapq0;                        // :1755
 					if (l == 0) mapq0 = mapq;
 					++l;
 				}
-				q[13] = mapq; q[14] = flag; q[15] = rep;
+				q[13] = mapq; q[14] = flag; q[15] = rep | (p.is_alt ? 2 : 0) | (p.alt_sc > 0 ? p.alt_sc << 2 : 0);
 			}
 			out_per_read[r] = (uint32_t)n;
 		}

@@ -83,16 +83,19 @@ extern "C" int64_t bmh_sam_need_cigar(const bmh_post_opt_t *po, const int32_t *f
 {
 	if (!po || !fin_per_read || !need || (n_reads && !fin)) { bmh_set_error("bmh_sam_need_cigar: null argument"); return BMH_EINVAL; }
 	int64_t total = 0; uint64_t base = 0;
-	std::vector<int> cnt;
+	std::vector<int> cnt, has_alt;
 	for (uint32_t r = 0; r < n_reads; ++r) {
 		const int n = (int)fin_per_read[r];
 		const int32_t *a = fin + 16 * base;
 		cnt.assign(n, 0);
-		for (int i = 0; i < n; ++i) need[base + i] = a[16 * i + 15] ? 1 : 0;
+		for (int i = 0; i < n; ++i) need[base + i] = (a[16 * i + 15] & 1) ? 1 : 0;
 		if (!po->flag_all) {
-			auto pri = [&](int i) { const int k = a[16 * i + 12]; return (k >= 0 && a[16 * i + 1] >= a[16 * k + 1] * (double)po->XA_drop_ratio) ? k : -1; };
-			for (int i = 0; i < n; ++i) { const int k = pri(i); if (k >= 0) ++cnt[k]; }
-			for (int i = 0; i < n; ++i) { const int k = pri(i); if (k >= 0 && cnt[k] <= po->max_XA_hits) need[base + i] = 1; }
+			// (with ALT contigs a record keeps secondary_all, the XA tag's key, in [11]: see bmh_post_opt_t)
+			const int sa = po->contig_is_alt ? 11 : 12;
+			auto pri = [&](int i) { const int k = a[16 * i + sa]; return (k >= 0 && a[16 * i + 1] >= a[16 * k + 1] * (double)po->XA_drop_ratio) ? k : -1; };
+			has_alt.assign(n, 0);
+			for (int i = 0; i < n; ++i) { const int k = pri(i); if (k >= 0) { ++cnt[k]; if (a[16 * i + 15] & 2) has_alt[k] = 1; } }
+			for (int i = 0; i < n; ++i) { const int k = pri(i); if (k >= 0 && !(cnt[k] > po->max_XA_hits_alt || (!has_alt[k] && cnt[k] > po->max_XA_hits))) need[base + i] = 1; }
 		}
 		for (int i = 0; i < n; ++i) total += need[base + i];
 		base += n;
@@ -129,7 +132,7 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 	std::string &out = parts[t];
 	const uint32_t r_lo = (uint32_t)((uint64_t)n_reads * t / n_thr), r_hi = (uint32_t)((uint64_t)n_reads * (t + 1) / n_thr);
 	out.reserve((size_t)(r_hi - r_lo) * 400);
-	std::vector<int> cnt, list;
+	std::vector<int> cnt, list, has_alt;
 	std::vector<std::string> xa;
 	for (uint32_t r = r_lo; r < r_hi; ++r) {
 		const uint64_t base = bases[r];
@@ -150,12 +153,13 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 		if ((int)xa.size() < n) xa.resize(n);
 		for (int i = 0; i < n; ++i) xa[i].clear();                  // (capacity kept: no allocation per read)
 		if (!po->flag_all) {
-			cnt.assign(n, 0);
-			auto pri = [&](int i) { const int k = a[16 * i + 12]; return (k >= 0 && a[16 * i + 1] >= a[16 * k + 1] * (double)po->XA_drop_ratio) ? k : -1; };
-			for (int i = 0; i < n; ++i) { const int k = pri(i); if (k >= 0) ++cnt[k]; }
+			cnt.assign(n, 0); has_alt.assign(n, 0);
+			const int sa = po->contig_is_alt ? 11 : 12;
+			auto pri = [&](int i) { const int k = a[16 * i + sa]; return (k >= 0 && a[16 * i + 1] >= a[16 * k + 1] * (double)po->XA_drop_ratio) ? k : -1; };
+			for (int i = 0; i < n; ++i) { const int k = pri(i); if (k >= 0) { ++cnt[k]; if (a[16 * i + 15] & 2) has_alt[k] = 1; } }
 			for (int i = 0; i < n; ++i) {
 				const int k = pri(i);
-				if (k < 0 || cnt[k] > po->max_XA_hits) continue;
+				if (k < 0 || cnt[k] > po->max_XA_hits_alt || (!has_alt[k] && cnt[k] > po->max_XA_hits)) continue;       // src/bwamem_extra.c:125
 				const Rec x = rec(i);
 				if (!x.aln) { bmh_set_error("bmh_format_sam: record %d of read %u has no CIGAR (see bmh_sam_need_cigar)", i, r); failed[t] = 1; return; }
 				const long long pos = aln_pos(x.aln);
@@ -167,7 +171,7 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 			}
 		}
 		list.clear();
-		for (int i = 0; i < n; ++i) if (a[16 * i + 15]) list.push_back(i);
+		for (int i = 0; i < n; ++i) if (a[16 * i + 15] & 1) list.push_back(i);
 		const uint8_t *seq = reads + read_offs[r];
 		const int l_seq = (int)read_lens[r];
 		auto mate_fields = [&](int p_rid, long long p_pos, int p_rev, int p_ncig, const uint32_t *p_cig, bool mate_mapped, int m_rid, long long m_pos, int m_rev,
@@ -209,7 +213,7 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 			const int m_rid = mate_mapped ? m.rid : rid; const long long m_pos = mate_mapped ? m.pos : pos; const int m_rev = mate_mapped ? m.is_rev : (x.aln[2] ? 1 : 0);
 			int flag = (x.aln[2] ? 0x10 : 0) | x.fin[14];
 			if (pe) { if (m.rid < 0) flag |= 8; if (m_rev) flag |= 0x20; }
-			const bool hard = which > 0 && !po->softclip;      // src/bwamem.c:1540,1578
+			const bool hard = which > 0 && !po->softclip && !(x.fin[15] & 2);      // src/bwamem.c:1540,1578 (never on an ALT hit)
 			out += names + name_off[r]; out += '\t'; put_int(out, (flag & 0xffff) | (flag & 0x10000 ? 0x100 : 0)); out += '\t';
 			out += contig_names[rid]; out += '\t'; put_int(out, pos - (n_contigs > 1 ? contig_offset[rid] : 0) + 1); out += '\t';
 			put_int(out, x.fin[13]); out += '\t';
@@ -247,6 +251,9 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 						out += ','; put_int(out, y.fin[13]); out += ','; put_int(out, y.aln[4]); out += ';';
 					}
 				}
+			}
+			if (!(flag & 0x100) && (x.fin[15] >> 2) > 0) {       // pa:f:<score / score of the ALT hit that shadows it> (src/bwamem.c:1663)
+				char buf[48]; snprintf(buf, sizeof(buf), "\tpa:f:%.3f", (double)x.fin[1] / (double)(x.fin[15] >> 2)); out += buf;
 			}
 			if (!xa[i].empty()) { out += "\tXA:Z:"; out += xa[i]; }
 			out += '\n';

@@ -236,6 +236,10 @@ typedef struct {
 	int a, b, o_del, e_del, o_ins, e_ins, w;
 	int min_seed_len, max_occ, max_chain_gap, min_chain_weight, max_chain_extend;
 	float mask_level, drop_ratio;
+	/* ALT contigs (the reference reads <prefix>.alt, src/bntseq.c:179-200; bns->anns[rid].is_alt): contig_is_alt[n_contigs] in HOST
+	 * memory, NULL = none.  Read by bmh_build_jobs (mem_chain_flt ignores an overlap whose kept chain is ALT while the current one is
+	 * not, src/bwamem.c:518); the device job builder takes the flags through bmh_chain_set_alt instead. */
+	const uint8_t *contig_is_alt;
 } bmh_chain_opt_t;
 void bmh_chain_opt_default(bmh_chain_opt_t *o);
 
@@ -283,6 +287,13 @@ typedef struct {
 	int max_XA_hits;            /* 5: ... when there are no more than this many */
 	int no_multi;               /* MEM_F_NO_MULTI (-M): shorter split hits are flagged secondary (0x100) instead of supplementary */
 	int softclip;               /* MEM_F_SOFTCLIP (-Y): soft clips on every record (no hard clips on the later ones) */
+	int max_XA_hits_alt;        /* 200: ... or this many when one of them lies on an ALT contig (-h INT,INT) */
+	/* ALT contigs: contig_is_alt[n_contigs] in HOST memory, NULL = none (src/bwamem.c:571-574,702,721-760,1540,1578,1663,1742,1755,
+	 * 2323; src/bwamem_extra.c:106-150).  With a table that flags at least one sequence the records change in two places:
+	 * [11] holds secondary_all (the parent of the FIRST marking round over all hits, which the XA tag goes by) instead of sub_n, and
+	 * [15] = reported | is_alt << 1 | alt_sc << 2 ([12] secondary is INT_MAX for an ALT hit that has a parent, as in the reference).
+	 * Host tail only: bmh_finalize_regs_device answers BMH_ECAPACITY for such a table and the caller takes bmh_finalize_regs. */
+	const uint8_t *contig_is_alt;
 } bmh_post_opt_t;
 void bmh_post_opt_default(bmh_post_opt_t *o);
 
@@ -294,7 +305,7 @@ void bmh_post_opt_default(bmh_post_opt_t *o);
  * the read's output, -1 = primary line), MAPQ, flag (0x100 secondary, 0x800 supplementary), reported (0/1)} in the
  * reference's order, capacity = the number of input regions; out_per_read[n_reads].  Returns the number of output
  * regions or a negative BMH_E* code.  contig_offset: start of every sequence in the packed reference (bns->anns[i].offset;
- * n_contigs <= 1: one sequence).  ALT contigs are not modelled. */
+ * n_contigs <= 1: one sequence).  ALT contigs: popt->contig_is_alt (see bmh_post_opt_t). */
 int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, int64_t l_pac,
                           const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
                           const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
@@ -319,7 +330,7 @@ float bmh_finalize_regs_device_last_ms(void);       /* device time of the thread
  * in the bmh_cigar_batch outputs (slot[i], -1 = none) and returns the text (malloc'd; free with bmh_free), one line per
  * record in the reference's order, an unmapped record for reads without a reported alignment.  names: the read names,
  * NUL-terminated, back to back, name_off[r] the start of read r's.  Formats ranges of reads on host threads.  reads: nt4 codes (the
- * path reads FASTA: QUAL is '*').  Pairing and ALT contigs are not modelled. */
+ * path reads FASTA: QUAL is '*').  ALT contigs: po->contig_is_alt (soft clips on ALT hits, the pa:f tag, the XA limits); pairs: bmh_format_sam_pe. */
 int64_t bmh_sam_need_cigar(const bmh_post_opt_t *po, const int32_t *fin, const uint32_t *fin_per_read, uint32_t n_reads, uint8_t *need);
 char *bmh_format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,
                      const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
@@ -390,6 +401,8 @@ bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_seeds);
 void bmh_chain_ws_free(bmh_chain_ws_t *ws);
 /* contig table of the reference (host arrays, as in bmh_build_jobs); default: one sequence of l_pac bases */
 int bmh_chain_set_contigs(bmh_chain_ws_t *ws, int n_contigs, const int64_t *contig_offset, const int32_t *contig_len);
+/* which of them are ALT contigs (is_alt[n_contigs], host memory; NULL or all zero: none) -- call after bmh_chain_set_contigs */
+int bmh_chain_set_alt(bmh_chain_ws_t *ws, int n_contigs, const uint8_t *is_alt);
 
 typedef struct {
 	uint64_t n_jobs, n_regs, q_bytes, t_bytes;

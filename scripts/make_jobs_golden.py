@@ -15,16 +15,43 @@ from bwamem_hip import fmindex, synth
 #        make_jobs_golden.py pe         -> pe_golden.npz (interleaved pairs, run with -p: insert-size statistics, mate rescue, pairing)
 MODE = sys.argv[1] if len(sys.argv) > 1 else "plain"
 #        make_jobs_golden.py pe_contigs -> pe_contigs_golden.npz (pairs on the three-sequence genome; some pairs span two sequences)
-REPEATS = MODE in ("repeats", "contigs", "pe", "pe_contigs")
-PE = MODE in ("pe", "pe_contigs")
-OUT = {"plain": "jobs_golden.npz", "repeats": "post_golden.npz", "contigs": "contigs_golden.npz", "pe": "pe_golden.npz", "pe_contigs": "pe_contigs_golden.npz"}[MODE]
+#        make_jobs_golden.py alt        -> alt_golden.npz (two primary sequences + two ALT contigs -- diverged copies of stretches of them -- named in g.fa.alt)
+#        make_jobs_golden.py pe_alt     -> pe_alt_golden.npz (the same genome, interleaved pairs)
+ALT = MODE in ("alt", "pe_alt")
+REPEATS = MODE in ("repeats", "contigs", "pe", "pe_contigs", "alt", "pe_alt")
+PE = MODE in ("pe", "pe_contigs", "pe_alt")
+OUT = {"plain": "jobs_golden.npz", "repeats": "post_golden.npz", "contigs": "contigs_golden.npz", "pe": "pe_golden.npz", "pe_contigs": "pe_contigs_golden.npz",
+       "alt": "alt_golden.npz", "pe_alt": "pe_alt_golden.npz"}[MODE]
 CONTIGS = [("ctgA", 120_000), ("ctgB", 100_037), ("ctgC", 79_963)] if MODE in ("contigs", "pe_contigs") else None
+if ALT:
+    CONTIGS = [("ctgA", 150_000), ("ctgB", 110_000), ("altA1", 20_000), ("altB1", 12_000), ("altA2", 8_000)]
+ALT_SRC = [(30_000, 20_000, 0.02), (170_000, 12_000, 0.04), (100_000, 8_000, 0.005)]      # (start on the primary assembly, length, divergence) of every ALT contig
 work = "/tmp/jobs_golden_" + MODE; os.makedirs(work, exist_ok=True)
 n_genome, n_reads, L = 300_000, 600, 150
 GENOME_KW = dict(repeat_frac=0.45, repeat_len=(150, 1500), repeat_copies=(3, 40), repeat_div=0.03) if REPEATS else {}
 g = synth.make_genome(n_genome, seed=42, **GENOME_KW)
+if ALT:
+    # the last 40 000 bases become ALT contigs: copies of stretches of the primary assembly with substitutions and a few short indels
+    rng = np.random.default_rng(77)
+    parts = [g[:260_000]]
+    for (p0, ln, div) in ALT_SRC:
+        x = g[p0:p0 + ln + 40].copy()
+        m = rng.random(x.size) < div; x[m] = (x[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+        for _k in range(3):                               # three indels of 1..6 bases
+            q = int(rng.integers(500, ln - 500)); d = int(rng.integers(1, 7))
+            x = np.concatenate([x[:q], x[q + d:]]) if rng.random() < 0.5 else np.concatenate([x[:q], rng.integers(0, 4, size=d).astype(np.uint8), x[q:]])
+        parts.append(x[:ln])
+    g = np.concatenate(parts).astype(np.uint8)
+    assert g.size == n_genome
 idx = fmindex.build_fmd_index(g, device="cuda:0")
 prefix = os.path.join(work, "g.fa"); fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g, contigs=CONTIGS)
+if ALT:
+    with open(prefix + ".alt", "w") as f:           # SAM-like lines as bwa-kit ships them: header lines, then one line per ALT contig (first field = its name)
+        f.write("@SQ\tSN:altA1\tLN:20000\n")
+        f.write("altA1\t0\tctgA\t30001\t60\t20000M\t*\t0\t0\t*\t*\n")
+        f.write("altB1\t16\tctgB\t20001\t60\t12000M\t*\t0\t0\t*\t*\n")
+        f.write("not_in_the_index\t0\tctgA\t1\t60\t10M\t*\t0\t0\t*\t*\n")
+        f.write("altA2\t0\tctgA\t100001\t60\t8000M\t*\t0\t0\t*\t*\r\n")
 reads, _ = synth.make_reads(g, n_reads, L, seed=21, sub_rate=0.02, indel_frac=0.2)
 if PE:
     reads, _ = synth.make_pairs(g, n_reads // 2, L, seed=21, sub_rate=0.02)
@@ -38,6 +65,24 @@ if PE:
             p0 = int(rng.integers(0, n_genome - L)); x = g[p0:p0 + L].copy(); reads[m] = x if rng.random() < 0.5 else synth.revcomp(x)
         elif kind == 7:                                    # unalignable mate
             reads[m] = rng.integers(0, 4, size=L).astype(np.uint8)
+if ALT:
+    # half of the reads (or of the pairs' first mates) come from the stretches that have an ALT copy, or from the ALT contigs themselves
+    rng = np.random.default_rng(12)
+    offs = np.concatenate([[0], np.cumsum([c[1] for c in CONTIGS])])
+    step = 2 if PE else 1
+    for i in range(0, n_reads, 2 * step):
+        k = int(rng.integers(0, len(ALT_SRC))); p0, ln, _ = ALT_SRC[k]
+        on_alt = rng.random() < 0.5
+        base = int(offs[2 + k]) if on_alt else p0
+        if PE:
+            ins = int(rng.integers(250, 450)); q = base + int(rng.integers(0, ln - ins))
+            a = g[q:q + L].copy(); b = synth.revcomp(g[q + ins - L:q + ins])
+            if rng.random() < 0.5: a, b = b, a
+            reads[i], reads[i + 1] = a, b
+        else:
+            q = base + int(rng.integers(0, ln - L)); x = g[q:q + L].copy()
+            m = rng.random(L) < 0.01; x[m] = (x[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+            reads[i] = x if rng.random() < 0.5 else synth.revcomp(x)
 if REPEATS and not PE:                                   # chimeric reads (two loci, either strand): supplementary records and SA tags
     rng = np.random.default_rng(6)
     for i in range(3, n_reads, 25):
@@ -118,7 +163,10 @@ lines_def = pack(sam_lines(sam)); lines_all = pack(sam_lines(sam_a))
 sam_text = np.frombuffer("".join(l for l in open(sam) if l[0] != "@").encode(), dtype=np.uint8)       # the records, verbatim
 sam_header = np.frombuffer("".join(l for l in open(sam) if l.startswith("@SQ")).encode(), dtype=np.uint8)
 seeds = B.seed_file(prefix, fq, 19)
-np.savez_compressed(os.path.join(ROOT, "gpurun_out", OUT), n_genome=n_genome, genome_seed=42, genome_kw=repr(GENOME_KW), contigs=repr(CONTIGS), reads=reads,
+extra = {}
+if ALT:                                       # the genome itself (2 bits per base) and the .alt file, as the test's inputs
+    extra = dict(genome_packed=np.packbits(np.stack([g >> 1, g & 1], axis=1).reshape(-1).astype(np.uint8)), alt_file=np.frombuffer(open(prefix + ".alt", "rb").read(), dtype=np.uint8))
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", OUT), n_genome=n_genome, genome_seed=42, genome_kw=repr(GENOME_KW), contigs=repr(CONTIGS), reads=reads, **extra,
                     job_digests=np.frombuffer(b"".join(digs), dtype=np.uint8).reshape(-1, 20), as_tag=as_tag,
                     **{"def_" + k: v for k, v in lines_def.items()}, **{"all_" + k: v for k, v in lines_all.items()},
                     sam_text=sam_text, sam_header=sam_header,

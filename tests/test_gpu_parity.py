@@ -737,6 +737,59 @@ def test_device_job_builder_matches_reference_job_stream(hip):
     cw.free(); dindex.free()
 
 
+def test_device_job_builder_with_alt_contigs_matches_reference_job_stream(hip):
+    """The same pin on a genome with ALT contigs (tests/golden/alt_golden.npz: two primary sequences and three ALT contigs named in
+    the .alt file): mem_chain_flt does not let a kept ALT chain shadow a chain on the primary assembly (src/bwamem.c:518), so the
+    job stream depends on the flags -- with them (bmh_chain_set_alt) it is the reference's, without them it is not."""
+    import ast, hashlib, torch
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.aligner import read_alt
+    from bwamem_hip.lib import ChainWorkspace, SeedsT, dev_jobs_to_host
+    B = hip
+    z = np.load(os.path.join(common.GOLDEN, "alt_golden.npz"))
+    n_g = int(z["n_genome"]); bits = np.unpackbits(z["genome_packed"])[: 2 * n_g].reshape(n_g, 2)
+    g = (bits[:, 0] * 2 + bits[:, 1]).astype(np.uint8)
+    contigs = ast.literal_eval(str(z["contigs"]))
+    names = [c[0] for c in contigs]
+    alt = np.array([1 if nm in ("altA1", "altB1", "altA2") else 0 for nm in names], np.uint8)
+    reads = z["reads"]
+    n, L = reads.shape
+    dindex = B.Index.upload(fmindex.build_fmd_index(g), pac=_pack_pac(g), l_pac=len(g))
+    dev = {k: torch.from_numpy(np.ascontiguousarray(z[k]).view(np.int64 if z[k].dtype == np.uint64 else np.int32)).cuda() for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")}
+    s = SeedsT()
+    s.n_seeds = len(z["rbeg"]); s.n_smems = int((z["score"] > 0).sum()); s.n_cands = 0
+    s.d_rbeg, s.d_qbeg, s.d_score, s.d_n_ref_pos, s.d_prefix = (dev[k].data_ptr() for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix"))
+    r = _to_dev(torch, synth.codes_to_ascii(reads.reshape(-1)))
+    o = (torch.arange(n, dtype=torch.int64) * L).to(torch.int32).cuda()
+    l = torch.full((n,), L, dtype=torch.int32).cuda()
+
+    def digests(with_alt):
+        cw = ChainWorkspace(n, max(int(s.n_seeds), 1))
+        cw.set_contigs(contigs)
+        if with_alt:
+            cw.set_alt(alt)
+        dj = cw.chain_batch(dindex, r, o, l, s)
+        got = dev_jobs_to_host(dj, n)
+        d = sorted(hashlib.sha1(bytes([int(got["h0"][i]) & 255, int(got["h0"][i]) >> 8]) + got["q"][got["qoff"][i]:got["qoff"][i] + got["qlen"][i]].tobytes() + b"|" +
+                                got["t"][got["toff"][i]:got["toff"][i] + got["tlen"][i]].tobytes()).digest() for i in range(int(dj.n_jobs)))
+        cw.free()
+        return d
+    want = [bytes(x) for x in z["job_digests"]]
+    assert digests(True) == want
+    assert digests(False) != want, "the golden read set does not exercise the ALT rule of the chain filter"
+    # the host builder under the same flags (bmh_chain_opt_t.contig_is_alt)
+    from bwamem_hip.lib import ChainOpt, HostJobs, load_library
+    import ctypes as C
+    copt = ChainOpt(); load_library().bmh_chain_opt_default(C.byref(copt)); copt.contig_is_alt = alt.ctypes.data
+    seeds_h = {k: z[k] for k in ("rbeg", "qbeg", "score", "n_ref_pos", "prefix")}
+    hj = HostJobs(g, reads.reshape(-1), np.arange(n, dtype=np.uint64) * L, np.full(n, L, np.uint32), seeds_h, n_threads=2, contigs=contigs, opt=copt)
+    q, qoff, qlen, t, toff, tlen, h0 = hj.jobs()
+    d_host = sorted(hashlib.sha1(bytes([int(h0[i]) & 255, int(h0[i]) >> 8]) + q[qoff[i]:qoff[i] + qlen[i]].tobytes() + b"|" + t[toff[i]:toff[i] + tlen[i]].tobytes()).digest() for i in range(hj.n_jobs))
+    hj.free()
+    assert d_host == want
+    dindex.free()
+
+
 def _cigar_case(B, oracle, g, idx, reads, scoring=None, max_regs=4000):
     """bmh_cigar_batch on the regions of the device pipeline (every region, not only the best ones) vs the oracle's
     mem_reg2aln restatement (pinned to the reference's SAM output and to its compiled ksw_global2)."""
@@ -935,18 +988,26 @@ def test_reads_to_sam_text_matches_reference(hip, oracle, golden):
     cw.free(); ws.free(); dindex.free()
 
 
-@pytest.mark.parametrize("golden", ["post_golden.npz", "contigs_golden.npz", "pe_golden.npz", "pe_contigs_golden.npz"])
+@pytest.mark.parametrize("golden", ["post_golden.npz", "contigs_golden.npz", "pe_golden.npz", "pe_contigs_golden.npz", "alt_golden.npz", "pe_alt_golden.npz"])
 def test_aligner_writes_reference_sam(hip, tmp_path, golden):
     """bwamem_hip.aligner (index files + FASTA -> SAM over the device-resident path) against the SAM text recorded from the
-    reference binary: single-end (repeat-rich, three sequences) and interleaved paired-end (-p)."""
+    reference binary: single-end (repeat-rich, three sequences) and interleaved paired-end (-p); alt_*: a genome with ALT contigs
+    named in <prefix>.alt (chain filter, two-round primary marking, MAPQ, XA / pa tags, soft clips on ALT hits)."""
     import ast, io
     from bwamem_hip import fmindex, synth
     from bwamem_hip.aligner import Aligner
     z = np.load(os.path.join(common.GOLDEN, golden))
-    g = synth.make_genome(int(z["n_genome"]), seed=int(z["genome_seed"]), **ast.literal_eval(str(z["genome_kw"])))
+    if "genome_packed" in z.files:                     # (the ALT genome is not a plain generator call: it travels with the golden file)
+        n = int(z["n_genome"]); bits = np.unpackbits(z["genome_packed"])[: 2 * n].reshape(n, 2)
+        g = (bits[:, 0] * 2 + bits[:, 1]).astype(np.uint8)
+    else:
+        g = synth.make_genome(int(z["n_genome"]), seed=int(z["genome_seed"]), **ast.literal_eval(str(z["genome_kw"])))
     contigs = ast.literal_eval(str(z["contigs"])) if "contigs" in z.files else None
     prefix = str(tmp_path / "g.fa")
     fmindex.write_index(prefix, fmindex.build_fmd_index(g)); fmindex.write_bns(prefix, g, contigs=contigs)
+    if "alt_file" in z.files:
+        with open(prefix + ".alt", "wb") as f:
+            f.write(bytes(z["alt_file"]))
     reads = z["reads"]
     pe = golden.startswith("pe_")
     fq = str(tmp_path / "r.fa")
@@ -977,7 +1038,7 @@ def test_aligner_writes_reference_sam(hip, tmp_path, golden):
         try:
             before = getattr(al, "host_tail_batches", 0)
             assert bytes(al.align_batch(rs.slice(0, n), id0=0, as_bytes="view")).decode() == want
-            assert al.host_tail_batches == before + 1
+            assert al.has_alt or al.host_tail_batches == before + 1          # (an index with ALT contigs takes the host tail in the first place)
         finally:
             del os.environ["BMH_FIN_FORCE_ECAPACITY"]
     al.close()

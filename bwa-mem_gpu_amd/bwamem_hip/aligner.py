@@ -172,7 +172,7 @@ class Aligner:
         self.has_alt = bool(self.alt.any())
         if self.has_alt:
             self.copt.contig_is_alt = self.alt.ctypes.data; self.po.contig_is_alt = self.alt.ctypes.data
-        self.n_threads = n_threads or (os.cpu_count() or 1)
+        self.n_threads = n_threads or int(self.L.bmh_effective_cpus())          # (the CPUs this process is granted, not the ones the machine shows)
         self.profile = bool(os.environ.get("BMH_ALIGNER_PROFILE"))
         self.c_off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([c[1] for c in self.contigs])]), dtype=np.int64)
 
@@ -424,6 +424,20 @@ class Aligner:
                 e += (e - b) & 1                                             # ... and is even (bseq_read: size >= chunk_size && (n & 1) == 0)
                 e = min(e, n)
                 cuts.append(e); b = e
+        # The native pipeline (csrc/align_pipeline.hip: batches driven by C threads, the text of batch k formatted while batches
+        # k+1, k+2 are on the device) takes every read set whose reads fit the device job builder; BMH_ALIGNER_NATIVE=0 keeps the
+        # batch-after-batch Python loop below (the same stages through the same entry points: the cross-check of the native one).
+        if n and os.environ.get("BMH_ALIGNER_NATIVE", "1") != "0" and rs.codes is not None and int(rs.lens.max()) <= 700 and not self.profile:
+            from .lib import NativeAligner
+            nat = getattr(self, "_native", None)
+            opts = (bytes(self.copt), bytes(self.ep), bytes(self.po), bytes(self.pe))
+            if nat is not None and nat.options != opts:          # (set_options since the last run)
+                nat.free(); nat = None
+            if nat is None:
+                nat = self._native = NativeAligner(self.index, self.pac, self.l_pac, self.contigs, self.alt if self.has_alt else None, self.copt, self.ep, self.po, self.pe)
+            self.last_stats = nat.run(rs, cuts, paired, (lambda mv: out.write(mv)) if binary else (lambda mv: out.write(bytes(mv).decode())),
+                                      n_lanes=int(os.environ.get("BMH_ALIGNER_LANES", "2")), n_threads=self.n_threads)
+            return n
         for b, e in zip(cuts[:-1], cuts[1:]):
             if e > b:
                 out.write(self.align_batch(rs.slice(b, e), id0=b, paired=paired, as_bytes="view" if binary else False))   # (binary: the library's buffer, uncopied)
@@ -486,6 +500,9 @@ class Aligner:
             pass
 
     def close(self):
+        nat = getattr(self, "_native", None)
+        if nat is not None:
+            nat.free(); self._native = None
         for nm in ("_ws_cache", "_cw_cache"):
             c = getattr(self, nm, None)
             if c is not None:

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_finalize_regs_device", "bmh_finalize_regs_device_last_ms", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
     "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_finalize_pairs_dev", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
     "bmh_chain_opt_default", "bmh_chain_last_timing", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
-    "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_alt", "bmh_chain_set_materialize", "bmh_chain_batch",
+    "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_alt", "bmh_effective_cpus", "bmh_aligner_create", "bmh_aligner_free", "bmh_aligner_run", "bmh_chain_set_materialize", "bmh_chain_batch",
     "bmh_chain_extend", "bmh_chain_merge", "bmh_chain_extend_merge", "bmh_chain_extend_merge_timing", "bmh_cigar_batch",
     "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
     "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
@@ -74,6 +74,71 @@ def load_fasta_reads(path: str, n_threads: int = 0) -> dict:
         return np.frombuffer(buf, dtype=dt)
     return dict(ascii=arr(rs.ascii, rs.n_bases, np.uint8), codes=arr(rs.codes, rs.n_bases, np.uint8), offs=arr(rs.offs, rs.n_reads, np.uint64),
                 lens=arr(rs.lens, rs.n_reads, np.uint32), names=arr(rs.names, rs.n_name_bytes, np.uint8), name_offs=arr(rs.name_offs, rs.n_reads, np.uint64))
+
+
+class AlignStats(C.Structure):
+    """bmh_align_stats_t"""
+    _fields_ = [("n_reads", C.c_uint64), ("n_bytes", C.c_uint64), ("n_batches", C.c_uint32), ("n_lanes", C.c_int)] + \
+               [(n, C.c_double) for n in ("seconds", "format_seconds", "h2d_seconds", "seed_seconds", "chain_extend_seconds", "tail_seconds", "select_seconds", "cigar_seconds")]
+
+
+SAM_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class NativeAligner:
+    """bmh_aligner_t: the native reads -> SAM pipeline; lanes (streams, workspaces, pinned staging) are kept between runs"""
+
+    def __init__(self, index: "Index", pac: np.ndarray, l_pac: int, contigs, is_alt, copt, ep, po, pe):
+        L = load_library()
+        L.bmh_aligner_create.restype = C.c_void_p
+        L.bmh_aligner_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.POINTER(ChainOpt), C.POINTER(ExtParams),
+                                         C.POINTER(PostOpt), C.POINTER(PeOpt)]
+        L.bmh_aligner_free.argtypes = [C.c_void_p]
+        L.bmh_aligner_run.restype = C.c_int
+        L.bmh_aligner_run.argtypes = [C.c_void_p, C.POINTER(ReadSetT), C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, SAM_SINK, C.c_void_p, C.POINTER(AlignStats)]
+        names = (C.c_char_p * len(contigs))(*[c[0].encode() for c in contigs])
+        lens = np.ascontiguousarray([c[1] for c in contigs], dtype=np.int32)
+        alt = np.ascontiguousarray(is_alt, dtype=np.uint8) if is_alt is not None else None
+        self._pac = np.ascontiguousarray(pac, dtype=np.uint8)          # (borrowed by the handle: kept alive here)
+        self._index = index
+        self.options = (bytes(copt), bytes(ep), bytes(po), bytes(pe))  # what the handle was made with: the caller makes a new one when they change
+        self.handle = L.bmh_aligner_create(index.handle, self._pac.ctypes.data, int(l_pac), len(contigs), names, lens.ctypes.data, alt.ctypes.data if alt is not None else None,
+                                           C.byref(copt), C.byref(ep), C.byref(po), C.byref(pe))
+        if not self.handle:
+            raise RuntimeError("bmh_aligner_create: " + _err(L))
+
+    def run(self, rs, cuts, paired: bool, write, n_lanes: int = 2, n_threads: int = 0) -> "AlignStats":
+        """the batches [cuts[b], cuts[b+1]) of the read set `rs` (an aligner.ReadSet; codes required); write(memoryview) receives every
+        batch's SAM records in order"""
+        L = load_library()
+        keep = [np.ascontiguousarray(rs.ascii, dtype=np.uint8), np.ascontiguousarray(rs.codes, dtype=np.uint8), np.ascontiguousarray(rs.offs, dtype=np.uint64),
+                np.ascontiguousarray(rs.lens, dtype=np.uint32), np.ascontiguousarray(rs.name_blob, dtype=np.uint8), np.ascontiguousarray(rs.name_off, dtype=np.uint64)]
+        c = ReadSetT()
+        c.n_reads = len(keep[3]); c.n_bases = int(keep[2][-1] + keep[3][-1]) if len(keep[3]) else 0; c.n_name_bytes = len(keep[4])
+        c.ascii, c.codes, c.offs, c.lens, c.names, c.name_offs = (k.ctypes.data for k in keep)
+        cu = np.ascontiguousarray(cuts, dtype=np.uint64)
+        err = []
+
+        def sink(_user, ptr, n):
+            try:
+                write(memoryview((C.c_char * n).from_address(ptr)))
+                return 0
+            except BaseException as e:                      # noqa: BLE001 -- reported after the run (an exception must not cross the C frames)
+                err.append(e)
+                return 1
+        cb = SAM_SINK(sink)
+        st = AlignStats()
+        rc = L.bmh_aligner_run(self.handle, C.byref(c), cu.ctypes.data, len(cu) - 1, 1 if paired else 0, int(n_lanes), int(n_threads), cb, None, C.byref(st))
+        if err:
+            raise err[0]
+        if rc != 0:
+            raise (CapacityError if rc == -3 else RuntimeError)(f"bmh_aligner_run rc={rc}: " + _err(L))
+        return st
+
+    def free(self):
+        if self.handle:
+            load_library().bmh_aligner_free(self.handle)
+            self.handle = None
 
 
 class SeedsT(C.Structure):

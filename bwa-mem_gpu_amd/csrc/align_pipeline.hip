@@ -1,0 +1,458 @@
+// Reads in host memory -> SAM text, driven from C threads (the host side of the gase_aln run around the
+// device path; what worker1 / worker2 + kt_pipeline do in the reference, /root/reference/src/bwamem.c:2042-2340, src/fastmap.c:59-120).
+//
+// The stages exist already as C-ABI entry points (seeding, chaining, extension, merge, the region tail, CIGARs, the formatter); until
+// round 4 a Python loop called them batch after batch and was three to ten times slower than the device path it drove.  Here:
+//   * `n_lanes` worker threads take the batches of the read set in turn; a worker owns a stream, its workspaces and pinned staging and
+//     takes its batch through H2D -> seeding -> chaining -> extension -> merge -> region tail -> CIGARs -> D2H;
+//   * one writer thread formats the finished batches IN ORDER (bmh_format_sam is itself multi-threaded) and hands the text to the
+//     caller's sink while the workers are on the next batches.
+// Single-end batches finish their region tail on the device (bmh_finalize_regs_device); a batch it refuses (BMH_ECAPACITY), an index
+// with ALT contigs and interleaved pairs (bmh_finalize_pairs_dev) take the host forms -- the same choices bwamem_hip/aligner.py makes,
+// the same text.  Reads longer than 700 bases (the device job builder's limit) are refused: the caller takes the slower path.
+#include <hip/hip_runtime.h>
+#include <sched.h>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "bmh_internal.h"
+
+namespace {
+
+struct aligner_t {
+	const bmh_index_t *idx;
+	const uint8_t *pac; int64_t l_pac;
+	int n_contigs;
+	std::vector<std::string> names; std::vector<const char *> name_ptr;
+	std::vector<int64_t> off; std::vector<int32_t> len; std::vector<uint8_t> alt; bool has_alt;
+	bmh_chain_opt_t co; bmh_ext_params_t ep; bmh_post_opt_t po; bmh_pe_opt_t pe;
+};
+
+}   // namespace
+
+// the CPUs this process may actually use: its affinity mask, capped by the cgroup's CPU quota (a container that shows 256 hardware threads
+// may be granted 16: two hundred threads on sixteen CPUs spend their time switching)
+extern "C" int bmh_effective_cpus(void)
+{
+	int n = (int)std::thread::hardware_concurrency();
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && (n < 1 || c < n)) n = c; }
+	FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+	if (f) {
+		char q[64]; long long per = 0;
+		if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { const long long c = (atoll(q) + per - 1) / per; if (c > 0 && c < n) n = (int)c; }
+		fclose(f);
+	} else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) != nullptr) {
+		long long quota = -1, per = 0;
+		if (fscanf(f, "%lld", &quota) != 1) quota = -1;
+		fclose(f);
+		FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+		if (g) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
+		if (quota > 0 && per > 0) { const long long c = (quota + per - 1) / per; if (c > 0 && c < n) n = (int)c; }
+	}
+	return n < 1 ? 1 : n;
+}
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// device / pinned buffers that only ever grow
+template <class T> struct dbuf_t {
+	T *p = nullptr; size_t cap = 0;
+	int need(size_t n) {
+		if (n <= cap) return BMH_OK;
+		if (p) (void)hipFree(p);
+		p = nullptr; cap = 0;
+		const size_t c = n + n / 4 + 1024;
+		if (hipMalloc((void **)&p, c * sizeof(T)) != hipSuccess) { bmh_set_error("bmh_aligner_run: %zu bytes of device memory: %s", c * sizeof(T), hipGetErrorString(hipGetLastError())); return BMH_ENOMEM; }
+		cap = c;
+		return BMH_OK;
+	}
+	~dbuf_t() { if (p) (void)hipFree(p); }
+};
+template <class T> struct hbuf_t {
+	T *p = nullptr; size_t cap = 0;
+	int need(size_t n) {
+		if (n <= cap) return BMH_OK;
+		if (p) (void)hipHostFree(p);
+		p = nullptr; cap = 0;
+		const size_t c = n + n / 4 + 1024;
+		if (hipHostMalloc((void **)&p, c * sizeof(T), hipHostMallocDefault) != hipSuccess) { bmh_set_error("bmh_aligner_run: %zu bytes of pinned memory: %s", c * sizeof(T), hipGetErrorString(hipGetLastError())); return BMH_ENOMEM; }
+		cap = c;
+		return BMH_OK;
+	}
+	~hbuf_t() { if (p) (void)hipHostFree(p); }
+};
+
+// What the writer needs of a finished batch.  The large arrays are PINNED buffers the device copies straight into; a result goes back
+// to a pool when its text is written, so the buffers are allocated a few times per run, not per batch (a million reads leave 70 MB
+// of records and 190 MB of CIGAR / MD arrays: every extra pass over them on one thread costs what a device stage costs).
+struct result_t {
+	uint32_t b0 = 0, n = 0; uint64_t m = 0, n_sel = 0;
+	hbuf_t<int32_t> fin, aln; hbuf_t<uint32_t> opr, cigar; hbuf_t<char> md; int max_cigar = 16, md_cap = 96;
+	std::vector<int64_t> slot;
+	std::vector<int32_t> h_rec, unflag;          // pairs
+	std::vector<uint32_t> cigar_big; std::vector<char> md_big;     // only when an alignment overflowed the compact buffers
+	const uint32_t *cigar_p = nullptr; const char *md_p = nullptr;
+};
+
+struct lane_t {
+	hipStream_t st = nullptr;
+	bmh_seed_ws_t *sws = nullptr; uint32_t sws_reads = 0; uint64_t sws_bases = 0;
+	bmh_chain_ws_t *cws = nullptr; uint32_t cws_reads = 0; uint64_t cws_seeds = 0;
+	dbuf_t<uint8_t> d_reads; dbuf_t<uint32_t> d_offs, d_lens, d_sel, d_opr, d_cigar; dbuf_t<int32_t> d_out3, d_regs, d_fin, d_aln; dbuf_t<char> d_md;
+	hbuf_t<uint32_t> h_offs, h_sel, h_rpr; hbuf_t<int32_t> h_regs; hbuf_t<float> h_fr; hbuf_t<uint8_t> h_need, h_reads;
+	double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // h2d, seed, chain+extend+merge, tail, select, cigar + d2h
+	~lane_t()
+	{
+		if (sws) bmh_seed_ws_free(sws);
+		if (cws) bmh_chain_ws_free(cws);
+		if (st) { bmh_extend_release(st); (void)hipStreamDestroy(st); }
+	}
+};
+
+#define LCK(x) do { const hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("bmh_aligner_run: %s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
+#define RCK(x) do { const int rc_ = (x); if (rc_ != BMH_OK) return rc_; } while (0)
+
+int cigars(const aligner_t &A, lane_t &Ln, const int32_t *d_fin, const uint32_t *sel, uint64_t n_sel, result_t &R)
+{
+	R.max_cigar = 16; R.md_cap = 96; R.n_sel = n_sel;
+	RCK(R.aln.need(8 * (n_sel + 1))); RCK(R.cigar.need((size_t)R.max_cigar * (n_sel + 1))); RCK(R.md.need((size_t)R.md_cap * (n_sel + 1)));
+	R.cigar_p = R.cigar.p; R.md_p = R.md.p;
+	if (n_sel == 0) return BMH_OK;
+	RCK(Ln.d_sel.need(n_sel)); RCK(Ln.d_aln.need(8 * n_sel)); RCK(Ln.d_cigar.need((size_t)R.max_cigar * n_sel)); RCK(Ln.d_md.need((size_t)R.md_cap * n_sel));
+	LCK(hipMemcpyAsync(Ln.d_sel.p, sel, 4 * n_sel, hipMemcpyHostToDevice, Ln.st));
+	RCK(bmh_cigar_batch(A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, d_fin, 16, Ln.d_sel.p, (uint32_t)n_sel, &A.ep, A.co.w, R.max_cigar, Ln.d_cigar.p, Ln.d_aln.p, R.md_cap, Ln.d_md.p, Ln.st));
+	LCK(hipMemcpyAsync(R.aln.p, Ln.d_aln.p, 32 * n_sel, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipMemcpyAsync(R.cigar.p, Ln.d_cigar.p, 4 * (size_t)R.max_cigar * n_sel, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipMemcpyAsync(R.md.p, Ln.d_md.p, (size_t)R.md_cap * n_sel, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipStreamSynchronize(Ln.st));
+	// the few alignments that overflow the compact buffers (flag 1: more operations, flag 8: a longer MD) are redone with large ones
+	std::vector<uint32_t> over;
+	for (uint64_t k = 0; k < n_sel; ++k) if (R.aln.p[8 * k + 7] & 9) over.push_back((uint32_t)k);
+	if (!over.empty()) {
+		const int MC = 64, MD = 1024;
+		R.cigar_big.assign((size_t)MC * n_sel, 0); R.md_big.assign((size_t)MD * n_sel, 0);
+		for (uint64_t k = 0; k < n_sel; ++k) { memcpy(&R.cigar_big[(size_t)MC * k], R.cigar.p + (size_t)R.max_cigar * k, 4 * (size_t)R.max_cigar); memcpy(&R.md_big[(size_t)MD * k], R.md.p + (size_t)R.md_cap * k, (size_t)R.md_cap); }
+		std::vector<uint32_t> sel2(over.size());
+		for (size_t k = 0; k < over.size(); ++k) sel2[k] = sel[over[k]];
+		const size_t no = over.size();
+		dbuf_t<uint32_t> d_cg2; dbuf_t<int32_t> d_aln2; dbuf_t<char> d_md2;
+		RCK(d_cg2.need((size_t)MC * no)); RCK(d_aln2.need(8 * no)); RCK(d_md2.need((size_t)MD * no));
+		LCK(hipMemcpyAsync(Ln.d_sel.p, sel2.data(), 4 * no, hipMemcpyHostToDevice, Ln.st));
+		RCK(bmh_cigar_batch(A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, d_fin, 16, Ln.d_sel.p, (uint32_t)no, &A.ep, A.co.w, MC, d_cg2.p, d_aln2.p, MD, d_md2.p, Ln.st));
+		std::vector<int32_t> a2(8 * no); std::vector<uint32_t> c2((size_t)MC * no); std::vector<char> m2((size_t)MD * no);
+		LCK(hipMemcpyAsync(a2.data(), d_aln2.p, 32 * no, hipMemcpyDeviceToHost, Ln.st));
+		LCK(hipMemcpyAsync(c2.data(), d_cg2.p, 4 * (size_t)MC * no, hipMemcpyDeviceToHost, Ln.st));
+		LCK(hipMemcpyAsync(m2.data(), d_md2.p, (size_t)MD * no, hipMemcpyDeviceToHost, Ln.st));
+		LCK(hipStreamSynchronize(Ln.st));
+		for (size_t k = 0; k < no; ++k) {
+			memcpy(R.aln.p + 8 * (size_t)over[k], &a2[8 * k], 32); memcpy(&R.cigar_big[(size_t)MC * over[k]], &c2[(size_t)MC * k], 4 * (size_t)MC); memcpy(&R.md_big[(size_t)MD * over[k]], &m2[(size_t)MD * k], (size_t)MD);
+		}
+		R.max_cigar = MC; R.md_cap = MD; R.cigar_p = R.cigar_big.data(); R.md_p = R.md_big.data();
+	}
+	for (uint64_t k = 0; k < n_sel; ++k)
+		if (R.aln.p[8 * k + 7] & ~2) { bmh_set_error("bmh_aligner_run: bmh_cigar_batch flagged an alignment (CIGAR or MD longer than the buffers)"); return BMH_ECAPACITY; }
+	return BMH_OK;
+}
+
+// one batch [b0, b1) of the read set on lane Ln -> R
+int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t b0, uint32_t b1, bool paired, int n_threads, result_t &R)
+{
+	const uint32_t n = b1 - b0;
+	R.b0 = b0; R.n = n;
+	const uint64_t a0 = rs.offs[b0], a1 = rs.offs[b1 - 1] + rs.lens[b1 - 1], nb = a1 - a0;
+	if (nb >> 31) { bmh_set_error("bmh_aligner_run: a batch holds 2^31 bases or more (offsets inside a batch are 32-bit)"); return BMH_EINVAL; }
+	double t0 = now_s();
+	// ---- reads to the device
+	RCK(Ln.d_reads.need(nb + 16)); RCK(Ln.d_offs.need(n + 1)); RCK(Ln.d_lens.need(n + 1)); RCK(Ln.h_offs.need(n + 1));
+	for (uint32_t r = 0; r < n; ++r) Ln.h_offs.p[r] = (uint32_t)(rs.offs[b0 + r] - a0);
+	RCK(Ln.h_reads.need(nb + 16));
+	memcpy(Ln.h_reads.p, rs.ascii + a0, nb);                          // (pageable -> pinned by this lane's thread, then one DMA: the lanes stage side by side)
+	LCK(hipMemcpyAsync(Ln.d_reads.p, Ln.h_reads.p, nb, hipMemcpyHostToDevice, Ln.st));
+	LCK(hipMemcpyAsync(Ln.d_offs.p, Ln.h_offs.p, 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
+	LCK(hipMemcpyAsync(Ln.d_lens.p, rs.lens + b0, 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
+	// ---- seeding
+	if (!Ln.sws || n > Ln.sws_reads || nb > Ln.sws_bases) {
+		if (Ln.sws) bmh_seed_ws_free(Ln.sws);
+		Ln.sws_reads = n + n / 4; Ln.sws_bases = nb + nb / 4;
+		const uint64_t occ = 64ull * Ln.sws_reads > (1ull << 16) ? 64ull * Ln.sws_reads : (1ull << 16);
+		Ln.sws = bmh_seed_ws_create(Ln.sws_reads, Ln.sws_bases, Ln.sws_bases, occ);          // one candidate per base is the hard upper bound
+		if (!Ln.sws) return BMH_ENOMEM;
+	}
+	double t1 = now_s(); Ln.t[0] += t1 - t0;
+	bmh_seeds_t seeds;
+	RCK(bmh_seed_batch(Ln.sws, A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, n, A.co.min_seed_len, Ln.st, &seeds));
+	double t2 = now_s(); Ln.t[1] += t2 - t1;
+	// ---- chains, jobs, extension, regions
+	const uint64_t ns = seeds.n_seeds ? seeds.n_seeds : 1;
+	if (!Ln.cws || n > Ln.cws_reads || ns > Ln.cws_seeds) {
+		if (Ln.cws) bmh_chain_ws_free(Ln.cws);
+		Ln.cws_reads = n + n / 4; Ln.cws_seeds = ns + ns / 4 + 1024;
+		Ln.cws = bmh_chain_ws_create(Ln.cws_reads, Ln.cws_seeds);
+		if (!Ln.cws) return BMH_ENOMEM;
+		RCK(bmh_chain_set_materialize(Ln.cws, 0));
+		if (A.n_contigs > 1) {
+			RCK(bmh_chain_set_contigs(Ln.cws, A.n_contigs, A.off.data(), A.len.data()));
+			if (A.has_alt) RCK(bmh_chain_set_alt(Ln.cws, A.n_contigs, A.alt.data()));
+		}
+	}
+	bmh_dev_jobs_t dj;
+	RCK(bmh_chain_batch(Ln.cws, &A.co, A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, n, &seeds, Ln.st, &dj));
+	const uint64_t nr = dj.n_regs, nj = dj.n_jobs;
+	RCK(Ln.d_out3.need(3 * (nj + 1))); RCK(Ln.d_regs.need(8 * (nr + 1)));
+	// the reference's GPU extension takes the deletion penalties for both gap kinds (src/fastmap.c:417-424)
+	bmh_ext_params_t xp = A.ep; xp.o_ins = A.ep.o_del; xp.e_ins = A.ep.e_del;
+	RCK(bmh_chain_extend(Ln.cws, &xp, Ln.d_out3.p, nullptr, Ln.st));
+	RCK(bmh_chain_merge(Ln.cws, Ln.d_out3.p, Ln.d_regs.p, Ln.st));
+	double t3 = now_s(); Ln.t[2] += t3 - t2;
+	bmh_post_opt_t po = A.po; po.id0 = (int64_t)b0;
+	const uint8_t *codes = rs.codes + a0;
+	std::vector<uint64_t> offs64;                                   // offsets relative to the batch, for the host forms
+	auto host_offs = [&]() { if (offs64.empty()) { offs64.resize(n); for (uint32_t r = 0; r < n; ++r) offs64[r] = rs.offs[b0 + r] - a0; } return offs64.data(); };
+	const int32_t *d_fin = nullptr;
+	// ---- the region tail
+	if (!paired) {
+		int64_t m = -1;
+		if (!A.has_alt) {
+			RCK(Ln.d_fin.need(16 * (nr + 1))); RCK(Ln.d_opr.need(n + 1));
+			m = bmh_finalize_regs_device(A.idx, &A.co, &A.ep, &po, Ln.d_reads.p, Ln.d_offs.p, n, Ln.d_regs.p, nr, dj.d_regs_per_read, dj.d_frac_rep,
+			                             A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr, Ln.d_fin.p, Ln.d_opr.p, Ln.st);
+			if (m < 0 && m != BMH_ECAPACITY) return (int)m;
+			if (m >= 0) {
+				RCK(R.fin.need(16 * (size_t)m + 16)); RCK(R.opr.need(n + 1));
+				if (m) LCK(hipMemcpyAsync(R.fin.p, Ln.d_fin.p, 64 * (size_t)m, hipMemcpyDeviceToHost, Ln.st));
+				LCK(hipMemcpyAsync(R.opr.p, Ln.d_opr.p, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
+				LCK(hipStreamSynchronize(Ln.st));
+				d_fin = Ln.d_fin.p;
+			}
+		}
+		if (m < 0) {                                                // the host tail: ALT contigs, or a read beyond the device tail's fixed limits
+			RCK(Ln.h_regs.need(8 * (nr + 1))); RCK(Ln.h_rpr.need(n + 1)); RCK(Ln.h_fr.need(n + 1));
+			if (nr) LCK(hipMemcpyAsync(Ln.h_regs.p, Ln.d_regs.p, 32 * (size_t)nr, hipMemcpyDeviceToHost, Ln.st));
+			LCK(hipMemcpyAsync(Ln.h_rpr.p, dj.d_regs_per_read, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
+			LCK(hipMemcpyAsync(Ln.h_fr.p, dj.d_frac_rep, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
+			LCK(hipStreamSynchronize(Ln.st));
+			RCK(R.fin.need(16 * (size_t)(nr + 1))); RCK(R.opr.need(n + 1));
+			m = bmh_finalize_regs(&A.co, &A.ep, &po, A.l_pac, A.pac, n, codes, host_offs(), Ln.h_regs.p, Ln.h_rpr.p, Ln.h_fr.p, A.n_contigs,
+			                      A.n_contigs > 1 ? A.off.data() : nullptr, R.fin.p, R.opr.p, n_threads);
+			if (m < 0) return (int)m;
+			RCK(Ln.d_fin.need(16 * ((size_t)m + 1)));
+			if (m) LCK(hipMemcpyAsync(Ln.d_fin.p, R.fin.p, 64 * (size_t)m, hipMemcpyHostToDevice, Ln.st));
+			d_fin = Ln.d_fin.p;
+		}
+		R.m = (uint64_t)m;
+	} else {
+		RCK(Ln.h_regs.need(8 * (nr + 1))); RCK(Ln.h_rpr.need(n + 1)); RCK(Ln.h_fr.need(n + 1));
+		if (nr) LCK(hipMemcpyAsync(Ln.h_regs.p, Ln.d_regs.p, 32 * (size_t)nr, hipMemcpyDeviceToHost, Ln.st));
+		LCK(hipMemcpyAsync(Ln.h_rpr.p, dj.d_regs_per_read, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
+		LCK(hipMemcpyAsync(Ln.h_fr.p, dj.d_frac_rep, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
+		LCK(hipStreamSynchronize(Ln.st));
+		uint64_t cap = nr + 2ull * n + 1024;                        // mate rescue adds a few regions per pair
+		int64_t m = BMH_ECAPACITY;
+		RCK(R.opr.need(n + 1)); R.h_rec.resize(n); R.unflag.resize(n);
+		for (int attempt = 0; attempt < 3 && m == BMH_ECAPACITY; ++attempt, cap *= 2) {
+			RCK(R.fin.need(16 * (size_t)cap));
+			m = bmh_finalize_pairs_dev(A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.st, &A.co, &A.ep, &po, &A.pe, A.l_pac, A.pac, n, codes, host_offs(), rs.lens + b0,
+			                           Ln.h_regs.p, Ln.h_rpr.p, Ln.h_fr.p, A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr, A.n_contigs > 1 ? A.len.data() : nullptr,
+			                           R.fin.p, cap, R.opr.p, R.h_rec.data(), R.unflag.data(), nullptr, n_threads);
+		}
+		if (m < 0) return (int)m;
+		R.m = (uint64_t)m;
+		RCK(Ln.d_fin.need(16 * ((size_t)m + 1)));
+		if (m) LCK(hipMemcpyAsync(Ln.d_fin.p, R.fin.p, 64 * (size_t)m, hipMemcpyHostToDevice, Ln.st));
+		d_fin = Ln.d_fin.p;
+	}
+	double t4 = now_s(); Ln.t[3] += t4 - t3;
+	// ---- which records need a CIGAR
+	const uint64_t m = R.m;
+	RCK(Ln.h_need.need(m + 1)); RCK(Ln.h_sel.need(m + 1));
+	const int64_t n_need = paired ? bmh_sam_need_cigar_pe(&po, R.fin.p, R.opr.p, R.h_rec.data(), n, Ln.h_need.p)
+	                              : bmh_sam_need_cigar(&po, R.fin.p, R.opr.p, n, Ln.h_need.p);
+	if (n_need < 0) return (int)n_need;
+	R.slot.assign(m ? m : 1, -1);
+	uint64_t ns_sel = 0;
+	for (uint64_t k = 0; k < m; ++k) if (Ln.h_need.p[k]) { Ln.h_sel.p[ns_sel] = (uint32_t)k; R.slot[k] = (int64_t)ns_sel; ++ns_sel; }
+	double t5 = now_s(); Ln.t[4] += t5 - t4;
+	RCK(cigars(A, Ln, d_fin, Ln.h_sel.p, ns_sel, R));
+	Ln.t[5] += now_s() - t5;
+	return BMH_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+// (lanes and result objects stay with the aligner between runs: their workspaces and pinned buffers -- gigabytes for million-read batches
+// -- cost more to allocate than a batch costs to align)
+struct bmh_aligner {
+	aligner_t a;
+	std::vector<std::unique_ptr<lane_t>> lanes;
+	std::vector<std::unique_ptr<result_t>> pool; int n_results = 0;
+	std::vector<std::string> parts;
+	int dev = -1;
+};
+
+bmh_aligner_t *bmh_aligner_create(const bmh_index_t *idx, const uint8_t *pac, int64_t l_pac, int n_contigs, const char *const *contig_names,
+                                  const int32_t *contig_len, const uint8_t *contig_is_alt, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep,
+                                  const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe)
+{
+	if (!idx || !pac || !copt || !ep || !popt || n_contigs < 1 || !contig_names || !contig_len) { bmh_set_error("bmh_aligner_create: null argument"); return nullptr; }
+	if (!idx->dev.pac || (int64_t)idx->dev.l_pac != l_pac) { bmh_set_error("bmh_aligner_create: the index must carry the 2-bit reference of l_pac bases"); return nullptr; }
+	bmh_aligner *h = new bmh_aligner();
+	aligner_t &A = h->a;
+	A.idx = idx; A.pac = pac; A.l_pac = l_pac; A.n_contigs = n_contigs;
+	int64_t o = 0;
+	for (int c = 0; c < n_contigs; ++c) { A.names.emplace_back(contig_names[c]); A.off.push_back(o); A.len.push_back(contig_len[c]); o += contig_len[c]; A.alt.push_back(contig_is_alt ? contig_is_alt[c] : 0); }
+	for (const std::string &s : A.names) A.name_ptr.push_back(s.c_str());
+	if (o != l_pac) { bmh_set_error("bmh_aligner_create: the sequences' lengths add up to %lld, l_pac is %lld", (long long)o, (long long)l_pac); delete h; return nullptr; }
+	A.has_alt = false;
+	for (uint8_t v : A.alt) A.has_alt = A.has_alt || v != 0;
+	A.co = *copt; A.ep = *ep; A.po = *popt;
+	if (pe) A.pe = *pe; else bmh_pe_opt_default(&A.pe);
+	A.co.contig_is_alt = A.has_alt ? A.alt.data() : nullptr; A.po.contig_is_alt = A.has_alt ? A.alt.data() : nullptr;
+	return h;
+}
+
+void bmh_aligner_free(bmh_aligner_t *h)
+{
+	if (!h) return;
+	int prev = 0;
+	const bool sw = h->dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != h->dev && hipSetDevice(h->dev) == hipSuccess;
+	h->lanes.clear(); h->pool.clear();                 // (device and pinned buffers, streams: released on their device)
+	if (sw) (void)hipSetDevice(prev);
+	delete h;
+}
+
+int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *cuts, uint32_t n_batches, int paired, int n_lanes, int n_threads,
+                    bmh_sam_sink_t sink, void *user, bmh_align_stats_t *stats)
+{
+	if (!h || !rs || !cuts || !sink) { bmh_set_error("bmh_aligner_run: null argument"); return BMH_EINVAL; }
+	const aligner_t &A = h->a;
+	if (stats) memset(stats, 0, sizeof(*stats));
+	if (n_batches == 0 || rs->n_reads == 0) return BMH_OK;
+	if (cuts[0] != 0 || cuts[n_batches] != rs->n_reads) { bmh_set_error("bmh_aligner_run: cuts[0] = 0 and cuts[n_batches] = n_reads are required"); return BMH_EINVAL; }
+	for (uint32_t b = 0; b < n_batches; ++b)
+		if (cuts[b + 1] < cuts[b] || (paired && ((cuts[b + 1] - cuts[b]) & 1)) || cuts[b + 1] - cuts[b] > 0xFFFFFFF0ull) { bmh_set_error("bmh_aligner_run: bad batch cuts"); return BMH_EINVAL; }
+	for (uint64_t r = 0; r < rs->n_reads; ++r)
+		if (rs->lens[r] > 700) { bmh_set_error("bmh_aligner_run: read %llu has %u bases: reads beyond 700 go through the host job builder (bmh_build_jobs)", (unsigned long long)r, rs->lens[r]); return BMH_EINVAL; }
+	if (n_lanes < 1) n_lanes = 1;
+	if ((uint32_t)n_lanes > n_batches) n_lanes = (int)n_batches;
+	if (n_threads < 1) n_threads = bmh_effective_cpus();
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) { bmh_set_error("bmh_aligner_run: no HIP device"); return BMH_ENODEV; }
+	const double t_start = now_s();
+	const bool trace = getenv("BMH_ALIGNER_TRACE") != nullptr;        // per-batch timeline on stderr
+	std::mutex mu; std::condition_variable cv;
+	std::map<uint32_t, std::unique_ptr<result_t>> done;             // finished batches waiting for their turn at the writer
+	std::vector<std::unique_ptr<result_t>> &pool = h->pool;         // result objects (pinned buffers) not in use: at most n_lanes + 2 exist
+	int &n_results = h->n_results;
+	std::atomic<uint32_t> next_batch{0};
+	uint32_t next_write = 0;                                        // (guarded by mu)
+	int first_rc = BMH_OK; std::string first_err;
+	auto fail = [&](int rc, const char *msg) { std::lock_guard<std::mutex> lk(mu); if (first_rc == BMH_OK) { first_rc = rc; first_err = msg ? msg : ""; } cv.notify_all(); };
+	std::vector<double> lane_t_sum(8, 0.0);
+	if (h->dev >= 0 && h->dev != dev) { bmh_set_error("bmh_aligner_run: the aligner's lanes live on device %d, the current device is %d", h->dev, dev); return BMH_EINVAL; }
+	h->dev = dev;
+	while ((int)h->lanes.size() < n_lanes) {
+		std::unique_ptr<lane_t> ln(new lane_t());
+		if (hipStreamCreateWithFlags(&ln->st, hipStreamNonBlocking) != hipSuccess) { bmh_set_error("bmh_aligner_run: hipStreamCreate: %s", hipGetErrorString(hipGetLastError())); return BMH_ENODEV; }
+		h->lanes.push_back(std::move(ln));
+	}
+	for (auto &ln : h->lanes) for (double &v : ln->t) v = 0.0;
+	auto worker = [&](int lane_index) {
+		if (hipSetDevice(dev) != hipSuccess) { fail(BMH_ENODEV, "hipSetDevice failed in a worker thread"); return; }
+		lane_t &Ln = *h->lanes[(size_t)lane_index];
+		for (;;) {
+			const uint32_t b = next_batch.fetch_add(1);
+			if (b >= n_batches) break;
+			std::unique_ptr<result_t> R;
+			{   // a result object from the pool: no more than n_lanes + 2 batches are ahead of the writer (their records and CIGARs are hundreds
+				// of megabytes each); the batch the writer waits for always gets one
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { return first_rc != BMH_OK || !pool.empty() || n_results < n_lanes + 2 || b == next_write; });
+				if (first_rc != BMH_OK) break;
+				if (!pool.empty()) { R = std::move(pool.back()); pool.pop_back(); }
+				else { R.reset(new result_t()); ++n_results; }
+			}
+			R->cigar_big.clear(); R->md_big.clear();
+			const uint32_t b0 = (uint32_t)cuts[b], b1 = (uint32_t)cuts[b + 1];
+			int rc = BMH_OK;
+			const double tb0 = now_s();
+			if (b1 > b0) rc = run_batch(A, Ln, *rs, b0, b1, paired != 0, n_threads, *R);
+			else { R->b0 = b0; R->n = 0; }
+			if (trace) fprintf(stderr, "[aligner] lane %d batch %u: %.1f .. %.1f ms\n", lane_index, b, (tb0 - t_start) * 1e3, (now_s() - t_start) * 1e3);
+			if (rc != BMH_OK) { fail(rc, bmh_last_error()); break; }
+			std::lock_guard<std::mutex> lk(mu);
+			done[b] = std::move(R);
+			cv.notify_all();
+		}
+		std::lock_guard<std::mutex> lk(mu);
+		for (int k = 0; k < 8; ++k) lane_t_sum[(size_t)k] += Ln.t[k];
+	};
+	double t_format = 0.0; uint64_t n_bytes = 0;
+	auto writer = [&]() {
+		std::vector<std::string> &parts = h->parts;                  // (kept with the aligner: their capacity is the text of a batch)
+		for (uint32_t b = 0; b < n_batches; ++b) {
+			std::unique_ptr<result_t> R;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { return first_rc != BMH_OK || done.count(b); });
+				if (first_rc != BMH_OK) return;
+				R = std::move(done[b]); done.erase(b);
+			}
+			if (R->n) {
+				const double t0 = now_s();
+				bmh_post_opt_t po = A.po; po.id0 = (int64_t)R->b0;
+				size_t len = 0;
+				const uint64_t a0 = rs->offs[R->b0];
+				std::vector<uint64_t> offs64(R->n), noff(R->n);
+				const uint64_t n0 = rs->name_offs[R->b0];
+				for (uint32_t r = 0; r < R->n; ++r) { offs64[r] = rs->offs[R->b0 + r] - a0; noff[r] = rs->name_offs[R->b0 + r] - n0; }
+				const bool ok = bmh_format_sam_parts(&po, R->n, (const char *)rs->names + n0, noff.data(), rs->codes + a0, offs64.data(), rs->lens + R->b0, A.n_contigs,
+				                                     A.name_ptr.data(), A.off.data(), R->fin.p, R->opr.p, R->slot.data(), R->aln.p, R->cigar_p, R->max_cigar, R->md_p, R->md_cap,
+				                                     paired ? R->h_rec.data() : nullptr, paired ? R->unflag.data() : nullptr, parts);
+				if (!ok) { fail(BMH_EINVAL, bmh_last_error()); return; }
+				t_format += now_s() - t0;
+				const double ts0 = now_s();
+				for (const std::string &part : parts) {
+					if (part.empty()) continue;
+					if (sink(user, part.data(), part.size()) != 0) { fail(BMH_EINVAL, "the sink refused the text"); return; }
+					n_bytes += part.size();
+				}
+				if (trace) fprintf(stderr, "[aligner] writer batch %u: format %.1f .. %.1f ms, sink .. %.1f\n", b, (t0 - t_start) * 1e3, (ts0 - t_start) * 1e3, (now_s() - t_start) * 1e3);
+			}
+			std::lock_guard<std::mutex> lk(mu);
+			next_write = b + 1;
+			pool.push_back(std::move(R));
+			cv.notify_all();
+		}
+	};
+	{
+		std::vector<std::thread> th;
+		for (int k = 0; k < n_lanes; ++k) th.emplace_back(worker, k);
+		std::thread wt(writer);
+		for (auto &t : th) t.join();
+		wt.join();
+	}
+	if (first_rc != BMH_OK) { bmh_set_error("%s", first_err.c_str()); return first_rc; }
+	if (stats) {
+		stats->n_reads = rs->n_reads; stats->n_bytes = n_bytes; stats->n_batches = n_batches; stats->n_lanes = n_lanes;
+		stats->seconds = now_s() - t_start; stats->format_seconds = t_format;
+		stats->h2d_seconds = lane_t_sum[0]; stats->seed_seconds = lane_t_sum[1]; stats->chain_extend_seconds = lane_t_sum[2]; stats->tail_seconds = lane_t_sum[3];
+		stats->select_seconds = lane_t_sum[4]; stats->cigar_seconds = lane_t_sum[5];
+	}
+	return BMH_OK;
+}
+
+}   // extern "C"

@@ -27,6 +27,15 @@ int bmh_extend_batch_desc(const bmh_ext_desc_t *desc, const uint32_t *d_qlen, co
 int bmh_extend_reserve(void *stream, uint64_t n);
 
 #ifdef __cplusplus
+#include <string>
+#include <vector>
+// bmh_format_sam / bmh_format_sam_pe (h_rec, unflag: the pairs' arrays, NULL for single-end reads) as the parts the formatting threads
+// made, in order; `parts` is reused by the caller (csrc/sam_format.cpp, csrc/align_pipeline.hip)
+bool bmh_format_sam_parts(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,
+                          const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
+                          const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
+                          const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap,
+                          const int32_t *h_rec, const int32_t *unflag, std::vector<std::string> &parts);
 extern "C" {
 #endif
 void bmh_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));

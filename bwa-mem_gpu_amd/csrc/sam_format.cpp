@@ -107,11 +107,13 @@ extern "C" int64_t bmh_sam_need_cigar(const bmh_post_opt_t *po, const int32_t *f
 // names: the read names, NUL-terminated, back to back; name_off[r] = start of read r's name.  contig_names: array of C
 // strings.  reads: nt4 codes.  h_rec / unflag: NULL for single-end reads; for interleaved
 // pairs the outputs of bmh_finalize_pairs (own-alignment record per read, flags of the unmapped record).
-static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,
-                        const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
-                        const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
-                        const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap,
-                        const int32_t *h_rec, const int32_t *unflag, size_t *len_out)
+// the text as the parts its formatting threads made, in order (`parts` is the caller's: a caller that formats batch after batch keeps
+// the strings, whose capacity survives clear(), so that no quarter-gigabyte buffer is allocated, faulted in and unmapped per batch)
+bool bmh_format_sam_parts(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,
+                          const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
+                          const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
+                          const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap,
+                          const int32_t *h_rec, const int32_t *unflag, std::vector<std::string> &parts)
 {
 	std::vector<uint64_t> bases((size_t)n_reads + 1, 0);
 	for (uint32_t r = 0; r < n_reads; ++r) bases[r + 1] = bases[r] + fin_per_read[r];
@@ -126,7 +128,8 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 	unsigned n_thr = n_reads >= 8192 ? std::thread::hardware_concurrency() : 1;
 	if (n_thr < 1) n_thr = 1;
 	if (n_thr > 64) n_thr = 64;
-	std::vector<std::string> parts(n_thr);
+	if (parts.size() < n_thr) parts.resize(n_thr);
+	for (std::string &p : parts) p.clear();
 	std::vector<int> failed(n_thr, 0);
 	auto work = [&](unsigned t) {
 	std::string &out = parts[t];
@@ -263,16 +266,29 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
 	if (n_thr == 1) work(0);
 	else { std::vector<std::thread> th; for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(work, t); for (auto &x : th) x.join(); }
 	for (unsigned t = 0; t < n_thr; ++t)
-		if (failed[t]) { if (n_thr > 1) bmh_set_error("bmh_format_sam: a record the text needs has no CIGAR (see bmh_sam_need_cigar)"); return nullptr; }
+		if (failed[t]) { if (n_thr > 1) bmh_set_error("bmh_format_sam: a record the text needs has no CIGAR (see bmh_sam_need_cigar)"); return false; }
+	return true;
+}
+
+static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,
+                        const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
+                        const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
+                        const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap,
+                        const int32_t *h_rec, const int32_t *unflag, size_t *len_out)
+{
+	std::vector<std::string> parts;
+	if (!bmh_format_sam_parts(po, n_reads, names, name_off, reads, read_offs, read_lens, n_contigs, contig_names, contig_offset, fin, fin_per_read, slot, aln, cigar, max_cigar,
+	                          md, md_cap, h_rec, unflag, parts)) return nullptr;
+	const unsigned n_thr = (unsigned)parts.size();
 	size_t total = 0;
 	for (const std::string &p : parts) total += p.size();
 	char *res = (char *)malloc(total + 1);
 	if (!res) { bmh_set_error("bmh_format_sam: out of memory"); return nullptr; }
-	{   // the parts into their places, on the same threads (the text of a million reads is a quarter of a gigabyte)
-		std::vector<size_t> at(n_thr, 0);
+	{   // the parts into their places, on as many threads (the text of a million reads is a quarter of a gigabyte)
+		std::vector<size_t> at(n_thr ? n_thr : 1, 0);
 		for (unsigned t = 1; t < n_thr; ++t) at[t] = at[t - 1] + parts[t - 1].size();
 		auto put = [&](unsigned t) { memcpy(res + at[t], parts[t].data(), parts[t].size()); std::string().swap(parts[t]); };
-		if (n_thr == 1) put(0);
+		if (n_thr <= 1) { if (n_thr) put(0); }
 		else { std::vector<std::thread> th; for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(put, t); for (auto &x : th) x.join(); }
 	}
 	res[total] = 0;

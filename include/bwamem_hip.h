@@ -468,6 +468,34 @@ int bmh_cigar_batch(const bmh_index_t *idx, const uint8_t *d_reads, const uint32
                     const int32_t *d_regs, int reg_stride, const uint32_t *d_sel, uint32_t n, const bmh_ext_params_t *p, int opt_w,
                     int max_cigar, uint32_t *d_cigar, int32_t *d_aln, int md_cap, char *d_md, void *stream);
 
+/* ------------------------------------------------- reads in host memory -> SAM text, batches driven by C threads (csrc/align_pipeline.hip)
+ *
+ * What gase_aln's worker threads do around the device libraries (src/bwamem.c:2042-2340, src/fastmap.c:59-120), on top of the entry
+ * points above: n_lanes worker threads take the batches [cuts[b], cuts[b+1]) of the read set in turn -- each with its own stream,
+ * workspaces and pinned staging: H2D, seeding, chaining, extension, merge, the region tail (on the device for single-end batches; the
+ * host forms for interleaved pairs, for an index with ALT contigs and for a batch the device tail refuses), CIGARs, D2H -- and ONE
+ * writer thread formats the finished batches in order and hands every batch's text to `sink` (return 0 to go on) while the workers
+ * are on the next ones.  The text is what bmh_format_sam / bmh_format_sam_pe write (records only: the caller writes the @SQ header).
+ * cuts: n_batches + 1 read indices, cuts[0] = 0, cuts[n_batches] = n_reads, even batch sizes when paired (the reference cuts its
+ * batches by bases, bseq_read src/bwa.c:48-66, and the insert-size statistics are those of a batch).  popt->id0 is ignored (a batch's
+ * id0 is its first read).  Reads longer than 700 bases: BMH_EINVAL (the device job builder's limit; such a set goes through
+ * bmh_build_jobs).  n_threads: host threads of the host forms (<= 0: all).  The aligner borrows idx and pac: both outlive it. */
+int bmh_effective_cpus(void);      /* CPUs this process may use: affinity mask capped by the cgroup quota (what n_threads <= 0 resolves to) */
+typedef struct bmh_aligner bmh_aligner_t;
+typedef int (*bmh_sam_sink_t)(void *user, const char *text, size_t len);
+typedef struct {
+	uint64_t n_reads, n_bytes; uint32_t n_batches; int n_lanes;
+	double seconds;                 /* wall clock of the run */
+	double format_seconds;          /* in the writer thread (overlaps the workers) */
+	double h2d_seconds, seed_seconds, chain_extend_seconds, tail_seconds, select_seconds, cigar_seconds;    /* summed over the lanes' host clocks */
+} bmh_align_stats_t;
+bmh_aligner_t *bmh_aligner_create(const bmh_index_t *idx, const uint8_t *pac, int64_t l_pac, int n_contigs, const char *const *contig_names,
+                                  const int32_t *contig_len, const uint8_t *contig_is_alt, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep,
+                                  const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe);
+void bmh_aligner_free(bmh_aligner_t *a);
+int bmh_aligner_run(bmh_aligner_t *a, const bmh_read_set_t *reads, const uint64_t *cuts, uint32_t n_batches, int paired, int n_lanes, int n_threads,
+                    bmh_sam_sink_t sink, void *user, bmh_align_stats_t *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,3 +43,9 @@ for it in range(2):
     al.align_file(fa, sink, batch_reads=n_reads // 4, paired=pe)
     dt = time.perf_counter() - t0
     print("%s: align_file, %d reads in 4 batches, FASTA on disk -> %d bytes of SAM: %.1f ms = %.2f Mreads/s" % ("PE" if pe else "SE", n_reads, sink.n, dt * 1e3, n_reads / dt / 1e6), flush=True)
+    st = getattr(al, "last_stats", None)
+    if st is not None:
+        print("   native pipeline: %.1f ms for %d reads in %d batches on %d lanes = %.2f Mreads/s (reads in host memory -> text handed to the sink); writer: format %.1f ms; "
+              "lanes (summed): H2D %.1f, seeding %.1f, chain+extend+merge %.1f, tail %.1f, select %.1f, CIGAR + D2H %.1f ms" %
+              (st.seconds * 1e3, st.n_reads, st.n_batches, st.n_lanes, st.n_reads / st.seconds / 1e6, st.format_seconds * 1e3, st.h2d_seconds * 1e3, st.seed_seconds * 1e3,
+               st.chain_extend_seconds * 1e3, st.tail_seconds * 1e3, st.select_seconds * 1e3, st.cigar_seconds * 1e3), flush=True)

@@ -15,6 +15,7 @@ def _declared_functions(header: str):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"typedef\s+[^;{}()]*\(\s*\*\s*\w+\s*\)\s*\([^;{}]*\)\s*;", "", src)      # function-pointer typedefs are not functions
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", src)
     return sorted(set(n for n in names if n not in ("defined", "__attribute__")))
 

@@ -43,7 +43,7 @@ from bwamem_hip.parallel import broadcast_built_index, shard_range  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz: a wave64 instruction issues in 2 cycles (MI355X_MICROARCH.md)
 CACHE_VERSION = "v3"          # bump when synth.make_genome_device or the index layout changes
-PROFILE_TAG = "r03"          # profiles/<tag>_pmc*.json: counters collected by scripts/profile_round.sh with this same command (one file per workload)
+PROFILE_TAG = "r04"          # profiles/<tag>_pmc*.json: counters collected by scripts/profile_round.sh with this same command (one file per workload)
 
 
 def profile_counters(workload_key: str):

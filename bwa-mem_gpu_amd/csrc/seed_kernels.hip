@@ -328,12 +328,13 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 	const int seg_end = lane + __builtin_ctzll(segb >> lane);      // >= lane, bit 63 is always set
 	const unsigned long long above = seg_end > lane ? ((~0ull >> (63 - (seg_end - lane - 1))) << 1 << lane) : 0ull;  // lanes lane+1..seg_end
 	uint32_t size = c.s;
+	unsigned st_mine = 0;                                  // (stats) rank steps of this lane's candidate
 	unsigned st_iter = 0, st_steps = 0, st_uniq = 0, st_u0 = (!RESUME && live && i >= 0 && c.s == 1) ? 1u : 0u, st_x0 = (!RESUME && live && i < 0) ? 1u : 0u;
 	// the read's packed words are re-fetched only when the walk crosses into the next one (16 / 32 bases)
 	uint32_t rw = 0, rm = 0;
 	if (act) { rw = rv.pk[(size_t)(i >> 4) * rv.n_reads + c.read]; rm = rv.nm[(size_t)(i >> 5) * rv.n_reads + c.read]; }
 	for (int it = 0; it < max_iter && __any(act); ++it) {
-		if (stats) { ++st_iter; st_steps += act ? 1u : 0u; st_uniq += (act && size == 1) ? 1u : 0u; }
+		if (stats) { ++st_iter; st_steps += act ? 1u : 0u; st_mine += act ? 1u : 0u; st_uniq += (act && size == 1) ? 1u : 0u; }
 		if (act) {
 			const int b = (int)((rw >> ((i & 15) << 1)) & 3);
 			const bool isn = (rm >> (i & 31)) & 1;
@@ -358,6 +359,7 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 		if (act && am && nsize == size) { act = false; dropped = true; }
 	}
 	if (stats) {
+		if (live && !RESUME) atomicAdd(stats + 8 + (st_mine < 39u ? st_mine : 39u), 1ull);      // histogram of rank steps per candidate (0 .. 38, 39+)
 		atomicAdd(stats + 1, (unsigned long long)st_steps); atomicAdd(stats + 4, (unsigned long long)st_uniq); atomicAdd(stats + 5, (unsigned long long)st_u0); atomicAdd(stats + 6, (unsigned long long)st_x0); { const bool nowalk = !__any(live && !st_x0); if (!RESUME && lane == 0 && nowalk) atomicAdd(stats + 7, 1ull); }
 		if (lane == 0) { atomicAdd(stats, (unsigned long long)st_iter); atomicAdd(stats + 2, 1ull); atomicMax(stats + 3, (unsigned long long)st_iter); }
 	}
@@ -773,7 +775,7 @@ extern "C" bmh_seed_ws_t *bmh_seed_ws_create(uint32_t max_reads, uint64_t max_ba
 	A(w->occ_off, 8 * (w->max_cands + 1));
 	A(w->rows, 8 * w->max_occ); A(w->qbeg, 8 * w->max_occ); A(w->score, 4 * w->max_occ);
 	A(w->n_ref_pos, 4 * (size_t)max_reads); A(w->prefix, 4 * (size_t)max_reads);
-	A(w->counter, 128);
+	A(w->counter, 1024);
 	A(w->bwd_cnt, 4 * 8 * BWD_NSUB);
 	A(w->skeys, 8 * w->max_cands); A(w->skeys2, 8 * w->max_cands); A(w->svals, 4 * w->max_cands); A(w->svals2, 4 * w->max_cands);
 	size_t t1 = 0, t2 = 0, t3 = 0;
@@ -970,7 +972,7 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 	{
 		static const bool want_stats = getenv("BMH_SEED_STATS") != nullptr;
 		unsigned long long *d_st = want_stats ? (unsigned long long *)w->counter + 8 : nullptr;
-		if (want_stats) HIPCK(hipMemsetAsync(d_st, 0, 64, st));
+		if (want_stats) HIPCK(hipMemsetAsync(d_st, 0, 64 + 40 * 8, st));
 		if (n_cands) {
 			// phases of the walk (BMH_SEED_BWD_PHASES="k1,k2,..": steps per phase, the last phase runs to the end).  Default: one launch --
 			// measured on the bench workload, "6,12,24,48" takes the wave-iterations from 14.7 M to 9.2 M (lane utilisation 38.5 -> 61.7 %)
@@ -995,9 +997,12 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 				                                                                       ph < np ? cnt + (size_t)ph * BWD_NSUB : nullptr, sub_cap, ph < np ? phases[ph] : big);
 		}
 		if (want_stats) {
-			unsigned long long h[8];
+			unsigned long long h[48];
 			HIPCK(hipStreamSynchronize(st));
-			HIPCK(hipMemcpy(h, d_st, 64, hipMemcpyDeviceToHost));
+			HIPCK(hipMemcpy(h, d_st, 64 + 40 * 8, hipMemcpyDeviceToHost));
+			fprintf(stderr, "[backward] rank steps per candidate (0, 1, .. 38, 39+):");
+			for (int q = 0; q < 40; ++q) fprintf(stderr, " %llu", h[8 + q]);
+			fprintf(stderr, "\n");
 			fprintf(stderr, "[backward] lane-steps on a one-row interval %llu (%.1f%%), candidates that start on one %llu (%.1f%%)\n", h[4], 100.0 * h[4] / (h[1] ? h[1] : 1), h[5], 100.0 * h[5] / (n_cands ? n_cands : 1));
 			fprintf(stderr, "[backward] candidates of a pass that starts at read position 0 (no walk) %llu (%.1f%%); waves made of such only %llu\n", h[6], 100.0 * h[6] / (n_cands ? n_cands : 1), h[7]);
 			fprintf(stderr, "[backward] candidates %llu, waves %llu (all phases), wave-iterations %llu (%.1f per wave, max %llu), lane-steps %llu (%.1f per candidate): lane utilisation %.1f%%\n",
@@ -1042,14 +1047,20 @@ extern "C" int bmh_seed_batch(bmh_seed_ws_t *w, const bmh_index_t *idx, const ui
 // pattern (MI355X_MICROARCH.md, HBM: the counter is only calibrated for wide streams) and (b) to
 // measure the practical ceiling of random block gathers that the seeding kernels are held against.
 // dependent != 0 chains each address on the previous block's contents, like a rank walk.
+// dependent bits 8..: the gather's width in 32-byte blocks (0 or 1: one block; 2: an aligned 64-byte pair; 4: an aligned 128-byte line) --
+// does the chip pay for random REQUESTS or for the bytes they move?  (what a wider rank block would cost)
 __global__ void __launch_bounds__(256) calib_gather_kernel(fmd_dev_t f, uint64_t n_blocks, int iters, int dependent, uint32_t *sink)
 {
 	uint64_t x = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
 	uint32_t acc = 0;
+	const int width = (dependent >> 8) > 1 ? (dependent >> 8) : 1;
+	dependent &= 1;
 	for (int i = 0; i < iters; ++i) {
 		x = x * 6364136223846793005ull + 1442695040888963407ull;
-		blk_t b = fmd_load_block(f, (x >> 20) % n_blocks);
+		const uint64_t b0 = ((x >> 20) % n_blocks) & ~(uint64_t)(width - 1);
+		blk_t b = fmd_load_block(f, b0);
 		acc += b.occ.x ^ (uint32_t)(b.hi >> 32);
+		for (int w = 1; w < width; ++w) { const blk_t c = fmd_load_block(f, b0 + (uint64_t)w); acc += c.occ.x ^ (uint32_t)(c.hi >> 32); }
 		if (dependent) x ^= (uint64_t)(b.occ.y + (uint32_t)b.lo) << 24;
 	}
 	if (acc == 0x12345678u) sink[0] = acc;    // keeps the loads alive
@@ -1063,7 +1074,7 @@ extern "C" int bmh_calib_gather(const bmh_index_t *idx, uint64_t n_lanes, int it
 	static thread_local uint32_t *sink = nullptr;
 	static thread_local hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (!sink) { HIPCK(hipMalloc((void **)&sink, 64)); HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1)); }
-	const uint64_t n_blocks = (idx->dev.seq_len + 63) / 64;
+	const uint64_t n_blocks = ((idx->dev.seq_len + 63) / 64) & ~3ull;
 	HIPCK(hipEventRecord(e0, st));
 	calib_gather_kernel<<<nblk(n_lanes, 256), 256, 0, st>>>(idx->dev, n_blocks, iters, dependent, sink);
 	HIPCK(hipEventRecord(e1, st));

@@ -17,6 +17,14 @@ L2 = np.array([0, gs // 2, gs, gs + gs // 2, 2 * gs], dtype=np.uint64)
 idx = B.Index.from_device(12345, L2, 2 * gs, bwt, 16, sa, bits)
 L = B.load_library()
 ms = C.c_float()
+gs_note = "(index of %.1f GB)" % (nblk * 32 / 1e9)
+# the width sweep (round 4): random requests of 32 / 64 / 128 aligned bytes -- is the ceiling in requests or in bytes?
+for width in (1, 2, 4):
+    lanes, iters = 1 << 22, 64
+    for _ in range(2):
+        L.bmh_calib_gather(idx.handle, lanes, iters, 1 | (width << 8), None, C.byref(ms))
+    n = lanes * iters
+    print(f"dependent gathers of {32 * width:3d} aligned bytes {gs_note}: {ms.value:.3f} ms, {n/ms.value/1e6:.1f} G requests/s, {n*32*width/ms.value/1e6:.0f} GB/s requested", flush=True)
 for dep in (0, 1):
     for lanes, iters in ((1 << 20, 128), (1 << 22, 64), (1 << 23, 32)):
         L.bmh_calib_gather(idx.handle, lanes, iters, dep, None, C.byref(ms))  # warm

@@ -775,7 +775,40 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
         torch.cuda.synchronize(); t0 = time.perf_counter()
         cg, aln, md = cigar_batch(dindex, dr.ascii, dr.offs, dr.lens, out_t, len(sel), sel_t=sel_t, params=params, max_cigar=24, md_cap=128)
         torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
-    return {**(dev_row if not paired else {}), name: dict({"ms": round(t_fin * 1e3, 2), "threads": nth, "regions_in": int(n_regs), "regions_out": int(m), "d2h_regions_ms": round(t_d2h * 1e3, 2)}, **extra),
+    # reads in host memory -> SAM text through the native pipeline (bmh_aligner_run: batches driven by C threads): the whole gase_aln run on this batch,
+    # cut into four batches so that the two lanes and the writer overlap; second of two runs (the first one allocates lanes, workspaces and pinned buffers)
+    sam_row = {}
+    try:
+        from bwamem_hip.aligner import ReadSet
+        from bwamem_hip.lib import NativeAligner, PeOpt
+        pe_o = PeOpt(); L.bmh_pe_opt_default(C.byref(pe_o))
+        asc = B.synth.codes_to_ascii(flat)
+        w = len(str(n_reads))
+        names = np.char.add("r", np.char.zfill((np.arange(n_reads) // (2 if paired else 1)).astype(str), w))
+        blob = np.frombuffer(("\0".join(names.tolist()) + "\0").encode(), dtype=np.uint8)
+        noff = np.arange(n_reads, dtype=np.uint64) * np.uint64(w + 2)
+        rs = ReadSet(asc, offs, np.full(n_reads, rl, np.uint32), blob, noff, codes=flat)
+        q4 = (n_reads // 4) & ~1
+        cuts4 = [0, q4, 2 * q4, 3 * q4, n_reads]
+        nat = NativeAligner(dindex, pac_h, len(g), contigs, None, co, params, po, pe_o)
+        nbytes = [0]
+
+        def sink(mv):
+            nbytes[0] += len(mv)
+        st_n = None
+        for _ in range(2):
+            nbytes[0] = 0
+            st_n = nat.run(rs, cuts4, paired, sink, n_lanes=int(os.environ.get("BENCH_SAM_LANES", "2")), n_threads=nth)
+        nat.free()
+        sam_row = {"reads_to_sam_native": {"Mreads_per_s": round(n_reads / st_n.seconds / 1e6, 2), "ms": round(st_n.seconds * 1e3, 1), "sam_bytes": int(nbytes[0]), "batches": 4, "lanes": 2,
+                                           "writer_format_ms": round(st_n.format_seconds * 1e3, 1),
+                                           "lanes_ms_summed": {"h2d": round(st_n.h2d_seconds * 1e3, 1), "seeding": round(st_n.seed_seconds * 1e3, 1), "chain_extend_merge": round(st_n.chain_extend_seconds * 1e3, 1),
+                                                               "tail": round(st_n.tail_seconds * 1e3, 1), "select": round(st_n.select_seconds * 1e3, 1), "cigar_d2h": round(st_n.cigar_seconds * 1e3, 1)},
+                                           "what": "bmh_aligner_run: ASCII reads in host memory -> H2D -> seeding -> chaining -> extension -> merge -> region tail -> CIGAR / NM / MD -> D2H -> SAM "
+                                                   "records formatted by the writer thread (text handed to a sink that counts it); the same text the golden SAM tests compare with the reference's"}}
+    except Exception as e:                                  # noqa: BLE001 -- an extra, never at the expense of the line
+        sam_row = {"reads_to_sam_native": {"error": repr(e)}}
+    return {**(dev_row if not paired else {}), **sam_row, name: dict({"ms": round(t_fin * 1e3, 2), "threads": nth, "regions_in": int(n_regs), "regions_out": int(m), "d2h_regions_ms": round(t_d2h * 1e3, 2)}, **extra),
             "cigar_batch_device": {"ms": round(min(ms), 3), "alignments": int(len(sel)), "M_alignments_per_s": round(len(sel) / (min(ms) * 1e-3) / 1e6, 1),
                                    "flagged": int((aln[:, 7].cpu().numpy() & ~2 != 0).sum())}}
 

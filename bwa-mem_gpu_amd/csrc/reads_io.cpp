@@ -3,6 +3,10 @@
 // into the flat arrays the device path takes: letters back to back (what goes to HBM), nt4 codes (nst_nt4_table: what the host
 // tail and the SAM text use), offsets, lengths, names (the header up to the first blank, NUL-terminated, back to back).
 // Two passes over the file in memory, both on host threads: count per chunk, then fill at the chunk's offsets.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -73,25 +77,25 @@ extern "C" int bmh_reads_load_fasta(const char *path, int n_threads, bmh_read_se
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t) { if (prof) { const auto n = now(); fprintf(stderr, "[reads_io] %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count()); t = n; } };
 	auto tp = now();
-	FILE *fp = fopen(path, "rb");
-	if (!fp) { bmh_set_error("bmh_reads_load_fasta: cannot open %s", path); return BMH_EINVAL; }
-	// the file is read whole and cut at headers by several threads: it has to be a regular, seekable file (a FIFO or a process
-	// substitution makes ftello return -1)
-	off_t fsz = -1;
-	if (fseeko(fp, 0, SEEK_END) != 0 || (fsz = ftello(fp)) < 0 || fseeko(fp, 0, SEEK_SET) != 0) {
-		fclose(fp);
-		bmh_set_error("bmh_reads_load_fasta: %s is not a regular, seekable file", path);
-		return BMH_EINVAL;
+	// the file is mapped, not copied (its pages come straight from the page cache; the two passes below read it on host threads); it has to be
+	// a regular file (a FIFO or a process substitution cannot be mapped or cut at headers)
+	const int fd = open(path, O_RDONLY);
+	if (fd < 0) { bmh_set_error("bmh_reads_load_fasta: cannot open %s", path); return BMH_EINVAL; }
+	struct stat sb;
+	if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { close(fd); bmh_set_error("bmh_reads_load_fasta: %s is not a regular, seekable file", path); return BMH_EINVAL; }
+	const size_t sz = (size_t)sb.st_size;
+	const uint8_t *buf = (const uint8_t *)"";
+	if (sz) {
+		void *m = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+		if (m == MAP_FAILED) { close(fd); bmh_set_error("bmh_reads_load_fasta: cannot map %s (%zu bytes)", path, sz); return BMH_ENOMEM; }
+		(void)madvise(m, sz, MADV_SEQUENTIAL);
+		buf = (const uint8_t *)m;
 	}
-	const size_t sz = (size_t)fsz;
-	uint8_t *buf = (uint8_t *)malloc(sz + 1);
-	if (!buf) { fclose(fp); bmh_set_error("bmh_reads_load_fasta: out of memory (%zu bytes)", sz); return BMH_ENOMEM; }
-	const size_t got = sz ? fread(buf, 1, sz, fp) : 0;
-	fclose(fp);
-	if (got != sz) { free(buf); bmh_set_error("bmh_reads_load_fasta: short read of %s", path); return BMH_EINVAL; }
+	close(fd);
+	auto unmap = [&]() { if (sz) (void)munmap((void *)buf, sz); };
 	lap("read", tp);
 	// chunks that begin at a header: the first '>' that follows a newline at or behind the nominal cut
-	unsigned T = n_threads > 0 ? (unsigned)n_threads : std::thread::hardware_concurrency();
+	unsigned T = n_threads > 0 ? (unsigned)n_threads : (unsigned)bmh_effective_cpus();      // (the CPUs the process is granted, not the ones the machine shows)
 	if (T == 0) T = 1;
 	if (T > 32) T = 32;                                    // (memory-bound beyond a few threads; the host may show hundreds of hardware threads)
 	if (sz < (1u << 20)) T = 1;
@@ -122,7 +126,7 @@ extern "C" int bmh_reads_load_fasta(const char *path, int n_threads, bmh_read_se
 	std::vector<uint64_t> r0(T), b0(T), n0(T);
 	for (unsigned t = 0; t < T; ++t) {
 		if (cnt[t].bad) {
-			free(buf);
+			unmap();
 			bmh_set_error(cnt[t].bad == 2 ? "bmh_reads_load_fasta: a sequence line of 2^32 bases or more" : "reads file: expected alternating '>' header and sequence lines");
 			return BMH_EINVAL;
 		}
@@ -130,18 +134,20 @@ extern "C" int bmh_reads_load_fasta(const char *path, int n_threads, bmh_read_se
 		nr += cnt[t].reads; nb += cnt[t].bases; nn += cnt[t].name_bytes;
 	}
 	out->n_reads = nr; out->n_bases = nb; out->n_name_bytes = nn;
+	// (no MADV_HUGEPAGE on the two large arrays: with the kernel's defrag = madvise the fill pass sometimes stalled for a second in
+	// direct compaction -- 60 ms or 1.7 s from one call to the next)
 	out->ascii = (uint8_t *)malloc(nb + 1); out->codes = (uint8_t *)malloc(nb + 1);
 	out->offs = (uint64_t *)malloc(8 * (nr + 1)); out->lens = (uint32_t *)malloc(4 * (nr + 1));
 	out->names = (uint8_t *)malloc(nn + 1); out->name_offs = (uint64_t *)malloc(8 * (nr + 1));
 	if (!out->ascii || !out->codes || !out->offs || !out->lens || !out->names || !out->name_offs) {
-		free(buf); bmh_reads_free(out);
+		unmap(); bmh_reads_free(out);
 		bmh_set_error("bmh_reads_load_fasta: out of memory"); return BMH_ENOMEM;
 	}
 	out->ascii[nb] = out->codes[nb] = 0; out->names[nn] = 0;
 	lap("alloc", tp);
 	run([&](unsigned t) { counts_t c; walk<true>(buf, cut[t], cut[t + 1], c, out, r0[t], b0[t], n0[t]); });
 	lap("fill", tp);
-	free(buf);
+	unmap();
 	return BMH_OK;
 }
 

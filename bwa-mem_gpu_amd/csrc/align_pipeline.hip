@@ -459,6 +459,7 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 		for (auto &t : th) t.join();
 		wt.join();
 	}
+	n_results = (int)pool.size();                                   // (after a failed run the results that were in flight are gone)
 	if (first_rc != BMH_OK) { bmh_set_error("%s", first_err.c_str()); return first_rc; }
 	if (stats) {
 		stats->n_reads = rs->n_reads; stats->n_bytes = n_bytes; stats->n_batches = n_batches; stats->n_lanes = n_lanes;

@@ -161,13 +161,16 @@ extern "C" int bmh_index_broadcast_rccl(void *comm_, int root, const bmh_index_t
 		h.magic = 0x424d48494458ull; h.primary = f.primary; memcpy(h.L2, f.L2, sizeof(h.L2)); h.seq_len = f.seq_len; h.n_sa = f.n_sa; h.l_pac = f.l_pac;
 		h.n_words = src->n_words; h.sa_shift = f.sa_shift; h.has_pac = f.pac != nullptr;
 	}
-	void *d_hdr = nullptr;
-	HCK(hipMalloc(&d_hdr, sizeof(h)));
-	HCK(hipMemcpyAsync(d_hdr, &h, sizeof(h), hipMemcpyHostToDevice, st));
-	NCK(R->Broadcast(d_hdr, d_hdr, sizeof(h), ncclUint8, root, comm, st));
-	HCK(hipMemcpyAsync(&h, d_hdr, sizeof(h), hipMemcpyDeviceToHost, st));
-	HCK(hipStreamSynchronize(st));
-	(void)hipFree(d_hdr);
+	{
+		void *d_hdr = nullptr;
+		HCK(hipMalloc(&d_hdr, sizeof(h)));
+		bool ok = hipMemcpyAsync(d_hdr, &h, sizeof(h), hipMemcpyHostToDevice, st) == hipSuccess;
+		ncclResult_t nr = ncclSuccess;
+		if (ok) { nr = R->Broadcast(d_hdr, d_hdr, sizeof(h), ncclUint8, root, comm, st); ok = nr == ncclSuccess; }
+		ok = ok && hipMemcpyAsync(&h, d_hdr, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+		(void)hipFree(d_hdr);
+		if (!ok) { bmh_set_error("bmh_index_broadcast_rccl: header: %s", nr != ncclSuccess ? R->GetErrorString(nr) : hipGetErrorString(hipGetLastError())); return BMH_ENODEV; }
+	}
 	if (h.magic != 0x424d48494458ull) { bmh_set_error("bmh_index_broadcast_rccl: bad header from rank %d", root); return BMH_EINVAL; }
 	// ---- arrays
 	fmd_dev_t f; memset(&f, 0, sizeof(f));
@@ -182,7 +185,11 @@ extern "C" int bmh_index_broadcast_rccl(void *comm_, int root, const bmh_index_t
 				for (int q = 0; q < k; ++q) (void)hipFree(d[q]);
 				return BMH_ENOMEM;
 			}
-		if (d[3]) HCK(hipMemsetAsync(d[3], 0, ab.bytes[3], st));          // (the text is read in aligned words past its last byte)
+		if (d[3] && hipMemsetAsync(d[3], 0, ab.bytes[3], st) != hipSuccess) {       // (the text is read in aligned words past its last byte)
+			bmh_set_error("bmh_index_broadcast_rccl: %s", hipGetErrorString(hipGetLastError()));
+			for (int k = 0; k < 4; ++k) if (d[k]) (void)hipFree(d[k]);
+			return BMH_ENODEV;
+		}
 	}
 	const void *s[4] = {nullptr, nullptr, nullptr, nullptr};
 	if (is_root) { s[0] = src->dev.blocks; s[1] = src->dev.sa; s[2] = src->dev.sa_bits; s[3] = src->dev.pac; }

@@ -104,6 +104,7 @@ struct result_t {
 	std::vector<int32_t> h_rec, unflag;          // pairs
 	std::vector<uint32_t> cigar_big; std::vector<char> md_big;     // only when an alignment overflowed the compact buffers
 	const uint32_t *cigar_p = nullptr; const char *md_p = nullptr;
+	std::vector<uint32_t> dev_index;             // record -> its place in the lane's d_fin when that is not the record's own index (ALT indexes); empty: identity
 };
 
 struct lane_t {
@@ -166,11 +167,81 @@ int cigars(const aligner_t &A, lane_t &Ln, const int32_t *d_fin, const uint32_t 
 	return BMH_OK;
 }
 
+// An index with ALT contigs, single-end: the device tail has run as if there were none.  A read WITHOUT a hit on an ALT contig comes out of
+// mem_mark_primary_se exactly as without the table (n_pri == n: one marking round, secondary_all = secondary, src/bwamem.c:714-760), so only the
+// reads that have one are redone on the host, from their regions, with the table -- same number of records (mem_sort_dedup_patch does not look at
+// is_alt), written over the device's; their copies for the CIGAR stage are appended behind the m records of d_fin (dev_index).
+int patch_alt_reads(const aligner_t &A, lane_t &Ln, const bmh_dev_jobs_t &dj, const bmh_post_opt_t &po, const uint8_t *codes, const uint64_t *offs64,
+                    uint32_t n, uint64_t nr, uint64_t m, int n_threads, result_t &R)
+{
+	RCK(Ln.h_regs.need(8 * (nr + 1))); RCK(Ln.h_rpr.need(n + 1)); RCK(Ln.h_fr.need(n + 1));
+	if (nr) LCK(hipMemcpyAsync(Ln.h_regs.p, Ln.d_regs.p, 32 * (size_t)nr, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipMemcpyAsync(Ln.h_rpr.p, dj.d_regs_per_read, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipMemcpyAsync(Ln.h_fr.p, dj.d_frac_rep, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipStreamSynchronize(Ln.st));
+	std::vector<uint64_t> rec_off((size_t)n + 1, 0), reg_off((size_t)n + 1, 0);
+	for (uint32_t r = 0; r < n; ++r) { rec_off[r + 1] = rec_off[r] + R.opr.p[r]; reg_off[r + 1] = reg_off[r] + Ln.h_rpr.p[r]; }
+	if (rec_off[n] != m || reg_off[n] != nr) { bmh_set_error("bmh_aligner_run: internal error: record / region counts do not add up"); return BMH_EINVAL; }
+	auto on_alt = [&](const int32_t *q) {
+		const int64_t rb = (int64_t)(uint32_t)q[4] | (int64_t)q[5] << 32, re = (int64_t)(uint32_t)q[6] | (int64_t)q[7] << 32;
+		const int64_t pos = rb < A.l_pac ? rb : (A.l_pac << 1) - 1 - (re - 1);
+		int lo = 0, hi = A.n_contigs;
+		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.off[(size_t)mid] <= pos) lo = mid; else hi = mid; }
+		return A.alt[(size_t)lo] != 0;
+	};
+	const int T = n >= 65536 ? (n_threads < 8 ? n_threads : 8) : 1;
+	std::vector<std::vector<uint32_t>> part((size_t)T);
+	auto scan = [&](int t) {
+		const uint32_t r0 = (uint32_t)((uint64_t)n * t / T), r1 = (uint32_t)((uint64_t)n * (t + 1) / T);
+		for (uint32_t r = r0; r < r1; ++r) {
+			bool any = false;
+			for (uint64_t k = rec_off[r]; k < rec_off[r + 1] && !any; ++k) any = on_alt(R.fin.p + 16 * k);
+			if (any) part[(size_t)t].push_back(r);
+			else for (uint64_t k = rec_off[r]; k < rec_off[r + 1]; ++k) R.fin.p[16 * k + 11] = R.fin.p[16 * k + 12];      // the ALT-mode record: [11] = secondary_all (= secondary here)
+		}
+	};
+	if (T == 1) scan(0);
+	else { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(scan, t); for (auto &x : th) x.join(); }
+	std::vector<uint32_t> ids;
+	for (const auto &v : part) ids.insert(ids.end(), v.begin(), v.end());
+	R.dev_index.clear();
+	if (ids.empty()) return BMH_OK;
+	const uint32_t ns = (uint32_t)ids.size();
+	std::vector<uint32_t> sub_rpr(ns); std::vector<float> sub_fr(ns); std::vector<uint64_t> sub_offs(ns);
+	uint64_t n_sub_regs = 0, n_sub_recs = 0;
+	for (uint32_t j = 0; j < ns; ++j) { const uint32_t r = ids[j]; sub_rpr[j] = Ln.h_rpr.p[r]; sub_fr[j] = Ln.h_fr.p[r]; sub_offs[j] = offs64[r]; n_sub_regs += sub_rpr[j]; n_sub_recs += R.opr.p[r]; }
+	std::vector<int32_t> sub_regs(8 * (size_t)(n_sub_regs + 1)), sub_out(16 * (size_t)(n_sub_regs + 1));
+	std::vector<uint32_t> sub_opr(ns);
+	{
+		uint64_t w = 0;
+		for (uint32_t j = 0; j < ns; ++j) { const uint32_t r = ids[j]; memcpy(&sub_regs[8 * w], Ln.h_regs.p + 8 * reg_off[r], 32 * (size_t)sub_rpr[j]); w += sub_rpr[j]; }
+	}
+	const int64_t ms = bmh_finalize_regs_ids(&A.co, &A.ep, &po, A.l_pac, A.pac, ns, codes, sub_offs.data(), sub_regs.data(), sub_rpr.data(), sub_fr.data(), A.n_contigs,
+	                                         A.n_contigs > 1 ? A.off.data() : nullptr, sub_out.data(), sub_opr.data(), n_threads, ids.data());
+	if (ms < 0) return (int)ms;
+	if ((uint64_t)ms != n_sub_recs) { bmh_set_error("bmh_aligner_run: internal error: the host tail left %lld records where the device tail left %llu", (long long)ms, (unsigned long long)n_sub_recs); return BMH_EINVAL; }
+	R.dev_index.resize(m);
+	for (uint64_t k = 0; k < m; ++k) R.dev_index[k] = (uint32_t)k;
+	uint64_t w = 0;
+	for (uint32_t j = 0; j < ns; ++j) {
+		const uint32_t r = ids[j];
+		if (sub_opr[j] != R.opr.p[r]) { bmh_set_error("bmh_aligner_run: internal error: read %u has %u records on the host, %u on the device", r, sub_opr[j], R.opr.p[r]); return BMH_EINVAL; }
+		memcpy(R.fin.p + 16 * rec_off[r], &sub_out[16 * w], 64 * (size_t)sub_opr[j]);
+		for (uint32_t q = 0; q < sub_opr[j]; ++q) R.dev_index[rec_off[r] + q] = (uint32_t)(m + w + q);
+		w += sub_opr[j];
+	}
+	// (d_fin was sized for twice the regions: the redone records go behind the device's own)
+	LCK(hipMemcpyAsync(Ln.d_fin.p + 16 * m, sub_out.data(), 64 * (size_t)ms, hipMemcpyHostToDevice, Ln.st));
+	LCK(hipStreamSynchronize(Ln.st));                              // (sub_out is a local)
+	return BMH_OK;
+}
+
 // one batch [b0, b1) of the read set on lane Ln -> R
 int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t b0, uint32_t b1, bool paired, int n_threads, result_t &R)
 {
 	const uint32_t n = b1 - b0;
 	R.b0 = b0; R.n = n;
+	R.dev_index.clear();
 	const uint64_t a0 = rs.offs[b0], a1 = rs.offs[b1 - 1] + rs.lens[b1 - 1], nb = a1 - a0;
 	if (nb >> 31) { bmh_set_error("bmh_aligner_run: a batch holds 2^31 bases or more (offsets inside a batch are 32-bit)"); return BMH_EINVAL; }
 	double t0 = now_s();
@@ -224,9 +295,11 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 	// ---- the region tail
 	if (!paired) {
 		int64_t m = -1;
-		if (!A.has_alt) {
-			RCK(Ln.d_fin.need(16 * (nr + 1))); RCK(Ln.d_opr.need(n + 1));
-			m = bmh_finalize_regs_device(A.idx, &A.co, &A.ep, &po, Ln.d_reads.p, Ln.d_offs.p, n, Ln.d_regs.p, nr, dj.d_regs_per_read, dj.d_frac_rep,
+		R.dev_index.clear();
+		{
+			bmh_post_opt_t po_dev = po; po_dev.contig_is_alt = nullptr;      // (ALT contigs: the reads they touch are redone below)
+			RCK(Ln.d_fin.need(16 * (nr + 1) * (A.has_alt ? 2 : 1))); RCK(Ln.d_opr.need(n + 1));
+			m = bmh_finalize_regs_device(A.idx, &A.co, &A.ep, &po_dev, Ln.d_reads.p, Ln.d_offs.p, n, Ln.d_regs.p, nr, dj.d_regs_per_read, dj.d_frac_rep,
 			                             A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr, Ln.d_fin.p, Ln.d_opr.p, Ln.st);
 			if (m < 0 && m != BMH_ECAPACITY) return (int)m;
 			if (m >= 0) {
@@ -235,6 +308,7 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 				LCK(hipMemcpyAsync(R.opr.p, Ln.d_opr.p, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
 				LCK(hipStreamSynchronize(Ln.st));
 				d_fin = Ln.d_fin.p;
+				if (A.has_alt) RCK(patch_alt_reads(A, Ln, dj, po, codes, host_offs(), n, nr, (uint64_t)m, n_threads, R));
 			}
 		}
 		if (m < 0) {                                                // the host tail: ALT contigs, or a read beyond the device tail's fixed limits
@@ -296,7 +370,7 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 	}
 	R.slot.assign(m ? m : 1, -1);
 	uint64_t ns_sel = 0;
-	for (uint64_t k = 0; k < m; ++k) if (Ln.h_need.p[k]) { Ln.h_sel.p[ns_sel] = (uint32_t)k; R.slot[k] = (int64_t)ns_sel; ++ns_sel; }
+	for (uint64_t k = 0; k < m; ++k) if (Ln.h_need.p[k]) { Ln.h_sel.p[ns_sel] = R.dev_index.empty() ? (uint32_t)k : R.dev_index[k]; R.slot[k] = (int64_t)ns_sel; ++ns_sel; }
 	double t5 = now_s(); Ln.t[4] += t5 - t4;
 	RCK(cigars(A, Ln, d_fin, Ln.h_sel.p, ns_sel, R));
 	Ln.t[5] += now_s() - t5;

@@ -36,6 +36,12 @@ bool bmh_format_sam_parts(const bmh_post_opt_t *po, uint32_t n_reads, const char
                           const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
                           const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap,
                           const int32_t *h_rec, const int32_t *unflag, std::vector<std::string> &parts);
+// bmh_finalize_regs on a subset of a batch's reads: read_ids[r] = the read's index in its batch (hash seed, record field [0]); NULL = r
+int64_t bmh_finalize_regs_ids(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, int64_t l_pac,
+                              const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                              const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
+                              int n_contigs, const int64_t *contig_offset,
+                              int32_t *out, uint32_t *out_per_read, int n_threads, const uint32_t *read_ids);
 extern "C" {
 #endif
 void bmh_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));

@@ -287,11 +287,13 @@ extern "C" void bmh_post_opt_default(bmh_post_opt_t *o)        // mem_opt_init, 
 // regs_in[n][8] = {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi} grouped by read (regs_per_read); frac_rep per read.
 // out[..][16] = {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi, truesc, w, sub, sub_n, secondary, mapq, flag, reported};
 // out_per_read[n_reads]; returns the number of output regions, < 0 on error.
-extern "C" int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, int64_t l_pac,
-                                     const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
-                                     const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
-                                     int n_contigs, const int64_t *contig_offset,
-                                     int32_t *out, uint32_t *out_per_read, int n_threads)
+// read_ids (optional): the identity of read r in its batch -- what seeds the tie-break hash (id0 + id) and goes into the records' [0] -- when the
+// reads handed over are a SUBSET of a batch (csrc/align_pipeline.hip: the reads with hits on ALT contigs, redone on the host)
+int64_t bmh_finalize_regs_ids(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, int64_t l_pac,
+                              const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                              const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
+                              int n_contigs, const int64_t *contig_offset,
+                              int32_t *out, uint32_t *out_per_read, int n_threads, const uint32_t *read_ids)
 {
 	if (!copt || !ep || !popt || !pac || (n_reads && (!reads || !read_offs || !regs_in || !regs_per_read || !out || !out_per_read))) {
 		bmh_set_error("bmh_finalize_regs: null argument"); return BMH_EINVAL;
@@ -312,7 +314,8 @@ extern "C" int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_
 			}
 			int n = sort_dedup_patch(x, reads + read_offs[r], n_in, a.data());
 			set_is_alt(x, n, a.data());
-			mark_primary(x, n, a.data(), popt->id0 + r);
+			const uint32_t rid_ = read_ids ? read_ids[r] : r;
+			mark_primary(x, n, a.data(), popt->id0 + rid_);
 			const bool altm = alt_mode(x);
 			// mem_reg2sam: which regions are reported, supplementary flag, MAPQ cap
 			int32_t *o = out + 16 * in_off[r];
@@ -320,7 +323,7 @@ extern "C" int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_
 			for (int k = 0; k < n; ++k) {
 				const Reg &p = a[k];
 				int32_t *q = o + 16 * k;
-				q[0] = (int32_t)r; q[1] = p.score; q[2] = p.qb; q[3] = p.qe;
+				q[0] = (int32_t)rid_; q[1] = p.score; q[2] = p.qb; q[3] = p.qe;
 				q[4] = (int32_t)(uint32_t)p.rb; q[5] = (int32_t)(p.rb >> 32); q[6] = (int32_t)(uint32_t)p.re; q[7] = (int32_t)(p.re >> 32);
 				q[8] = p.truesc; q[9] = p.w; q[10] = p.sub > p.csub ? p.sub : p.csub; q[11] = altm ? p.secondary_all : p.sub_n; q[12] = p.secondary;
 				int mapq = p.secondary < 0 ? approx_mapq(x, p) : 0, flag = p.secondary >= 0 ? 0x100 : 0, rep = 1;
@@ -355,4 +358,13 @@ extern "C" int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_
 		w += out_per_read[r];
 	}
 	return (int64_t)w;
+}
+
+extern "C" int64_t bmh_finalize_regs(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, int64_t l_pac,
+                                     const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                                     const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
+                                     int n_contigs, const int64_t *contig_offset,
+                                     int32_t *out, uint32_t *out_per_read, int n_threads)
+{
+	return bmh_finalize_regs_ids(copt, ep, popt, l_pac, pac, n_reads, reads, read_offs, regs_in, regs_per_read, frac_rep, n_contigs, contig_offset, out, out_per_read, n_threads, nullptr);
 }

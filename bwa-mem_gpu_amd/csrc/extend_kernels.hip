@@ -1224,9 +1224,10 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		fprintf(stderr, "[ext] %u jobs: prefilter %.3f ms, keys %.3f, offsets + sort %.3f, class kernels %.3f\n", n, a, b, c, d);
 	}
 	if (want_stats) {
-		unsigned long long h[4];
+		unsigned long long h[8];
 		HIPCK(hipStreamSynchronize(st));
-		HIPCK(hipMemcpy(h, d_stats, 32, hipMemcpyDeviceToHost));
+		HIPCK(hipMemcpy(h, d_stats, 64, hipMemcpyDeviceToHost));
+		fprintf(stderr, "[ext] packed kernels: wave-rows with a running alignment %llu, of them with every running alignment at end == qlen %llu (%.1f%%)\n", h[4], h[5], 100.0 * h[5] / (h[4] ? h[4] : 1));
 		fprintf(stderr, "[ext] alignments %llu, rows executed %llu of %llu target rows (%.1f%%), wave-rows %llu (%.2f alignments per wave-row)\n", h[2], h[0], h[1], 100.0 * h[0] / (h[1] ? h[1] : 1), h[3], (double)h[0] / (h[3] ? h[3] : 1));
 	}
 	return BMH_OK;

@@ -545,6 +545,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P > PK
 		++wave_rows;
 		const int ti = (int)*tp;
 		const bool run = alive;
+		if (A.stats) {          // (BMH_EXT_STATS) wave-rows in which every running alignment has reached the query end: candidates of a row without end masks
+			const bool all_at_end = !__any(run && S.end != qlen), any_run = __any(run);
+			if (lane == 0 && any_run) { atomicAdd(A.stats + 4, 1ull); if (all_at_end) atomicAdd(A.stats + 5, 1ull); }
+		}
 		rows_done += run ? 1 : 0;
 		const int hnx = max(0, h0 - dn);
 		alive = pk_row<G, P, SAME_OE>(K, A.zdrop, H, E, NZ, sel, ti, run, hfc, hnx, i, qlen, j0, eCl, g0, phi0, em_tab, hrow, owner, (const uint16_t *)h_lds, goff, S, alive, (wave_rows & PK_BOUND_MASK) == 0, tlen - 1 - i, A.raw == nullptr, A.end_bonus);

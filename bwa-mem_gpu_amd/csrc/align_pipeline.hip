@@ -110,7 +110,7 @@ struct result_t {
 struct lane_t {
 	hipStream_t st = nullptr;
 	bmh_seed_ws_t *sws = nullptr; uint32_t sws_reads = 0; uint64_t sws_bases = 0;
-	bmh_chain_ws_t *cws = nullptr; uint32_t cws_reads = 0; uint64_t cws_seeds = 0;
+	bmh_chain_ws_t *cws = nullptr; uint32_t cws_reads = 0; uint64_t cws_seeds = 0; uint64_t regs_guess = 0;
 	dbuf_t<uint8_t> d_reads; dbuf_t<uint32_t> d_offs, d_lens, d_sel, d_opr, d_cigar; dbuf_t<int32_t> d_out3, d_regs, d_fin, d_aln; dbuf_t<char> d_md;
 	hbuf_t<uint32_t> h_offs, h_sel, h_rpr; hbuf_t<int32_t> h_regs; hbuf_t<float> h_fr; hbuf_t<uint8_t> h_need, h_reads;
 	double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // h2d, seed, chain+extend+merge, tail, select, cigar + d2h
@@ -279,13 +279,27 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		}
 	}
 	bmh_dev_jobs_t dj;
-	RCK(bmh_chain_batch(Ln.cws, &A.co, A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, n, &seeds, Ln.st, &dj));
-	const uint64_t nr = dj.n_regs, nj = dj.n_jobs;
-	RCK(Ln.d_out3.need(3 * (nj + 1))); RCK(Ln.d_regs.need(8 * (nr + 1)));
 	// the reference's GPU extension takes the deletion penalties for both gap kinds (src/fastmap.c:417-424)
 	bmh_ext_params_t xp = A.ep; xp.o_ins = A.ep.o_del; xp.e_ins = A.ep.e_del;
-	RCK(bmh_chain_extend(Ln.cws, &xp, Ln.d_out3.p, nullptr, Ln.st));
-	RCK(bmh_chain_merge(Ln.cws, Ln.d_out3.p, Ln.d_regs.p, Ln.st));
+	// one call for chaining, extension and merge: the seed-rich reads are chained beside the extension of the others (bmh_chain_extend_merge); the
+	// regions' array is sized by a guess (the last batch's count, 6 per read to begin with) and the call repeated if the batch has more
+	static const bool three_calls = getenv("BMH_ALIGNER_THREE_CALLS") != nullptr;       // (A/B: bmh_chain_batch -> bmh_chain_extend -> bmh_chain_merge)
+	if (!three_calls) {
+		uint64_t cap = Ln.regs_guess > 6ull * n ? Ln.regs_guess : 6ull * n;
+		int rc = BMH_ECAPACITY;
+		for (int attempt = 0; attempt < 4 && rc == BMH_ECAPACITY; ++attempt, cap *= 2) {
+			RCK(Ln.d_regs.need(8 * (cap + 1)));
+			rc = bmh_chain_extend_merge(Ln.cws, &A.co, A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, n, &seeds, &xp, Ln.d_regs.p, cap, Ln.st, &dj);
+		}
+		if (rc != BMH_OK) return rc;
+		Ln.regs_guess = dj.n_regs + dj.n_regs / 8;
+	} else {
+		RCK(bmh_chain_batch(Ln.cws, &A.co, A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, n, &seeds, Ln.st, &dj));
+		RCK(Ln.d_out3.need(3 * (dj.n_jobs + 1))); RCK(Ln.d_regs.need(8 * (dj.n_regs + 1)));
+		RCK(bmh_chain_extend(Ln.cws, &xp, Ln.d_out3.p, nullptr, Ln.st));
+		RCK(bmh_chain_merge(Ln.cws, Ln.d_out3.p, Ln.d_regs.p, Ln.st));
+	}
+	const uint64_t nr = dj.n_regs;
 	double t3 = now_s(); Ln.t[2] += t3 - t2;
 	bmh_post_opt_t po = A.po; po.id0 = (int64_t)b0;
 	const uint8_t *codes = rs.codes + a0;

@@ -28,7 +28,8 @@ EXPORTED_SYMBOLS = [
     "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_finalize_pairs_dev", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
     "bmh_chain_opt_default", "bmh_chain_last_timing", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
     "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_alt", "bmh_effective_cpus", "bmh_aligner_create", "bmh_aligner_free", "bmh_aligner_run", "bmh_chain_set_materialize", "bmh_chain_batch",
-    "bmh_chain_extend", "bmh_chain_merge", "bmh_chain_extend_merge", "bmh_chain_extend_merge_timing", "bmh_cigar_batch",
+    "bmh_chain_extend", "bmh_chain_merge", "bmh_chain_extend_merge", "bmh_chain_extend_merge_timing", "bmh_cigar_batch", "bmh_cigar_release",
+    "bmh_sam_select_work", "bmh_sam_select_device", "bmh_cigar_pack_work", "bmh_cigar_pack_sizes", "bmh_cigar_pack",
     "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
     "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
     "bmh_reads_load_fasta", "bmh_reads_free",
@@ -324,6 +325,17 @@ def load_library() -> C.CDLL:
     L.bmh_cigar_batch.restype = C.c_int
     L.bmh_cigar_batch.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_uint32, C.POINTER(ExtParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_void_p, C.c_void_p]
+    L.bmh_cigar_release.restype = None
+    L.bmh_sam_select_work.restype = C.c_size_t
+    L.bmh_sam_select_work.argtypes = [C.c_uint32, C.c_uint64]
+    L.bmh_sam_select_device.restype = C.c_int64
+    L.bmh_sam_select_device.argtypes = [C.POINTER(PostOpt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.bmh_cigar_pack_work.restype = C.c_size_t
+    L.bmh_cigar_pack_work.argtypes = [C.c_uint32]
+    L.bmh_cigar_pack_sizes.restype = C.c_int64
+    L.bmh_cigar_pack_sizes.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.bmh_cigar_pack.restype = C.c_int
+    L.bmh_cigar_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwt_restore_bwt_gpu.restype = C.POINTER(BwtTGpu)
     L.bwt_restore_bwt_gpu.argtypes = [C.c_char_p]
     L.bwt_restore_sa_gpu.argtypes = [C.c_char_p, C.POINTER(BwtTGpu)]
@@ -536,6 +548,44 @@ def cigar_batch(index: Index, reads_t, offs_t, lens_t, regs_t, n: int, sel_t=Non
     if rc != 0:
         raise RuntimeError(f"bmh_cigar_batch rc={rc}: " + _err(L))
     return cigar, aln, md
+
+
+def sam_select_device(po: "PostOpt", fin_t, fin_per_read_t, h_rec_t=None, stream: int = 0):
+    """bmh_sam_select_device on torch CUDA tensors (fin int32 [m, 16], fin_per_read int32 [n_reads], h_rec int32 [n_reads] for pairs):
+    returns (sel int32 [n_sel], slot int32 [m]) on the device."""
+    import torch
+    L = load_library()
+    m, n_reads = int(fin_t.shape[0]), int(fin_per_read_t.shape[0])
+    dev = fin_t.device
+    sel = torch.empty(max(m, 1), dtype=torch.int32, device=dev); slot = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+    wb = int(L.bmh_sam_select_work(n_reads, m))
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    k = L.bmh_sam_select_device(C.byref(po), fin_t.data_ptr(), fin_per_read_t.data_ptr(), h_rec_t.data_ptr() if h_rec_t is not None else None, n_reads, m,
+                                sel.data_ptr(), slot.data_ptr(), work.data_ptr(), wb, stream)
+    if k < 0:
+        raise RuntimeError(f"bmh_sam_select_device rc={k}: " + _err(L))
+    return sel[:k], slot[:m]
+
+
+def cigar_pack(aln_t, cigar_t, md_t=None, stream: int = 0):
+    """bmh_cigar_pack_sizes + bmh_cigar_pack on the outputs of cigar_batch: returns (off int32 [n + 1], packed int32 [words]) on the device"""
+    import torch
+    L = load_library()
+    n = int(aln_t.shape[0])
+    dev = aln_t.device
+    off = torch.empty(n + 2, dtype=torch.int32, device=dev)
+    wb = int(L.bmh_cigar_pack_work(n))
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    words = L.bmh_cigar_pack_sizes(aln_t.data_ptr(), n, 1 if md_t is not None else 0, off.data_ptr(), work.data_ptr(), wb, stream)
+    if words < 0:
+        raise RuntimeError(f"bmh_cigar_pack_sizes rc={words}: " + _err(L))
+    packed = torch.empty(max(int(words), 1), dtype=torch.int32, device=dev)
+    rc = L.bmh_cigar_pack(aln_t.data_ptr(), cigar_t.data_ptr(), int(cigar_t.shape[1]), md_t.data_ptr() if md_t is not None else None,
+                          int(md_t.shape[1]) if md_t is not None else 0, n, off.data_ptr(), packed.data_ptr(), stream)
+    if rc != 0:
+        raise RuntimeError(f"bmh_cigar_pack rc={rc}: " + _err(L))
+    torch.cuda.synchronize()
+    return off[:n + 1], packed[:int(words)]
 
 
 class CapacityError(RuntimeError):

@@ -99,71 +99,115 @@ template <class T> struct hbuf_t {
 // of records and 190 MB of CIGAR / MD arrays: every extra pass over them on one thread costs what a device stage costs).
 struct result_t {
 	uint32_t b0 = 0, n = 0; uint64_t m = 0, n_sel = 0;
-	hbuf_t<int32_t> fin, aln; hbuf_t<uint32_t> opr, cigar; hbuf_t<char> md; int max_cigar = 16, md_cap = 96;
-	std::vector<int64_t> slot;
+	hbuf_t<int32_t> fin, aln, slot32; hbuf_t<uint32_t> opr, off, packed;
+	hbuf_t<char> text; uint64_t text_len = 0; bool has_text = false;     // the text written on the device (no formatting on the host)
+	std::vector<int64_t> slot;                   // (host selection only; empty: slot32)
 	std::vector<int32_t> h_rec, unflag;          // pairs
-	std::vector<uint32_t> cigar_big; std::vector<char> md_big;     // only when an alignment overflowed the compact buffers
-	const uint32_t *cigar_p = nullptr; const char *md_p = nullptr;
 	std::vector<uint32_t> dev_index;             // record -> its place in the lane's d_fin when that is not the record's own index (ALT indexes); empty: identity
 };
 
 struct lane_t {
-	hipStream_t st = nullptr;
+	hipStream_t st = nullptr, st2 = nullptr;     // st2: copies to the host beside the kernels of st
 	bmh_seed_ws_t *sws = nullptr; uint32_t sws_reads = 0; uint64_t sws_bases = 0;
 	bmh_chain_ws_t *cws = nullptr; uint32_t cws_reads = 0; uint64_t cws_seeds = 0; uint64_t regs_guess = 0;
-	dbuf_t<uint8_t> d_reads; dbuf_t<uint32_t> d_offs, d_lens, d_sel, d_opr, d_cigar; dbuf_t<int32_t> d_out3, d_regs, d_fin, d_aln; dbuf_t<char> d_md;
-	hbuf_t<uint32_t> h_offs, h_sel, h_rpr; hbuf_t<int32_t> h_regs; hbuf_t<float> h_fr; hbuf_t<uint8_t> h_need, h_reads;
+	dbuf_t<uint8_t> d_reads, d_work; dbuf_t<uint32_t> d_offs, d_lens, d_sel, d_opr, d_cigar, d_off, d_packed, d_over, d_sel2; dbuf_t<int32_t> d_out3, d_regs, d_fin, d_aln, d_slot, d_hrec, d_unflag; dbuf_t<char> d_md;
+	dbuf_t<char> d_names, d_text, d_ctg_names; dbuf_t<uint64_t> d_name_off, d_text_off; dbuf_t<uint32_t> d_ctg_name_off; dbuf_t<int64_t> d_ctg_off; bool ctg_up = false;
+	hbuf_t<uint32_t> h_offs, h_sel, h_rpr; hbuf_t<int32_t> h_regs; hbuf_t<float> h_fr; hbuf_t<uint8_t> h_need, h_reads; hbuf_t<char> h_names; hbuf_t<uint64_t> h_name_off;
 	double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // h2d, seed, chain+extend+merge, tail, select, cigar + d2h
 	~lane_t()
 	{
 		if (sws) bmh_seed_ws_free(sws);
 		if (cws) bmh_chain_ws_free(cws);
 		if (st) { bmh_extend_release(st); (void)hipStreamDestroy(st); }
+		if (st2) (void)hipStreamDestroy(st2);
 	}
 };
 
 #define LCK(x) do { const hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("bmh_aligner_run: %s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
 #define RCK(x) do { const int rc_ = (x); if (rc_ != BMH_OK) return rc_; } while (0)
 
-int cigars(const aligner_t &A, lane_t &Ln, const int32_t *d_fin, const uint32_t *sel, uint64_t n_sel, result_t &R)
+// pageable -> pinned on a few threads (one thread copies 15 GB/s: the letters of a million reads were 10 ms of a lane's batch)
+void par_memcpy(void *dst, const void *src, size_t n, int n_threads)
 {
-	R.max_cigar = 16; R.md_cap = 96; R.n_sel = n_sel;
-	RCK(R.aln.need(8 * (n_sel + 1))); RCK(R.cigar.need((size_t)R.max_cigar * (n_sel + 1))); RCK(R.md.need((size_t)R.md_cap * (n_sel + 1)));
-	R.cigar_p = R.cigar.p; R.md_p = R.md.p;
-	if (n_sel == 0) return BMH_OK;
-	RCK(Ln.d_sel.need(n_sel)); RCK(Ln.d_aln.need(8 * n_sel)); RCK(Ln.d_cigar.need((size_t)R.max_cigar * n_sel)); RCK(Ln.d_md.need((size_t)R.md_cap * n_sel));
-	LCK(hipMemcpyAsync(Ln.d_sel.p, sel, 4 * n_sel, hipMemcpyHostToDevice, Ln.st));
-	RCK(bmh_cigar_batch(A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, d_fin, 16, Ln.d_sel.p, (uint32_t)n_sel, &A.ep, A.co.w, R.max_cigar, Ln.d_cigar.p, Ln.d_aln.p, R.md_cap, Ln.d_md.p, Ln.st));
-	LCK(hipMemcpyAsync(R.aln.p, Ln.d_aln.p, 32 * n_sel, hipMemcpyDeviceToHost, Ln.st));
-	LCK(hipMemcpyAsync(R.cigar.p, Ln.d_cigar.p, 4 * (size_t)R.max_cigar * n_sel, hipMemcpyDeviceToHost, Ln.st));
-	LCK(hipMemcpyAsync(R.md.p, Ln.d_md.p, (size_t)R.md_cap * n_sel, hipMemcpyDeviceToHost, Ln.st));
-	LCK(hipStreamSynchronize(Ln.st));
-	// the few alignments that overflow the compact buffers (flag 1: more operations, flag 8: a longer MD) are redone with large ones
-	std::vector<uint32_t> over;
-	for (uint64_t k = 0; k < n_sel; ++k) if (R.aln.p[8 * k + 7] & 9) over.push_back((uint32_t)k);
-	if (!over.empty()) {
-		const int MC = 64, MD = 1024;
-		R.cigar_big.assign((size_t)MC * n_sel, 0); R.md_big.assign((size_t)MD * n_sel, 0);
-		for (uint64_t k = 0; k < n_sel; ++k) { memcpy(&R.cigar_big[(size_t)MC * k], R.cigar.p + (size_t)R.max_cigar * k, 4 * (size_t)R.max_cigar); memcpy(&R.md_big[(size_t)MD * k], R.md.p + (size_t)R.md_cap * k, (size_t)R.md_cap); }
-		std::vector<uint32_t> sel2(over.size());
-		for (size_t k = 0; k < over.size(); ++k) sel2[k] = sel[over[k]];
-		const size_t no = over.size();
-		dbuf_t<uint32_t> d_cg2; dbuf_t<int32_t> d_aln2; dbuf_t<char> d_md2;
-		RCK(d_cg2.need((size_t)MC * no)); RCK(d_aln2.need(8 * no)); RCK(d_md2.need((size_t)MD * no));
-		LCK(hipMemcpyAsync(Ln.d_sel.p, sel2.data(), 4 * no, hipMemcpyHostToDevice, Ln.st));
-		RCK(bmh_cigar_batch(A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, d_fin, 16, Ln.d_sel.p, (uint32_t)no, &A.ep, A.co.w, MC, d_cg2.p, d_aln2.p, MD, d_md2.p, Ln.st));
-		std::vector<int32_t> a2(8 * no); std::vector<uint32_t> c2((size_t)MC * no); std::vector<char> m2((size_t)MD * no);
-		LCK(hipMemcpyAsync(a2.data(), d_aln2.p, 32 * no, hipMemcpyDeviceToHost, Ln.st));
-		LCK(hipMemcpyAsync(c2.data(), d_cg2.p, 4 * (size_t)MC * no, hipMemcpyDeviceToHost, Ln.st));
-		LCK(hipMemcpyAsync(m2.data(), d_md2.p, (size_t)MD * no, hipMemcpyDeviceToHost, Ln.st));
-		LCK(hipStreamSynchronize(Ln.st));
-		for (size_t k = 0; k < no; ++k) {
-			memcpy(R.aln.p + 8 * (size_t)over[k], &a2[8 * k], 32); memcpy(&R.cigar_big[(size_t)MC * over[k]], &c2[(size_t)MC * k], 4 * (size_t)MC); memcpy(&R.md_big[(size_t)MD * over[k]], &m2[(size_t)MD * k], (size_t)MD);
-		}
-		R.max_cigar = MC; R.md_cap = MD; R.cigar_p = R.cigar_big.data(); R.md_p = R.md_big.data();
+	const int T = n < (8u << 20) ? 1 : (n_threads < 4 ? (n_threads < 1 ? 1 : n_threads) : 4);
+	if (T == 1) { memcpy(dst, src, n); return; }
+	std::vector<std::thread> th;
+	for (int t = 0; t < T; ++t) {
+		const size_t a = (n * (size_t)t / T) & ~(size_t)63, b = t == T - 1 ? n : (n * (size_t)(t + 1) / T) & ~(size_t)63;
+		th.emplace_back([=] { memcpy((uint8_t *)dst + a, (const uint8_t *)src + a, b - a); });
 	}
+	for (auto &x : th) x.join();
+}
+
+// CIGAR / NM / MD of the n_sel records listed in Ln.d_sel, packed on the device (bmh_cigar_pack: an alignment's operations and MD string are a dozen
+// bytes, its fixed slots 160); the few alignments that overflow the fixed slots (flag 1: more operations, flag 8: a longer MD) are redone with
+// large ones and put in place there too.  to_host: the alignments, their offsets and the packed words go to R (the host formatter's inputs).
+int cigars(const aligner_t &A, lane_t &Ln, const int32_t *d_fin, uint64_t n_sel, result_t &R, bool to_host, uint64_t *words_out)
+{
+	const int max_cigar = 16, md_cap = 96, MC = 64, MD = 1024;
+	R.n_sel = n_sel;
+	*words_out = 0;
+	if (to_host) { RCK(R.aln.need(8 * (n_sel + 1))); RCK(R.off.need(n_sel + 2)); }
+	RCK(Ln.d_aln.need(8 * (n_sel + 1))); RCK(Ln.d_off.need(n_sel + 2)); RCK(Ln.d_packed.need(1));
+	if (n_sel == 0) return BMH_OK;
+	RCK(Ln.d_cigar.need((size_t)max_cigar * n_sel)); RCK(Ln.d_md.need((size_t)md_cap * n_sel)); RCK(Ln.d_over.need(n_sel + 8)); RCK(Ln.d_sel2.need(n_sel));
+	RCK(bmh_cigar_batch(A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, d_fin, 16, Ln.d_sel.p, (uint32_t)n_sel, &A.ep, A.co.w, max_cigar, Ln.d_cigar.p, Ln.d_aln.p, md_cap, Ln.d_md.p, Ln.st));
+	const size_t wb = bmh_cigar_pack_work((uint32_t)n_sel);
+	RCK(Ln.d_work.need(wb));
+	// (the counter of the overflowed alignments: the last word of d_over's spare room)
+	const int64_t n_over = bmh_cigar_overflowed(Ln.d_aln.p, (uint32_t)n_sel, Ln.d_sel.p, Ln.d_over.p, Ln.d_sel2.p, Ln.d_over.p + n_sel + 4, Ln.st);
+	if (n_over < 0) return (int)n_over;
+	int64_t words = bmh_cigar_pack_sizes(Ln.d_aln.p, (uint32_t)n_sel, 1, Ln.d_off.p, Ln.d_work.p, Ln.d_work.cap, Ln.st);
+	if (words < 0) return (int)words;
+	RCK(Ln.d_packed.need((size_t)words + (size_t)n_over * (MC + MD / 4) + 1));
+	RCK(bmh_cigar_pack(Ln.d_aln.p, Ln.d_cigar.p, max_cigar, Ln.d_md.p, md_cap, (uint32_t)n_sel, Ln.d_off.p, Ln.d_packed.p, Ln.st));
+	if (n_over) {
+		const size_t no = (size_t)n_over;
+		dbuf_t<uint32_t> d_cg2, d_scr; dbuf_t<int32_t> d_aln2; dbuf_t<char> d_md2;
+		RCK(d_cg2.need((size_t)MC * no)); RCK(d_aln2.need(8 * no)); RCK(d_md2.need((size_t)MD * no)); RCK(d_scr.need(no + 1));
+		RCK(bmh_cigar_batch(A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, d_fin, 16, Ln.d_sel2.p, (uint32_t)no, &A.ep, A.co.w, MC, d_cg2.p, d_aln2.p, MD, d_md2.p, Ln.st));
+		words = bmh_cigar_patch(Ln.d_aln.p, Ln.d_off.p, Ln.d_packed.p, (uint64_t)words, Ln.d_over.p, (uint32_t)no, d_aln2.p, d_cg2.p, MC, d_md2.p, MD, d_scr.p, Ln.st);
+		if (words < 0) return (int)words;           // (the call waited for the stream: the temporaries may go)
+	}
+	*words_out = (uint64_t)words;
+	if (!to_host) return BMH_OK;
+	RCK(R.packed.need((size_t)words + 1));
+	LCK(hipMemcpyAsync(R.aln.p, Ln.d_aln.p, 32 * n_sel, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipMemcpyAsync(R.off.p, Ln.d_off.p, 4 * (n_sel + 1), hipMemcpyDeviceToHost, Ln.st));
+	if (words) LCK(hipMemcpyAsync(R.packed.p, Ln.d_packed.p, 4 * (size_t)words, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipStreamSynchronize(Ln.st));
 	for (uint64_t k = 0; k < n_sel; ++k)
 		if (R.aln.p[8 * k + 7] & ~2) { bmh_set_error("bmh_aligner_run: bmh_cigar_batch flagged an alignment (CIGAR or MD longer than the buffers)"); return BMH_ECAPACITY; }
+	return BMH_OK;
+}
+
+// the batch's SAM text written on the device (bmh_sam_text_sizes / _write) and copied into R.text
+int text_on_device(const aligner_t &A, lane_t &Ln, const bmh_post_opt_t &po, const int32_t *d_fin, uint32_t n, bool paired, result_t &R)
+{
+	if (!Ln.ctg_up) {                                              // the sequences' names and offsets, once per lane
+		std::vector<char> blob; std::vector<uint32_t> noff;
+		for (const std::string &s : A.names) { noff.push_back((uint32_t)blob.size()); blob.insert(blob.end(), s.begin(), s.end()); blob.push_back(0); }
+		RCK(Ln.d_ctg_names.need(blob.size())); RCK(Ln.d_ctg_name_off.need(noff.size())); RCK(Ln.d_ctg_off.need(A.off.size()));
+		LCK(hipMemcpy(Ln.d_ctg_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+		LCK(hipMemcpy(Ln.d_ctg_name_off.p, noff.data(), 4 * noff.size(), hipMemcpyHostToDevice));
+		LCK(hipMemcpy(Ln.d_ctg_off.p, A.off.data(), 8 * A.off.size(), hipMemcpyHostToDevice));
+		Ln.ctg_up = true;
+	}
+	bmh_sam_dev_t d;
+	memset(&d, 0, sizeof(d));
+	d.n_reads = n; d.d_names = Ln.d_names.p; d.d_name_off = Ln.d_name_off.p; d.d_reads = Ln.d_reads.p; d.d_offs = Ln.d_offs.p; d.d_lens = Ln.d_lens.p;
+	d.n_contigs = A.n_contigs; d.d_contig_names = Ln.d_ctg_names.p; d.d_contig_name_off = Ln.d_ctg_name_off.p; d.d_contig_offset = Ln.d_ctg_off.p;
+	d.d_fin = d_fin; d.d_fin_per_read = Ln.d_opr.p; d.d_slot = Ln.d_slot.p; d.d_aln = Ln.d_aln.p; d.d_cig_off = Ln.d_off.p; d.d_packed = Ln.d_packed.p;
+	d.d_h_rec = paired ? Ln.d_hrec.p : nullptr; d.d_unflag = paired ? Ln.d_unflag.p : nullptr;
+	const size_t wb = bmh_sam_text_work(n);
+	RCK(Ln.d_work.need(wb)); RCK(Ln.d_text_off.need((size_t)n + 2));
+	const int64_t total = bmh_sam_text_sizes(&po, &d, Ln.d_text_off.p, Ln.d_work.p, Ln.d_work.cap, Ln.st);
+	if (total < 0) return (int)total;
+	RCK(Ln.d_text.need((size_t)total + 1)); RCK(R.text.need((size_t)total + 1));
+	RCK(bmh_sam_text_write(&po, &d, Ln.d_text_off.p, Ln.d_text.p, Ln.d_work.p, Ln.d_work.cap, Ln.st));
+	if (total) LCK(hipMemcpyAsync(R.text.p, Ln.d_text.p, (size_t)total, hipMemcpyDeviceToHost, Ln.st));
+	RCK(bmh_sam_text_check(Ln.d_work.p, n, Ln.st));
+	R.text_len = (uint64_t)total; R.has_text = true;
 	return BMH_OK;
 }
 
@@ -249,10 +293,23 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 	RCK(Ln.d_reads.need(nb + 16)); RCK(Ln.d_offs.need(n + 1)); RCK(Ln.d_lens.need(n + 1)); RCK(Ln.h_offs.need(n + 1));
 	for (uint32_t r = 0; r < n; ++r) Ln.h_offs.p[r] = (uint32_t)(rs.offs[b0 + r] - a0);
 	RCK(Ln.h_reads.need(nb + 16));
-	memcpy(Ln.h_reads.p, rs.ascii + a0, nb);                          // (pageable -> pinned by this lane's thread, then one DMA: the lanes stage side by side)
+	par_memcpy(Ln.h_reads.p, rs.ascii + a0, nb, n_threads);           // (pageable -> pinned by this lane's threads, then one DMA: the lanes stage side by side)
 	LCK(hipMemcpyAsync(Ln.d_reads.p, Ln.h_reads.p, nb, hipMemcpyHostToDevice, Ln.st));
 	LCK(hipMemcpyAsync(Ln.d_offs.p, Ln.h_offs.p, 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
 	LCK(hipMemcpyAsync(Ln.d_lens.p, rs.lens + b0, 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
+	// the text is written on the device (bmh_sam_text_*) unless the index has ALT contigs (their tags are the host formatter's): the names go along
+	const bool host_format = getenv("BMH_ALIGNER_HOST_FORMAT") != nullptr;          // (A/B and cross-check: records to the host, text by bmh_format_sam)
+	const bool host_select = getenv("BMH_ALIGNER_HOST_SELECT") != nullptr;          // (A/B and cross-check: the host's selection for every batch; implies the host's text)
+	const bool text_dev = !A.has_alt && !host_format && !host_select;
+	R.has_text = false; R.text_len = 0;
+	if (text_dev) {
+		const uint64_t n0 = rs.name_offs[b0], n1 = b1 < rs.n_reads ? rs.name_offs[b1] : rs.n_name_bytes;
+		RCK(Ln.h_names.need(n1 - n0 + 1)); RCK(Ln.h_name_off.need(n + 1)); RCK(Ln.d_names.need(n1 - n0 + 1)); RCK(Ln.d_name_off.need(n + 1));
+		memcpy(Ln.h_names.p, rs.names + n0, n1 - n0);
+		for (uint32_t r = 0; r < n; ++r) Ln.h_name_off.p[r] = rs.name_offs[b0 + r] - n0;
+		LCK(hipMemcpyAsync(Ln.d_names.p, Ln.h_names.p, n1 - n0, hipMemcpyHostToDevice, Ln.st));
+		LCK(hipMemcpyAsync(Ln.d_name_off.p, Ln.h_name_off.p, 8 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
+	}
 	// ---- seeding
 	if (!Ln.sws || n > Ln.sws_reads || nb > Ln.sws_bases) {
 		if (Ln.sws) bmh_seed_ws_free(Ln.sws);
@@ -306,6 +363,7 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 	std::vector<uint64_t> offs64;                                   // offsets relative to the batch, for the host forms
 	auto host_offs = [&]() { if (offs64.empty()) { offs64.resize(n); for (uint32_t r = 0; r < n; ++r) offs64[r] = rs.offs[b0 + r] - a0; } return offs64.data(); };
 	const int32_t *d_fin = nullptr;
+	bool dev_select = true;                                         // the records that need a CIGAR are chosen on the device (bmh_sam_select_device)
 	// ---- the region tail
 	if (!paired) {
 		int64_t m = -1;
@@ -317,15 +375,21 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 			                             A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr, Ln.d_fin.p, Ln.d_opr.p, Ln.st);
 			if (m < 0 && m != BMH_ECAPACITY) return (int)m;
 			if (m >= 0) {
-				RCK(R.fin.need(16 * (size_t)m + 16)); RCK(R.opr.need(n + 1));
-				if (m) LCK(hipMemcpyAsync(R.fin.p, Ln.d_fin.p, 64 * (size_t)m, hipMemcpyDeviceToHost, Ln.st));
-				LCK(hipMemcpyAsync(R.opr.p, Ln.d_opr.p, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
-				LCK(hipStreamSynchronize(Ln.st));
+				// (the stream is idle: the records go home on the second stream while the selection and the CIGAR kernels run on the first)
+				if (!text_dev) {
+					RCK(R.fin.need(16 * (size_t)m + 16)); RCK(R.opr.need(n + 1));
+					if (m) LCK(hipMemcpyAsync(R.fin.p, Ln.d_fin.p, 64 * (size_t)m, hipMemcpyDeviceToHost, Ln.st2));
+					LCK(hipMemcpyAsync(R.opr.p, Ln.d_opr.p, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st2));
+				}
 				d_fin = Ln.d_fin.p;
-				if (A.has_alt) RCK(patch_alt_reads(A, Ln, dj, po, codes, host_offs(), n, nr, (uint64_t)m, n_threads, R));
+				if (A.has_alt) {
+					LCK(hipStreamSynchronize(Ln.st2));
+					RCK(patch_alt_reads(A, Ln, dj, po, codes, host_offs(), n, nr, (uint64_t)m, n_threads, R));
+					dev_select = false;                                 // (patched records live behind the device tail's: the host's list maps them)
+				}
 			}
 		}
-		if (m < 0) {                                                // the host tail: ALT contigs, or a read beyond the device tail's fixed limits
+		if (m < 0) {                                                // the host tail: a read beyond the device tail's fixed limits
 			RCK(Ln.h_regs.need(8 * (nr + 1))); RCK(Ln.h_rpr.need(n + 1)); RCK(Ln.h_fr.need(n + 1));
 			if (nr) LCK(hipMemcpyAsync(Ln.h_regs.p, Ln.d_regs.p, 32 * (size_t)nr, hipMemcpyDeviceToHost, Ln.st));
 			LCK(hipMemcpyAsync(Ln.h_rpr.p, dj.d_regs_per_read, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
@@ -335,8 +399,9 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 			m = bmh_finalize_regs(&A.co, &A.ep, &po, A.l_pac, A.pac, n, codes, host_offs(), Ln.h_regs.p, Ln.h_rpr.p, Ln.h_fr.p, A.n_contigs,
 			                      A.n_contigs > 1 ? A.off.data() : nullptr, R.fin.p, R.opr.p, n_threads);
 			if (m < 0) return (int)m;
-			RCK(Ln.d_fin.need(16 * ((size_t)m + 1)));
+			RCK(Ln.d_fin.need(16 * ((size_t)m + 1))); RCK(Ln.d_opr.need(n + 1));
 			if (m) LCK(hipMemcpyAsync(Ln.d_fin.p, R.fin.p, 64 * (size_t)m, hipMemcpyHostToDevice, Ln.st));
+			LCK(hipMemcpyAsync(Ln.d_opr.p, R.opr.p, 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
 			d_fin = Ln.d_fin.p;
 		}
 		R.m = (uint64_t)m;
@@ -357,16 +422,31 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		}
 		if (m < 0) return (int)m;
 		R.m = (uint64_t)m;
-		RCK(Ln.d_fin.need(16 * ((size_t)m + 1)));
+		RCK(Ln.d_fin.need(16 * ((size_t)m + 1))); RCK(Ln.d_opr.need(n + 1)); RCK(Ln.d_hrec.need(n + 1));
 		if (m) LCK(hipMemcpyAsync(Ln.d_fin.p, R.fin.p, 64 * (size_t)m, hipMemcpyHostToDevice, Ln.st));
+		LCK(hipMemcpyAsync(Ln.d_opr.p, R.opr.p, 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
+		LCK(hipMemcpyAsync(Ln.d_hrec.p, R.h_rec.data(), 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
+		if (text_dev) { RCK(Ln.d_unflag.need(n + 1)); LCK(hipMemcpyAsync(Ln.d_unflag.p, R.unflag.data(), 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st)); }
 		d_fin = Ln.d_fin.p;
 	}
 	double t4 = now_s(); Ln.t[3] += t4 - t3;
 	// ---- which records need a CIGAR
 	const uint64_t m = R.m;
-	RCK(Ln.h_need.need(m + 1)); RCK(Ln.h_sel.need(m + 1));
-	// (reads are independent: ranges of them on host threads -- 3 M records of a million reads were 11 ms on one)
-	{
+	uint64_t ns_sel = 0;
+	RCK(Ln.d_sel.need(m + 1)); RCK(Ln.h_sel.need(m + 1));
+	if (dev_select && !host_select) {
+		R.slot.clear();
+		RCK(Ln.d_slot.need(m + 1)); RCK(R.slot32.need(m + 1));
+		const size_t wb = bmh_sam_select_work(n, m);
+		RCK(Ln.d_work.need(wb));
+		const int64_t k = bmh_sam_select_device(&po, d_fin, Ln.d_opr.p, paired ? Ln.d_hrec.p : nullptr, n, m, Ln.d_sel.p, Ln.d_slot.p, Ln.d_work.p, Ln.d_work.cap, Ln.st);
+		if (k < 0) return (int)k;
+		ns_sel = (uint64_t)k;
+		if (m && !text_dev) LCK(hipMemcpyAsync(R.slot32.p, Ln.d_slot.p, 4 * (size_t)m, hipMemcpyDeviceToHost, Ln.st2));
+	} else {
+		LCK(hipStreamSynchronize(Ln.st2));                          // (the records)
+		RCK(Ln.h_need.need(m + 1));
+		// (reads are independent: ranges of them on host threads -- 3 M records of a million reads were 11 ms on one)
 		std::vector<uint64_t> base((size_t)n + 1, 0);
 		for (uint32_t r = 0; r < n; ++r) base[r + 1] = base[r] + R.opr.p[r];
 		if (base[n] != m) { bmh_set_error("bmh_aligner_run: internal error: %llu records, the per-read counts add up to %llu", (unsigned long long)m, (unsigned long long)base[n]); return BMH_EINVAL; }
@@ -381,12 +461,16 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		if (T == 1) part(0);
 		else { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(part, t); for (auto &x : th) x.join(); }
 		for (int64_t v : part_rc) if (v < 0) return (int)v;
+		R.slot.assign(m ? m : 1, -1);
+		for (uint64_t k = 0; k < m; ++k) if (Ln.h_need.p[k]) { Ln.h_sel.p[ns_sel] = R.dev_index.empty() ? (uint32_t)k : R.dev_index[k]; R.slot[k] = (int64_t)ns_sel; ++ns_sel; }
+		if (ns_sel) LCK(hipMemcpyAsync(Ln.d_sel.p, Ln.h_sel.p, 4 * ns_sel, hipMemcpyHostToDevice, Ln.st));
 	}
-	R.slot.assign(m ? m : 1, -1);
-	uint64_t ns_sel = 0;
-	for (uint64_t k = 0; k < m; ++k) if (Ln.h_need.p[k]) { Ln.h_sel.p[ns_sel] = R.dev_index.empty() ? (uint32_t)k : R.dev_index[k]; R.slot[k] = (int64_t)ns_sel; ++ns_sel; }
 	double t5 = now_s(); Ln.t[4] += t5 - t4;
-	RCK(cigars(A, Ln, d_fin, Ln.h_sel.p, ns_sel, R));
+	uint64_t words = 0;
+	const bool dev_text_now = text_dev && dev_select;
+	RCK(cigars(A, Ln, d_fin, ns_sel, R, !dev_text_now, &words));
+	if (dev_text_now) RCK(text_on_device(A, Ln, po, d_fin, n, paired, R));
+	LCK(hipStreamSynchronize(Ln.st2));
 	Ln.t[5] += now_s() - t5;
 	return BMH_OK;
 }
@@ -468,7 +552,9 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 	h->dev = dev;
 	while ((int)h->lanes.size() < n_lanes) {
 		std::unique_ptr<lane_t> ln(new lane_t());
-		if (hipStreamCreateWithFlags(&ln->st, hipStreamNonBlocking) != hipSuccess) { bmh_set_error("bmh_aligner_run: hipStreamCreate: %s", hipGetErrorString(hipGetLastError())); return BMH_ENODEV; }
+		if (hipStreamCreateWithFlags(&ln->st, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ln->st2, hipStreamNonBlocking) != hipSuccess) {
+			bmh_set_error("bmh_aligner_run: hipStreamCreate: %s", hipGetErrorString(hipGetLastError())); return BMH_ENODEV;
+		}
 		h->lanes.push_back(std::move(ln));
 	}
 	for (auto &ln : h->lanes) for (double &v : ln->t) v = 0.0;
@@ -487,7 +573,6 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 				if (!pool.empty()) { R = std::move(pool.back()); pool.pop_back(); }
 				else { R.reset(new result_t()); ++n_results; }
 			}
-			R->cigar_big.clear(); R->md_big.clear();
 			const uint32_t b0 = (uint32_t)cuts[b], b1 = (uint32_t)cuts[b + 1];
 			int rc = BMH_OK;
 			const double tb0 = now_s();
@@ -499,6 +584,7 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 			done[b] = std::move(R);
 			cv.notify_all();
 		}
+		bmh_cigar_release();                                         // (the thread's scratch of bmh_cigar_batch ends with the thread)
 		std::lock_guard<std::mutex> lk(mu);
 		for (int k = 0; k < 8; ++k) lane_t_sum[(size_t)k] += Ln.t[k];
 	};
@@ -513,7 +599,11 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 				if (first_rc != BMH_OK) return;
 				R = std::move(done[b]); done.erase(b);
 			}
-			if (R->n) {
+			if (R->n && R->has_text) {                               // written on the device: nothing to format
+				const double ts0 = now_s();
+				if (R->text_len) { if (sink(user, R->text.p, (size_t)R->text_len) != 0) { fail(BMH_EINVAL, "the sink refused the text"); return; } n_bytes += R->text_len; }
+				if (trace) fprintf(stderr, "[aligner] writer batch %u: text of the device, sink %.1f .. %.1f ms\n", b, (ts0 - t_start) * 1e3, (now_s() - t_start) * 1e3);
+			} else if (R->n) {
 				const double t0 = now_s();
 				bmh_post_opt_t po = A.po; po.id0 = (int64_t)R->b0;
 				size_t len = 0;
@@ -521,8 +611,11 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 				std::vector<uint64_t> offs64(R->n), noff(R->n);
 				const uint64_t n0 = rs->name_offs[R->b0];
 				for (uint32_t r = 0; r < R->n; ++r) { offs64[r] = rs->offs[R->b0 + r] - a0; noff[r] = rs->name_offs[R->b0 + r] - n0; }
+				bmh_cigar_src_t cs;
+				if (R->slot.empty()) cs.slot32 = R->slot32.p; else cs.slot64 = R->slot.data();
+				cs.aln = R->aln.p; cs.packed = R->packed.p; cs.off = R->off.p;
 				const bool ok = bmh_format_sam_parts(&po, R->n, (const char *)rs->names + n0, noff.data(), rs->codes + a0, offs64.data(), rs->lens + R->b0, A.n_contigs,
-				                                     A.name_ptr.data(), A.off.data(), R->fin.p, R->opr.p, R->slot.data(), R->aln.p, R->cigar_p, R->max_cigar, R->md_p, R->md_cap,
+				                                     A.name_ptr.data(), A.off.data(), R->fin.p, R->opr.p, cs,
 				                                     paired ? R->h_rec.data() : nullptr, paired ? R->unflag.data() : nullptr, parts);
 				if (!ok) { fail(BMH_EINVAL, bmh_last_error()); return; }
 				t_format += now_s() - t0;

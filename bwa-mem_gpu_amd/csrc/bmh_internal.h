@@ -29,13 +29,26 @@ int bmh_extend_reserve(void *stream, uint64_t n);
 #ifdef __cplusplus
 #include <string>
 #include <vector>
+// where the formatter finds a record's alignment: slot (64- or 32-bit, -1 = none) -> aln[8], and the operations / MD string either in the
+// fixed slots bmh_cigar_batch writes or in the packed words of bmh_cigar_pack (off[s] = first word of alignment s: its operations, then
+// its MD string)
+struct bmh_cigar_src_t {
+	const int64_t *slot64 = nullptr; const int32_t *slot32 = nullptr;
+	const int32_t *aln = nullptr;
+	const uint32_t *cigar = nullptr; int max_cigar = 0; const char *md = nullptr; int md_cap = 0;
+	const uint32_t *packed = nullptr; const uint32_t *off = nullptr; bool packed_md = true;
+};
 // bmh_format_sam / bmh_format_sam_pe (h_rec, unflag: the pairs' arrays, NULL for single-end reads) as the parts the formatting threads
 // made, in order; `parts` is reused by the caller (csrc/sam_format.cpp, csrc/align_pipeline.hip)
 bool bmh_format_sam_parts(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,
                           const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
-                          const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
-                          const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap,
+                          const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const bmh_cigar_src_t &cs,
                           const int32_t *h_rec, const int32_t *unflag, std::vector<std::string> &parts);
+// csrc/sam_kernels.hip, for csrc/align_pipeline.hip: the alignments whose fixed slots overflowed (flags 1, 8) found and, once redone with large
+// slots, put in place on the device (see the definitions)
+int64_t bmh_cigar_overflowed(const int32_t *d_aln, uint32_t n, const uint32_t *d_sel, uint32_t *d_over, uint32_t *d_sel2, uint32_t *d_counter, void *stream);
+int64_t bmh_cigar_patch(int32_t *d_aln, uint32_t *d_off, uint32_t *d_packed, uint64_t words, const uint32_t *d_over, uint32_t n_over,
+                        const int32_t *d_aln2, const uint32_t *d_cigar2, int mc2, const char *d_md2, int mdc2, uint32_t *d_scratch, void *stream);
 // bmh_finalize_regs on a subset of a batch's reads: read_ids[r] = the read's index in its batch (hash seed, record field [0]); NULL = r
 int64_t bmh_finalize_regs_ids(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, int64_t l_pac,
                               const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,

@@ -641,12 +641,24 @@ __global__ void __launch_bounds__(256) cigar_size_kernel(const int32_t *regs, in
 	if ((threadIdx.x & 63) == 0) { atomicMax(out, zb); atomicMax(out + 1, ml); }
 }
 
+// the calling thread's scratch, on the device it was first used on: dropped by bmh_cigar_release (a thread that ends calls it: the lanes of
+// bmh_aligner_run are threads of one run) or when the thread turns to another device
 struct cigar_scratch_t {
-	unsigned long long *d_sizes;       // [0] largest rectangle [1] longest sequence [2] fast-path matrix bytes; then CG_NKIND list counts (u32)
-	uint8_t *slab; size_t slab_bytes;
-	cg_job_t *jobs; uint32_t *lists, *rev; size_t cap_n, cap_rev; uint8_t *z; size_t z_bytes;
+	unsigned long long *d_sizes = nullptr;       // [0] largest rectangle [1] longest sequence [2] fast-path matrix bytes; then CG_NKIND list counts (u32)
+	uint8_t *slab = nullptr; size_t slab_bytes = 0;
+	cg_job_t *jobs = nullptr; uint32_t *lists = nullptr, *rev = nullptr; size_t cap_n = 0, cap_rev = 0; uint8_t *z = nullptr; size_t z_bytes = 0;
+	int dev = -1;
+	void drop()
+	{
+		void *ps[] = {d_sizes, slab, jobs, lists, rev, z};
+		for (void *q : ps) if (q) (void)hipFree(q);
+		d_sizes = nullptr; slab = nullptr; jobs = nullptr; lists = rev = nullptr; z = nullptr;
+		slab_bytes = cap_n = cap_rev = z_bytes = 0; dev = -1;
+	}
 };
-static thread_local cigar_scratch_t g_cs = {nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, 0};
+static thread_local cigar_scratch_t g_cs;
+
+extern "C" void bmh_cigar_release(void) { g_cs.drop(); }
 
 template <int C, int CLO>
 static int launch_cigar(const cigar_args_t &a, unsigned grid, size_t lds, hipStream_t st)
@@ -673,6 +685,11 @@ extern "C" int bmh_cigar_batch(const bmh_index_t *idx, const uint8_t *d_reads, c
 	if (n == 0) return BMH_OK;
 	hipStream_t st = (hipStream_t)stream_;
 	static const bool slow_only = getenv("BMH_CIGAR_SLOW") != nullptr;
+	{
+		int dev = 0;
+		HIPCK(hipGetDevice(&dev));
+		if (g_cs.dev != dev) { g_cs.drop(); g_cs.dev = dev; }
+	}
 	if (!g_cs.d_sizes) HIPCK(hipMalloc((void **)&g_cs.d_sizes, 64));
 	HIPCK(hipMemsetAsync(g_cs.d_sizes, 0, 64, st));
 	cigar_size_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_regs, reg_stride, d_sel, n, g_cs.d_sizes);

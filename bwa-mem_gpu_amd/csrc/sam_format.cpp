@@ -111,8 +111,7 @@ extern "C" int64_t bmh_sam_need_cigar(const bmh_post_opt_t *po, const int32_t *f
 // the strings, whose capacity survives clear(), so that no quarter-gigabyte buffer is allocated, faulted in and unmapped per batch)
 bool bmh_format_sam_parts(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,
                           const uint64_t *read_offs, const uint32_t *read_lens, int n_contigs, const char *const *contig_names,
-                          const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const int64_t *slot,
-                          const int32_t *aln, const uint32_t *cigar, int max_cigar, const char *md, int md_cap,
+                          const int64_t *contig_offset, const int32_t *fin, const uint32_t *fin_per_read, const bmh_cigar_src_t &cs,
                           const int32_t *h_rec, const int32_t *unflag, std::vector<std::string> &parts)
 {
 	std::vector<uint64_t> bases((size_t)n_reads + 1, 0);
@@ -120,11 +119,18 @@ bool bmh_format_sam_parts(const bmh_post_opt_t *po, uint32_t n_reads, const char
 	const bool pe = h_rec != nullptr;
 	auto rec_at = [&](uint64_t base, const int32_t *a, int i) {
 		Rec x; x.fin = a + 16 * i;
-		const int64_t s = slot[base + i];
-		x.aln = s >= 0 ? aln + 8 * s : nullptr; x.cigar = s >= 0 ? cigar + (size_t)max_cigar * s : nullptr; x.md = (s >= 0 && md) ? md + (size_t)md_cap * s : "";
+		const int64_t s = cs.slot32 ? (int64_t)cs.slot32[base + i] : cs.slot64[base + i];
+		x.aln = nullptr; x.cigar = nullptr; x.md = "";
+		if (s >= 0) {
+			x.aln = cs.aln + 8 * s;
+			if (cs.packed) { x.cigar = cs.packed + cs.off[s]; if (cs.packed_md) x.md = (const char *)(x.cigar + x.aln[3]); }
+			else { x.cigar = cs.cigar + (size_t)cs.max_cigar * s; if (cs.md) x.md = cs.md + (size_t)cs.md_cap * s; }
+		}
 		return x;
 	};
 	// reads are independent: format ranges of them on host threads (the reference formats inside its worker threads)
+	// (threads: the hardware's, not bmh_effective_cpus(): a CPU quota limits the RATE of CPU time, and a batch's text is a burst -- on a box that
+	// shows 256 threads and grants 16 CPUs' worth of time, 64 threads format a million reads in 14 ms, 16 threads in 45 ms)
 	unsigned n_thr = n_reads >= 8192 ? std::thread::hardware_concurrency() : 1;
 	if (n_thr < 1) n_thr = 1;
 	if (n_thr > 64) n_thr = 64;
@@ -277,8 +283,9 @@ static char *format_sam(const bmh_post_opt_t *po, uint32_t n_reads, const char *
                         const int32_t *h_rec, const int32_t *unflag, size_t *len_out)
 {
 	std::vector<std::string> parts;
-	if (!bmh_format_sam_parts(po, n_reads, names, name_off, reads, read_offs, read_lens, n_contigs, contig_names, contig_offset, fin, fin_per_read, slot, aln, cigar, max_cigar,
-	                          md, md_cap, h_rec, unflag, parts)) return nullptr;
+	bmh_cigar_src_t cs;
+	cs.slot64 = slot; cs.aln = aln; cs.cigar = cigar; cs.max_cigar = max_cigar; cs.md = md; cs.md_cap = md_cap;
+	if (!bmh_format_sam_parts(po, n_reads, names, name_off, reads, read_offs, read_lens, n_contigs, contig_names, contig_offset, fin, fin_per_read, cs, h_rec, unflag, parts)) return nullptr;
 	const unsigned n_thr = (unsigned)parts.size();
 	size_t total = 0;
 	for (const std::string &p : parts) total += p.size();

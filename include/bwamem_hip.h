@@ -468,6 +468,49 @@ int bmh_cigar_batch(const bmh_index_t *idx, const uint8_t *d_reads, const uint32
                     const int32_t *d_regs, int reg_stride, const uint32_t *d_sel, uint32_t n, const bmh_ext_params_t *p, int opt_w,
                     int max_cigar, uint32_t *d_cigar, int32_t *d_aln, int md_cap, char *d_md, void *stream);
 
+/* frees the calling thread's scratch of bmh_cigar_batch (device buffers it keeps between calls); a worker thread calls it before it ends */
+void bmh_cigar_release(void);
+
+/* ---- what the SAM writer needs of a batch, chosen and packed on the device (csrc/sam_kernels.hip)
+ * bmh_sam_select_device: bmh_sam_need_cigar over records in HBM (d_fin [m][16], d_fin_per_read [n_reads]: what bmh_finalize_regs_device
+ * left; d_h_rec: NULL, or for interleaved pairs the own-alignment record of every read as in bmh_sam_need_cigar_pe).  d_sel [m]
+ * receives the indices of the selected records in ascending order -- the d_sel of bmh_cigar_batch --, d_slot [m] the place of every
+ * record in that list or -1 (the slot[] of bmh_format_sam, 32-bit).  d_work: bmh_sam_select_work(n_reads, m) bytes of device memory.
+ * Returns the number selected (waits for the stream) or a negative BMH_E* code.
+ * bmh_cigar_pack_sizes / bmh_cigar_pack: the outputs of bmh_cigar_batch without their padding.  _sizes fills d_off [n + 1] with the
+ * start (in 32-bit words) of every alignment in the packed array and returns the total number of words (waits for the stream):
+ * n_cigar operations, then -- with_md -- the MD string with its NUL, padded to a word; an alignment flagged 1, 4 or 8 takes no words
+ * (the caller redoes it with larger slots).  bmh_cigar_pack then copies (asynchronous; md_cap a multiple of 4; d_md NULL if _sizes
+ * was called with with_md = 0).  d_work: bmh_cigar_pack_work(n) bytes. */
+size_t bmh_sam_select_work(uint32_t n_reads, uint64_t m);
+int64_t bmh_sam_select_device(const bmh_post_opt_t *popt, const int32_t *d_fin, const uint32_t *d_fin_per_read, const int32_t *d_h_rec,
+                              uint32_t n_reads, uint64_t m, uint32_t *d_sel, int32_t *d_slot, void *d_work, size_t work_bytes, void *stream);
+size_t bmh_cigar_pack_work(uint32_t n);
+int64_t bmh_cigar_pack_sizes(const int32_t *d_aln, uint32_t n, int with_md, uint32_t *d_off, void *d_work, size_t work_bytes, void *stream);
+int bmh_cigar_pack(const int32_t *d_aln, const uint32_t *d_cigar, int max_cigar, const char *d_md, int md_cap, uint32_t n,
+                   const uint32_t *d_off, uint32_t *d_packed, void *stream);
+
+/* ---- the SAM text itself written on the device (csrc/sam_kernels.hip): the text of bmh_format_sam / bmh_format_sam_pe, byte for byte,
+ * from records, alignments and packed CIGARs that never leave HBM.  Every pointer of bmh_sam_dev_t is device memory.  Not for an index
+ * with ALT contigs (popt->contig_is_alt must be NULL: BMH_ECAPACITY otherwise; the caller takes the host formatter).
+ * bmh_sam_text_sizes: first pass, d_text_off [n_reads + 1] = start of every read's records in the text; returns the text's length
+ * (waits for the stream).  bmh_sam_text_write: second pass into d_text (asynchronous; the same d_work, untouched in between);
+ * bmh_sam_text_check afterwards waits for the stream and reports an inconsistency between the passes.  d_work: bmh_sam_text_work bytes. */
+typedef struct {
+	uint32_t n_reads;
+	const char *d_names; const uint64_t *d_name_off;           /* names NUL-terminated back to back, start of read r's */
+	const uint8_t *d_reads; const uint32_t *d_offs, *d_lens;   /* the batch's ASCII reads (what bmh_seed_batch takes) */
+	int n_contigs; const char *d_contig_names; const uint32_t *d_contig_name_off; const int64_t *d_contig_offset;
+	const int32_t *d_fin; const uint32_t *d_fin_per_read;      /* records [m][16], records per read */
+	const int32_t *d_slot;                                     /* [m] record -> alignment (bmh_sam_select_device) */
+	const int32_t *d_aln; const uint32_t *d_cig_off, *d_packed; /* bmh_cigar_batch's d_aln; bmh_cigar_pack's d_off / d_packed (with MD) */
+	const int32_t *d_h_rec, *d_unflag;                         /* interleaved pairs (bmh_finalize_pairs' out_h / out_unflag) or NULL */
+} bmh_sam_dev_t;
+size_t bmh_sam_text_work(uint32_t n_reads);
+int64_t bmh_sam_text_sizes(const bmh_post_opt_t *popt, const bmh_sam_dev_t *d, uint64_t *d_text_off, void *d_work, size_t work_bytes, void *stream);
+int bmh_sam_text_write(const bmh_post_opt_t *popt, const bmh_sam_dev_t *d, const uint64_t *d_text_off, char *d_text, void *d_work, size_t work_bytes, void *stream);
+int bmh_sam_text_check(const void *d_work, uint32_t n_reads, void *stream);
+
 /* ------------------------------------------------- reads in host memory -> SAM text, batches driven by C threads (csrc/align_pipeline.hip)
  *
  * What gase_aln's worker threads do around the device libraries (src/bwamem.c:2042-2340, src/fastmap.c:59-120), on top of the entry

@@ -1,0 +1,65 @@
+"""Native reads -> SAM pipeline (bmh_aligner_run) on the bench workload (hg38-scale synthetic index built on the device): lanes x batch
+counts, with the per-batch timeline of the last run (BMH_ALIGNER_TRACE).  usage: lanes_probe.py [genome_mbp] [n_reads] [pe]"""
+import os, sys, time, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))
+import numpy as np, torch
+import bwamem_hip as B
+from bwamem_hip import fmindex as F
+from bwamem_hip.aligner import ReadSet
+from bwamem_hip.lib import NativeAligner, PeOpt, ChainOpt, PostOpt
+mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 3100
+n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+paired = len(sys.argv) > 3 and sys.argv[3] == "pe"
+dev = torch.device("cuda:0")
+L = B.load_library()
+n_genome = int(mbp * 1e6)
+g_t, meta = B.synth.make_genome_device(n_genome, dev, seed=42, return_meta=True)
+pac_t = F.pack_pac_device(g_t)
+g = g_t.cpu().numpy()
+del g_t
+torch.cuda.empty_cache()
+d = F.build_fmd_index_device(pac_t, n_genome, sa_intv=int(os.environ.get("SA_INTV", "1")))
+contigs, holes = meta["contigs"], meta["holes"]
+dindex = B.Index.from_device(d.primary, d.L2.astype(np.uint64), d.seq_len, d.bwt_t, d.sa_intv, d.sa_t, d.bits_t, pac_t=pac_t, l_pac=n_genome)
+torch.cuda.empty_cache()
+rl = 150
+reads = (B.synth.make_pairs(g, n_reads // 2, rl, seed=7, holes=holes) if paired else B.synth.make_reads(g, n_reads, rl, seed=7, holes=holes))[0]
+flat = np.ascontiguousarray(np.asarray(reads, np.uint8).reshape(-1))
+offs = np.arange(n_reads, dtype=np.uint64) * np.uint64(rl)
+co = ChainOpt(); L.bmh_chain_opt_default(C.byref(co)); po = PostOpt(); L.bmh_post_opt_default(C.byref(po))
+params = B.ExtParams.default()
+pe_o = PeOpt(); L.bmh_pe_opt_default(C.byref(pe_o))
+pac_h = pac_t.cpu().numpy()
+asc = B.synth.codes_to_ascii(flat)
+w = len(str(n_reads))
+names = np.char.add("r", np.char.zfill((np.arange(n_reads) // (2 if paired else 1)).astype(str), w))
+blob = np.frombuffer(("\0".join(names.tolist()) + "\0").encode(), dtype=np.uint8)
+noff = np.arange(n_reads, dtype=np.uint64) * np.uint64(w + 2)
+rs = ReadSet(asc, offs, np.full(n_reads, rl, np.uint32), blob, noff, codes=flat)
+nat = NativeAligner(dindex, pac_h, len(g), contigs, None, co, params, po, pe_o)
+nbytes = [0]
+def sink(mv): nbytes[0] += len(mv)
+nth = int(os.environ.get("LANES_THREADS", "0")) or L.bmh_effective_cpus()
+def throttled():
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0)) / 1e3, int(d.get("usage_usec", 0)) / 1e3
+    except Exception:
+        return 0, 0.0, 0.0
+cfgs = [tuple(int(v) for v in c.split("x")) for c in os.environ.get("LANES_CFGS", "2x4,3x4,3x8,4x8,2x8,2x4").split(",")]
+for lanes, nb in cfgs:
+    q = (n_reads // nb) & ~1
+    cuts = [k * q for k in range(nb)] + [n_reads]
+    for it in range(3):
+        if it == 2 and os.environ.get("LANES_TRACE"): os.environ["BMH_ALIGNER_TRACE"] = "1"
+        nbytes[0] = 0
+        th0 = throttled()
+        st = nat.run(rs, cuts, paired, sink, n_lanes=lanes, n_threads=nth)
+        th1 = throttled()
+        os.environ.pop("BMH_ALIGNER_TRACE", None)
+    print("   [cgroup] throttled %d times for %.1f ms during the run; CPU time used %.0f ms (%d threads asked for)" % (th1[0] - th0[0], th1[1] - th0[1], th1[2] - th0[2], nth))
+    print("lanes %d batches %d: %.1f ms = %.2f Mreads/s (%d bytes); format %.1f; lanes summed: H2D %.1f seed %.1f cem %.1f tail %.1f select %.1f cigar %.1f" %
+          (lanes, nb, st.seconds * 1e3, n_reads / st.seconds / 1e6, nbytes[0], st.format_seconds * 1e3, st.h2d_seconds * 1e3, st.seed_seconds * 1e3,
+           st.chain_extend_seconds * 1e3, st.tail_seconds * 1e3, st.select_seconds * 1e3, st.cigar_seconds * 1e3), flush=True)
+nat.free()

@@ -979,6 +979,32 @@ def test_reads_to_sam_text_matches_reference(hip, oracle, golden):
     cigar, aln, md = cigar_batch(dindex, r, o, l, torch.from_numpy(out.copy()).cuda(), len(sel), sel_t=torch.from_numpy(sel).cuda(), max_cigar=48, md_cap=640)
     torch.cuda.synchronize()
     slot = np.full(max(m, 1), -1, np.int64); slot[sel] = np.arange(len(sel))
+    # the selection and the packing the native pipeline does on the device (csrc/sam_kernels.hip): the host's list, the fixed slots' contents
+    from bwamem_hip.lib import sam_select_device, cigar_pack
+    for fa in (0, 1):
+        po2 = PostOpt(); Lb.bmh_post_opt_default(C.byref(po2)); po2.flag_all = fa
+        need2 = np.zeros(max(m, 1), np.uint8)
+        Lb.bmh_sam_need_cigar(C.byref(po2), _np_ptr(out, _i32p), _np_ptr(opr, _u32p), n, _np_ptr(need2, _u8p))
+        d_sel, d_slot = sam_select_device(po2, d_out.contiguous(), d_opr[:n].contiguous())
+        want_sel = np.nonzero(need2[:m])[0]
+        assert np.array_equal(d_sel.cpu().numpy(), want_sel), fa
+        want_slot = np.full(m, -1, np.int64); want_slot[want_sel] = np.arange(len(want_sel))
+        assert np.array_equal(d_slot.cpu().numpy(), want_slot), fa
+    for mc, mdc in ((48, 640), (4, 4)):                      # (small slots: some alignments overflow them and take no words)
+        cg2, al2, md2 = cigar_batch(dindex, r, o, l, d_out.contiguous(), len(sel), sel_t=torch.from_numpy(sel).cuda(), max_cigar=mc, md_cap=mdc)
+        off_t, packed_t = cigar_pack(al2, cg2, md2)
+        offp, pk = off_t.cpu().numpy().astype(np.int64), packed_t.cpu().numpy().view(np.uint32)
+        a2, c2, m2 = al2.cpu().numpy(), cg2.cpu().numpy().view(np.uint32), md2.cpu().numpy()
+        n_over = 0
+        for k2 in range(len(sel)):
+            if a2[k2, 7] & ~2:
+                assert offp[k2 + 1] == offp[k2]; n_over += 1
+                continue
+            nc, ml = int(a2[k2, 3]), int(a2[k2, 6])
+            assert offp[k2 + 1] - offp[k2] == nc + (ml + 4) // 4
+            assert np.array_equal(pk[offp[k2]: offp[k2] + nc], c2[k2, :nc])
+            assert pk[offp[k2] + nc: offp[k2 + 1]].tobytes()[: ml + 1] == m2[k2, : ml + 1].tobytes()
+        assert offp[len(sel)] == len(pk) and (mc == 48 or n_over > 0)
     txt = format_sam(po, [f"r{i}" for i in range(n)], flat, np.arange(n, dtype=np.uint64) * L, np.full(n, L, np.uint32), contigs, out, opr, slot,
                      aln.cpu().numpy(), cigar.cpu().numpy().view(np.uint32), md.cpu().numpy())
     want = bytes(z["sam_text"]).decode()
@@ -1024,6 +1050,16 @@ def test_aligner_writes_reference_sam(hip, tmp_path, golden):
         gl, wl = body.split("\n"), want.split("\n")
         assert False, (len(gl), len(wl), [(a, b) for a, b in zip(gl, wl) if a != b][:2])
     assert buf.getvalue().startswith(bytes(z["sam_header"]).decode())
+    # the native pipeline wrote that text on the device (bmh_sam_text_*); the host formatter from records copied home, and the host's selection
+    # of the records that need a CIGAR, give the same bytes -- and so does a batch whose region tail ran on the host (device tail refused)
+    for env in ("BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_HOST_SELECT", "BMH_FIN_FORCE_ECAPACITY"):
+        os.environ[env] = "1"
+        try:
+            buf2 = io.StringIO()
+            al.align_file(fq, buf2, batch_reads=1 << 30 if pe else 256, paired=pe)
+            assert buf2.getvalue() == buf.getvalue(), env
+        finally:
+            del os.environ[env]
     if not pe:
         # batches that grow and shrink: the aligner keeps its workspaces and pinned buffers between batches and replaces them when a batch
         # needs more; the text comes back as a view of the library's buffer (binary output)
@@ -1041,6 +1077,61 @@ def test_aligner_writes_reference_sam(hip, tmp_path, golden):
             assert al.has_alt or al.host_tail_batches == before + 1          # (an index with ALT contigs takes the host tail in the first place)
         finally:
             del os.environ["BMH_FIN_FORCE_ECAPACITY"]
+    al.close()
+
+
+@pytest.mark.parametrize("pe", [False, True])
+def test_native_pipeline_device_text_equals_host_text(hip, tmp_path, pe):
+    """bmh_aligner_run on a repeat-rich genome of three sequences, reads with many substitutions and indels among them (alignments that overflow
+    the fixed CIGAR / MD slots and are redone on the device): the text written on the device (bmh_sam_select_device, bmh_cigar_pack,
+    bmh_sam_text_*) is the text of the host path (records to the host, bmh_sam_need_cigar, bmh_format_sam), byte for byte."""
+    import io
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.aligner import Aligner
+    g = synth.make_genome(1_500_000, seed=11, repeat_frac=0.3)
+    contigs = [("chrA", 600_000), ("chrB", 500_000), ("chrC", 400_000)]
+    prefix = str(tmp_path / "g.fa")
+    fmindex.write_index(prefix, fmindex.build_fmd_index(g)); fmindex.write_bns(prefix, g, contigs=contigs)
+    n = 12000
+    L = 250
+    reads = (synth.make_pairs(g, n // 2, L, seed=5) if pe else synth.make_reads(g, n, L, seed=5))[0].copy()
+    rng = np.random.default_rng(9)
+    for r in rng.choice(n, 600, replace=False):                   # many substitutions (an MD string beyond 95 characters) ...
+        pos = rng.choice(L, 45, replace=False)
+        reads[r, pos] = (reads[r, pos] + rng.integers(1, 4, len(pos))) % 4
+    asc = [a.tobytes() for a in synth.codes_to_ascii(reads)]
+    for r in rng.choice(n, 600, replace=False):                   # ... and a dozen short indels (more operations than the fixed slot holds)
+        b = bytearray(asc[r])
+        for p in sorted(rng.choice(np.arange(15, L - 15, 16), 10, replace=False).tolist(), reverse=True):
+            if rng.integers(2):
+                del b[p]
+            else:
+                b.insert(p, b"ACGT"[int(rng.integers(4))])
+        asc[r] = bytes(b)
+    fq = str(tmp_path / "r.fa")
+    with open(fq, "wb") as f:
+        for i, a in enumerate(asc):
+            f.write((b">p%d\n" % (i // 2)) if pe else (b">r%d\n" % i)); f.write(a); f.write(b"\n")
+    al = Aligner(prefix, n_threads=4)
+    texts = {}
+    for env in ("", "BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_HOST_SELECT"):
+        if env:
+            os.environ[env] = "1"
+        try:
+            buf = io.BytesIO()
+            al.align_file(fq, buf, batch_reads=5000, paired=pe)
+            texts[env] = buf.getvalue()
+        finally:
+            if env:
+                del os.environ[env]
+    body = texts[""]
+    assert body.count(b"\n") >= n and b"\tXA:Z:" in body and b"\tSA:Z:" in body
+    lines = [l for l in body.split(b"\n") if l and not l.startswith(b"@")]
+    assert max(l.split(b"\t")[5].count(b"I") + l.split(b"\t")[5].count(b"D") for l in lines) >= 8       # the overflow path was taken
+    for env in ("BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_HOST_SELECT"):
+        if texts[env] != body:
+            a, b = body.split(b"\n"), texts[env].split(b"\n")
+            assert False, (env, len(a), len(b), [(x, y) for x, y in zip(a, b) if x != y][:2])
     al.close()
 
 

@@ -29,11 +29,19 @@ EXPORTED_SYMBOLS = [
     "bmh_chain_opt_default", "bmh_chain_last_timing", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
     "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_alt", "bmh_effective_cpus", "bmh_aligner_create", "bmh_aligner_free", "bmh_aligner_run", "bmh_chain_set_materialize", "bmh_chain_batch",
     "bmh_chain_extend", "bmh_chain_merge", "bmh_chain_extend_merge", "bmh_chain_extend_merge_timing", "bmh_cigar_batch", "bmh_cigar_release",
-    "bmh_sam_select_work", "bmh_sam_select_device", "bmh_cigar_pack_work", "bmh_cigar_pack_sizes", "bmh_cigar_pack",
+    "bmh_sam_select_work", "bmh_sam_select_device", "bmh_cigar_pack_work", "bmh_cigar_pack_sizes", "bmh_cigar_pack", "bmh_sam_text_work", "bmh_sam_text_sizes", "bmh_sam_text_write", "bmh_sam_text_check",
     "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
     "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
     "bmh_reads_load_fasta", "bmh_reads_free",
 ]
+
+
+class SamDev(C.Structure):
+    """bmh_sam_dev_t: device pointers of bmh_sam_text_sizes / bmh_sam_text_write"""
+    _fields_ = [("n_reads", C.c_uint32), ("d_names", C.c_void_p), ("d_name_off", C.c_void_p), ("d_reads", C.c_void_p), ("d_offs", C.c_void_p), ("d_lens", C.c_void_p),
+                ("n_contigs", C.c_int), ("d_contig_names", C.c_void_p), ("d_contig_name_off", C.c_void_p), ("d_contig_offset", C.c_void_p),
+                ("d_fin", C.c_void_p), ("d_fin_per_read", C.c_void_p), ("d_slot", C.c_void_p), ("d_aln", C.c_void_p), ("d_cig_off", C.c_void_p), ("d_packed", C.c_void_p),
+                ("d_h_rec", C.c_void_p), ("d_unflag", C.c_void_p)]
 
 
 class ReadSetT(C.Structure):
@@ -336,6 +344,14 @@ def load_library() -> C.CDLL:
     L.bmh_cigar_pack_sizes.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.bmh_cigar_pack.restype = C.c_int
     L.bmh_cigar_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bmh_sam_text_work.restype = C.c_size_t
+    L.bmh_sam_text_work.argtypes = [C.c_uint32]
+    L.bmh_sam_text_sizes.restype = C.c_int64
+    L.bmh_sam_text_sizes.argtypes = [C.POINTER(PostOpt), C.POINTER(SamDev), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.bmh_sam_text_write.restype = C.c_int
+    L.bmh_sam_text_write.argtypes = [C.POINTER(PostOpt), C.POINTER(SamDev), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.bmh_sam_text_check.restype = C.c_int
+    L.bmh_sam_text_check.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.bwt_restore_bwt_gpu.restype = C.POINTER(BwtTGpu)
     L.bwt_restore_bwt_gpu.argtypes = [C.c_char_p]
     L.bwt_restore_sa_gpu.argtypes = [C.c_char_p, C.POINTER(BwtTGpu)]
@@ -586,6 +602,40 @@ def cigar_pack(aln_t, cigar_t, md_t=None, stream: int = 0):
         raise RuntimeError(f"bmh_cigar_pack rc={rc}: " + _err(L))
     torch.cuda.synchronize()
     return off[:n + 1], packed[:int(words)]
+
+
+def sam_text_device(po: "PostOpt", names, reads_t, offs_t, lens_t, contigs, fin_t, fin_per_read_t, slot_t, aln_t, cig_off_t, packed_t, h_rec_t=None, unflag_t=None,
+                    stream: int = 0) -> bytes:
+    """bmh_sam_text_sizes + bmh_sam_text_write on torch CUDA tensors: the SAM text of a batch written on the device.  names: list of str;
+    contigs: list of (name, length); reads_t / offs_t / lens_t: the batch's ASCII reads; the rest as sam_select_device / cigar_batch / cigar_pack
+    left them.  Returns the text as bytes."""
+    import torch
+    L = load_library()
+    dev = fin_t.device
+    n = int(fin_per_read_t.shape[0])
+    enc = [x.encode() + b"\0" for x in names]
+    nblob = torch.from_numpy(np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8).copy()).to(dev)
+    noff = torch.from_numpy(np.concatenate([[0], np.cumsum([len(e) for e in enc])[:-1]]).astype(np.int64) if enc else np.zeros(1, np.int64)).to(dev)
+    cenc = [c[0].encode() + b"\0" for c in contigs]
+    cblob = torch.from_numpy(np.frombuffer(b"".join(cenc), dtype=np.uint8).copy()).to(dev)
+    cnoff = torch.from_numpy(np.concatenate([[0], np.cumsum([len(e) for e in cenc])[:-1]]).astype(np.int32)).to(dev)
+    coff = torch.from_numpy(np.concatenate([[0], np.cumsum([c[1] for c in contigs])[:-1]]).astype(np.int64)).to(dev)
+    d = SamDev(n, nblob.data_ptr(), noff.data_ptr(), reads_t.data_ptr(), offs_t.data_ptr(), lens_t.data_ptr(), len(contigs), cblob.data_ptr(), cnoff.data_ptr(), coff.data_ptr(),
+               fin_t.data_ptr(), fin_per_read_t.data_ptr(), slot_t.data_ptr(), aln_t.data_ptr(), cig_off_t.data_ptr(), packed_t.data_ptr(),
+               h_rec_t.data_ptr() if h_rec_t is not None else None, unflag_t.data_ptr() if unflag_t is not None else None)
+    wb = int(L.bmh_sam_text_work(n))
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    toff = torch.empty(n + 2, dtype=torch.int64, device=dev)
+    total = L.bmh_sam_text_sizes(C.byref(po), C.byref(d), toff.data_ptr(), work.data_ptr(), wb, stream)
+    if total < 0:
+        raise RuntimeError(f"bmh_sam_text_sizes rc={total}: " + _err(L))
+    text = torch.empty(max(int(total), 1), dtype=torch.uint8, device=dev)
+    rc = L.bmh_sam_text_write(C.byref(po), C.byref(d), toff.data_ptr(), text.data_ptr(), work.data_ptr(), wb, stream)
+    if rc == 0:
+        rc = L.bmh_sam_text_check(work.data_ptr(), n, stream)
+    if rc != 0:
+        raise RuntimeError(f"bmh_sam_text_write rc={rc}: " + _err(L))
+    return text[: int(total)].cpu().numpy().tobytes()
 
 
 class CapacityError(RuntimeError):

@@ -411,6 +411,7 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		LCK(hipMemcpyAsync(Ln.h_rpr.p, dj.d_regs_per_read, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
 		LCK(hipMemcpyAsync(Ln.h_fr.p, dj.d_frac_rep, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
 		LCK(hipStreamSynchronize(Ln.st));
+		if (getenv("BMH_PAIR_PROFILE")) fprintf(stderr, "[pairs] regions on the host after %.1f ms of the tail\n", (now_s() - t3) * 1e3);
 		uint64_t cap = nr + 2ull * n + 1024;                        // mate rescue adds a few regions per pair
 		int64_t m = BMH_ECAPACITY;
 		RCK(R.opr.need(n + 1)); R.h_rec.resize(n); R.unflag.resize(n);
@@ -421,6 +422,7 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 			                           R.fin.p, cap, R.opr.p, R.h_rec.data(), R.unflag.data(), nullptr, n_threads);
 		}
 		if (m < 0) return (int)m;
+		if (getenv("BMH_PAIR_PROFILE")) fprintf(stderr, "[pairs] bmh_finalize_pairs_dev back after %.1f ms of the tail\n", (now_s() - t3) * 1e3);
 		R.m = (uint64_t)m;
 		RCK(Ln.d_fin.need(16 * ((size_t)m + 1))); RCK(Ln.d_opr.need(n + 1)); RCK(Ln.d_hrec.need(n + 1));
 		if (m) LCK(hipMemcpyAsync(Ln.d_fin.p, R.fin.p, 64 * (size_t)m, hipMemcpyHostToDevice, Ln.st));

@@ -43,6 +43,9 @@ struct PCtx {
 	int sw_mode = 0;
 	std::vector<SwKey> *col_keys = nullptr; std::vector<bmh_msw_job_t> *col_jobs = nullptr;      // sw_mode 1 (per thread)
 	const SwKey *keys = nullptr; const uint64_t *pair_off = nullptr; const int32_t *res = nullptr;   // sw_mode 2
+	// sw_mode 1 writes, sw_mode 2 reads: 1 = a mem_matesw call of the pair got as far as a window (only then can the rescue change the pair's
+	// regions: for the other pairs -- nearly all -- the second walk skips the rescue, which is most of a walk on repeat-rich reads)
+	uint8_t *pair_active = nullptr;
 };
 
 inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)      // mem_infer_dir
@@ -158,12 +161,14 @@ int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector
 	const int64_t l_pac = c.x.l_pac;
 	int skip[4], n = 0;
 	for (int r = 0; r < 4; ++r) skip[r] = c.pes[r].failed ? 1 : 0;
+	int n_skip = skip[0] + skip[1] + skip[2] + skip[3];
 	for (const Reg &m : ma) {
+		if (n_skip == 4) break;                                     // (nothing left to rule out: the rest of the mate's hits change nothing)
 		int64_t dist;
 		const int r = infer_dir(l_pac, a.rb, m.rb, &dist);
-		if (dist >= c.pes[r].low && dist <= c.pes[r].high) skip[r] = 1;
+		if (dist >= c.pes[r].low && dist <= c.pes[r].high && !skip[r]) { skip[r] = 1; ++n_skip; }
 	}
-	if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
+	if (n_skip == 4) return 0;
 	std::vector<uint8_t> rev, ref, seqbuf;
 	for (int r = 0; r < 4; ++r) {
 		if (skip[r]) continue;
@@ -188,6 +193,7 @@ int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector
 		bool have = false;
 		if (rb < re) have = fetch_window(c, &rb, (rb + re) >> 1, &re, &rid, ref, false);
 		if (have && a.rid == rid && re - rb >= c.x.co->min_seed_len) {
+			if (c.sw_mode == 1 && c.pair_active) c.pair_active[key.pair] = 1;
 			const int xtra = BMH_SW_XSUBO | BMH_SW_XSTART | (l_ms * c.x.ep->a < 250 ? BMH_SW_XBYTE : 0) | (c.x.co->min_seed_len * c.x.ep->a);
 			bmh_sw_result_t aln = {0, -1, -1, -1, -1, -1, -1};
 			bool done = false;
@@ -324,7 +330,7 @@ int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // 
 	const uint8_t *seq[2] = {c.reads + c.offs[r0], c.reads + c.offs[r0 + 1]};
 	const int l_seq[2] = {(int)c.lens[r0], (int)c.lens[r0 + 1]};
 	int z[2] = {0, 0}, o, subo = 0, n_sub = 0, extra_flag = 1, n_pri[2];
-	if (!c.pe->no_rescue) {   // mate rescue for the best regions of each end (src/bwamem_pair.c:273)
+	if (!c.pe->no_rescue && !(c.sw_mode == 2 && c.pair_active && !c.pair_active[r0 >> 1])) {   // mate rescue for the best regions of each end (src/bwamem_pair.c:273)
 		std::vector<Reg> b[2];
 		for (int i = 0; i < 2; ++i)
 			for (const Reg &r : *a[i]) if (r.score >= (*a[i])[0].score - c.pe->pen_unpaired) b[i].push_back(r);
@@ -416,6 +422,21 @@ extern "C" void bmh_pe_opt_default(bmh_pe_opt_t *o) { o->pen_unpaired = 17; o->m
 // [12] = the record's primary for the XA tag or -1); out_h[r] = record of read r's own alignment within its list (what the
 // mate's RNEXT / PNEXT / TLEN are taken from) or -1 if unmapped; out_unflag[r] = flag bits of the unmapped record of a read
 // without reported alignment; pes_out[4][5] = {low, high, failed, avg, std} as doubles.  Returns the record count (<= cap).
+// What a call needs in large arrays, kept by the calling THREAD between calls: the regions of a million reads are 400 MB, the records another 250 --
+// allocated, faulted in and unmapped per call they cost a third of the call.  Freed when the thread ends.
+namespace {
+struct PairPart { std::vector<int32_t> rec; std::vector<uint32_t> n; std::vector<int32_t> h, uf; };
+struct PairScratch {
+	Reg *flat = nullptr; size_t flat_cap = 0;
+	std::vector<PairPart> parts;
+	std::vector<std::vector<SwKey>> tk; std::vector<std::vector<bmh_msw_job_t>> tj;
+	std::vector<SwKey> all_keys; std::vector<bmh_msw_job_t> all_jobs; std::vector<uint64_t> pair_off, in_off; std::vector<int32_t> sw_res; std::vector<uint8_t> pair_active;
+	std::vector<uint32_t> cnt;
+	~PairScratch() { free(flat); }
+};
+thread_local PairScratch g_pair_scratch;
+}
+
 static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
                                    int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
                                    const uint32_t *read_lens, const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
@@ -427,15 +448,24 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 	    (n_contigs > 1 && (!contig_offset || !contig_len))) { bmh_set_error("bmh_finalize_pairs: null argument"); return BMH_EINVAL; }
 	if (n_reads & 1) { bmh_set_error("bmh_finalize_pairs: odd number of reads (pairs are interleaved)"); return BMH_EINVAL; }
 	if (!(popt->mapQ_coef_len > 0)) { bmh_set_error("bmh_finalize_pairs: mapQ_coef_len <= 0 is not restated"); return BMH_EINVAL; }
+	const double t_in = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 	PCtx c;
 	c.x = {copt, ep, popt, l_pac, pac, n_contigs, contig_offset};
 	c.pe = pe; c.ctg_off = contig_offset; c.ctg_len = contig_len; c.reads = reads; c.offs = read_offs; c.lens = read_lens;
-	std::vector<uint64_t> in_off((size_t)n_reads + 1, 0);
+	PairScratch &S = g_pair_scratch;
+	std::vector<uint64_t> &in_off = S.in_off;
+	in_off.assign((size_t)n_reads + 1, 0);
 	for (uint32_t r = 0; r < n_reads; ++r) in_off[r + 1] = in_off[r] + regs_per_read[r];
 	// regions of all reads in one array (no per-read heap traffic: that, not the arithmetic, dominated on many threads)
-	std::unique_ptr<Reg[]> flat_mem(new Reg[(size_t)in_off[n_reads] + 1]);        // not zeroed: reg_from_record sets every field
-	Reg *const flat = flat_mem.get();
-	std::vector<uint32_t> cnt(n_reads, 0);
+	if ((size_t)in_off[n_reads] + 1 > S.flat_cap) {                  // not zeroed: reg_from_record sets every field
+		free(S.flat);
+		S.flat_cap = (size_t)in_off[n_reads] + (size_t)in_off[n_reads] / 4 + 1024;
+		S.flat = (Reg *)malloc(sizeof(Reg) * S.flat_cap);
+		if (!S.flat) { S.flat_cap = 0; bmh_set_error("bmh_finalize_pairs: out of memory"); return BMH_ENOMEM; }
+	}
+	Reg *const flat = S.flat;
+	std::vector<uint32_t> &cnt = S.cnt;
+	cnt.assign(n_reads, 0);
 	if (n_threads < 1) n_threads = 1;
 	if ((uint32_t)n_threads > n_reads / 2 + 1) n_threads = (int)(n_reads / 2 + 1);
 	auto par = [&](auto fn, uint32_t n_units) {
@@ -462,10 +492,17 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 	if (pes_out) for (int d = 0; d < 4; ++d) { pes_out[5 * d] = c.pes[d].low; pes_out[5 * d + 1] = c.pes[d].high; pes_out[5 * d + 2] = c.pes[d].failed; pes_out[5 * d + 3] = c.pes[d].avg; pes_out[5 * d + 4] = c.pes[d].std; }
 	// With a device: the local alignments of the mate rescue as one batch (pair_kernels.hip).  First walk: which alignments mem_matesw asks
 	// for (ranges of pairs on threads; their lists concatenate in pair order); then the kernel; the walk below takes the results.
-	std::vector<SwKey> all_keys; std::vector<bmh_msw_job_t> all_jobs; std::vector<uint64_t> pair_off; std::vector<int32_t> sw_res;
+	std::vector<SwKey> &all_keys = S.all_keys; std::vector<bmh_msw_job_t> &all_jobs = S.all_jobs; std::vector<uint64_t> &pair_off = S.pair_off; std::vector<int32_t> &sw_res = S.sw_res;
+	std::vector<uint8_t> &pair_active = S.pair_active;
+	all_keys.clear(); all_jobs.clear();
 	double t_sw0 = now(), t_sw1 = t_sw0, t_sw2 = t_sw0;
 	if (idx && !pe->no_rescue && n_reads) {
-		std::vector<std::vector<SwKey>> tk((size_t)n_threads); std::vector<std::vector<bmh_msw_job_t>> tj((size_t)n_threads);
+		std::vector<std::vector<SwKey>> &tk = S.tk; std::vector<std::vector<bmh_msw_job_t>> &tj = S.tj;
+		if (tk.size() < (size_t)n_threads) { tk.resize((size_t)n_threads); tj.resize((size_t)n_threads); }
+		for (auto &v : tk) v.clear();
+		for (auto &v : tj) v.clear();
+		pair_active.assign((size_t)n_reads / 2 + 1, 0);
+		c.pair_active = pair_active.data();                         // (a pair belongs to one thread: plain bytes)
 		par([&](int t, uint32_t p0, uint32_t p1) {
 			PCtx cl = c;
 			cl.sw_mode = 1; cl.col_keys = &tk[(size_t)t]; cl.col_jobs = &tj[(size_t)t];
@@ -487,8 +524,10 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 		c.sw_mode = 2; c.keys = all_keys.data(); c.pair_off = pair_off.data(); c.res = sw_res.data();
 	}
 	// per pair: mem_sam_pe's decisions; every thread appends the records of its (contiguous) pairs to its own buffer
-	struct Part { std::vector<int32_t> rec; std::vector<uint32_t> n; std::vector<int32_t> h, uf; };
-	std::vector<Part> parts((size_t)n_threads);
+	typedef PairPart Part;
+	std::vector<Part> &parts = S.parts;
+	parts.resize((size_t)n_threads);
+	for (Part &P : parts) { P.rec.clear(); P.n.clear(); P.h.clear(); P.uf.clear(); }
 	par([&](int t, uint32_t p0, uint32_t p1) {
 		Part &P = parts[(size_t)t];
 		P.rec.reserve((size_t)(in_off[2 * p1] - in_off[2 * p0]) * 16 + 64);
@@ -525,7 +564,7 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 		}
 	}, n_reads / 2);
 	const double t_d = now();
-	if (prof) fprintf(stderr, "[pairs] dedup %.1f ms, pestat %.1f ms, rescue jobs collected %.1f ms (%zu), on the device %.1f ms, mem_sam_pe %.1f ms (%d threads)\n", t_b - t_a, t_c - t_b, t_sw1 - t_sw0, all_jobs.size(), t_sw2 - t_sw1, t_d - t_sw2, n_threads);
+	if (prof) fprintf(stderr, "[pairs] setup %.1f ms, dedup %.1f ms, pestat %.1f ms, rescue jobs collected %.1f ms (%zu), on the device %.1f ms, mem_sam_pe %.1f ms (%d threads)\n", t_a - t_in, t_b - t_a, t_c - t_b, t_sw1 - t_sw0, all_jobs.size(), t_sw2 - t_sw1, t_d - t_sw2, n_threads);
 	// the parts go out side by side: offsets first, then every thread copies its own part
 	std::vector<uint64_t> w_off(parts.size() + 1, 0), r_off(parts.size() + 1, 0);
 	for (size_t t = 0; t < parts.size(); ++t) { w_off[t + 1] = w_off[t] + parts[t].rec.size() / 16; r_off[t + 1] = r_off[t] + parts[t].n.size(); }
@@ -538,6 +577,7 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 			for (size_t k = 0; k < P.n.size(); ++k, ++r) { out_per_read[r] = P.n[k]; out_h[r] = P.h[k]; out_unflag[r] = P.uf[k]; }
 		}
 	}, (uint32_t)parts.size());
+	if (prof) fprintf(stderr, "[pairs] records put in place %.1f ms; the whole call %.1f ms\n", now() - t_d, now() - t_in);
 	if (getenv("BMH_POST_STATS"))
 		fprintf(stderr, "[finalize_pairs] %u reads: mem_matesw calls %llu, local alignments on the host %llu (%.0f cells each), rescued regions %llu\n", n_reads,
 		        (unsigned long long)g_ms_calls.exchange(0), (unsigned long long)g_ms_sw.load(), (double)g_ms_cells.exchange(0) / (double)(g_ms_sw.load() ? g_ms_sw.load() : 1),

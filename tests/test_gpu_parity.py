@@ -1011,6 +1011,13 @@ def test_reads_to_sam_text_matches_reference(hip, oracle, golden):
     if txt != want:
         gl, wl = txt.split("\n"), want.split("\n")
         assert False, (len(gl), len(wl), [(a, b) for a, b in zip(gl, wl) if a != b][:2])
+    # ... and the same text written by the device (bmh_sam_text_sizes / _write) from the device's own selection and packed CIGARs
+    from bwamem_hip.lib import sam_text_device
+    d_sel, d_slot = sam_select_device(po, d_out.contiguous(), d_opr[:n].contiguous())
+    cg3, al3, md3 = cigar_batch(dindex, r, o, l, d_out.contiguous(), int(d_sel.shape[0]), sel_t=d_sel.contiguous(), max_cigar=48, md_cap=640)
+    off3, pk3 = cigar_pack(al3, cg3, md3)
+    txt_dev = sam_text_device(po, [f"r{i}" for i in range(n)], r, o, l, contigs, d_out.contiguous(), d_opr[:n].contiguous(), d_slot.contiguous(), al3, off3.contiguous(), pk3.contiguous())
+    assert txt_dev.decode() == want
     cw.free(); ws.free(); dindex.free()
 
 

@@ -692,7 +692,7 @@ def main():
             res["extension_stage"] = valu
             if a.next_rows:
                 try:
-                    res["next_rows"] = downstream_stages(L, dindex, batches[1][1], cw, regs_out[1], st["n_regs"], n_reads, g, pac_t, batches[1][0], params, contigs, a.paired)
+                    res["next_rows"] = downstream_stages(L, dindex, batches[1][1], cw, regs_out[1], st["n_regs"], n_reads, g, pac_t, batches[1][0], params, contigs, a.paired, reads2=batches[0][0])
                 except Exception as e:                      # never lose the bench line over the extras
                     res["next_rows"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
@@ -704,7 +704,7 @@ def main():
         sys.exit(3)
 
 
-def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, reads, params, contigs, paired=False):
+def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, reads, params, contigs, paired=False, reads2=None):
     """The rows after the hot path, measured on the same batch and reported beside the metric, not in it:
     bmh_finalize_regs / bmh_finalize_pairs (host threads, like the reference) and bmh_cigar_batch (device: CIGAR / NM / MD of every reported alignment)."""
     from bwamem_hip.lib import ChainOpt, PostOpt, cigar_batch, _np_ptr, _u8p, _u64p, _i32p, _u32p
@@ -775,37 +775,50 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
         torch.cuda.synchronize(); t0 = time.perf_counter()
         cg, aln, md = cigar_batch(dindex, dr.ascii, dr.offs, dr.lens, out_t, len(sel), sel_t=sel_t, params=params, max_cigar=24, md_cap=128)
         torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
-    # reads in host memory -> SAM text through the native pipeline (bmh_aligner_run: batches driven by C threads): the whole gase_aln run on this batch,
-    # cut into four batches so that the two lanes and the writer overlap; second of two runs (the first one allocates lanes, workspaces and pinned buffers)
+    # reads in host memory -> SAM text through the native pipeline (bmh_aligner_run: batches driven by C threads): the whole gase_aln run on FOUR batches of
+    # the step's size (the step's two batches, twice: a batch of a quarter of a million reads spends a third of its time in fixed per-batch latencies,
+    # and the reference's own batches are 10 Mbases per thread), two lanes; second of two runs (the first one allocates lanes, workspaces and pinned buffers)
     sam_row = {}
     try:
         from bwamem_hip.aligner import ReadSet
         from bwamem_hip.lib import NativeAligner, PeOpt
         pe_o = PeOpt(); L.bmh_pe_opt_default(C.byref(pe_o))
-        asc = B.synth.codes_to_ascii(flat)
-        w = len(str(n_reads))
-        names = np.char.add("r", np.char.zfill((np.arange(n_reads) // (2 if paired else 1)).astype(str), w))
+        flat2 = flat if reads2 is None else np.ascontiguousarray(reads2.reshape(-1))
+        flat4 = np.concatenate([flat, flat2, flat, flat2])
+        n4 = 4 * n_reads
+        asc = B.synth.codes_to_ascii(flat4)
+        w = len(str(n4))
+        names = np.char.add("r", np.char.zfill((np.arange(n4) // (2 if paired else 1)).astype(str), w))
         blob = np.frombuffer(("\0".join(names.tolist()) + "\0").encode(), dtype=np.uint8)
-        noff = np.arange(n_reads, dtype=np.uint64) * np.uint64(w + 2)
-        rs = ReadSet(asc, offs, np.full(n_reads, rl, np.uint32), blob, noff, codes=flat)
-        q4 = (n_reads // 4) & ~1
-        cuts4 = [0, q4, 2 * q4, 3 * q4, n_reads]
+        noff = np.arange(n4, dtype=np.uint64) * np.uint64(w + 2)
+        rs = ReadSet(asc, np.arange(n4, dtype=np.uint64) * np.uint64(rl), np.full(n4, rl, np.uint32), blob, noff, codes=flat4)
+        cuts4 = [0, n_reads, 2 * n_reads, 3 * n_reads, n4]
         nat = NativeAligner(dindex, pac_h, len(g), contigs, None, co, params, po, pe_o)
         nbytes = [0]
 
         def sink(mv):
             nbytes[0] += len(mv)
+
+        def cpu_ms():
+            try:
+                return int(dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))["usage_usec"]) / 1e3
+            except Exception:               # noqa: BLE001
+                return float("nan")
         st_n = None
+        lanes_n = int(os.environ.get("BENCH_SAM_LANES", "2"))
         for _ in range(2):
             nbytes[0] = 0
-            st_n = nat.run(rs, cuts4, paired, sink, n_lanes=int(os.environ.get("BENCH_SAM_LANES", "2")), n_threads=nth)
+            c0 = cpu_ms()
+            st_n = nat.run(rs, cuts4, paired, sink, n_lanes=lanes_n, n_threads=nth)
+            c1 = cpu_ms()
         nat.free()
-        sam_row = {"reads_to_sam_native": {"Mreads_per_s": round(n_reads / st_n.seconds / 1e6, 2), "ms": round(st_n.seconds * 1e3, 1), "sam_bytes": int(nbytes[0]), "batches": 4, "lanes": 2,
-                                           "writer_format_ms": round(st_n.format_seconds * 1e3, 1),
+        sam_row = {"reads_to_sam_native": {"Mreads_per_s": round(n4 / st_n.seconds / 1e6, 2), "ms": round(st_n.seconds * 1e3, 1), "reads": int(n4), "sam_bytes": int(nbytes[0]), "batches": 4, "lanes": lanes_n,
+                                           "host_cpu_ms_per_million_reads": round((c1 - c0) / (n4 / 1e6), 1), "writer_format_ms": round(st_n.format_seconds * 1e3, 1),
                                            "lanes_ms_summed": {"h2d": round(st_n.h2d_seconds * 1e3, 1), "seeding": round(st_n.seed_seconds * 1e3, 1), "chain_extend_merge": round(st_n.chain_extend_seconds * 1e3, 1),
-                                                               "tail": round(st_n.tail_seconds * 1e3, 1), "select": round(st_n.select_seconds * 1e3, 1), "cigar_d2h": round(st_n.cigar_seconds * 1e3, 1)},
-                                           "what": "bmh_aligner_run: ASCII reads in host memory -> H2D -> seeding -> chaining -> extension -> merge -> region tail -> CIGAR / NM / MD -> D2H -> SAM "
-                                                   "records formatted by the writer thread (text handed to a sink that counts it); the same text the golden SAM tests compare with the reference's"}}
+                                                               "tail": round(st_n.tail_seconds * 1e3, 1), "select": round(st_n.select_seconds * 1e3, 1), "cigar_text_d2h": round(st_n.cigar_seconds * 1e3, 1)},
+                                           "what": "bmh_aligner_run: ASCII reads in host memory -> H2D -> seeding -> chaining -> extension -> merge -> region tail -> selection of the records -> "
+                                                   "CIGAR / NM / MD -> the SAM text written on the device (bmh_sam_text_*; interleaved pairs: the region tail of mem_sam_pe on host threads in between) -> "
+                                                   "D2H of the text -> a sink that counts it; the same text the golden SAM tests compare with the reference's"}}
     except Exception as e:                                  # noqa: BLE001 -- an extra, never at the expense of the line
         sam_row = {"reads_to_sam_native": {"error": repr(e)}}
     return {**(dev_row if not paired else {}), **sam_row, name: dict({"ms": round(t_fin * 1e3, 2), "threads": nth, "regions_in": int(n_regs), "regions_out": int(m), "d2h_regions_ms": round(t_d2h * 1e3, 2)}, **extra),

@@ -792,7 +792,10 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
         blob = np.frombuffer(("\0".join(names.tolist()) + "\0").encode(), dtype=np.uint8)
         noff = np.arange(n4, dtype=np.uint64) * np.uint64(w + 2)
         rs = ReadSet(asc, np.arange(n4, dtype=np.uint64) * np.uint64(rl), np.full(n4, rl, np.uint32), blob, noff, codes=flat4)
-        cuts4 = [0, n_reads, 2 * n_reads, 3 * n_reads, n4]
+        # single-end: four batches of a million reads on two lanes; interleaved pairs (the host walks of mem_sam_pe between the device stages): six batches on three
+        lanes_n = int(os.environ.get("BENCH_SAM_LANES", "3" if paired else "2"))
+        nb4 = int(os.environ.get("BENCH_SAM_BATCHES", "6" if paired else "4"))
+        cuts4 = [((n4 * k // nb4) & ~1) for k in range(nb4)] + [n4]
         nat = NativeAligner(dindex, pac_h, len(g), contigs, None, co, params, po, pe_o)
         nbytes = [0]
 
@@ -805,14 +808,13 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
             except Exception:               # noqa: BLE001
                 return float("nan")
         st_n = None
-        lanes_n = int(os.environ.get("BENCH_SAM_LANES", "2"))
         for _ in range(2):
             nbytes[0] = 0
             c0 = cpu_ms()
             st_n = nat.run(rs, cuts4, paired, sink, n_lanes=lanes_n, n_threads=nth)
             c1 = cpu_ms()
         nat.free()
-        sam_row = {"reads_to_sam_native": {"Mreads_per_s": round(n4 / st_n.seconds / 1e6, 2), "ms": round(st_n.seconds * 1e3, 1), "reads": int(n4), "sam_bytes": int(nbytes[0]), "batches": 4, "lanes": lanes_n,
+        sam_row = {"reads_to_sam_native": {"Mreads_per_s": round(n4 / st_n.seconds / 1e6, 2), "ms": round(st_n.seconds * 1e3, 1), "reads": int(n4), "sam_bytes": int(nbytes[0]), "batches": nb4, "lanes": lanes_n,
                                            "host_cpu_ms_per_million_reads": round((c1 - c0) / (n4 / 1e6), 1), "writer_format_ms": round(st_n.format_seconds * 1e3, 1),
                                            "lanes_ms_summed": {"h2d": round(st_n.h2d_seconds * 1e3, 1), "seeding": round(st_n.seed_seconds * 1e3, 1), "chain_extend_merge": round(st_n.chain_extend_seconds * 1e3, 1),
                                                                "tail": round(st_n.tail_seconds * 1e3, 1), "select": round(st_n.select_seconds * 1e3, 1), "cigar_text_d2h": round(st_n.cigar_seconds * 1e3, 1)},

@@ -406,18 +406,29 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		}
 		R.m = (uint64_t)m;
 	} else {
-		RCK(Ln.h_regs.need(8 * (nr + 1))); RCK(Ln.h_rpr.need(n + 1)); RCK(Ln.h_fr.need(n + 1));
-		if (nr) LCK(hipMemcpyAsync(Ln.h_regs.p, Ln.d_regs.p, 32 * (size_t)nr, hipMemcpyDeviceToHost, Ln.st));
-		LCK(hipMemcpyAsync(Ln.h_rpr.p, dj.d_regs_per_read, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
+		// mem_sort_dedup_patch of every read on the device (the first step of the single-end tail: bmh_dedup_regs_device), the rest of mem_sam_pe on host
+		// threads from its records; a batch the device refuses (a read beyond its fixed limits), or BMH_ALIGNER_PE_HOST_DEDUP, takes the regions themselves
+		int64_t md = BMH_ECAPACITY;
+		if (!getenv("BMH_ALIGNER_PE_HOST_DEDUP")) {
+			RCK(Ln.d_fin.need(16 * (nr + 1))); RCK(Ln.d_opr.need(n + 1));
+			md = bmh_dedup_regs_device(A.idx, &A.co, &A.ep, &po, Ln.d_reads.p, Ln.d_offs.p, n, Ln.d_regs.p, nr, dj.d_regs_per_read, A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr,
+			                           Ln.d_fin.p, Ln.d_opr.p, Ln.st);
+			if (md < 0 && md != BMH_ECAPACITY) return (int)md;
+		}
+		const bool deduped = md >= 0;
+		const uint64_t n_in = deduped ? (uint64_t)md : nr;
+		RCK(Ln.h_regs.need((deduped ? 16 : 8) * (n_in + 1))); RCK(Ln.h_rpr.need(n + 1)); RCK(Ln.h_fr.need(n + 1));
+		if (n_in) LCK(hipMemcpyAsync(Ln.h_regs.p, deduped ? Ln.d_fin.p : Ln.d_regs.p, (deduped ? 64 : 32) * (size_t)n_in, hipMemcpyDeviceToHost, Ln.st));
+		LCK(hipMemcpyAsync(Ln.h_rpr.p, deduped ? Ln.d_opr.p : dj.d_regs_per_read, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
 		LCK(hipMemcpyAsync(Ln.h_fr.p, dj.d_frac_rep, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
 		LCK(hipStreamSynchronize(Ln.st));
 		if (getenv("BMH_PAIR_PROFILE")) fprintf(stderr, "[pairs] regions on the host after %.1f ms of the tail\n", (now_s() - t3) * 1e3);
-		uint64_t cap = nr + 2ull * n + 1024;                        // mate rescue adds a few regions per pair
+		uint64_t cap = n_in + 2ull * n + 1024;                      // mate rescue adds a few regions per pair
 		int64_t m = BMH_ECAPACITY;
 		RCK(R.opr.need(n + 1)); R.h_rec.resize(n); R.unflag.resize(n);
 		for (int attempt = 0; attempt < 3 && m == BMH_ECAPACITY; ++attempt, cap *= 2) {
 			RCK(R.fin.need(16 * (size_t)cap));
-			m = bmh_finalize_pairs_dev(A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.st, &A.co, &A.ep, &po, &A.pe, A.l_pac, A.pac, n, codes, host_offs(), rs.lens + b0,
+			m = (deduped ? bmh_finalize_pairs_deduped : bmh_finalize_pairs_dev)(A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.st, &A.co, &A.ep, &po, &A.pe, A.l_pac, A.pac, n, codes, host_offs(), rs.lens + b0,
 			                           Ln.h_regs.p, Ln.h_rpr.p, Ln.h_fr.p, A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr, A.n_contigs > 1 ? A.len.data() : nullptr,
 			                           R.fin.p, cap, R.opr.p, R.h_rec.data(), R.unflag.data(), nullptr, n_threads);
 		}

@@ -442,7 +442,7 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
                                    const uint32_t *read_lens, const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
                                    int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
                                    int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
-                                   int n_threads, const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream)
+                                   int n_threads, const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream, bool deduped = false)
 {
 	if (!copt || !ep || !popt || !pe || !pac || !reads || !read_offs || !read_lens || !regs_per_read || !out || !out_per_read || !out_h || !out_unflag ||
 	    (n_contigs > 1 && (!contig_offset || !contig_len))) { bmh_set_error("bmh_finalize_pairs: null argument"); return BMH_EINVAL; }
@@ -481,6 +481,19 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 		for (uint32_t r = r0; r < r1; ++r) {
 			const int n_in = (int)regs_per_read[r];
 			Reg *a = flat + in_off[r];
+			if (deduped) {
+				// records of bmh_dedup_regs_device: mem_sort_dedup_patch has run on the device; [1..9] as a region leaves it, [13] its sequence
+				for (int i = 0; i < n_in; ++i) {
+					const int32_t *g = regs_in + 16 * (in_off[r] + i);
+					Reg &p = a[i];
+					memset(&p, 0, sizeof(p));
+					p.score = g[1]; p.qb = g[2]; p.qe = g[3]; p.rb = (int64_t)(uint32_t)g[4] | (int64_t)g[5] << 32; p.re = (int64_t)(uint32_t)g[6] | (int64_t)g[7] << 32;
+					p.truesc = g[8]; p.w = g[9]; p.rid = g[13]; p.secondary = -1; p.frac_rep = frac_rep ? frac_rep[r] : 0.f;
+				}
+				cnt[r] = (uint32_t)n_in;
+				set_is_alt(c.x, n_in, a);
+				continue;
+			}
 			for (int i = 0; i < n_in; ++i) reg_from_record(c.x, regs_in + 8 * (in_off[r] + i), frac_rep ? frac_rep[r] : 0.f, a[i]);
 			cnt[r] = (uint32_t)sort_dedup_patch(c.x, reads + read_offs[r], n_in, a);
 			set_is_alt(c.x, (int)cnt[r], a);                            // src/bwamem.c:2321-2325
@@ -609,4 +622,19 @@ extern "C" int64_t bmh_finalize_pairs_dev(const bmh_index_t *idx, const uint8_t 
 	if (!idx || !d_reads || !d_offs) { bmh_set_error("bmh_finalize_pairs_dev: null argument"); return BMH_EINVAL; }
 	return finalize_pairs_impl(copt, ep, popt, pe, l_pac, pac, n_reads, reads, read_offs, read_lens, regs_in, regs_per_read, frac_rep, n_contigs, contig_offset, contig_len,
 	                           out, cap, out_per_read, out_h, out_unflag, pes_out, n_threads, idx, d_reads, d_offs, stream);
+}
+
+// The same from regions mem_sort_dedup_patch has been through already ON THE DEVICE: dedup_recs[..][16] / dedup_per_read as bmh_dedup_regs_device left them
+// (copied to the host).  Same results as bmh_finalize_pairs_dev on the regions they were made from.
+extern "C" int64_t bmh_finalize_pairs_deduped(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream,
+                                              const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
+                                              int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                                              const uint32_t *read_lens, const int32_t *dedup_recs, const uint32_t *dedup_per_read, const float *frac_rep,
+                                              int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
+                                              int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
+                                              int n_threads)
+{
+	if (!idx || !d_reads || !d_offs) { bmh_set_error("bmh_finalize_pairs_deduped: null argument"); return BMH_EINVAL; }
+	return finalize_pairs_impl(copt, ep, popt, pe, l_pac, pac, n_reads, reads, read_offs, read_lens, dedup_recs, dedup_per_read, frac_rep, n_contigs, contig_offset, contig_len,
+	                           out, cap, out_per_read, out_h, out_unflag, pes_out, n_threads, idx, d_reads, d_offs, stream, true);
 }

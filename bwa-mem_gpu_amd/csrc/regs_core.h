@@ -34,6 +34,9 @@ struct ctx_t {
 	// scratch of the patch test's global alignment (qcap + 2 ints each); null: the caller cannot run it (the lane kernel) and the
 	// core reports NEED_DP instead
 	int32_t *dp_h, *dp_e; int dp_cap;
+	// 1: the tail stops behind mem_sort_dedup_patch (interleaved pairs: mem_sam_pe takes the reads' regions from there): the records keep
+	// [1..9] and the sequence id in [13], [0] = the read
+	int dedup_only;
 };
 
 enum { OK = 0, NEED_DP = 1, E_LOG = 2, E_DPCAP = 3 };
@@ -479,6 +482,7 @@ RC_HD inline int finalize_read(const ctx_t &x, const uint8_t *query, uint32_t re
 	for (int i = 0; i < n_in; ++i) init_one(x, a[i]);
 	int n = sort_dedup_patch<ASCII, NSTK>(x, query, n_in, a);
 	if (n < 0) return n;
+	if (x.dedup_only) { for (int i = 0; i < n; ++i) a[i].v[0] = (int32_t)read; return n; }
 	mark_primary<NSTK>(x, n, a, id, z);
 	return emit_all(x, read, frac_rep, n, a);
 }

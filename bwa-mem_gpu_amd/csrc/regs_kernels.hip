@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) fin_lane_kernel(fin_args_t A)
 			const int4 u = src[0], v = src[1];
 			a[i].v[0] = u.x; a[i].v[1] = u.y; a[i].v[2] = u.z; a[i].v[3] = u.w; a[i].v[4] = v.x; a[i].v[5] = v.y; a[i].v[6] = v.z; a[i].v[7] = v.w;
 		}
-		const int n = finalize_read<true, 1>(A.x, A.reads + A.read_offs[r], r, A.x.po.id0 + r, A.frac_rep[r], n_in, a, z);
+		const int n = finalize_read<true, 1>(A.x, A.reads + A.read_offs[r], r, A.x.po.id0 + r, A.frac_rep ? A.frac_rep[r] : 0.f, n_in, a, z);
 		if (n == -NEED_DP) defer = true;
 		else if (n < 0) { A.ctr[16] = (uint32_t)-n; A.opr[r] = 0; return; }
 		else {
@@ -492,6 +492,11 @@ template <bool STAGED> __device__ int fin_wave_read(const ctx_t &x, const uint8_
 		{ rec_t *a = P.a; n = fin_wave_compact(P, n, [a](int i) { return i == 0 || a[i].v[3] > a[i].v[2]; }); }
 		FIN_STAMP(5);
 	}
+	if (x.dedup_only) {
+		for (int i = lane; i < n; i += 64) P.a[i].v[0] = (int32_t)read;
+		ch_wave_fence<false>();
+		return n;
+	}
 	for (int i = lane; i < n; i += 64) mark_init_one(P.a[i], id, i);
 	ch_wave_fence<false>();
 	if (!fin_wave_sort<KEY_SCORE_HASH, STAGED>(P, n, stage)) return -E_DPCAP;
@@ -555,7 +560,7 @@ __global__ void __launch_bounds__(64) fin_wave_kernel(fin_args_t A)
 			d.v[0] = u.x; d.v[1] = u.y; d.v[2] = u.z; d.v[3] = u.w; d.v[4] = v.x; d.v[5] = v.y; d.v[6] = v.z; d.v[7] = v.w;
 		}
 		ch_wave_fence<false>();
-		const int n = fin_wave_read<NMAX == 0>(x, A.reads + A.read_offs[r], r, x.po.id0 + r, A.frac_rep[r], n_in, P, lstage);
+		const int n = fin_wave_read<NMAX == 0>(x, A.reads + A.read_offs[r], r, x.po.id0 + r, A.frac_rep ? A.frac_rep[r] : 0.f, n_in, P, lstage);
 		if (n < 0) { if (lane == 0) { A.ctr[16] = (uint32_t)-n; A.opr[r] = 0; } continue; }
 		rec_t *dst = (rec_t *)(A.work + 16 * (size_t)off);
 		if (P.a != dst) for (int i = lane; i < n; i += 64) dst[i] = P.a[i];
@@ -637,20 +642,42 @@ extern "C" float bmh_finalize_regs_device_last_ms(void)
 	return ms;
 }
 
+static int64_t finalize_regs_device_impl(const bmh_index_t *idx, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt,
+                                         const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
+                                         const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read, const float *d_frac_rep,
+                                         int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream_, int dedup_only);
+
 extern "C" int64_t bmh_finalize_regs_device(const bmh_index_t *idx, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt,
                                             const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
                                             const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read, const float *d_frac_rep,
                                             int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream_)
 {
-	if (!idx || !copt || !ep || !popt || (n_reads && (!d_reads || !d_offs || !d_regs_per_read || !d_frac_rep || !d_out_per_read)) || (n_regs && (!d_regs || !d_out))) {
+	return finalize_regs_device_impl(idx, copt, ep, popt, d_reads, d_offs, n_reads, d_regs, n_regs, d_regs_per_read, d_frac_rep, n_contigs, contig_offset, d_out, d_out_per_read, stream_, 0);
+}
+
+// mem_sort_dedup_patch alone (the first step of the region tail, the step interleaved pairs share with single-end reads): see the header
+extern "C" int64_t bmh_dedup_regs_device(const bmh_index_t *idx, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt,
+                                         const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
+                                         const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read,
+                                         int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream_)
+{
+	return finalize_regs_device_impl(idx, copt, ep, popt, d_reads, d_offs, n_reads, d_regs, n_regs, d_regs_per_read, nullptr, n_contigs, contig_offset, d_out, d_out_per_read, stream_, 1);
+}
+
+static int64_t finalize_regs_device_impl(const bmh_index_t *idx, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt,
+                                         const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
+                                         const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read, const float *d_frac_rep,
+                                         int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream_, int dedup_only)
+{
+	if (!idx || !copt || !ep || !popt || (n_reads && (!d_reads || !d_offs || !d_regs_per_read || (!d_frac_rep && !dedup_only) || !d_out_per_read)) || (n_regs && (!d_regs || !d_out))) {
 		bmh_set_error("bmh_finalize_regs_device: null argument"); return BMH_EINVAL;
 	}
 	if (!idx->dev.pac) { bmh_set_error("bmh_finalize_regs_device: the index has no 2-bit reference"); return BMH_EINVAL; }
-	if (!(popt->mapQ_coef_len > 0)) { bmh_set_error("bmh_finalize_regs_device: mapQ_coef_len <= 0 (the seed-coverage form of MAPQ) is not restated"); return BMH_EINVAL; }
+	if (!dedup_only && !(popt->mapQ_coef_len > 0)) { bmh_set_error("bmh_finalize_regs_device: mapQ_coef_len <= 0 (the seed-coverage form of MAPQ) is not restated"); return BMH_EINVAL; }
 	if (n_contigs > 1 && !contig_offset) { bmh_set_error("bmh_finalize_regs_device: null contig table"); return BMH_EINVAL; }
 	if (n_regs >> 31) { bmh_set_error("bmh_finalize_regs_device: 2^31 regions or more in one batch"); return BMH_ECAPACITY; }
 	if (n_reads == 0) return 0;
-	if (popt->contig_is_alt) {
+	if (popt->contig_is_alt && !dedup_only) {
 		// ALT contigs (a second marking round over the primary assembly's hits, secondary_all, alt_sc: src/bwamem.c:714-760) are the host tail's
 		bmh_set_error("bmh_finalize_regs_device: ALT contigs are not modelled on the device: this batch belongs to bmh_finalize_regs");
 		return BMH_ECAPACITY;
@@ -718,7 +745,8 @@ extern "C" int64_t bmh_finalize_regs_device(const bmh_index_t *idx, const bmh_ch
 	memset(&A, 0, sizeof(A));
 	A.x.co = *copt; A.x.ep = *ep; A.x.po = *popt; A.x.l_pac = (int64_t)idx->dev.l_pac; A.x.pac = idx->dev.pac;
 	A.x.n_contigs = n_contigs > 1 ? n_contigs : 1; A.x.ctg_off = n_contigs > 1 ? S->ctg : nullptr;
-	A.x.logtab = S->logtab; A.x.n_log = FIN_NLOG; A.x.dp_h = A.x.dp_e = nullptr; A.x.dp_cap = 0;
+	A.x.logtab = S->logtab; A.x.n_log = FIN_NLOG; A.x.dp_h = A.x.dp_e = nullptr; A.x.dp_cap = 0; A.x.dedup_only = dedup_only;
+	A.x.po.contig_is_alt = nullptr;                               // (a host pointer: never followed on the device)
 	A.reads = d_reads; A.read_offs = d_offs; A.regs_in = d_regs; A.rpr = d_regs_per_read; A.in_off = S->in_off; A.frac_rep = d_frac_rep;
 	A.work = S->work; A.work2 = S->work2; A.g_keys = S->g_keys; A.g_k128 = S->g_k128; A.g_tmp = S->g_tmp; A.g_order = S->g_order; A.g_z = S->g_z;
 	A.opr = d_out_per_read; A.n_reads = n_reads; A.defer = S->defer; A.ctr = S->ctr; A.g_dp = S->g_dp;

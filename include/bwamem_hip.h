@@ -380,6 +380,23 @@ int64_t bmh_finalize_pairs_dev(const bmh_index_t *idx, const uint8_t *d_reads, c
                                int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
                                int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
                                int n_threads);
+/* mem_sort_dedup_patch alone on the device (csrc/regs_kernels.hip: the first step of bmh_finalize_regs_device, the step the tail of interleaved
+ * pairs shares with it): arguments as bmh_finalize_regs_device without d_frac_rep; d_out [n_regs][16] receives, grouped by read in the input's
+ * order, the regions that are left -- [0] read, [1] score, [2] qb, [3] qe, [4..7] rb / re, [8] truesc, [9] w (a patched region carries a wider
+ * band), [13] its sequence; the other fields are unspecified --, d_out_per_read their numbers.  Returns their total or a negative BMH_E* code
+ * (BMH_ECAPACITY: a read beyond the kernels' fixed limits: the caller takes the host form); waits for the stream.  ALT tables are not looked at.
+ * bmh_finalize_pairs_deduped: bmh_finalize_pairs_dev from those records (copied to the host) instead of the regions: same results. */
+int64_t bmh_dedup_regs_device(const bmh_index_t *idx, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt,
+                              const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
+                              const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read,
+                              int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream);
+int64_t bmh_finalize_pairs_deduped(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream,
+                                   const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
+                                   int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                                   const uint32_t *read_lens, const int32_t *dedup_recs, const uint32_t *dedup_per_read, const float *frac_rep,
+                                   int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
+                                   int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
+                                   int n_threads);
 int64_t bmh_sam_need_cigar_pe(const bmh_post_opt_t *po, const int32_t *fin, const uint32_t *fin_per_read, const int32_t *h_rec,
                               uint32_t n_reads, uint8_t *need);
 char *bmh_format_sam_pe(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,

@@ -1059,7 +1059,7 @@ def test_aligner_writes_reference_sam(hip, tmp_path, golden):
     assert buf.getvalue().startswith(bytes(z["sam_header"]).decode())
     # the native pipeline wrote that text on the device (bmh_sam_text_*); the host formatter from records copied home, and the host's selection
     # of the records that need a CIGAR, give the same bytes -- and so does a batch whose region tail ran on the host (device tail refused)
-    for env in ("BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_HOST_SELECT", "BMH_FIN_FORCE_ECAPACITY"):
+    for env in ("BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_HOST_SELECT", "BMH_FIN_FORCE_ECAPACITY", "BMH_ALIGNER_PE_HOST_DEDUP"):
         os.environ[env] = "1"
         try:
             buf2 = io.StringIO()
@@ -1121,7 +1121,7 @@ def test_native_pipeline_device_text_equals_host_text(hip, tmp_path, pe):
             f.write((b">p%d\n" % (i // 2)) if pe else (b">r%d\n" % i)); f.write(a); f.write(b"\n")
     al = Aligner(prefix, n_threads=4)
     texts = {}
-    for env in ("", "BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_HOST_SELECT"):
+    for env in ("", "BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_HOST_SELECT") + (("BMH_ALIGNER_PE_HOST_DEDUP",) if pe else ()):
         if env:
             os.environ[env] = "1"
         try:
@@ -1135,7 +1135,7 @@ def test_native_pipeline_device_text_equals_host_text(hip, tmp_path, pe):
     assert body.count(b"\n") >= n and b"\tXA:Z:" in body and b"\tSA:Z:" in body
     lines = [l for l in body.split(b"\n") if l and not l.startswith(b"@")]
     assert max(l.split(b"\t")[5].count(b"I") + l.split(b"\t")[5].count(b"D") for l in lines) >= 8       # the overflow path was taken
-    for env in ("BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_HOST_SELECT"):
+    for env in [e for e in texts if e]:                            # (BMH_ALIGNER_PE_HOST_DEDUP: mem_sort_dedup_patch of the pairs on host threads instead of the device)
         if texts[env] != body:
             a, b = body.split(b"\n"), texts[env].split(b"\n")
             assert False, (env, len(a), len(b), [(x, y) for x, y in zip(a, b) if x != y][:2])

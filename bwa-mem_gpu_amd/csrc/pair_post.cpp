@@ -169,7 +169,7 @@ int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector
 		if (dist >= c.pes[r].low && dist <= c.pes[r].high && !skip[r]) { skip[r] = 1; ++n_skip; }
 	}
 	if (n_skip == 4) return 0;
-	std::vector<uint8_t> rev, ref, seqbuf;
+	static thread_local std::vector<uint8_t> rev, ref, seqbuf;
 	for (int r = 0; r < 4; ++r) {
 		if (skip[r]) continue;
 		const int is_rev = (r >> 1 != (r & 1)), is_larger = !(r >> 1);
@@ -246,7 +246,8 @@ inline bool p64_lt(const P64 &a, const P64 &b) { return a.x < b.x || (a.x == b.x
 int pair_regs(const PCtx &c, std::vector<Reg> *const a[2], int id, int *sub, int *n_sub, int z[2], const int n_pri[2])     // mem_pair
 {
 	const int64_t l_pac = c.x.l_pac;
-	std::vector<P64> v, u;
+	static thread_local std::vector<P64> v, u;                     // (kept by the thread: two allocations a pair were a tenth of the walk)
+	v.clear(); u.clear();
 	for (int r = 0; r < 2; ++r)
 		for (int i = 0; i < n_pri[r]; ++i) {
 			const Reg &e = (*a[r])[i];
@@ -331,9 +332,11 @@ int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // 
 	const int l_seq[2] = {(int)c.lens[r0], (int)c.lens[r0 + 1]};
 	int z[2] = {0, 0}, o, subo = 0, n_sub = 0, extra_flag = 1, n_pri[2];
 	if (!c.pe->no_rescue && !(c.sw_mode == 2 && c.pair_active && !c.pair_active[r0 >> 1])) {   // mate rescue for the best regions of each end (src/bwamem_pair.c:273)
-		std::vector<Reg> b[2];
-		for (int i = 0; i < 2; ++i)
+		static thread_local std::vector<Reg> b[2];
+		for (int i = 0; i < 2; ++i) {
+			b[i].clear();
 			for (const Reg &r : *a[i]) if (r.score >= (*a[i])[0].score - c.pe->pen_unpaired) b[i].push_back(r);
+		}
 		for (int i = 0; i < 2; ++i)
 			for (size_t j = 0; j < b[i].size() && (int)j < c.pe->max_matesw; ++j)
 				matesw(c, b[i][j], l_seq[!i], seq[!i], *a[!i], SwKey{(uint32_t)(r0 >> 1), (uint16_t)j, (uint8_t)i, 0}, r0 + (uint32_t)!i);

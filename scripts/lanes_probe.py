@@ -3,7 +3,11 @@ counts, with the per-batch timeline of the last run (BMH_ALIGNER_TRACE).  usage:
 import os, sys, time, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))
-import numpy as np, torch
+import numpy as np
+if os.environ.get("LANES_BLOCKING"):
+    _hip = C.CDLL("libamdhip64.so")
+    print("hipSetDeviceFlags(blocking sync) ->", _hip.hipSetDeviceFlags(C.c_uint(4)))
+import torch
 import bwamem_hip as B
 from bwamem_hip import fmindex as F
 from bwamem_hip.aligner import ReadSet

@@ -620,10 +620,10 @@ def sam_text_device(po: "PostOpt", names, reads_t, offs_t, lens_t, contigs, fin_
     n = int(fin_per_read_t.shape[0])
     enc = [x.encode() + b"\0" for x in names]
     nblob = torch.from_numpy(np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8).copy()).to(dev)
-    noff = torch.from_numpy(np.concatenate([[0], np.cumsum([len(e) for e in enc])[:-1]]).astype(np.int64) if enc else np.zeros(1, np.int64)).to(dev)
+    noff = torch.from_numpy(np.concatenate([[0], np.cumsum([len(e) for e in enc])]).astype(np.int64)).to(dev)            # [n + 1]
     cenc = [c[0].encode() + b"\0" for c in contigs]
     cblob = torch.from_numpy(np.frombuffer(b"".join(cenc), dtype=np.uint8).copy()).to(dev)
-    cnoff = torch.from_numpy(np.concatenate([[0], np.cumsum([len(e) for e in cenc])[:-1]]).astype(np.int32)).to(dev)
+    cnoff = torch.from_numpy(np.concatenate([[0], np.cumsum([len(e) for e in cenc])]).astype(np.int32)).to(dev)         # [n_contigs + 1]
     coff = torch.from_numpy(np.concatenate([[0], np.cumsum([c[1] for c in contigs])[:-1]]).astype(np.int64)).to(dev)
     d = SamDev(n, nblob.data_ptr(), noff.data_ptr(), reads_t.data_ptr(), offs_t.data_ptr(), lens_t.data_ptr(), len(contigs), cblob.data_ptr(), cnoff.data_ptr(), coff.data_ptr(),
                fin_t.data_ptr(), fin_per_read_t.data_ptr(), slot_t.data_ptr(), aln_t.data_ptr(), cig_off_t.data_ptr(), packed_t.data_ptr(),

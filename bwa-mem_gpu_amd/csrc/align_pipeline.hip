@@ -187,6 +187,7 @@ int text_on_device(const aligner_t &A, lane_t &Ln, const bmh_post_opt_t &po, con
 	if (!Ln.ctg_up) {                                              // the sequences' names and offsets, once per lane
 		std::vector<char> blob; std::vector<uint32_t> noff;
 		for (const std::string &s : A.names) { noff.push_back((uint32_t)blob.size()); blob.insert(blob.end(), s.begin(), s.end()); blob.push_back(0); }
+		noff.push_back((uint32_t)blob.size());
 		RCK(Ln.d_ctg_names.need(blob.size())); RCK(Ln.d_ctg_name_off.need(noff.size())); RCK(Ln.d_ctg_off.need(A.off.size()));
 		LCK(hipMemcpy(Ln.d_ctg_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
 		LCK(hipMemcpy(Ln.d_ctg_name_off.p, noff.data(), 4 * noff.size(), hipMemcpyHostToDevice));
@@ -304,11 +305,12 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 	R.has_text = false; R.text_len = 0;
 	if (text_dev) {
 		const uint64_t n0 = rs.name_offs[b0], n1 = b1 < rs.n_reads ? rs.name_offs[b1] : rs.n_name_bytes;
-		RCK(Ln.h_names.need(n1 - n0 + 1)); RCK(Ln.h_name_off.need(n + 1)); RCK(Ln.d_names.need(n1 - n0 + 1)); RCK(Ln.d_name_off.need(n + 1));
+		RCK(Ln.h_names.need(n1 - n0 + 1)); RCK(Ln.h_name_off.need(n + 2)); RCK(Ln.d_names.need(n1 - n0 + 1)); RCK(Ln.d_name_off.need(n + 2));
 		memcpy(Ln.h_names.p, rs.names + n0, n1 - n0);
 		for (uint32_t r = 0; r < n; ++r) Ln.h_name_off.p[r] = rs.name_offs[b0 + r] - n0;
+		Ln.h_name_off.p[n] = n1 - n0;
 		LCK(hipMemcpyAsync(Ln.d_names.p, Ln.h_names.p, n1 - n0, hipMemcpyHostToDevice, Ln.st));
-		LCK(hipMemcpyAsync(Ln.d_name_off.p, Ln.h_name_off.p, 8 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
+		LCK(hipMemcpyAsync(Ln.d_name_off.p, Ln.h_name_off.p, 8 * ((size_t)n + 1), hipMemcpyHostToDevice, Ln.st));
 	}
 	// ---- seeding
 	if (!Ln.sws || n > Ln.sws_reads || nb > Ln.sws_bases) {

@@ -206,7 +206,7 @@ template <> struct sam_ptr_t<2> { typedef sam_lds_char *type; };
 template <int W> struct sam_out_t {
 	typename sam_ptr_t<W>::type p; uint32_t n;
 	__device__ __forceinline__ void ch(char c) { if (W) *p++ = c; else ++n; }
-	__device__ __forceinline__ void str(const char *s) { for (; *s; ++s) ch(*s); }               // NUL-terminated, from global memory
+	__device__ __forceinline__ void str(const char *s, int len) { if (W) { for (int i = 0; i < len; ++i) *p++ = s[i]; } else n += (uint32_t)len; }   // len bytes, from global memory
 	template <int N> __device__ __forceinline__ void lit(const char (&s)[N]) { for (int i = 0; i < N - 1; ++i) ch(s[i]); }
 	__device__ void num(long long v)                                                             // put_int
 	{
@@ -243,6 +243,7 @@ __device__ __forceinline__ int sam_rid(const sam_args_t &A, long long pos)
 }
 __device__ __forceinline__ long long sam_ctg0(const sam_args_t &A, int rid) { return A.d.n_contigs > 1 ? A.d.d_contig_offset[rid] : 0; }
 __device__ __forceinline__ const char *sam_ctg(const sam_args_t &A, int rid) { return A.d.d_contig_names + A.d.d_contig_name_off[rid]; }
+__device__ __forceinline__ int sam_ctg_len(const sam_args_t &A, int rid) { return (int)(A.d.d_contig_name_off[rid + 1] - A.d.d_contig_name_off[rid]) - 1; }
 template <int W> __device__ void sam_cigar(sam_out_t<W> &o, const sam_rec_t &r, bool hard)
 {
 	const int n = r.aln[3];
@@ -264,12 +265,22 @@ __device__ __forceinline__ int sam_nt4(uint8_t c)            // nst_nt4_table as
 	c &= 0xDF;
 	return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
 }
+// the letter SEQ shows for a read's letter: upper case, N for everything that is not A C G T; complemented on the reverse strand
+__device__ __forceinline__ char sam_letter(uint8_t c, bool rev)
+{
+	c &= 0xDF;
+	const bool a = c == 'A', cc = c == 'C', g = c == 'G', t = c == 'T';
+	if (!rev) return (a || cc || g || t) ? (char)c : 'N';
+	return a ? 'T' : cc ? 'G' : g ? 'C' : t ? 'A' : 'N';
+}
 template <int W> __device__ void sam_seq(sam_out_t<W> &o, const uint8_t *seq, int qb, int qe, bool rev)
 {
 	if (qe <= qb) return;
 	if (!W) { o.n += (uint32_t)(qe - qb); return; }
-	if (!rev) for (int k = qb; k < qe; ++k) *o.p++ = "ACGTN"[sam_nt4(seq[k])];
-	else for (int k = qe - 1; k >= qb; --k) *o.p++ = "TGCAN"[sam_nt4(seq[k])];
+	// (eight letters in flight at a time, and the whole wave copying read after read in coalesced steps, were both tried: the writing pass is bound
+	// by its two waves per SIMD -- 16 KB of LDS per wave -- and the dependent loads of the records, not by these bytes)
+	if (!rev) for (int k = qb; k < qe; ++k) *o.p++ = sam_letter(seq[k], false);
+	else for (int k = qe - 1; k >= qb; --k) *o.p++ = sam_letter(seq[k], true);
 }
 
 struct sam_mate_t { int rid; long long pos; int is_rev, n_cigar; const uint32_t *cigar; };
@@ -278,7 +289,7 @@ template <int W> __device__ void sam_mate_fields(const sam_args_t &A, sam_out_t<
                                                   bool mate_mapped, int m_rid, long long m_pos, int m_rev, int m_ncig, const uint32_t *m_cig)
 {
 	if (pe && mate_mapped) {
-		if (p_rid == m_rid) o.ch('='); else o.str(sam_ctg(A, m_rid));
+		if (p_rid == m_rid) o.ch('='); else o.str(sam_ctg(A, m_rid), sam_ctg_len(A, m_rid));
 		o.ch('\t'); o.num(m_pos - sam_ctg0(A, m_rid) + 1); o.ch('\t');
 		if (p_rid == m_rid) {
 			const long long p0 = p_pos + (p_rev ? sam_ref_len(p_ncig, p_cig) - 1 : 0), p1 = m_pos + (m_rev ? sam_ref_len(m_ncig, m_cig) - 1 : 0);
@@ -307,6 +318,7 @@ template <int W> __device__ bool sam_read(const sam_args_t &A, uint32_t r, sam_o
 		}
 	}
 	const char *name = A.d.d_names + A.d.d_name_off[r];
+	const int name_len = (int)(A.d.d_name_off[r + 1] - A.d.d_name_off[r]) - 1;     // (names are NUL-terminated back to back: no strlen)
 	const uint8_t *seq = A.d.d_reads + A.d.d_offs[r];
 	const int l_seq = (int)A.d.d_lens[r];
 	int n_rep = 0;
@@ -318,8 +330,8 @@ template <int W> __device__ bool sam_read(const sam_args_t &A, uint32_t r, sam_o
 		const int p_rev = mm ? m.is_rev : 0;
 		if (p_rev) flag |= 0x10;
 		if (mm && m.is_rev) flag |= 0x20;
-		out.str(name); out.ch('\t'); out.num(flag); out.ch('\t');
-		if (mm) { out.str(sam_ctg(A, m.rid)); out.ch('\t'); out.num(m.pos - sam_ctg0(A, m.rid) + 1); out.lit("\t0\t*\t"); }
+		out.str(name, name_len); out.ch('\t'); out.num(flag); out.ch('\t');
+		if (mm) { out.str(sam_ctg(A, m.rid), sam_ctg_len(A, m.rid)); out.ch('\t'); out.num(m.pos - sam_ctg0(A, m.rid) + 1); out.lit("\t0\t*\t"); }
 		else out.lit("*\t0\t0\t*\t");
 		sam_mate_fields<W>(A, out, pe, mm ? m.rid : -1, m.pos, p_rev, 0, nullptr, mm, m.rid, m.pos, m.is_rev, m.n_cigar, m.cigar);
 		sam_seq<W>(out, seq, 0, l_seq, p_rev != 0);
@@ -339,8 +351,8 @@ template <int W> __device__ bool sam_read(const sam_args_t &A, uint32_t r, sam_o
 		int flag = (x.aln[2] ? 0x10 : 0) | x.fin[14];
 		if (pe) { if (m.rid < 0) flag |= 8; if (m_rev) flag |= 0x20; }
 		const bool hard = which > 0 && !A.softclip && !(x.fin[15] & 2);
-		out.str(name); out.ch('\t'); out.num((flag & 0xffff) | (flag & 0x10000 ? 0x100 : 0)); out.ch('\t');
-		out.str(sam_ctg(A, rid)); out.ch('\t'); out.num(pos - sam_ctg0(A, rid) + 1); out.ch('\t');
+		out.str(name, name_len); out.ch('\t'); out.num((flag & 0xffff) | (flag & 0x10000 ? 0x100 : 0)); out.ch('\t');
+		out.str(sam_ctg(A, rid), sam_ctg_len(A, rid)); out.ch('\t'); out.num(pos - sam_ctg0(A, rid) + 1); out.ch('\t');
 		out.num(x.fin[13]); out.ch('\t');
 		if (x.aln[3]) sam_cigar<W>(out, x, hard); else out.ch('*');
 		out.ch('\t');
@@ -357,7 +369,7 @@ template <int W> __device__ bool sam_read(const sam_args_t &A, uint32_t r, sam_o
 			sam_seq<W>(out, seq, qb, qe, x.aln[2] != 0);
 			out.lit("\t*");
 		}
-		if (x.aln[3]) { out.lit("\tNM:i:"); out.num(x.aln[4]); out.lit("\tMD:Z:"); out.str(x.md); }
+		if (x.aln[3]) { out.lit("\tNM:i:"); out.num(x.aln[4]); out.lit("\tMD:Z:"); out.str(x.md, x.aln[6]); }
 		if (x.fin[1] >= 0) { out.lit("\tAS:i:"); out.num(x.fin[1]); }
 		if (!(flag & 0x100)) {
 			if (x.fin[10] >= 0) { out.lit("\tXS:i:"); out.num(x.fin[10]); }
@@ -371,7 +383,7 @@ template <int W> __device__ bool sam_read(const sam_args_t &A, uint32_t r, sam_o
 					if (!y.aln) return false;
 					const long long p2 = sam_pos(y.aln);
 					const int rid2 = sam_rid(A, p2);
-					out.str(sam_ctg(A, rid2)); out.ch(','); out.num(p2 - sam_ctg0(A, rid2) + 1); out.ch(',');
+					out.str(sam_ctg(A, rid2), sam_ctg_len(A, rid2)); out.ch(','); out.num(p2 - sam_ctg0(A, rid2) + 1); out.ch(',');
 					out.ch("+-"[y.aln[2] ? 1 : 0]); out.ch(',');
 					sam_cigar<W>(out, y, false);
 					out.ch(','); out.num(y.fin[13]); out.ch(','); out.num(y.aln[4]); out.ch(';');
@@ -389,7 +401,7 @@ template <int W> __device__ bool sam_read(const sam_args_t &A, uint32_t r, sam_o
 					if (!y.aln) return false;
 					const long long p2 = sam_pos(y.aln);
 					const int rid2 = sam_rid(A, p2);
-					out.str(sam_ctg(A, rid2)); out.ch(','); out.ch("+-"[y.aln[2] ? 1 : 0]); out.num(p2 - sam_ctg0(A, rid2) + 1); out.ch(',');
+					out.str(sam_ctg(A, rid2), sam_ctg_len(A, rid2)); out.ch(','); out.ch("+-"[y.aln[2] ? 1 : 0]); out.num(p2 - sam_ctg0(A, rid2) + 1); out.ch(',');
 					sam_cigar<W>(out, y, false);
 					out.ch(','); out.num(y.aln[4]); out.ch(';');
 				}
@@ -427,11 +439,12 @@ __global__ void __launch_bounds__(256) sam_text_write_kernel(sam_args_t A)
 	const uint32_t a = (uint32_t)((uintptr_t)(A.text + t0) & 3u);                  // the image starts where its first byte sits in a dword of the text
 	if (t1 - t0 + a <= SAM_LDS_WAVE) {
 		sam_lds_char *img = (sam_lds_char *)lds[wv] + a;
+		sam_out_t<2> o; o.p = img; o.n = 0;
 		if (r < n) {
-			sam_out_t<2> o; o.p = img + (uint32_t)(A.text_off[r] - t0); o.n = 0;
+			o.p = img + (uint32_t)(A.text_off[r] - t0);
 			const bool ok = sam_read<2>(A, r, o);
 			if (ok && (uint32_t)(o.p - img) != (uint32_t)(A.text_off[r + 1] - t0)) atomicOr(A.err, 2u);   // (the two passes disagree: internal error)
-			if (!ok) atomicOr(A.err, 1u);
+			if (!ok) { atomicOr(A.err, 1u); }
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 		__builtin_amdgcn_s_waitcnt(0xC07F);                                           // (the wave's LDS stores are done: lgkmcnt 0)

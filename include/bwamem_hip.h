@@ -515,9 +515,9 @@ int bmh_cigar_pack(const int32_t *d_aln, const uint32_t *d_cigar, int max_cigar,
  * bmh_sam_text_check afterwards waits for the stream and reports an inconsistency between the passes.  d_work: bmh_sam_text_work bytes. */
 typedef struct {
 	uint32_t n_reads;
-	const char *d_names; const uint64_t *d_name_off;           /* names NUL-terminated back to back, start of read r's */
+	const char *d_names; const uint64_t *d_name_off;           /* names NUL-terminated back to back; [n_reads + 1]: start of read r's, [n_reads] = their total length */
 	const uint8_t *d_reads; const uint32_t *d_offs, *d_lens;   /* the batch's ASCII reads (what bmh_seed_batch takes) */
-	int n_contigs; const char *d_contig_names; const uint32_t *d_contig_name_off; const int64_t *d_contig_offset;
+	int n_contigs; const char *d_contig_names; const uint32_t *d_contig_name_off; const int64_t *d_contig_offset;   /* names as above, [n_contigs + 1] */
 	const int32_t *d_fin; const uint32_t *d_fin_per_read;      /* records [m][16], records per read */
 	const int32_t *d_slot;                                     /* [m] record -> alignment (bmh_sam_select_device) */
 	const int32_t *d_aln; const uint32_t *d_cig_off, *d_packed; /* bmh_cigar_batch's d_aln; bmh_cigar_pack's d_off / d_packed (with MD) */

@@ -415,6 +415,10 @@ class Aligner:
             cuts = list(range(0, n, batch_reads)) + [n]
         else:
             cb = chunk_bases or int(getattr(self, "ref_chunk_bases", 0)) or 10_000_000 * max(1, int(getattr(self, "ref_threads", 1)))
+            if not paired and not chunk_bases:
+                # single-end records do not depend on where the batches are cut (the tie-break hash takes the read's index in the run), and a
+                # batch of a quarter of a million reads spends a third of its time in fixed per-batch latencies: at least 150 Mbases a batch
+                cb = max(cb, 150_000_000)
             cb = min(cb, (1 << 31) - 1024)                               # offsets inside a batch are 32-bit
             csum = np.cumsum(rs.lens.astype(np.int64))
             cuts, b = [0], 0

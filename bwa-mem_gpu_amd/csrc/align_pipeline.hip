@@ -69,6 +69,10 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // device / pinned buffers that only ever grow
 template <class T> struct dbuf_t {
 	T *p = nullptr; size_t cap = 0;
+	dbuf_t() = default;
+	dbuf_t(const dbuf_t &) = delete;
+	dbuf_t &operator=(const dbuf_t &) = delete;
+	void swap(dbuf_t &o) { T *q = p; p = o.p; o.p = q; const size_t c = cap; cap = o.cap; o.cap = c; }
 	int need(size_t n) {
 		if (n <= cap) return BMH_OK;
 		if (p) (void)hipFree(p);
@@ -82,6 +86,9 @@ template <class T> struct dbuf_t {
 };
 template <class T> struct hbuf_t {
 	T *p = nullptr; size_t cap = 0;
+	hbuf_t() = default;
+	hbuf_t(const hbuf_t &) = delete;
+	hbuf_t &operator=(const hbuf_t &) = delete;
 	int need(size_t n) {
 		if (n <= cap) return BMH_OK;
 		if (p) (void)hipHostFree(p);
@@ -111,6 +118,8 @@ struct lane_t {
 	bmh_seed_ws_t *sws = nullptr; uint32_t sws_reads = 0; uint64_t sws_bases = 0;
 	bmh_chain_ws_t *cws = nullptr; uint32_t cws_reads = 0; uint64_t cws_seeds = 0; uint64_t regs_guess = 0;
 	dbuf_t<uint8_t> d_reads, d_work; dbuf_t<uint32_t> d_offs, d_lens, d_sel, d_opr, d_cigar, d_off, d_packed, d_over, d_sel2; dbuf_t<int32_t> d_out3, d_regs, d_fin, d_aln, d_slot, d_hrec, d_unflag; dbuf_t<char> d_md;
+	dbuf_t<int32_t> d_dedup, d_fin2, d_hrec2, d_unflag2, d_rslot, d_hh, d_ufh, d_finh; dbuf_t<uint32_t> d_roff, d_roff2, d_opr2, d_todo_pairs, d_oprh, d_offh; dbuf_t<uint8_t> d_todo, d_scan;   // pairs on the device
+	hbuf_t<uint8_t> h_todo; std::vector<uint32_t> todo_pairs, offh;
 	dbuf_t<char> d_names, d_text, d_ctg_names; dbuf_t<uint64_t> d_name_off, d_text_off; dbuf_t<uint32_t> d_ctg_name_off; dbuf_t<int64_t> d_ctg_off; bool ctg_up = false;
 	hbuf_t<uint32_t> h_offs, h_sel, h_rpr; hbuf_t<int32_t> h_regs; hbuf_t<float> h_fr; hbuf_t<uint8_t> h_need, h_reads; hbuf_t<char> h_names; hbuf_t<uint64_t> h_name_off;
 	double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // h2d, seed, chain+extend+merge, tail, select, cigar + d2h
@@ -281,6 +290,103 @@ int patch_alt_reads(const aligner_t &A, lane_t &Ln, const bmh_dev_jobs_t &dj, co
 	return BMH_OK;
 }
 
+// Interleaved pairs with mem_pair / mem_sam_pe's choices on the device (csrc/pair_dev.hip) for the pairs the mate rescue does not touch: the single-end tail
+// for every read (mem_sort_dedup_patch, mem_mark_primary_se, mem_reg2sam's selection) with a copy of the regions behind mem_sort_dedup_patch for the host;
+// the host computes the insert-size statistics and finds the pairs the rescue touches (bmh_finalize_pairs_split), the device pairs the others meanwhile;
+// the host walks the pairs that are left -- the rescued ones, the ones the device hands back -- and their records take their places on the device.
+// On return *d_fin_out / Ln.d_opr / Ln.d_hrec / Ln.d_unflag hold the batch's records as bmh_finalize_pairs would have left them; R.m their number.
+struct pd_user_t { const aligner_t *A; lane_t *Ln; const bmh_dev_jobs_t *dj; const bmh_post_opt_t *po; bmh_fin_extra_t *ex; uint32_t n; };
+int pd_after_pestat(void *u_, const double *pes)
+{
+	pd_user_t &u = *(pd_user_t *)u_;
+	lane_t &Ln = *u.Ln; const aligner_t &A = *u.A;
+	RCK(bmh_pair_device(&A.co, &A.ep, u.po, &A.pe, pes, A.l_pac, A.n_contigs, u.ex->d_ctg_off, u.ex->d_logtab, u.ex->n_log, Ln.d_fin.p, Ln.d_opr.p, Ln.d_roff.p,
+	                    u.dj->d_frac_rep, u.n, Ln.d_hrec.p, Ln.d_unflag.p, Ln.d_todo.p, Ln.st));
+	LCK(hipMemcpyAsync(Ln.h_todo.p, Ln.d_todo.p, u.n / 2, hipMemcpyDeviceToHost, Ln.st));
+	return BMH_OK;
+}
+int pd_before_final(void *u_, const uint8_t **extra)
+{
+	pd_user_t &u = *(pd_user_t *)u_;
+	LCK(hipStreamSynchronize(u.Ln->st));
+	*extra = u.Ln->h_todo.p;
+	return BMH_OK;
+}
+int pairs_on_device(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, const bmh_dev_jobs_t &dj, const bmh_post_opt_t &po, const uint8_t *codes, const uint64_t *offs64,
+                    uint32_t b0, uint32_t n, uint64_t nr, int n_threads, result_t &R, const int32_t **d_fin_out)
+{
+	const bool prof = getenv("BMH_PAIR_PROFILE") != nullptr;
+	const double t0 = now_s();
+	RCK(Ln.d_fin.need(16 * (nr + 1))); RCK(Ln.d_opr.need(n + 1)); RCK(Ln.d_dedup.need(16 * (nr + 1))); RCK(Ln.d_roff.need(n + 1));
+	RCK(Ln.d_hrec.need(n + 1)); RCK(Ln.d_unflag.need(n + 1)); RCK(Ln.d_todo.need(n / 2 + 1)); RCK(Ln.h_todo.need(n / 2 + 1));
+	bmh_fin_extra_t ex; memset(&ex, 0, sizeof(ex));
+	ex.d_dedup_out = Ln.d_dedup.p; ex.d_out_off = Ln.d_roff.p;
+	const int64_t m1 = bmh_finalize_regs_device_ex(A.idx, &A.co, &A.ep, &po, Ln.d_reads.p, Ln.d_offs.p, n, Ln.d_regs.p, nr, dj.d_regs_per_read, dj.d_frac_rep,
+	                                               A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr, Ln.d_fin.p, Ln.d_opr.p, Ln.st, &ex);
+	if (m1 < 0) return (int)m1;
+	RCK(Ln.h_regs.need(16 * ((size_t)m1 + 1))); RCK(Ln.h_rpr.need(n + 1)); RCK(Ln.h_fr.need(n + 1));
+	if (m1) LCK(hipMemcpyAsync(Ln.h_regs.p, Ln.d_dedup.p, 64 * (size_t)m1, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipMemcpyAsync(Ln.h_rpr.p, Ln.d_opr.p, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipMemcpyAsync(Ln.h_fr.p, dj.d_frac_rep, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipStreamSynchronize(Ln.st));
+	const double t1 = now_s();
+	// the host: statistics, the rescue's windows (aligned on the device), the pairs that are the host's
+	pd_user_t u = {&A, &Ln, &dj, &po, &ex, n};
+	Ln.todo_pairs.resize(n / 2 + 1);
+	bmh_pairs_split_t split; memset(&split, 0, sizeof(split));
+	split.after_pestat = pd_after_pestat; split.before_final = pd_before_final; split.user = &u; split.todo_pairs = Ln.todo_pairs.data();
+	uint64_t cap = (uint64_t)m1 + 2ull * n + 4096;                  // (room for every pair: the pairs the device hands back are the ones with the most records)
+	int64_t mh = BMH_ECAPACITY;
+	RCK(R.opr.need(n + 1)); R.h_rec.resize(n); R.unflag.resize(n);
+	for (int attempt = 0; attempt < 4 && mh == BMH_ECAPACITY; ++attempt, cap *= 4) {
+		// (a second attempt repeats the device's pair kernel on records it has changed already: they are restored first)
+		if (attempt) { bmh_fin_extra_t ex2 = ex; const int64_t m2 = bmh_finalize_regs_device_ex(A.idx, &A.co, &A.ep, &po, Ln.d_reads.p, Ln.d_offs.p, n, Ln.d_regs.p, nr, dj.d_regs_per_read, dj.d_frac_rep,
+		                                               A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr, Ln.d_fin.p, Ln.d_opr.p, Ln.st, &ex2); if (m2 != m1) return m2 < 0 ? (int)m2 : BMH_EINVAL; }
+		RCK(R.fin.need(16 * (size_t)cap));
+		mh = bmh_finalize_pairs_split(A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.st, &A.co, &A.ep, &po, &A.pe, A.l_pac, A.pac, n, codes, offs64, rs.lens + b0,
+		                              Ln.h_regs.p, Ln.h_rpr.p, Ln.h_fr.p, A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr, A.n_contigs > 1 ? A.len.data() : nullptr,
+		                              R.fin.p, cap, R.opr.p, R.h_rec.data(), R.unflag.data(), n_threads, &split);
+	}
+	if (mh < 0) return (int)mh;
+	const double t2 = now_s();
+	// the host's records take their places
+	const uint32_t nt = (uint32_t)split.n_todo;
+	Ln.offh.resize(2 * (size_t)nt + 1);
+	{ uint32_t o = 0; for (uint32_t k = 0; k < 2 * nt; ++k) { Ln.offh[k] = o; o += R.opr.p[k]; } if ((int64_t)o != mh) { bmh_set_error("bmh_aligner_run: internal error: the host's pairs left %lld records, their counts add up to %u", (long long)mh, o); return BMH_EINVAL; } }
+	RCK(Ln.d_todo_pairs.need(nt + 1)); RCK(Ln.d_oprh.need(2 * (size_t)nt + 1)); RCK(Ln.d_offh.need(2 * (size_t)nt + 1)); RCK(Ln.d_hh.need(2 * (size_t)nt + 1)); RCK(Ln.d_ufh.need(2 * (size_t)nt + 1));
+	RCK(Ln.d_finh.need(16 * ((size_t)mh + 1))); RCK(Ln.d_rslot.need(n + 1)); RCK(Ln.d_opr2.need(n + 1)); RCK(Ln.d_hrec2.need(n + 1)); RCK(Ln.d_unflag2.need(n + 1)); RCK(Ln.d_roff2.need(n + 1));
+	if (nt) {
+		LCK(hipMemcpyAsync(Ln.d_todo_pairs.p, Ln.todo_pairs.data(), 4 * (size_t)nt, hipMemcpyHostToDevice, Ln.st));
+		LCK(hipMemcpyAsync(Ln.d_oprh.p, R.opr.p, 8 * (size_t)nt, hipMemcpyHostToDevice, Ln.st));
+		LCK(hipMemcpyAsync(Ln.d_offh.p, Ln.offh.data(), 8 * (size_t)nt, hipMemcpyHostToDevice, Ln.st));
+		LCK(hipMemcpyAsync(Ln.d_hh.p, R.h_rec.data(), 8 * (size_t)nt, hipMemcpyHostToDevice, Ln.st));
+		LCK(hipMemcpyAsync(Ln.d_ufh.p, R.unflag.data(), 8 * (size_t)nt, hipMemcpyHostToDevice, Ln.st));
+		if (mh) LCK(hipMemcpyAsync(Ln.d_finh.p, R.fin.p, 64 * (size_t)mh, hipMemcpyHostToDevice, Ln.st));
+	}
+	RCK(bmh_pair_merge_counts(n, Ln.d_todo_pairs.p, nt, Ln.d_rslot.p, Ln.d_opr.p, Ln.d_hrec.p, Ln.d_unflag.p, Ln.d_oprh.p, Ln.d_hh.p, Ln.d_ufh.p, Ln.d_opr2.p, Ln.d_hrec2.p, Ln.d_unflag2.p, Ln.st));
+	const size_t sb = bmh_pair_scan_bytes(n);
+	RCK(Ln.d_scan.need(sb));
+	RCK(bmh_pair_scan(Ln.d_opr2.p, Ln.d_roff2.p, n, Ln.d_scan.p, Ln.d_scan.cap, Ln.st));
+	uint32_t last[2] = {0, 0};
+	LCK(hipMemcpyAsync(&last[0], Ln.d_roff2.p + (n - 1), 4, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipMemcpyAsync(&last[1], Ln.d_opr2.p + (n - 1), 4, hipMemcpyDeviceToHost, Ln.st));
+	LCK(hipStreamSynchronize(Ln.st));
+	const uint64_t m = (uint64_t)last[0] + last[1];
+	RCK(Ln.d_fin2.need(16 * (m + 1)));
+	RCK(bmh_pair_merge_records(n, Ln.d_rslot.p, Ln.d_fin.p, Ln.d_roff.p, Ln.d_finh.p, Ln.d_offh.p, Ln.d_opr2.p, Ln.d_roff2.p, Ln.d_fin2.p, Ln.st));
+	Ln.d_opr.swap(Ln.d_opr2); Ln.d_hrec.swap(Ln.d_hrec2); Ln.d_unflag.swap(Ln.d_unflag2);
+	*d_fin_out = Ln.d_fin2.p;
+	R.m = m;
+	if (prof) {
+		uint32_t n1 = 0, n2 = 0;
+		for (uint32_t q = 0; q < n / 2; ++q) { n1 += Ln.h_todo.p[q] == 1; n2 += Ln.h_todo.p[q] == 2; }
+		fprintf(stderr, "[pairs] handed back by the device: %u pairs with a score too close to an integer, %u beyond %d hits\n", n1, n2, bmh_pair_limit());
+	}
+	if (prof) fprintf(stderr, "[pairs] on the device: single-end tail + regions to the host %.1f ms, host (statistics, rescue, %u of %u pairs walked) %.1f ms, merge %.1f ms\n",
+	                  (t1 - t0) * 1e3, nt, n / 2, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
+	return BMH_OK;
+}
+
 // one batch [b0, b1) of the read set on lane Ln -> R
 int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t b0, uint32_t b1, bool paired, int n_threads, result_t &R)
 {
@@ -408,6 +514,13 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		}
 		R.m = (uint64_t)m;
 	} else {
+		bool pe_done = false;
+		if (text_dev && !getenv("BMH_ALIGNER_PE_HOST") && !getenv("BMH_ALIGNER_PE_HOST_DEDUP")) {
+			int rc_pd = pairs_on_device(A, Ln, rs, dj, po, codes, host_offs(), b0, n, nr, n_threads, R, &d_fin);
+			if (rc_pd == BMH_OK) pe_done = true;
+			else if (rc_pd != BMH_ECAPACITY) return rc_pd;              // (BMH_ECAPACITY: a read beyond the device tail's fixed limits: the host forms below)
+		}
+		if (!pe_done) {
 		// mem_sort_dedup_patch of every read on the device (the first step of the single-end tail: bmh_dedup_regs_device), the rest of mem_sam_pe on host
 		// threads from its records; a batch the device refuses (a read beyond its fixed limits), or BMH_ALIGNER_PE_HOST_DEDUP, takes the regions themselves
 		int64_t md = BMH_ECAPACITY;
@@ -443,6 +556,7 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		LCK(hipMemcpyAsync(Ln.d_hrec.p, R.h_rec.data(), 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
 		if (text_dev) { RCK(Ln.d_unflag.need(n + 1)); LCK(hipMemcpyAsync(Ln.d_unflag.p, R.unflag.data(), 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st)); }
 		d_fin = Ln.d_fin.p;
+		}
 	}
 	double t4 = now_s(); Ln.t[3] += t4 - t3;
 	// ---- which records need a CIGAR

@@ -49,6 +49,39 @@ bool bmh_format_sam_parts(const bmh_post_opt_t *po, uint32_t n_reads, const char
 int64_t bmh_cigar_overflowed(const int32_t *d_aln, uint32_t n, const uint32_t *d_sel, uint32_t *d_over, uint32_t *d_sel2, uint32_t *d_counter, void *stream);
 int64_t bmh_cigar_patch(int32_t *d_aln, uint32_t *d_off, uint32_t *d_packed, uint64_t words, const uint32_t *d_over, uint32_t n_over,
                         const int32_t *d_aln2, const uint32_t *d_cigar2, int mc2, const char *d_md2, int mdc2, uint32_t *d_scratch, void *stream);
+// csrc/regs_kernels.hip: bmh_finalize_regs_device with by-products (in: d_dedup_out [n_regs][16] or NULL, d_out_off [n_reads] or NULL; out: the device's
+// logarithm table and contig offsets, valid until the stream's scratch is released)
+struct bmh_fin_extra_t { int32_t *d_dedup_out; uint32_t *d_out_off; const double *d_logtab; int n_log; const int64_t *d_ctg_off; };
+int64_t bmh_finalize_regs_device_ex(const bmh_index_t *idx, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt,
+                                    const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
+                                    const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read, const float *d_frac_rep,
+                                    int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream, bmh_fin_extra_t *extra);
+// ---- interleaved pairs with mem_pair / mem_sam_pe's choices on the device (csrc/pair_dev.hip) for the pairs the mate rescue does not touch
+// The host call (csrc/pair_post.cpp: bmh_finalize_pairs_split = bmh_finalize_pairs_deduped on a subset) tells the caller the insert-size statistics as
+// soon as it has them (after_pestat: the caller starts the device's pair kernel), asks before its own final walk which pairs the device handed back
+// (before_final: extra[n_pairs], non-zero = the host's), and walks those and the pairs the rescue touches; todo_pairs (room for n_reads / 2) receives them.
+struct bmh_pairs_split_t {
+	int (*after_pestat)(void *user, const double *pes /* [4][5] low, high, failed, avg, std */);
+	int (*before_final)(void *user, const uint8_t **extra);
+	void *user;
+	uint32_t *todo_pairs; uint64_t n_todo;
+};
+int64_t bmh_finalize_pairs_split(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream,
+                                 const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
+                                 int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                                 const uint32_t *read_lens, const int32_t *dedup_recs, const uint32_t *dedup_per_read, const float *frac_rep,
+                                 int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
+                                 int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, int n_threads, bmh_pairs_split_t *split);
+int bmh_pair_device(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe, const double *pes, int64_t l_pac,
+                    int n_contigs, const int64_t *d_ctg_off, const double *d_logtab, int n_log, int32_t *d_fin, const uint32_t *d_opr, const uint32_t *d_off,
+                    const float *d_frac_rep, uint32_t n_reads, int32_t *d_h_rec, int32_t *d_unflag, uint8_t *d_todo, void *stream);
+int bmh_pair_limit(void);
+int bmh_pair_merge_counts(uint32_t n_reads, const uint32_t *d_todo_pairs, uint32_t n_todo, int32_t *d_slot, const uint32_t *d_opr_dev, const int32_t *d_h_dev, const int32_t *d_uf_dev,
+                          const uint32_t *d_opr_host, const int32_t *d_h_host, const int32_t *d_uf_host, uint32_t *d_opr, int32_t *d_h, int32_t *d_uf, void *stream);
+int bmh_pair_merge_records(uint32_t n_reads, const int32_t *d_slot, const int32_t *d_fin_dev, const uint32_t *d_off_dev, const int32_t *d_fin_host, const uint32_t *d_off_host,
+                           const uint32_t *d_opr, const uint32_t *d_off, int32_t *d_fin, void *stream);
+size_t bmh_pair_scan_bytes(uint32_t n);
+int bmh_pair_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, void *d_tmp, size_t tmp_bytes, void *stream);
 // bmh_finalize_regs on a subset of a batch's reads: read_ids[r] = the read's index in its batch (hash seed, record field [0]); NULL = r
 int64_t bmh_finalize_regs_ids(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, int64_t l_pac,
                               const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,

@@ -155,6 +155,11 @@ bool fetch_window(const PCtx &c, int64_t *beg, int64_t mid, int64_t *end, int *r
 static std::atomic<unsigned long long> g_ms_calls{0}, g_ms_sw{0}, g_ms_cells{0}, g_ms_hits{0};
 static const bool g_pair_stats = getenv("BMH_POST_STATS") != nullptr;      // the counters are only read (and only bumped) with it set
 
+// BMH_PAIR_PROFILE: where the second walk spends its time (nanoseconds summed over the threads)
+static const bool g_pair_prof = getenv("BMH_PAIR_PROFILE") != nullptr;
+static std::atomic<unsigned long long> g_ns_msw{0}, g_ns_msw_dedup{0}, g_ns_mark{0}, g_ns_pair{0}, g_ns_rest{0};
+static inline unsigned long long now_ns() { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector<Reg> &ma, SwKey key = SwKey{0, 0, 0, 0}, uint32_t mate_read = 0)        // mem_matesw
 {
 	if (g_pair_stats) g_ms_calls++;
@@ -235,7 +240,11 @@ int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector
 			}
 			++n;
 		}
-		if (n) { const int m = sort_dedup_patch(c.x, nullptr, (int)ma.size(), ma.data()); ma.resize((size_t)m); }
+		if (n) {
+			const unsigned long long t0 = g_pair_prof ? now_ns() : 0;
+			const int m = sort_dedup_patch(c.x, nullptr, (int)ma.size(), ma.data()); ma.resize((size_t)m);
+			if (g_pair_prof) g_ns_msw_dedup += now_ns() - t0;
+		}
 	}
 	return n;
 }
@@ -337,16 +346,22 @@ int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // 
 			b[i].clear();
 			for (const Reg &r : *a[i]) if (r.score >= (*a[i])[0].score - c.pe->pen_unpaired) b[i].push_back(r);
 		}
+		const unsigned long long t0 = g_pair_prof && c.sw_mode == 2 ? now_ns() : 0;
 		for (int i = 0; i < 2; ++i)
 			for (size_t j = 0; j < b[i].size() && (int)j < c.pe->max_matesw; ++j)
 				matesw(c, b[i][j], l_seq[!i], seq[!i], *a[!i], SwKey{(uint32_t)(r0 >> 1), (uint16_t)j, (uint8_t)i, 0}, r0 + (uint32_t)!i);
+		if (t0) g_ns_msw += now_ns() - t0;
 	}
 	if (c.sw_mode == 1) return 0;
+	const unsigned long long t_m0 = g_pair_prof ? now_ns() : 0;
 	for (int i = 0; i < 2; ++i) n_pri[i] = mark_primary(c.x, (int)a[i]->size(), a[i]->data(), (int64_t)(id << 1 | (uint64_t)i));
+	if (g_pair_prof) g_ns_mark += now_ns() - t_m0;
 	for (int i = 0; i < 2; ++i) { out[i].sec_all.resize(a[i]->size()); for (size_t j = 0; j < a[i]->size(); ++j) out[i].sec_all[j] = (*a[i])[j].secondary_all; }
 	bool paired = false;
 	if (!c.pe->no_pairing && n_pri[0] && n_pri[1]) {        // src/bwamem_pair.c:287
+		const unsigned long long t_p0 = g_pair_prof ? now_ns() : 0;
 		o = pair_regs(c, a, (int)id, &subo, &n_sub, z, n_pri);
+		if (g_pair_prof) g_ns_pair += now_ns() - t_p0;
 		if (o > 0) {
 			int is_multi[2];
 			for (int i = 0; i < 2; ++i) {
@@ -428,7 +443,7 @@ extern "C" void bmh_pe_opt_default(bmh_pe_opt_t *o) { o->pen_unpaired = 17; o->m
 // What a call needs in large arrays, kept by the calling THREAD between calls: the regions of a million reads are 400 MB, the records another 250 --
 // allocated, faulted in and unmapped per call they cost a third of the call.  Freed when the thread ends.
 namespace {
-struct PairPart { std::vector<int32_t> rec; std::vector<uint32_t> n; std::vector<int32_t> h, uf; };
+struct PairPart { std::vector<int32_t> rec; std::vector<uint32_t> n, pairs; std::vector<int32_t> h, uf; };
 struct PairScratch {
 	Reg *flat = nullptr; size_t flat_cap = 0;
 	std::vector<PairPart> parts;
@@ -445,7 +460,8 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
                                    const uint32_t *read_lens, const int32_t *regs_in, const uint32_t *regs_per_read, const float *frac_rep,
                                    int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
                                    int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
-                                   int n_threads, const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream, bool deduped = false)
+                                   int n_threads, const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream, bool deduped = false,
+                                   bmh_pairs_split_t *split = nullptr)
 {
 	if (!copt || !ep || !popt || !pe || !pac || !reads || !read_offs || !read_lens || !regs_per_read || !out || !out_per_read || !out_h || !out_unflag ||
 	    (n_contigs > 1 && (!contig_offset || !contig_len))) { bmh_set_error("bmh_finalize_pairs: null argument"); return BMH_EINVAL; }
@@ -505,6 +521,12 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 	const double t_b = now();
 	pestat(c, n_reads, [&](size_t r) { return Span{flat + in_off[r], cnt[r]}; }, n_threads);
 	const double t_c = now();
+	if (split && split->after_pestat) {
+		double pv[20];
+		for (int d = 0; d < 4; ++d) { pv[5 * d] = c.pes[d].low; pv[5 * d + 1] = c.pes[d].high; pv[5 * d + 2] = c.pes[d].failed; pv[5 * d + 3] = c.pes[d].avg; pv[5 * d + 4] = c.pes[d].std; }
+		const int rc = split->after_pestat(split->user, pv);
+		if (rc != BMH_OK) return rc;
+	}
 	if (pes_out) for (int d = 0; d < 4; ++d) { pes_out[5 * d] = c.pes[d].low; pes_out[5 * d + 1] = c.pes[d].high; pes_out[5 * d + 2] = c.pes[d].failed; pes_out[5 * d + 3] = c.pes[d].avg; pes_out[5 * d + 4] = c.pes[d].std; }
 	// With a device: the local alignments of the mate rescue as one batch (pair_kernels.hip).  First walk: which alignments mem_matesw asks
 	// for (ranges of pairs on threads; their lists concatenate in pair order); then the kernel; the walk below takes the results.
@@ -539,16 +561,27 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 		t_sw2 = now();
 		c.sw_mode = 2; c.keys = all_keys.data(); c.pair_off = pair_off.data(); c.res = sw_res.data();
 	}
+	// split mode: the device has made the records of the pairs the rescue does not touch (csrc/pair_dev.hip); the walk below takes the others -- the pairs
+	// a mem_matesw call got a window for, and the ones the device hands back (`extra`: a lane's worth of hits exceeded, a score too close to an
+	// integer to trust the device's erfc / log) -- and writes their records, and only theirs, in pair order
+	const uint8_t *todo_extra = nullptr;
+	if (split) {
+		if (split->before_final) { const int rc = split->before_final(split->user, &todo_extra); if (rc != BMH_OK) return rc; }
+		if (!c.pair_active) { pair_active.assign((size_t)n_reads / 2 + 1, 0); c.pair_active = pair_active.data(); }     // (no rescue: no pair is active, and the walk does not ask)
+	}
+	auto is_todo = [&](uint32_t p) { return !split || pair_active[p] || (todo_extra && todo_extra[p]); };
 	// per pair: mem_sam_pe's decisions; every thread appends the records of its (contiguous) pairs to its own buffer
 	typedef PairPart Part;
 	std::vector<Part> &parts = S.parts;
 	parts.resize((size_t)n_threads);
-	for (Part &P : parts) { P.rec.clear(); P.n.clear(); P.h.clear(); P.uf.clear(); }
+	for (Part &P : parts) { P.rec.clear(); P.n.clear(); P.h.clear(); P.uf.clear(); P.pairs.clear(); }
 	par([&](int t, uint32_t p0, uint32_t p1) {
 		Part &P = parts[(size_t)t];
-		P.rec.reserve((size_t)(in_off[2 * p1] - in_off[2 * p0]) * 16 + 64);
+		if (!split) P.rec.reserve((size_t)(in_off[2 * p1] - in_off[2 * p0]) * 16 + 64);
 		ReadOut o2[2];
 		for (uint32_t p = p0; p < p1; ++p) {
+			if (!is_todo(p)) continue;
+			if (split) P.pairs.push_back(p);
 			for (int i = 0; i < 2; ++i) {
 				const uint32_t r = 2 * p + (uint32_t)i;
 				o2[i].regs.assign(flat + in_off[r], flat + in_off[r] + cnt[r]);
@@ -591,8 +624,12 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 			if (!P.rec.empty()) memcpy(out + 16 * w_off[t], P.rec.data(), sizeof(int32_t) * P.rec.size());
 			uint64_t r = r_off[t];
 			for (size_t k = 0; k < P.n.size(); ++k, ++r) { out_per_read[r] = P.n[k]; out_h[r] = P.h[k]; out_unflag[r] = P.uf[k]; }
+			if (split && split->todo_pairs) for (size_t k = 0; k < P.pairs.size(); ++k) split->todo_pairs[r_off[t] / 2 + k] = P.pairs[k];
 		}
 	}, (uint32_t)parts.size());
+	if (split) split->n_todo = r_off[parts.size()] / 2;
+	if (prof) fprintf(stderr, "[pairs] second walk, summed over the threads: mem_matesw %.1f ms (of which mem_sort_dedup_patch %.1f), mem_mark_primary_se %.1f, mem_pair %.1f\n",
+	                  g_ns_msw.exchange(0) / 1e6, g_ns_msw_dedup.exchange(0) / 1e6, g_ns_mark.exchange(0) / 1e6, g_ns_pair.exchange(0) / 1e6);
 	if (prof) fprintf(stderr, "[pairs] records put in place %.1f ms; the whole call %.1f ms\n", now() - t_d, now() - t_in);
 	if (getenv("BMH_POST_STATS"))
 		fprintf(stderr, "[finalize_pairs] %u reads: mem_matesw calls %llu, local alignments on the host %llu (%.0f cells each), rescued regions %llu\n", n_reads,
@@ -640,4 +677,18 @@ extern "C" int64_t bmh_finalize_pairs_deduped(const bmh_index_t *idx, const uint
 	if (!idx || !d_reads || !d_offs) { bmh_set_error("bmh_finalize_pairs_deduped: null argument"); return BMH_EINVAL; }
 	return finalize_pairs_impl(copt, ep, popt, pe, l_pac, pac, n_reads, reads, read_offs, read_lens, dedup_recs, dedup_per_read, frac_rep, n_contigs, contig_offset, contig_len,
 	                           out, cap, out_per_read, out_h, out_unflag, pes_out, n_threads, idx, d_reads, d_offs, stream, true);
+}
+
+// bmh_finalize_pairs_deduped for the pairs the device does not finish itself (csrc/pair_dev.hip, csrc/align_pipeline.hip): see bmh_pairs_split_t.
+// out / out_per_read / out_h / out_unflag are COMPACT: the reads of the pairs listed in split->todo_pairs, in that order.
+int64_t bmh_finalize_pairs_split(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream,
+                                 const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
+                                 int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,
+                                 const uint32_t *read_lens, const int32_t *dedup_recs, const uint32_t *dedup_per_read, const float *frac_rep,
+                                 int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
+                                 int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, int n_threads, bmh_pairs_split_t *split)
+{
+	if (!idx || !d_reads || !d_offs || !split) { bmh_set_error("bmh_finalize_pairs_split: null argument"); return BMH_EINVAL; }
+	return finalize_pairs_impl(copt, ep, popt, pe, l_pac, pac, n_reads, reads, read_offs, read_lens, dedup_recs, dedup_per_read, frac_rep, n_contigs, contig_offset, contig_len,
+	                           out, cap, out_per_read, out_h, out_unflag, nullptr, n_threads, idx, d_reads, d_offs, stream, true, split);
 }

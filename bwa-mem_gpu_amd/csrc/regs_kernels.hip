@@ -60,6 +60,7 @@ struct fin_args_t {
 	uint32_t *opr; uint32_t n_reads;
 	uint32_t *defer, *ctr;            // defer[c * n_reads ..]: reads handed to wave class c; ctr[c] their number, ctr[8 + c] next to be drawn, ctr[16] error
 	int32_t *g_dp;                    // [FIN_NCLS][FIN_WAVE_GRID][2][FIN_DPCAP]
+	int32_t *dedup_out;               // optional [n_regs][16] at in_off: the regions as mem_sort_dedup_patch leaves them (before the marking sorts them), [0] = read
 };
 __device__ __forceinline__ int fin_class(int n) { return n <= 32 ? 0 : n <= 128 ? 1 : n <= 256 ? 2 : n <= FIN_NMAX ? 3 : 4; }
 
@@ -78,7 +79,21 @@ __global__ void __launch_bounds__(256) fin_lane_kernel(fin_args_t A)
 			const int4 u = src[0], v = src[1];
 			a[i].v[0] = u.x; a[i].v[1] = u.y; a[i].v[2] = u.z; a[i].v[3] = u.w; a[i].v[4] = v.x; a[i].v[5] = v.y; a[i].v[6] = v.z; a[i].v[7] = v.w;
 		}
-		const int n = finalize_read<true, 1>(A.x, A.reads + A.read_offs[r], r, A.x.po.id0 + r, A.frac_rep ? A.frac_rep[r] : 0.f, n_in, a, z);
+		int n;
+		if (!A.dedup_out) n = finalize_read<true, 1>(A.x, A.reads + A.read_offs[r], r, A.x.po.id0 + r, A.frac_rep ? A.frac_rep[r] : 0.f, n_in, a, z);
+		else {                                                      // (finalize_read with a copy of the regions between its two halves)
+			for (int i = 0; i < n_in; ++i) init_one(A.x, a[i]);
+			n = sort_dedup_patch<true, 1>(A.x, A.reads + A.read_offs[r], n_in, a);
+			if (n >= 0) {
+				for (int i = 0; i < n; ++i) {
+					int4 *dst = (int4 *)(A.dedup_out + 16 * (size_t)(off + i));
+					dst[0] = make_int4((int)r, a[i].v[1], a[i].v[2], a[i].v[3]); dst[1] = make_int4(a[i].v[4], a[i].v[5], a[i].v[6], a[i].v[7]);
+					dst[2] = make_int4(a[i].v[8], a[i].v[9], a[i].v[10], a[i].v[11]); dst[3] = make_int4(a[i].v[12], a[i].v[13], a[i].v[14], a[i].v[15]);
+				}
+				mark_primary<1>(A.x, n, a, A.x.po.id0 + r, z);
+				n = emit_all(A.x, r, A.frac_rep ? A.frac_rep[r] : 0.f, n, a);
+			}
+		}
 		if (n == -NEED_DP) defer = true;
 		else if (n < 0) { A.ctr[16] = (uint32_t)-n; A.opr[r] = 0; return; }
 		else {
@@ -457,7 +472,8 @@ __device__ int fin_wave_emit(const ctx_t &x, uint32_t read, float frac_rep, cons
 }
 
 // the tail of one read by a wave; the result is in P.a[0..n) (P.a / P.b may have changed places)
-template <bool STAGED> __device__ int fin_wave_read(const ctx_t &x, const uint8_t *query, uint32_t read, int64_t id, float frac_rep, int n_in, wptr_t &P, uint64_t *stage)
+template <bool STAGED> __device__ int fin_wave_read(const ctx_t &x, const uint8_t *query, uint32_t read, int64_t id, float frac_rep, int n_in, wptr_t &P, uint64_t *stage,
+                                                    rec_t *dedup_out = nullptr)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	using namespace chain_core;
@@ -497,6 +513,7 @@ template <bool STAGED> __device__ int fin_wave_read(const ctx_t &x, const uint8_
 		ch_wave_fence<false>();
 		return n;
 	}
+	if (dedup_out) for (int i = lane; i < n; i += 64) { rec_t t = P.a[i]; t.v[0] = (int32_t)read; dedup_out[i] = t; }
 	for (int i = lane; i < n; i += 64) mark_init_one(P.a[i], id, i);
 	ch_wave_fence<false>();
 	if (!fin_wave_sort<KEY_SCORE_HASH, STAGED>(P, n, stage)) return -E_DPCAP;
@@ -560,7 +577,8 @@ __global__ void __launch_bounds__(64) fin_wave_kernel(fin_args_t A)
 			d.v[0] = u.x; d.v[1] = u.y; d.v[2] = u.z; d.v[3] = u.w; d.v[4] = v.x; d.v[5] = v.y; d.v[6] = v.z; d.v[7] = v.w;
 		}
 		ch_wave_fence<false>();
-		const int n = fin_wave_read<NMAX == 0>(x, A.reads + A.read_offs[r], r, x.po.id0 + r, A.frac_rep ? A.frac_rep[r] : 0.f, n_in, P, lstage);
+		const int n = fin_wave_read<NMAX == 0>(x, A.reads + A.read_offs[r], r, x.po.id0 + r, A.frac_rep ? A.frac_rep[r] : 0.f, n_in, P, lstage,
+		                                       A.dedup_out ? (rec_t *)(A.dedup_out + 16 * (size_t)off) : nullptr);
 		if (n < 0) { if (lane == 0) { A.ctr[16] = (uint32_t)-n; A.opr[r] = 0; } continue; }
 		rec_t *dst = (rec_t *)(A.work + 16 * (size_t)off);
 		if (P.a != dst) for (int i = lane; i < n; i += 64) dst[i] = P.a[i];
@@ -596,6 +614,7 @@ struct fin_scratch_t {
 	uint32_t *in_off, *out_off, *opr_tmp, *defer, *ctr; size_t cap_reads; int32_t *g_dp;
 	hipStream_t side[3]; hipEvent_t fork, join[3];
 	int32_t *work, *work2; uint64_t *g_keys, *g_k128; uint32_t *g_tmp, *g_order; int32_t *g_z; size_t cap_regs;
+	int32_t *dedup; size_t cap_dedup;       // the regions between the two halves of the tail, for callers that ask (bmh_finalize_regs_device_ex)
 	void *scan_tmp; size_t scan_bytes;
 	double *logtab; int64_t *ctg; int cap_ctg;
 	uint32_t *h_pin;
@@ -623,7 +642,7 @@ extern "C" void bmh_finalize_release(void *stream_)
 		g_fin_map.erase(it);
 	}
 	if (g_fin_last == S) g_fin_last = nullptr;
-	void *ps[] = {S->in_off, S->out_off, S->opr_tmp, S->defer, S->ctr, S->g_dp, S->work, S->work2, S->g_keys, S->g_k128, S->g_tmp, S->g_order, S->g_z, S->scan_tmp, S->logtab, S->ctg};
+	void *ps[] = {S->in_off, S->out_off, S->opr_tmp, S->defer, S->ctr, S->g_dp, S->work, S->work2, S->g_keys, S->g_k128, S->g_tmp, S->g_order, S->g_z, S->scan_tmp, S->logtab, S->ctg, S->dedup};
 	for (void *q : ps) if (q) (void)hipFree(q);
 	if (S->h_pin) (void)hipHostFree(S->h_pin);
 	if (S->ev0) (void)hipEventDestroy(S->ev0);
@@ -645,7 +664,18 @@ extern "C" float bmh_finalize_regs_device_last_ms(void)
 static int64_t finalize_regs_device_impl(const bmh_index_t *idx, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt,
                                          const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
                                          const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read, const float *d_frac_rep,
-                                         int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream_, int dedup_only);
+                                         int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream_, int dedup_only,
+                                         bmh_fin_extra_t *extra = nullptr);
+
+// bmh_finalize_regs_device that also leaves (csrc/align_pipeline.hip: interleaved pairs) the regions as mem_sort_dedup_patch left them, the first record of
+// every read and the device's copies of the logarithm table and the contig offsets
+int64_t bmh_finalize_regs_device_ex(const bmh_index_t *idx, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt,
+                                    const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
+                                    const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read, const float *d_frac_rep,
+                                    int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream_, bmh_fin_extra_t *extra)
+{
+	return finalize_regs_device_impl(idx, copt, ep, popt, d_reads, d_offs, n_reads, d_regs, n_regs, d_regs_per_read, d_frac_rep, n_contigs, contig_offset, d_out, d_out_per_read, stream_, 0, extra);
+}
 
 extern "C" int64_t bmh_finalize_regs_device(const bmh_index_t *idx, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt,
                                             const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
@@ -667,7 +697,8 @@ extern "C" int64_t bmh_dedup_regs_device(const bmh_index_t *idx, const bmh_chain
 static int64_t finalize_regs_device_impl(const bmh_index_t *idx, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt,
                                          const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
                                          const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read, const float *d_frac_rep,
-                                         int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream_, int dedup_only)
+                                         int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream_, int dedup_only,
+                                         bmh_fin_extra_t *extra)
 {
 	if (!idx || !copt || !ep || !popt || (n_reads && (!d_reads || !d_offs || !d_regs_per_read || (!d_frac_rep && !dedup_only) || !d_out_per_read)) || (n_regs && (!d_regs || !d_out))) {
 		bmh_set_error("bmh_finalize_regs_device: null argument"); return BMH_EINVAL;
@@ -750,6 +781,11 @@ static int64_t finalize_regs_device_impl(const bmh_index_t *idx, const bmh_chain
 	A.reads = d_reads; A.read_offs = d_offs; A.regs_in = d_regs; A.rpr = d_regs_per_read; A.in_off = S->in_off; A.frac_rep = d_frac_rep;
 	A.work = S->work; A.work2 = S->work2; A.g_keys = S->g_keys; A.g_k128 = S->g_k128; A.g_tmp = S->g_tmp; A.g_order = S->g_order; A.g_z = S->g_z;
 	A.opr = d_out_per_read; A.n_reads = n_reads; A.defer = S->defer; A.ctr = S->ctr; A.g_dp = S->g_dp;
+	A.dedup_out = nullptr;
+	if (extra && extra->d_dedup_out) {
+		if (n_regs + 1 > S->cap_dedup) { const size_t c = n_regs + n_regs / 4 + 1024; if (fin_grow(S->dedup, 16 * c) != BMH_OK) return BMH_ENOMEM; S->cap_dedup = c; }
+		A.dedup_out = S->dedup;
+	}
 	HIPCK(hipEventRecord(S->ev0, st));
 	HIPCK(hipMemsetAsync(S->ctr, 0, 128, st));
 	size_t tb = S->scan_bytes;
@@ -784,6 +820,11 @@ static int64_t finalize_regs_device_impl(const bmh_index_t *idx, const bmh_chain
 	tb = S->scan_bytes;
 	HIPCK(rocprim::exclusive_scan(S->scan_tmp, tb, d_out_per_read, S->out_off, 0u, (size_t)n_reads, rocprim::plus<uint32_t>(), st));
 	fin_compact_kernel<<<(n_reads + 255) / 256, 256, 0, st>>>(S->work, S->in_off, S->out_off, d_out_per_read, n_reads, d_out);
+	if (extra) {
+		if (extra->d_dedup_out) fin_compact_kernel<<<(n_reads + 255) / 256, 256, 0, st>>>(A.dedup_out, S->in_off, S->out_off, d_out_per_read, n_reads, extra->d_dedup_out);
+		if (extra->d_out_off) HIPCK(hipMemcpyAsync(extra->d_out_off, S->out_off, 4 * (size_t)n_reads, hipMemcpyDeviceToDevice, st));
+		extra->d_logtab = S->logtab; extra->n_log = FIN_NLOG; extra->d_ctg_off = n_contigs > 1 ? S->ctg : nullptr;
+	}
 	HIPCK(hipMemcpyAsync(S->h_pin, S->out_off + (n_reads - 1), 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipMemcpyAsync(S->h_pin + 1, d_out_per_read + (n_reads - 1), 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipMemcpyAsync(S->h_pin + 2, S->ctr, 68, hipMemcpyDeviceToHost, st));

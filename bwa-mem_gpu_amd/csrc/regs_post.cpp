@@ -118,10 +118,27 @@ static int patch_reg(const Ctx &x, const uint8_t *query, const Reg &a, const Reg
 	return score;
 }
 
+// klib's introsort of regions by a key, for lists long enough to care: the exchanges the sort makes depend on the outcomes of its comparisons only, so
+// sorting (key, place) pairs of 24 bytes with the same code gives the permutation sorting the 104-byte regions would have given, ties included; the
+// regions are then moved once.  (mem_matesw re-sorts the mate's list after every window: on repeat-rich pairs this was 60 % of the second walk.)
+template <class K, class KeyOf, class LT> static void sort_regs_by_key(int n, Reg *a, KeyOf key_of, LT lt)
+{
+	if (n <= 12) { klib::klib_introsort((size_t)n, a, [&](const Reg &p, const Reg &q) { return lt(key_of(p), key_of(q)); }); return; }
+	struct E { K k; int at; };
+	static thread_local std::vector<E> es;
+	static thread_local std::vector<Reg> tmp;
+	es.resize((size_t)n);
+	for (int i = 0; i < n; ++i) { es[(size_t)i].k = key_of(a[i]); es[(size_t)i].at = i; }
+	klib::klib_introsort((size_t)n, es.data(), [&](const E &p, const E &q) { return lt(p.k, q.k); });
+	tmp.assign(a, a + n);
+	for (int i = 0; i < n; ++i) a[i] = tmp[(size_t)es[(size_t)i].at];
+}
+struct KeySRQ { int score; int64_t rb; int qb; };
+
 int sort_dedup_patch(const Ctx &x, const uint8_t *query, int n, Reg *a)        // mem_sort_dedup_patch
 {
 	if (n <= 1) return n;
-	klib::klib_introsort((size_t)n, a, [](const Reg &p, const Reg &q) { return p.re < q.re; });
+	sort_regs_by_key<int64_t>(n, a, [](const Reg &p) { return p.re; }, [](int64_t p, int64_t q) { return p < q; });
 	for (int i = 0; i < n; ++i) a[i].n_comp = 1;
 	for (int i = 1; i < n; ++i) {
 		Reg *p = &a[i];
@@ -152,7 +169,7 @@ int sort_dedup_patch(const Ctx &x, const uint8_t *query, int n, Reg *a)        /
 	int m = 0;
 	for (int i = 0; i < n; ++i) if (a[i].qe > a[i].qb) { if (m != i) a[m] = a[i]; ++m; }
 	n = m;
-	klib::klib_introsort((size_t)n, a, [](const Reg &p, const Reg &q) {
+	sort_regs_by_key<KeySRQ>(n, a, [](const Reg &p) { return KeySRQ{p.score, p.rb, p.qb}; }, [](const KeySRQ &p, const KeySRQ &q) {
 		return p.score > q.score || (p.score == q.score && (p.rb < q.rb || (p.rb == q.rb && p.qb < q.qb)));
 	});
 	for (int i = 1; i < n; ++i)

@@ -160,7 +160,11 @@ static const bool g_pair_prof = getenv("BMH_PAIR_PROFILE") != nullptr;
 static std::atomic<unsigned long long> g_ns_msw{0}, g_ns_msw_dedup{0}, g_ns_mark{0}, g_ns_pair{0}, g_ns_rest{0};
 static inline unsigned long long now_ns() { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector<Reg> &ma, SwKey key = SwKey{0, 0, 0, 0}, uint32_t mate_read = 0)        // mem_matesw
+// ma_state (optional, one byte per mate list, 0 at first): bit 0 = the list has been through a mem_sort_dedup_patch call of THIS function (the one without
+// patching) and nothing was inserted since -- another such call leaves it as it is (every surviving pair of hits has been tested in its final form and the
+// closing sort orders by a key no two survivors share), so it is skipped.  The list's first call is always made: the state the patching call left it in
+// is not a fixed point (a hit that grew by a patch is not tested again against the hits it had been compared with).
+int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector<Reg> &ma, SwKey key = SwKey{0, 0, 0, 0}, uint32_t mate_read = 0, uint8_t *ma_state = nullptr)        // mem_matesw
 {
 	if (g_pair_stats) g_ms_calls++;
 	const int64_t l_pac = c.x.l_pac;
@@ -237,12 +241,14 @@ int matesw(const PCtx &c, const Reg &a, int l_ms, const uint8_t *ms, std::vector
 				if (g_pair_stats) g_ms_hits++;
 				for (i = 0; i < ma.size(); ++i) if (ma[i].score < b.score) break;     // keep ma sorted by score
 				ma.insert(ma.begin() + (long)i, b);
+				if (ma_state) *ma_state = 0;
 			}
 			++n;
 		}
-		if (n) {
+		if (n && !(ma_state && (*ma_state & 1))) {
 			const unsigned long long t0 = g_pair_prof ? now_ns() : 0;
 			const int m = sort_dedup_patch(c.x, nullptr, (int)ma.size(), ma.data()); ma.resize((size_t)m);
+			if (ma_state) *ma_state = 1;
 			if (g_pair_prof) g_ns_msw_dedup += now_ns() - t0;
 		}
 	}
@@ -347,9 +353,10 @@ int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // 
 			for (const Reg &r : *a[i]) if (r.score >= (*a[i])[0].score - c.pe->pen_unpaired) b[i].push_back(r);
 		}
 		const unsigned long long t0 = g_pair_prof && c.sw_mode == 2 ? now_ns() : 0;
+		uint8_t ma_state[2] = {0, 0};
 		for (int i = 0; i < 2; ++i)
 			for (size_t j = 0; j < b[i].size() && (int)j < c.pe->max_matesw; ++j)
-				matesw(c, b[i][j], l_seq[!i], seq[!i], *a[!i], SwKey{(uint32_t)(r0 >> 1), (uint16_t)j, (uint8_t)i, 0}, r0 + (uint32_t)!i);
+				matesw(c, b[i][j], l_seq[!i], seq[!i], *a[!i], SwKey{(uint32_t)(r0 >> 1), (uint16_t)j, (uint8_t)i, 0}, r0 + (uint32_t)!i, &ma_state[!i]);
 		if (t0) g_ns_msw += now_ns() - t0;
 	}
 	if (c.sw_mode == 1) return 0;

@@ -120,6 +120,7 @@ struct lane_t {
 	dbuf_t<uint8_t> d_reads, d_work; dbuf_t<uint32_t> d_offs, d_lens, d_sel, d_opr, d_cigar, d_off, d_packed, d_over, d_sel2; dbuf_t<int32_t> d_out3, d_regs, d_fin, d_aln, d_slot, d_hrec, d_unflag; dbuf_t<char> d_md;
 	dbuf_t<int32_t> d_dedup, d_fin2, d_hrec2, d_unflag2, d_rslot, d_hh, d_ufh, d_finh; dbuf_t<uint32_t> d_roff, d_roff2, d_opr2, d_todo_pairs, d_oprh, d_offh; dbuf_t<uint8_t> d_todo, d_scan;   // pairs on the device
 	hbuf_t<uint8_t> h_todo; std::vector<uint32_t> todo_pairs, offh;
+	dbuf_t<uint32_t> d_cg2; dbuf_t<int32_t> d_aln2; dbuf_t<char> d_md2; uint32_t max_read_len = 0;      // the redo of the alignments that overflow the fixed slots
 	dbuf_t<char> d_names, d_text, d_ctg_names; dbuf_t<uint64_t> d_name_off, d_text_off; dbuf_t<uint32_t> d_ctg_name_off; dbuf_t<int64_t> d_ctg_off; bool ctg_up = false;
 	hbuf_t<uint32_t> h_offs, h_sel, h_rpr; hbuf_t<int32_t> h_regs; hbuf_t<float> h_fr; hbuf_t<uint8_t> h_need, h_reads; hbuf_t<char> h_names; hbuf_t<uint64_t> h_name_off;
 	double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // h2d, seed, chain+extend+merge, tail, select, cigar + d2h
@@ -153,7 +154,9 @@ void par_memcpy(void *dst, const void *src, size_t n, int n_threads)
 // large ones and put in place there too.  to_host: the alignments, their offsets and the packed words go to R (the host formatter's inputs).
 int cigars(const aligner_t &A, lane_t &Ln, const int32_t *d_fin, uint64_t n_sel, result_t &R, bool to_host, uint64_t *words_out)
 {
-	const int max_cigar = 16, md_cap = 96, MC = 64, MD = 1024;
+	// fixed slots: 16 operations; an MD string of 96 bytes for reads up to 192 bases, half a read's length beyond (a 300 bp read with a dozen mismatches
+	// writes 60-100 characters: with 96 every tenth alignment went the way of the overflowed ones)
+	const int max_cigar = 16, md_cap = Ln.max_read_len <= 192 ? 96 : (int)((Ln.max_read_len / 2 + 31) & ~31u), MC = 64, MD = 1024;
 	R.n_sel = n_sel;
 	*words_out = 0;
 	if (to_host) { RCK(R.aln.need(8 * (n_sel + 1))); RCK(R.off.need(n_sel + 2)); }
@@ -172,11 +175,11 @@ int cigars(const aligner_t &A, lane_t &Ln, const int32_t *d_fin, uint64_t n_sel,
 	RCK(bmh_cigar_pack(Ln.d_aln.p, Ln.d_cigar.p, max_cigar, Ln.d_md.p, md_cap, (uint32_t)n_sel, Ln.d_off.p, Ln.d_packed.p, Ln.st));
 	if (n_over) {
 		const size_t no = (size_t)n_over;
-		dbuf_t<uint32_t> d_cg2, d_scr; dbuf_t<int32_t> d_aln2; dbuf_t<char> d_md2;
-		RCK(d_cg2.need((size_t)MC * no)); RCK(d_aln2.need(8 * no)); RCK(d_md2.need((size_t)MD * no)); RCK(d_scr.need(no + 1));
-		RCK(bmh_cigar_batch(A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, d_fin, 16, Ln.d_sel2.p, (uint32_t)no, &A.ep, A.co.w, MC, d_cg2.p, d_aln2.p, MD, d_md2.p, Ln.st));
-		words = bmh_cigar_patch(Ln.d_aln.p, Ln.d_off.p, Ln.d_packed.p, (uint64_t)words, Ln.d_over.p, (uint32_t)no, d_aln2.p, d_cg2.p, MC, d_md2.p, MD, d_scr.p, Ln.st);
-		if (words < 0) return (int)words;           // (the call waited for the stream: the temporaries may go)
+		RCK(Ln.d_cg2.need((size_t)MC * no)); RCK(Ln.d_aln2.need(8 * no)); RCK(Ln.d_md2.need((size_t)MD * no)); RCK(Ln.d_work.need(bmh_cigar_patch_work((uint32_t)no)));
+		RCK(bmh_cigar_batch(A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, d_fin, 16, Ln.d_sel2.p, (uint32_t)no, &A.ep, A.co.w, MC, Ln.d_cg2.p, Ln.d_aln2.p, MD, Ln.d_md2.p, Ln.st));
+		words = bmh_cigar_patch(Ln.d_aln.p, Ln.d_off.p, Ln.d_packed.p, (uint64_t)words, Ln.d_over.p, (uint32_t)no, Ln.d_aln2.p, Ln.d_cg2.p, MC, Ln.d_md2.p, MD, Ln.d_work.p, Ln.d_work.cap, Ln.st);
+		if (words < 0) return (int)words;
+		if (getenv("BMH_ALIGNER_TRACE")) fprintf(stderr, "[aligner] %zu of %llu alignments redone with large CIGAR / MD slots\n", no, (unsigned long long)n_sel);
 	}
 	*words_out = (uint64_t)words;
 	if (!to_host) return BMH_OK;
@@ -398,7 +401,8 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 	double t0 = now_s();
 	// ---- reads to the device
 	RCK(Ln.d_reads.need(nb + 16)); RCK(Ln.d_offs.need(n + 1)); RCK(Ln.d_lens.need(n + 1)); RCK(Ln.h_offs.need(n + 1));
-	for (uint32_t r = 0; r < n; ++r) Ln.h_offs.p[r] = (uint32_t)(rs.offs[b0 + r] - a0);
+	Ln.max_read_len = 0;
+	for (uint32_t r = 0; r < n; ++r) { Ln.h_offs.p[r] = (uint32_t)(rs.offs[b0 + r] - a0); if (rs.lens[b0 + r] > Ln.max_read_len) Ln.max_read_len = rs.lens[b0 + r]; }
 	RCK(Ln.h_reads.need(nb + 16));
 	par_memcpy(Ln.h_reads.p, rs.ascii + a0, nb, n_threads);           // (pageable -> pinned by this lane's threads, then one DMA: the lanes stage side by side)
 	LCK(hipMemcpyAsync(Ln.d_reads.p, Ln.h_reads.p, nb, hipMemcpyHostToDevice, Ln.st));

@@ -47,8 +47,9 @@ bool bmh_format_sam_parts(const bmh_post_opt_t *po, uint32_t n_reads, const char
 // csrc/sam_kernels.hip, for csrc/align_pipeline.hip: the alignments whose fixed slots overflowed (flags 1, 8) found and, once redone with large
 // slots, put in place on the device (see the definitions)
 int64_t bmh_cigar_overflowed(const int32_t *d_aln, uint32_t n, const uint32_t *d_sel, uint32_t *d_over, uint32_t *d_sel2, uint32_t *d_counter, void *stream);
+size_t bmh_cigar_patch_work(uint32_t n_over);
 int64_t bmh_cigar_patch(int32_t *d_aln, uint32_t *d_off, uint32_t *d_packed, uint64_t words, const uint32_t *d_over, uint32_t n_over,
-                        const int32_t *d_aln2, const uint32_t *d_cigar2, int mc2, const char *d_md2, int mdc2, uint32_t *d_scratch, void *stream);
+                        const int32_t *d_aln2, const uint32_t *d_cigar2, int mc2, const char *d_md2, int mdc2, void *d_work, size_t work_bytes, void *stream);
 // csrc/regs_kernels.hip: bmh_finalize_regs_device with by-products (in: d_dedup_out [n_regs][16] or NULL, d_out_off [n_reads] or NULL; out: the device's
 // logarithm table and contig offsets, valid until the stream's scratch is released)
 struct bmh_fin_extra_t { int32_t *d_dedup_out; uint32_t *d_out_off; const double *d_logtab; int n_log; const int64_t *d_ctg_off; };

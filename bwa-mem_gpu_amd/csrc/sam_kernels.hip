@@ -566,32 +566,30 @@ __global__ void __launch_bounds__(256) cigar_over_kernel(const int32_t *aln, uin
 	if (aln[8 * (size_t)k + 7] & 9) { const uint32_t t = atomicAdd(counter, 1u); over[t] = k; sel2[t] = sel ? sel[k] : k; }
 }
 
-__global__ void __launch_bounds__(256) cigar_patch_kernel(int32_t *aln, uint32_t *off, uint32_t *packed, uint64_t words, const uint32_t *over, uint32_t n_over,
-                                                          const int32_t *aln2, const uint32_t *cigar2, int mc2, const char *md2, int mdc2, uint32_t *start, uint32_t *total)
+// the redone alignments take their places: words of each (cigar_patch_words), a scan, then one wave per alignment copies
+__global__ void __launch_bounds__(256) cigar_patch_words_kernel(const int32_t *aln2, uint32_t n_over, uint32_t *words)
 {
-	// (one workgroup: the list is a handful of alignments; thread 0 places them, all threads copy)
-	if (threadIdx.x == 0) {
-		uint64_t at = words;
-		for (uint32_t t = 0; t < n_over; ++t) {
-			const int32_t *a = aln2 + 8 * (size_t)t;
-			start[t] = (uint32_t)at;
-			if (!(a[7] & ~2)) at += (uint64_t)a[3] + (((uint64_t)a[6] + 4) >> 2);
-		}
-		*total = (uint32_t)at;
-	}
-	__syncthreads();
-	for (uint32_t t = 0; t < n_over; ++t) {
-		const int32_t *a = aln2 + 8 * (size_t)t;
-		const uint32_t k = over[t];
-		if (threadIdx.x < 8) aln[8 * (size_t)k + threadIdx.x] = a[threadIdx.x];
-		if (a[7] & ~2) continue;
-		if (threadIdx.x == 0) off[k] = start[t];
-		const uint32_t nc = (uint32_t)a[3], nw = ((uint32_t)a[6] + 4u) >> 2;
-		uint32_t *o = packed + start[t];
-		const uint32_t *cg = cigar2 + (size_t)mc2 * t; const uint32_t *ms = (const uint32_t *)(md2 + (size_t)mdc2 * t);
-		for (uint32_t i = threadIdx.x; i < nc; i += 256) o[i] = cg[i];
-		for (uint32_t i = threadIdx.x; i < nw; i += 256) o[nc + i] = ms[i];
-	}
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	if (t > n_over) return;
+	uint32_t w = 0;
+	if (t < n_over) { const int32_t *a = aln2 + 8 * (size_t)t; if (!(a[7] & ~2)) w = (uint32_t)a[3] + (((uint32_t)a[6] + 4u) >> 2); }
+	words[t] = w;
+}
+__global__ void __launch_bounds__(64) cigar_patch_kernel(int32_t *aln, uint32_t *off, uint32_t *packed, const uint32_t *over, uint32_t n_over,
+                                                         const int32_t *aln2, const uint32_t *cigar2, int mc2, const char *md2, int mdc2, const uint32_t *start)
+{
+	const uint32_t t = blockIdx.x, lane = threadIdx.x;
+	if (t >= n_over) return;
+	const int32_t *a = aln2 + 8 * (size_t)t;
+	const uint32_t k = over[t];
+	if (lane < 8) aln[8 * (size_t)k + lane] = a[lane];
+	if (a[7] & ~2) return;
+	if (lane == 0) off[k] = start[t];
+	const uint32_t nc = (uint32_t)a[3], nw = ((uint32_t)a[6] + 4u) >> 2;
+	uint32_t *o = packed + start[t];
+	const uint32_t *cg = cigar2 + (size_t)mc2 * t; const uint32_t *ms = (const uint32_t *)(md2 + (size_t)mdc2 * t);
+	for (uint32_t i = lane; i < nc; i += 64) o[i] = cg[i];
+	for (uint32_t i = lane; i < nw; i += 64) o[nc + i] = ms[i];
 }
 
 }   // namespace
@@ -612,16 +610,24 @@ int64_t bmh_cigar_overflowed(const int32_t *d_aln, uint32_t n, const uint32_t *d
 }
 
 // the redone alignments (d_aln2 / d_cigar2 [n_over][mc2] / d_md2 [n_over][mdc2], in d_over's order) take their places: d_aln[k] is replaced, the words
-// are appended behind the `words` packed ones (the caller left room for n_over * (mc2 + mdc2 / 4) more) and d_off[k] points at them; d_scratch:
-// n_over + 1 words.  Returns the new number of words (waits for the stream).
+// are appended behind the `words` packed ones (the caller left room for n_over * (mc2 + mdc2 / 4) more) and d_off[k] points at them; d_work:
+// bmh_cigar_patch_work(n_over) bytes.  Returns the new number of words (waits for the stream).
+size_t bmh_cigar_patch_work(uint32_t n_over) { return 2 * al256(4 * ((size_t)n_over + 2)) + scan_bytes((size_t)n_over + 2) + 256; }
 int64_t bmh_cigar_patch(int32_t *d_aln, uint32_t *d_off, uint32_t *d_packed, uint64_t words, const uint32_t *d_over, uint32_t n_over,
-                        const int32_t *d_aln2, const uint32_t *d_cigar2, int mc2, const char *d_md2, int mdc2, uint32_t *d_scratch, void *stream_)
+                        const int32_t *d_aln2, const uint32_t *d_cigar2, int mc2, const char *d_md2, int mdc2, void *d_work, size_t work_bytes, void *stream_)
 {
 	hipStream_t st = (hipStream_t)stream_;
 	if (n_over == 0) return (int64_t)words;
-	cigar_patch_kernel<<<1, 256, 0, st>>>(d_aln, d_off, d_packed, words, d_over, n_over, d_aln2, d_cigar2, mc2, d_md2, mdc2, d_scratch, d_scratch + n_over);
+	if (!d_work || work_bytes < bmh_cigar_patch_work(n_over)) { bmh_set_error("bmh_cigar_patch: work space too small"); return BMH_EINVAL; }
+	uint8_t *w = (uint8_t *)d_work;
+	uint32_t *wd = (uint32_t *)w; w += al256(4 * ((size_t)n_over + 2));
+	uint32_t *start = (uint32_t *)w; w += al256(4 * ((size_t)n_over + 2));
+	cigar_patch_words_kernel<<<(n_over + 1 + 255) / 256, 256, 0, st>>>(d_aln2, n_over, wd);
+	size_t tb = scan_bytes((size_t)n_over + 2);
+	HIPCK(rocprim::exclusive_scan((void *)w, tb, wd, start, (uint32_t)words, (size_t)n_over + 1, rocprim::plus<uint32_t>(), st));      // start[n_over] = the new total
+	cigar_patch_kernel<<<n_over, 64, 0, st>>>(d_aln, d_off, d_packed, d_over, n_over, d_aln2, d_cigar2, mc2, d_md2, mdc2, start);
 	uint32_t h = 0;
-	HIPCK(hipMemcpyAsync(&h, d_scratch + n_over, 4, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(&h, start + n_over, 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));
 	HIPCK(hipGetLastError());
 	return (int64_t)h;

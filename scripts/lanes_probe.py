@@ -27,7 +27,7 @@ d = F.build_fmd_index_device(pac_t, n_genome, sa_intv=int(os.environ.get("SA_INT
 contigs, holes = meta["contigs"], meta["holes"]
 dindex = B.Index.from_device(d.primary, d.L2.astype(np.uint64), d.seq_len, d.bwt_t, d.sa_intv, d.sa_t, d.bits_t, pac_t=pac_t, l_pac=n_genome)
 torch.cuda.empty_cache()
-rl = 150
+rl = int(os.environ.get("LANES_READ_LEN", "150"))
 reads = (B.synth.make_pairs(g, n_reads // 2, rl, seed=7, holes=holes) if paired else B.synth.make_reads(g, n_reads, rl, seed=7, holes=holes))[0]
 flat = np.ascontiguousarray(np.asarray(reads, np.uint8).reshape(-1))
 offs = np.arange(n_reads, dtype=np.uint64) * np.uint64(rl)

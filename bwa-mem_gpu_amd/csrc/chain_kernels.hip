@@ -601,11 +601,13 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 	HIPCK(hipEventRecord(w->ev_t[3], w->side));
 	const bool ctg_lds = w->n_contigs > 1 && w->n_contigs <= CH_LDS_CONTIGS;
 	HIPCK(hipFuncSetAttribute(ctg_lds ? (const void *)chain_wave_kernel<true, FLT> : (const void *)chain_wave_kernel<false, FLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[CH_N_CLASSES - 2] * CH_LDS_BYTES_PER_ENTRY_HYBRID)));
+	static const bool serial = getenv("BMH_CHAIN_SERIAL") != nullptr;          // (measurement: one class after the other, so that BMH_CHAIN_STATS shows what each costs alone)
 	for (int cls = CH_N_CLASSES - 1; cls >= 0; --cls) {
 		const uint32_t lds_cap = CH_CLASS_CAP[cls];
 		const int hybrid = cls >= CH_HYBRID_CLASS && lds_cap != 0;
 		const size_t lds_bytes = (size_t)lds_cap * (hybrid ? CH_LDS_BYTES_PER_ENTRY_HYBRID : CH_LDS_BYTES_PER_ENTRY);
 		HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->ev_fork, 0));
+		if (serial && cls < CH_N_CLASSES - 1) HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->cls_done[cls + 1], 0));
 		if (cls == 0) {                                                                                                   // (blocks beyond the list leave at once)
 			if (list_private && !FLT && A.lane_max <= 32u) chain_lane_list_kernel<FLT, 32><<<nblk(n_reads, 256), 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls);
 			else chain_lane_list_kernel<FLT, 0><<<nblk(n_reads, 256), 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls);

@@ -175,3 +175,61 @@ def test_baseline_configs_3_and_4_at_full_size(variant):
     v = res["verified"]
     assert v["reads"] == 100_000 and v["seeds_identical"] and v["regions_identical"], v
     assert res["value"] > 0
+
+
+def test_reads_to_sam_device_forms_equal_host_forms_beyond_2_pow_32(hip):
+    """bmh_aligner_run on a 2.2 Gbp hg38-like genome (24 sequences, seq_len 4.4e9, 50 % repeats), 200 000 single-end reads and 100 000 pairs: the
+    text the device writes (records selected, CIGARs packed, SAM assembled on the device; pairs: mem_pair / mem_sam_pe's choices on the device for
+    the pairs the rescue leaves alone) is byte for byte the text of the host forms (bmh_sam_need_cigar + bmh_format_sam[_pe]; all pairs through the
+    host walks of mem_sam_pe), at positions beyond 2^32 and on reads with hundreds of hits."""
+    import ctypes as C
+    import torch
+    B = hip
+    from bwamem_hip import fmindex as F, synth
+    from bwamem_hip.aligner import ReadSet
+    from bwamem_hip.lib import NativeAligner, PeOpt, ChainOpt, PostOpt
+    dev = torch.device("cuda", 0)
+    L = B.load_library()
+    n = 2_200_000_000
+    g_t, meta = synth.make_genome_device(n, dev, seed=11, return_meta=True)
+    pac_t = F.pack_pac_device(g_t)
+    g = g_t.cpu().numpy()
+    del g_t
+    torch.cuda.empty_cache()
+    d = F.build_fmd_index_device(pac_t, n, sa_intv=1)
+    dindex = B.Index.from_device(d.primary, d.L2.astype(np.uint64), d.seq_len, d.bwt_t, 1, d.sa_t, d.bits_t, pac_t=pac_t, l_pac=n)
+    co = ChainOpt(); L.bmh_chain_opt_default(C.byref(co)); po = PostOpt(); L.bmh_post_opt_default(C.byref(po))
+    pe_o = PeOpt(); L.bmh_pe_opt_default(C.byref(pe_o))
+    pac_h = pac_t.cpu().numpy()
+    nat = NativeAligner(dindex, pac_h, n, meta["contigs"], None, co, B.ExtParams.default(), po, pe_o)
+    nth = L.bmh_effective_cpus()
+    n_reads, rl = 200_000, 150
+    for paired in (False, True):
+        reads = (synth.make_pairs(g, n_reads // 2, rl, seed=21, holes=meta["holes"]) if paired else synth.make_reads(g, n_reads, rl, seed=21, holes=meta["holes"]))[0]
+        flat = np.ascontiguousarray(np.asarray(reads, np.uint8).reshape(-1))
+        w = len(str(n_reads))
+        names = np.char.add("r", np.char.zfill((np.arange(n_reads) // (2 if paired else 1)).astype(str), w))
+        blob = np.frombuffer(("\0".join(names.tolist()) + "\0").encode(), dtype=np.uint8)
+        rs = ReadSet(synth.codes_to_ascii(flat), np.arange(n_reads, dtype=np.uint64) * np.uint64(rl), np.full(n_reads, rl, np.uint32), blob,
+                     np.arange(n_reads, dtype=np.uint64) * np.uint64(w + 2), codes=flat)
+        cuts = [0, (n_reads // 3) & ~1, (2 * n_reads // 3) & ~1, n_reads]
+        texts = {}
+        for env in ("", "BMH_ALIGNER_HOST_FORMAT") + (("BMH_ALIGNER_PE_HOST",) if paired else ()):
+            if env:
+                os.environ[env] = "1"
+            try:
+                parts = []
+                nat.run(rs, cuts, paired, lambda mv: parts.append(bytes(mv)), n_lanes=2, n_threads=nth)
+                texts[env] = b"".join(parts)
+            finally:
+                if env:
+                    del os.environ[env]
+        body = texts[""]
+        assert body.count(b"\n") >= n_reads and b"\tXA:Z:" in body
+        pos = np.array([int(l.split(b"\t")[3]) for l in body.split(b"\n")[:20000] if l and l.split(b"\t")[2] != b"*"])
+        assert pos.max() > 100_000_000
+        for env, t in texts.items():
+            if t != body:
+                a, b = body.split(b"\n"), t.split(b"\n")
+                assert False, (paired, env, len(a), len(b), [(x, y) for x, y in zip(a, b) if x != y][:2])
+    nat.free(); dindex.free()

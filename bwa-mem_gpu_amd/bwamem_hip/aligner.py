@@ -440,7 +440,7 @@ class Aligner:
             if nat is None:
                 nat = self._native = NativeAligner(self.index, self.pac, self.l_pac, self.contigs, self.alt if self.has_alt else None, self.copt, self.ep, self.po, self.pe)
             self.last_stats = nat.run(rs, cuts, paired, (lambda mv: out.write(mv)) if binary else (lambda mv: out.write(bytes(mv).decode())),
-                                      n_lanes=int(os.environ.get("BMH_ALIGNER_LANES", "2")), n_threads=self.n_threads)
+                                      n_lanes=int(os.environ.get("BMH_ALIGNER_LANES", "3" if paired else "2")), n_threads=self.n_threads)   # (pairs: a lane waits for host walks in the middle of its batch)
             return n
         for b, e in zip(cuts[:-1], cuts[1:]):
             if e > b:

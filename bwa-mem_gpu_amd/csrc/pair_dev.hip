@@ -22,7 +22,7 @@
 
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
 
-#define PD_NMAX 160         // hits of a pair's two reads together the kernel takes (a lane's private arrays)
+#define PD_NMAX 64          // hits of a pair's two reads together the kernel takes (a lane's private arrays)
 
 using namespace regs_core;
 

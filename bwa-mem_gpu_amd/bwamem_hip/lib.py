@@ -339,6 +339,7 @@ def load_library() -> C.CDLL:
     L.bmh_cigar_batch.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_uint32, C.POINTER(ExtParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_void_p, C.c_void_p]
     L.bmh_cigar_release.restype = None
+    L.bmh_cigar_release.argtypes = [C.c_void_p]
     L.bmh_sam_select_work.restype = C.c_size_t
     L.bmh_sam_select_work.argtypes = [C.c_uint32, C.c_uint64]
     L.bmh_sam_select_device.restype = C.c_int64

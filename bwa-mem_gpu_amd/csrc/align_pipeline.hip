@@ -717,7 +717,6 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 			done[b] = std::move(R);
 			cv.notify_all();
 		}
-		bmh_cigar_release();                                         // (the thread's scratch of bmh_cigar_batch ends with the thread)
 		std::lock_guard<std::mutex> lk(mu);
 		for (int k = 0; k < 8; ++k) lane_t_sum[(size_t)k] += Ln.t[k];
 	};

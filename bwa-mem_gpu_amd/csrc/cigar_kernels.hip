@@ -8,6 +8,9 @@
 // The direction matrix (one byte per in-band cell) lives in LDS when it fits, else in a per-wave slab in HBM; the
 // traceback, the run-length CIGAR, NM and the MD string are produced by the wave in lock step (one lane writes).
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 #include <stdio.h>
@@ -641,24 +644,39 @@ __global__ void __launch_bounds__(256) cigar_size_kernel(const int32_t *regs, in
 	if ((threadIdx.x & 63) == 0) { atomicMax(out, zb); atomicMax(out + 1, ml); }
 }
 
-// the calling thread's scratch, on the device it was first used on: dropped by bmh_cigar_release (a thread that ends calls it: the lanes of
-// bmh_aligner_run are threads of one run) or when the thread turns to another device
+// the scratch of bmh_cigar_batch per (device, stream), like the other stages': kept between calls (the direction matrices of a million 300 bp alignments are
+// gigabytes: allocating them per run of a worker thread cost more than the kernels), dropped by bmh_cigar_release(stream) when the caller retires the stream.
+// A stream belongs to one thread at a time (the library's rule for all per-stream scratch).
 struct cigar_scratch_t {
 	unsigned long long *d_sizes = nullptr;       // [0] largest rectangle [1] longest sequence [2] fast-path matrix bytes; then CG_NKIND list counts (u32)
 	uint8_t *slab = nullptr; size_t slab_bytes = 0;
 	cg_job_t *jobs = nullptr; uint32_t *lists = nullptr, *rev = nullptr; size_t cap_n = 0, cap_rev = 0; uint8_t *z = nullptr; size_t z_bytes = 0;
-	int dev = -1;
 	void drop()
 	{
 		void *ps[] = {d_sizes, slab, jobs, lists, rev, z};
 		for (void *q : ps) if (q) (void)hipFree(q);
 		d_sizes = nullptr; slab = nullptr; jobs = nullptr; lists = rev = nullptr; z = nullptr;
-		slab_bytes = cap_n = cap_rev = z_bytes = 0; dev = -1;
+		slab_bytes = cap_n = cap_rev = z_bytes = 0;
 	}
 };
-static thread_local cigar_scratch_t g_cs;
+static std::mutex g_cs_mu;
+static std::map<std::pair<int, void *>, cigar_scratch_t *> g_cs_map;
 
-extern "C" void bmh_cigar_release(void) { g_cs.drop(); }
+extern "C" void bmh_cigar_release(void *stream_)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return;
+	cigar_scratch_t *S = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(g_cs_mu);
+		auto it = g_cs_map.find(std::make_pair(dev, stream_));
+		if (it == g_cs_map.end()) return;
+		S = it->second;
+		g_cs_map.erase(it);
+	}
+	S->drop();
+	delete S;
+}
 
 template <int C, int CLO>
 static int launch_cigar(const cigar_args_t &a, unsigned grid, size_t lds, hipStream_t st)
@@ -685,11 +703,17 @@ extern "C" int bmh_cigar_batch(const bmh_index_t *idx, const uint8_t *d_reads, c
 	if (n == 0) return BMH_OK;
 	hipStream_t st = (hipStream_t)stream_;
 	static const bool slow_only = getenv("BMH_CIGAR_SLOW") != nullptr;
+	cigar_scratch_t *gs;
 	{
 		int dev = 0;
 		HIPCK(hipGetDevice(&dev));
-		if (g_cs.dev != dev) { g_cs.drop(); g_cs.dev = dev; }
+		std::lock_guard<std::mutex> lk(g_cs_mu);
+		auto key = std::make_pair(dev, stream_);
+		auto it = g_cs_map.find(key);
+		if (it == g_cs_map.end()) { gs = new cigar_scratch_t(); g_cs_map[key] = gs; }
+		else gs = it->second;
 	}
+	cigar_scratch_t &g_cs = *gs;
 	if (!g_cs.d_sizes) HIPCK(hipMalloc((void **)&g_cs.d_sizes, 64));
 	HIPCK(hipMemsetAsync(g_cs.d_sizes, 0, 64, st));
 	cigar_size_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_regs, reg_stride, d_sel, n, g_cs.d_sizes);

@@ -997,11 +997,12 @@ int bmh_extend_reserve(void *stream_, uint64_t n)
 // stream must be idle.  A stream must not be used for extensions by two host threads at once: they would share this scratch.
 extern "C" void bmh_finalize_release(void *stream_);
 extern "C" void bmh_matesw_release(void *stream_);
+extern "C" void bmh_cigar_release(void *stream_);
 extern "C" void bmh_extend_release(void *stream_)
 {
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) return;
-	bmh_finalize_release(stream_); bmh_matesw_release(stream_);      // the per-stream scratch of the stages after the extension goes with it
+	bmh_finalize_release(stream_); bmh_matesw_release(stream_); bmh_cigar_release(stream_);      // the per-stream scratch of the stages after the extension goes with it
 	ext_scratch_t *s = nullptr;
 	{
 		std::lock_guard<std::mutex> lk(g_scr_mu);

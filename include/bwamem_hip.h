@@ -485,8 +485,9 @@ int bmh_cigar_batch(const bmh_index_t *idx, const uint8_t *d_reads, const uint32
                     const int32_t *d_regs, int reg_stride, const uint32_t *d_sel, uint32_t n, const bmh_ext_params_t *p, int opt_w,
                     int max_cigar, uint32_t *d_cigar, int32_t *d_aln, int md_cap, char *d_md, void *stream);
 
-/* frees the calling thread's scratch of bmh_cigar_batch (device buffers it keeps between calls); a worker thread calls it before it ends */
-void bmh_cigar_release(void);
+/* frees the (device, stream) scratch of bmh_cigar_batch (device buffers it keeps between calls: the direction matrices of a batch are gigabytes);
+ * the stream idle, its device current -- bmh_extend_release(stream) calls it too */
+void bmh_cigar_release(void *stream);
 
 /* ---- what the SAM writer needs of a batch, chosen and packed on the device (csrc/sam_kernels.hip)
  * bmh_sam_select_device: bmh_sam_need_cigar over records in HBM (d_fin [m][16], d_fin_per_read [n_reads]: what bmh_finalize_regs_device

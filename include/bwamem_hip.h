@@ -533,10 +533,14 @@ int bmh_sam_text_check(const void *d_work, uint32_t n_reads, void *stream);
  *
  * What gase_aln's worker threads do around the device libraries (src/bwamem.c:2042-2340, src/fastmap.c:59-120), on top of the entry
  * points above: n_lanes worker threads take the batches [cuts[b], cuts[b+1]) of the read set in turn -- each with its own stream,
- * workspaces and pinned staging: H2D, seeding, chaining, extension, merge, the region tail (on the device for single-end batches; the
- * host forms for interleaved pairs, for an index with ALT contigs and for a batch the device tail refuses), CIGARs, D2H -- and ONE
- * writer thread formats the finished batches in order and hands every batch's text to `sink` (return 0 to go on) while the workers
- * are on the next ones.  The text is what bmh_format_sam / bmh_format_sam_pe write (records only: the caller writes the @SQ header).
+ * workspaces and pinned staging: H2D, seeding, chaining, extension, merge, the region tail, the selection of the records that need a
+ * CIGAR, CIGAR / NM / MD, and the SAM text itself (bmh_sam_text_*), all on the device; the text goes to the host -- and ONE writer
+ * thread hands every batch's text to `sink` in order (return 0 to go on) while the workers are on the next ones.  Interleaved pairs:
+ * mem_sort_dedup_patch, mem_mark_primary_se and, for the pairs the mate rescue does not touch, mem_pair and mem_sam_pe's choices on
+ * the device too; the insert-size statistics, the rescue's bookkeeping and the pairs it touches on n_threads host threads in the
+ * middle of the batch.  The host forms take over for an index with ALT contigs (region tail of the reads that touch one, and the
+ * formatter: bmh_format_sam[_pe] in the writer thread) and for a batch the device tail refuses (BMH_ECAPACITY).  The text is what
+ * bmh_format_sam / bmh_format_sam_pe write, byte for byte (records only: the caller writes the @SQ header).
  * cuts: n_batches + 1 read indices, cuts[0] = 0, cuts[n_batches] = n_reads, even batch sizes when paired (the reference cuts its
  * batches by bases, bseq_read src/bwa.c:48-66, and the insert-size statistics are those of a batch).  popt->id0 is ignored (a batch's
  * id0 is its first read).  Reads longer than 700 bases: BMH_EINVAL (the device job builder's limit; such a set goes through

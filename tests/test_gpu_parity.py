@@ -1142,6 +1142,57 @@ def test_native_pipeline_device_text_equals_host_text(hip, tmp_path, pe):
     al.close()
 
 
+@pytest.mark.parametrize("pe", [False, True])
+def test_native_pipeline_edge_reads(hip, tmp_path, pe):
+    """Reads the device forms must not trip over: all-N reads, reads shorter than a seed, lower-case letters, IUPAC codes, a one-read batch, pairs with one or both
+    mates unmappable, names of different lengths: device text == host-formatter text == the batch-after-batch Python loop's text."""
+    import io
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.aligner import Aligner
+    g = synth.make_genome(300_000, seed=4, repeat_frac=0.2)
+    prefix = str(tmp_path / "g.fa")
+    fmindex.write_index(prefix, fmindex.build_fmd_index(g)); fmindex.write_bns(prefix, g, contigs=[("c1", 100_000), ("chrTwo_long_name", 200_000)])
+    rng = np.random.default_rng(3)
+    L = 120
+    base = [synth.codes_to_ascii(g[p:p + L]).tobytes() for p in rng.integers(0, len(g) - L, 40)]
+    seqs = []
+    for i, b in enumerate(base):
+        if i % 8 == 1: b = b"N" * L
+        elif i % 8 == 2: b = b[:12]
+        elif i % 8 == 3: b = b.lower()
+        elif i % 8 == 4: b = b[:30] + b"RYKM" + b[34:]
+        elif i % 8 == 5: b = bytes(rng.choice(list(b"ACGT"), L).tolist())          # random: no hit
+        elif i % 8 == 6: b = b[:60] + b"NNNNN" + b[65:]
+        seqs.append(b)
+    fq = str(tmp_path / "r.fa")
+    with open(fq, "wb") as f:
+        for i, b in enumerate(seqs):
+            name = (b"pair%d" % (i // 2)) if pe else (b"r%d" % i if i % 3 else b"read_with_a_longer_name_%d" % i)
+            f.write(b">" + name + b"\n" + b + b"\n")
+    al = Aligner(prefix, n_threads=2)
+    texts = {}
+    for env, batch in (("", 40), ("", 1 if not pe else 2), ("BMH_ALIGNER_HOST_FORMAT", 40), ("BMH_ALIGNER_NATIVE=0", 40)) + ((("BMH_ALIGNER_PE_HOST", 40),) if pe else ()):
+        key, val = (env.split("=") + ["1"])[:2] if env else ("", "")
+        if key:
+            os.environ[key] = val
+        try:
+            buf = io.BytesIO()
+            al.align_file(fq, buf, batch_reads=batch, paired=pe)
+            texts[(env, batch)] = buf.getvalue()
+        finally:
+            if key:
+                del os.environ[key]
+    body = texts[("", 40)]
+    assert body.count(b"\n") >= len(seqs) and b"\t4\t*\t0\t0\t*" in body or pe
+    for k, t in texts.items():
+        if pe and k == ("", 2):
+            continue                                              # (pairs: another batch size means other insert-size statistics)
+        if t != body:
+            a, b = body.split(b"\n"), t.split(b"\n")
+            assert False, (k, len(a), len(b), [(x, y) for x, y in zip(a, b) if x != y][:2])
+    al.close()
+
+
 def test_aligner_refuses_flanks_beyond_the_extension_kernels(hip, tmp_path):
     """Reads of 1000 bp seeded near one end need a query side longer than the 768 bases the DP kernels take: the aligner must
     raise instead of folding the kernels' INT32_MIN placeholders into regions and SAM (and still aligns 700 bp reads)."""

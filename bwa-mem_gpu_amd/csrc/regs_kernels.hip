@@ -599,14 +599,13 @@ __global__ void __launch_bounds__(64) fin_wave_kernel(fin_args_t A)
 __global__ void __launch_bounds__(256) fin_compact_kernel(const int32_t *__restrict__ work, const uint32_t *__restrict__ in_off, const uint32_t *__restrict__ out_off,
                                                           const uint32_t *__restrict__ opr, uint32_t n_reads, int32_t *__restrict__ out)
 {
-	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	// (sixteen lanes a read, a quarter record each: a lane a read wrote 64 bytes at a time to 64 different places)
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, r = t >> 4, l = t & 15u;
 	if (r >= n_reads) return;
 	const uint32_t n = opr[r], si = in_off[r], so = out_off[r];
-	for (uint32_t k = 0; k < n; ++k) {
-		const int4 *s = (const int4 *)(work + 16 * (size_t)(si + k));
-		int4 *d = (int4 *)(out + 16 * (size_t)(so + k));
-		d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
-	}
+	const int4 *s = (const int4 *)(work + 16 * (size_t)si);
+	int4 *d = (int4 *)(out + 16 * (size_t)so);
+	for (uint32_t q = l; q < 4 * n; q += 16) d[q] = s[q];
 }
 
 // ---- host side: scratch per (device, stream), grown on demand
@@ -819,9 +818,9 @@ static int64_t finalize_regs_device_impl(const bmh_index_t *idx, const bmh_chain
 	if (want_phases) HIPCK(hipEventRecord(ph[2], st));
 	tb = S->scan_bytes;
 	HIPCK(rocprim::exclusive_scan(S->scan_tmp, tb, d_out_per_read, S->out_off, 0u, (size_t)n_reads, rocprim::plus<uint32_t>(), st));
-	fin_compact_kernel<<<(n_reads + 255) / 256, 256, 0, st>>>(S->work, S->in_off, S->out_off, d_out_per_read, n_reads, d_out);
+	fin_compact_kernel<<<(unsigned)(((size_t)n_reads * 16 + 255) / 256), 256, 0, st>>>(S->work, S->in_off, S->out_off, d_out_per_read, n_reads, d_out);
 	if (extra) {
-		if (extra->d_dedup_out) fin_compact_kernel<<<(n_reads + 255) / 256, 256, 0, st>>>(A.dedup_out, S->in_off, S->out_off, d_out_per_read, n_reads, extra->d_dedup_out);
+		if (extra->d_dedup_out) fin_compact_kernel<<<(unsigned)(((size_t)n_reads * 16 + 255) / 256), 256, 0, st>>>(A.dedup_out, S->in_off, S->out_off, d_out_per_read, n_reads, extra->d_dedup_out);
 		if (extra->d_out_off) HIPCK(hipMemcpyAsync(extra->d_out_off, S->out_off, 4 * (size_t)n_reads, hipMemcpyDeviceToDevice, st));
 		extra->d_logtab = S->logtab; extra->n_log = FIN_NLOG; extra->d_ctg_off = n_contigs > 1 ? S->ctg : nullptr;
 	}

@@ -63,13 +63,15 @@ struct msw_res_t { int score, te, qe, score2, te2; };
 // One pass of the striped kernel for the job of this 16-lane group (sw_pass of local_sw.cpp).  All lanes of the wave call it together;
 // `on`: this group has a job.  query position k of the pass = qbase[k * qstep] through qmap (ASCII read, optionally complemented);
 // target row i = trow(i).  xtra as in ksw_align2.
-template <class QF, class TF>
+// BYTE_ALL: every job of the batch runs in byte mode (mates of up to 249 bases at a = 1: the usual case) -- the word-mode arithmetic and the per-lane choice between
+// the two are compiled out of the loops.
+template <bool BYTE_ALL, class QF, class TF>
 __device__ void msw_pass(const msw_args_t &A, const bool on, const int lanes, const int qlen, const int tlen, QF qcode, TF trow, const int xtra,
                          uint16_t *H0, uint16_t *H1, uint16_t *E, uint16_t *Hm, uint8_t *qc, uint8_t *tbuf, uint32_t *blist, msw_res_t &R)
 {
 	const int lane = threadIdx.x & 63, l = lane & 15;
 	const unsigned long long gmask = 0xFFFFull << (lane & 48);
-	const bool byte = lanes == 16;
+	const bool byte = BYTE_ALL ? true : lanes == 16;
 	const bool lact = on && l < lanes;                         // this lane is one of the job's SSE lanes
 	const int slen = on ? (qlen + lanes - 1) / lanes : 0;
 	const int minsc = (xtra & BMH_SW_XSUBO) ? xtra & 0xffff : 0x10000, endsc = (xtra & BMH_SW_XSTOP) ? xtra & 0xffff : 0x10000;
@@ -95,21 +97,26 @@ __device__ void msw_pass(const msw_args_t &A, const bool on, const int lanes, co
 		}
 		const bool run = alive && i < tlen;
 		const int t = tbuf[i & (MSW_TBUF - 1)];
+		// the row's target base against a query code: a match scores a, an N on either side -1, padding (5) nothing -- without branches: teq never equals a
+		// query code when the target base is an N, mis is what a mismatch with THIS target base costs
+		const int teq = t > 3 ? 99 : t, mis = t > 3 ? -1 : -A.b;
 		int hv = msw_shl(run ? (int)h0[(slen > 0 ? slen - 1 : 0) * MSW_ROW + l] : 0, l);
 		int f = 0, mxv = 0;
 		for (int j = 0; j < slen_w; ++j) {
 			if (run && j < slen) {
 				const int q = qc[j * MSW_ROW + l];
-				const int S = q == 5 ? 0 : ((t > 3 || q > 3) ? -1 : (t == q ? A.a : -A.b));
-				int h = byte ? msw_sat0(min(hv + S + shift, 255) - shift) : max(min(hv + S, 32767), -32768);
 				int e = E[j * MSW_ROW + l];
+				const int hnext = h0[j * MSW_ROW + l];                   // (the three loads of the segment in flight together)
+				int S = q == teq ? A.a : mis;
+				S = q > 3 ? (q & 1) - 1 : S;
+				int h = byte ? msw_sat0(min(hv + S + shift, 255) - shift) : max(min(hv + S, 32767), -32768);
 				h = max(h, e); h = max(h, f);
 				mxv = max(mxv, h);
 				h1[j * MSW_ROW + l] = (uint16_t)h;
 				e = max(msw_sat0(e - A.e_del), msw_sat0(h - oe_del));
 				E[j * MSW_ROW + l] = (uint16_t)e;
 				f = max(msw_sat0(f - A.e_ins), msw_sat0(h - oe_ins));
-				hv = h0[j * MSW_ROW + l];
+				hv = hnext;
 			}
 		}
 		// lazy F (ksw.c:497-511, 627-638): at most 16 rounds; a round ends the whole loop at the first segment where no lane's F can still raise H
@@ -183,7 +190,7 @@ __device__ void msw_pass(const msw_args_t &A, const bool on, const int lanes, co
 // so that a wave's four jobs read one row of 64 dwords -- every bank once (with the jobs' columns one after the other all four hit
 // the same banks) -- and `cap`, the longest column of the batch, sizes the block: 12 KB for 150 bp mates instead of 46 KB for the
 // longest the kernel takes, four times the waves per CU for a loop that waits for its LDS round trips.
-__global__ void __launch_bounds__(16 * MSW_JOBS_PER_BLOCK) msw_kernel(msw_args_t A, const int cap)
+template <bool BYTE_ALL> __global__ void __launch_bounds__(16 * MSW_JOBS_PER_BLOCK) msw_kernel(msw_args_t A, const int cap)
 {
 	extern __shared__ __align__(16) uint8_t msw_lds[];
 	__shared__ uint8_t st[MSW_JOBS_PER_BLOCK][MSW_TBUF];
@@ -205,7 +212,7 @@ __global__ void __launch_bounds__(16 * MSW_JOBS_PER_BLOCK) msw_kernel(msw_args_t
 	uint32_t *bl = A.blist + (on ? J.bl_off : 0);
 	uint16_t *sH0 = (uint16_t *)msw_lds + g * 16, *sH1 = sH0 + (size_t)cap * MSW_ROW, *sE = sH1 + (size_t)cap * MSW_ROW, *sHm = sE + (size_t)cap * MSW_ROW;
 	uint8_t *sq = msw_lds + (size_t)cap * MSW_ROW * 8 + g * 16;
-	msw_pass(A, on, lanes, l_ms, tlen, qfwd, tfwd, J.xtra, sH0, sH1, sE, sHm, sq, st[g], bl, R1);
+	msw_pass<BYTE_ALL>(A, on, lanes, l_ms, tlen, qfwd, tfwd, J.xtra, sH0, sH1, sE, sHm, sq, st[g], bl, R1);
 	int tb = -1, qb = -1;
 	const bool second = on && (J.xtra & BMH_SW_XSTART) && !((J.xtra & BMH_SW_XSUBO) && R1.score < (J.xtra & 0xffff));
 	if (__any(second)) {
@@ -215,7 +222,7 @@ __global__ void __launch_bounds__(16 * MSW_JOBS_PER_BLOCK) msw_kernel(msw_args_t
 		auto qrev = [&](int k) { return qfwd(qe - k); };
 		auto trev = [&](int i) { return i <= te ? msw_text(A, rb + (te - i)) : msw_text(A, rb + i); };
 		msw_res_t R2;
-		msw_pass(A, second, lanes, qe + 1, tlen, qrev, trev, BMH_SW_XSTOP | R1.score, sH0, sH1, sE, sHm, sq, st[g], bl, R2);
+		msw_pass<BYTE_ALL>(A, second, lanes, qe + 1, tlen, qrev, trev, BMH_SW_XSTOP | R1.score, sH0, sH1, sE, sHm, sq, st[g], bl, R2);
 		if (second && R1.score == R2.score) { tb = R1.te - R2.te; qb = R1.qe - R2.qe; }
 	}
 	if (on && (threadIdx.x & 15) == 0) {
@@ -274,7 +281,8 @@ extern "C" int bmh_matesw_batch_device(const bmh_index_t *idx, const uint8_t *d_
 	}
 	uint64_t bl = 0;
 	int cap = 1;                                             // the longest lane-private column of the batch, in segments
-	for (uint64_t k = 0; k < n_jobs; ++k) { const int lanes = (jobs[k].xtra & BMH_SW_XBYTE) ? 16 : 8; const int sl = (jobs[k].l_ms + lanes - 1) / lanes; cap = sl > cap ? sl : cap; }
+	bool byte_all = true;
+	for (uint64_t k = 0; k < n_jobs; ++k) { const int lanes = (jobs[k].xtra & BMH_SW_XBYTE) ? 16 : 8; const int sl = (jobs[k].l_ms + lanes - 1) / lanes; cap = sl > cap ? sl : cap; byte_all = byte_all && lanes == 16; }
 	if (cap > MSW_SLEN) { bmh_set_error("bmh_matesw_batch_device: a job the kernel does not take (see bmh_matesw_device_takes)"); return BMH_EINVAL; }
 	for (uint64_t k = 0; k < n_jobs; ++k) { jobs[k].bl_off = (uint32_t)bl; bl += (uint64_t)(jobs[k].re - jobs[k].rb) / 2 + 2; if (bl >> 32) { bmh_set_error("bmh_matesw_batch_device: windows too long"); return BMH_ECAPACITY; } }
 	if (n_jobs > S->cap_jobs) {
@@ -297,7 +305,8 @@ extern "C" int bmh_matesw_batch_device(const bmh_index_t *idx, const uint8_t *d_
 	A.jobs = S->d_jobs; A.n_jobs = (uint32_t)n_jobs; A.reads = d_reads; A.read_offs = d_offs; A.pac = idx->dev.pac; A.l_pac = (long long)idx->dev.l_pac;
 	A.a = ep->a; A.b = ep->b; A.o_del = ep->o_del; A.e_del = ep->e_del; A.o_ins = ep->o_ins; A.e_ins = ep->e_ins;
 	A.blist = S->d_bl; A.out = S->d_out;
-	msw_kernel<<<(unsigned)((n_jobs + MSW_JOBS_PER_BLOCK - 1) / MSW_JOBS_PER_BLOCK), 16 * MSW_JOBS_PER_BLOCK, (size_t)cap * MSW_ROW * 9, st>>>(A, cap);
+	if (byte_all) msw_kernel<true><<<(unsigned)((n_jobs + MSW_JOBS_PER_BLOCK - 1) / MSW_JOBS_PER_BLOCK), 16 * MSW_JOBS_PER_BLOCK, (size_t)cap * MSW_ROW * 9, st>>>(A, cap);
+	else msw_kernel<false><<<(unsigned)((n_jobs + MSW_JOBS_PER_BLOCK - 1) / MSW_JOBS_PER_BLOCK), 16 * MSW_JOBS_PER_BLOCK, (size_t)cap * MSW_ROW * 9, st>>>(A, cap);
 	HIPCK(hipMemcpyAsync(out, S->d_out, sizeof(int32_t) * 7 * n_jobs, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));
 	HIPCK(hipGetLastError());

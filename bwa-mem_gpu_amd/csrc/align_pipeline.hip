@@ -119,7 +119,7 @@ struct lane_t {
 	bmh_chain_ws_t *cws = nullptr; uint32_t cws_reads = 0; uint64_t cws_seeds = 0; uint64_t regs_guess = 0;
 	dbuf_t<uint8_t> d_reads, d_work; dbuf_t<uint32_t> d_offs, d_lens, d_sel, d_opr, d_cigar, d_off, d_packed, d_over, d_sel2; dbuf_t<int32_t> d_out3, d_regs, d_fin, d_aln, d_slot, d_hrec, d_unflag; dbuf_t<char> d_md;
 	dbuf_t<int32_t> d_dedup, d_fin2, d_hrec2, d_unflag2, d_rslot, d_hh, d_ufh, d_finh; dbuf_t<uint32_t> d_roff, d_roff2, d_opr2, d_todo_pairs, d_oprh, d_offh; dbuf_t<uint8_t> d_todo, d_scan;   // pairs on the device
-	hbuf_t<uint8_t> h_todo; std::vector<uint32_t> todo_pairs, offh;
+	hbuf_t<uint8_t> h_todo; std::vector<uint32_t> todo_pairs, offh; void *pair_scratch = nullptr;
 	dbuf_t<uint32_t> d_cg2; dbuf_t<int32_t> d_aln2; dbuf_t<char> d_md2; uint32_t max_read_len = 0;      // the redo of the alignments that overflow the fixed slots
 	dbuf_t<char> d_names, d_text, d_ctg_names; dbuf_t<uint64_t> d_name_off, d_text_off; dbuf_t<uint32_t> d_ctg_name_off; dbuf_t<int64_t> d_ctg_off; bool ctg_up = false;
 	hbuf_t<uint32_t> h_offs, h_sel, h_rpr; hbuf_t<int32_t> h_regs; hbuf_t<float> h_fr; hbuf_t<uint8_t> h_need, h_reads; hbuf_t<char> h_names; hbuf_t<uint64_t> h_name_off;
@@ -130,6 +130,7 @@ struct lane_t {
 		if (cws) bmh_chain_ws_free(cws);
 		if (st) { bmh_extend_release(st); (void)hipStreamDestroy(st); }
 		if (st2) (void)hipStreamDestroy(st2);
+		if (pair_scratch) bmh_pairs_scratch_free(pair_scratch);
 	}
 };
 
@@ -337,7 +338,7 @@ int pairs_on_device(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, co
 	pd_user_t u = {&A, &Ln, &dj, &po, &ex, n};
 	Ln.todo_pairs.resize(n / 2 + 1);
 	bmh_pairs_split_t split; memset(&split, 0, sizeof(split));
-	split.after_pestat = pd_after_pestat; split.before_final = pd_before_final; split.user = &u; split.todo_pairs = Ln.todo_pairs.data();
+	split.after_pestat = pd_after_pestat; split.before_final = pd_before_final; split.user = &u; split.todo_pairs = Ln.todo_pairs.data(); split.scratch_slot = &Ln.pair_scratch;
 	uint64_t cap = (uint64_t)m1 + 2ull * n + 4096;                  // (room for every pair: the pairs the device hands back are the ones with the most records)
 	int64_t mh = BMH_ECAPACITY;
 	RCK(R.opr.need(n + 1)); R.h_rec.resize(n); R.unflag.resize(n);

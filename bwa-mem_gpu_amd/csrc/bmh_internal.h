@@ -66,7 +66,9 @@ struct bmh_pairs_split_t {
 	int (*before_final)(void *user, const uint8_t **extra);
 	void *user;
 	uint32_t *todo_pairs; uint64_t n_todo;
+	void **scratch_slot;            // optional: where the call keeps its large host arrays between calls (NULL at first; bmh_pairs_scratch_free); else the thread's
 };
+void bmh_pairs_scratch_free(void *p);
 int64_t bmh_finalize_pairs_split(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream,
                                  const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe,
                                  int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads, const uint64_t *read_offs,

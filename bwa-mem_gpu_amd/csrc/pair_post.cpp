@@ -478,7 +478,9 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 	PCtx c;
 	c.x = {copt, ep, popt, l_pac, pac, n_contigs, contig_offset};
 	c.pe = pe; c.ctg_off = contig_offset; c.ctg_len = contig_len; c.reads = reads; c.offs = read_offs; c.lens = read_lens;
-	PairScratch &S = g_pair_scratch;
+	// (a caller that outlives its threads -- the lanes of bmh_aligner_run -- keeps the scratch itself: split->scratch_slot)
+	if (split && split->scratch_slot && !*split->scratch_slot) *split->scratch_slot = new PairScratch();
+	PairScratch &S = (split && split->scratch_slot) ? *(PairScratch *)*split->scratch_slot : g_pair_scratch;
 	std::vector<uint64_t> &in_off = S.in_off;
 	in_off.assign((size_t)n_reads + 1, 0);
 	for (uint32_t r = 0; r < n_reads; ++r) in_off[r + 1] = in_off[r] + regs_per_read[r];
@@ -699,3 +701,5 @@ int64_t bmh_finalize_pairs_split(const bmh_index_t *idx, const uint8_t *d_reads,
 	return finalize_pairs_impl(copt, ep, popt, pe, l_pac, pac, n_reads, reads, read_offs, read_lens, dedup_recs, dedup_per_read, frac_rep, n_contigs, contig_offset, contig_len,
 	                           out, cap, out_per_read, out_h, out_unflag, nullptr, n_threads, idx, d_reads, d_offs, stream, true, split);
 }
+
+void bmh_pairs_scratch_free(void *p) { delete (PairScratch *)p; }

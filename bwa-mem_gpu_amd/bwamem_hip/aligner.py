@@ -399,14 +399,44 @@ class Aligner:
                          h_rec=h_rec, unflag=unflag, as_bytes=self._as_bytes)
         return txt
 
+    def _native_aligner(self):
+        """the bmh_aligner_t of this aligner's index and options (made again when set_options changed them)"""
+        from .lib import NativeAligner
+        nat = getattr(self, "_native", None)
+        opts = (bytes(self.copt), bytes(self.ep), bytes(self.po), bytes(self.pe))
+        if nat is not None and nat.options != opts:
+            nat.free(); nat = None
+        if nat is None:
+            nat = self._native = NativeAligner(self.index, self.pac, self.l_pac, self.contigs, self.alt if self.has_alt else None, self.copt, self.ep, self.po, self.pe)
+        return nat
+
     def align_file(self, reads_fa: str, out, batch_reads: int = 0, paired: bool = False, chunk_bases: int = 0) -> int:
         """out: a text or binary file object.  Batches are cut the way the reference's bseq_read cuts them (src/bwa.c, called with
         chunk_size * n_threads = 10 Mbases per thread, or -K, src/fastmap.c:527): reads are added until the batch holds at least
         chunk_bases bases and an even number of reads -- in paired mode the insert-size statistics are those of the batch, so the
         cut decides flags and MAPQ of borderline pairs.  chunk_bases 0: 10 000 000 x the thread count given with -t (1).
         batch_reads > 0 cuts by read count instead (the earlier behaviour)."""
-        rs = read_fasta_reads(reads_fa)
         binary = "b" in getattr(out, "mode", "") or hasattr(out, "getbuffer")
+        # The file batch by batch through bmh_aligner_run_fasta (a loader thread cuts and fills batch k+1 .. while the lanes are on batch k: nothing of the file is
+        # held beyond the batches in flight), when every read fits the device job builder (bmh_fasta_scan: one counting pass); BMH_ALIGNER_STREAM=0: load the
+        # whole file first (below).
+        if os.environ.get("BMH_ALIGNER_NATIVE", "1") != "0" and os.environ.get("BMH_ALIGNER_STREAM", "1") != "0" and not self.profile:
+            from .lib import NativeAligner, fasta_scan
+            info = fasta_scan(reads_fa)
+            if info["n_reads"] and info["max_len"] <= 700:
+                out.write(self.header().encode() if binary else self.header())
+                cb = 0
+                if batch_reads <= 0:
+                    cb = chunk_bases or int(getattr(self, "ref_chunk_bases", 0)) or 10_000_000 * max(1, int(getattr(self, "ref_threads", 1)))
+                    if not paired and not chunk_bases:
+                        cb = max(cb, 150_000_000)             # (single-end records do not depend on the cuts: see below)
+                    cb = min(cb, (1 << 31) - 1024)
+                nat = self._native_aligner()
+                self.last_stats = nat.run_fasta(reads_fa, paired, (lambda mv: out.write(mv)) if binary else (lambda mv: out.write(bytes(mv).decode())),
+                                                batch_bases=cb, batch_reads=max(batch_reads, 0),
+                                                n_lanes=int(os.environ.get("BMH_ALIGNER_LANES", "3" if paired else "2")), n_threads=self.n_threads)
+                return info["n_reads"]
+        rs = read_fasta_reads(reads_fa)
         out.write(self.header().encode() if binary else self.header())
         n = len(rs)
         if batch_reads > 0:
@@ -432,13 +462,7 @@ class Aligner:
         # k+1, k+2 are on the device) takes every read set whose reads fit the device job builder; BMH_ALIGNER_NATIVE=0 keeps the
         # batch-after-batch Python loop below (the same stages through the same entry points: the cross-check of the native one).
         if n and os.environ.get("BMH_ALIGNER_NATIVE", "1") != "0" and rs.codes is not None and int(rs.lens.max()) <= 700 and not self.profile:
-            from .lib import NativeAligner
-            nat = getattr(self, "_native", None)
-            opts = (bytes(self.copt), bytes(self.ep), bytes(self.po), bytes(self.pe))
-            if nat is not None and nat.options != opts:          # (set_options since the last run)
-                nat.free(); nat = None
-            if nat is None:
-                nat = self._native = NativeAligner(self.index, self.pac, self.l_pac, self.contigs, self.alt if self.has_alt else None, self.copt, self.ep, self.po, self.pe)
+            nat = self._native_aligner()
             self.last_stats = nat.run(rs, cuts, paired, (lambda mv: out.write(mv)) if binary else (lambda mv: out.write(bytes(mv).decode())),
                                       n_lanes=int(os.environ.get("BMH_ALIGNER_LANES", "3" if paired else "2")), n_threads=self.n_threads)   # (pairs: a lane waits for host walks in the middle of its batch)
             return n

@@ -27,12 +27,12 @@ EXPORTED_SYMBOLS = [
     "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_finalize_regs_device", "bmh_finalize_regs_device_last_ms", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
     "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_finalize_pairs_dev", "bmh_dedup_regs_device", "bmh_finalize_pairs_deduped", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
     "bmh_chain_opt_default", "bmh_chain_last_timing", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
-    "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_alt", "bmh_effective_cpus", "bmh_aligner_create", "bmh_aligner_free", "bmh_aligner_run", "bmh_chain_set_materialize", "bmh_chain_batch",
+    "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_alt", "bmh_effective_cpus", "bmh_aligner_create", "bmh_aligner_free", "bmh_aligner_run", "bmh_aligner_run_fasta", "bmh_chain_set_materialize", "bmh_chain_batch",
     "bmh_chain_extend", "bmh_chain_merge", "bmh_chain_extend_merge", "bmh_chain_extend_merge_timing", "bmh_cigar_batch", "bmh_cigar_release",
     "bmh_sam_select_work", "bmh_sam_select_device", "bmh_cigar_pack_work", "bmh_cigar_pack_sizes", "bmh_cigar_pack", "bmh_sam_text_work", "bmh_sam_text_sizes", "bmh_sam_text_write", "bmh_sam_text_check",
     "bwt_destroy_gpu", "bwt_restore_sa_gpu", "bwt_restore_bwt_gpu", "gpu_cpy_wrapper",
     "pre_calc_seed_intervals_wrapper", "free_gpuseed_data", "seed_gpu", "seed_gpu_last_n_reads",
-    "bmh_reads_load_fasta", "bmh_reads_free",
+    "bmh_reads_load_fasta", "bmh_reads_free", "bmh_fasta_scan",
 ]
 
 
@@ -61,6 +61,18 @@ class _ReadSetOwner:
             self.L.bmh_reads_free(C.byref(self.rs))
         except Exception:
             pass
+
+
+def fasta_scan(path: str, n_threads: int = 0) -> dict:
+    """bmh_fasta_scan: reads / bases / name bytes / longest read of a read file, from one counting pass (nothing is loaded)"""
+    L = load_library()
+    L.bmh_fasta_scan.restype = C.c_int
+    L.bmh_fasta_scan.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint64)]
+    out = (C.c_uint64 * 4)()
+    rc = L.bmh_fasta_scan(path.encode(), n_threads, out)
+    if rc != 0:
+        raise RuntimeError(f"bmh_fasta_scan rc={rc}: " + _err(L))
+    return dict(n_reads=int(out[0]), n_bases=int(out[1]), n_name_bytes=int(out[2]), max_len=int(out[3]))
 
 
 def load_fasta_reads(path: str, n_threads: int = 0) -> dict:
@@ -142,6 +154,30 @@ class NativeAligner:
             raise err[0]
         if rc != 0:
             raise (CapacityError if rc == -3 else RuntimeError)(f"bmh_aligner_run rc={rc}: " + _err(L))
+        return st
+
+    def run_fasta(self, path: str, paired: bool, write, batch_bases: int = 0, batch_reads: int = 0, n_lanes: int = 2, n_threads: int = 0) -> "AlignStats":
+        """bmh_aligner_run_fasta: the read file `path` batch by batch (cut by bases like the reference's bseq_read, or by reads), a loader thread ahead of the
+        lanes; write(memoryview) receives every batch's SAM records in order"""
+        L = load_library()
+        L.bmh_aligner_run_fasta.restype = C.c_int
+        L.bmh_aligner_run_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, SAM_SINK, C.c_void_p, C.POINTER(AlignStats)]
+        err = []
+
+        def sink(_user, ptr, n):
+            try:
+                write(memoryview((C.c_char * n).from_address(ptr)))
+                return 0
+            except BaseException as e:                      # noqa: BLE001 -- reported after the run (an exception must not cross the C frames)
+                err.append(e)
+                return 1
+        cb = SAM_SINK(sink)
+        st = AlignStats()
+        rc = L.bmh_aligner_run_fasta(self.handle, path.encode(), int(batch_bases), int(batch_reads), 1 if paired else 0, int(n_lanes), int(n_threads), cb, None, C.byref(st))
+        if err:
+            raise err[0]
+        if rc != 0:
+            raise (CapacityError if rc == -3 else RuntimeError)(f"bmh_aligner_run_fasta rc={rc}: " + _err(L))
         return st
 
     def free(self):

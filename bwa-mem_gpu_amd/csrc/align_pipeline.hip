@@ -15,6 +15,11 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -106,6 +111,7 @@ template <class T> struct hbuf_t {
 // of records and 190 MB of CIGAR / MD arrays: every extra pass over them on one thread costs what a device stage costs).
 struct result_t {
 	uint32_t b0 = 0, n = 0; uint64_t m = 0, n_sel = 0;
+	const bmh_read_set_t *rs = nullptr; int64_t id0 = 0; void *token = nullptr;      // the read set the batch [b0, b0 + n) lies in, the index of its first read in the run, the source's handle
 	hbuf_t<int32_t> fin, aln, slot32; hbuf_t<uint32_t> opr, off, packed;
 	hbuf_t<char> text; uint64_t text_len = 0; bool has_text = false;     // the text written on the device (no formatting on the host)
 	std::vector<int64_t> slot;                   // (host selection only; empty: slot32)
@@ -392,10 +398,11 @@ int pairs_on_device(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, co
 }
 
 // one batch [b0, b1) of the read set on lane Ln -> R
-int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t b0, uint32_t b1, bool paired, int n_threads, result_t &R)
+// id0: index of the batch's first read in the run (the tie-break hash of mem_mark_primary_se takes it); src_pinned: rs.ascii is pinned host memory (no staging copy)
+int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t b0, uint32_t b1, int64_t id0, bool src_pinned, bool paired, int n_threads, result_t &R)
 {
 	const uint32_t n = b1 - b0;
-	R.b0 = b0; R.n = n;
+	R.b0 = b0; R.n = n; R.rs = &rs; R.id0 = id0;
 	R.dev_index.clear();
 	const uint64_t a0 = rs.offs[b0], a1 = rs.offs[b1 - 1] + rs.lens[b1 - 1], nb = a1 - a0;
 	if (nb >> 31) { bmh_set_error("bmh_aligner_run: a batch holds 2^31 bases or more (offsets inside a batch are 32-bit)"); return BMH_EINVAL; }
@@ -404,9 +411,12 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 	RCK(Ln.d_reads.need(nb + 16)); RCK(Ln.d_offs.need(n + 1)); RCK(Ln.d_lens.need(n + 1)); RCK(Ln.h_offs.need(n + 1));
 	Ln.max_read_len = 0;
 	for (uint32_t r = 0; r < n; ++r) { Ln.h_offs.p[r] = (uint32_t)(rs.offs[b0 + r] - a0); if (rs.lens[b0 + r] > Ln.max_read_len) Ln.max_read_len = rs.lens[b0 + r]; }
-	RCK(Ln.h_reads.need(nb + 16));
-	par_memcpy(Ln.h_reads.p, rs.ascii + a0, nb, n_threads);           // (pageable -> pinned by this lane's threads, then one DMA: the lanes stage side by side)
-	LCK(hipMemcpyAsync(Ln.d_reads.p, Ln.h_reads.p, nb, hipMemcpyHostToDevice, Ln.st));
+	if (src_pinned) LCK(hipMemcpyAsync(Ln.d_reads.p, rs.ascii + a0, nb, hipMemcpyHostToDevice, Ln.st));       // (a batch of a read file: filled into pinned memory by the loader)
+	else {
+		RCK(Ln.h_reads.need(nb + 16));
+		par_memcpy(Ln.h_reads.p, rs.ascii + a0, nb, n_threads);       // (pageable -> pinned by this lane's threads, then one DMA: the lanes stage side by side)
+		LCK(hipMemcpyAsync(Ln.d_reads.p, Ln.h_reads.p, nb, hipMemcpyHostToDevice, Ln.st));
+	}
 	LCK(hipMemcpyAsync(Ln.d_offs.p, Ln.h_offs.p, 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
 	LCK(hipMemcpyAsync(Ln.d_lens.p, rs.lens + b0, 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
 	// the text is written on the device (bmh_sam_text_*) unless the index has ALT contigs (their tags are the host formatter's): the names go along
@@ -471,7 +481,7 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 	}
 	const uint64_t nr = dj.n_regs;
 	double t3 = now_s(); Ln.t[2] += t3 - t2;
-	bmh_post_opt_t po = A.po; po.id0 = (int64_t)b0;
+	bmh_post_opt_t po = A.po; po.id0 = id0;
 	const uint8_t *codes = rs.codes + a0;
 	std::vector<uint64_t> offs64;                                   // offsets relative to the batch, for the host forms
 	auto host_offs = [&]() { if (offs64.empty()) { offs64.resize(n); for (uint32_t r = 0; r < n; ++r) offs64[r] = rs.offs[b0 + r] - a0; } return offs64.data(); };
@@ -615,7 +625,15 @@ extern "C" {
 
 // (lanes and result objects stay with the aligner between runs: their workspaces and pinned buffers -- gigabytes for million-read batches
 // -- cost more to allocate than a batch costs to align)
+namespace {
+struct fbatch_t {
+	hbuf_t<uint8_t> ascii, codes, names; hbuf_t<uint64_t> offs, name_offs; hbuf_t<uint32_t> lens;
+	bmh_read_set_t rs; uint32_t index = 0; int64_t id0 = 0;
+};
+}
+
 struct bmh_aligner {
+	std::vector<std::unique_ptr<fbatch_t>> fbatches;      // batch buffers of bmh_aligner_run_fasta (pinned host memory), kept between runs
 	aligner_t a;
 	std::vector<std::unique_ptr<lane_t>> lanes;
 	std::vector<std::unique_ptr<result_t>> pool; int n_results = 0;
@@ -649,45 +667,43 @@ void bmh_aligner_free(bmh_aligner_t *h)
 	if (!h) return;
 	int prev = 0;
 	const bool sw = h->dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != h->dev && hipSetDevice(h->dev) == hipSuccess;
-	h->lanes.clear(); h->pool.clear();                 // (device and pinned buffers, streams: released on their device)
+	h->lanes.clear(); h->pool.clear(); h->fbatches.clear();                 // (device and pinned buffers, streams: released on their device)
 	if (sw) (void)hipSetDevice(prev);
 	delete h;
 }
 
-int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *cuts, uint32_t n_batches, int paired, int n_lanes, int n_threads,
-                    bmh_sam_sink_t sink, void *user, bmh_align_stats_t *stats)
+// where the batches of a run come from: a read set in host memory cut at given places, or a read file cut and filled by a loader thread
+struct batch_t { uint32_t index = 0; const bmh_read_set_t *rs = nullptr; uint32_t b0 = 0, b1 = 0; int64_t id0 = 0; bool pinned = false; void *token = nullptr; };
+struct batch_src_t {
+	std::function<int(batch_t &)> next;               // 1: a batch (in index order over the callers), 0: no more, < 0: an error (message set); thread-safe, may block
+	std::function<void(void *)> release;              // the text of the batch with this token has been written
+	std::function<void()> stop;                       // the run failed: stop producing, unblock next()
+};
+
+static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int paired, int n_lanes, int n_threads, bmh_sam_sink_t sink, void *user, bmh_align_stats_t *stats)
 {
-	if (!h || !rs || !cuts || !sink) { bmh_set_error("bmh_aligner_run: null argument"); return BMH_EINVAL; }
 	const aligner_t &A = h->a;
-	if (stats) memset(stats, 0, sizeof(*stats));
-	if (n_batches == 0 || rs->n_reads == 0) return BMH_OK;
-	if (cuts[0] != 0 || cuts[n_batches] != rs->n_reads) { bmh_set_error("bmh_aligner_run: cuts[0] = 0 and cuts[n_batches] = n_reads are required"); return BMH_EINVAL; }
-	for (uint32_t b = 0; b < n_batches; ++b)
-		if (cuts[b + 1] < cuts[b] || (paired && ((cuts[b + 1] - cuts[b]) & 1)) || cuts[b + 1] - cuts[b] > 0xFFFFFFF0ull) { bmh_set_error("bmh_aligner_run: bad batch cuts"); return BMH_EINVAL; }
-	for (uint64_t r = 0; r < rs->n_reads; ++r)
-		if (rs->lens[r] > 700) { bmh_set_error("bmh_aligner_run: read %llu has %u bases: reads beyond 700 go through the host job builder (bmh_build_jobs)", (unsigned long long)r, rs->lens[r]); return BMH_EINVAL; }
 	if (n_lanes < 1) n_lanes = 1;
-	if ((uint32_t)n_lanes > n_batches) n_lanes = (int)n_batches;
 	if (n_threads < 1) n_threads = bmh_effective_cpus();
 	int dev = 0;
-	if (hipGetDevice(&dev) != hipSuccess) { bmh_set_error("bmh_aligner_run: no HIP device"); return BMH_ENODEV; }
+	if (hipGetDevice(&dev) != hipSuccess) { bmh_set_error("%s: no HIP device", fn); return BMH_ENODEV; }
 	const double t_start = now_s();
 	const bool trace = getenv("BMH_ALIGNER_TRACE") != nullptr;        // per-batch timeline on stderr
 	std::mutex mu; std::condition_variable cv;
 	std::map<uint32_t, std::unique_ptr<result_t>> done;             // finished batches waiting for their turn at the writer
 	std::vector<std::unique_ptr<result_t>> &pool = h->pool;         // result objects (pinned buffers) not in use: at most n_lanes + 2 exist
 	int &n_results = h->n_results;
-	std::atomic<uint32_t> next_batch{0};
-	uint32_t next_write = 0;                                        // (guarded by mu)
+	uint32_t next_write = 0, n_taken = 0; bool src_done = false;    // (guarded by mu)
+	uint64_t n_reads_total = 0;
 	int first_rc = BMH_OK; std::string first_err;
-	auto fail = [&](int rc, const char *msg) { std::lock_guard<std::mutex> lk(mu); if (first_rc == BMH_OK) { first_rc = rc; first_err = msg ? msg : ""; } cv.notify_all(); };
+	auto fail = [&](int rc, const char *msg) { { std::lock_guard<std::mutex> lk(mu); if (first_rc == BMH_OK) { first_rc = rc; first_err = msg ? msg : ""; } cv.notify_all(); } if (src.stop) src.stop(); };
 	std::vector<double> lane_t_sum(8, 0.0);
-	if (h->dev >= 0 && h->dev != dev) { bmh_set_error("bmh_aligner_run: the aligner's lanes live on device %d, the current device is %d", h->dev, dev); return BMH_EINVAL; }
+	if (h->dev >= 0 && h->dev != dev) { bmh_set_error("%s: the aligner's lanes live on device %d, the current device is %d", fn, h->dev, dev); return BMH_EINVAL; }
 	h->dev = dev;
 	while ((int)h->lanes.size() < n_lanes) {
 		std::unique_ptr<lane_t> ln(new lane_t());
 		if (hipStreamCreateWithFlags(&ln->st, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ln->st2, hipStreamNonBlocking) != hipSuccess) {
-			bmh_set_error("bmh_aligner_run: hipStreamCreate: %s", hipGetErrorString(hipGetLastError())); return BMH_ENODEV;
+			bmh_set_error("%s: hipStreamCreate: %s", fn, hipGetErrorString(hipGetLastError())); return BMH_ENODEV;
 		}
 		h->lanes.push_back(std::move(ln));
 	}
@@ -696,24 +712,29 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 		if (hipSetDevice(dev) != hipSuccess) { fail(BMH_ENODEV, "hipSetDevice failed in a worker thread"); return; }
 		lane_t &Ln = *h->lanes[(size_t)lane_index];
 		for (;;) {
-			const uint32_t b = next_batch.fetch_add(1);
-			if (b >= n_batches) break;
+			batch_t bt;
+			const int got = src.next(bt);
+			if (got < 0) { fail(got, bmh_last_error()); break; }
+			if (got == 0) { std::lock_guard<std::mutex> lk(mu); src_done = true; cv.notify_all(); break; }
+			const uint32_t b = bt.index;
 			std::unique_ptr<result_t> R;
-			{   // a result object from the pool: no more than n_lanes + 2 batches are ahead of the writer (their records and CIGARs are hundreds
-				// of megabytes each); the batch the writer waits for always gets one
+			{   // a result object from the pool: no more than n_lanes + 2 batches are ahead of the writer (their text is hundreds of megabytes each); the
+				// batch the writer waits for always gets one
 				std::unique_lock<std::mutex> lk(mu);
+				if (b + 1 > n_taken) n_taken = b + 1;
+				n_reads_total += bt.b1 - bt.b0;
 				cv.wait(lk, [&] { return first_rc != BMH_OK || !pool.empty() || n_results < n_lanes + 2 || b == next_write; });
-				if (first_rc != BMH_OK) break;
+				if (first_rc != BMH_OK) { if (src.release) src.release(bt.token); break; }
 				if (!pool.empty()) { R = std::move(pool.back()); pool.pop_back(); }
 				else { R.reset(new result_t()); ++n_results; }
 			}
-			const uint32_t b0 = (uint32_t)cuts[b], b1 = (uint32_t)cuts[b + 1];
+			R->token = bt.token;
 			int rc = BMH_OK;
 			const double tb0 = now_s();
-			if (b1 > b0) rc = run_batch(A, Ln, *rs, b0, b1, paired != 0, n_threads, *R);
-			else { R->b0 = b0; R->n = 0; }
+			if (bt.b1 > bt.b0) rc = run_batch(A, Ln, *bt.rs, bt.b0, bt.b1, bt.id0, bt.pinned, paired != 0, n_threads, *R);
+			else { R->b0 = bt.b0; R->n = 0; R->rs = bt.rs; R->id0 = bt.id0; R->has_text = false; }
 			if (trace) fprintf(stderr, "[aligner] lane %d batch %u: %.1f .. %.1f ms\n", lane_index, b, (tb0 - t_start) * 1e3, (now_s() - t_start) * 1e3);
-			if (rc != BMH_OK) { fail(rc, bmh_last_error()); break; }
+			if (rc != BMH_OK) { if (src.release) src.release(bt.token); fail(rc, bmh_last_error()); break; }
 			std::lock_guard<std::mutex> lk(mu);
 			done[b] = std::move(R);
 			cv.notify_all();
@@ -721,25 +742,26 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 		std::lock_guard<std::mutex> lk(mu);
 		for (int k = 0; k < 8; ++k) lane_t_sum[(size_t)k] += Ln.t[k];
 	};
-	double t_format = 0.0; uint64_t n_bytes = 0;
+	double t_format = 0.0; uint64_t n_bytes = 0; uint32_t n_written = 0;
 	auto writer = [&]() {
 		std::vector<std::string> &parts = h->parts;                  // (kept with the aligner: their capacity is the text of a batch)
-		for (uint32_t b = 0; b < n_batches; ++b) {
+		for (uint32_t b = 0;; ++b) {
 			std::unique_ptr<result_t> R;
 			{
 				std::unique_lock<std::mutex> lk(mu);
-				cv.wait(lk, [&] { return first_rc != BMH_OK || done.count(b); });
+				cv.wait(lk, [&] { return first_rc != BMH_OK || done.count(b) || (src_done && b >= n_taken); });
 				if (first_rc != BMH_OK) return;
+				if (!done.count(b)) return;                             // (every batch written)
 				R = std::move(done[b]); done.erase(b);
 			}
+			const bmh_read_set_t *rs = R->rs;
 			if (R->n && R->has_text) {                               // written on the device: nothing to format
 				const double ts0 = now_s();
 				if (R->text_len) { if (sink(user, R->text.p, (size_t)R->text_len) != 0) { fail(BMH_EINVAL, "the sink refused the text"); return; } n_bytes += R->text_len; }
 				if (trace) fprintf(stderr, "[aligner] writer batch %u: text of the device, sink %.1f .. %.1f ms\n", b, (ts0 - t_start) * 1e3, (now_s() - t_start) * 1e3);
 			} else if (R->n) {
 				const double t0 = now_s();
-				bmh_post_opt_t po = A.po; po.id0 = (int64_t)R->b0;
-				size_t len = 0;
+				bmh_post_opt_t po = A.po; po.id0 = R->id0;
 				const uint64_t a0 = rs->offs[R->b0];
 				std::vector<uint64_t> offs64(R->n), noff(R->n);
 				const uint64_t n0 = rs->name_offs[R->b0];
@@ -760,8 +782,10 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 				}
 				if (trace) fprintf(stderr, "[aligner] writer batch %u: format %.1f .. %.1f ms, sink .. %.1f\n", b, (t0 - t_start) * 1e3, (ts0 - t_start) * 1e3, (now_s() - t_start) * 1e3);
 			}
+			if (src.release) src.release(R->token);
+			R->token = nullptr; R->rs = nullptr;
 			std::lock_guard<std::mutex> lk(mu);
-			next_write = b + 1;
+			next_write = b + 1; ++n_written;
 			pool.push_back(std::move(R));
 			cv.notify_all();
 		}
@@ -773,15 +797,133 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 		for (auto &t : th) t.join();
 		wt.join();
 	}
+	if (src.release) for (auto &kv : done) if (kv.second) src.release(kv.second->token);       // (a failed run: what was waiting for the writer)
 	n_results = (int)pool.size();                                   // (after a failed run the results that were in flight are gone)
 	if (first_rc != BMH_OK) { bmh_set_error("%s", first_err.c_str()); return first_rc; }
 	if (stats) {
-		stats->n_reads = rs->n_reads; stats->n_bytes = n_bytes; stats->n_batches = n_batches; stats->n_lanes = n_lanes;
+		stats->n_reads = n_reads_total; stats->n_bytes = n_bytes; stats->n_batches = n_written; stats->n_lanes = n_lanes;
 		stats->seconds = now_s() - t_start; stats->format_seconds = t_format;
 		stats->h2d_seconds = lane_t_sum[0]; stats->seed_seconds = lane_t_sum[1]; stats->chain_extend_seconds = lane_t_sum[2]; stats->tail_seconds = lane_t_sum[3];
 		stats->select_seconds = lane_t_sum[4]; stats->cigar_seconds = lane_t_sum[5];
 	}
 	return BMH_OK;
+}
+
+int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *cuts, uint32_t n_batches, int paired, int n_lanes, int n_threads,
+                    bmh_sam_sink_t sink, void *user, bmh_align_stats_t *stats)
+{
+	if (!h || !rs || !cuts || !sink) { bmh_set_error("bmh_aligner_run: null argument"); return BMH_EINVAL; }
+	if (stats) memset(stats, 0, sizeof(*stats));
+	if (n_batches == 0 || rs->n_reads == 0) return BMH_OK;
+	if (cuts[0] != 0 || cuts[n_batches] != rs->n_reads) { bmh_set_error("bmh_aligner_run: cuts[0] = 0 and cuts[n_batches] = n_reads are required"); return BMH_EINVAL; }
+	for (uint32_t b = 0; b < n_batches; ++b)
+		if (cuts[b + 1] < cuts[b] || (paired && ((cuts[b + 1] - cuts[b]) & 1)) || cuts[b + 1] - cuts[b] > 0xFFFFFFF0ull) { bmh_set_error("bmh_aligner_run: bad batch cuts"); return BMH_EINVAL; }
+	for (uint64_t r = 0; r < rs->n_reads; ++r)
+		if (rs->lens[r] > 700) { bmh_set_error("bmh_aligner_run: read %llu has %u bases: reads beyond 700 go through the host job builder (bmh_build_jobs)", (unsigned long long)r, rs->lens[r]); return BMH_EINVAL; }
+	if ((uint32_t)n_lanes > n_batches) n_lanes = (int)n_batches;
+	std::atomic<uint32_t> next_batch{0};
+	batch_src_t src;
+	src.next = [&](batch_t &bt) {
+		const uint32_t b = next_batch.fetch_add(1);
+		if (b >= n_batches) return 0;
+		bt.index = b; bt.rs = rs; bt.b0 = (uint32_t)cuts[b]; bt.b1 = (uint32_t)cuts[b + 1]; bt.id0 = (int64_t)cuts[b]; bt.pinned = false; bt.token = nullptr;
+		return 1;
+	};
+	return run_core(h, src, "bmh_aligner_run", paired, n_lanes, n_threads, sink, user, stats);
+}
+
+// ---- the same from a read FILE, batch by batch: a loader thread cuts the mapped file the way the reference's bseq_read cuts its stream (reads are added until the
+// batch holds at least batch_bases bases -- or exactly batch_reads reads if that is not 0 -- and, paired, an even number of reads; src/bwa.c:48-66) and fills every
+// batch into pinned host memory (csrc/reads_io.cpp: bmh_fasta_cut / bmh_fasta_fill, on host threads) while the lanes are on the batches before it: the letters go to
+// the device straight from there, nothing of the file is held beyond the batches in flight (n_lanes + 3 of them).
+
+int bmh_aligner_run_fasta(bmh_aligner_t *h, const char *path, uint64_t batch_bases, uint64_t batch_reads, int paired, int n_lanes, int n_threads,
+                          bmh_sam_sink_t sink, void *user, bmh_align_stats_t *stats)
+{
+	if (!h || !path || !sink) { bmh_set_error("bmh_aligner_run_fasta: null argument"); return BMH_EINVAL; }
+	if (stats) memset(stats, 0, sizeof(*stats));
+	if (batch_bases == 0 && batch_reads == 0) { bmh_set_error("bmh_aligner_run_fasta: batch_bases or batch_reads must be given"); return BMH_EINVAL; }
+	if (batch_bases >= (1ull << 31) - 4096) batch_bases = (1ull << 31) - 4096;      // offsets inside a batch are 32-bit
+	if (paired && (batch_reads & 1)) --batch_reads;
+	if (n_lanes < 1) n_lanes = 1;
+	if (n_threads < 1) n_threads = bmh_effective_cpus();
+	const int fd = open(path, O_RDONLY);
+	if (fd < 0) { bmh_set_error("bmh_aligner_run_fasta: cannot open %s", path); return BMH_EINVAL; }
+	struct stat sb;
+	if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { close(fd); bmh_set_error("bmh_aligner_run_fasta: %s is not a regular, seekable file", path); return BMH_EINVAL; }
+	const size_t sz = (size_t)sb.st_size;
+	if (sz == 0) { close(fd); return BMH_OK; }
+	void *m = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
+	close(fd);
+	if (m == MAP_FAILED) { bmh_set_error("bmh_aligner_run_fasta: cannot map %s (%zu bytes)", path, sz); return BMH_ENOMEM; }
+	(void)madvise(m, sz, MADV_SEQUENTIAL);
+	const uint8_t *buf = (const uint8_t *)m;
+	const bool need_codes = true;        // nt4 codes: every host form reads them (pairs' walks, ALT reads, a batch the device tail refuses, the host formatter)
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) { (void)munmap(m, sz); bmh_set_error("bmh_aligner_run_fasta: no HIP device"); return BMH_ENODEV; }
+	// the loader: batches in file order into `ready`; at most n_lanes + 3 batch buffers exist
+	std::mutex qm; std::condition_variable qcv;
+	std::vector<std::unique_ptr<fbatch_t>> &all = h->fbatches; std::vector<fbatch_t *> free_list; std::map<uint32_t, fbatch_t *> ready;
+	for (auto &fb : all) free_list.push_back(fb.get());
+	uint32_t next_out = 0; bool eof = false, stopped = false; int load_rc = BMH_OK; std::string load_err;
+	const int max_batches = n_lanes + 3;
+	const int load_threads = n_threads < 8 ? n_threads : 8;
+	auto loader = [&]() {
+		if (hipSetDevice(dev) != hipSuccess) { std::lock_guard<std::mutex> lk(qm); load_rc = BMH_ENODEV; load_err = "hipSetDevice failed in the loader thread"; eof = true; qcv.notify_all(); return; }
+		size_t p = 0, est = 0; uint32_t index = 0; int64_t id0 = 0;
+		while (p < sz) {
+			fbatch_t *fb = nullptr;
+			{
+				std::unique_lock<std::mutex> lk(qm);
+				qcv.wait(lk, [&] { return stopped || !free_list.empty() || (int)all.size() < max_batches; });
+				if (stopped) break;
+				if (!free_list.empty()) { fb = free_list.back(); free_list.pop_back(); }
+				else { all.emplace_back(new fbatch_t()); fb = all.back().get(); }
+			}
+			size_t end = sz; uint64_t nr = 0, nb = 0, nn = 0;
+			int rc = bmh_fasta_cut(buf, sz, p, batch_bases, batch_reads, /* even counts, as bseq_read ends its batches */ batch_reads == 0, load_threads, est, &end, &nr, &nb, &nn);
+			if (rc == BMH_OK && paired && (nr & 1)) { bmh_set_error("bmh_aligner_run_fasta: an odd number of reads in a paired file"); rc = BMH_EINVAL; }
+			if (rc == BMH_OK && (nb >> 31)) { bmh_set_error("bmh_aligner_run_fasta: a batch holds 2^31 bases or more"); rc = BMH_EINVAL; }
+			if (rc == BMH_OK && nr) {
+				if (fb->ascii.need(nb + 16) != BMH_OK || (need_codes && fb->codes.need(nb + 16) != BMH_OK) || fb->names.need(nn + 16) != BMH_OK || fb->offs.need(nr + 2) != BMH_OK ||
+				    fb->name_offs.need(nr + 2) != BMH_OK || fb->lens.need(nr + 2) != BMH_OK) rc = BMH_ENOMEM;
+			}
+			if (rc == BMH_OK && nr) {
+				memset(&fb->rs, 0, sizeof(fb->rs));
+				fb->rs.ascii = fb->ascii.p; fb->rs.codes = need_codes ? fb->codes.p : nullptr; fb->rs.names = fb->names.p; fb->rs.offs = fb->offs.p; fb->rs.name_offs = fb->name_offs.p; fb->rs.lens = fb->lens.p;
+				rc = bmh_fasta_fill(buf, p, end, nr, nb, nn, load_threads, &fb->rs);
+				if (rc == BMH_OK) for (uint64_t r = 0; r < nr; ++r) if (fb->lens.p[r] > 700) { bmh_set_error("bmh_aligner_run_fasta: read %lld has %u bases: reads beyond 700 go through the host job builder (bmh_build_jobs)", (long long)(id0 + (int64_t)r), fb->lens.p[r]); rc = BMH_EINVAL; break; }
+			}
+			std::lock_guard<std::mutex> lk(qm);
+			if (rc != BMH_OK) { load_rc = rc; load_err = bmh_last_error(); free_list.push_back(fb); break; }
+			if (nr == 0) { free_list.push_back(fb); p = end; continue; }
+			fb->index = index++; fb->id0 = id0; id0 += (int64_t)nr;
+			est = end - p; p = end;
+			ready[fb->index] = fb;
+			qcv.notify_all();
+		}
+		std::lock_guard<std::mutex> lk(qm);
+		eof = true;
+		qcv.notify_all();
+	};
+	batch_src_t src;
+	src.next = [&](batch_t &bt) {
+		std::unique_lock<std::mutex> lk(qm);
+		qcv.wait(lk, [&] { return stopped || ready.count(next_out) || eof; });
+		if (stopped) return 0;
+		if (!ready.count(next_out)) { if (load_rc != BMH_OK) { bmh_set_error("%s", load_err.c_str()); return load_rc; } return 0; }
+		fbatch_t *fb = ready[next_out]; ready.erase(next_out); ++next_out;
+		bt.index = fb->index; bt.rs = &fb->rs; bt.b0 = 0; bt.b1 = (uint32_t)fb->rs.n_reads; bt.id0 = fb->id0; bt.pinned = true; bt.token = fb;
+		return 1;
+	};
+	src.release = [&](void *tok) { if (!tok) return; std::lock_guard<std::mutex> lk(qm); free_list.push_back((fbatch_t *)tok); qcv.notify_all(); };
+	src.stop = [&]() { std::lock_guard<std::mutex> lk(qm); stopped = true; qcv.notify_all(); };
+	std::thread lt(loader);
+	const int rc = run_core(h, src, "bmh_aligner_run_fasta", paired, n_lanes, n_threads, sink, user, stats);
+	src.stop();
+	lt.join();
+	(void)munmap(m, sz);
+	return rc;
 }
 
 }   // extern "C"

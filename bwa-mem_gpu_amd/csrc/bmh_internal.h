@@ -57,6 +57,10 @@ int64_t bmh_finalize_regs_device_ex(const bmh_index_t *idx, const bmh_chain_opt_
                                     const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
                                     const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read, const float *d_frac_rep,
                                     int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream, bmh_fin_extra_t *extra);
+// csrc/reads_io.cpp: a mapped read file cut and filled batch by batch (bmh_aligner_run_fasta)
+int bmh_fasta_cut(const uint8_t *buf, size_t sz, size_t p, uint64_t want_bases, uint64_t want_reads, bool even, int n_threads, size_t est_bytes,
+                  size_t *end, uint64_t *n_reads, uint64_t *n_bases, uint64_t *n_name_bytes);
+int bmh_fasta_fill(const uint8_t *buf, size_t p, size_t end, uint64_t n_reads, uint64_t n_bases, uint64_t n_name_bytes, int n_threads, bmh_read_set_t *o);
 // ---- interleaved pairs with mem_pair / mem_sam_pe's choices on the device (csrc/pair_dev.hip) for the pairs the mate rescue does not touch
 // The host call (csrc/pair_post.cpp: bmh_finalize_pairs_split = bmh_finalize_pairs_deduped on a subset) tells the caller the insert-size statistics as
 // soon as it has them (after_pestat: the caller starts the device's pair kernel), asks before its own final walk which pairs the device handed back

@@ -344,6 +344,9 @@ void bmh_free(void *p);
  * src/bntseq.c: what the host tail and bmh_format_sam read), offsets, lengths, and the names (the header up to the first blank,
  * NUL-terminated, back to back: bmh_format_sam's names / name_off).  Blank lines are skipped, CR LF line ends accepted; headers and
  * sequence lines that do not alternate: BMH_EINVAL.  n_threads <= 0: all host threads.  Arrays are malloc'd: bmh_reads_free. */
+/* bmh_fasta_scan: reads, bases, name bytes and the longest read of such a file -- out[4] -- from one counting pass of the mapped file, without loading it
+ * (what a driver looks at before it chooses between bmh_aligner_run_fasta and the paths that take longer reads). */
+int bmh_fasta_scan(const char *path, int n_threads, uint64_t *out);
 typedef struct {
 	uint64_t n_reads, n_bases, n_name_bytes;
 	uint8_t *ascii, *codes;        /* [n_bases] */
@@ -560,6 +563,13 @@ bmh_aligner_t *bmh_aligner_create(const bmh_index_t *idx, const uint8_t *pac, in
 void bmh_aligner_free(bmh_aligner_t *a);
 int bmh_aligner_run(bmh_aligner_t *a, const bmh_read_set_t *reads, const uint64_t *cuts, uint32_t n_batches, int paired, int n_lanes, int n_threads,
                     bmh_sam_sink_t sink, void *user, bmh_align_stats_t *stats);
+/* The same from a read FILE (one '>' header line and one sequence line per read, as bmh_reads_load_fasta takes), batch by batch: a loader thread cuts the
+ * mapped file the way bseq_read cuts its stream -- reads are added until the batch holds at least batch_bases bases (or exactly batch_reads reads, if that is
+ * not 0) and, paired, an even number of reads (src/bwa.c:48-66; the reference's batch_bases is 10 000 000 x its thread count) -- and fills every batch into
+ * pinned host memory while the workers are on the batches before it; nothing of the file is held beyond the n_lanes + 3 batches in flight.  Same text as
+ * bmh_reads_load_fasta + bmh_aligner_run with the same cuts. */
+int bmh_aligner_run_fasta(bmh_aligner_t *a, const char *reads_fa, uint64_t batch_bases, uint64_t batch_reads, int paired, int n_lanes, int n_threads,
+                          bmh_sam_sink_t sink, void *user, bmh_align_stats_t *stats);
 
 #ifdef __cplusplus
 }

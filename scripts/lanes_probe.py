@@ -66,4 +66,21 @@ for lanes, nb in cfgs:
     print("lanes %d batches %d: %.1f ms = %.2f Mreads/s (%d bytes); format %.1f; lanes summed: H2D %.1f seed %.1f cem %.1f tail %.1f select %.1f cigar %.1f" %
           (lanes, nb, st.seconds * 1e3, n_reads / st.seconds / 1e6, nbytes[0], st.format_seconds * 1e3, st.h2d_seconds * 1e3, st.seed_seconds * 1e3,
            st.chain_extend_seconds * 1e3, st.tail_seconds * 1e3, st.select_seconds * 1e3, st.cigar_seconds * 1e3), flush=True)
+if os.environ.get("LANES_FILE"):
+    # the same reads from a FILE: bmh_aligner_run_fasta (a loader thread ahead of the lanes) against loading the file first (bmh_reads_load_fasta) and bmh_aligner_run
+    from bwamem_hip.lib import load_fasta_reads
+    fa = "/tmp/lanes_probe.fa"
+    recs = np.empty((n_reads, w + 3 + rl + 1), np.uint8)
+    recs[:, 0] = ord(">"); recs[:, 1:w + 2] = np.frombuffer("".join(names.tolist()).encode(), np.uint8).reshape(n_reads, w + 1); recs[:, w + 2] = 10
+    recs[:, w + 3:w + 3 + rl] = asc.reshape(n_reads, rl); recs[:, -1] = 10
+    recs.tofile(fa); del recs
+    for lanes, nb in cfgs:
+        for it in range(3):
+            nbytes[0] = 0
+            t0 = time.perf_counter()
+            st = nat.run_fasta(fa, paired, sink, batch_reads=(n_reads // nb) & ~1, n_lanes=lanes, n_threads=nth)
+            dt = time.perf_counter() - t0
+        print("FILE  lanes %d batches %d: file -> SAM %.1f ms = %.2f Mreads/s (%d bytes)" % (lanes, nb, dt * 1e3, n_reads / dt / 1e6, nbytes[0]), flush=True)
+    t0 = time.perf_counter(); d_ = load_fasta_reads(fa); t_load = time.perf_counter() - t0
+    print("FILE  bmh_reads_load_fasta alone: %.1f ms (%d reads)" % (t_load * 1e3, len(d_["lens"])), flush=True)
 nat.free()

@@ -1059,8 +1059,9 @@ def test_aligner_writes_reference_sam(hip, tmp_path, golden):
     assert buf.getvalue().startswith(bytes(z["sam_header"]).decode())
     # the native pipeline wrote that text on the device (bmh_sam_text_*); the host formatter from records copied home, and the host's selection
     # of the records that need a CIGAR, give the same bytes -- and so does a batch whose region tail ran on the host (device tail refused)
-    for env in ("BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_HOST_SELECT", "BMH_FIN_FORCE_ECAPACITY", "BMH_ALIGNER_PE_HOST_DEDUP"):
-        os.environ[env] = "1"
+    for env, val in (("BMH_ALIGNER_HOST_FORMAT", "1"), ("BMH_ALIGNER_HOST_SELECT", "1"), ("BMH_FIN_FORCE_ECAPACITY", "1"), ("BMH_ALIGNER_PE_HOST_DEDUP", "1"), ("BMH_ALIGNER_PE_HOST", "1"),
+                     ("BMH_ALIGNER_STREAM", "0")):          # (STREAM=0: the whole file loaded first, bmh_aligner_run on its cuts, instead of bmh_aligner_run_fasta)
+        os.environ[env] = val
         try:
             buf2 = io.StringIO()
             al.align_file(fq, buf2, batch_reads=1 << 30 if pe else 256, paired=pe)
@@ -1139,6 +1140,56 @@ def test_native_pipeline_device_text_equals_host_text(hip, tmp_path, pe):
         if texts[env] != body:
             a, b = body.split(b"\n"), texts[env].split(b"\n")
             assert False, (env, len(a), len(b), [(x, y) for x, y in zip(a, b) if x != y][:2])
+    al.close()
+
+
+@pytest.mark.parametrize("pe", [False, True])
+def test_read_file_batch_by_batch_equals_the_loaded_file(hip, tmp_path, pe):
+    """bmh_aligner_run_fasta (a loader thread cuts and fills the batches of the mapped file while the lanes work) against bmh_reads_load_fasta + bmh_aligner_run on
+    the same cuts: by read count and by bases, batches of a handful of reads and of thousands, CR LF line ends, blank lines, a last line without a newline, header
+    lines with descriptions."""
+    import io
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.aligner import Aligner
+    g = synth.make_genome(400_000, seed=8, repeat_frac=0.25)
+    prefix = str(tmp_path / "g.fa")
+    fmindex.write_index(prefix, fmindex.build_fmd_index(g)); fmindex.write_bns(prefix, g, contigs=[("a", 150_000), ("b", 250_000)])
+    n = 5000
+    rng = np.random.default_rng(12)
+    if pe:
+        reads = synth.make_pairs(g, n // 2, 101, seed=2)[0]
+        seqs = [synth.codes_to_ascii(r).tobytes() for r in reads]
+    else:
+        seqs = [synth.codes_to_ascii(g[p:p + int(l)]).tobytes() for p, l in zip(rng.integers(0, len(g) - 260, n), rng.integers(30, 251, n))]     # ragged lengths
+    fq = str(tmp_path / "r.fa")
+    with open(fq, "wb") as f:
+        for i, b in enumerate(seqs):
+            nl = b"\r\n" if i % 5 == 0 else b"\n"
+            f.write(b">" + ((b"p%d" % (i // 2)) if pe else (b"r%d" % i)) + (b" a description" if i % 3 == 0 else b"") + nl)
+            if i % 97 == 0:
+                f.write(nl)
+            f.write(b + (b"" if i == n - 1 else nl))
+    al = Aligner(prefix, n_threads=2)
+    for kw in (dict(batch_reads=7 if not pe else 8), dict(batch_reads=1000), dict(chunk_bases=20_000), dict(chunk_bases=300_000), dict(batch_reads=1 << 30)):
+        texts = []
+        for stream in ("1", "0"):
+            os.environ["BMH_ALIGNER_STREAM"] = stream
+            try:
+                buf = io.BytesIO()
+                assert al.align_file(fq, buf, paired=pe, **kw) == n
+                texts.append(buf.getvalue())
+            finally:
+                del os.environ["BMH_ALIGNER_STREAM"]
+        assert texts[0].count(b"\n") >= n
+        if texts[0] != texts[1]:
+            a, b = texts[0].split(b"\n"), texts[1].split(b"\n")
+            assert False, (kw, len(a), len(b), [(x, y) for x, y in zip(a, b) if x != y][:2])
+    # a file whose lines do not alternate is refused, whichever batch the fault lies in
+    bad = str(tmp_path / "bad.fa")
+    with open(bad, "wb") as f:
+        f.write(b">x0\nACGTACGTACGTACGTACGTACGTACGT\n" * 50 + b">x\n>y\nACGT\n")
+    with pytest.raises(RuntimeError):
+        al.align_file(bad, io.BytesIO(), batch_reads=10)
     al.close()
 
 

@@ -693,7 +693,7 @@ static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int pair
 	std::map<uint32_t, std::unique_ptr<result_t>> done;             // finished batches waiting for their turn at the writer
 	std::vector<std::unique_ptr<result_t>> &pool = h->pool;         // result objects (pinned buffers) not in use: at most n_lanes + 2 exist
 	int &n_results = h->n_results;
-	uint32_t next_write = 0, n_taken = 0; bool src_done = false;    // (guarded by mu)
+	uint32_t next_write = 0; int workers_alive = n_lanes;           // (guarded by mu)
 	uint64_t n_reads_total = 0;
 	int first_rc = BMH_OK; std::string first_err;
 	auto fail = [&](int rc, const char *msg) { { std::lock_guard<std::mutex> lk(mu); if (first_rc == BMH_OK) { first_rc = rc; first_err = msg ? msg : ""; } cv.notify_all(); } if (src.stop) src.stop(); };
@@ -715,13 +715,12 @@ static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int pair
 			batch_t bt;
 			const int got = src.next(bt);
 			if (got < 0) { fail(got, bmh_last_error()); break; }
-			if (got == 0) { std::lock_guard<std::mutex> lk(mu); src_done = true; cv.notify_all(); break; }
+			if (got == 0) break;
 			const uint32_t b = bt.index;
 			std::unique_ptr<result_t> R;
 			{   // a result object from the pool: no more than n_lanes + 2 batches are ahead of the writer (their text is hundreds of megabytes each); the
 				// batch the writer waits for always gets one
 				std::unique_lock<std::mutex> lk(mu);
-				if (b + 1 > n_taken) n_taken = b + 1;
 				n_reads_total += bt.b1 - bt.b0;
 				cv.wait(lk, [&] { return first_rc != BMH_OK || !pool.empty() || n_results < n_lanes + 2 || b == next_write; });
 				if (first_rc != BMH_OK) { if (src.release) src.release(bt.token); break; }
@@ -741,6 +740,8 @@ static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int pair
 		}
 		std::lock_guard<std::mutex> lk(mu);
 		for (int k = 0; k < 8; ++k) lane_t_sum[(size_t)k] += Ln.t[k];
+		--workers_alive;                                             // (the writer ends when every worker has: a batch that was taken is in `done` by then)
+		cv.notify_all();
 	};
 	double t_format = 0.0; uint64_t n_bytes = 0; uint32_t n_written = 0;
 	auto writer = [&]() {
@@ -749,7 +750,7 @@ static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int pair
 			std::unique_ptr<result_t> R;
 			{
 				std::unique_lock<std::mutex> lk(mu);
-				cv.wait(lk, [&] { return first_rc != BMH_OK || done.count(b) || (src_done && b >= n_taken); });
+				cv.wait(lk, [&] { return first_rc != BMH_OK || done.count(b) || workers_alive == 0; });
 				if (first_rc != BMH_OK) return;
 				if (!done.count(b)) return;                             // (every batch written)
 				R = std::move(done[b]); done.erase(b);

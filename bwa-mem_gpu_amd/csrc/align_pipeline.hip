@@ -126,6 +126,7 @@ struct lane_t {
 	dbuf_t<uint8_t> d_reads, d_work; dbuf_t<uint32_t> d_offs, d_lens, d_sel, d_opr, d_cigar, d_off, d_packed, d_over, d_sel2; dbuf_t<int32_t> d_out3, d_regs, d_fin, d_aln, d_slot, d_hrec, d_unflag; dbuf_t<char> d_md;
 	dbuf_t<int32_t> d_dedup, d_fin2, d_hrec2, d_unflag2, d_rslot, d_hh, d_ufh, d_finh; dbuf_t<uint32_t> d_roff, d_roff2, d_opr2, d_todo_pairs, d_oprh, d_offh; dbuf_t<uint8_t> d_todo, d_scan;   // pairs on the device
 	hbuf_t<uint8_t> h_todo; std::vector<uint32_t> todo_pairs, offh; void *pair_scratch = nullptr;
+	dbuf_t<uint32_t> d_alt_ids, d_alt_off; dbuf_t<int32_t> d_alt_sub;         // ALT contigs: the reads the host redid, on their way into d_fin
 	dbuf_t<uint32_t> d_cg2; dbuf_t<int32_t> d_aln2; dbuf_t<char> d_md2; uint32_t max_read_len = 0;      // the redo of the alignments that overflow the fixed slots
 	dbuf_t<char> d_names, d_text, d_ctg_names; dbuf_t<uint64_t> d_name_off, d_text_off; dbuf_t<uint32_t> d_ctg_name_off; dbuf_t<int64_t> d_ctg_off; bool ctg_up = false;
 	hbuf_t<uint32_t> h_offs, h_sel, h_rpr; hbuf_t<int32_t> h_regs; hbuf_t<float> h_fr; hbuf_t<uint8_t> h_need, h_reads; hbuf_t<char> h_names; hbuf_t<uint64_t> h_name_off;
@@ -269,7 +270,7 @@ int patch_alt_reads(const aligner_t &A, lane_t &Ln, const bmh_dev_jobs_t &dj, co
 	std::vector<uint32_t> ids;
 	for (const auto &v : part) ids.insert(ids.end(), v.begin(), v.end());
 	R.dev_index.clear();
-	if (ids.empty()) return BMH_OK;
+	if (ids.empty()) return bmh_alt_records_device(Ln.d_fin.p, m, nullptr, nullptr, nullptr, nullptr, 0, Ln.st);
 	const uint32_t ns = (uint32_t)ids.size();
 	std::vector<uint32_t> sub_rpr(ns); std::vector<float> sub_fr(ns); std::vector<uint64_t> sub_offs(ns);
 	uint64_t n_sub_regs = 0, n_sub_recs = 0;
@@ -284,19 +285,24 @@ int patch_alt_reads(const aligner_t &A, lane_t &Ln, const bmh_dev_jobs_t &dj, co
 	                                         A.n_contigs > 1 ? A.off.data() : nullptr, sub_out.data(), sub_opr.data(), n_threads, ids.data());
 	if (ms < 0) return (int)ms;
 	if ((uint64_t)ms != n_sub_recs) { bmh_set_error("bmh_aligner_run: internal error: the host tail left %lld records where the device tail left %llu", (long long)ms, (unsigned long long)n_sub_recs); return BMH_EINVAL; }
-	R.dev_index.resize(m);
-	for (uint64_t k = 0; k < m; ++k) R.dev_index[k] = (uint32_t)k;
+	std::vector<uint32_t> sub_off((size_t)ns + 1, 0);
 	uint64_t w = 0;
 	for (uint32_t j = 0; j < ns; ++j) {
 		const uint32_t r = ids[j];
 		if (sub_opr[j] != R.opr.p[r]) { bmh_set_error("bmh_aligner_run: internal error: read %u has %u records on the host, %u on the device", r, sub_opr[j], R.opr.p[r]); return BMH_EINVAL; }
 		memcpy(R.fin.p + 16 * rec_off[r], &sub_out[16 * w], 64 * (size_t)sub_opr[j]);
-		for (uint32_t q = 0; q < sub_opr[j]; ++q) R.dev_index[rec_off[r] + q] = (uint32_t)(m + w + q);
+		sub_off[j] = (uint32_t)w;
 		w += sub_opr[j];
 	}
-	// (d_fin was sized for twice the regions: the redone records go behind the device's own)
-	LCK(hipMemcpyAsync(Ln.d_fin.p + 16 * m, sub_out.data(), 64 * (size_t)ms, hipMemcpyHostToDevice, Ln.st));
-	LCK(hipStreamSynchronize(Ln.st));                              // (sub_out is a local)
+	sub_off[ns] = (uint32_t)w;
+	// the redone records take their places in the device's array too (a read keeps its number of records: mem_sort_dedup_patch does not look at the table), after every
+	// record of the batch has become an ALT-mode record ([11] = secondary_all)
+	RCK(Ln.d_alt_ids.need(ns)); RCK(Ln.d_alt_off.need((size_t)ns + 1)); RCK(Ln.d_alt_sub.need(16 * ((size_t)ms + 1)));
+	LCK(hipMemcpyAsync(Ln.d_alt_ids.p, ids.data(), 4 * (size_t)ns, hipMemcpyHostToDevice, Ln.st));
+	LCK(hipMemcpyAsync(Ln.d_alt_off.p, sub_off.data(), 4 * ((size_t)ns + 1), hipMemcpyHostToDevice, Ln.st));
+	if (ms) LCK(hipMemcpyAsync(Ln.d_alt_sub.p, sub_out.data(), 64 * (size_t)ms, hipMemcpyHostToDevice, Ln.st));
+	RCK(bmh_alt_records_device(Ln.d_fin.p, m, Ln.d_roff.p, Ln.d_alt_ids.p, Ln.d_alt_off.p, Ln.d_alt_sub.p, ns, Ln.st));
+	LCK(hipStreamSynchronize(Ln.st));                              // (ids, sub_off, sub_out are locals)
 	return BMH_OK;
 }
 
@@ -419,10 +425,10 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 	}
 	LCK(hipMemcpyAsync(Ln.d_offs.p, Ln.h_offs.p, 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
 	LCK(hipMemcpyAsync(Ln.d_lens.p, rs.lens + b0, 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
-	// the text is written on the device (bmh_sam_text_*) unless the index has ALT contigs (their tags are the host formatter's): the names go along
+	// the text is written on the device (bmh_sam_text_*): the names go along
 	const bool host_format = getenv("BMH_ALIGNER_HOST_FORMAT") != nullptr;          // (A/B and cross-check: records to the host, text by bmh_format_sam)
 	const bool host_select = getenv("BMH_ALIGNER_HOST_SELECT") != nullptr;          // (A/B and cross-check: the host's selection for every batch; implies the host's text)
-	const bool text_dev = !A.has_alt && !host_format && !host_select;
+	const bool text_dev = !host_format && !host_select;
 	R.has_text = false; R.text_len = 0;
 	if (text_dev) {
 		const uint64_t n0 = rs.name_offs[b0], n1 = b1 < rs.n_reads ? rs.name_offs[b1] : rs.n_name_bytes;
@@ -493,13 +499,15 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		R.dev_index.clear();
 		{
 			bmh_post_opt_t po_dev = po; po_dev.contig_is_alt = nullptr;      // (ALT contigs: the reads they touch are redone below)
-			RCK(Ln.d_fin.need(16 * (nr + 1) * (A.has_alt ? 2 : 1))); RCK(Ln.d_opr.need(n + 1));
-			m = bmh_finalize_regs_device(A.idx, &A.co, &A.ep, &po_dev, Ln.d_reads.p, Ln.d_offs.p, n, Ln.d_regs.p, nr, dj.d_regs_per_read, dj.d_frac_rep,
-			                             A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr, Ln.d_fin.p, Ln.d_opr.p, Ln.st);
+			RCK(Ln.d_fin.need(16 * (nr + 1))); RCK(Ln.d_opr.need(n + 1));
+			bmh_fin_extra_t ex; memset(&ex, 0, sizeof(ex));
+			if (A.has_alt) { RCK(Ln.d_roff.need(n + 1)); ex.d_out_off = Ln.d_roff.p; }      // (the first record of every read: where the host's redone reads go)
+			m = bmh_finalize_regs_device_ex(A.idx, &A.co, &A.ep, &po_dev, Ln.d_reads.p, Ln.d_offs.p, n, Ln.d_regs.p, nr, dj.d_regs_per_read, dj.d_frac_rep,
+			                                A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr, Ln.d_fin.p, Ln.d_opr.p, Ln.st, &ex);
 			if (m < 0 && m != BMH_ECAPACITY) return (int)m;
 			if (m >= 0) {
 				// (the stream is idle: the records go home on the second stream while the selection and the CIGAR kernels run on the first)
-				if (!text_dev) {
+				if (!text_dev || A.has_alt) {                        // (ALT contigs: the host looks the records through for hits on them)
 					RCK(R.fin.need(16 * (size_t)m + 16)); RCK(R.opr.need(n + 1));
 					if (m) LCK(hipMemcpyAsync(R.fin.p, Ln.d_fin.p, 64 * (size_t)m, hipMemcpyDeviceToHost, Ln.st2));
 					LCK(hipMemcpyAsync(R.opr.p, Ln.d_opr.p, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st2));
@@ -508,7 +516,6 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 				if (A.has_alt) {
 					LCK(hipStreamSynchronize(Ln.st2));
 					RCK(patch_alt_reads(A, Ln, dj, po, codes, host_offs(), n, nr, (uint64_t)m, n_threads, R));
-					dev_select = false;                                 // (patched records live behind the device tail's: the host's list maps them)
 				}
 			}
 		}
@@ -530,7 +537,7 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		R.m = (uint64_t)m;
 	} else {
 		bool pe_done = false;
-		if (text_dev && !getenv("BMH_ALIGNER_PE_HOST") && !getenv("BMH_ALIGNER_PE_HOST_DEDUP")) {
+		if (text_dev && !A.has_alt && !getenv("BMH_ALIGNER_PE_HOST") && !getenv("BMH_ALIGNER_PE_HOST_DEDUP")) {
 			int rc_pd = pairs_on_device(A, Ln, rs, dj, po, codes, host_offs(), b0, n, nr, n_threads, R, &d_fin);
 			if (rc_pd == BMH_OK) pe_done = true;
 			else if (rc_pd != BMH_ECAPACITY) return rc_pd;              // (BMH_ECAPACITY: a read beyond the device tail's fixed limits: the host forms below)

@@ -57,6 +57,9 @@ int64_t bmh_finalize_regs_device_ex(const bmh_index_t *idx, const bmh_chain_opt_
                                     const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
                                     const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read, const float *d_frac_rep,
                                     int n_contigs, const int64_t *contig_offset, int32_t *d_out, uint32_t *d_out_per_read, void *stream, bmh_fin_extra_t *extra);
+// csrc/sam_kernels.hip: the device tail's records as ALT-mode records ([11] = [12]), then the records of the ns reads the host redid with the ALT table (d_ids, their
+// records d_sub at d_sub_off [ns + 1]) in their places (d_rec_off: first record of every read)
+int bmh_alt_records_device(int32_t *d_fin, uint64_t m, const uint32_t *d_rec_off, const uint32_t *d_ids, const uint32_t *d_sub_off, const int32_t *d_sub, uint32_t ns, void *stream);
 // csrc/reads_io.cpp: a mapped read file cut and filled batch by batch (bmh_aligner_run_fasta)
 int bmh_fasta_cut(const uint8_t *buf, size_t sz, size_t p, uint64_t want_bases, uint64_t want_reads, bool even, int n_threads, size_t est_bytes,
                   size_t *end, uint64_t *n_reads, uint64_t *n_bases, uint64_t *n_name_bytes);

@@ -196,6 +196,7 @@ struct sam_args_t {
 	const uint32_t *rec_off;       // [n_reads] first record of every read
 	uint32_t *len; const uint64_t *text_off; char *text; uint32_t *err;
 	int flag_all, max_XA_hits, max_XA_hits_alt, no_multi, softclip; double drop;
+	int sa;                        // field of a record that holds the XA tag's key: [12] secondary, with ALT contigs [11] secondary_all (bmh_post_opt_t)
 };
 
 // where the text goes: W = 0 counts the bytes, 1 writes them to global memory, 2 into the wave's image in LDS (copied out in dwords afterwards:
@@ -218,6 +219,34 @@ template <int W> struct sam_out_t {
 		else n += (uint32_t)nd;
 	}
 };
+
+// a / b as printf("%.3f") writes it (the pa:f tag, src/bwamem.c:1663): the double nearest to a / b, rounded to three decimals from its EXACT value, ties to even
+// -- m x 2^e x 1000 in integers
+template <int W> __device__ void sam_fmt3(sam_out_t<W> &o, int a, int b)
+{
+#pragma clang fp contract(off)
+	const double x = (double)a / (double)b;
+	unsigned long long q = 0;
+	if (x > 0.) {
+		const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+		const int ex = (int)(bits >> 52 & 0x7FF);
+		const unsigned long long m = ex ? (bits & 0xFFFFFFFFFFFFFull) | 1ull << 52 : (bits & 0xFFFFFFFFFFFFFull);
+		const int e = (ex ? ex : 1) - 1075;                         // x = m * 2^e
+		const unsigned long long N = m * 1000ull;                   // < 2^63
+		if (e >= 0) q = N << e;                                     // (not reached for a ratio of two scores)
+		else if (-e >= 64) q = 0;
+		else {
+			const int sft = -e;
+			q = N >> sft;
+			const unsigned long long rem = N & ((1ull << sft) - 1), half = 1ull << (sft - 1);
+			if (rem > half || (rem == half && (q & 1))) ++q;
+		}
+	}
+	o.num((long long)(q / 1000));
+	o.ch('.');
+	const int f = (int)(q % 1000);
+	o.ch((char)('0' + f / 100)); o.ch((char)('0' + f / 10 % 10)); o.ch((char)('0' + f % 10));
+}
 
 struct sam_rec_t { const int32_t *fin; const int32_t *aln; const uint32_t *cigar; const char *md; };
 
@@ -338,7 +367,7 @@ template <int W> __device__ bool sam_read(const sam_args_t &A, uint32_t r, sam_o
 		out.lit("\t*\tAS:i:0\tXS:i:0\n");
 		return true;
 	}
-	auto pri = [&](int i) { const int k = a[16 * i + 12]; return (k >= 0 && (double)a[16 * i + 1] >= (double)a[16 * k + 1] * A.drop) ? k : -1; };
+	auto pri = [&](int i) { const int k = a[16 * i + A.sa]; return (k >= 0 && (double)a[16 * i + 1] >= (double)a[16 * k + 1] * A.drop) ? k : -1; };
 	int which = 0;
 	for (int i = 0; i < n; ++i) {
 		if (!(a[16 * i + 15] & 1)) continue;
@@ -390,10 +419,11 @@ template <int W> __device__ bool sam_read(const sam_args_t &A, uint32_t r, sam_o
 				}
 			}
 		}
+		if (!(flag & 0x100) && (x.fin[15] >> 2) > 0) { out.lit("\tpa:f:"); sam_fmt3<W>(out, x.fin[1], x.fin[15] >> 2); }      // score / score of the ALT hit that shadows it
 		if (!A.flag_all) {                                       // the XA tag of this record: the hits listed under it (mem_gen_alt)
-			int cnt = 0;
-			for (int j = 0; j < n; ++j) if (pri(j) == i) ++cnt;
-			if (cnt > 0 && !(cnt > A.max_XA_hits_alt || cnt > A.max_XA_hits)) {         // (no hit on an ALT contig here: the smaller limit, src/bwamem_extra.c:125)
+			int cnt = 0; bool has_alt = false;
+			for (int j = 0; j < n; ++j) if (pri(j) == i) { ++cnt; has_alt = has_alt || (a[16 * j + 15] & 2); }
+			if (cnt > 0 && !(cnt > A.max_XA_hits_alt || (!has_alt && cnt > A.max_XA_hits))) {         // src/bwamem_extra.c:125
 				out.lit("\tXA:Z:");
 				for (int j = 0; j < n; ++j) {
 					if (pri(j) != i) continue;
@@ -476,7 +506,6 @@ size_t scan64_bytes(size_t n)
 int sam_args(const bmh_post_opt_t *popt, const bmh_sam_dev_t *d, const char *fn, sam_args_t &A)
 {
 	if (!popt || !d) { bmh_set_error("%s: null argument", fn); return BMH_EINVAL; }
-	if (popt->contig_is_alt) { bmh_set_error("%s: ALT contigs are the host formatter's (bmh_format_sam)", fn); return BMH_ECAPACITY; }
 	if (d->n_reads && (!d->d_names || !d->d_name_off || !d->d_reads || !d->d_offs || !d->d_lens || !d->d_contig_names || !d->d_contig_name_off || !d->d_fin_per_read ||
 	                   !d->d_slot || !d->d_aln || !d->d_cig_off || !d->d_packed || (d->n_contigs > 1 && !d->d_contig_offset) || (d->d_h_rec && (!d->d_unflag || (d->n_reads & 1))))) {
 		bmh_set_error("%s: null argument", fn); return BMH_EINVAL;
@@ -485,10 +514,37 @@ int sam_args(const bmh_post_opt_t *popt, const bmh_sam_dev_t *d, const char *fn,
 	A.d = *d;
 	A.flag_all = popt->flag_all; A.max_XA_hits = popt->max_XA_hits; A.max_XA_hits_alt = popt->max_XA_hits_alt; A.no_multi = popt->no_multi; A.softclip = popt->softclip;
 	A.drop = (double)popt->XA_drop_ratio;
+	A.sa = popt->contig_is_alt ? 11 : 12;
 	return BMH_OK;
 }
 
+// ALT contigs in the native pipeline (csrc/align_pipeline.hip): the device tail runs without the table; its records become ALT-mode records in place ([11] = secondary_all,
+// which without a hit on an ALT contig is the secondary), and the reads the host has redone with the table take theirs
+__global__ void __launch_bounds__(256) alt_records_kernel(int32_t *fin, uint64_t m)
+{
+	const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+	if (k < m) fin[16 * k + 11] = fin[16 * k + 12];
+}
+__global__ void __launch_bounds__(256) alt_scatter_kernel(int32_t *fin, const uint32_t *rec_off, const uint32_t *ids, const uint32_t *sub_off, const int32_t *sub, uint32_t ns)
+{
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x, j = t >> 4, l = t & 15u;
+	if (j >= ns) return;
+	const uint32_t n = sub_off[j + 1] - sub_off[j];
+	const int4 *src = (const int4 *)(sub + 16 * (size_t)sub_off[j]);
+	int4 *dst = (int4 *)(fin + 16 * (size_t)rec_off[ids[j]]);
+	for (uint32_t q = l; q < 4 * n; q += 16) dst[q] = src[q];
+}
+
 }   // namespace
+
+int bmh_alt_records_device(int32_t *d_fin, uint64_t m, const uint32_t *d_rec_off, const uint32_t *d_ids, const uint32_t *d_sub_off, const int32_t *d_sub, uint32_t ns, void *stream)
+{
+	hipStream_t st = (hipStream_t)stream;
+	if (m) alt_records_kernel<<<(unsigned)((m + 255) / 256), 256, 0, st>>>(d_fin, m);
+	if (ns) alt_scatter_kernel<<<(unsigned)(((size_t)ns * 16 + 255) / 256), 256, 0, st>>>(d_fin, d_rec_off, d_ids, d_sub_off, d_sub, ns);
+	HIPCK(hipGetLastError());
+	return BMH_OK;
+}
 
 extern "C" size_t bmh_sam_text_work(uint32_t n_reads)
 {

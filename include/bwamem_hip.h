@@ -512,8 +512,9 @@ int bmh_cigar_pack(const int32_t *d_aln, const uint32_t *d_cigar, int max_cigar,
                    const uint32_t *d_off, uint32_t *d_packed, void *stream);
 
 /* ---- the SAM text itself written on the device (csrc/sam_kernels.hip): the text of bmh_format_sam / bmh_format_sam_pe, byte for byte,
- * from records, alignments and packed CIGARs that never leave HBM.  Every pointer of bmh_sam_dev_t is device memory.  Not for an index
- * with ALT contigs (popt->contig_is_alt must be NULL: BMH_ECAPACITY otherwise; the caller takes the host formatter).
+ * from records, alignments and packed CIGARs that never leave HBM.  Every pointer of bmh_sam_dev_t is device memory.  ALT contigs: with
+ * popt->contig_is_alt set the records are ALT-mode records (bmh_post_opt_t: [11] the XA tag's key, [15] carries is_alt and alt_sc) and the
+ * text follows (soft clips on ALT hits, the larger XA limit, pa:f written as printf's %.3f).
  * bmh_sam_text_sizes: first pass, d_text_off [n_reads + 1] = start of every read's records in the text; returns the text's length
  * (waits for the stream).  bmh_sam_text_write: second pass into d_text (asynchronous; the same d_work, untouched in between);
  * bmh_sam_text_check afterwards waits for the stream and reports an inconsistency between the passes.  d_work: bmh_sam_text_work bytes. */
@@ -541,8 +542,9 @@ int bmh_sam_text_check(const void *d_work, uint32_t n_reads, void *stream);
  * thread hands every batch's text to `sink` in order (return 0 to go on) while the workers are on the next ones.  Interleaved pairs:
  * mem_sort_dedup_patch, mem_mark_primary_se and, for the pairs the mate rescue does not touch, mem_pair and mem_sam_pe's choices on
  * the device too; the insert-size statistics, the rescue's bookkeeping and the pairs it touches on n_threads host threads in the
- * middle of the batch.  The host forms take over for an index with ALT contigs (region tail of the reads that touch one, and the
- * formatter: bmh_format_sam[_pe] in the writer thread) and for a batch the device tail refuses (BMH_ECAPACITY).  The text is what
+ * middle of the batch.  An index with ALT contigs: the region tail of the reads that touch one is redone on host threads and put in
+ * place on the device (pairs: all of mem_sam_pe on the host), the rest as above.  A batch the device tail refuses (BMH_ECAPACITY)
+ * takes the host tail.  The text is what
  * bmh_format_sam / bmh_format_sam_pe write, byte for byte (records only: the caller writes the @SQ header).
  * cuts: n_batches + 1 read indices, cuts[0] = 0, cuts[n_batches] = n_reads, even batch sizes when paired (the reference cuts its
  * batches by bases, bseq_read src/bwa.c:48-66, and the insert-size statistics are those of a batch).  popt->id0 is ignored (a batch's

@@ -1143,6 +1143,34 @@ def test_native_pipeline_device_text_equals_host_text(hip, tmp_path, pe):
     al.close()
 
 
+def test_device_text_pa_tag_rounds_like_printf(hip):
+    """The pa:f tag of the device formatter (score / score of the shadowing ALT hit as %.3f, src/bwamem.c:1663) for every pair of scores up to 300: the
+    decimal string C's printf writes (exact value of the nearest double, ties to even: 1/16 -> 0.062, 3/16 -> 0.188)."""
+    import ctypes as C, torch
+    from bwamem_hip.lib import PostOpt, load_library, sam_text_device
+    Lb = load_library()
+    po = PostOpt(); Lb.bmh_post_opt_default(C.byref(po))
+    A, Bm = np.meshgrid(np.arange(1, 301), np.arange(1, 301), indexing="ij")
+    a, b = A.reshape(-1).astype(np.int32), Bm.reshape(-1).astype(np.int32)
+    n, L = len(a), 10
+    fin = np.zeros((n, 16), np.int32)
+    fin[:, 0] = np.arange(n); fin[:, 1] = a; fin[:, 3] = L; fin[:, 6] = L; fin[:, 8] = a; fin[:, 9] = 100; fin[:, 10] = -1; fin[:, 12] = -1; fin[:, 13] = 60
+    fin[:, 15] = 1 | (b << 2)
+    aln = np.zeros((n, 8), np.int32); aln[:, 3] = 1; aln[:, 6] = 2                      # position 0, forward, one operation, NM 0, MD "10"
+    packed = np.zeros((n, 2), np.uint32); packed[:, 0] = L << 4; packed[:, 1] = np.frombuffer(b"10\0\0", np.uint32)[0]
+    dev = "cuda"
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    reads = t(np.frombuffer(b"ACGTACGTAC" * n, np.uint8).copy())
+    txt = sam_text_device(po, [f"r{i}" for i in range(n)], reads, t((np.arange(n) * L).astype(np.int32)), t(np.full(n, L, np.int32)), [("c", 1000)],
+                          t(fin), t(np.ones(n, np.int32)), t(np.arange(n, dtype=np.int32)), t(aln), t((np.arange(n + 1) * 2).astype(np.int32)), t(packed.reshape(-1).view(np.int32)))
+    got = [l.split(b"pa:f:")[1].split(b"\t")[0].decode() for l in txt.split(b"\n") if l]
+    want = ["%.3f" % (float(x) / float(y)) for x, y in zip(a.tolist(), b.tolist())]
+    assert len(got) == n
+    bad = [(int(x), int(y), g, w) for x, y, g, w in zip(a, b, got, want) if g != w]
+    assert not bad, (len(bad), bad[:5])
+    assert "0.062" in got and "0.188" in got
+
+
 @pytest.mark.parametrize("pe", [False, True])
 def test_read_file_batch_by_batch_equals_the_loaded_file(hip, tmp_path, pe):
     """bmh_aligner_run_fasta (a loader thread cuts and fills the batches of the mapped file while the lanes work) against bmh_reads_load_fasta + bmh_aligner_run on

@@ -239,11 +239,14 @@ int text_on_device(const aligner_t &A, lane_t &Ln, const bmh_post_opt_t &po, con
 int patch_alt_reads(const aligner_t &A, lane_t &Ln, const bmh_dev_jobs_t &dj, const bmh_post_opt_t &po, const uint8_t *codes, const uint64_t *offs64,
                     uint32_t n, uint64_t nr, uint64_t m, int n_threads, result_t &R)
 {
+	const bool tr = getenv("BMH_ALIGNER_TRACE") != nullptr;
+	const double ta = now_s();
 	RCK(Ln.h_regs.need(8 * (nr + 1))); RCK(Ln.h_rpr.need(n + 1)); RCK(Ln.h_fr.need(n + 1));
 	if (nr) LCK(hipMemcpyAsync(Ln.h_regs.p, Ln.d_regs.p, 32 * (size_t)nr, hipMemcpyDeviceToHost, Ln.st));
 	LCK(hipMemcpyAsync(Ln.h_rpr.p, dj.d_regs_per_read, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
 	LCK(hipMemcpyAsync(Ln.h_fr.p, dj.d_frac_rep, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st));
 	LCK(hipStreamSynchronize(Ln.st));
+	const double tb = now_s();
 	std::vector<uint64_t> rec_off((size_t)n + 1, 0), reg_off((size_t)n + 1, 0);
 	for (uint32_t r = 0; r < n; ++r) { rec_off[r + 1] = rec_off[r] + R.opr.p[r]; reg_off[r + 1] = reg_off[r] + Ln.h_rpr.p[r]; }
 	if (rec_off[n] != m || reg_off[n] != nr) { bmh_set_error("bmh_aligner_run: internal error: record / region counts do not add up"); return BMH_EINVAL; }
@@ -272,6 +275,8 @@ int patch_alt_reads(const aligner_t &A, lane_t &Ln, const bmh_dev_jobs_t &dj, co
 	R.dev_index.clear();
 	if (ids.empty()) return bmh_alt_records_device(Ln.d_fin.p, m, nullptr, nullptr, nullptr, nullptr, 0, Ln.st);
 	const uint32_t ns = (uint32_t)ids.size();
+	const double tc = now_s();
+	if (tr) fprintf(stderr, "[aligner] ALT contigs: %u of %u reads have a hit on one and are redone on the host; regions to the host %.1f ms, records looked through %.1f ms\n", ns, n, (tb - ta) * 1e3, (tc - tb) * 1e3);
 	std::vector<uint32_t> sub_rpr(ns); std::vector<float> sub_fr(ns); std::vector<uint64_t> sub_offs(ns);
 	uint64_t n_sub_regs = 0, n_sub_recs = 0;
 	for (uint32_t j = 0; j < ns; ++j) { const uint32_t r = ids[j]; sub_rpr[j] = Ln.h_rpr.p[r]; sub_fr[j] = Ln.h_fr.p[r]; sub_offs[j] = offs64[r]; n_sub_regs += sub_rpr[j]; n_sub_recs += R.opr.p[r]; }
@@ -303,6 +308,7 @@ int patch_alt_reads(const aligner_t &A, lane_t &Ln, const bmh_dev_jobs_t &dj, co
 	if (ms) LCK(hipMemcpyAsync(Ln.d_alt_sub.p, sub_out.data(), 64 * (size_t)ms, hipMemcpyHostToDevice, Ln.st));
 	RCK(bmh_alt_records_device(Ln.d_fin.p, m, Ln.d_roff.p, Ln.d_alt_ids.p, Ln.d_alt_off.p, Ln.d_alt_sub.p, ns, Ln.st));
 	LCK(hipStreamSynchronize(Ln.st));                              // (ids, sub_off, sub_out are locals)
+	if (tr) fprintf(stderr, "[aligner] ALT contigs: host tail of those reads and their way back %.1f ms\n", (now_s() - tc) * 1e3);
 	return BMH_OK;
 }
 

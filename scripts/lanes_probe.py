@@ -41,7 +41,12 @@ names = np.char.add("r", np.char.zfill((np.arange(n_reads) // (2 if paired else 
 blob = np.frombuffer(("\0".join(names.tolist()) + "\0").encode(), dtype=np.uint8)
 noff = np.arange(n_reads, dtype=np.uint64) * np.uint64(w + 2)
 rs = ReadSet(asc, offs, np.full(n_reads, rl, np.uint32), blob, noff, codes=flat)
-nat = NativeAligner(dindex, pac_h, len(g), contigs, None, co, params, po, pe_o)
+n_alt = int(os.environ.get("LANES_ALT", "0"))                 # the last LANES_ALT sequences flagged as ALT contigs
+is_alt = None
+if n_alt:
+    is_alt = np.zeros(len(contigs), np.uint8); is_alt[-n_alt:] = 1
+    print("ALT contigs:", [c[0] for c in contigs[-n_alt:]], "%.1f %% of the genome" % (100.0 * sum(c[1] for c in contigs[-n_alt:]) / len(g)), flush=True)
+nat = NativeAligner(dindex, pac_h, len(g), contigs, is_alt, co, params, po, pe_o)
 nbytes = [0]
 def sink(mv): nbytes[0] += len(mv)
 nth = int(os.environ.get("LANES_THREADS", "0")) or L.bmh_effective_cpus()

@@ -504,22 +504,25 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		int64_t m = -1;
 		R.dev_index.clear();
 		{
-			bmh_post_opt_t po_dev = po; po_dev.contig_is_alt = nullptr;      // (ALT contigs: the reads they touch are redone below)
+			// (ALT contigs: the table goes along; BMH_ALIGNER_ALT_HOST_PATCH: the device tail without it and the reads that touch an ALT contig redone on the host,
+			// the form before the device's second marking round: the cross-check)
+			const bool alt_patch = A.has_alt && getenv("BMH_ALIGNER_ALT_HOST_PATCH") != nullptr;
+			bmh_post_opt_t po_dev = po; if (alt_patch) po_dev.contig_is_alt = nullptr;
 			RCK(Ln.d_fin.need(16 * (nr + 1))); RCK(Ln.d_opr.need(n + 1));
 			bmh_fin_extra_t ex; memset(&ex, 0, sizeof(ex));
-			if (A.has_alt) { RCK(Ln.d_roff.need(n + 1)); ex.d_out_off = Ln.d_roff.p; }      // (the first record of every read: where the host's redone reads go)
+			if (alt_patch) { RCK(Ln.d_roff.need(n + 1)); ex.d_out_off = Ln.d_roff.p; }      // (the first record of every read: where the host's redone reads go)
 			m = bmh_finalize_regs_device_ex(A.idx, &A.co, &A.ep, &po_dev, Ln.d_reads.p, Ln.d_offs.p, n, Ln.d_regs.p, nr, dj.d_regs_per_read, dj.d_frac_rep,
 			                                A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr, Ln.d_fin.p, Ln.d_opr.p, Ln.st, &ex);
 			if (m < 0 && m != BMH_ECAPACITY) return (int)m;
 			if (m >= 0) {
 				// (the stream is idle: the records go home on the second stream while the selection and the CIGAR kernels run on the first)
-				if (!text_dev || A.has_alt) {                        // (ALT contigs: the host looks the records through for hits on them)
+				if (!text_dev || alt_patch) {                        // (the host looks the records through for hits on ALT contigs)
 					RCK(R.fin.need(16 * (size_t)m + 16)); RCK(R.opr.need(n + 1));
 					if (m) LCK(hipMemcpyAsync(R.fin.p, Ln.d_fin.p, 64 * (size_t)m, hipMemcpyDeviceToHost, Ln.st2));
 					LCK(hipMemcpyAsync(R.opr.p, Ln.d_opr.p, 4 * (size_t)n, hipMemcpyDeviceToHost, Ln.st2));
 				}
 				d_fin = Ln.d_fin.p;
-				if (A.has_alt) {
+				if (alt_patch) {
 					LCK(hipStreamSynchronize(Ln.st2));
 					RCK(patch_alt_reads(A, Ln, dj, po, codes, host_offs(), n, nr, (uint64_t)m, n_threads, R));
 				}

@@ -37,6 +37,10 @@ struct ctx_t {
 	// 1: the tail stops behind mem_sort_dedup_patch (interleaved pairs: mem_sam_pe takes the reads' regions from there): the records keep
 	// [1..9] and the sequence id in [13], [0] = the read
 	int dedup_only;
+	// ALT contigs (src/bwamem.c:571-574,702,714-760,1742,1755,2323): ctg_alt[n_contigs] != 0 for a sequence that is one, NULL = no table.  With a table a region
+	// carries is_alt in bit 30 of its sequence id ([13]) while the tail runs, the marking has its second round and the records come out as ALT-mode records
+	// ([11] = secondary_all, [15] = reported | is_alt << 1 | alt_sc << 2: see bmh_post_opt_t)
+	const uint8_t *ctg_alt;
 };
 
 enum { OK = 0, NEED_DP = 1, E_LOG = 2, E_DPCAP = 3 };
@@ -45,6 +49,7 @@ RC_HD inline int64_t r_rb(const rec_t &r) { return (int64_t)(uint32_t)r.v[4] | (
 RC_HD inline int64_t r_re(const rec_t &r) { return (int64_t)(uint32_t)r.v[6] | (int64_t)r.v[7] << 32; }
 RC_HD inline void r_set_rb(rec_t &r, int64_t x) { r.v[4] = (int32_t)(uint32_t)x; r.v[5] = (int32_t)(x >> 32); }
 RC_HD inline uint64_t r_hash(const rec_t &r) { return (uint64_t)(uint32_t)r.v[14] | (uint64_t)(uint32_t)r.v[15] << 32; }
+RC_HD inline int r_alt(const rec_t &r) { return (r.v[13] >> 30) & 1; }            // (while the tail runs; the dedup stage compares [13] as a whole: same sequence, same bit)
 
 RC_HD inline int text_base(const uint8_t *pac, int64_t l_pac, int64_t i)
 {
@@ -141,8 +146,19 @@ struct lt_score_rb_qb {
 		return p.v[1] > q.v[1] || (p.v[1] == q.v[1] && (prb < qrb || (prb == qrb && p.v[2] < q.v[2])));
 	}
 };
-struct lt_score_hash {       // (is_alt is 0 everywhere: ALT contigs are not modelled)
-	RC_HD bool operator()(const rec_t &p, const rec_t &q) const { return p.v[1] > q.v[1] || (p.v[1] == q.v[1] && r_hash(p) < r_hash(q)); }
+struct lt_score_hash {       // alnreg_hlt (src/bwamem.c:141): score, the primary assembly before ALT contigs, the hash
+	RC_HD bool operator()(const rec_t &p, const rec_t &q) const
+	{
+		const int pa = r_alt(p), qa = r_alt(q);
+		return p.v[1] > q.v[1] || (p.v[1] == q.v[1] && (pa < qa || (pa == qa && r_hash(p) < r_hash(q))));
+	}
+};
+struct lt_alt_score_hash {   // alnreg_hlt2: the primary assembly first
+	RC_HD bool operator()(const rec_t &p, const rec_t &q) const
+	{
+		const int pa = r_alt(p), qa = r_alt(q);
+		return pa < qa || (pa == qa && (p.v[1] > q.v[1] || (p.v[1] == q.v[1] && r_hash(p) < r_hash(q))));
+	}
 };
 
 // ---- the patch test's global alignment: ksw_global2's score under bwa_gen_cigar2's band (src/bwa.c:111-216, src/ksw.c:1120-1241),
@@ -388,12 +404,33 @@ RC_HD inline void mark_loop(const ctx_t &x, int n, rec_t *a, int32_t *z)
 			const int j = z[k];
 			if (mark_overlap(x, a[j], a[i])) {
 				if (a[j].v[10] == 0) a[j].v[10] = a[i].v[1];
-				if (a[j].v[1] - a[i].v[1] <= tmp) ++a[j].v[11];
+				if (a[j].v[1] - a[i].v[1] <= tmp && (r_alt(a[j]) || !r_alt(a[i]))) ++a[j].v[11];
 				break;
 			}
 		}
 		if (k == nz) z[nz++] = i;
 		else a[i].v[12] = z[k];
+	}
+}
+// the second round of mem_mark_primary_se (src/bwamem.c:727-757) once the first one has run on a[0..n): the rank of the first round is kept ([0]: secondary_all),
+// the hits of the primary assembly come first and are marked again among themselves (sub_n adds up over both rounds, as there).  Without ALT hits in the
+// read [0] = [12].  z: n ints.
+template <int NSTK = 64>
+RC_HD inline void mark_second_round(const ctx_t &x, int n, rec_t *a, int32_t *z)
+{
+	int n_pri = 0;
+	for (int i = 0; i < n; ++i) n_pri += !r_alt(a[i]);
+	if (n_pri == n) { for (int i = 0; i < n; ++i) a[i].v[0] = a[i].v[12]; return; }
+	for (int i = 0; i < n; ++i) a[i].v[0] = i;
+	if (n_pri > 0) r_introsort<NSTK>(n, a, lt_alt_score_hash());
+	for (int i = 0; i < n; ++i) z[a[i].v[0]] = i;
+	for (int i = 0; i < n; ++i) {
+		if (a[i].v[12] >= 0) { a[i].v[0] = z[a[i].v[12]]; if (r_alt(a[i])) a[i].v[12] = 0x7FFFFFFF; }
+		else a[i].v[0] = -1;
+	}
+	if (n_pri > 0) {
+		for (int i = 0; i < n_pri; ++i) { a[i].v[10] = 0; a[i].v[12] = -1; }
+		mark_loop(x, n_pri, a, z);
 	}
 }
 template <int NSTK = 64>
@@ -403,6 +440,7 @@ RC_HD inline void mark_primary(const ctx_t &x, int n, rec_t *a, int64_t id, int3
 	for (int i = 0; i < n; ++i) mark_init_one(a[i], id, i);
 	r_introsort<NSTK>(n, a, lt_score_hash());
 	mark_loop(x, n, a, z);
+	if (x.ctg_alt) mark_second_round<NSTK>(x, n, a, z);
 }
 
 // mem_approx_mapq_se, mapQ_coef_len > 0 form; logarithms of integers from the host's table
@@ -441,6 +479,7 @@ RC_HD inline void init_one(const ctx_t &x, rec_t &p)
 	const int64_t rb = r_rb(p), re = r_re(p);
 	p.v[8] = p.v[1]; p.v[9] = x.co.w; p.v[10] = 0; p.v[11] = 0; p.v[12] = -1;
 	p.v[13] = pos2rid(x, rb < x.l_pac ? rb : (x.l_pac << 1) - 1 - (re - 1));
+	if (x.ctg_alt && p.v[13] >= 0 && x.ctg_alt[p.v[13]]) p.v[13] |= 1 << 30;
 	p.v[14] = p.v[15] = 0;
 }
 // what a region's record says by itself (MAPQ before the cap of the supplementary records, secondary flag, reported or not)
@@ -452,23 +491,34 @@ RC_HD inline void emit_one(const ctx_t &x, float frac_rep, const rec_t *a, int k
 	const rec_t &p = a[k];
 	*mapq = p.v[12] < 0 ? approx_mapq(x, p, frac_rep, err) : 0; *flag = p.v[12] >= 0 ? 0x100 : 0; *rep = 1;
 	if (p.v[1] < x.po.T) *rep = 0;
-	else if (p.v[12] >= 0 && !x.po.flag_all) *rep = 0;
-	else if (p.v[12] >= 0 && p.v[1] < a[p.v[12]].v[1] * x.co.drop_ratio) *rep = 0;
+	else if (p.v[12] >= 0 && (r_alt(p) || !x.po.flag_all)) *rep = 0;                                  // src/bwamem.c:1742
+	else if (p.v[12] >= 0 && p.v[12] < 0x7FFFFFFF && p.v[1] < a[p.v[12]].v[1] * x.co.drop_ratio) *rep = 0;
 }
-RC_HD inline int emit_all(const ctx_t &x, uint32_t read, float frac_rep, int n, rec_t *a)
+// ALT mode: the score of the ALT hit that shadows region k in the first marking round (src/bwamem.c:724), from [0] = secondary_all; before any record is emitted
+RC_HD inline int alt_score_of(const rec_t *a, int k)
+{
+	const rec_t &p = a[k];
+	return (!r_alt(p) && p.v[0] >= 0 && r_alt(a[p.v[0]])) ? a[p.v[0]].v[1] : 0;
+}
+// z: n ints of scratch (ALT mode)
+RC_HD inline int emit_all(const ctx_t &x, uint32_t read, float frac_rep, int n, rec_t *a, int32_t *z = nullptr)
 {
 	int l = 0, mapq0 = 0, err = 0;
+	const bool altm = x.ctg_alt != nullptr;
+	if (altm) for (int k = 0; k < n; ++k) z[k] = alt_score_of(a, k);              // (is_alt of another record is gone once that record is emitted)
 	for (int k = 0; k < n; ++k) {
 		rec_t &p = a[k];
 		int mapq, flag, rep;
 		emit_one(x, frac_rep, a, k, &mapq, &flag, &rep, &err);
 		if (err) return -err;
+		const int alt = r_alt(p);
 		if (rep) {
 			if (l && p.v[12] < 0) flag |= x.po.no_multi ? 0x10000 : 0x800;     // src/bwamem.c:1754
-			if (l && mapq > mapq0) mapq = mapq0;
+			if (l && !alt && mapq > mapq0) mapq = mapq0;                        // :1755
 			if (l == 0) mapq0 = mapq;
 			++l;
 		}
+		if (altm) { p.v[11] = p.v[0]; rep |= alt << 1 | (z[k] > 0 ? z[k] << 2 : 0); }
 		p.v[0] = (int32_t)read; p.v[13] = mapq; p.v[14] = flag; p.v[15] = rep;
 	}
 	return n;
@@ -482,9 +532,9 @@ RC_HD inline int finalize_read(const ctx_t &x, const uint8_t *query, uint32_t re
 	for (int i = 0; i < n_in; ++i) init_one(x, a[i]);
 	int n = sort_dedup_patch<ASCII, NSTK>(x, query, n_in, a);
 	if (n < 0) return n;
-	if (x.dedup_only) { for (int i = 0; i < n; ++i) a[i].v[0] = (int32_t)read; return n; }
+	if (x.dedup_only) { for (int i = 0; i < n; ++i) { a[i].v[0] = (int32_t)read; a[i].v[13] &= 0x3FFFFFFF; } return n; }
 	mark_primary<NSTK>(x, n, a, id, z);
-	return emit_all(x, read, frac_rep, n, a);
+	return emit_all(x, read, frac_rep, n, a, z);
 }
 
 } // namespace regs_core

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) fin_lane_kernel(fin_args_t A)
 					dst[2] = make_int4(a[i].v[8], a[i].v[9], a[i].v[10], a[i].v[11]); dst[3] = make_int4(a[i].v[12], a[i].v[13], a[i].v[14], a[i].v[15]);
 				}
 				mark_primary<1>(A.x, n, a, A.x.po.id0 + r, z);
-				n = emit_all(A.x, r, A.frac_rep ? A.frac_rep[r] : 0.f, n, a);
+				n = emit_all(A.x, r, A.frac_rep ? A.frac_rep[r] : 0.f, n, a, z);
 			}
 		}
 		if (n == -NEED_DP) defer = true;
@@ -111,13 +111,14 @@ __global__ void __launch_bounds__(256) fin_lane_kernel(fin_args_t A)
 // ---- the wave form
 struct wptr_t { rec_t *a, *b; uint64_t *keys, *k128; uint32_t *tmp, *order; int32_t *z; };
 
-enum { KEY_RE = 0, KEY_SCORE_RB_QB = 1, KEY_SCORE_HASH = 2 };
+enum { KEY_RE = 0, KEY_SCORE_RB_QB = 1, KEY_SCORE_HASH = 2, KEY_ALT_SCORE_HASH = 3 };
 // 128-bit key whose unsigned lexicographic order is the comparator's strict weak order (lt_re / lt_score_rb_qb / lt_score_hash)
 template <int WHICH> __device__ __forceinline__ void fin_key(const rec_t &r, uint64_t &hi, uint64_t &lo)
 {
 	if (WHICH == KEY_RE) { hi = 0; lo = (uint64_t)r_re(r); }
 	else if (WHICH == KEY_SCORE_RB_QB) { hi = (uint64_t)(0x7FFFFFFFll - (long long)r.v[1]); lo = ((uint64_t)r_rb(r) << 24) | (uint64_t)(uint32_t)(r.v[2] & 0xFFFFFF); }
-	else { hi = (uint64_t)(0x7FFFFFFFll - (long long)r.v[1]); lo = r_hash(r); }
+	else if (WHICH == KEY_SCORE_HASH) { hi = (uint64_t)(0x7FFFFFFFll - (long long)r.v[1]) << 1 | (uint64_t)r_alt(r); lo = r_hash(r); }      // lt_score_hash: score, primary assembly first, hash
+	else { hi = (uint64_t)r_alt(r) << 32 | (uint64_t)(0x7FFFFFFFll - (long long)r.v[1]); lo = r_hash(r); }                                      // lt_alt_score_hash
 }
 
 // a[0..n) sorted as r_introsort<lt> would leave it (same permutation: ties included).  All 64 lanes.  Every record gets its rank,
@@ -145,7 +146,8 @@ template <int WHICH, bool STAGED> __device__ bool fin_wave_sort(wptr_t &P, const
 		const int sc_ = P.a[x].v[1];
 		uint64_t k64 = l;
 		if (WHICH == KEY_SCORE_RB_QB) { small = small && sc_ >= 0 && sc_ < 16384 && (uint32_t)P.a[x].v[2] < 65536u; k64 = ((uint64_t)(16383 - sc_) << 50) | ((uint64_t)r_rb(P.a[x]) << 16) | (uint64_t)(uint32_t)(P.a[x].v[2] & 0xFFFF); }
-		if (WHICH == KEY_SCORE_HASH) { small = small && sc_ >= 0; k64 = (h << 33) | (l >> 31); }
+		if (WHICH == KEY_SCORE_HASH) { small = small && sc_ >= 0; k64 = (h << 32) | (l >> 32); }
+		if (WHICH == KEY_ALT_SCORE_HASH) { small = small && sc_ >= 0; k64 = (h << 31) | (l >> 33); }
 		P.keys[x] = k64;
 	}
 	small = !__any(!small);
@@ -203,7 +205,7 @@ template <int WHICH, bool STAGED> __device__ bool fin_wave_sort(wptr_t &P, const
 		}
 		ties = __any(ties);
 		// equal short keys of the hash order are not ties of the order itself: once more with the full keys
-		if (ties && !wide && WHICH == KEY_SCORE_HASH) { wide = true; continue; }
+		if (ties && !wide && (WHICH == KEY_SCORE_HASH || WHICH == KEY_ALT_SCORE_HASH)) { wide = true; continue; }
 		break;
 	}
 	ch_wave_fence<false>();
@@ -428,7 +430,8 @@ __device__ void fin_wave_mark(const ctx_t &x, const int n, rec_t *a, int32_t *z)
 			const unsigned long long mine = __ballot(have && hit == k);
 			const int sj = a[j].v[1];
 			const unsigned long long nzs = __ballot(have && hit == k && me.v[1] != 0);
-			const unsigned long long near = __ballot(have && hit == k && sj - me.v[1] <= tmp);
+			const int aj = r_alt(a[j]);
+			const unsigned long long near = __ballot(have && hit == k && sj - me.v[1] <= tmp && (aj || !r_alt(me)));
 			if (lane == l1) {
 				if (a[j].v[10] == 0 && nzs) a[j].v[10] = __builtin_amdgcn_readlane(me.v[1], (int)__builtin_ctzll(nzs));
 				a[j].v[11] += (int)__builtin_popcountll(near);
@@ -443,17 +446,23 @@ __device__ void fin_wave_mark(const ctx_t &x, const int n, rec_t *a, int32_t *z)
 
 // the output records (regs_core.h: emit_all) 64 at a time: every record by itself, then the two things that depend on the records
 // before it -- a primary record after the first reported one is supplementary and its MAPQ is capped by that first one's
-__device__ int fin_wave_emit(const ctx_t &x, uint32_t read, float frac_rep, const int n, rec_t *a)
+__device__ int fin_wave_emit(const ctx_t &x, uint32_t read, float frac_rep, const int n, rec_t *a, int32_t *z)
 {
 	int err_any = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 	using namespace chain_core;
 	const int lane = ch_lane();
 	int first = -1, mapq0 = 0;                                   // first reported record and its MAPQ (wave-uniform)
+	const bool altm = x.ctg_alt != nullptr;
+	if (altm) {                                                  // (regs_core.h: emit_all) the ALT score of every record while every record still says whether it is one
+		for (int k = lane; k < n; k += 64) z[k] = alt_score_of(a, k);
+		ch_wave_fence<false>();
+	}
 	for (int b = 0; b < n; b += 64) {
 		const int k = b + lane;
 		const bool have = k < n;
 		int mapq = 0, flag = 0, rep = 0, err = 0;
+		const int alt = have ? r_alt(a[k]) : 0;
 		if (have) emit_one(x, frac_rep, a, k, &mapq, &flag, &rep, &err);
 		const unsigned long long em = __ballot(err != 0);
 		if (em) { err_any = __builtin_amdgcn_readlane(err, (int)__builtin_ctzll(em)); break; }
@@ -461,10 +470,13 @@ __device__ int fin_wave_emit(const ctx_t &x, uint32_t read, float frac_rep, cons
 		if (first < 0 && rm) { const int l0 = (int)__builtin_ctzll(rm); first = b + l0; mapq0 = __builtin_amdgcn_readlane(mapq, l0); }
 		if (have && rep && first >= 0 && k > first) {
 			if (a[k].v[12] < 0) flag |= x.po.no_multi ? 0x10000 : 0x800;
-			if (mapq > mapq0) mapq = mapq0;
+			if (!alt && mapq > mapq0) mapq = mapq0;
 		}
 		ch_wave_fence<false>();                                  // (every lane has read what it needs of the other records: their [1] and [12] are not written here)
-		if (have) { a[k].v[0] = (int32_t)read; a[k].v[13] = mapq; a[k].v[14] = flag; a[k].v[15] = rep; }
+		if (have) {
+			if (altm) { a[k].v[11] = a[k].v[0]; rep |= alt << 1 | (z[k] > 0 ? z[k] << 2 : 0); }
+			a[k].v[0] = (int32_t)read; a[k].v[13] = mapq; a[k].v[14] = flag; a[k].v[15] = rep;
+		}
 	}
 	ch_wave_fence<false>();
 #endif
@@ -519,8 +531,31 @@ template <bool STAGED> __device__ int fin_wave_read(const ctx_t &x, const uint8_
 	if (!fin_wave_sort<KEY_SCORE_HASH, STAGED>(P, n, stage)) return -E_DPCAP;
 	FIN_STAMP(6);
 	fin_wave_mark(x, n, P.a, P.z);
+	if (x.ctg_alt) {                                                // the second round (regs_core.h: mark_second_round), 64 regions at a time
+		int n_pri = 0;
+		for (int b = 0; b < n; b += 64) n_pri += (int)__builtin_popcountll(__ballot(b + lane < n && !r_alt(P.a[b + lane])));
+		if (n_pri == n) { for (int i = lane; i < n; i += 64) P.a[i].v[0] = P.a[i].v[12]; ch_wave_fence<false>(); }
+		else {
+			for (int i = lane; i < n; i += 64) P.a[i].v[0] = i;
+			ch_wave_fence<false>();
+			if (n_pri > 0 && !fin_wave_sort<KEY_ALT_SCORE_HASH, STAGED>(P, n, stage)) return -E_DPCAP;
+			for (int i = lane; i < n; i += 64) P.z[P.a[i].v[0]] = i;
+			ch_wave_fence<false>();
+			for (int i = lane; i < n; i += 64) {
+				rec_t &p = P.a[i];
+				if (p.v[12] >= 0) { p.v[0] = P.z[p.v[12]]; if (r_alt(p)) p.v[12] = 0x7FFFFFFF; }
+				else p.v[0] = -1;
+			}
+			ch_wave_fence<false>();
+			if (n_pri > 0) {
+				for (int i = lane; i < n_pri; i += 64) { P.a[i].v[10] = 0; P.a[i].v[12] = -1; }
+				ch_wave_fence<false>();
+				fin_wave_mark(x, n_pri, P.a, P.z);
+			}
+		}
+	}
 	FIN_STAMP(7);
-	const int rc = fin_wave_emit(x, read, frac_rep, n, P.a);
+	const int rc = fin_wave_emit(x, read, frac_rep, n, P.a, P.z);
 	FIN_STAMP(8);
 	return rc;
 #else
@@ -614,6 +649,7 @@ struct fin_scratch_t {
 	hipStream_t side[3]; hipEvent_t fork, join[3];
 	int32_t *work, *work2; uint64_t *g_keys, *g_k128; uint32_t *g_tmp, *g_order; int32_t *g_z; size_t cap_regs;
 	int32_t *dedup; size_t cap_dedup;       // the regions between the two halves of the tail, for callers that ask (bmh_finalize_regs_device_ex)
+	uint8_t *ctg_alt; int cap_alt;          // the ALT table on the device
 	void *scan_tmp; size_t scan_bytes;
 	double *logtab; int64_t *ctg; int cap_ctg;
 	uint32_t *h_pin;
@@ -641,7 +677,7 @@ extern "C" void bmh_finalize_release(void *stream_)
 		g_fin_map.erase(it);
 	}
 	if (g_fin_last == S) g_fin_last = nullptr;
-	void *ps[] = {S->in_off, S->out_off, S->opr_tmp, S->defer, S->ctr, S->g_dp, S->work, S->work2, S->g_keys, S->g_k128, S->g_tmp, S->g_order, S->g_z, S->scan_tmp, S->logtab, S->ctg, S->dedup};
+	void *ps[] = {S->in_off, S->out_off, S->opr_tmp, S->defer, S->ctr, S->g_dp, S->work, S->work2, S->g_keys, S->g_k128, S->g_tmp, S->g_order, S->g_z, S->scan_tmp, S->logtab, S->ctg, S->dedup, S->ctg_alt};
 	for (void *q : ps) if (q) (void)hipFree(q);
 	if (S->h_pin) (void)hipHostFree(S->h_pin);
 	if (S->ev0) (void)hipEventDestroy(S->ev0);
@@ -707,11 +743,7 @@ static int64_t finalize_regs_device_impl(const bmh_index_t *idx, const bmh_chain
 	if (n_contigs > 1 && !contig_offset) { bmh_set_error("bmh_finalize_regs_device: null contig table"); return BMH_EINVAL; }
 	if (n_regs >> 31) { bmh_set_error("bmh_finalize_regs_device: 2^31 regions or more in one batch"); return BMH_ECAPACITY; }
 	if (n_reads == 0) return 0;
-	if (popt->contig_is_alt && !dedup_only) {
-		// ALT contigs (a second marking round over the primary assembly's hits, secondary_all, alt_sc: src/bwamem.c:714-760) are the host tail's
-		bmh_set_error("bmh_finalize_regs_device: ALT contigs are not modelled on the device: this batch belongs to bmh_finalize_regs");
-		return BMH_ECAPACITY;
-	}
+	const bool alt_mode = popt->contig_is_alt && !dedup_only;      // ALT contigs: the table goes to the device (below), the marking gets its second round
 	if (getenv("BMH_FIN_FORCE_ECAPACITY")) { bmh_set_error("bmh_finalize_regs_device: capacity error forced by BMH_FIN_FORCE_ECAPACITY (test hook of the callers' host fallback)"); return BMH_ECAPACITY; }
 	hipStream_t st = (hipStream_t)stream_;
 	int dev = 0;
@@ -777,6 +809,13 @@ static int64_t finalize_regs_device_impl(const bmh_index_t *idx, const bmh_chain
 	A.x.n_contigs = n_contigs > 1 ? n_contigs : 1; A.x.ctg_off = n_contigs > 1 ? S->ctg : nullptr;
 	A.x.logtab = S->logtab; A.x.n_log = FIN_NLOG; A.x.dp_h = A.x.dp_e = nullptr; A.x.dp_cap = 0; A.x.dedup_only = dedup_only;
 	A.x.po.contig_is_alt = nullptr;                               // (a host pointer: never followed on the device)
+	A.x.ctg_alt = nullptr;
+	if (alt_mode) {
+		const int nc = n_contigs > 1 ? n_contigs : 1;
+		if (nc > S->cap_alt) { if (fin_grow(S->ctg_alt, (size_t)nc) != BMH_OK) return BMH_ENOMEM; S->cap_alt = nc; }
+		HIPCK(hipMemcpyAsync(S->ctg_alt, popt->contig_is_alt, (size_t)nc, hipMemcpyHostToDevice, st));
+		A.x.ctg_alt = S->ctg_alt;
+	}
 	A.reads = d_reads; A.read_offs = d_offs; A.regs_in = d_regs; A.rpr = d_regs_per_read; A.in_off = S->in_off; A.frac_rep = d_frac_rep;
 	A.work = S->work; A.work2 = S->work2; A.g_keys = S->g_keys; A.g_k128 = S->g_k128; A.g_tmp = S->g_tmp; A.g_order = S->g_order; A.g_z = S->g_z;
 	A.opr = d_out_per_read; A.n_reads = n_reads; A.defer = S->defer; A.ctr = S->ctr; A.g_dp = S->g_dp;

@@ -19,6 +19,7 @@ extern "C" int64_t regs_core_run(const bmh_chain_opt_t *copt, const bmh_ext_para
 	ctx_t x; memset(&x, 0, sizeof(x));
 	x.co = *copt; x.ep = *ep; x.po = *popt; x.l_pac = l_pac; x.pac = pac; x.n_contigs = n_contigs; x.ctg_off = contig_offset;
 	x.logtab = logtab.data(); x.n_log = (int)logtab.size();
+	x.ctg_alt = popt->contig_is_alt;                              // (ALT contigs: the table is host memory here)
 	if (with_dp) { x.dp_h = dph.data(); x.dp_e = dpe.data(); x.dp_cap = (int)dph.size(); }
 	uint64_t in = 0, w = 0;
 	std::vector<rec_t> a; std::vector<int32_t> z;

@@ -1060,6 +1060,7 @@ def test_aligner_writes_reference_sam(hip, tmp_path, golden):
     # the native pipeline wrote that text on the device (bmh_sam_text_*); the host formatter from records copied home, and the host's selection
     # of the records that need a CIGAR, give the same bytes -- and so does a batch whose region tail ran on the host (device tail refused)
     for env, val in (("BMH_ALIGNER_HOST_FORMAT", "1"), ("BMH_ALIGNER_HOST_SELECT", "1"), ("BMH_FIN_FORCE_ECAPACITY", "1"), ("BMH_ALIGNER_PE_HOST_DEDUP", "1"), ("BMH_ALIGNER_PE_HOST", "1"),
+                     ("BMH_ALIGNER_ALT_HOST_PATCH", "1"),      # (ALT contigs: the device tail without the table, the reads that touch an ALT contig redone on the host)
                      ("BMH_ALIGNER_STREAM", "0")):          # (STREAM=0: the whole file loaded first, bmh_aligner_run on its cuts, instead of bmh_aligner_run_fasta)
         os.environ[env] = val
         try:
@@ -1141,6 +1142,56 @@ def test_native_pipeline_device_text_equals_host_text(hip, tmp_path, pe):
             a, b = body.split(b"\n"), texts[env].split(b"\n")
             assert False, (env, len(a), len(b), [(x, y) for x, y in zip(a, b) if x != y][:2])
     al.close()
+
+
+@pytest.mark.parametrize("flag_all", [0, 1])
+def test_device_tail_with_alt_contigs_equals_host_tail(hip, flag_all):
+    """bmh_finalize_regs_device WITH an ALT table (second marking round, secondary_all, alt_sc, mem_reg2sam's rules for ALT hits -- lane form and the wave classes)
+    against bmh_finalize_regs with the same table: 40 000 reads of a repeat-rich genome of five sequences two of which are flagged, among them reads with hundreds
+    of regions."""
+    import ctypes as C, torch
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.lib import ChainOpt, ChainWorkspace, PostOpt, load_library, finalize_regs_device, dev_jobs_to_host, _np_ptr, _u8p, _u64p, _i32p, _u32p
+    Lb = load_library()
+    g = synth.make_genome(3_000_000, seed=31, repeat_frac=0.5, repeat_len=(150, 700), repeat_copies=(20, 600), repeat_div=0.02)
+    contigs = [("c1", 1_000_000), ("c2", 900_000), ("c3", 500_000), ("c2_alt", 400_000), ("c3_alt", 200_000)]
+    is_alt = np.ascontiguousarray([0, 0, 0, 1, 1], dtype=np.uint8)
+    c_off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([c[1] for c in contigs])]), dtype=np.int64)
+    idx = fmindex.build_fmd_index(g, device="cuda:0")
+    n, L = 40_000, 150
+    reads = synth.make_reads(g, n, L, seed=3)[0]
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    pac = _pack_pac(g)
+    dindex = hip.Index.upload(idx, pac=pac, l_pac=len(g))
+    ws = hip.SeedWorkspace(n, n * L, max_cands=n * L, max_occ=1 << 22)
+    r = _to_dev(torch, synth.codes_to_ascii(flat))
+    o = (torch.arange(n, dtype=torch.int64) * L).to(torch.int32).cuda()
+    l = torch.full((n,), L, dtype=torch.int32).cuda()
+    s = ws.seed_batch(dindex, r, o, l, 19)
+    cw = ChainWorkspace(n, max(int(s.n_seeds), 1)); cw.set_materialize(False); cw.set_contigs(contigs); cw.set_alt(is_alt)
+    dj = cw.chain_batch(dindex, r, o, l, s)
+    nr = int(dj.n_regs)
+    out3 = torch.zeros(max(int(dj.n_jobs), 1), 3, dtype=torch.int32, device="cuda"); regs = torch.zeros(max(nr, 1), 8, dtype=torch.int32, device="cuda")
+    cw.extend(out3); cw.merge(out3, regs); torch.cuda.synchronize()
+    dh = dev_jobs_to_host(dj, n)
+    co = ChainOpt(); Lb.bmh_chain_opt_default(C.byref(co)); co.contig_is_alt = is_alt.ctypes.data_as(C.c_void_p).value
+    ep = hip.ExtParams.default()
+    po = PostOpt(); Lb.bmh_post_opt_default(C.byref(po)); po.flag_all = flag_all; po.id0 = 1000; po.contig_is_alt = is_alt.ctypes.data_as(C.c_void_p).value
+    out = np.zeros((max(nr, 1), 16), np.int32); opr = np.zeros(n, np.uint32)
+    fr = np.ascontiguousarray(dh["frac_rep"], dtype=np.float32)
+    m = Lb.bmh_finalize_regs(C.byref(co), C.byref(ep), C.byref(po), len(g), _np_ptr(pac, _u8p), n, _np_ptr(flat, _u8p), _np_ptr(np.arange(n, dtype=np.uint64) * L, _u64p),
+                             _np_ptr(np.ascontiguousarray(regs.cpu().numpy()[:nr]), _i32p), _np_ptr(np.ascontiguousarray(dh["regs_per_read"]), _u32p), fr.ctypes.data_as(C.POINTER(C.c_float)),
+                             len(contigs), c_off.ctypes.data_as(C.c_void_p), _np_ptr(out, _i32p), _np_ptr(opr, _u32p), 8)
+    assert m >= 0
+    out = out[:m]
+    d_out, d_opr = finalize_regs_device(dindex, co, ep, po, r, o, regs, nr, dj.d_regs_per_read, dj.d_frac_rep, n, contigs=contigs)
+    got = d_out.cpu().numpy()
+    assert np.array_equal(d_opr.cpu().numpy().view(np.uint32)[:n], opr)
+    if not np.array_equal(got, out):
+        bad = np.nonzero((got != out).any(1))[0]
+        assert False, (len(bad), bad[:5], out[bad[:3]], got[bad[:3]])
+    assert (out[:, 15] & 2).sum() > 2000 and (out[:, 15] >> 2 > 0).sum() > 200 and (out[:, 12] == 0x7FFFFFFF).sum() > 500 and opr.max() > 100
+    cw.free(); ws.free(); dindex.free()
 
 
 def test_device_text_pa_tag_rounds_like_printf(hip):

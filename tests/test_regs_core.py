@@ -92,3 +92,35 @@ def test_region_tail_core_equals_host_form(oracle, case):
     if case == "indels_flag_all":
         assert len(h_out) < len(regs) - 100          # regions were merged / dropped
     hj.free()
+
+
+@pytest.mark.parametrize("flag_all", [0, 1])
+def test_region_tail_core_with_alt_contigs_equals_host_form(oracle, flag_all):
+    """ALT contigs (two-round primary marking, secondary_all, alt_sc, the rules of mem_reg2sam for hits on them): the device core with the table against
+    bmh_finalize_regs with the table, on a repeat-rich genome of four sequences two of which are ALT copies of stretches of the others."""
+    L = load_library()
+    lib = core_lib()
+    rng = np.random.default_rng(21)
+    base = synth.make_genome(360_000, seed=17, repeat_frac=0.4, repeat_len=(150, 600), repeat_copies=(10, 80), repeat_div=0.02)
+    alt1 = base[40_000:70_000].copy(); alt2 = base[200_000:220_000].copy()
+    for a_ in (alt1, alt2):                                       # a diverged copy: a substitution every ~60 bases
+        m = rng.random(len(a_)) < 1 / 60; a_[m] = (a_[m] + rng.integers(1, 4, int(m.sum()))) & 3
+    g = np.ascontiguousarray(np.concatenate([base, alt1, alt2]))
+    contigs = [("c1", 180_000), ("c2", 180_000), ("c1_alt", len(alt1)), ("c2_alt", len(alt2))]
+    is_alt = np.ascontiguousarray([0, 0, 1, 1], dtype=np.uint8)
+    idx = fmindex.build_fmd_index(g)
+    reads, _ = synth.make_reads(g, 3000, 150, seed=6)
+    reads[:1200] = synth.make_reads(g[40_000:70_000], 1200, 150, seed=7)[0]      # reads of a stretch that has an ALT copy
+    flat, offs, lens = common.flat_reads(reads)
+    s = oracle.seed_reads(oracle.fmd(idx), flat, offs, lens, 19, n_threads=4)
+    co = ChainOpt(); L.bmh_chain_opt_default(C.byref(co)); co.contig_is_alt = is_alt.ctypes.data_as(C.c_void_p).value
+    ep = ExtParams.default()
+    hj = HostJobs(g, flat, offs, lens, s, n_threads=4, opt=co, contigs=contigs)
+    o3, _, _ = oracle.extend_batch(*hj.jobs(), n_threads=4)
+    regs = np.ascontiguousarray(hj.merge(o3)); rpr = np.ascontiguousarray(hj.regs_per_read.copy()); fr = np.ascontiguousarray(hj.frac_rep(), dtype=np.float32)
+    po = PostOpt(); L.bmh_post_opt_default(C.byref(po)); po.id0 = 12; po.flag_all = flag_all; po.contig_is_alt = is_alt.ctypes.data_as(C.c_void_p).value
+    (h_out, h_opr), (c_out, c_opr) = both(lib, L, co, ep, po, g, pack(g), np.ascontiguousarray(flat), np.ascontiguousarray(offs), regs, rpr, fr, contigs=contigs)
+    assert np.array_equal(h_opr, c_opr)
+    assert np.array_equal(h_out, c_out), (np.nonzero((h_out != c_out).any(1))[0][:5], h_out[(h_out != c_out).any(1)][:3], c_out[(h_out != c_out).any(1)][:3])
+    assert (h_out[:, 15] & 2).sum() > 300 and (h_out[:, 15] >> 2 > 0).sum() > 100 and (h_out[:, 12] == 0x7FFFFFFF).sum() > 50      # ALT hits, shadowed hits, ALT hits with a parent
+    hj.free()

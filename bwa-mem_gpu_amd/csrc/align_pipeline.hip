@@ -342,7 +342,7 @@ int pairs_on_device(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, co
 	RCK(Ln.d_fin.need(16 * (nr + 1))); RCK(Ln.d_opr.need(n + 1)); RCK(Ln.d_dedup.need(16 * (nr + 1))); RCK(Ln.d_roff.need(n + 1));
 	RCK(Ln.d_hrec.need(n + 1)); RCK(Ln.d_unflag.need(n + 1)); RCK(Ln.d_todo.need(n / 2 + 1)); RCK(Ln.h_todo.need(n / 2 + 1));
 	bmh_fin_extra_t ex; memset(&ex, 0, sizeof(ex));
-	ex.d_dedup_out = Ln.d_dedup.p; ex.d_out_off = Ln.d_roff.p;
+	ex.d_dedup_out = Ln.d_dedup.p; ex.d_out_off = Ln.d_roff.p; ex.alt_keep_sub_n = 1;
 	const int64_t m1 = bmh_finalize_regs_device_ex(A.idx, &A.co, &A.ep, &po, Ln.d_reads.p, Ln.d_offs.p, n, Ln.d_regs.p, nr, dj.d_regs_per_read, dj.d_frac_rep,
 	                                               A.n_contigs, A.n_contigs > 1 ? A.off.data() : nullptr, Ln.d_fin.p, Ln.d_opr.p, Ln.st, &ex);
 	if (m1 < 0) return (int)m1;
@@ -400,9 +400,9 @@ int pairs_on_device(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, co
 	*d_fin_out = Ln.d_fin2.p;
 	R.m = m;
 	if (prof) {
-		uint32_t n1 = 0, n2 = 0;
-		for (uint32_t q = 0; q < n / 2; ++q) { n1 += Ln.h_todo.p[q] == 1; n2 += Ln.h_todo.p[q] == 2; }
-		fprintf(stderr, "[pairs] handed back by the device: %u pairs with a score too close to an integer, %u beyond %d hits\n", n1, n2, bmh_pair_limit());
+		uint32_t n1 = 0, n2 = 0, n3 = 0;
+		for (uint32_t q = 0; q < n / 2; ++q) { n1 += Ln.h_todo.p[q] == 1; n2 += Ln.h_todo.p[q] == 2; n3 += Ln.h_todo.p[q] == 3; }
+		fprintf(stderr, "[pairs] handed back by the device: %u pairs with a score too close to an integer, %u beyond %d hits, %u with a hit on an ALT contig\n", n1, n2, bmh_pair_limit(), n3);
 	}
 	if (prof) fprintf(stderr, "[pairs] on the device: single-end tail + regions to the host %.1f ms, host (statistics, rescue, %u of %u pairs walked) %.1f ms, merge %.1f ms\n",
 	                  (t1 - t0) * 1e3, nt, n / 2, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
@@ -546,7 +546,7 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		R.m = (uint64_t)m;
 	} else {
 		bool pe_done = false;
-		if (text_dev && !A.has_alt && !getenv("BMH_ALIGNER_PE_HOST") && !getenv("BMH_ALIGNER_PE_HOST_DEDUP")) {
+		if (text_dev && !getenv("BMH_ALIGNER_PE_HOST") && !getenv("BMH_ALIGNER_PE_HOST_DEDUP")) {
 			int rc_pd = pairs_on_device(A, Ln, rs, dj, po, codes, host_offs(), b0, n, nr, n_threads, R, &d_fin);
 			if (rc_pd == BMH_OK) pe_done = true;
 			else if (rc_pd != BMH_ECAPACITY) return rc_pd;              // (BMH_ECAPACITY: a read beyond the device tail's fixed limits: the host forms below)

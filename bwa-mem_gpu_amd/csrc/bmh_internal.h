@@ -51,8 +51,8 @@ size_t bmh_cigar_patch_work(uint32_t n_over);
 int64_t bmh_cigar_patch(int32_t *d_aln, uint32_t *d_off, uint32_t *d_packed, uint64_t words, const uint32_t *d_over, uint32_t n_over,
                         const int32_t *d_aln2, const uint32_t *d_cigar2, int mc2, const char *d_md2, int mdc2, void *d_work, size_t work_bytes, void *stream);
 // csrc/regs_kernels.hip: bmh_finalize_regs_device with by-products (in: d_dedup_out [n_regs][16] or NULL, d_out_off [n_reads] or NULL; out: the device's
-// logarithm table and contig offsets, valid until the stream's scratch is released)
-struct bmh_fin_extra_t { int32_t *d_dedup_out; uint32_t *d_out_off; const double *d_logtab; int n_log; const int64_t *d_ctg_off; };
+// logarithm table and contig offsets, valid until the stream's scratch is released; alt_keep_sub_n: with an ALT table [11] stays sub_n -- regs_core.h ctx_t)
+struct bmh_fin_extra_t { int32_t *d_dedup_out; uint32_t *d_out_off; const double *d_logtab; int n_log; const int64_t *d_ctg_off; int alt_keep_sub_n; };
 int64_t bmh_finalize_regs_device_ex(const bmh_index_t *idx, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, const bmh_post_opt_t *popt,
                                     const uint8_t *d_reads, const uint32_t *d_offs, uint32_t n_reads,
                                     const int32_t *d_regs, uint64_t n_regs, const uint32_t *d_regs_per_read, const float *d_frac_rep,

@@ -34,6 +34,7 @@ struct pd_args_t {
 	int32_t *fin; const uint32_t *opr; const uint32_t *off; const float *frac_rep;
 	uint32_t n_pairs; int64_t id0;
 	int32_t *h_rec, *unflag; uint8_t *todo;
+	int alt_mode;                   // the index has ALT contigs: a pair with a hit on one is the host's (todo = 3); the others leave as ALT-mode records ([11] = [12])
 };
 
 __device__ __forceinline__ int pd_infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)      // mem_infer_dir
@@ -60,6 +61,13 @@ __global__ void __launch_bounds__(64) pair_kernel(pd_args_t A)
 	const int n[2] = {(int)A.opr[r0], (int)A.opr[r0 + 1]};
 	rec_t *a[2] = {(rec_t *)(A.fin + 16 * (size_t)A.off[r0]), (rec_t *)(A.fin + 16 * (size_t)A.off[r0 + 1])};
 	if (n[0] + n[1] > PD_NMAX) { A.todo[p] = 2; return; }
+	if (A.alt_mode) {
+		// (the single-end tail ran with the table and left is_alt in bit 1 of [15]; a read without such a hit went through mem_mark_primary_se as without a table --
+		// no second round, secondary_all == secondary --, and nothing below looks at the table: src/bwamem_pair.c:349-356 is for reads WITH an ALT hit)
+		bool any = false;
+		for (int i = 0; i < 2; ++i) for (int j = 0; j < n[i]; ++j) any = any || (a[i][j].v[15] & 2);
+		if (any) { A.todo[p] = 3; return; }
+	}
 	const int64_t l_pac = x.l_pac;
 	const uint64_t id = (uint64_t)(A.id0 / 2) + p;
 	int z[2] = {0, 0}, o = 0, subo = 0, n_sub = 0, extra_flag = 1;
@@ -192,6 +200,7 @@ __global__ void __launch_bounds__(64) pair_kernel(pd_args_t A)
 			A.h_rec[r0 + i] = hh[i]; A.unflag[r0 + i] = any ? 0 : extra;
 		}
 	}
+	if (A.alt_mode) for (int i = 0; i < 2; ++i) for (int j = 0; j < n[i]; ++j) a[i][j].v[11] = a[i][j].v[12];     // ALT-mode records: [11] is the XA tag's key
 	A.todo[p] = 0;
 }
 
@@ -245,7 +254,7 @@ int bmh_pair_device(const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep, con
 	A.pe = *pe;
 	for (int d = 0; d < 4; ++d) { A.pes[d].low = (int)pes[5 * d]; A.pes[d].high = (int)pes[5 * d + 1]; A.pes[d].failed = (int)pes[5 * d + 2]; A.pes[d].avg = pes[5 * d + 3]; A.pes[d].std = pes[5 * d + 4]; }
 	A.fin = d_fin; A.opr = d_opr; A.off = d_off; A.frac_rep = d_frac_rep; A.n_pairs = n_reads / 2; A.id0 = popt->id0;
-	A.h_rec = d_h_rec; A.unflag = d_unflag; A.todo = d_todo;
+	A.h_rec = d_h_rec; A.unflag = d_unflag; A.todo = d_todo; A.alt_mode = popt->contig_is_alt != nullptr;
 	pair_kernel<<<(A.n_pairs + 63) / 64, 64, 0, (hipStream_t)stream>>>(A);
 	HIPCK(hipGetLastError());
 	return BMH_OK;

@@ -41,6 +41,9 @@ struct ctx_t {
 	// carries is_alt in bit 30 of its sequence id ([13]) while the tail runs, the marking has its second round and the records come out as ALT-mode records
 	// ([11] = secondary_all, [15] = reported | is_alt << 1 | alt_sc << 2: see bmh_post_opt_t)
 	const uint8_t *ctg_alt;
+	// 1 (with a table): [11] keeps sub_n -- the form the pairing kernel reads (csrc/pair_dev.hip: it pairs the reads without a hit on an ALT contig, whose
+	// secondary_all is their [12], and needs sub_n for the MAPQ of a hit it promotes; it writes [11] = [12] itself when it is done)
+	int alt_keep_sub_n;
 };
 
 enum { OK = 0, NEED_DP = 1, E_LOG = 2, E_DPCAP = 3 };
@@ -48,8 +51,9 @@ enum { OK = 0, NEED_DP = 1, E_LOG = 2, E_DPCAP = 3 };
 RC_HD inline int64_t r_rb(const rec_t &r) { return (int64_t)(uint32_t)r.v[4] | (int64_t)r.v[5] << 32; }
 RC_HD inline int64_t r_re(const rec_t &r) { return (int64_t)(uint32_t)r.v[6] | (int64_t)r.v[7] << 32; }
 RC_HD inline void r_set_rb(rec_t &r, int64_t x) { r.v[4] = (int32_t)(uint32_t)x; r.v[5] = (int32_t)(x >> 32); }
+RC_HD inline int r_seq(const rec_t &r) { return r.v[13] >= 0 ? r.v[13] & 0x3FFFFFFF : r.v[13]; }      // the sequence id without the ALT bit (-1 stays -1)
 RC_HD inline uint64_t r_hash(const rec_t &r) { return (uint64_t)(uint32_t)r.v[14] | (uint64_t)(uint32_t)r.v[15] << 32; }
-RC_HD inline int r_alt(const rec_t &r) { return (r.v[13] >> 30) & 1; }            // (while the tail runs; the dedup stage compares [13] as a whole: same sequence, same bit)
+RC_HD inline int r_alt(const rec_t &r) { return (int)((uint32_t)r.v[13] >> 30) == 1; }   // (bit 30 of a non-negative id)            // (while the tail runs; the dedup stage compares [13] as a whole: same sequence, same bit)
 
 RC_HD inline int text_base(const uint8_t *pac, int64_t l_pac, int64_t i)
 {
@@ -518,7 +522,7 @@ RC_HD inline int emit_all(const ctx_t &x, uint32_t read, float frac_rep, int n, 
 			if (l == 0) mapq0 = mapq;
 			++l;
 		}
-		if (altm) { p.v[11] = p.v[0]; rep |= alt << 1 | (z[k] > 0 ? z[k] << 2 : 0); }
+		if (altm) { if (!x.alt_keep_sub_n) p.v[11] = p.v[0]; rep |= alt << 1 | (z[k] > 0 ? z[k] << 2 : 0); }
 		p.v[0] = (int32_t)read; p.v[13] = mapq; p.v[14] = flag; p.v[15] = rep;
 	}
 	return n;
@@ -532,7 +536,7 @@ RC_HD inline int finalize_read(const ctx_t &x, const uint8_t *query, uint32_t re
 	for (int i = 0; i < n_in; ++i) init_one(x, a[i]);
 	int n = sort_dedup_patch<ASCII, NSTK>(x, query, n_in, a);
 	if (n < 0) return n;
-	if (x.dedup_only) { for (int i = 0; i < n; ++i) { a[i].v[0] = (int32_t)read; a[i].v[13] &= 0x3FFFFFFF; } return n; }
+	if (x.dedup_only) { for (int i = 0; i < n; ++i) { a[i].v[0] = (int32_t)read; a[i].v[13] = r_seq(a[i]); } return n; }
 	mark_primary<NSTK>(x, n, a, id, z);
 	return emit_all(x, read, frac_rep, n, a, z);
 }

@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) fin_lane_kernel(fin_args_t A)
 				for (int i = 0; i < n; ++i) {
 					int4 *dst = (int4 *)(A.dedup_out + 16 * (size_t)(off + i));
 					dst[0] = make_int4((int)r, a[i].v[1], a[i].v[2], a[i].v[3]); dst[1] = make_int4(a[i].v[4], a[i].v[5], a[i].v[6], a[i].v[7]);
-					dst[2] = make_int4(a[i].v[8], a[i].v[9], a[i].v[10], a[i].v[11]); dst[3] = make_int4(a[i].v[12], a[i].v[13], a[i].v[14], a[i].v[15]);
+					dst[2] = make_int4(a[i].v[8], a[i].v[9], a[i].v[10], a[i].v[11]); dst[3] = make_int4(a[i].v[12], r_seq(a[i]), a[i].v[14], a[i].v[15]);   // (the sequence without the ALT bit)
 				}
 				mark_primary<1>(A.x, n, a, A.x.po.id0 + r, z);
 				n = emit_all(A.x, r, A.frac_rep ? A.frac_rep[r] : 0.f, n, a, z);
@@ -474,7 +474,7 @@ __device__ int fin_wave_emit(const ctx_t &x, uint32_t read, float frac_rep, cons
 		}
 		ch_wave_fence<false>();                                  // (every lane has read what it needs of the other records: their [1] and [12] are not written here)
 		if (have) {
-			if (altm) { a[k].v[11] = a[k].v[0]; rep |= alt << 1 | (z[k] > 0 ? z[k] << 2 : 0); }
+			if (altm) { if (!x.alt_keep_sub_n) a[k].v[11] = a[k].v[0]; rep |= alt << 1 | (z[k] > 0 ? z[k] << 2 : 0); }
 			a[k].v[0] = (int32_t)read; a[k].v[13] = mapq; a[k].v[14] = flag; a[k].v[15] = rep;
 		}
 	}
@@ -525,7 +525,7 @@ template <bool STAGED> __device__ int fin_wave_read(const ctx_t &x, const uint8_
 		ch_wave_fence<false>();
 		return n;
 	}
-	if (dedup_out) for (int i = lane; i < n; i += 64) { rec_t t = P.a[i]; t.v[0] = (int32_t)read; dedup_out[i] = t; }
+	if (dedup_out) for (int i = lane; i < n; i += 64) { rec_t t = P.a[i]; t.v[0] = (int32_t)read; t.v[13] = r_seq(t); dedup_out[i] = t; }     // (the sequence without the ALT bit)
 	for (int i = lane; i < n; i += 64) mark_init_one(P.a[i], id, i);
 	ch_wave_fence<false>();
 	if (!fin_wave_sort<KEY_SCORE_HASH, STAGED>(P, n, stage)) return -E_DPCAP;
@@ -809,7 +809,7 @@ static int64_t finalize_regs_device_impl(const bmh_index_t *idx, const bmh_chain
 	A.x.n_contigs = n_contigs > 1 ? n_contigs : 1; A.x.ctg_off = n_contigs > 1 ? S->ctg : nullptr;
 	A.x.logtab = S->logtab; A.x.n_log = FIN_NLOG; A.x.dp_h = A.x.dp_e = nullptr; A.x.dp_cap = 0; A.x.dedup_only = dedup_only;
 	A.x.po.contig_is_alt = nullptr;                               // (a host pointer: never followed on the device)
-	A.x.ctg_alt = nullptr;
+	A.x.ctg_alt = nullptr; A.x.alt_keep_sub_n = extra ? extra->alt_keep_sub_n : 0;
 	if (alt_mode) {
 		const int nc = n_contigs > 1 ? n_contigs : 1;
 		if (nc > S->cap_alt) { if (fin_grow(S->ctg_alt, (size_t)nc) != BMH_OK) return BMH_ENOMEM; S->cap_alt = nc; }

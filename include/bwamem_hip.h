@@ -292,7 +292,8 @@ typedef struct {
 	 * 2323; src/bwamem_extra.c:106-150).  With a table that flags at least one sequence the records change in two places:
 	 * [11] holds secondary_all (the parent of the FIRST marking round over all hits, which the XA tag goes by) instead of sub_n, and
 	 * [15] = reported | is_alt << 1 | alt_sc << 2 ([12] secondary is INT_MAX for an ALT hit that has a parent, as in the reference).
-	 * Host tail only: bmh_finalize_regs_device answers BMH_ECAPACITY for such a table and the caller takes bmh_finalize_regs. */
+	 * bmh_finalize_regs and bmh_finalize_regs_device both take the table (the device form uploads it; the second marking round,
+	 * secondary_all and alt_sc are in csrc/regs_core.h and the wave classes of csrc/regs_kernels.hip): same records. */
 	const uint8_t *contig_is_alt;
 } bmh_post_opt_t;
 void bmh_post_opt_default(bmh_post_opt_t *o);
@@ -542,8 +543,8 @@ int bmh_sam_text_check(const void *d_work, uint32_t n_reads, void *stream);
  * thread hands every batch's text to `sink` in order (return 0 to go on) while the workers are on the next ones.  Interleaved pairs:
  * mem_sort_dedup_patch, mem_mark_primary_se and, for the pairs the mate rescue does not touch, mem_pair and mem_sam_pe's choices on
  * the device too; the insert-size statistics, the rescue's bookkeeping and the pairs it touches on n_threads host threads in the
- * middle of the batch.  An index with ALT contigs: the region tail of the reads that touch one is redone on host threads and put in
- * place on the device (pairs: all of mem_sam_pe on the host), the rest as above.  A batch the device tail refuses (BMH_ECAPACITY)
+ * middle of the batch.  An index with ALT contigs: single-end as above (the device tail knows the ALT rules); pairs: all of
+ * mem_sam_pe on the host, the text on the device.  A batch the device tail refuses (BMH_ECAPACITY)
  * takes the host tail.  The text is what
  * bmh_format_sam / bmh_format_sam_pe write, byte for byte (records only: the caller writes the @SQ header).
  * cuts: n_batches + 1 read indices, cuts[0] = 0, cuts[n_batches] = n_reads, even batch sizes when paired (the reference cuts its

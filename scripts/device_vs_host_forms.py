@@ -1,6 +1,7 @@
 """One-off parity run at bench scale: bmh_aligner_run on N reads against the hg38-scale synthetic index, the device forms (selection, packed CIGARs, SAM text,
 pairing on the device) against the host forms (BMH_ALIGNER_HOST_FORMAT, BMH_ALIGNER_PE_HOST): sha256 of the text per mode.
-usage: device_vs_host_forms.py [genome_mbp] [n_reads] [read_len]"""
+usage: device_vs_host_forms.py [genome_mbp] [n_reads] [read_len]      FORMS_ALT=<n>: the last n sequences are ALT contigs (single-end: the device tail's ALT rules
+against the host tail's, BMH_ALIGNER_ALT_HOST_PATCH)"""
 import os, sys, hashlib, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))
@@ -23,7 +24,12 @@ d = F.build_fmd_index_device(pac_t, n_genome, sa_intv=1)
 dindex = B.Index.from_device(d.primary, d.L2.astype(np.uint64), d.seq_len, d.bwt_t, d.sa_intv, d.sa_t, d.bits_t, pac_t=pac_t, l_pac=n_genome)
 torch.cuda.empty_cache()
 co = ChainOpt(); L.bmh_chain_opt_default(C.byref(co)); po = PostOpt(); L.bmh_post_opt_default(C.byref(po)); pe_o = PeOpt(); L.bmh_pe_opt_default(C.byref(pe_o))
-nat = NativeAligner(dindex, pac_t.cpu().numpy(), n_genome, meta["contigs"], None, co, B.ExtParams.default(), po, pe_o)
+n_alt = int(os.environ.get("FORMS_ALT", "0"))
+is_alt = None
+if n_alt:
+    is_alt = np.zeros(len(meta["contigs"]), np.uint8); is_alt[-n_alt:] = 1
+    print("ALT contigs:", [c[0] for c in meta["contigs"][-n_alt:]], flush=True)
+nat = NativeAligner(dindex, pac_t.cpu().numpy(), n_genome, meta["contigs"], is_alt, co, B.ExtParams.default(), po, pe_o)
 nth = L.bmh_effective_cpus()
 bad = 0
 for paired in (False, True):
@@ -37,7 +43,7 @@ for paired in (False, True):
                      np.arange(n_reads, dtype=np.uint64) * np.uint64(w + 2), codes=flat)
         cuts = [0, (n_reads // 2) & ~1, n_reads]
         hs = {}
-        for env in ("", "BMH_ALIGNER_HOST_FORMAT") + (("BMH_ALIGNER_PE_HOST",) if paired else ()):
+        for env in ("", "BMH_ALIGNER_HOST_FORMAT") + (("BMH_ALIGNER_PE_HOST",) if paired else ()) + (("BMH_ALIGNER_ALT_HOST_PATCH",) if n_alt and not paired else ()):
             if env:
                 os.environ[env] = "1"
             h = hashlib.sha256(); nb = [0]

@@ -1144,6 +1144,50 @@ def test_native_pipeline_device_text_equals_host_text(hip, tmp_path, pe):
     al.close()
 
 
+@pytest.mark.parametrize("pe", [False, True])
+def test_native_pipeline_with_alt_contigs_device_forms_equal_host_forms(hip, tmp_path, pe):
+    """An index with ALT contigs (<prefix>.alt) through bmh_aligner_run: the device tail's ALT rules and, for pairs, pair_kernel (pairs without a hit on an ALT
+    contig) + the host's mem_sam_pe (the others), against the host forms: the host tail of the reads that touch an ALT contig (BMH_ALIGNER_ALT_HOST_PATCH), all
+    of mem_sam_pe on the host (BMH_ALIGNER_PE_HOST), the host's formatter, and the Python loop (host tail of every read)."""
+    import io
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.aligner import Aligner
+    g = synth.make_genome(1_500_000, seed=12, repeat_frac=0.4, repeat_len=(150, 600), repeat_copies=(4, 60), repeat_div=0.02)
+    contigs = [("chrA", 600_000), ("chrB", 500_000), ("chrB_alt1", 250_000), ("chrA_alt1", 150_000)]
+    prefix = str(tmp_path / "g.fa")
+    fmindex.write_index(prefix, fmindex.build_fmd_index(g)); fmindex.write_bns(prefix, g, contigs=contigs)
+    with open(prefix + ".alt", "w") as f:
+        f.write("@SQ\tSN:chrB_alt1\nchrB_alt1\t0\tchrB\t1\t60\t100M\nchrA_alt1\t0\tchrA\t1\t60\t100M\n")
+    n, L = 20000, 150
+    reads = (synth.make_pairs(g, n // 2, L, seed=6) if pe else synth.make_reads(g, n, L, seed=6))[0]
+    fq = str(tmp_path / "r.fa")
+    with open(fq, "wb") as f:
+        for i, a in enumerate(synth.codes_to_ascii(reads)):
+            f.write((b">p%d\n" % (i // 2)) if pe else (b">r%d\n" % i)); f.write(a.tobytes()); f.write(b"\n")
+    al = Aligner(prefix, n_threads=4)
+    assert al.has_alt
+    texts = {}
+    for env in ("", "BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_PE_HOST" if pe else "BMH_ALIGNER_ALT_HOST_PATCH", "BMH_ALIGNER_NATIVE"):
+        if env:
+            os.environ[env] = "0" if env == "BMH_ALIGNER_NATIVE" else "1"
+        try:
+            buf = io.BytesIO()
+            al.align_file(fq, buf, batch_reads=8000, paired=pe)
+            texts[env] = buf.getvalue()
+        finally:
+            if env:
+                del os.environ[env]
+    body = texts[""]
+    lines = [l.split(b"\t") for l in body.split(b"\n") if l and not l.startswith(b"@")]
+    on_alt = sum(1 for l in lines if l[2].endswith(b"_alt1"))
+    assert len(lines) >= n and on_alt > 500 and body.count(b"\tpa:f:") > 100 and b"\tXA:Z:" in body, (len(lines), on_alt, body.count(b"\tpa:f:"))
+    for env in [e for e in texts if e]:
+        if texts[env] != body:
+            a, b = body.split(b"\n"), texts[env].split(b"\n")
+            assert False, (env, len(a), len(b), [(x, y) for x, y in zip(a, b) if x != y][:2])
+    al.close()
+
+
 @pytest.mark.parametrize("flag_all", [0, 1])
 def test_device_tail_with_alt_contigs_equals_host_tail(hip, flag_all):
     """bmh_finalize_regs_device WITH an ALT table (second marking round, secondary_all, alt_sc, mem_reg2sam's rules for ALT hits -- lane form and the wave classes)

@@ -61,23 +61,21 @@ __global__ void __launch_bounds__(64) pair_kernel(pd_args_t A)
 	const int n[2] = {(int)A.opr[r0], (int)A.opr[r0 + 1]};
 	rec_t *a[2] = {(rec_t *)(A.fin + 16 * (size_t)A.off[r0]), (rec_t *)(A.fin + 16 * (size_t)A.off[r0 + 1])};
 	if (n[0] + n[1] > PD_NMAX) { A.todo[p] = 2; return; }
-	if (A.alt_mode) {
-		// (the single-end tail ran with the table and left is_alt in bit 1 of [15]; a read without such a hit went through mem_mark_primary_se as without a table --
-		// no second round, secondary_all == secondary --, and nothing below looks at the table: src/bwamem_pair.c:349-356 is for reads WITH an ALT hit)
-		bool any = false;
-		for (int i = 0; i < 2; ++i) for (int j = 0; j < n[i]; ++j) any = any || (a[i][j].v[15] & 2);
-		if (any) { A.todo[p] = 3; return; }
-	}
+	// ALT contigs: the single-end tail ran with the table (ctx_t::alt_keep_sub_n): the hits of the primary assembly come first (n_pri of them: mem_pair and the
+	// is_multi test look at those only, src/bwamem_pair.c:287-295), [15] carries is_alt (bit 1) and alt_sc, [12] is `secondary` of the second marking round and
+	// secondary_all + 1 rides above the MAPQ in [13]
+	int n_pri[2] = {n[0], n[1]};
+	if (A.alt_mode) for (int i = 0; i < 2; ++i) { n_pri[i] = 0; for (int j = 0; j < n[i]; ++j) n_pri[i] += !(a[i][j].v[15] & 2); }
 	const int64_t l_pac = x.l_pac;
 	const uint64_t id = (uint64_t)(A.id0 / 2) + p;
 	int z[2] = {0, 0}, o = 0, subo = 0, n_sub = 0, extra_flag = 1;
 	bool paired = false, uncertain = false;
-	if (!A.pe.no_pairing && n[0] && n[1]) {
+	if (!A.pe.no_pairing && n_pri[0] && n_pri[1]) {
 		// ---- mem_pair: the hits of both reads by position
 		uint64_t vx[PD_NMAX], vy[PD_NMAX];
 		int nv = 0;
 		for (int r = 0; r < 2; ++r)
-			for (int i = 0; i < n[r]; ++i) {
+			for (int i = 0; i < n_pri[r]; ++i) {
 				const rec_t &e = a[r][i];
 				const int64_t rb = r_rb(e), re = r_re(e);
 				const int rid = pos2rid(x, rb < l_pac ? rb : (l_pac << 1) - 1 - (re - 1));
@@ -135,8 +133,8 @@ __global__ void __launch_bounds__(64) pair_kernel(pd_args_t A)
 			int is_multi[2];
 			for (int i = 0; i < 2; ++i) {
 				int j;
-				for (j = 1; j < n[i]; ++j) if (a[i][j].v[12] < 0 && a[i][j].v[1] >= x.po.T) break;
-				is_multi[i] = j < n[i] ? 1 : 0;
+				for (j = 1; j < n_pri[i]; ++j) if (a[i][j].v[12] < 0 && a[i][j].v[1] >= x.po.T) break;
+				is_multi[i] = j < n_pri[i] ? 1 : 0;
 			}
 			if (!is_multi[0] && !is_multi[1]) {
 				paired = true;
@@ -163,18 +161,30 @@ __global__ void __launch_bounds__(64) pair_kernel(pd_args_t A)
 					q_se[0] = approx_mapq(x, a[0][0], A.frac_rep[r0], &err);
 					q_se[1] = approx_mapq(x, a[1][0], A.frac_rep[r0 + 1], &err);
 				}
+				// the best ALT hit of a read goes along as a supplementary record (src/bwamem_pair.c:349-356)
+				int supp_q[2] = {-1, -1};
+				if (A.alt_mode) {
+					for (int i = 0; i < 2; ++i) {
+						if (n_pri[i] >= n[i]) continue;
+						const rec_t &q = a[i][n_pri[i]];
+						if (!(q.v[1] < x.po.T || q.v[12] >= 0 || !(q.v[15] & 2))) supp_q[i] = approx_mapq(x, q, A.frac_rep[r0 + i], &err);
+					}
+					// from here on [12] is secondary_all, as in the records the host's mem_sam_pe leaves (`secondary` has been read for the last time)
+					for (int i = 0; i < 2; ++i) for (int j = 0; j < n[i]; ++j) { a[i][j].v[12] = (a[i][j].v[13] >> 8) - 1; a[i][j].v[13] &= 0xFF; }
+				}
 				if (err) { A.todo[p] = 2; return; }
 				for (int i = 0; i < 2; ++i) {                              // the chosen hit becomes the primary of its group (for the XA tag)
 					const int k = a[i][z[i]].v[12];
-					if (k >= 0 && k < n[i]) {
+					if (k >= 0 && k < n_pri[i]) {
 						for (int j = 0; j < n[i]; ++j) if (a[i][j].v[12] == k || j == k) a[i][j].v[12] = z[i];
 						a[i][z[i]].v[12] = -1;
 					}
 				}
 				for (int i = 0; i < 2; ++i) {
-					for (int j = 0; j < n[i]; ++j) { a[i][j].v[13] = 0; a[i][j].v[14] = 0; a[i][j].v[15] = 0; }
+					for (int j = 0; j < n[i]; ++j) { a[i][j].v[13] = 0; a[i][j].v[14] = 0; a[i][j].v[15] &= ~1; }     // (is_alt and alt_sc stay; without a table [15] is `reported` alone)
 					rec_t &c = a[i][z[i]];
-					c.v[15] = 1; c.v[13] = q_se[i]; c.v[14] = 0x40 << i | extra_flag;
+					c.v[15] |= 1; c.v[13] = q_se[i]; c.v[14] = 0x40 << i | extra_flag;
+					if (supp_q[i] >= 0) { rec_t &q = a[i][n_pri[i]]; q.v[15] |= 1; q.v[13] = supp_q[i]; q.v[14] = 0x800 | 0x40 << i | extra_flag; }
 					A.h_rec[r0 + i] = z[i]; A.unflag[r0 + i] = 0;
 				}
 			}
@@ -200,7 +210,14 @@ __global__ void __launch_bounds__(64) pair_kernel(pd_args_t A)
 			A.h_rec[r0 + i] = hh[i]; A.unflag[r0 + i] = any ? 0 : extra;
 		}
 	}
-	if (A.alt_mode) for (int i = 0; i < 2; ++i) for (int j = 0; j < n[i]; ++j) a[i][j].v[11] = a[i][j].v[12];     // ALT-mode records: [11] is the XA tag's key
+	if (A.alt_mode) {                                               // ALT-mode records: [11] = [12] = secondary_all (the XA tag's key), [13] the MAPQ alone
+		for (int i = 0; i < 2; ++i)
+			for (int j = 0; j < n[i]; ++j) {
+				rec_t &q = a[i][j];
+				if (!paired) { q.v[12] = (q.v[13] >> 8) - 1; q.v[13] &= 0xFF; }
+				q.v[11] = q.v[12];
+			}
+	}
 	A.todo[p] = 0;
 }
 

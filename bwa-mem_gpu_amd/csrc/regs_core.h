@@ -41,8 +41,8 @@ struct ctx_t {
 	// carries is_alt in bit 30 of its sequence id ([13]) while the tail runs, the marking has its second round and the records come out as ALT-mode records
 	// ([11] = secondary_all, [15] = reported | is_alt << 1 | alt_sc << 2: see bmh_post_opt_t)
 	const uint8_t *ctg_alt;
-	// 1 (with a table): [11] keeps sub_n -- the form the pairing kernel reads (csrc/pair_dev.hip: it pairs the reads without a hit on an ALT contig, whose
-	// secondary_all is their [12], and needs sub_n for the MAPQ of a hit it promotes; it writes [11] = [12] itself when it is done)
+	// 1 (with a table): [11] keeps sub_n and secondary_all + 1 rides in [13] above the MAPQ's eight bits -- the form the pairing kernel reads (csrc/pair_dev.hip:
+	// it needs sub_n for the MAPQ of a hit it promotes and of the ALT hit it adds; it writes ALT-mode records itself when it is done)
 	int alt_keep_sub_n;
 };
 
@@ -522,7 +522,7 @@ RC_HD inline int emit_all(const ctx_t &x, uint32_t read, float frac_rep, int n, 
 			if (l == 0) mapq0 = mapq;
 			++l;
 		}
-		if (altm) { if (!x.alt_keep_sub_n) p.v[11] = p.v[0]; rep |= alt << 1 | (z[k] > 0 ? z[k] << 2 : 0); }
+		if (altm) { if (!x.alt_keep_sub_n) p.v[11] = p.v[0]; else mapq |= (p.v[0] + 1) << 8; rep |= alt << 1 | (z[k] > 0 ? z[k] << 2 : 0); }
 		p.v[0] = (int32_t)read; p.v[13] = mapq; p.v[14] = flag; p.v[15] = rep;
 	}
 	return n;

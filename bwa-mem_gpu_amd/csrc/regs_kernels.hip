@@ -474,7 +474,7 @@ __device__ int fin_wave_emit(const ctx_t &x, uint32_t read, float frac_rep, cons
 		}
 		ch_wave_fence<false>();                                  // (every lane has read what it needs of the other records: their [1] and [12] are not written here)
 		if (have) {
-			if (altm) { if (!x.alt_keep_sub_n) a[k].v[11] = a[k].v[0]; rep |= alt << 1 | (z[k] > 0 ? z[k] << 2 : 0); }
+			if (altm) { if (!x.alt_keep_sub_n) a[k].v[11] = a[k].v[0]; else mapq |= (a[k].v[0] + 1) << 8; rep |= alt << 1 | (z[k] > 0 ? z[k] << 2 : 0); }
 			a[k].v[0] = (int32_t)read; a[k].v[13] = mapq; a[k].v[14] = flag; a[k].v[15] = rep;
 		}
 	}

@@ -543,8 +543,7 @@ int bmh_sam_text_check(const void *d_work, uint32_t n_reads, void *stream);
  * thread hands every batch's text to `sink` in order (return 0 to go on) while the workers are on the next ones.  Interleaved pairs:
  * mem_sort_dedup_patch, mem_mark_primary_se and, for the pairs the mate rescue does not touch, mem_pair and mem_sam_pe's choices on
  * the device too; the insert-size statistics, the rescue's bookkeeping and the pairs it touches on n_threads host threads in the
- * middle of the batch.  An index with ALT contigs: single-end as above (the device tail knows the ALT rules); pairs: the ones with a
- * hit on an ALT contig go to the host's mem_sam_pe as well, the others are paired on the device.  A batch the device tail refuses (BMH_ECAPACITY)
+ * middle of the batch.  An index with ALT contigs: the same (the device tail and the pairing kernel know the ALT rules).  A batch the device tail refuses (BMH_ECAPACITY)
  * takes the host tail.  The text is what
  * bmh_format_sam / bmh_format_sam_pe write, byte for byte (records only: the caller writes the @SQ header).
  * cuts: n_batches + 1 read indices, cuts[0] = 0, cuts[n_batches] = n_reads, even batch sizes when paired (the reference cuts its

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(64) pair_kernel(pd_args_t A)
 				}
 				y[vy[i] & 3] = i;
 			}
-			if (nu == 0) break;
+			if (nu <= 1) break;                                      // (the second pass counts the pairs beside the best one: none)
 		}
 		if (nu > 0) {
 			const int i = (int)(by >> 32), k = (int)(by << 32 >> 32);

@@ -181,7 +181,9 @@ def test_reads_to_sam_device_forms_equal_host_forms_beyond_2_pow_32(hip):
     """bmh_aligner_run on a 2.2 Gbp hg38-like genome (24 sequences, seq_len 4.4e9, 50 % repeats), 200 000 single-end reads and 100 000 pairs: the
     text the device writes (records selected, CIGARs packed, SAM assembled on the device; pairs: mem_pair / mem_sam_pe's choices on the device for
     the pairs the rescue leaves alone) is byte for byte the text of the host forms (bmh_sam_need_cigar + bmh_format_sam[_pe]; all pairs through the
-    host walks of mem_sam_pe), at positions beyond 2^32 and on reads with hundreds of hits."""
+    host walks of mem_sam_pe), at positions beyond 2^32 and on reads with hundreds of hits.  Then the same with the last three sequences flagged as
+    ALT contigs: the device tail's second marking round and pair_kernel's ALT rules against the host tail (BMH_ALIGNER_ALT_HOST_PATCH) and the host's
+    mem_sam_pe (BMH_ALIGNER_PE_HOST)."""
     import ctypes as C
     import torch
     B = hip
@@ -202,9 +204,12 @@ def test_reads_to_sam_device_forms_equal_host_forms_beyond_2_pow_32(hip):
     pe_o = PeOpt(); L.bmh_pe_opt_default(C.byref(pe_o))
     pac_h = pac_t.cpu().numpy()
     nat = NativeAligner(dindex, pac_h, n, meta["contigs"], None, co, B.ExtParams.default(), po, pe_o)
+    # the same index with its last three sequences flagged as ALT contigs: the device tail's and the pairing kernel's ALT rules against the host's
+    is_alt = np.zeros(len(meta["contigs"]), np.uint8); is_alt[-3:] = 1
+    nat_alt = NativeAligner(dindex, pac_h, n, meta["contigs"], is_alt, co, B.ExtParams.default(), po, pe_o)
     nth = L.bmh_effective_cpus()
     n_reads, rl = 200_000, 150
-    for paired in (False, True):
+    for paired, alt in ((False, False), (True, False), (False, True), (True, True)):
         reads = (synth.make_pairs(g, n_reads // 2, rl, seed=21, holes=meta["holes"]) if paired else synth.make_reads(g, n_reads, rl, seed=21, holes=meta["holes"]))[0]
         flat = np.ascontiguousarray(np.asarray(reads, np.uint8).reshape(-1))
         w = len(str(n_reads))
@@ -214,22 +219,24 @@ def test_reads_to_sam_device_forms_equal_host_forms_beyond_2_pow_32(hip):
                      np.arange(n_reads, dtype=np.uint64) * np.uint64(w + 2), codes=flat)
         cuts = [0, (n_reads // 3) & ~1, (2 * n_reads // 3) & ~1, n_reads]
         texts = {}
-        for env in ("", "BMH_ALIGNER_HOST_FORMAT") + (("BMH_ALIGNER_PE_HOST",) if paired else ()):
+        for env in ("", "BMH_ALIGNER_HOST_FORMAT") + (("BMH_ALIGNER_PE_HOST",) if paired else ()) + (("BMH_ALIGNER_ALT_HOST_PATCH",) if alt and not paired else ()):
             if env:
                 os.environ[env] = "1"
             try:
                 parts = []
-                nat.run(rs, cuts, paired, lambda mv: parts.append(bytes(mv)), n_lanes=2, n_threads=nth)
+                (nat_alt if alt else nat).run(rs, cuts, paired, lambda mv: parts.append(bytes(mv)), n_lanes=2, n_threads=nth)
                 texts[env] = b"".join(parts)
             finally:
                 if env:
                     del os.environ[env]
         body = texts[""]
         assert body.count(b"\n") >= n_reads and b"\tXA:Z:" in body
+        if alt:
+            assert body.count(b"\tpa:f:") > 200, body.count(b"\tpa:f:")
         pos = np.array([int(l.split(b"\t")[3]) for l in body.split(b"\n")[:20000] if l and l.split(b"\t")[2] != b"*"])
         assert pos.max() > 100_000_000
         for env, t in texts.items():
             if t != body:
                 a, b = body.split(b"\n"), t.split(b"\n")
-                assert False, (paired, env, len(a), len(b), [(x, y) for x, y in zip(a, b) if x != y][:2])
-    nat.free(); dindex.free()
+                assert False, (paired, alt, env, len(a), len(b), [(x, y) for x, y in zip(a, b) if x != y][:2])
+    nat.free(); nat_alt.free(); dindex.free()

@@ -384,6 +384,7 @@ struct bmh_chain_ws {
 	uint32_t *h_pin;               // pinned host words for the small D2H copies
 	bmh_chain_opt_t last_opt;      // the options of the last batch (the merge kernels' score of a bare seed depends on them)
 	hipStream_t side; hipEvent_t ev_fork, ev_join;   // the wave kernels run beside the lane kernel
+	hipStream_t st_hi;                // bmh_chain_extend_merge: classification, lane kernel and counts (what the first extension pass waits for) at the highest priority
 	hipStream_t cls_stream[CH_N_CLASSES]; hipEvent_t cls_done[CH_N_CLASSES]; // ... and beside each other, one stream per size class
 	hipEvent_t ev_t[8]; float ms[8]; uint32_t heavy_per_class[CH_N_CLASSES];
 	// bmh_chain_extend_merge: the batch in two passes (reads of the lane kernel, reads of the wave kernels)
@@ -405,6 +406,7 @@ extern "C" void bmh_chain_ws_free(bmh_chain_ws_t *w)
 	for (void *p : ps) if (p) (void)hipFree(p);
 	if (w->h_pin) (void)hipHostFree(w->h_pin);
 	if (w->side) (void)hipStreamDestroy(w->side);
+	if (w->st_hi) (void)hipStreamDestroy(w->st_hi);
 	if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
 	if (w->ev_join) (void)hipEventDestroy(w->ev_join);
 	for (hipEvent_t e : w->ev_t) if (e) (void)hipEventDestroy(e);
@@ -456,6 +458,10 @@ extern "C" bmh_chain_ws_t *bmh_chain_ws_create(uint32_t max_reads, uint64_t max_
 	const int cls_prio = pe && pe[0] == 'h' ? prio_hi : pe && pe[0] == 'n' ? 0 : prio_lo;
 	// (BMH_CHAIN_CUS=n: experiment knob -- the wave kernels' streams confined to n of the chip's compute units, evenly spread, so that
 	// their LDS-hungry waves displace extension waves on those units only; measured in DESIGN.md section 5)
+	// bmh_chain_extend_merge: classification, lane kernel and the counts of the first pass -- short kernels the batch's first extension pass waits for -- on a stream
+	// of the highest priority: beside another batch's extension they were stretched from 1.5 to 3-4 ms (measured: 35.1-35.2 -> 35.8-36.1 Mreads/s on top of the
+	// seeding's priority stream; BMH_CHAIN_LIGHT_PRIO=normal: A/B)
+	{ const char *le = getenv("BMH_CHAIN_LIGHT_PRIO"); if (!(le && le[0] == 'n')) ok = ok && hipStreamCreateWithPriority(&w->st_hi, hipStreamNonBlocking, prio_hi) == hipSuccess; }
 	const char *cue = getenv("BMH_CHAIN_CUS");
 	const int n_cus = cue ? atoi(cue) : 0;
 	uint32_t cumask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -845,6 +851,10 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	if (n_reads == 0) return BMH_OK;
 	chain_args_t A;
 	chain_fill_args(w, A, opt, idx, d_reads, d_offs, d_lens, n_reads, seeds);
+	// (the host waits for the caller's stream -- the seeds -- and the short kernels go to the priority stream: a barrier packet waiting in a high-priority queue
+	// costs what the priority gains, see bmh_seed_batch)
+	hipStream_t st_user = st;
+	if (w->st_hi) { HIPCK(hipStreamSynchronize(st)); st = w->st_hi; }
 	{ const int rc = chain_launch(w, A, st, false); if (rc != BMH_OK) return rc; }
 	// ---- pass A: the reads of the lane kernel
 	// (the counts of a pass are read through a transform iterator: no pass over the reads to mask them first)
@@ -859,6 +869,7 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	HIPCK(hipMemcpyAsync(w->h_pin + 40, w->counters + 32 + CH_N_BINS, 4, hipMemcpyDeviceToHost, st));
 	HIPCK(hipEventRecord(w->ev_t[5], st));
 	HIPCK(hipStreamSynchronize(st));                          // (the lane kernel; the wave kernels go on)
+	st = st_user;
 	const uint64_t n_regs_a = w->h_pin[0], n_jobs_a = w->h_pin[1], need_b = h64[0];
 	// capacity for both passes now (a reallocation later would wait for everything and have to move pass A): pass B makes at
 	// most one region per sampled occurrence and two jobs per region

@@ -121,6 +121,7 @@ struct result_t {
 
 struct lane_t {
 	hipStream_t st = nullptr, st2 = nullptr;     // st2: copies to the host beside the kernels of st
+	hipStream_t st_hi = nullptr;                 // highest priority: takes st's place for what follows the extension (region tail, selection, CIGARs, text) -- run_batch
 	bmh_seed_ws_t *sws = nullptr; uint32_t sws_reads = 0; uint64_t sws_bases = 0;
 	bmh_chain_ws_t *cws = nullptr; uint32_t cws_reads = 0; uint64_t cws_seeds = 0; uint64_t regs_guess = 0;
 	dbuf_t<uint8_t> d_reads, d_work; dbuf_t<uint32_t> d_offs, d_lens, d_sel, d_opr, d_cigar, d_off, d_packed, d_over, d_sel2; dbuf_t<int32_t> d_out3, d_regs, d_fin, d_aln, d_slot, d_hrec, d_unflag; dbuf_t<char> d_md;
@@ -137,6 +138,7 @@ struct lane_t {
 		if (cws) bmh_chain_ws_free(cws);
 		if (st) { bmh_extend_release(st); (void)hipStreamDestroy(st); }
 		if (st2) (void)hipStreamDestroy(st2);
+		if (st_hi) { bmh_extend_release(st_hi); (void)hipStreamDestroy(st_hi); }
 		if (pair_scratch) bmh_pairs_scratch_free(pair_scratch);
 	}
 };
@@ -492,6 +494,11 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		RCK(bmh_chain_merge(Ln.cws, Ln.d_out3.p, Ln.d_regs.p, Ln.st));
 	}
 	const uint64_t nr = dj.n_regs;
+	// What follows the extension -- short kernels that wait on memory: the region tail, the selection, the CIGARs' traceback, the text -- goes to a stream of the
+	// highest priority: beside the other lanes' extension kernels, whose waves fill the register files, these are the kernels that should get the slots that
+	// become free.  The host waits for the lane's stream first (see bmh_seed_batch: no barrier packet waits in a high-priority queue).
+	struct swap_back_t { lane_t &L; bool on; ~swap_back_t() { if (on) std::swap(L.st, L.st_hi); } } sb{Ln, false};
+	if (Ln.st_hi) { LCK(hipStreamSynchronize(Ln.st)); std::swap(Ln.st, Ln.st_hi); sb.on = true; }
 	double t3 = now_s(); Ln.t[2] += t3 - t2;
 	bmh_post_opt_t po = A.po; po.id0 = id0;
 	const uint8_t *codes = rs.codes + a0;
@@ -631,6 +638,7 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 	RCK(cigars(A, Ln, d_fin, ns_sel, R, !dev_text_now, &words));
 	if (dev_text_now) RCK(text_on_device(A, Ln, po, d_fin, n, paired, R));
 	LCK(hipStreamSynchronize(Ln.st2));
+	if (sb.on) LCK(hipStreamSynchronize(Ln.st));                   // (the priority stream is idle before the lane's own takes its place again)
 	Ln.t[5] += now_s() - t5;
 	return BMH_OK;
 }
@@ -720,6 +728,14 @@ static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int pair
 		std::unique_ptr<lane_t> ln(new lane_t());
 		if (hipStreamCreateWithFlags(&ln->st, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ln->st2, hipStreamNonBlocking) != hipSuccess) {
 			bmh_set_error("%s: hipStreamCreate: %s", fn, hipGetErrorString(hipGetLastError())); return BMH_ENODEV;
+		}
+		{
+			const char *pe = getenv("BMH_ALIGNER_TAIL_PRIO");          // (BMH_ALIGNER_TAIL_PRIO=normal: A/B -- everything on the lane's own stream)
+			int prio_lo = 0, prio_hi = 0;
+			(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+			if (!(pe && pe[0] == 'n') && hipStreamCreateWithPriority(&ln->st_hi, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+				bmh_set_error("%s: hipStreamCreateWithPriority: %s", fn, hipGetErrorString(hipGetLastError())); return BMH_ENODEV;
+			}
 		}
 		h->lanes.push_back(std::move(ln));
 	}

@@ -60,14 +60,18 @@ cfgs = [tuple(int(v) for v in c.split("x")) for c in os.environ.get("LANES_CFGS"
 for lanes, nb in cfgs:
     q = (n_reads // nb) & ~1
     cuts = [k * q for k in range(nb)] + [n_reads]
-    for it in range(3):
-        if it == 2 and os.environ.get("LANES_TRACE"): os.environ["BMH_ALIGNER_TRACE"] = "1"
+    n_it = int(os.environ.get("LANES_ITERS", "3"))
+    all_ms = []
+    for it in range(n_it):
+        if it == n_it - 1 and os.environ.get("LANES_TRACE"): os.environ["BMH_ALIGNER_TRACE"] = "1"
         nbytes[0] = 0
         th0 = throttled()
         st = nat.run(rs, cuts, paired, sink, n_lanes=lanes, n_threads=nth)
         th1 = throttled()
+        all_ms.append(round(st.seconds * 1e3, 1))
         os.environ.pop("BMH_ALIGNER_TRACE", None)
     print("   [cgroup] throttled %d times for %.1f ms during the run; CPU time used %.0f ms (%d threads asked for)" % (th1[0] - th0[0], th1[1] - th0[1], th1[2] - th0[2], nth))
+    if n_it > 3: print("   every run, ms:", all_ms, "best %.2f Mreads/s, median %.2f" % (n_reads / min(all_ms[1:]) / 1e3, n_reads / sorted(all_ms[1:])[len(all_ms[1:]) // 2] / 1e3))
     print("lanes %d batches %d: %.1f ms = %.2f Mreads/s (%d bytes); format %.1f; lanes summed: H2D %.1f seed %.1f cem %.1f tail %.1f select %.1f cigar %.1f" %
           (lanes, nb, st.seconds * 1e3, n_reads / st.seconds / 1e6, nbytes[0], st.format_seconds * 1e3, st.h2d_seconds * 1e3, st.seed_seconds * 1e3,
            st.chain_extend_seconds * 1e3, st.tail_seconds * 1e3, st.select_seconds * 1e3, st.cigar_seconds * 1e3), flush=True)

@@ -152,7 +152,11 @@ typedef struct {
 
 /* d_reads: ASCII bases of all reads back to back (no separators), d_offs/d_lens
  * per read (what the reference copies to the GPU, seed_gen.cu:1841-1843).
- * stream: a hipStream_t (NULL = default stream).  Synchronises the stream. */
+ * stream: a hipStream_t (NULL = default stream).  Synchronises the stream: the call waits on the host for what the stream
+ * holds, runs its kernels on a stream of the highest priority that the workspace owns (beside another batch's extension kernels
+ * the seeding waves -- which wait on HBM most of the time -- then take the wave slots that become free; BMH_SEED_PRIO=normal in the
+ * environment when the workspace is created: on `stream` itself), and leaves `stream` waiting for them: work queued on `stream`
+ * afterwards sees the seeds. */
 int bmh_seed_batch(bmh_seed_ws_t *ws, const bmh_index_t *idx, const uint8_t *d_reads,
                    const uint32_t *d_offs, const uint32_t *d_lens, uint32_t n_reads,
                    int min_seed_len, void *stream, bmh_seeds_t *out);
@@ -464,7 +468,9 @@ int bmh_chain_merge(bmh_chain_ws_t *ws, const int32_t *d_out3, int32_t *d_regs_o
  * receives the regions in read order -- the same array the three-call form produces; out->n_regs / n_jobs / d_regs_per_read /
  * d_frac_rep as for bmh_chain_batch; the job arrays in *out are in pass order (all jobs of the first pass, then the second);
  * d_q / d_t are not materialised.  Synchronises the stream twice (counts); the second extension and the merge are still in
- * flight on `stream` when it returns.  BMH_ECAPACITY if the batch has more than cap_regs_out regions. */
+ * flight on `stream` when it returns.  The short kernels the first extension pass waits for (classification, the lane kernel, the
+ * counts) run on a stream of the highest priority owned by the workspace, behind a host-side wait for `stream` (see bmh_seed_batch;
+ * BMH_CHAIN_LIGHT_PRIO=normal when the workspace is created: on `stream`); the wave-per-read classes on streams of the lowest.  BMH_ECAPACITY if the batch has more than cap_regs_out regions. */
 int bmh_chain_extend_merge(bmh_chain_ws_t *ws, const bmh_chain_opt_t *opt, const bmh_index_t *idx, const uint8_t *d_reads,
                            const uint32_t *d_offs, const uint32_t *d_lens, uint32_t n_reads, const bmh_seeds_t *seeds,
                            const bmh_ext_params_t *ep, int32_t *d_regs_out, uint64_t cap_regs_out, void *stream, bmh_dev_jobs_t *out);

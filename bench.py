@@ -807,12 +807,20 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
                 return int(dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))["usage_usec"]) / 1e3
             except Exception:               # noqa: BLE001
                 return float("nan")
+        # one run to warm the lanes, then five: the median is the row (a run is 0.2-0.3 s and the device is shared by the lanes' kernels in an order that differs
+        # from run to run: single runs scatter by +-5 %; every run is listed)
         st_n = None
-        for _ in range(2):
+        runs_n = []
+        for it in range(6):
             nbytes[0] = 0
             c0 = cpu_ms()
-            st_n = nat.run(rs, cuts4, paired, sink, n_lanes=lanes_n, n_threads=nth)
-            c1 = cpu_ms()
+            st_i = nat.run(rs, cuts4, paired, sink, n_lanes=lanes_n, n_threads=nth)
+            c1_i = cpu_ms()
+            if it:
+                runs_n.append((st_i.seconds, st_i, c1_i - c0))
+        runs_n.sort(key=lambda t: t[0])
+        _, st_n, cpu_used = runs_n[len(runs_n) // 2]
+        c0, c1 = 0.0, cpu_used
         # ... and the same reads from a FILE (bmh_aligner_run_fasta: a loader thread cuts and fills the batches of the mapped file ahead of the lanes), the file in the
         # page cache as a freshly written read file would be: what `bwa mem ref.fa reads.fa` starts from
         file_row = {}
@@ -823,18 +831,22 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
             recs[:, 0] = ord(">"); recs[:, 1:w + 2] = np.frombuffer("".join(names.tolist()).encode(), np.uint8).reshape(n4, w + 1); recs[:, w + 2] = 10
             recs[:, w + 3:w + 3 + rl] = asc.reshape(n4, rl); recs[:, -1] = 10
             recs.tofile(fa); del recs
-            for _ in range(2):
+            runs_f = []
+            for it in range(4):
                 nbytes_f = [0]
                 t0f = time.perf_counter()
                 st_f = nat.run_fasta(fa, paired, lambda mv: nbytes_f.__setitem__(0, nbytes_f[0] + len(mv)), batch_reads=(n4 // nb4) & ~1, n_lanes=lanes_n, n_threads=nth)
-                dt_f = time.perf_counter() - t0f
+                if it:
+                    runs_f.append(time.perf_counter() - t0f)
+            dt_f = sorted(runs_f)[len(runs_f) // 2]
             os.remove(fa)
-            file_row = {"file_to_sam_native": {"Mreads_per_s": round(n4 / dt_f / 1e6, 2), "ms": round(dt_f * 1e3, 1), "reads": int(n4), "sam_bytes": int(nbytes_f[0]), "identical_text_size": bool(nbytes_f[0] == nbytes[0]),
+            file_row = {"file_to_sam_native": {"Mreads_per_s": round(n4 / dt_f / 1e6, 2), "ms": round(dt_f * 1e3, 1), "reads": int(n4), "sam_bytes": int(nbytes_f[0]), "identical_text_size": bool(nbytes_f[0] == nbytes[0]), "runs_ms": [round(v * 1e3, 1) for v in runs_f], "row_is": "median",
                                                "what": "bmh_aligner_run_fasta: a FASTA file (in the page cache) -> batches cut and filled by a loader thread -> the same pipeline -> SAM text at the sink"}}
         except Exception as e:                              # noqa: BLE001
             file_row = {"file_to_sam_native": {"error": repr(e)}}
         nat.free()
         sam_row = {**file_row, "reads_to_sam_native": {"Mreads_per_s": round(n4 / st_n.seconds / 1e6, 2), "ms": round(st_n.seconds * 1e3, 1), "reads": int(n4), "sam_bytes": int(nbytes[0]), "batches": nb4, "lanes": lanes_n,
+                                           "runs_ms": [round(t[0] * 1e3, 1) for t in runs_n], "row_is": "median",
                                            "host_cpu_ms_per_million_reads": round((c1 - c0) / (n4 / 1e6), 1), "writer_format_ms": round(st_n.format_seconds * 1e3, 1),
                                            "lanes_ms_summed": {"h2d": round(st_n.h2d_seconds * 1e3, 1), "seeding": round(st_n.seed_seconds * 1e3, 1), "chain_extend_merge": round(st_n.chain_extend_seconds * 1e3, 1),
                                                                "tail": round(st_n.tail_seconds * 1e3, 1), "select": round(st_n.select_seconds * 1e3, 1), "cigar_text_d2h": round(st_n.cigar_seconds * 1e3, 1)},

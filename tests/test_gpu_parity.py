@@ -1144,8 +1144,9 @@ def test_native_pipeline_device_text_equals_host_text(hip, tmp_path, pe):
     al.close()
 
 
+@pytest.mark.parametrize("opts", [{}, {"flag_all": 1}, {"no_multi": 1, "softclip": 1}], ids=["default", "all", "M_Y"])
 @pytest.mark.parametrize("pe", [False, True])
-def test_native_pipeline_with_alt_contigs_device_forms_equal_host_forms(hip, tmp_path, pe):
+def test_native_pipeline_with_alt_contigs_device_forms_equal_host_forms(hip, tmp_path, pe, opts):
     """An index with ALT contigs (<prefix>.alt) through bmh_aligner_run: the device tail's ALT rules and, for pairs, pair_kernel (pairs without a hit on an ALT
     contig) + the host's mem_sam_pe (the others), against the host forms: the host tail of the reads that touch an ALT contig (BMH_ALIGNER_ALT_HOST_PATCH), all
     of mem_sam_pe on the host (BMH_ALIGNER_PE_HOST), the host's formatter, and the Python loop (host tail of every read)."""
@@ -1166,6 +1167,8 @@ def test_native_pipeline_with_alt_contigs_device_forms_equal_host_forms(hip, tmp
             f.write((b">p%d\n" % (i // 2)) if pe else (b">r%d\n" % i)); f.write(a.tobytes()); f.write(b"\n")
     al = Aligner(prefix, n_threads=4)
     assert al.has_alt
+    for k_, v_ in opts.items():                                    # (-a: every hit a record; -M -Y: shorter split hits secondary, soft clips everywhere)
+        setattr(al.po, k_, v_)
     texts = {}
     for env in ("", "BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_PE_HOST" if pe else "BMH_ALIGNER_ALT_HOST_PATCH", "BMH_ALIGNER_NATIVE"):
         if env:
@@ -1180,7 +1183,7 @@ def test_native_pipeline_with_alt_contigs_device_forms_equal_host_forms(hip, tmp
     body = texts[""]
     lines = [l.split(b"\t") for l in body.split(b"\n") if l and not l.startswith(b"@")]
     on_alt = sum(1 for l in lines if l[2].endswith(b"_alt1"))
-    assert len(lines) >= n and on_alt > 500 and body.count(b"\tpa:f:") > 100 and b"\tXA:Z:" in body, (len(lines), on_alt, body.count(b"\tpa:f:"))
+    assert len(lines) >= n and on_alt > 500 and body.count(b"\tpa:f:") > 100 and (b"\tXA:Z:" in body or opts.get("flag_all")), (len(lines), on_alt, body.count(b"\tpa:f:"))
     for env in [e for e in texts if e]:
         if texts[env] != body:
             a, b = body.split(b"\n"), texts[env].split(b"\n")

@@ -1087,6 +1087,27 @@ def test_aligner_writes_reference_sam(hip, tmp_path, golden):
         finally:
             del os.environ["BMH_FIN_FORCE_ECAPACITY"]
     al.close()
+    # ... and the reference's -a run (every hit a record: secondary ones included) record by record -- flag, POS, MAPQ, CIGAR, NM, AS, XS, MD, RNAME --
+    # through the same device path with flag_all set
+    if "all_read" in z.files:
+        al2 = Aligner(prefix, n_threads=2)
+        al2.po.flag_all = 1
+        buf3 = io.StringIO()
+        al2.align_file(fq, buf3, batch_reads=1 << 30 if pe else 256, paired=pe)
+        got = []
+        for line in buf3.getvalue().split("\n"):
+            if not line or line[0] == "@":
+                continue
+            c = line.split("\t")
+            tags = {t[:2]: t[5:] for t in c[11:]}
+            rd = int(c[0][1:]) if not pe else 2 * int(c[0][1:]) + (1 if int(c[1]) & 0x80 else 0)
+            got.append((rd, int(c[1]), int(c[3]), int(c[4]), c[5], int(tags.get("NM", -1)), int(tags.get("AS", -1)), int(tags.get("XS", -1)), tags.get("MD", ""), c[2]))
+        want_a = list(zip(z["all_read"].tolist(), z["all_flag"].tolist(), z["all_pos"].tolist(), z["all_mapq"].tolist(), [str(x) for x in z["all_cigar"]],
+                          z["all_nm"].tolist(), z["all_as_"].tolist(), z["all_xs"].tolist(), [str(x) for x in z["all_md"]], [str(x) for x in z["all_rname"]]))
+        assert len(got) == len(want_a), (len(got), len(want_a))
+        bad = [(a, b) for a, b in zip(got, want_a) if a != b]
+        assert not bad, (len(bad), bad[:3])
+        al2.close()
 
 
 @pytest.mark.parametrize("pe", [False, True])

@@ -192,11 +192,20 @@ __global__ void __launch_bounds__(64) pair_kernel(pd_args_t A)
 	}
 	if (uncertain) { A.todo[p] = 1; return; }                         // (what was written is overwritten by the host's records)
 	if (!paired) {
+		// the alignment a read shows its mate (src/bwamem_pair.c:376-385): its best hit, or -- when that one (the best of the primary assembly) is below the
+		// threshold -- its best ALT hit; the orientation test below still takes the FIRST hits' positions (:389)
 		int hh[2];
-		for (int i = 0; i < 2; ++i) hh[i] = (n[i] && a[i][0].v[1] >= x.po.T) ? 0 : -1;
+		for (int i = 0; i < 2; ++i) {
+			hh[i] = -1;
+			if (n[i]) {
+				if (a[i][0].v[1] >= x.po.T) hh[i] = 0;
+				else if (n_pri[i] < n[i] && a[i][n_pri[i]].v[1] >= x.po.T) hh[i] = n_pri[i];
+			}
+		}
 		if (!A.pe.no_pairing && hh[0] >= 0 && hh[1] >= 0) {            // src/bwamem_pair.c:386
 			const int64_t rb0 = r_rb(a[0][0]), rb1 = r_rb(a[1][0]);
-			const int rid0 = pos2rid(x, rb0 < l_pac ? rb0 : (l_pac << 1) - 1 - (r_re(a[0][0]) - 1)), rid1 = pos2rid(x, rb1 < l_pac ? rb1 : (l_pac << 1) - 1 - (r_re(a[1][0]) - 1));
+			const int64_t hb0 = r_rb(a[0][hh[0]]), hb1 = r_rb(a[1][hh[1]]);
+			const int rid0 = pos2rid(x, hb0 < l_pac ? hb0 : (l_pac << 1) - 1 - (r_re(a[0][hh[0]]) - 1)), rid1 = pos2rid(x, hb1 < l_pac ? hb1 : (l_pac << 1) - 1 - (r_re(a[1][hh[1]]) - 1));
 			if (rid0 == rid1) {
 				int64_t dist;
 				const int d = pd_infer_dir(l_pac, rb0, rb1, &dist);

@@ -427,9 +427,17 @@ int sam_pe(const PCtx &c, uint64_t id, uint32_t r0, ReadOut out[2])          // 
 		}
 	}
 	if (!paired) {
+		// the alignment a read shows its mate (src/bwamem_pair.c:376-385): its best hit, or -- when that one (the best of the primary assembly, which the second
+		// marking round has put first) is below the threshold -- its best ALT hit; the orientation test below still takes the FIRST hits' positions (:389)
 		int hh[2];
-		for (int i = 0; i < 2; ++i) hh[i] = (!a[i]->empty() && (*a[i])[0].score >= c.x.po->T) ? 0 : -1;
-		if (!c.pe->no_pairing && hh[0] >= 0 && hh[1] >= 0 && (*a[0])[0].rid == (*a[1])[0].rid) {      // src/bwamem_pair.c:386
+		for (int i = 0; i < 2; ++i) {
+			hh[i] = -1;
+			if (!a[i]->empty()) {
+				if ((*a[i])[0].score >= c.x.po->T) hh[i] = 0;
+				else if (n_pri[i] < (int)a[i]->size() && (*a[i])[(size_t)n_pri[i]].score >= c.x.po->T) hh[i] = n_pri[i];
+			}
+		}
+		if (!c.pe->no_pairing && hh[0] >= 0 && hh[1] >= 0 && (*a[0])[(size_t)hh[0]].rid == (*a[1])[(size_t)hh[1]].rid) {      // src/bwamem_pair.c:386
 			int64_t dist;
 			const int d = infer_dir(c.x.l_pac, (*a[0])[0].rb, (*a[1])[0].rb, &dist);
 			if (!c.pes[d].failed && dist >= c.pes[d].low && dist <= c.pes[d].high) extra_flag |= 2;

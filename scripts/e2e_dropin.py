@@ -40,6 +40,14 @@ if n_ctg > 1:
     edges = [0] + cuts + [n_genome]
     contigs = [("ctg%d" % i, edges[i + 1] - edges[i]) for i in range(len(edges) - 1)]
 fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g, contigs=contigs)
+# E2E_ALT=k (with E2E_CONTIGS): the last k sequences are ALT contigs, named in <prefix>.alt the way bwa-kit's files name them (both sides read the file)
+if os.path.exists(prefix + ".alt"):
+    os.remove(prefix + ".alt")
+if contigs and int(os.environ.get("E2E_ALT", "0")) > 0:
+    with open(prefix + ".alt", "w") as f:
+        f.write("@SQ\tSN:%s\n" % contigs[-1][0])
+        for c in contigs[-int(os.environ["E2E_ALT"]):]:
+            f.write("%s\t0\t%s\t1\t60\t100M\t*\t0\t0\t*\t*\n" % (c[0], contigs[0][0]))
 print("index built+written in %.1fs" % (time.time() - t), flush=True)
 fq = os.path.join(work, "reads.fa")
 if paired:   # configs[3]: one interleaved file with -p (the only coherent PE input of the reference, SURVEY.md 8 notes)
@@ -132,6 +140,17 @@ if paired:
                 i = int(a.split("\t")[0][1:])
                 f.write("OURS   " + a + "\nTHEIRS " + b + "\n")
                 f.write("R1 " + asc[2 * i].tobytes().decode() + "\nR2 " + asc[2 * i + 1].tobytes().decode() + "\n")
+            names = []
+            for a, b in diff:
+                nm = a.split("\t")[0]
+                if nm not in names: names.append(nm)
+                if len(names) >= 8: break
+            f.write("\nEVERY RECORD OF THE FIRST DIFFERING PAIRS (fields 1-9, tags)\n")
+            for nm in names:
+                for tag, lines in (("OURS  ", ours), ("THEIRS", theirs)):
+                    for l in lines:
+                        c = l.split("\t")
+                        if c[0] == nm: f.write(tag + " " + "\t".join(c[:9]) + "\t" + "\t".join(c[11:]) + "\n")
     assert len(ours) == len(theirs) and not diff, diff[:2]
     print("SAM IDENTICAL")
     print("E2E DROP-IN OK")

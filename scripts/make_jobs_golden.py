@@ -17,11 +17,12 @@ MODE = sys.argv[1] if len(sys.argv) > 1 else "plain"
 #        make_jobs_golden.py pe_contigs -> pe_contigs_golden.npz (pairs on the three-sequence genome; some pairs span two sequences)
 #        make_jobs_golden.py alt        -> alt_golden.npz (two primary sequences + two ALT contigs -- diverged copies of stretches of them -- named in g.fa.alt)
 #        make_jobs_golden.py pe_alt     -> pe_alt_golden.npz (the same genome, interleaved pairs)
-ALT = MODE in ("alt", "pe_alt")
-REPEATS = MODE in ("repeats", "contigs", "pe", "pe_contigs", "alt", "pe_alt")
-PE = MODE in ("pe", "pe_contigs", "pe_alt")
+ALT = MODE in ("alt", "pe_alt", "pe_alt2")
+REPEATS = MODE in ("repeats", "contigs", "pe", "pe_contigs", "alt", "pe_alt", "pe_alt2")
+PE = MODE in ("pe", "pe_contigs", "pe_alt", "pe_alt2")
+ALT2 = MODE == "pe_alt2"     # an ALT contig with a stretch the primary assembly does not have, and pairs whose mates reach it with nothing but a weak hit on the primary assembly
 OUT = {"plain": "jobs_golden.npz", "repeats": "post_golden.npz", "contigs": "contigs_golden.npz", "pe": "pe_golden.npz", "pe_contigs": "pe_contigs_golden.npz",
-       "alt": "alt_golden.npz", "pe_alt": "pe_alt_golden.npz"}[MODE]
+       "alt": "alt_golden.npz", "pe_alt": "pe_alt_golden.npz", "pe_alt2": "pe_alt2_golden.npz"}[MODE]
 CONTIGS = [("ctgA", 120_000), ("ctgB", 100_037), ("ctgC", 79_963)] if MODE in ("contigs", "pe_contigs") else None
 if ALT:
     CONTIGS = [("ctgA", 150_000), ("ctgB", 110_000), ("altA1", 20_000), ("altB1", 12_000), ("altA2", 8_000)]
@@ -43,6 +44,8 @@ if ALT:
         parts.append(x[:ln])
     g = np.concatenate(parts).astype(np.uint8)
     assert g.size == n_genome
+    if ALT2:                                              # 3 000 novel bases inside altA1 (an insertion the primary assembly lacks)
+        g[265_000:268_000] = np.random.default_rng(78).integers(0, 4, size=3000).astype(np.uint8)
 idx = fmindex.build_fmd_index(g, device="cuda:0")
 prefix = os.path.join(work, "g.fa"); fmindex.write_index(prefix, idx); fmindex.write_bns(prefix, g, contigs=CONTIGS)
 if ALT:
@@ -83,6 +86,29 @@ if ALT:
             q = base + int(rng.integers(0, ln - L)); x = g[q:q + L].copy()
             m = rng.random(L) < 0.01; x[m] = (x[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
             reads[i] = x if rng.random() < 0.5 else synth.revcomp(x)
+if ALT2:
+    # pairs that reach mem_sam_pe's rules for a read whose best hit on the primary assembly is below the threshold while it has a good ALT hit
+    # (src/bwamem_pair.c:376-389): mate B = 126 bases of the novel ALT stretch + 24 bases of a unique primary locus
+    rng = np.random.default_rng(13)
+    def weak_plus_alt(q):
+        p1 = int(rng.integers(200_000, 255_000))
+        x = np.concatenate([g[q:q + 126], g[p1:p1 + 24]])
+        return x
+    for i in range(0, n_reads, 2):
+        kind = (i // 2) % 5
+        q = 265_100 + int(rng.integers(0, 2300))
+        if kind == 0:      # the other mate unalignable
+            a, b = rng.integers(0, 4, size=L).astype(np.uint8), weak_plus_alt(q)
+        elif kind == 1:    # the other mate a good hit on the primary assembly
+            p0 = int(rng.integers(1000, 250_000)); a, b = g[p0:p0 + L].copy(), synth.revcomp(weak_plus_alt(q))
+        elif kind == 2:    # both mates inside the novel stretch, a proper pair there
+            ins = int(rng.integers(250, 450)); a, b = g[q:q + L].copy(), synth.revcomp(g[q + ins - L:q + ins])
+        elif kind == 3:    # both with a weak hit on the primary assembly in front of their ALT hit
+            ins = int(rng.integers(250, 450)); a, b = weak_plus_alt(q), synth.revcomp(weak_plus_alt(q + ins - L))
+        else:
+            continue       # (the pairs of the pe_alt set stay)
+        if rng.random() < 0.5: a, b = b, a
+        reads[i], reads[i + 1] = a, b
 if REPEATS and not PE:                                   # chimeric reads (two loci, either strand): supplementary records and SA tags
     rng = np.random.default_rng(6)
     for i in range(3, n_reads, 25):

@@ -1021,11 +1021,13 @@ def test_reads_to_sam_text_matches_reference(hip, oracle, golden):
     cw.free(); ws.free(); dindex.free()
 
 
-@pytest.mark.parametrize("golden", ["post_golden.npz", "contigs_golden.npz", "pe_golden.npz", "pe_contigs_golden.npz", "alt_golden.npz", "pe_alt_golden.npz"])
+@pytest.mark.parametrize("golden", ["post_golden.npz", "contigs_golden.npz", "pe_golden.npz", "pe_contigs_golden.npz", "alt_golden.npz", "pe_alt_golden.npz", "pe_alt2_golden.npz"])
 def test_aligner_writes_reference_sam(hip, tmp_path, golden):
     """bwamem_hip.aligner (index files + FASTA -> SAM over the device-resident path) against the SAM text recorded from the
     reference binary: single-end (repeat-rich, three sequences) and interleaved paired-end (-p); alt_*: a genome with ALT contigs
-    named in <prefix>.alt (chain filter, two-round primary marking, MAPQ, XA / pa tags, soft clips on ALT hits)."""
+    named in <prefix>.alt (chain filter, two-round primary marking, MAPQ, XA / pa tags, soft clips on ALT hits); pe_alt2: an ALT contig with a stretch the
+    primary assembly lacks and pairs whose mates reach it with nothing but a weak hit on the primary assembly (mem_sam_pe shows the mate the best ALT hit,
+    src/bwamem_pair.c:376-389)."""
     import ast, io
     from bwamem_hip import fmindex, synth
     from bwamem_hip.aligner import Aligner

@@ -30,7 +30,15 @@ prefix = os.path.join(work, "g.fa")
 import ast
 g = synth.make_genome(n_genome, seed=42, **ast.literal_eval(os.environ.get("E2E_GENOME_KW", "{}")))     # e.g. "{'repeat_frac': 0.6, 'repeat_copies': (2000, 5000)}"
 t = time.time()
-idx = fmindex.build_fmd_index(g, device="cuda:0" if torch.cuda.is_available() else None)
+if os.environ.get("E2E_NATIVE_BUILD"):       # genomes beyond the torch builder's reach (seq_len > 2^32: E2E_NATIVE_BUILD=1 with a genome of 2.2e9 bases): bmh_index_build on the device, the files from its arrays
+    g_t = torch.from_numpy(g).cuda()
+    pac_t = fmindex.pack_pac_device(g_t); del g_t
+    d = fmindex.build_fmd_index_device(pac_t, n_genome, sa_intv=16)
+    idx = fmindex.FMDIndex(primary=int(d.primary), L2=np.asarray(d.L2, dtype=np.int64), seq_len=int(d.seq_len), bwt_words=d.bwt_t.cpu().numpy().view(np.uint32),
+                           sa_intv=16, n_sa=int(d.sa_t.numel()), sa=d.sa_t.cpu().numpy().view(np.uint32), sa_bits=d.bits_t.cpu().numpy().view(np.uint32), pack_size=1)
+    del d, pac_t; torch.cuda.empty_cache()
+else:
+    idx = fmindex.build_fmd_index(g, device="cuda:0" if torch.cuda.is_available() else None)
 # E2E_CONTIGS=k: the genome is written as k sequences of unequal lengths (reads that straddle a cut lose the seeds that bridge it
 # and get their extension windows clipped, src/bwamem.c:437, src/bntseq.c:531-556; positions are reported per sequence)
 n_ctg = int(os.environ.get("E2E_CONTIGS", "1"))

@@ -19,10 +19,10 @@ N=200000 M=pe_hard run3 E2E_TAG=hg5
 N=100000 M=se_hard run3 E2E_TAG=hg6 E2E_READLEN=300
 rm -rf /tmp/e2e_hg
 fi
-# ... and BASELINE.json's configs at FULL size against the reference's own SAM: `full_se`: configs[1], 1 M single-end reads of 150 bp; `full_pe`: configs[3], 1 M pairs; `full_300`: configs[4], 1 M single-end reads of 300 bp
-if [ "$1" = "full_se" ] || [ "$1" = "full_pe" ] || [ "$1" = "full_300" ]; then
+# ... and BASELINE.json's configs at FULL size against the reference's own SAM: `full_se`: configs[1], 1 M single-end reads of 150 bp; `full_pe`: configs[3], 1 M pairs; `full_300`: configs[4], 1 M single-end reads of 300 bp; `full_10m`: configs[2], 10 M single-end reads
+if [ "$1" = "full_se" ] || [ "$1" = "full_pe" ] || [ "$1" = "full_300" ] || [ "$1" = "full_10m" ]; then
 run4() { echo "== G=3.1e9 N=$N $M [$O] $*"; env E2E_CONTIGS=24 E2E_NATIVE_BUILD=1 "$KW" "$@" timeout 1150 python scripts/e2e_dropin.py /tmp/e2e_hg 3100000000 $N 1 $M "$O" 2>&1 | grep -a "built\|differing\|IDENTICAL\|rc=\|Error\|error\|rror\|Killed" | cut -c1-250; }
 O=""
-if [ "$1" = "full_se" ]; then N=1000000 M=se_hard run4 E2E_TAG=hg7; elif [ "$1" = "full_300" ]; then N=1000000 M=se_hard run4 E2E_TAG=hg9 E2E_READLEN=300; else N=2000000 M=pe_hard run4 E2E_TAG=hg8; fi
+if [ "$1" = "full_se" ]; then N=1000000 M=se_hard run4 E2E_TAG=hg7; elif [ "$1" = "full_300" ]; then N=1000000 M=se_hard run4 E2E_TAG=hg9 E2E_READLEN=300; elif [ "$1" = "full_10m" ]; then N=10000000 M=se_hard run4 E2E_TAG=hg10; else N=2000000 M=pe_hard run4 E2E_TAG=hg8; fi
 rm -rf /tmp/e2e_hg
 fi

@@ -104,7 +104,10 @@ else:
 sam = os.path.join(work, "out.sam")
 t = time.time()
 with open(sam, "w") as f:
-    r = subprocess.run([exe, "gase_aln", "-t", threads, "-K", "2000000000", "-l", os.environ.get("E2E_READLEN", "150")] + opts + (["-p"] if paired else []) + [prefix, fq], stdout=f, stderr=subprocess.PIPE, cwd=work)
+    # E2E_DEFAULT_K=1: no -K -- the reference cuts its batches itself (10 Mbases per thread, src/fastmap.c:527; the insert-size statistics are per batch) and the aligner
+    # below cuts the same way (align_file's default); only meaningful with E2E_EXE=bwa-gasal2-seqidx: the stock build indexes seq[] batch-relative (see the docstring)
+    kopt = [] if os.environ.get("E2E_DEFAULT_K") else ["-K", "2000000000"]
+    r = subprocess.run([exe, "gase_aln", "-t", threads] + kopt + ["-l", os.environ.get("E2E_READLEN", "150")] + opts + (["-p"] if paired else []) + [prefix, fq], stdout=f, stderr=subprocess.PIPE, cwd=work)
 dt = time.time() - t
 print("gase_aln rc=%d in %.2fs" % (r.returncode, dt))
 print(r.stderr.decode()[-1500:])
@@ -135,7 +138,7 @@ if paired:
     import io
     al = Aligner(prefix); al.set_options(opts)
     buf = io.StringIO()
-    al.align_file(fq, buf, batch_reads=1 << 30, paired=True)
+    al.align_file(fq, buf, batch_reads=0 if os.environ.get("E2E_DEFAULT_K") else 1 << 30, paired=True)
     ours = [l for l in buf.getvalue().split("\n") if l and l[0] != "@"]
     theirs = [l.rstrip("\n") for l in open(sam) if l[0] != "@"]
     diff = [(a, b) for a, b in zip(ours, theirs) if a != b]

@@ -6,3 +6,6 @@ KW="E2E_GENOME_KW={'repeat_frac': 0.5, 'repeat_copies': (5, 400), 'repeat_len': 
 O=""
 G=30000000 N=300000 M=pe_hard run E2E_TAG=k1 E2E_EXE=bwa-gasal2-seqidx E2E_DEFAULT_K=1 E2E_CONTIGS=24 "$KW"
 G=30000000 N=300000 M=pe_hard run E2E_TAG=k2 E2E_EXE=bwa-gasal2-seqidx E2E_DEFAULT_K=1 E2E_CONTIGS=24 E2E_ALT=5 "$KW"
+# ... and with four host threads on the reference's side (batches of 40 Mbases: three of them for 600 000 reads)
+run4t() { echo "== G=$G N=$N $M -t 4 [$O] $*"; env "$@" timeout 1100 python scripts/e2e_dropin.py /tmp/e2e_b $G $N 4 $M "$O" 2>&1 | grep -a "differing\|IDENTICAL\|rc=\|Error\|error\|rror" | cut -c1-250; }
+G=30000000 N=600000 M=pe_hard run4t E2E_TAG=k3 E2E_EXE=bwa-gasal2-seqidx E2E_DEFAULT_K=1 E2E_CONTIGS=24 E2E_ALT=5 "$KW"

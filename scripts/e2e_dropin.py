@@ -136,7 +136,7 @@ if paired:
     # the same job through the device-resident path: one batch like the reference's (its insert-size statistics are per batch)
     from bwamem_hip.aligner import Aligner
     import io
-    al = Aligner(prefix); al.set_options(opts)
+    al = Aligner(prefix); al.set_options(opts + (["-t", threads] if os.environ.get("E2E_DEFAULT_K") else []))       # (-t: the reference's batches hold 10 Mbases per thread)
     buf = io.StringIO()
     al.align_file(fq, buf, batch_reads=0 if os.environ.get("E2E_DEFAULT_K") else 1 << 30, paired=True)
     ours = [l for l in buf.getvalue().split("\n") if l and l[0] != "@"]

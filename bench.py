@@ -152,8 +152,8 @@ def verify_against_oracle(check, gpu_seeds, gpu_regs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("BENCH_GENOME_MBP", "3100")))
     ap.add_argument("--reads-per-gpu", type=int, default=int(os.environ.get("BENCH_READS_PER_GPU", "1000000")))
     ap.add_argument("--read-len", type=int, default=150)

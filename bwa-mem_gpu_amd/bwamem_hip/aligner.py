@@ -136,6 +136,11 @@ def read_fasta_reads_numpy(path: str) -> ReadSet:
         first_blank = np.where(ok & (cand < he), cand, -1)
     name_end = np.where(first_blank >= 0, first_blank, he)
     nlen = (name_end - hs).astype(np.int64)
+    # a trailing "/<digit>" is not part of the name (trim_readno, src/bwa.c:27-31)
+    e1, e2 = buf[np.maximum(name_end - 1, 0)], buf[np.maximum(name_end - 2, 0)]
+    trim = (nlen > 2) & (e2 == ord("/")) & (e1 >= ord("0")) & (e1 <= ord("9"))
+    name_end = name_end - 2 * trim
+    nlen = (name_end - hs).astype(np.int64)
     noff = np.concatenate([[0], np.cumsum(nlen + 1)[:-1]]).astype(np.uint64)
     blob = np.zeros(int((nlen + 1).sum()), np.uint8)
     nmark = np.zeros(buf.size + 1, np.int8); np.add.at(nmark, hs, 1); np.add.at(nmark, name_end, -1)

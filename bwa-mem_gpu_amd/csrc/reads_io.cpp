@@ -19,6 +19,17 @@
 
 namespace {
 
+// a record's name: the header up to the first blank, without a trailing "/<digit>" (kseq's name, then trim_readno: src/bwa.c:27-31,57,62 -- "read/1" and "read/2"
+// of an interleaved file are the same QNAME, and mem_sam_pe insists that the two names of a pair are equal, src/bwamem_pair.c:369)
+inline size_t name_len(const uint8_t *buf, size_t s, size_t le)
+{
+	size_t q = s;
+	while (q < le && buf[q] != ' ' && buf[q] != '\t') ++q;
+	size_t n = q - s;
+	if (n > 2 && buf[s + n - 2] == '/' && buf[s + n - 1] >= '0' && buf[s + n - 1] <= '9') n -= 2;
+	return n;
+}
+
 struct counts_t { uint64_t reads = 0, bases = 0, name_bytes = 0, max_len = 0; int bad = 0; };
 
 // nst_nt4_table (src/bntseq.c): A/a 0, C/c 1, G/g 2, T/t 3, everything else 4
@@ -44,9 +55,7 @@ void walk(const uint8_t *buf, size_t b, size_t e, counts_t &c, bmh_read_set_t *o
 			const bool hdr = buf[p] == '>';
 			if (hdr != want_hdr) { c.bad = 1; return; }
 			if (hdr) {
-				size_t q = p + 1;
-				while (q < le && buf[q] != ' ' && buf[q] != '\t') ++q;
-				const size_t nl_ = q - (p + 1);
+				const size_t nl_ = name_len(buf, p + 1, le);
 				if (FILL) { memcpy(o->names + nn, buf + p + 1, nl_); o->names[nn + nl_] = 0; o->name_offs[r] = nn; }
 				nn += nl_ + 1;
 			} else {
@@ -196,7 +205,7 @@ size_t walk_until(const uint8_t *buf, size_t b, size_t e, uint64_t reads0, uint6
 		if (le > p) {
 			const bool hdr = buf[p] == '>';
 			if (hdr != want_hdr) { c.bad = 1; return last; }
-			if (hdr) { size_t q = p + 1; while (q < le && buf[q] != ' ' && buf[q] != '\t') ++q; nn += q - (p + 1) + 1; }
+			if (hdr) nn += name_len(buf, p + 1, le) + 1;
 			else {
 				nb += le - p; ++r; last = next;
 				const bool full = want_reads ? r >= want_reads : nb >= want_bases;

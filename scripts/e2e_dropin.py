@@ -77,7 +77,8 @@ if paired:   # configs[3]: one interleaved file with -p (the only coherent PE in
     asc = synth.codes_to_ascii(reads)
     with open(fq, "wb") as f:
         for i in range(asc.shape[0]):
-            f.write(b">p%d\n" % (i // 2)); f.write(asc[i].tobytes()); f.write(b"\n")
+            # E2E_READNO=1: names "p<k>/1", "p<k>/2 comment" -- both sides cut the comment and the read number (trim_readno, src/bwa.c:27-31)
+            f.write((b">p%d/%d%s\n" % (i // 2, i % 2 + 1, b" x:y z" if i % 3 == 0 else b"")) if os.environ.get("E2E_READNO") else (b">p%d\n" % (i // 2))); f.write(asc[i].tobytes()); f.write(b"\n")
 else:
     RL = int(os.environ.get("E2E_READLEN", "150"))
     reads, truth = synth.make_reads(g, n_reads, RL, seed=7, sub_rate=0.04 if hard else 0.01, indel_frac=0.4 if hard else 0.05,
@@ -99,6 +100,11 @@ else:
         with open(fq, "wb") as f:
             for i in range(n_reads):
                 f.write(b">r%d\n" % i); f.write(asc[i, :lens_r[i]].tobytes()); f.write(b"\n")
+    elif os.environ.get("E2E_READNO"):
+        asc = synth.codes_to_ascii(reads)
+        with open(fq, "wb") as f:
+            for i in range(n_reads):
+                f.write(b">r%d/%d\tcomment\n" % (i, 1 + i % 2)); f.write(asc[i].tobytes()); f.write(b"\n")
     else:
         synth.write_fasta_reads(fq, reads)
 sam = os.path.join(work, "out.sam")

@@ -16,3 +16,7 @@ O="-a -T 20 -k 15"
 G=5000000 N=60000 M=se_hard run E2E_TAG=x3
 O="-c 5 -D 0.9 -N 3"
 G=5000000 N=60000 M=pe_hard run E2E_TAG=x4
+# read names with read numbers and comments ("p7/1", "p7/2 x:y z"; "r7/2<TAB>comment"): both sides cut them (trim_readno, src/bwa.c:27-31)
+O=""
+G=5000000 N=40000 M=pe_hard run E2E_TAG=n1 E2E_READNO=1
+G=5000000 N=40000 M=se_hard run E2E_TAG=n2 E2E_READNO=1

@@ -5,12 +5,12 @@ import pytest
 from bwamem_hip.aligner import _NT4, read_fasta_reads, read_fasta_reads_numpy
 
 
-def _write(path, rng, n, crlf=False, blanks=False, tail_nl=True, words=False):
+def _write(path, rng, n, crlf=False, blanks=False, tail_nl=True, words=False, readno=False):
     alphabet = np.frombuffer(b"ACGTNacgtnRY", dtype=np.uint8)
     with open(path, "wb") as f:
         for i in range(n):
             s = rng.choice(alphabet, size=int(rng.integers(1, 300))).tobytes()
-            nm = b"r%d" % i + ((b"\tdesc x" if i % 3 == 0 else b" more words") if words else b"")
+            nm = b"r%d" % i + ((b"/%d" % (1 + i % 2) if i % 4 else b"/x") if readno else b"") + ((b"\tdesc x" if i % 3 == 0 else b" more words") if words else b"")
             e = b"\r\n" if crlf else b"\n"
             f.write(b">" + nm + e)
             if blanks and i % 5 == 0:
@@ -19,7 +19,7 @@ def _write(path, rng, n, crlf=False, blanks=False, tail_nl=True, words=False):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(crlf=True), dict(blanks=True, words=True), dict(tail_nl=False),
-                                dict(crlf=True, blanks=True, words=True, tail_nl=False)])
+                                dict(crlf=True, blanks=True, words=True, tail_nl=False), dict(readno=True), dict(readno=True, words=True, crlf=True)])
 def test_loader_equals_numpy_parse(tmp_path, kw):
     """letters, nt4 codes, offsets, lengths and names of files with LF / CR LF line ends, blank lines, descriptions behind the
     name, no newline at the end; 1 read, a few, and enough for the loader's chunks (a file beyond 1 MB is cut at headers and
@@ -32,6 +32,9 @@ def test_loader_equals_numpy_parse(tmp_path, kw):
         assert len(a) == len(b) == n
         for k in ("ascii", "offs", "lens", "name_blob", "name_off"):
             assert np.array_equal(getattr(a, k), getattr(b, k)), (kw, n, k)
+        if kw.get("readno"):           # "r5/2" is read r5 (trim_readno, src/bwa.c:27-31); "r4/x" keeps its tail
+            names = bytes(a.name_blob).split(b"\0")[:n]
+            assert names == [b"r%d" % i + (b"" if i % 4 else b"/x") for i in range(n)], names[:6]
         assert np.array_equal(a.codes, _NT4[a.ascii])
         s = a.slice(n // 2, n)
         assert np.array_equal(s.codes, _NT4[s.ascii]) and len(s) == n - n // 2

@@ -197,7 +197,7 @@ class Aligner:
         the host stages.  Unlike the reference (update_a, src/fastmap.c), nothing is rescaled by -A: pass every value you want
         changed (-B -O -E -T -U).
         -d and -L are accepted and ignored (they do not reach the reference's GPU extension either).  Not modelled: -x -r -s
-        -y (seeding variants the GPU seeding of the reference ignores too), -I -R -H -C -V -j."""
+        -y (seeding variants the GPU seeding of the reference ignores too), -I -R -H -C -V."""
         import math
         co, ep, po, pe = self.copt, self.ep, self.po, self.pe
         i = 0
@@ -206,8 +206,11 @@ class Aligner:
             return int(a), int(b) if b else int(a)
         while i < len(argv):
             f = argv[i]
-            if f in ("-a", "-M", "-Y", "-S", "-P"):
-                if f == "-a": po.flag_all = 1
+            if f in ("-a", "-M", "-Y", "-S", "-P", "-j"):
+                if f == "-j":                             # the .alt file is ignored (src/fastmap.c:186,390-392): every sequence belongs to the primary assembly
+                    self.alt[:] = 0; self.has_alt = False; co.contig_is_alt = None; po.contig_is_alt = None
+                    if getattr(self, "_native", None) is not None: self._native.free(); self._native = None
+                elif f == "-a": po.flag_all = 1
                 elif f == "-M": po.no_multi = 1
                 elif f == "-Y": po.softclip = 1
                 elif f == "-S": pe.no_rescue = 1

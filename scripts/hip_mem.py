@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """hip_mem.py [-p] [gase_aln options] <index prefix> <reads.fa> [batch reads] > out.sam   -- alignment on the device-resident
 path (bwamem_hip.aligner); -p: the file holds interleaved pairs; options: see Aligner.set_options (-k -w -c -D -G -N -W -X
--A -B -O -E -T -h -Q -U -m -a -M -Y -S -P)."""
+-A -B -O -E -T -h -Q -U -m -a -M -Y -S -P -j)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))
@@ -11,7 +11,7 @@ argv = [x for x in sys.argv[1:] if x != "-p"]
 opts, args, i = [], [], 0
 while i < len(argv):
     if argv[i].startswith("-") and not args:
-        k = 1 if argv[i] in ("-a", "-M", "-Y", "-S", "-P") else 2
+        k = 1 if argv[i] in ("-a", "-M", "-Y", "-S", "-P", "-j") else 2
         opts += argv[i:i + k]; i += k
     else:
         args.append(argv[i]); i += 1

@@ -197,7 +197,7 @@ class Aligner:
         the host stages.  Unlike the reference (update_a, src/fastmap.c), nothing is rescaled by -A: pass every value you want
         changed (-B -O -E -T -U).
         -d and -L are accepted and ignored (they do not reach the reference's GPU extension either).  Not modelled: -x -r -s
-        -y (seeding variants the GPU seeding of the reference ignores too), -I -R -H -C -V."""
+        -y (seeding variants the GPU seeding of the reference ignores too), -I -H -C -V."""
         import math
         co, ep, po, pe = self.copt, self.ep, self.po, self.pe
         i = 0
@@ -236,6 +236,15 @@ class Aligner:
             elif f == "-Q": po.mapQ_coef_len = float(int(v)); po.mapQ_coef_fac = int(math.log(int(v))) if int(v) > 0 else 0
             elif f == "-U": pe.pen_unpaired = int(v)
             elif f == "-m": pe.max_matesw = int(v)
+            elif f == "-R":                                             # read group (bwa_set_rg, src/bwa.c:425-452): the header line and the records' RG:Z tag
+                line = v.replace("\\t", "\t").replace("\\n", "\n").replace("\\r", "\r").replace("\\\\", "\\")      # bwa_escape
+                if not line.startswith("@RG") or "\tID:" not in line:
+                    raise ValueError("-R: the read group line must start with @RG and hold an ID")
+                rid = line.split("\tID:", 1)[1].split("\t", 1)[0].split("\n", 1)[0]
+                if len(rid) > 255:
+                    raise ValueError("-R: @RG:ID is longer than 255 characters")
+                self.rg_line = line; self._rg_id = rid.encode(); po.rg_id = self._rg_id
+                if getattr(self, "_native", None) is not None: self._native.free(); self._native = None
             elif f == "-t": self.ref_threads = int(v)                   # the reference cuts its batches at chunk_size * n_threads bases (align_file)
             elif f == "-K": self.ref_chunk_bases = int(v)               # ... or at this fixed size
             elif f in ("-l", "-v", "-f", "-d", "-L"): pass              # bookkeeping; -d -L: no effect on the GPU extension
@@ -243,7 +252,7 @@ class Aligner:
                 raise ValueError(f"option {f} is not modelled")
 
     def header(self) -> str:
-        return "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in self.contigs)
+        return "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in self.contigs) + (getattr(self, "rg_line", "") + "\n" if getattr(self, "rg_line", "") else "")
 
     def align_batch(self, names, seqs=None, id0: int = 0, paired: bool = False, as_bytes: bool = False):
         """SAM records of one batch of reads: a ReadSet, or (names, seqs) lists of str / ASCII uint8 arrays; id0 = index of

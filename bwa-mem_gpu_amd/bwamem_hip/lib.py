@@ -211,7 +211,7 @@ class PostOpt(C.Structure):
     """bmh_post_opt_t"""
     _fields_ = [("T", C.c_int), ("mask_level_redun", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int),
                 ("flag_all", C.c_int), ("id0", C.c_int64), ("XA_drop_ratio", C.c_float), ("max_XA_hits", C.c_int),
-                ("no_multi", C.c_int), ("softclip", C.c_int), ("max_XA_hits_alt", C.c_int), ("contig_is_alt", C.c_void_p)]
+                ("no_multi", C.c_int), ("softclip", C.c_int), ("max_XA_hits_alt", C.c_int), ("contig_is_alt", C.c_void_p), ("rg_id", C.c_char_p)]
 
 
 class PeOpt(C.Structure):

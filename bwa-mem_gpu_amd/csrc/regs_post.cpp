@@ -298,7 +298,7 @@ extern "C" void bmh_post_opt_default(bmh_post_opt_t *o)        // mem_opt_init, 
 {
 	memset(o, 0, sizeof(*o));
 	o->T = 30; o->mask_level_redun = 0.95f; o->mapQ_coef_len = 50.f; o->mapQ_coef_fac = (int)log(50.f); o->flag_all = 0; o->id0 = 0;
-	o->XA_drop_ratio = 0.80f; o->max_XA_hits = 5; o->max_XA_hits_alt = 200; o->contig_is_alt = nullptr;
+	o->XA_drop_ratio = 0.80f; o->max_XA_hits = 5; o->max_XA_hits_alt = 200; o->contig_is_alt = nullptr; o->rg_id = nullptr;
 }
 
 // regs_in[n][8] = {read, score, qb, qe, rb_lo, rb_hi, re_lo, re_hi} grouped by read (regs_per_read); frac_rep per read.

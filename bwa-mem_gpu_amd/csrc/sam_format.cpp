@@ -117,6 +117,7 @@ bool bmh_format_sam_parts(const bmh_post_opt_t *po, uint32_t n_reads, const char
 	std::vector<uint64_t> bases((size_t)n_reads + 1, 0);
 	for (uint32_t r = 0; r < n_reads; ++r) bases[r + 1] = bases[r] + fin_per_read[r];
 	const bool pe = h_rec != nullptr;
+	const char *rg = po->rg_id && po->rg_id[0] ? po->rg_id : nullptr;      // read group: RG:Z:<id> on every record
 	auto rec_at = [&](uint64_t base, const int32_t *a, int i) {
 		Rec x; x.fin = a + 16 * i;
 		const int64_t s = cs.slot32 ? (int64_t)cs.slot32[base + i] : cs.slot64[base + i];
@@ -208,7 +209,9 @@ bool bmh_format_sam_parts(const bmh_post_opt_t *po, uint32_t n_reads, const char
 			else out += "*\t0\t0\t*\t";
 			mate_fields(mm ? m.rid : -1, m.pos, p_rev, 0, nullptr, mm, m.rid, m.pos, m.is_rev, m.n_cigar, m.cigar);
 			put_seq(out, seq, 0, l_seq, p_rev != 0);
-			out += "\t*\tAS:i:0\tXS:i:0\n";
+			out += "\t*\tAS:i:0\tXS:i:0";
+			if (rg) { out += "\tRG:Z:"; out += rg; }
+			out += '\n';
 			continue;
 		}
 		for (size_t which = 0; which < list.size(); ++which) {
@@ -243,8 +246,9 @@ bool bmh_format_sam_parts(const bmh_post_opt_t *po, uint32_t n_reads, const char
 			}
 			if (x.aln[3]) { out += "\tNM:i:"; put_int(out, x.aln[4]); out += "\tMD:Z:"; out += x.md; }
 			if (x.fin[1] >= 0) { out += "\tAS:i:"; put_int(out, x.fin[1]); }
-			if (!(flag & 0x100)) {                               // sub is not printed for secondary records (q->sub = -1)
-				if (x.fin[10] >= 0) { out += "\tXS:i:"; put_int(out, x.fin[10]); }
+			if (!(flag & 0x100) && x.fin[10] >= 0) { out += "\tXS:i:"; put_int(out, x.fin[10]); }      // sub is not printed for secondary records (q->sub = -1)
+			if (rg) { out += "\tRG:Z:"; out += rg; }               // src/bwamem.c:1631-1634
+			if (!(flag & 0x100)) {
 				bool other = false;
 				for (size_t j = 0; j < list.size(); ++j) if (j != which && !(a[16 * list[j] + 14] & 0x100)) other = true;
 				if (other) {

@@ -197,6 +197,7 @@ struct sam_args_t {
 	uint32_t *len; const uint64_t *text_off; char *text; uint32_t *err;
 	int flag_all, max_XA_hits, max_XA_hits_alt, no_multi, softclip; double drop;
 	int sa;                        // field of a record that holds the XA tag's key: [12] secondary, with ALT contigs [11] secondary_all (bmh_post_opt_t)
+	int rg_len; char rg[256];      // read group id (bmh_post_opt_t::rg_id), 0 = none
 };
 
 // where the text goes: W = 0 counts the bytes, 1 writes them to global memory, 2 into the wave's image in LDS (copied out in dwords afterwards:
@@ -364,7 +365,9 @@ template <int W> __device__ bool sam_read(const sam_args_t &A, uint32_t r, sam_o
 		else out.lit("*\t0\t0\t*\t");
 		sam_mate_fields<W>(A, out, pe, mm ? m.rid : -1, m.pos, p_rev, 0, nullptr, mm, m.rid, m.pos, m.is_rev, m.n_cigar, m.cigar);
 		sam_seq<W>(out, seq, 0, l_seq, p_rev != 0);
-		out.lit("\t*\tAS:i:0\tXS:i:0\n");
+		out.lit("\t*\tAS:i:0\tXS:i:0");
+		if (A.rg_len) { out.lit("\tRG:Z:"); out.str(A.rg, A.rg_len); }
+		out.ch('\n');
 		return true;
 	}
 	auto pri = [&](int i) { const int k = a[16 * i + A.sa]; return (k >= 0 && (double)a[16 * i + 1] >= (double)a[16 * k + 1] * A.drop) ? k : -1; };
@@ -400,8 +403,9 @@ template <int W> __device__ bool sam_read(const sam_args_t &A, uint32_t r, sam_o
 		}
 		if (x.aln[3]) { out.lit("\tNM:i:"); out.num(x.aln[4]); out.lit("\tMD:Z:"); out.str(x.md, x.aln[6]); }
 		if (x.fin[1] >= 0) { out.lit("\tAS:i:"); out.num(x.fin[1]); }
+		if (!(flag & 0x100) && x.fin[10] >= 0) { out.lit("\tXS:i:"); out.num(x.fin[10]); }
+		if (A.rg_len) { out.lit("\tRG:Z:"); out.str(A.rg, A.rg_len); }      // src/bwamem.c:1631-1634
 		if (!(flag & 0x100)) {
-			if (x.fin[10] >= 0) { out.lit("\tXS:i:"); out.num(x.fin[10]); }
 			bool other = false;
 			for (int j = 0; j < n; ++j) if (j != i && (a[16 * j + 15] & 1) && !(a[16 * j + 14] & 0x100)) other = true;
 			if (other) {
@@ -515,6 +519,11 @@ int sam_args(const bmh_post_opt_t *popt, const bmh_sam_dev_t *d, const char *fn,
 	A.flag_all = popt->flag_all; A.max_XA_hits = popt->max_XA_hits; A.max_XA_hits_alt = popt->max_XA_hits_alt; A.no_multi = popt->no_multi; A.softclip = popt->softclip;
 	A.drop = (double)popt->XA_drop_ratio;
 	A.sa = popt->contig_is_alt ? 11 : 12;
+	if (popt->rg_id && popt->rg_id[0]) {
+		const size_t l = strlen(popt->rg_id);
+		if (l > 255) { bmh_set_error("%s: the read group id is longer than 255 characters", fn); return BMH_EINVAL; }
+		A.rg_len = (int)l; memcpy(A.rg, popt->rg_id, l);
+	}
 	return BMH_OK;
 }
 

@@ -299,6 +299,9 @@ typedef struct {
 	 * bmh_finalize_regs and bmh_finalize_regs_device both take the table (the device form uploads it; the second marking round,
 	 * secondary_all and alt_sc are in csrc/regs_core.h and the wave classes of csrc/regs_kernels.hip): same records. */
 	const uint8_t *contig_is_alt;
+	/* read group (-R: bwa_set_rg, src/bwa.c:425-452): the ID of the @RG line, NUL-terminated, in HOST memory, at most 255 characters; NULL or empty = none.  Every
+	 * record -- the unmapped ones too -- gets RG:Z:<id> behind AS / XS and in front of SA (mem_aln2sam, src/bwamem.c:1631-1634); the caller writes the @RG header line. */
+	const char *rg_id;
 } bmh_post_opt_t;
 void bmh_post_opt_default(bmh_post_opt_t *o);
 

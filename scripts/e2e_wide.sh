@@ -20,3 +20,9 @@ G=5000000 N=60000 M=pe_hard run E2E_TAG=x4
 O=""
 G=5000000 N=40000 M=pe_hard run E2E_TAG=n1 E2E_READNO=1
 G=5000000 N=40000 M=se_hard run E2E_TAG=n2 E2E_READNO=1
+# read group: -R '@RG\tID:grp1\tSM:s1' (RG:Z:grp1 on every record, the unmapped ones too)
+O='-R @RG\tID:grp1\tSM:s1'
+G=5000000 N=40000 M=pe_hard run E2E_TAG=g1
+G=5000000 N=40000 M=se_hard run E2E_TAG=g2
+O='-a -R @RG\tID:x.y-7\tPL:ILLUMINA'
+G=5000000 N=30000 M=se_hard run E2E_TAG=g3 E2E_CONTIGS=6 E2E_ALT=2

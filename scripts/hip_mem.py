@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """hip_mem.py [-p] [gase_aln options] <index prefix> <reads.fa> [batch reads] > out.sam   -- alignment on the device-resident
 path (bwamem_hip.aligner); -p: the file holds interleaved pairs; options: see Aligner.set_options (-k -w -c -D -G -N -W -X
--A -B -O -E -T -h -Q -U -m -a -M -Y -S -P -j)."""
+-A -B -O -E -T -h -Q -U -m -R -a -M -Y -S -P -j)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))

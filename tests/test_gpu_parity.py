@@ -1214,6 +1214,51 @@ def test_native_pipeline_with_alt_contigs_device_forms_equal_host_forms(hip, tmp
     al.close()
 
 
+@pytest.mark.parametrize("pe", [False, True])
+def test_read_group_tag_on_every_record(hip, tmp_path, pe):
+    """-R: the @RG line behind the @SQ lines, RG:Z:<id> on every record -- unmapped reads, secondary and supplementary records too -- behind AS / XS and in front of
+    SA (mem_aln2sam, src/bwamem.c:1631-1634), from the device's SAM writer and from the host's formatter: the same bytes.  (Against the reference binary: scripts/e2e_wide.sh.)"""
+    import io
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.aligner import Aligner
+    g = synth.make_genome(800_000, seed=15, repeat_frac=0.4, repeat_len=(150, 600), repeat_copies=(4, 60), repeat_div=0.02)
+    prefix = str(tmp_path / "g.fa")
+    fmindex.write_index(prefix, fmindex.build_fmd_index(g)); fmindex.write_bns(prefix, g, contigs=[("chrA", 500_000), ("chrB", 300_000)])
+    n, L = 6000, 150
+    reads = (synth.make_pairs(g, n // 2, L, seed=6) if pe else synth.make_reads(g, n, L, seed=6))[0].copy()
+    reads[7] = np.random.default_rng(1).integers(0, 4, L)            # an unalignable read
+    for r in range(11, n, 97):                                        # chimeric reads: supplementary records and SA tags
+        p2 = (r * 7919) % (len(g) - L); reads[r, 70:] = g[p2:p2 + L - 70]
+    fq = str(tmp_path / "r.fa")
+    with open(fq, "wb") as f:
+        for i, a in enumerate(synth.codes_to_ascii(reads)):
+            f.write((b">p%d\n" % (i // 2)) if pe else (b">r%d\n" % i)); f.write(a.tobytes()); f.write(b"\n")
+    al = Aligner(prefix, n_threads=4)
+    al.set_options(["-a", "-R", "@RG\\tID:g7.x\\tSM:s1"])
+    texts = {}
+    for env in ("", "BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_NATIVE"):
+        if env:
+            os.environ[env] = "0" if env == "BMH_ALIGNER_NATIVE" else "1"
+        try:
+            buf = io.BytesIO(); al.align_file(fq, buf, batch_reads=2500 if not pe else 1 << 30, paired=pe); texts[env] = buf.getvalue()
+        finally:
+            if env:
+                del os.environ[env]
+    body = texts[""]
+    hdr = [l for l in body.split(b"\n") if l.startswith(b"@")]
+    assert hdr == [b"@SQ\tSN:chrA\tLN:500000", b"@SQ\tSN:chrB\tLN:300000", b"@RG\tID:g7.x\tSM:s1"], hdr
+    recs = [l for l in body.split(b"\n") if l and not l.startswith(b"@")]
+    assert len(recs) > n and all(b"\tRG:Z:g7.x" in l for l in recs)
+    assert any(int(l.split(b"\t")[1]) & 4 for l in recs) and any(b"\tSA:Z:" in l for l in recs) and any(int(l.split(b"\t")[1]) & 0x100 for l in recs)
+    for l in recs:                                                    # behind XS / AS, in front of SA and XA
+        t = [x[:2] for x in l.split(b"\t")[11:]]
+        k = t.index(b"RG")
+        assert t[k - 1] in (b"XS", b"AS") and all(x in (b"SA", b"XA", b"pa") for x in t[k + 1:]), l
+    for env, t in texts.items():
+        assert t == body, env
+    al.close()
+
+
 @pytest.mark.parametrize("flag_all", [0, 1])
 def test_device_tail_with_alt_contigs_equals_host_tail(hip, flag_all):
     """bmh_finalize_regs_device WITH an ALT table (second marking round, secondary_all, alt_sc, mem_reg2sam's rules for ALT hits -- lane form and the wave classes)

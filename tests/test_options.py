@@ -42,6 +42,19 @@ def test_set_options_maps_every_modelled_flag():
 
 def test_set_options_rejects_what_is_not_modelled():
     o = _Opts()
-    for bad in (["-x", "pacbio"], ["-r", "1.2"], ["-R", "@RG\\tID:x"], ["-k"]):
+    for bad in (["-x", "pacbio"], ["-r", "1.2"], ["-R", "RG\\tID:x"], ["-R", "@RG\\tSM:x"], ["-R", "@RG\\tID:" + "x" * 256], ["-C", "1"], ["-k"]):
         with pytest.raises(ValueError):
             Aligner.set_options(o, bad)
+
+
+def test_read_group_and_ignore_alt_options():
+    """-R: the line unescaped like bwa_escape, the ID (up to the next tab) for the records' RG:Z tag (bwa_set_rg, src/bwa.c:425-452); -j: the ALT flags dropped"""
+    import numpy as np
+    o = _Opts()
+    o.alt = np.array([0, 1, 1], np.uint8); o.has_alt = True
+    o.copt.contig_is_alt = o.alt.ctypes.data; o.po.contig_is_alt = o.alt.ctypes.data
+    Aligner.set_options(o, ["-R", "@RG\\tID:grp.1\\tSM:s 1\\tPL:x", "-j"])
+    assert o.rg_line == "@RG\tID:grp.1\tSM:s 1\tPL:x" and o.po.rg_id == b"grp.1"
+    assert not o.has_alt and not o.alt.any() and not o.copt.contig_is_alt and not o.po.contig_is_alt
+    o.contigs = [("a", 5), ("b", 7)]
+    assert Aligner.header(o) == "@SQ\tSN:a\tLN:5\n@SQ\tSN:b\tLN:7\n@RG\tID:grp.1\tSM:s 1\tPL:x\n"

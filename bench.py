@@ -486,6 +486,12 @@ def main():
         per_rank = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(per_rank, mine)
         per_rank_ms = [float(x[0]) / a.steps * 1e3 for x in per_rank]
+        # what every rank did in setup: ranks other than 0 generate the text and draw their reads, then sit in the broadcast until rank 0 has
+        # built (and proven) the index -- `in_broadcast` of rank r minus rank 0's is the time it waited with idle hands
+        su = torch.tensor([t_gen, t_index, t_reads_early, t_bcast], dtype=torch.float64, device=tt.device)
+        su_all = [torch.zeros_like(su) for _ in range(world)]
+        dist.all_gather(su_all, su)
+        setup_per_rank = [{"genome": round(float(x[0]), 2), "index_build": round(float(x[1]), 2), "reads_drawn_early": round(float(x[2]), 2), "in_broadcast": round(float(x[3]), 2)} for x in su_all]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, dt_pcie = float(tt[0]), (float(tt[1]) if a.pcie else None)
         tot = torch.tensor([n_reads], dtype=torch.int64, device=tt.device)
@@ -542,6 +548,19 @@ def main():
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = total_reads * a.steps / dt / 1e6
+        # VALU calibration of THIS device in THIS run (bmh_calib_valu: the DP kernels' instruction kinds without their data, 8 waves per SIMD), with
+        # the shader clock read inside the kernel (s_memtime over s_memrealtime around a VALU-dense loop): the extension is VALU-bound, MI355X boards
+        # differ by up to 12 % in sustained clock (MI355X_MICROARCH.md), so two bench lines can be split into clock and code
+        cal, clock = {}, {}
+        L.bmh_calib_valu.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+        L.bmh_calib_last_clock.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        ms_c = C.c_float(0); ops_c = C.c_double(0); mhz_c = C.c_double(0); cpi_c = C.c_double(0)
+        for mode, nm in ((0, "independent_v_max_add"), (1, "dependent_chain"), (2, "dpp_row_shr_max"), (4, "packed_u16_add_max")):
+            if L.bmh_calib_valu(mode, 8, 20000, None, C.byref(ms_c), C.byref(ops_c)) == 0:
+                cal[nm] = round(ops_c.value / (ms_c.value * 1e-3) / VALU_PEAK_LANEOPS, 3)
+                if mode == 0 and L.bmh_calib_last_clock(C.byref(mhz_c), C.byref(cpi_c)) == 0:
+                    clock = {"clock_mhz": round(mhz_c.value, 1), "valu_cycles_per_wave_instr_8_waves": round(cpi_c.value / 8.0, 3),
+                             "how": "shader cycles (s_memtime) / 100 MHz ticks (s_memrealtime) of one wave around 2.56 M VALU instructions, 8 waves per SIMD on every SIMD"}
         st = stats[-1]
         index_how = ("loaded from --index-cache (built on the device by an earlier run of this command)" if build_stats.get("loaded_from_cache") else
                      "built on the device in setup" + (" and verified completely (every adjacent pair of suffix-array rows)" if build_stats.get("verified") else ", not verified (--no-verify-index)"))
@@ -550,6 +569,12 @@ def main():
             "metric": "Mreads/s (150 bp single-end vs hg38-scale index; seed-and-extend hot path)", "value": round(value, 3), "unit": "Mreads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "clock_mhz": clock.get("clock_mhz"),
+            "incl_pcie_value": round(total_reads * a.steps / dt_pcie / 1e6, 3) if dt_pcie else None,
+            "stage_ms_isolated": {k: round(v, 3) for k, v in iso_ms.items()},
+            "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "verified_identical": None if verified is None else bool(verified["seeds_identical"] and verified["regions_identical"]),
+            "clock": clock,
             "config": {"workload": f"{a.reads_per_gpu} synthetic {a.read_len} bp {'paired-end (interleaved)' if a.paired else 'single-end'} reads per GPU vs an hg38-scale FMD index: seeded synthetic "
                                    f"{a.genome_mbp:g} Mbp genome, 24 contigs, 50% planted repeats (mid-copy families, LINE-like, high-copy SINE-like, satellites, low-divergence segmental "
                                    f"duplications), N-runs; seq_len = {d.seq_len} rows{' > 2^32' if d.seq_len >> 32 else ''}; index {index_how}; "
@@ -562,11 +587,9 @@ def main():
                        "regions_per_read": round(st["n_regs"] / n_reads, 2), "reads_chained_by_a_whole_wave": st["n_heavy"],
                        "ext_jobs_per_gpu": st["n_jobs"], "regions_per_gpu": st["n_regs"], "seeds_per_gpu": st["n_seeds"], "min_seed_len": 19,
                        "scoring": "a1 b4 o6 e1 clip5 zdrop0",
-                       "setup_s": {"genome": round(t_gen, 2), "index_build": round(t_index, 2), "index_broadcast": round(t_bcast, 2)},
+                       "setup_s": {"genome": round(t_gen, 2), "index_build": round(t_index, 2), "index_broadcast": round(t_bcast, 2), "reads_drawn_while_waiting": round(t_reads_early, 2)},
                        "index_build": build_stats},
             "passes": passes,
-            "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
-            "stage_ms_isolated": {k: round(v, 3) for k, v in iso_ms.items()},
         }
         if dt_pcie:
             res["incl_pcie"] = {"value": round(total_reads * a.steps / dt_pcie / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(dt_pcie / a.steps * 1e3, 3),
@@ -578,6 +601,8 @@ def main():
         if distributed:
             res["distributed"] = {"backend": dist.get_backend(), "ranks": world, "devices_on_this_node": n_dev, "index_broadcast_s": round(t_bcast, 2),
                                   "text_generated_on_every_rank": bool(same_text), "ms_per_step_per_rank": {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3)},
+                                  "setup_s_per_rank": setup_per_rank,
+                                  "ranks_idle_behind_rank0_s": round(max([0.0] + [x["in_broadcast"] - setup_per_rank[0]["in_broadcast"] for x in setup_per_rank[1:]]), 2),
                                   "what": "one process per GPU; rank 0 builds the index while the others generate the same genome and draw their shards' reads, then ONE broadcast "
                                           "of the index arrays (RCCL over xGMI with backend nccl); no collective on the data path; `value` = reads of all ranks / slowest rank's time"}
         if world > 1:
@@ -664,19 +689,12 @@ def main():
                                  "frac_of_hbm_peak": round(kernel_bytes["extend"] / t_ext_s / 1e9 / HBM_PEAK_GBS, 5)}}
             if valu["traffic"] is not None:
                 valu["traffic_source"] = prof_src
-            if hasattr(L, "bmh_calib_valu"):
-                ms_c = C.c_float(0); ops_c = C.c_double(0)
-                L.bmh_calib_valu.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]
-                cal = {}
-                for mode, nm in ((0, "independent_v_max_add"), (1, "dependent_chain"), (2, "dpp_row_shr_max"), (4, "packed_u16_add_max")):
-                    if L.bmh_calib_valu(mode, 8, 20000, None, C.byref(ms_c), C.byref(ops_c)) == 0:
-                        cal[nm] = round(ops_c.value / (ms_c.value * 1e-3) / VALU_PEAK_LANEOPS, 3)
-                valu["calibration_frac_of_peak_measured_now"] = cal
-                if cal.get("independent_v_max_add"):
-                    # what the chip sustains on plain integer VALU instructions, measured in this run: one wave64 instruction per ~4.4 cycles per
-                    # SIMD whatever the number of resident waves (scripts/calib_valu.py), i.e. about half of the 2-cycle figure of the guide
-                    valu["measured_ceiling"] = round(cal["independent_v_max_add"] * VALU_PEAK_LANEOPS / 1e12, 2)
-                    valu["frac_of_measured_ceiling"] = round(valu["frac"] / cal["independent_v_max_add"], 4)
+            valu["calibration_frac_of_peak_measured_now"] = cal
+            if cal.get("independent_v_max_add"):
+                # what the chip sustains on plain integer VALU instructions, measured in this run: one wave64 instruction per ~4.4 cycles per
+                # SIMD whatever the number of resident waves (scripts/calib_valu.py), i.e. about half of the 2-cycle figure of the guide
+                valu["measured_ceiling"] = round(cal["independent_v_max_add"] * VALU_PEAK_LANEOPS / 1e12, 2)
+                valu["frac_of_measured_ceiling"] = round(valu["frac"] / cal["independent_v_max_add"], 4)
             issued = from_prof("extend", "valu_wave_instr_per_launch")
             if issued is not None:
                 valu["issue_slot_frac"] = round(issued * 64.0 / t_ext_s / VALU_PEAK_LANEOPS, 4)

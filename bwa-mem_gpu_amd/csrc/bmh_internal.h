@@ -101,6 +101,13 @@ int64_t bmh_finalize_regs_ids(const bmh_chain_opt_t *copt, const bmh_ext_params_
 extern "C" {
 #endif
 void bmh_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+// Measurement knobs (csrc/c_api.hip): the value of knob `name` -- what bmh_tune_set gave it in this process, else the environment
+// variable BMH_<NAME>, else dflt.  Looked up at every use (a map lookup), so that one process can sweep a knob (scripts/corun_probe.py).
+int bmh_tune(const char *name, int dflt);
+// wave residency trace (csrc/wtrace.h): one setter per translation unit with instrumented kernels
+int bmh_wtrace_set_seed(void *buf, unsigned int *cnt, unsigned int cap);
+int bmh_wtrace_set_chain(void *buf, unsigned int *cnt, unsigned int cap);
+int bmh_wtrace_set_extend(void *buf, unsigned int *cnt, unsigned int cap);
 #ifdef __cplusplus
 }
 #endif

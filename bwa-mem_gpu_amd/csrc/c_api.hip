@@ -6,9 +6,78 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
 #include "bmh_internal.h"
 
 static thread_local char g_err[512] = "";
+
+// ---- measurement knobs: bmh_tune("EXT_PERSIST", d) = bmh_tune_set's value, else $BMH_EXT_PERSIST, else d
+static std::mutex g_tune_mu;
+static std::map<std::string, int> g_tune_set;
+int bmh_tune(const char *name, int dflt)
+{
+	{
+		std::lock_guard<std::mutex> lk(g_tune_mu);
+		auto it = g_tune_set.find(name);
+		if (it != g_tune_set.end()) return it->second;
+	}
+	const std::string env = std::string("BMH_") + name;
+	const char *e = getenv(env.c_str());
+	return e && *e ? atoi(e) : dflt;
+}
+// sets (or, with clear != 0, forgets) a knob for this process; returns 0
+extern "C" int bmh_tune_set(const char *name, int value, int clear)
+{
+	if (!name) return BMH_EINVAL;
+	std::lock_guard<std::mutex> lk(g_tune_mu);
+	if (clear) g_tune_set.erase(name); else g_tune_set[name] = value;
+	return BMH_OK;
+}
+
+// ---- wave residency trace (csrc/wtrace.h): records of up to `cap` waves of the instrumented kernels launched between start and stop
+static void *g_wt_dev = nullptr; static unsigned int *g_wt_cnt_dev = nullptr; static unsigned int g_wt_cap_host = 0, g_wt_kept = 0;
+#define WT_SEGS 2048u      /* = csrc/wtrace.h */
+extern "C" int bmh_wtrace_start(uint32_t cap)
+{
+	cap -= cap % WT_SEGS;
+	if (g_wt_dev || cap == 0) { bmh_set_error("bmh_wtrace_start: a trace is running, or cap < %u", WT_SEGS); return BMH_EINVAL; }
+	if (hipMalloc(&g_wt_dev, (size_t)cap * 32) != hipSuccess || hipMalloc((void **)&g_wt_cnt_dev, WT_SEGS * 64) != hipSuccess) { bmh_set_error("bmh_wtrace_start: no device memory"); return BMH_ENOMEM; }
+	(void)hipMemset(g_wt_cnt_dev, 0, WT_SEGS * 64);
+	g_wt_cap_host = cap;
+	if (bmh_wtrace_set_seed(g_wt_dev, g_wt_cnt_dev, cap) || bmh_wtrace_set_chain(g_wt_dev, g_wt_cnt_dev, cap) || bmh_wtrace_set_extend(g_wt_dev, g_wt_cnt_dev, cap)) {
+		bmh_set_error("bmh_wtrace_start: hipMemcpyToSymbol failed"); return BMH_ENODEV;
+	}
+	return BMH_OK;
+}
+// stops the trace (waits for the device) and copies up to max_recs records of 32 bytes {u32 kernel, hw_id, xcc_id, aux; u64 t0, t1 (100 MHz)} to `out`
+// (the segments' records back to back); returns the number of waves that reported (may exceed what was kept), or a negative error
+extern "C" int64_t bmh_wtrace_stop(void *out, uint32_t max_recs)
+{
+	if (!g_wt_dev) { bmh_set_error("bmh_wtrace_stop: no trace running"); return BMH_EINVAL; }
+	(void)hipDeviceSynchronize();
+	(void)bmh_wtrace_set_seed(nullptr, nullptr, 0); (void)bmh_wtrace_set_chain(nullptr, nullptr, 0); (void)bmh_wtrace_set_extend(nullptr, nullptr, 0);
+	std::vector<unsigned int> cnt(WT_SEGS * 16);
+	(void)hipMemcpy(cnt.data(), g_wt_cnt_dev, WT_SEGS * 64, hipMemcpyDeviceToHost);
+	const unsigned int per = g_wt_cap_host / WT_SEGS;
+	int64_t reported = 0; uint32_t kept = 0;
+	for (unsigned int sgm = 0; sgm < WT_SEGS; ++sgm) {
+		const unsigned int c = cnt[sgm * 16];
+		reported += c;
+		unsigned int k = c < per ? c : per;
+		if (kept + k > max_recs) k = max_recs - kept;
+		if (out && k) (void)hipMemcpy((char *)out + (size_t)kept * 32, (char *)g_wt_dev + (size_t)sgm * per * 32, (size_t)k * 32, hipMemcpyDeviceToHost);
+		kept += k;
+	}
+	(void)hipFree(g_wt_dev); (void)hipFree(g_wt_cnt_dev);
+	g_wt_dev = nullptr; g_wt_cnt_dev = nullptr; g_wt_cap_host = 0;
+	g_wt_kept = kept;
+	return reported;
+}
+// records the last bmh_wtrace_stop copied out
+extern "C" uint32_t bmh_wtrace_kept(void) { return g_wt_kept; }
 
 extern "C" void bmh_set_error(const char *fmt, ...)
 {

@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "bmh_internal.h"
+#include "wtrace.h"
 #include "chain_core.h"
 
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
@@ -56,6 +57,7 @@ static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {0u, 8192u, 4096u, 2048u, 10
 __device__ __forceinline__ int ch_bin_of(uint32_t need) { return need <= 2u ? 0 : need <= 4u ? 1 : need <= 8u ? 2 : 3; }
 __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 {
+	wtrace_scope_t wt_(WT_CHAIN_CLASSIFY);
 	// (bins CH_N_BINS.. of the block counters: the wave / lane-list classes -- 50 000 appends to two counters, one atomic each, were
 	// 0.4 ms of same-address atomics)
 	__shared__ uint32_t l_cnt[CH_N_BINS + CH_N_CLASSES], l_base[CH_N_BINS + CH_N_CLASSES];
@@ -109,6 +111,7 @@ template <int CAP> struct ch_private_t {
 template <bool FLT, int CAP>
 __global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A, const uint32_t skip_bins)
 {
+	wtrace_scope_t wt_(WT_CHAIN_LANE);
 	uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	int bin = CH_N_BINS - 1;
 	for (; bin >= 0; --bin) { const uint32_t c = (skip_bins >> bin & 1u) ? 0u : A.light_n[bin]; if (t < c) break; t -= c; }
@@ -154,6 +157,7 @@ __global__ void __launch_bounds__(64) chain_lane_lds_kernel(chain_args_t A, int 
 template <bool FLT, int CAP>
 __global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, uint32_t cls)
 {
+	wtrace_scope_t wt_(WT_CHAIN_LIST, cls);
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= A.heavy_n[cls]) return;
 	const uint32_t r = A.heavy_list[(size_t)cls * A.n_reads + i];
@@ -175,6 +179,7 @@ __global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, ui
 template <bool CTG_LDS, bool FLT>
 __global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_t A, uint32_t cls, uint32_t lds_cap, int hybrid)
 {
+	wtrace_scope_t wt_(WT_CHAIN_WAVE, cls);
 	extern __shared__ __align__(16) uint8_t ch_lds[];
 	const uint32_t nh = A.heavy_n[cls];
 	const uint32_t *list = A.heavy_list + (size_t)cls * A.n_reads;
@@ -227,6 +232,7 @@ struct emit_args_t {
 #define CH_EMIT_LANE_MAX 32
 __global__ void __launch_bounds__(256) emit_kernel(emit_args_t A)
 {
+	wtrace_scope_t wt_(WT_CHAIN_EMIT);
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
 	if (r >= A.n_reads) return;
 	const uint32_t nr = (A.need && (A.need[r] > A.thresh) != (A.pass == 1)) ? 0u : A.regs_per_read[r];
@@ -256,6 +262,7 @@ __global__ void __launch_bounds__(256) emit_kernel(emit_args_t A)
 // cannot make that many): one wave per read, one region per lane, the jobs' places by ballot counts
 __global__ void __launch_bounds__(256) emit_wave_kernel(emit_args_t A, const uint32_t *__restrict__ lists, const uint32_t *__restrict__ list_n, int cls_lo, int cls_hi)
 {
+	wtrace_scope_t wt_(WT_CHAIN_EMIT, 1);
 	const int lane = threadIdx.x & 63;
 	const uint32_t gw = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
 	const unsigned long long lt = (1ull << lane) - 1ull;
@@ -949,3 +956,6 @@ extern "C" int bmh_chain_extend_merge_timing(const bmh_chain_ws_t *w, float ms[3
 	jobs[0] = w->n_jobs_a; jobs[1] = w->n_jobs - w->n_jobs_a;
 	return BMH_OK;
 }
+
+// wave residency trace (wtrace.h): this translation unit's copy of the trace symbols
+WTRACE_DEFINE_SETTER(bmh_wtrace_set_chain)

@@ -36,6 +36,7 @@
 #include <mutex>
 #include <utility>
 #include "bmh_internal.h"
+#include "wtrace.h"
 
 #define NEG_INF (-(1 << 29))
 #define EXT_T_CAP 1024        // target bases of an alignment staged in LDS by extend16_kernel
@@ -73,6 +74,7 @@ struct ext_args_t {
 	const uint8_t *reads, *pac; long long l_pac;
 	const uint32_t *jq_src, *job_side; const long long *jt0;
 	const uint32_t *ids;          // alignment ids of this class
+	const uint4 *recs;            // the same list as 32-byte job records (ext_scatter_kernel), two uint4 per job: {id, qlen | tlen << 16, h0, jq_src or qoff} {job_side, toff, jt0 lo, jt0 hi}
 	const uint32_t *count;        // how many
 	uint32_t *ctr;                // next unassigned job of this class (extend16_kernel draws from it)
 	int32_t *out, *raw;
@@ -645,10 +647,6 @@ __global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t
 }
 
 
-#include "extpk_dev.h"
-
-// ------------------------------------------------------------------ closed-form prefilter
-
 // classes: 0 = unsupported length (query longer than 768 bases: all three outputs INT32_MIN, counted, see
 // bmh_extend_last_unsupported); 1..18 = extend16_kernel<C>; 19..26 = extend_wide_kernel<5..12>
 #define EXT_WIDE_MAX_C 12
@@ -659,6 +657,15 @@ __global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t
 // (up to 16 P); 40 = extpk_kernel<16, 9> (up to 288)
 #define EXT_PK_BASE 28
 #define EXT_PK_MAXQ 288
+
+// (G = 4, P = 17: queries of 129..136 columns -- the flank of a 150 bp read whose seed sits at its very end -- on four lanes
+// instead of eight: 26 instead of 34 wave-instructions per alignment row, for 15 % of the extension's time on 150 bp reads)
+#define EXT_PK17_CLS (EXT_PK_BASE + 13)
+constexpr int ext_pk_cls_of(int G, int P) { return G == 4 && P == 17 ? EXT_PK17_CLS : EXT_PK_BASE + (G == 4 ? P / 2 - 2 : G == 16 ? 12 : P == 9 ? 7 : P == 10 ? 8 : P / 2 + 3); }
+
+#include "extpk_dev.h"
+
+// ------------------------------------------------------------------ closed-form prefilter
 
 // packed 16-bit class of a query length (0: none)
 __device__ __forceinline__ int ext_pk_class(uint32_t ql)
@@ -673,11 +680,6 @@ __device__ __forceinline__ int ext_class(uint32_t ql)
 	const int wc = (int)((ql + 63) / 64);
 	return wc <= EXT_WIDE_MAX_C ? 19 + (wc - 5) : 0;
 }
-// (G = 4, P = 17: queries of 129..136 columns -- the flank of a 150 bp read whose seed sits at its very end -- on four lanes
-// instead of eight: 26 instead of 34 wave-instructions per alignment row, for 15 % of the extension's time on 150 bp reads)
-#define EXT_PK17_CLS (EXT_PK_BASE + 13)
-constexpr int ext_pk_cls_of(int G, int P) { return G == 4 && P == 17 ? EXT_PK17_CLS : EXT_PK_BASE + (G == 4 ? P / 2 - 2 : G == 16 ? 12 : P == 9 ? 7 : P == 10 ? 8 : P / 2 + 3); }
-
 // The jobs of a batch are grouped by class and, inside a class, by target length in steps of 32 rows (the class kernels draw from
 // the long end, so that their tails are short jobs): a counting sort over EXT_N_BINS = classes x 16 bins -- the bin of every job and
 // the histogram come out of the prefilter kernel below, then offsets and a scatter -- instead of a radix sort of (class << 20 | tlen)
@@ -798,6 +800,7 @@ __device__ __forceinline__ void pk_q8(const ext_args_t &A, const job_src_t &s, c
 }
 __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint32_t n, uint32_t *__restrict__ bin_of, uint32_t *__restrict__ bin_cnt, int pk_a)
 {
+	wtrace_scope_t wt_(WT_EXT_CLOSED);
 	__shared__ uint32_t hist[EXT_N_BINS];
 	for (int k = threadIdx.x; k < EXT_N_BINS; k += 256) hist[k] = 0;
 	__syncthreads();
@@ -928,9 +931,12 @@ __global__ void ext_offsets_kernel(uint32_t *counts, const uint32_t *__restrict_
 	}
 }
 
-// every block takes a range of each of its bins with one atomic, its jobs their places in it with LDS atomics
-__global__ void __launch_bounds__(256) ext_scatter_kernel(const uint32_t *__restrict__ bin_of, uint32_t n, const uint32_t *__restrict__ bin_base,
-                                                          uint32_t *__restrict__ bin_cur, uint32_t *__restrict__ ids)
+// every block takes a range of each of its bins with one atomic, its jobs their places in it with LDS atomics; beside its id every job
+// leaves a 32-byte RECORD of what a kernel needs to start it (lengths, seed score, where its bases are) at its place in the grouped list:
+// a wave that draws jobs reads them in one coalesced load per chunk instead of chasing ids[] -> qlen / tlen / h0 -> jq_src / jt0 / job_side
+// through three dependent gathers per job (extpk_dev.h: what the packed kernels' waves waited for)
+__global__ void __launch_bounds__(256) ext_scatter_kernel(ext_args_t A, const uint32_t *__restrict__ bin_of, uint32_t n, const uint32_t *__restrict__ bin_base,
+                                                          uint32_t *__restrict__ bin_cur, uint32_t *__restrict__ ids, uint4 *__restrict__ recs)
 {
 	__shared__ uint32_t hist[EXT_N_BINS], base[EXT_N_BINS];
 	for (int k = threadIdx.x; k < EXT_N_BINS; k += 256) hist[k] = 0;
@@ -941,7 +947,17 @@ __global__ void __launch_bounds__(256) ext_scatter_kernel(const uint32_t *__rest
 	__syncthreads();
 	for (int k = threadIdx.x; k < EXT_N_BINS; k += 256) if (hist[k]) base[k] = bin_base[k] + atomicAdd(&bin_cur[k], hist[k]);
 	__syncthreads();
-	if (t < n) ids[base[bin] + my] = t;
+	if (t < n) {
+		const uint32_t pos = base[bin] + my;
+		ids[pos] = t;
+		if (bin / EXT_TL_BINS == EXT_DONE_CLS) return;          // decided by the prefilter: nobody draws it
+		const uint32_t ql = A.qlen[t], tl = A.tlen[t];
+		uint4 r0, r1;
+		r0.x = t; r0.y = (ql & 0xFFFFu) | ((tl < 0xFFFFu ? tl : 0xFFFFu) << 16); r0.z = A.h0[t];
+		if (A.desc) { const long long t0 = A.jt0[t]; r0.w = A.jq_src[t]; r1.x = A.job_side[t]; r1.y = 0; r1.z = (uint32_t)t0; r1.w = (uint32_t)((unsigned long long)t0 >> 32); }
+		else { r0.w = A.qoff[t]; r1.x = 1; r1.y = A.toff[t]; r1.z = r1.w = 0; }
+		recs[2 * (size_t)pos] = r0; recs[2 * (size_t)pos + 1] = r1;
+	}
 }
 
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { bmh_set_error("%s: %s", #x, hipGetErrorString(e_)); return BMH_ENODEV; } } while (0)
@@ -949,7 +965,7 @@ __global__ void __launch_bounds__(256) ext_scatter_kernel(const uint32_t *__rest
 // scratch for the sorted job list: one per (device, stream), grown on demand and reused across calls, so
 // that batches in flight on different streams never share it
 struct ext_scratch_t {
-	uint32_t *keys, *vals2, *counts, *bins; size_t cap; int dev;      // keys: bin of every job; vals2: job ids grouped by bin; bins: [3][EXT_N_BINS] count / base / cursor
+	uint32_t *keys, *vals2, *counts, *bins; uint4 *recs; size_t cap; int dev;      // keys: bin of every job; vals2: job ids grouped by bin; bins: [3][EXT_N_BINS] count / base / cursor
 	hipEvent_t ev0, ev1; bool have_ev;
 	hipStream_t side[4]; hipEvent_t fork, join[4];     // class kernels run concurrently on side streams
 };
@@ -975,10 +991,11 @@ static int scratch_reserve(ext_scratch_t &g_scr, int dev, size_t n)
 {
 	if (g_scr.cap >= n) return BMH_OK;
 	const size_t c = n + n / 4 + 1024;
-	void *ps[] = {g_scr.keys, g_scr.vals2, g_scr.counts, g_scr.bins};
+	void *ps[] = {g_scr.keys, g_scr.vals2, g_scr.counts, g_scr.bins, g_scr.recs};
 	for (void *q : ps) if (q) (void)hipFree(q);
-	g_scr.keys = g_scr.vals2 = g_scr.counts = g_scr.bins = nullptr; g_scr.cap = 0;
+	g_scr.keys = g_scr.vals2 = g_scr.counts = g_scr.bins = nullptr; g_scr.recs = nullptr; g_scr.cap = 0;
 	HIPCK(hipMalloc((void **)&g_scr.keys, 4 * c)); HIPCK(hipMalloc((void **)&g_scr.vals2, 4 * c));
+	HIPCK(hipMalloc((void **)&g_scr.recs, 32 * c));
 	HIPCK(hipMalloc((void **)&g_scr.counts, 4 * 3 * EXT_N_CLS));
 	HIPCK(hipMalloc((void **)&g_scr.bins, 4 * 3 * EXT_N_BINS));
 	g_scr.cap = c; g_scr.dev = dev;
@@ -1012,7 +1029,7 @@ extern "C" void bmh_extend_release(void *stream_)
 		g_scr_map.erase(it);
 	}
 	if (g_last == s) g_last = nullptr;
-	void *ps[] = {s->keys, s->vals2, s->counts, s->bins};
+	void *ps[] = {s->keys, s->vals2, s->counts, s->bins, s->recs};
 	for (void *q : ps) if (q) (void)hipFree(q);
 	if (s->have_ev) {
 		(void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1); (void)hipEventDestroy(s->fork);
@@ -1135,7 +1152,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	a.desc = desc ? 1 : 0;
 	a.reads = desc ? desc->reads : nullptr; a.pac = desc ? desc->pac : nullptr; a.l_pac = desc ? desc->l_pac : 0;
 	a.jq_src = desc ? desc->jq_src : nullptr; a.job_side = desc ? desc->job_side : nullptr; a.jt0 = desc ? (const long long *)desc->jt0 : nullptr;
-	a.ids = g_scr.vals2; a.count = g_scr.counts; a.ctr = g_scr.counts + 2 * EXT_N_CLS; a.out = d_out; a.raw = d_raw;
+	a.ids = g_scr.vals2; a.recs = g_scr.recs; a.count = g_scr.counts; a.ctr = g_scr.counts + 2 * EXT_N_CLS; a.out = d_out; a.raw = d_raw;
 	a.a = p->a; a.b = p->b; a.o_del = p->o_del; a.e_del = p->e_del; a.o_ins = p->o_ins; a.e_ins = p->e_ins;
 	a.zdrop = p->zdrop; a.end_bonus = p->end_bonus;
 	a.stats = nullptr;
@@ -1162,7 +1179,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	}
 	if (want_phases) { HIPCK(hipEventRecord(ph[1], st)); HIPCK(hipEventRecord(ph[2], st)); }
 	ext_offsets_kernel<<<1, 64, 0, st>>>(g_scr.counts, g_scr.bins, g_scr.bins + EXT_N_BINS);
-	ext_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(g_scr.keys, n, g_scr.bins + EXT_N_BINS, g_scr.bins + 2 * EXT_N_BINS, g_scr.vals2);
+	ext_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(a, g_scr.keys, n, g_scr.bins + EXT_N_BINS, g_scr.bins + 2 * EXT_N_BINS, g_scr.vals2, g_scr.recs);
 	// class sizes stay on the device (no host sync): every class kernel is launched with a grid
 	// that covers the whole batch and its waves stride over the class's slice of the sorted list
 	unsigned g16 = (unsigned)((n + 15) / 16), gw = (unsigned)((n + 3) / 4);
@@ -1179,7 +1196,19 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	// classes beyond it: they would find their lists empty, but each occupies its side stream until it has had its turn on the chip)
 	const uint32_t mq = desc && desc->max_qlen ? desc->max_qlen : 0xFFFFFFFFu;
 	// the packed classes hold the bulk of the jobs when they are enabled: they go first, widest (longest running) first
-	if (pk_ok) {
+	// Persistent form (EXT_PERSIST = blocks per CU, 0 = one kernel per class): one launch works all packed classes off and keeps a fixed
+	// share of every SIMD for the whole pass (extpk_dev.h: extpk_persist_kernel)
+	const int persist = pk_ok ? bmh_tune("EXT_PERSIST", PK_PERSIST_DEFAULT) : 0;
+	if (persist > 0) {
+		static thread_local int n_cu = 0;
+		if (!n_cu) { hipDeviceProp_t prop; HIPCK(hipGetDeviceProperties(&prop, dev)); n_cu = prop.multiProcessorCount; }
+		unsigned gp = (unsigned)(n_cu * (persist > 3 ? 3 : persist));
+		const unsigned need = (unsigned)((n + 15) / 16 + 3) / 4;            // blocks that 16 jobs a wave would fill
+		if (gp > need) gp = need ? need : 1;
+		const unsigned lds_pad = (unsigned)bmh_tune("EXT_LDS_PAD", 0);
+		if (a.o_ins + a.e_ins == a.o_del + a.e_del) extpk_persist_kernel<true><<<gp, 256, lds_pad, S[0]>>>(a);
+		else extpk_persist_kernel<false><<<gp, 256, lds_pad, S[0]>>>(a);
+	} else if (pk_ok) {
 		// grids sized to what is resident at once (the waves draw their jobs): 3 waves per SIMD beyond PK_WAVES4_MAXP pairs per lane (768 blocks), 4 up to there
 		unsigned g4 = (unsigned)((n + 63) / 64), g8 = (unsigned)((n + 31) / 32);
 		if (g4 > max_grid) g4 = max_grid;
@@ -1347,6 +1376,16 @@ static void calib_launch(int mode, unsigned grid, int iters, int *sink, unsigned
 // bmh_calib_valu_placed: the same, and place[grid * 4] (host memory, may be NULL) receives for every wave of the timed launch
 // (xcc_id << 32 | HW_ID): which SIMD of which CU it ran on -- the evidence that the launch covered every SIMD evenly.
 extern "C" int bmh_calib_valu_placed(int mode, int waves_per_simd, int iters, void *stream_, float *ms, double *lane_ops, unsigned long long *place, unsigned *n_place);
+// The shader clock during the calling thread's last calibration launch, measured IN the kernel: shader cycles (s_memtime) over 100 MHz
+// ticks (s_memrealtime) of wave 0 around its instruction loop, and the shader cycles one wave64 instruction of that wave took.  A
+// VALU-bound stage scales with this clock: the bench line carries it so that two runs on two boxes can be told apart from two builds.
+static thread_local double g_calib_mhz = 0.0, g_calib_cpi = 0.0;
+extern "C" int bmh_calib_last_clock(double *mhz, double *cycles_per_instr)
+{
+	if (mhz) *mhz = g_calib_mhz;
+	if (cycles_per_instr) *cycles_per_instr = g_calib_cpi;
+	return g_calib_mhz > 0.0 ? BMH_OK : BMH_EINVAL;
+}
 extern "C" int bmh_calib_valu(int mode, int waves_per_simd, int iters, void *stream_, float *ms, double *lane_ops)
 {
 	return bmh_calib_valu_placed(mode, waves_per_simd, iters, stream_, ms, lane_ops, nullptr, nullptr);
@@ -1378,11 +1417,16 @@ extern "C" int bmh_calib_valu_placed(int mode, int waves_per_simd, int iters, vo
 		if (n_place) *n_place = grid * 4;
 	}
 	*lane_ops = (double)grid * 256.0 * 128.0 * (double)iters;
+	unsigned long long h[3];
+	HIPCK(hipMemcpy(h, sink, 24, hipMemcpyDeviceToHost));
+	g_calib_cpi = (double)h[1] / (128.0 * iters);
+	g_calib_mhz = h[2] ? (double)h[1] / (double)h[2] * 100.0 : 0.0;
 	if (getenv("BMH_CALIB_VERBOSE")) {
-		unsigned long long h[3];
-		HIPCK(hipMemcpy(h, sink, 24, hipMemcpyDeviceToHost));
 		fprintf(stderr, "[calib] mode %d, %d waves/SIMD: %.2f shader cycles per instruction of one wave, shader clock %.0f MHz\n", mode, waves_per_simd,
 		        (double)h[1] / (128.0 * iters), h[2] ? (double)h[1] / (double)h[2] * 100.0 : 0.0);
 	}
 	return BMH_OK;
 }
+
+// wave residency trace (wtrace.h): this translation unit's copy of the trace symbols
+WTRACE_DEFINE_SETTER(bmh_wtrace_set_extend)

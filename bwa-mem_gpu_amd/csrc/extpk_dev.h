@@ -22,7 +22,7 @@
 // target bases of an alignment staged in LDS, by group width (the 4-lane groups are the many small queries: 64 of them per block)
 #define PK_TCAP(G) ((G) == 4 ? 384 : (G) == 8 ? 512 : 640)
 #ifndef PK_WAVES4_MAXP
-#define PK_WAVES4_MAXP 10     // classes of up to this many pairs per lane run four waves per SIMD (registers and grid; 120 VGPRs at 10 pairs), the larger ones three (8 -> 10: -0.5 % at 150 bp, -0.7 % at 300 bp)
+#define PK_WAVES4_MAXP 8      // classes of up to this many pairs per lane run four waves per SIMD (registers and grid; 120 VGPRs at 10 pairs), the larger ones three (8 -> 10: -0.5 % at 150 bp, -0.7 % at 300 bp)
 #endif
 #ifndef PK_BOUND_MASK
 #define PK_BOUND_MASK 15      // the exact early-stop bound is evaluated every (mask + 1)-th row of a wave (every 2nd / 4th / 8th / 16th / 32nd: 17.6 / 17.3 / 17.2 / 17.1 / 17.4 ms)
@@ -30,6 +30,9 @@
 #define PK_HMAX 4096          // scores stay below this (keys are h << 4 | pair in 16 bits)
 #define PK_HMAX17 2048        // ... in the 17-pair class (keys h << 5 | pair)
 #define PK_NEG (-(1 << 28))
+#ifndef PK_PERSIST_DEFAULT
+#define PK_PERSIST_DEFAULT 0  // blocks per CU of the persistent packed kernel (0: one kernel per class); knob EXT_PERSIST
+#endif
 
 // The pair steps are spelled out as asm blocks: left to itself the compiler turns min(x, 1) and the 0/1 multiply into per-half
 // compares and selects (five instructions instead of one), and reorders the in-place updates so that every loop-carried pair needs
@@ -53,6 +56,56 @@ __device__ __forceinline__ uint32_t pk_spread4(uint32_t z)
 	const uint32_t a = (z | (z << 12)) & 0x000F000Fu;
 	return (a | (a << 6)) & 0x03030303u;
 }
+// Where the eight target rows k0..k0+7 of a descriptor job sit in the 2-bit text, and their decoding from the dword loaded there --
+// split so that the load can be issued long before its result is needed (extpk_body fetches the next job's bases ahead).
+struct pk_t8w_t { long long fa; int D; bool asc, rev; };
+__device__ __forceinline__ pk_t8w_t pk_t8_where(const long long l_pac, const long long t0, const int tdir, const int k0)
+{
+	pk_t8w_t w;
+	const long long p0 = t0 + (long long)k0 * tdir;
+	w.rev = p0 >= l_pac;
+	const long long f0 = w.rev ? (l_pac << 1) - 1 - p0 : p0;        // forward-strand position of row k0
+	w.asc = w.rev ? tdir < 0 : tdir > 0;                            // the rows walk the forward strand upwards
+	w.fa = w.asc ? f0 : f0 - 7;                                     // lowest position of the eight
+	w.D = 7;                                                        // descending: row u is symbol D - u of the window at fa
+	if (w.fa < 0) { w.D = (int)f0; w.fa = 0; }
+	return w;
+}
+__device__ __forceinline__ void pk_t8_decode(const uint32_t raw, const pk_t8w_t &w, uint32_t &lo, uint32_t &hi)
+{
+	const uint32_t v = __builtin_bswap32(raw) >> 8;
+	const uint32_t y = (v << (8 + 2 * ((int)w.fa & 3))) >> 16;      // eight symbols, position fa+j at bits 15-2j:14-2j
+	const uint32_t z = w.asc ? y : y >> (2 * (7 - w.D));
+	const uint32_t w0 = pk_spread4(z & 0xFFu), w1 = pk_spread4((z >> 8) & 0xFFu);
+	lo = w.asc ? __builtin_bswap32(w1) : w0;
+	hi = w.asc ? __builtin_bswap32(w0) : w1;
+	if (w.rev) { lo ^= 0x03030303u; hi ^= 0x03030303u; }
+}
+// Four query columns c0..c0+3 of a descriptor job from ONE dword of the ASCII reads.  The dword is the four bytes at the columns' lowest
+// address, moved into the query segment where it would reach outside (the lane at the segment's end: a load must not leave the
+// reads' buffer); sh = how many bytes it was moved.  Needs qlen >= 4.
+__device__ __forceinline__ const uint8_t *pk_q4_where(const uint8_t *qp, const int qstep, const int qlen, const int c0, int &sh)
+{
+	const uint8_t *lo = qstep > 0 ? qp + c0 : qp - c0 - 3;
+	const uint8_t *seg = qstep > 0 ? qp : qp - (qlen - 1);
+	const uint8_t *ld = lo < seg ? seg : (lo > seg + (qlen - 4) ? seg + (qlen - 4) : lo);
+	sh = (int)(lo - ld);
+	return ld;
+}
+// ... and its decoding: codes 0..3, 4 = anything else (N), 7 = pad at and beyond qlen, column c0+u in byte u (what ext_q_at gives byte by byte)
+__device__ __forceinline__ uint32_t pk_q4_decode(const uint32_t raw, const int sh, const int qstep, const int qlen, const int c0)
+{
+	uint32_t v = sh >= 0 ? raw >> (8 * sh) : raw << (8 * -sh);       // byte u = the byte at (lowest address + u)
+	if (qstep < 0) v = __builtin_bswap32(v);
+	const uint32_t W = v & 0xDFDFDFDFu, t = (W >> 1) & 0x03030303u;
+	uint32_t code = t ^ ((t >> 1) & 0x01010101u);
+	const uint32_t x = __builtin_amdgcn_perm(0u, 0x54474341u, code) ^ W;                    // non-zero byte: not the letter the code stands for
+	const uint32_t m = (((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u) >> 7) * 0xFFu;
+	code = (code & ~m) | (0x04040404u & m);
+	const int nv = qlen - c0;
+	const uint32_t vm = nv >= 4 ? 0xFFFFFFFFu : nv <= 0 ? 0u : (1u << (8 * nv)) - 1u;
+	return (code & vm) | (0x07070707u & ~vm);
+}
 // Target codes of rows k0..k0+7 of one job as two dwords (byte u of `lo` = row k0+u; rows at and beyond tlen: don't care).
 // Descriptor jobs decode them from three bytes of the 2-bit text at once (the rows of a job walk ONE strand up or down:
 // chain2aln clips a window that would cross the strand boundary, src/bwamem.c:1261-1264); array jobs read their bytes.
@@ -68,23 +121,11 @@ __device__ __forceinline__ void pk_t8(const ext_args_t &A, const job_src_t &s, c
 		}
 		return;
 	}
-	const long long p0 = s.t0 + (long long)k0 * s.tdir;
-	const bool rev = p0 >= A.l_pac;
-	const long long f0 = rev ? (A.l_pac << 1) - 1 - p0 : p0;          // forward-strand position of row k0
-	const bool asc = rev ? s.tdir < 0 : s.tdir > 0;                  // the rows walk the forward strand upwards
-	long long fa = asc ? f0 : f0 - 7;                                // lowest position of the eight
-	int D = 7;                                                       // descending: row u is symbol D - u of the window at fa
-	if (fa < 0) { D = (int)f0; fa = 0; }
+	const pk_t8w_t w = pk_t8_where(A.l_pac, s.t0, s.tdir, k0);
 	// three bytes of the text as ONE unaligned dword load (the 64 lanes of a staging step read 64 different lines: what such a step
 	// costs is its number of load instructions; pac is readable 9 bytes past its end)
-	uint32_t raw; __builtin_memcpy(&raw, A.pac + (fa >> 2), 4);
-	const uint32_t v = __builtin_bswap32(raw) >> 8;
-	const uint32_t y = (v << (8 + 2 * ((int)fa & 3))) >> 16;          // eight symbols, position fa+j at bits 15-2j:14-2j
-	const uint32_t z = asc ? y : y >> (2 * (7 - D));
-	const uint32_t w0 = pk_spread4(z & 0xFFu), w1 = pk_spread4((z >> 8) & 0xFFu);
-	lo = asc ? __builtin_bswap32(w1) : w0;
-	hi = asc ? __builtin_bswap32(w0) : w1;
-	if (rev) { lo ^= 0x03030303u; hi ^= 0x03030303u; }
+	uint32_t raw; __builtin_memcpy(&raw, A.pac + (w.fa >> 2), 4);
+	pk_t8_decode(raw, w, lo, hi);
 }
 
 // first pass of a pair: M = hd ? max(hd + score, 0) : 0 and the chain's local F, i.e. what the chain's own cells send out of its last
@@ -247,12 +288,29 @@ template <int P> __device__ __forceinline__ pk_consts_t<P> pk_consts(const ext_a
 // per-alignment control state, replicated over the lanes of the group
 struct pk_rs_t { int end, mx, max_i, max_j, max_ie, gscore, max_off; };
 
-template <int P, bool SAME_OE, int PP, int... Is>
-__device__ __forceinline__ void pk_pass2(uint32_t (&H)[P], uint32_t (&E)[P], uint32_t (&NZ)[P], const uint32_t (&M)[P], const uint32_t (&em)[PP],
-                                         uint32_t &f, uint32_t &key, uint32_t &nzb, uint32_t &nzb2, const pk_consts_t<P> &K, std::integer_sequence<int, Is...>)
+// second pass over four pairs (one uint4 of end masks); FIRST = the chunk's first pair
+template <int P, bool SAME_OE, int FIRST, int... Is>
+__device__ __forceinline__ void pk_pass2_chunk(uint32_t (&H)[P], uint32_t (&E)[P], uint32_t (&NZ)[P], const uint32_t (&M)[P], const uint4 em,
+                                               uint32_t &f, uint32_t &key, uint32_t &nzb, uint32_t &nzb2, const pk_consts_t<P> &K, std::integer_sequence<int, Is...>)
 {
 	// (keys are h << 4 | pair up to 16 pairs, h << 5 | pair beyond; the non-zero bits of pairs 16.. go to a second register)
-	(pk_pair2<Is, SAME_OE, (P > 16 ? 32 : 16)>(H[Is], E[Is], NZ[Is], f, key, Is < 16 ? nzb : nzb2, M[Is], em[Is], K.ei2, K.ed2, K.oei2, K.oed2), ...);
+	const uint32_t e[4] = {em.x, em.y, em.z, em.w};
+	(pk_pair2<FIRST + Is, SAME_OE, (P > 16 ? 32 : 16)>(H[FIRST + Is], E[FIRST + Is], NZ[FIRST + Is], f, key, FIRST + Is < 16 ? nzb : nzb2, M[FIRST + Is], e[Is], K.ei2, K.ed2, K.oei2, K.oed2), ...);
+}
+// the whole second pass: the end masks of the lane come from LDS one uint4 (four pairs) at a time, each asked for while the four pairs
+// before it are worked on -- all PP of them held at once were the registers that the job pipeline's loads in flight needed
+template <int P, bool SAME_OE, int K0>
+__device__ __forceinline__ void pk_pass2(uint32_t (&H)[P], uint32_t (&E)[P], uint32_t (&NZ)[P], const uint32_t (&M)[P], const uint4 *src, const uint4 cur,
+                                         uint32_t &f, uint32_t &key, uint32_t &nzb, uint32_t &nzb2, const pk_consts_t<P> &K)
+{
+	constexpr int PP = (P + 3) & ~3, NCH = PP / 4, CNT = (K0 + 1) * 4 <= P ? 4 : P - K0 * 4;
+	if constexpr (K0 + 1 < NCH) {
+		const uint4 nxt = src[K0 + 1];
+		pk_pass2_chunk<P, SAME_OE, K0 * 4>(H, E, NZ, M, cur, f, key, nzb, nzb2, K, std::make_integer_sequence<int, CNT>());
+		pk_pass2<P, SAME_OE, K0 + 1>(H, E, NZ, M, src, nxt, f, key, nzb, nzb2, K);
+	} else {
+		pk_pass2_chunk<P, SAME_OE, K0 * 4>(H, E, NZ, M, cur, f, key, nzb, nzb2, K, std::make_integer_sequence<int, CNT>());
+	}
 }
 
 // One DP row of the wave's alignments.  em_tab: the end masks, [2P+1][PP] dwords in LDS; hrow: the group's PP dwords of the H
@@ -261,7 +319,7 @@ __device__ __forceinline__ void pk_pass2(uint32_t (&H)[P], uint32_t (&E)[P], uin
 template <int G, int P, bool SAME_OE>
 __device__ __forceinline__ bool pk_row(const pk_consts_t<P> &K, const int zdrop, uint32_t (&H)[P], uint32_t (&E)[P], uint32_t (&NZ)[P], const uint32_t (&sel)[P],
                                        const int ti, const bool run, const int hfc, const int hnx, const int i, const int qlen,
-                                       const int j0, const int eCl, const bool g0, const uint32_t phi0,
+                                       const int j0, const int eCl, const bool g0,
                                        const uint32_t *em_tab, uint32_t *hrow, const bool owner, const uint16_t *h16, const int goff,
                                        pk_rs_t &S, bool alive, const bool bound, const int rl, const bool o3only, const int end_bonus)
 {
@@ -269,12 +327,8 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t<P> &K, const int zdrop,
 	// end masks of this lane: cells [0, wend) of the lane are left of `end`
 	const int wend = run ? S.end - j0 : 0;
 	const int wc = min(max(wend, 0), C);
-	uint32_t em[PP];
-	{
-		const uint4 *src = (const uint4 *)(em_tab + wc * PS);
-#pragma unroll
-		for (int k = 0; k < PP / 4; ++k) { const uint4 v = src[k]; em[4 * k] = v.x; em[4 * k + 1] = v.y; em[4 * k + 2] = v.z; em[4 * k + 3] = v.w; }
-	}
+	const uint4 *em_src = (const uint4 *)(em_tab + wc * PS);
+	const uint4 em0 = em_src[0];
 	// score + b of this row's target base against query codes 0..3 (bytes of tbl_lo); N rows: b-1 everywhere
 	const uint32_t tbl_lo = ti < 4 ? (K.ab << (8 * ti)) : K.nrow;
 	// diagonal input of pair 0: (last column of the left lane | first-column value, own column P-1)
@@ -302,7 +356,7 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t<P> &K, const int zdrop,
 		f = (uint32_t)fin_lo | ((uint32_t)fin_hi << 16);
 	}
 	uint32_t key = 0, nzb = 0, nzb2 = 0;
-	pk_pass2<P, SAME_OE>(H, E, NZ, M, em, f, key, nzb, nzb2, K, std::make_integer_sequence<int, P>());
+	pk_pass2<P, SAME_OE, 0>(H, E, NZ, M, em_src, em0, f, key, nzb, nzb2, K);
 	// last non-zero H column of the lane, + 1 (0: none): pair p sits at bit P-1-p of its half of nzb (branch-free)
 	int nlast;
 	{
@@ -363,6 +417,8 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t<P> &K, const int zdrop,
 	// Exact early stop (see ext_row): Phi = H + a*(qlen-1-column) over the NON-ZERO cells of the frontier; E(i+1,j) <= H(i,j), so H
 	// alone carries it.  Zero cells are lifted out of the maximum by an offset that the non-zero ones carry (NZ * 0x4000).
 	if (bound) {                                                // wave-uniform
+		// potential of the lane's first column of either chain: a * (columns right of it)
+		const uint32_t phi0 = ((uint32_t)(K.a * (qlen - 1 - j0)) & 0xFFFFu) | ((uint32_t)(K.a * (qlen - 1 - j0 - P)) << 16);
 		// max over the pairs of H[p] - a*p, as a Horner-style chain from the last pair down (one constant instead of P)
 #ifdef PK_BOUND_R2      // (A/B builds: round 2's rule, zero cells carry potential too)
 		uint32_t u2 = H[P - 1];
@@ -389,56 +445,90 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t<P> &K, const int zdrop,
 	return alive;
 }
 
-// The kernel: every group of G lanes runs its own alignment and row index and draws its next job from the class counter when
-// the alignment ends (as extend16_kernel does with its four rows).
-template <int G, int P, bool SAME_OE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P > PK_WAVES4_MAXP ? 3 : 4))) extpk_kernel(ext_args_t A)
+#ifndef PK_CHUNK
+#define PK_CHUNK 32           // jobs a wave takes from its class counter per atomic (their records: one coalesced load into the wave's LDS)
+#endif
+#ifndef PK_PREFETCH_AGE
+#define PK_PREFETCH_AGE 3     // rows after which the bases fetched ahead are taken out of their registers (they have long arrived by then)
+#endif
+// LDS of one wave, by class: the target rows of its 64 / G groups + the one the next job is staged in (row strides padded so that the
+// groups of a wave, which read the same offsets of their own rows, hit different banks: unpadded, the 16 groups' target bytes sat in
+// two banks and every row's read was an 8-way conflict), the query codes of the job the wave is staging, the H parking rows, the
+// records of its chunk of jobs; the end-mask table is per block in the per-class kernels and per wave in the persistent one
+template <int G, int P> struct pk_lds_t {
+	static constexpr int C = 2 * P, PP = (P + 3) & ~3, PS = PP + 4, NGW = 64 / G, TCAP = PK_TCAP(G);
+	static constexpr int T_BYTES = ((NGW + 1) * (TCAP + 4) + 15) & ~15, Q_BYTES = (C * G + 15) & ~15, EM_DWORDS = (C + 1) * PS, H_DWORDS = NGW * PS, RC_BYTES = PK_CHUNK * 32;
+	static constexpr int WAVE_BYTES = T_BYTES + Q_BYTES + 4 * EM_DWORDS + 4 * H_DWORDS + RC_BYTES;      // (all parts are multiples of 16 bytes)
+};
+template <int P> __device__ __forceinline__ void pk_em_init(uint32_t *em_tab, const int first, const int step)
 {
-	constexpr int C = 2 * P, PP = (P + 3) & ~3, PS = PP + 4, NG = 256 / G;
+	constexpr int C = 2 * P, PP = (P + 3) & ~3, PS = PP + 4;
+	for (int k = first; k < (C + 1) * PS; k += step) {
+		const int w = k / PS, p = k % PS;
+		em_tab[k] = p < P ? ((p < w ? 0xFFFFu : 0u) | (P + p < w ? 0xFFFF0000u : 0u)) : 0u;
+	}
+}
+
+// The body of a class: every group of G lanes of the wave runs its own alignment and row index and takes its next job when the
+// alignment ends; returns when the class is drained and the wave's alignments are through.  t_wave: the wave's 64 / G + 1 target rows
+// of TCAP + 4 bytes; qw: its query staging row; em_tab: the end masks; h_wave: its H parking rows; rc_wave: PK_CHUNK job records.
+// A.count / A.ctr / A.recs are the class's.
+//
+// The job pipeline (round 5).  A wave used to stand still at every draw for a chain of dependent round trips to memory -- the class
+// counter, ids[], qlen / tlen / h0, the descriptor, the bases -- with all sixteen alignments waiting: alone on its SIMD a wave spent
+// half its time there (3 850 cycles per row of which ~1 950 are the row), and beside the gather-bound seeding kernels of another batch,
+// whose requests fill the memory system's queues, far more: that, not the register file, was why the two did not share the chip
+// (profiles/r05_corun.txt).  Now: (1) the jobs of a class lie as 32-byte RECORDS in list order (ext_scatter_kernel); a wave takes
+// PK_CHUNK of them with one atomic and one coalesced load into its LDS; (2) ONE JOB IS ALWAYS STAGED AHEAD: as soon as the staged job
+// is handed to a group the next record is read from LDS and the loads of its bases are issued -- one dword of the 2-bit text per eight
+// rows and one dword of the reads per four columns, per lane -- into registers that nobody looks at for the next PK_PREFETCH_AGE rows
+// (or until a group asks); decoding them into the spare target row and the query row costs no wait then.  A group that ends takes the
+// spare row as its own and leaves its old one as the next spare.  Only when several groups end within the same few rows (the start of
+// a class, very short jobs) does the wave wait for a load, as before.
+template <int G, int P, bool SAME_OE>
+__device__ __forceinline__ void extpk_body(const ext_args_t &A, uint8_t *t_wave, uint8_t *qw, const uint32_t *em_tab, uint32_t *h_wave, uint4 *rc_wave)
+{
+	constexpr int C = 2 * P, PP = (P + 3) & ~3, PS = PP + 4, TCAP = PK_TCAP(G), TROW = TCAP + 4, NGW = 64 / G;
+	constexpr int NT = (TCAP + 511) / 512, NQ = (C * G + 255) / 256;      // dwords a lane fetches ahead: eight target rows / four query columns each
 	const int lane = threadIdx.x & 63, l = lane & (G - 1);
 	const bool g0 = l == 0;
 	const uint32_t n = A.count[0];
-	const uint32_t *ids = A.ids + A.count[1];
+	const uint4 *recs = A.recs + 2 * (size_t)A.count[1];
 	const int oe_ins = A.o_ins + A.e_ins, oe_del = A.o_del + A.e_del;
 	const int j0 = l * C;
 	const pk_consts_t<P> K = pk_consts<P>(A);
 	const int eCl = K.eC * l;
-	constexpr int TCAP = PK_TCAP(G);
-	// (row strides padded so that the groups of a wave, which read the same offsets of their own rows, hit different banks:
-	// unpadded, the 16 groups' target bytes sat in two banks and every row's read was an 8-way conflict)
-	__shared__ __attribute__((aligned(16))) uint8_t t_lds[NG][TCAP + 4];
-	__shared__ __attribute__((aligned(16))) uint8_t q_lds[4][(C * G + 15) & ~15];      // the query codes of the job a wave is staging
-	__shared__ __attribute__((aligned(16))) uint32_t em_tab[(C + 1) * PS];
-	__shared__ __attribute__((aligned(16))) uint32_t h_lds[NG * PS];
-	for (int k = threadIdx.x; k < (C + 1) * PS; k += 256) {
-		const int w = k / PS, p = k % PS;
-		em_tab[k] = p < P ? ((p < w ? 0xFFFFu : 0u) | (P + p < w ? 0xFFFF0000u : 0u)) : 0u;
-	}
-	__syncthreads();
-	uint8_t *tl = t_lds[threadIdx.x / G];
-	uint8_t *qw = q_lds[threadIdx.x >> 6];
-	const int hgrp = (int)(threadIdx.x / G) * PS;              // the group's dwords in h_lds
-	uint32_t *hrow = h_lds + hgrp;
+	int trow = (lane / G) * TROW;                              // the group's target row in t_wave (rows change hands at every draw)
+	int spare = NGW * TROW;                                    // the row the next job is staged in (wave-uniform)
+	const int hgrp = (lane / G) * PS;                          // the group's dwords in h_wave
+	uint32_t *hrow = h_wave + hgrp;
 	bool owner = false;                                        // this lane holds column qlen-1
 	bool have = false, alive = false;
-	uint32_t id = 0;
-	int qlen = 0, tlen = 0, h0 = 1, i = 0;
-	int hfc = 0, dn = 0;
-	const uint8_t *tp = tl;
-	int goff = 0;                                              // halfword of h_lds that holds H(i, qlen-1)
-	uint32_t phi0 = 0;
+	int qlen = 0, tlen = 0, i = 0;
+	int hfc = 0, hnx = 0;                                      // H(i-1, -1) and H(i, -1): max(0, h0 - o_del - e_del (i + 1)), stepped row by row (once 0, 0 for good)
+	int goff = 0;                                              // halfword of h_wave that holds H(i, qlen-1)
 	uint32_t H[P], E[P], NZ[P], sel[P];
 #pragma unroll
 	for (int p = 0; p < P; ++p) { H[p] = E[p] = NZ[p] = 0; sel[p] = 0x0C070C07u; }
 	pk_rs_t S = {0, 0, -1, -1, -1, -1, 0};
-	int rows_done = 0, wave_rows = 0;
-	bool more = true, more_g = true;                           // jobs left for this wave / on the class counter (wave-uniform)
-	uint32_t qn = 0, qe = 0;
+	int wave_rows = 0;                                         // (rows an alignment has executed = its i)
+	// the job pipeline (all wave-uniform but the raw dwords)
+	uint32_t qn = 0, qe = 0, cbase = 0;                        // the wave's chunk [qn, qe) of the class list; rc_wave holds the records of [cbase, qe)
+	bool more_g = n > 0;                                       // jobs left on the class counter
+	bool pre = false, pend = false, p_async = false;           // the next job is staged / its bases are on their way (as loads in flight)
+	int age = 0;
+	uint32_t p_id = 0, p_qt = 0, p_h0 = 1, p_w3 = 0, p_side = 1, p_w5 = 0, p_t0l = 0, p_t0h = 0;      // its record
+	uint32_t raw_t[NT], raw_q[NQ];
+#pragma unroll
+	for (int u = 0; u < NT; ++u) raw_t[u] = 0;
+#pragma unroll
+	for (int u = 0; u < NQ; ++u) raw_q[u] = 0;
 	for (;;) {
-		const unsigned long long nb = __ballot(!alive && g0 && (more || have));
-		if (nb) {
+		unsigned long long reqs = __ballot(!alive && g0);        // groups without a running alignment
+		if (reqs) {
 			if (!alive && have && g0) {                          // results of the alignment that just ended
 				const int qle = S.max_j + 1, tle = S.max_i + 1, gtle = S.max_ie + 1;
+				const uint32_t id = hrow[PP];                    // (the job's id waits in a padding word of the group's parking row)
 				int32_t *o = A.out + 3 * (size_t)id;
 				if (S.gscore <= 0 || S.gscore <= S.mx - A.end_bonus) { o[0] = S.mx; o[1] = qle; o[2] = tle; }
 				else { o[0] = S.gscore; o[1] = qlen; o[2] = gtle; }
@@ -446,114 +536,219 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P > PK
 					int32_t *r = A.raw + 6 * (size_t)id;
 					r[0] = S.mx; r[1] = qle; r[2] = tle; r[3] = gtle; r[4] = S.gscore; r[5] = S.max_off;
 				}
-				if (A.stats) { atomicAdd(A.stats, (unsigned long long)rows_done); atomicAdd(A.stats + 1, (unsigned long long)tlen); atomicAdd(A.stats + 2, 1ull); }
+				if (A.stats) { atomicAdd(A.stats, (unsigned long long)i); atomicAdd(A.stats + 1, (unsigned long long)tlen); atomicAdd(A.stats + 2, 1ull); }
 			}
-			// jobs come from a wave-local range [qn, qe) refilled EXT_DRAW_CHUNK at a time: one atomic per job on the class counter
-			// (a single address: ~90 atomics/us for the whole chip) was what short jobs waited for
-			if (qn == qe && more_g) {
-				uint32_t b0 = 0;
-				if (lane == 0) b0 = atomicAdd(A.ctr, (uint32_t)EXT_DRAW_CHUNK);
-				qn = __builtin_amdgcn_readfirstlane(b0);
-				qe = qn + EXT_DRAW_CHUNK < n ? qn + EXT_DRAW_CHUNK : n;
-				if (qn >= n) { qn = qe = n; }
-				more_g = qe < n;
-			}
-			const uint32_t base = qn;
-			{
-				const uint32_t cnt = (uint32_t)__builtin_popcountll(nb), avail = qe - qn;
-				qn += cnt < avail ? cnt : avail;            // groups beyond `avail` stay idle this round and ask again
-			}
-			more = more_g || qn < qe;
-			const bool drawing = !alive;
-			job_src_t src = ext_job_src(A, 0, false, 0, 0);
-			if (drawing) {
-				const uint32_t k = base + (uint32_t)__builtin_popcountll(nb & ((1ull << (lane & ~(G - 1))) - 1));
-				have = k < qe;
-				id = have ? ids[n - 1 - k] : 0;
-				qlen = have ? (int)A.qlen[id] : 0; tlen = have ? (int)A.tlen[id] : 0; h0 = have ? (int)A.h0[id] : 1;
-				src = ext_job_src(A, id, have, qlen, tlen);
-				{
-					const int jq = qlen > 0 ? qlen - 1 : 0, lq = jq / C, r = jq % C;       // lane, chain and pair of column qlen-1
-					goff = 2 * (hgrp + (r >= P ? r - P : r)) + (r >= P ? 1 : 0); owner = l == lq;
-					const int pl = K.a * (qlen - 1 - j0), ph = K.a * (qlen - 1 - j0 - P);
-					phi0 = ((uint32_t)pl & 0xFFFFu) | ((uint32_t)ph << 16);
-				}
-				S.end = qlen; S.mx = h0; S.max_i = -1; S.max_j = -1; S.max_ie = -1; S.gscore = -1; S.max_off = 0;
-				i = 0; rows_done = 0; hfc = h0; dn = oe_del; tp = tl;
-			}
-			// The bases of the new jobs, staged by ALL 64 lanes of the wave one job at a time (eight target rows and four query
-			// columns per lane): done by the four lanes of the drawing group alone, a draw cost the wave two to three DP rows
-			// of instructions during which its other fifteen alignments stood still.
-			for (unsigned long long todo = __ballot(drawing && have && g0 && tlen > 0); todo; todo &= todo - 1) {
-				const int gl = (int)__builtin_ctzll(todo);                      // first lane of the group (wave-uniform)
-				const int tlen_g = __builtin_amdgcn_readlane(tlen, gl), qlen_g = __builtin_amdgcn_readlane(qlen, gl);
-				job_src_t sg;
-				sg.qp = (const uint8_t *)pk_readlane64((unsigned long long)src.qp, gl); sg.qstep = __builtin_amdgcn_readlane(src.qstep, gl);
-				sg.tp = (const uint8_t *)pk_readlane64((unsigned long long)src.tp, gl);
-				sg.t0 = (long long)pk_readlane64((unsigned long long)src.t0, gl); sg.tdir = __builtin_amdgcn_readlane(src.tdir, gl);
-				uint8_t *tg = t_lds[(threadIdx.x >> 6) * (64 / G) + gl / G];
-				for (int k0 = 8 * lane; k0 < tlen_g; k0 += 512) {
-					uint32_t lo, hi;
-					pk_t8(A, sg, k0, tlen_g, lo, hi);
-					*(uint32_t *)(tg + k0) = lo;
-					if (k0 + 4 < tlen_g) *(uint32_t *)(tg + k0 + 4) = hi;
-				}
-				for (int c0 = 4 * lane; c0 < C * G; c0 += 256) {
-					uint32_t w = 0;
+			have = have && alive;
+		}
+		// serve the groups that ask, one job each, then leave the next job on its way
+		for (;;) {
+			const bool waiting = reqs != 0;
+			if (!pre) {
+				if (!pend) {
+					if (qn == qe && more_g) {                        // the next chunk: one atomic on the class counter, its records in one coalesced load
+						uint32_t b0 = 0;
+						if (lane == 0) b0 = atomicAdd(A.ctr, (uint32_t)PK_CHUNK);
+						qn = __builtin_amdgcn_readfirstlane(b0);
+						qe = qn + PK_CHUNK < n ? qn + PK_CHUNK : n;
+						if (qn >= n) { qn = qe = n; }
+						more_g = qe < n;
+						cbase = qn;
+						if ((uint32_t)lane < qe - qn) {               // (the class kernels draw from the long end of the list)
+							const uint4 *r = recs + 2 * (size_t)(n - 1 - (qn + (uint32_t)lane));
+							rc_wave[2 * lane] = r[0]; rc_wave[2 * lane + 1] = r[1];
+						}
+						__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (LDS operations of a wave execute in order; the fences hold the compiler to it)
+					}
+					if (qn < qe) {
+						const uint4 r0 = rc_wave[2 * (qn - cbase)], r1 = rc_wave[2 * (qn - cbase) + 1];
+						++qn;
+						p_id = __builtin_amdgcn_readfirstlane(r0.x); p_qt = __builtin_amdgcn_readfirstlane(r0.y); p_h0 = __builtin_amdgcn_readfirstlane(r0.z);
+						p_w3 = __builtin_amdgcn_readfirstlane(r0.w); p_side = __builtin_amdgcn_readfirstlane(r1.x); p_w5 = __builtin_amdgcn_readfirstlane(r1.y);
+						p_t0l = __builtin_amdgcn_readfirstlane(r1.z); p_t0h = __builtin_amdgcn_readfirstlane(r1.w);
+						const int ql = (int)(p_qt & 0xFFFFu), tln = (int)(p_qt >> 16);
+						p_async = A.desc && ql >= 4;
+						if (p_async) {                               // the bases: loads only, nobody waits for them here
+							const bool left = p_side == 0;
+							const long long t0 = (long long)(((unsigned long long)p_t0h << 32) | p_t0l) + (left ? tln - 1 : 0);
+							const uint8_t *qp = A.reads + p_w3 + (left ? ql - 1 : 0);
 #pragma unroll
-					for (int u = 0; u < 4; ++u) { const int j = c0 + u; w |= (uint32_t)(j < qlen_g ? min(ext_q_at(A, sg, j), 4) : 7) << (8 * u); }      // 4 = N, 7 = pad
-					*(uint32_t *)(qw + c0) = w;
+							for (int u = 0; u < NT; ++u) {
+								const int k0 = 8 * lane + 512 * u;
+								if (k0 < tln) { const pk_t8w_t w = pk_t8_where(A.l_pac, t0, left ? -1 : 1, k0); __builtin_memcpy(&raw_t[u], A.pac + (w.fa >> 2), 4); }
+							}
+#pragma unroll
+							for (int u = 0; u < NQ; ++u) {
+								const int c0 = 4 * lane + 256 * u;
+								if (c0 < ql) { int sh; const uint8_t *a = pk_q4_where(qp, left ? -1 : 1, ql, c0, sh); __builtin_memcpy(&raw_q[u], a, 4); }
+							}
+						}
+						pend = true; age = 0;
+					}
 				}
-				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (LDS operations of a wave execute in order; the fences hold the compiler to it)
+				if (pend && (waiting || age >= PK_PREFETCH_AGE)) {   // into the spare row and the query row
+					const int ql = (int)(p_qt & 0xFFFFu), tln = (int)(p_qt >> 16);
+					const bool left = A.desc && p_side == 0;
+					uint8_t *tg = t_wave + spare;
+					if (p_async) {
+						const long long t0 = (long long)(((unsigned long long)p_t0h << 32) | p_t0l) + (left ? tln - 1 : 0);
+#pragma unroll
+						for (int u = 0; u < NT; ++u) {
+							const int k0 = 8 * lane + 512 * u;
+							if (k0 < tln) {
+								uint32_t lo, hi;
+								pk_t8_decode(raw_t[u], pk_t8_where(A.l_pac, t0, left ? -1 : 1, k0), lo, hi);
+								*(uint32_t *)(tg + k0) = lo;
+								if (k0 + 4 < tln) *(uint32_t *)(tg + k0 + 4) = hi;
+							}
+						}
+#pragma unroll
+						for (int u = 0; u < NQ; ++u) {
+							const int c0 = 4 * lane + 256 * u;
+							if (c0 < C * G) {
+								int sh = 0;
+								if (c0 < ql) (void)pk_q4_where(nullptr, left ? -1 : 1, ql, c0, sh);
+								*(uint32_t *)(qw + c0) = c0 < ql ? pk_q4_decode(raw_q[u], sh, left ? -1 : 1, ql, c0) : 0x07070707u;
+							}
+						}
+					} else {                                         // array jobs and queries of under four columns: fetched here and now
+						job_src_t sg;
+						if (A.desc) { sg.qp = A.reads + p_w3 + (left ? ql - 1 : 0); sg.qstep = left ? -1 : 1; sg.tp = nullptr; sg.t0 = (long long)(((unsigned long long)p_t0h << 32) | p_t0l) + (left ? tln - 1 : 0); sg.tdir = left ? -1 : 1; }
+						else { sg.qp = A.q + p_w3; sg.qstep = 1; sg.tp = A.t + p_w5; sg.t0 = 0; sg.tdir = 1; }
+						for (int k0 = 8 * lane; k0 < tln; k0 += 512) {
+							uint32_t lo, hi;
+							pk_t8(A, sg, k0, tln, lo, hi);
+							*(uint32_t *)(tg + k0) = lo;
+							if (k0 + 4 < tln) *(uint32_t *)(tg + k0 + 4) = hi;
+						}
+						for (int c0 = 4 * lane; c0 < C * G; c0 += 256) {
+							uint32_t w = 0;
+#pragma unroll
+							for (int u = 0; u < 4; ++u) { const int j = c0 + u; w |= (uint32_t)(j < ql ? min(ext_q_at(A, sg, j), 4) : 7) << (8 * u); }      // 4 = N, 7 = pad
+							*(uint32_t *)(qw + c0) = w;
+						}
+					}
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+					pend = false; pre = true;
+				}
+			}
+			if (!waiting || !pre) break;
+			{   // the staged job goes to the first group that asks; its row becomes the next spare
+				const int gl = (int)__builtin_ctzll(reqs);           // first lane of the group (wave-uniform)
+				const int old = __builtin_amdgcn_readlane(trow, gl);
 				if ((lane & ~(G - 1)) == gl) {
+					const uint32_t id = p_id; const int h0 = (int)p_h0;
+					qlen = (int)(p_qt & 0xFFFFu); tlen = (int)(p_qt >> 16);
+					if (g0) hrow[PP] = id;
+					trow = spare;
 #pragma unroll
 					for (int p = 0; p < P; ++p) sel[p] = 0x0C000C00u | (uint32_t)qw[j0 + p] | ((uint32_t)qw[j0 + P + p] << 16);
-				}
-				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-			}
-			if (drawing) {
-				// H(-1, j) = max(0, h0 - o_ins - e_ins*(j+1)) left of qlen (ksw.c:880-883): one saturating packed subtract per pair
-				const int wq = min(max(qlen - j0, 0), C);
-				const uint4 *mrow = (const uint4 *)(em_tab + wq * PS);
-				uint32_t em[PP];
+					{
+						const int jq = qlen > 0 ? qlen - 1 : 0, lq = jq / C, r = jq % C;       // lane, chain and pair of column qlen-1
+						goff = 2 * (hgrp + (r >= P ? r - P : r)) + (r >= P ? 1 : 0); owner = l == lq;
+					}
+					S.end = qlen; S.mx = h0; S.max_i = -1; S.max_j = -1; S.max_ie = -1; S.gscore = -1; S.max_off = 0;
+					i = 0; hfc = h0; hnx = max(0, h0 - oe_del);
+					// H(-1, j) = max(0, h0 - o_ins - e_ins*(j+1)) left of qlen (ksw.c:880-883): one saturating packed subtract per pair
+					const int wq = min(max(qlen - j0, 0), C);
+					const uint4 *mrow = (const uint4 *)(em_tab + wq * PS);
+					uint32_t em[PP];
 #pragma unroll
-				for (int k = 0; k < PP / 4; ++k) { const uint4 v = mrow[k]; em[4 * k] = v.x; em[4 * k + 1] = v.y; em[4 * k + 2] = v.z; em[4 * k + 3] = v.w; }
-				uint32_t X = (uint32_t)max(h0 - oe_ins - j0 * A.e_ins, 0) | ((uint32_t)max(h0 - oe_ins - (j0 + P) * A.e_ins, 0) << 16);
+					for (int k = 0; k < PP / 4; ++k) { const uint4 v = mrow[k]; em[4 * k] = v.x; em[4 * k + 1] = v.y; em[4 * k + 2] = v.z; em[4 * k + 3] = v.w; }
+					uint32_t X = (uint32_t)max(h0 - oe_ins - j0 * A.e_ins, 0) | ((uint32_t)max(h0 - oe_ins - (j0 + P) * A.e_ins, 0) << 16);
 #pragma unroll
-				for (int p = 0; p < P; ++p) {
-					H[p] = X & em[p];
-					NZ[p] = pk_min1(H[p]);
-					E[p] = 0;
-					X = pk_subsK(X, K.ei2);
-					if (!have) sel[p] = 0x0C070C07u;
-				}
-				alive = have && tlen > 0;
-				if (have && tlen == 0) {
-					if (g0) {
+					for (int p = 0; p < P; ++p) {
+						H[p] = X & em[p];
+						NZ[p] = pk_min1(H[p]);
+						E[p] = 0;
+						X = pk_subsK(X, K.ei2);
+					}
+					have = tlen > 0; alive = have;
+					if (tlen == 0 && g0) {                           // no target rows (a window clipped away): the answer is (h0, 0, 0)
 						int32_t *o = A.out + 3 * (size_t)id;
 						o[0] = h0; o[1] = 0; o[2] = 0;
 						if (A.raw) { int32_t *r = A.raw + 6 * (size_t)id; r[0] = h0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = -1; r[5] = 0; }
 						if (A.stats) atomicAdd(A.stats + 2, 1ull);
 					}
-					have = false;
 				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // qw has been read before the next job is staged into it
+				spare = old;
+				pre = false;
+				reqs &= reqs - 1;
 			}
 		}
-		if (!__any(alive) && !more) break;
-		// (no `continue` past the row when every group drew a job without rows: a second path around the row body makes the
-		// compiler keep two copies of all loop-carried pairs; the idle row is harmless and rare)
+		if (pend) ++age;
+		if (!__any(alive) && !pre && !pend && qn == qe && !more_g) break;
+		// (no `continue` past the row when no group runs: a second path around the row body makes the compiler keep two copies of all
+		// loop-carried pairs; the idle row is harmless and rare)
 		++wave_rows;
-		const int ti = (int)*tp;
+		const int ti = (int)t_wave[trow + i];
 		const bool run = alive;
 		if (A.stats) {          // (BMH_EXT_STATS) wave-rows in which every running alignment has reached the query end: candidates of a row without end masks
 			const bool all_at_end = !__any(run && S.end != qlen), any_run = __any(run);
 			if (lane == 0 && any_run) { atomicAdd(A.stats + 4, 1ull); if (all_at_end) atomicAdd(A.stats + 5, 1ull); }
 		}
-		rows_done += run ? 1 : 0;
-		const int hnx = max(0, h0 - dn);
-		alive = pk_row<G, P, SAME_OE>(K, A.zdrop, H, E, NZ, sel, ti, run, hfc, hnx, i, qlen, j0, eCl, g0, phi0, em_tab, hrow, owner, (const uint16_t *)h_lds, goff, S, alive, (wave_rows & PK_BOUND_MASK) == 0, tlen - 1 - i, A.raw == nullptr, A.end_bonus);
-		if (run) { ++i; ++tp; hfc = hnx; dn += A.e_del; }
+		alive = pk_row<G, P, SAME_OE>(K, A.zdrop, H, E, NZ, sel, ti, run, hfc, hnx, i, qlen, j0, eCl, g0, em_tab, hrow, owner, (const uint16_t *)h_wave, goff, S, alive, (wave_rows & PK_BOUND_MASK) == 0, tlen - 1 - i, A.raw == nullptr, A.end_bonus);
+		if (run) { ++i; hfc = hnx; hnx = max(0, hnx - A.e_del); }
 		alive = alive && i < tlen;
 	}
 	if (A.stats && lane == 0) atomicAdd(A.stats + 3, (unsigned long long)wave_rows);
+}
+
+// One kernel per class (the form the side streams of extend_launch run when the persistent kernel is off): the end masks are the block's.
+template <int G, int P, bool SAME_OE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P > PK_WAVES4_MAXP ? 3 : 4))) extpk_kernel(ext_args_t A)
+{
+	wtrace_scope_t wt_(WT_EXT_PK, (uint32_t)(G << 8 | P));
+	using L = pk_lds_t<G, P>;
+	__shared__ __attribute__((aligned(16))) uint8_t t_lds[4][L::T_BYTES];
+	__shared__ __attribute__((aligned(16))) uint8_t q_lds[4][L::Q_BYTES];      // the query codes of the job a wave is staging
+	__shared__ __attribute__((aligned(16))) uint32_t em_tab[L::EM_DWORDS];
+	__shared__ __attribute__((aligned(16))) uint32_t h_lds[4][L::H_DWORDS];
+	__shared__ __attribute__((aligned(16))) uint4 rc_lds[4][2 * PK_CHUNK];
+	pk_em_init<P>(em_tab, threadIdx.x, 256);
+	__syncthreads();
+	const int w = threadIdx.x >> 6;
+	extpk_body<G, P, SAME_OE>(A, t_lds[w], q_lds[w], em_tab, h_lds[w], rc_lds[w]);
+}
+
+// The persistent form: ONE launch for all packed classes of a pass.  A wave works the classes off one after the other, widest
+// first, each with the class's own body (registers: the largest class's; LDS: a slice per wave carved per class, so that no
+// block-wide barrier ties a wave to its block mates).  Its blocks stay resident from the first job of the pass to the last: the
+// extension holds a FIXED share of every SIMD's registers (grid = blocks per CU x CUs, chosen by the host) instead of taking and
+// giving up the whole chip class by class, and the gather-bound kernels of the other batch in flight run in what it leaves.
+template <int G, int P> constexpr int pk_wave_lds_max(int m) { return pk_lds_t<G, P>::WAVE_BYTES > m ? pk_lds_t<G, P>::WAVE_BYTES : m; }
+constexpr int PK_PERSIST_WAVE_LDS =
+	pk_wave_lds_max<16, 9>(pk_wave_lds_max<8, 16>(pk_wave_lds_max<8, 14>(pk_wave_lds_max<8, 12>(pk_wave_lds_max<8, 10>(pk_wave_lds_max<8, 9>(
+	pk_wave_lds_max<4, 17>(pk_wave_lds_max<4, 16>(pk_wave_lds_max<4, 14>(pk_wave_lds_max<4, 12>(pk_wave_lds_max<4, 10>(pk_wave_lds_max<4, 8>(
+	pk_wave_lds_max<4, 6>(pk_wave_lds_max<4, 4>(0))))))))))))));
+template <int G, int P, bool SAME_OE>
+__device__ __forceinline__ void pk_persist_class(const ext_args_t &A0, uint8_t *base)
+{
+	using L = pk_lds_t<G, P>;
+	ext_args_t a = A0;
+	constexpr int cls = ext_pk_cls_of(G, P);
+	a.count = A0.count + 2 * cls;
+	a.ctr = A0.ctr + cls;
+	if (a.count[0] == 0) return;                               // (wave-uniform)
+	uint8_t *t_wave = base, *qw = base + L::T_BYTES;
+	uint32_t *em_tab = (uint32_t *)(qw + L::Q_BYTES), *h_wave = em_tab + L::EM_DWORDS;
+	uint4 *rc_wave = (uint4 *)(h_wave + L::H_DWORDS);
+	pk_em_init<P>(em_tab, threadIdx.x & 63, 64);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // (LDS operations of a wave execute in order; the fences hold the compiler to it)
+	extpk_body<G, P, SAME_OE>(a, t_wave, qw, em_tab, h_wave, rc_wave);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+template <bool SAME_OE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) extpk_persist_kernel(ext_args_t A)
+{
+	wtrace_scope_t wt_(WT_EXT_PERSIST);
+	__shared__ __attribute__((aligned(16))) uint8_t lds[4][PK_PERSIST_WAVE_LDS];
+	uint8_t *base = lds[threadIdx.x >> 6];
+	// longest rows first: what is left at the end of the pass are the short jobs of the narrow classes
+	pk_persist_class<16, 9, SAME_OE>(A, base);
+	pk_persist_class<8, 16, SAME_OE>(A, base); pk_persist_class<8, 14, SAME_OE>(A, base); pk_persist_class<8, 12, SAME_OE>(A, base);
+	pk_persist_class<8, 10, SAME_OE>(A, base); pk_persist_class<8, 9, SAME_OE>(A, base);
+	pk_persist_class<4, 17, SAME_OE>(A, base); pk_persist_class<4, 16, SAME_OE>(A, base); pk_persist_class<4, 14, SAME_OE>(A, base);
+	pk_persist_class<4, 12, SAME_OE>(A, base); pk_persist_class<4, 10, SAME_OE>(A, base); pk_persist_class<4, 8, SAME_OE>(A, base);
+	pk_persist_class<4, 6, SAME_OE>(A, base); pk_persist_class<4, 4, SAME_OE>(A, base);
 }

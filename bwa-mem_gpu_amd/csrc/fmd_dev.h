@@ -32,7 +32,16 @@ struct fmd_dev_t {
 	// unique-interval shortcut; 0 when absent
 	const uint8_t *pac;
 	uint64_t l_pac;
+	int wave_prio;            // measurement knob SEED_SETPRIO (0 = off): s_setprio level of the seeding kernels' waves
 };
+
+// the wave's issue priority (the SIMD arbitrates by priority, then age): the gather-bound kernels run short bursts between loads
+__device__ __forceinline__ void fmd_wave_prio(const int p)
+{
+	if (p == 1) __builtin_amdgcn_s_setprio(1);
+	else if (p == 2) __builtin_amdgcn_s_setprio(2);
+	else if (p >= 3) __builtin_amdgcn_s_setprio(3);
+}
 
 struct blk_t { uint4 occ; uint64_t lo, hi; };
 

@@ -38,6 +38,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "bmh_internal.h"
+#include "wtrace.h"
 #include "fmd_dev.h"
 
 // ---------------------------------------------------------------- read access
@@ -70,6 +71,7 @@ __global__ void __launch_bounds__(256) pack_reads_kernel(const uint8_t *__restri
                                                          const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t n_grp,
                                                          uint32_t lds_bytes, uint32_t *__restrict__ pk, uint32_t *__restrict__ nm)
 {
+	wtrace_scope_t wt_(WT_PACK);
 	extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
 	const uint32_t r0 = blockIdx.x * PACK_READS_PER_BLOCK;
 	const uint32_t nr = min((uint32_t)PACK_READS_PER_BLOCK, n_reads - r0);
@@ -146,13 +148,27 @@ __device__ __forceinline__ void cand_append(bool want, const cand_t &c, uint64_t
 #ifndef FWD_UNIQ_WORDS
 #define FWD_UNIQ_WORDS 1
 #endif
+#ifndef FWD_CHUNK
+#define FWD_CHUNK 64u         // reads a wave takes from the batch's cursor per atomic
+#endif
+#ifndef FWD_REFILL_MIN
+#define FWD_REFILL_MIN 8u     // idle lanes that make a wave with no undealt reads go back to the cursor
+#endif
 __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_view_t rv, const uint32_t *__restrict__ lens,
                                                            int min_seed_len, cand_t *__restrict__ out_a, uint64_t *__restrict__ out_k,
                                                            unsigned long long *counter, uint64_t cap, uint32_t *__restrict__ n_cand)
 {
-	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	bool live = r < rv.n_reads;
-	int len = live ? (int)lens[r] : 0;
+	wtrace_scope_t wt_(WT_FORWARD);
+	fmd_wave_prio(f.wave_prio);
+	// Reads are PULLED, not owned (round 5): a wave used to take 64 consecutive reads and run until its slowest one was through -- a read
+	// inside a repeat walks 150 rank steps, a unique one leaves for the text comparison after ~16 -- so most lanes of most waves idled.
+	// Now the grid is what the chip keeps resident; a wave takes FWD_CHUNK reads from the batch's cursor (counter[1]) with one atomic and
+	// deals them to its lanes as they finish, FWD_REFILL_MIN idle lanes at a time.  Which lane walks which read changes nothing: a
+	// candidate names its read and ordinal, cand_scatter_kernel puts the list in (read, ordinal) order.
+	const int lane = __lane_id();
+	unsigned long long *rd_cursor = counter + 1;
+	uint32_t r = 0;
+	int len = 0;
 	int i = 0, x = 0;
 	uint32_t j = 0;
 	uint64_t k = 0, l = 0, s = 0;
@@ -164,9 +180,35 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 	// candidate pushed at the end is the one the rank walk would push (src/bwt.c:505-519 with x[2] == 1)
 	enum { ST_START, ST_EXT, ST_DONE, ST_TAIL, ST_UNIQ };
 	uint64_t tp = 0;                 // ST_UNIQ: text index that pairs with read position i
-	int st = live && len > 0 ? ST_START : ST_DONE;
+	int st = ST_DONE;
+	uint32_t lc = 0, le = 0;         // the wave's reads not yet dealt (wave-uniform)
+	bool more = true;                // reads left on the batch's cursor (wave-uniform)
 	cand_cursor_t cc = {0, 0};
-	while (__any(st != ST_DONE)) {
+	for (;;) {
+		const unsigned long long idle = __ballot(st == ST_DONE);
+		if (idle) {
+			const uint32_t n_idle = (uint32_t)__popcll(idle);
+			if (lc == le && more && (n_idle >= FWD_REFILL_MIN || n_idle == 64u)) {
+				unsigned long long b0 = 0;
+				if (lane == 0) b0 = atomicAdd(rd_cursor, (unsigned long long)FWD_CHUNK);
+				b0 = __shfl(b0, 0);
+				lc = b0 < rv.n_reads ? (uint32_t)b0 : rv.n_reads;
+				le = b0 + FWD_CHUNK < rv.n_reads ? (uint32_t)(b0 + FWD_CHUNK) : rv.n_reads;
+				more = le < rv.n_reads;
+			}
+			if (lc < le) {
+				const uint32_t take = n_idle < le - lc ? n_idle : le - lc;
+				const uint32_t mine = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+				if (st == ST_DONE && mine < take) {
+					r = lc + mine; len = (int)lens[r]; i = 0; x = 0; j = 0;
+					st = len > 0 ? ST_START : ST_DONE;
+					if (len <= 0) n_cand[r] = 0;
+				}
+				lc += take;
+			}
+		}
+		if (!__any(st != ST_DONE)) { if (lc == le && !more) break; else continue; }
+		const bool was = st != ST_DONE;
 		bool want = false;
 		cand_t c = {r, 0, 0, 0};
 		uint64_t ck = 0;
@@ -244,9 +286,9 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 		}
 		if (want) ++j;
 		cand_append(want, c, ck, out_a, out_k, counter, cap, cc);
+		if (was && st == ST_DONE) n_cand[r] = j;     // the read is through
 	}
 	cand_fill_invalid(cc, out_a, cap);
-	if (live) n_cand[r] = j;
 }
 
 // ---------------------------------------------------------------- backward
@@ -292,6 +334,8 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
                                                             const bwd_state_t *__restrict__ in_state, const uint32_t *__restrict__ in_count,
                                                             bwd_state_t *__restrict__ out_state, uint32_t *__restrict__ out_count, const uint32_t sub_cap, const int max_iter)
 {
+	wtrace_scope_t wt_(WT_BACKWARD);
+	fmd_wave_prio(f.wave_prio);
 	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int lane = __lane_id();
 	// L2[b] for a per-lane b: one LDS read per step instead of a conditional-move tree over four 64-bit scalars
@@ -392,6 +436,7 @@ __global__ void __launch_bounds__(256) smem_backward_kernel(fmd_dev_t f, read_vi
 // the next longer one does, so the comparison partner is the first survivor after it)
 __global__ void __launch_bounds__(256) smem_filter_kernel(const res_t *__restrict__ res_a, uint64_t n, uint32_t *__restrict__ occ)
 {
+	wtrace_scope_t wt_(WT_FILTER);
 	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	res_t e = {0xFFFFFFFEu, 0, 0, 0};
 	if (t < n) e = res_a[t];
@@ -454,6 +499,7 @@ __global__ void __launch_bounds__(256) expand_kernel(const res_t *__restrict__ r
                                                      const uint32_t *__restrict__ occ, const uint64_t *__restrict__ occ_off, uint64_t n,
                                                      uint64_t *__restrict__ rows, int2 *__restrict__ qbeg, uint32_t *__restrict__ score)
 {
+	wtrace_scope_t wt_(WT_EXPAND);
 	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t s = 0;
 	uint64_t k = 0, off = 0;
@@ -489,6 +535,8 @@ __global__ void __launch_bounds__(256) expand_kernel(const res_t *__restrict__ r
 #endif
 __global__ void __launch_bounds__(256) locate_kernel(fmd_dev_t f, uint64_t *__restrict__ rows, uint64_t n)
 {
+	wtrace_scope_t wt_(WT_LOCATE);
+	fmd_wave_prio(f.wave_prio);
 	const int lane = __lane_id();
 	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const uint64_t c0 = wave * LOCATE_PER_WAVE;
@@ -879,7 +927,9 @@ static int seed_batch_on(bmh_seed_ws_t *w, const bmh_index_t *idx, const uint8_t
 	out->d_n_ref_pos = w->n_ref_pos; out->d_prefix = w->prefix;
 	memset(w->ms, 0, sizeof(w->ms));
 	if (n_reads == 0) return BMH_OK;
-	const fmd_dev_t &f = idx->dev;
+	fmd_dev_t f = idx->dev;
+	f.wave_prio = bmh_tune("SEED_SETPRIO", 0);
+	const unsigned lds_pad = (unsigned)bmh_tune("SEED_LDS_PAD", 0);      // (measurement knob: unused dynamic LDS per block of the gather-bound kernels = a cap on their blocks per CU)
 	// longest read -> packed geometry (host needs it; one small D2H reduce)
 	uint32_t max_len = 0;
 	{
@@ -982,9 +1032,11 @@ static int seed_batch_on(bmh_seed_ws_t *w, const bmh_index_t *idx, const uint8_t
 		return BMH_OK;
 	}
 	HIPCK(hipEventRecord(w->ev[1], st));
-	HIPCK(hipMemsetAsync(w->counter, 0, 8, st));
+	HIPCK(hipMemsetAsync(w->counter, 0, 16, st));           // [0] the candidate list's cursor, [1] the reads' (smem_forward_kernel pulls them)
 	HIPCK(hipMemsetAsync(w->n_cand + n_reads, 0, 4, st));
-	smem_forward_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(f, rv, d_lens, min_seed_len, w->cand_a, w->cand_k, w->counter, w->max_cands, w->n_cand);
+	static thread_local unsigned fwd_resident = 0;            // blocks the chip keeps resident (8 waves per SIMD)
+	if (!fwd_resident) { int dev = 0; hipDeviceProp_t prop; HIPCK(hipGetDevice(&dev)); HIPCK(hipGetDeviceProperties(&prop, dev)); fwd_resident = (unsigned)prop.multiProcessorCount * 8u; }
+	smem_forward_kernel<<<nblk(n_reads, 256) < fwd_resident ? nblk(n_reads, 256) : fwd_resident, 256, lds_pad, st>>>(f, rv, d_lens, min_seed_len, w->cand_a, w->cand_k, w->counter, w->max_cands, w->n_cand);
 	HIPCK(hipEventRecord(w->ev[2], st));
 	{
 		size_t tb = w->scan_tmp_bytes;
@@ -1019,7 +1071,7 @@ static int seed_batch_on(bmh_seed_ws_t *w, const bmh_index_t *idx, const uint8_t
 			uint32_t *cnt = w->bwd_cnt;                                              // [np][BWD_NSUB] survivors of every phase
 			if (np) HIPCK(hipMemsetAsync(cnt, 0, 4 * (size_t)np * BWD_NSUB, st));
 			const int big = 0x7FFFFFFF;
-			smem_backward_kernel<false><<<nb, 256, 0, st>>>(f, rv, n_cands, min_seed_len, w->cand_a, w->cand_k, w->svals, w->res_a, w->res_k, d_st,
+			smem_backward_kernel<false><<<nb, 256, lds_pad, st>>>(f, rv, n_cands, min_seed_len, w->cand_a, w->cand_k, w->svals, w->res_a, w->res_k, d_st,
 			                                                nullptr, nullptr, np ? w->bwd_state[0] : nullptr, np ? cnt : nullptr, sub_cap, np ? phases[0] : big);
 			// (a resumed launch is sized by an upper bound of its lists -- every lane of the first launch -- and the blocks beyond a list leave at once)
 			for (int ph = 1; ph <= np; ++ph)
@@ -1062,7 +1114,7 @@ static int seed_batch_on(bmh_seed_ws_t *w, const bmh_index_t *idx, const uint8_t
 		expand_kernel<<<nblk(n_cands, 256), 256, 0, st>>>(w->res_a, w->res_k, w->occ, w->occ_off, n_cands, w->rows, w->qbeg, w->score);
 	HIPCK(hipEventRecord(w->ev[5], st));
 	if (tot[0])
-		locate_kernel<<<nblk(nblk(tot[0], LOCATE_PER_WAVE) * 64ull, 256), 256, 0, st>>>(f, w->rows, tot[0]);
+		locate_kernel<<<nblk(nblk(tot[0], LOCATE_PER_WAVE) * 64ull, 256), 256, lds_pad, st>>>(f, w->rows, tot[0]);
 	HIPCK(hipEventRecord(w->ev[6], st));
 	HIPCK(hipStreamSynchronize(st));
 	HIPCK(hipGetLastError());
@@ -1113,3 +1165,6 @@ extern "C" int bmh_calib_gather(const bmh_index_t *idx, uint64_t n_lanes, int it
 	HIPCK(hipEventElapsedTime(ms, e0, e1));
 	return BMH_OK;
 }
+
+// wave residency trace (wtrace.h): this translation unit's copy of the trace symbols
+WTRACE_DEFINE_SETTER(bmh_wtrace_set_seed)

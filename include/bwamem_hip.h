@@ -183,6 +183,9 @@ int bmh_calib_gather(const bmh_index_t *idx, uint64_t n_lanes, int iters, int de
 int bmh_calib_valu(int mode, int waves_per_simd, int iters, void *stream, float *ms, double *lane_ops);
 int bmh_calib_valu_placed(int mode, int waves_per_simd, int iters, void *stream, float *ms, double *lane_ops,
                           unsigned long long *place, unsigned *n_place);
+/* The shader clock (MHz) and the shader cycles per wave64 instruction of one wave during the calling thread's last bmh_calib_valu[_placed]
+ * launch, measured inside the kernel (s_memtime over s_memrealtime); BMH_EINVAL before any calibration. */
+int bmh_calib_last_clock(double *mhz, double *cycles_per_instr);
 
 /* -------------------------------------------------------------- extension */
 
@@ -217,6 +220,17 @@ int64_t bmh_extend_last_unsupported(void);
  * with tlen <= 512 (8 lanes, 8 jobs per wave), qlen <= 288 with tlen <= 640 (16 lanes, 4 jobs per wave) -- run on the packed 16-bit
  * kernels (two DP columns per register), everything else on the 32-bit kernels; results are identical.  on = 0 sends every job to the 32-bit kernels (tests, A/B timing).  Process-wide; returns the previous setting. */
 int bmh_extend_set_packed(int on);
+
+/* Measurement knobs of the library (each documented where it is read): knob NAME takes the value given here, else
+ * the environment variable BMH_<NAME>, else its default; clear != 0 forgets a value set earlier.  Process-wide; for A/B sweeps inside
+ * one process (scripts/corun_probe.py).  No reference counterpart. */
+int bmh_tune_set(const char *name, int value, int clear);
+/* Wave residency trace (measurement; csrc/wtrace.h): between start and stop every wave of the seeding, chaining and packed extension
+ * kernels leaves a 32-byte record {u32 kernel id, HW_ID, XCC_ID, aux; u64 t0, t1 in 100 MHz ticks}; stop waits for the device, copies up to
+ * max_recs records and returns how many waves reported.  scripts/wave_residency.py turns them into waves of each kernel per SIMD over time. */
+int bmh_wtrace_start(uint32_t cap);
+int64_t bmh_wtrace_stop(void *out, uint32_t max_recs);
+uint32_t bmh_wtrace_kept(void);          /* records the last bmh_wtrace_stop copied out */
 
 /* bmh_extend_batch keeps scratch (the sorted job list, four side streams, events) per (device, stream) and reuses it across calls.
  * Call this before destroying a stream that ran extensions (stream idle, its device current); without it the entry stays until the

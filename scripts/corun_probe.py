@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Do the gather-bound seeding of one batch and the VALU-bound extension of another share the chip productively?  The bench workload
 (hg38-scale index, 1 M x 150 bp): seeding of batch B alone, chaining + extension of batch A alone, then both at once on two streams
-(seeding on a high-priority stream or not); run it with BMH_EXT_LDS_PAD=<bytes> to cap the extension's waves per CU.
+(seeding on a high-priority stream or not); CORUN_CONFIGS sweeps the library's knobs (bmh_tune_set) inside one process.
 usage: corun_probe.py [genome_mbp] [reads]"""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,23 +29,42 @@ cw.set_contigs(meta["contigs"]); cw.set_materialize(False)
 dj = cw.chain_batch(dindex, batches[0].ascii, batches[0].offs, batches[0].lens, sA)
 out = torch.zeros(int(dj.n_jobs) + 4096, 3, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
-for prio in (0, -1):
-    s_ext, s_seed = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=prio)
-    ext = lambda: cw.extend(out, params=params, stream=s_ext.cuda_stream)
-    seed = lambda: wsB.seed_batch(dindex, batches[1].ascii, batches[1].offs, batches[1].lens, 19, stream=s_seed.cuda_stream)
+import threading
 
-    def timeit(fs, n=4):
+
+def timeit(fs, n=4):
+    for f in fs: f()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n):
         for f in fs: f()
-        torch.cuda.synchronize(); t = time.perf_counter()
-        for _ in range(n):
-            for f in fs: f()
-        torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
-    te, ts = timeit([ext]), timeit([seed])
-    # both at once: the seeding call returns to the host after its last internal synchronisation, so it is issued from a second thread
-    import threading
-    def both():
-        th = threading.Thread(target=lambda: (L.bmh_set_device(0), torch.cuda.set_device(0), seed()))
-        th.start(); ext(); th.join()
-    tb = timeit([both])
-    print(f"LDS pad {os.environ.get('BMH_EXT_LDS_PAD', '0')}, seeding stream priority {prio}: extension alone {te:.2f} ms, seeding alone {ts:.2f} ms, "
-          f"sum {te + ts:.2f}, both at once {tb:.2f} ms ({(te + ts - tb) / min(te, ts) * 100:.0f} % of the shorter one hidden)", flush=True)
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
+
+
+# knob settings to sweep (bmh_tune_set; "-" = the library's defaults): CORUN_CONFIGS="EXT_PERSIST=3;EXT_PERSIST=2,SEED_LDS_PAD=20000;..."
+configs = [c for c in os.environ.get("CORUN_CONFIGS", "-;EXT_PERSIST=3;EXT_PERSIST=2;EXT_PERSIST=1").split(";") if c]
+prios = [int(x) for x in os.environ.get("CORUN_PRIOS", "0,-1").split(",")]
+for cfg in configs:
+    kv = [] if cfg == "-" else [x.split("=") for x in cfg.split(",")]
+    for k, v in kv:
+        L.bmh_tune_set(k.encode(), int(v), 0)
+    for prio in prios:
+        s_ext, s_seed = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=prio)
+        ext = lambda: cw.extend(out, params=params, stream=s_ext.cuda_stream)
+        seed = lambda: wsB.seed_batch(dindex, batches[1].ascii, batches[1].offs, batches[1].lens, 19, stream=s_seed.cuda_stream)
+        te, ts = timeit([ext]), timeit([seed])
+
+        # both at once: the seeding call returns to the host after its last internal synchronisation, so it is issued from a second thread
+        def both():
+            th = threading.Thread(target=lambda: (L.bmh_set_device(0), torch.cuda.set_device(0), seed()))
+            th.start(); ext(); th.join()
+        tb = timeit([both])
+        if os.environ.get("CORUN_TRACE"):                  # one more co-run under the wave residency trace (csrc/wtrace.h)
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            from wave_residency import trace, summary
+            with trace(L) as tr:
+                both(); torch.cuda.synchronize()
+            print(summary(tr.records, title=f"[{cfg}] co-run: "), flush=True)
+        print(f"{cfg:40s} seeding stream priority {prio:2d}: extension alone {te:6.2f} ms, seeding alone {ts:6.2f} ms, sum {te + ts:6.2f}, "
+              f"both at once {tb:6.2f} ms ({(te + ts - tb) / min(te, ts) * 100:.0f} % of the shorter one hidden)", flush=True)
+    for k, v in kv:
+        L.bmh_tune_set(k.encode(), 0, 1)

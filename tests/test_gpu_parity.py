@@ -195,6 +195,19 @@ def gpu_extend(B, jobs, zdrop=0, want_raw=True, scoring=None, packed=None):
             prm = B.ExtParams(a_, b_, o_, e_, o_, e_, zdrop, 5)
     B.extend_batch(*d, out, params=prm, raw_t=raw)
     torch.cuda.synchronize()
+    # both launch forms of the packed kernels -- one kernel per class, and the persistent kernel that works all classes off
+    # (csrc/extpk_dev.h: extpk_persist_kernel; knob EXT_PERSIST = blocks per CU) -- must give the same numbers
+    L_ = B.load_library()
+    for persist in (0, 1, 3):
+        L_.bmh_tune_set(b"EXT_PERSIST", persist, 0)
+        try:
+            out_p = torch.zeros(n, 3, dtype=torch.int32, device="cuda")         # (zeros like `out`: an unsupported job's raw tuple is left alone)
+            raw_p = torch.zeros(n, 6, dtype=torch.int32, device="cuda") if want_raw else None
+            B.extend_batch(*d, out_p, params=prm, raw_t=raw_p)
+            torch.cuda.synchronize()
+        finally:
+            L_.bmh_tune_set(b"EXT_PERSIST", 0, 1)
+        assert torch.equal(out_p, out) and (not want_raw or torch.equal(raw_p, raw)), f"EXT_PERSIST={persist} differs from the default launch form"
     if want_raw:
         # the production form (three results per job, no raw 6-tuple) may stop a job earlier -- as soon as the local-vs-to-end
         # rule is decided -- and must return the same three numbers

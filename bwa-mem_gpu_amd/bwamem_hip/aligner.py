@@ -210,6 +210,8 @@ class Aligner:
                 if f == "-j":                             # the .alt file is ignored (src/fastmap.c:186,390-392): every sequence belongs to the primary assembly
                     self.alt[:] = 0; self.has_alt = False; co.contig_is_alt = None; po.contig_is_alt = None
                     if getattr(self, "_native", None) is not None: self._native.free(); self._native = None
+                    c = getattr(self, "_cw_cache", None)         # a cached chain workspace still holds the ALT table (set_alt): the batch-by-batch path must not filter chains with it
+                    if c is not None: c[0].free(); self._cw_cache = None
                 elif f == "-a": po.flag_all = 1
                 elif f == "-M": po.no_multi = 1
                 elif f == "-Y": po.softclip = 1
@@ -237,10 +239,15 @@ class Aligner:
             elif f == "-U": pe.pen_unpaired = int(v)
             elif f == "-m": pe.max_matesw = int(v)
             elif f == "-R":                                             # read group (bwa_set_rg, src/bwa.c:425-452): the header line and the records' RG:Z tag
-                line = v.replace("\\t", "\t").replace("\\n", "\n").replace("\\r", "\r").replace("\\\\", "\\")      # bwa_escape
-                if not line.startswith("@RG") or "\tID:" not in line:
-                    raise ValueError("-R: the read group line must start with @RG and hold an ID")
-                rid = line.split("\tID:", 1)[1].split("\t", 1)[0].split("\n", 1)[0]
+                # bwa_escape (src/bwa.c:409-423): ONE pass from the left -- a backslash consumes the character behind it, which becomes a tab / newline /
+                # carriage return / backslash for t / n / r / \\ and nothing at all otherwise ("\\\\t" is a backslash and a 't', not a backslash and a tab)
+                if not v.startswith("@RG"):
+                    raise ValueError("-R: the read group line must start with @RG")
+                import re
+                line = re.sub(r"\\(.?)", lambda m: {"t": "\t", "n": "\n", "r": "\r", "\\": "\\"}.get(m.group(1), ""), v, flags=re.S)
+                if "\tID:" not in line:
+                    raise ValueError("-R: the read group line must hold an ID")
+                rid = re.split("[\t\n]", line.split("\tID:", 1)[1], 1)[0]            # the ID ends at the first tab or newline (src/bwa.c:440-446)
                 if len(rid) > 255:
                     raise ValueError("-R: @RG:ID is longer than 255 characters")
                 self.rg_line = line; self._rg_id = rid.encode(); po.rg_id = self._rg_id

@@ -40,6 +40,7 @@ struct aligner_t {
 	std::vector<std::string> names; std::vector<const char *> name_ptr;
 	std::vector<int64_t> off; std::vector<int32_t> len; std::vector<uint8_t> alt; bool has_alt;
 	bmh_chain_opt_t co; bmh_ext_params_t ep; bmh_post_opt_t po; bmh_pe_opt_t pe;
+	std::string rg_id;             // the aligner's own copy of popt->rg_id (po.rg_id points into it): the caller's string need not outlive the call that created the aligner
 };
 
 }   // namespace
@@ -166,7 +167,11 @@ int cigars(const aligner_t &A, lane_t &Ln, const int32_t *d_fin, uint64_t n_sel,
 {
 	// fixed slots: 16 operations; an MD string of 96 bytes for reads up to 192 bases, half a read's length beyond (a 300 bp read with a dozen mismatches
 	// writes 60-100 characters: with 96 every tenth alignment went the way of the overflowed ones)
-	const int max_cigar = 16, md_cap = Ln.max_read_len <= 192 ? 96 : (int)((Ln.max_read_len / 2 + 31) & ~31u), MC = 64, MD = 1024;
+	// The slots of the redone alignments cannot overflow: an alignment of a read of L bases has at most 2 L + 1 operations (every operation but a
+	// deletion consumes a base of the read, a deletion stands between two others) and an MD string of at most two characters per reference base it
+	// spans (L + the band at most) -- so one pathological read no longer ends a run of millions
+	const int max_cigar = 16, md_cap = Ln.max_read_len <= 192 ? 96 : (int)((Ln.max_read_len / 2 + 31) & ~31u);
+	const int MC = std::max(64, 2 * (int)Ln.max_read_len + 2), MD = std::max(1024, (int)((4 * Ln.max_read_len + 2 * (uint32_t)std::max(A.co.w, 0) + 64 + 31) & ~31u));
 	R.n_sel = n_sel;
 	*words_out = 0;
 	if (to_host) { RCK(R.aln.need(8 * (n_sel + 1))); RCK(R.off.need(n_sel + 2)); }
@@ -681,6 +686,7 @@ bmh_aligner_t *bmh_aligner_create(const bmh_index_t *idx, const uint8_t *pac, in
 	A.has_alt = false;
 	for (uint8_t v : A.alt) A.has_alt = A.has_alt || v != 0;
 	A.co = *copt; A.ep = *ep; A.po = *popt;
+	if (popt->rg_id) { A.rg_id = popt->rg_id; A.po.rg_id = A.rg_id.c_str(); }
 	if (pe) A.pe = *pe; else bmh_pe_opt_default(&A.pe);
 	A.co.contig_is_alt = A.has_alt ? A.alt.data() : nullptr; A.po.contig_is_alt = A.has_alt ? A.alt.data() : nullptr;
 	return h;
@@ -848,6 +854,8 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 	if (!h || !rs || !cuts || !sink) { bmh_set_error("bmh_aligner_run: null argument"); return BMH_EINVAL; }
 	if (stats) memset(stats, 0, sizeof(*stats));
 	if (n_batches == 0 || rs->n_reads == 0) return BMH_OK;
+	// (the device path reads ascii / offs / lens only, but the host forms -- the pairs' walks, the host tail after BMH_ECAPACITY, the host formatter -- read every array)
+	if (!rs->ascii || !rs->codes || !rs->offs || !rs->lens || !rs->names || !rs->name_offs) { bmh_set_error("bmh_aligner_run: the read set lacks one of ascii / codes / offs / lens / names / name_offs"); return BMH_EINVAL; }
 	if (cuts[0] != 0 || cuts[n_batches] != rs->n_reads) { bmh_set_error("bmh_aligner_run: cuts[0] = 0 and cuts[n_batches] = n_reads are required"); return BMH_EINVAL; }
 	for (uint32_t b = 0; b < n_batches; ++b)
 		if (cuts[b + 1] < cuts[b] || (paired && ((cuts[b + 1] - cuts[b]) & 1)) || cuts[b + 1] - cuts[b] > 0xFFFFFFF0ull) { bmh_set_error("bmh_aligner_run: bad batch cuts"); return BMH_EINVAL; }

@@ -155,10 +155,14 @@ __global__ void __launch_bounds__(64) chain_lane_lds_kernel(chain_args_t A, int 
 // such read -- but compacted into their own list they are 64 reads of similar cost per wave, a few hundred waves that leave the
 // CUs (and all of the LDS) to the wave kernels of the larger classes.  One wave per read, they took a third of the stage.
 template <bool FLT, int CAP>
-__global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, uint32_t cls)
+__global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, uint32_t cls, const uint32_t lanes)
 {
 	wtrace_scope_t wt_(WT_CHAIN_LIST, cls);
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	// `lanes` reads per wave (knob CHAIN_LIST_LANES; 64 = every lane): a wave of this kernel executes the union of its lanes' paths through
+	// the sequential chaining core, so fewer reads per wave are shorter waves -- and there are wave slots to spare (100 000 reads are 1 563 full waves)
+	const uint32_t lane = threadIdx.x & 63u;
+	if (lane >= lanes) return;
+	const uint32_t i = ((blockIdx.x * 256u + threadIdx.x) >> 6) * lanes + lane;
 	if (i >= A.heavy_n[cls]) return;
 	const uint32_t r = A.heavy_list[(size_t)cls * A.n_reads + i];
 	if (CAP > 0) {
@@ -173,6 +177,9 @@ __global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, ui
 // for decides how many of these waves a CU runs side by side (64 entries: 20, 128: 10, 256: 5, 512: 2, 1250: 1), which is why the classes exist.
 #define CH_LDS_BYTES_PER_ENTRY_HYBRID (8 + 8 + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4)
 #define CH_LDS_CONTIGS 256         // contig tables up to this size are copied into LDS (3 KB)
+#ifndef CH_LIST_LANES
+#define CH_LIST_LANES 64           // reads per wave of chain_lane_list_kernel (knob CHAIN_LIST_LANES)
+#endif
 #ifndef CH_WAVE_ATTR
 #define CH_WAVE_ATTR
 #endif
@@ -622,8 +629,11 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 		HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->ev_fork, 0));
 		if (serial && cls < CH_N_CLASSES - 1) HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->cls_done[cls + 1], 0));
 		if (cls == 0) {                                                                                                   // (blocks beyond the list leave at once)
-			if (list_private && !FLT && A.lane_max <= 32u) chain_lane_list_kernel<FLT, 32><<<nblk(n_reads, 256), 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls);
-			else chain_lane_list_kernel<FLT, 0><<<nblk(n_reads, 256), 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls);
+			const int ll = bmh_tune("CHAIN_LIST_LANES", CH_LIST_LANES);
+			const uint32_t lanes = (uint32_t)(ll < 1 ? 1 : ll > 64 ? 64 : ll);
+			const unsigned lgrid = nblk((uint64_t)nblk(n_reads, lanes) * 64u, 256);
+			if (list_private && !FLT && A.lane_max <= 32u) chain_lane_list_kernel<FLT, 32><<<lgrid, 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls, lanes);
+			else chain_lane_list_kernel<FLT, 0><<<lgrid, 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls, lanes);
 		}
 		else if (ctg_lds) chain_wave_kernel<true, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
 		else chain_wave_kernel<false, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);

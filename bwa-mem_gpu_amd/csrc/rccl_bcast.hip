@@ -31,6 +31,7 @@ struct rccl_api_t {
 	ncclResult_t (*CommCount)(const ncclComm_t, int *);
 	ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
 	ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+	ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
 	ncclResult_t (*GroupStart)();
 	ncclResult_t (*GroupEnd)();
 	const char *(*GetErrorString)(ncclResult_t);
@@ -46,7 +47,7 @@ bool bind_all(void *h, const char *where)
 	rccl_api_t a = {};
 #define BIND(f) *(void **)&a.f = dlsym(h, "nccl" #f); if (!a.f) return false
 	BIND(GetUniqueId); BIND(CommInitRank); BIND(CommInitAll); BIND(CommDestroy); BIND(CommCount); BIND(CommUserRank);
-	BIND(Broadcast); BIND(GroupStart); BIND(GroupEnd); BIND(GetErrorString);
+	BIND(Broadcast); BIND(AllReduce); BIND(GroupStart); BIND(GroupEnd); BIND(GetErrorString);
 #undef BIND
 	a.where = where; a.ok = true;
 	g_api = a;
@@ -178,17 +179,32 @@ extern "C" int bmh_index_broadcast_rccl(void *comm_, int root, const bmh_index_t
 	const arrays_t ab = array_bytes(f, h.has_pac != 0);
 	const bool recv = out != nullptr;
 	void *d[4] = {nullptr, nullptr, nullptr, nullptr};
+	int alloc_rc = BMH_OK;
 	if (recv) {
-		for (int k = 0; k < 4; ++k)
+		for (int k = 0; k < 4 && alloc_rc == BMH_OK; ++k)
 			if (ab.bytes[k] && hipMalloc(&d[k], ab.bytes[k]) != hipSuccess) {
 				bmh_set_error("bmh_index_broadcast_rccl: %zu bytes of device memory: %s", ab.bytes[k], hipGetErrorString(hipGetLastError()));
-				for (int q = 0; q < k; ++q) (void)hipFree(d[q]);
-				return BMH_ENOMEM;
+				d[k] = nullptr; alloc_rc = BMH_ENOMEM;
 			}
-		if (d[3] && hipMemsetAsync(d[3], 0, ab.bytes[3], st) != hipSuccess) {       // (the text is read in aligned words past its last byte)
+		if (alloc_rc == BMH_OK && d[3] && hipMemsetAsync(d[3], 0, ab.bytes[3], st) != hipSuccess) {       // (the text is read in aligned words past its last byte)
 			bmh_set_error("bmh_index_broadcast_rccl: %s", hipGetErrorString(hipGetLastError()));
+			alloc_rc = BMH_ENODEV;
+		}
+	}
+	// Every rank says whether it is ready BEFORE the grouped broadcast: a rank that could not allocate used to leave here alone and its peers
+	// waited in the broadcast for good.  One int per rank, minimum over the communicator: all go on, or all leave with an error.
+	{
+		int *d_ok = nullptr, ok_all = 0;
+		const int mine = alloc_rc == BMH_OK ? 1 : 0;
+		bool fine = hipMalloc((void **)&d_ok, sizeof(int)) == hipSuccess && hipMemcpyAsync(d_ok, &mine, sizeof(int), hipMemcpyHostToDevice, st) == hipSuccess;
+		// (a rank that cannot even do this still takes part in the reduction with a null buffer error on its side only if RCCL lets it: nothing more can be done for it)
+		const ncclResult_t ar = fine ? R->AllReduce(d_ok, d_ok, 1, ncclInt32, ncclMin, comm, st) : ncclInternalError;
+		fine = fine && ar == ncclSuccess && hipMemcpyAsync(&ok_all, d_ok, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+		if (d_ok) (void)hipFree(d_ok);
+		if (!fine || ok_all != 1) {
 			for (int k = 0; k < 4; ++k) if (d[k]) (void)hipFree(d[k]);
-			return BMH_ENODEV;
+			if (alloc_rc == BMH_OK) bmh_set_error("bmh_index_broadcast_rccl: %s", fine ? "another rank could not allocate its copy of the index" : "the ranks could not agree that all are ready");
+			return alloc_rc != BMH_OK ? alloc_rc : BMH_ENODEV;
 		}
 	}
 	const void *s[4] = {nullptr, nullptr, nullptr, nullptr};

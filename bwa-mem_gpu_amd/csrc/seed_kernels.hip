@@ -148,27 +148,18 @@ __device__ __forceinline__ void cand_append(bool want, const cand_t &c, uint64_t
 #ifndef FWD_UNIQ_WORDS
 #define FWD_UNIQ_WORDS 1
 #endif
-#ifndef FWD_CHUNK
-#define FWD_CHUNK 64u         // reads a wave takes from the batch's cursor per atomic
-#endif
-#ifndef FWD_REFILL_MIN
-#define FWD_REFILL_MIN 8u     // idle lanes that make a wave with no undealt reads go back to the cursor
-#endif
 __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_view_t rv, const uint32_t *__restrict__ lens,
                                                            int min_seed_len, cand_t *__restrict__ out_a, uint64_t *__restrict__ out_k,
                                                            unsigned long long *counter, uint64_t cap, uint32_t *__restrict__ n_cand)
 {
 	wtrace_scope_t wt_(WT_FORWARD);
 	fmd_wave_prio(f.wave_prio);
-	// Reads are PULLED, not owned (round 5): a wave used to take 64 consecutive reads and run until its slowest one was through -- a read
-	// inside a repeat walks 150 rank steps, a unique one leaves for the text comparison after ~16 -- so most lanes of most waves idled.
-	// Now the grid is what the chip keeps resident; a wave takes FWD_CHUNK reads from the batch's cursor (counter[1]) with one atomic and
-	// deals them to its lanes as they finish, FWD_REFILL_MIN idle lanes at a time.  Which lane walks which read changes nothing: a
-	// candidate names its read and ordinal, cand_scatter_kernel puts the list in (read, ordinal) order.
-	const int lane = __lane_id();
-	unsigned long long *rd_cursor = counter + 1;
-	uint32_t r = 0;
-	int len = 0;
+	// (round 5, measured and dropped: reads PULLED from a cursor by a resident grid -- a wave deals 64-read chunks to its lanes as they
+	// finish, 8 idle lanes at a time -- instead of 64 consecutive reads per wave: 2.66-2.71 -> 2.84 ms; the kernel's time is its gathers
+	// and the candidate appends, not the lanes that wait for their wave's slowest read)
+	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	bool live = r < rv.n_reads;
+	int len = live ? (int)lens[r] : 0;
 	int i = 0, x = 0;
 	uint32_t j = 0;
 	uint64_t k = 0, l = 0, s = 0;
@@ -180,35 +171,9 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 	// candidate pushed at the end is the one the rank walk would push (src/bwt.c:505-519 with x[2] == 1)
 	enum { ST_START, ST_EXT, ST_DONE, ST_TAIL, ST_UNIQ };
 	uint64_t tp = 0;                 // ST_UNIQ: text index that pairs with read position i
-	int st = ST_DONE;
-	uint32_t lc = 0, le = 0;         // the wave's reads not yet dealt (wave-uniform)
-	bool more = true;                // reads left on the batch's cursor (wave-uniform)
+	int st = live && len > 0 ? ST_START : ST_DONE;
 	cand_cursor_t cc = {0, 0};
-	for (;;) {
-		const unsigned long long idle = __ballot(st == ST_DONE);
-		if (idle) {
-			const uint32_t n_idle = (uint32_t)__popcll(idle);
-			if (lc == le && more && (n_idle >= FWD_REFILL_MIN || n_idle == 64u)) {
-				unsigned long long b0 = 0;
-				if (lane == 0) b0 = atomicAdd(rd_cursor, (unsigned long long)FWD_CHUNK);
-				b0 = __shfl(b0, 0);
-				lc = b0 < rv.n_reads ? (uint32_t)b0 : rv.n_reads;
-				le = b0 + FWD_CHUNK < rv.n_reads ? (uint32_t)(b0 + FWD_CHUNK) : rv.n_reads;
-				more = le < rv.n_reads;
-			}
-			if (lc < le) {
-				const uint32_t take = n_idle < le - lc ? n_idle : le - lc;
-				const uint32_t mine = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-				if (st == ST_DONE && mine < take) {
-					r = lc + mine; len = (int)lens[r]; i = 0; x = 0; j = 0;
-					st = len > 0 ? ST_START : ST_DONE;
-					if (len <= 0) n_cand[r] = 0;
-				}
-				lc += take;
-			}
-		}
-		if (!__any(st != ST_DONE)) { if (lc == le && !more) break; else continue; }
-		const bool was = st != ST_DONE;
+	while (__any(st != ST_DONE)) {
 		bool want = false;
 		cand_t c = {r, 0, 0, 0};
 		uint64_t ck = 0;
@@ -286,9 +251,9 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 		}
 		if (want) ++j;
 		cand_append(want, c, ck, out_a, out_k, counter, cap, cc);
-		if (was && st == ST_DONE) n_cand[r] = j;     // the read is through
 	}
 	cand_fill_invalid(cc, out_a, cap);
+	if (live) n_cand[r] = j;
 }
 
 // ---------------------------------------------------------------- backward
@@ -843,6 +808,17 @@ extern "C" bmh_seed_ws_t *bmh_seed_ws_create(uint32_t max_reads, uint64_t max_ba
 		if (!(pe && pe[0] == 'n')) {
 			int prio_lo = 0, prio_hi = 0;
 			(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+			// (BMH_SEED_CUS=n, measurement knob: the seeding stage on a stream confined to n of the chip's compute units -- a pseudo-random subset, so that
+			// whatever order the driver hands mask bits to XCDs and shader engines in, every one of them keeps its share.  The gather-bound kernels
+			// lose less than proportionally on fewer units (what they wait for is memory), and the units they do not take stay with the other
+			// batch's extension, whose blocks cannot be dislodged by a flood of small waves there: DESIGN.md section 5)
+			const char *cue = getenv("BMH_SEED_CUS");
+			const int n_cus = cue ? atoi(cue) : 0;
+			if (n_cus > 0 && n_cus < 256) {
+				uint32_t cumask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+				for (int i = 0; i < n_cus; ++i) { const int b = (i * 167 + 13) & 255; cumask[b >> 5] |= 1u << (b & 31); }
+				ok = ok && hipExtStreamCreateWithCUMask(&w->st_hi, 8, cumask) == hipSuccess;
+			} else
 			ok = ok && hipStreamCreateWithPriority(&w->st_hi, hipStreamNonBlocking, prio_hi) == hipSuccess;
 			ok = ok && hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_out, hipEventDisableTiming) == hipSuccess;
 		}
@@ -1032,11 +1008,9 @@ static int seed_batch_on(bmh_seed_ws_t *w, const bmh_index_t *idx, const uint8_t
 		return BMH_OK;
 	}
 	HIPCK(hipEventRecord(w->ev[1], st));
-	HIPCK(hipMemsetAsync(w->counter, 0, 16, st));           // [0] the candidate list's cursor, [1] the reads' (smem_forward_kernel pulls them)
+	HIPCK(hipMemsetAsync(w->counter, 0, 8, st));
 	HIPCK(hipMemsetAsync(w->n_cand + n_reads, 0, 4, st));
-	static thread_local unsigned fwd_resident = 0;            // blocks the chip keeps resident (8 waves per SIMD)
-	if (!fwd_resident) { int dev = 0; hipDeviceProp_t prop; HIPCK(hipGetDevice(&dev)); HIPCK(hipGetDeviceProperties(&prop, dev)); fwd_resident = (unsigned)prop.multiProcessorCount * 8u; }
-	smem_forward_kernel<<<nblk(n_reads, 256) < fwd_resident ? nblk(n_reads, 256) : fwd_resident, 256, lds_pad, st>>>(f, rv, d_lens, min_seed_len, w->cand_a, w->cand_k, w->counter, w->max_cands, w->n_cand);
+	smem_forward_kernel<<<nblk(n_reads, 256), 256, lds_pad, st>>>(f, rv, d_lens, min_seed_len, w->cand_a, w->cand_k, w->counter, w->max_cands, w->n_cand);
 	HIPCK(hipEventRecord(w->ev[2], st));
 	{
 		size_t tb = w->scan_tmp_bytes;
@@ -1131,16 +1105,23 @@ static int seed_batch_on(bmh_seed_ws_t *w, const bmh_index_t *idx, const uint8_t
 // measure the practical ceiling of random block gathers that the seeding kernels are held against.
 // dependent != 0 chains each address on the previous block's contents, like a rank walk.
 // dependent bits 8..: the gather's width in 32-byte blocks (0 or 1: one block; 2: an aligned 64-byte pair; 4: an aligned 128-byte line) --
-// does the chip pay for random REQUESTS or for the bytes they move?  (what a wider rank block would cost)
+// does the chip pay for random REQUESTS or for the bytes they move?  (what a wider rank block would cost); dependent bit 16: 16-byte requests, one load each
 __global__ void __launch_bounds__(256) calib_gather_kernel(fmd_dev_t f, uint64_t n_blocks, int iters, int dependent, uint32_t *sink)
 {
 	uint64_t x = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
 	uint32_t acc = 0;
-	const int width = (dependent >> 8) > 1 ? (dependent >> 8) : 1;
+	const int width = ((dependent >> 8) & 0xFF) > 1 ? ((dependent >> 8) & 0xFF) : 1;
+	const bool half = (dependent >> 16) & 1;     // bit 16: a request is ONE 16-byte load (half a block): what a request costs per load instruction
 	dependent &= 1;
 	for (int i = 0; i < iters; ++i) {
 		x = x * 6364136223846793005ull + 1442695040888963407ull;
 		const uint64_t b0 = ((x >> 20) % n_blocks) & ~(uint64_t)(width - 1);
+		if (half) {
+			const uint4 h = f.blocks[2 * b0 + ((x >> 19) & 1)];
+			acc += h.x ^ h.w;
+			if (dependent) x ^= (uint64_t)(h.y + h.z) << 24;
+			continue;
+		}
 		blk_t b = fmd_load_block(f, b0);
 		acc += b.occ.x ^ (uint32_t)(b.hi >> 32);
 		for (int w = 1; w < width; ++w) { const blk_t c = fmd_load_block(f, b0 + (uint64_t)w); acc += c.occ.x ^ (uint32_t)(c.hi >> 32); }

@@ -572,7 +572,7 @@ int bmh_sam_text_check(const void *d_work, uint32_t n_reads, void *stream);
  * cuts: n_batches + 1 read indices, cuts[0] = 0, cuts[n_batches] = n_reads, even batch sizes when paired (the reference cuts its
  * batches by bases, bseq_read src/bwa.c:48-66, and the insert-size statistics are those of a batch).  popt->id0 is ignored (a batch's
  * id0 is its first read).  Reads longer than 700 bases: BMH_EINVAL (the device job builder's limit; such a set goes through
- * bmh_build_jobs).  n_threads: host threads of the host forms (<= 0: all).  The aligner borrows idx and pac: both outlive it. */
+ * bmh_build_jobs).  n_threads: host threads of the host forms (<= 0: all).  The aligner borrows idx and pac: both outlive it; popt->rg_id is copied. */
 int bmh_effective_cpus(void);      /* CPUs this process may use: affinity mask capped by the cgroup quota (what n_threads <= 0 resolves to) */
 typedef struct bmh_aligner bmh_aligner_t;
 typedef int (*bmh_sam_sink_t)(void *user, const char *text, size_t len);

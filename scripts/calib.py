@@ -25,6 +25,14 @@ for width in (1, 2, 4):
         L.bmh_calib_gather(idx.handle, lanes, iters, 1 | (width << 8), None, C.byref(ms))
     n = lanes * iters
     print(f"dependent gathers of {32 * width:3d} aligned bytes {gs_note}: {ms.value:.3f} ms, {n/ms.value/1e6:.1f} G requests/s, {n*32*width/ms.value/1e6:.0f} GB/s requested", flush=True)
+# ... and of 16 bytes, ONE load instruction per request (round 5): is a request paid per load instruction (then a rank structure that needs one 16-byte
+# load per rank would lift the seeding kernels' ceiling) or per cache line touched?
+for dep in (1, 0):
+    lanes, iters = 1 << 22, 64
+    for _ in range(2):
+        L.bmh_calib_gather(idx.handle, lanes, iters, dep | (1 << 16), None, C.byref(ms))
+    n = lanes * iters
+    print(f"{'dependent' if dep else 'independent'} gathers of  16 bytes, one load instruction {gs_note}: {ms.value:.3f} ms, {n/ms.value/1e6:.1f} G requests/s", flush=True)
 for dep in (0, 1):
     for lanes, iters in ((1 << 20, 128), (1 << 22, 64), (1 << 23, 32)):
         L.bmh_calib_gather(idx.handle, lanes, iters, dep, None, C.byref(ms))  # warm

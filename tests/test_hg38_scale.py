@@ -164,17 +164,40 @@ def test_baseline_configs_3_and_4_at_full_size(variant):
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    extra = ["--paired"] if variant == "paired" else ["--read-len", "300"]
+    # (configs[3] is 1 M PAIRS: two million interleaved reads per batch)
+    extra = ["--paired", "--reads-per-gpu", "2000000"] if variant == "paired" else ["--read-len", "300"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--verify-sample", "100000", "--no-next-rows", "--cpu-sample", "0",
                         "--no-pcie"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
     cfg = res["config"]
-    assert cfg["reads_per_gpu"] == 1_000_000 and cfg["seq_len"] > 2**32 and cfg["genome_mbp"] == 3100
+    assert cfg["reads_per_gpu"] == (2_000_000 if variant == "paired" else 1_000_000) and cfg["seq_len"] > 2**32 and cfg["genome_mbp"] == 3100
     assert cfg["read_len"] == (300 if variant == "300bp" else 150) and cfg["paired_interleaved"] == (variant == "paired")
     v = res["verified"]
     assert v["reads"] == 100_000 and v["seeds_identical"] and v["regions_identical"], v
     assert res["value"] > 0
+
+
+@pytest.mark.parametrize("shape", ["pairs_150bp", "single_300bp"])
+def test_reference_host_code_at_hg38_scale(hip, tmp_path, shape):
+    """The REFERENCE's own host code against the device-resident path on the 3.1 Gbp genome (24 sequences, seq_len 6.2e9 > 2^32; index built by
+    bmh_index_build and written in the reference's file layout for both sides to load): build/dropin/bwa-gasal2 -- the reference's src/*.c compiled
+    unchanged against include/seed_gen.h + include/gasal2_root, linked with libbwamem_hip.so -- at -t 1 beside bwamem_hip.aligner on 100 000 hard
+    pairs of 150 bp (configs[3]'s shape: diverged / relocated / random / chimeric mates) and on 50 000 hard single-end reads of 300 bp (configs[4]'s):
+    every SAM record identical.  This is the comparison of the host-side record logic (positions, TLEN, pairing windows, the mate rescue's windows,
+    CIGARs) with the reference's own code at coordinates that do not fit 32 bits (scripts/e2e_hg.sh baseline, now inside the driver-run suite)."""
+    import subprocess
+    import sys
+    if not os.path.exists(os.path.join(ROOT, "build", "dropin", "bwa-gasal2")):
+        pytest.skip("build/dropin/bwa-gasal2 not built (needs /root/reference at build time)")
+    n, mode, rl = ("200000", "pe_hard", "150") if shape == "pairs_150bp" else ("50000", "se_hard", "300")
+    env = dict(os.environ, E2E_CONTIGS="24", E2E_NATIVE_BUILD="1", E2E_READLEN=rl, E2E_TAG="gputest_" + shape,
+               E2E_GENOME_KW="{'repeat_frac': 0.3, 'repeat_copies': (10, 3000), 'repeat_len': (300, 3000), 'repeat_div': 0.03}")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "e2e_dropin.py"), str(tmp_path), "3100000000", n, "1", mode],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=1500)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "E2E DROP-IN OK" in out and "SAM IDENTICAL" in out, out[-3000:]
+    assert "differing records: 0" in out, out[-3000:]
 
 
 def test_reads_to_sam_device_forms_equal_host_forms_beyond_2_pow_32(hip):

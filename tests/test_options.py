@@ -58,3 +58,20 @@ def test_read_group_and_ignore_alt_options():
     assert not o.has_alt and not o.alt.any() and not o.copt.contig_is_alt and not o.po.contig_is_alt
     o.contigs = [("a", 5), ("b", 7)]
     assert Aligner.header(o) == "@SQ\tSN:a\tLN:5\n@SQ\tSN:b\tLN:7\n@RG\tID:grp.1\tSM:s 1\tPL:x\n"
+
+
+def test_read_group_line_is_unescaped_in_one_pass_like_bwa_escape():
+    """bwa_escape (src/bwa.c:409-423) walks the line once: "\\\\t" is a backslash followed by 't' (not a backslash and a tab), an unknown escape
+    drops both characters, and the ID ends at the first tab OR newline (src/bwa.c:440-446).  -j also forgets a cached chain workspace (its ALT table)."""
+    o = _Opts()
+    Aligner.set_options(o, ["-R", "@RG\\tID:a\\\\tb\\qc\\nSM:x"])
+    assert o.rg_line == "@RG\tID:a\\tbc\nSM:x" and o.po.rg_id == b"a\\tbc"
+
+    class _Ws:
+        freed = False
+        def free(self): self.freed = True
+    import numpy as np
+    o = _Opts(); o.alt = np.zeros(2, np.uint8); o.has_alt = True
+    ws = _Ws(); o._cw_cache = (ws, 1, 1)
+    Aligner.set_options(o, ["-j"])
+    assert ws.freed and o._cw_cache is None

@@ -43,7 +43,7 @@ from bwamem_hip.parallel import broadcast_built_index, shard_range  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz: a wave64 instruction issues in 2 cycles (MI355X_MICROARCH.md)
 CACHE_VERSION = "v3"          # bump when synth.make_genome_device or the index layout changes
-PROFILE_TAG = "r04"          # profiles/<tag>_pmc*.json: counters collected by scripts/profile_round.sh with this same command (one file per workload)
+PROFILE_TAG = "r05"          # profiles/<tag>_pmc*.json: counters collected by scripts/profile_round.sh with this same command (one file per workload)
 
 
 def profile_counters(workload_key: str):
@@ -357,38 +357,66 @@ def main():
             self.out3 = torch.zeros(cap_jobs, 3, dtype=torch.int32, device=dev) if a.passes == 1 else None
             self.n_regs = 0
             self.acc = {}
-            # PCIe form: the lane's own device copy of the reads and pinned host buffer of the regions
-            self.slot = None; self.host_out = None
+            # PCIe form: the lane's own device copies of the reads (two slots: the next batch arrives while this one is worked on) and pinned host
+            # buffer of the regions, its own copy streams (the DMA engines run beside the kernels) and two region buffers on the device
+            self.slot = None; self.host_out = None; self.cs_in = self.cs_out = None
+            self.ev_in = [None, None]; self.ev_free = None; self.ev_regs = None; self.ev_out = [None, None]; self.regs2 = None; self.n_pcie = 0
+
+        def _h2d(self, k, host_in, i):
+            """reads of step i into input slot k, on the lane's inbound copy stream, once the kernels that read the slot are through"""
+            with torch.cuda.stream(self.cs_in):
+                if self.ev_free is not None:
+                    self.cs_in.wait_event(self.ev_free)
+                for dst, src in zip(self.slot[k], host_in[i & 1]):
+                    dst.copy_(src, non_blocking=True)
+                self.ev_in[k] = torch.cuda.Event(); self.ev_in[k].record(self.cs_in)
 
         def step(self, i, host_in=None):
             dr = batches[i & 1][1]
             ascii_t, offs_t, lens_t = dr.ascii, dr.offs, dr.lens
-            if host_in is not None:                                   # reads arrive over PCIe on the lane's stream
+            regs_t = self.regs
+            if host_in is not None:
                 if self.slot is None:
-                    self.slot = (torch.empty_like(dr.ascii), torch.empty_like(dr.offs), torch.empty_like(dr.lens))
+                    self.slot = [tuple(torch.empty_like(x) for x in (dr.ascii, dr.offs, dr.lens)) for _ in range(2)]
                     self.host_out = torch.empty(cap_regs, 8, dtype=torch.int32).pin_memory()
-                with torch.cuda.stream(self.stream):
-                    for dst, src in zip(self.slot, host_in[i & 1]):
-                        dst.copy_(src, non_blocking=True)
-                ascii_t, offs_t, lens_t = self.slot
+                    self.cs_in, self.cs_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+                    self.regs2 = [self.regs, torch.zeros_like(self.regs)]
+                k = self.n_pcie & 1
+                prev_done = self.ev_free                                # end of the lane's previous step: the other slot's last reader
+                if self.ev_in[k] is None:                               # (the lane's first step of a loop: nothing was sent ahead)
+                    self._h2d(k, host_in, i)
+                self.stream.wait_event(self.ev_in[k]); self.ev_in[k] = None
+                ascii_t, offs_t, lens_t = self.slot[k]
+                regs_t = self.regs2[k]
+                if self.ev_out[k] is not None:                          # the regions that left this buffer two steps ago have reached the host
+                    self.stream.wait_event(self.ev_out[k])
             t_host = [time.time()]
             sd = self.ws.seed_batch(dindex, ascii_t, offs_t, lens_t, 19, stream=self.h)
             t_host.append(time.time())
             tm = self.ws.timing()
+            if host_in is not None and i + n_lanes < self.k_end:        # the lane's next batch sets out now, into the other slot (behind the previous step's last kernel)
+                self.ev_free = prev_done
+                self._h2d(k ^ 1, host_in, i + n_lanes)
             if a.passes == 1:
                 dj_ = self.cw.chain_batch(dindex, ascii_t, offs_t, lens_t, sd, stream=self.h)
                 self.cw.extend(self.out3, params=params, stream=self.h)
                 tm["extend_one_pass"] = 0.0
-                self.cw.merge(self.out3, self.regs, stream=self.h)
+                self.cw.merge(self.out3, regs_t, stream=self.h)
             else:
-                dj_ = self.cw.extend_merge(dindex, ascii_t, offs_t, lens_t, sd, self.regs, params=params, stream=self.h)
+                dj_ = self.cw.extend_merge(dindex, ascii_t, offs_t, lens_t, sd, regs_t, params=params, stream=self.h)
             self.n_regs = int(dj_.n_regs); self.last_batch = i & 1; self.last_pcie = host_in is not None
+            self.last_regs = regs_t
             t_host.append(time.time())
             if lane_log is not None:                                  # (BENCH_LANE_LOG=1: host-side begin / seeded / launched of every batch)
                 lane_log.append((self.k, i, *t_host))
-            if host_in is not None:                                   # regions leave over PCIe, behind the lane's next batch
-                with torch.cuda.stream(self.stream):
-                    self.host_out[: self.n_regs].copy_(self.regs[: self.n_regs], non_blocking=True)
+            if host_in is not None:                                   # regions leave over PCIe on the outbound copy stream, beside the lane's next batch
+                ev = torch.cuda.Event(); ev.record(self.stream)
+                with torch.cuda.stream(self.cs_out):
+                    self.cs_out.wait_event(ev)
+                    self.host_out[: self.n_regs].copy_(regs_t[: self.n_regs], non_blocking=True)
+                    self.ev_out[k] = torch.cuda.Event(); self.ev_out[k].record(self.cs_out)
+                self.n_pcie += 1
+                self.ev_free = ev
             cm = self.cw.timing()
             tm["chain_light"] = cm["to_counts"]    # classify + lane kernel + counts: what the first extension waits for
             tm["chain_heavy_beside"] = cm["wave"]  # wave kernels on side streams (hidden behind extend_a as far as it lasts)
@@ -413,6 +441,7 @@ def main():
             try:
                 L.bmh_set_device(dev_id)                              # HIP's current device is per host thread
                 torch.cuda.set_device(dev_id)
+                lane.k_end = k
                 for i in range(lane.k, k, n_lanes):
                     lane.step(i, host_in)
             except Exception as e:                                    # noqa: BLE001 -- re-raised on the main thread
@@ -476,9 +505,10 @@ def main():
     # one more (untimed) step of the same code path on batch 1.
     vlane = lanes[-1]
     if getattr(vlane, "last_batch", 0) != 1:
+        vlane.k_end = 0
         vlane.step(1, host_in if a.pcie else None)
     torch.cuda.synchronize()
-    last_regs_h = vlane.host_out[: vlane.n_regs].numpy().copy() if vlane.last_pcie else vlane.regs[: vlane.n_regs].cpu().numpy()
+    last_regs_h = vlane.host_out[: vlane.n_regs].numpy().copy() if vlane.last_pcie else vlane.last_regs[: vlane.n_regs].cpu().numpy()
 
     if distributed:
         tt = torch.tensor([dt, dt_pcie or 0.0], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -559,8 +589,9 @@ def main():
             if L.bmh_calib_valu(mode, 8, 20000, None, C.byref(ms_c), C.byref(ops_c)) == 0:
                 cal[nm] = round(ops_c.value / (ms_c.value * 1e-3) / VALU_PEAK_LANEOPS, 3)
                 if mode == 0 and L.bmh_calib_last_clock(C.byref(mhz_c), C.byref(cpi_c)) == 0:
-                    clock = {"clock_mhz": round(mhz_c.value, 1), "valu_cycles_per_wave_instr_8_waves": round(cpi_c.value / 8.0, 3),
-                             "how": "shader cycles (s_memtime) / 100 MHz ticks (s_memrealtime) of one wave around 2.56 M VALU instructions, 8 waves per SIMD on every SIMD"}
+                    clock = {"clock_mhz": round(mhz_c.value, 1), "shader_cycles_per_instr_of_the_first_wave": round(cpi_c.value, 3),
+                             "how": "shader cycles (s_memtime) / 100 MHz ticks (s_memrealtime) of the first wave of the launch around its 2.56 M VALU instructions, 8 waves per SIMD "
+                                    "on every SIMD (the SIMD issues its oldest ready wave first: that wave runs at the SIMD's rate, one instruction per ~4.4 cycles)"}
         st = stats[-1]
         index_how = ("loaded from --index-cache (built on the device by an earlier run of this command)" if build_stats.get("loaded_from_cache") else
                      "built on the device in setup" + (" and verified completely (every adjacent pair of suffix-array rows)" if build_stats.get("verified") else ", not verified (--no-verify-index)"))
@@ -594,8 +625,9 @@ def main():
         if dt_pcie:
             res["incl_pcie"] = {"value": round(total_reads * a.steps / dt_pcie / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(dt_pcie / a.steps * 1e3, 3),
                                 "h2d_bytes_per_step": int(pcie_bytes[0]), "d2h_bytes_per_step": int(pcie_bytes[1]),
-                                "how": "pinned host reads -> H2D -> path -> D2H of the regions into pinned host memory, every batch on its lane's stream: the copies "
-                                       "of one batch in flight overlap the kernels of the other(s)"}
+                                "how": "pinned host reads -> H2D -> path -> D2H of the regions into pinned host memory; every lane double-buffers both directions on copy streams "
+                                       "of its own (the next batch's reads arrive while this one is worked on, its regions leave beside the next one): what a host "
+                                       "worker of the reference's boundary does with two gpu_storage batches"}
         if verified is not None:
             res["verified"] = verified
         if distributed:

@@ -1209,25 +1209,25 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		if (a.o_ins + a.e_ins == a.o_del + a.e_del) extpk_persist_kernel<true><<<gp, 256, lds_pad, S[0]>>>(a);
 		else extpk_persist_kernel<false><<<gp, 256, lds_pad, S[0]>>>(a);
 	} else if (pk_ok) {
-		// grids sized to what is resident at once (the waves draw their jobs): 3 waves per SIMD beyond PK_WAVES4_MAXP pairs per lane (768 blocks), 4 up to there
+		// grids sized to what is resident at once (the waves draw their jobs): 4 waves per SIMD for the classes of PK_WAVES4 (extpk_dev.h), 3 for the others (768 blocks)
 		unsigned g4 = (unsigned)((n + 63) / 64), g8 = (unsigned)((n + 31) / 32);
 		if (g4 > max_grid) g4 = max_grid;
 		if (g8 > max_grid) g8 = max_grid;
 		const unsigned g4w = g4 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g4, g8w = g8 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g8, g16w = g16 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g16;
-		if (mq > 128) launch_pk<4, 17>(a, S[2], PK_WAVES4_MAXP >= 17 ? g4 : g4w);
-		if (mq > 112) launch_pk<4, 16>(a, S[3], PK_WAVES4_MAXP >= 16 ? g4 : g4w);
-		if (mq > 96) launch_pk<4, 14>(a, S[0], PK_WAVES4_MAXP >= 14 ? g4 : g4w);
-		if (mq > 80) launch_pk<4, 12>(a, S[1], PK_WAVES4_MAXP >= 12 ? g4 : g4w);
-		if (mq > 64) launch_pk<4, 10>(a, S[2], PK_WAVES4_MAXP >= 10 ? g4 : g4w);
+		if (mq > 128) launch_pk<4, 17>(a, S[2], PK_WAVES4(4, 17) ? g4 : g4w);
+		if (mq > 112) launch_pk<4, 16>(a, S[3], PK_WAVES4(4, 16) ? g4 : g4w);
+		if (mq > 96) launch_pk<4, 14>(a, S[0], PK_WAVES4(4, 14) ? g4 : g4w);
+		if (mq > 80) launch_pk<4, 12>(a, S[1], PK_WAVES4(4, 12) ? g4 : g4w);
+		if (mq > 64) launch_pk<4, 10>(a, S[2], PK_WAVES4(4, 10) ? g4 : g4w);
 		if (mq > 48) launch_pk<4, 8>(a, S[3], g4);
 		if (mq > 32) launch_pk<4, 6>(a, S[0], g4);
 		launch_pk<4, 4>(a, S[1], g4);
-		if (mq > 128) launch_pk<8, 9>(a, S[2], PK_WAVES4_MAXP >= 9 ? g8 : g8w);
-		if (mq > 144) launch_pk<8, 10>(a, S[3], PK_WAVES4_MAXP >= 10 ? g8 : g8w);
-		if (mq > 160) launch_pk<8, 12>(a, S[0], PK_WAVES4_MAXP >= 12 ? g8 : g8w);
-		if (mq > 192) launch_pk<8, 14>(a, S[1], PK_WAVES4_MAXP >= 14 ? g8 : g8w);
-		if (mq > 224) launch_pk<8, 16>(a, S[2], PK_WAVES4_MAXP >= 16 ? g8 : g8w);
-		if (mq > 256) launch_pk<16, 9>(a, S[3], PK_WAVES4_MAXP >= 9 ? g16 : g16w);
+		if (mq > 128) launch_pk<8, 9>(a, S[2], PK_WAVES4(8, 9) ? g8 : g8w);
+		if (mq > 144) launch_pk<8, 10>(a, S[3], PK_WAVES4(8, 10) ? g8 : g8w);
+		if (mq > 160) launch_pk<8, 12>(a, S[0], PK_WAVES4(8, 12) ? g8 : g8w);
+		if (mq > 192) launch_pk<8, 14>(a, S[1], PK_WAVES4(8, 14) ? g8 : g8w);
+		if (mq > 224) launch_pk<8, 16>(a, S[2], PK_WAVES4(8, 16) ? g8 : g8w);
+		if (mq > 256) launch_pk<16, 9>(a, S[3], PK_WAVES4(16, 9) ? g16 : g16w);
 	}
 	// (narrow classes first measured better than widest first: 10.8 vs 11.1 ms)
 	// class C of extend16 holds the queries of 16 (C - 1) + 1 .. 16 C columns; wide class C those of 64 (C - 1) + 1 .. 64 C, and class 5

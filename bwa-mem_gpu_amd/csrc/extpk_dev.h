@@ -446,8 +446,13 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t<P> &K, const int zdrop,
 }
 
 #ifndef PK_CHUNK
-#define PK_CHUNK 32           // jobs a wave takes from its class counter per atomic (their records: one coalesced load into the wave's LDS)
+#define PK_CHUNK 16           // jobs a wave takes from its class counter per atomic (their records: one coalesced load into the wave's LDS); 16 / 32 / 64: extension 13.9-14.1 / 14.3-14.5 / 14.6-14.8 ms (the last chunks of a class are its tail)
 #endif
+// classes whose next job's bases are fetched AHEAD (loads in flight across rows): the four-lane classes, whose jobs are short and whose draws are
+// frequent.  The eight- and sixteen-lane classes (300 bp reads) draw rarely, and the two to four registers the loads in flight occupy cost their
+// nine- and ten-pair kernels the fourth wave per SIMD: measured at 300 bp with everything fetched ahead, the extension 66.5 -> 70.0 ms
+#define PK_AHEAD(G) ((G) == 4)
+#define PK_WAVES4(G, P) ((G) == 4 ? (P) <= PK_WAVES4_MAXP : (P) <= 10)
 #ifndef PK_PREFETCH_AGE
 #define PK_PREFETCH_AGE 3     // rows after which the bases fetched ahead are taken out of their registers (they have long arrived by then)
 #endif
@@ -566,7 +571,7 @@ __device__ __forceinline__ void extpk_body(const ext_args_t &A, uint8_t *t_wave,
 						p_w3 = __builtin_amdgcn_readfirstlane(r0.w); p_side = __builtin_amdgcn_readfirstlane(r1.x); p_w5 = __builtin_amdgcn_readfirstlane(r1.y);
 						p_t0l = __builtin_amdgcn_readfirstlane(r1.z); p_t0h = __builtin_amdgcn_readfirstlane(r1.w);
 						const int ql = (int)(p_qt & 0xFFFFu), tln = (int)(p_qt >> 16);
-						p_async = A.desc && ql >= 4;
+						p_async = PK_AHEAD(G) && A.desc && ql >= 4;
 						if (p_async) {                               // the bases: loads only, nobody waits for them here
 							const bool left = p_side == 0;
 							const long long t0 = (long long)(((unsigned long long)p_t0h << 32) | p_t0l) + (left ? tln - 1 : 0);
@@ -696,7 +701,7 @@ __device__ __forceinline__ void extpk_body(const ext_args_t &A, uint8_t *t_wave,
 
 // One kernel per class (the form the side streams of extend_launch run when the persistent kernel is off): the end masks are the block's.
 template <int G, int P, bool SAME_OE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P > PK_WAVES4_MAXP ? 3 : 4))) extpk_kernel(ext_args_t A)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK_WAVES4(G, P) ? 4 : 3))) extpk_kernel(ext_args_t A)
 {
 	wtrace_scope_t wt_(WT_EXT_PK, (uint32_t)(G << 8 | P));
 	using L = pk_lds_t<G, P>;

@@ -4,7 +4,7 @@
 # counters are collected in their own runs, one counter group per run, without any trace option beside them; the program itself
 # (python3 bench.py ...) stands directly behind `--`.
 set -x
-TAG=${1:-r03}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT; cd $R
 mkdir -p gpurun_out
 df -h /tmp /dev/shm | tail -2; free -g | head -2

@@ -19,7 +19,7 @@ FAMILIES = {
     "backward": (("smem_backward_kernel", "cand_scatter"), "seed"),
     "locate": (("locate_kernel",), "seed"),
     "seed_other": (("pack_reads", "smem_filter", "per_read_counts", "expand_kernel", "cand_count"), "seed"),
-    "extend": (("ext_closed_form", "ext_key", "ext_offsets", "extend16", "extend_wide", "extpk"), "extend"),
+    "extend": (("ext_closed_form", "ext_key", "ext_offsets", "ext_scatter", "extend16", "extend_wide", "extpk"), "extend"),
     "chain": (("chain_", "emit_kernel", "split_counts", "merge_kernel", "merge2_kernel"), "chain"),
 }
 SQ = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE")

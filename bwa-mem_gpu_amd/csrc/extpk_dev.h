@@ -27,6 +27,9 @@
 #ifndef PK_BOUND_MASK
 #define PK_BOUND_MASK 15      // the exact early-stop bound is evaluated every (mask + 1)-th row of a wave (every 2nd / 4th / 8th / 16th / 32nd: 17.6 / 17.3 / 17.2 / 17.1 / 17.4 ms)
 #endif
+#ifndef PK_EM_EAGER
+#define PK_EM_EAGER(G, P) 0      // (A/B knob: classes whose end masks are all loaded before the row's first pass, round 4's order, instead of one uint4 at a time inside the second)
+#endif
 #define PK_HMAX 4096          // scores stay below this (keys are h << 4 | pair in 16 bits)
 #define PK_HMAX17 2048        // ... in the 17-pair class (keys h << 5 | pair)
 #define PK_NEG (-(1 << 28))
@@ -313,6 +316,16 @@ __device__ __forceinline__ void pk_pass2(uint32_t (&H)[P], uint32_t (&E)[P], uin
 	}
 }
 
+// ... and with all masks in registers before the row's first pass (classes with registers to spare)
+template <int P, bool SAME_OE, int K0>
+__device__ __forceinline__ void pk_pass2_eager(uint32_t (&H)[P], uint32_t (&E)[P], uint32_t (&NZ)[P], const uint32_t (&M)[P], const uint4 (&em)[((P + 3) & ~3) / 4],
+                                               uint32_t &f, uint32_t &key, uint32_t &nzb, uint32_t &nzb2, const pk_consts_t<P> &K)
+{
+	constexpr int PP = (P + 3) & ~3, NCH = PP / 4, CNT = (K0 + 1) * 4 <= P ? 4 : P - K0 * 4;
+	pk_pass2_chunk<P, SAME_OE, K0 * 4>(H, E, NZ, M, em[K0], f, key, nzb, nzb2, K, std::make_integer_sequence<int, CNT>());
+	if constexpr (K0 + 1 < NCH) pk_pass2_eager<P, SAME_OE, K0 + 1>(H, E, NZ, M, em, f, key, nzb, nzb2, K);
+}
+
 // One DP row of the wave's alignments.  em_tab: the end masks, [2P+1][PP] dwords in LDS; hrow: the group's PP dwords of the H
 // parking area, written by the lane that owns column qlen-1 (`owner`); h16[goff]: where the group finds H(i, qlen-1) in it.
 // Returns the new `alive`.
@@ -329,6 +342,11 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t<P> &K, const int zdrop,
 	const int wc = min(max(wend, 0), C);
 	const uint4 *em_src = (const uint4 *)(em_tab + wc * PS);
 	const uint4 em0 = em_src[0];
+	uint4 em_all[PP / 4];
+	if constexpr (PK_EM_EAGER(G, P)) {
+#pragma unroll
+		for (int k = 0; k < PP / 4; ++k) em_all[k] = em_src[k];
+	}
 	// score + b of this row's target base against query codes 0..3 (bytes of tbl_lo); N rows: b-1 everywhere
 	const uint32_t tbl_lo = ti < 4 ? (K.ab << (8 * ti)) : K.nrow;
 	// diagonal input of pair 0: (last column of the left lane | first-column value, own column P-1)
@@ -356,7 +374,8 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t<P> &K, const int zdrop,
 		f = (uint32_t)fin_lo | ((uint32_t)fin_hi << 16);
 	}
 	uint32_t key = 0, nzb = 0, nzb2 = 0;
-	pk_pass2<P, SAME_OE, 0>(H, E, NZ, M, em_src, em0, f, key, nzb, nzb2, K);
+	if constexpr (PK_EM_EAGER(G, P)) pk_pass2_eager<P, SAME_OE, 0>(H, E, NZ, M, em_all, f, key, nzb, nzb2, K);
+	else pk_pass2<P, SAME_OE, 0>(H, E, NZ, M, em_src, em0, f, key, nzb, nzb2, K);
 	// last non-zero H column of the lane, + 1 (0: none): pair p sits at bit P-1-p of its half of nzb (branch-free)
 	int nlast;
 	{

@@ -541,7 +541,8 @@ __device__ __forceinline__ void extpk_body(const ext_args_t &A, uint8_t *t_wave,
 	bool more_g = n > 0;                                       // jobs left on the class counter
 	bool pre = false, pend = false, p_async = false;           // the next job is staged / its bases are on their way (as loads in flight)
 	int age = 0;
-	uint32_t p_id = 0, p_qt = 0, p_h0 = 1, p_w3 = 0, p_side = 1, p_w5 = 0, p_t0l = 0, p_t0h = 0;      // its record
+	uint32_t p_slot = 0;                                       // its record's place in rc_wave (the record itself is re-read from LDS where it is needed: eight scalars carried
+	                                                           // through the row loop were eight more spilled into vector lanes and fetched back row after row)
 	uint32_t raw_t[NT], raw_q[NQ];
 #pragma unroll
 	for (int u = 0; u < NT; ++u) raw_t[u] = 0;
@@ -549,168 +550,178 @@ __device__ __forceinline__ void extpk_body(const ext_args_t &A, uint8_t *t_wave,
 	for (int u = 0; u < NQ; ++u) raw_q[u] = 0;
 	for (;;) {
 		unsigned long long reqs = __ballot(!alive && g0);        // groups without a running alignment
-		if (reqs) {
-			if (!alive && have && g0) {                          // results of the alignment that just ended
-				const int qle = S.max_j + 1, tle = S.max_i + 1, gtle = S.max_ie + 1;
-				const uint32_t id = hrow[PP];                    // (the job's id waits in a padding word of the group's parking row)
-				int32_t *o = A.out + 3 * (size_t)id;
-				if (S.gscore <= 0 || S.gscore <= S.mx - A.end_bonus) { o[0] = S.mx; o[1] = qle; o[2] = tle; }
-				else { o[0] = S.gscore; o[1] = qlen; o[2] = gtle; }
-				if (A.raw) {
-					int32_t *r = A.raw + 6 * (size_t)id;
-					r[0] = S.mx; r[1] = qle; r[2] = tle; r[3] = gtle; r[4] = S.gscore; r[5] = S.max_off;
-				}
-				if (A.stats) { atomicAdd(A.stats, (unsigned long long)i); atomicAdd(A.stats + 1, (unsigned long long)tlen); atomicAdd(A.stats + 2, 1ull); }
-			}
-			have = have && alive;
-		}
-		// serve the groups that ask, one job each, then leave the next job on its way
-		for (;;) {
-			const bool waiting = reqs != 0;
-			if (!pre) {
-				if (!pend) {
-					if (qn == qe && more_g) {                        // the next chunk: one atomic on the class counter, its records in one coalesced load
-						uint32_t b0 = 0;
-						if (lane == 0) b0 = atomicAdd(A.ctr, (uint32_t)PK_CHUNK);
-						qn = __builtin_amdgcn_readfirstlane(b0);
-						qe = qn + PK_CHUNK < n ? qn + PK_CHUNK : n;
-						if (qn >= n) { qn = qe = n; }
-						more_g = qe < n;
-						cbase = qn;
-						if ((uint32_t)lane < qe - qn) {               // (the class kernels draw from the long end of the list)
-							const uint4 *r = recs + 2 * (size_t)(n - 1 - (qn + (uint32_t)lane));
-							rc_wave[2 * lane] = r[0]; rc_wave[2 * lane + 1] = r[1];
-						}
-						__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (LDS operations of a wave execute in order; the fences hold the compiler to it)
+		// ONE wave-uniform branch around everything that is not a DP row: in the steady state -- a job staged ahead, every group running -- a row pays the ballot and this
+		// test (the nine- and ten-pair rows of the eight- and sixteen-lane classes are short: five branches a row were 3 % of the 300 bp extension)
+		if (reqs || !pre) {
+			if (reqs) {
+				if (!alive && have && g0) {                          // results of the alignment that just ended
+					const int qle = S.max_j + 1, tle = S.max_i + 1, gtle = S.max_ie + 1;
+					const uint32_t id = hrow[PP];                    // (the job's id waits in a padding word of the group's parking row)
+					int32_t *o = A.out + 3 * (size_t)id;
+					if (S.gscore <= 0 || S.gscore <= S.mx - A.end_bonus) { o[0] = S.mx; o[1] = qle; o[2] = tle; }
+					else { o[0] = S.gscore; o[1] = qlen; o[2] = gtle; }
+					if (A.raw) {
+						int32_t *r = A.raw + 6 * (size_t)id;
+						r[0] = S.mx; r[1] = qle; r[2] = tle; r[3] = gtle; r[4] = S.gscore; r[5] = S.max_off;
 					}
-					if (qn < qe) {
-						const uint4 r0 = rc_wave[2 * (qn - cbase)], r1 = rc_wave[2 * (qn - cbase) + 1];
-						++qn;
-						p_id = __builtin_amdgcn_readfirstlane(r0.x); p_qt = __builtin_amdgcn_readfirstlane(r0.y); p_h0 = __builtin_amdgcn_readfirstlane(r0.z);
-						p_w3 = __builtin_amdgcn_readfirstlane(r0.w); p_side = __builtin_amdgcn_readfirstlane(r1.x); p_w5 = __builtin_amdgcn_readfirstlane(r1.y);
-						p_t0l = __builtin_amdgcn_readfirstlane(r1.z); p_t0h = __builtin_amdgcn_readfirstlane(r1.w);
+					if (A.stats) { atomicAdd(A.stats, (unsigned long long)i); atomicAdd(A.stats + 1, (unsigned long long)tlen); atomicAdd(A.stats + 2, 1ull); }
+				}
+				have = have && alive;
+			}
+			// serve the groups that ask, one job each, then leave the next job on its way
+			for (;;) {
+				const bool waiting = reqs != 0;
+				if (!pre) {
+					if (!pend) {
+						if (qn == qe && more_g) {                        // the next chunk: one atomic on the class counter, its records in one coalesced load
+							uint32_t b0 = 0;
+							if (lane == 0) b0 = atomicAdd(A.ctr, (uint32_t)PK_CHUNK);
+							qn = __builtin_amdgcn_readfirstlane(b0);
+							qe = qn + PK_CHUNK < n ? qn + PK_CHUNK : n;
+							if (qn >= n) { qn = qe = n; }
+							more_g = qe < n;
+							cbase = qn;
+							if ((uint32_t)lane < qe - qn) {               // (the class kernels draw from the long end of the list)
+								const uint4 *r = recs + 2 * (size_t)(n - 1 - (qn + (uint32_t)lane));
+								rc_wave[2 * lane] = r[0]; rc_wave[2 * lane + 1] = r[1];
+							}
+							__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (LDS operations of a wave execute in order; the fences hold the compiler to it)
+						}
+						if (qn < qe) {
+							p_slot = qn - cbase;
+							const uint4 r0 = rc_wave[2 * p_slot], r1 = rc_wave[2 * p_slot + 1];
+							++qn;
+							const uint32_t p_qt = __builtin_amdgcn_readfirstlane(r0.y), p_w3 = __builtin_amdgcn_readfirstlane(r0.w), p_side = __builtin_amdgcn_readfirstlane(r1.x);
+							const uint32_t p_t0l = __builtin_amdgcn_readfirstlane(r1.z), p_t0h = __builtin_amdgcn_readfirstlane(r1.w);
+							const int ql = (int)(p_qt & 0xFFFFu), tln = (int)(p_qt >> 16);
+							p_async = PK_AHEAD(G) && A.desc && ql >= 4;
+							if (p_async) {                               // the bases: loads only, nobody waits for them here
+								const bool left = p_side == 0;
+								const long long t0 = (long long)(((unsigned long long)p_t0h << 32) | p_t0l) + (left ? tln - 1 : 0);
+								const uint8_t *qp = A.reads + p_w3 + (left ? ql - 1 : 0);
+	#pragma unroll
+								for (int u = 0; u < NT; ++u) {
+									const int k0 = 8 * lane + 512 * u;
+									if (k0 < tln) { const pk_t8w_t w = pk_t8_where(A.l_pac, t0, left ? -1 : 1, k0); __builtin_memcpy(&raw_t[u], A.pac + (w.fa >> 2), 4); }
+								}
+	#pragma unroll
+								for (int u = 0; u < NQ; ++u) {
+									const int c0 = 4 * lane + 256 * u;
+									if (c0 < ql) { int sh; const uint8_t *a = pk_q4_where(qp, left ? -1 : 1, ql, c0, sh); __builtin_memcpy(&raw_q[u], a, 4); }
+								}
+							}
+							pend = true; age = 0;
+						}
+					}
+					if (pend && (waiting || age >= PK_PREFETCH_AGE)) {   // into the spare row and the query row
+						const uint4 r0 = rc_wave[2 * p_slot], r1 = rc_wave[2 * p_slot + 1];
+						const uint32_t p_qt = __builtin_amdgcn_readfirstlane(r0.y), p_w3 = __builtin_amdgcn_readfirstlane(r0.w), p_side = __builtin_amdgcn_readfirstlane(r1.x);
+						const uint32_t p_w5 = __builtin_amdgcn_readfirstlane(r1.y), p_t0l = __builtin_amdgcn_readfirstlane(r1.z), p_t0h = __builtin_amdgcn_readfirstlane(r1.w);
 						const int ql = (int)(p_qt & 0xFFFFu), tln = (int)(p_qt >> 16);
-						p_async = PK_AHEAD(G) && A.desc && ql >= 4;
-						if (p_async) {                               // the bases: loads only, nobody waits for them here
-							const bool left = p_side == 0;
+						const bool left = A.desc && p_side == 0;
+						uint8_t *tg = t_wave + spare;
+						if (p_async) {
 							const long long t0 = (long long)(((unsigned long long)p_t0h << 32) | p_t0l) + (left ? tln - 1 : 0);
-							const uint8_t *qp = A.reads + p_w3 + (left ? ql - 1 : 0);
-#pragma unroll
+	#pragma unroll
 							for (int u = 0; u < NT; ++u) {
 								const int k0 = 8 * lane + 512 * u;
-								if (k0 < tln) { const pk_t8w_t w = pk_t8_where(A.l_pac, t0, left ? -1 : 1, k0); __builtin_memcpy(&raw_t[u], A.pac + (w.fa >> 2), 4); }
+								if (k0 < tln) {
+									uint32_t lo, hi;
+									pk_t8_decode(raw_t[u], pk_t8_where(A.l_pac, t0, left ? -1 : 1, k0), lo, hi);
+									*(uint32_t *)(tg + k0) = lo;
+									if (k0 + 4 < tln) *(uint32_t *)(tg + k0 + 4) = hi;
+								}
 							}
-#pragma unroll
+	#pragma unroll
 							for (int u = 0; u < NQ; ++u) {
 								const int c0 = 4 * lane + 256 * u;
-								if (c0 < ql) { int sh; const uint8_t *a = pk_q4_where(qp, left ? -1 : 1, ql, c0, sh); __builtin_memcpy(&raw_q[u], a, 4); }
+								if (c0 < C * G) {
+									int sh = 0;
+									if (c0 < ql) (void)pk_q4_where(nullptr, left ? -1 : 1, ql, c0, sh);
+									*(uint32_t *)(qw + c0) = c0 < ql ? pk_q4_decode(raw_q[u], sh, left ? -1 : 1, ql, c0) : 0x07070707u;
+								}
 							}
-						}
-						pend = true; age = 0;
-					}
-				}
-				if (pend && (waiting || age >= PK_PREFETCH_AGE)) {   // into the spare row and the query row
-					const int ql = (int)(p_qt & 0xFFFFu), tln = (int)(p_qt >> 16);
-					const bool left = A.desc && p_side == 0;
-					uint8_t *tg = t_wave + spare;
-					if (p_async) {
-						const long long t0 = (long long)(((unsigned long long)p_t0h << 32) | p_t0l) + (left ? tln - 1 : 0);
-#pragma unroll
-						for (int u = 0; u < NT; ++u) {
-							const int k0 = 8 * lane + 512 * u;
-							if (k0 < tln) {
+						} else {                                         // array jobs and queries of under four columns: fetched here and now
+							job_src_t sg;
+							if (A.desc) { sg.qp = A.reads + p_w3 + (left ? ql - 1 : 0); sg.qstep = left ? -1 : 1; sg.tp = nullptr; sg.t0 = (long long)(((unsigned long long)p_t0h << 32) | p_t0l) + (left ? tln - 1 : 0); sg.tdir = left ? -1 : 1; }
+							else { sg.qp = A.q + p_w3; sg.qstep = 1; sg.tp = A.t + p_w5; sg.t0 = 0; sg.tdir = 1; }
+							for (int k0 = 8 * lane; k0 < tln; k0 += 512) {
 								uint32_t lo, hi;
-								pk_t8_decode(raw_t[u], pk_t8_where(A.l_pac, t0, left ? -1 : 1, k0), lo, hi);
+								pk_t8(A, sg, k0, tln, lo, hi);
 								*(uint32_t *)(tg + k0) = lo;
 								if (k0 + 4 < tln) *(uint32_t *)(tg + k0 + 4) = hi;
 							}
-						}
-#pragma unroll
-						for (int u = 0; u < NQ; ++u) {
-							const int c0 = 4 * lane + 256 * u;
-							if (c0 < C * G) {
-								int sh = 0;
-								if (c0 < ql) (void)pk_q4_where(nullptr, left ? -1 : 1, ql, c0, sh);
-								*(uint32_t *)(qw + c0) = c0 < ql ? pk_q4_decode(raw_q[u], sh, left ? -1 : 1, ql, c0) : 0x07070707u;
+							for (int c0 = 4 * lane; c0 < C * G; c0 += 256) {
+								uint32_t w = 0;
+	#pragma unroll
+								for (int u = 0; u < 4; ++u) { const int j = c0 + u; w |= (uint32_t)(j < ql ? min(ext_q_at(A, sg, j), 4) : 7) << (8 * u); }      // 4 = N, 7 = pad
+								*(uint32_t *)(qw + c0) = w;
 							}
 						}
-					} else {                                         // array jobs and queries of under four columns: fetched here and now
-						job_src_t sg;
-						if (A.desc) { sg.qp = A.reads + p_w3 + (left ? ql - 1 : 0); sg.qstep = left ? -1 : 1; sg.tp = nullptr; sg.t0 = (long long)(((unsigned long long)p_t0h << 32) | p_t0l) + (left ? tln - 1 : 0); sg.tdir = left ? -1 : 1; }
-						else { sg.qp = A.q + p_w3; sg.qstep = 1; sg.tp = A.t + p_w5; sg.t0 = 0; sg.tdir = 1; }
-						for (int k0 = 8 * lane; k0 < tln; k0 += 512) {
-							uint32_t lo, hi;
-							pk_t8(A, sg, k0, tln, lo, hi);
-							*(uint32_t *)(tg + k0) = lo;
-							if (k0 + 4 < tln) *(uint32_t *)(tg + k0 + 4) = hi;
-						}
-						for (int c0 = 4 * lane; c0 < C * G; c0 += 256) {
-							uint32_t w = 0;
-#pragma unroll
-							for (int u = 0; u < 4; ++u) { const int j = c0 + u; w |= (uint32_t)(j < ql ? min(ext_q_at(A, sg, j), 4) : 7) << (8 * u); }      // 4 = N, 7 = pad
-							*(uint32_t *)(qw + c0) = w;
-						}
-					}
-					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-					pend = false; pre = true;
-				}
-			}
-			if (!waiting || !pre) break;
-			{   // the staged job goes to the first group that asks; its row becomes the next spare
-				const int gl = (int)__builtin_ctzll(reqs);           // first lane of the group (wave-uniform)
-				const int old = __builtin_amdgcn_readlane(trow, gl);
-				if ((lane & ~(G - 1)) == gl) {
-					const uint32_t id = p_id; const int h0 = (int)p_h0;
-					qlen = (int)(p_qt & 0xFFFFu); tlen = (int)(p_qt >> 16);
-					if (g0) hrow[PP] = id;
-					trow = spare;
-#pragma unroll
-					for (int p = 0; p < P; ++p) sel[p] = 0x0C000C00u | (uint32_t)qw[j0 + p] | ((uint32_t)qw[j0 + P + p] << 16);
-					{
-						const int jq = qlen > 0 ? qlen - 1 : 0, lq = jq / C, r = jq % C;       // lane, chain and pair of column qlen-1
-						goff = 2 * (hgrp + (r >= P ? r - P : r)) + (r >= P ? 1 : 0); owner = l == lq;
-					}
-					S.end = qlen; S.mx = h0; S.max_i = -1; S.max_j = -1; S.max_ie = -1; S.gscore = -1; S.max_off = 0;
-					i = 0; hfc = h0; hnx = max(0, h0 - oe_del);
-					// H(-1, j) = max(0, h0 - o_ins - e_ins*(j+1)) left of qlen (ksw.c:880-883): one saturating packed subtract per pair
-					const int wq = min(max(qlen - j0, 0), C);
-					const uint4 *mrow = (const uint4 *)(em_tab + wq * PS);
-					uint32_t em[PP];
-#pragma unroll
-					for (int k = 0; k < PP / 4; ++k) { const uint4 v = mrow[k]; em[4 * k] = v.x; em[4 * k + 1] = v.y; em[4 * k + 2] = v.z; em[4 * k + 3] = v.w; }
-					uint32_t X = (uint32_t)max(h0 - oe_ins - j0 * A.e_ins, 0) | ((uint32_t)max(h0 - oe_ins - (j0 + P) * A.e_ins, 0) << 16);
-#pragma unroll
-					for (int p = 0; p < P; ++p) {
-						H[p] = X & em[p];
-						NZ[p] = pk_min1(H[p]);
-						E[p] = 0;
-						X = pk_subsK(X, K.ei2);
-					}
-					have = tlen > 0; alive = have;
-					if (tlen == 0 && g0) {                           // no target rows (a window clipped away): the answer is (h0, 0, 0)
-						int32_t *o = A.out + 3 * (size_t)id;
-						o[0] = h0; o[1] = 0; o[2] = 0;
-						if (A.raw) { int32_t *r = A.raw + 6 * (size_t)id; r[0] = h0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = -1; r[5] = 0; }
-						if (A.stats) atomicAdd(A.stats + 2, 1ull);
+						__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+						pend = false; pre = true;
 					}
 				}
-				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // qw has been read before the next job is staged into it
-				spare = old;
-				pre = false;
-				reqs &= reqs - 1;
+				if (!waiting || !pre) break;
+				{   // the staged job goes to the first group that asks; its row becomes the next spare
+					const int gl = (int)__builtin_ctzll(reqs);           // first lane of the group (wave-uniform)
+					const int old = __builtin_amdgcn_readlane(trow, gl);
+					if ((lane & ~(G - 1)) == gl) {
+						const uint4 r0 = rc_wave[2 * p_slot];
+						const uint32_t id = r0.x, p_qt = r0.y; const int h0 = (int)r0.z;
+						qlen = (int)(p_qt & 0xFFFFu); tlen = (int)(p_qt >> 16);
+						if (g0) hrow[PP] = id;
+						trow = spare;
+	#pragma unroll
+						for (int p = 0; p < P; ++p) sel[p] = 0x0C000C00u | (uint32_t)qw[j0 + p] | ((uint32_t)qw[j0 + P + p] << 16);
+						{
+							const int jq = qlen > 0 ? qlen - 1 : 0, lq = jq / C, r = jq % C;       // lane, chain and pair of column qlen-1
+							goff = 2 * (hgrp + (r >= P ? r - P : r)) + (r >= P ? 1 : 0); owner = l == lq;
+						}
+						S.end = qlen; S.mx = h0; S.max_i = -1; S.max_j = -1; S.max_ie = -1; S.gscore = -1; S.max_off = 0;
+						i = 0; hfc = h0; hnx = max(0, h0 - oe_del);
+						// H(-1, j) = max(0, h0 - o_ins - e_ins*(j+1)) left of qlen (ksw.c:880-883): one saturating packed subtract per pair
+						const int wq = min(max(qlen - j0, 0), C);
+						const uint4 *mrow = (const uint4 *)(em_tab + wq * PS);
+						uint32_t em[PP];
+	#pragma unroll
+						for (int k = 0; k < PP / 4; ++k) { const uint4 v = mrow[k]; em[4 * k] = v.x; em[4 * k + 1] = v.y; em[4 * k + 2] = v.z; em[4 * k + 3] = v.w; }
+						uint32_t X = (uint32_t)max(h0 - oe_ins - j0 * A.e_ins, 0) | ((uint32_t)max(h0 - oe_ins - (j0 + P) * A.e_ins, 0) << 16);
+	#pragma unroll
+						for (int p = 0; p < P; ++p) {
+							H[p] = X & em[p];
+							NZ[p] = pk_min1(H[p]);
+							E[p] = 0;
+							X = pk_subsK(X, K.ei2);
+						}
+						have = tlen > 0; alive = have;
+						if (tlen == 0 && g0) {                           // no target rows (a window clipped away): the answer is (h0, 0, 0)
+							int32_t *o = A.out + 3 * (size_t)id;
+							o[0] = h0; o[1] = 0; o[2] = 0;
+							if (A.raw) { int32_t *r = A.raw + 6 * (size_t)id; r[0] = h0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = -1; r[5] = 0; }
+							if (A.stats) atomicAdd(A.stats + 2, 1ull);
+						}
+					}
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // qw has been read before the next job is staged into it
+					spare = old;
+					pre = false;
+					reqs &= reqs - 1;
+				}
 			}
+			if (pend) ++age;
+			if (!__any(alive) && !pre && !pend && qn == qe && !more_g) break;
 		}
-		if (pend) ++age;
-		if (!__any(alive) && !pre && !pend && qn == qe && !more_g) break;
 		// (no `continue` past the row when no group runs: a second path around the row body makes the compiler keep two copies of all
 		// loop-carried pairs; the idle row is harmless and rare)
 		++wave_rows;
 		const int ti = (int)t_wave[trow + i];
 		const bool run = alive;
-		if (A.stats) {          // (BMH_EXT_STATS) wave-rows in which every running alignment has reached the query end: candidates of a row without end masks
+#ifdef PK_STATS            // (a -DPK_STATS build + BMH_EXT_STATS) wave-rows in which every running alignment has reached the query end: candidates of a row without end
+		if (A.stats) {          // masks.  Not in the shipped build: a wave-uniform branch per row costs about ten cycles, whichever way it goes
 			const bool all_at_end = !__any(run && S.end != qlen), any_run = __any(run);
 			if (lane == 0 && any_run) { atomicAdd(A.stats + 4, 1ull); if (all_at_end) atomicAdd(A.stats + 5, 1ull); }
 		}
+#endif
 		alive = pk_row<G, P, SAME_OE>(K, A.zdrop, H, E, NZ, sel, ti, run, hfc, hnx, i, qlen, j0, eCl, g0, em_tab, hrow, owner, (const uint16_t *)h_wave, goff, S, alive, (wave_rows & PK_BOUND_MASK) == 0, tlen - 1 - i, A.raw == nullptr, A.end_bonus);
 		if (run) { ++i; hfc = hnx; hnx = max(0, hnx - A.e_del); }
 		alive = alive && i < tlen;

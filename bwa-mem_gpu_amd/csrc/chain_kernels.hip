@@ -177,6 +177,9 @@ __global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, ui
 // for decides how many of these waves a CU runs side by side (64 entries: 20, 128: 10, 256: 5, 512: 2, 1250: 1), which is why the classes exist.
 #define CH_LDS_BYTES_PER_ENTRY_HYBRID (8 + 8 + sizeof(ch_chain_t) + sizeof(ch_seed_t) + 4)
 #define CH_LDS_CONTIGS 256         // contig tables up to this size are copied into LDS (3 KB)
+#ifndef CH_B_SIDE
+#define CH_B_SIDE 1                // bmh_chain_extend_merge: pass B's emit + extension on the second stream, beside pass A's (knob CHAIN_B_SIDE)
+#endif
 #ifndef CH_LIST_LANES
 #define CH_LIST_LANES 64           // reads per wave of chain_lane_list_kernel (knob CHAIN_LIST_LANES)
 #endif
@@ -428,7 +431,7 @@ extern "C" void bmh_chain_ws_free(bmh_chain_ws_t *w)
 	for (int i = 0; i < 4; ++i) if (w->off2[i]) (void)hipFree(w->off2[i]);
 	if (w->need_sum) (void)hipFree(w->need_sum);
 	if (w->out3) (void)hipFree(w->out3);
-	if (w->side2) (void)hipStreamDestroy(w->side2);
+	if (w->side2) { bmh_extend_release((void *)w->side2); (void)hipStreamDestroy(w->side2); }      // (the extension keeps scratch per stream: pass B may have run on this one)
 	for (hipEvent_t e : w->ev_x) if (e) (void)hipEventDestroy(e);
 	for (hipEvent_t e : w->cls_done) if (e) (void)hipEventDestroy(e);
 	free(w);
@@ -931,18 +934,25 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	const uint64_t n_regs = n_regs_a + n_regs_b, n_jobs = n_jobs_a + n_jobs_b;
 	if (n_regs_b > need_b || n_jobs_b > 2 * need_b) { bmh_set_error("bmh_chain_extend_merge: internal error: pass B outgrew its bound"); return BMH_ENODEV; }
 	if (n_regs > cap_regs_out) { bmh_set_error("bmh_chain_extend_merge: %llu regions > capacity %llu of the output array", (unsigned long long)n_regs, (unsigned long long)cap_regs_out); return BMH_ECAPACITY; }
-	HIPCK(hipStreamWaitEvent(st, w->ev_x[2], 0));
-	HIPCK(hipEventRecord(w->ev_x[3], st));
+	// Pass B's jobs and extension go to the second stream (knob CHAIN_B_SIDE, 0 = behind pass A on the caller's stream as until round 4): its emit kernels, its
+	// prefilter and its job sort -- latency-bound, ~1.5 ms -- then run beside pass A's DP kernels instead of behind them; the merge waits for both.
+	const bool b_side = bmh_tune("CHAIN_B_SIDE", CH_B_SIDE) != 0;
+	hipStream_t sb = b_side ? w->side2 : st;
+	if (!b_side) HIPCK(hipStreamWaitEvent(st, w->ev_x[2], 0));
+	HIPCK(hipEventRecord(w->ev_x[3], sb));
 	if (n_regs_b) {
 		E.regs_per_read = w->regs_per_read; E.need = w->need; E.thresh = A.heavy_thresh; E.pass = 1; E.reg_off = w->off2[2]; E.job_off = w->off2[3]; E.reg_base = (uint32_t)n_regs_a; E.job_base = (uint32_t)n_jobs_a;
-		emit_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(E);
-		emit_wave_kernel<<<1024, 256, 0, st>>>(E, w->heavy_list, w->counters, 0, CH_N_CLASSES - 1);
+		emit_kernel<<<nblk(n_reads, 256), 256, 0, sb>>>(E);
+		emit_wave_kernel<<<1024, 256, 0, sb>>>(E, w->heavy_list, w->counters, 0, CH_N_CLASSES - 1);
 		if (n_jobs_b) {
 			d.jq_src = w->jq_src + n_jobs_a; d.job_side = w->job_side + n_jobs_a; d.jt0 = w->jt0 + n_jobs_a;
-			const int rc = bmh_extend_batch_desc(&d, w->qlen + n_jobs_a, w->tlen + n_jobs_a, w->h0 + n_jobs_a, (uint32_t)n_jobs_b, ep, w->out3 + 3 * n_jobs_a, nullptr, stream_);
+			if (b_side) { const int rc = bmh_extend_reserve((void *)sb, 2 * need_b); if (rc != BMH_OK) return rc; }
+			const int rc = bmh_extend_batch_desc(&d, w->qlen + n_jobs_a, w->tlen + n_jobs_a, w->h0 + n_jobs_a, (uint32_t)n_jobs_b, ep, w->out3 + 3 * n_jobs_a, nullptr, b_side ? (void *)sb : stream_);
 			if (rc != BMH_OK) return rc;
 		}
 	}
+	HIPCK(hipEventRecord(w->ev_x[4], sb));
+	if (b_side) HIPCK(hipStreamWaitEvent(st, w->ev_x[4], 0));
 	HIPCK(hipEventRecord(w->ev_x[4], st));
 	if (n_regs) merge2_kernel<<<nblk(n_regs, 256), 256, 0, st>>>(w->outregs, (uint32_t)n_regs, (uint32_t)n_regs_a, w->off2[0], w->off2[2], w->out3, d_regs_out, w->last_opt);
 	HIPCK(hipEventRecord(w->ev_x[5], st));

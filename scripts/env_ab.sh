@@ -11,6 +11,6 @@ for r in $(seq 1 $rounds); do
     python bench.py $ARGS 2>>${AB_ERR:-/dev/null} | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); i=d['stage_ms_isolated']; s=d['stage_ms']
-print('%-44s value %.2f step %.2f ms verified %s | iso: seed %.2f (bwd %.2f) chain %.2f ext %.2f | piped: seed %.1f chain_light %.1f heavy %.1f ext_a %.1f ext_b %.1f' % ('$c', d['value'], d['ms_per_step'], d.get('verified',{}).get('identical'), i['total'], i['backward'], i['chain'], i['extend'], s['total'], s['chain_light'], s['chain_heavy_beside'], s.get('extend_a',0), s.get('extend_b',0)))" )
+print('%-44s value %.2f step %.2f ms verified %s | iso: seed %.2f (bwd %.2f) chain %.2f ext %.2f | piped: seed %.1f chain_light %.1f heavy %.1f ext_a %.1f ext_b %.1f' % ('$c', d['value'], d['ms_per_step'], d.get('verified_identical'), i['total'], i['backward'], i['chain'], i['extend'], s['total'], s['chain_light'], s['chain_heavy_beside'], s.get('extend_a',0), s.get('extend_b',0)))" )
   done
 done

@@ -15,6 +15,9 @@
 //   * F: per-chain local recurrence, 32-bit max-plus scan over the group's lanes (DPP), exact inflow for both chains of a lane.
 //   * row maximum and its last column from max over (h << 4 | pair) keys; new end = last non-zero H column + 3.
 //   * H(i, qlen-1) for gscore: the lanes park their H pairs in LDS, the group reads the one halfword it needs (VALU-free).
+//   * jobs (round 5): 32-byte records in list order, taken PK_CHUNK at a time into the wave's LDS; in the four-lane classes the NEXT job's
+//     bases are always on their way (two dwords per lane in flight across rows, decoded into a spare LDS row), so that a draw costs no
+//     round trip to memory; one wave-uniform branch per row around all of it (extpk_body).
 // Eligibility (ext_route): 1 <= b, a + b <= 255, h0 + qlen*a < 4096, qlen <= 288, tlen <= PK_TCAP(G); everything else takes the
 // 32-bit kernels.  Results are bit-identical to those (tests/test_gpu_parity.py runs both).
 #pragma once

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: the round's profile (bench lines of the three workloads, kernel stats, PMC passes), then the driver's command once more
+# the round's profile (bench lines of the three workloads, kernel stats, PMC passes), then the driver's command once more
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R
 ( while true; do sleep 60; echo "[$(date +%T)] profiling"; done ) &
 HB=$!

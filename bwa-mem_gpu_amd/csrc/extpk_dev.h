@@ -23,7 +23,12 @@
 #pragma once
 
 // target bases of an alignment staged in LDS, by group width (the 4-lane groups are the many small queries: 64 of them per block)
-#define PK_TCAP(G) ((G) == 4 ? 384 : (G) == 8 ? 512 : 640)
+#ifndef PK_TCAP4
+#define PK_TCAP4 384
+#define PK_TCAP8 512
+#define PK_TCAP16 640
+#endif
+#define PK_TCAP(G) ((G) == 4 ? PK_TCAP4 : (G) == 8 ? PK_TCAP8 : PK_TCAP16)
 #ifndef PK_WAVES4_MAXP
 #define PK_WAVES4_MAXP 8      // classes of up to this many pairs per lane run four waves per SIMD (registers and grid; 120 VGPRs at 10 pairs), the larger ones three (8 -> 10: -0.5 % at 150 bp, -0.7 % at 300 bp)
 #endif

@@ -559,7 +559,7 @@ __device__ __forceinline__ void extpk_body(const ext_args_t &A, uint8_t *t_wave,
 	for (;;) {
 		unsigned long long reqs = __ballot(!alive && g0);        // groups without a running alignment
 		// ONE wave-uniform branch around everything that is not a DP row: in the steady state -- a job staged ahead, every group running -- a row pays the ballot and this
-		// test (the nine- and ten-pair rows of the eight- and sixteen-lane classes are short: five branches a row were 3 % of the 300 bp extension)
+		// test (the nine- and ten-pair rows of the eight- and sixteen-lane classes are short: five tests a row, with their scalar arithmetic, were 3 % of the 300 bp extension)
 		if (reqs || !pre) {
 			if (reqs) {
 				if (!alive && have && g0) {                          // results of the alignment that just ended
@@ -725,7 +725,7 @@ __device__ __forceinline__ void extpk_body(const ext_args_t &A, uint8_t *t_wave,
 		const int ti = (int)t_wave[trow + i];
 		const bool run = alive;
 #ifdef PK_STATS            // (a -DPK_STATS build + BMH_EXT_STATS) wave-rows in which every running alignment has reached the query end: candidates of a row without end
-		if (A.stats) {          // masks.  Not in the shipped build: a wave-uniform branch per row costs about ten cycles, whichever way it goes
+		if (A.stats) {          // masks.  Not in the shipped build: the row loop carries no test that is not a DP row's
 			const bool all_at_end = !__any(run && S.end != qlen), any_run = __any(run);
 			if (lane == 0 && any_run) { atomicAdd(A.stats + 4, 1ull); if (all_at_end) atomicAdd(A.stats + 5, 1ull); }
 		}

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 #include "bmh_internal.h"
 #include "local_sw.h"
@@ -186,6 +187,176 @@ __device__ void msw_pass(const msw_args_t &A, const bool on, const int lanes, co
 	}
 }
 
+// ---- byte mode with the lane's columns in REGISTERS (round 5): the same numbers without walking the striped kernel's loops.
+// What the lazy-F loop leaves in H is the ordinary F recurrence over the query positions in order -- its exit test (no lane's F above
+// H - oe_ins at a segment) only fires once every lane's inflow is dominated by an F chain that has been applied already, given
+// o_ins > 0 -- so H after the loop is: first sweep (F starting at 0 at the lane's first column) + the F that flows in from the lanes
+// to the left, a max-plus scan over the group's sixteen lanes of what each lane's sweep sends out, exactly as in the extension
+// kernels.  The two places where the striping shows stay as they are: E(i+1, j) and the row maximum are taken from the FIRST
+// sweep's H (before the inflow), and the padding columns (score 0) are columns like any other.  The 255 cap of the byte
+// arithmetic never acts before the row whose maximum ends the pass (gmax + shift >= 255), and that row's maximum is at least as
+// large uncapped, so plain integers return the same score (255), row and nothing else.  Checked against local_sw.cpp on 2.4 M
+// random windows (substitutions, gaps, repeats, N, six scorings, both exit flags) before the kernel was written.
+// A lane holds SL columns, the job's slen of them right-aligned (register r = column r - (SL - slen)): the column its right
+// neighbour's diagonal comes from is always register SL - 1.  No LDS but the staged target rows: ~70 / ~90 registers, no waits for
+// lane-private LDS columns (the form above spends its time there), a row of ten columns is ~170 instructions for four jobs.
+__device__ __forceinline__ int msw_scan_max16(int v)          // inclusive max-scan over the 16 lanes of a DPP row
+{
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+	return v;
+}
+template <int SL, class QF, class TF>
+__device__ void msw_pass_reg(const msw_args_t &A, const bool on, const int qlen, const int tlen, QF qcode, TF trow, const int xtra,
+                             uint8_t *tbuf, uint32_t *blist, msw_res_t &R)
+{
+	constexpr int NQ = (SL + 3) / 4;
+	const int lane = threadIdx.x & 63, l = lane & 15;
+	const int slen = on ? (qlen + 15) / 16 : 0;
+	const int r0 = SL - slen;                                  // first register in use
+	const int minsc = (xtra & BMH_SW_XSUBO) ? xtra & 0xffff : 0x10000, endsc = (xtra & BMH_SW_XSTOP) ? xtra & 0xffff : 0x10000;
+	const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins;
+	const int mn = min(min(A.a, -A.b), -1), mx = max(max(A.a, -A.b), -1);
+	const int shift = (256 - (mn & 0xff)) & 0xff;
+	const int eS = A.e_ins * slen;
+	int H[SL], E[SL], Hm[SL];
+	uint32_t qsel[NQ];
+#pragma unroll
+	for (int u = 0; u < NQ; ++u) qsel[u] = 0x05050505u;
+#pragma unroll
+	for (int r = 0; r < SL; ++r) {
+		H[r] = E[r] = Hm[r] = 0;
+		const int k = l * slen + (r - r0);
+		const uint32_t c = (on && r >= r0 && k < qlen) ? (uint32_t)qcode(k) : 5u;       // 5: padding, scores 0 against everything
+		qsel[r >> 2] = (qsel[r >> 2] & ~(0xFFu << (8 * (r & 3)))) | (c << (8 * (r & 3)));
+	}
+	// scores of a row as a byte table: codes 0..3 from tbl_lo (match a, mismatch -b; a target N: -1 everywhere), N (4) -1 and padding (5) 0 from tbl_hi
+	const uint32_t mis4 = (uint32_t)(-A.b & 0xFF) * 0x01010101u, xab = (uint32_t)((A.a ^ -A.b) & 0xFF);
+	int gmax = 0, te = -1;
+	int bl_n = 0, bl_val = 0, bl_i = -2;
+	bool alive = on && tlen > 0;
+	int i = 0, mxv = 0;
+	// every job of the wave fills its lanes' SL columns (the usual case: mates of one length): the row without a test per column
+	const bool full = !__any(on && slen != SL);
+	// one row: first sweep, the inflow from the left, the row's maximum over the first sweep's H (FULL: no column test)
+	auto row = [&](auto full_c) {
+		constexpr bool FULL = decltype(full_c)::value;
+		const int t = tbuf[i & (MSW_TBUF - 1)];
+		const uint32_t tbl_lo = t > 3 ? 0xFFFFFFFFu : mis4 ^ (xab << (8 * t));
+		int hv = msw_shl(H[SL - 1], l);
+		int f = 0;
+		mxv = 0;
+#pragma unroll
+		for (int r = 0; r < SL; ++r) {
+			if (FULL || r >= r0) {
+				const uint32_t sc4 = __builtin_amdgcn_perm(0x000000FFu, tbl_lo, qsel[r >> 2]);
+				const int S = (int)(int8_t)(sc4 >> (8 * (r & 3)));
+				const int h = max(max(hv + S, E[r]), f);            // >= 0: E and F are
+				mxv = max(mxv, h);
+				hv = H[r];
+				H[r] = h;
+				E[r] = max(max(E[r] - A.e_del, h - oe_del), 0);
+				f = max(max(f - A.e_ins, h - oe_ins), 0);
+			}
+		}
+		// what flows in from the left: lane l' sends f out, e_ins per column further on
+		const int Y = msw_scan_max16(f + eS * l);
+		const int fin = l == 0 ? 0 : max(msw_shl(Y, l) - eS * (l - 1), 0);
+		if (__any(fin > 0)) {
+			int fv = fin + A.e_ins * r0;                            // fin - e_ins * (r - r0) at register r
+#pragma unroll
+			for (int r = 0; r < SL; ++r) {
+				if (FULL || r >= r0) H[r] = max(H[r], fv);
+				fv -= A.e_ins;
+			}
+		}
+	};
+	for (; __any(alive); ++i) {
+		if ((i & (MSW_TBUF - 1)) == 0) {
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			for (int u = l; u < MSW_TBUF; u += 16) tbuf[u] = (uint8_t)((alive && i + u < tlen) ? trow(i + u) : 4);
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		}
+		const bool run = alive && i < tlen;
+		if (run) {                                              // (all sixteen lanes of a group agree: the DPP steps below stay inside it)
+			if (full) row(std::true_type()); else row(std::false_type());
+			const int imax = msw_gmax(mxv);
+			if (imax >= minsc && l == 0) {                       // ksw.c:519-527: consecutive rows keep one entry, at the row of their maximum so far
+				if (bl_i + 1 != i) { if (bl_i >= 0) blist[bl_n++] = (uint32_t)bl_val << 16 | (uint32_t)bl_i; bl_val = imax; bl_i = i; }
+				else if (bl_val < imax) { bl_val = imax; bl_i = i; }
+			}
+			if (imax > gmax) {
+				gmax = imax; te = i;
+#pragma unroll
+				for (int r = 0; r < SL; ++r) Hm[r] = H[r];
+				if (gmax + shift >= 255 || gmax >= endsc) alive = false;
+			}
+			if (i + 1 >= tlen) alive = false;
+		}
+	}
+	if (l == 0 && bl_i >= 0) blist[bl_n++] = (uint32_t)bl_val << 16 | (uint32_t)bl_i;
+	bl_n = __shfl(bl_n, lane & 48);
+	R.score = gmax + shift < 255 ? gmax : 255;
+	R.te = te; R.qe = -1; R.score2 = -1; R.te2 = -1;
+	if (on && R.score != 255) {
+		// end of the query: the largest H of the best row, the smallest position among equals (ksw.c:540-547)
+		int key = -1;
+#pragma unroll
+		for (int r = 0; r < SL; ++r) if (r >= r0) key = max(key, Hm[r] << 12 | (0xFFF - (l * slen + r - r0)));
+		key = msw_gmax(key);
+		R.qe = 0xFFF - (key & 0xFFF);
+		if (bl_n > 0) {
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			__builtin_amdgcn_s_waitcnt(0);
+			const int d = (R.score + mx - 1) / mx, low = te - d, high = te + d;
+			int best = -1;
+			for (int u = l; u < bl_n; u += 16) {
+				const uint32_t x = blist[u];
+				const int e = (int)(x & 0xFFFF), v = (int)(x >> 16);
+				if (e < low || e > high) best = max(best, (v << 16) | (0xFFFF - min(u, 0xFFFF)));
+			}
+			best = msw_gmax(best);
+			if (best >= 0) { R.score2 = best >> 16; R.te2 = (int)(blist[0xFFFF - (best & 0xFFFF)] & 0xFFFF); }
+		}
+	}
+}
+
+template <int SL> __global__ void __launch_bounds__(16 * MSW_JOBS_PER_BLOCK) msw_reg_kernel(msw_args_t A)
+{
+	__shared__ uint8_t st[MSW_JOBS_PER_BLOCK][MSW_TBUF];
+	const int g = threadIdx.x >> 4;
+	const uint32_t jid = blockIdx.x * MSW_JOBS_PER_BLOCK + g;
+	const bool on = jid < A.n_jobs;
+	bmh_msw_job_t J;
+	memset(&J, 0, sizeof(J));
+	if (on) J = A.jobs[jid];
+	const uint8_t *rd = A.reads + (on ? A.read_offs[J.read] : 0);
+	const int l_ms = J.l_ms, is_rev = J.is_rev;
+	const long long rb = J.rb;
+	const int tlen = (int)(J.re - J.rb);
+	auto qfwd = [&](int k) { const int c = msw_nt4(rd[is_rev ? l_ms - 1 - k : k]); return is_rev ? (c < 4 ? 3 - c : 4) : c; };
+	auto tfwd = [&](int i) { return msw_text(A, rb + i); };
+	msw_res_t R1;
+	uint32_t *bl = A.blist + (on ? J.bl_off : 0);
+	msw_pass_reg<SL>(A, on, l_ms, tlen, qfwd, tfwd, J.xtra, st[g], bl, R1);
+	int tb = -1, qb = -1;
+	const bool second = on && (J.xtra & BMH_SW_XSTART) && !((J.xtra & BMH_SW_XSUBO) && R1.score < (J.xtra & 0xffff));
+	if (__any(second)) {
+		const int qe = R1.qe, te = R1.te;
+		auto qrev = [&](int k) { return qfwd(qe - k); };
+		auto trev = [&](int i) { return i <= te ? msw_text(A, rb + (te - i)) : msw_text(A, rb + i); };
+		msw_res_t R2;
+		msw_pass_reg<SL>(A, second, qe + 1, tlen, qrev, trev, BMH_SW_XSTOP | R1.score, st[g], bl, R2);
+		if (second && R1.score == R2.score) { tb = R1.te - R2.te; qb = R1.qe - R2.qe; }
+	}
+	if (on && (threadIdx.x & 15) == 0) {
+		int32_t *o = A.out + 7 * (size_t)jid;
+		o[0] = R1.score; o[1] = R1.te; o[2] = R1.qe; o[3] = R1.score2; o[4] = R1.te2; o[5] = tb; o[6] = qb;
+	}
+}
+
 // LDS: four 16-bit arrays and the query codes, each [cap][MSW_JOBS_PER_BLOCK][16]: segment j of the block's eight jobs side by side,
 // so that a wave's four jobs read one row of 64 dwords -- every bank once (with the jobs' columns one after the other all four hit
 // the same banks) -- and `cap`, the longest column of the batch, sizes the block: 12 KB for 150 bp mates instead of 46 KB for the
@@ -305,7 +476,12 @@ extern "C" int bmh_matesw_batch_device(const bmh_index_t *idx, const uint8_t *d_
 	A.jobs = S->d_jobs; A.n_jobs = (uint32_t)n_jobs; A.reads = d_reads; A.read_offs = d_offs; A.pac = idx->dev.pac; A.l_pac = (long long)idx->dev.l_pac;
 	A.a = ep->a; A.b = ep->b; A.o_del = ep->o_del; A.e_del = ep->e_del; A.o_ins = ep->o_ins; A.e_ins = ep->e_ins;
 	A.blist = S->d_bl; A.out = S->d_out;
-	if (byte_all) msw_kernel<true><<<(unsigned)((n_jobs + MSW_JOBS_PER_BLOCK - 1) / MSW_JOBS_PER_BLOCK), 16 * MSW_JOBS_PER_BLOCK, (size_t)cap * MSW_ROW * 9, st>>>(A, cap);
+	// the register form: every job in byte mode, columns of at most 16 segments, gap opens that cost something (its F is the plain recurrence only then)
+	const unsigned nblk = (unsigned)((n_jobs + MSW_JOBS_PER_BLOCK - 1) / MSW_JOBS_PER_BLOCK);
+	const bool reg_form = byte_all && cap <= 16 && ep->o_ins > 0 && ep->e_ins > 0 && ep->a < 100 && ep->b < 100 && bmh_tune("MSW_REG", 1) != 0;
+	if (reg_form && cap <= 10) msw_reg_kernel<10><<<nblk, 16 * MSW_JOBS_PER_BLOCK, 0, st>>>(A);
+	else if (reg_form) msw_reg_kernel<16><<<nblk, 16 * MSW_JOBS_PER_BLOCK, 0, st>>>(A);
+	else if (byte_all) msw_kernel<true><<<(unsigned)((n_jobs + MSW_JOBS_PER_BLOCK - 1) / MSW_JOBS_PER_BLOCK), 16 * MSW_JOBS_PER_BLOCK, (size_t)cap * MSW_ROW * 9, st>>>(A, cap);
 	else msw_kernel<false><<<(unsigned)((n_jobs + MSW_JOBS_PER_BLOCK - 1) / MSW_JOBS_PER_BLOCK), 16 * MSW_JOBS_PER_BLOCK, (size_t)cap * MSW_ROW * 9, st>>>(A, cap);
 	HIPCK(hipMemcpyAsync(out, S->d_out, sizeof(int32_t) * 7 * n_jobs, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));

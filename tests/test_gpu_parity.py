@@ -1654,22 +1654,33 @@ def test_mate_rescue_alignments_on_the_device(hip):
             jobs[i].xtra = XSUBO | XSTART | (XBYTE if rl < 250 else 0) | 19
         r = _to_dev(torch, synth.codes_to_ascii(reads.reshape(-1)))
         o = (torch.arange(n_reads, dtype=torch.int64) * rl).to(torch.int32).cuda()
-        out = np.zeros((n_reads, 7), np.int32)
-        ep = B.ExtParams.default()
         L.bmh_matesw_batch_device.restype = C.c_int
         L.bmh_matesw_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
-        rc = L.bmh_matesw_batch_device(dindex.handle, r.data_ptr(), o.data_ptr(), C.byref(ep), C.byref(jobs), n_reads, out.ctypes.data_as(C.c_void_p), None)
-        assert rc == 0, L.bmh_last_error()
         L.bmh_local_sw_c.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-        n_hit = n_sub = 0
-        for i in range(n_reads):
-            q = reads[i].copy()
-            if jobs[i].is_rev:
-                q = synth.revcomp(q)
-            t = np.ascontiguousarray(text[jobs[i].rb:jobs[i].re]); q = np.ascontiguousarray(q)
-            want = np.zeros(7, np.int32)
-            L.bmh_local_sw_c(rl, q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), C.byref(ep), jobs[i].xtra, want.ctypes.data_as(C.c_void_p))
-            assert np.array_equal(out[i], want), (rl, i, out[i], want, jobs[i].rb, jobs[i].re, jobs[i].is_rev)
-            n_hit += want[0] >= 19 and want[6] >= 0; n_sub += want[3] > 0
-        assert n_hit > 200 and (rl < 100 or n_sub > 3), (rl, n_hit, n_sub)
+        # the reference's scoring, and (mates short enough for byte mode at a = 2) others: gap opens that differ, a free insertion open (the register form of
+        # the kernel steps aside for that one: its F is the plain recurrence only where an open costs something)
+        scorings = [None] + ([(2, 3, 5, 2, 5, 2), (1, 4, 6, 1, 2, 2), (1, 4, 6, 1, 0, 1)] if rl <= 100 else [])
+        for sc in scorings:
+            ep = B.ExtParams.default()
+            if sc:
+                ep.a, ep.b, ep.o_del, ep.e_del, ep.o_ins, ep.e_ins = sc
+            want_all = np.zeros((n_reads, 7), np.int32)
+            n_hit = n_sub = 0
+            for i in range(n_reads):
+                q = reads[i].copy()
+                if jobs[i].is_rev:
+                    q = synth.revcomp(q)
+                t = np.ascontiguousarray(text[jobs[i].rb:jobs[i].re]); q = np.ascontiguousarray(q)
+                L.bmh_local_sw_c(rl, q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), C.byref(ep), jobs[i].xtra, want_all[i].ctypes.data_as(C.c_void_p))
+                n_hit += want_all[i, 0] >= 19 and want_all[i, 6] >= 0; n_sub += want_all[i, 3] > 0
+            assert n_hit > 200 and (rl < 100 or n_sub > 3), (rl, n_hit, n_sub)
+            # both forms of the kernel: the lane's columns in registers (byte mode up to 256 columns, MSW_REG 1: the default) and in LDS
+            for knob in (1, 0):
+                L.bmh_tune_set(b"MSW_REG", knob, 0)
+                out = np.zeros((n_reads, 7), np.int32)
+                rc = L.bmh_matesw_batch_device(dindex.handle, r.data_ptr(), o.data_ptr(), C.byref(ep), C.byref(jobs), n_reads, out.ctypes.data_as(C.c_void_p), None)
+                L.bmh_tune_set(b"MSW_REG", 0, 1)
+                assert rc == 0, L.bmh_last_error()
+                bad = np.nonzero((out != want_all).any(1))[0]
+                assert bad.size == 0, (rl, sc, knob, bad[:5], out[bad[:3]], want_all[bad[:3]])
     dindex.free()

@@ -842,9 +842,9 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
         blob = np.frombuffer(("\0".join(names.tolist()) + "\0").encode(), dtype=np.uint8)
         noff = np.arange(n4, dtype=np.uint64) * np.uint64(w + 2)
         rs = ReadSet(asc, np.arange(n4, dtype=np.uint64) * np.uint64(rl), np.full(n4, rl, np.uint32), blob, noff, codes=flat4)
-        # single-end: four batches of a million reads on two lanes; interleaved pairs (the host walks of mem_sam_pe between the device stages): six batches on three
-        lanes_n = int(os.environ.get("BENCH_SAM_LANES", "3" if paired else "2"))
-        nb4 = int(os.environ.get("BENCH_SAM_BATCHES", "6" if paired else "4"))
+        # single-end: four batches of a million reads on two lanes; interleaved pairs (the host walks of mem_sam_pe between the device stages): eight batches on four
+        lanes_n = int(os.environ.get("BENCH_SAM_LANES", "4" if paired else "2"))
+        nb4 = int(os.environ.get("BENCH_SAM_BATCHES", "8" if paired else "4"))
         cuts4 = [((n4 * k // nb4) & ~1) for k in range(nb4)] + [n4]
         nat = NativeAligner(dindex, pac_h, len(g), contigs, None, co, params, po, pe_o)
         nbytes = [0]

@@ -57,7 +57,10 @@ def throttled():
     except Exception:
         return 0, 0.0, 0.0
 cfgs = [tuple(int(v) for v in c.split("x")) for c in os.environ.get("LANES_CFGS", "2x4,3x4,3x8,4x8,2x8,2x4").split(",")]
-for lanes, nb in cfgs:
+cfgs = [(l_, b_, int(s_)) for s_ in os.environ.get("LANES_SLOTS", "-1").split(",") for l_, b_ in cfgs]      # LANES_SLOTS: values of the knob ALIGNER_GPU_SLOTS (-1: leave it alone)
+for lanes, nb, slots in cfgs:
+    if slots >= 0:
+        L.bmh_tune_set(b"ALIGNER_GPU_SLOTS", slots, 0); print("ALIGNER_GPU_SLOTS = %d" % slots)
     q = (n_reads // nb) & ~1
     cuts = [k * q for k in range(nb)] + [n_reads]
     n_it = int(os.environ.get("LANES_ITERS", "3"))
@@ -83,7 +86,7 @@ if os.environ.get("LANES_FILE"):
     recs[:, 0] = ord(">"); recs[:, 1:w + 2] = np.frombuffer("".join(names.tolist()).encode(), np.uint8).reshape(n_reads, w + 1); recs[:, w + 2] = 10
     recs[:, w + 3:w + 3 + rl] = asc.reshape(n_reads, rl); recs[:, -1] = 10
     recs.tofile(fa); del recs
-    for lanes, nb in cfgs:
+    for lanes, nb, _ in cfgs:
         for it in range(3):
             nbytes[0] = 0
             t0 = time.perf_counter()

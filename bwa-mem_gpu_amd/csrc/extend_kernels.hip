@@ -654,7 +654,7 @@ __global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t
 #define EXT_DONE_CLS 27     // decided by the closed-form prefilter: no DP
 #define EXT16_MAX_C 18
 // 28..34 = extpk_kernel<4, P>, P = 4, 6, .. 16 (queries up to 8 P columns); 35..39 = extpk_kernel<8, P>, P = 9, 10, 12, 14, 16
-// (up to 16 P); 40 = extpk_kernel<16, 9> (up to 288)
+// (up to 16 P); 40 = extpk_kernel<8, 18> (up to 288; extpk_kernel<16, 9> in builds with PK_WIDE18 0 and in the persistent kernel)
 #define EXT_PK_BASE 28
 #define EXT_PK_MAXQ 288
 
@@ -694,7 +694,7 @@ __device__ __forceinline__ int ext_route(uint32_t ql, uint32_t tl, uint32_t h0, 
 	if (cls >= 1 && cls <= EXT16_MAX_C && tl > EXT_T_CAP) cls = 19;     // very long target: wide kernel (streams it)
 	if (pk_a > 0 && h0 + ql * (uint32_t)pk_a < PK_HMAX) {
 		const int pc = ext_pk_class(ql);
-		if (pc && tl <= (uint32_t)(ql <= 128 ? PK_TCAP(4) : ql <= 256 ? PK_TCAP(8) : PK_TCAP(16))) cls = pc;
+		if (pc && tl <= (uint32_t)(ql <= 128 ? PK_TCAP(4) : ql <= 256 ? PK_TCAP(8) : PK_TCAP(16)) && (!PK_WIDE18 || ql <= 256 || h0 + ql * (uint32_t)pk_a < PK_HMAX17)) cls = pc;
 		if (pc && ql > 128 && ql <= 136 && tl <= (uint32_t)PK_TCAP(4) && h0 + ql * (uint32_t)pk_a < PK_HMAX17) cls = EXT_PK17_CLS;
 	}
 	return cls;
@@ -1227,7 +1227,12 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		if (mq > 160) launch_pk<8, 12>(a, S[0], PK_WAVES4(8, 12) ? g8 : g8w);
 		if (mq > 192) launch_pk<8, 14>(a, S[1], PK_WAVES4(8, 14) ? g8 : g8w);
 		if (mq > 224) launch_pk<8, 16>(a, S[2], PK_WAVES4(8, 16) ? g8 : g8w);
+#if PK_WIDE18
+		(void)g16w;
+		if (mq > 256) launch_pk<8, 18>(a, S[3], g8w);
+#else
 		if (mq > 256) launch_pk<16, 9>(a, S[3], PK_WAVES4(16, 9) ? g16 : g16w);
+#endif
 	}
 	// (narrow classes first measured better than widest first: 10.8 vs 11.1 ms)
 	// class C of extend16 holds the queries of 16 (C - 1) + 1 .. 16 C columns; wide class C those of 64 (C - 1) + 1 .. 64 C, and class 5

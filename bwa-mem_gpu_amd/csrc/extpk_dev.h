@@ -29,6 +29,11 @@
 #define PK_TCAP16 640
 #endif
 #define PK_TCAP(G) ((G) == 4 ? PK_TCAP4 : (G) == 8 ? PK_TCAP8 : PK_TCAP16)
+#ifndef PK_WIDE18
+#define PK_WIDE18 1           // the queries of 257 .. 288 columns on EIGHT lanes of 18 pairs (eight alignments per wave, 161 registers) instead of sixteen lanes of 9 (four):
+                              // 46 instead of 54 wave-instructions per alignment row; 300 bp reads: extension 65.2 -> 62.2 ms, step 90.9 -> 87.7 ms (three interleaved pairs)
+#endif
+#define PK_TCAPGP(G, P) ((G) == 8 && (P) == 18 ? PK_TCAP16 : PK_TCAP(G))      // (the 18-pair class takes the sixteen-lane class's jobs: their target rows)
 #ifndef PK_WAVES4_MAXP
 #define PK_WAVES4_MAXP 8      // classes of up to this many pairs per lane run four waves per SIMD (registers and grid; 120 VGPRs at 10 pairs), the larger ones three (8 -> 10: -0.5 % at 150 bp, -0.7 % at 300 bp)
 #endif
@@ -488,7 +493,7 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t<P> &K, const int zdrop,
 // two banks and every row's read was an 8-way conflict), the query codes of the job the wave is staging, the H parking rows, the
 // records of its chunk of jobs; the end-mask table is per block in the per-class kernels and per wave in the persistent one
 template <int G, int P> struct pk_lds_t {
-	static constexpr int C = 2 * P, PP = (P + 3) & ~3, PS = PP + 4, NGW = 64 / G, TCAP = PK_TCAP(G);
+	static constexpr int C = 2 * P, PP = (P + 3) & ~3, PS = PP + 4, NGW = 64 / G, TCAP = PK_TCAPGP(G, P);
 	static constexpr int T_BYTES = ((NGW + 1) * (TCAP + 4) + 15) & ~15, Q_BYTES = (C * G + 15) & ~15, EM_DWORDS = (C + 1) * PS, H_DWORDS = NGW * PS, RC_BYTES = PK_CHUNK * 32;
 	static constexpr int WAVE_BYTES = T_BYTES + Q_BYTES + 4 * EM_DWORDS + 4 * H_DWORDS + RC_BYTES;      // (all parts are multiples of 16 bytes)
 };
@@ -520,7 +525,7 @@ template <int P> __device__ __forceinline__ void pk_em_init(uint32_t *em_tab, co
 template <int G, int P, bool SAME_OE>
 __device__ __forceinline__ void extpk_body(const ext_args_t &A, uint8_t *t_wave, uint8_t *qw, const uint32_t *em_tab, uint32_t *h_wave, uint4 *rc_wave)
 {
-	constexpr int C = 2 * P, PP = (P + 3) & ~3, PS = PP + 4, TCAP = PK_TCAP(G), TROW = TCAP + 4, NGW = 64 / G;
+	constexpr int C = 2 * P, PP = (P + 3) & ~3, PS = PP + 4, TCAP = PK_TCAPGP(G, P), TROW = TCAP + 4, NGW = 64 / G;
 	constexpr int NT = (TCAP + 511) / 512, NQ = (C * G + 255) / 256;      // dwords a lane fetches ahead: eight target rows / four query columns each
 	const int lane = threadIdx.x & 63, l = lane & (G - 1);
 	const bool g0 = l == 0;

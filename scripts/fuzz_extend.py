@@ -21,7 +21,7 @@ O = oracle_py.Oracle()
 def make_jobs(n, max_q):
     q_parts, t_parts, qlen, tlen, h0 = [], [], [], [], []
     for _ in range(n):
-        ql = int(rng.integers(1, max_q + 1))
+        ql = int(rng.integers(min(MIN_Q, max_q), max_q + 1))
         q = rng.integers(0, 4, size=ql).astype(np.uint8)
         kind = rng.random()
         # the related part of the target: the query's prefix of length k, mutated
@@ -49,11 +49,13 @@ def make_jobs(n, max_q):
     return np.concatenate(q_parts), qoff, qlen, (np.concatenate(t_parts) if int(tlen.sum()) else np.zeros(1, np.uint8)), toff, tlen, np.array(h0, np.uint32)
 
 
+MIN_Q = int(os.environ.get("FUZZ_MINQ", "1"))
 SCHEMES = [(1, 4, 6, 1, 6, 1), (2, 5, 4, 2, 7, 1), (1, 1, 1, 1, 1, 1), (3, 9, 11, 3, 5, 2), (1, 4, 6, 1, 6, 1), (1, 2, 3, 1, 2, 2), (4, 4, 10, 1, 10, 1), (1, 4, 0, 1, 0, 1)]
 total = 0
 t_start = time.time()
 for r in range(rounds):
     max_q = [128, 128, 280, 60, 136, 700, 128, 256][r % 8]
+    if os.environ.get("FUZZ_MAXQ"): max_q = int(os.environ["FUZZ_MAXQ"])      # (FUZZ_MINQ / FUZZ_MAXQ: every round on one range of query lengths -- one class of kernels)
     jobs = make_jobs(n_jobs if max_q <= 300 else n_jobs // 8, max_q)
     a, b, od, ed, oi, ei = SCHEMES[r % len(SCHEMES)]
     zdrop = [0, 100, 0, 7, 0, 100, 0, 30][r % 8]

@@ -653,15 +653,15 @@ __global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t
 #define EXT_N_CLS 42
 #define EXT_DONE_CLS 27     // decided by the closed-form prefilter: no DP
 #define EXT16_MAX_C 18
-// 28..34 = extpk_kernel<4, P>, P = 4, 6, .. 16 (queries up to 8 P columns); 35..39 = extpk_kernel<8, P>, P = 9, 10, 12, 14, 16
-// (up to 16 P); 40 = extpk_kernel<8, 18> (up to 288; extpk_kernel<16, 9> in builds with PK_WIDE18 0 and in the persistent kernel)
+// 28..34 = extpk_kernel<4, P>, P = 4, 6, .. 16 (queries up to 8 P columns); 35..36 = extpk_kernel<8, P>, P = 9, 10 (up to 16 P); 37..39 = extpk_kernel<4, P>, P = 24, 28, 32
+// (up to 8 P; extpk_kernel<8, P>, P = 12, 14, 16 in builds with PK_WIDE4 0 and in the persistent kernel); 40 = extpk_kernel<8, 18> (up to 288; extpk_kernel<16, 9> in builds with PK_WIDE18 0 and in the persistent kernel)
 #define EXT_PK_BASE 28
 #define EXT_PK_MAXQ 288
 
 // (G = 4, P = 17: queries of 129..136 columns -- the flank of a 150 bp read whose seed sits at its very end -- on four lanes
 // instead of eight: 26 instead of 34 wave-instructions per alignment row, for 15 % of the extension's time on 150 bp reads)
 #define EXT_PK17_CLS (EXT_PK_BASE + 13)
-constexpr int ext_pk_cls_of(int G, int P) { return G == 4 && P == 17 ? EXT_PK17_CLS : EXT_PK_BASE + (G == 4 ? P / 2 - 2 : G == 16 ? 12 : P == 9 ? 7 : P == 10 ? 8 : P / 2 + 3); }
+constexpr int ext_pk_cls_of(int G, int P) { return G == 4 && P == 17 ? EXT_PK17_CLS : G == 4 && P > 18 ? EXT_PK_BASE + P / 4 + 3 : EXT_PK_BASE + (G == 4 ? P / 2 - 2 : G == 16 ? 12 : P == 9 ? 7 : P == 10 ? 8 : P / 2 + 3); }      // (G = 4, P = 24 / 28 / 32: the places of G = 8, P = 12 / 14 / 16)
 
 #include "extpk_dev.h"
 
@@ -694,7 +694,7 @@ __device__ __forceinline__ int ext_route(uint32_t ql, uint32_t tl, uint32_t h0, 
 	if (cls >= 1 && cls <= EXT16_MAX_C && tl > EXT_T_CAP) cls = 19;     // very long target: wide kernel (streams it)
 	if (pk_a > 0 && h0 + ql * (uint32_t)pk_a < PK_HMAX) {
 		const int pc = ext_pk_class(ql);
-		if (pc && tl <= (uint32_t)(ql <= 128 ? PK_TCAP(4) : ql <= 256 ? PK_TCAP(8) : PK_TCAP(16)) && (!PK_WIDE18 || ql <= 256 || h0 + ql * (uint32_t)pk_a < PK_HMAX17)) cls = pc;
+		if (pc && tl <= (uint32_t)(ql <= 128 ? PK_TCAP(4) : ql <= 256 ? PK_TCAP(8) : PK_TCAP(16)) && (!PK_WIDE18 || ql <= 256 || h0 + ql * (uint32_t)pk_a < PK_HMAX17) && (!PK_WIDE4 || ql <= 160 || ql > 256 || h0 + ql * (uint32_t)pk_a < PK_HMAX17)) cls = pc;
 		if (pc && ql > 128 && ql <= 136 && tl <= (uint32_t)PK_TCAP(4) && h0 + ql * (uint32_t)pk_a < PK_HMAX17) cls = EXT_PK17_CLS;
 	}
 	return cls;
@@ -1224,9 +1224,16 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		launch_pk<4, 4>(a, S[1], g4);
 		if (mq > 128) launch_pk<8, 9>(a, S[2], PK_WAVES4(8, 9) ? g8 : g8w);
 		if (mq > 144) launch_pk<8, 10>(a, S[3], PK_WAVES4(8, 10) ? g8 : g8w);
+#if PK_WIDE4
+		const unsigned g4h = g4 > max_grid / 2 ? max_grid / 2 : g4;       // (two waves per SIMD)
+		if (mq > 160) launch_pk<4, 24>(a, S[0], g4h);
+		if (mq > 192) launch_pk<4, 28>(a, S[1], g4h);
+		if (mq > 224) launch_pk<4, 32>(a, S[2], g4h);
+#else
 		if (mq > 160) launch_pk<8, 12>(a, S[0], PK_WAVES4(8, 12) ? g8 : g8w);
 		if (mq > 192) launch_pk<8, 14>(a, S[1], PK_WAVES4(8, 14) ? g8 : g8w);
 		if (mq > 224) launch_pk<8, 16>(a, S[2], PK_WAVES4(8, 16) ? g8 : g8w);
+#endif
 #if PK_WIDE18
 		(void)g16w;
 		if (mq > 256) launch_pk<8, 18>(a, S[3], g8w);

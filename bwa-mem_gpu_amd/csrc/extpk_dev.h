@@ -6,8 +6,8 @@
 //     The reference clamps M-oe, E and F at zero, which is what an unsigned saturating subtract does for free.
 //     Lane l of a group owns the 2P columns [l*2P, l*2P+2P): low halves = its first P columns, high halves = the next P, so the
 //     diagonal neighbour of pair p is simply pair p-1 of the previous row (pair 0: one DPP shift + v_alignbit).
-//   * G = 4 lanes per alignment up to 128 query columns (8 up to 256, 16 up to 288): SIXTEEN alignments per wave share the per-row
-//     control code (scan, reductions, end / maximum bookkeeping), which is what a row costs besides its cells.
+//   * G = 4 lanes per alignment up to 136 query columns and, with 24 / 28 / 32 pairs a lane, from 161 to 256 (8 lanes for 137 .. 160 and, 18 pairs a lane, 257 .. 288): SIXTEEN
+//     alignments per wave share the per-row control code (scan, reductions, end / maximum bookkeeping), which is what a row costs besides its cells.
 //   * substitution scores by ONE v_perm_b32 per pair from an 8-byte row table {score(t, code) + b}: M = (hd != 0) * scb + hd -sat b.
 //   * no `beg` bookkeeping: the first-column value max(0, h0 - o_del - e_del*(i+1)) applies in every row -- beg > 0 implies it has
 //     reached zero for good, and cells left of beg have zero inputs (scripts/extpk_model.py checks this algebra against the oracle).
@@ -33,7 +33,12 @@
 #define PK_WIDE18 1           // the queries of 257 .. 288 columns on EIGHT lanes of 18 pairs (eight alignments per wave, 161 registers) instead of sixteen lanes of 9 (four):
                               // 46 instead of 54 wave-instructions per alignment row; 300 bp reads: extension 65.2 -> 62.2 ms, step 90.9 -> 87.7 ms (three interleaved pairs)
 #endif
-#define PK_TCAPGP(G, P) ((G) == 8 && (P) == 18 ? PK_TCAP16 : PK_TCAP(G))      // (the 18-pair class takes the sixteen-lane class's jobs: their target rows)
+#ifndef PK_WIDE4
+#define PK_WIDE4 1            // the queries of 161 .. 256 columns on FOUR lanes of 24 / 28 / 32 pairs (sixteen alignments per wave; 216 / 237 / 256 registers: two waves per SIMD, which still
+                              // issue at the SIMD's rate) instead of eight lanes of 12 / 14 / 16: 300 bp reads: extension 62.4 -> 60.9 ms, step 88.2 -> 87.0 ms (three interleaved pairs)
+#endif
+#define PK_TCAPGP(G, P) ((G) == 8 && (P) == 18 ? PK_TCAP16 : (G) == 4 && (P) > 18 ? PK_TCAP8 : PK_TCAP(G))      // (the many-pair classes take the wider groups' jobs: their target rows)
+#define PK_WAVES2(G, P) ((P) > 18)
 #ifndef PK_WAVES4_MAXP
 #define PK_WAVES4_MAXP 8      // classes of up to this many pairs per lane run four waves per SIMD (registers and grid; 120 VGPRs at 10 pairs), the larger ones three (8 -> 10: -0.5 % at 150 bp, -0.7 % at 300 bp)
 #endif
@@ -744,7 +749,7 @@ __device__ __forceinline__ void extpk_body(const ext_args_t &A, uint8_t *t_wave,
 
 // One kernel per class (the form the side streams of extend_launch run when the persistent kernel is off): the end masks are the block's.
 template <int G, int P, bool SAME_OE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK_WAVES4(G, P) ? 4 : 3))) extpk_kernel(ext_args_t A)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK_WAVES2(G, P) ? 2 : PK_WAVES4(G, P) ? 4 : 3))) extpk_kernel(ext_args_t A)
 {
 	wtrace_scope_t wt_(WT_EXT_PK, (uint32_t)(G << 8 | P));
 	using L = pk_lds_t<G, P>;

@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t
 // classes: 0 = unsupported length (query longer than 768 bases: all three outputs INT32_MIN, counted, see
 // bmh_extend_last_unsupported); 1..18 = extend16_kernel<C>; 19..26 = extend_wide_kernel<5..12>
 #define EXT_WIDE_MAX_C 12
-#define EXT_N_CLS 42
+#define EXT_N_CLS 49
 #define EXT_DONE_CLS 27     // decided by the closed-form prefilter: no DP
 #define EXT16_MAX_C 18
 // 28..34 = extpk_kernel<4, P>, P = 4, 6, .. 16 (queries up to 8 P columns); 35..36 = extpk_kernel<8, P>, P = 9, 10 (up to 16 P); 37..39 = extpk_kernel<4, P>, P = 24, 28, 32
@@ -661,7 +661,9 @@ __global__ void __launch_bounds__(256, EXT_MIN_WAVES) extend16_kernel(ext_args_t
 // (G = 4, P = 17: queries of 129..136 columns -- the flank of a 150 bp read whose seed sits at its very end -- on four lanes
 // instead of eight: 26 instead of 34 wave-instructions per alignment row, for 15 % of the extension's time on 150 bp reads)
 #define EXT_PK17_CLS (EXT_PK_BASE + 13)
-constexpr int ext_pk_cls_of(int G, int P) { return G == 4 && P == 17 ? EXT_PK17_CLS : G == 4 && P > 18 ? EXT_PK_BASE + P / 4 + 3 : EXT_PK_BASE + (G == 4 ? P / 2 - 2 : G == 16 ? 12 : P == 9 ? 7 : P == 10 ? 8 : P / 2 + 3); }      // (G = 4, P = 24 / 28 / 32: the places of G = 8, P = 12 / 14 / 16)
+// 42..48 = extpk_kernel<2, P>, P = 8, 12, .. 32 (queries up to 4 P columns, targets up to 8 P rows)
+#define EXT_PK2_BASE 42
+constexpr int ext_pk_cls_of(int G, int P) { return G == 2 ? EXT_PK2_BASE + P / 4 - 2 : G == 4 && P == 17 ? EXT_PK17_CLS : G == 4 && P > 18 ? EXT_PK_BASE + P / 4 + 3 : EXT_PK_BASE + (G == 4 ? P / 2 - 2 : G == 16 ? 12 : P == 9 ? 7 : P == 10 ? 8 : P / 2 + 3); }      // (G = 4, P = 24 / 28 / 32: the places of G = 8, P = 12 / 14 / 16)
 
 #include "extpk_dev.h"
 
@@ -688,7 +690,7 @@ __device__ __forceinline__ int ext_class(uint32_t ql)
 #define EXT_TL_BINS 16
 #define EXT_N_BINS (EXT_N_CLS * EXT_TL_BINS)
 // class of a job the prefilter has not decided (pk_a > 0: packed 16-bit kernels allowed, match score)
-__device__ __forceinline__ int ext_route(uint32_t ql, uint32_t tl, uint32_t h0, int pk_a)
+__device__ __forceinline__ int ext_route(uint32_t ql, uint32_t tl, uint32_t h0, int pk_a, const uint32_t g2)
 {
 	int cls = ext_class(ql);
 	if (cls >= 1 && cls <= EXT16_MAX_C && tl > EXT_T_CAP) cls = 19;     // very long target: wide kernel (streams it)
@@ -696,6 +698,12 @@ __device__ __forceinline__ int ext_route(uint32_t ql, uint32_t tl, uint32_t h0, 
 		const int pc = ext_pk_class(ql);
 		if (pc && tl <= (uint32_t)(ql <= 128 ? PK_TCAP(4) : ql <= 256 ? PK_TCAP(8) : PK_TCAP(16)) && (!PK_WIDE18 || ql <= 256 || h0 + ql * (uint32_t)pk_a < PK_HMAX17) && (!PK_WIDE4 || ql <= 160 || ql > 256 || h0 + ql * (uint32_t)pk_a < PK_HMAX17)) cls = pc;
 		if (pc && ql > 128 && ql <= 136 && tl <= (uint32_t)PK_TCAP(4) && h0 + ql * (uint32_t)pk_a < PK_HMAX17) cls = EXT_PK17_CLS;
+#if PK_G2
+		if (g2 && ql <= 128 && ql > 16u * (g2 - 1u)) {                                            // two lanes of 4 h pairs where the target fits the class's rows
+			const uint32_t h = ql <= 32 ? 2u : (ql + 15u) / 16u;
+			if (tl <= 32u * h && (h <= 4u || h0 + ql * (uint32_t)pk_a < PK_HMAX17)) cls = EXT_PK2_BASE + (int)h - 2;
+		}
+#endif
 	}
 	return cls;
 }
@@ -798,7 +806,7 @@ __device__ __forceinline__ void pk_q8(const ext_args_t &A, const job_src_t &s, c
 	}
 	lo = w[0]; hi = w[1];
 }
-__global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint32_t n, uint32_t *__restrict__ bin_of, uint32_t *__restrict__ bin_cnt, int pk_a)
+__global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint32_t n, uint32_t *__restrict__ bin_of, uint32_t *__restrict__ bin_cnt, int pk_a, int g2)
 {
 	wtrace_scope_t wt_(WT_EXT_CLOSED);
 	__shared__ uint32_t hist[EXT_N_BINS];
@@ -886,7 +894,7 @@ __global__ void __launch_bounds__(256) ext_closed_form_kernel(ext_args_t A, uint
 		if (A.zdrop > 0 && two) ok = ok && (max(V1, V2) - V2 + A.b <= A.zdrop);
 		if (have && l8 == 0) {
 			{   // the job's bin: decided here (no DP), or its DP class by query / target length and score range
-				const int cls = ok ? EXT_DONE_CLS : ext_route((uint32_t)qlen, (uint32_t)tlen, (uint32_t)h0, pk_a);
+				const int cls = ok ? EXT_DONE_CLS : ext_route((uint32_t)qlen, (uint32_t)tlen, (uint32_t)h0, pk_a, (uint32_t)g2);
 				if (cls == 0) A.out[3 * (size_t)id] = A.out[3 * (size_t)id + 1] = A.out[3 * (size_t)id + 2] = INT32_MIN;
 				const uint32_t tb = (uint32_t)tlen >> 5;
 				const uint32_t bin = (uint32_t)cls * EXT_TL_BINS + (tb < EXT_TL_BINS - 1 ? tb : EXT_TL_BINS - 1);
@@ -1172,10 +1180,11 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	HIPCK(hipMemsetAsync(g_scr.bins, 0, 4 * 3 * EXT_N_BINS, st));
 	// packed 16-bit rows need 1 <= b, a + b <= 255 (byte score table), a >= 0 and gap penalties that fit the 16-bit lanes
 	const bool pk_ok = g_ext_packed && p->a > 0 && p->b >= 1 && p->a + p->b <= 255 && p->o_del + p->e_del < 4096 && p->o_ins + p->e_ins < 4096 && p->e_ins * 32 < 4096;
+	const int persist = pk_ok ? bmh_tune("EXT_PERSIST", PK_PERSIST_DEFAULT) : 0;
 	{
 		unsigned gp = (unsigned)((n + 31) / 32);
 		if (gp > 4096) gp = 4096;
-		ext_closed_form_kernel<<<gp, 256, 0, st>>>(a, n, g_scr.keys, g_scr.bins, pk_ok ? p->a : 0);
+		ext_closed_form_kernel<<<gp, 256, 0, st>>>(a, n, g_scr.keys, g_scr.bins, pk_ok ? p->a : 0, persist == 0 ? bmh_tune("EXT_G2", 1) : 0);      // (EXT_G2 = k: the two-lane classes for queries beyond 16 (k - 1) columns, 0: none; the persistent kernel knows them not)
 	}
 	if (want_phases) { HIPCK(hipEventRecord(ph[1], st)); HIPCK(hipEventRecord(ph[2], st)); }
 	ext_offsets_kernel<<<1, 64, 0, st>>>(g_scr.counts, g_scr.bins, g_scr.bins + EXT_N_BINS);
@@ -1198,7 +1207,6 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 	// the packed classes hold the bulk of the jobs when they are enabled: they go first, widest (longest running) first
 	// Persistent form (EXT_PERSIST = blocks per CU, 0 = one kernel per class): one launch works all packed classes off and keeps a fixed
 	// share of every SIMD for the whole pass (extpk_dev.h: extpk_persist_kernel)
-	const int persist = pk_ok ? bmh_tune("EXT_PERSIST", PK_PERSIST_DEFAULT) : 0;
 	if (persist > 0) {
 		static thread_local int n_cu = 0;
 		if (!n_cu) { hipDeviceProp_t prop; HIPCK(hipGetDeviceProperties(&prop, dev)); n_cu = prop.multiProcessorCount; }
@@ -1214,6 +1222,20 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		if (g4 > max_grid) g4 = max_grid;
 		if (g8 > max_grid) g8 = max_grid;
 		const unsigned g4w = g4 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g4, g8w = g8 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g8, g16w = g16 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g16;
+#if PK_G2
+		{
+			unsigned g2 = (unsigned)((n + 127) / 128);
+			if (g2 > max_grid) g2 = max_grid;
+			const unsigned g2w = g2 > max_grid * 3 / 4 ? max_grid * 3 / 4 : g2, g2h = g2 > max_grid / 2 ? max_grid / 2 : g2;
+			if (mq > 112) launch_pk<2, 32>(a, S[0], g2h);
+			if (mq > 96) launch_pk<2, 28>(a, S[1], g2h);
+			if (mq > 80) launch_pk<2, 24>(a, S[2], g2h);
+			if (mq > 64) launch_pk<2, 20>(a, S[3], g2h);
+			if (mq > 48) launch_pk<2, 16>(a, S[0], g2w);
+			if (mq > 32) launch_pk<2, 12>(a, S[1], g2w);
+			launch_pk<2, 8>(a, S[2], g2);
+		}
+#endif
 		if (mq > 128) launch_pk<4, 17>(a, S[2], PK_WAVES4(4, 17) ? g4 : g4w);
 		if (mq > 112) launch_pk<4, 16>(a, S[3], PK_WAVES4(4, 16) ? g4 : g4w);
 		if (mq > 96) launch_pk<4, 14>(a, S[0], PK_WAVES4(4, 14) ? g4 : g4w);
@@ -1270,6 +1292,13 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		HIPCK(hipStreamSynchronize(st));
 		HIPCK(hipMemcpy(h, d_stats, 64, hipMemcpyDeviceToHost));
 		fprintf(stderr, "[ext] packed kernels: wave-rows with a running alignment %llu, of them with every running alignment at end == qlen %llu (%.1f%%)\n", h[4], h[5], 100.0 * h[5] / (h[4] ? h[4] : 1));
+		{
+			uint32_t hc[2 * EXT_N_CLS];
+			HIPCK(hipMemcpy(hc, g_scr.counts, sizeof(hc), hipMemcpyDeviceToHost));
+			fprintf(stderr, "[ext] jobs per class:");
+			for (int c = 0; c < EXT_N_CLS; ++c) if (hc[2 * c]) fprintf(stderr, " %d:%u", c, hc[2 * c]);
+			fprintf(stderr, "\n");
+		}
 		fprintf(stderr, "[ext] alignments %llu, rows executed %llu of %llu target rows (%.1f%%), wave-rows %llu (%.2f alignments per wave-row)\n", h[2], h[0], h[1], 100.0 * h[0] / (h[1] ? h[1] : 1), h[3], (double)h[0] / (h[3] ? h[3] : 1));
 	}
 	return BMH_OK;

@@ -28,7 +28,7 @@
 #define PK_TCAP8 512
 #define PK_TCAP16 640
 #endif
-#define PK_TCAP(G) ((G) == 4 ? PK_TCAP4 : (G) == 8 ? PK_TCAP8 : PK_TCAP16)
+#define PK_TCAP(G) ((G) <= 4 ? PK_TCAP4 : (G) == 8 ? PK_TCAP8 : PK_TCAP16)
 #ifndef PK_WIDE18
 #define PK_WIDE18 1           // the queries of 257 .. 288 columns on EIGHT lanes of 18 pairs (eight alignments per wave, 161 registers) instead of sixteen lanes of 9 (four):
                               // 46 instead of 54 wave-instructions per alignment row; 300 bp reads: extension 65.2 -> 62.2 ms, step 90.9 -> 87.7 ms (three interleaved pairs)
@@ -37,7 +37,12 @@
 #define PK_WIDE4 1            // the queries of 161 .. 256 columns on FOUR lanes of 24 / 28 / 32 pairs (sixteen alignments per wave; 216 / 237 / 256 registers: two waves per SIMD, which still
                               // issue at the SIMD's rate) instead of eight lanes of 12 / 14 / 16: 300 bp reads: extension 62.4 -> 60.9 ms, step 88.2 -> 87.0 ms (three interleaved pairs)
 #endif
-#define PK_TCAPGP(G, P) ((G) == 8 && (P) == 18 ? PK_TCAP16 : (G) == 4 && (P) > 18 ? PK_TCAP8 : PK_TCAP(G))      // (the many-pair classes take the wider groups' jobs: their target rows)
+#ifndef PK_G2
+#define PK_G2 0               // the queries of up to 128 columns on TWO lanes of 8 .. 32 pairs (thirty-two alignments per wave) where their targets are short enough (see PK_TCAPGP)
+#endif
+// (the many-pair classes take the wider groups' jobs: their target rows.  The two-lane classes hold thirty-two target rows a wave: rows of 8 P = twice the class's longest
+// query -- what mem_chain2aln's windows come to under the default scoring --, so that two blocks of the widest and four of the others share a CU's LDS; longer targets stay with four lanes)
+#define PK_TCAPGP(G, P) ((G) == 2 ? 8 * (P) : (G) == 8 && (P) == 18 ? PK_TCAP16 : (G) == 4 && (P) > 18 ? PK_TCAP8 : PK_TCAP(G))
 #define PK_WAVES2(G, P) ((P) > 18)
 #ifndef PK_WAVES4_MAXP
 #define PK_WAVES4_MAXP 8      // classes of up to this many pairs per lane run four waves per SIMD (registers and grid; 120 VGPRs at 10 pairs), the larger ones three (8 -> 10: -0.5 % at 150 bp, -0.7 % at 300 bp)
@@ -210,7 +215,7 @@ __device__ __forceinline__ void pk_pair2(uint32_t &H, uint32_t &E, uint32_t &NZ,
 		    : [M] "v"(M), [em] "v"(em), [ei] "s"(ei2), [ed] "s"(ed2), [oei] "s"(oei2), [oed] "s"(oed2), [slot] "n"(SLOT), [kmul] "n"(KMUL));
 }
 
-// ---- group primitives: G = 16 is one DPP row, G = 8 half of one, G = 4 a quad
+// ---- group primitives: G = 16 is one DPP row, G = 8 half of one, G = 4 a quad, G = 2 half a quad
 template <int G> __device__ __forceinline__ int grp_shr1(int v, int fill, bool g0)      // lane-1 of the group; its lane 0 receives `fill`
 {
 	int t = __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false);
@@ -220,6 +225,12 @@ template <int G> __device__ __forceinline__ int grp_shr1(int v, int fill, bool g
 template <int G> __device__ __forceinline__ int grp_scan_max(int v)                     // inclusive max-scan over the group
 {
 	if (G == 16) return row_scan_max_f(v);
+	if (G == 2) {
+		asm volatile("s_nop 1\n\t"
+		             "v_max_i32_dpp %0, %0, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+		             : "+v"(v));
+		return v;
+	}
 	if (G == 4) {
 		asm volatile("s_nop 1\n\t"
 		             "v_max_i32_dpp %0, %0, %0 quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
@@ -260,6 +271,11 @@ template <int G> __device__ __forceinline__ void grp_allmax2(int &x, int &y)    
 		             "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
 		             "v_max_i32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
 		             : "+v"(x), "+v"(y));
+	else if (G == 2)
+		asm volatile("s_nop 1\n\t"
+		             "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+		             "v_max_i32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+		             : "+v"(x), "+v"(y));
 	else
 		asm volatile("s_nop 1\n\t"
 		             "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -276,6 +292,10 @@ template <int G> __device__ __forceinline__ int grp_allmax(int v)
 		             "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
 		             "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
 		             "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+		             : "+v"(v));
+	else if (G == 2)
+		asm volatile("s_nop 1\n\t"
+		             "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1"
 		             : "+v"(v));
 	else
 		asm volatile("s_nop 1\n\t"
@@ -488,8 +508,8 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t<P> &K, const int zdrop,
 // classes whose next job's bases are fetched AHEAD (loads in flight across rows): the four-lane classes, whose jobs are short and whose draws are
 // frequent.  The eight- and sixteen-lane classes (300 bp reads) draw rarely, and the two to four registers the loads in flight occupy cost their
 // nine- and ten-pair kernels the fourth wave per SIMD: measured at 300 bp with everything fetched ahead, the extension 66.5 -> 70.0 ms
-#define PK_AHEAD(G) ((G) == 4)
-#define PK_WAVES4(G, P) ((G) == 4 ? (P) <= PK_WAVES4_MAXP : (P) <= 10)
+#define PK_AHEAD(G) ((G) <= 4)
+#define PK_WAVES4(G, P) ((G) <= 4 ? (P) <= PK_WAVES4_MAXP : (P) <= 10)
 #ifndef PK_PREFETCH_AGE
 #define PK_PREFETCH_AGE 3     // rows after which the bases fetched ahead are taken out of their registers (they have long arrived by then)
 #endif

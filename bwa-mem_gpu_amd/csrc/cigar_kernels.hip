@@ -56,7 +56,7 @@ struct cigar_args_t {
 	int use_list;                   // wave-per-region kernel: 0 = all jobs, 1 = list[CG_SLOW]
 };
 
-enum { CG_REJECT = 0, CG_TRIVIAL = 1, CG_F5 = 2, CG_F10 = 3, CG_F16 = 4, CG_SLOW = 5, CG_NKIND = 6 };
+enum { CG_REJECT = 0, CG_TRIVIAL = 1, CG_F2 = 2, CG_F3 = 3, CG_F5 = 4, CG_F10 = 5, CG_F16 = 6, CG_SLOW = 7, CG_NKIND = 8 };
 struct cg_job_t { int32_t w, n_col, score, kind; unsigned long long zoff; };
 
 __device__ __forceinline__ int g_code(uint8_t ch) { ch &= 0xDF; return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4; }
@@ -364,7 +364,9 @@ __global__ void __launch_bounds__(256) cigar_classify_kernel(cigar_args_t A)
 				w = w > diff + 3 ? w : diff + 3;
 				n_col = g.qlen < 2 * w + 1 ? g.qlen : 2 * w + 1;
 				const int slots = n_col;                        // columns alive in one row: end - beg <= min(qlen, 2w+1)
-				kind = slots <= 80 ? CG_F5 : slots <= 160 ? CG_F10 : slots <= 256 ? CG_F16 : CG_SLOW;
+				// (bands of up to 32 and 48 columns have kernels of their own: three to five mismatches in a read without a gap ask for 23 .. 43 columns, and most of the
+				// regions that need a DP at all are such reads)
+				kind = slots <= 32 ? CG_F2 : slots <= 48 ? CG_F3 : slots <= 80 ? CG_F5 : slots <= 160 ? CG_F10 : slots <= 256 ? CG_F16 : CG_SLOW;
 				if (kind != CG_SLOW) zb = (unsigned long long)n_col * (unsigned long long)g.rlen;
 			}
 		}
@@ -378,7 +380,7 @@ __global__ void __launch_bounds__(256) cigar_classify_kernel(cigar_args_t A)
 	base = (unsigned long long)__shfl((long long)base, 0);
 	if (job < A.n) { cg_job_t j; j.w = w; j.n_col = n_col; j.score = 0; j.kind = kind; j.zoff = base + incl - zb; A.jobs[job] = j; }
 	// per-kind lists, one atomic per wave and kind
-	for (int k = CG_F5; k <= CG_SLOW; ++k) {
+	for (int k = CG_F2; k <= CG_SLOW; ++k) {
 		const unsigned long long m = __ballot(kind == k);
 		if (!m) continue;
 		uint32_t b = 0;
@@ -737,7 +739,7 @@ extern "C" int bmh_cigar_batch(const bmh_index_t *idx, const uint8_t *d_reads, c
 	HIPCK(hipStreamSynchronize(st));
 	const uint32_t *h_list_n = (const uint32_t *)(h + 3);
 	if (!slow_only && getenv("BMH_CIGAR_STATS"))
-		fprintf(stderr, "[cigar] %u regions: band<=80 %u, <=160 %u, <=256 %u, wide/other %u; direction matrices %.1f MB\n", n, h_list_n[CG_F5], h_list_n[CG_F10],
+		fprintf(stderr, "[cigar] %u regions: band<=32 %u, <=48 %u, <=80 %u, <=160 %u, <=256 %u, wide/other %u; direction matrices %.1f MB\n", n, h_list_n[CG_F2], h_list_n[CG_F3], h_list_n[CG_F5], h_list_n[CG_F10],
 		        h_list_n[CG_F16], h_list_n[CG_SLOW], (double)h[2] / 1e6);
 	const uint32_t max_len = (uint32_t)((h[1] + 15) & ~15ull);
 	if (max_len > 704) { bmh_set_error("bmh_cigar_batch: a region spans %llu bases (limit 704)", h[1]); return BMH_ECAPACITY; }
@@ -747,6 +749,8 @@ extern "C" int bmh_cigar_batch(const bmh_index_t *idx, const uint8_t *d_reads, c
 		if (g_cs.z_bytes < h[2] + 256) { const size_t c = (size_t)h[2] + (size_t)h[2] / 4 + 4096; if (cg_grow(g_cs.z, c) != BMH_OK) return BMH_ENOMEM; g_cs.z_bytes = c; }
 		if (g_cs.cap_rev < (size_t)n * max_cigar) { const size_t c = (size_t)n * max_cigar + 1024; if (cg_grow(g_cs.rev, 4 * c) != BMH_OK) return BMH_ENOMEM; g_cs.cap_rev = c; }
 		a.z = g_cs.z; a.rev = g_cs.rev;
+		if (h_list_n[CG_F2]) cigar_dp16_kernel<2><<<(h_list_n[CG_F2] + 15) / 16, 256, 0, st>>>(a, CG_F2);
+		if (h_list_n[CG_F3]) cigar_dp16_kernel<3><<<(h_list_n[CG_F3] + 15) / 16, 256, 0, st>>>(a, CG_F3);
 		if (h_list_n[CG_F5]) cigar_dp16_kernel<5><<<(h_list_n[CG_F5] + 15) / 16, 256, 0, st>>>(a, CG_F5);
 		if (h_list_n[CG_F10]) cigar_dp16_kernel<10><<<(h_list_n[CG_F10] + 15) / 16, 256, 0, st>>>(a, CG_F10);
 		if (h_list_n[CG_F16]) cigar_dp16_kernel<16><<<(h_list_n[CG_F16] + 15) / 16, 256, 0, st>>>(a, CG_F16);

@@ -391,7 +391,8 @@ def main():
                 if self.ev_out[k] is not None:                          # the regions that left this buffer two steps ago have reached the host
                     self.stream.wait_event(self.ev_out[k])
             t_host = [time.time()]
-            sd = self.ws.seed_batch(dindex, ascii_t, offs_t, lens_t, 19, stream=self.h)
+            with seed_gate:
+                sd = self.ws.seed_batch(dindex, ascii_t, offs_t, lens_t, 19, stream=self.h)
             t_host.append(time.time())
             tm = self.ws.timing()
             if host_in is not None and i + n_lanes < self.k_end:        # the lane's next batch sets out now, into the other slot (behind the previous step's last kernel)
@@ -403,7 +404,8 @@ def main():
                 tm["extend_one_pass"] = 0.0
                 self.cw.merge(self.out3, regs_t, stream=self.h)
             else:
-                dj_ = self.cw.extend_merge(dindex, ascii_t, offs_t, lens_t, sd, regs_t, params=params, stream=self.h)
+                with cem_gate:
+                    dj_ = self.cw.extend_merge(dindex, ascii_t, offs_t, lens_t, sd, regs_t, params=params, stream=self.h)
             self.n_regs = int(dj_.n_regs); self.last_batch = i & 1; self.last_pcie = host_in is not None
             self.last_regs = regs_t
             t_host.append(time.time())
@@ -432,6 +434,13 @@ def main():
 
     n_lanes = max(1, a.inflight)
     lanes = [Lane(k) for k in range(n_lanes)]
+    # One batch in the seeding call at a time: two batches that seed side by side share the gather rate and then ask for the VALU together; with the gate they fall
+    # into step -- one seeds while the other extends -- and stay there (26.8 -> 26.1 ms per step, four interleaved pairs, profiles/r05_phase_gate.txt).
+    # BENCH_PHASE_LOCKS: bit 0 that gate (default), bit 1 the same around the chaining / extension call (measured: slower)
+    import contextlib
+    _pl = int(os.environ.get("BENCH_PHASE_LOCKS", "1"))
+    seed_gate = threading.Lock() if _pl & 1 else contextlib.nullcontext()
+    cem_gate = threading.Lock() if _pl & 2 else contextlib.nullcontext()
 
     def run_steps(k, host_in=None):
         """k steps, step i on lane i mod N; returns when all of them are through (device idle)"""

@@ -1292,6 +1292,7 @@ static int extend_launch(const uint8_t *d_q, const uint32_t *d_qoff, const uint3
 		HIPCK(hipStreamSynchronize(st));
 		HIPCK(hipMemcpy(h, d_stats, 64, hipMemcpyDeviceToHost));
 		fprintf(stderr, "[ext] packed kernels: wave-rows with a running alignment %llu, of them with every running alignment at end == qlen %llu (%.1f%%)\n", h[4], h[5], 100.0 * h[5] / (h[4] ? h[4] : 1));
+		fprintf(stderr, "[ext] packed kernels (-DPK_STATS builds): idle group-rows while the wave still had jobs to draw %llu, in the wave's drain %llu\n", h[6], h[7]);
 		{
 			uint32_t hc[2 * EXT_N_CLS];
 			HIPCK(hipMemcpy(hc, g_scr.counts, sizeof(hc), hipMemcpyDeviceToHost));

@@ -758,6 +758,10 @@ __device__ __forceinline__ void extpk_body(const ext_args_t &A, uint8_t *t_wave,
 		if (A.stats) {          // masks.  Not in the shipped build: the row loop carries no test that is not a DP row's
 			const bool all_at_end = !__any(run && S.end != qlen), any_run = __any(run);
 			if (lane == 0 && any_run) { atomicAdd(A.stats + 4, 1ull); if (all_at_end) atomicAdd(A.stats + 5, 1ull); }
+			// groups without a running alignment in this row: while the class still has jobs for the wave (a draw that waited for its bases) / in the wave's drain
+			const int idle = (int)__builtin_popcountll(__ballot(!run && g0));
+			const bool work_left = pre || pend || qn != qe || more_g;
+			if (lane == 0 && idle) atomicAdd(A.stats + (work_left ? 6 : 7), (unsigned long long)idle);
 		}
 #endif
 		alive = pk_row<G, P, SAME_OE>(K, A.zdrop, H, E, NZ, sel, ti, run, hfc, hnx, i, qlen, j0, eCl, g0, em_tab, hrow, owner, (const uint16_t *)h_wave, goff, S, alive, (wave_rows & PK_BOUND_MASK) == 0, tlen - 1 - i, A.raw == nullptr, A.end_bonus);

@@ -262,8 +262,11 @@ __device__ void msw_pass_reg(const msw_args_t &A, const bool on, const int qlen,
 			}
 		}
 		// what flows in from the left: lane l' sends f out, e_ins per column further on
+		// (lane 0 receives a large negative value, not a select behind the shift: around `l == 0 ? 0 : ...` the compiler built a branch and folded the DPP read
+		// INTO it -- with lane 0 masked off, lane 1 read a zero for what lane 0 sends out and insertions that cross from the first lane into the second lost
+		// their F: 2 of 200 000 hard windows, found by scripts/msw_bench.py's kernel-against-kernel run)
 		const int Y = msw_scan_max16(f + eS * l);
-		const int fin = l == 0 ? 0 : max(msw_shl(Y, l) - eS * (l - 1), 0);
+		const int fin = max(__builtin_amdgcn_update_dpp(-(1 << 28), Y, 0x111, 0xf, 0xf, false) - eS * (l - 1), 0);
 		if (__any(fin > 0)) {
 			int fv = fin + A.e_ins * r0;                            // fin - e_ins * (r - r0) at register r
 #pragma unroll

@@ -1632,7 +1632,7 @@ def test_mate_rescue_alignments_on_the_device(hip):
         _fields_ = [("rb", C.c_int64), ("re", C.c_int64), ("read", C.c_uint32), ("l_ms", C.c_int32), ("is_rev", C.c_int32), ("xtra", C.c_int32), ("bl_off", C.c_uint32), ("pad", C.c_uint32)]
     XBYTE, XSUBO, XSTART = 0x10000, 0x40000, 0x80000
     for rl in (150, 100, 249, 300, 37):
-        n_reads = 600
+        n_reads = 2400 if rl == 150 else 600
         reads = np.zeros((n_reads, rl), np.uint8)
         jobs = (Job * n_reads)()
         for i in range(n_reads):
@@ -1643,6 +1643,9 @@ def test_mate_rescue_alignments_on_the_device(hip):
                 x[int(rng.integers(0, rl))] = 4
             if i % 7 == 0 and rl >= 60:                             # a deletion in the mate
                 k = int(rng.integers(20, rl - 20)); x = np.concatenate([x[:k], g[p0 + k + 3:p0 + rl + 3]])[:rl]
+            if i % 4 == 1 and rl >= 60:                             # an insertion into the mate, anywhere -- also across the columns of two SSE lanes: F that flows from lane to lane
+                k = int(rng.integers(5, rl - 5)); m_ = int(rng.integers(1, 5))
+                x = np.concatenate([x[:k], rng.integers(0, 4, size=m_).astype(np.uint8), x[k:]])[:rl]
             is_rev = int(rng.integers(0, 2))
             reads[i] = synth.revcomp(x) if is_rev else x         # the job aligns the read's reverse complement when is_rev
             w0 = p0 - int(rng.integers(0, 400)) if i % 5 else int(rng.integers(0, n - 1000))       # every 5th window misses the mate
@@ -1684,3 +1687,15 @@ def test_mate_rescue_alignments_on_the_device(hip):
                 bad = np.nonzero((out != want_all).any(1))[0]
                 assert bad.size == 0, (rl, sc, knob, bad[:5], out[bad[:3]], want_all[bad[:3]])
     dindex.free()
+
+
+def test_mate_rescue_kernels_agree_on_hard_windows(hip):
+    """The two forms of the mate rescue's kernel (columns in registers / in LDS, csrc/pair_kernels.hip) on 60 000 windows each of two shapes with diverged mates,
+    insertions and deletions, N, windows without the mate and repeats (scripts/msw_bench.py with MSW_HARD: it asserts that every result word is equal and, where
+    they are not, says which form left the host walk of the striped kernel).  This run found what the golden sets had not: insertions whose F crosses from the
+    first SSE lane into the second (2 of 200 000 windows) were lost by the register form while a select sat behind its DPP shift."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for shape in (("60000", "150", "480"), ("40000", "249", "700")):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "msw_bench.py"), *shape], env=dict(os.environ, MSW_HARD="1"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "identical results: True" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])

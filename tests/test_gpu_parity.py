@@ -265,9 +265,9 @@ def test_extension_asymmetric_gap_penalties(hip, oracle, scoring, packed):
 
 def test_extension_packed_class_boundaries(hip, oracle):
     """Jobs at the edges of what the packed 16-bit kernels take (csrc/extpk_dev.h): query lengths around every group / pair-count
-    boundary (128|129 columns: 16 -> 17 pairs on 4 lanes, 136|137: 4 -> 8 lanes, 256|257: 8 -> 16, 288|289: packed -> 32-bit), targets around the LDS staging caps
-    (384, 512, 640) and seed scores that push h0 + qlen*a across the 4096 limit of the 16-bit keys -- the router must send each job
-    to a kernel that is exact for it."""
+    boundary (128|129 columns: 16 -> 17 pairs on 4 lanes, 136|137: 4 -> 8 lanes, 160|161: 8 lanes of 10 pairs -> 4 lanes of 24, 256|257: 4 lanes of 32 pairs -> 8 of 18,
+    288|289: packed -> 32-bit), targets around the LDS staging caps (384, 512, 640) and seed scores that push h0 + qlen*a across the 4096 limit of the 16-bit keys (2048 where a
+    lane holds more than 16 pairs: 5-bit pair indices) -- the router must send each job to a kernel that is exact for it."""
     import oracle_py
     rng = np.random.default_rng(99)
     qs, ts, h0 = [], [], []

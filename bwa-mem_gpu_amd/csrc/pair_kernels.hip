@@ -198,8 +198,10 @@ __device__ void msw_pass(const msw_args_t &A, const bool on, const int lanes, co
 // large uncapped, so plain integers return the same score (255), row and nothing else.  Checked against local_sw.cpp on 2.4 M
 // random windows (substitutions, gaps, repeats, N, six scorings, both exit flags) before the kernel was written.
 // A lane holds SL columns, the job's slen of them right-aligned (register r = column r - (SL - slen)): the column its right
-// neighbour's diagonal comes from is always register SL - 1.  No LDS but the staged target rows: ~70 / ~90 registers, no waits for
-// lane-private LDS columns (the form above spends its time there), a row of ten columns is ~170 instructions for four jobs.
+// neighbour's diagonal comes from is always register SL - 1.  No LDS but the staged target rows: 102 / 140 registers (both forms of the
+// row -- with and without a test per column -- are in the kernel), no waits for lane-private LDS columns (the form above spends its time there),
+// a row of ten columns is ~170 instructions for four jobs.  The kernel against the form above, word for word: scripts/msw_bench.py (MSW_HARD),
+// in the GPU suite.
 __device__ __forceinline__ int msw_scan_max16(int v)          // inclusive max-scan over the 16 lanes of a DPP row
 {
 	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));

@@ -503,7 +503,7 @@ __device__ __forceinline__ bool pk_row(const pk_consts_t<P> &K, const int zdrop,
 }
 
 #ifndef PK_CHUNK
-#define PK_CHUNK 16           // jobs a wave takes from its class counter per atomic (their records: one coalesced load into the wave's LDS); 16 / 32 / 64: extension 13.9-14.1 / 14.3-14.5 / 14.6-14.8 ms (the last chunks of a class are its tail); 8 / 4: 14.1 / 14.5-15.4 (the draws)
+#define PK_CHUNK 16           // jobs a wave takes from its class counter per atomic (their records: one coalesced load into the wave's LDS); 16 / 32 / 64: extension 13.9-14.1 / 14.3-14.5 / 14.6-14.8 ms (the last chunks of a class are its tail); 8 / 4: 14.1 / 14.5-15.4 (the draws); the END of a list in smaller chunks (what is left shared out among 256 / 1024 waves, a look at the counter before the atomic): 14.8-15.3 / 15.2-15.6
 #endif
 // classes whose next job's bases are fetched AHEAD (loads in flight across rows): the four-lane classes, whose jobs are short and whose draws are
 // frequent.  The eight- and sixteen-lane classes (300 bp reads) draw rarely, and the two to four registers the loads in flight occupy cost their

@@ -43,20 +43,21 @@ from bwamem_hip.parallel import broadcast_built_index, shard_range  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz: a wave64 instruction issues in 2 cycles (MI355X_MICROARCH.md)
 CACHE_VERSION = "v3"          # bump when synth.make_genome_device or the index layout changes
-PROFILE_TAG = "r05"          # profiles/<tag>_pmc*.json: counters collected by scripts/profile_round.sh with this same command (one file per workload)
+PROFILE_TAG = "r06"          # profiles/<tag>_pmc*.json: counters collected by scripts/profile_round.sh with this same command (one file per workload)
 
 
-def profile_counters(workload_key: str):
+def profile_counters(workload_key: str, lib_sha: str):
     """Per-kernel-family counters of the committed rocprofv3 PMC passes (profiles/<tag>_pmc.json, written by
     scripts/summarize_profiles.py from separate --pmc runs of this command).  They are NOT measured by this run: every
-    field taken from them is labelled from_profile and dropped when the profile's workload differs from this run's."""
+    field taken from them is labelled from_profile and dropped when the profile's workload differs from this run's or when it was
+    collected on another build of the library (lib_sources_sha16: hash of csrc/ + include/, bwamem_hip.lib.sources_sha16)."""
     import glob
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "*_pmc.json"))):
         try:
             d = json.load(open(fn))
         except Exception:
             continue
-        if d.get("workload_key") == workload_key:
+        if d.get("workload_key") == workload_key and d.get("lib_sources_sha16") == lib_sha:
             d["_file"] = os.path.relpath(fn, ROOT)
             return d
     return None
@@ -175,7 +176,11 @@ def main():
     ap.add_argument("--verify-sample", type=int, default=int(os.environ.get("BENCH_VERIFY_SAMPLE", "-1")), help="reads of the last timed batch whose GPU seeds and regions are "
                     "compared with the oracle after the timed loops (-1: the CPU sample at N = 1, 10000 per rank at N > 1; 0: off)")
     ap.add_argument("--print-cache-dir", action="store_true", help="print the --index-cache directory this command would use and exit (for the profile scripts)")
+    ap.add_argument("--distinct-batches", type=int, default=int(os.environ.get("BENCH_DISTINCT_BATCHES", "4")), help="different read batches the steps take in turn "
+                    "(step i works on batch i mod N; 10 puts configs[2]'s 10 M distinct reads through one GPU in 10 steps); at least 2")
     a = ap.parse_args()
+    n_batches = max(2, a.distinct_batches)
+    CB = 1                        # the batch the isolated passes, the CPU baseline and the self-check work on
     if a.print_cache_dir:
         print(os.path.join(a.index_cache, f"g{a.genome_mbp:g}_sa{a.sa_intv}_seed42_{CACHE_VERSION}") if a.index_cache else ""); return
 
@@ -217,7 +222,7 @@ def main():
     def draw_batches(g_host, holes_):
         lo_, hi_ = shard_range(a.reads_per_gpu * world, rank, world, multiple=2 if a.paired else 1)
         out_ = []
-        for bseed in (7, 1007):                 # two different batches, alternated step by step
+        for bseed in [7 + 1000 * j for j in range(n_batches)]:      # --distinct-batches different batches, taken in turn step by step
             if a.paired:
                 reads_, _ = B.synth.make_pairs(g_host, (hi_ - lo_) // 2, a.read_len, seed=bseed + rank, holes=holes_)
             else:
@@ -309,20 +314,21 @@ def main():
     from bwamem_hip.lib import ChainWorkspace, _memcpy_d2d
     params = B.ExtParams.default()
     ws = B.SeedWorkspace(n_reads, n_reads * a.read_len)
-    # dry run of both batches: workspace capacities, workload statistics
+    # dry run of every batch: workspace capacities, workload statistics
     stats = []
     for reads, dr in batches:
         s = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19)
         stats.append(dict(n_seeds=int(s.n_seeds), n_smems=int(s.n_smems), n_cands=int(s.n_cands)))
+    dry_order = [j for j in range(n_batches) if j != CB] + [CB]      # (the check batch last: its job lengths are copied below)
     cap_seeds = int(max(x["n_seeds"] for x in stats) * 1.25) + 4096
     cw = ChainWorkspace(n_reads, cap_seeds)
     cw.set_contigs(contigs)
     cw.set_materialize(False)             # jobs stay descriptors: the DP kernels fetch bases from the reads / 2-bit reference
-    for (reads, dr), stt in zip(batches, stats):
+    for (reads, dr), stt in ((batches[j], stats[j]) for j in dry_order):
         s = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19)
         dj = cw.chain_batch(dindex, dr.ascii, dr.offs, dr.lens, s)
         stt.update(n_jobs=int(dj.n_jobs), n_regs=int(dj.n_regs), n_heavy=int(dj.n_heavy_reads))
-    n_jobs, n_regs = stats[-1]["n_jobs"], stats[-1]["n_regs"]
+    n_jobs, n_regs = stats[CB]["n_jobs"], stats[CB]["n_regs"]
     jq = torch.empty(n_jobs, dtype=torch.int32, device=dev); jt = torch.empty(n_jobs, dtype=torch.int32, device=dev)
     _memcpy_d2d(jq.data_ptr(), dj.d_qlen, 4 * n_jobs); _memcpy_d2d(jt.data_ptr(), dj.d_tlen, 4 * n_jobs)
     cap_jobs = int(max(x["n_jobs"] for x in stats) * 1.25) + 4096
@@ -334,6 +340,11 @@ def main():
     h_main = s_main.cuda_stream
     # how often each stage ran in this process: divides the per-process counter sums of a rocprofv3 run (scripts/summarize_profiles.py)
     passes = {"seed": 2 * len(batches), "chain": len(batches), "extend": 0}
+    # ablation (BENCH_CHAIN_REPLAY=<class mask>, with --distinct-batches 2 --inflight 2: a lane then sees the same batch in every step): the chaining kernels
+    # of these size classes are skipped in the timed steps and their reads' stored regions stand (knob CHAIN_REPLAY_HEAVY, csrc/chain_kernels.hip)
+    chain_replay = int(os.environ.get("BENCH_CHAIN_REPLAY", "0"), 0)
+    if chain_replay:
+        assert n_batches == max(1, a.inflight) == 2, "BENCH_CHAIN_REPLAY needs --distinct-batches 2 --inflight 2"
     import threading
     plock = threading.Lock()
 
@@ -367,12 +378,12 @@ def main():
             with torch.cuda.stream(self.cs_in):
                 if self.ev_free is not None:
                     self.cs_in.wait_event(self.ev_free)
-                for dst, src in zip(self.slot[k], host_in[i & 1]):
+                for dst, src in zip(self.slot[k], host_in[i % n_batches]):
                     dst.copy_(src, non_blocking=True)
                 self.ev_in[k] = torch.cuda.Event(); self.ev_in[k].record(self.cs_in)
 
         def step(self, i, host_in=None):
-            dr = batches[i & 1][1]
+            dr = batches[i % n_batches][1]
             ascii_t, offs_t, lens_t = dr.ascii, dr.offs, dr.lens
             regs_t = self.regs
             if host_in is not None:
@@ -406,7 +417,7 @@ def main():
             else:
                 with cem_gate:
                     dj_ = self.cw.extend_merge(dindex, ascii_t, offs_t, lens_t, sd, regs_t, params=params, stream=self.h)
-            self.n_regs = int(dj_.n_regs); self.last_batch = i & 1; self.last_pcie = host_in is not None
+            self.n_regs = int(dj_.n_regs); self.last_batch = i % n_batches; self.last_pcie = host_in is not None
             self.last_regs = regs_t
             t_host.append(time.time())
             if lane_log is not None:                                  # (BENCH_LANE_LOG=1: host-side begin / seeded / launched of every batch)
@@ -466,6 +477,8 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(max(a.warmup, n_lanes if a.warmup else 0))
+    if chain_replay:
+        L.bmh_tune_set(b"CHAIN_REPLAY_HEAVY", chain_replay, 0)
     for ln in lanes:
         ln.acc = {}
     torch.cuda.synchronize()
@@ -509,13 +522,15 @@ def main():
         dt_pcie = time.perf_counter() - t0
         pcie_bytes = (host_in[0][0].numel() + 8 * n_reads, 32 * n_regs)
 
+    if chain_replay:
+        L.bmh_tune_set(b"CHAIN_REPLAY_HEAVY", 0, 1)
     # ---------------- the regions of the LAST TIMED step of the last lane, as they left the timed loop (over PCIe when that loop ran):
-    # what the self-check below compares with the oracle.  The check is made on batch 1; a lane whose last step was batch 0 runs
-    # one more (untimed) step of the same code path on batch 1.
+    # what the self-check below compares with the oracle.  The check is made on batch CB; a lane whose last step was another batch runs
+    # one more (untimed) step of the same code path on batch CB.
     vlane = lanes[-1]
-    if getattr(vlane, "last_batch", 0) != 1:
+    if getattr(vlane, "last_batch", -1) != CB or chain_replay:
         vlane.k_end = 0
-        vlane.step(1, host_in if a.pcie else None)
+        vlane.step(CB, host_in if a.pcie else None)
     torch.cuda.synchronize()
     last_regs_h = vlane.host_out[: vlane.n_regs].numpy().copy() if vlane.last_pcie else vlane.last_regs[: vlane.n_regs].cpu().numpy()
 
@@ -540,7 +555,7 @@ def main():
         total_reads = n_reads
     # per-kernel durations of one more pass on the last batch (HIP events on the launch stream), for the roofline
     iso_ms = {}
-    dr = batches[1][1]
+    dr = batches[CB][1]
     for _ in range(3):
         sd = ws.seed_batch(dindex, dr.ascii, dr.offs, dr.lens, 19, stream=h_main)
         tm = ws.timing()
@@ -567,17 +582,19 @@ def main():
         ncores = max(1, effective_cores() // (world if n_dev >= world else 1))
         t0 = time.time()
         hidx = F.device_index_to_host(d, max(16, a.sa_intv))
-        cb = cpu_baseline(g, pac_t.cpu().numpy(), hidx, batches[1][0], contigs, max(n_check, n_cpu_all), max(1, min(a.cpu_sample_1t, n_reads)) if world == 1 and n_cpu_all else 0, ncores)
+        cb = cpu_baseline(g, pac_t.cpu().numpy(), hidx, batches[CB][0], contigs, max(n_check, n_cpu_all), max(1, min(a.cpu_sample_1t, n_reads)) if world == 1 and n_cpu_all else 0, ncores)
         t_cpu_setup = time.time() - t0 - sum(cb[k][t] for k in ("all", "one") if k in cb for t in ("t_seed", "t_chain", "t_ext"))
         del hidx
         if n_check > 0:
             ck = cb["_check"]
-            sd_v = ws.seed_batch(dindex, batches[1][1].ascii, batches[1][1].offs, batches[1][1].lens, 19, stream=h_main)
+            sd_v = ws.seed_batch(dindex, batches[CB][1].ascii, batches[CB][1].offs, batches[CB][1].lens, 19, stream=h_main)
             torch.cuda.synchronize()
             head = SeedsT.from_buffer_copy(bytes(sd_v)); head.n_seeds = min(int(sd_v.n_seeds), len(ck["seeds"]["rbeg"]))      # only the sample's seeds travel to the host
             verified = verify_against_oracle(ck, seeds_to_host(head, ck["n"]), last_regs_h)
             verified["what"] = ("GPU seeds and alignment regions of the first reads of the last timed batch (regions as they left the timed loop"
-                                + (", D2H over PCIe" if vlane.last_pcie else "") + ") vs oracle seeding -> bmh_build_jobs -> oracle ksw_extend2 -> bmh_merge_regs")
+                                + (", D2H over PCIe" if vlane.last_pcie else "") + ") vs oracle seeding -> bmh_build_jobs -> oracle ksw_extend2 -> bmh_merge_regs; "
+                                  "bmh_build_jobs / bmh_merge_regs are this library's HOST job builder and merge (csrc/host_jobs.cpp: product code, pinned on its own to the "
+                                  "reference's recorded job stream, tests/golden/jobs_golden.npz), the seeding and the extension between them are the oracle's")
             if distributed:
                 ok = torch.tensor([int(verified["seeds_identical"]), int(verified["regions_identical"]), verified["reads"]], dtype=torch.int64, device=tt.device)
                 mn = ok.clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN); dist.all_reduce(ok)
@@ -601,15 +618,17 @@ def main():
                     clock = {"clock_mhz": round(mhz_c.value, 1), "shader_cycles_per_instr_of_the_first_wave": round(cpi_c.value, 3),
                              "how": "shader cycles (s_memtime) / 100 MHz ticks (s_memrealtime) of the first wave of the launch around its 2.56 M VALU instructions, 8 waves per SIMD "
                                     "on every SIMD (the SIMD issues its oldest ready wave first: that wave runs at the SIMD's rate, one instruction per ~4.4 cycles)"}
-        st = stats[-1]
+        st = stats[CB]
         index_how = ("loaded from --index-cache (built on the device by an earlier run of this command)" if build_stats.get("loaded_from_cache") else
                      "built on the device in setup" + (" and verified completely (every adjacent pair of suffix-array rows)" if build_stats.get("verified") else ", not verified (--no-verify-index)"))
+        from bwamem_hip.lib import sources_sha16
+        lib_sha = sources_sha16()
         workload_key = f"g{a.genome_mbp:g}_r{n_reads}_l{a.read_len}_{'pe' if a.paired else 'se'}_sa{a.sa_intv}"
         res = {
             "metric": "Mreads/s (150 bp single-end vs hg38-scale index; seed-and-extend hot path)", "value": round(value, 3), "unit": "Mreads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-            "clock_mhz": clock.get("clock_mhz"),
+            "clock_mhz": clock.get("clock_mhz"), "lib_sources_sha16": lib_sha,
             "incl_pcie_value": round(total_reads * a.steps / dt_pcie / 1e6, 3) if dt_pcie else None,
             "stage_ms_isolated": {k: round(v, 3) for k, v in iso_ms.items()},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
@@ -620,8 +639,8 @@ def main():
                                    f"duplications), N-runs; seq_len = {d.seq_len} rows{' > 2^32' if d.seq_len >> 32 else ''}; index {index_how}; "
                                    "seeding = all SMEMs >= 19 bp + locate; extension = every left/right job the reference's chaining (mem_chain, mem_chain_flt, mem_chain2aln) produces; "
                                    "chaining, job construction with on-device reference fetch and the region merge run on the device inside the timed region (reads in, regions out); "
-                                   "two different read batches alternate",
-                       "batches_in_flight": n_lanes, "extension_passes_per_batch": a.passes, "workload_key": workload_key, "reads_per_gpu": n_reads, "read_len": a.read_len, "paired_interleaved": bool(a.paired), "genome_mbp": a.genome_mbp,
+                                   f"{n_batches} different read batches taken in turn ({min(n_batches, a.steps) * n_reads} distinct reads per GPU in the timed steps)",
+                       "distinct_batches": n_batches, "batches_in_flight": n_lanes, "extension_passes_per_batch": a.passes, "workload_key": workload_key, "reads_per_gpu": n_reads, "read_len": a.read_len, "paired_interleaved": bool(a.paired), "genome_mbp": a.genome_mbp,
                        "seq_len": int(d.seq_len), "index_bytes": int(d.bwt_t.numel() * 4 + d.sa_t.numel() * 4 + d.bits_t.numel() * 4 + pac_t.numel()), "sa_intv": a.sa_intv,
                        "seeds_per_read": round(st["n_seeds"] / n_reads, 2), "smems_per_read": round(st["n_smems"] / n_reads, 2), "ext_jobs_per_read": round(st["n_jobs"] / n_reads, 2),
                        "regions_per_read": round(st["n_regs"] / n_reads, 2), "reads_chained_by_a_whole_wave": st["n_heavy"],
@@ -686,7 +705,7 @@ def main():
             kernel_bytes = {k: v * n_reads for k, v in per_read.items()}
             kernel_bytes["extend"] = ext_bytes
             cells = al["cells"] / max(al["n_jobs"], 1) * n_jobs
-            prof = profile_counters(workload_key)
+            prof = profile_counters(workload_key, lib_sha)
             names = {"forward": "smem_forward_kernel", "backward": "smem_backward_kernel", "locate": "locate_kernel",
                      "extend": "extension kernel family (ext_closed_form, extpk<G,P> packed 16-bit, extend16<C> / extend16_static<C> / extend_wide<C> 32-bit)", "chain": "chain_lane_kernel + chain_wave_kernel"}
 
@@ -751,7 +770,7 @@ def main():
             res["extension_stage"] = valu
             if a.next_rows:
                 try:
-                    res["next_rows"] = downstream_stages(L, dindex, batches[1][1], cw, regs_out[1], st["n_regs"], n_reads, g, pac_t, batches[1][0], params, contigs, a.paired, reads2=batches[0][0])
+                    res["next_rows"] = downstream_stages(L, dindex, batches[CB][1], cw, regs_out[1], st["n_regs"], n_reads, g, pac_t, batches[CB][0], params, contigs, a.paired, reads2=batches[0][0])
                 except Exception as e:                      # never lose the bench line over the extras
                     res["next_rows"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)

@@ -100,7 +100,7 @@ def load_fasta_reads(path: str, n_threads: int = 0) -> dict:
 class AlignStats(C.Structure):
     """bmh_align_stats_t"""
     _fields_ = [("n_reads", C.c_uint64), ("n_bytes", C.c_uint64), ("n_batches", C.c_uint32), ("n_lanes", C.c_int)] + \
-               [(n, C.c_double) for n in ("seconds", "format_seconds", "h2d_seconds", "seed_seconds", "chain_extend_seconds", "tail_seconds", "select_seconds", "cigar_seconds")]
+               [(n, C.c_double) for n in ("seconds", "format_seconds", "h2d_seconds", "seed_seconds", "chain_extend_seconds", "tail_seconds", "select_seconds", "cigar_seconds", "gate_wait_seconds")]
 
 
 SAM_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -252,6 +252,23 @@ class GpuseedStorageVector(C.Structure):
 
 
 _LIB = None
+
+
+def sources_sha16() -> str:
+    """First 16 hex digits of the sha256 over the library's sources (csrc/*.hip, *.h, *.cpp and include/**/*.h, in name order):
+    the build id a counter profile under profiles/ is stamped with (scripts/summarize_profiles.py) and bench.py compares
+    before it quotes a counter from such a file."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(here)
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")) + glob.glob(os.path.join(here, "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(root, "include", "**", "*.h"), recursive=True))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, root).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load_library() -> C.CDLL:

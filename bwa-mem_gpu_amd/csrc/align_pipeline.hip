@@ -132,7 +132,7 @@ struct lane_t {
 	dbuf_t<uint32_t> d_cg2; dbuf_t<int32_t> d_aln2; dbuf_t<char> d_md2; uint32_t max_read_len = 0;      // the redo of the alignments that overflow the fixed slots
 	dbuf_t<char> d_names, d_text, d_ctg_names; dbuf_t<uint64_t> d_name_off, d_text_off; dbuf_t<uint32_t> d_ctg_name_off; dbuf_t<int64_t> d_ctg_off; bool ctg_up = false;
 	hbuf_t<uint32_t> h_offs, h_sel, h_rpr; hbuf_t<int32_t> h_regs; hbuf_t<float> h_fr; hbuf_t<uint8_t> h_need, h_reads; hbuf_t<char> h_names; hbuf_t<uint64_t> h_name_off;
-	double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // h2d, seed, chain+extend+merge, tail, select, cigar + d2h
+	double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // h2d, seed, chain+extend+merge, tail, select, cigar + d2h, wait at the gate
 	~lane_t()
 	{
 		if (sws) bmh_seed_ws_free(sws);
@@ -420,22 +420,22 @@ int pairs_on_device(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, co
 // id0: index of the batch's first read in the run (the tie-break hash of mem_mark_primary_se takes it); src_pinned: rs.ascii is pinned host memory (no staging copy)
 // How many lanes may be in the path's device stages (seeding .. regions) at once: knob ALIGNER_GPU_SLOTS, 0 = as many as there are.  Lanes that start together
 // stay in step -- all of them seeding, then all of them in the host's walks with the device idle --; with fewer slots than lanes they fall out of step for good.
-struct gate_t { std::mutex mu; std::condition_variable cv; int in = 0; };
-static gate_t g_gate;
+// (one gate per run -- run_core owns it --, so that two runs in one process with different lane counts do not share a count under different caps)
+struct gate_t { std::mutex mu; std::condition_variable cv; int in = 0; int cap = 0; };
 struct gate_hold_t {
-	int cap; bool held = false;
-	explicit gate_hold_t(int cap_) : cap(cap_)
+	gate_t &g; bool held = false;
+	explicit gate_hold_t(gate_t &g_) : g(g_)
 	{
-		if (cap <= 0) return;
-		std::unique_lock<std::mutex> lk(g_gate.mu);
-		g_gate.cv.wait(lk, [&] { return g_gate.in < cap; });
-		++g_gate.in; held = true;
+		if (g.cap <= 0) return;
+		std::unique_lock<std::mutex> lk(g.mu);
+		g.cv.wait(lk, [&] { return g.in < g.cap; });
+		++g.in; held = true;
 	}
-	void release() { if (!held) return; { std::lock_guard<std::mutex> lk(g_gate.mu); --g_gate.in; } g_gate.cv.notify_one(); held = false; }
+	void release() { if (!held) return; { std::lock_guard<std::mutex> lk(g.mu); --g.in; } g.cv.notify_all(); held = false; }
 	~gate_hold_t() { release(); }
 };
 
-int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t b0, uint32_t b1, int64_t id0, bool src_pinned, bool paired, int n_threads, int gpu_slots, result_t &R)
+int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t b0, uint32_t b1, int64_t id0, bool src_pinned, bool paired, int n_threads, gate_t &gpu_gate, result_t &R)
 {
 	const uint32_t n = b1 - b0;
 	R.b0 = b0; R.n = n; R.rs = &rs; R.id0 = id0;
@@ -477,8 +477,9 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		Ln.sws = bmh_seed_ws_create(Ln.sws_reads, Ln.sws_bases, Ln.sws_bases, occ);          // one candidate per base is the hard upper bound
 		if (!Ln.sws) return BMH_ENOMEM;
 	}
-	gate_hold_t gate(gpu_slots);
-	double t1 = now_s(); Ln.t[0] += t1 - t0;
+	const double tg = now_s(); Ln.t[0] += tg - t0;
+	gate_hold_t gate(gpu_gate);
+	double t1 = now_s(); Ln.t[6] += t1 - tg;                     // (the wait at the gate is its own entry, not part of the upload)
 	bmh_seeds_t seeds;
 	RCK(bmh_seed_batch(Ln.sws, A.idx, Ln.d_reads.p, Ln.d_offs.p, Ln.d_lens.p, n, A.co.min_seed_len, Ln.st, &seeds));
 	double t2 = now_s(); Ln.t[1] += t2 - t1;
@@ -736,7 +737,7 @@ static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int pair
 	if (n_lanes < 1) n_lanes = 1;
 	if (n_threads < 1) n_threads = bmh_effective_cpus();
 	// half of the lanes in the path's device stages, the others in their tails (gate_t): measured on 2 / 3 / 4 lanes, single-end and paired, never slower than all of them, +5-7 % with 2 and 4
-	const int gpu_slots = bmh_tune("ALIGNER_GPU_SLOTS", n_lanes > 1 ? n_lanes / 2 : 0);
+	gate_t gpu_gate; gpu_gate.cap = bmh_tune("ALIGNER_GPU_SLOTS", n_lanes > 1 ? n_lanes / 2 : 0);
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) { bmh_set_error("%s: no HIP device", fn); return BMH_ENODEV; }
 	const double t_start = now_s();
@@ -790,7 +791,7 @@ static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int pair
 			R->token = bt.token;
 			int rc = BMH_OK;
 			const double tb0 = now_s();
-			if (bt.b1 > bt.b0) rc = run_batch(A, Ln, *bt.rs, bt.b0, bt.b1, bt.id0, bt.pinned, paired != 0, n_threads, gpu_slots, *R);
+			if (bt.b1 > bt.b0) rc = run_batch(A, Ln, *bt.rs, bt.b0, bt.b1, bt.id0, bt.pinned, paired != 0, n_threads, gpu_gate, *R);
 			else { R->b0 = bt.b0; R->n = 0; R->rs = bt.rs; R->id0 = bt.id0; R->has_text = false; }
 			if (trace) fprintf(stderr, "[aligner] lane %d batch %u: %.1f .. %.1f ms\n", lane_index, b, (tb0 - t_start) * 1e3, (now_s() - t_start) * 1e3);
 			if (rc != BMH_OK) { if (src.release) src.release(bt.token); fail(rc, bmh_last_error()); break; }
@@ -865,7 +866,7 @@ static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int pair
 		stats->n_reads = n_reads_total; stats->n_bytes = n_bytes; stats->n_batches = n_written; stats->n_lanes = n_lanes;
 		stats->seconds = now_s() - t_start; stats->format_seconds = t_format;
 		stats->h2d_seconds = lane_t_sum[0]; stats->seed_seconds = lane_t_sum[1]; stats->chain_extend_seconds = lane_t_sum[2]; stats->tail_seconds = lane_t_sum[3];
-		stats->select_seconds = lane_t_sum[4]; stats->cigar_seconds = lane_t_sum[5];
+		stats->select_seconds = lane_t_sum[4]; stats->cigar_seconds = lane_t_sum[5]; stats->gate_wait_seconds = lane_t_sum[6];
 	}
 	return BMH_OK;
 }

@@ -40,15 +40,27 @@ extern "C" int bmh_tune_set(const char *name, int value, int clear)
 // ---- wave residency trace (csrc/wtrace.h): records of up to `cap` waves of the instrumented kernels launched between start and stop
 static void *g_wt_dev = nullptr; static unsigned int *g_wt_cnt_dev = nullptr; static unsigned int g_wt_cap_host = 0, g_wt_kept = 0;
 #define WT_SEGS 2048u      /* = csrc/wtrace.h */
+// Call it while the device is idle: the trace symbols of the three translation units are set one after the other (cnt and cap first, the
+// buffer pointer -- what a kernel tests -- last), and they are per device: only the current device is traced.
+static void wtrace_drop()
+{
+	(void)bmh_wtrace_set_seed(nullptr, nullptr, 0); (void)bmh_wtrace_set_chain(nullptr, nullptr, 0); (void)bmh_wtrace_set_extend(nullptr, nullptr, 0);
+	if (g_wt_dev) (void)hipFree(g_wt_dev);
+	if (g_wt_cnt_dev) (void)hipFree(g_wt_cnt_dev);
+	g_wt_dev = nullptr; g_wt_cnt_dev = nullptr; g_wt_cap_host = 0;
+}
 extern "C" int bmh_wtrace_start(uint32_t cap)
 {
 	cap -= cap % WT_SEGS;
 	if (g_wt_dev || cap == 0) { bmh_set_error("bmh_wtrace_start: a trace is running, or cap < %u", WT_SEGS); return BMH_EINVAL; }
-	if (hipMalloc(&g_wt_dev, (size_t)cap * 32) != hipSuccess || hipMalloc((void **)&g_wt_cnt_dev, WT_SEGS * 64) != hipSuccess) { bmh_set_error("bmh_wtrace_start: no device memory"); return BMH_ENOMEM; }
+	(void)hipDeviceSynchronize();
+	if (hipMalloc(&g_wt_dev, (size_t)cap * 32) != hipSuccess || hipMalloc((void **)&g_wt_cnt_dev, WT_SEGS * 64) != hipSuccess) {
+		wtrace_drop(); bmh_set_error("bmh_wtrace_start: no device memory"); return BMH_ENOMEM;
+	}
 	(void)hipMemset(g_wt_cnt_dev, 0, WT_SEGS * 64);
 	g_wt_cap_host = cap;
 	if (bmh_wtrace_set_seed(g_wt_dev, g_wt_cnt_dev, cap) || bmh_wtrace_set_chain(g_wt_dev, g_wt_cnt_dev, cap) || bmh_wtrace_set_extend(g_wt_dev, g_wt_cnt_dev, cap)) {
-		bmh_set_error("bmh_wtrace_start: hipMemcpyToSymbol failed"); return BMH_ENODEV;
+		wtrace_drop(); bmh_set_error("bmh_wtrace_start: hipMemcpyToSymbol failed"); return BMH_ENODEV;
 	}
 	return BMH_OK;
 }

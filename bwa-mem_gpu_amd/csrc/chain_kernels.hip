@@ -187,9 +187,10 @@ __global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, ui
 #define CH_WAVE_ATTR
 #endif
 template <bool CTG_LDS, bool FLT>
-__global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_t A, uint32_t cls, uint32_t lds_cap, int hybrid)
+__global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_t A, uint32_t cls, uint32_t lds_cap, int hybrid, int prio)
 {
 	wtrace_scope_t wt_(WT_CHAIN_WAVE, cls);
+	if (prio) __builtin_amdgcn_s_setprio(3);             // (knob CHAIN_WAVE_PRIO: the few long-lived waves of the largest classes ahead of their SIMD's other waves)
 	extern __shared__ __align__(16) uint8_t ch_lds[];
 	const uint32_t nh = A.heavy_n[cls];
 	const uint32_t *list = A.heavy_list + (size_t)cls * A.n_reads;
@@ -408,7 +409,7 @@ struct bmh_chain_ws {
 	uint32_t *off2[4];               // [0] regions A [1] jobs A [2] regions B [3] jobs B: exclusive scans of the per-read counts of a pass
 	uint64_t *need_sum;              // [0] sampled occurrences of the wave-kernel reads (bound of their regions)
 	int32_t *out3; uint64_t cap_out3;
-	hipStream_t side2; hipEvent_t ev_x[6];
+	hipStream_t side2; hipEvent_t ev_x[7];     // [0..1] extension of pass A  [2] counts of pass B  [3], [6] pass B's emit + extension on its stream  [4] join  [5] end of the merge
 	uint64_t n_regs_a, n_jobs_a;                 // kernel times of the last batch (bmh_chain_last_timing)
 	int materialize;               // 1: bmh_chain_batch also writes the base arrays q/t (+ qoff/toff)
 	const uint8_t *last_reads, *last_pac; uint64_t last_l_pac;   // sources of the last batch, for bmh_chain_extend
@@ -625,21 +626,27 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 	const bool ctg_lds = w->n_contigs > 1 && w->n_contigs <= CH_LDS_CONTIGS;
 	HIPCK(hipFuncSetAttribute(ctg_lds ? (const void *)chain_wave_kernel<true, FLT> : (const void *)chain_wave_kernel<false, FLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[CH_N_CLASSES - 2] * CH_LDS_BYTES_PER_ENTRY_HYBRID)));
 	static const bool serial = getenv("BMH_CHAIN_SERIAL") != nullptr;          // (measurement: one class after the other, so that BMH_CHAIN_STATS shows what each costs alone)
+	// Ablation knob CHAIN_REPLAY_HEAVY (bit c = size class c): the class's kernel is NOT launched -- the regions, counts and repeat fractions its reads left in
+	// this workspace the last time stand.  Only meaningful when the workspace saw the same batch in its previous call (bench.py --distinct-batches 2 with two
+	// batches in flight): the step measured without a class is the ceiling of what a faster kernel for that class can gain.
+	const unsigned replay = (unsigned)bmh_tune("CHAIN_REPLAY_HEAVY", 0);
+	const unsigned wave_prio = (unsigned)bmh_tune("CHAIN_WAVE_PRIO", 0);      // bit c: the waves of size class c raise their priority (s_setprio 3)
 	for (int cls = CH_N_CLASSES - 1; cls >= 0; --cls) {
 		const uint32_t lds_cap = CH_CLASS_CAP[cls];
 		const int hybrid = cls >= CH_HYBRID_CLASS && lds_cap != 0;
 		const size_t lds_bytes = (size_t)lds_cap * (hybrid ? CH_LDS_BYTES_PER_ENTRY_HYBRID : CH_LDS_BYTES_PER_ENTRY);
 		HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->ev_fork, 0));
 		if (serial && cls < CH_N_CLASSES - 1) HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->cls_done[cls + 1], 0));
-		if (cls == 0) {                                                                                                   // (blocks beyond the list leave at once)
+		if (replay >> cls & 1u) { }                                                                                       // (ablation: the class's stored output stands)
+		else if (cls == 0) {                                                                                                   // (blocks beyond the list leave at once)
 			const int ll = bmh_tune("CHAIN_LIST_LANES", CH_LIST_LANES);
 			const uint32_t lanes = (uint32_t)(ll < 1 ? 1 : ll > 64 ? 64 : ll);
 			const unsigned lgrid = nblk((uint64_t)nblk(n_reads, lanes) * 64u, 256);
 			if (list_private && !FLT && A.lane_max <= 32u) chain_lane_list_kernel<FLT, 32><<<lgrid, 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls, lanes);
 			else chain_lane_list_kernel<FLT, 0><<<lgrid, 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls, lanes);
 		}
-		else if (ctg_lds) chain_wave_kernel<true, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
-		else chain_wave_kernel<false, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid);
+		else if (ctg_lds) chain_wave_kernel<true, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid, (int)(wave_prio >> cls & 1u));
+		else chain_wave_kernel<false, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid, (int)(wave_prio >> cls & 1u));
 		HIPCK(hipEventRecord(w->cls_done[cls], w->cls_stream[cls]));
 		HIPCK(hipStreamWaitEvent(w->side, w->cls_done[cls], 0));
 	}
@@ -951,8 +958,8 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 			if (rc != BMH_OK) return rc;
 		}
 	}
-	HIPCK(hipEventRecord(w->ev_x[4], sb));
-	if (b_side) HIPCK(hipStreamWaitEvent(st, w->ev_x[4], 0));
+	HIPCK(hipEventRecord(w->ev_x[6], sb));                     // end of pass B on ITS stream (what bmh_chain_extend_merge_timing reports)
+	if (b_side) HIPCK(hipStreamWaitEvent(st, w->ev_x[6], 0));
 	HIPCK(hipEventRecord(w->ev_x[4], st));
 	if (n_regs) merge2_kernel<<<nblk(n_regs, 256), 256, 0, st>>>(w->outregs, (uint32_t)n_regs, (uint32_t)n_regs_a, w->off2[0], w->off2[2], w->out3, d_regs_out, w->last_opt);
 	HIPCK(hipEventRecord(w->ev_x[5], st));
@@ -965,13 +972,15 @@ extern "C" int bmh_chain_extend_merge(bmh_chain_ws_t *w, const bmh_chain_opt_t *
 	return BMH_OK;
 }
 
-// ms[0] = extension of pass A, ms[1] = extension of pass B, ms[2] = from the start of the stage to the end of the merge (HIP events;
-// waits for the stream), jobs[0..1] = jobs of the two passes -- of the last bmh_chain_extend_merge
+// ms[0] = extension of pass A (emit + extension on the caller's stream), ms[1] = pass B's emit + extension from their first to their last
+// command ON THE STREAM THEY RAN ON -- with CHAIN_B_SIDE (the default) that is the second stream and the interval lies BESIDE pass A's, not
+// behind it: ms[0] + ms[1] then counts the overlap twice --, ms[2] = from the start of the stage to the end of the merge (HIP events; waits
+// for the stream), jobs[0..1] = jobs of the two passes -- of the last bmh_chain_extend_merge
 extern "C" int bmh_chain_extend_merge_timing(const bmh_chain_ws_t *w, float ms[3], uint64_t jobs[2])
 {
 	if (!w) return BMH_EINVAL;
 	if (hipEventSynchronize(w->ev_x[5]) != hipSuccess) return BMH_ENODEV;
-	(void)hipEventElapsedTime(&ms[0], w->ev_x[0], w->ev_x[1]); (void)hipEventElapsedTime(&ms[1], w->ev_x[3], w->ev_x[4]);
+	(void)hipEventElapsedTime(&ms[0], w->ev_x[0], w->ev_x[1]); (void)hipEventElapsedTime(&ms[1], w->ev_x[3], w->ev_x[6]);
 	(void)hipEventElapsedTime(&ms[2], w->ev_t[0], w->ev_x[5]);
 	jobs[0] = w->n_jobs_a; jobs[1] = w->n_jobs - w->n_jobs_a;
 	return BMH_OK;

@@ -110,13 +110,18 @@ __device__ __forceinline__ void pk_t8_decode(const uint32_t raw, const pk_t8w_t 
 // Four query columns c0..c0+3 of a descriptor job from ONE dword of the ASCII reads.  The dword is the four bytes at the columns' lowest
 // address, moved into the query segment where it would reach outside (the lane at the segment's end: a load must not leave the
 // reads' buffer); sh = how many bytes it was moved.  Needs qlen >= 4.
+// (pk_q4_offset: the same as plain integers relative to qp -- the load address is qp + offset, and the decoding recomputes sh from the offsets alone)
+__device__ __forceinline__ int pk_q4_offset(const int qstep, const int qlen, const int c0, int &sh)
+{
+	const int lo = qstep > 0 ? c0 : -c0 - 3;                   // lowest address of the four columns, relative to qp
+	const int seg = qstep > 0 ? 0 : -(qlen - 1);               // ... of the segment
+	const int ld = lo < seg ? seg : (lo > seg + (qlen - 4) ? seg + (qlen - 4) : lo);
+	sh = lo - ld;
+	return ld;
+}
 __device__ __forceinline__ const uint8_t *pk_q4_where(const uint8_t *qp, const int qstep, const int qlen, const int c0, int &sh)
 {
-	const uint8_t *lo = qstep > 0 ? qp + c0 : qp - c0 - 3;
-	const uint8_t *seg = qstep > 0 ? qp : qp - (qlen - 1);
-	const uint8_t *ld = lo < seg ? seg : (lo > seg + (qlen - 4) ? seg + (qlen - 4) : lo);
-	sh = (int)(lo - ld);
-	return ld;
+	return qp + pk_q4_offset(qstep, qlen, c0, sh);
 }
 // ... and its decoding: codes 0..3, 4 = anything else (N), 7 = pad at and beyond qlen, column c0+u in byte u (what ext_q_at gives byte by byte)
 __device__ __forceinline__ uint32_t pk_q4_decode(const uint32_t raw, const int sh, const int qstep, const int qlen, const int c0)
@@ -675,7 +680,7 @@ __device__ __forceinline__ void extpk_body(const ext_args_t &A, uint8_t *t_wave,
 								const int c0 = 4 * lane + 256 * u;
 								if (c0 < C * G) {
 									int sh = 0;
-									if (c0 < ql) (void)pk_q4_where(nullptr, left ? -1 : 1, ql, c0, sh);
+									if (c0 < ql) (void)pk_q4_offset(left ? -1 : 1, ql, c0, sh);
 									*(uint32_t *)(qw + c0) = c0 < ql ? pk_q4_decode(raw_q[u], sh, left ? -1 : 1, ql, c0) : 0x07070707u;
 								}
 							}

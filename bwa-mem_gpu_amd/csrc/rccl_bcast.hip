@@ -162,17 +162,19 @@ extern "C" int bmh_index_broadcast_rccl(void *comm_, int root, const bmh_index_t
 		h.magic = 0x424d48494458ull; h.primary = f.primary; memcpy(h.L2, f.L2, sizeof(h.L2)); h.seq_len = f.seq_len; h.n_sa = f.n_sa; h.l_pac = f.l_pac;
 		h.n_words = src->n_words; h.sa_shift = f.sa_shift; h.has_pac = f.pac != nullptr;
 	}
+	// (the header's device buffer stays until the ranks have agreed that all are ready: the readiness flag below reuses it, so that a rank
+	// which got this far needs no further allocation to take part in that reduction)
+	void *d_hdr = nullptr;
 	{
-		void *d_hdr = nullptr;
 		HCK(hipMalloc(&d_hdr, sizeof(h)));
 		bool ok = hipMemcpyAsync(d_hdr, &h, sizeof(h), hipMemcpyHostToDevice, st) == hipSuccess;
 		ncclResult_t nr = ncclSuccess;
 		if (ok) { nr = R->Broadcast(d_hdr, d_hdr, sizeof(h), ncclUint8, root, comm, st); ok = nr == ncclSuccess; }
 		ok = ok && hipMemcpyAsync(&h, d_hdr, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
-		(void)hipFree(d_hdr);
+		if (!ok) (void)hipFree(d_hdr);
 		if (!ok) { bmh_set_error("bmh_index_broadcast_rccl: header: %s", nr != ncclSuccess ? R->GetErrorString(nr) : hipGetErrorString(hipGetLastError())); return BMH_ENODEV; }
 	}
-	if (h.magic != 0x424d48494458ull) { bmh_set_error("bmh_index_broadcast_rccl: bad header from rank %d", root); return BMH_EINVAL; }
+	if (h.magic != 0x424d48494458ull) { (void)hipFree(d_hdr); bmh_set_error("bmh_index_broadcast_rccl: bad header from rank %d", root); return BMH_EINVAL; }
 	// ---- arrays
 	fmd_dev_t f; memset(&f, 0, sizeof(f));
 	f.primary = h.primary; memcpy(f.L2, h.L2, sizeof(h.L2)); f.seq_len = h.seq_len; f.n_sa = h.n_sa; f.sa_shift = h.sa_shift; f.l_pac = h.l_pac;
@@ -193,14 +195,15 @@ extern "C" int bmh_index_broadcast_rccl(void *comm_, int root, const bmh_index_t
 	}
 	// Every rank says whether it is ready BEFORE the grouped broadcast: a rank that could not allocate used to leave here alone and its peers
 	// waited in the broadcast for good.  One int per rank, minimum over the communicator: all go on, or all leave with an error.
+	// The flag lives in the header's buffer (allocated before anything above could fail) and is set by a memset -- no host buffer, no staging: 0x01010101
+	// = ready, 0 = not; a rank whose memset fails still JOINS the reduction (contributing what the buffer holds) and reports the failure on its side.
 	{
-		int *d_ok = nullptr, ok_all = 0;
-		const int mine = alloc_rc == BMH_OK ? 1 : 0;
-		bool fine = hipMalloc((void **)&d_ok, sizeof(int)) == hipSuccess && hipMemcpyAsync(d_ok, &mine, sizeof(int), hipMemcpyHostToDevice, st) == hipSuccess;
-		// (a rank that cannot even do this still takes part in the reduction with a null buffer error on its side only if RCCL lets it: nothing more can be done for it)
-		const ncclResult_t ar = fine ? R->AllReduce(d_ok, d_ok, 1, ncclInt32, ncclMin, comm, st) : ncclInternalError;
+		int *d_ok = (int *)d_hdr, ok_all = 0;
+		bool fine = hipMemsetAsync(d_ok, alloc_rc == BMH_OK ? 1 : 0, sizeof(int), st) == hipSuccess;
+		const ncclResult_t ar = R->AllReduce(d_ok, d_ok, 1, ncclInt32, ncclMin, comm, st);
 		fine = fine && ar == ncclSuccess && hipMemcpyAsync(&ok_all, d_ok, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
-		if (d_ok) (void)hipFree(d_ok);
+		(void)hipFree(d_hdr); d_hdr = nullptr;
+		ok_all = ok_all == 0x01010101 ? 1 : 0;
 		if (!fine || ok_all != 1) {
 			for (int k = 0; k < 4; ++k) if (d[k]) (void)hipFree(d[k]);
 			if (alloc_rc == BMH_OK) bmh_set_error("bmh_index_broadcast_rccl: %s", fine ? "another rank could not allocate its copy of the index" : "the ranks could not agree that all are ready");

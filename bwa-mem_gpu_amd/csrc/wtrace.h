@@ -49,12 +49,14 @@ struct wtrace_scope_t {
 	}
 };
 
+// (start: counter and capacity first, the buffer pointer -- what a wave tests -- last; stop: the buffer pointer first)
 #define WTRACE_DEFINE_SETTER(fn)                                                                                              \
 	int fn(void *buf, unsigned int *cnt, unsigned int cap)                                                                    \
 	{                                                                                                                         \
 		wtrace_rec_t *b = (wtrace_rec_t *)buf;                                                                                \
-		if (hipMemcpyToSymbol(HIP_SYMBOL(g_wt_buf), &b, sizeof(b)) != hipSuccess) return -1;                                  \
+		if (!b && hipMemcpyToSymbol(HIP_SYMBOL(g_wt_buf), &b, sizeof(b)) != hipSuccess) return -1;                            \
 		if (hipMemcpyToSymbol(HIP_SYMBOL(g_wt_cnt), &cnt, sizeof(cnt)) != hipSuccess) return -1;                              \
 		if (hipMemcpyToSymbol(HIP_SYMBOL(g_wt_cap), &cap, sizeof(cap)) != hipSuccess) return -1;                              \
+		if (b && hipMemcpyToSymbol(HIP_SYMBOL(g_wt_buf), &b, sizeof(b)) != hipSuccess) return -1;                             \
 		return 0;                                                                                                             \
 	}

@@ -581,6 +581,7 @@ typedef struct {
 	double seconds;                 /* wall clock of the run */
 	double format_seconds;          /* in the writer thread (overlaps the workers) */
 	double h2d_seconds, seed_seconds, chain_extend_seconds, tail_seconds, select_seconds, cigar_seconds;    /* summed over the lanes' host clocks */
+	double gate_wait_seconds;       /* lanes waiting for a slot in the path's device stages (ALIGNER_GPU_SLOTS), summed likewise */
 } bmh_align_stats_t;
 bmh_aligner_t *bmh_aligner_create(const bmh_index_t *idx, const uint8_t *pac, int64_t l_pac, int n_contigs, const char *const *contig_names,
                                   const int32_t *contig_len, const uint8_t *contig_is_alt, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep,

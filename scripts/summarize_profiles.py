@@ -64,7 +64,10 @@ def counter_sums(d, counters):
 
 def main():
     tag, stats_dir, fetch_dir, write_dir, sq_dir = sys.argv[1:6]
-    out = {"tag": tag, "kernels": {}, "families": {}}
+    sys.path.insert(0, os.path.join(ROOT, "bwa-mem_gpu_amd"))
+    from bwamem_hip.lib import sources_sha16
+    # the build the counters belong to: bench.py quotes a counter of this file only while the library's sources still hash to this
+    out = {"tag": tag, "lib_sources_sha16": sources_sha16(), "kernels": {}, "families": {}}
     # ---- kernel stats of the --kernel-trace --stats run
     p = find(stats_dir, "kernel_stats.csv")
     rows = list(csv.reader(open(p)))
@@ -76,6 +79,8 @@ def main():
     bl = bench_line(stats_dir)
     if bl:
         out["workload_key"] = bl["config"]["workload_key"]
+        if bl.get("lib_sources_sha16") and bl["lib_sources_sha16"] != out["lib_sources_sha16"]:
+            print("WARNING: the stats run's library sources differ from the tree's:", bl["lib_sources_sha16"], out["lib_sources_sha16"])
         out["stats_run"] = {"passes": bl.get("passes"), "value": bl["value"], "ms_per_step": bl["ms_per_step"], "steps": bl["steps"], "warmup": bl["warmup"]}
     for r in keep[1:]:
         out["kernels"].setdefault(short(r[iname]), {}).update(calls=int(r[icalls]), total_ms=round(float(r[itot]) / 1e6, 3),

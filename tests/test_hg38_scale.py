@@ -155,9 +155,9 @@ def test_hot_path_on_a_text_beyond_2_pow_32(hip, oracle):
     hj.free(); cw.free(); ws.free(); dindex.free()
 
 
-@pytest.mark.parametrize("variant", ["paired", "300bp"])
-def test_baseline_configs_3_and_4_at_full_size(variant):
-    """BASELINE.json configs[3] (1 M x 150 bp pairs, interleaved) and configs[4] (1 M x 300 bp) at their stated size against the
+@pytest.mark.parametrize("variant", ["single", "paired", "300bp"])
+def test_baseline_configs_1_3_and_4_at_full_size(variant):
+    """BASELINE.json configs[1] (1 M x 150 bp single-end: the headline workload), configs[3] (1 M x 150 bp pairs, interleaved) and configs[4] (1 M x 300 bp) at their stated size against the
     3.1 Gbp index (seq_len 6.2e9 > 2^32, built on the device in the run's setup): the bench command itself, two timed steps, the
     first 100 000 reads of the last timed batch compared with the oracle inside the run (seeds and regions identical or exit 3)."""
     import json
@@ -165,7 +165,7 @@ def test_baseline_configs_3_and_4_at_full_size(variant):
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     # (configs[3] is 1 M PAIRS: two million interleaved reads per batch)
-    extra = ["--paired", "--reads-per-gpu", "2000000"] if variant == "paired" else ["--read-len", "300"]
+    extra = {"single": [], "paired": ["--paired", "--reads-per-gpu", "2000000"], "300bp": ["--read-len", "300"]}[variant] + ["--distinct-batches", "2"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--verify-sample", "100000", "--no-next-rows", "--cpu-sample", "0",
                         "--no-pcie"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert r.returncode == 0, r.stderr.decode()[-3000:]

@@ -23,8 +23,13 @@
 
 #if defined(__HIPCC__)
 #define CH_HD __host__ __device__
+// (the per-read core is inlined into every kernel call site: only then does each scratch pointer have ONE address space the compiler can see -- an
+// outlined copy shared by call sites with LDS and with global scratch makes every access a flat one, several times the latency of ds_read on the LDS side;
+// round 6 found the wave kernel's hybrid and global-scratch forms compiled that way: 279 flat loads)
+#define CH_INLINE __attribute__((always_inline))
 #else
 #define CH_HD
+#define CH_INLINE
 #endif
 
 struct ch_seed_t { int64_t rbeg; int32_t qbeg, len; uint32_t next, pad; };                       // 24 B
@@ -82,17 +87,47 @@ template <bool LDSX = false> __device__ __forceinline__ void ch_wave_fence()
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 	__builtin_amdgcn_s_waitcnt(LDSX ? 0xC07F : 0);            // gfx9 encoding: vmcnt 63 / expcnt 7 left alone, lgkmcnt 0
 }
+// A GROUP of W lanes works on one read in the cooperative form: the whole wave (W = 64), or a quarter of it -- one 16-lane row (W = 16):
+// four reads per wave, each with its own scratch in LDS (round 6: the reads of 9 .. 64 sampled seeds, the bulk of the seed-rich reads,
+// whose quadratic loops are 16 wide at most and who paid a whole wave, or a lane with its scratch in global memory, each).  Every
+// cross-lane operation of the core goes through this interface and stays inside the group, so the groups of a wave may diverge freely:
+//   lane()      index inside the group          ballot(p)   the group's lanes with p, bit 0 = the group's first lane
+//   bcast(v, u) v of the group's lane u (u uniform over the GROUP: a v_readlane for the wave, a ds_bpermute for a row)
+template <int W> struct ch_grp;
+template <> struct ch_grp<64> {
+	static __device__ __forceinline__ int lane() { return ch_lane(); }
+	static __device__ __forceinline__ unsigned long long ballot(const bool p) { return __ballot(p); }
+	static __device__ __forceinline__ bool any(const bool p) { return __ballot(p) != 0ull; }
+	static __device__ __forceinline__ int bcast(const int v, const int u) { return __builtin_amdgcn_readlane(v, u); }
+	static __device__ __forceinline__ long long bcast64(const long long v, const int u)
+	{
+		return (long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xFFFFFFFFll), u) | ((long long)__builtin_amdgcn_readlane((int)(v >> 32), u) << 32);
+	}
+	static __device__ __forceinline__ long long shfl_up64(const long long v, const int d) { return __shfl_up(v, d); }
+};
+template <> struct ch_grp<16> {
+	static __device__ __forceinline__ int lane() { return ch_lane() & 15; }
+	static __device__ __forceinline__ unsigned long long ballot(const bool p) { return (__ballot(p) >> (ch_lane() & 48)) & 0xFFFFull; }
+	static __device__ __forceinline__ bool any(const bool p) { return ballot(p) != 0ull; }
+	static __device__ __forceinline__ int bcast(const int v, const int u) { return __shfl(v, u, 16); }
+	static __device__ __forceinline__ long long bcast64(const long long v, const int u) { return __shfl(v, u, 16); }
+	static __device__ __forceinline__ long long shfl_up64(const long long v, const int d) { return __shfl_up(v, d, 16); }
+};
 #endif
 
-template <bool COOP = false> CH_HD inline int pos2rid(const ch_ctx_t &x, int64_t pos_f)
+template <bool COOP = false, int W = 64> CH_HD inline int pos2rid(const ch_ctx_t &x, int64_t pos_f)
 {
 	if (pos_f >= x.l_pac) return -1;
 	if (x.n_contigs <= 1) return 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-	if (COOP && x.n_contigs <= 64) {             // wave form: one contig start per lane, the answer is a ballot (the table sits in LDS)
-		const int lane = ch_lane();
-		const bool le = lane < x.n_contigs && x.ctg_off[lane] <= pos_f;
-		return __builtin_popcountll(__ballot(le)) - 1;
+	if (COOP && x.n_contigs <= 64) {             // cooperative form: one contig start per lane, the answer is a ballot (the table sits in LDS)
+		const int lane = ch_grp<W>::lane();
+		int cnt = 0;
+		for (int c0 = 0; c0 < x.n_contigs; c0 += W) {
+			const bool le = c0 + lane < x.n_contigs && x.ctg_off[c0 + lane] <= pos_f;
+			cnt += __builtin_popcountll(ch_grp<W>::ballot(le));
+		}
+		return cnt - 1;
 	}
 #endif
 	int left = 0, mid = 0, right = x.n_contigs;
@@ -107,16 +142,18 @@ template <bool COOP = false> CH_HD inline int pos2rid(const ch_ctx_t &x, int64_t
 	return mid;
 }
 CH_HD inline int64_t depos(const ch_ctx_t &x, int64_t pos, int *is_rev) { return (*is_rev = (pos >= x.l_pac)) ? (x.l_pac << 1) - 1 - pos : pos; }
-template <bool COOP = false> CH_HD inline int intv2rid(const ch_ctx_t &x, int64_t rb, int64_t re)
+template <bool COOP = false, int W = 64> CH_HD inline int intv2rid(const ch_ctx_t &x, int64_t rb, int64_t re)
 {
 	int is_rev;
 	if (rb < x.l_pac && re > x.l_pac) return -2;
-	const int rid_b = pos2rid<COOP>(x, depos(x, rb, &is_rev));
-	const int rid_e = rb < re ? pos2rid<COOP>(x, depos(x, re - 1, &is_rev)) : rid_b;
+	const int rid_b = pos2rid<COOP, W>(x, depos(x, rb, &is_rev));
+	const int rid_e = rb < re ? pos2rid<COOP, W>(x, depos(x, re - 1, &is_rev)) : rid_b;
 	return rid_b == rid_e ? rid_b : -1;
 }
 // (an integer form, (n + e) / e, gives the same values but measured slower on the device than the double division)
-CH_HD inline int ch_div_plus1(int n, int e) { return (int)((double)n / e + 1.); }
+// (gap extension penalties of 1 -- the default -- need no division: (double)n / 1 + 1. is n + 1 exactly, for either sign of n; the branch is uniform
+// over a launch, and a double division is some forty instructions of which the chaining core made four to eight per seed)
+CH_HD inline int ch_div_plus1(int n, int e) { return e == 1 ? n + 1 : (int)((double)n / e + 1.); }
 CH_HD inline int cal_max_gap(const bmh_chain_opt_t &o, int qlen)
 {
 	const int l_del = ch_div_plus1(qlen * o.a - o.o_del, o.e_del);
@@ -193,26 +230,26 @@ template <bool FINAL = true> CH_HD inline bool w_introsort(uint64_t *a, int n)
 // lane against all others, 64 of those at a time through v_readlane; the chain ids go straight to order[] (nothing reads the
 // sorted keys).  Sequentially this pass was about half of the sort, and the sort a third of the chaining of a 500-seed read.
 // (weights are at most the read length, indices below 2^16: mem_chain samples at most max_occ occurrences per SMEM)
-template <int NU> __device__ __forceinline__ void w_place_part(const uint64_t *a, const uint32_t *hi, uint32_t *order, int n, int xb, int lane)
+template <int NU, int W = 64> __device__ __forceinline__ void w_place_part(const uint64_t *a, const uint32_t *hi, uint32_t *order, int n, int xb, int lane)
 {
 	uint32_t cx[NU]; int pos[NU];
 #pragma unroll
 	for (int u = 0; u < NU; ++u) {
-		const int x = xb + 64 * u + lane, xc = x < n ? x : n - 1;
+		const int x = xb + W * u + lane, xc = x < n ? x : n - 1;
 		cx[u] = (hi[2 * xc] << 16) | (0xFFFFu - (uint32_t)xc); pos[u] = 0;
 	}
-	for (int yb = 0; yb < n; yb += 64) {
+	for (int yb = 0; yb < n; yb += W) {
 		const int y = yb + lane;
 		const uint32_t cy = y < n ? (hi[2 * y] << 16) | (0xFFFFu - (uint32_t)y) : 0u;       // 0 sorts behind every entry
-		const int ke = n - yb < 64 ? n - yb : 64;
+		const int ke = n - yb < W ? n - yb : W;
 		for (int k = 0; k < ke; ++k) {
-			const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cy, k);
+			const uint32_t c = (uint32_t)ch_grp<W>::bcast((int)cy, k);
 #pragma unroll
 			for (int u = 0; u < NU; ++u) pos[u] += c > cx[u] ? 1 : 0;
 		}
 	}
 #pragma unroll
-	for (int u = 0; u < NU; ++u) { const int x = xb + 64 * u + lane; if (x < n) order[pos[u]] = (uint32_t)a[x]; }
+	for (int u = 0; u < NU; ++u) { const int x = xb + W * u + lane; if (x < n) order[pos[u]] = (uint32_t)a[x]; }
 }
 // The quicksort phase of the same introsort with its partition loop spread over the wave.  ks_introsort's Hoare partition looks at
 // every entry at most once from either side before the pointers meet, so which entries it exchanges follows from the array as it is
@@ -222,36 +259,36 @@ template <int NU> __device__ __forceinline__ void w_place_part(const uint64_t *a
 // exchanges the pairs and finds where the left pointer stops: at the first candidate without a partner, or on the entry the last
 // exchange brought to the right -- whichever comes first.  64 entries per step instead of one; pivot choice, recursion stack, depth
 // limit and the order of the partitions are the sequential code's.  tmp: n words (order[], not in use before the sort ends).
-template <bool LDSX> __device__ inline int w_partition_coop(uint64_t *a, uint32_t *tmp, const int s, const int t, const uint32_t wp)
+template <bool LDSX, int W = 64> __device__ inline int w_partition_coop(uint64_t *a, uint32_t *tmp, const int s, const int t, const uint32_t wp)
 {
-	const int lane = ch_lane();
+	const int lane = ch_grp<W>::lane();
 	const uint32_t *hi = (const uint32_t *)a + 1;
 	const unsigned long long below = (1ull << lane) - 1ull;
 	int nle = 0;
-	for (int top = t - 1; top >= s; top -= 64) {                       // pass A: lane l looks at position top - l
+	for (int top = t - 1; top >= s; top -= W) {                        // pass A: lane l looks at position top - l
 		const int x = top - lane;
 		const bool le = x >= s && hi[2 * (x >= s ? x : s)] >= wp;
-		const unsigned long long m = __ballot(le);
+		const unsigned long long m = ch_grp<W>::ballot(le);
 		if (le) tmp[s + nle + (int)__builtin_popcountll(m & below)] = (uint32_t)x;
 		nle += (int)__builtin_popcountll(m);
 	}
 	ch_wave_fence<LDSX>();
 	int k0 = 0, ipos = -1;
-	for (int lo = s + 1; ipos < 0; lo += 64) {                         // pass B (position t holds the pivot: the loop ends there at the latest)
+	for (int lo = s + 1; ipos < 0; lo += W) {                          // pass B (position t holds the pivot: the loop ends there at the latest)
 		const int x = lo + lane;
 		const bool ge = x <= t && hi[2 * (x <= t ? x : t)] <= wp;
-		const unsigned long long m = __ballot(ge);
+		const unsigned long long m = ch_grp<W>::ballot(ge);
 		const int k = k0 + (int)__builtin_popcountll(m & below);
 		int r = -1;
 		if (ge && k < nle) r = (int)tmp[s + k];
 		const bool sw = ge && r > x;
-		const unsigned long long ms = __ballot(sw);
+		const unsigned long long ms = ch_grp<W>::ballot(sw);
 		if (sw) { const uint64_t va = a[x], vb = a[r]; a[x] = vb; a[r] = va; }
 		const unsigned long long stop = m & ~ms;
 		int cand = stop ? lo + (int)__builtin_ctzll(stop) : 0x7FFFFFFF;
 		if (ms) {
-			const int rl = __builtin_amdgcn_readlane(r, 63 - (int)__builtin_clzll(ms));      // where the last exchange put a left-hand entry
-			if (rl <= lo + 63 && rl < cand) cand = rl;
+			const int rl = ch_grp<W>::bcast(r, 63 - (int)__builtin_clzll(ms));               // where the last exchange put a left-hand entry
+			if (rl <= lo + W - 1 && rl < cand) cand = rl;
 		}
 		if (cand != 0x7FFFFFFF) ipos = cand;
 		k0 += (int)__builtin_popcountll(m);
@@ -259,7 +296,7 @@ template <bool LDSX> __device__ inline int w_partition_coop(uint64_t *a, uint32_
 	}
 	return ipos;
 }
-template <bool LDSX> __device__ inline bool w_introsort_coop(uint64_t *a, uint32_t *tmp, int n)
+template <bool LDSX, int W = 64> __device__ inline bool w_introsort_coop(uint64_t *a, uint32_t *tmp, int n)
 {
 	if (n < 1) return true;
 	if (n == 2) { if (wlt(a[1], a[0])) wswap(a, 0, 1); ch_wave_fence<LDSX>(); return true; }
@@ -279,7 +316,7 @@ template <bool LDSX> __device__ inline bool w_introsort_coop(uint64_t *a, uint32
 			}
 			const uint64_t rp = a[k];
 			if (k != t) { wswap(a, k, t); ch_wave_fence<LDSX>(); }
-			i = w_partition_coop<LDSX>(a, tmp, s, t, (uint32_t)(rp >> 32));
+			i = w_partition_coop<LDSX, W>(a, tmp, s, t, (uint32_t)(rp >> 32));
 			if (i != t) { wswap(a, i, t); ch_wave_fence<LDSX>(); }
 			if (i - s > t - i) {
 				if (i - s > 16) { if (sp >= 40) return false; st_l[sp] = s; st_r[sp] = i - 1; st_d[sp] = d; ++sp; }
@@ -294,16 +331,16 @@ template <bool LDSX> __device__ inline bool w_introsort_coop(uint64_t *a, uint32
 		}
 	}
 }
-template <bool LDSX> __device__ inline void w_place_coop(const uint64_t *a, uint32_t *order, int n)
+template <bool LDSX, int W = 64> __device__ inline void w_place_coop(const uint64_t *a, uint32_t *order, int n)
 {
-	const int lane = ch_lane();
+	const int lane = ch_grp<W>::lane();
 	const uint32_t *hi = (const uint32_t *)a + 1;                     // the weights: high words of the keys
-	for (int xb = 0; xb < n; xb += 512) {
+	for (int xb = 0; xb < n; xb += 8 * W) {
 		const int rem = n - xb;
-		if (rem <= 64) w_place_part<1>(a, hi, order, n, xb, lane);
-		else if (rem <= 128) w_place_part<2>(a, hi, order, n, xb, lane);
-		else if (rem <= 256) w_place_part<4>(a, hi, order, n, xb, lane);
-		else w_place_part<8>(a, hi, order, n, xb, lane);
+		if (rem <= W) w_place_part<1, W>(a, hi, order, n, xb, lane);
+		else if (rem <= 2 * W) w_place_part<2, W>(a, hi, order, n, xb, lane);
+		else if (rem <= 4 * W) w_place_part<4, W>(a, hi, order, n, xb, lane);
+		else w_place_part<8, W>(a, hi, order, n, xb, lane);
 	}
 	ch_wave_fence<LDSX>();
 }
@@ -311,20 +348,20 @@ template <bool LDSX> __device__ inline void w_place_coop(const uint64_t *a, uint
 
 // ---- helpers that are split across the wave when COOP
 // insert (cv, pv) at position at of order/opos[0..nc)
-template <bool COOP, bool LDSX = false> CH_HD inline void sorted_insert(uint32_t *order, int64_t *opos, int nc, int at, uint32_t cv, int64_t pv)
+template <bool COOP, bool LDSX = false, int W = 64> CH_HD inline void sorted_insert(uint32_t *order, int64_t *opos, int nc, int at, uint32_t cv, int64_t pv)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (COOP) {
-		// each round moves the top 256 entries of [at, hi) up by one: four independent loads per lane, then the four stores
-		// (a round of 64 costs the same two LDS latencies)
-		const int lane = ch_lane();
-		for (int hi = nc; hi > at; hi -= 256) {
+		// each round moves the top 4 W entries of [at, hi) up by one: four independent loads per lane, then the four stores
+		// (a round of W costs the same two LDS latencies)
+		const int lane = ch_grp<W>::lane();
+		for (int hi = nc; hi > at; hi -= 4 * W) {
 			uint32_t v[4]; int64_t p[4];
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - 64 * u, jc = j >= at ? j : at; v[u] = order[jc]; p[u] = opos[jc]; }   // no branch: the loads overlap
+			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - W * u, jc = j >= at ? j : at; v[u] = order[jc]; p[u] = opos[jc]; }   // no branch: the loads overlap
 			ch_wave_fence<LDSX>();
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - 64 * u; if (j >= at) { order[j + 1] = v[u]; opos[j + 1] = p[u]; } }
+			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - W * u; if (j >= at) { order[j + 1] = v[u]; opos[j + 1] = p[u]; } }
 			ch_wave_fence<LDSX>();
 		}
 		order[at] = cv; opos[at] = pv;
@@ -337,21 +374,21 @@ template <bool COOP, bool LDSX = false> CH_HD inline void sorted_insert(uint32_t
 }
 
 // upper bound of rb in the ascending opos[0..nc): number of entries <= rb
-template <bool COOP> CH_HD inline int upper_bound_pos(const int64_t *opos, int nc, int64_t rb)
+template <bool COOP, int W = 64> CH_HD inline int upper_bound_pos(const int64_t *opos, int nc, int64_t rb)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	if (COOP && nc > 8 && nc <= 4096) {          // two 64-way steps instead of log2(nc) dependent ones
-		const int lane = ch_lane();
-		const int stride = (nc + 63) >> 6;
+	if (COOP && nc > 8 && nc <= W * W) {         // two W-way steps instead of log2(nc) dependent ones
+		const int lane = ch_grp<W>::lane();
+		const int stride = (nc + W - 1) / W;
 		const int last = ((lane + 1) * stride < nc ? (lane + 1) * stride : nc) - 1;
 		const bool le = lane * stride < nc && opos[last] <= rb;
-		const int b = __builtin_popcountll(__ballot(le));
+		const int b = __builtin_popcountll(ch_grp<W>::ballot(le));
 		if (stride == 1) return b;
 		const int base = b * stride;
 		if (base >= nc) return nc;
 		const int idx = base + lane;
 		const bool le2 = lane < stride && idx < nc && opos[idx] <= rb;
-		return base + __builtin_popcountll(__ballot(le2));
+		return base + __builtin_popcountll(ch_grp<W>::ballot(le2));
 	}
 #endif
 	int lo = 0, hi = nc;
@@ -360,18 +397,18 @@ template <bool COOP> CH_HD inline int upper_bound_pos(const int64_t *opos, int n
 }
 
 // first index in [lo, hi) for which f is true, hi if none; f must be free of side effects
-template <bool COOP, class F> CH_HD inline int first_true(int lo, int hi, F f)
+template <bool COOP, int W = 64, class F> CH_HD inline int first_true(int lo, int hi, F f)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (COOP) {
-		// 256 candidates per round: the four predicates are independent, so their LDS loads overlap (f is free of side effects)
-		const int lane = ch_lane();
-		for (int b = lo; b < hi; b += 256) {
+		// 4 W candidates per round: the four predicates are independent, so their LDS loads overlap (f is free of side effects)
+		const int lane = ch_grp<W>::lane();
+		for (int b = lo; b < hi; b += 4 * W) {
 			unsigned long long m[4];
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { const int i = b + 64 * u + lane; m[u] = __ballot(i < hi && f(i)); }
+			for (int u = 0; u < 4; ++u) { const int i = b + W * u + lane; m[u] = ch_grp<W>::ballot(i < hi && f(i)); }
 #pragma unroll
-			for (int u = 0; u < 4; ++u) if (m[u]) return b + 64 * u + (int)__builtin_ctzll(m[u]);
+			for (int u = 0; u < 4; ++u) if (m[u]) return b + W * u + (int)__builtin_ctzll(m[u]);
 		}
 		return hi;
 	}
@@ -381,12 +418,12 @@ template <bool COOP, class F> CH_HD inline int first_true(int lo, int hi, F f)
 }
 
 // sort n distinct 64-bit keys ascending (any algorithm gives the same result)
-template <bool COOP, bool LDSX = false> CH_HD inline void sort_distinct(uint64_t *a, uint64_t *tmp, int n)
+template <bool COOP, bool LDSX = false, int W = 64> CH_HD inline void sort_distinct(uint64_t *a, uint64_t *tmp, int n)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	if (COOP && n > 24) {          // rank sort: element i goes to the number of keys below it
-		const int lane = ch_lane();
-		for (int b = 0; b < n; b += 64) {
+	if (COOP && n > (W == 64 ? 24 : 6)) {          // rank sort: element i goes to the number of keys below it
+		const int lane = ch_grp<W>::lane();
+		for (int b = 0; b < n; b += W) {
 			const int i = b + lane;
 			if (i < n) {
 				const uint64_t v = a[i]; int rank = 0;
@@ -395,7 +432,7 @@ template <bool COOP, bool LDSX = false> CH_HD inline void sort_distinct(uint64_t
 			}
 		}
 		ch_wave_fence<LDSX>();
-		for (int b = 0; b < n; b += 64) { const int i = b + lane; if (i < n) a[i] = tmp[i]; }
+		for (int b = 0; b < n; b += W) { const int i = b + lane; if (i < n) a[i] = tmp[i]; }
 		ch_wave_fence<LDSX>();
 		return;
 	}
@@ -684,7 +721,14 @@ CH_HD inline ch_scr_t global_scratch(const ch_ctx_t &x, uint32_t r)
 }
 
 // The read: returns through x.regs (slot order = creation order), x.regs_per_read[r], x.jobs_per_read[r].
-template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(const ch_ctx_t &x, uint32_t r, const ch_scr_t &sc)
+// (W: lanes of the group that works on the read in the cooperative form -- the wave, or a 16-lane row with its own scratch, ch_grp)
+// STG (cooperative device forms whose read has at most as many located seeds as its scratch has entries): the read's seed arrays -- group sizes, query
+// intervals, positions -- are copied into the scratch (the space of E, not in use before mem_chain_flt) by the whole group in ONE round trip to global
+// memory; without it every SMEM group costs a chain of dependent global loads (its size, its interval, its positions), which was most of the time a
+// read of a dozen seeds took.
+// SITE: a tag that gives a call site an instantiation of its own -- the wave kernel calls the same form with scratch pointers of different address spaces
+// (all global; the arrays of the sequential phases in LDS), and ONE shared copy of the function makes every access through them a flat one.
+template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG = false, int SITE = 0> CH_HD CH_INLINE void chain_read(const ch_ctx_t &x, uint32_t r, const ch_scr_t &sc)
 {
 	const bmh_chain_opt_t &o = x.o;
 	const uint32_t base = x.prefix[r];
@@ -701,7 +745,20 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 	int min_HSP_score = 0;
 	const bool flt_on = seed_filter_applies(o, l_query, &min_HSP_score);
 	if (l_query > CH_MAX_READ_LEN || (flt_on && !FLT)) { *x.err = 1; return; }
-	const uint64_t *g_rbeg = x.rbeg + base; const int32_t *g_qbeg = x.qbeg + 2 * (size_t)base; const uint32_t *g_score = x.score + base;
+	const uint64_t *g_rbeg; const int32_t *g_qbeg; const uint32_t *g_score;
+#if defined(__HIP_DEVICE_COMPILE__)
+	if constexpr (STG) {
+		static_assert(COOP, "staged seeds: cooperative forms only");
+		const uint64_t *s_rbeg = x.rbeg + base; const int32_t *s_qbeg = x.qbeg + 2 * (size_t)base; const uint32_t *s_score = x.score + base;
+		uint32_t *ls = (uint32_t *)E; int32_t *lq = (int32_t *)(ls + n); uint64_t *lr = (uint64_t *)(ls + ((3 * n + 1) & ~1));      // 20 n + 4 bytes of E's 32 n
+		const int lane = ch_grp<W>::lane();
+		for (int k = lane; k < n; k += W) { ls[k] = s_score[k]; lr[k] = s_rbeg[k]; }
+		for (int k = lane; k < 2 * n; k += W) lq[k] = s_qbeg[k];
+		ch_wave_fence<false>();                                    // (the loads must have arrived: vmcnt and lgkmcnt 0)
+		g_rbeg = lr; g_qbeg = lq; g_score = ls;
+	} else
+#endif
+	{ g_rbeg = x.rbeg + base; g_qbeg = x.qbeg + 2 * (size_t)base; g_score = x.score + base; }
 
 	// ---------------------------------------------------------------- mem_chain
 	CH_STAMP(0);
@@ -730,10 +787,10 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 		const int n_it = (int)(((int64_t)cnt + step - 1) / step) < o.max_occ ? (int)(((int64_t)cnt + step - 1) / step) : o.max_occ;
 		// one occurrence of the SMEM (sb, slen) at reference position rb, the reference's way: closest chain at or below it, merge or new
 		auto seq_one = [&](const int64_t rb) {
-			const int rid = intv2rid<COOP>(x, rb, rb + slen);
+			const int rid = intv2rid<COOP, W>(x, rb, rb + slen);
 			if (rid < 0) return;
 			// closest chain at or below the seed: upper bound over opos[0..nc), then one back
-			const int lo = upper_bound_pos<COOP>(opos, nc, rb);
+			const int lo = upper_bound_pos<COOP, W>(opos, nc, rb);
 			bool to_add = true;
 			if (lo > 0) {
 				ch_chain_t &c = CH[order[lo - 1]];
@@ -756,7 +813,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 				S[ns] = s;
 				ch_chain_t c; c.head = c.tail = (uint32_t)ns; c.n = 1; c.rid = rid; c.w = 0; c.first = -1; c.beg = c.end = 0; c.kept = 0; c.pad = 0;
 				CH[nc] = c;
-				sorted_insert<COOP, LDSX>(order, opos, nc, lo, (uint32_t)nc, rb);
+				sorted_insert<COOP, LDSX, W>(order, opos, nc, lo, (uint32_t)nc, rb);
 				++ns; ++nc;
 			}
 		};
@@ -770,8 +827,8 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 			// later one is tested against.  Lanes look for such a pair among themselves (64 register reads each); a batch without
 			// one -- the rule on a seed-rich read, whose occurrences lie at loci of their own -- is committed by all lanes at once and
 			// its new chains are merged into the sorted chain index in one pass; any other batch takes the sequential path below.
-			const int lane = ch_lane();
-			for (int c0 = 0; c0 < n_it; c0 += 64) {
+			const int lane = ch_grp<W>::lane();
+			for (int c0 = 0; c0 < n_it; c0 += W) {
 				const int cc = c0 + lane;
 				const bool act = cc < n_it;
 				const long long rbl = act ? (long long)g_rbeg[i + (int64_t)cc * step] : 0;
@@ -803,11 +860,11 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 					}
 					bool inter = false; int below = 0;
 					const int rlo = (int)(unsigned)(rbl & 0xFFFFFFFFll), rhi = (int)(rbl >> 32);
-					for (int v = 0; v < 64; ++v) {
-						const int kv = __builtin_amdgcn_readlane(kind, v);
-						if (kv != 1 && kv != 2) continue;                 // (wave-uniform)
-						const long long rv = (long long)(unsigned)__builtin_amdgcn_readlane(rlo, v) | ((long long)__builtin_amdgcn_readlane(rhi, v) << 32);
-						const uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)pc, v);
+					for (int v = 0; v < W; ++v) {
+						const int kv = ch_grp<W>::bcast(kind, v);
+						if (kv != 1 && kv != 2) continue;                 // (uniform over the group)
+						const long long rv = (long long)(unsigned)ch_grp<W>::bcast(rlo, v) | ((long long)ch_grp<W>::bcast(rhi, v) << 32);
+						const uint32_t pv = (uint32_t)ch_grp<W>::bcast((int)pc, v);
 						if (valid) {
 							if (v < lane) {
 								if (kv == 1 && rv <= rbl && (lo == 0 || rv >= ppos) && (kind != 1 || rbl - rv <= o.w)) inter = true;
@@ -816,9 +873,9 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 							if (kv == 1 && kind == 1 && rv < rbl) ++below;
 						}
 					}
-					if (!__any(inter)) {
+					if (!ch_grp<W>::any(inter)) {
 						const bool isnew = kind == 1, ismrg = kind == 2;
-						const unsigned long long lt = (1ull << lane) - 1, mnew = __ballot(isnew), madd = __ballot(isnew || ismrg);
+						const unsigned long long lt = (1ull << lane) - 1, mnew = ch_grp<W>::ballot(isnew), madd = ch_grp<W>::ballot(isnew || ismrg);
 						const uint32_t my_ns = (uint32_t)ns + (uint32_t)__builtin_popcountll(madd & lt), my_nc = (uint32_t)nc + (uint32_t)__builtin_popcountll(mnew & lt);
 						if (isnew || ismrg) { ch_seed_t sd; sd.rbeg = rbl; sd.qbeg = sb; sd.len = slen; sd.next = 0xFFFFFFFFu; sd.pad = 0; S[my_ns] = sd; }
 						if (ismrg) { S[ptail].next = my_ns; CH[pc].tail = my_ns; CH[pc].n += 1; }
@@ -831,12 +888,12 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 							// the K new chains into the sorted index: old entry j moves up by the number of new chains that go at or below it
 							// (chunks from the top, every chunk read before it is written; moved entries never collide: the shift grows with j)
 							int minlo = 0x7FFFFFFF;
-							for (unsigned long long mm = mnew; mm; mm &= mm - 1) { const int lv = __builtin_amdgcn_readlane(lo, (int)__builtin_ctzll(mm)); minlo = lv < minlo ? lv : minlo; }
-							for (int hi = nc; hi > minlo; hi -= 64) {
+							for (unsigned long long mm = mnew; mm; mm &= mm - 1) { const int lv = ch_grp<W>::bcast(lo, (int)__builtin_ctzll(mm)); minlo = lv < minlo ? lv : minlo; }
+							for (int hi = nc; hi > minlo; hi -= W) {
 								const int jj = hi - 1 - lane;
 								uint32_t ov = 0; int64_t op = 0; int sh = 0;
 								if (jj >= minlo) { ov = order[jj]; op = opos[jj]; }
-								for (unsigned long long mm = mnew; mm; mm &= mm - 1) { const int lv = __builtin_amdgcn_readlane(lo, (int)__builtin_ctzll(mm)); sh += lv <= jj ? 1 : 0; }
+								for (unsigned long long mm = mnew; mm; mm &= mm - 1) { const int lv = ch_grp<W>::bcast(lo, (int)__builtin_ctzll(mm)); sh += lv <= jj ? 1 : 0; }
 								ch_wave_fence<LDSX>();
 								if (jj >= minlo && sh) { order[jj + sh] = ov; opos[jj + sh] = op; }
 								ch_wave_fence<LDSX>();
@@ -850,9 +907,9 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 				}
 				CH_ACC_END(6, 9);
 				if (!done) {
-					const int m = n_it - c0 < 64 ? n_it - c0 : 64;
+					const int m = n_it - c0 < W ? n_it - c0 : W;
 					CH_ACC_BEGIN();
-					for (int u = 0; u < m; ++u) seq_one((int64_t)__shfl(rbl, u));
+					for (int u = 0; u < m; ++u) seq_one((int64_t)ch_grp<W>::bcast64(rbl, u));
 					CH_ACC_END(7, 8);
 				}
 			}
@@ -890,13 +947,13 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 	};
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (COOP) {                                                           // one chain per lane, kept in order
-		const int lane = ch_lane();
-		for (int b = 0; b < nc; b += 64) {
+		const int lane = ch_grp<W>::lane();
+		for (int b = 0; b < nc; b += W) {
 			const int i = b + lane;
 			uint32_t ci = 0; int w = -1;
 			if (i < nc) { ci = order[i]; w = weigh(ci); opos[i] |= (int64_t)ci << 40; }       // (position rank -> chain, for the isolation pass below)
 			const bool keep = i < nc && w >= o.min_chain_weight;
-			const unsigned long long m = __ballot(keep);
+			const unsigned long long m = ch_grp<W>::ballot(keep);
 			if (keep) srt[na + __builtin_popcountll(m & ((1ull << lane) - 1))] = (uint64_t)(uint32_t)w << 32 | ci;
 			na += __builtin_popcountll(m);
 		}
@@ -912,8 +969,8 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 	CH_STAMP(2);
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (COOP) {
-		if (!w_introsort_coop<LDSX>(srt, order, na)) { *x.err = 2; return; }
-		if (na < 65536) w_place_coop<LDSX>(srt, order, na);
+		if (!w_introsort_coop<LDSX, W>(srt, order, na)) { *x.err = 2; return; }
+		if (na < 65536) w_place_coop<LDSX, W>(srt, order, na);
 		else {                                                        // (more chains than the 16-bit index of the rank keys holds: a huge -c)
 			w_insertion(srt, 0, na);
 			for (int i = 0; i < na; ++i) order[i] = (uint32_t)srt[i];
@@ -933,8 +990,9 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 	// its 8 bytes per entry hold the kept weights and the class links)
 #ifndef CH_NO_CLASSES
 	// (with ALT contigs whether two chains "overlap" also depends on which of them is ALT, src/bwamem.c:518: not a function of the spans alone)
-	if (COOP && na > 48 && !x.ctg_alt) kept_done = ch_kept_by_classes<LDSX>(o, CH, order, klist, (int32_t *)srt, (uint32_t *)srt + na, cidx, na, nk);
-	if (COOP && na > 48 && !x.ctg_alt && !kept_done) ch_wave_fence<LDSX>();
+	// (the whole wave only: a class is owned by a lane and the minimum runs over the wave's DPP rows; a row's reads have at most 64 chains)
+	if (COOP && W == 64 && na > 48 && !x.ctg_alt) kept_done = ch_kept_by_classes<LDSX>(o, CH, order, klist, (int32_t *)srt, (uint32_t *)srt + na, cidx, na, nk);
+	if (COOP && W == 64 && na > 48 && !x.ctg_alt && !kept_done) ch_wave_fence<LDSX>();
 #endif
 #endif
 	// kept chains: klist[k] = index in the sorted array, ks[k] = {beg, end, w, chain} so the scan reads one entry per k
@@ -968,20 +1026,20 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 		};
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (COOP) {
-			// 256 kept chains per round, four per lane with independent loads; the scan ends behind the first chain that drops
+			// 4 W kept chains per round, four per lane with independent loads; the scan ends behind the first chain that drops
 			// chain i (src/bwamem.c:520-535), the marks of `first` stop there too
-			const int lane = ch_lane();
-			for (int b = 0; b < nk && !broke; b += 256) {
+			const int lane = ch_grp<W>::lane();
+			for (int b = 0; b < nk && !broke; b += 4 * W) {
 				ks_t aj[4]; bool ovl[4]; unsigned long long mb[4], mo[4];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) { const int k = b + 64 * u + lane; aj[u] = ks[k < nk ? k : nk - 1]; }   // four loads in flight
+				for (int u = 0; u < 4; ++u) { const int k = b + W * u + lane; aj[u] = ks[k < nk ? k : nk - 1]; }   // four loads in flight
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
-					const int k = b + 64 * u + lane;
+					const int k = b + W * u + lane;
 					bool brk = false;
 					test(aj[u], ovl[u], brk);
 					ovl[u] = ovl[u] && k < nk; brk = brk && k < nk;
-					mb[u] = __ballot(brk); mo[u] = __ballot(ovl[u]);
+					mb[u] = ch_grp<W>::ballot(brk); mo[u] = ch_grp<W>::ballot(ovl[u]);
 				}
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
@@ -1034,7 +1092,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (COOP) {
 			ch_wave_fence<LDSX>();
-			for (int k = ch_lane(); k < nsd; k += 64) { const uint32_t p = cidx[k]; S[p].pad = (uint32_t)seed_sw(x, r, l_query, S[p]); }
+			for (int k = ch_grp<W>::lane(); k < nsd; k += W) { const uint32_t p = cidx[k]; S[p].pad = (uint32_t)seed_sw(x, r, l_query, S[p]); }
 			ch_wave_fence<LDSX>();
 		} else
 #endif
@@ -1077,10 +1135,10 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 		// covered by a region of ANOTHER chain: the "made before?" scan of its seeds needs the chain's own regions only.  On a
 		// seed-rich read almost every chain is a single seed at its own locus, and the scan over all earlier regions was half of
 		// this phase.  opos still holds the chains in position order (with the chain index in its high bits since the weights).
-		const int lane = ch_lane();
+		const int lane = ch_grp<W>::lane();
 		const int64_t PMASK = ((int64_t)1 << 40) - 1;
 		int64_t run_max = -((int64_t)1 << 60);
-		for (int b = 0; b < nc; b += 64) {
+		for (int b = 0; b < nc; b += W) {
 			const int r = b + lane;
 			int64_t pos = 0, tail = -((int64_t)1 << 60), nextpos = (int64_t)1 << 60; uint32_t ci = 0;
 			if (r < nc) {
@@ -1090,12 +1148,12 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 			}
 			int64_t incl = tail;
 #pragma unroll
-			for (int d = 1; d < 64; d <<= 1) { const int64_t t = __shfl_up(incl, d); if (lane >= d && t > incl) incl = t; }
-			int64_t excl = __shfl_up(incl, 1);
+			for (int d = 1; d < W; d <<= 1) { const int64_t t = ch_grp<W>::shfl_up64(incl, d); if (lane >= d && t > incl) incl = t; }
+			int64_t excl = ch_grp<W>::shfl_up64(incl, 1);
 			if (lane == 0 || excl < run_max) excl = run_max;
 			const bool iso = excl + 2 * (int64_t)l_query < pos && nextpos > tail + 2 * (int64_t)l_query;
 			if (r < nc) CH[ci].pad = iso ? 1u : 0u;
-			const int64_t tot = __shfl(incl, 63);
+			const int64_t tot = ch_grp<W>::bcast64(incl, W - 1);
 			run_max = tot > run_max ? tot : run_max;
 		}
 		ch_wave_fence<LDSX>();
@@ -1109,16 +1167,16 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 			// (their "made before?" scan is empty: no other chain's region can cover the seed and the chain has no earlier region of
 			// its own) -- is handled one chain per lane: the region of such a chain is a function of its seed alone, and its slot is
 			// its rank in the run.  The chains of a seed-rich read are almost all of this kind.
-			const int lane = ch_lane();
+			const int lane = ch_grp<W>::lane();
 			const int i = ia + lane;
 			const bool in = i < na;
 			ch_chain_t cl; cl.kept = 0; cl.n = 0; cl.pad = 0; cl.head = 0;
 			if (in) cl = CH[order[i]];
-			const unsigned long long im = __ballot(in), slow = im & ~__ballot(in && (cl.kept == 0 || (cl.pad != 0 && cl.n == 1)));
+			const unsigned long long im = ch_grp<W>::ballot(in), slow = im & ~ch_grp<W>::ballot(in && (cl.kept == 0 || (cl.pad != 0 && cl.n == 1)));
 			const int run = slow ? (int)__builtin_ctzll(slow) : (int)__builtin_popcountll(im);
 			if (run > 0) {
 				const bool me = lane < run && cl.kept != 0;
-				const unsigned long long mm = __ballot(me);
+				const unsigned long long mm = ch_grp<W>::ballot(me);
 				bool jl = false, jr = false;
 				if (me) {
 					const int idx = n_regs + (int)__builtin_popcountll(mm & ((1ull << lane) - 1));
@@ -1155,7 +1213,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 					jl = t.qbeg > 0; jr = a.rq > 0;
 				}
 				n_regs += (int)__builtin_popcountll(mm);
-				n_jobs += (int)__builtin_popcountll(__ballot(jl)) + (int)__builtin_popcountll(__ballot(jr));
+				n_jobs += (int)__builtin_popcountll(ch_grp<W>::ballot(jl)) + (int)__builtin_popcountll(ch_grp<W>::ballot(jr));
 				ia += run - 1;                                                    // (the loop adds the last one)
 				ch_wave_fence<LDSX>();
 				continue;
@@ -1185,7 +1243,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 		if (rmax0 < l_pac && l_pac < rmax1) { if (s0.rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
 		{   // bns_fetch_seq clips the window to the contig of the first seed (src/bntseq.c:531-556)
 			int is_rev;
-			const int rid = pos2rid<COOP>(x, depos(x, s0.rbeg, &is_rev));
+			const int rid = pos2rid<COOP, W>(x, depos(x, s0.rbeg, &is_rev));
 			int64_t far_beg = x.n_contigs > 1 ? x.ctg_off[rid] : 0, far_end = far_beg + (x.n_contigs > 1 ? x.ctg_len[rid] : l_pac);
 			if (is_rev) { const int64_t tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
 			rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
@@ -1194,7 +1252,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (COOP) ch_wave_fence<LDSX>();
 #endif
-		sort_distinct<COOP, LDSX>(srt, (uint64_t *)(opos), cn);       // opos is free by now (8 bytes per entry)
+		sort_distinct<COOP, LDSX, W>(srt, (uint64_t *)(opos), cn);    // opos is free by now (8 bytes per entry)
 		for (int k = cn - 1; k >= 0; --k) {
 			const ch_seed_t s = S[cidx[(uint32_t)srt[k]]];
 			auto covered = [&](const ch_est_t &p) {                                 // extension (estimated) made before? :1235-1256
@@ -1212,22 +1270,22 @@ template <bool COOP, bool LDSX = false, bool FLT = false> CH_HD void chain_read(
 			int hit = n_regs;
 #if defined(__HIP_DEVICE_COMPILE__)
 			if (COOP) {
-				// 256 regions per round; the four entries of a lane are loaded before any is tested, so the loads overlap
-				const int lane = ch_lane();
-				for (int b = scan_from; b < n_regs && hit == n_regs; b += 256) {
+				// 4 W regions per round; the four entries of a lane are loaded before any is tested, so the loads overlap
+				const int lane = ch_grp<W>::lane();
+				for (int b = scan_from; b < n_regs && hit == n_regs; b += 4 * W) {
 					ch_est_t p4[4]; unsigned long long m[4];
 #pragma unroll
-					for (int u = 0; u < 4; ++u) { const int i = b + 64 * u + lane; p4[u] = E[i < n_regs ? i : n_regs - 1]; }
+					for (int u = 0; u < 4; ++u) { const int i = b + W * u + lane; p4[u] = E[i < n_regs ? i : n_regs - 1]; }
 #pragma unroll
-					for (int u = 0; u < 4; ++u) { const int i = b + 64 * u + lane; m[u] = __ballot(i < n_regs && covered(p4[u])); }
+					for (int u = 0; u < 4; ++u) { const int i = b + W * u + lane; m[u] = ch_grp<W>::ballot(i < n_regs && covered(p4[u])); }
 #pragma unroll
-					for (int u = 3; u >= 0; --u) if (m[u]) hit = b + 64 * u + (int)__builtin_ctzll(m[u]);
+					for (int u = 3; u >= 0; --u) if (m[u]) hit = b + W * u + (int)__builtin_ctzll(m[u]);
 				}
 			} else
 #endif
 			for (int i = 0; i < n_regs; ++i) if (covered(E[i])) { hit = i; break; }
 			if (hit < n_regs) {                                                   // :1258-1276
-				const int j = first_true<COOP>(k + 1, cn, [&](int j) {
+				const int j = first_true<COOP, W>(k + 1, cn, [&](int j) {
 					if (srt[j] == 0) return false;
 					const ch_seed_t t = S[cidx[(uint32_t)srt[j]]];
 					if (t.len < s.len * .95) return false;

@@ -25,7 +25,6 @@ struct ch_outreg_t { int64_t seed_rbeg; int32_t seed_qbeg, seedlen0, job0, job1;
 struct chain_args_t {
 	ch_ctx_t x;
 	uint32_t n_reads, heavy_thresh;
-	uint32_t lane_max;            // class 0 (lane form over its list) takes the reads of heavy_thresh+1 .. lane_max entries
 	uint32_t *heavy_list; uint32_t *heavy_n;
 	uint32_t *need;               // [n_reads] seed occurrences the chaining core will sample
 	uint32_t *light_list, *light_n;   // the reads of the lane kernel by need bin: [CH_N_BINS][n_reads], [CH_N_BINS]
@@ -36,18 +35,22 @@ struct chain_args_t {
 // src/bwamem.c:430-436), not the number located: on an hg38-like genome 0.25 % of the reads carry SMEMs with thousands of
 // occurrences (90 % of all located seeds) of which 500 each are used.  need[r] = that number; it sizes the read's scratch.
 // Reads that need more than heavy_thresh entries go to the wave kernels, one list per LDS size class.
-#define CH_N_CLASSES 10
-#define CH_HYBRID_CLASS 5        // classes from here on keep only the arrays of the sequential phases in LDS
-#define CH_LANE_LIST_MAX 32     // class 0: reads of heavy_thresh+1 .. this many entries, chained one per LANE from their compacted list
-__device__ __forceinline__ int ch_class_of(uint32_t need, uint32_t lane_max) { return need <= lane_max ? 0 : need <= 64u ? 1 : need <= 128u ? 2 : need <= 256u ? 3 : need <= 384u ? 4 : need <= 512u ? 5 : need <= 620u ? 6 : need <= 1250u ? 7 : need <= 1860u ? 8 : 9; }
+#define CH_N_CLASSES 11
+#define CH_HYBRID_CLASS 6        // classes from here on keep only the arrays of the sequential phases in LDS
+#define CH_N_SUB 3               // classes 0 .. 2 (reads of heavy_thresh+1 .. 16, .. 32, .. 64 entries: 115 000 of the 124 000 seed-rich reads of a million at hg38 scale):
+                                 // FOUR READS PER WAVE, a 16-lane row each with its scratch in LDS (chain_sub_kernel, round 6); knob CHAIN_SUB, bit c clear: class c in its
+                                 // round-5 form -- a lane per read over the class's list with global scratch (classes 0, 1), a wave per read (class 2)
+__device__ __forceinline__ int ch_class_of(uint32_t need) { return need <= 16u ? 0 : need <= 32u ? 1 : need <= 64u ? 2 : need <= 128u ? 3 : need <= 256u ? 4 : need <= 384u ? 5 : need <= 512u ? 6 : need <= 620u ? 7 : need <= 1250u ? 8 : need <= 1860u ? 9 : 10; }
 // LDS entries per class; the hybrid classes (512 entries and up) keep only the arrays of the sequential phases in LDS (seeds, chains,
 // the sorted chain index, the sort keys: 84 bytes per entry instead of 124) and the rest in the read's slice of the global scratch:
 // these classes are LDS-bound -- three reads of 620 entries per CU instead of two was worth 1 ms of a 10 ms stage; the last class
 // (a read that samples more than 1860 occurrences: four SMEMs of 465+ hits each) works in global memory altogether
 // (a read that samples one SMEM of 500+ occurrences plus a few more seeds needs 500-600 entries: on the hg38-like genome most of
 // the reads beyond 256 entries sit there, hence the 512 and 620 classes)
-static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {CH_LANE_LIST_MAX, 64u, 128u, 256u, 384u, 512u, 620u, 1250u, 1860u, 0u};
-static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {0u, 8192u, 4096u, 2048u, 1024u, 1024u, 768u, 512u, 256u, 256u};
+static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {16u, 32u, 64u, 128u, 256u, 384u, 512u, 620u, 1250u, 1860u, 0u};
+static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {0u, 0u, 8192u, 4096u, 2048u, 1024u, 1024u, 768u, 512u, 256u, 256u};
+// blocks (one wave, four reads at a time) of chain_sub_kernel per class: about what the chip holds at once (LDS: 4 x cap x 124 bytes a block), the reads dealt round robin
+static const uint32_t CH_SUB_GRID[CH_N_SUB] = {4096u, 2560u, 1280u};
 
 // need, the wave / lane-list class of a seed-rich read -- and, for the reads of the lane kernel, a BIN by need (<= 2, <= 4, <= 8,
 // the rest): the lane kernel walks the bins' compacted lists, so the 64 reads of a wave cost about the same.  In read order every
@@ -82,7 +85,13 @@ __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 			}
 		}
 		A.need[r] = need;
-		bin = need > A.heavy_thresh ? CH_N_BINS + ch_class_of(need, A.lane_max) : ch_bin_of(need);
+		if (need > A.heavy_thresh) {
+			// (the four-per-wave classes stage a read's LOCATED seeds in its scratch: a read that samples few of many -- a small -c -- goes by that count,
+			// to a wave class if need be)
+			int c = ch_class_of(need);
+			if (c < CH_N_SUB && n > need) { const int c2 = ch_class_of(n); c = c2 < CH_N_SUB ? c2 : CH_N_SUB; }
+			bin = CH_N_BINS + c;
+		} else bin = ch_bin_of(need);
 		my = atomicAdd(&l_cnt[bin], 1u);
 		if (need > A.heavy_thresh) atomicAdd(&l_need, need);
 		atomicMax(&l_maxlen, A.x.read_lens[r]);
@@ -222,10 +231,54 @@ __global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_
 		else if (lds_cap) {
 			const ch_scr_t G = chain_core::global_scratch(A.x, r);
 			ch_scr_t H = L; H.E = G.E; H.klist = G.klist; H.cidx = G.cidx;
-			chain_core::chain_read<true, false, FLT>(A.x, r, H);
+			chain_core::chain_read<true, false, FLT, 64, false, 1>(A.x, r, H);
 		} else chain_core::chain_read<true, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 		__builtin_amdgcn_s_waitcnt(0);                           // the read's output stores before the scratch is reused
+	}
+}
+
+// FOUR reads per wave, one per 16-lane row, for the classes of at most 64 entries: the cooperative core with W = 16 (chain_core.h: ch_grp<16>) -- every
+// ballot, broadcast and scan stays inside the row, the rows of a wave diverge freely --, each row's scratch in its own slice of the block's LDS (cap entries of
+// CH_LDS_BYTES_PER_ENTRY bytes), global memory only for the read's seeds and its regions.  These reads used to take a lane each with their scratch in global memory
+// (2.5 ms of dependent round trips per lane, 3 x the stage's algorithmic traffic) or a whole wave for loops that are sixteen wide at most.
+// CTGN > 0: the contig table (at most CTGN sequences) is copied into LDS.
+#define CH_SUB_LDS_CONTIGS 64
+#ifndef CH_SUB_ATTR
+#define CH_SUB_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 registers (148 unconstrained, four spilled): four waves per SIMD; the class of 16 entries alone 0.67 -> 0.47 ms
+#endif
+template <int CTGN, bool FLT>
+__global__ void __launch_bounds__(64) CH_SUB_ATTR chain_sub_kernel(chain_args_t A, uint32_t cls, uint32_t cap)
+{
+	wtrace_scope_t wt_(WT_CHAIN_SUB, cls);
+	extern __shared__ __align__(16) uint8_t ch_lds[];
+	const uint32_t nh = A.heavy_n[cls];
+	if (blockIdx.x * 4u >= nh) return;
+	const uint32_t *list = A.heavy_list + (size_t)cls * A.n_reads;
+	const uint32_t g = threadIdx.x >> 4;
+	ch_scr_t L;
+	{
+		uint8_t *p = ch_lds + (size_t)g * cap * CH_LDS_BYTES_PER_ENTRY;           // (cap is even: every array of a slice starts on an 8-byte boundary)
+		L.opos = (int64_t *)p; p += 8 * (size_t)cap;
+		L.srt = (uint64_t *)p; p += 8 * (size_t)cap;
+		L.CH = (ch_chain_t *)p; p += sizeof(ch_chain_t) * (size_t)cap;
+		L.S = (ch_seed_t *)p; p += sizeof(ch_seed_t) * (size_t)cap;
+		L.order = (uint32_t *)p; p += 4 * (size_t)cap;
+		L.E = (ch_est_t *)p; p += sizeof(ch_est_t) * (size_t)cap;
+		L.klist = (uint32_t *)p; p += 4 * (size_t)cap;
+		L.cidx = (uint32_t *)p;
+	}
+	__shared__ int64_t ctg_off_l[CTGN > 0 ? CTGN : 1];
+	__shared__ int32_t ctg_len_l[CTGN > 0 ? CTGN : 1];
+	if (CTGN > 0) {
+		for (int c = (int)threadIdx.x; c < A.x.n_contigs; c += 64) { ctg_off_l[c] = A.x.ctg_off[c]; ctg_len_l[c] = A.x.ctg_len[c]; }
+		A.x.ctg_off = ctg_off_l; A.x.ctg_len = ctg_len_l;
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0);
+	}
+	for (uint32_t i = blockIdx.x * 4u + g; i < nh; i += gridDim.x * 4u) {
+		// (the read's seed arrays are staged in its scratch: chain_classify_kernel sends no read here that has more located seeds than the class has entries)
+		chain_core::chain_read<true, true, FLT, 16, true>(A.x, list[i], L);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                    // (LDS operations of a wave execute in order; the region stores hold their data already)
 	}
 }
 
@@ -500,7 +553,7 @@ extern "C" void bmh_chain_last_timing(const bmh_chain_ws_t *w, float ms[8])
 	for (int i = 0; i < 4; ++i) ms[i] = w->ms[i];
 	ms[4] = w->ms[4]; ms[5] = w->ms[5];
 	ms[6] = ms[7] = 0.f;                                       // reads chained by a wave: up to 512 entries / beyond
-	for (int c = 0; c < CH_N_CLASSES; ++c) ms[c <= 5 ? 6 : 7] += (float)w->heavy_per_class[c];
+	for (int c = 0; c < CH_N_CLASSES; ++c) ms[c <= 6 ? 6 : 7] += (float)w->heavy_per_class[c];
 }
 
 extern "C" int bmh_chain_set_contigs(bmh_chain_ws_t *w, int n_contigs, const int64_t *offset, const int32_t *len)
@@ -566,10 +619,6 @@ static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_op
 	// (8: measured on the bench workload -- with the 9..16-entry reads on the lane-list stream, beside the first extension pass instead
 	// of ahead of it, the step is 2.5 % shorter than with 16 (five interleaved pairs of runs); paired and 300 bp: no difference)
 	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : 8u;
-	{
-		static const uint32_t lm = [] { const char *e = getenv("BMH_CHAIN_LANE_MAX"); const int v = e ? atoi(e) : CH_LANE_LIST_MAX; return (uint32_t)(v < 0 ? 0 : v > 64 ? 64 : v); }();   // (experiment knob; 0: no lane class)
-		A.lane_max = lm;
-	}
 	A.heavy_list = w->heavy_list; A.heavy_n = w->counters; A.need = w->need;
 	A.light_list = w->heavy_list + (size_t)CH_N_CLASSES * w->max_reads; A.light_n = w->counters + 32;
 	A.need_sum = (unsigned long long *)w->need_sum;
@@ -631,6 +680,12 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 	// batches in flight): the step measured without a class is the ceiling of what a faster kernel for that class can gain.
 	const unsigned replay = (unsigned)bmh_tune("CHAIN_REPLAY_HEAVY", 0);
 	const unsigned wave_prio = (unsigned)bmh_tune("CHAIN_WAVE_PRIO", 0);      // bit c: the waves of size class c raise their priority (s_setprio 3)
+	const unsigned sub_mask = (unsigned)bmh_tune("CHAIN_SUB", (1 << CH_N_SUB) - 1);
+	const bool sub_ctg = w->n_contigs > 1 && w->n_contigs <= CH_SUB_LDS_CONTIGS;
+	if (sub_mask) {
+		const int mx = (int)(4 * (size_t)CH_CLASS_CAP[CH_N_SUB - 1] * CH_LDS_BYTES_PER_ENTRY);
+		HIPCK(hipFuncSetAttribute(sub_ctg ? (const void *)chain_sub_kernel<CH_SUB_LDS_CONTIGS, FLT> : (const void *)chain_sub_kernel<0, FLT>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+	}
 	for (int cls = CH_N_CLASSES - 1; cls >= 0; --cls) {
 		const uint32_t lds_cap = CH_CLASS_CAP[cls];
 		const int hybrid = cls >= CH_HYBRID_CLASS && lds_cap != 0;
@@ -638,11 +693,16 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 		HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->ev_fork, 0));
 		if (serial && cls < CH_N_CLASSES - 1) HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->cls_done[cls + 1], 0));
 		if (replay >> cls & 1u) { }                                                                                       // (ablation: the class's stored output stands)
-		else if (cls == 0) {                                                                                                   // (blocks beyond the list leave at once)
+		else if (cls < CH_N_SUB && (sub_mask >> cls & 1u)) {                                                              // four reads per wave (blocks beyond the list leave at once)
+			const size_t sub_lds = 4 * (size_t)lds_cap * CH_LDS_BYTES_PER_ENTRY;
+			if (sub_ctg) chain_sub_kernel<CH_SUB_LDS_CONTIGS, FLT><<<CH_SUB_GRID[cls], 64, sub_lds, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap);
+			else chain_sub_kernel<0, FLT><<<CH_SUB_GRID[cls], 64, sub_lds, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap);
+		}
+		else if (cls < 2) {                                                                                               // (round-5 form: a lane per read over the class's list)
 			const int ll = bmh_tune("CHAIN_LIST_LANES", CH_LIST_LANES);
 			const uint32_t lanes = (uint32_t)(ll < 1 ? 1 : ll > 64 ? 64 : ll);
 			const unsigned lgrid = nblk((uint64_t)nblk(n_reads, lanes) * 64u, 256);
-			if (list_private && !FLT && A.lane_max <= 32u) chain_lane_list_kernel<FLT, 32><<<lgrid, 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls, lanes);
+			if (list_private && !FLT) chain_lane_list_kernel<FLT, 32><<<lgrid, 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls, lanes);
 			else chain_lane_list_kernel<FLT, 0><<<lgrid, 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls, lanes);
 		}
 		else if (ctg_lds) chain_wave_kernel<true, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid, (int)(wave_prio >> cls & 1u));

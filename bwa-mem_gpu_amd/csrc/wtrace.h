@@ -19,7 +19,7 @@ static __device__ unsigned int g_wt_cap = 0;
 // kernel ids (scripts/wave_residency.py names them)
 enum { WT_FORWARD = 1, WT_BACKWARD = 2, WT_LOCATE = 3, WT_EXPAND = 4, WT_FILTER = 5, WT_PACK = 6, WT_SCATTER = 7,
        WT_EXT_CLOSED = 16, WT_EXT_PK = 17, WT_EXT_PERSIST = 18, WT_EXT_32 = 19,
-       WT_CHAIN_CLASSIFY = 32, WT_CHAIN_LANE = 33, WT_CHAIN_LIST = 34, WT_CHAIN_WAVE = 35, WT_CHAIN_EMIT = 36, WT_CHAIN_MERGE = 37 };
+       WT_CHAIN_CLASSIFY = 32, WT_CHAIN_LANE = 33, WT_CHAIN_LIST = 34, WT_CHAIN_WAVE = 35, WT_CHAIN_EMIT = 36, WT_CHAIN_MERGE = 37, WT_CHAIN_SUB = 38 };
 
 struct wtrace_scope_t {
 	unsigned long long t0;

@@ -15,7 +15,7 @@ import numpy as np
 REC = np.dtype([("kid", "<u4"), ("hw", "<u4"), ("xcc", "<u4"), ("aux", "<u4"), ("t0", "<u8"), ("t1", "<u8")])
 NAMES = {1: "smem_forward", 2: "smem_backward", 3: "locate", 4: "expand", 5: "smem_filter", 6: "pack_reads", 7: "cand_scatter",
          16: "ext_closed_form", 17: "extpk<G,P>", 18: "extpk_persist", 19: "extend16/wide",
-         32: "chain_classify", 33: "chain_lane", 34: "chain_lane_list", 35: "chain_wave", 36: "emit", 37: "merge"}
+         32: "chain_classify", 33: "chain_lane", 34: "chain_lane_list", 35: "chain_wave", 36: "emit", 37: "merge", 38: "chain_sub"}
 FAMILIES = ("seeding", "extension", "chaining")
 
 

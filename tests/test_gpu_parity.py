@@ -578,7 +578,7 @@ def _pack_pac(g):
     return np.ascontiguousarray(np.concatenate([pac, np.zeros(1, np.uint8)]))      # + the .pac tail byte slot
 
 
-def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None, scoring=False):
+def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None, scoring=False, sub=None):
     """reads -> bmh_seed_batch -> bmh_chain_batch -> bmh_extend_batch -> bmh_chain_merge, all in HBM, against the
     host job builder on the same seeds (byte-identical batch) and its merge of the oracle's extension results."""
     import ctypes as C, os, torch
@@ -605,8 +605,12 @@ def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None, scor
     ext_p = B.ExtParams(opt.a, opt.b, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, 0, 5) if scoring else B.ExtParams.default()
     import oracle_py
     ksw_p = oracle_py.KswParams(ext_p.a, ext_p.b, ext_p.o_del, ext_p.e_del, ext_p.o_ins, ext_p.e_ins, 0, 5, 1)
+    # heavy: reads with more sampled seeds than this leave the lane kernel; sub: mask of the classes (<= 16 / 32 / 64 entries) chained four reads per wave
+    # (knob CHAIN_SUB; 0 = their round-5 forms: a lane per read over the class list, a wave per read)
     if heavy is not None:
         os.environ["BMH_CHAIN_HEAVY"] = str(heavy)
+    if sub is not None:
+        os.environ["BMH_CHAIN_SUB"] = str(sub)
     try:
         dj = cw.chain_batch(dindex, r, o, l, s)
     finally:
@@ -653,6 +657,7 @@ def _device_chain_case(B, oracle, g, idx, reads, opt_over=None, heavy=None, scor
         with pytest.raises(RuntimeError, match="capacity"):
             cw.extend_merge(dindex, r, o, l, s, regs3[: hj.n_regs - 1])
     stats = (hj.n_jobs, hj.n_regs, int(dj.n_heavy_reads))
+    os.environ.pop("BMH_CHAIN_SUB", None)
     hj.free(); cw.free(); ws.free(); dindex.free()
     return stats
 
@@ -666,8 +671,11 @@ def test_device_job_builder_matches_host_builder(hip, oracle):
     reads, _ = synth.make_reads(g, 3000, 150, seed=5, sub_rate=0.02, indel_frac=0.2)
     nj, nr, nh = _device_chain_case(hip, oracle, g, idx, reads)
     assert nj > 3000 and nr > 2500
-    _, _, nh = _device_chain_case(hip, oracle, g, idx, reads[:1500], heavy=0)          # all reads by the wave kernel
+    _, _, nh = _device_chain_case(hip, oracle, g, idx, reads[:1500], heavy=0)          # all reads by the cooperative forms: four reads per wave up to 64 entries
     assert nh > 1400
+    _, _, nh = _device_chain_case(hip, oracle, g, idx, reads[:1500], heavy=0, sub=0)   # ... a lane per read over the class lists / a wave per read (the round-5 forms)
+    assert nh > 1400
+    _device_chain_case(hip, oracle, g, idx, reads[:1500], heavy=0, sub=5)              # ... mixed
     reads3, _ = synth.make_reads(g, 1000, 300, seed=6, sub_rate=0.03, indel_frac=0.3)
     _device_chain_case(hip, oracle, g, idx, reads3)
     _device_chain_case(hip, oracle, g, idx, reads[:1500], opt_over=dict(max_occ=3, max_chain_extend=2, min_chain_weight=25, drop_ratio=0.8))
@@ -675,6 +683,7 @@ def test_device_job_builder_matches_host_builder(hip, oracle):
     # (W = 5 and 6 at 150 bp, 13 at 300 bp), lane and wave forms, default and other scores (the local alignment's and the extension's)
     _device_chain_case(hip, oracle, g, idx, reads[:1500], opt_over=dict(min_chain_weight=5))
     _device_chain_case(hip, oracle, g, idx, reads[:800], opt_over=dict(min_chain_weight=5), heavy=0)
+    _device_chain_case(hip, oracle, g, idx, reads[:800], opt_over=dict(min_chain_weight=5), heavy=0, sub=0)
     _device_chain_case(hip, oracle, g, idx, reads3[:500], opt_over=dict(min_chain_weight=13))
     _device_chain_case(hip, oracle, g, idx, reads[:1000], opt_over=dict(min_chain_weight=6, a=2, b=5, o_del=4, e_del=2, o_ins=7, e_ins=1), scoring=True)
     # repeat-rich genome: many copies, little divergence -> reads with hundreds of seeds and chains
@@ -683,6 +692,8 @@ def test_device_job_builder_matches_host_builder(hip, oracle):
     readsr, _ = synth.make_reads(gr, 2000, 150, seed=8, sub_rate=0.01)
     nj, nr, nh = _device_chain_case(hip, oracle, gr, idxr, readsr)
     assert nh > 20, nh
+    _device_chain_case(hip, oracle, gr, idxr, readsr, sub=0)
+    _device_chain_case(hip, oracle, gr, idxr, readsr, heavy=0)                          # the single-seed reads of a repeat-rich genome through the four-per-wave form too
     _device_chain_case(hip, oracle, gr, idxr, readsr[:800], opt_over=dict(min_chain_weight=5))      # seed-rich reads through the filter
     # ragged batch: reads of 30..250 bases (some shorter than a seed), N bases, the edge cases of the seeding tests
     rng = np.random.default_rng(31)

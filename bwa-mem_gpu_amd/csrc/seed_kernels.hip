@@ -150,7 +150,8 @@ __device__ __forceinline__ void cand_append(bool want, const cand_t &c, uint64_t
 #endif
 __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_view_t rv, const uint32_t *__restrict__ lens,
                                                            int min_seed_len, cand_t *__restrict__ out_a, uint64_t *__restrict__ out_k,
-                                                           unsigned long long *counter, uint64_t cap, uint32_t *__restrict__ n_cand)
+                                                           unsigned long long *counter, uint64_t cap, uint32_t *__restrict__ n_cand,
+                                                           unsigned long long *__restrict__ fst, const uint32_t *__restrict__ deal, uint32_t *__restrict__ iters_out)
 {
 	wtrace_scope_t wt_(WT_FORWARD);
 	fmd_wave_prio(f.wave_prio);
@@ -159,6 +160,9 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 	// and the candidate appends, not the lanes that wait for their wave's slowest read)
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	bool live = r < rv.n_reads;
+	// (experiment, knob SEED_FWD_SORT: the reads dealt in the order of a list -- the previous call's reads by their iteration counts, costliest first --, so that
+	// the 64 reads of a wave cost alike; the candidates do not depend on the deal: they are placed by (read, ordinal) afterwards)
+	if (deal && live) r = deal[r];
 	int len = live ? (int)lens[r] : 0;
 	int i = 0, x = 0;
 	uint32_t j = 0;
@@ -173,7 +177,9 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 	uint64_t tp = 0;                 // ST_UNIQ: text index that pairs with read position i
 	int st = live && len > 0 ? ST_START : ST_DONE;
 	cand_cursor_t cc = {0, 0};
+	unsigned it_wave = 0, it_mine = 0;                   // (BMH_SEED_STATS: iterations of the wave / in which this lane's read was still at work)
 	while (__any(st != ST_DONE)) {
+		++it_wave; it_mine += st != ST_DONE ? 1u : 0u;
 		bool want = false;
 		cand_t c = {r, 0, 0, 0};
 		uint64_t ck = 0;
@@ -254,6 +260,11 @@ __global__ void __launch_bounds__(256) smem_forward_kernel(fmd_dev_t f, read_vie
 	}
 	cand_fill_invalid(cc, out_a, cap);
 	if (live) n_cand[r] = j;
+	if (iters_out && live) iters_out[r] = it_mine;
+	if (fst) {       // [0] wave-iterations [1] lane-iterations [2] waves [3] longest wave; [8..40) reads by iterations / 8; [40..64) waves by iterations / 8
+		if (live) { atomicAdd(fst + 1, (unsigned long long)it_mine); atomicAdd(fst + 8 + (it_mine / 8u < 31u ? it_mine / 8u : 31u), 1ull); }
+		if ((threadIdx.x & 63) == 0) { atomicAdd(fst, (unsigned long long)it_wave); atomicAdd(fst + 2, 1ull); atomicMax(fst + 3, (unsigned long long)it_wave); atomicAdd(fst + 40 + (it_wave / 8u < 23u ? it_wave / 8u : 23u), 1ull); }
+	}
 }
 
 // ---------------------------------------------------------------- backward
@@ -288,6 +299,7 @@ __global__ void __launch_bounds__(256) cand_scatter_kernel(const cand_t *__restr
 // adjacent and in step -- and the next launch (RESUME) continues that list with full waves.
 // The list is BWD_NSUB lists, block b appending to list b mod BWD_NSUB (one counter each: appends to a single address run at ~90 per
 // microsecond, 650 000 waves would take 7 ms); a list holds at most the lanes of the blocks that feed it (sub_cap).
+__global__ void __launch_bounds__(256) iota_kernel(uint32_t *__restrict__ v, uint32_t n) { const uint32_t i = blockIdx.x * 256u + threadIdx.x; if (i < n) v[i] = i; }
 #define BWD_NSUB 64
 struct bwd_state_t { uint64_t lo, hi; uint32_t read, t; uint16_t x, end, i, beg; };     // 32 B (a parked lane has i >= 0)
 template <bool RESUME>
@@ -764,6 +776,7 @@ struct bmh_seed_ws {
 	uint64_t *skeys, *skeys2; uint32_t *svals, *svals2;   // SMEM sort
 	bwd_state_t *bwd_state[2]; uint64_t bwd_state_cap;   // parked walks between the phases of the backward search (allocated on first use)
 	uint32_t *bwd_cnt;                                   // [8][BWD_NSUB] list lengths per phase
+	uint32_t *fwd_iters; uint32_t fwd_iters_n;           // experiment SEED_FWD_SORT: iterations of every read in the last forward search
 	void *scan_tmp; size_t scan_tmp_bytes;
 	hipEvent_t ev[8];
 	float ms[7];
@@ -832,7 +845,7 @@ extern "C" void bmh_seed_ws_free(bmh_seed_ws_t *w)
 	if (!w) return;
 	void *ps[] = {w->pk, w->nm, w->cand_a, w->cand_k, w->res_a, w->res_k, w->n_cand, w->cand_base, w->occ,
 	              w->occ_off, w->rows, w->qbeg, w->score, w->n_ref_pos, w->prefix, w->counter, w->scan_tmp,
-	              w->scratch, w->skeys, w->skeys2, w->svals, w->svals2, w->bwd_state[0], w->bwd_state[1], w->bwd_cnt};
+	              w->scratch, w->skeys, w->skeys2, w->svals, w->svals2, w->bwd_state[0], w->bwd_state[1], w->bwd_cnt, w->fwd_iters};
 	for (void *p : ps) if (p) (void)hipFree(p);
 	for (int i = 0; i < 8; ++i) if (w->ev[i]) (void)hipEventDestroy(w->ev[i]);
 	if (w->st_hi) (void)hipStreamDestroy(w->st_hi);
@@ -1010,7 +1023,36 @@ static int seed_batch_on(bmh_seed_ws_t *w, const bmh_index_t *idx, const uint8_t
 	HIPCK(hipEventRecord(w->ev[1], st));
 	HIPCK(hipMemsetAsync(w->counter, 0, 8, st));
 	HIPCK(hipMemsetAsync(w->n_cand + n_reads, 0, 4, st));
-	smem_forward_kernel<<<nblk(n_reads, 256), 256, lds_pad, st>>>(f, rv, d_lens, min_seed_len, w->cand_a, w->cand_k, w->counter, w->max_cands, w->n_cand);
+	{
+		static const bool fwd_stats = getenv("BMH_SEED_STATS") != nullptr;
+		unsigned long long *d_fst = fwd_stats ? (unsigned long long *)w->counter + 64 : nullptr;
+		if (fwd_stats) HIPCK(hipMemsetAsync(d_fst, 0, 64 * 8, st));
+		// experiment SEED_FWD_SORT (1: deal by the previous call's iteration counts -- the same batch again is then an ideally sorted deal)
+		const uint32_t *d_deal = nullptr; uint32_t *d_iters = nullptr;
+		if (bmh_tune("SEED_FWD_SORT", 0)) {
+			if (!w->fwd_iters) HIPCK(hipMalloc((void **)&w->fwd_iters, 4 * ((size_t)w->max_reads + 1)));
+			uint32_t *k0 = (uint32_t *)w->skeys, *k1 = (uint32_t *)w->skeys2;
+			if (w->fwd_iters_n == n_reads) {
+				iota_kernel<<<nblk(n_reads, 256), 256, 0, st>>>(w->svals, n_reads);
+				HIPCK(hipMemcpyAsync(k0, w->fwd_iters, 4 * (size_t)n_reads, hipMemcpyDeviceToDevice, st));
+				size_t tb = w->scan_tmp_bytes;
+				HIPCK(rocprim::radix_sort_pairs_desc(w->scan_tmp, tb, k0, k1, w->svals, w->svals2, (size_t)n_reads, 0, 32, st));
+				d_deal = w->svals2;
+			}
+			d_iters = w->fwd_iters; w->fwd_iters_n = n_reads;
+		}
+		smem_forward_kernel<<<nblk(n_reads, 256), 256, lds_pad, st>>>(f, rv, d_lens, min_seed_len, w->cand_a, w->cand_k, w->counter, w->max_cands, w->n_cand, d_fst, d_deal, d_iters);
+		if (fwd_stats) {
+			unsigned long long h[64];
+			HIPCK(hipStreamSynchronize(st));
+			HIPCK(hipMemcpy(h, d_fst, sizeof(h), hipMemcpyDeviceToHost));
+			fprintf(stderr, "[forward] reads %u, waves %llu, wave-iterations %llu (%.1f per wave, longest %llu), lane-iterations %llu (%.1f per read): lane utilisation %.1f%%\n", n_reads, h[2], h[0],
+			        (double)h[0] / (h[2] ? h[2] : 1), h[3], h[1], (double)h[1] / (n_reads ? n_reads : 1), 100.0 * h[1] / (64.0 * (h[0] ? h[0] : 1)));
+			fprintf(stderr, "[forward] reads by iterations (0-7, 8-15, .. 248+):"); for (int q = 0; q < 32; ++q) fprintf(stderr, " %llu", h[8 + q]);
+			fprintf(stderr, "\n[forward] waves by iterations (0-7, .. 184+):"); for (int q = 0; q < 24; ++q) fprintf(stderr, " %llu", h[40 + q]);
+			fprintf(stderr, "\n");
+		}
+	}
 	HIPCK(hipEventRecord(w->ev[2], st));
 	{
 		size_t tb = w->scan_tmp_bytes;

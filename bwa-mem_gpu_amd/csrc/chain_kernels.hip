@@ -35,19 +35,26 @@ struct chain_args_t {
 // src/bwamem.c:430-436), not the number located: on an hg38-like genome 0.25 % of the reads carry SMEMs with thousands of
 // occurrences (90 % of all located seeds) of which 500 each are used.  need[r] = that number; it sizes the read's scratch.
 // Reads that need more than heavy_thresh entries go to the wave kernels, one list per LDS size class.
+#ifndef CH_HEAVY_DEFAULT
+#define CH_HEAVY_DEFAULT 12u
+#endif
 #define CH_N_CLASSES 11
 #define CH_HYBRID_CLASS 6        // classes from here on keep only the arrays of the sequential phases in LDS
 #define CH_N_SUB 3               // classes 0 .. 2 (reads of heavy_thresh+1 .. 16, .. 32, .. 64 entries: 115 000 of the 124 000 seed-rich reads of a million at hg38 scale):
                                  // FOUR READS PER WAVE, a 16-lane row each with its scratch in LDS (chain_sub_kernel, round 6); knob CHAIN_SUB, bit c clear: class c in its
                                  // round-5 form -- a lane per read over the class's list with global scratch (classes 0, 1), a wave per read (class 2)
-__device__ __forceinline__ int ch_class_of(uint32_t need) { return need <= 16u ? 0 : need <= 32u ? 1 : need <= 64u ? 2 : need <= 128u ? 3 : need <= 256u ? 4 : need <= 384u ? 5 : need <= 512u ? 6 : need <= 620u ? 7 : need <= 1250u ? 8 : need <= 1860u ? 9 : 10; }
+#ifndef CH_SUB_CAP0
+#define CH_SUB_CAP0 16u          // (even numbers: the arrays of a row's slice start on 8-byte boundaries)
+#define CH_SUB_CAP1 32u
+#endif
+__device__ __forceinline__ int ch_class_of(uint32_t need) { return need <= CH_SUB_CAP0 ? 0 : need <= CH_SUB_CAP1 ? 1 : need <= 64u ? 2 : need <= 128u ? 3 : need <= 256u ? 4 : need <= 384u ? 5 : need <= 512u ? 6 : need <= 620u ? 7 : need <= 1250u ? 8 : need <= 1860u ? 9 : 10; }
 // LDS entries per class; the hybrid classes (512 entries and up) keep only the arrays of the sequential phases in LDS (seeds, chains,
 // the sorted chain index, the sort keys: 84 bytes per entry instead of 124) and the rest in the read's slice of the global scratch:
 // these classes are LDS-bound -- three reads of 620 entries per CU instead of two was worth 1 ms of a 10 ms stage; the last class
 // (a read that samples more than 1860 occurrences: four SMEMs of 465+ hits each) works in global memory altogether
 // (a read that samples one SMEM of 500+ occurrences plus a few more seeds needs 500-600 entries: on the hg38-like genome most of
 // the reads beyond 256 entries sit there, hence the 512 and 620 classes)
-static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {16u, 32u, 64u, 128u, 256u, 384u, 512u, 620u, 1250u, 1860u, 0u};
+static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {CH_SUB_CAP0, CH_SUB_CAP1, 64u, 128u, 256u, 384u, 512u, 620u, 1250u, 1860u, 0u};
 static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {0u, 0u, 8192u, 4096u, 2048u, 1024u, 1024u, 768u, 512u, 256u, 256u};
 // blocks (one wave, four reads at a time) of chain_sub_kernel per class: about what the chip holds at once (LDS: 4 x cap x 124 bytes a block), the reads dealt round robin
 static const uint32_t CH_SUB_GRID[CH_N_SUB] = {4096u, 2560u, 1280u};
@@ -616,9 +623,9 @@ static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_op
 	A.x.g.E = w->est; A.x.regs = w->regs; A.x.regs_per_read = w->regs_per_read; A.x.jobs_per_read = w->jobs_per_read; A.x.frac_rep = w->frac_rep; A.x.err = (int *)(w->counters + CH_N_CLASSES);
 	A.n_reads = n_reads;
 	const char *ht = getenv("BMH_CHAIN_HEAVY");
-	// (8: measured on the bench workload -- with the 9..16-entry reads on the lane-list stream, beside the first extension pass instead
-	// of ahead of it, the step is 2.5 % shorter than with 16 (five interleaved pairs of runs); paired and 300 bp: no difference)
-	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : 8u;
+	// (round 3: 8 -- with the 9..16-entry reads on the lane-list stream, beside the first extension pass instead of ahead of it, the step was 2.5 % shorter than
+	// with 16; round 6, with those reads chained four per wave: 12 -- 25.4-25.6 against 25.7-26.1 ms per step with 8, three interleaved rounds, 10 and 14 between)
+	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : CH_HEAVY_DEFAULT;
 	A.heavy_list = w->heavy_list; A.heavy_n = w->counters; A.need = w->need;
 	A.light_list = w->heavy_list + (size_t)CH_N_CLASSES * w->max_reads; A.light_n = w->counters + 32;
 	A.need_sum = (unsigned long long *)w->need_sum;
@@ -668,6 +675,7 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 		}
 		if ((lane_lds_env & 15) != 15) chain_lane_kernel<false, 0><<<nblk(n_reads, 256), 256, 0, st>>>(A, (uint32_t)lane_lds_env);
 	} else if (lane_private && !FLT && A.heavy_thresh <= 8u) chain_lane_kernel<FLT, 8><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
+	else if (lane_private && !FLT && A.heavy_thresh <= 12u) chain_lane_kernel<FLT, 12><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
 	else if (lane_private && !FLT && A.heavy_thresh <= 16u) chain_lane_kernel<FLT, 16><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
 	else chain_lane_kernel<FLT, 0><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
 	HIPCK(hipEventRecord(w->ev_t[2], st));

@@ -876,6 +876,10 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
         cuts4 = [((n4 * k // nb4) & ~1) for k in range(nb4)] + [n4]
         nat = NativeAligner(dindex, pac_h, len(g), contigs, None, co, params, po, pe_o)
         nbytes = [0]
+        # the letters in REGISTERED host memory (bmh_host_pin = hipHostRegister, once, before the runs): the batches go to the device straight from the caller's
+        # buffer, as the batches of a read file go from the loader's pinned buffers; BENCH_SAM_PIN=0: pageable, staged by the lanes' host threads as until round 5
+        L.bmh_host_pin.argtypes = [C.c_void_p, C.c_size_t]; L.bmh_host_unpin.argtypes = [C.c_void_p]
+        pinned_reads = os.environ.get("BENCH_SAM_PIN", "1") != "0" and L.bmh_host_pin(asc.ctypes.data, asc.nbytes) == 0
 
         def sink(mv):
             nbytes[0] += len(mv)
@@ -923,11 +927,21 @@ def downstream_stages(L, dindex, dr, cw, regs_out, n_regs, n_reads, g, pac_t, re
         except Exception as e:                              # noqa: BLE001
             file_row = {"file_to_sam_native": {"error": repr(e)}}
         nat.free()
+        if pinned_reads:
+            L.bmh_host_unpin(asc.ctypes.data)
+        gbs = lambda b, t: round(b / t / 1e9, 1) if t > 0 else None
         sam_row = {**file_row, "reads_to_sam_native": {"Mreads_per_s": round(n4 / st_n.seconds / 1e6, 2), "ms": round(st_n.seconds * 1e3, 1), "reads": int(n4), "sam_bytes": int(nbytes[0]), "batches": nb4, "lanes": lanes_n,
                                            "runs_ms": [round(t[0] * 1e3, 1) for t in runs_n], "row_is": "median",
                                            "host_cpu_ms_per_million_reads": round((c1 - c0) / (n4 / 1e6), 1), "writer_format_ms": round(st_n.format_seconds * 1e3, 1),
                                            "lanes_ms_summed": {"h2d": round(st_n.h2d_seconds * 1e3, 1), "seeding": round(st_n.seed_seconds * 1e3, 1), "chain_extend_merge": round(st_n.chain_extend_seconds * 1e3, 1),
-                                                               "tail": round(st_n.tail_seconds * 1e3, 1), "select": round(st_n.select_seconds * 1e3, 1), "cigar_text_d2h": round(st_n.cigar_seconds * 1e3, 1)},
+                                                               "tail": round(st_n.tail_seconds * 1e3, 1), "select": round(st_n.select_seconds * 1e3, 1), "cigar_text_d2h": round(st_n.cigar_seconds * 1e3, 1),
+                                                               "wait_for_a_device_slot": round(st_n.gate_wait_seconds * 1e3, 1)},
+                                           "copies": {"h2d_bytes": int(st_n.h2d_bytes), "h2d_ms": round(st_n.h2d_copy_seconds * 1e3, 2), "h2d_GBps": gbs(st_n.h2d_bytes, st_n.h2d_copy_seconds),
+                                                      "d2h_bytes": int(st_n.d2h_bytes), "d2h_ms": round(st_n.d2h_copy_seconds * 1e3, 2), "d2h_GBps": gbs(st_n.d2h_bytes, st_n.d2h_copy_seconds),
+                                                      "reads_in_registered_host_memory": bool(pinned_reads),
+                                                      "how": "HIP events on the lanes' streams around the copies themselves (reads + offsets + names in, SAM text out; the lanes' copies share the link "
+                                                             "with each other).  lanes_ms_summed.h2d / .cigar_text_d2h are HOST clocks around whole stages -- the staging of offsets and names on host "
+                                                             "threads, the CIGAR and text kernels the host waits for -- not copy times"},
                                            "what": "bmh_aligner_run: ASCII reads in host memory -> H2D -> seeding -> chaining -> extension -> merge -> region tail -> selection of the records -> "
                                                    "CIGAR / NM / MD -> the SAM text written on the device (bmh_sam_text_*; interleaved pairs: the region tail of mem_sam_pe on host threads in between) -> "
                                                    "D2H of the text -> a sink that counts it; the same text the golden SAM tests compare with the reference's"}}

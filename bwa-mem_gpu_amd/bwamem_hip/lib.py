@@ -23,7 +23,7 @@ def lib_path() -> str:
 EXPORTED_SYMBOLS = [
     "bmh_last_error", "bmh_device_count", "bmh_set_device", "bmh_index_upload", "bmh_index_from_device",
     "bmh_index_free", "bmh_index_probe", "bmh_index_replicate", "bmh_rccl_where", "bmh_rccl_unique_id", "bmh_rccl_comm_init_rank", "bmh_rccl_comm_destroy", "bmh_index_broadcast_rccl", "bmh_index_replicate_all", "bmh_shard_range", "bmh_index_densify_sa", "bmh_index_build", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
-    "bmh_extend_batch", "bmh_extend_last_ms", "bmh_extend_last_unsupported", "bmh_extend_set_packed", "bmh_tune_set", "bmh_wtrace_start", "bmh_wtrace_stop", "bmh_wtrace_kept", "bmh_extend_release", "bmh_finalize_release", "bmh_matesw_release", "bmh_calib_gather", "bmh_calib_valu", "bmh_calib_valu_placed", "bmh_calib_last_clock",
+    "bmh_host_pin", "bmh_host_unpin", "bmh_extend_batch", "bmh_extend_last_ms", "bmh_extend_last_unsupported", "bmh_extend_set_packed", "bmh_tune_set", "bmh_wtrace_start", "bmh_wtrace_stop", "bmh_wtrace_kept", "bmh_extend_release", "bmh_finalize_release", "bmh_matesw_release", "bmh_calib_gather", "bmh_calib_valu", "bmh_calib_valu_placed", "bmh_calib_last_clock",
     "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_finalize_regs_device", "bmh_finalize_regs_device_last_ms", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
     "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_finalize_pairs_dev", "bmh_dedup_regs_device", "bmh_finalize_pairs_deduped", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
     "bmh_chain_opt_default", "bmh_chain_last_timing", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
@@ -100,7 +100,8 @@ def load_fasta_reads(path: str, n_threads: int = 0) -> dict:
 class AlignStats(C.Structure):
     """bmh_align_stats_t"""
     _fields_ = [("n_reads", C.c_uint64), ("n_bytes", C.c_uint64), ("n_batches", C.c_uint32), ("n_lanes", C.c_int)] + \
-               [(n, C.c_double) for n in ("seconds", "format_seconds", "h2d_seconds", "seed_seconds", "chain_extend_seconds", "tail_seconds", "select_seconds", "cigar_seconds", "gate_wait_seconds")]
+               [(n, C.c_double) for n in ("seconds", "format_seconds", "h2d_seconds", "seed_seconds", "chain_extend_seconds", "tail_seconds", "select_seconds", "cigar_seconds", "gate_wait_seconds", "h2d_copy_seconds", "d2h_copy_seconds")] + \
+               [("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64)]
 
 
 SAM_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)

@@ -133,8 +133,12 @@ struct lane_t {
 	dbuf_t<char> d_names, d_text, d_ctg_names; dbuf_t<uint64_t> d_name_off, d_text_off; dbuf_t<uint32_t> d_ctg_name_off; dbuf_t<int64_t> d_ctg_off; bool ctg_up = false;
 	hbuf_t<uint32_t> h_offs, h_sel, h_rpr; hbuf_t<int32_t> h_regs; hbuf_t<float> h_fr; hbuf_t<uint8_t> h_need, h_reads; hbuf_t<char> h_names; hbuf_t<uint64_t> h_name_off;
 	double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // h2d, seed, chain+extend+merge, tail, select, cigar + d2h, wait at the gate
+	// the copies themselves, timed by events on the lane's stream (what t[0] and t[5] are NOT: those are host clocks around the whole stage -- the staging of the
+	// letters, offsets and names on host threads / the CIGAR and text kernels the host waits for): [0] reads, offsets, names H2D  [1] SAM text D2H
+	hipEvent_t ev_c[4] = {nullptr, nullptr, nullptr, nullptr}; double copy_ms[2] = {0, 0}; uint64_t copy_bytes[2] = {0, 0}; bool d2h_marked = false;
 	~lane_t()
 	{
+		for (hipEvent_t e : ev_c) if (e) (void)hipEventDestroy(e);
 		if (sws) bmh_seed_ws_free(sws);
 		if (cws) bmh_chain_ws_free(cws);
 		if (st) { bmh_extend_release(st); (void)hipStreamDestroy(st); }
@@ -233,7 +237,12 @@ int text_on_device(const aligner_t &A, lane_t &Ln, const bmh_post_opt_t &po, con
 	if (total < 0) return (int)total;
 	RCK(Ln.d_text.need((size_t)total + 1)); RCK(R.text.need((size_t)total + 1));
 	RCK(bmh_sam_text_write(&po, &d, Ln.d_text_off.p, Ln.d_text.p, Ln.d_work.p, Ln.d_work.cap, Ln.st));
-	if (total) LCK(hipMemcpyAsync(R.text.p, Ln.d_text.p, (size_t)total, hipMemcpyDeviceToHost, Ln.st));
+	if (total) {
+		LCK(hipEventRecord(Ln.ev_c[2], Ln.st));
+		LCK(hipMemcpyAsync(R.text.p, Ln.d_text.p, (size_t)total, hipMemcpyDeviceToHost, Ln.st));
+		LCK(hipEventRecord(Ln.ev_c[3], Ln.st));
+		Ln.copy_bytes[1] += (uint64_t)total; Ln.d2h_marked = true;
+	}
 	RCK(bmh_sam_text_check(Ln.d_work.p, n, Ln.st));
 	R.text_len = (uint64_t)total; R.has_text = true;
 	return BMH_OK;
@@ -447,12 +456,14 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 	RCK(Ln.d_reads.need(nb + 16)); RCK(Ln.d_offs.need(n + 1)); RCK(Ln.d_lens.need(n + 1)); RCK(Ln.h_offs.need(n + 1));
 	Ln.max_read_len = 0;
 	for (uint32_t r = 0; r < n; ++r) { Ln.h_offs.p[r] = (uint32_t)(rs.offs[b0 + r] - a0); if (rs.lens[b0 + r] > Ln.max_read_len) Ln.max_read_len = rs.lens[b0 + r]; }
-	if (src_pinned) LCK(hipMemcpyAsync(Ln.d_reads.p, rs.ascii + a0, nb, hipMemcpyHostToDevice, Ln.st));       // (a batch of a read file: filled into pinned memory by the loader)
-	else {
-		RCK(Ln.h_reads.need(nb + 16));
-		par_memcpy(Ln.h_reads.p, rs.ascii + a0, nb, n_threads);       // (pageable -> pinned by this lane's threads, then one DMA: the lanes stage side by side)
-		LCK(hipMemcpyAsync(Ln.d_reads.p, Ln.h_reads.p, nb, hipMemcpyHostToDevice, Ln.st));
-	}
+	for (hipEvent_t &e : Ln.ev_c) if (!e) LCK(hipEventCreate(&e));
+	Ln.d2h_marked = false;
+	uint64_t h2d_bytes = nb + 8 * (uint64_t)n;
+	if (!src_pinned) RCK(Ln.h_reads.need(nb + 16));
+	if (!src_pinned) par_memcpy(Ln.h_reads.p, rs.ascii + a0, nb, n_threads);       // (pageable -> pinned by this lane's threads, then one DMA: the lanes stage side by side)
+	LCK(hipEventRecord(Ln.ev_c[0], Ln.st));
+	if (src_pinned) LCK(hipMemcpyAsync(Ln.d_reads.p, rs.ascii + a0, nb, hipMemcpyHostToDevice, Ln.st));       // (pinned or registered host memory -- a batch of a read file filled by the loader, a caller's registered buffer: no staging copy)
+	else LCK(hipMemcpyAsync(Ln.d_reads.p, Ln.h_reads.p, nb, hipMemcpyHostToDevice, Ln.st));
 	LCK(hipMemcpyAsync(Ln.d_offs.p, Ln.h_offs.p, 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
 	LCK(hipMemcpyAsync(Ln.d_lens.p, rs.lens + b0, 4 * (size_t)n, hipMemcpyHostToDevice, Ln.st));
 	// the text is written on the device (bmh_sam_text_*): the names go along
@@ -468,7 +479,10 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 		Ln.h_name_off.p[n] = n1 - n0;
 		LCK(hipMemcpyAsync(Ln.d_names.p, Ln.h_names.p, n1 - n0, hipMemcpyHostToDevice, Ln.st));
 		LCK(hipMemcpyAsync(Ln.d_name_off.p, Ln.h_name_off.p, 8 * ((size_t)n + 1), hipMemcpyHostToDevice, Ln.st));
+		h2d_bytes += (n1 - n0) + 8 * ((uint64_t)n + 1);
 	}
+	LCK(hipEventRecord(Ln.ev_c[1], Ln.st));
+	Ln.copy_bytes[0] += h2d_bytes;
 	// ---- seeding
 	if (!Ln.sws || n > Ln.sws_reads || nb > Ln.sws_bases) {
 		if (Ln.sws) bmh_seed_ws_free(Ln.sws);
@@ -665,6 +679,11 @@ int run_batch(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, uint32_t
 	if (dev_text_now) RCK(text_on_device(A, Ln, po, d_fin, n, paired, R));
 	LCK(hipStreamSynchronize(Ln.st2));
 	if (sb.on) LCK(hipStreamSynchronize(Ln.st));                   // (the priority stream is idle before the lane's own takes its place again)
+	{
+		float ms = 0.f;
+		if (hipEventSynchronize(Ln.ev_c[1]) == hipSuccess && hipEventElapsedTime(&ms, Ln.ev_c[0], Ln.ev_c[1]) == hipSuccess) Ln.copy_ms[0] += ms;
+		if (Ln.d2h_marked && hipEventSynchronize(Ln.ev_c[3]) == hipSuccess && hipEventElapsedTime(&ms, Ln.ev_c[2], Ln.ev_c[3]) == hipSuccess) Ln.copy_ms[1] += ms;
+	}
 	Ln.t[5] += now_s() - t5;
 	return BMH_OK;
 }
@@ -751,6 +770,7 @@ static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int pair
 	int first_rc = BMH_OK; std::string first_err;
 	auto fail = [&](int rc, const char *msg) { { std::lock_guard<std::mutex> lk(mu); if (first_rc == BMH_OK) { first_rc = rc; first_err = msg ? msg : ""; } cv.notify_all(); } if (src.stop) src.stop(); };
 	std::vector<double> lane_t_sum(8, 0.0);
+	double copy_sum[2] = {0, 0}; uint64_t copy_bytes_sum[2] = {0, 0};
 	if (h->dev >= 0 && h->dev != dev) { bmh_set_error("%s: the aligner's lanes live on device %d, the current device is %d", fn, h->dev, dev); return BMH_EINVAL; }
 	h->dev = dev;
 	while ((int)h->lanes.size() < n_lanes) {
@@ -768,7 +788,7 @@ static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int pair
 		}
 		h->lanes.push_back(std::move(ln));
 	}
-	for (auto &ln : h->lanes) for (double &v : ln->t) v = 0.0;
+	for (auto &ln : h->lanes) { for (double &v : ln->t) v = 0.0; ln->copy_ms[0] = ln->copy_ms[1] = 0.0; ln->copy_bytes[0] = ln->copy_bytes[1] = 0; }
 	auto worker = [&](int lane_index) {
 		if (hipSetDevice(dev) != hipSuccess) { fail(BMH_ENODEV, "hipSetDevice failed in a worker thread"); return; }
 		lane_t &Ln = *h->lanes[(size_t)lane_index];
@@ -801,6 +821,7 @@ static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int pair
 		}
 		std::lock_guard<std::mutex> lk(mu);
 		for (int k = 0; k < 8; ++k) lane_t_sum[(size_t)k] += Ln.t[k];
+		for (int k = 0; k < 2; ++k) { copy_sum[k] += Ln.copy_ms[k]; copy_bytes_sum[k] += Ln.copy_bytes[k]; }
 		--workers_alive;                                             // (the writer ends when every worker has: a batch that was taken is in `done` by then)
 		cv.notify_all();
 	};
@@ -867,7 +888,25 @@ static int run_core(bmh_aligner_t *h, batch_src_t &src, const char *fn, int pair
 		stats->seconds = now_s() - t_start; stats->format_seconds = t_format;
 		stats->h2d_seconds = lane_t_sum[0]; stats->seed_seconds = lane_t_sum[1]; stats->chain_extend_seconds = lane_t_sum[2]; stats->tail_seconds = lane_t_sum[3];
 		stats->select_seconds = lane_t_sum[4]; stats->cigar_seconds = lane_t_sum[5]; stats->gate_wait_seconds = lane_t_sum[6];
+		stats->h2d_copy_seconds = copy_sum[0] * 1e-3; stats->d2h_copy_seconds = copy_sum[1] * 1e-3; stats->h2d_bytes = copy_bytes_sum[0]; stats->d2h_bytes = copy_bytes_sum[1];
 	}
+	return BMH_OK;
+}
+
+// page-locks (registers) a caller's host buffer so that the device copies straight out of it / releases it; what bmh_aligner_run does with a read set whose
+// letters lie in such memory: no staging copy
+int bmh_host_pin(void *p, size_t bytes)
+{
+	if (!p || !bytes) { bmh_set_error("bmh_host_pin: null argument"); return BMH_EINVAL; }
+	const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+	if (e != hipSuccess) { bmh_set_error("bmh_host_pin: hipHostRegister of %zu bytes: %s", bytes, hipGetErrorString(e)); (void)hipGetLastError(); return BMH_ENODEV; }
+	return BMH_OK;
+}
+int bmh_host_unpin(void *p)
+{
+	if (!p) return BMH_OK;
+	const hipError_t e = hipHostUnregister(p);
+	if (e != hipSuccess) { bmh_set_error("bmh_host_unpin: %s", hipGetErrorString(e)); (void)hipGetLastError(); return BMH_ENODEV; }
 	return BMH_OK;
 }
 
@@ -885,12 +924,24 @@ int bmh_aligner_run(bmh_aligner_t *h, const bmh_read_set_t *rs, const uint64_t *
 	for (uint64_t r = 0; r < rs->n_reads; ++r)
 		if (rs->lens[r] > 700) { bmh_set_error("bmh_aligner_run: read %llu has %u bases: reads beyond 700 go through the host job builder (bmh_build_jobs)", (unsigned long long)r, rs->lens[r]); return BMH_EINVAL; }
 	if ((uint32_t)n_lanes > n_batches) n_lanes = (int)n_batches;
+	// the letters in pinned or registered host memory (hipHostMalloc, hipHostRegister / bmh_host_pin): the batches go to the device straight from there --
+	// no staging copy into the lane's pinned buffer on host threads
+	bool ascii_pinned = false;
+	{
+		hipPointerAttribute_t pa; memset(&pa, 0, sizeof(pa));
+		const uint8_t *last = rs->ascii + (rs->n_bases ? rs->n_bases - 1 : 0);
+		if (hipPointerGetAttributes(&pa, rs->ascii) == hipSuccess && pa.type == hipMemoryTypeHost) {
+			hipPointerAttribute_t pb; memset(&pb, 0, sizeof(pb));
+			ascii_pinned = hipPointerGetAttributes(&pb, last) == hipSuccess && pb.type == hipMemoryTypeHost;
+		}
+		(void)hipGetLastError();                                   // (an ordinary pointer: the query fails, and that is the answer)
+	}
 	std::atomic<uint32_t> next_batch{0};
 	batch_src_t src;
 	src.next = [&](batch_t &bt) {
 		const uint32_t b = next_batch.fetch_add(1);
 		if (b >= n_batches) return 0;
-		bt.index = b; bt.rs = rs; bt.b0 = (uint32_t)cuts[b]; bt.b1 = (uint32_t)cuts[b + 1]; bt.id0 = (int64_t)cuts[b]; bt.pinned = false; bt.token = nullptr;
+		bt.index = b; bt.rs = rs; bt.b0 = (uint32_t)cuts[b]; bt.b1 = (uint32_t)cuts[b + 1]; bt.id0 = (int64_t)cuts[b]; bt.pinned = ascii_pinned; bt.token = nullptr;
 		return 1;
 	};
 	return run_core(h, src, "bmh_aligner_run", paired, n_lanes, n_threads, sink, user, stats);

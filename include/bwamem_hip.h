@@ -582,7 +582,14 @@ typedef struct {
 	double format_seconds;          /* in the writer thread (overlaps the workers) */
 	double h2d_seconds, seed_seconds, chain_extend_seconds, tail_seconds, select_seconds, cigar_seconds;    /* summed over the lanes' host clocks */
 	double gate_wait_seconds;       /* lanes waiting for a slot in the path's device stages (ALIGNER_GPU_SLOTS), summed likewise */
+	/* the copies themselves, timed by HIP events on the lanes' streams (h2d_seconds / cigar_seconds above are HOST clocks around whole stages: the staging of
+	 * letters, offsets and names on host threads; the CIGAR and text kernels the host waits for): reads + offsets + names in, SAM text out */
+	double h2d_copy_seconds, d2h_copy_seconds; uint64_t h2d_bytes, d2h_bytes;
 } bmh_align_stats_t;
+/* Page-locks a caller's host buffer (hipHostRegister) / releases it.  bmh_aligner_run sends the batches of a read set whose letters lie in pinned or registered
+ * memory to the device straight from there (no staging copy on host threads). */
+int bmh_host_pin(void *p, size_t bytes);
+int bmh_host_unpin(void *p);
 bmh_aligner_t *bmh_aligner_create(const bmh_index_t *idx, const uint8_t *pac, int64_t l_pac, int n_contigs, const char *const *contig_names,
                                   const int32_t *contig_len, const uint8_t *contig_is_alt, const bmh_chain_opt_t *copt, const bmh_ext_params_t *ep,
                                   const bmh_post_opt_t *popt, const bmh_pe_opt_t *pe);

@@ -47,6 +47,8 @@ if n_alt:
     is_alt = np.zeros(len(contigs), np.uint8); is_alt[-n_alt:] = 1
     print("ALT contigs:", [c[0] for c in contigs[-n_alt:]], "%.1f %% of the genome" % (100.0 * sum(c[1] for c in contigs[-n_alt:]) / len(g)), flush=True)
 nat = NativeAligner(dindex, pac_h, len(g), contigs, is_alt, co, params, po, pe_o)
+L.bmh_host_pin.argtypes = [C.c_void_p, C.c_size_t]
+pinned = os.environ.get("LANES_PIN", "1") != "0" and L.bmh_host_pin(asc.ctypes.data, asc.nbytes) == 0       # LANES_PIN=0: pageable letters, staged by the lanes' host threads
 nbytes = [0]
 def sink(mv): nbytes[0] += len(mv)
 nth = int(os.environ.get("LANES_THREADS", "0")) or L.bmh_effective_cpus()
@@ -78,6 +80,9 @@ for lanes, nb, slots in cfgs:
     print("lanes %d batches %d: %.1f ms = %.2f Mreads/s (%d bytes); format %.1f; lanes summed: H2D %.1f seed %.1f cem %.1f tail %.1f select %.1f cigar %.1f" %
           (lanes, nb, st.seconds * 1e3, n_reads / st.seconds / 1e6, nbytes[0], st.format_seconds * 1e3, st.h2d_seconds * 1e3, st.seed_seconds * 1e3,
            st.chain_extend_seconds * 1e3, st.tail_seconds * 1e3, st.select_seconds * 1e3, st.cigar_seconds * 1e3), flush=True)
+    print("   copies (events on the lanes' streams): H2D %.1f MB in %.2f ms = %.1f GB/s, text D2H %.1f MB in %.2f ms = %.1f GB/s; reads %s; waits for a device slot %.1f ms" %
+          (st.h2d_bytes / 1e6, st.h2d_copy_seconds * 1e3, st.h2d_bytes / max(st.h2d_copy_seconds, 1e-9) / 1e9, st.d2h_bytes / 1e6, st.d2h_copy_seconds * 1e3,
+           st.d2h_bytes / max(st.d2h_copy_seconds, 1e-9) / 1e9, "in registered host memory" if pinned else "pageable (staged by the lanes)", st.gate_wait_seconds * 1e3), flush=True)
 if os.environ.get("LANES_FILE"):
     # the same reads from a FILE: bmh_aligner_run_fasta (a loader thread ahead of the lanes) against loading the file first (bmh_reads_load_fasta) and bmh_aligner_run
     from bwamem_hip.lib import load_fasta_reads

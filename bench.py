@@ -279,7 +279,9 @@ def main():
         # did every rank arrive at rank 0's text?  (a 64-bit sum of the packed text; if not -- another generator build, a cache from
         # elsewhere -- the text and its metadata are broadcast like the index)
         cdev = torch.device("cpu") if gloo_shared else dev
-        chk = pac_t.sum(dtype=torch.int64).reshape(1).to(cdev) + (pac_t.numel() << 40)
+        # (the length folded into the high bits modulo a 22-bit prime: numel << 40 left the 64 bits from 2^24 bytes of text on -- an hg38-scale text would
+        # have raised here on the first run with more than one rank; found by tests/test_parallel_gpu.py's four-rank case, round 6)
+        chk = pac_t.sum(dtype=torch.int64).reshape(1).to(cdev) + ((pac_t.numel() % 4194301) << 40)
         ref_chk = chk.clone(); dist.broadcast(ref_chk, 0)
         agree = (chk == ref_chk).to(torch.int64); dist.all_reduce(agree, op=dist.ReduceOp.MIN)
         same_text = bool(agree.item())

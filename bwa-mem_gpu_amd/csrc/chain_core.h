@@ -37,10 +37,23 @@ struct ch_chain_t { uint32_t head, tail, n; int32_t rid, w, first, beg, end; uin
 struct ch_reg_t { int64_t seed_rbeg, rmax0; int32_t seed_qbeg, seedlen0, lr, rr, rq, pad; };        // 40 B: region + job geometry
 struct ch_est_t { int64_t rb_est, re_est; int32_t qb_est, qe_est, seedlen0, pad; };                // 32 B: what the "covered already" test reads
 
+// The same records in COMPACT form for scratch that lives in LDS (round 6): the cooperative kernels' classes hold at most 1860 entries of a read of at most
+// CH_MAX_READ_LEN bases, so list links, chain fields and read coordinates fit 16 bits -- 82 instead of 124 bytes per entry (54 instead of 84 in the hybrid
+// classes), and LDS bytes x residency is what bounds the stage.  The core is written against a TYPE POLICY (ch_wide_ty / ch_compact_ty): same field names,
+// same code, only the widths and the end-of-list mark differ.  The forms with the reference's seed filter (FLT: a seed's re-scored weight rides in `pad`),
+// the lane forms and the global-scratch class (more than 65 535 entries are possible there) keep the wide records.
+struct ch_seed_c { int64_t rbeg; int16_t qbeg, len; uint16_t next; int16_t pad; };                                        // 16 B
+struct ch_chain_c { uint16_t head, tail, n; int16_t first; int32_t rid; uint16_t w; int16_t beg, end; uint8_t kept, pad; };   // 20 B
+struct ch_est_c { int64_t rb_est, re_est; int16_t qb_est, qe_est, seedlen0, pad; };                                      // 24 B
+struct ch_wide_ty { typedef ch_seed_t seed_t; typedef ch_chain_t chain_t; typedef ch_est_t est_t; typedef uint32_t idx_t; static constexpr uint32_t NIL = 0xFFFFFFFFu; };
+struct ch_compact_ty { typedef ch_seed_c seed_t; typedef ch_chain_c chain_t; typedef ch_est_c est_t; typedef uint16_t idx_t; static constexpr uint32_t NIL = 0xFFFFu; };
+
 // per-read scratch (a read never needs more entries than it has seeds): global memory, or LDS for a wave-form read
-struct ch_scr_t {
-	ch_seed_t *S; ch_chain_t *CH; uint32_t *order; int64_t *opos; uint32_t *klist; uint64_t *srt; uint32_t *cidx; ch_est_t *E;
+template <class TY> struct ch_scr {
+	typedef TY ty;
+	typename TY::seed_t *S; typename TY::chain_t *CH; typename TY::idx_t *order; int64_t *opos; typename TY::idx_t *klist; uint64_t *srt; typename TY::idx_t *cidx; typename TY::est_t *E;
 };
+typedef ch_scr<ch_wide_ty> ch_scr_t;
 
 struct ch_ctx_t {
 	bmh_chain_opt_t o;
@@ -230,7 +243,7 @@ template <bool FINAL = true> CH_HD inline bool w_introsort(uint64_t *a, int n)
 // lane against all others, 64 of those at a time through v_readlane; the chain ids go straight to order[] (nothing reads the
 // sorted keys).  Sequentially this pass was about half of the sort, and the sort a third of the chaining of a 500-seed read.
 // (weights are at most the read length, indices below 2^16: mem_chain samples at most max_occ occurrences per SMEM)
-template <int NU, int W = 64> __device__ __forceinline__ void w_place_part(const uint64_t *a, const uint32_t *hi, uint32_t *order, int n, int xb, int lane)
+template <int NU, int W = 64, class IDX> __device__ __forceinline__ void w_place_part(const uint64_t *a, const uint32_t *hi, IDX *order, int n, int xb, int lane)
 {
 	uint32_t cx[NU]; int pos[NU];
 #pragma unroll
@@ -249,7 +262,7 @@ template <int NU, int W = 64> __device__ __forceinline__ void w_place_part(const
 		}
 	}
 #pragma unroll
-	for (int u = 0; u < NU; ++u) { const int x = xb + W * u + lane; if (x < n) order[pos[u]] = (uint32_t)a[x]; }
+	for (int u = 0; u < NU; ++u) { const int x = xb + W * u + lane; if (x < n) order[pos[u]] = (IDX)a[x]; }
 }
 // The quicksort phase of the same introsort with its partition loop spread over the wave.  ks_introsort's Hoare partition looks at
 // every entry at most once from either side before the pointers meet, so which entries it exchanges follows from the array as it is
@@ -259,7 +272,7 @@ template <int NU, int W = 64> __device__ __forceinline__ void w_place_part(const
 // exchanges the pairs and finds where the left pointer stops: at the first candidate without a partner, or on the entry the last
 // exchange brought to the right -- whichever comes first.  64 entries per step instead of one; pivot choice, recursion stack, depth
 // limit and the order of the partitions are the sequential code's.  tmp: n words (order[], not in use before the sort ends).
-template <bool LDSX, int W = 64> __device__ inline int w_partition_coop(uint64_t *a, uint32_t *tmp, const int s, const int t, const uint32_t wp)
+template <bool LDSX, int W = 64, class IDX> __device__ inline int w_partition_coop(uint64_t *a, IDX *tmp, const int s, const int t, const uint32_t wp)
 {
 	const int lane = ch_grp<W>::lane();
 	const uint32_t *hi = (const uint32_t *)a + 1;
@@ -269,7 +282,7 @@ template <bool LDSX, int W = 64> __device__ inline int w_partition_coop(uint64_t
 		const int x = top - lane;
 		const bool le = x >= s && hi[2 * (x >= s ? x : s)] >= wp;
 		const unsigned long long m = ch_grp<W>::ballot(le);
-		if (le) tmp[s + nle + (int)__builtin_popcountll(m & below)] = (uint32_t)x;
+		if (le) tmp[s + nle + (int)__builtin_popcountll(m & below)] = (IDX)x;
 		nle += (int)__builtin_popcountll(m);
 	}
 	ch_wave_fence<LDSX>();
@@ -296,7 +309,7 @@ template <bool LDSX, int W = 64> __device__ inline int w_partition_coop(uint64_t
 	}
 	return ipos;
 }
-template <bool LDSX, int W = 64> __device__ inline bool w_introsort_coop(uint64_t *a, uint32_t *tmp, int n)
+template <bool LDSX, int W = 64, class IDX> __device__ inline bool w_introsort_coop(uint64_t *a, IDX *tmp, int n)
 {
 	if (n < 1) return true;
 	if (n == 2) { if (wlt(a[1], a[0])) wswap(a, 0, 1); ch_wave_fence<LDSX>(); return true; }
@@ -331,7 +344,7 @@ template <bool LDSX, int W = 64> __device__ inline bool w_introsort_coop(uint64_
 		}
 	}
 }
-template <bool LDSX, int W = 64> __device__ inline void w_place_coop(const uint64_t *a, uint32_t *order, int n)
+template <bool LDSX, int W = 64, class IDX> __device__ inline void w_place_coop(const uint64_t *a, IDX *order, int n)
 {
 	const int lane = ch_grp<W>::lane();
 	const uint32_t *hi = (const uint32_t *)a + 1;                     // the weights: high words of the keys
@@ -348,7 +361,7 @@ template <bool LDSX, int W = 64> __device__ inline void w_place_coop(const uint6
 
 // ---- helpers that are split across the wave when COOP
 // insert (cv, pv) at position at of order/opos[0..nc)
-template <bool COOP, bool LDSX = false, int W = 64> CH_HD inline void sorted_insert(uint32_t *order, int64_t *opos, int nc, int at, uint32_t cv, int64_t pv)
+template <bool COOP, bool LDSX = false, int W = 64, class IDX> CH_HD inline void sorted_insert(IDX *order, int64_t *opos, int nc, int at, uint32_t cv, int64_t pv)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (COOP) {
@@ -361,16 +374,16 @@ template <bool COOP, bool LDSX = false, int W = 64> CH_HD inline void sorted_ins
 			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - W * u, jc = j >= at ? j : at; v[u] = order[jc]; p[u] = opos[jc]; }   // no branch: the loads overlap
 			ch_wave_fence<LDSX>();
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - W * u; if (j >= at) { order[j + 1] = v[u]; opos[j + 1] = p[u]; } }
+			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - W * u; if (j >= at) { order[j + 1] = (IDX)v[u]; opos[j + 1] = p[u]; } }
 			ch_wave_fence<LDSX>();
 		}
-		order[at] = cv; opos[at] = pv;
+		order[at] = (IDX)cv; opos[at] = pv;
 		ch_wave_fence<LDSX>();
 		return;
 	}
 #endif
 	for (int j = nc; j > at; --j) { order[j] = order[j - 1]; opos[j] = opos[j - 1]; }
-	order[at] = cv; opos[at] = pv;
+	order[at] = (IDX)cv; opos[at] = pv;
 }
 
 // upper bound of rb in the ascending opos[0..nc): number of entries <= rb
@@ -476,8 +489,8 @@ __device__ __forceinline__ uint32_t ch_wave_min_u32(uint32_t v)
 //    pointer per class, advanced as members get marked.
 // kept_w[k] / mem_next[k]: weight of kept chain k and the next kept chain of its class; cls[i]: class of sorted chain i.
 // Returns false (nothing modified but scratch) when the read has more than 64 distinct spans.
-template <bool LDSX> __device__ inline bool ch_kept_by_classes(const bmh_chain_opt_t &o, ch_chain_t *CH, const uint32_t *order, uint32_t *klist, int32_t *kept_w,
-                                          uint32_t *mem_next, uint32_t *cls, int na, int &nk_out)
+template <bool LDSX, class CHT, class IDX> __device__ inline bool ch_kept_by_classes(const bmh_chain_opt_t &o, CHT *CH, const IDX *order, IDX *klist, int32_t *kept_w,
+                                          uint32_t *mem_next, IDX *cls, int na, int &nk_out)
 {
 	const int lane = ch_lane();
 	const uint32_t NIL = 0xFFFFFFFFu, INF = 0x7FFFFFFFu;
@@ -486,7 +499,7 @@ template <bool LDSX> __device__ inline bool ch_kept_by_classes(const bmh_chain_o
 	for (int b = 0; b < na; b += 64) {
 		const int i = b + lane;
 		uint32_t key = 0xFFFFFFFEu;
-		if (i < na) { const ch_chain_t c = CH[order[i]]; key = (uint32_t)c.beg << 16 | (uint32_t)c.end; }
+		if (i < na) { const CHT c = CH[order[i]]; key = (uint32_t)c.beg << 16 | (uint32_t)c.end; }
 		int id = -1;
 		for (int t = 0; t < ncls; ++t) { const uint32_t kt = (uint32_t)__builtin_amdgcn_readlane((int)classkey, t); if (key == kt) id = t; }
 		unsigned long long un = __ballot(i < na && id < 0);
@@ -498,7 +511,7 @@ template <bool LDSX> __device__ inline bool ch_kept_by_classes(const bmh_chain_o
 			++ncls;
 			un = __ballot(i < na && id < 0);
 		}
-		if (i < na) cls[i] = (uint32_t)id;
+		if (i < na) cls[i] = (IDX)id;
 	}
 	ch_wave_fence<LDSX>();
 	const int cbeg = (int)(classkey >> 16), cend = (int)(classkey & 0xFFFFu);
@@ -506,7 +519,7 @@ template <bool LDSX> __device__ inline bool ch_kept_by_classes(const bmh_chain_o
 	int nk = 0, bp = 0, wbp = 0;                               // wbp = kept_w[bp] while bp < nk (kept in a register: the test runs for every chain)
 	for (int b = 0; b < na; b += 64) {
 		int vbeg = 0, vend = 0, vw = 0, vcls = 0; uint32_t vci = 0;
-		if (b + lane < na) { vci = order[b + lane]; const ch_chain_t c = CH[vci]; vbeg = c.beg; vend = c.end; vw = c.w; vcls = (int)cls[b + lane]; }
+		if (b + lane < na) { vci = order[b + lane]; const CHT c = CH[vci]; vbeg = c.beg; vend = c.end; vw = c.w; vcls = (int)cls[b + lane]; }
 		const int m = na - b < 64 ? na - b : 64;
 		for (int u = 0; u < m; ++u) {
 			const int i = b + u;
@@ -534,7 +547,7 @@ template <bool LDSX> __device__ inline bool ch_kept_by_classes(const bmh_chain_o
 			}
 			if (!broke) {
 				const uint32_t k = (uint32_t)nk;
-				if (lane == 0) { klist[k] = (uint32_t)i; kept_w[k] = iw; mem_next[k] = NIL; cls[k] = ci; CH[ci].kept = large ? 2u : 3u; }
+				if (lane == 0) { klist[k] = (IDX)i; kept_w[k] = iw; mem_next[k] = NIL; cls[k] = (IDX)ci; CH[ci].kept = large ? 2u : 3u; }
 				if ((int)k == bp) wbp = iw;                               // the prefix had caught up with the list: its next entry is this one
 				if (lane == sc) { if (c_n == 0) c_first = k; else mem_next[c_tail] = k; c_tail = k; if (c_um == NIL) c_um = k; ++c_n; }
 				++nk;
@@ -560,7 +573,7 @@ template <bool LDSX> __device__ inline bool ch_kept_by_classes(const bmh_chain_o
 						const uint32_t k0 = (uint32_t)nk;                             // kept index of the run's first chain (j = 1); chain i has k0 - 1
 						if (j >= 1 && j <= run) {
 							const uint32_t k = k0 + (uint32_t)(j - 1);
-							klist[k] = (uint32_t)(i + j); kept_w[k] = iw; cls[k] = vci; mem_next[k] = j < run ? k + 1 : NIL;
+							klist[k] = (IDX)(i + j); kept_w[k] = iw; cls[k] = (IDX)vci; mem_next[k] = j < run ? k + 1 : NIL;
 							CH[vci].kept = large2 ? 2u : 3u;
 							if (self && j < run) CH[vci].first = i + j + 1;            // marked by the next chain of the run
 						}
@@ -684,7 +697,7 @@ template <class QB, class TB> CH_HD inline int seed_sw_score(const bmh_chain_opt
 }
 // mem_seed_sw :774-807: local alignment score of the seed's neighbourhood (50 bases either side), -1 when the seed or its window is
 // long enough to be trusted as it is
-CH_HD inline int seed_sw(const ch_ctx_t &x, uint32_t r, int l_query, const ch_seed_t &s)
+template <class ST> CH_HD inline int seed_sw(const ch_ctx_t &x, uint32_t r, int l_query, const ST &s)
 {
 	const int SHORT_EXT = 50, SHORT_LEN = CH_SW_MAXQ;                    // MEM_SHORT_EXT, MEM_SHORT_LEN
 	const int64_t l_pac = x.l_pac;
@@ -728,15 +741,18 @@ CH_HD inline ch_scr_t global_scratch(const ch_ctx_t &x, uint32_t r)
 // read of a dozen seeds took.
 // SITE: a tag that gives a call site an instantiation of its own -- the wave kernel calls the same form with scratch pointers of different address spaces
 // (all global; the arrays of the sequential phases in LDS), and ONE shared copy of the function makes every access through them a flat one.
-template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG = false, int SITE = 0> CH_HD CH_INLINE void chain_read(const ch_ctx_t &x, uint32_t r, const ch_scr_t &sc)
+template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG = false, int SITE = 0, class SCR = ch_scr_t> CH_HD CH_INLINE void chain_read(const ch_ctx_t &x, uint32_t r, const SCR &sc)
 {
+	typedef typename SCR::ty TY;                                  // the records' widths: ch_wide_ty or ch_compact_ty
+	typedef typename TY::seed_t seed_t; typedef typename TY::chain_t chain_t; typedef typename TY::est_t est_t; typedef typename TY::idx_t idx_t;
+	constexpr uint32_t NIL = TY::NIL;                             // end of a chain's seed list
 	const bmh_chain_opt_t &o = x.o;
 	const uint32_t base = x.prefix[r];
 	const int n = (int)x.n_ref[r];
 	const int l_query = (int)x.read_lens[r];
 	const int64_t l_pac = x.l_pac;
-	ch_seed_t *S = sc.S; ch_chain_t *CH = sc.CH; uint32_t *order = sc.order; int64_t *opos = sc.opos;
-	uint32_t *klist = sc.klist; uint64_t *srt = sc.srt; uint32_t *cidx = sc.cidx; ch_est_t *E = sc.E; ch_reg_t *R = x.regs + base;
+	seed_t *S = sc.S; chain_t *CH = sc.CH; idx_t *order = sc.order; int64_t *opos = sc.opos;
+	idx_t *klist = sc.klist; uint64_t *srt = sc.srt; idx_t *cidx = sc.cidx; est_t *E = sc.E; ch_reg_t *R = x.regs + base;
 	x.regs_per_read[r] = 0; x.jobs_per_read[r] = 0; x.frac_rep[r] = 0.f;
 	if (n == 0 || l_query < o.min_seed_len) return;
 	// the reference's seed filter (mem_flt_chained_seeds, src/bwamem.c:970-991) applies to a read with (W ? 1.1f W : 5.5 ln l) <= 0.05f l,
@@ -793,15 +809,15 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 			const int lo = upper_bound_pos<COOP, W>(opos, nc, rb);
 			bool to_add = true;
 			if (lo > 0) {
-				ch_chain_t &c = CH[order[lo - 1]];
-				const ch_seed_t first = S[c.head], last = S[c.tail];
+				chain_t &c = CH[order[lo - 1]];
+				const seed_t first = S[c.head], last = S[c.tail];
 				const int64_t qend = last.qbeg + last.len, rend = last.rbeg + last.len;
 				if (rid == c.rid) {                            // test_and_merge
 					if (sb >= first.qbeg && sb + slen <= qend && rb >= first.rbeg && rb + slen <= rend) to_add = false;   // contained
 					else if (!((last.rbeg < l_pac || first.rbeg < l_pac) && rb >= l_pac)) {
 						const int64_t xq = sb - last.qbeg, y = rb - last.rbeg;
 						if (y >= 0 && xq - y <= o.w && y - xq <= o.w && xq - last.len < o.max_chain_gap && y - last.len < o.max_chain_gap) {
-							ch_seed_t s; s.rbeg = rb; s.qbeg = sb; s.len = slen; s.next = 0xFFFFFFFFu; s.pad = 0;
+							seed_t s; s.rbeg = rb; s.qbeg = sb; s.len = slen; s.next = NIL; s.pad = 0;
 							S[ns] = s; S[c.tail].next = (uint32_t)ns; c.tail = (uint32_t)ns; ++c.n; ++ns;
 							to_add = false;
 						}
@@ -809,9 +825,9 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 				}
 			}
 			if (to_add) {
-				ch_seed_t s; s.rbeg = rb; s.qbeg = sb; s.len = slen; s.next = 0xFFFFFFFFu; s.pad = 0;
+				seed_t s; s.rbeg = rb; s.qbeg = sb; s.len = slen; s.next = NIL; s.pad = 0;
 				S[ns] = s;
-				ch_chain_t c; c.head = c.tail = (uint32_t)ns; c.n = 1; c.rid = rid; c.w = 0; c.first = -1; c.beg = c.end = 0; c.kept = 0; c.pad = 0;
+				chain_t c; c.head = c.tail = (uint32_t)ns; c.n = 1; c.rid = rid; c.w = 0; c.first = -1; c.beg = c.end = 0; c.kept = 0; c.pad = 0;
 				CH[nc] = c;
 				sorted_insert<COOP, LDSX, W>(order, opos, nc, lo, (uint32_t)nc, rb);
 				++ns; ++nc;
@@ -845,8 +861,8 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 						kind = 1;
 						if (lo > 0) {
 							pc = order[lo - 1]; ppos = opos[lo - 1];
-							const ch_chain_t c = CH[pc];
-							const ch_seed_t first = S[c.head], last = S[c.tail];
+							const chain_t c = CH[pc];
+							const seed_t first = S[c.head], last = S[c.tail];
 							ptail = c.tail;
 							const int64_t qend = last.qbeg + last.len, rend = last.rbeg + last.len;
 							if (rid == c.rid) {
@@ -877,10 +893,10 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 						const bool isnew = kind == 1, ismrg = kind == 2;
 						const unsigned long long lt = (1ull << lane) - 1, mnew = ch_grp<W>::ballot(isnew), madd = ch_grp<W>::ballot(isnew || ismrg);
 						const uint32_t my_ns = (uint32_t)ns + (uint32_t)__builtin_popcountll(madd & lt), my_nc = (uint32_t)nc + (uint32_t)__builtin_popcountll(mnew & lt);
-						if (isnew || ismrg) { ch_seed_t sd; sd.rbeg = rbl; sd.qbeg = sb; sd.len = slen; sd.next = 0xFFFFFFFFu; sd.pad = 0; S[my_ns] = sd; }
+						if (isnew || ismrg) { seed_t sd; sd.rbeg = rbl; sd.qbeg = sb; sd.len = slen; sd.next = NIL; sd.pad = 0; S[my_ns] = sd; }
 						if (ismrg) { S[ptail].next = my_ns; CH[pc].tail = my_ns; CH[pc].n += 1; }
 						if (isnew) {
-							ch_chain_t c; c.head = c.tail = my_ns; c.n = 1; c.rid = rid; c.w = 0; c.first = -1; c.beg = c.end = 0; c.kept = 0; c.pad = 0;
+							chain_t c; c.head = c.tail = my_ns; c.n = 1; c.rid = rid; c.w = 0; c.first = -1; c.beg = c.end = 0; c.kept = 0; c.pad = 0;
 							CH[my_nc] = c;
 						}
 						const int K = (int)__builtin_popcountll(mnew);
@@ -924,17 +940,17 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 	CH_STAMP(1);
 	int na = 0;
 	auto weigh = [&](uint32_t ci) {                                       // mem_chain_weight + the chain's query span
-		ch_chain_t &c = CH[ci];
+		chain_t &c = CH[ci];
 		int64_t end = 0; int w = 0;
-		for (uint32_t p = c.head; p != 0xFFFFFFFFu; p = S[p].next) {       // query cover
-			const ch_seed_t s = S[p];
+		for (uint32_t p = c.head; p != NIL; p = S[p].next) {       // query cover
+			const seed_t s = S[p];
 			if (s.qbeg >= end) w += s.len;
 			else if (s.qbeg + s.len > end) w += (int)(s.qbeg + s.len - end);
 			end = end > s.qbeg + s.len ? end : s.qbeg + s.len;
 		}
 		const int tmp = w; w = 0; end = 0;
-		for (uint32_t p = c.head; p != 0xFFFFFFFFu; p = S[p].next) {       // reference cover
-			const ch_seed_t s = S[p];
+		for (uint32_t p = c.head; p != NIL; p = S[p].next) {       // reference cover
+			const seed_t s = S[p];
 			if (s.rbeg >= end) w += s.len;
 			else if (s.rbeg + s.len > end) w += (int)(s.rbeg + s.len - end);
 			end = end > s.rbeg + s.len ? end : s.rbeg + s.len;
@@ -1000,7 +1016,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 	struct ks_t { int32_t beg, end, w; uint32_t chain; };                 // chain: index | is_alt << 31
 	ks_t *ks = (ks_t *)E;
 	if (!kept_done) {
-		{ const ch_chain_t c0 = CH[order[0]]; ks_t e; e.beg = c0.beg; e.end = c0.end; e.w = c0.w; e.chain = order[0] | chain_is_alt(x, c0.rid) << 31; ks[0] = e; }
+		{ const chain_t c0 = CH[order[0]]; ks_t e; e.beg = c0.beg; e.end = c0.end; e.w = c0.w; e.chain = order[0] | chain_is_alt(x, c0.rid) << 31; ks[0] = e; }
 		CH[order[0]].kept = 3; klist[nk++] = 0;
 	}
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1008,7 +1024,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 #endif
 	for (int i = 1; i < na && !kept_done; ++i) {
 		const uint32_t ci = order[i];
-		const ch_chain_t ai = CH[ci];
+		const chain_t ai = CH[ci];
 		const uint32_t ai_alt = chain_is_alt(x, ai.rid);
 		bool large_ovlp = false, broke = false;
 		auto test = [&](const ks_t &aj, bool &ovl, bool &brk) {
@@ -1046,7 +1062,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 					if (broke) break;
 					unsigned long long vm = ~0ull;
 					if (mb[u]) { const int f = (int)__builtin_ctzll(mb[u]); vm = f == 63 ? ~0ull : ((1ull << (f + 1)) - 1); broke = true; }
-					if (ovl[u] && ((vm >> lane) & 1)) { ch_chain_t &cj = CH[aj[u].chain & 0x7FFFFFFFu]; if (cj.first < 0) cj.first = i; }
+					if (ovl[u] && ((vm >> lane) & 1)) { chain_t &cj = CH[aj[u].chain & 0x7FFFFFFFu]; if (cj.first < 0) cj.first = i; }
 					if (mo[u] & vm) large_ovlp = true;
 				}
 			}
@@ -1057,7 +1073,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 				bool ovl, brk;
 				const ks_t aj = ks[k];
 				test(aj, ovl, brk);
-				if (ovl) { large_ovlp = true; ch_chain_t &cj = CH[aj.chain & 0x7FFFFFFFu]; if (cj.first < 0) cj.first = i; }
+				if (ovl) { large_ovlp = true; chain_t &cj = CH[aj.chain & 0x7FFFFFFFu]; if (cj.first < 0) cj.first = i; }
 				if (brk) { broke = true; break; }
 			}
 		}
@@ -1085,9 +1101,9 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 		// the seeds of the kept chains, flat (cidx is free until mem_chain2aln); every seed's score is independent of the others
 		int nsd = 0;
 		for (int ia = 0; ia < na; ++ia) {
-			const ch_chain_t c = CH[order[ia]];
+			const chain_t c = CH[order[ia]];
 			if (c.kept == 0) continue;
-			for (uint32_t p = c.head; p != 0xFFFFFFFFu; p = S[p].next) cidx[nsd++] = p;
+			for (uint32_t p = c.head; p != NIL; p = S[p].next) cidx[nsd++] = p;
 		}
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (COOP) {
@@ -1099,20 +1115,20 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 		for (int k = 0; k < nsd; ++k) { const uint32_t p = cidx[k]; S[p].pad = (uint32_t)seed_sw(x, r, l_query, S[p]); }
 		// the weak seeds leave their chains (:979-987); a chain may end up empty: mem_chain2aln returns at once for it (:1187)
 		for (int ia = 0; ia < na; ++ia) {
-			ch_chain_t c = CH[order[ia]];
+			chain_t c = CH[order[ia]];
 			if (c.kept == 0) continue;
-			uint32_t head = 0xFFFFFFFFu, last = 0xFFFFFFFFu, cnt = 0;
-			for (uint32_t p = c.head; p != 0xFFFFFFFFu;) {
+			uint32_t head = NIL, last = NIL, cnt = 0;
+			for (uint32_t p = c.head; p != NIL;) {
 				const uint32_t nx = S[p].next;
 				const int scv = (int)S[p].pad;
 				if (scv < 0 || scv >= min_HSP_score) {
 					S[p].pad = (uint32_t)(scv < 0 ? S[p].len * o.a : scv);
-					if (last == 0xFFFFFFFFu) head = p; else S[last].next = p;
+					if (last == NIL) head = p; else S[last].next = p;
 					last = p; ++cnt;
 				}
 				p = nx;
 			}
-			if (last != 0xFFFFFFFFu) S[last].next = 0xFFFFFFFFu;
+			if (last != NIL) S[last].next = NIL;
 			if (cnt != c.n) {
 				if (cnt == 0) c.kept = 0; else { c.head = head; c.tail = last; }
 				c.n = cnt;
@@ -1170,7 +1186,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 			const int lane = ch_grp<W>::lane();
 			const int i = ia + lane;
 			const bool in = i < na;
-			ch_chain_t cl; cl.kept = 0; cl.n = 0; cl.pad = 0; cl.head = 0;
+			chain_t cl; cl.kept = 0; cl.n = 0; cl.pad = 0; cl.head = 0;
 			if (in) cl = CH[order[i]];
 			const unsigned long long im = ch_grp<W>::ballot(in), slow = im & ~ch_grp<W>::ballot(in && (cl.kept == 0 || (cl.pad != 0 && cl.n == 1)));
 			const int run = slow ? (int)__builtin_ctzll(slow) : (int)__builtin_popcountll(im);
@@ -1180,7 +1196,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 				bool jl = false, jr = false;
 				if (me) {
 					const int idx = n_regs + (int)__builtin_popcountll(mm & ((1ull << lane) - 1));
-					const ch_seed_t t = S[cl.head];
+					const seed_t t = S[cl.head];
 					int64_t rmax0 = t.rbeg - (t.qbeg + cal_max_gap(o, t.qbeg));
 					int64_t rmax1 = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + cal_max_gap(o, l_query - t.qbeg - t.len));
 					rmax0 = rmax0 > 0 ? rmax0 : 0;
@@ -1194,7 +1210,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 						rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
 						rmax1 = rmax1 < far_end ? rmax1 : far_end;
 					}
-					ch_reg_t a; ch_est_t e;
+					ch_reg_t a; est_t e;
 					const int fwd = (int)(0.85 * (l_query - (t.qbeg + t.len)));
 					e.qe_est = (t.qbeg + t.len) + fwd < l_query ? (t.qbeg + t.len) + fwd : l_query;
 					e.re_est = (t.rbeg + t.len) + fwd < l_pac << 1 ? (t.rbeg + t.len) + fwd : l_pac << 1;
@@ -1220,15 +1236,15 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 			}
 		}
 #endif
-		const ch_chain_t c = CH[order[ia]];
+		const chain_t c = CH[order[ia]];
 		if (c.kept == 0) continue;
 		const int cn = (int)c.n;
 		const int scan_from = c.pad ? n_regs : 0;                               // isolated chain: only its own regions can cover its seeds
 		int64_t rmax0 = l_pac << 1, rmax1 = 0;
 		{
 			int i = 0;
-			for (uint32_t p = c.head; p != 0xFFFFFFFFu; p = S[p].next, ++i) {
-				const ch_seed_t t = S[p];
+			for (uint32_t p = c.head; p != NIL; p = S[p].next, ++i) {
+				const seed_t t = S[p];
 				const int64_t b = t.rbeg - (t.qbeg + cal_max_gap(o, t.qbeg));
 				const int64_t e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + cal_max_gap(o, l_query - t.qbeg - t.len));
 				rmax0 = rmax0 < b ? rmax0 : b;
@@ -1239,7 +1255,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 		}
 		rmax0 = rmax0 > 0 ? rmax0 : 0;
 		rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
-		const ch_seed_t s0 = S[c.head];
+		const seed_t s0 = S[c.head];
 		if (rmax0 < l_pac && l_pac < rmax1) { if (s0.rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
 		{   // bns_fetch_seq clips the window to the contig of the first seed (src/bntseq.c:531-556)
 			int is_rev;
@@ -1254,8 +1270,8 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 #endif
 		sort_distinct<COOP, LDSX, W>(srt, (uint64_t *)(opos), cn);    // opos is free by now (8 bytes per entry)
 		for (int k = cn - 1; k >= 0; --k) {
-			const ch_seed_t s = S[cidx[(uint32_t)srt[k]]];
-			auto covered = [&](const ch_est_t &p) {                                 // extension (estimated) made before? :1235-1256
+			const seed_t s = S[cidx[(uint32_t)srt[k]]];
+			auto covered = [&](const est_t &p) {                                 // extension (estimated) made before? :1235-1256
 				if (s.rbeg < p.rb_est || s.rbeg + s.len > p.re_est || s.qbeg < p.qb_est || s.qbeg + s.len > p.qe_est) return false;
 				if (s.len - p.seedlen0 > .1 * l_query) return false;
 				int qd = s.qbeg - p.qb_est; int64_t rd = s.rbeg - p.rb_est;
@@ -1273,7 +1289,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 				// 4 W regions per round; the four entries of a lane are loaded before any is tested, so the loads overlap
 				const int lane = ch_grp<W>::lane();
 				for (int b = scan_from; b < n_regs && hit == n_regs; b += 4 * W) {
-					ch_est_t p4[4]; unsigned long long m[4];
+					est_t p4[4]; unsigned long long m[4];
 #pragma unroll
 					for (int u = 0; u < 4; ++u) { const int i = b + W * u + lane; p4[u] = E[i < n_regs ? i : n_regs - 1]; }
 #pragma unroll
@@ -1287,7 +1303,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 			if (hit < n_regs) {                                                   // :1258-1276
 				const int j = first_true<COOP, W>(k + 1, cn, [&](int j) {
 					if (srt[j] == 0) return false;
-					const ch_seed_t t = S[cidx[(uint32_t)srt[j]]];
+					const seed_t t = S[cidx[(uint32_t)srt[j]]];
 					if (t.len < s.len * .95) return false;
 					if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) return true;
 					if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) return true;
@@ -1301,7 +1317,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 					continue;
 				}
 			}
-			ch_reg_t a; ch_est_t e;
+			ch_reg_t a; est_t e;
 			const int fwd = (int)(0.85 * (l_query - (s.qbeg + s.len)));           // FILTER_COEF, :52, :1285-1298
 			e.qe_est = (s.qbeg + s.len) + fwd < l_query ? (s.qbeg + s.len) + fwd : l_query;
 			e.re_est = (s.rbeg + s.len) + fwd < l_pac << 1 ? (s.rbeg + s.len) + fwd : l_pac << 1;

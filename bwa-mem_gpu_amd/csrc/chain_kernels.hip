@@ -202,6 +202,33 @@ __global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, ui
 #ifndef CH_WAVE_ATTR
 #define CH_WAVE_ATTR
 #endif
+// Scratch records of the cooperative kernels: compact (chain_core.h: ch_compact_ty, 82 / 54 bytes per entry) unless the launch carries the reference's seed
+// filter; knob -DCH_WIDE_SCRATCH: the wide records everywhere (124 / 84 bytes: rounds 2-5).
+#ifdef CH_WIDE_SCRATCH
+template <bool FLT> struct ch_coop_ty { typedef ch_wide_ty ty; };
+#else
+template <bool FLT> struct ch_coop_ty { typedef ch_compact_ty ty; };
+template <> struct ch_coop_ty<true> { typedef ch_wide_ty ty; };
+#endif
+// bytes of LDS per entry (hybrid: only the arrays of the sequential phases -- position index, sort keys, seeds, chains, sorted order)
+template <class TY> constexpr size_t ch_lds_entry_bytes(bool hybrid)
+{
+	return 8 + 8 + sizeof(typename TY::seed_t) + sizeof(typename TY::chain_t) + sizeof(typename TY::idx_t) + (hybrid ? 0 : sizeof(typename TY::est_t) + 2 * sizeof(typename TY::idx_t));
+}
+// a slice of LDS as a read's scratch (cap even; 8-byte arrays first, every array aligned for either record width); hybrid: E / klist / cidx are set by the caller
+template <class TY> __device__ __forceinline__ ch_scr<TY> ch_carve(uint8_t *p, const size_t cap, const bool hybrid)
+{
+	ch_scr<TY> L;
+	L.opos = (int64_t *)p; p += 8 * cap;
+	L.srt = (uint64_t *)p; p += 8 * cap;
+	L.S = (typename TY::seed_t *)p; p += sizeof(typename TY::seed_t) * cap;
+	L.E = (typename TY::est_t *)p; if (!hybrid) p += sizeof(typename TY::est_t) * cap;
+	L.CH = (typename TY::chain_t *)p; p += sizeof(typename TY::chain_t) * cap;
+	L.order = (typename TY::idx_t *)p; p += sizeof(typename TY::idx_t) * cap;
+	L.klist = (typename TY::idx_t *)p; p += sizeof(typename TY::idx_t) * cap;
+	L.cidx = (typename TY::idx_t *)p;
+	return L;
+}
 template <bool CTG_LDS, bool FLT>
 __global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_t A, uint32_t cls, uint32_t lds_cap, int hybrid, int prio)
 {
@@ -210,18 +237,8 @@ __global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_
 	extern __shared__ __align__(16) uint8_t ch_lds[];
 	const uint32_t nh = A.heavy_n[cls];
 	const uint32_t *list = A.heavy_list + (size_t)cls * A.n_reads;
-	ch_scr_t L;
-	{
-		uint8_t *p = ch_lds;
-		L.opos = (int64_t *)p; p += 8 * (size_t)lds_cap;
-		L.srt = (uint64_t *)p; p += 8 * (size_t)lds_cap;
-		L.CH = (ch_chain_t *)p; p += sizeof(ch_chain_t) * (size_t)lds_cap;
-		L.S = (ch_seed_t *)p; p += sizeof(ch_seed_t) * (size_t)lds_cap;
-		L.order = (uint32_t *)p; p += 4 * (size_t)lds_cap;
-		L.E = (ch_est_t *)p; p += sizeof(ch_est_t) * (size_t)lds_cap;           // (not there in the hybrid form: replaced below)
-		L.klist = (uint32_t *)p; p += 4 * (size_t)lds_cap;
-		L.cidx = (uint32_t *)p;
-	}
+	typedef typename ch_coop_ty<FLT>::ty TY;
+	const ch_scr<TY> L = ch_carve<TY>(ch_lds, (size_t)lds_cap, hybrid != 0);
 	// the contig table is looked up twice per seed occurrence (bns_intv2rid): a copy in LDS instead of dependent global loads
 	__shared__ int64_t ctg_off_l[CH_LDS_CONTIGS];
 	__shared__ int32_t ctg_len_l[CH_LDS_CONTIGS];
@@ -236,8 +253,9 @@ __global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_
 		// LDS or global becomes a flat access, several times the latency of ds_read on the LDS side)
 		if (lds_cap && !hybrid) chain_core::chain_read<true, true, FLT>(A.x, r, L);
 		else if (lds_cap) {
+			// (the arrays of the parallel phases in the read's slices of the global scratch, as records of this form's width: the slices are sized for the wide ones)
 			const ch_scr_t G = chain_core::global_scratch(A.x, r);
-			ch_scr_t H = L; H.E = G.E; H.klist = G.klist; H.cidx = G.cidx;
+			ch_scr<TY> H = L; H.E = (typename TY::est_t *)G.E; H.klist = (typename TY::idx_t *)G.klist; H.cidx = (typename TY::idx_t *)G.cidx;
 			chain_core::chain_read<true, false, FLT, 64, false, 1>(A.x, r, H);
 		} else chain_core::chain_read<true, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -263,18 +281,8 @@ __global__ void __launch_bounds__(64) CH_SUB_ATTR chain_sub_kernel(chain_args_t 
 	if (blockIdx.x * 4u >= nh) return;
 	const uint32_t *list = A.heavy_list + (size_t)cls * A.n_reads;
 	const uint32_t g = threadIdx.x >> 4;
-	ch_scr_t L;
-	{
-		uint8_t *p = ch_lds + (size_t)g * cap * CH_LDS_BYTES_PER_ENTRY;           // (cap is even: every array of a slice starts on an 8-byte boundary)
-		L.opos = (int64_t *)p; p += 8 * (size_t)cap;
-		L.srt = (uint64_t *)p; p += 8 * (size_t)cap;
-		L.CH = (ch_chain_t *)p; p += sizeof(ch_chain_t) * (size_t)cap;
-		L.S = (ch_seed_t *)p; p += sizeof(ch_seed_t) * (size_t)cap;
-		L.order = (uint32_t *)p; p += 4 * (size_t)cap;
-		L.E = (ch_est_t *)p; p += sizeof(ch_est_t) * (size_t)cap;
-		L.klist = (uint32_t *)p; p += 4 * (size_t)cap;
-		L.cidx = (uint32_t *)p;
-	}
+	typedef typename ch_coop_ty<FLT>::ty TY;
+	const ch_scr<TY> L = ch_carve<TY>(ch_lds + (size_t)g * cap * ch_lds_entry_bytes<TY>(false), (size_t)cap, false);   // (cap is a multiple of four: a slice starts on an 8-byte boundary)
 	__shared__ int64_t ctg_off_l[CTGN > 0 ? CTGN : 1];
 	__shared__ int32_t ctg_len_l[CTGN > 0 ? CTGN : 1];
 	if (CTGN > 0) {
@@ -681,7 +689,8 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 	HIPCK(hipEventRecord(w->ev_t[2], st));
 	HIPCK(hipEventRecord(w->ev_t[3], w->side));
 	const bool ctg_lds = w->n_contigs > 1 && w->n_contigs <= CH_LDS_CONTIGS;
-	HIPCK(hipFuncSetAttribute(ctg_lds ? (const void *)chain_wave_kernel<true, FLT> : (const void *)chain_wave_kernel<false, FLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[CH_N_CLASSES - 2] * CH_LDS_BYTES_PER_ENTRY_HYBRID)));
+	typedef typename ch_coop_ty<FLT>::ty TY;
+	HIPCK(hipFuncSetAttribute(ctg_lds ? (const void *)chain_wave_kernel<true, FLT> : (const void *)chain_wave_kernel<false, FLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[CH_N_CLASSES - 2] * ch_lds_entry_bytes<ch_wide_ty>(true))));
 	static const bool serial = getenv("BMH_CHAIN_SERIAL") != nullptr;          // (measurement: one class after the other, so that BMH_CHAIN_STATS shows what each costs alone)
 	// Ablation knob CHAIN_REPLAY_HEAVY (bit c = size class c): the class's kernel is NOT launched -- the regions, counts and repeat fractions its reads left in
 	// this workspace the last time stand.  Only meaningful when the workspace saw the same batch in its previous call (bench.py --distinct-batches 2 with two
@@ -691,18 +700,18 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 	const unsigned sub_mask = (unsigned)bmh_tune("CHAIN_SUB", (1 << CH_N_SUB) - 1);
 	const bool sub_ctg = w->n_contigs > 1 && w->n_contigs <= CH_SUB_LDS_CONTIGS;
 	if (sub_mask) {
-		const int mx = (int)(4 * (size_t)CH_CLASS_CAP[CH_N_SUB - 1] * CH_LDS_BYTES_PER_ENTRY);
+		const int mx = (int)(4 * (size_t)CH_CLASS_CAP[CH_N_SUB - 1] * ch_lds_entry_bytes<ch_wide_ty>(false));
 		HIPCK(hipFuncSetAttribute(sub_ctg ? (const void *)chain_sub_kernel<CH_SUB_LDS_CONTIGS, FLT> : (const void *)chain_sub_kernel<0, FLT>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
 	}
 	for (int cls = CH_N_CLASSES - 1; cls >= 0; --cls) {
 		const uint32_t lds_cap = CH_CLASS_CAP[cls];
 		const int hybrid = cls >= CH_HYBRID_CLASS && lds_cap != 0;
-		const size_t lds_bytes = (size_t)lds_cap * (hybrid ? CH_LDS_BYTES_PER_ENTRY_HYBRID : CH_LDS_BYTES_PER_ENTRY);
+		const size_t lds_bytes = (size_t)lds_cap * ch_lds_entry_bytes<TY>(hybrid != 0);
 		HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->ev_fork, 0));
 		if (serial && cls < CH_N_CLASSES - 1) HIPCK(hipStreamWaitEvent(w->cls_stream[cls], w->cls_done[cls + 1], 0));
 		if (replay >> cls & 1u) { }                                                                                       // (ablation: the class's stored output stands)
 		else if (cls < CH_N_SUB && (sub_mask >> cls & 1u)) {                                                              // four reads per wave (blocks beyond the list leave at once)
-			const size_t sub_lds = 4 * (size_t)lds_cap * CH_LDS_BYTES_PER_ENTRY;
+			const size_t sub_lds = 4 * (size_t)lds_cap * ch_lds_entry_bytes<TY>(false);
 			if (sub_ctg) chain_sub_kernel<CH_SUB_LDS_CONTIGS, FLT><<<CH_SUB_GRID[cls], 64, sub_lds, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap);
 			else chain_sub_kernel<0, FLT><<<CH_SUB_GRID[cls], 64, sub_lds, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap);
 		}

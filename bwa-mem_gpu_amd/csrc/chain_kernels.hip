@@ -36,7 +36,7 @@ struct chain_args_t {
 // occurrences (90 % of all located seeds) of which 500 each are used.  need[r] = that number; it sizes the read's scratch.
 // Reads that need more than heavy_thresh entries go to the wave kernels, one list per LDS size class.
 #ifndef CH_HEAVY_DEFAULT
-#define CH_HEAVY_DEFAULT 12u
+#define CH_HEAVY_DEFAULT 8u
 #endif
 #define CH_N_CLASSES 11
 #define CH_HYBRID_CLASS 6        // classes from here on keep only the arrays of the sequential phases in LDS
@@ -632,7 +632,8 @@ static void chain_fill_args(bmh_chain_ws *w, chain_args_t &A, const bmh_chain_op
 	A.n_reads = n_reads;
 	const char *ht = getenv("BMH_CHAIN_HEAVY");
 	// (round 3: 8 -- with the 9..16-entry reads on the lane-list stream, beside the first extension pass instead of ahead of it, the step was 2.5 % shorter than
-	// with 16; round 6, with those reads chained four per wave: 12 -- 25.4-25.6 against 25.7-26.1 ms per step with 8, three interleaved rounds, 10 and 14 between)
+	// with 16; round 6: with those reads chained four per wave and wide scratch records 12 was better (25.4-25.6 against 25.7-26.1 ms per step), with the compact
+	// records 8 is again: 24.8-25.1 against 25.1-25.3 ms, five interleaved pairs of 40 steps)
 	A.heavy_thresh = ht ? (uint32_t)atoi(ht) : CH_HEAVY_DEFAULT;
 	A.heavy_list = w->heavy_list; A.heavy_n = w->counters; A.need = w->need;
 	A.light_list = w->heavy_list + (size_t)CH_N_CLASSES * w->max_reads; A.light_n = w->counters + 32;

@@ -367,14 +367,17 @@ template <bool COOP, bool LDSX = false, int W = 64, class IDX> CH_HD inline void
 	if (COOP) {
 		// each round moves the top 4 W entries of [at, hi) up by one: four independent loads per lane, then the four stores
 		// (a round of W costs the same two LDS latencies)
+		// (U: entries per lane and round -- four for the wave, whose lists run to thousands; ONE for a 16-lane row, whose lists hold 64 entries at most and mostly
+		// a dozen: the quarters beyond the end were three quarters of a row's instructions in these loops)
 		const int lane = ch_grp<W>::lane();
-		for (int hi = nc; hi > at; hi -= 4 * W) {
-			uint32_t v[4]; int64_t p[4];
+		constexpr int U = W == 64 ? 4 : 1;
+		for (int hi = nc; hi > at; hi -= U * W) {
+			uint32_t v[U]; int64_t p[U];
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - W * u, jc = j >= at ? j : at; v[u] = order[jc]; p[u] = opos[jc]; }   // no branch: the loads overlap
+			for (int u = 0; u < U; ++u) { const int j = hi - 1 - lane - W * u, jc = j >= at ? j : at; v[u] = order[jc]; p[u] = opos[jc]; }   // no branch: the loads overlap
 			ch_wave_fence<LDSX>();
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { const int j = hi - 1 - lane - W * u; if (j >= at) { order[j + 1] = (IDX)v[u]; opos[j + 1] = p[u]; } }
+			for (int u = 0; u < U; ++u) { const int j = hi - 1 - lane - W * u; if (j >= at) { order[j + 1] = (IDX)v[u]; opos[j + 1] = p[u]; } }
 			ch_wave_fence<LDSX>();
 		}
 		order[at] = (IDX)cv; opos[at] = pv;
@@ -416,12 +419,13 @@ template <bool COOP, int W = 64, class F> CH_HD inline int first_true(int lo, in
 	if (COOP) {
 		// 4 W candidates per round: the four predicates are independent, so their LDS loads overlap (f is free of side effects)
 		const int lane = ch_grp<W>::lane();
-		for (int b = lo; b < hi; b += 4 * W) {
-			unsigned long long m[4];
+		constexpr int U = W == 64 ? 4 : 1;
+		for (int b = lo; b < hi; b += U * W) {
+			unsigned long long m[U];
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { const int i = b + W * u + lane; m[u] = ch_grp<W>::ballot(i < hi && f(i)); }
+			for (int u = 0; u < U; ++u) { const int i = b + W * u + lane; m[u] = ch_grp<W>::ballot(i < hi && f(i)); }
 #pragma unroll
-			for (int u = 0; u < 4; ++u) if (m[u]) return b + W * u + (int)__builtin_ctzll(m[u]);
+			for (int u = 0; u < U; ++u) if (m[u]) return b + W * u + (int)__builtin_ctzll(m[u]);
 		}
 		return hi;
 	}
@@ -1045,12 +1049,13 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 			// 4 W kept chains per round, four per lane with independent loads; the scan ends behind the first chain that drops
 			// chain i (src/bwamem.c:520-535), the marks of `first` stop there too
 			const int lane = ch_grp<W>::lane();
-			for (int b = 0; b < nk && !broke; b += 4 * W) {
-				ks_t aj[4]; bool ovl[4]; unsigned long long mb[4], mo[4];
+			constexpr int U = W == 64 ? 4 : 1;
+			for (int b = 0; b < nk && !broke; b += U * W) {
+				ks_t aj[U]; bool ovl[U]; unsigned long long mb[U], mo[U];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) { const int k = b + W * u + lane; aj[u] = ks[k < nk ? k : nk - 1]; }   // four loads in flight
+				for (int u = 0; u < U; ++u) { const int k = b + W * u + lane; aj[u] = ks[k < nk ? k : nk - 1]; }   // U loads in flight
 #pragma unroll
-				for (int u = 0; u < 4; ++u) {
+				for (int u = 0; u < U; ++u) {
 					const int k = b + W * u + lane;
 					bool brk = false;
 					test(aj[u], ovl[u], brk);
@@ -1058,7 +1063,7 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 					mb[u] = ch_grp<W>::ballot(brk); mo[u] = ch_grp<W>::ballot(ovl[u]);
 				}
 #pragma unroll
-				for (int u = 0; u < 4; ++u) {
+				for (int u = 0; u < U; ++u) {
 					if (broke) break;
 					unsigned long long vm = ~0ull;
 					if (mb[u]) { const int f = (int)__builtin_ctzll(mb[u]); vm = f == 63 ? ~0ull : ((1ull << (f + 1)) - 1); broke = true; }
@@ -1288,14 +1293,15 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 			if (COOP) {
 				// 4 W regions per round; the four entries of a lane are loaded before any is tested, so the loads overlap
 				const int lane = ch_grp<W>::lane();
-				for (int b = scan_from; b < n_regs && hit == n_regs; b += 4 * W) {
-					est_t p4[4]; unsigned long long m[4];
+				constexpr int U = W == 64 ? 4 : 1;
+				for (int b = scan_from; b < n_regs && hit == n_regs; b += U * W) {
+					est_t p4[U]; unsigned long long m[U];
 #pragma unroll
-					for (int u = 0; u < 4; ++u) { const int i = b + W * u + lane; p4[u] = E[i < n_regs ? i : n_regs - 1]; }
+					for (int u = 0; u < U; ++u) { const int i = b + W * u + lane; p4[u] = E[i < n_regs ? i : n_regs - 1]; }
 #pragma unroll
-					for (int u = 0; u < 4; ++u) { const int i = b + W * u + lane; m[u] = ch_grp<W>::ballot(i < n_regs && covered(p4[u])); }
+					for (int u = 0; u < U; ++u) { const int i = b + W * u + lane; m[u] = ch_grp<W>::ballot(i < n_regs && covered(p4[u])); }
 #pragma unroll
-					for (int u = 3; u >= 0; --u) if (m[u]) hit = b + W * u + (int)__builtin_ctzll(m[u]);
+					for (int u = U - 1; u >= 0; --u) if (m[u]) hit = b + W * u + (int)__builtin_ctzll(m[u]);
 				}
 			} else
 #endif

@@ -210,12 +210,14 @@ template <bool FLT> struct ch_coop_ty { typedef ch_wide_ty ty; };
 template <bool FLT> struct ch_coop_ty { typedef ch_compact_ty ty; };
 template <> struct ch_coop_ty<true> { typedef ch_wide_ty ty; };
 #endif
-// bytes of LDS per entry (hybrid: only the arrays of the sequential phases -- position index, sort keys, seeds, chains, sorted order)
+// bytes of LDS per entry (hybrid: everything but the region estimates, which only the last phase reads -- until round 6 the kept list and the seed list lay in
+// global memory too, and every kept chain cost the wave a round trip there: 0.2 ms of a 600-entry read's 0.67)
 template <class TY> constexpr size_t ch_lds_entry_bytes(bool hybrid)
 {
-	return 8 + 8 + sizeof(typename TY::seed_t) + sizeof(typename TY::chain_t) + sizeof(typename TY::idx_t) + (hybrid ? 0 : sizeof(typename TY::est_t) + 2 * sizeof(typename TY::idx_t));
+	// (wide records: the hybrid classes keep the two lists in global memory as before -- 1860 entries of 92 bytes would not fit the LDS)
+	return 8 + 8 + sizeof(typename TY::seed_t) + sizeof(typename TY::chain_t) + (hybrid && sizeof(typename TY::idx_t) == 4 ? 1 : 3) * sizeof(typename TY::idx_t) + (hybrid ? 0 : sizeof(typename TY::est_t));
 }
-// a slice of LDS as a read's scratch (cap even; 8-byte arrays first, every array aligned for either record width); hybrid: E / klist / cidx are set by the caller
+// a slice of LDS as a read's scratch (cap even; 8-byte arrays first, every array aligned for either record width); hybrid: E is set by the caller
 template <class TY> __device__ __forceinline__ ch_scr<TY> ch_carve(uint8_t *p, const size_t cap, const bool hybrid)
 {
 	ch_scr<TY> L;
@@ -229,7 +231,9 @@ template <class TY> __device__ __forceinline__ ch_scr<TY> ch_carve(uint8_t *p, c
 	L.cidx = (typename TY::idx_t *)p;
 	return L;
 }
-template <bool CTG_LDS, bool FLT>
+// (CTG_LDS: entries of the contig table's copy in LDS -- 0: none, the table stays in global memory; 64: 768 bytes; CH_LDS_CONTIGS: 3 KB, which cost the
+// 512-entry class its fifth block per CU)
+template <int CTG_LDS, bool FLT>
 __global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_t A, uint32_t cls, uint32_t lds_cap, int hybrid, int prio)
 {
 	wtrace_scope_t wt_(WT_CHAIN_WAVE, cls);
@@ -240,9 +244,9 @@ __global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_
 	typedef typename ch_coop_ty<FLT>::ty TY;
 	const ch_scr<TY> L = ch_carve<TY>(ch_lds, (size_t)lds_cap, hybrid != 0);
 	// the contig table is looked up twice per seed occurrence (bns_intv2rid): a copy in LDS instead of dependent global loads
-	__shared__ int64_t ctg_off_l[CH_LDS_CONTIGS];
-	__shared__ int32_t ctg_len_l[CH_LDS_CONTIGS];
-	if (CTG_LDS) {                      // (a template parameter: the table pointer must have one address space per instantiation)
+	__shared__ int64_t ctg_off_l[CTG_LDS > 0 ? CTG_LDS : 1];
+	__shared__ int32_t ctg_len_l[CTG_LDS > 0 ? CTG_LDS : 1];
+	if (CTG_LDS > 0) {                  // (a template parameter: the table pointer must have one address space per instantiation)
 		for (int c = (int)threadIdx.x; c < A.x.n_contigs; c += 64) { ctg_off_l[c] = A.x.ctg_off[c]; ctg_len_l[c] = A.x.ctg_len[c]; }
 		A.x.ctg_off = ctg_off_l; A.x.ctg_len = ctg_len_l;
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0);
@@ -253,9 +257,10 @@ __global__ void __launch_bounds__(64) CH_WAVE_ATTR chain_wave_kernel(chain_args_
 		// LDS or global becomes a flat access, several times the latency of ds_read on the LDS side)
 		if (lds_cap && !hybrid) chain_core::chain_read<true, true, FLT>(A.x, r, L);
 		else if (lds_cap) {
-			// (the arrays of the parallel phases in the read's slices of the global scratch, as records of this form's width: the slices are sized for the wide ones)
+			// (the region estimates in the read's slice of the global scratch, as records of this form's width: the slices are sized for the wide ones)
 			const ch_scr_t G = chain_core::global_scratch(A.x, r);
-			ch_scr<TY> H = L; H.E = (typename TY::est_t *)G.E; H.klist = (typename TY::idx_t *)G.klist; H.cidx = (typename TY::idx_t *)G.cidx;
+			ch_scr<TY> H = L; H.E = (typename TY::est_t *)G.E;
+			if (sizeof(typename TY::idx_t) == 4) { H.klist = (typename TY::idx_t *)G.klist; H.cidx = (typename TY::idx_t *)G.cidx; }
 			chain_core::chain_read<true, false, FLT, 64, false, 1>(A.x, r, H);
 		} else chain_core::chain_read<true, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -689,9 +694,10 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 	else chain_lane_kernel<FLT, 0><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
 	HIPCK(hipEventRecord(w->ev_t[2], st));
 	HIPCK(hipEventRecord(w->ev_t[3], w->side));
-	const bool ctg_lds = w->n_contigs > 1 && w->n_contigs <= CH_LDS_CONTIGS;
+	const int ctg_lds = w->n_contigs <= 1 ? 0 : w->n_contigs <= 64 ? 64 : w->n_contigs <= CH_LDS_CONTIGS ? CH_LDS_CONTIGS : 0;
+	const void *wave_fn = ctg_lds == 64 ? (const void *)chain_wave_kernel<64, FLT> : ctg_lds ? (const void *)chain_wave_kernel<CH_LDS_CONTIGS, FLT> : (const void *)chain_wave_kernel<0, FLT>;
 	typedef typename ch_coop_ty<FLT>::ty TY;
-	HIPCK(hipFuncSetAttribute(ctg_lds ? (const void *)chain_wave_kernel<true, FLT> : (const void *)chain_wave_kernel<false, FLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[CH_N_CLASSES - 2] * ch_lds_entry_bytes<ch_wide_ty>(true))));
+	HIPCK(hipFuncSetAttribute(wave_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_CLASS_CAP[CH_N_CLASSES - 2] * ch_lds_entry_bytes<ch_wide_ty>(true))));
 	static const bool serial = getenv("BMH_CHAIN_SERIAL") != nullptr;          // (measurement: one class after the other, so that BMH_CHAIN_STATS shows what each costs alone)
 	// Ablation knob CHAIN_REPLAY_HEAVY (bit c = size class c): the class's kernel is NOT launched -- the regions, counts and repeat fractions its reads left in
 	// this workspace the last time stand.  Only meaningful when the workspace saw the same batch in its previous call (bench.py --distinct-batches 2 with two
@@ -723,8 +729,9 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 			if (list_private && !FLT) chain_lane_list_kernel<FLT, 32><<<lgrid, 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls, lanes);
 			else chain_lane_list_kernel<FLT, 0><<<lgrid, 256, 0, w->cls_stream[cls]>>>(A, (uint32_t)cls, lanes);
 		}
-		else if (ctg_lds) chain_wave_kernel<true, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid, (int)(wave_prio >> cls & 1u));
-		else chain_wave_kernel<false, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid, (int)(wave_prio >> cls & 1u));
+		else if (ctg_lds == 64) chain_wave_kernel<64, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid, (int)(wave_prio >> cls & 1u));
+		else if (ctg_lds) chain_wave_kernel<CH_LDS_CONTIGS, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid, (int)(wave_prio >> cls & 1u));
+		else chain_wave_kernel<0, FLT><<<CH_CLASS_GRID[cls], 64, lds_bytes, w->cls_stream[cls]>>>(A, (uint32_t)cls, lds_cap, hybrid, (int)(wave_prio >> cls & 1u));
 		HIPCK(hipEventRecord(w->cls_done[cls], w->cls_stream[cls]));
 		HIPCK(hipStreamWaitEvent(w->side, w->cls_done[cls], 0));
 	}

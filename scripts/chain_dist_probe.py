@@ -52,7 +52,7 @@ for ht in (os.environ.get("BMH_CHAIN_HEAVY", "32").split(",")):
         print("   kernel ms:", [round(x, 3) for x in ms])
 if os.environ.get("CHAIN_PROF"):
     # phase stamps of the largest reads of each class (needs a -DCH_PROFILE build: BMH_LIB=build/variants/lib_prof.so)
-    for lo, hi in ((40, 64), (100, 128), (200, 256), (500, 512), (520, 620), (600, 1250), (1250, 1900)):
+    for lo, hi in ((12, 16), (20, 32), (40, 64), (100, 128), (200, 256), (500, 512), (520, 620), (600, 1250), (1250, 1900)):
         cand = np.nonzero((need > lo) & (need <= hi))[0]
         if len(cand) == 0: continue
         r = int(cand[len(cand) // 2])

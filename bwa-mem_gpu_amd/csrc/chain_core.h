@@ -160,8 +160,12 @@ template <bool COOP = false, int W = 64> CH_HD inline int intv2rid(const ch_ctx_
 	int is_rev;
 	if (rb < x.l_pac && re > x.l_pac) return -2;
 	const int rid_b = pos2rid<COOP, W>(x, depos(x, rb, &is_rev));
-	const int rid_e = rb < re ? pos2rid<COOP, W>(x, depos(x, re - 1, &is_rev)) : rid_b;
-	return rid_b == rid_e ? rid_b : -1;
+	if (rb >= re || rid_b < 0 || x.n_contigs <= 1) return rid_b;
+	// (the sequence of the interval's last base is only compared with rid_b, bns_intv2rid src/bntseq.c:362-373: no second search -- it is rid_b exactly when
+	// that base lies in [ctg_off[rid_b], ctg_off[rid_b + 1]), the slice pos2rid's search assigns to rid_b)
+	const int64_t pe = depos(x, re - 1, &is_rev);
+	const int64_t hi = rid_b + 1 < x.n_contigs ? x.ctg_off[rid_b + 1] : x.l_pac;
+	return pe >= x.ctg_off[rid_b] && pe < hi ? rid_b : -1;
 }
 // (an integer form, (n + e) / e, gives the same values but measured slower on the device than the double division)
 // (gap extension penalties of 1 -- the default -- need no division: (double)n / 1 + 1. is n + 1 exactly, for either sign of n; the branch is uniform

@@ -1094,8 +1094,14 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 		if (COOP) ch_wave_fence<LDSX>();
 #endif
 	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (COOP) {                                                           // (the marks are independent of each other: one kept chain per lane)
+		for (int k = ch_grp<W>::lane(); k < nk; k += W) { const int f = CH[order[klist[k]]].first; if (f >= 0) CH[order[f]].kept = 1; }
+		ch_wave_fence<LDSX>();
+	} else
+#endif
 	for (int k = 0; k < nk; ++k) { const int f = CH[order[klist[k]]].first; if (f >= 0) CH[order[f]].kept = 1; }
-	{
+	if (na >= o.max_chain_extend) {                                       // (fewer chains than max_chain_extend -- always, with the default of 2^30: the count below cannot reach it)
 		int i, k;
 		for (i = k = 0; i < na; ++i) {
 			const uint32_t kp = CH[order[i]].kept;

@@ -915,9 +915,12 @@ template <bool COOP, bool LDSX = false, bool FLT = false, int W = 64, bool STG =
 							for (unsigned long long mm = mnew; mm; mm &= mm - 1) { const int lv = ch_grp<W>::bcast(lo, (int)__builtin_ctzll(mm)); minlo = lv < minlo ? lv : minlo; }
 							for (int hi = nc; hi > minlo; hi -= W) {
 								const int jj = hi - 1 - lane;
-								uint32_t ov = 0; int64_t op = 0; int sh = 0;
+								uint32_t ov = 0; int64_t op = 0;
 								if (jj >= minlo) { ov = order[jj]; op = opos[jj]; }
-								for (unsigned long long mm = mnew; mm; mm &= mm - 1) { const int lv = ch_grp<W>::bcast(lo, (int)__builtin_ctzll(mm)); sh += lv <= jj ? 1 : 0; }
+								// new chains that go below this round's entries shift all of them alike (one count); only those that go INSIDE the round's window are
+								// compared lane by lane -- K comparisons over all rounds instead of K per round (a 1500-entry read: 29 rounds of up to 64)
+								int sh = (int)__builtin_popcountll(ch_grp<W>::ballot(isnew && lo <= hi - W - 1));
+								for (unsigned long long mm = ch_grp<W>::ballot(isnew && lo >= hi - W && lo <= hi - 1); mm; mm &= mm - 1) { const int lv = ch_grp<W>::bcast(lo, (int)__builtin_ctzll(mm)); sh += lv <= jj ? 1 : 0; }
 								ch_wave_fence<LDSX>();
 								if (jj >= minlo && sh) { order[jj + sh] = ov; opos[jj + sh] = op; }
 								ch_wave_fence<LDSX>();

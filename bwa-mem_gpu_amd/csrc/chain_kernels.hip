@@ -57,7 +57,10 @@ __device__ __forceinline__ int ch_class_of(uint32_t need) { return need <= CH_SU
 static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {CH_SUB_CAP0, CH_SUB_CAP1, 64u, 128u, 256u, 384u, 512u, 620u, 1250u, 1860u, 0u};
 static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {0u, 0u, 8192u, 4096u, 2048u, 1024u, 1024u, 768u, 512u, 256u, 256u};
 // blocks (one wave, four reads at a time) of chain_sub_kernel per class: about what the chip holds at once (LDS: 4 x cap x 124 bytes a block), the reads dealt round robin
-static const uint32_t CH_SUB_GRID[CH_N_SUB] = {4096u, 2560u, 1280u};
+#ifndef CH_SUB_GRIDS
+#define CH_SUB_GRIDS 4096u, 2560u, 1280u
+#endif
+static const uint32_t CH_SUB_GRID[CH_N_SUB] = {CH_SUB_GRIDS};
 
 // need, the wave / lane-list class of a seed-rich read -- and, for the reads of the lane kernel, a BIN by need (<= 2, <= 4, <= 8,
 // the rest): the lane kernel walks the bins' compacted lists, so the 64 reads of a wave cost about the same.  In read order every

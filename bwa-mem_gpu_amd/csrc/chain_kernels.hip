@@ -55,7 +55,10 @@ __device__ __forceinline__ int ch_class_of(uint32_t need) { return need <= CH_SU
 // (a read that samples one SMEM of 500+ occurrences plus a few more seeds needs 500-600 entries: on the hg38-like genome most of
 // the reads beyond 256 entries sit there, hence the 512 and 620 classes)
 static const uint32_t CH_CLASS_CAP[CH_N_CLASSES] = {CH_SUB_CAP0, CH_SUB_CAP1, 64u, 128u, 256u, 384u, 512u, 620u, 1250u, 1860u, 0u};
-static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {0u, 0u, 8192u, 4096u, 2048u, 1024u, 1024u, 768u, 512u, 256u, 256u};
+#ifndef CH_WAVE_GRIDS
+#define CH_WAVE_GRIDS 4096u, 2048u, 1024u, 1024u, 768u, 512u, 256u, 256u
+#endif
+static const uint32_t CH_CLASS_GRID[CH_N_CLASSES] = {0u, 0u, 8192u, CH_WAVE_GRIDS};
 // blocks (one wave, four reads at a time) of chain_sub_kernel per class: about what the chip holds at once (LDS: 4 x cap x 124 bytes a block), the reads dealt round robin
 #ifndef CH_SUB_GRIDS
 #define CH_SUB_GRIDS 4096u, 3584u, 1792u     // (2560 and 1280 for the last two until the compact records: 24.2 against 24.5 ms per step)

@@ -2,7 +2,7 @@
 """The table of DESIGN.md section 5.1 from the round's bench lines: design_numbers.py [tag]  (profiles/<tag>_bench*.json)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 def ld(nm):
     p = os.path.join(ROOT, "profiles", nm)
     return json.loads([l for l in open(p) if l.startswith("{")][-1]) if os.path.exists(p) else None

@@ -123,9 +123,17 @@ __global__ void __launch_bounds__(256) chain_classify_kernel(chain_args_t A)
 // lanes of a wave, so the 64 lanes' accesses to entry i of an array are consecutive addresses -- 256 bytes in one to four cache
 // lines -- where the per-read slices of the global scratch are 64 lines per wave instruction (round 2 measured 3.4 GB of the chain
 // family's 5.7 GB of HBM traffic there, for arrays nobody reads afterwards).  Only the regions (x.regs) leave the kernel.
-template <int CAP> struct ch_private_t {
-	ch_seed_t S[CAP]; ch_chain_t CH[CAP]; ch_est_t E[CAP]; int64_t opos[CAP]; uint64_t srt[CAP]; uint32_t order[CAP], klist[CAP], cidx[CAP];
-	__device__ __forceinline__ ch_scr_t scr() { ch_scr_t L; L.S = S; L.CH = CH; L.E = E; L.opos = opos; L.srt = srt; L.order = order; L.klist = klist; L.cidx = cidx; return L; }
+// Scratch records of the cooperative kernels and of the lane kernels' private scratch: compact (chain_core.h: ch_compact_ty, 82 / 58 bytes per entry) unless the
+// launch carries the reference's seed filter; knob -DCH_WIDE_SCRATCH: the wide records everywhere (124 / 84 bytes: rounds 2-5).
+#ifdef CH_WIDE_SCRATCH
+template <bool FLT> struct ch_coop_ty { typedef ch_wide_ty ty; };
+#else
+template <bool FLT> struct ch_coop_ty { typedef ch_compact_ty ty; };
+template <> struct ch_coop_ty<true> { typedef ch_wide_ty ty; };
+#endif
+template <int CAP, class TY> struct ch_private_t {
+	typename TY::seed_t S[CAP]; typename TY::chain_t CH[CAP]; typename TY::est_t E[CAP]; int64_t opos[CAP]; uint64_t srt[CAP]; typename TY::idx_t order[CAP], klist[CAP], cidx[CAP];
+	__device__ __forceinline__ ch_scr<TY> scr() { ch_scr<TY> L; L.S = S; L.CH = CH; L.E = E; L.opos = opos; L.srt = srt; L.order = order; L.klist = klist; L.cidx = cidx; return L; }
 };
 
 // one read per lane, the bins from the costliest down as one sequence (CAP > 0: private scratch of CAP entries -- the caller makes sure
@@ -140,7 +148,7 @@ __global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A, const u
 	if (bin < 0) return;
 	const uint32_t r = A.light_list[(size_t)bin * A.n_reads + t];
 	if (CAP > 0) {
-		ch_private_t<(CAP > 0 ? CAP : 1)> P;
+		ch_private_t<(CAP > 0 ? CAP : 1), typename ch_coop_ty<FLT>::ty> P;
 		chain_core::chain_read<false, false, FLT>(A.x, r, P.scr());
 	} else chain_core::chain_read<false, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
 }
@@ -188,7 +196,7 @@ __global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, ui
 	if (i >= A.heavy_n[cls]) return;
 	const uint32_t r = A.heavy_list[(size_t)cls * A.n_reads + i];
 	if (CAP > 0) {
-		ch_private_t<(CAP > 0 ? CAP : 1)> P;
+		ch_private_t<(CAP > 0 ? CAP : 1), typename ch_coop_ty<FLT>::ty> P;
 		chain_core::chain_read<false, false, FLT>(A.x, r, P.scr());
 	} else chain_core::chain_read<false, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
 }
@@ -207,14 +215,6 @@ __global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, ui
 #endif
 #ifndef CH_WAVE_ATTR
 #define CH_WAVE_ATTR
-#endif
-// Scratch records of the cooperative kernels: compact (chain_core.h: ch_compact_ty, 82 / 54 bytes per entry) unless the launch carries the reference's seed
-// filter; knob -DCH_WIDE_SCRATCH: the wide records everywhere (124 / 84 bytes: rounds 2-5).
-#ifdef CH_WIDE_SCRATCH
-template <bool FLT> struct ch_coop_ty { typedef ch_wide_ty ty; };
-#else
-template <bool FLT> struct ch_coop_ty { typedef ch_compact_ty ty; };
-template <> struct ch_coop_ty<true> { typedef ch_wide_ty ty; };
 #endif
 // bytes of LDS per entry (hybrid: everything but the region estimates, which only the last phase reads -- until round 6 the kept list and the seed list lay in
 // global memory too, and every kept chain cost the wave a round trip there: 0.2 ms of a 600-entry read's 0.67)

@@ -147,7 +147,16 @@ __global__ void __launch_bounds__(256) chain_lane_kernel(chain_args_t A, const u
 	for (; bin >= 0; --bin) { const uint32_t c = (skip_bins >> bin & 1u) ? 0u : A.light_n[bin]; if (t < c) break; t -= c; }
 	if (bin < 0) return;
 	const uint32_t r = A.light_list[(size_t)bin * A.n_reads + t];
-	if (CAP > 0) {
+	if (CAP > 0 && A.need[r] > (uint32_t)CAP) { *A.x.err = 3; return; }      // (a launch whose bins do not fit its private arrays: an internal error, never an overrun)
+	if (CAP == 8 && skip_bins == 0u) {
+		// ONE launch, the private arrays sized by the read's bin (the waves are bin-pure but for the seams: a wave of 2-entry reads dirties a quarter of the
+		// scratch lines an 8-entry frame would): private memory is written back like any other, and with eight entries for every lane this kernel moved
+		// 0.98 GB out and 0.83 GB in per million reads -- more than all the other chaining kernels together -- for 44 MB of regions
+		typedef typename ch_coop_ty<FLT>::ty TY;
+		if (bin == 0) { ch_private_t<2, TY> P; chain_core::chain_read<false, false, FLT, 64, false, 2>(A.x, r, P.scr()); }
+		else if (bin == 1) { ch_private_t<4, TY> P; chain_core::chain_read<false, false, FLT, 64, false, 4>(A.x, r, P.scr()); }
+		else { ch_private_t<8, TY> P; chain_core::chain_read<false, false, FLT, 64, false, 8>(A.x, r, P.scr()); }
+	} else if (CAP > 0) {
 		ch_private_t<(CAP > 0 ? CAP : 1), typename ch_coop_ty<FLT>::ty> P;
 		chain_core::chain_read<false, false, FLT>(A.x, r, P.scr());
 	} else chain_core::chain_read<false, false, FLT>(A.x, r, chain_core::global_scratch(A.x, r));
@@ -195,6 +204,7 @@ __global__ void __launch_bounds__(256) chain_lane_list_kernel(chain_args_t A, ui
 	const uint32_t i = ((blockIdx.x * 256u + threadIdx.x) >> 6) * lanes + lane;
 	if (i >= A.heavy_n[cls]) return;
 	const uint32_t r = A.heavy_list[(size_t)cls * A.n_reads + i];
+	if (CAP > 0 && A.need[r] > (uint32_t)CAP) { *A.x.err = 3; return; }
 	if (CAP > 0) {
 		ch_private_t<(CAP > 0 ? CAP : 1), typename ch_coop_ty<FLT>::ty> P;
 		chain_core::chain_read<false, false, FLT>(A.x, r, P.scr());
@@ -694,7 +704,17 @@ static int chain_launch_t(bmh_chain_ws *w, const chain_args_t &A, hipStream_t st
 			}
 		}
 		if ((lane_lds_env & 15) != 15) chain_lane_kernel<false, 0><<<nblk(n_reads, 256), 256, 0, st>>>(A, (uint32_t)lane_lds_env);
-	} else if (lane_private && !FLT && A.heavy_thresh <= 8u) chain_lane_kernel<FLT, 8><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
+	} else if (lane_private && !FLT && A.heavy_thresh <= 8u) {
+		// (knob CHAIN_LANE_SPLIT=1: one launch per scratch size instead of one launch that sizes the arrays by the read's bin -- measured: the same traffic, but
+		// three launches one behind the other on the path the first extension pass waits for: +0.1 ms per step)
+		if (bmh_tune("CHAIN_LANE_SPLIT", 0)) {
+			// (ch_bin_of: bin 0 = at most 2 entries, 1 = at most 4, 2 = at most 8, 3 = the rest up to the threshold; the argument is the mask of the bins a launch SKIPS)
+			static_assert(CH_N_BINS == 4, "the masks below name four bins");
+			chain_lane_kernel<FLT, 8><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0x3u);        // bins 3 and 2
+			chain_lane_kernel<FLT, 4><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0xDu);        // bin 1
+			chain_lane_kernel<FLT, 2><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0xEu);        // bin 0
+		} else chain_lane_kernel<FLT, 8><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
+	}
 	else if (lane_private && !FLT && A.heavy_thresh <= 12u) chain_lane_kernel<FLT, 12><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
 	else if (lane_private && !FLT && A.heavy_thresh <= 16u) chain_lane_kernel<FLT, 16><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);
 	else chain_lane_kernel<FLT, 0><<<nblk(n_reads, 256), 256, 0, st>>>(A, 0u);

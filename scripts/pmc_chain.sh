@@ -7,7 +7,9 @@ A="--cpu-sample 0 --no-next-rows --no-pcie --distinct-batches 2 $*"
 [ -f "$(python bench.py $A --print-cache-dir)/meta.json" ] || python bench.py $A --steps 1 --warmup 0 > /dev/null 2>&1
 for pass in a b; do
   D=$R/gpurun_out/pmcchain_${TAG}_$pass; rm -rf $D; mkdir -p $D
-  if [ $pass = a ]; then CTR="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"; else CTR="SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"; fi
+  # (PMC_MEM=1: the two passes are FETCH_SIZE and WRITE_SIZE instead -- KB per launch, with SQ_WAVES beside them for the launch count)
+  if [ -n "$PMC_MEM" ]; then if [ $pass = a ]; then CTR="FETCH_SIZE SQ_WAVES"; else CTR="WRITE_SIZE SQ_WAVES"; fi
+  elif [ $pass = a ]; then CTR="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"; else CTR="SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"; fi
   ( cd /tmp; export TMPDIR=/tmp; rocprofv3 --pmc $CTR --output-format csv -d $D -- python3 $R/bench.py --steps 2 --warmup 1 $A > $D/bench.json 2> $D/err.log ) || { tail -5 $D/err.log; continue; }
   python - <<PY
 import csv, glob, json, collections

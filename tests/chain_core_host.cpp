@@ -17,9 +17,11 @@ struct result_t {
 
 template <class T> static T *dup(const std::vector<T> &v) { T *p = (T *)malloc(sizeof(T) * (v.size() + 1)); if (!v.empty()) memcpy(p, v.data(), sizeof(T) * v.size()); return p; }
 
-extern "C" result_t *chain_core_run(const bmh_chain_opt_t *opt, int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads,
-                                    const uint64_t *read_offs, const uint32_t *read_lens, const uint64_t *rbeg, const int32_t *qbeg,
-                                    const uint32_t *score, const uint32_t *n_ref, const uint32_t *prefix, uint64_t n_seeds)
+// compact != 0: the scratch records of the cooperative kernels' LDS (ch_compact_ty: 16-bit links and read coordinates) instead of the wide ones, in the form
+// without the seed filter -- the same decisions are expected wherever that filter does not apply and no read samples 65 535 seeds or more
+static result_t *run(const bmh_chain_opt_t *opt, int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads,
+                     const uint64_t *read_offs, const uint32_t *read_lens, const uint64_t *rbeg, const int32_t *qbeg,
+                     const uint32_t *score, const uint32_t *n_ref, const uint32_t *prefix, uint64_t n_seeds, int compact)
 {
 	const size_t S = n_seeds + 1;
 	std::vector<ch_seed_t> seeds(S); std::vector<ch_chain_t> chains(S); std::vector<uint32_t> order(S), klist(S), cidx(S);
@@ -35,7 +37,17 @@ extern "C" result_t *chain_core_run(const bmh_chain_opt_t *opt, int64_t l_pac, c
 	for (uint32_t r = 0; r < n_reads; ++r) offs32[r] = (uint32_t)read_offs[r];
 	x.reads = reads; x.read_offs = offs32.data(); x.pac = pac;
 	// (the form with the reference's seed filter: it runs for the reads the options make it apply to, as in the kernels launched for such options)
-	for (uint32_t r = 0; r < n_reads; ++r) chain_core::chain_read<false, false, true>(x, r, chain_core::global_scratch(x, r));
+	if (!compact) for (uint32_t r = 0; r < n_reads; ++r) chain_core::chain_read<false, false, true>(x, r, chain_core::global_scratch(x, r));
+	else {
+		std::vector<ch_seed_c> cs(S); std::vector<ch_chain_c> cc(S); std::vector<ch_est_c> ce(S); std::vector<uint16_t> co(S), ck(S), ci(S);
+		for (uint32_t r = 0; r < n_reads; ++r) {
+			if (n_ref[r] >= 0xFFFFu) { err = 9; break; }
+			const uint32_t b = prefix[r];
+			ch_scr<ch_compact_ty> L;
+			L.S = cs.data() + b; L.CH = cc.data() + b; L.E = ce.data() + b; L.order = co.data() + b; L.klist = ck.data() + b; L.cidx = ci.data() + b; L.opos = opos.data() + b; L.srt = srt.data() + b;
+			chain_core::chain_read<false, false, false>(x, r, L);
+		}
+	}
 	std::vector<uint32_t> qoff, qlen, toff, tlen, h0, job_read, job_reg, job_side;
 	std::vector<uint8_t> q, t;
 	auto text = [&](int64_t p) { const bool rev = p >= l_pac; const int64_t f = rev ? (l_pac << 1) - 1 - p : p; const int c = (pac[f >> 2] >> ((~f & 3) << 1)) & 3; return (uint8_t)(rev ? 3 - c : c); };
@@ -64,6 +76,19 @@ extern "C" result_t *chain_core_run(const bmh_chain_opt_t *opt, int64_t l_pac, c
 	R->regs_per_read = dup(rpr); R->qoff = dup(qoff); R->qlen = dup(qlen); R->toff = dup(toff); R->tlen = dup(tlen); R->h0 = dup(h0);
 	R->job_read = dup(job_read); R->job_reg = dup(job_reg); R->job_side = dup(job_side); R->q = dup(q); R->t = dup(t);
 	return R;
+}
+
+extern "C" result_t *chain_core_run(const bmh_chain_opt_t *opt, int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads,
+                                    const uint64_t *read_offs, const uint32_t *read_lens, const uint64_t *rbeg, const int32_t *qbeg,
+                                    const uint32_t *score, const uint32_t *n_ref, const uint32_t *prefix, uint64_t n_seeds)
+{
+	return run(opt, l_pac, pac, n_reads, reads, read_offs, read_lens, rbeg, qbeg, score, n_ref, prefix, n_seeds, 0);
+}
+extern "C" result_t *chain_core_run_compact(const bmh_chain_opt_t *opt, int64_t l_pac, const uint8_t *pac, uint32_t n_reads, const uint8_t *reads,
+                                            const uint64_t *read_offs, const uint32_t *read_lens, const uint64_t *rbeg, const int32_t *qbeg,
+                                            const uint32_t *score, const uint32_t *n_ref, const uint32_t *prefix, uint64_t n_seeds)
+{
+	return run(opt, l_pac, pac, n_reads, reads, read_offs, read_lens, rbeg, qbeg, score, n_ref, prefix, n_seeds, 1);
 }
 
 extern "C" void chain_core_free(result_t *R)

@@ -59,11 +59,12 @@ def _chain_core_lib():
                    [(k, C.POINTER(C.c_uint32)) for k in ("regs_per_read", "qoff", "qlen", "toff", "tlen", "h0", "job_read", "job_reg", "job_side")] + \
                    [("q", C.POINTER(C.c_uint8)), ("t", C.POINTER(C.c_uint8)), ("err", C.c_int)]
     lib.chain_core_run.restype = C.POINTER(Res)
+    lib.chain_core_run_compact.restype = C.POINTER(Res)
     lib.chain_core_free.argtypes = [C.POINTER(Res)]
     return lib
 
 
-def _run_core(lib, opt, g, reads, seeds):
+def _run_core(lib, opt, g, reads, seeds, compact=False):
     import ctypes as C
     n, L = reads.shape
     pad = (-len(g)) % 4
@@ -73,7 +74,8 @@ def _run_core(lib, opt, g, reads, seeds):
     keep = [pac, a(reads.reshape(-1), np.uint8), np.arange(n, dtype=np.uint64) * L, np.full(n, L, np.uint32), a(seeds["rbeg"], np.uint64),
             a(seeds["qbeg"], np.int32), a(seeds["score"], np.uint32), a(seeds["n_ref_pos"], np.uint32), a(seeds["prefix"], np.uint32)]
     p = lambda x: x.ctypes.data_as(C.c_void_p)
-    rp = lib.chain_core_run(C.byref(opt), C.c_int64(len(g)), p(keep[0]), C.c_uint32(n), *[p(k) for k in keep[1:]], C.c_uint64(len(keep[4])))
+    fn = lib.chain_core_run_compact if compact else lib.chain_core_run
+    rp = fn(C.byref(opt), C.c_int64(len(g)), p(keep[0]), C.c_uint32(n), *[p(k) for k in keep[1:]], C.c_uint64(len(keep[4])))
     r = rp.contents
     arr = lambda ptr, nn: np.ctypeslib.as_array(ptr, shape=(max(int(nn), 1),))[:int(nn)].copy()
     out = {k: arr(getattr(r, k), r.n_jobs) for k in ("qoff", "qlen", "toff", "tlen", "h0", "job_read", "job_reg", "job_side")}
@@ -99,6 +101,9 @@ def test_device_chain_core_matches_reference_jobs_and_host_builder(oracle):
     digs = sorted(hashlib.sha1(bytes([int(c["h0"][i]) & 255, int(c["h0"][i]) >> 8]) + c["q"][c["qoff"][i]:c["qoff"][i] + c["qlen"][i]].tobytes() + b"|" +
                                c["t"][c["toff"][i]:c["toff"][i] + c["tlen"][i]].tobytes()).digest() for i in range(c["n_jobs"]))
     assert digs == [bytes(r) for r in z["job_digests"]]
+    # the same with the COMPACT scratch records of the cooperative kernels (round 6: 16-bit links and read coordinates, csrc/chain_core.h ch_compact_ty)
+    cc = _run_core(lib, opt, g, z["reads"], seeds, compact=True)
+    assert cc["err"] == 0 and all(np.array_equal(cc[k], c[k]) for k in ("qoff", "qlen", "toff", "tlen", "h0", "job_read", "job_reg", "job_side", "regs_per_read", "q", "t"))
     # repeat-rich genome, default and non-default options, against the host builder
     gr = synth.make_genome(400_000, seed=9, repeat_frac=0.6, repeat_len=(200, 800), repeat_copies=(50, 400), repeat_div=0.02)
     idx = fmindex.build_fmd_index(gr)
@@ -117,6 +122,10 @@ def test_device_chain_core_matches_reference_jobs_and_host_builder(oracle):
         assert c["n_jobs"] == hj.n_jobs and c["n_regs"] == hj.n_regs
         for k in ("qoff", "qlen", "toff", "tlen", "h0", "job_read", "job_reg", "job_side", "regs_per_read", "q", "t"):
             assert np.array_equal(c[k], getattr(hj, k)), (over, k)
+        if not over.get("min_chain_weight", 0) or over["min_chain_weight"] >= 30:      # (the compact records are for the forms without the seed filter)
+            cc = _run_core(lib, o, gr, reads, s, compact=True)
+            for k in ("qoff", "qlen", "toff", "tlen", "h0", "job_read", "job_reg", "job_side", "regs_per_read", "q", "t"):
+                assert np.array_equal(cc[k], getattr(hj, k)), ("compact", over, k)
         hj.free()
 
 

@@ -12,8 +12,8 @@ Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
   no network) and verified completely (every adjacent pair of suffix-array rows compared).
   A step = one pass of the hot path over one batch, reads in -> alignment regions out, entirely on the device:
   SMEM seeding (pack, forward, backward, filter, expand, locate) -> chaining, chain filter and extension-job construction
-  with on-device reference fetch (bmh_chain_batch) -> seed extension (ksw_extend2 kernels) -> region merge.  Steps alternate
-  between two different read batches; `--inflight` (2) batches are in flight at a time, each on its own stream with its own
+  with on-device reference fetch (bmh_chain_batch) -> seed extension (ksw_extend2 kernels) -> region merge.  Steps take
+  `--distinct-batches` (4) different read batches in turn; `--inflight` (2) batches are in flight at a time, each on its own stream with its own
   workspaces and host thread, the way the reference keeps several gpu_storage batches in flight across its host threads
   (src/fastmap.c:417-534); every timed batch goes through the whole path (--inflight 1: strictly one batch at a time).  `value` has the reads resident in HBM when the timed region starts (bench contract);
   `incl_pcie` times the same steps fed from pinned host memory (reads H2D, regions D2H, double-buffered on copy streams) --

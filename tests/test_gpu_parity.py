@@ -1710,3 +1710,45 @@ def test_mate_rescue_kernels_agree_on_hard_windows(hip):
     for shape in (("60000", "150", "480"), ("40000", "249", "700")):
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "msw_bench.py"), *shape], env=dict(os.environ, MSW_HARD="1"), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "identical results: True" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_aligner_takes_registered_host_memory_and_times_its_copies(hip):
+    """bmh_aligner_run with the letters of the read set in pageable memory (staged into the lanes' pinned buffers by host threads) and in REGISTERED host
+    memory (bmh_host_pin = hipHostRegister: the batches go to the device straight from the caller's buffer): the same text; bmh_align_stats_t reports the
+    copies themselves -- bytes in (letters + offsets + lengths + names) and out (the SAM text), seconds from events on the lanes' streams."""
+    import ctypes as C
+    from bwamem_hip import fmindex, synth
+    from bwamem_hip.aligner import ReadSet
+    from bwamem_hip.lib import NativeAligner, PeOpt, ChainOpt, PostOpt
+    B = hip
+    L = B.load_library()
+    g = synth.make_genome(1_200_000, seed=23, repeat_frac=0.3)
+    contigs = [("chrA", 700_000), ("chrB", 500_000)]
+    dindex = B.Index.upload(fmindex.build_fmd_index(g), pac=_pack_pac(g), l_pac=len(g))
+    dindex.densify_sa(1)
+    n, rl = 6000, 150
+    reads = synth.make_reads(g, n, rl, seed=3)[0]
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    asc = synth.codes_to_ascii(flat)
+    names = [("r%05d" % i) for i in range(n)]
+    blob = np.frombuffer(("\0".join(names) + "\0").encode(), dtype=np.uint8)
+    rs = ReadSet(asc, np.arange(n, dtype=np.uint64) * np.uint64(rl), np.full(n, rl, np.uint32), blob, np.arange(n, dtype=np.uint64) * np.uint64(7), codes=flat)
+    co = ChainOpt(); L.bmh_chain_opt_default(C.byref(co)); po = PostOpt(); L.bmh_post_opt_default(C.byref(po)); pe_o = PeOpt(); L.bmh_pe_opt_default(C.byref(pe_o))
+    nat = NativeAligner(dindex, _pack_pac(g), len(g), contigs, None, co, B.ExtParams.default(), po, pe_o)
+    cuts = [0, 2000, 4000, n]
+    L.bmh_host_pin.argtypes = [C.c_void_p, C.c_size_t]; L.bmh_host_unpin.argtypes = [C.c_void_p]
+    texts, stats = [], []
+    for pinned in (False, True):
+        if pinned:
+            assert L.bmh_host_pin(asc.ctypes.data, asc.nbytes) == 0, B.lib._err(L)
+        try:
+            parts = []
+            st = nat.run(rs, cuts, False, lambda mv: parts.append(bytes(mv)), n_lanes=2, n_threads=4)
+            texts.append(b"".join(parts)); stats.append(st)
+        finally:
+            if pinned:
+                assert L.bmh_host_unpin(asc.ctypes.data) == 0
+    assert texts[0] == texts[1] and texts[0].count(b"\n") >= n
+    for st in stats:
+        assert st.d2h_bytes == len(texts[0]) and st.h2d_bytes >= n * rl + 8 * n and st.h2d_copy_seconds > 0 and st.d2h_copy_seconds > 0
+    nat.free(); dindex.free()

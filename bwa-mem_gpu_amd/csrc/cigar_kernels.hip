@@ -535,26 +535,55 @@ __global__ void __launch_bounds__(256) cigar_finish_kernel(cigar_args_t A)
 	const bool go = work && !rej;
 	const int qlen = g.qlen, rlen = g.rlen;
 	int n_ops = 0, flags = 0;
-	if (lead && !rej) {
-		if (J.kind == CG_TRIVIAL) { rev[0] = (uint32_t)qlen << 4; n_ops = 1; }
-		else {
-			const int w = J.w, n_col = J.n_col;
-			const uint8_t *z = A.z + J.zoff;
-			int i = rlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, state = 0, cur_op = -1, cur_len = 0;
-#define G_PUSH(op_, len_) do { if ((op_) == cur_op) cur_len += (len_); else { if (cur_op >= 0) { if (n_ops < A.max_cigar - 2) rev[n_ops] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; else flags |= 1; ++n_ops; } cur_op = (op_); cur_len = (len_); } } while (0)
-			while (i >= 0 && k >= 0) {
-				const int beg = i > w ? i - w : 0;
-				state = (int)z[(size_t)i * n_col + (k - beg)] >> (state << 1) & 3;
+	// The walk back through the direction matrix is a chain of dependent byte loads -- one round trip to HBM per step, 150-300 us for a read with a gap while the
+	// row's other fifteen lanes waited (round 6: the kernel was 4.6 ms per million alignments, the largest of the rows behind the path).  The path only ever moves
+	// up and to the left, one row and / or one column a step, so the next sixteen steps lie in the 16 x 16 window whose lower right corner is the current cell:
+	// the row's lanes fetch that window -- lane l the sixteen bytes of row i - l, all loads in flight at once -- into LDS, and ALL of them walk it (the same values
+	// in every lane; only the first one writes the operations), then the next window.
+	__shared__ uint32_t zwin[4][4][16 * 4 + 4];                                  // [wave of the block][row of the wave][16 rows x 4 dwords]
+	const bool dp = go && J.kind != CG_TRIVIAL;
+	if (lead && !rej && J.kind == CG_TRIVIAL) { rev[0] = (uint32_t)qlen << 4; n_ops = 1; }
+	{
+		const int w = J.w, n_col = J.n_col;
+		const uint8_t *z = A.z + J.zoff;
+		uint32_t *win = zwin[threadIdx.x >> 6][(lane >> 4) & 3];
+		int i = rlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, state = 0, cur_op = -1, cur_len = 0;
+#define G_PUSH(op_, len_) do { if ((op_) == cur_op) cur_len += (len_); else { if (cur_op >= 0) { if (n_ops < A.max_cigar - 2) { if (l16 == 0) rev[n_ops] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; } else flags |= 1; ++n_ops; } cur_op = (op_); cur_len = (len_); } } while (0)
+		while (dp && i >= 0 && k >= 0) {                                          // (uniform over the row's sixteen lanes)
+			const int i0 = i, k0 = k;
+			{
+				const int row = i0 - l16;
+				uint32_t b4[4] = {0u, 0u, 0u, 0u};
+				if (row >= 0) {
+					const int beg = row > w ? row - w : 0;
+					const uint8_t *zr = z + (size_t)row * n_col - beg;                // zr[column] for the columns of the row's band
+#pragma unroll
+					for (int c = 0; c < 16; ++c) {
+						const int kk = k0 - 15 + c, rel = kk - beg;
+						const uint32_t v = (kk >= 0 && rel >= 0 && rel < n_col) ? (uint32_t)zr[kk] : 0u;
+						b4[c >> 2] |= v << ((c & 3) << 3);
+					}
+				}
+#pragma unroll
+				for (int c = 0; c < 4; ++c) win[l16 * 4 + c] = b4[c];
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F);      // (the window is in LDS: lgkmcnt 0)
+			while (i >= 0 && k >= 0 && i0 - i < 16 && k0 - k < 16) {
+				const int byte = (int)(((const uint8_t *)win)[(i0 - i) * 16 + (k - (k0 - 15))]);
+				state = byte >> (state << 1) & 3;
 				const int op = state == 0 ? 0 : state == 1 ? 2 : 1;
 				G_PUSH(op, 1);
 				i -= state != 2; k -= state != 1;
 			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F);      // (read before the next window overwrites it)
+		}
+		if (dp) {
 			if (i >= 0) G_PUSH(2, i + 1);
 			if (k >= 0) G_PUSH(1, k + 1);
 			G_PUSH(-2, 0);
-#undef G_PUSH
 			if (n_ops > A.max_cigar - 2) n_ops = A.max_cigar - 2;
 		}
+#undef G_PUSH
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0);
 	n_ops = __shfl(n_ops, sh); flags = __shfl(flags, sh);

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "bmh_index_free", "bmh_index_probe", "bmh_index_replicate", "bmh_rccl_where", "bmh_rccl_unique_id", "bmh_rccl_comm_init_rank", "bmh_rccl_comm_destroy", "bmh_index_broadcast_rccl", "bmh_index_replicate_all", "bmh_shard_range", "bmh_index_densify_sa", "bmh_index_build", "bmh_seed_ws_create", "bmh_seed_ws_free", "bmh_seed_batch", "bmh_seed_last_timing",
     "bmh_host_pin", "bmh_host_unpin", "bmh_extend_batch", "bmh_extend_last_ms", "bmh_extend_last_unsupported", "bmh_extend_set_packed", "bmh_tune_set", "bmh_wtrace_start", "bmh_wtrace_stop", "bmh_wtrace_kept", "bmh_extend_release", "bmh_finalize_release", "bmh_matesw_release", "bmh_calib_gather", "bmh_calib_valu", "bmh_calib_valu_placed", "bmh_calib_last_clock",
     "bmh_jobs_frac_rep", "bmh_post_opt_default", "bmh_finalize_regs", "bmh_finalize_regs_device", "bmh_finalize_regs_device_last_ms", "bmh_sam_need_cigar", "bmh_format_sam", "bmh_free",
-    "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_finalize_pairs_dev", "bmh_dedup_regs_device", "bmh_finalize_pairs_deduped", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
+    "bmh_pe_opt_default", "bmh_finalize_pairs", "bmh_finalize_pairs_dev", "bmh_dedup_regs_device", "bmh_finalize_pairs_deduped", "bmh_rescue_check_counts", "bmh_sam_need_cigar_pe", "bmh_format_sam_pe",
     "bmh_chain_opt_default", "bmh_chain_last_timing", "bmh_build_jobs", "bmh_jobs_free", "bmh_jobs_sizes", "bmh_jobs_arrays", "bmh_merge_regs",
     "bmh_chain_ws_create", "bmh_chain_ws_free", "bmh_chain_set_contigs", "bmh_chain_set_alt", "bmh_effective_cpus", "bmh_aligner_create", "bmh_aligner_free", "bmh_aligner_run", "bmh_aligner_run_fasta", "bmh_chain_set_materialize", "bmh_chain_batch",
     "bmh_chain_extend", "bmh_chain_merge", "bmh_chain_extend_merge", "bmh_chain_extend_merge_timing", "bmh_cigar_batch", "bmh_cigar_release",
@@ -362,6 +362,8 @@ def load_library() -> C.CDLL:
                                      C.c_void_p, C.c_int]
     L.bmh_finalize_pairs_dev.restype = C.c_int64
     L.bmh_finalize_pairs_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + list(L.bmh_finalize_pairs.argtypes)
+    L.bmh_rescue_check_counts.restype = None
+    L.bmh_rescue_check_counts.argtypes = [C.POINTER(C.c_uint64)]
     L.bmh_finalize_pairs_deduped.restype = C.c_int64
     L.bmh_finalize_pairs_deduped.argtypes = list(L.bmh_finalize_pairs_dev.argtypes)
     L.bmh_dedup_regs_device.restype = C.c_int64

@@ -74,6 +74,7 @@ struct bmh_pairs_split_t {
 	void *user;
 	uint32_t *todo_pairs; uint64_t n_todo;
 	void **scratch_slot;            // optional: where the call keeps its large host arrays between calls (NULL at first; bmh_pairs_scratch_free); else the thread's
+	const struct bmh_rescue_in_t *rescue_in;     // optional (csrc/pair_kernels.h): the same regions on the device -- the rescue's windows are then found there, not by a host walk
 };
 void bmh_pairs_scratch_free(void *p);
 int64_t bmh_finalize_pairs_split(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, void *stream,

@@ -407,12 +407,166 @@ template <bool BYTE_ALL> __global__ void __launch_bounds__(16 * MSW_JOBS_PER_BLO
 	}
 }
 
+// ---- the rescue's windows found on the device (the first of pair_post.cpp's two walks): mem_matesw's tests up to the ksw_align2 call
+// (/root/reference/src/bwamem_pair.c:119-150) for every pair, on the regions mem_sort_dedup_patch left on the device.  A pair is
+// walked twice: pass 0 counts the alignments its mem_matesw calls would ask for (and the words of second-best bookkeeping they need), pass 1 -- after a
+// scan of the counts -- writes the jobs and their keys in pair order, the order the host's walk collected them in.  The reference calls
+// mem_sort_dedup_patch on the mate's list after a window was reached, which can remove a hit and with it change what a LATER call of the same pair
+// skips; the lists are taken as they are here.  That is exact where it matters: `active` (a call of the pair got as far as a window) is decided before
+// the first such call, and for an active pair the host's walk looks its alignments up by (end, hit, orientation) and computes the ones it does not
+// find itself (pair_post.cpp: matesw, sw_mode 2) -- a list that differs costs host time or a wasted job, never a different record.
+struct rj_pes_t { int low, high, failed; };
+struct rj_args_t {
+	long long l_pac; int n_contigs; const int64_t *ctg_off;
+	rj_pes_t pes[4]; int pen_unpaired, max_matesw, min_seed_len, a;
+	const int32_t *ded; const uint32_t *opr, *off, *lens;      // [..][16] regions behind mem_sort_dedup_patch, their number and first record per read, read lengths
+	uint32_t n_pairs;
+	uint32_t *cnt, *blw;                                        // [n_pairs + 1]: pass 0 counts, pass 1 reads the scanned offsets
+	uint8_t *active;
+	uint32_t *stat;                                             // [0] longest lane-private column in segments, [1] != 0: a job in 16-bit mode, [2..3] words of bookkeeping (64 bits)
+	bmh_msw_job_t *jobs; bmh_msw_key_t *keys;
+};
+
+__device__ __forceinline__ int rj_infer_dir(long long l_pac, long long b1, long long b2, long long *dist)      // mem_infer_dir
+{
+	const int r1 = b1 >= l_pac, r2 = b2 >= l_pac;
+	const long long p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+	*dist = p2 > b1 ? p2 - b1 : b1 - p2;
+	return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+__device__ __forceinline__ long long rj_rb(const int32_t *g) { return (long long)(uint32_t)g[4] | (long long)g[5] << 32; }
+__device__ __forceinline__ int rj_pos2rid(const rj_args_t &A, long long pos_f)          // bns_pos2rid
+{
+	if (pos_f >= A.l_pac) return -1;
+	if (A.n_contigs <= 1) return 0;
+	int left = 0, mid = 0, right = A.n_contigs;
+	while (left < right) {
+		mid = (left + right) >> 1;
+		if (pos_f >= A.ctg_off[mid]) {
+			if (mid == A.n_contigs - 1) break;
+			if (pos_f < A.ctg_off[mid + 1]) break;
+			left = mid + 1;
+		} else right = mid;
+	}
+	return mid;
+}
+__device__ __forceinline__ bool rj_takes(int l_ms, long long tlen, int xtra)        // bmh_matesw_device_takes
+{
+	const int lanes = (xtra & BMH_SW_XBYTE) ? 16 : 8;
+	return l_ms > 0 && (l_ms + lanes - 1) / lanes <= MSW_SLEN && tlen > 0 && tlen < 65536;
+}
+
+// OR over the 16 lanes of a row (every lane gets it)
+__device__ __forceinline__ int rj_row_or(int v)
+{
+	v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+	v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+	v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+	v |= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+	return v;
+}
+
+// One pair per ROW of 16 lanes (four pairs a wave): the calls of a pair are walked in order by the row, the mate's hits of a call are tested 64 at a time,
+// four by each lane (a pair of repeat-rich reads is 50 calls x hundreds of hits: one lane per pair took 15 ms a pass for the longest of them).
+template <int PASS> __global__ void __launch_bounds__(64) rescue_jobs_kernel(rj_args_t A)
+{
+	const uint32_t l = threadIdx.x & 15u, p = blockIdx.x * 4u + (threadIdx.x >> 4);
+	if (p >= A.n_pairs) return;                                       // (a whole row leaves: the DPP steps above never cross rows)
+	const long long l_pac = A.l_pac;
+	uint32_t nj = 0, nb = 0;
+	const uint32_t at = PASS ? A.cnt[p] : 0u, bl = PASS ? A.blw[p] : 0u;
+	int seg_max = 0, wide = 0;
+	bool active = false;
+	if (PASS && A.cnt[p + 1] == at) return;
+	for (int i = 0; i < 2; ++i) {
+		const uint32_t ra = 2 * p + (uint32_t)i, rm = 2 * p + (uint32_t)!i;
+		const int na = (int)A.opr[ra], nm = (int)A.opr[rm];
+		if (na == 0) continue;
+		const int32_t *a = A.ded + 16 * (size_t)A.off[ra], *m = A.ded + 16 * (size_t)A.off[rm];
+		const int l_ms = (int)A.lens[rm];
+		const int thr = a[1] - A.pen_unpaired;
+		int j = 0;
+		for (int k = 0; k < na && j < A.max_matesw; ++k) {
+			const int32_t *g = a + 16 * k;
+			if (g[1] < thr) continue;
+			const long long arb = rj_rb(g);
+			// ---- one mem_matesw call: which orientations the mate's hits leave open
+			int skip = 0;
+			for (int r = 0; r < 4; ++r) skip |= (A.pes[r].failed ? 1 : 0) << r;
+			for (int t0 = 0; t0 < nm && skip != 15; t0 += 64) {
+				int bits = 0;
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const int t = t0 + u * 16 + (int)l;
+					if (t < nm) {
+						long long dist;
+						const int r = rj_infer_dir(l_pac, arb, rj_rb(m + 16 * t), &dist);
+						if (dist >= A.pes[r].low && dist <= A.pes[r].high) bits |= 1 << r;
+					}
+				}
+				skip |= rj_row_or(bits);
+			}
+			for (int r = 0; r < 4 && skip != 15; ++r) {
+				if (skip >> r & 1) continue;
+				const int is_rev = (r >> 1 != (r & 1)), is_larger = !(r >> 1);
+				long long rb, re;
+				if (!is_rev) {
+					rb = is_larger ? arb + A.pes[r].low : arb - A.pes[r].high;
+					re = (is_larger ? arb + A.pes[r].high : arb - A.pes[r].low) + l_ms;
+				} else {
+					rb = (is_larger ? arb + A.pes[r].low : arb - A.pes[r].high) - l_ms;
+					re = is_larger ? arb + A.pes[r].high : arb - A.pes[r].low;
+				}
+				if (rb < 0) rb = 0;
+				if (re > l_pac << 1) re = l_pac << 1;
+				if (rb >= re) continue;
+				// bns_fetch_seq's clipping to the sequence (and strand) of the window's middle
+				const long long mid = (rb + re) >> 1;
+				const bool mrev = mid >= l_pac;
+				const int rid = rj_pos2rid(A, mrev ? (l_pac << 1) - 1 - mid : mid);
+				long long far_beg = A.n_contigs > 1 ? A.ctg_off[rid] : 0, far_end = A.n_contigs > 1 ? (rid + 1 < A.n_contigs ? A.ctg_off[rid + 1] : l_pac) : l_pac;
+				if (mrev) { const long long t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
+				rb = rb > far_beg ? rb : far_beg;
+				re = re < far_end ? re : far_end;
+				if (rb >= re || g[13] != rid || re - rb < A.min_seed_len) continue;
+				active = true;
+				const int xtra = BMH_SW_XSUBO | BMH_SW_XSTART | (l_ms * A.a < 250 ? BMH_SW_XBYTE : 0) | (A.min_seed_len * A.a);
+				if (!rj_takes(l_ms, re - rb, xtra)) continue;
+				const uint32_t words = (uint32_t)((re - rb) / 2 + 2);
+				if (PASS) {
+					if (l == 0) {
+						bmh_msw_job_t jb;
+						jb.rb = rb; jb.re = re; jb.read = rm; jb.l_ms = l_ms; jb.is_rev = is_rev; jb.xtra = xtra; jb.bl_off = bl + nb; jb.pad = 0;
+						A.jobs[at + nj] = jb;
+						bmh_msw_key_t ky; ky.pair = p; ky.j = (uint16_t)j; ky.i = (uint8_t)i; ky.r = (uint8_t)r;
+						A.keys[at + nj] = ky;
+					}
+				} else {
+					const int lanes = (xtra & BMH_SW_XBYTE) ? 16 : 8, sl = (l_ms + lanes - 1) / lanes;
+					seg_max = sl > seg_max ? sl : seg_max; wide |= lanes == 8;
+				}
+				++nj; nb += words;
+			}
+			++j;
+		}
+	}
+	if (!PASS && l == 0) {
+		A.cnt[p] = nj; A.blw[p] = nb; A.active[p] = active ? 1 : 0;
+		if (nj) { atomicMax(A.stat, (uint32_t)seg_max); if (wide) atomicOr(A.stat + 1, 1u); atomicAdd((unsigned long long *)(A.stat + 2), (unsigned long long)nb); }
+	}
+}
+
 // ---- host side
-struct msw_scratch_t { bmh_msw_job_t *d_jobs; int32_t *d_out; uint32_t *d_bl; size_t cap_jobs, cap_bl; };
+struct msw_scratch_t {
+	bmh_msw_job_t *d_jobs; int32_t *d_out; uint32_t *d_bl; size_t cap_jobs, cap_bl;
+	// the rescue's windows found on the device
+	uint32_t *d_cnt, *d_blw, *d_stat; uint8_t *d_active; bmh_msw_key_t *d_keys; void *d_scan; size_t cap_pairs, cap_keys, cap_scan;
+	uint32_t rj_n_jobs, rj_cap; uint64_t rj_bl; bool rj_byte_all; rj_args_t rj;
+};
 static std::mutex g_msw_mu;
 static std::map<std::pair<int, void *>, msw_scratch_t *> g_msw_map;
 
-// the (device, stream) scratch of bmh_matesw_batch_device: freed when the caller retires the stream (stream idle, its device current)
+// the (device, stream) scratch of bmh_matesw_batch_device / bmh_rescue_*_device: freed when the caller retires the stream (stream idle, its device current)
 extern "C" void bmh_matesw_release(void *stream_)
 {
 	int dev = 0;
@@ -425,10 +579,9 @@ extern "C" void bmh_matesw_release(void *stream_)
 		S = it->second;
 		g_msw_map.erase(it);
 	}
-	if (S->d_jobs) (void)hipFree(S->d_jobs);
-	if (S->d_out) (void)hipFree(S->d_out);
-	if (S->d_bl) (void)hipFree(S->d_bl);
-	free(S);
+	void *ps[] = {S->d_jobs, S->d_out, S->d_bl, S->d_cnt, S->d_blw, S->d_stat, S->d_active, S->d_keys, S->d_scan};
+	for (void *q : ps) if (q) (void)hipFree(q);
+	delete S;
 }
 
 // can the kernel take this job? (the host computes the others itself)
@@ -438,29 +591,19 @@ extern "C" int bmh_matesw_device_takes(int l_ms, int64_t tlen, int xtra)
 	return l_ms > 0 && (l_ms + lanes - 1) / lanes <= MSW_SLEN && tlen > 0 && tlen < 65536;
 }
 
-extern "C" int bmh_matesw_batch_device(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, const bmh_ext_params_t *ep,
-                                       bmh_msw_job_t *jobs, uint64_t n_jobs, int32_t *out, void *stream_)
+static int msw_scratch_of(void *stream_, msw_scratch_t **out)
 {
-	if (!idx || !idx->dev.pac || !d_reads || !d_offs || !ep || (n_jobs && (!jobs || !out))) { bmh_set_error("bmh_matesw_batch_device: null argument"); return BMH_EINVAL; }
-	if (n_jobs == 0) return BMH_OK;
-	if (n_jobs >> 31) { bmh_set_error("bmh_matesw_batch_device: too many jobs"); return BMH_ECAPACITY; }
-	hipStream_t st = (hipStream_t)stream_;
 	int dev = 0;
 	HIPCK(hipGetDevice(&dev));
-	msw_scratch_t *S;
-	{
-		std::lock_guard<std::mutex> lk(g_msw_mu);
-		auto key = std::make_pair(dev, stream_);
-		auto it = g_msw_map.find(key);
-		if (it == g_msw_map.end()) { S = (msw_scratch_t *)calloc(1, sizeof(msw_scratch_t)); g_msw_map[key] = S; }
-		else S = it->second;
-	}
-	uint64_t bl = 0;
-	int cap = 1;                                             // the longest lane-private column of the batch, in segments
-	bool byte_all = true;
-	for (uint64_t k = 0; k < n_jobs; ++k) { const int lanes = (jobs[k].xtra & BMH_SW_XBYTE) ? 16 : 8; const int sl = (jobs[k].l_ms + lanes - 1) / lanes; cap = sl > cap ? sl : cap; byte_all = byte_all && lanes == 16; }
-	if (cap > MSW_SLEN) { bmh_set_error("bmh_matesw_batch_device: a job the kernel does not take (see bmh_matesw_device_takes)"); return BMH_EINVAL; }
-	for (uint64_t k = 0; k < n_jobs; ++k) { jobs[k].bl_off = (uint32_t)bl; bl += (uint64_t)(jobs[k].re - jobs[k].rb) / 2 + 2; if (bl >> 32) { bmh_set_error("bmh_matesw_batch_device: windows too long"); return BMH_ECAPACITY; } }
+	std::lock_guard<std::mutex> lk(g_msw_mu);
+	auto key = std::make_pair(dev, stream_);
+	auto it = g_msw_map.find(key);
+	if (it == g_msw_map.end()) { *out = new msw_scratch_t(); memset((void *)*out, 0, sizeof(msw_scratch_t)); g_msw_map[key] = *out; }
+	else *out = it->second;
+	return BMH_OK;
+}
+static int msw_room(msw_scratch_t *S, uint64_t n_jobs, uint64_t bl)
+{
 	if (n_jobs > S->cap_jobs) {
 		if (S->d_jobs) (void)hipFree(S->d_jobs);
 		if (S->d_out) (void)hipFree(S->d_out);
@@ -476,7 +619,11 @@ extern "C" int bmh_matesw_batch_device(const bmh_index_t *idx, const uint8_t *d_
 		HIPCK(hipMalloc((void **)&S->d_bl, 4 * c));
 		S->cap_bl = c;
 	}
-	HIPCK(hipMemcpyAsync(S->d_jobs, jobs, sizeof(bmh_msw_job_t) * n_jobs, hipMemcpyHostToDevice, st));
+	return BMH_OK;
+}
+// the jobs in S->d_jobs (bl_off set) -> S->d_out
+static int msw_launch(msw_scratch_t *S, const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, const bmh_ext_params_t *ep, uint64_t n_jobs, int cap, bool byte_all, hipStream_t st)
+{
 	msw_args_t A;
 	A.jobs = S->d_jobs; A.n_jobs = (uint32_t)n_jobs; A.reads = d_reads; A.read_offs = d_offs; A.pac = idx->dev.pac; A.l_pac = (long long)idx->dev.l_pac;
 	A.a = ep->a; A.b = ep->b; A.o_del = ep->o_del; A.e_del = ep->e_del; A.o_ins = ep->o_ins; A.e_ins = ep->e_ins;
@@ -486,10 +633,116 @@ extern "C" int bmh_matesw_batch_device(const bmh_index_t *idx, const uint8_t *d_
 	const bool reg_form = byte_all && cap <= 16 && ep->o_ins > 0 && ep->e_ins > 0 && ep->a < 100 && ep->b < 100 && bmh_tune("MSW_REG", 1) != 0;
 	if (reg_form && cap <= 10) msw_reg_kernel<10><<<nblk, 16 * MSW_JOBS_PER_BLOCK, 0, st>>>(A);
 	else if (reg_form) msw_reg_kernel<16><<<nblk, 16 * MSW_JOBS_PER_BLOCK, 0, st>>>(A);
-	else if (byte_all) msw_kernel<true><<<(unsigned)((n_jobs + MSW_JOBS_PER_BLOCK - 1) / MSW_JOBS_PER_BLOCK), 16 * MSW_JOBS_PER_BLOCK, (size_t)cap * MSW_ROW * 9, st>>>(A, cap);
-	else msw_kernel<false><<<(unsigned)((n_jobs + MSW_JOBS_PER_BLOCK - 1) / MSW_JOBS_PER_BLOCK), 16 * MSW_JOBS_PER_BLOCK, (size_t)cap * MSW_ROW * 9, st>>>(A, cap);
+	else if (byte_all) msw_kernel<true><<<nblk, 16 * MSW_JOBS_PER_BLOCK, (size_t)cap * MSW_ROW * 9, st>>>(A, cap);
+	else msw_kernel<false><<<nblk, 16 * MSW_JOBS_PER_BLOCK, (size_t)cap * MSW_ROW * 9, st>>>(A, cap);
+	HIPCK(hipGetLastError());
+	return BMH_OK;
+}
+
+extern "C" int bmh_matesw_batch_device(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, const bmh_ext_params_t *ep,
+                                       bmh_msw_job_t *jobs, uint64_t n_jobs, int32_t *out, void *stream_)
+{
+	if (!idx || !idx->dev.pac || !d_reads || !d_offs || !ep || (n_jobs && (!jobs || !out))) { bmh_set_error("bmh_matesw_batch_device: null argument"); return BMH_EINVAL; }
+	if (n_jobs == 0) return BMH_OK;
+	if (n_jobs >> 31) { bmh_set_error("bmh_matesw_batch_device: too many jobs"); return BMH_ECAPACITY; }
+	hipStream_t st = (hipStream_t)stream_;
+	msw_scratch_t *S;
+	{ const int rc = msw_scratch_of(stream_, &S); if (rc != BMH_OK) return rc; }
+	uint64_t bl = 0;
+	int cap = 1;                                             // the longest lane-private column of the batch, in segments
+	bool byte_all = true;
+	for (uint64_t k = 0; k < n_jobs; ++k) { const int lanes = (jobs[k].xtra & BMH_SW_XBYTE) ? 16 : 8; const int sl = (jobs[k].l_ms + lanes - 1) / lanes; cap = sl > cap ? sl : cap; byte_all = byte_all && lanes == 16; }
+	if (cap > MSW_SLEN) { bmh_set_error("bmh_matesw_batch_device: a job the kernel does not take (see bmh_matesw_device_takes)"); return BMH_EINVAL; }
+	for (uint64_t k = 0; k < n_jobs; ++k) { jobs[k].bl_off = (uint32_t)bl; bl += (uint64_t)(jobs[k].re - jobs[k].rb) / 2 + 2; if (bl >> 32) { bmh_set_error("bmh_matesw_batch_device: windows too long"); return BMH_ECAPACITY; } }
+	{ const int rc = msw_room(S, n_jobs, bl); if (rc != BMH_OK) return rc; }
+	HIPCK(hipMemcpyAsync(S->d_jobs, jobs, sizeof(bmh_msw_job_t) * n_jobs, hipMemcpyHostToDevice, st));
+	{ const int rc = msw_launch(S, idx, d_reads, d_offs, ep, n_jobs, cap, byte_all, st); if (rc != BMH_OK) return rc; }
 	HIPCK(hipMemcpyAsync(out, S->d_out, sizeof(int32_t) * 7 * n_jobs, hipMemcpyDeviceToHost, st));
 	HIPCK(hipStreamSynchronize(st));
 	HIPCK(hipGetLastError());
+	return BMH_OK;
+}
+
+// The rescue's windows of a batch of interleaved pairs found on the device (rescue_jobs_kernel), in two calls on one stream:
+// bmh_rescue_count_device: pair_off [n_reads / 2 + 1] receives the first job of every pair (and the number of jobs at the end), active [n_reads / 2] whether a
+// mem_matesw call of the pair reached a window; returns the number of jobs.  bmh_rescue_run_device: the jobs' keys [n_jobs] and results [n_jobs][7]
+// (as bmh_matesw_batch_device).  pes [4][5] as bmh_finalize_pairs' pes_out.  Both wait for the stream.
+extern "C" int64_t bmh_rescue_count_device(const bmh_index_t *idx, const bmh_rescue_in_t *in, const bmh_ext_params_t *ep, int min_seed_len, const bmh_pe_opt_t *pe,
+                                           const double *pes, uint32_t n_reads, uint32_t *pair_off, uint8_t *active, void *stream_)
+{
+	if (!idx || !idx->dev.pac || !in || !in->d_dedup || !in->d_opr || !in->d_roff || !in->d_lens || !ep || !pe || !pes || !pair_off || !active || (in->n_contigs > 1 && !in->d_ctg_off)) {
+		bmh_set_error("bmh_rescue_count_device: null argument"); return BMH_EINVAL;
+	}
+	const uint32_t np = n_reads / 2;
+	hipStream_t st = (hipStream_t)stream_;
+	msw_scratch_t *S;
+	{ const int rc = msw_scratch_of(stream_, &S); if (rc != BMH_OK) return rc; }
+	S->rj_n_jobs = 0;
+	pair_off[0] = 0;
+	if (np == 0) return 0;
+	if ((size_t)np + 1 > S->cap_pairs) {
+		void *ps[] = {S->d_cnt, S->d_blw, S->d_active};
+		for (void *q : ps) if (q) (void)hipFree(q);
+		S->d_cnt = S->d_blw = nullptr; S->d_active = nullptr; S->cap_pairs = 0;
+		const size_t c = (size_t)np + np / 4 + 1024;
+		HIPCK(hipMalloc((void **)&S->d_cnt, 4 * c)); HIPCK(hipMalloc((void **)&S->d_blw, 4 * c)); HIPCK(hipMalloc((void **)&S->d_active, c));
+		S->cap_pairs = c;
+	}
+	if (!S->d_stat) HIPCK(hipMalloc((void **)&S->d_stat, 16));
+	const size_t sb = bmh_pair_scan_bytes(np + 1);
+	if (sb > S->cap_scan) { if (S->d_scan) (void)hipFree(S->d_scan); S->d_scan = nullptr; S->cap_scan = 0; HIPCK(hipMalloc(&S->d_scan, sb)); S->cap_scan = sb; }
+	rj_args_t &A = S->rj;
+	memset(&A, 0, sizeof(A));
+	A.l_pac = (long long)idx->dev.l_pac; A.n_contigs = in->n_contigs > 1 ? in->n_contigs : 1; A.ctg_off = in->n_contigs > 1 ? in->d_ctg_off : nullptr;
+	for (int d = 0; d < 4; ++d) { A.pes[d].low = (int)pes[5 * d]; A.pes[d].high = (int)pes[5 * d + 1]; A.pes[d].failed = (int)pes[5 * d + 2]; }
+	A.pen_unpaired = pe->pen_unpaired; A.max_matesw = pe->max_matesw; A.min_seed_len = min_seed_len; A.a = ep->a;
+	A.ded = in->d_dedup; A.opr = in->d_opr; A.off = in->d_roff; A.lens = in->d_lens; A.n_pairs = np;
+	A.cnt = S->d_cnt; A.blw = S->d_blw; A.active = S->d_active; A.stat = S->d_stat;
+	HIPCK(hipMemsetAsync(S->d_stat, 0, 16, st));
+	HIPCK(hipMemsetAsync(S->d_cnt + np, 0, 4, st)); HIPCK(hipMemsetAsync(S->d_blw + np, 0, 4, st));
+	rescue_jobs_kernel<0><<<(np + 3) / 4, 64, 0, st>>>(A);
+	HIPCK(hipGetLastError());
+	{ const int rc = bmh_pair_scan(S->d_cnt, S->d_cnt, np + 1, S->d_scan, S->cap_scan, st); if (rc != BMH_OK) return rc; }
+	uint32_t stat[4] = {0, 0, 0, 0}, last_bl = 0;
+	HIPCK(hipMemcpyAsync(pair_off, S->d_cnt, 4 * ((size_t)np + 1), hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(active, S->d_active, np, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(stat, S->d_stat, 16, hipMemcpyDeviceToHost, st));
+	HIPCK(hipStreamSynchronize(st));
+	const uint32_t nj = pair_off[np];
+	if (nj >> 31) { bmh_set_error("bmh_rescue_count_device: too many jobs"); return BMH_ECAPACITY; }
+	if (stat[3]) { bmh_set_error("bmh_rescue_count_device: windows too long"); return BMH_ECAPACITY; }      // (the words of bookkeeping: offsets of 32 bits, like bmh_matesw_batch_device)
+	{ const int rc = bmh_pair_scan(S->d_blw, S->d_blw, np + 1, S->d_scan, S->cap_scan, st); if (rc != BMH_OK) return rc; }
+	HIPCK(hipMemcpyAsync(&last_bl, S->d_blw + np, 4, hipMemcpyDeviceToHost, st));
+	HIPCK(hipStreamSynchronize(st));
+	S->rj_n_jobs = nj; S->rj_bl = last_bl; S->rj_cap = stat[0] ? stat[0] : 1; S->rj_byte_all = stat[1] == 0;
+	return (int64_t)nj;
+}
+
+extern "C" int bmh_rescue_run_device(const bmh_index_t *idx, const uint8_t *d_reads, const uint32_t *d_offs, const bmh_ext_params_t *ep, bmh_msw_key_t *keys, int32_t *out, void *stream_)
+{
+	if (!idx || !idx->dev.pac || !d_reads || !d_offs || !ep) { bmh_set_error("bmh_rescue_run_device: null argument"); return BMH_EINVAL; }
+	hipStream_t st = (hipStream_t)stream_;
+	msw_scratch_t *S;
+	{ const int rc = msw_scratch_of(stream_, &S); if (rc != BMH_OK) return rc; }
+	const uint64_t nj = S->rj_n_jobs;
+	if (nj == 0) return BMH_OK;
+	if (!keys || !out) { bmh_set_error("bmh_rescue_run_device: null argument"); return BMH_EINVAL; }
+	if ((int)S->rj_cap > MSW_SLEN) { bmh_set_error("bmh_rescue_run_device: internal error: a job the kernel does not take"); return BMH_EINVAL; }
+	{ const int rc = msw_room(S, nj, S->rj_bl); if (rc != BMH_OK) return rc; }
+	if (nj > S->cap_keys) {
+		if (S->d_keys) (void)hipFree(S->d_keys);
+		S->d_keys = nullptr; S->cap_keys = 0;
+		const size_t c = nj + nj / 4 + 1024;
+		HIPCK(hipMalloc((void **)&S->d_keys, sizeof(bmh_msw_key_t) * c));
+		S->cap_keys = c;
+	}
+	rj_args_t A = S->rj;
+	A.jobs = S->d_jobs; A.keys = S->d_keys;
+	rescue_jobs_kernel<1><<<(A.n_pairs + 3) / 4, 64, 0, st>>>(A);
+	HIPCK(hipGetLastError());
+	{ const int rc = msw_launch(S, idx, d_reads, d_offs, ep, nj, (int)S->rj_cap, S->rj_byte_all, st); if (rc != BMH_OK) return rc; }
+	HIPCK(hipMemcpyAsync(keys, S->d_keys, sizeof(bmh_msw_key_t) * nj, hipMemcpyDeviceToHost, st));
+	HIPCK(hipMemcpyAsync(out, S->d_out, sizeof(int32_t) * 7 * nj, hipMemcpyDeviceToHost, st));
+	HIPCK(hipStreamSynchronize(st));
 	return BMH_OK;
 }

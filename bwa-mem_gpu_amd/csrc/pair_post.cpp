@@ -35,7 +35,8 @@ struct Pes { int low, high, failed; double avg, std; };
 // sw_mode 1: an alignment that is about to be computed is written down instead (and answered "nothing found"); sw_mode 2: it is taken
 // from the batch's results (or computed here, if the first walk did not foresee it -- the regions a rescue adds can change which
 // orientations later calls of the same pair skip); sw_mode 0: computed on the spot (the host-only form).
-struct SwKey { uint32_t pair; uint16_t j; uint8_t i, r; };
+// With the batch's regions on the device (bmh_pairs_split_t::rescue_in) the first walk is a kernel too (pair_kernels.hip: rescue_jobs_kernel).
+typedef bmh_msw_key_t SwKey;
 struct PCtx {
 	Ctx x; const bmh_pe_opt_t *pe; Pes pes[4];
 	const int64_t *ctg_off; const int32_t *ctg_len;
@@ -155,9 +156,12 @@ bool fetch_window(const PCtx &c, int64_t *beg, int64_t mid, int64_t *end, int *r
 static std::atomic<unsigned long long> g_ms_calls{0}, g_ms_sw{0}, g_ms_cells{0}, g_ms_hits{0};
 static const bool g_pair_stats = getenv("BMH_POST_STATS") != nullptr;      // the counters are only read (and only bumped) with it set
 
+// knob RESCUE_CHECK (BMH_RESCUE_CHECK=1 / bmh_tune_set): the device's search for the rescue's windows against the host's first walk (bmh_rescue_check_counts)
+static std::atomic<unsigned long long> g_chk_batches{0}, g_chk_pairs{0}, g_chk_jobs{0}, g_chk_active{0}, g_chk_lists{0};
+
 // BMH_PAIR_PROFILE: where the second walk spends its time (nanoseconds summed over the threads)
 static const bool g_pair_prof = getenv("BMH_PAIR_PROFILE") != nullptr;
-static std::atomic<unsigned long long> g_ns_msw{0}, g_ns_msw_dedup{0}, g_ns_mark{0}, g_ns_pair{0}, g_ns_rest{0};
+static std::atomic<unsigned long long> g_ns_msw{0}, g_ns_msw_dedup{0}, g_ns_mark{0}, g_ns_pair{0};
 static inline unsigned long long now_ns() { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ma_state (optional, one byte per mate list, 0 at first): bit 0 = the list has been through a mem_sort_dedup_patch call of THIS function (the one without
@@ -464,7 +468,7 @@ struct PairScratch {
 	std::vector<PairPart> parts;
 	std::vector<std::vector<SwKey>> tk; std::vector<std::vector<bmh_msw_job_t>> tj;
 	std::vector<SwKey> all_keys; std::vector<bmh_msw_job_t> all_jobs; std::vector<uint64_t> pair_off, in_off; std::vector<int32_t> sw_res; std::vector<uint8_t> pair_active;
-	std::vector<uint32_t> cnt;
+	std::vector<uint32_t> cnt, off32;
 	~PairScratch() { free(flat); }
 };
 thread_local PairScratch g_pair_scratch;
@@ -545,29 +549,72 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 		if (rc != BMH_OK) return rc;
 	}
 	if (pes_out) for (int d = 0; d < 4; ++d) { pes_out[5 * d] = c.pes[d].low; pes_out[5 * d + 1] = c.pes[d].high; pes_out[5 * d + 2] = c.pes[d].failed; pes_out[5 * d + 3] = c.pes[d].avg; pes_out[5 * d + 4] = c.pes[d].std; }
-	// With a device: the local alignments of the mate rescue as one batch (pair_kernels.hip).  First walk: which alignments mem_matesw asks
-	// for (ranges of pairs on threads; their lists concatenate in pair order); then the kernel; the walk below takes the results.
+	// With a device: the local alignments of the mate rescue as one batch (pair_kernels.hip).  First which alignments mem_matesw asks for -- a walk of
+	// all pairs here, or a kernel where the regions are on the device too --, then the kernel that computes them; the walk below takes the results.
 	std::vector<SwKey> &all_keys = S.all_keys; std::vector<bmh_msw_job_t> &all_jobs = S.all_jobs; std::vector<uint64_t> &pair_off = S.pair_off; std::vector<int32_t> &sw_res = S.sw_res;
 	std::vector<uint8_t> &pair_active = S.pair_active;
 	all_keys.clear(); all_jobs.clear();
 	double t_sw0 = now(), t_sw1 = t_sw0, t_sw2 = t_sw0;
-	if (idx && !pe->no_rescue && n_reads) {
+	// the host's first walk: the alignments every pair's mem_matesw calls ask for (ranges of pairs on threads; their lists concatenate in pair order)
+	auto first_walk = [&](std::vector<SwKey> &keys_out, std::vector<bmh_msw_job_t> &jobs_out, std::vector<uint8_t> &active_out) {
 		std::vector<std::vector<SwKey>> &tk = S.tk; std::vector<std::vector<bmh_msw_job_t>> &tj = S.tj;
 		if (tk.size() < (size_t)n_threads) { tk.resize((size_t)n_threads); tj.resize((size_t)n_threads); }
 		for (auto &v : tk) v.clear();
 		for (auto &v : tj) v.clear();
-		pair_active.assign((size_t)n_reads / 2 + 1, 0);
-		c.pair_active = pair_active.data();                         // (a pair belongs to one thread: plain bytes)
+		active_out.assign((size_t)n_reads / 2 + 1, 0);
 		par([&](int t, uint32_t p0, uint32_t p1) {
 			PCtx cl = c;
 			cl.sw_mode = 1; cl.col_keys = &tk[(size_t)t]; cl.col_jobs = &tj[(size_t)t];
+			cl.pair_active = active_out.data();                     // (a pair belongs to one thread: plain bytes)
 			ReadOut o2[2];
 			for (uint32_t p = p0; p < p1; ++p) {
 				for (int i = 0; i < 2; ++i) { const uint32_t r = 2 * p + (uint32_t)i; o2[i].regs.assign(flat + in_off[r], flat + in_off[r] + cnt[r]); }
 				sam_pe(cl, (uint64_t)(popt->id0 / 2) + p, 2 * p, o2);
 			}
 		}, n_reads / 2);
-		for (int t = 0; t < n_threads; ++t) { all_keys.insert(all_keys.end(), tk[(size_t)t].begin(), tk[(size_t)t].end()); all_jobs.insert(all_jobs.end(), tj[(size_t)t].begin(), tj[(size_t)t].end()); }
+		keys_out.clear(); jobs_out.clear();
+		for (int t = 0; t < n_threads; ++t) { keys_out.insert(keys_out.end(), tk[(size_t)t].begin(), tk[(size_t)t].end()); jobs_out.insert(jobs_out.end(), tj[(size_t)t].begin(), tj[(size_t)t].end()); }
+	};
+	if (idx && !pe->no_rescue && n_reads && split && split->rescue_in) {
+		// the windows of every pair's mem_matesw calls found by a kernel on the regions the device kept, aligned there, keys and results copied back
+		double pv[20];
+		for (int d = 0; d < 4; ++d) { pv[5 * d] = c.pes[d].low; pv[5 * d + 1] = c.pes[d].high; pv[5 * d + 2] = c.pes[d].failed; pv[5 * d + 3] = c.pes[d].avg; pv[5 * d + 4] = c.pes[d].std; }
+		pair_active.assign((size_t)n_reads / 2 + 1, 0);
+		S.off32.assign((size_t)n_reads / 2 + 1, 0);
+		const int64_t nj = bmh_rescue_count_device(idx, split->rescue_in, ep, copt->min_seed_len, pe, pv, n_reads, S.off32.data(), pair_active.data(), stream);
+		if (nj < 0) return nj;
+		t_sw1 = now();
+		all_keys.resize((size_t)nj); all_jobs.resize((size_t)nj); sw_res.resize(7 * (size_t)nj + 7);       // (all_jobs: its size is what the profile line prints)
+		const int rc = bmh_rescue_run_device(idx, d_reads, d_offs, ep, all_keys.data(), sw_res.data(), stream);
+		if (rc != BMH_OK) return rc;
+		pair_off.resize((size_t)n_reads / 2 + 1);
+		for (size_t p = 0; p <= (size_t)n_reads / 2; ++p) pair_off[p] = S.off32[p];
+		t_sw2 = now();
+		if (bmh_tune("RESCUE_CHECK", 0) != 0) {
+			// the host's walk beside it -- the same pairs active (always), the same calls asked for in the same order (unless a
+			// mem_sort_dedup_patch call of the walk changed a list: counted apart)
+			std::vector<SwKey> hk; std::vector<bmh_msw_job_t> hj; std::vector<uint8_t> ha;
+			first_walk(hk, hj, ha);
+			unsigned long long bad_active = 0, bad_lists = 0;
+			std::vector<uint64_t> ho((size_t)n_reads / 2 + 1, 0);
+			for (const SwKey &k : hk) ++ho[(size_t)k.pair + 1];
+			for (size_t p = 0; p < (size_t)n_reads / 2; ++p) ho[p + 1] += ho[p];
+			for (size_t p = 0; p < (size_t)n_reads / 2; ++p) {
+				bad_active += ha[p] != pair_active[p];
+				bool same = ho[p + 1] - ho[p] == pair_off[p + 1] - pair_off[p];
+				for (uint64_t t = 0; same && t < ho[p + 1] - ho[p]; ++t) {
+					const SwKey &x = hk[ho[p] + t], &y = all_keys[pair_off[p] + t];
+					same = x.pair == y.pair && x.j == y.j && x.i == y.i && x.r == y.r;
+				}
+				bad_lists += !same;
+			}
+			g_chk_batches++; g_chk_pairs += n_reads / 2; g_chk_jobs += (unsigned long long)nj; g_chk_active += bad_active; g_chk_lists += bad_lists;
+		}
+		c.pair_active = pair_active.data();
+		c.sw_mode = 2; c.keys = all_keys.data(); c.pair_off = pair_off.data(); c.res = sw_res.data();
+	} else if (idx && !pe->no_rescue && n_reads) {
+		first_walk(all_keys, all_jobs, pair_active);
+		c.pair_active = pair_active.data();
 		pair_off.assign((size_t)n_reads / 2 + 1, 0);
 		for (const SwKey &k : all_keys) ++pair_off[(size_t)k.pair + 1];
 		for (size_t p = 0; p < (size_t)n_reads / 2; ++p) pair_off[p + 1] += pair_off[p];
@@ -592,7 +639,9 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 	std::vector<Part> &parts = S.parts;
 	parts.resize((size_t)n_threads);
 	for (Part &P : parts) { P.rec.clear(); P.n.clear(); P.h.clear(); P.uf.clear(); P.pairs.clear(); }
+	std::vector<double> th_ms((size_t)n_threads, 0.0); const double t_w0 = now();
 	par([&](int t, uint32_t p0, uint32_t p1) {
+		struct Stamp { double *o; double t0; ~Stamp() { *o = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; } } stamp{&th_ms[(size_t)t], t_w0};
 		Part &P = parts[(size_t)t];
 		if (!split) P.rec.reserve((size_t)(in_off[2 * p1] - in_off[2 * p0]) * 16 + 64);
 		ReadOut o2[2];
@@ -630,6 +679,8 @@ static int64_t finalize_pairs_impl(const bmh_chain_opt_t *copt, const bmh_ext_pa
 		}
 	}, n_reads / 2);
 	const double t_d = now();
+	if (prof) { double mn = 1e30, mx = 0, sm = 0; for (double v : th_ms) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; sm += v; }
+	            fprintf(stderr, "[pairs] second walk: threads done after min %.1f / mean %.1f / max %.1f ms of its start (before it: %.1f ms waiting for the device's pairs)\n", mn, sm / th_ms.size(), mx, t_w0 - t_sw2); }
 	if (prof) fprintf(stderr, "[pairs] setup %.1f ms, dedup %.1f ms, pestat %.1f ms, rescue jobs collected %.1f ms (%zu), on the device %.1f ms, mem_sam_pe %.1f ms (%d threads)\n", t_a - t_in, t_b - t_a, t_c - t_b, t_sw1 - t_sw0, all_jobs.size(), t_sw2 - t_sw1, t_d - t_sw2, n_threads);
 	// the parts go out side by side: offsets first, then every thread copies its own part
 	std::vector<uint64_t> w_off(parts.size() + 1, 0), r_off(parts.size() + 1, 0);
@@ -711,3 +762,10 @@ int64_t bmh_finalize_pairs_split(const bmh_index_t *idx, const uint8_t *d_reads,
 }
 
 void bmh_pairs_scratch_free(void *p) { delete (PairScratch *)p; }
+
+// With the knob RESCUE_CHECK set every batch whose rescue windows the device found was also walked by the host: out[5] = batches, pairs, jobs of the
+// device, pairs whose `active` flag differs (must be 0), pairs whose list of calls differs (possible where a mem_sort_dedup_patch of the walk changed a list).
+extern "C" void bmh_rescue_check_counts(uint64_t *out)
+{
+	out[0] = g_chk_batches.load(); out[1] = g_chk_pairs.load(); out[2] = g_chk_jobs.load(); out[3] = g_chk_active.load(); out[4] = g_chk_lists.load();
+}

@@ -422,6 +422,12 @@ int64_t bmh_finalize_pairs_deduped(const bmh_index_t *idx, const uint8_t *d_read
                                    int n_contigs, const int64_t *contig_offset, const int32_t *contig_len,
                                    int32_t *out, uint64_t cap, uint32_t *out_per_read, int32_t *out_h, int32_t *out_unflag, double *pes_out,
                                    int n_threads);
+/* The windows of the mate rescue (mem_matesw up to its ksw_align2 call, src/bwamem_pair.c:119-150) are found by the host's walk of every pair; with the knob
+ * ALIGNER_RESCUE_DEV=1 bmh_aligner_run finds them with a kernel on the regions the device keeps (csrc/pair_kernels.hip: rescue_jobs_kernel; same records,
+ * measured slower on a busy device).  With the knob RESCUE_CHECK set as well the host's walk runs beside the kernel; out[5] = batches checked, pairs,
+ * alignments the device asked for, pairs whose "a call reached a window" flag differs (0: the flag decides which pairs the host walks), pairs whose list of
+ * calls differs (the host walk's mem_sort_dedup_patch calls can change a list; such a call is then computed by the host's second walk). */
+void bmh_rescue_check_counts(uint64_t *out);
 int64_t bmh_sam_need_cigar_pe(const bmh_post_opt_t *po, const int32_t *fin, const uint32_t *fin_per_read, const int32_t *h_rec,
                               uint32_t n_reads, uint8_t *need);
 char *bmh_format_sam_pe(const bmh_post_opt_t *po, uint32_t n_reads, const char *names, const uint64_t *name_off, const uint8_t *reads,

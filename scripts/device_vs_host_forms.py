@@ -1,5 +1,6 @@
 """One-off parity run at bench scale: bmh_aligner_run on N reads against the hg38-scale synthetic index, the device forms (selection, packed CIGARs, SAM text,
-pairing on the device) against the host forms (BMH_ALIGNER_HOST_FORMAT, BMH_ALIGNER_PE_HOST): sha256 of the text per mode.
+pairing on the device) against the host forms (BMH_ALIGNER_HOST_FORMAT, BMH_ALIGNER_PE_HOST) and, paired, with the rescue's windows found on the device
+(BMH_ALIGNER_RESCUE_DEV, the host's first walk beside it: BMH_RESCUE_CHECK): sha256 of the text per mode.  FORMS_ONLY=pe|se: one of the two halves.
 usage: device_vs_host_forms.py [genome_mbp] [n_reads] [read_len]      FORMS_ALT=<n>: the last n sequences are ALT contigs (single-end: the device tail's ALT rules
 against the host tail's, BMH_ALIGNER_ALT_HOST_PATCH)"""
 import os, sys, hashlib, ctypes as C
@@ -32,7 +33,7 @@ if n_alt:
 nat = NativeAligner(dindex, pac_t.cpu().numpy(), n_genome, meta["contigs"], is_alt, co, B.ExtParams.default(), po, pe_o)
 nth = L.bmh_effective_cpus()
 bad = 0
-for paired in (False, True):
+for paired in [q for q in (False, True) if os.environ.get("FORMS_ONLY", "") in ("", "pe" if q else "se")]:
     for seed in (101, 202):
         reads = (B.synth.make_pairs(g, n_reads // 2, rl, seed=seed, holes=meta["holes"]) if paired else B.synth.make_reads(g, n_reads, rl, seed=seed, holes=meta["holes"]))[0]
         flat = np.ascontiguousarray(np.asarray(reads, np.uint8).reshape(-1))
@@ -43,15 +44,21 @@ for paired in (False, True):
                      np.arange(n_reads, dtype=np.uint64) * np.uint64(w + 2), codes=flat)
         cuts = [0, (n_reads // 2) & ~1, n_reads]
         hs = {}
-        for env in ("", "BMH_ALIGNER_HOST_FORMAT") + (("BMH_ALIGNER_PE_HOST",) if paired else ()) + (("BMH_ALIGNER_ALT_HOST_PATCH",) if n_alt and not paired else ()):
+        for env in ("", "BMH_ALIGNER_HOST_FORMAT") + (("BMH_ALIGNER_PE_HOST", "BMH_ALIGNER_RESCUE_DEV") if paired else ()) + (("BMH_ALIGNER_ALT_HOST_PATCH",) if n_alt and not paired else ()):
             if env:
                 os.environ[env] = "1"
+            if env == "BMH_ALIGNER_RESCUE_DEV":
+                os.environ["BMH_RESCUE_CHECK"] = "1"
             h = hashlib.sha256(); nb = [0]
             def sink(mv):
                 h.update(mv); nb[0] += len(mv)
             nat.run(rs, cuts, paired, sink, n_lanes=2, n_threads=nth)
             if env:
                 del os.environ[env]
+            if os.environ.pop("BMH_RESCUE_CHECK", None):
+                chk = (C.c_uint64 * 5)(); L.bmh_rescue_check_counts(chk)
+                print("   rescue windows on the device vs the host's first walk, so far: batches %d, pairs %d, alignments asked for %d, pairs whose active flag differs %d, pairs whose call list differs %d" % tuple(chk), flush=True)
+                bad += chk[3] != 0
             hs[env or "device"] = (h.hexdigest()[:16], nb[0])
         ok = len(set(hs.values())) == 1
         bad += not ok

@@ -60,9 +60,17 @@ def throttled():
         return 0, 0.0, 0.0
 cfgs = [tuple(int(v) for v in c.split("x")) for c in os.environ.get("LANES_CFGS", "2x4,3x4,3x8,4x8,2x8,2x4").split(",")]
 cfgs = [(l_, b_, int(s_)) for s_ in os.environ.get("LANES_SLOTS", "-1").split(",") for l_, b_ in cfgs]      # LANES_SLOTS: values of the knob ALIGNER_GPU_SLOTS (-1: leave it alone)
-for lanes, nb, slots in cfgs:
+# LANES_KNOB=NAME:v1,v2[:rounds]: every configuration under these values of the knob NAME in turn, `rounds` times over (an A/B on one box)
+if os.environ.get("LANES_KNOB"):
+    kn = os.environ["LANES_KNOB"].split(":")
+    cfgs = [(l_, b_, s_, (kn[0], int(v))) for _ in range(int(kn[2]) if len(kn) > 2 else 1) for l_, b_, s_ in cfgs for v in kn[1].split(",")]
+else:
+    cfgs = [c + (None,) for c in cfgs]
+for lanes, nb, slots, knob in cfgs:
     if slots >= 0:
         L.bmh_tune_set(b"ALIGNER_GPU_SLOTS", slots, 0); print("ALIGNER_GPU_SLOTS = %d" % slots)
+    if knob:
+        L.bmh_tune_set(knob[0].encode(), knob[1], 0); print("%s = %d" % knob)
     q = (n_reads // nb) & ~1
     cuts = [k * q for k in range(nb)] + [n_reads]
     n_it = int(os.environ.get("LANES_ITERS", "3"))
@@ -91,7 +99,7 @@ if os.environ.get("LANES_FILE"):
     recs[:, 0] = ord(">"); recs[:, 1:w + 2] = np.frombuffer("".join(names.tolist()).encode(), np.uint8).reshape(n_reads, w + 1); recs[:, w + 2] = 10
     recs[:, w + 3:w + 3 + rl] = asc.reshape(n_reads, rl); recs[:, -1] = 10
     recs.tofile(fa); del recs
-    for lanes, nb, _ in cfgs:
+    for lanes, nb, _, _ in cfgs:
         for it in range(3):
             nbytes[0] = 0
             t0 = time.perf_counter()

@@ -14,5 +14,5 @@ one() {     # <name> <reads> <lanes_probe args...>
 	head -25 $R/gpurun_out/sam_${T}_$N.csv | cut -c1-150
 }
 export LANES_ITERS=4
-if [ "$W" = pe ] || [ "$W" = both ]; then LANES_CFGS=3x6 BMH_PAIR_PROFILE=1 one pe 3100 4000000 pe || exit 1; fi
+if [ "$W" = pe ] || [ "$W" = both ]; then LANES_CFGS=${LANES_CFGS_PE:-4x8} BMH_PAIR_PROFILE=1 one pe 3100 4000000 pe || exit 1; fi
 if [ "$W" = se300 ] || [ "$W" = both ]; then LANES_CFGS=2x4 LANES_READ_LEN=300 one se300 3100 4000000 || exit 1; fi

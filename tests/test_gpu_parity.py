@@ -1170,16 +1170,29 @@ def test_native_pipeline_device_text_equals_host_text(hip, tmp_path, pe):
             f.write((b">p%d\n" % (i // 2)) if pe else (b">r%d\n" % i)); f.write(a); f.write(b"\n")
     al = Aligner(prefix, n_threads=4)
     texts = {}
-    for env in ("", "BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_HOST_SELECT") + (("BMH_ALIGNER_PE_HOST_DEDUP",) if pe else ()):
-        if env:
-            os.environ[env] = "1"
+    import ctypes as C
+    lib = hip.load_library()
+    chk0 = (C.c_uint64 * 5)(); chk1 = (C.c_uint64 * 5)()
+    lib.bmh_rescue_check_counts(chk0)
+    # (BMH_ALIGNER_RESCUE_DEV=1: the rescue's windows found by rescue_jobs_kernel instead of the host's first walk; RESCUE_CHECK runs that walk beside it)
+    for env in ("", "BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_HOST_SELECT") + (("BMH_ALIGNER_PE_HOST_DEDUP", "BMH_ALIGNER_RESCUE_DEV") if pe else ()):
+        names = [env] if env else []
+        if env == "BMH_ALIGNER_RESCUE_DEV":
+            names.append("BMH_RESCUE_CHECK")
+        for k in names:
+            os.environ[k] = "1"
         try:
             buf = io.BytesIO()
             al.align_file(fq, buf, batch_reads=5000, paired=pe)
             texts[env] = buf.getvalue()
         finally:
-            if env:
-                del os.environ[env]
+            for k in names:
+                del os.environ[k]
+    lib.bmh_rescue_check_counts(chk1)
+    if pe:      # batches checked, jobs found on the device, no pair whose `active` flag differs from the host walk's
+        d = [int(b) - int(a) for a, b in zip(chk0, chk1)]
+        assert d[0] >= 3 and d[1] == n // 2 and d[2] > 100 and d[3] == 0, d
+        print("rescue windows on the device vs the host's first walk: batches, pairs, jobs, active differs, call list differs:", d)
     body = texts[""]
     assert body.count(b"\n") >= n and b"\tXA:Z:" in body and b"\tSA:Z:" in body
     lines = [l for l in body.split(b"\n") if l and not l.startswith(b"@")]

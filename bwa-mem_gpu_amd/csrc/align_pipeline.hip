@@ -376,7 +376,7 @@ int pairs_on_device(const aligner_t &A, lane_t &Ln, const bmh_read_set_t &rs, co
 	split.after_pestat = pd_after_pestat; split.before_final = pd_before_final; split.user = &u; split.todo_pairs = Ln.todo_pairs.data(); split.scratch_slot = &Ln.pair_scratch;
 	// knob ALIGNER_RESCUE_DEV=1: the rescue's windows found by a kernel on the regions the device keeps (pair_kernels.hip: rescue_jobs_kernel) instead of the host's
 	// first walk -- the same records (tests/test_gpu_parity.py).  Off by default: measured beside each other on one box (profiles/r06_rescue_ab.txt) the host's walk
-	// is the faster one by 3 % -- its 9 ms a batch overlap the other lanes' kernels, the kernels (1 ms each) queue behind them and are waited for three times
+	// is the faster one by 3 %: the device is the bound of paired reads -> SAM, the walk's 9 ms a batch overlap the other lanes' kernels, the two passes (1 ms each) do not
 	const bmh_rescue_in_t rin = {Ln.d_dedup.p, Ln.d_opr.p, Ln.d_roff.p, Ln.d_lens.p, ex.d_ctg_off, A.n_contigs};
 	if (bmh_tune("ALIGNER_RESCUE_DEV", 0) != 0) split.rescue_in = &rin;
 	uint64_t cap = (uint64_t)m1 + 2ull * n + 4096;                  // (room for every pair: the pairs the device hands back are the ones with the most records)

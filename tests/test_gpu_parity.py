@@ -1230,7 +1230,7 @@ def test_native_pipeline_with_alt_contigs_device_forms_equal_host_forms(hip, tmp
     for k_, v_ in opts.items():                                    # (-a: every hit a record; -M -Y: shorter split hits secondary, soft clips everywhere)
         setattr(al.po, k_, v_)
     texts = {}
-    for env in ("", "BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_PE_HOST" if pe else "BMH_ALIGNER_ALT_HOST_PATCH", "BMH_ALIGNER_NATIVE"):
+    for env in ("", "BMH_ALIGNER_HOST_FORMAT", "BMH_ALIGNER_PE_HOST" if pe else "BMH_ALIGNER_ALT_HOST_PATCH", "BMH_ALIGNER_NATIVE") + (("BMH_ALIGNER_RESCUE_DEV",) if pe else ()):
         if env:
             os.environ[env] = "0" if env == "BMH_ALIGNER_NATIVE" else "1"
         try:
@@ -1453,7 +1453,7 @@ def test_native_pipeline_edge_reads(hip, tmp_path, pe):
             f.write(b">" + name + b"\n" + b + b"\n")
     al = Aligner(prefix, n_threads=2)
     texts = {}
-    for env, batch in (("", 40), ("", 1 if not pe else 2), ("BMH_ALIGNER_HOST_FORMAT", 40), ("BMH_ALIGNER_NATIVE=0", 40)) + ((("BMH_ALIGNER_PE_HOST", 40),) if pe else ()):
+    for env, batch in (("", 40), ("", 1 if not pe else 2), ("BMH_ALIGNER_HOST_FORMAT", 40), ("BMH_ALIGNER_NATIVE=0", 40)) + ((("BMH_ALIGNER_PE_HOST", 40), ("BMH_ALIGNER_RESCUE_DEV", 40)) if pe else ()):
         key, val = (env.split("=") + ["1"])[:2] if env else ("", "")
         if key:
             os.environ[key] = val

@@ -41,6 +41,13 @@ else:
     idx = fmindex.build_fmd_index(g, device="cuda:0" if torch.cuda.is_available() else None)
 # E2E_CONTIGS=k: the genome is written as k sequences of unequal lengths (reads that straddle a cut lose the seeds that bridge it
 # and get their extension windows clipped, src/bwamem.c:437, src/bntseq.c:531-556; positions are reported per sequence)
+def rescue_check_line():
+    """with BMH_RESCUE_CHECK (and BMH_ALIGNER_RESCUE_DEV=1): what the host's walk beside the device's search for the rescue's windows found"""
+    if os.environ.get("BMH_RESCUE_CHECK"):
+        import ctypes as _C
+        from bwamem_hip.lib import load_library as _ll
+        _chk = (_C.c_uint64 * 5)(); _ll().bmh_rescue_check_counts(_chk)
+        print("   rescue windows on the device vs the host's walk: batches %d, pairs %d, alignments asked for %d, pairs whose active flag is differing %d, pairs whose call list is differing %d" % tuple(_chk))
 n_ctg = int(os.environ.get("E2E_CONTIGS", "1"))
 contigs = None
 if n_ctg > 1:
@@ -149,6 +156,7 @@ if paired:
     theirs = [l.rstrip("\n") for l in open(sam) if l[0] != "@"]
     diff = [(a, b) for a, b in zip(ours, theirs) if a != b]
     print(f"device-resident path: {len(ours)} records; reference host code: {len(theirs)} records; differing records: {len(diff)}")
+    rescue_check_line()
     if diff:                                              # keep the evidence: both records and the pair's reads
         os.makedirs("gpurun_out", exist_ok=True)
         with open("gpurun_out/e2e_diff_%s.txt" % os.environ.get("E2E_TAG", "pe_t" + threads), "w") as f:
